@@ -1,0 +1,85 @@
+"""ctypes loader for ``libgraphite_mi355x.so`` (the C-ABI of include/graphite_mi355x.h).
+
+There is no CPU fallback: if the library is missing, or no GPU is visible when a
+compute entry point is called, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgraphite_mi355x.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+GR_OK = 0
+STATUS_NAMES = {0: "GR_OK", 1: "GR_ERR_INVALID", 2: "GR_ERR_HIP", 3: "GR_ERR_NO_DEVICE",
+                4: "GR_ERR_DUPLICATE_EDGE", 5: "GR_ERR_SOLVE_FAILED", 6: "GR_ERR_COMM"}
+
+# every symbol include/graphite_mi355x.h declares
+EXPORTS = [
+    "gr_version", "gr_last_error_string", "gr_device_count",
+    "gr_bal_create", "gr_bal_destroy", "gr_bal_set_loss", "gr_bal_set_scale_system",
+    "gr_bal_set_params", "gr_bal_get_params", "gr_bal_linearize", "gr_bal_chi2",
+    "gr_bal_backup_parameters", "gr_bal_revert_parameters", "gr_bal_apply_update",
+    "gr_bal_solver_update_structure", "gr_bal_solver_update_values", "gr_bal_solver_set_damping",
+    "gr_bal_solver_solve", "gr_bal_schur_update_values", "gr_bal_schur_matvec",
+    "gr_bal_landmark_update", "gr_bal_schur_structure", "gr_bal_get",
+    "gr_bal_levenberg_marquardt", "gr_bal_kernel_stats", "gr_comm_unique_id", "gr_bal_comm_init",
+]
+
+
+class GraphiteError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {msg}")
+        self.status = status
+
+
+class LMOptions(C.Structure):
+    _fields_ = [("solver", C.c_int32), ("iterations", C.c_int32), ("initial_damping", C.c_double),
+                ("use_identity", C.c_int32), ("pcg_max_iter", C.c_int32), ("pcg_tol", C.c_double),
+                ("pcg_rejection_ratio", C.c_double), ("profile", C.c_int32), ("reserved", C.c_int32)]
+
+
+class LMStats(C.Structure):
+    _fields_ = [("iterations_run", C.c_int32), ("accepted", C.c_int32), ("pcg_iterations", C.c_int32),
+                ("ok", C.c_int32), ("setup_seconds", C.c_double), ("loop_seconds", C.c_double),
+                ("solve_seconds", C.c_double), ("final_chi2", C.c_double)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("bytes_per_launch", C.c_double), ("flops_per_launch", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "graphite_mi355x.h"))
+    stale = (not os.path.exists(LIB_PATH)
+             or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-B"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GraphiteError(-1, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.gr_version.restype = C.c_char_p
+        _lib.gr_last_error_string.restype = C.c_char_p
+    return _lib
+
+
+def check(status):
+    if status != GR_OK:
+        raise GraphiteError(status, lib().gr_last_error_string().decode())

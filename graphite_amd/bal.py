@@ -1,0 +1,171 @@
+"""Python harness over the C-ABI for BAL problems (tests, bench, smoke).
+
+Mirrors the reference's call sequence for this path — Graph / Solver /
+levenberg_marquardt (graph.hpp, solver/solver.hpp,
+optimizer/levenberg_marquardt.hpp) — with the same method names, so the parity
+tests read like the reference's own tests.  All compute happens inside
+``libgraphite_mi355x.so``; numpy arrays only cross the boundary as host
+pointers, torch CUDA tensors as device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LMOptions, LMStats, KernelStat, check
+
+SOLVER_PCG_SCHUR, SOLVER_PCG, SOLVER_PCG_IDENTITY = 0, 1, 2
+LOSS_DEFAULT, LOSS_HUBER = 0, 1
+F32, F64 = 0, 1
+
+_GET = dict(scales=0, b=1, Hcc=2, Hcp=3, Hll=4, S=5, b_schur=6, Hll_inv=7, residuals=8)
+
+
+def _ptr(a):
+    """host numpy array or torch tensor (host or cuda) -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a.data_ptr())  # torch tensor
+
+
+class BalProblem:
+    """Device-resident BAL problem (gr_bal_problem handle)."""
+
+    def __init__(self, cameras, points, obs, cam_idx, pt_idx, dtype=np.float64, device=0, stream=None):
+        self.lib = _lib.lib()
+        self.dt = np.dtype(dtype)
+        self.code = F32 if self.dt == np.float32 else F64
+        cameras = np.ascontiguousarray(cameras, dtype=self.dt).reshape(-1, 9)
+        points = np.ascontiguousarray(points, dtype=self.dt).reshape(-1, 3)
+        obs = np.ascontiguousarray(obs, dtype=self.dt).reshape(-1, 2)
+        ci = np.ascontiguousarray(cam_idx, dtype=np.int32)
+        pi = np.ascontiguousarray(pt_idx, dtype=np.int32)
+        self.Nc, self.Np, self.No = len(cameras), len(points), len(obs)
+        self.n = 9 * self.Nc + 3 * self.Np
+        self.h = C.c_void_p()
+        check(self.lib.gr_bal_create(C.byref(self.h), C.c_int(self.code), C.c_int64(self.Nc), C.c_int64(self.Np),
+                                     C.c_int64(self.No), _ptr(cameras), _ptr(points), _ptr(obs), _ptr(ci),
+                                     _ptr(pi), C.c_int(device), C.c_void_p(stream or 0)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.gr_bal_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- Graph -------------------------------------------------------------------------
+    def set_loss(self, kind, delta=0.0):
+        check(self.lib.gr_bal_set_loss(self.h, C.c_int(kind), C.c_double(delta)))
+
+    def scale_system(self, on):
+        check(self.lib.gr_bal_set_scale_system(self.h, C.c_int(int(on))))
+
+    def set_params(self, cameras, points):
+        c = np.ascontiguousarray(cameras, dtype=self.dt)
+        p = np.ascontiguousarray(points, dtype=self.dt)
+        check(self.lib.gr_bal_set_params(self.h, _ptr(c), _ptr(p)))
+
+    def get_params(self):
+        c = np.zeros((self.Nc, 9), self.dt)
+        p = np.zeros((self.Np, 3), self.dt)
+        check(self.lib.gr_bal_get_params(self.h, _ptr(c), _ptr(p)))
+        return c, p
+
+    def linearize(self):
+        check(self.lib.gr_bal_linearize(self.h))
+
+    def chi2(self):
+        v = C.c_double()
+        check(self.lib.gr_bal_chi2(self.h, C.byref(v)))
+        return v.value
+
+    def backup_parameters(self):
+        check(self.lib.gr_bal_backup_parameters(self.h))
+
+    def revert_parameters(self):
+        check(self.lib.gr_bal_revert_parameters(self.h))
+
+    def apply_update(self, dx):
+        dx = np.ascontiguousarray(dx, dtype=self.dt)
+        check(self.lib.gr_bal_apply_update(self.h, _ptr(dx)))
+
+    # --- Solver --------------------------------------------------------------------------
+    def solver_update_structure(self, solver):
+        check(self.lib.gr_bal_solver_update_structure(self.h, C.c_int(solver)))
+
+    def solver_update_values(self, solver):
+        check(self.lib.gr_bal_solver_update_values(self.h, C.c_int(solver)))
+
+    def solver_set_damping(self, solver, mu, use_identity=False):
+        check(self.lib.gr_bal_solver_set_damping(self.h, C.c_int(solver), C.c_double(mu), C.c_int(int(use_identity))))
+
+    def solver_solve(self, solver, max_iter=10, tol=1.0, rej=5.0):
+        dx = np.zeros(self.n, self.dt)
+        it = C.c_int()
+        check(self.lib.gr_bal_solver_solve(self.h, C.c_int(solver), C.c_int(max_iter), C.c_double(tol),
+                                           C.c_double(rej), _ptr(dx), C.byref(it)))
+        return dx, it.value
+
+    # --- Schur ---------------------------------------------------------------------------
+    def schur_update_values(self):
+        check(self.lib.gr_bal_schur_update_values(self.h))
+
+    def schur_matvec(self, x):
+        x = np.ascontiguousarray(x, dtype=self.dt)
+        y = np.zeros(9 * self.Nc, self.dt)
+        check(self.lib.gr_bal_schur_matvec(self.h, _ptr(x), _ptr(y)))
+        return y
+
+    def landmark_update(self, xp):
+        xp = np.ascontiguousarray(xp, dtype=self.dt)
+        xl = np.zeros(3 * self.Np, self.dt)
+        check(self.lib.gr_bal_landmark_update(self.h, _ptr(xp), _ptr(xl)))
+        return xl
+
+    def schur_structure(self):
+        nb = C.c_int64()
+        check(self.lib.gr_bal_schur_structure(self.h, C.byref(nb), None, None))
+        colptr = np.zeros(self.Nc + 1, np.int64)
+        rowidx = np.zeros(nb.value, np.int64)
+        check(self.lib.gr_bal_schur_structure(self.h, C.byref(nb), _ptr(colptr), _ptr(rowidx)))
+        return colptr, rowidx
+
+    def get(self, name):
+        cnt = C.c_int64()
+        check(self.lib.gr_bal_get(self.h, C.c_int(_GET[name]), None, C.byref(cnt)))
+        out = np.zeros(cnt.value, self.dt)
+        check(self.lib.gr_bal_get(self.h, C.c_int(_GET[name]), _ptr(out), C.byref(cnt)))
+        return out
+
+    # --- optimizer ------------------------------------------------------------------------
+    def levenberg_marquardt(self, solver=SOLVER_PCG_SCHUR, iterations=10, initial_damping=1e-4,
+                            use_identity=False, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0, profile=False):
+        opt = LMOptions(solver, iterations, initial_damping, int(use_identity), pcg_max_iter, pcg_tol, pcg_rej,
+                        int(profile), 0)
+        st = LMStats()
+        ct = np.full(iterations + 1, np.nan)
+        lt = np.full(iterations + 1, np.nan)
+        check(self.lib.gr_bal_levenberg_marquardt(self.h, C.byref(opt), C.byref(st), _ptr(ct), _ptr(lt)))
+        k = st.iterations_run + 1
+        stats = {f: getattr(st, f) for f, _ in LMStats._fields_}
+        return ct[:k], lt[:k], stats
+
+    def kernel_stats(self):
+        arr = (KernelStat * 64)()
+        n = C.c_int()
+        check(self.lib.gr_bal_kernel_stats(self.h, arr, C.c_int(64), C.byref(n)))
+        out = {}
+        for i in range(min(n.value, 64)):
+            k = arr[i]
+            out[k.name.decode()] = dict(launches=k.launches, total_ms=k.total_ms,
+                                        bytes_per_launch=k.bytes_per_launch, flops_per_launch=k.flops_per_launch)
+        return out

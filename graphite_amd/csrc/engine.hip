@@ -1,0 +1,740 @@
+// libgraphite_mi355x.so — host side of the BAL hot path on MI355X.
+//
+// Engine<T> owns the device-resident problem and mirrors, method for method,
+// the reference objects on this path:
+//   Graph<T,S>            linearize / chi2 / apply_update / backup / revert   (graph.hpp)
+//   Hessian<T,S>          update_values / apply_damping                        (hessian.hpp)
+//   SchurComplement<T,S>  build_structure / update_values / landmark update    (schur.hpp)
+//   PCGSchurSolver, PCGSolver + block-Jacobi preconditioners                   (solver/, preconditioner/)
+//   optimizer::levenberg_marquardt                                             (optimizer/levenberg_marquardt.hpp)
+// The C ABI at the bottom (include/graphite_mi355x.h) is the drop-in boundary.
+#include "../../include/graphite_mi355x.h"
+#include "kernels.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <numeric>
+
+namespace gr {
+
+static thread_local std::string g_last_error;
+
+static inline int cdiv(size_t a, size_t b) { return (int)((a + b - 1) / b); }
+
+struct KernelProf {
+  std::string name;
+  int64_t launches = 0;
+  double total_ms = 0, bytes = 0, flops = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct EngineBase {
+  virtual ~EngineBase() = default;
+  virtual void set_loss(int kind, double delta) = 0;
+  virtual void set_scale_system(bool on) = 0;
+  virtual void set_params(const void *c, const void *p) = 0;
+  virtual void get_params(void *c, void *p) = 0;
+  virtual void linearize() = 0;
+  virtual double chi2() = 0;
+  virtual void backup() = 0;
+  virtual void revert() = 0;
+  virtual void apply_update(const void *dx) = 0;
+  virtual void solver_update_structure(int solver) = 0;
+  virtual void solver_update_values(int solver) = 0;
+  virtual void solver_set_damping(int solver, double mu, bool use_identity) = 0;
+  virtual bool solver_solve(int solver, int max_iter, double tol, double rej, void *dx, int *iters) = 0;
+  virtual void schur_update_values() = 0;
+  virtual void schur_matvec(const void *x, void *y) = 0;
+  virtual void landmark_update(const void *xp, void *xl) = 0;
+  virtual void schur_structure(int64_t *nnzb, int64_t *colptr, int64_t *rowidx) = 0;
+  virtual void get(int which, void *out, int64_t *count) = 0;
+  virtual void lm(const gr_lm_options &opt, gr_lm_stats &st, double *chi2_trace, double *lambda_trace) = 0;
+  virtual int kernel_stats(gr_kernel_stat *out, int cap) = 0;
+  int device = 0;
+};
+
+template <typename T> struct Engine final : EngineBase {
+  hipStream_t stream = nullptr;
+  int64_t Nc = 0, Np = 0, No = 0;
+  size_t n = 0, pose_dim = 0;
+  int loss_kind = 0;
+  T loss_delta = 0;
+  bool scale_system = true;
+
+  // host structure
+  std::vector<int> h_pt_ptr, h_cam_pm, h_pt_pm, h_cam_ptr, h_pt_cm, h_pos_cm, h_pm_of_orig;
+  // Schur structure (lazy)
+  bool schur_ready = false;
+  int64_t nnzb = 0, nprod = 0;
+  std::vector<int> h_S_colptr, h_S_rowi, h_S_coli, h_S_diag;
+
+  // device data
+  DevBuf<T> cams, pts, cams_bak, pts_bak, pack, obs_pm, obs_cm;
+  DevBuf<int> pt_ptr, cam_pm, pt_pm, cam_ptr, pt_cm, pos_cm;
+  DevBuf<T> Hcc, Hll, Hcp, scales, bu; // bu = [bc (9Nc) ; bl (3Np)] unscaled -J^T rho' r
+  struct View { T *p = nullptr; } bc, bl;
+  DevBuf<double> chi2_partial, dscalars; // dscalars[0]=chi2, [1]=rho denom
+  // Schur
+  DevBuf<int> blk_order, prod_ptr, prod_a, prod_b, S_rowi, S_coli, S_diag, row_ptr, row_blk, row_col;
+  DevBuf<T> S, b_schur, Hll_inv, Mp, vl, MinvS;
+  // PCG work vectors
+  DevBuf<T> v_r, v_p, v_z, v_Ap, v_xb, v_dx, v_ps, v_diag, MinvC, MinvP;
+  DevBuf<double> sc_d;
+  DevBuf<int> sc_i;
+  int sc_cap = 0;
+  // tmp
+  DevBuf<T> tmp;
+
+  double damping = 0;
+  bool damping_identity = false;
+  bool hcp_valid = false;
+  int n_point_blocks = 0, n_chi2_blocks = 0;
+
+  // profiling
+  bool profiling = false;
+  std::map<std::string, KernelProf> prof;
+
+  Engine(int64_t nc, int64_t np, int64_t no, const void *c, const void *p, const void *o,
+         const int32_t *ci, const int32_t *pi, int dev, hipStream_t s) {
+    device = dev;
+    stream = s;
+    Nc = nc; Np = np; No = no;
+    pose_dim = 9 * (size_t)Nc;
+    n = pose_dim + 3 * (size_t)Np;
+    std::vector<T> hc(9 * Nc), hp(3 * Np), ho(2 * No);
+    std::vector<int32_t> hci(No), hpi(No);
+    GR_HIP(hipMemcpy(hc.data(), c, hc.size() * sizeof(T), hipMemcpyDefault));
+    GR_HIP(hipMemcpy(hp.data(), p, hp.size() * sizeof(T), hipMemcpyDefault));
+    GR_HIP(hipMemcpy(ho.data(), o, ho.size() * sizeof(T), hipMemcpyDefault));
+    GR_HIP(hipMemcpy(hci.data(), ci, No * sizeof(int32_t), hipMemcpyDefault));
+    GR_HIP(hipMemcpy(hpi.data(), pi, No * sizeof(int32_t), hipMemcpyDefault));
+    build_orderings(hci, hpi, ho);
+    cams.upload(hc, stream);
+    pts.upload(hp, stream);
+    cams_bak.alloc(hc.size());
+    pts_bak.alloc(hp.size());
+    pack.alloc(PACK * (size_t)Nc);
+    Hcc.alloc(81 * (size_t)Nc); Hll.alloc(9 * (size_t)Np);
+    bu.alloc(n); bc.p = bu.p; bl.p = bu.p + pose_dim;
+    scales.alloc(n);
+    n_point_blocks = cdiv(Np, TPB);
+    n_chi2_blocks = std::min(cdiv(No, TPB), 2048);
+    chi2_partial.alloc(std::max(n_point_blocks, n_chi2_blocks));
+    dscalars.alloc(4);
+    v_dx.alloc(n);
+    tmp.alloc(std::max<size_t>(n, 27 * (size_t)No));
+    GR_HIP(hipStreamSynchronize(stream));
+  }
+
+  // ---- symbolic phase -----------------------------------------------------------
+  // Replaces the host hash-map walks of factor.hpp:458-461 / 731-758: two counting
+  // sorts of the observation list (by point, by camera).
+  void build_orderings(const std::vector<int32_t> &ci, const std::vector<int32_t> &pi, const std::vector<T> &ho) {
+    for (int64_t o = 0; o < No; ++o)
+      if (ci[o] < 0 || ci[o] >= Nc || pi[o] < 0 || pi[o] >= Np) throw std::invalid_argument("observation index out of range");
+    h_pt_ptr.assign(Np + 1, 0);
+    for (int64_t o = 0; o < No; ++o) h_pt_ptr[pi[o] + 1]++;
+    for (int64_t l = 0; l < Np; ++l) h_pt_ptr[l + 1] += h_pt_ptr[l];
+    std::vector<int> pm_obs(No), w(h_pt_ptr.begin(), h_pt_ptr.end() - 1);
+    for (int64_t o = 0; o < No; ++o) pm_obs[w[pi[o]]++] = (int)o;
+    for (int64_t l = 0; l < Np; ++l)
+      std::sort(pm_obs.begin() + h_pt_ptr[l], pm_obs.begin() + h_pt_ptr[l + 1],
+                [&](int a, int b) { return ci[a] != ci[b] ? ci[a] < ci[b] : a < b; });
+    h_cam_pm.resize(No); h_pt_pm.resize(No); h_pm_of_orig.resize(No);
+    std::vector<T> h_obs_pm(2 * No);
+    for (int64_t a = 0; a < No; ++a) {
+      const int o = pm_obs[a];
+      h_cam_pm[a] = ci[o]; h_pt_pm[a] = pi[o]; h_pm_of_orig[o] = (int)a;
+      h_obs_pm[2 * a] = ho[2 * (size_t)o]; h_obs_pm[2 * a + 1] = ho[2 * (size_t)o + 1];
+    }
+    for (int64_t l = 0; l < Np; ++l)
+      for (int a = h_pt_ptr[l] + 1; a < h_pt_ptr[l + 1]; ++a)
+        if (h_cam_pm[a] == h_cam_pm[a - 1]) throw std::domain_error("duplicate (camera, point) edge");
+    h_cam_ptr.assign(Nc + 1, 0);
+    for (int64_t a = 0; a < No; ++a) h_cam_ptr[h_cam_pm[a] + 1]++;
+    for (int64_t c = 0; c < Nc; ++c) h_cam_ptr[c + 1] += h_cam_ptr[c];
+    h_pos_cm.resize(No); h_pt_cm.resize(No);
+    std::vector<T> h_obs_cm(2 * No);
+    std::vector<int> wc(h_cam_ptr.begin(), h_cam_ptr.end() - 1);
+    for (int64_t a = 0; a < No; ++a) {
+      const int j = wc[h_cam_pm[a]]++;
+      h_pos_cm[j] = (int)a; h_pt_cm[j] = h_pt_pm[a];
+      h_obs_cm[2 * (size_t)j] = h_obs_pm[2 * a]; h_obs_cm[2 * (size_t)j + 1] = h_obs_pm[2 * a + 1];
+    }
+    pt_ptr.upload(h_pt_ptr, stream); cam_pm.upload(h_cam_pm, stream); pt_pm.upload(h_pt_pm, stream);
+    cam_ptr.upload(h_cam_ptr, stream); pt_cm.upload(h_pt_cm, stream); pos_cm.upload(h_pos_cm, stream);
+    obs_pm.upload(h_obs_pm, stream); obs_cm.upload(h_obs_cm, stream);
+    GR_HIP(hipStreamSynchronize(stream));
+  }
+
+  // SchurComplement::build_structure (schur.hpp:194-225).  The reference walks
+  // Pi tuples with two hash lookups each on the host (:556-580); here the block
+  // map is a dense Nc x Nc table (Nc <= 16384) and the product list is counting-
+  // sorted by destination block.
+  void build_schur_structure() {
+    if (schur_ready) return;
+    if (Nc > 16384) throw std::invalid_argument("explicit Schur complement supports at most 16384 cameras");
+    std::vector<int> map((size_t)Nc * Nc, -1); // map[j*Nc+i], i<=j
+    for (int64_t c = 0; c < Nc; ++c) map[(size_t)c * Nc + c] = 0;
+    int64_t np = 0;
+    for (int64_t l = 0; l < Np; ++l) {
+      const int64_t k = h_pt_ptr[l + 1] - h_pt_ptr[l];
+      np += k * (k + 1) / 2;
+      for (int a = h_pt_ptr[l]; a < h_pt_ptr[l + 1]; ++a)
+        for (int b = a; b < h_pt_ptr[l + 1]; ++b) map[(size_t)h_cam_pm[b] * Nc + h_cam_pm[a]] = 0;
+    }
+    if (np >= (int64_t)std::numeric_limits<int>::max()) throw std::invalid_argument("too many Schur products for 32-bit indices");
+    nprod = np;
+    h_S_colptr.assign(Nc + 1, 0); h_S_rowi.clear(); h_S_coli.clear(); h_S_diag.assign(Nc, -1);
+    for (int64_t j = 0; j < Nc; ++j) {
+      for (int64_t i = 0; i <= j; ++i)
+        if (map[(size_t)j * Nc + i] == 0) {
+          map[(size_t)j * Nc + i] = (int)h_S_rowi.size();
+          if (i == j) h_S_diag[j] = (int)h_S_rowi.size();
+          h_S_rowi.push_back((int)i); h_S_coli.push_back((int)j);
+        }
+      h_S_colptr[j + 1] = (int)h_S_rowi.size();
+    }
+    nnzb = (int64_t)h_S_rowi.size();
+    std::vector<int> h_prod_ptr(nnzb + 1, 0);
+    for (int64_t l = 0; l < Np; ++l)
+      for (int a = h_pt_ptr[l]; a < h_pt_ptr[l + 1]; ++a)
+        for (int b = a; b < h_pt_ptr[l + 1]; ++b) h_prod_ptr[map[(size_t)h_cam_pm[b] * Nc + h_cam_pm[a]] + 1]++;
+    for (int64_t q = 0; q < nnzb; ++q) h_prod_ptr[q + 1] += h_prod_ptr[q];
+    std::vector<int> h_prod_a(nprod), h_prod_b(nprod), w(h_prod_ptr.begin(), h_prod_ptr.end() - 1);
+    for (int64_t l = 0; l < Np; ++l)
+      for (int a = h_pt_ptr[l]; a < h_pt_ptr[l + 1]; ++a)
+        for (int b = a; b < h_pt_ptr[l + 1]; ++b) {
+          const int q = w[map[(size_t)h_cam_pm[b] * Nc + h_cam_pm[a]]]++;
+          h_prod_a[q] = a; h_prod_b[q] = b;
+        }
+    std::vector<int> order(nnzb);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+      return (h_prod_ptr[x + 1] - h_prod_ptr[x]) > (h_prod_ptr[y + 1] - h_prod_ptr[y]);
+    });
+    // row lists for y = S x: upper blocks of row i, then lower blocks as transposes (~blk)
+    std::vector<int> h_row_ptr(Nc + 1, 0);
+    for (int64_t q = 0; q < nnzb; ++q) {
+      h_row_ptr[h_S_rowi[q] + 1]++;
+      if (h_S_rowi[q] != h_S_coli[q]) h_row_ptr[h_S_coli[q] + 1]++;
+    }
+    for (int64_t c = 0; c < Nc; ++c) h_row_ptr[c + 1] += h_row_ptr[c];
+    std::vector<int> h_row_blk(h_row_ptr[Nc]), h_row_col(h_row_ptr[Nc]), wr(h_row_ptr.begin(), h_row_ptr.end() - 1);
+    for (int64_t q = 0; q < nnzb; ++q) {
+      const int i = h_S_rowi[q], j = h_S_coli[q];
+      int e = wr[i]++;
+      h_row_blk[e] = (int)q; h_row_col[e] = j;
+      if (i != j) { e = wr[j]++; h_row_blk[e] = ~(int)q; h_row_col[e] = i; }
+    }
+    blk_order.upload(order, stream); prod_ptr.upload(h_prod_ptr, stream);
+    prod_a.upload(h_prod_a, stream); prod_b.upload(h_prod_b, stream);
+    S_rowi.upload(h_S_rowi, stream); S_coli.upload(h_S_coli, stream); S_diag.upload(h_S_diag, stream);
+    row_ptr.upload(h_row_ptr, stream); row_blk.upload(h_row_blk, stream); row_col.upload(h_row_col, stream);
+    S.alloc(81 * (size_t)nnzb); b_schur.alloc(pose_dim);
+    Hll_inv.alloc(9 * (size_t)Np); Mp.alloc(9 * (size_t)Np); vl.alloc(3 * (size_t)Np);
+    MinvS.alloc(81 * (size_t)Nc);
+    Hcp.alloc(27 * (size_t)No);
+    v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_Ap.alloc(n); v_xb.alloc(n);
+    GR_HIP(hipStreamSynchronize(stream));
+    schur_ready = true;
+  }
+
+  // ---- profiling ------------------------------------------------------------------
+  struct Scope {
+    Engine *e; KernelProf *kp = nullptr; hipEvent_t a{}, b{};
+    Scope(Engine *e_, const char *name, double bytes, double flops) : e(e_) {
+      if (!e->profiling) return;
+      kp = &e->prof[name];
+      kp->name = name; kp->bytes = bytes; kp->flops = flops;
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, e->stream);
+    }
+    ~Scope() {
+      if (!kp) return;
+      (void)hipEventRecord(b, e->stream);
+      kp->pending.emplace_back(a, b);
+    }
+  };
+  void flush_prof() {
+    for (auto &it : prof) {
+      for (auto &ev : it.second.pending) {
+        (void)hipEventSynchronize(ev.second);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev.first, ev.second);
+        it.second.total_ms += ms; it.second.launches++;
+        (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+      }
+      it.second.pending.clear();
+    }
+  }
+  int kernel_stats(gr_kernel_stat *out, int cap) override {
+    flush_prof();
+    int k = 0;
+    for (auto &it : prof) {
+      if (k < cap) {
+        std::memset(&out[k], 0, sizeof(gr_kernel_stat));
+        std::strncpy(out[k].name, it.second.name.c_str(), sizeof(out[k].name) - 1);
+        out[k].launches = it.second.launches; out[k].total_ms = it.second.total_ms;
+        out[k].bytes_per_launch = it.second.bytes; out[k].flops_per_launch = it.second.flops;
+      }
+      ++k;
+    }
+    return k;
+  }
+
+  // ---- Graph --------------------------------------------------------------------
+  void set_loss(int kind, double delta) override { loss_kind = kind; loss_delta = (T)delta; }
+  void set_scale_system(bool on) override { scale_system = on; }
+  void set_params(const void *c, const void *p) override {
+    GR_HIP(hipMemcpyAsync(cams.p, c, cams.n * sizeof(T), hipMemcpyDefault, stream));
+    GR_HIP(hipMemcpyAsync(pts.p, p, pts.n * sizeof(T), hipMemcpyDefault, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+  }
+  void get_params(void *c, void *p) override {
+    GR_HIP(hipMemcpyAsync(c, cams.p, cams.n * sizeof(T), hipMemcpyDefault, stream));
+    GR_HIP(hipMemcpyAsync(p, pts.p, pts.n * sizeof(T), hipMemcpyDefault, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+  }
+  double w() const { return (double)sizeof(T); }
+
+  void campack() { k_campack<T><<<cdiv(Nc, TPB), TPB, 0, stream>>>((int)Nc, cams.p, pack.p); }
+
+  // Graph::linearize (graph.hpp:236-290) fused with Hessian::update_values
+  // (hessian.hpp:290-307): one point pass + one camera pass over the observations.
+  void linearize_impl(bool write_hcp) {
+    campack();
+    {
+      Scope sc(this, write_hcp ? "point_linearize_hcp" : "point_linearize",
+               No * (2 * w() + 4) + Np * (3 * w() + 4 + 12 * w()) + (write_hcp ? 27.0 * No * w() : 0.0),
+               No * (250.0 + (write_hcp ? 81.0 : 0.0)));
+      if (write_hcp)
+        k_point_linearize<T, true><<<n_point_blocks, TPB, 0, stream>>>((int)Np, pt_ptr.p, cam_pm.p, obs_pm.p, pts.p, pack.p, loss_kind, loss_delta, Hll.p, bl.p, Hcp.p, chi2_partial.p);
+      else
+        k_point_linearize<T, false><<<n_point_blocks, TPB, 0, stream>>>((int)Np, pt_ptr.p, cam_pm.p, obs_pm.p, pts.p, pack.p, loss_kind, loss_delta, Hll.p, bl.p, nullptr, chi2_partial.p);
+    }
+    {
+      Scope sc(this, "camera_linearize", No * (2 * w() + 4 + 3 * w()) + Nc * 90.0 * w(), No * 330.0);
+      k_camera_linearize<T><<<(int)Nc, TPB, 0, stream>>>(cam_ptr.p, pt_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, Hcc.p, bc.p);
+    }
+    k_scales<T><<<cdiv(n, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, Hcc.p, Hll.p, scales.p, n_point_blocks, chi2_partial.p, dscalars.p);
+    hcp_valid = write_hcp;
+  }
+  bool want_hcp = false;
+  void linearize() override { linearize_impl(want_hcp); }
+
+  // Graph::compute_error + Graph::chi2 (graph.hpp:212-225)
+  double chi2() override {
+    chi2_async(nullptr);
+    double v = 0;
+    GR_HIP(hipMemcpyAsync(&v, dscalars.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+    return v;
+  }
+  void chi2_async(T *res_out) {
+    campack();
+    Scope sc(this, "chi2", No * (2 * w() + 8), No * 40.0);
+    k_chi2<T><<<n_chi2_blocks, TPB, 0, stream>>>((int)No, cam_pm.p, pt_pm.p, obs_pm.p, pts.p, pack.p, loss_kind, loss_delta, chi2_partial.p, res_out);
+    k_reduce_partials<T><<<1, TPB, 0, stream>>>(n_chi2_blocks, chi2_partial.p, dscalars.p);
+  }
+  double read_scalar(int idx) {
+    double v = 0;
+    GR_HIP(hipMemcpyAsync(&v, dscalars.p + idx, sizeof(double), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+    return v;
+  }
+
+  void backup() override { // graph.hpp:302-309
+    GR_HIP(hipMemcpyAsync(cams_bak.p, cams.p, cams.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    GR_HIP(hipMemcpyAsync(pts_bak.p, pts.p, pts.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+  }
+  void revert() override { // graph.hpp:311-318
+    GR_HIP(hipMemcpyAsync(cams.p, cams_bak.p, cams.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    GR_HIP(hipMemcpyAsync(pts.p, pts_bak.p, pts.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    campack(); // the matrix-free operator recomputes J from the pack: keep it in step with the vertices
+  }
+  void apply_update_dev(const T *dx) { // graph.hpp:292-300, ops/update.hpp:11-31
+    k_apply_update<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>(pose_dim, cams.p, dx, scales.p);
+    k_apply_update<T><<<cdiv(3 * Np, TPB), TPB, 0, stream>>>(3 * (size_t)Np, pts.p, dx + pose_dim, scales.p + pose_dim);
+  }
+  void apply_update(const void *dx) override {
+    GR_HIP(hipMemcpyAsync(v_dx.p, dx, n * sizeof(T), hipMemcpyDefault, stream));
+    apply_update_dev(v_dx.p);
+  }
+
+  // ---- Solver interface ---------------------------------------------------------
+  void ensure_scalars(int max_iter) {
+    const int cap = max_iter + 2;
+    if (cap > sc_cap) { sc_cap = cap; sc_d.alloc(4 * (size_t)cap); sc_i.alloc((size_t)cap + 1); }
+  }
+  PcgScalars scalars() {
+    PcgScalars sc;
+    sc.rz = sc_d.p; sc.den = sc_d.p + sc_cap; sc.rz0 = sc_d.p + 2 * (size_t)sc_cap; sc.rr = sc_d.p + 3 * (size_t)sc_cap;
+    sc.done = sc_i.p; sc.iters = sc_i.p + sc_cap;
+    return sc;
+  }
+
+  void solver_update_structure(int solver) override {
+    if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
+    else {
+      want_hcp = false;
+      v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_Ap.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
+      MinvC.alloc(81 * (size_t)Nc); MinvP.alloc(9 * (size_t)Np);
+    }
+  }
+  // H.update_values / preconditioner->update_values: the blocks are produced by
+  // linearize() already (fused); only the Hcp blocks may have to be (re)built.
+  void solver_update_values(int solver) override {
+    if (solver == GR_SOLVER_PCG_SCHUR && !hcp_valid) linearize_impl(true);
+  }
+  void solver_set_damping(int solver, double mu, bool use_identity) override {
+    damping = mu; damping_identity = use_identity;
+    if (solver == GR_SOLVER_PCG) { // BlockJacobiPreconditioner::set_damping_factor (block_jacobi.hpp:120-172)
+      k_inv9<T, 1><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Hcc.p, nullptr, scales.p, mu, use_identity ? 1 : 0, MinvC.p, v_diag.p);
+      k_inv3_points<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, scales.p, mu, use_identity ? 1 : 0, MinvP.p, v_diag.p);
+    } else if (solver == GR_SOLVER_PCG_IDENTITY) {
+      // only the clamped diagonal is needed (pcg.hpp:93-103)
+      k_inv9<T, 1><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Hcc.p, nullptr, scales.p, mu, use_identity ? 1 : 0, MinvC.p, v_diag.p);
+      k_inv3_points<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, scales.p, mu, use_identity ? 1 : 0, MinvP.p, v_diag.p);
+    }
+  }
+
+  // SchurComplement::update_values (schur.hpp:227-235)
+  void schur_update_values() override {
+    build_schur_structure();
+    if (!hcp_valid) linearize_impl(true);
+    k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, damping_identity ? 1 : 0, Hll_inv.p, Mp.p, vl.p);
+    {
+      Scope sc(this, "schur_products", nprod * 60.0 * w() + 81.0 * nnzb * w(), nprod * 342.0);
+      k_schur_products<T><<<cdiv(nnzb, 28), TPB, 0, stream>>>((int)nnzb, blk_order.p, prod_ptr.p, prod_a.p, prod_b.p, S_rowi.p, S_coli.p, pt_pm.p, Hcp.p, Mp.p, Hcc.p, scales.p, damping, damping_identity ? 1 : 0, S.p);
+    }
+    {
+      Scope sc(this, "b_schur", No * (27.0 * w() + 8 + 3 * w()), No * 54.0);
+      k_bschur<T><<<(int)Nc, TPB, 0, stream>>>(cam_ptr.p, pt_cm.p, pos_cm.p, Hcp.p, vl.p, bc.p, scales.p, b_schur.p);
+    }
+  }
+  void schur_matvec_dev(const T *x, T *y, int k) {
+    Scope sc(this, "schur_matvec", (2.0 * nnzb - Nc) * 81.0 * w(), (2.0 * nnzb - Nc) * 162.0);
+    k_schur_matvec<T><<<cdiv(Nc, 4), TPB, 0, stream>>>((int)Nc, row_ptr.p, row_blk.p, row_col.p, S.p, x, y, scalars(), k);
+  }
+  void schur_matvec(const void *x, void *y) override {
+    build_schur_structure();
+    ensure_scalars(1);
+    GR_HIP(hipMemcpyAsync(v_p.p, x, pose_dim * sizeof(T), hipMemcpyDefault, stream));
+    schur_matvec_dev(v_p.p, v_Ap.p, -1);
+    GR_HIP(hipMemcpyAsync(y, v_Ap.p, pose_dim * sizeof(T), hipMemcpyDefault, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+  }
+  void landmark_update_dev(const T *xp, T *xl) {
+    Scope sc(this, "backsub", No * (27.0 * w() + 4) + Np * 15.0 * w(), No * 54.0);
+    k_backsub<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bl.p, scales.p, xp, xl);
+  }
+  void landmark_update(const void *xp, void *xl) override {
+    GR_HIP(hipMemcpyAsync(v_p.p, xp, pose_dim * sizeof(T), hipMemcpyDefault, stream));
+    landmark_update_dev(v_p.p, v_dx.p + pose_dim);
+    GR_HIP(hipMemcpyAsync(xl, v_dx.p + pose_dim, 3 * (size_t)Np * sizeof(T), hipMemcpyDefault, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+  }
+  void schur_structure(int64_t *nb, int64_t *colptr, int64_t *rowidx) override {
+    build_schur_structure();
+    if (nb) *nb = nnzb;
+    if (colptr) for (int64_t c = 0; c <= Nc; ++c) colptr[c] = h_S_colptr[c];
+    if (rowidx) for (int64_t q = 0; q < nnzb; ++q) rowidx[q] = h_S_rowi[q];
+  }
+
+  // PCGSchurSolver::solve (solver/pcg_schur.hpp:79-168); device-resident scalars,
+  // no host round trip inside the loop.
+  int solve_pcg_schur(int max_iter, double tol, double rej, T *x) {
+    schur_update_values();
+    k_inv9<T, 0><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, S.p, S_diag.p, nullptr, 0.0, 0, MinvS.p, nullptr);
+    ensure_scalars(max_iter);
+    PcgScalars sc = scalars();
+    k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
+    GR_HIP(hipMemsetAsync(x, 0, n * sizeof(T), stream));
+    k_pcgs_init<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, sc);
+    for (int k = 0; k < max_iter; ++k) {
+      schur_matvec_dev(v_p.p, v_Ap.p, k);
+      k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k);
+      k_pcgs_direction<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_p.p, v_z.p, sc, k, tol, rej);
+    }
+    landmark_update_dev(x, x + pose_dim);
+    return 0;
+  }
+
+  // PCGSolver::solve (solver/pcg.hpp:61-232)
+  template <bool IDENTITY> void solve_pcg(int max_iter, double tol, double rej, T *x) {
+    ensure_scalars(max_iter);
+    PcgScalars sc = scalars();
+    k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
+    const int ublocks = cdiv(pose_dim, 252) + cdiv(3 * (size_t)Np, 252);
+    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvC.p, MinvP.p, sc, 0);
+    k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>(n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, sc, -1, tol, rej);
+    const double op_bytes = No * (2.0 * w() + 4) * 2 + No * 7.0 * w() + 6.0 * n * w();
+    for (int k = 0; k < max_iter; ++k) {
+      {
+        Scope s1(this, "pcg_op_points", No * (2 * w() + 4) + Np * (4 + 12.0 * w()), No * 330.0);
+        k_op_points<T><<<n_point_blocks, TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, cam_pm.p, obs_pm.p, pts.p, pack.p, loss_kind, loss_delta, scales.p, v_ps.p, v_p.p, v_diag.p, damping, damping_identity ? 1 : 0, v_Ap.p, sc, k);
+      }
+      {
+        Scope s2(this, "pcg_op_cameras", No * (2 * w() + 4 + 6 * w()) + Nc * 36.0 * w(), No * 340.0);
+        k_op_cameras<T><<<(int)Nc, TPB, 0, stream>>>((int)Nc, cam_ptr.p, pt_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, scales.p, v_ps.p, v_p.p, v_diag.p, damping, damping_identity ? 1 : 0, v_Ap.p, sc, k);
+      }
+      (void)op_bytes;
+      k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvC.p, MinvP.p, sc, k);
+      k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>(n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, sc, k, tol, rej);
+    }
+  }
+
+  int last_iters() {
+    int it = 0;
+    GR_HIP(hipMemcpyAsync(&it, sc_i.p + sc_cap, sizeof(int), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+    return it;
+  }
+  bool solver_solve_dev(int solver, int max_iter, double tol, double rej, T *x) {
+    switch (solver) {
+    case GR_SOLVER_PCG_SCHUR: solve_pcg_schur(max_iter, tol, rej, x); return true;
+    case GR_SOLVER_PCG: solve_pcg<false>(max_iter, tol, rej, x); return true;
+    case GR_SOLVER_PCG_IDENTITY: solve_pcg<true>(max_iter, tol, rej, x); return true;
+    }
+    throw std::invalid_argument("unknown solver");
+  }
+  bool solver_solve(int solver, int max_iter, double tol, double rej, void *dx, int *iters) override {
+    const bool ok = solver_solve_dev(solver, max_iter, tol, rej, v_dx.p);
+    GR_HIP(hipMemcpyAsync(dx, v_dx.p, n * sizeof(T), hipMemcpyDefault, stream));
+    const int it = last_iters();
+    if (iters) *iters = it;
+    return ok;
+  }
+
+  // ---- getters (scaled space, reference layouts) ------------------------------------
+  void get(int which, void *out, int64_t *count) override {
+    int64_t cnt = 0;
+    const T *src = nullptr;
+    std::vector<int> map;
+    DevBuf<int> dmap, dmap2;
+    auto launch_export = [&](size_t nb, int rows, int cols, const T *s, const T *srow, const T *scol, const int *rm, const int *cm, const int *sm) {
+      k_export_blocks<T><<<cdiv(nb * rows * cols, TPB), TPB, 0, stream>>>(nb, rows, cols, s, srow, scol, rm, cm, sm, tmp.p);
+    };
+    switch (which) {
+    case GR_GET_SCALES: cnt = (int64_t)n; src = scales.p; break;
+    case GR_GET_B:
+      cnt = (int64_t)n;
+      k_mul<T><<<cdiv(n, TPB), TPB, 0, stream>>>(n, tmp.p, scales.p, bu.p);
+      src = tmp.p; break;
+    case GR_GET_HCC: cnt = 81 * Nc; launch_export(Nc, 9, 9, Hcc.p, scales.p, scales.p, nullptr, nullptr, nullptr); src = tmp.p; break;
+    case GR_GET_HLL: cnt = 9 * Np; launch_export(Np, 3, 3, Hll.p, scales.p + pose_dim, scales.p + pose_dim, nullptr, nullptr, nullptr); src = tmp.p; break;
+    case GR_GET_HCP: {
+      if (!hcp_valid) { Hcp.alloc(27 * (size_t)No); linearize_impl(true); }
+      cnt = 27 * No;
+      std::vector<int> rm(No), cmv(No);
+      for (int64_t o = 0; o < No; ++o) { const int a = h_pm_of_orig[o]; rm[o] = h_cam_pm[a]; cmv[o] = h_pt_pm[a]; }
+      dmap.upload(rm, stream); dmap2.upload(cmv, stream);
+      DevBuf<int> dsrc; dsrc.upload(h_pm_of_orig, stream);
+      launch_export(No, 9, 3, Hcp.p, scales.p, scales.p + pose_dim, dmap.p, dmap2.p, dsrc.p);
+      GR_HIP(hipStreamSynchronize(stream));
+      src = tmp.p; break;
+    }
+    case GR_GET_S: build_schur_structure(); cnt = 81 * nnzb; src = S.p; break;
+    case GR_GET_B_SCHUR: build_schur_structure(); cnt = (int64_t)pose_dim; src = b_schur.p; break;
+    case GR_GET_HLL_INV: build_schur_structure(); cnt = 9 * Np; src = Hll_inv.p; break;
+    case GR_GET_RESIDUALS: {
+      cnt = 2 * No;
+      DevBuf<T> rpm; rpm.alloc(2 * (size_t)No);
+      chi2_async(rpm.p);
+      std::vector<T> h = rpm.download(stream), ho(2 * (size_t)No);
+      for (int64_t o = 0; o < No; ++o) { ho[2 * o] = h[2 * (size_t)h_pm_of_orig[o]]; ho[2 * o + 1] = h[2 * (size_t)h_pm_of_orig[o] + 1]; }
+      if (out) GR_HIP(hipMemcpy(out, ho.data(), ho.size() * sizeof(T), hipMemcpyDefault));
+      if (count) *count = cnt;
+      return;
+    }
+    default: throw std::invalid_argument("unknown array id");
+    }
+    if (count) *count = cnt;
+    if (out && cnt) {
+      GR_HIP(hipMemcpyAsync(out, src, (size_t)cnt * sizeof(T), hipMemcpyDefault, stream));
+      GR_HIP(hipStreamSynchronize(stream));
+    }
+  }
+
+  // ---- optimizer::levenberg_marquardt (optimizer/levenberg_marquardt.hpp:110-242) -----
+  void lm(const gr_lm_options &opt, gr_lm_stats &st, double *chi2_trace, double *lambda_trace) override {
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    profiling = opt.profile != 0;
+    if (profiling) { flush_prof(); prof.clear(); }
+    std::memset(&st, 0, sizeof(st));
+    T mu = (T)opt.initial_damping;
+    T nu = 2;
+    solver_update_structure(opt.solver);
+    linearize();
+    solver_update_values(opt.solver);
+    T chi2v = (T)read_scalar(0);
+    bool run = true;
+    if (chi2_trace) chi2_trace[0] = (double)chi2v;
+    if (lambda_trace) lambda_trace[0] = (double)mu;
+    hipEvent_t ev_a, ev_b;
+    GR_HIP(hipEventCreate(&ev_a)); GR_HIP(hipEventCreate(&ev_b));
+    GR_HIP(hipStreamSynchronize(stream));
+    st.setup_seconds = std::chrono::duration<double>(clk::now() - t0).count();
+    auto tl = clk::now();
+    for (int i = 0; i < opt.iterations && run; ++i) {
+      solver_set_damping(opt.solver, (double)mu, opt.use_identity != 0);
+      GR_HIP(hipEventRecord(ev_a, stream));
+      const bool solve_ok = solver_solve_dev(opt.solver, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, v_dx.p);
+      GR_HIP(hipEventRecord(ev_b, stream));
+      backup();
+      apply_update_dev(v_dx.p);
+      // compute_rho denominator (:20-47) queued before the chi2 read so one sync serves both
+      GR_HIP(hipMemsetAsync(dscalars.p + 1, 0, sizeof(double), stream));
+      k_rho_denom<T><<<std::min(cdiv(n, TPB), 1024), TPB, 0, stream>>>(n, v_dx.p, bu.p, scales.p, (double)mu, dscalars.p + 1);
+      chi2_async(nullptr);
+      double hs[2];
+      GR_HIP(hipMemcpyAsync(hs, dscalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+      int it = 0;
+      GR_HIP(hipMemcpyAsync(&it, sc_i.p + sc_cap, sizeof(int), hipMemcpyDeviceToHost, stream));
+      GR_HIP(hipStreamSynchronize(stream));
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, ev_a, ev_b);
+      st.solve_seconds += ms * 1e-3;
+      st.pcg_iterations += it;
+      T new_chi2 = (T)hs[0];
+      if (!solve_ok) new_chi2 = std::numeric_limits<T>::max();
+      T denom = solve_ok ? (T)hs[1] + (T)1.0e-3 : T(1);
+      const T rho = (chi2v - new_chi2) / denom;
+      if (solve_ok && std::isfinite(new_chi2) && rho > 0) {
+        double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3);
+        alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
+        mu *= (T)alpha;
+        nu = 2;
+        linearize();
+        solver_update_values(opt.solver);
+        st.accepted++;
+      } else {
+        revert();
+        // the reference recomputes error + chi2 here (:199-201); every consumer below
+        // recomputes residuals from the reverted vertices, so nothing is stale.
+        mu *= nu;
+        nu *= 2;
+        new_chi2 = chi2v;
+      }
+      chi2v = new_chi2;
+      st.iterations_run++;
+      if (chi2_trace) chi2_trace[i + 1] = (double)chi2v;
+      if (lambda_trace) lambda_trace[i + 1] = (double)mu;
+      if (!std::isfinite(mu)) run = false;
+      if (rho == 0) break;
+    }
+    GR_HIP(hipStreamSynchronize(stream));
+    st.loop_seconds = std::chrono::duration<double>(clk::now() - tl).count();
+    st.ok = run ? 1 : 0;
+    st.final_chi2 = (double)chi2v;
+    (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b);
+    if (profiling) flush_prof();
+    profiling = false;
+  }
+};
+
+} // namespace gr
+
+// =============================================================================
+// C ABI
+// =============================================================================
+using namespace gr;
+
+struct gr_bal_problem {
+  std::unique_ptr<EngineBase> e;
+  int dtype;
+};
+
+template <typename F> static gr_status guarded(gr_bal_problem *p, F &&f) {
+  if (!p || !p->e) { g_last_error = "null problem handle"; return GR_ERR_INVALID; }
+  try {
+    (void)hipSetDevice(p->e->device);
+    f();
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::domain_error &ex) { g_last_error = ex.what(); return GR_ERR_DUPLICATE_EDGE; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
+}
+
+extern "C" {
+
+const char *gr_version(void) { return "graphite-mi355x 0.1 (gfx950)"; }
+const char *gr_last_error_string(void) { return g_last_error.c_str(); }
+int gr_device_count(void) {
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess) return 0;
+  return nd;
+}
+
+gr_status gr_bal_create(gr_bal_problem **out, gr_dtype dtype, int64_t nc, int64_t np, int64_t no,
+                        const void *cameras, const void *points, const void *observations,
+                        const int32_t *cam_idx, const int32_t *pt_idx, int device, void *stream) {
+  if (!out || nc <= 0 || np <= 0 || no <= 0 || !cameras || !points || !observations || !cam_idx || !pt_idx ||
+      no >= (int64_t)std::numeric_limits<int>::max() / 27) {
+    g_last_error = "gr_bal_create: bad argument";
+    return GR_ERR_INVALID;
+  }
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= device || device < 0) {
+    g_last_error = "no HIP device: the MI355X path has no CPU fallback";
+    return GR_ERR_NO_DEVICE;
+  }
+  try {
+    GR_HIP(hipSetDevice(device));
+    auto *p = new gr_bal_problem();
+    p->dtype = dtype;
+    if (dtype == GR_F32) p->e.reset(new Engine<float>(nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, (hipStream_t)stream));
+    else if (dtype == GR_F64) p->e.reset(new Engine<double>(nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, (hipStream_t)stream));
+    else { delete p; g_last_error = "bad dtype"; return GR_ERR_INVALID; }
+    *out = p;
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::domain_error &ex) { g_last_error = ex.what(); return GR_ERR_DUPLICATE_EDGE; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
+}
+gr_status gr_bal_destroy(gr_bal_problem *p) {
+  if (!p) return GR_ERR_INVALID;
+  (void)hipSetDevice(p->e->device);
+  delete p;
+  return GR_OK;
+}
+gr_status gr_bal_set_loss(gr_bal_problem *p, gr_loss kind, double delta) { return guarded(p, [&] { p->e->set_loss(kind, delta); }); }
+gr_status gr_bal_set_scale_system(gr_bal_problem *p, int enable) { return guarded(p, [&] { p->e->set_scale_system(enable != 0); }); }
+gr_status gr_bal_set_params(gr_bal_problem *p, const void *c, const void *q) { return guarded(p, [&] { p->e->set_params(c, q); }); }
+gr_status gr_bal_get_params(gr_bal_problem *p, void *c, void *q) { return guarded(p, [&] { p->e->get_params(c, q); }); }
+gr_status gr_bal_linearize(gr_bal_problem *p) { return guarded(p, [&] { p->e->linearize(); }); }
+gr_status gr_bal_chi2(gr_bal_problem *p, double *chi2) { return guarded(p, [&] { const double v = p->e->chi2(); if (chi2) *chi2 = v; }); }
+gr_status gr_bal_backup_parameters(gr_bal_problem *p) { return guarded(p, [&] { p->e->backup(); }); }
+gr_status gr_bal_revert_parameters(gr_bal_problem *p) { return guarded(p, [&] { p->e->revert(); }); }
+gr_status gr_bal_apply_update(gr_bal_problem *p, const void *dx) { return guarded(p, [&] { p->e->apply_update(dx); }); }
+gr_status gr_bal_solver_update_structure(gr_bal_problem *p, gr_solver s) { return guarded(p, [&] { p->e->solver_update_structure(s); }); }
+gr_status gr_bal_solver_update_values(gr_bal_problem *p, gr_solver s) { return guarded(p, [&] { p->e->solver_update_values(s); }); }
+gr_status gr_bal_solver_set_damping(gr_bal_problem *p, gr_solver s, double mu, int use_identity) { return guarded(p, [&] { p->e->solver_set_damping(s, mu, use_identity != 0); }); }
+gr_status gr_bal_solver_solve(gr_bal_problem *p, gr_solver s, int max_iter, double tol, double rej, void *dx, int *iters) {
+  bool ok = true;
+  const gr_status st = guarded(p, [&] { ok = p->e->solver_solve(s, max_iter, tol, rej, dx, iters); });
+  if (st == GR_OK && !ok) return GR_ERR_SOLVE_FAILED;
+  return st;
+}
+gr_status gr_bal_schur_update_values(gr_bal_problem *p) { return guarded(p, [&] { p->e->schur_update_values(); }); }
+gr_status gr_bal_schur_matvec(gr_bal_problem *p, const void *x, void *y) { return guarded(p, [&] { p->e->schur_matvec(x, y); }); }
+gr_status gr_bal_landmark_update(gr_bal_problem *p, const void *xp, void *xl) { return guarded(p, [&] { p->e->landmark_update(xp, xl); }); }
+gr_status gr_bal_schur_structure(gr_bal_problem *p, int64_t *nnzb, int64_t *colptr, int64_t *rowidx) { return guarded(p, [&] { p->e->schur_structure(nnzb, colptr, rowidx); }); }
+gr_status gr_bal_get(gr_bal_problem *p, gr_bal_array which, void *out, int64_t *count) { return guarded(p, [&] { p->e->get(which, out, count); }); }
+gr_status gr_bal_levenberg_marquardt(gr_bal_problem *p, const gr_lm_options *opt, gr_lm_stats *stats, double *chi2_trace, double *lambda_trace) {
+  if (!opt || !stats) { g_last_error = "null options/stats"; return GR_ERR_INVALID; }
+  return guarded(p, [&] { p->e->lm(*opt, *stats, chi2_trace, lambda_trace); });
+}
+gr_status gr_bal_kernel_stats(gr_bal_problem *p, gr_kernel_stat *out, int cap, int *n) {
+  return guarded(p, [&] { const int k = p->e->kernel_stats(out, cap); if (n) *n = k; });
+}
+gr_status gr_comm_unique_id(void *) { g_last_error = "RCCL path not built yet"; return GR_ERR_COMM; }
+gr_status gr_bal_comm_init(gr_bal_problem *, const void *, int, int) { g_last_error = "RCCL path not built yet"; return GR_ERR_COMM; }
+
+} // extern "C"

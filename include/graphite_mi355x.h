@@ -1,0 +1,181 @@
+/* graphite_mi355x.h — C-ABI of libgraphite_mi355x.so
+ *
+ * The drop-in boundary for the hot path of sfu-rsl/graphite on MI355X
+ * (gfx950): per-factor residual/Jacobian -> blocked J^T J / J^T r -> Schur
+ * reduction -> PCG inner solve, inside Levenberg-Marquardt, for BAL graphs
+ * (camera d=9, point d=3, reprojection factor E=2).
+ *
+ * The reference has no C ABI: its boundary is a C++17 template/virtual
+ * interface consumed from .cu files (docs/markdown/main.md:54-55).  Each entry
+ * point below names the reference member function it replaces (file:line are
+ * relative to /root/reference).  The C++ mirror of that interface
+ * (include/graphite/) is a thin layer over these calls; INTEGRATION.md shows
+ * the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  `dtype` selects
+ * the scalar type T (= S) of every `void*` array: GR_F32 or GR_F64.  Unless a
+ * parameter says "host", data pointers may be host or device pointers
+ * (detected with hipPointerGetAttributes).  Every function returns a
+ * gr_status; nothing throws.  All work of one problem handle is issued on the
+ * hipStream_t given at creation (0 = the null stream).  Functions that return
+ * scalars to the host synchronise that stream; the others are asynchronous.
+ */
+#ifndef GRAPHITE_MI355X_H
+#define GRAPHITE_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GR_OK = 0,
+  GR_ERR_INVALID = 1,        /* bad argument / wrong state                         */
+  GR_ERR_HIP = 2,            /* a HIP runtime call failed (gr_last_error_string)    */
+  GR_ERR_NO_DEVICE = 3,      /* no gfx950 device visible                            */
+  GR_ERR_DUPLICATE_EDGE = 4, /* the same (camera, point) pair appears twice         */
+  GR_ERR_SOLVE_FAILED = 5,   /* solver->solve() returned false                      */
+  GR_ERR_COMM = 6            /* RCCL call failed                                    */
+} gr_status;
+
+typedef enum { GR_F32 = 0, GR_F64 = 1 } gr_dtype;
+
+/* Solver<T,S> implementations (solver/solver.hpp:12-25) */
+typedef enum {
+  GR_SOLVER_PCG_SCHUR = 0,    /* PCGSchurSolver + BlockJacobiSchurPreconditioner (solver/pcg_schur.hpp, preconditioner/block_jacobi_schur.hpp) */
+  GR_SOLVER_PCG = 1,          /* PCGSolver + BlockJacobiPreconditioner (solver/pcg.hpp, preconditioner/block_jacobi.hpp)                      */
+  GR_SOLVER_PCG_IDENTITY = 2  /* PCGSolver + IdentityPreconditioner (preconditioner/identity.hpp)                                              */
+} gr_solver;
+
+typedef enum { GR_LOSS_DEFAULT = 0, GR_LOSS_HUBER = 1 } gr_loss; /* loss.hpp:15-51 */
+
+/* arrays retrievable with gr_bal_get (all in the reference's column-SCALED space) */
+typedef enum {
+  GR_GET_SCALES = 0,   /* n        jacobian_scales                  graph.hpp:262-270            */
+  GR_GET_B = 1,        /* n        b = -J^T rho' P r                ops/linearize.hpp:240-303    */
+  GR_GET_HCC = 2,      /* 81 Nc    camera diagonal blocks of H      ops/hessian.hpp:10-78        */
+  GR_GET_HCP = 3,      /* 27 No    camera-point blocks, INPUT observation order, 9x3 col-major   */
+  GR_GET_HLL = 4,      /* 9 Np     point diagonal blocks of H                                    */
+  GR_GET_S = 5,        /* 81 nnzb  Schur complement blocks (upper, column-major block order)     */
+  GR_GET_B_SCHUR = 6,  /* 9 Nc     b_S                              schur.hpp:901-920            */
+  GR_GET_HLL_INV = 7,  /* 9 Np     (Hll + damping)^-1               schur.hpp:1067-1114          */
+  GR_GET_RESIDUALS = 8 /* 2 No     residuals, INPUT observation order ops/error.hpp:253          */
+} gr_bal_array;
+
+typedef struct gr_bal_problem gr_bal_problem; /* opaque */
+
+/* optimizer::LevenbergMarquardtOptions (optimizer/levenberg_marquardt.hpp:52-98)
+ * + the PCG constructor arguments (solver/pcg.hpp:35-40, pcg_schur.hpp:42-47). */
+typedef struct {
+  int32_t solver;           /* gr_solver */
+  int32_t iterations;       /* default 10 */
+  double initial_damping;   /* default 1e-4 */
+  int32_t use_identity;     /* identity instead of diagonal-scaled damping */
+  int32_t pcg_max_iter;     /* bal.cu default 10 */
+  double pcg_tol;           /* bal.cu default 1.0 */
+  double pcg_rejection_ratio; /* bal.cu default 5.0 */
+  int32_t profile;          /* record HIP events around the dominant kernels */
+  int32_t reserved;
+} gr_lm_options;
+
+typedef struct {
+  int32_t iterations_run;
+  int32_t accepted;
+  int32_t pcg_iterations;   /* total inner iterations */
+  int32_t ok;               /* return value of levenberg_marquardt() */
+  double setup_seconds;     /* update_structure + first linearize + update_values */
+  double loop_seconds;      /* the LM for-loop (host wall clock, stream synchronised) */
+  double solve_seconds;     /* device time inside solver->solve (HIP events)          */
+  double final_chi2;
+} gr_lm_stats;
+
+const char *gr_version(void);
+const char *gr_last_error_string(void);
+/* number of visible HIP devices (0 if none); never initialises a device */
+int gr_device_count(void);
+
+/* ---- problem handle ------------------------------------------------------------
+ * Replaces the construction done by examples/bal.cu:55-141 (descriptors,
+ * add_vertex/add_factor) plus Graph::initialize_optimization (graph.hpp:92-167):
+ * cameras take Hessian block columns 0..Nc-1, points (eliminated) Nc..Nc+Np-1.
+ * cameras: Nc x 9 [r(3) t(3) f k1 k2]; points: Np x 3; obs: No x 2;
+ * cam_idx/pt_idx: No int32 (host or device).  `device` is the HIP ordinal,
+ * `stream` a hipStream_t (may be NULL). */
+gr_status gr_bal_create(gr_bal_problem **out, gr_dtype dtype, int64_t num_cameras,
+                        int64_t num_points, int64_t num_observations, const void *cameras,
+                        const void *points, const void *observations, const int32_t *cam_idx,
+                        const int32_t *pt_idx, int device, void *stream);
+gr_status gr_bal_destroy(gr_bal_problem *p);
+
+/* FactorDescriptor::add_factor loss argument (factor.hpp:373-412), one loss for all factors */
+gr_status gr_bal_set_loss(gr_bal_problem *p, gr_loss kind, double delta);
+/* Graph::scale_system (graph.hpp:331) */
+gr_status gr_bal_set_scale_system(gr_bal_problem *p, int enable);
+
+/* vertex values (user-owned Vertex* in the reference, vertex.hpp:65) */
+gr_status gr_bal_set_params(gr_bal_problem *p, const void *cameras, const void *points);
+gr_status gr_bal_get_params(gr_bal_problem *p, void *cameras, void *points);
+
+/* Graph::linearize (graph.hpp:236-290) */
+gr_status gr_bal_linearize(gr_bal_problem *p);
+/* Graph::compute_error (graph.hpp:212-217) followed by Graph::chi2 (graph.hpp:219-225) */
+gr_status gr_bal_chi2(gr_bal_problem *p, double *chi2);
+/* Graph::backup_parameters / revert_parameters / apply_update (graph.hpp:292-318);
+ * delta_x: n scalars in the scaled space (host or device) */
+gr_status gr_bal_backup_parameters(gr_bal_problem *p);
+gr_status gr_bal_revert_parameters(gr_bal_problem *p);
+gr_status gr_bal_apply_update(gr_bal_problem *p, const void *delta_x);
+
+/* Solver<T,S>::update_structure / update_values / set_damping_factor / solve
+ * (solver/solver.hpp:12-25).  delta_x: n scalars (host or device), iterations:
+ * number of inner PCG iterations executed (may be NULL). */
+gr_status gr_bal_solver_update_structure(gr_bal_problem *p, gr_solver solver);
+gr_status gr_bal_solver_update_values(gr_bal_problem *p, gr_solver solver);
+gr_status gr_bal_solver_set_damping(gr_bal_problem *p, gr_solver solver, double mu, int use_identity);
+gr_status gr_bal_solver_solve(gr_bal_problem *p, gr_solver solver, int max_iter, double tol,
+                              double rejection_ratio, void *delta_x, int *iterations);
+
+/* SchurComplement::update_values (schur.hpp:227-235): S, b_S, Hll^-1 with the current damping */
+gr_status gr_bal_schur_update_values(gr_bal_problem *p);
+/* SchurComplement::execute_schur_vector_multiply (schur.hpp:347-393): y = S x, 9 Nc scalars */
+gr_status gr_bal_schur_matvec(gr_bal_problem *p, const void *x, void *y);
+/* SchurComplement::compute_landmark_update (schur.hpp:279-302): xl (3 Np) from xp (9 Nc) */
+gr_status gr_bal_landmark_update(gr_bal_problem *p, const void *xp, void *xl);
+/* block structure of S: colptr (Nc+1) and rowidx (nnzb) int64 host arrays; pass NULL to size */
+gr_status gr_bal_schur_structure(gr_bal_problem *p, int64_t *nnzb, int64_t *colptr, int64_t *rowidx);
+
+/* copy one array (gr_bal_array) to `out` (host or device); *count receives its length */
+gr_status gr_bal_get(gr_bal_problem *p, gr_bal_array which, void *out, int64_t *count);
+
+/* optimizer::levenberg_marquardt (optimizer/levenberg_marquardt.hpp:110-242).
+ * chi2_trace / lambda_trace: host double[iterations+1] (entry 0 = initial), may be NULL. */
+gr_status gr_bal_levenberg_marquardt(gr_bal_problem *p, const gr_lm_options *options,
+                                     gr_lm_stats *stats, double *chi2_trace, double *lambda_trace);
+
+/* ---- measurement -----------------------------------------------------------------
+ * HIP-event timing of the kernels of the last gr_bal_levenberg_marquardt call with
+ * options->profile != 0.  Fills up to `cap` entries; returns the number of distinct
+ * kernels in *n.  Times are device milliseconds summed over `launches` launches. */
+typedef struct {
+  char name[48];
+  int64_t launches;
+  double total_ms;
+  double bytes_per_launch; /* algorithmic HBM bytes per launch */
+  double flops_per_launch;
+} gr_kernel_stat;
+gr_status gr_bal_kernel_stats(gr_bal_problem *p, gr_kernel_stat *out, int cap, int *n);
+
+/* ---- multi-GPU (RCCL over xGMI) ----------------------------------------------------
+ * One process per GPU.  Each rank creates its problem from ITS landmark partition
+ * (all cameras, a contiguous range of points and all their observations);
+ * camera-space sums are all-reduced.  unique_id: 128-byte ncclUniqueId produced on
+ * rank 0 by gr_comm_unique_id and broadcast by the caller (e.g. torch.distributed). */
+gr_status gr_comm_unique_id(void *unique_id_128);
+gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int rank, int world_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHITE_MI355X_H */

@@ -1,0 +1,177 @@
+"""GPU parity: every stage of the HIP hot path (through the C-ABI) against the CPU oracle
+on the same seeded inputs.  fp64 bar: 1e-9 relative on assembled quantities (the
+reference holds itself to 1e-12 on the 2x3 fixture, tests/schur.cu:180-239, asserted
+separately below); fp32 bar: stated per test."""
+import numpy as np
+import pytest
+
+import graphite_amd as ga
+from graphite_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("mini-6", np.float64), ("mini-50", np.float64), ("mini-50", np.float32), ("ladybug-49", np.float32),
+         ("ladybug-49", np.float64)]
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def make_pair(oracle_mod, name, dtype):
+    prob = synth.schur_test_fixture(dtype) if name == "schur-2x3" else synth.make_config(name)
+    gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+    ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+    return prob, gpu, ref
+
+
+def tol_for(dtype, t64, t32):
+    return t64 if np.dtype(dtype) == np.float64 else t32
+
+
+@pytest.mark.parametrize("name,dtype", CASES)
+def test_linearize_and_hessian(oracle_mod, name, dtype):
+    prob, gpu, ref = make_pair(oracle_mod, name, dtype)
+    gpu.solver_update_structure(ga.SOLVER_PCG_SCHUR)
+    gpu.linearize()
+    ref.linearize()
+    ref.hessian_update()
+    chi2_g, chi2_r = gpu.chi2(), ref.chi2()
+    assert abs(chi2_g - chi2_r) / chi2_r < tol_for(dtype, 1e-12, 1e-5)
+    assert relerr(gpu.get("residuals"), ref.get("res")) < tol_for(dtype, 1e-12, 1e-4)
+    assert relerr(gpu.get("scales"), ref.get("scales")) < tol_for(dtype, 1e-11, 1e-4)
+    # b: fp32 sums of thousands of terms in a different order
+    assert relerr(gpu.get("b"), ref.get("b")) < tol_for(dtype, 1e-10, 2e-3)
+    assert relerr(gpu.get("Hcc"), ref.get("Hcc")) < tol_for(dtype, 1e-10, 2e-3)
+    assert relerr(gpu.get("Hll"), ref.get("Hll")) < tol_for(dtype, 1e-10, 1e-3)
+    assert relerr(gpu.get("Hcp"), ref.get("Hcp")) < tol_for(dtype, 1e-10, 1e-3)
+    gpu.close()
+
+
+@pytest.mark.parametrize("name,dtype", [("schur-2x3", np.float64)] + CASES)
+def test_schur_complement(oracle_mod, name, dtype):
+    """S, b_S, Hll^-1, landmark back-substitution and S*x (tests/schur.cu:113-240)."""
+    prob, gpu, ref = make_pair(oracle_mod, name, dtype)
+    mu = 0.0 if name == "schur-2x3" else 1e-4  # the reference's Schur test runs undamped
+    gpu.solver_update_structure(ga.SOLVER_PCG_SCHUR)
+    gpu.linearize()
+    gpu.solver_update_values(ga.SOLVER_PCG_SCHUR)
+    gpu.solver_set_damping(ga.SOLVER_PCG_SCHUR, mu)
+    gpu.schur_update_values()
+    ref.linearize()
+    ref.hessian_update()
+    ref.apply_damping(mu)
+    ref.schur_update()
+    cp_g, ri_g = gpu.schur_structure()
+    cp_r, ri_r = ref.schur_structure()
+    assert np.array_equal(cp_g, cp_r) and np.array_equal(ri_g, ri_r)  # index work: bit-exact
+    t = tol_for(dtype, 1e-12 if name == "schur-2x3" else 1e-9, 5e-3)
+    assert relerr(gpu.get("Hll_inv"), ref.get("Hll_inv")) < t
+    assert relerr(gpu.get("S"), ref.get("S")) < t
+    assert relerr(gpu.get("b_schur"), ref.get("b_schur")) < t
+    xp = (0.01 * np.arange(1, 9 * gpu.Nc + 1)).astype(dtype)  # tests/schur.cu:211-214
+    assert relerr(gpu.landmark_update(xp), ref.landmark_update(xp)) < t
+    assert relerr(gpu.schur_matvec(xp), ref.schur_matvec(xp)) < t
+    gpu.close()
+
+
+@pytest.mark.parametrize("solver", ["pcg_schur", "pcg", "pcg_identity"])
+@pytest.mark.parametrize("name,dtype", [("mini-50", np.float64), ("mini-50", np.float32), ("ladybug-49", np.float64)])
+def test_solver_solve(oracle_mod, name, dtype, solver):
+    prob, gpu, ref = make_pair(oracle_mod, name, dtype)
+    gs = dict(pcg_schur=ga.SOLVER_PCG_SCHUR, pcg=ga.SOLVER_PCG, pcg_identity=ga.SOLVER_PCG_IDENTITY)[solver]
+    os_ = dict(pcg_schur=oracle_mod.SOLVER_PCG_SCHUR, pcg=oracle_mod.SOLVER_PCG,
+               pcg_identity=oracle_mod.SOLVER_PCG_IDENTITY)[solver]
+    gpu.solver_update_structure(gs)
+    gpu.linearize()
+    gpu.solver_update_values(gs)
+    gpu.solver_set_damping(gs, 1e-4)
+    ref.linearize()
+    ref.solver_update_values(os_)
+    ref.solver_set_damping(os_, 1e-4)
+    for max_iter, tol in ((4, 0.0), (25, 1e-12)):
+        dx_g, it_g = gpu.solver_solve(gs, max_iter=max_iter, tol=tol, rej=1e6)
+        dx_r, it_r = ref.solver_solve(os_, max_iter=max_iter, tol=tol, rej=1e6)
+        assert it_g == it_r
+        # PCG amplifies rounding differences with the iteration count
+        assert relerr(dx_g, dx_r) < tol_for(dtype, 1e-6, 5e-2)
+    gpu.close()
+
+
+def test_pcg_schur_matches_direct_solve(oracle_mod):
+    """tests/schur.cu:340-389: PCG-Schur (512 it, tol 1e-14, rejection 1e6) vs the direct Schur
+    LDLT solve, mu = 1e-4, |delta| < 5e-4 on the 2x3 fixture."""
+    prob, gpu, ref = make_pair(oracle_mod, "schur-2x3", np.float64)
+    gpu.solver_update_structure(ga.SOLVER_PCG_SCHUR)
+    gpu.linearize()
+    gpu.solver_update_values(ga.SOLVER_PCG_SCHUR)
+    gpu.solver_set_damping(ga.SOLVER_PCG_SCHUR, 1e-4)
+    dx_g, _ = gpu.solver_solve(ga.SOLVER_PCG_SCHUR, max_iter=512, tol=1e-14, rej=1e6)
+    ref.linearize()
+    ref.solver_update_values(oracle_mod.SOLVER_LDLT_SCHUR)
+    ref.solver_set_damping(oracle_mod.SOLVER_LDLT_SCHUR, 1e-4)
+    dx_r, _ = ref.solver_solve(oracle_mod.SOLVER_LDLT_SCHUR)
+    assert np.abs(dx_g - dx_r).max() < 5e-4
+    gpu.close()
+
+
+@pytest.mark.parametrize("solver", ["pcg_schur", "pcg"])
+@pytest.mark.parametrize("name,dtype,rtol", [("mini-50", np.float64, 1e-9), ("ladybug-49", np.float64, 1e-8),
+                                             ("ladybug-49", np.float32, 2e-3)])
+def test_levenberg_marquardt_trace(oracle_mod, name, dtype, rtol, solver):
+    """Whole LM loop: chi2 and lambda traces against the oracle (north star: 1e-6 relative in fp64)."""
+    prob, gpu, ref = make_pair(oracle_mod, name, dtype)
+    gs = dict(pcg_schur=ga.SOLVER_PCG_SCHUR, pcg=ga.SOLVER_PCG)[solver]
+    os_ = dict(pcg_schur=oracle_mod.SOLVER_PCG_SCHUR, pcg=oracle_mod.SOLVER_PCG)[solver]
+    ct_g, lt_g, st = gpu.levenberg_marquardt(solver=gs, iterations=8)
+    ct_r, lt_r, st_r = ref.levenberg_marquardt(solver=os_, iterations=8)
+    assert len(ct_g) == len(ct_r)
+    assert np.abs(ct_g - ct_r).max() / ct_r.max() < rtol
+    assert np.allclose(ct_g, ct_r, rtol=max(rtol, 1e-6))
+    assert np.allclose(lt_g, lt_r, rtol=1e-3)
+    assert ct_g[-1] < 0.1 * ct_g[0]
+    if np.dtype(dtype) == np.float64:
+        assert st["pcg_iterations"] == st_r["pcg_iterations"]
+    cg, pg = gpu.get_params()
+    cr, pr = ref.get_params()
+    assert relerr(cg, cr) < max(rtol, 1e-6) and relerr(pg, pr) < max(rtol, 1e-6)
+    gpu.close()
+
+
+def test_huber_loss(oracle_mod):
+    prob, gpu, ref = make_pair(oracle_mod, "mini-50", np.float64)
+    gpu.set_loss(ga.LOSS_HUBER, 1.0)
+    ref.set_loss(oracle_mod.LOSS_HUBER, 1.0)
+    ct_g, _, _ = gpu.levenberg_marquardt(solver=ga.SOLVER_PCG_SCHUR, iterations=5)
+    ct_r, _, _ = ref.levenberg_marquardt(solver=oracle_mod.SOLVER_PCG_SCHUR, iterations=5)
+    assert np.allclose(ct_g, ct_r, rtol=1e-8)
+    gpu.close()
+
+
+def test_apply_update_backup_revert(oracle_mod):
+    """tests/vertex.cu:76-119 (v + delta*scale) and :299-341 (backup/restore)."""
+    prob, gpu, ref = make_pair(oracle_mod, "mini-6", np.float64)
+    gpu.linearize()
+    s = gpu.get("scales")
+    dx = np.linspace(-1e-3, 1e-3, gpu.n)
+    gpu.backup_parameters()
+    gpu.apply_update(dx)
+    c, p = gpu.get_params()
+    assert np.allclose(c.ravel(), prob.cameras.ravel() + dx[:9 * gpu.Nc] * s[:9 * gpu.Nc], rtol=0, atol=1e-15)
+    assert np.allclose(p.ravel(), prob.points.ravel() + dx[9 * gpu.Nc:] * s[9 * gpu.Nc:], rtol=0, atol=1e-15)
+    gpu.revert_parameters()
+    c, p = gpu.get_params()
+    assert np.array_equal(c, prob.cameras) and np.array_equal(p, prob.points)
+    gpu.close()
+
+
+def test_duplicate_edge_is_rejected():
+    prob = synth.make_config("mini-6")
+    ci = prob.cam_idx.copy()
+    pi = prob.pt_idx.copy()
+    ci[1], pi[1] = ci[0], pi[0]
+    with pytest.raises(ga._lib.GraphiteError) as e:
+        ga.BalProblem(prob.cameras, prob.points, prob.obs, ci, pi)
+    assert e.value.status == 4
