@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — LM iterations/s of the MI355X hot path on a synthetic BAL-shaped problem.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--solver pcg|pcg-schur] [--dtype f64|f32]
+
+A "step" is one Levenberg-Marquardt iteration (solve + trial update + chi2 +
+accept/relinearise or reject) of optimizer::levenberg_marquardt
+(/root/reference/include/graphite/optimizer/levenberg_marquardt.hpp:166-240) over the whole
+problem.  Default workload: BASELINE.json configs[2], BAL Ladybug-1723 shape
+(1723 cameras, 156502 points, 678718 observations), fp64, block-Jacobi PCG
+(PCGSolver + BlockJacobiPreconditioner, 10 inner iterations, tol 1.0, rejection 5.0 =
+examples/bal.cu:296-309 defaults), lambda 1e-4 — the configuration the north star's
+1-GPU target is quoted on.  Inputs are resident in HBM before the timed region.
+
+N > 1: one process per GPU (torch.distributed.run); the factor graph is sharded by
+landmark range, cameras replicated, camera-space sums all-reduced with RCCL inside
+libgraphite_mi355x.so.  The SAME problem is split over the ranks, so scaling = "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="ladybug-1723")
+    ap.add_argument("--solver", default=None, choices=[None, "pcg", "pcg-schur"])
+    ap.add_argument("--dtype", default=None, choices=[None, "f32", "f64"])
+    ap.add_argument("--pcg-iterations", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=2)
+    ap.add_argument("--dump-kernels", default=None, help="write per-kernel HIP-event table to this JSON file")
+    return ap.parse_args()
+
+
+DEFAULTS = {  # workload -> (solver, dtype) as BASELINE.json configs name them
+    "ladybug-49": ("pcg-schur", "f32"),
+    "ladybug-1723": ("pcg", "f64"),
+    "venice-1778": ("pcg-schur", "f32"),
+    "final-13682": ("pcg", "f64"),
+}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import graphite_amd as ga
+    from graphite_amd import synth
+
+    dsolver, ddtype = DEFAULTS.get(args.workload, ("pcg", "f64"))
+    solver_name = args.solver or dsolver
+    dtype_name = args.dtype or ddtype
+    dtype = np.float64 if dtype_name == "f64" else np.float32
+    solver = ga.SOLVER_PCG if solver_name == "pcg" else ga.SOLVER_PCG_SCHUR
+
+    prob = synth.make_config(args.workload)
+    Nc, Np, No = prob.shape
+    if world > 1:
+        from graphite_amd import dist as gdist
+        part = gdist.partition_by_landmark(prob, rank, world)
+        gpu = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype,
+                            device=local_rank)
+        gdist.init_comm(gpu, rank, world)
+    else:
+        part = prob
+        gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype,
+                            device=local_rank)
+
+    lm_kw = dict(solver=solver, initial_damping=1e-4, pcg_max_iter=args.pcg_iterations, pcg_tol=1.0, pcg_rej=5.0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warmup: W untimed LM iterations, then restart from the initial guess
+    if args.warmup > 0:
+        gpu.levenberg_marquardt(iterations=args.warmup, **lm_kw)
+    gpu.set_params(part.cameras, part.points)
+
+    barrier()
+    t0 = time.perf_counter()
+    ct, lt, st = gpu.levenberg_marquardt(iterations=args.steps, profile=False, **lm_kw)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # second, identical pass with HIP events around every hot kernel (kept out of `value`)
+    gpu.set_params(part.cameras, part.points)
+    barrier()
+    ct2, _, st2 = gpu.levenberg_marquardt(iterations=args.steps, profile=True, **lm_kw)
+    barrier()
+    ks = gpu.kernel_stats()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    steps_run = st["iterations_run"]
+    w = np.dtype(dtype).itemsize
+    dominant = max(ks.items(), key=lambda kv: kv[1]["total_ms"]) if ks else None
+    roofline = None
+    if dominant:
+        name, k = dominant
+        avg_s = k["total_ms"] * 1e-3 / max(k["launches"], 1)
+        achieved = k["bytes_per_launch"] / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_us": round(avg_s * 1e6, 3), "launches": k["launches"],
+                    "algorithmic_bytes_per_launch": k["bytes_per_launch"],
+                    "flops_per_launch": k["flops_per_launch"],
+                    "achieved_gflops": round(k["flops_per_launch"] / avg_s / 1e9, 1)}
+    # PCG GFLOP/s with the reference's flop count for one matrix-free iteration
+    n = 9 * Nc + 3 * Np
+    flops_pcg_iter = (104.0 * No + 2 * (81 * Nc + 9 * Np) + 12 * n) if solver_name == "pcg" else None
+    pcg_gflops = None
+    if flops_pcg_iter and st["solve_seconds"] > 0:
+        pcg_gflops = flops_pcg_iter * st["pcg_iterations"] / st["solve_seconds"] / 1e9
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        import oracle
+        ref = oracle.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+        it = args.cpu_baseline_iters
+        _, _, cst = ref.levenberg_marquardt(solver=oracle.SOLVER_LDLT_SCHUR, iterations=it, initial_damping=1e-4)
+        cpu = {"value": round(cst["iterations_run"] / cst["loop_seconds"], 5), "unit": "LM iterations/s",
+               "cores": 1, "kind": "port",
+               "sample": f"{it} LM iterations of the same workload ({args.workload} {dtype_name}), CPU restatement "
+                         "of the reference's eigen-schur path (all stages on one host core: linearise, Schur, "
+                         "simplicial LDL^T; the reference runs only the LDL^T on the CPU)",
+               "seconds": round(cst["loop_seconds"], 3)}
+
+    line = {
+        "metric": "lm_iterations_per_sec", "value": round(steps_run / dt, 4), "unit": "LM iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / max(steps_run, 1) * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+        "config": {"workload": f"BAL {args.workload} shape ({Nc} cameras, {Np} points, {No} observations), "
+                               f"{solver_name}, {args.pcg_iterations} inner iterations, lambda 1e-4",
+                   "solver": solver_name, "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU"},
+        "steps_run": steps_run, "accepted_steps": st["accepted"], "pcg_iterations": st["pcg_iterations"],
+        "pcg_gflops": None if pcg_gflops is None else round(pcg_gflops, 2),
+        "chi2_initial": float(ct[0]), "chi2_final": float(ct[-1]), "mse_final": float(ct[-1]) / No,
+        "solve_seconds": round(st["solve_seconds"], 6), "loop_seconds": round(st["loop_seconds"], 6),
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    if args.dump_kernels:
+        with open(args.dump_kernels, "w") as f:
+            json.dump({"kernels": ks, "line": line}, f, indent=1)
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
