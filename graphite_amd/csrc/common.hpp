@@ -77,6 +77,64 @@ template <typename T> __device__ __forceinline__ T block_sum_256(T v, T *smem) {
   return v;
 }
 
+// butterfly sum: every lane gets the wave total
+template <typename T> __device__ __forceinline__ T wave_allsum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Inclusive segmented sum over runs of equal `key` in a wave (keys sorted, so a
+// match at distance o implies the whole span matches).  After the call the LAST
+// lane of each run holds the run total.
+template <typename T, int NV> __device__ __forceinline__ void seg_scan(T (&v)[NV], int key, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int kk = __shfl_up(key, o, 64);
+    const bool ok = (lane >= o) && (kk == key);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const T t = __shfl_up(v[i], o, 64);
+      if (ok) v[i] += t;
+    }
+  }
+}
+
+// Sum NV (= 16 or 64) per-lane values over the 64 lanes with NV-1 (+2) shuffles instead
+// of 6*NV: at every halving step a lane keeps one half of its values and hands the
+// other half to its partner (lane ^ offset).  On return lane L holds the wave total of
+// value index (NV == 64 ? L : L >> 2) in v[0].
+template <typename T, int NV> __device__ __forceinline__ T wave_transpose_sum(T (&v)[NV], int lane) {
+  static_assert(NV == 64 || NV == 16, "NV must be 16 or 64");
+  int offset = 32;
+#pragma unroll
+  for (int half = NV / 2; half >= 1; half >>= 1) {
+    const bool hi = (lane & offset) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const T keep = hi ? v[i + half] : v[i];
+      const T send = hi ? v[i] : v[i + half];
+      v[i] = keep + __shfl_xor(send, offset, 64);
+    }
+    offset >>= 1;
+  }
+  T r = v[0];
+  if (NV == 16) { r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64); }
+  return r;
+}
+
+// Dot-product accumulators.  Thousands of workgroups adding to ONE address
+// serialise at ~12 ns per atomic (MI355X_MICROARCH.md "fanin"), which is longer
+// than the kernels themselves; every logical scalar is therefore NS partial
+// sums, picked by blockIdx, and re-summed (fixed order) by its readers.
+constexpr int NS = 64;
+__device__ __forceinline__ void slot_add(double *base, int k, double v) {
+  atomicAdd(&base[(size_t)k * NS + (blockIdx.x & (NS - 1))], v);
+}
+__device__ __forceinline__ double slot_sum(const double *base, int k) { // whole wave must call
+  return wave_allsum(base[(size_t)k * NS + (threadIdx.x & 63)]);
+}
+
 __device__ __forceinline__ double clampd(double x, double lo, double hi) {
   return x < lo ? lo : (x > hi ? hi : x);
 }

@@ -54,6 +54,7 @@ struct EngineBase {
   virtual void get(int which, void *out, int64_t *count) = 0;
   virtual void lm(const gr_lm_options &opt, gr_lm_stats &st, double *chi2_trace, double *lambda_trace) = 0;
   virtual int kernel_stats(gr_kernel_stat *out, int cap) = 0;
+  virtual double diag_time(int which, int variant, int reps) = 0;
   int device = 0;
 };
 
@@ -67,6 +68,8 @@ template <typename T> struct Engine final : EngineBase {
 
   // host structure
   std::vector<int> h_pt_ptr, h_cam_pm, h_pt_pm, h_cam_ptr, h_pt_cm, h_pos_cm, h_pm_of_orig;
+  std::vector<int> h_chunk_cam, h_chunk_beg, h_cam_chunk_ptr;
+  int nch = 0, nb_pm = 0;
   // Schur structure (lazy)
   bool schur_ready = false;
   int64_t nnzb = 0, nprod = 0;
@@ -74,12 +77,17 @@ template <typename T> struct Engine final : EngineBase {
 
   // device data
   DevBuf<T> cams, pts, cams_bak, pts_bak, pack, obs_pm, obs_cm;
-  DevBuf<int> pt_ptr, cam_pm, pt_pm, cam_ptr, pt_cm, pos_cm;
+  DevBuf<int> pt_ptr, cam_pm, pt_pm, cam_ptr, pt_cm, pos_cm, cam_cm, chunk_cam, chunk_beg, cam_chunk_ptr;
+  DevBuf<T> cam_partial, op_partial, g9, g3, part9, xl_acc;
+  DevBuf<int> boundary_flag;
+  DevBuf<unsigned> ticket;
   DevBuf<T> Hcc, Hll, Hcp, scales, bu; // bu = [bc (9Nc) ; bl (3Np)] unscaled -J^T rho' r
   struct View { T *p = nullptr; } bc, bl;
   DevBuf<double> chi2_partial, dscalars; // dscalars[0]=chi2, [1]=rho denom
   // Schur
-  DevBuf<int> blk_order, prod_ptr, prod_a, prod_b, S_rowi, S_coli, S_diag, row_ptr, row_blk, row_col;
+  DevBuf<int> prod_a, prod_b, S_rowi, S_coli, S_diag, row_ptr, row_blk, row_col;
+  DevBuf<int> item_blk, item_beg, item_end, item_single, multi_blk;
+  int nitems = 0, nmulti = 0;
   DevBuf<T> S, b_schur, Hll_inv, Mp, vl, MinvS;
   // PCG work vectors
   DevBuf<T> v_r, v_p, v_z, v_Ap, v_xb, v_dx, v_ps, v_diag, MinvC, MinvP;
@@ -121,10 +129,13 @@ template <typename T> struct Engine final : EngineBase {
     Hcc.alloc(81 * (size_t)Nc); Hll.alloc(9 * (size_t)Np);
     bu.alloc(n); bc.p = bu.p; bl.p = bu.p + pose_dim;
     scales.alloc(n);
-    n_point_blocks = cdiv(Np, TPB);
-    n_chi2_blocks = std::min(cdiv(No, TPB), 2048);
-    chi2_partial.alloc(std::max(n_point_blocks, n_chi2_blocks));
+    nb_pm = cdiv(No, TPB);
+    n_chi2_blocks = std::min(cdiv(No, TPB), 1024);
+    chi2_partial.alloc(std::max(cdiv(nch, 4), 2 * n_chi2_blocks));
     dscalars.alloc(4);
+    ticket.alloc(1); ticket.zero(stream);
+    cam_partial.alloc(54 * (size_t)nch); op_partial.alloc(9 * (size_t)nch); part9.alloc(9 * (size_t)nch);
+    g9.alloc(9 * (size_t)No); g3.alloc(3 * (size_t)No);
     v_dx.alloc(n);
     tmp.alloc(std::max<size_t>(n, 27 * (size_t)No));
     GR_HIP(hipStreamSynchronize(stream));
@@ -156,17 +167,29 @@ template <typename T> struct Engine final : EngineBase {
         if (h_cam_pm[a] == h_cam_pm[a - 1]) throw std::domain_error("duplicate (camera, point) edge");
     h_cam_ptr.assign(Nc + 1, 0);
     for (int64_t a = 0; a < No; ++a) h_cam_ptr[h_cam_pm[a] + 1]++;
+    for (int64_t c = 0; c < Nc; ++c) if (h_cam_ptr[c + 1] == 0) throw std::invalid_argument("camera without observations (the reference deactivates it, graph.hpp:171; remove it from the problem)");
+    for (int64_t l = 0; l < Np; ++l) if (h_pt_ptr[l + 1] == h_pt_ptr[l]) throw std::invalid_argument("point without observations (the reference deactivates it, graph.hpp:171; remove it from the problem)");
     for (int64_t c = 0; c < Nc; ++c) h_cam_ptr[c + 1] += h_cam_ptr[c];
     h_pos_cm.resize(No); h_pt_cm.resize(No);
+    std::vector<int> h_cam_cm(No);
     std::vector<T> h_obs_cm(2 * No);
     std::vector<int> wc(h_cam_ptr.begin(), h_cam_ptr.end() - 1);
     for (int64_t a = 0; a < No; ++a) {
       const int j = wc[h_cam_pm[a]]++;
-      h_pos_cm[j] = (int)a; h_pt_cm[j] = h_pt_pm[a];
+      h_pos_cm[j] = (int)a; h_pt_cm[j] = h_pt_pm[a]; h_cam_cm[j] = h_cam_pm[a];
       h_obs_cm[2 * (size_t)j] = h_obs_pm[2 * a]; h_obs_cm[2 * (size_t)j + 1] = h_obs_pm[2 * a + 1];
     }
+    // camera-major chunks: <= CHUNK consecutive observations of one camera per wave
+    h_chunk_cam.clear(); h_chunk_beg.clear(); h_cam_chunk_ptr.assign(Nc + 1, 0);
+    for (int64_t c = 0; c < Nc; ++c) {
+      for (int j = h_cam_ptr[c]; j < h_cam_ptr[c + 1]; j += CHUNK) { h_chunk_cam.push_back((int)c); h_chunk_beg.push_back(j); }
+      h_cam_chunk_ptr[c + 1] = (int)h_chunk_cam.size();
+    }
+    nch = (int)h_chunk_cam.size();
+    h_chunk_beg.push_back((int)No);
+    chunk_cam.upload(h_chunk_cam, stream); chunk_beg.upload(h_chunk_beg, stream); cam_chunk_ptr.upload(h_cam_chunk_ptr, stream);
     pt_ptr.upload(h_pt_ptr, stream); cam_pm.upload(h_cam_pm, stream); pt_pm.upload(h_pt_pm, stream);
-    cam_ptr.upload(h_cam_ptr, stream); pt_cm.upload(h_pt_cm, stream); pos_cm.upload(h_pos_cm, stream);
+    cam_ptr.upload(h_cam_ptr, stream); pt_cm.upload(h_pt_cm, stream); pos_cm.upload(h_pos_cm, stream); cam_cm.upload(h_cam_cm, stream);
     obs_pm.upload(h_obs_pm, stream); obs_cm.upload(h_obs_cm, stream);
     GR_HIP(hipStreamSynchronize(stream));
   }
@@ -212,11 +235,20 @@ template <typename T> struct Engine final : EngineBase {
           const int q = w[map[(size_t)h_cam_pm[b] * Nc + h_cam_pm[a]]]++;
           h_prod_a[q] = a; h_prod_b[q] = b;
         }
-    std::vector<int> order(nnzb);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-      return (h_prod_ptr[x + 1] - h_prod_ptr[x]) > (h_prod_ptr[y + 1] - h_prod_ptr[y]);
-    });
+    // work items: <= 56 products of one block per wave
+    std::vector<int> h_item_blk, h_item_beg, h_item_end, h_item_single, h_multi;
+    for (int64_t q = 0; q < nnzb; ++q) {
+      const int beg = h_prod_ptr[q], end = h_prod_ptr[q + 1];
+      const bool single = (end - beg) <= 56;
+      if (!single) h_multi.push_back((int)q);
+      int b0 = beg;
+      do {
+        const int e0 = std::min(b0 + 56, end);
+        h_item_blk.push_back((int)q); h_item_beg.push_back(b0); h_item_end.push_back(e0); h_item_single.push_back(single ? 1 : 0);
+        b0 = e0;
+      } while (b0 < end);
+    }
+    nitems = (int)h_item_blk.size(); nmulti = (int)h_multi.size();
     // row lists for y = S x: upper blocks of row i, then lower blocks as transposes (~blk)
     std::vector<int> h_row_ptr(Nc + 1, 0);
     for (int64_t q = 0; q < nnzb; ++q) {
@@ -231,7 +263,8 @@ template <typename T> struct Engine final : EngineBase {
       h_row_blk[e] = (int)q; h_row_col[e] = j;
       if (i != j) { e = wr[j]++; h_row_blk[e] = ~(int)q; h_row_col[e] = i; }
     }
-    blk_order.upload(order, stream); prod_ptr.upload(h_prod_ptr, stream);
+    item_blk.upload(h_item_blk, stream); item_beg.upload(h_item_beg, stream); item_end.upload(h_item_end, stream);
+    item_single.upload(h_item_single, stream); multi_blk.upload(h_multi, stream);
     prod_a.upload(h_prod_a, stream); prod_b.upload(h_prod_b, stream);
     S_rowi.upload(h_S_rowi, stream); S_coli.upload(h_S_coli, stream); S_diag.upload(h_S_diag, stream);
     row_ptr.upload(h_row_ptr, stream); row_blk.upload(h_row_blk, stream); row_col.upload(h_row_col, stream);
@@ -239,6 +272,8 @@ template <typename T> struct Engine final : EngineBase {
     Hll_inv.alloc(9 * (size_t)Np); Mp.alloc(9 * (size_t)Np); vl.alloc(3 * (size_t)Np);
     MinvS.alloc(81 * (size_t)Nc);
     Hcp.alloc(27 * (size_t)No);
+    xl_acc.alloc(3 * (size_t)Np); xl_acc.zero(stream);
+    boundary_flag.alloc(Np); boundary_flag.zero(stream);
     v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_Ap.alloc(n); v_xb.alloc(n);
     GR_HIP(hipStreamSynchronize(stream));
     schur_ready = true;
@@ -302,26 +337,29 @@ template <typename T> struct Engine final : EngineBase {
   }
   double w() const { return (double)sizeof(T); }
 
-  void campack() { k_campack<T><<<cdiv(Nc, TPB), TPB, 0, stream>>>((int)Nc, cams.p, pack.p); }
+  void campack(const T *dx = nullptr) {
+    k_campack<T><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, cams.p, pack.p, dx, scales.p);
+  }
 
   // Graph::linearize (graph.hpp:236-290) fused with Hessian::update_values
-  // (hessian.hpp:290-307): one point pass + one camera pass over the observations.
-  void linearize_impl(bool write_hcp) {
-    campack();
+  // (hessian.hpp:290-307): ONE launch over the observations (pm blocks + cm chunks)
+  // followed by the finalize kernel (chunk sums, scales, chi2).
+  void linearize_impl(bool write_hcp, bool pack_valid = false) {
+    if (!pack_valid) campack();
+    const int grid = cdiv(nch, 4);
     {
-      Scope sc(this, write_hcp ? "point_linearize_hcp" : "point_linearize",
-               No * (2 * w() + 4) + Np * (3 * w() + 4 + 12 * w()) + (write_hcp ? 27.0 * No * w() : 0.0),
-               No * (250.0 + (write_hcp ? 81.0 : 0.0)));
+      // algorithmic bytes: every array touched once (obs, indices, points, packs, g9 out, partials, Hcp)
+      const double bytes = No * (2 * w() + 8.0) + (24.0 * Nc + 3.0 * Np) * w() + 9.0 * No * w() + 54.0 * nch * w() + (write_hcp ? 27.0 * No * w() : 0.0);
+      Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)));
       if (write_hcp)
-        k_point_linearize<T, true><<<n_point_blocks, TPB, 0, stream>>>((int)Np, pt_ptr.p, cam_pm.p, obs_pm.p, pts.p, pack.p, loss_kind, loss_delta, Hll.p, bl.p, Hcp.p, chi2_partial.p);
+        k_linearize<T, true><<<grid, TPB, 0, stream>>>(nch, chunk_cam.p, chunk_beg.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p);
       else
-        k_point_linearize<T, false><<<n_point_blocks, TPB, 0, stream>>>((int)Np, pt_ptr.p, cam_pm.p, obs_pm.p, pts.p, pack.p, loss_kind, loss_delta, Hll.p, bl.p, nullptr, chi2_partial.p);
+        k_linearize<T, false><<<grid, TPB, 0, stream>>>(nch, chunk_cam.p, chunk_beg.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
     }
     {
-      Scope sc(this, "camera_linearize", No * (2 * w() + 4 + 3 * w()) + Nc * 90.0 * w(), No * 330.0);
-      k_camera_linearize<T><<<(int)Nc, TPB, 0, stream>>>(cam_ptr.p, pt_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, Hcc.p, bc.p);
+      Scope sc(this, "linearize_finalize", 9.0 * No * w() + 54.0 * nch * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nch);
+      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, cam_chunk_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid, chi2_partial.p, dscalars.p);
     }
-    k_scales<T><<<cdiv(n, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, Hcc.p, Hll.p, scales.p, n_point_blocks, chi2_partial.p, dscalars.p);
     hcp_valid = write_hcp;
   }
   bool want_hcp = false;
@@ -329,17 +367,14 @@ template <typename T> struct Engine final : EngineBase {
 
   // Graph::compute_error + Graph::chi2 (graph.hpp:212-225)
   double chi2() override {
-    chi2_async(nullptr);
-    double v = 0;
-    GR_HIP(hipMemcpyAsync(&v, dscalars.p, sizeof(double), hipMemcpyDeviceToHost, stream));
-    GR_HIP(hipStreamSynchronize(stream));
-    return v;
-  }
-  void chi2_async(T *res_out) {
     campack();
-    Scope sc(this, "chi2", No * (2 * w() + 8), No * 40.0);
-    k_chi2<T><<<n_chi2_blocks, TPB, 0, stream>>>((int)No, cam_pm.p, pt_pm.p, obs_pm.p, pts.p, pack.p, loss_kind, loss_delta, chi2_partial.p, res_out);
-    k_reduce_partials<T><<<1, TPB, 0, stream>>>(n_chi2_blocks, chi2_partial.p, dscalars.p);
+    chi2_async(nullptr, nullptr, 0.0);
+    return read_scalar(0);
+  }
+  // dscalars[0] = chi2; with dx also dscalars[1] = sum dx (mu dx + b)   (compute_rho)
+  void chi2_async(T *res_out, const T *dx, double mu) {
+    Scope sc(this, "chi2", No * (2 * w() + 8) + (24.0 * Nc + 3.0 * Np) * w() + (dx ? 3.0 * n * w() : 0.0), No * 40.0);
+    k_chi2<T><<<n_chi2_blocks, TPB, 0, stream>>>((int)No, (unsigned)n, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, res_out);
   }
   double read_scalar(int idx) {
     double v = 0;
@@ -358,8 +393,8 @@ template <typename T> struct Engine final : EngineBase {
     campack(); // the matrix-free operator recomputes J from the pack: keep it in step with the vertices
   }
   void apply_update_dev(const T *dx) { // graph.hpp:292-300, ops/update.hpp:11-31
-    k_apply_update<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>(pose_dim, cams.p, dx, scales.p);
-    k_apply_update<T><<<cdiv(3 * Np, TPB), TPB, 0, stream>>>(3 * (size_t)Np, pts.p, dx + pose_dim, scales.p + pose_dim);
+    campack(dx); // cameras: x += dx .* s fused with the pack rebuild
+    k_apply_update<T><<<cdiv(3 * Np, TPB), TPB, 0, stream>>>((unsigned)(3 * Np), pts.p, dx + pose_dim, scales.p + pose_dim);
   }
   void apply_update(const void *dx) override {
     GR_HIP(hipMemcpyAsync(v_dx.p, dx, n * sizeof(T), hipMemcpyDefault, stream));
@@ -369,11 +404,12 @@ template <typename T> struct Engine final : EngineBase {
   // ---- Solver interface ---------------------------------------------------------
   void ensure_scalars(int max_iter) {
     const int cap = max_iter + 2;
-    if (cap > sc_cap) { sc_cap = cap; sc_d.alloc(4 * (size_t)cap); sc_i.alloc((size_t)cap + 1); }
+    if (cap > sc_cap) { sc_cap = cap; sc_d.alloc((4 * (size_t)NS + 1) * cap); sc_i.alloc((size_t)cap + 1); }
   }
   PcgScalars scalars() {
     PcgScalars sc;
-    sc.rz = sc_d.p; sc.den = sc_d.p + sc_cap; sc.rz0 = sc_d.p + 2 * (size_t)sc_cap; sc.rr = sc_d.p + 3 * (size_t)sc_cap;
+    const size_t blk = (size_t)sc_cap * NS;
+    sc.rz = sc_d.p; sc.den = sc_d.p + blk; sc.rr = sc_d.p + 2 * blk; sc.pdp = sc_d.p + 3 * blk; sc.rz0 = sc_d.p + 4 * blk;
     sc.done = sc_i.p; sc.iters = sc_i.p + sc_cap;
     return sc;
   }
@@ -382,7 +418,7 @@ template <typename T> struct Engine final : EngineBase {
     if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
     else {
       want_hcp = false;
-      v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_Ap.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
+      v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
       MinvC.alloc(81 * (size_t)Nc); MinvP.alloc(9 * (size_t)Np);
     }
   }
@@ -393,11 +429,9 @@ template <typename T> struct Engine final : EngineBase {
   }
   void solver_set_damping(int solver, double mu, bool use_identity) override {
     damping = mu; damping_identity = use_identity;
-    if (solver == GR_SOLVER_PCG) { // BlockJacobiPreconditioner::set_damping_factor (block_jacobi.hpp:120-172)
-      k_inv9<T, 1><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Hcc.p, nullptr, scales.p, mu, use_identity ? 1 : 0, MinvC.p, v_diag.p);
-      k_inv3_points<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, scales.p, mu, use_identity ? 1 : 0, MinvP.p, v_diag.p);
-    } else if (solver == GR_SOLVER_PCG_IDENTITY) {
-      // only the clamped diagonal is needed (pcg.hpp:93-103)
+    if (solver == GR_SOLVER_PCG || solver == GR_SOLVER_PCG_IDENTITY) {
+      // BlockJacobiPreconditioner::set_damping_factor (block_jacobi.hpp:120-172); the identity
+      // variant only needs the clamped diagonal (pcg.hpp:93-103)
       k_inv9<T, 1><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Hcc.p, nullptr, scales.p, mu, use_identity ? 1 : 0, MinvC.p, v_diag.p);
       k_inv3_points<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, scales.p, mu, use_identity ? 1 : 0, MinvP.p, v_diag.p);
     }
@@ -407,15 +441,19 @@ template <typename T> struct Engine final : EngineBase {
   void schur_update_values() override {
     build_schur_structure();
     if (!hcp_valid) linearize_impl(true);
-    k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, damping_identity ? 1 : 0, Hll_inv.p, Mp.p, vl.p);
+    const int ui = damping_identity ? 1 : 0;
+    k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p);
+    if (nmulti) k_schur_multi<T, 0><<<cdiv(9 * (size_t)nmulti, TPB), TPB, 0, stream>>>(nmulti, multi_blk.p, S_rowi.p, S_coli.p, Hcc.p, scales.p, damping, ui, S.p);
     {
-      Scope sc(this, "schur_products", nprod * 60.0 * w() + 81.0 * nnzb * w(), nprod * 342.0);
-      k_schur_products<T><<<cdiv(nnzb, 28), TPB, 0, stream>>>((int)nnzb, blk_order.p, prod_ptr.p, prod_a.p, prod_b.p, S_rowi.p, S_coli.p, pt_pm.p, Hcp.p, Mp.p, Hcc.p, scales.p, damping, damping_identity ? 1 : 0, S.p);
+      Scope sc(this, "schur_products", nprod * (54.0 * w() + 8) + 9.0 * Np * w() + 81.0 * nnzb * w(), nprod * 342.0);
+      k_schur_products<T><<<cdiv(nitems, 4), TPB, 0, stream>>>(nitems, item_blk.p, item_beg.p, item_end.p, item_single.p, prod_a.p, prod_b.p, S_rowi.p, S_coli.p, pt_pm.p, Hcp.p, Mp.p, Hcc.p, scales.p, damping, ui, S.p);
     }
+    if (nmulti) k_schur_multi<T, 1><<<cdiv(9 * (size_t)nmulti, TPB), TPB, 0, stream>>>(nmulti, multi_blk.p, S_rowi.p, S_coli.p, Hcc.p, scales.p, damping, ui, S.p);
     {
-      Scope sc(this, "b_schur", No * (27.0 * w() + 8 + 3 * w()), No * 54.0);
-      k_bschur<T><<<(int)Nc, TPB, 0, stream>>>(cam_ptr.p, pt_cm.p, pos_cm.p, Hcp.p, vl.p, bc.p, scales.p, b_schur.p);
+      Scope sc(this, "b_schur", No * (27.0 * w() + 8) + 3.0 * Np * w(), No * 54.0);
+      k_bschur_partial<T><<<cdiv(nch, 4), TPB, 0, stream>>>(nch, chunk_beg.p, pt_cm.p, pos_cm.p, Hcp.p, vl.p, part9.p);
     }
+    k_bschur_finalize<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p);
   }
   void schur_matvec_dev(const T *x, T *y, int k) {
     Scope sc(this, "schur_matvec", (2.0 * nnzb - Nc) * 81.0 * w(), (2.0 * nnzb - Nc) * 162.0);
@@ -430,8 +468,11 @@ template <typename T> struct Engine final : EngineBase {
     GR_HIP(hipStreamSynchronize(stream));
   }
   void landmark_update_dev(const T *xp, T *xl) {
-    Scope sc(this, "backsub", No * (27.0 * w() + 4) + Np * 15.0 * w(), No * 54.0);
-    k_backsub<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bl.p, scales.p, xp, xl);
+    {
+      Scope sc(this, "backsub", No * (27.0 * w() + 8) + Np * 15.0 * w(), No * 54.0);
+      k_backsub<T><<<nb_pm, TPB, 0, stream>>>((int)No, (int)Nc, pt_ptr.p, cam_pm.p, pt_pm.p, Hcp.p, Hll_inv.p, bl.p, scales.p, xp, xl, xl_acc.p, boundary_flag.p);
+    }
+    k_backsub_fixup<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll_inv.p, bl.p, scales.p, xl, xl_acc.p, boundary_flag.p);
   }
   void landmark_update(const void *xp, void *xl) override {
     GR_HIP(hipMemcpyAsync(v_p.p, xp, pose_dim * sizeof(T), hipMemcpyDefault, stream));
@@ -454,8 +495,7 @@ template <typename T> struct Engine final : EngineBase {
     ensure_scalars(max_iter);
     PcgScalars sc = scalars();
     k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
-    GR_HIP(hipMemsetAsync(x, 0, n * sizeof(T), stream));
-    k_pcgs_init<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, sc);
+    k_pcgs_init<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, sc);
     for (int k = 0; k < max_iter; ++k) {
       schur_matvec_dev(v_p.p, v_Ap.p, k);
       k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k);
@@ -465,28 +505,84 @@ template <typename T> struct Engine final : EngineBase {
     return 0;
   }
 
+  // bytes one matrix-free operator launch has to move at minimum (J recomputed): every
+  // array touched once per pass (pm pass + cm pass); see DESIGN.md
+  double operator_bytes() const {
+    return No * (2.0 * sizeof(T) + 8.0) + (n + 24.0 * Nc + 3.0 * Np) * sizeof(T) + 3.0 * No * sizeof(T) + 9.0 * nch * sizeof(T);
+  }
   // PCGSolver::solve (solver/pcg.hpp:61-232)
   template <bool IDENTITY> void solve_pcg(int max_iter, double tol, double rej, T *x) {
     ensure_scalars(max_iter);
     PcgScalars sc = scalars();
+    const int ui = damping_identity ? 1 : 0;
     k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
     const int ublocks = cdiv(pose_dim, 252) + cdiv(3 * (size_t)Np, 252);
-    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvC.p, MinvP.p, sc, 0);
-    k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>(n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, sc, -1, tol, rej);
-    const double op_bytes = No * (2.0 * w() + 4) * 2 + No * 7.0 * w() + 6.0 * n * w();
+    const int ogrid = cdiv(nch, 4);
+    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_chunk_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, sc, 0);
+    k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, sc, -1, tol, rej);
     for (int k = 0; k < max_iter; ++k) {
       {
-        Scope s1(this, "pcg_op_points", No * (2 * w() + 4) + Np * (4 + 12.0 * w()), No * 330.0);
-        k_op_points<T><<<n_point_blocks, TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, cam_pm.p, obs_pm.p, pts.p, pack.p, loss_kind, loss_delta, scales.p, v_ps.p, v_p.p, v_diag.p, damping, damping_identity ? 1 : 0, v_Ap.p, sc, k);
+        Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
+        k_pcg_operator<T><<<ogrid, TPB, 0, stream>>>((int)Nc, nch, chunk_cam.p, chunk_beg.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, sc, k);
       }
       {
-        Scope s2(this, "pcg_op_cameras", No * (2 * w() + 4 + 6 * w()) + Nc * 36.0 * w(), No * 340.0);
-        k_op_cameras<T><<<(int)Nc, TPB, 0, stream>>>((int)Nc, cam_ptr.p, pt_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, scales.p, v_ps.p, v_p.p, v_diag.p, damping, damping_identity ? 1 : 0, v_Ap.p, sc, k);
+        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nch * sizeof(T) + 3.0 * No * sizeof(T), 12.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
+        k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_chunk_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, sc, k);
       }
-      (void)op_bytes;
-      k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvC.p, MinvP.p, sc, k);
-      k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>(n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, sc, k, tol, rej);
+      {
+        Scope s3(this, "pcg_direction", 7.0 * n * sizeof(T), 6.0 * n);
+        k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, sc, k, tol, rej);
+      }
     }
+  }
+
+  // Diagnostic: average device time (us) of `reps` back-to-back launches of one hot kernel
+  // (which: 0 operator, 1 linearize, 2 chi2, 3 pcg_update, 4 pcg_direction, 5 linearize_finalize).
+  // Needs a previous linearize + set_damping for the matrix-free solver.
+  double diag_time(int which, int variant, int reps) override {
+    solver_update_structure(GR_SOLVER_PCG);
+    linearize_impl(false);
+    solver_set_damping(GR_SOLVER_PCG, 1e-4, false);
+    ensure_scalars(4);
+    PcgScalars sc = scalars();
+    const int ui = 0;
+    const int ublocks = cdiv(pose_dim, 252) + cdiv(3 * (size_t)Np, 252);
+    auto prep = [&] {
+      k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
+      k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_chunk_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, sc, 0);
+      k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, sc, -1, 1.0, 5.0);
+    };
+    prep();
+    hipEvent_t a, b;
+    GR_HIP(hipEventCreate(&a)); GR_HIP(hipEventCreate(&b));
+    const int ogrid = cdiv(nch, 4);
+    auto launch = [&] {
+      switch (which) {
+      case 0:
+#define GR_OP(V) k_pcg_operator<T, V><<<ogrid, TPB, 0, stream>>>((int)Nc, nch, chunk_cam.p, chunk_beg.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, sc, 0)
+#ifdef GR_DIAG
+        switch (variant) { case 1: GR_OP(1); break; case 2: GR_OP(2); break; case 4: GR_OP(4); break; case 7: GR_OP(7); break; case 8: GR_OP(8); break; case 15: GR_OP(15); break; case 16: GR_OP(16); break; case 31: GR_OP(31); break; default: GR_OP(0); }
+#else
+        GR_OP(0);
+#endif
+        break;
+      case 1: k_linearize<T, false><<<ogrid, TPB, 0, stream>>>(nch, chunk_cam.p, chunk_beg.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); break;
+      case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
+      case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_chunk_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, sc, 0); break;
+      case 4: k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, sc, -1, 1.0, 5.0); break;
+      case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, cam_chunk_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, ogrid, chi2_partial.p, dscalars.p); break;
+      default: throw std::invalid_argument("diag_time: unknown kernel");
+      }
+    };
+    for (int i = 0; i < 3; ++i) launch();
+    GR_HIP(hipEventRecord(a, stream));
+    for (int i = 0; i < reps; ++i) launch();
+    GR_HIP(hipEventRecord(b, stream));
+    GR_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    GR_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return ms * 1e3 / reps;
   }
 
   int last_iters() {
@@ -524,7 +620,7 @@ template <typename T> struct Engine final : EngineBase {
     case GR_GET_SCALES: cnt = (int64_t)n; src = scales.p; break;
     case GR_GET_B:
       cnt = (int64_t)n;
-      k_mul<T><<<cdiv(n, TPB), TPB, 0, stream>>>(n, tmp.p, scales.p, bu.p);
+      k_mul<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, tmp.p, scales.p, bu.p);
       src = tmp.p; break;
     case GR_GET_HCC: cnt = 81 * Nc; launch_export(Nc, 9, 9, Hcc.p, scales.p, scales.p, nullptr, nullptr, nullptr); src = tmp.p; break;
     case GR_GET_HLL: cnt = 9 * Np; launch_export(Np, 3, 3, Hll.p, scales.p + pose_dim, scales.p + pose_dim, nullptr, nullptr, nullptr); src = tmp.p; break;
@@ -545,7 +641,8 @@ template <typename T> struct Engine final : EngineBase {
     case GR_GET_RESIDUALS: {
       cnt = 2 * No;
       DevBuf<T> rpm; rpm.alloc(2 * (size_t)No);
-      chi2_async(rpm.p);
+      campack();
+      chi2_async(rpm.p, nullptr, 0.0);
       std::vector<T> h = rpm.download(stream), ho(2 * (size_t)No);
       for (int64_t o = 0; o < No; ++o) { ho[2 * o] = h[2 * (size_t)h_pm_of_orig[o]]; ho[2 * o + 1] = h[2 * (size_t)h_pm_of_orig[o] + 1]; }
       if (out) GR_HIP(hipMemcpy(out, ho.data(), ho.size() * sizeof(T), hipMemcpyDefault));
@@ -589,10 +686,8 @@ template <typename T> struct Engine final : EngineBase {
       GR_HIP(hipEventRecord(ev_b, stream));
       backup();
       apply_update_dev(v_dx.p);
-      // compute_rho denominator (:20-47) queued before the chi2 read so one sync serves both
-      GR_HIP(hipMemsetAsync(dscalars.p + 1, 0, sizeof(double), stream));
-      k_rho_denom<T><<<std::min(cdiv(n, TPB), 1024), TPB, 0, stream>>>(n, v_dx.p, bu.p, scales.p, (double)mu, dscalars.p + 1);
-      chi2_async(nullptr);
+      // trial chi2 + compute_rho denominator (:20-47) in one kernel, one sync serves both
+      chi2_async(nullptr, v_dx.p, (double)mu);
       double hs[2];
       GR_HIP(hipMemcpyAsync(hs, dscalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
       int it = 0;
@@ -611,7 +706,7 @@ template <typename T> struct Engine final : EngineBase {
         alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
         mu *= (T)alpha;
         nu = 2;
-        linearize();
+        linearize_impl(want_hcp, /*pack_valid=*/true);
         solver_update_values(opt.solver);
         st.accepted++;
       } else {
@@ -733,6 +828,12 @@ gr_status gr_bal_levenberg_marquardt(gr_bal_problem *p, const gr_lm_options *opt
 }
 gr_status gr_bal_kernel_stats(gr_bal_problem *p, gr_kernel_stat *out, int cap, int *n) {
   return guarded(p, [&] { const int k = p->e->kernel_stats(out, cap); if (n) *n = k; });
+}
+// diagnostic (not part of the drop-in surface): mean device time in us of one hot kernel
+double gr_bal_diag_time(gr_bal_problem *p, int which, int variant, int reps) {
+  double us = -1;
+  guarded(p, [&] { us = p->e->diag_time(which, variant, reps); });
+  return us;
 }
 gr_status gr_comm_unique_id(void *) { g_last_error = "RCCL path not built yet"; return GR_ERR_COMM; }
 gr_status gr_bal_comm_init(gr_bal_problem *, const void *, int, int) { g_last_error = "RCCL path not built yet"; return GR_ERR_COMM; }
