@@ -103,21 +103,26 @@ template <typename T, int NV> __device__ __forceinline__ void seg_scan(T (&v)[NV
 // Sum NV (= 16 or 64) per-lane values over the 64 lanes with NV-1 (+2) shuffles instead
 // of 6*NV: at every halving step a lane keeps one half of its values and hands the
 // other half to its partner (lane ^ offset).  On return lane L holds the wave total of
-// value index (NV == 64 ? L : L >> 2) in v[0].
+// value index (NV == 64 ? L : L >> 2).  Template recursion keeps every array index a
+// compile-time constant (the array must stay in VGPRs).
+template <typename T, int NV, int HALF, int OFFSET> struct TransposeStep {
+  static __device__ __forceinline__ void run(T (&v)[NV], int lane) {
+    const bool hi = (lane & OFFSET) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+      const T keep = hi ? v[i + HALF] : v[i];
+      const T send = hi ? v[i] : v[i + HALF];
+      v[i] = keep + __shfl_xor(send, OFFSET, 64);
+    }
+    TransposeStep<T, NV, HALF / 2, OFFSET / 2>::run(v, lane);
+  }
+};
+template <typename T, int NV, int OFFSET> struct TransposeStep<T, NV, 0, OFFSET> {
+  static __device__ __forceinline__ void run(T (&)[NV], int) {}
+};
 template <typename T, int NV> __device__ __forceinline__ T wave_transpose_sum(T (&v)[NV], int lane) {
   static_assert(NV == 64 || NV == 16, "NV must be 16 or 64");
-  int offset = 32;
-#pragma unroll
-  for (int half = NV / 2; half >= 1; half >>= 1) {
-    const bool hi = (lane & offset) != 0;
-#pragma unroll
-    for (int i = 0; i < half; ++i) {
-      const T keep = hi ? v[i + half] : v[i];
-      const T send = hi ? v[i] : v[i + half];
-      v[i] = keep + __shfl_xor(send, offset, 64);
-    }
-    offset >>= 1;
-  }
+  TransposeStep<T, NV, NV / 2, 32>::run(v, lane);
   T r = v[0];
   if (NV == 16) { r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64); }
   return r;

@@ -9,7 +9,7 @@
 //   optimizer::levenberg_marquardt                                             (optimizer/levenberg_marquardt.hpp)
 // The C ABI at the bottom (include/graphite_mi355x.h) is the drop-in boundary.
 #include "../../include/graphite_mi355x.h"
-#include "kernels.hpp"
+#include "kernels_mf.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -68,8 +68,8 @@ template <typename T> struct Engine final : EngineBase {
 
   // host structure
   std::vector<int> h_pt_ptr, h_cam_pm, h_pt_pm, h_cam_ptr, h_pt_cm, h_pos_cm, h_pm_of_orig;
-  std::vector<int> h_chunk_cam, h_chunk_beg, h_cam_chunk_ptr;
-  int nch = 0, nb_pm = 0;
+  std::vector<int> h_chunk_cam, h_chunk_beg, h_cam_chunk_ptr, h_cam_seg_ptr;
+  int nch = 0, nb_pm = 0, nseg = 0;
   // Schur structure (lazy)
   bool schur_ready = false;
   int64_t nnzb = 0, nprod = 0;
@@ -81,6 +81,16 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<T> cam_partial, op_partial, g9, g3, part9, xl_acc;
   DevBuf<int> boundary_flag;
   DevBuf<unsigned> ticket;
+  DevBuf<int> cam_seg_ptr;
+  // matrix-free PCG control
+  DevBuf<PcgCtl> ctl;
+  DevBuf<double> grid_partial;
+  DevBuf<int> pcg_iters;
+  int ctl_cap = 0;
+  // pinned host mirror: [0..1] chi2 / rho doubles, then ints: seq, flags[]
+  double *h_res = nullptr;
+  volatile int *h_seq = nullptr, *h_flag = nullptr;
+  int h_flag_cap = 0, seq_counter = 0;
   DevBuf<T> Hcc, Hll, Hcp, scales, bu; // bu = [bc (9Nc) ; bl (3Np)] unscaled -J^T rho' r
   struct View { T *p = nullptr; } bc, bl;
   DevBuf<double> chi2_partial, dscalars; // dscalars[0]=chi2, [1]=rho denom
@@ -131,14 +141,44 @@ template <typename T> struct Engine final : EngineBase {
     scales.alloc(n);
     nb_pm = cdiv(No, TPB);
     n_chi2_blocks = std::min(cdiv(No, TPB), 1024);
-    chi2_partial.alloc(std::max(cdiv(nch, 4), 2 * n_chi2_blocks));
+    chi2_partial.alloc(std::max<size_t>(nb_pm, 2 * (size_t)cdiv(std::max<size_t>(No, n), TPB)) + 64);
     dscalars.alloc(4);
-    ticket.alloc(1); ticket.zero(stream);
-    cam_partial.alloc(54 * (size_t)nch); op_partial.alloc(9 * (size_t)nch); part9.alloc(9 * (size_t)nch);
+    ticket.alloc(1 + TICKET_GROUPS); ticket.zero(stream);
+    cam_partial.alloc(54 * (size_t)nseg); op_partial.alloc(9 * (size_t)nseg); part9.alloc(9 * (size_t)nch);
+    grid_partial.alloc(2 * (size_t)std::max(cdiv(std::max<size_t>(No, n), TPB), cdiv(n, 252) + cdiv(Np, TPB)) + 64);
+    pcg_iters.alloc(1);
+    alloc_pinned(64);
     g9.alloc(9 * (size_t)No); g3.alloc(3 * (size_t)No);
     v_dx.alloc(n);
     tmp.alloc(std::max<size_t>(n, 27 * (size_t)No));
     GR_HIP(hipStreamSynchronize(stream));
+  }
+
+  void alloc_pinned(int flag_cap) {
+    if (h_res && flag_cap <= h_flag_cap) return;
+    if (h_res) (void)hipHostFree(h_res);
+    void *p = nullptr;
+    GR_HIP(hipHostMalloc(&p, 64 + sizeof(int) * (size_t)(flag_cap + 16), hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(p, 0, 64 + sizeof(int) * (size_t)(flag_cap + 16));
+    h_res = static_cast<double *>(p);
+    h_seq = reinterpret_cast<volatile int *>(static_cast<char *>(p) + 16);
+    h_flag = reinterpret_cast<volatile int *>(static_cast<char *>(p) + 64);
+    h_flag_cap = flag_cap;
+  }
+  ~Engine() override {
+    if (h_res) (void)hipHostFree(h_res);
+  }
+  // spin on a pinned word written by a kernel (system-scope fence on the device side)
+  template <typename Pred> void spin_until(Pred pred) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; ++it) {
+      if (pred()) return;
+      if ((it & 0xFFFF) == 0xFFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
+        GR_HIP(hipStreamSynchronize(stream)); // surfaces a kernel fault instead of hanging
+        if (pred()) return;
+        throw HipError("timeout waiting for a device flag");
+      }
+    }
   }
 
   // ---- symbolic phase -----------------------------------------------------------
@@ -187,6 +227,12 @@ template <typename T> struct Engine final : EngineBase {
     }
     nch = (int)h_chunk_cam.size();
     h_chunk_beg.push_back((int)No);
+    // (wave, camera) segments of the flat camera-major kernels
+    h_cam_seg_ptr.assign(Nc + 1, 0);
+    for (int64_t c = 0; c < Nc; ++c)
+      h_cam_seg_ptr[c + 1] = h_cam_seg_ptr[c] + (((h_cam_ptr[c + 1] - 1) >> 6) - (h_cam_ptr[c] >> 6) + 1);
+    nseg = h_cam_seg_ptr[Nc];
+    cam_seg_ptr.upload(h_cam_seg_ptr, stream);
     chunk_cam.upload(h_chunk_cam, stream); chunk_beg.upload(h_chunk_beg, stream); cam_chunk_ptr.upload(h_cam_chunk_ptr, stream);
     pt_ptr.upload(h_pt_ptr, stream); cam_pm.upload(h_cam_pm, stream); pt_pm.upload(h_pt_pm, stream);
     cam_ptr.upload(h_cam_ptr, stream); pt_cm.upload(h_pt_cm, stream); pos_cm.upload(h_pos_cm, stream); cam_cm.upload(h_cam_cm, stream);
@@ -337,8 +383,8 @@ template <typename T> struct Engine final : EngineBase {
   }
   double w() const { return (double)sizeof(T); }
 
-  void campack(const T *dx = nullptr) {
-    k_campack<T><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, cams.p, pack.p, dx, scales.p);
+  void campack(const T *dx = nullptr, T *bak = nullptr) {
+    k_campack<T><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, cams.p, pack.p, dx, scales.p, bak);
   }
 
   // Graph::linearize (graph.hpp:236-290) fused with Hessian::update_values
@@ -346,19 +392,18 @@ template <typename T> struct Engine final : EngineBase {
   // followed by the finalize kernel (chunk sums, scales, chi2).
   void linearize_impl(bool write_hcp, bool pack_valid = false) {
     if (!pack_valid) campack();
-    const int grid = cdiv(nch, 4);
     {
-      // algorithmic bytes: every array touched once (obs, indices, points, packs, g9 out, partials, Hcp)
-      const double bytes = No * (2 * w() + 8.0) + (24.0 * Nc + 3.0 * Np) * w() + 9.0 * No * w() + 54.0 * nch * w() + (write_hcp ? 27.0 * No * w() : 0.0);
+      // algorithmic bytes: every array touched once (obs, 3 index streams, points, packs, g9 out, partials, Hcp)
+      const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 9.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
       Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)));
       if (write_hcp)
-        k_linearize<T, true><<<grid, TPB, 0, stream>>>(nch, chunk_cam.p, chunk_beg.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p);
+        k_linearize<T, true><<<nb_pm, TPB, 0, stream>>>((int)No, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p);
       else
-        k_linearize<T, false><<<grid, TPB, 0, stream>>>(nch, chunk_cam.p, chunk_beg.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
+        k_linearize<T, false><<<nb_pm, TPB, 0, stream>>>((int)No, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
     }
     {
-      Scope sc(this, "linearize_finalize", 9.0 * No * w() + 54.0 * nch * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nch);
-      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, cam_chunk_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid, chi2_partial.p, dscalars.p);
+      Scope sc(this, "linearize_finalize", 9.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
+      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, nb_pm, chi2_partial.p, dscalars.p);
     }
     hcp_valid = write_hcp;
   }
@@ -368,13 +413,20 @@ template <typename T> struct Engine final : EngineBase {
   // Graph::compute_error + Graph::chi2 (graph.hpp:212-225)
   double chi2() override {
     campack();
-    chi2_async(nullptr, nullptr, 0.0);
-    return read_scalar(0);
+    const int seq = chi2_async(nullptr, nullptr, 0.0);
+    wait_chi2(seq);
+    return h_res[0];
   }
-  // dscalars[0] = chi2; with dx also dscalars[1] = sum dx (mu dx + b)   (compute_rho)
-  void chi2_async(T *res_out, const T *dx, double mu) {
+  // dscalars[0] = chi2; with dx also dscalars[1] = sum dx (mu dx + b) (compute_rho).  The last
+  // block mirrors both into pinned host memory and then publishes `seq`.
+  int chi2_async(T *res_out, const T *dx, double mu) {
+    const int seq = ++seq_counter;
     Scope sc(this, "chi2", No * (2 * w() + 8) + (24.0 * Nc + 3.0 * Np) * w() + (dx ? 3.0 * n * w() : 0.0), No * 40.0);
-    k_chi2<T><<<n_chi2_blocks, TPB, 0, stream>>>((int)No, (unsigned)n, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, res_out);
+    k_chi2<T><<<cdiv(std::max<size_t>(No, n), TPB), TPB, 0, stream>>>((int)No, (unsigned)n, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, h_res, h_seq, seq, res_out);
+    return seq;
+  }
+  void wait_chi2(int seq) {
+    spin_until([&] { return __atomic_load_n(const_cast<const int *>(h_seq), __ATOMIC_ACQUIRE) == seq; });
   }
   double read_scalar(int idx) {
     double v = 0;
@@ -392,9 +444,9 @@ template <typename T> struct Engine final : EngineBase {
     GR_HIP(hipMemcpyAsync(pts.p, pts_bak.p, pts.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
     campack(); // the matrix-free operator recomputes J from the pack: keep it in step with the vertices
   }
-  void apply_update_dev(const T *dx) { // graph.hpp:292-300, ops/update.hpp:11-31
-    campack(dx); // cameras: x += dx .* s fused with the pack rebuild
-    k_apply_update<T><<<cdiv(3 * Np, TPB), TPB, 0, stream>>>((unsigned)(3 * Np), pts.p, dx + pose_dim, scales.p + pose_dim);
+  void apply_update_dev(const T *dx, bool with_backup = false) { // graph.hpp:292-300, ops/update.hpp:11-31
+    campack(dx, with_backup ? cams_bak.p : nullptr); // cameras: x += dx .* s fused with backup + pack rebuild
+    k_apply_update<T><<<cdiv(3 * Np, TPB), TPB, 0, stream>>>((unsigned)(3 * Np), pts.p, dx + pose_dim, scales.p + pose_dim, with_backup ? pts_bak.p : nullptr);
   }
   void apply_update(const void *dx) override {
     GR_HIP(hipMemcpyAsync(v_dx.p, dx, n * sizeof(T), hipMemcpyDefault, stream));
@@ -505,72 +557,86 @@ template <typename T> struct Engine final : EngineBase {
     return 0;
   }
 
-  // bytes one matrix-free operator launch has to move at minimum (J recomputed): every
-  // array touched once per pass (pm pass + cm pass); see DESIGN.md
+  // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
+  // touched once): obs + 3 index streams, ps, packs, points, g3 out, segment partials
   double operator_bytes() const {
-    return No * (2.0 * sizeof(T) + 8.0) + (n + 24.0 * Nc + 3.0 * Np) * sizeof(T) + 3.0 * No * sizeof(T) + 9.0 * nch * sizeof(T);
+    return No * (2.0 * sizeof(T) + 12.0) + (n + 24.0 * Nc + 3.0 * Np) * sizeof(T) + 3.0 * No * sizeof(T) + 9.0 * nseg * sizeof(T);
   }
-  // PCGSolver::solve (solver/pcg.hpp:61-232)
+  void ensure_ctl(int max_iter) {
+    const int cap = max_iter + 2;
+    if (cap > ctl_cap) { ctl_cap = cap; ctl.alloc(cap); }
+    alloc_pinned(cap);
+  }
+  PcgState pcg_state() {
+    PcgState st;
+    st.ctl = ctl.p; st.partial = grid_partial.p; st.ticket = ticket.p; st.iters = pcg_iters.p; st.hflag = h_flag; st.hiters = h_seq + 1;
+    return st;
+  }
+  // PCGSolver::solve (solver/pcg.hpp:61-232).  Scalars stay on the device; the host only
+  // watches a pinned flag per iteration so that it stops enqueueing once the loop has left
+  // (one iteration of look-ahead keeps the queue full).
   template <bool IDENTITY> void solve_pcg(int max_iter, double tol, double rej, T *x) {
-    ensure_scalars(max_iter);
-    PcgScalars sc = scalars();
+    ensure_ctl(max_iter);
+    PcgState st = pcg_state();
     const int ui = damping_identity ? 1 : 0;
-    k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
-    const int ublocks = cdiv(pose_dim, 252) + cdiv(3 * (size_t)Np, 252);
-    const int ogrid = cdiv(nch, 4);
-    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_chunk_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, sc, 0);
-    k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, sc, -1, tol, rej);
-    for (int k = 0; k < max_iter; ++k) {
+    for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
+    h_seq[1] = 0;
+    k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
+    const int ublocks = cdiv(pose_dim, 252) + cdiv(Np, TPB);
+    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, tol, rej);
+    k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1);
+    auto enqueue = [&](int k) {
       {
         Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
-        k_pcg_operator<T><<<ogrid, TPB, 0, stream>>>((int)Nc, nch, chunk_cam.p, chunk_beg.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, sc, k);
+        k_pcg_operator<T><<<nb_pm, TPB, 0, stream>>>((int)No, (int)Nc, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k);
       }
       {
-        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nch * sizeof(T) + 3.0 * No * sizeof(T), 12.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
-        k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_chunk_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, sc, k);
+        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 12.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
+        k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, tol, rej);
       }
       {
         Scope s3(this, "pcg_direction", 7.0 * n * sizeof(T), 6.0 * n);
-        k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, sc, k, tol, rej);
+        k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, k);
       }
+    };
+    if (max_iter > 0) enqueue(0);
+    for (int k = 0; k < max_iter; ++k) {
+      if (k + 1 < max_iter) enqueue(k + 1); // look-ahead
+      spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
+      if (h_flag[k] == 2) break;
     }
   }
 
   // Diagnostic: average device time (us) of `reps` back-to-back launches of one hot kernel
   // (which: 0 operator, 1 linearize, 2 chi2, 3 pcg_update, 4 pcg_direction, 5 linearize_finalize).
-  // Needs a previous linearize + set_damping for the matrix-free solver.
   double diag_time(int which, int variant, int reps) override {
     solver_update_structure(GR_SOLVER_PCG);
     linearize_impl(false);
     solver_set_damping(GR_SOLVER_PCG, 1e-4, false);
-    ensure_scalars(4);
-    PcgScalars sc = scalars();
+    ensure_ctl(4);
+    PcgState st = pcg_state();
     const int ui = 0;
-    const int ublocks = cdiv(pose_dim, 252) + cdiv(3 * (size_t)Np, 252);
-    auto prep = [&] {
-      k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
-      k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_chunk_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, sc, 0);
-      k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, sc, -1, 1.0, 5.0);
-    };
-    prep();
+    const int ublocks = cdiv(pose_dim, 252) + cdiv(Np, TPB);
+    k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
+    k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, 0.0, 1e30);
+    k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1);
     hipEvent_t a, b;
     GR_HIP(hipEventCreate(&a)); GR_HIP(hipEventCreate(&b));
-    const int ogrid = cdiv(nch, 4);
     auto launch = [&] {
       switch (which) {
       case 0:
-#define GR_OP(V) k_pcg_operator<T, V><<<ogrid, TPB, 0, stream>>>((int)Nc, nch, chunk_cam.p, chunk_beg.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, sc, 0)
+#define GR_OP(V) k_pcg_operator<T, V><<<nb_pm, TPB, 0, stream>>>((int)No, (int)Nc, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0)
 #ifdef GR_DIAG
         switch (variant) { case 1: GR_OP(1); break; case 2: GR_OP(2); break; case 4: GR_OP(4); break; case 7: GR_OP(7); break; case 8: GR_OP(8); break; case 15: GR_OP(15); break; case 16: GR_OP(16); break; case 31: GR_OP(31); break; default: GR_OP(0); }
 #else
         GR_OP(0);
 #endif
         break;
-      case 1: k_linearize<T, false><<<ogrid, TPB, 0, stream>>>(nch, chunk_cam.p, chunk_beg.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); break;
+      case 1: k_linearize<T, false><<<nb_pm, TPB, 0, stream>>>((int)No, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); break;
       case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
-      case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_chunk_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, sc, 0); break;
-      case 4: k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, sc, -1, 1.0, 5.0); break;
-      case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, cam_chunk_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, ogrid, chi2_partial.p, dscalars.p); break;
+      case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, 0.0, 1e30); break;
+      case 4: k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1); break;
+      case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, nb_pm, chi2_partial.p, dscalars.p); break;
       default: throw std::invalid_argument("diag_time: unknown kernel");
       }
     };
@@ -585,13 +651,16 @@ template <typename T> struct Engine final : EngineBase {
     return ms * 1e3 / reps;
   }
 
+  int last_solver = 0;
   int last_iters() {
     int it = 0;
-    GR_HIP(hipMemcpyAsync(&it, sc_i.p + sc_cap, sizeof(int), hipMemcpyDeviceToHost, stream));
+    const int *src = (last_solver == GR_SOLVER_PCG_SCHUR) ? sc_i.p + sc_cap : pcg_iters.p;
+    GR_HIP(hipMemcpyAsync(&it, src, sizeof(int), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));
     return it;
   }
   bool solver_solve_dev(int solver, int max_iter, double tol, double rej, T *x) {
+    last_solver = solver;
     switch (solver) {
     case GR_SOLVER_PCG_SCHUR: solve_pcg_schur(max_iter, tol, rej, x); return true;
     case GR_SOLVER_PCG: solve_pcg<false>(max_iter, tol, rej, x); return true;
@@ -642,7 +711,7 @@ template <typename T> struct Engine final : EngineBase {
       cnt = 2 * No;
       DevBuf<T> rpm; rpm.alloc(2 * (size_t)No);
       campack();
-      chi2_async(rpm.p, nullptr, 0.0);
+      wait_chi2(chi2_async(rpm.p, nullptr, 0.0));
       std::vector<T> h = rpm.download(stream), ho(2 * (size_t)No);
       for (int64_t o = 0; o < No; ++o) { ho[2 * o] = h[2 * (size_t)h_pm_of_orig[o]]; ho[2 * o + 1] = h[2 * (size_t)h_pm_of_orig[o] + 1]; }
       if (out) GR_HIP(hipMemcpy(out, ho.data(), ho.size() * sizeof(T), hipMemcpyDefault));
@@ -684,16 +753,18 @@ template <typename T> struct Engine final : EngineBase {
       GR_HIP(hipEventRecord(ev_a, stream));
       const bool solve_ok = solver_solve_dev(opt.solver, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, v_dx.p);
       GR_HIP(hipEventRecord(ev_b, stream));
-      backup();
-      apply_update_dev(v_dx.p);
-      // trial chi2 + compute_rho denominator (:20-47) in one kernel, one sync serves both
-      chi2_async(nullptr, v_dx.p, (double)mu);
-      double hs[2];
-      GR_HIP(hipMemcpyAsync(hs, dscalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+      apply_update_dev(v_dx.p, /*with_backup=*/true); // backup_parameters + apply_update fused
+      // trial chi2 + compute_rho denominator (:20-47) in one kernel; its last block mirrors the two
+      // sums into pinned host memory, so the host polls one word instead of memcpy + stream sync
+      const int seq = chi2_async(nullptr, v_dx.p, (double)mu);
       int it = 0;
-      GR_HIP(hipMemcpyAsync(&it, sc_i.p + sc_cap, sizeof(int), hipMemcpyDeviceToHost, stream));
-      GR_HIP(hipStreamSynchronize(stream));
+      if (opt.solver == GR_SOLVER_PCG_SCHUR) GR_HIP(hipMemcpyAsync(&it, sc_i.p + sc_cap, sizeof(int), hipMemcpyDeviceToHost, stream));
+      wait_chi2(seq);
+      if (opt.solver == GR_SOLVER_PCG_SCHUR) GR_HIP(hipStreamSynchronize(stream));
+      else it = h_seq[1];
+      const double hs[2] = {h_res[0], h_res[1]};
       float ms = 0;
+      (void)hipEventSynchronize(ev_b);
       (void)hipEventElapsedTime(&ms, ev_a, ev_b);
       st.solve_seconds += ms * 1e-3;
       st.pcg_iterations += it;

@@ -18,13 +18,8 @@
 // diagonal congruence H = D H^u D, b = D b^u is folded into the small
 // per-vertex matrices where it is needed.
 //
-// Parallelisation: ONE THREAD PER OBSERVATION everywhere (No is 4-7x the number
-// of points, and the chip wants >= 0.5 M threads).  Point-side sums are wave-level
-// segmented scans over the pm order (a point's observations are consecutive);
-// camera-side sums are wave reductions over cm-order chunks followed by a
-// fixed-order sum of the chunk partials.  The only float atomics left are the two
-// halves of a point whose observations straddle a wave boundary (commutative, so
-// still deterministic) and the slotted dot-product accumulators.
+// This file: shared helpers, the Schur-complement path (PCGSchurSolver) and the small
+// block inverses.  Linearisation, chi2 and the matrix-free PCG live in kernels_mf.hpp.
 #pragma once
 #include "bal_device.hpp"
 #include "common.hpp"
@@ -49,7 +44,7 @@ template <typename T> __device__ __forceinline__ void load_pack(const T *__restr
 // camera pack (+ optional x += dx .* s on the cameras first): Nc threads
 template <typename T>
 __global__ void k_campack(int Nc, T *__restrict__ cams, T *__restrict__ pack, const T *__restrict__ dx,
-                          const T *__restrict__ scales) {
+                          const T *__restrict__ scales, T *__restrict__ backup) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Nc) return;
   T cam[9], pk[PACK];
@@ -57,7 +52,11 @@ __global__ void k_campack(int Nc, T *__restrict__ cams, T *__restrict__ pack, co
   for (int i = 0; i < 9; ++i) cam[i] = cams[9 * c + i];
   if (dx) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { cam[i] += dx[9 * c + i] * scales[9 * c + i]; cams[9 * c + i] = cam[i]; }
+    for (int i = 0; i < 9; ++i) {
+      if (backup) backup[9 * c + i] = cam[i]; // Graph::backup_parameters fused (graph.hpp:302-309)
+      cam[i] += dx[9 * c + i] * scales[9 * c + i];
+      cams[9 * c + i] = cam[i];
+    }
   }
   make_campack(cam, pk);
 #pragma unroll
@@ -65,198 +64,16 @@ __global__ void k_campack(int Nc, T *__restrict__ cams, T *__restrict__ pack, co
 }
 
 // ---------------------------------------------------------------------------
-// Graph::linearize + Hessian::update_values (A4-A10 of SURVEY §8a): ONE pass over the
-// observations in CAMERA-major order, one wave per chunk (<= 128 observations of one
-// camera).  The camera pack is wave-uniform (scalar loads); the only divergent
-// accesses are the point gather and the per-observation scatter below — in
-// point-major order every lane would need its own 192-byte pack, and the 24 x 64
-// cache-line requests per wave were measured to dominate the kernel.
-//   camera side : 45 + 9 sums reduced across the wave (transpose-sum) -> cam_partial[ch][54]
-//   point side  : per-observation [w Jp^T Jp (6), -w Jp^T e (3)] -> g9[pm position][9]
-//                 (summed per point by k_linearize_finalize; consecutive in pm order)
-//   Hcp^u       : per-observation 9x3 block -> Hcp[pm position][27]  (Schur solvers only)
-//   chi2        : block partial
-template <typename T, bool WRITE_HCP>
-__global__ void __launch_bounds__(TPB)
-k_linearize(int nch, const int *__restrict__ chunk_cam, const int *__restrict__ chunk_beg,
-            const int *__restrict__ pt_cm, const int *__restrict__ pos_cm, const T *__restrict__ obs_cm,
-            const T *__restrict__ pts, const T *__restrict__ pack, int loss_kind, T loss_delta,
-            T *__restrict__ g9, T *__restrict__ Hcp, T *__restrict__ cam_partial,
-            double *__restrict__ chi2_partial) {
-  __shared__ double red[4];
-  const int lane = threadIdx.x & 63;
-  using V2 = typename Vec2T<T>::type;
-  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
-  double chi2 = 0.0;
-  if (ch < nch) {
-    const int c = __builtin_amdgcn_readfirstlane(chunk_cam[ch]);
-    T pk[PACK];
-    load_pack(pack, c, pk);
-    T acc[64];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) acc[i] = T(0);
-    const int beg = __builtin_amdgcn_readfirstlane(chunk_beg[ch]), end = __builtin_amdgcn_readfirstlane(chunk_beg[ch + 1]);
-    for (int j = beg + lane; j < end; j += 64) {
-      const int l = pt_cm[j];
-      const size_t a = (size_t)pos_cm[j];
-      const V2 o = reinterpret_cast<const V2 *>(obs_cm)[j];
-      T e0, e1, Jc[18], Jp[6];
-      bal_linearize(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], o.x, o.y, e0, e1, Jc, Jp);
-      const T raw = e0 * e0 + e1 * e1;
-      const T w = loss_drho(loss_kind, loss_delta, raw);
-      chi2 += (double)loss_rho(loss_kind, loss_delta, raw);
-      int k = 0;
-#pragma unroll
-      for (int col = 0; col < 9; ++col) {
-        const T wx = w * Jc[2 * col], wy = w * Jc[2 * col + 1];
-#pragma unroll
-        for (int row = 0; row <= col; ++row) acc[k++] += Jc[2 * row] * wx + Jc[2 * row + 1] * wy;
-        acc[45 + col] -= wx * e0 + wy * e1;
-      }
-      const T wp0x = w * Jp[0], wp0y = w * Jp[1], wp1x = w * Jp[2], wp1y = w * Jp[3], wp2x = w * Jp[4], wp2y = w * Jp[5];
-      T *g = g9 + 9 * a;
-      g[0] = wp0x * Jp[0] + wp0y * Jp[1];
-      g[1] = wp0x * Jp[2] + wp0y * Jp[3];
-      g[2] = wp0x * Jp[4] + wp0y * Jp[5];
-      g[3] = wp1x * Jp[2] + wp1y * Jp[3];
-      g[4] = wp1x * Jp[4] + wp1y * Jp[5];
-      g[5] = wp2x * Jp[4] + wp2y * Jp[5];
-      g[6] = -(wp0x * e0 + wp0y * e1);
-      g[7] = -(wp1x * e0 + wp1y * e1);
-      g[8] = -(wp2x * e0 + wp2y * e1);
-      if (WRITE_HCP) {
-        T *h = Hcp + 27 * a;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-          h[r] = Jc[2 * r] * wp0x + Jc[2 * r + 1] * wp0y;
-          h[r + 9] = Jc[2 * r] * wp1x + Jc[2 * r + 1] * wp1y;
-          h[r + 18] = Jc[2 * r] * wp2x + Jc[2 * r + 1] * wp2y;
-        }
-      }
-    }
-    const T tot = wave_transpose_sum<T, 64>(acc, lane);
-    if (lane < 54) cam_partial[54 * (size_t)ch + lane] = tot;
-  }
-  chi2 = block_sum_256(chi2, red);
-  if (threadIdx.x == 0) chi2_partial[blockIdx.x] = chi2;
-}
-
-// Finalise a linearisation:
-//   threads [0, 90 Nc)        fixed-order sum of the chunk partials -> Hcc^u, bc^u, camera scales
-//   threads [90 Nc, +Np)      one per point: sum of its observations' g9 -> Hll^u, bl^u, point scales
-//   block 0                   chi2 total
-// (column scales: graph.hpp:254-270)
-template <typename T>
-__global__ void __launch_bounds__(TPB)
-k_linearize_finalize(int Nc, int Np, int scale_system, const int *__restrict__ cam_chunk_ptr,
-                     const T *__restrict__ cam_partial, const int *__restrict__ pt_ptr,
-                     const T *__restrict__ g9, T *__restrict__ Hcc, T *__restrict__ bc, T *__restrict__ Hll,
-                     T *__restrict__ bl, T *__restrict__ scales, int n_partials,
-                     const double *__restrict__ chi2_partial, double *__restrict__ chi2_out) {
-  const unsigned t = blockIdx.x * TPB + threadIdx.x;
-  const unsigned ncam = 90u * (unsigned)Nc;
-  if (t < ncam) {
-    const unsigned c = t / 90u, e = t % 90u;
-    int idx;
-    unsigned row = 0, col = 0;
-    if (e < 81u) {
-      row = e % 9u; col = e / 9u;
-      const unsigned r = row < col ? row : col, cc = row < col ? col : row;
-      idx = (int)(cc * (cc + 1) / 2 + r);
-    } else idx = 45 + (int)(e - 81u);
-    T s = 0;
-    for (int ch = cam_chunk_ptr[c]; ch < cam_chunk_ptr[c + 1]; ++ch) s += cam_partial[54 * (size_t)ch + idx];
-    if (e < 81u) {
-      Hcc[81 * (size_t)c + e] = s;
-      if (row == col) scales[9 * c + row] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)s))) : T(1);
-    } else bc[9 * c + (e - 81u)] = s;
-  } else if (t < ncam + (unsigned)Np) {
-    const unsigned l = t - ncam;
-    T v[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) v[i] = T(0);
-    for (int a = pt_ptr[l]; a < pt_ptr[l + 1]; ++a) {
-      const T *g = g9 + 9 * (size_t)a;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) v[i] += g[i];
-    }
-    T *H = Hll + 9 * (size_t)l;
-    H[0] = v[0]; H[1] = v[1]; H[2] = v[2]; H[3] = v[1]; H[4] = v[3]; H[5] = v[4]; H[6] = v[2]; H[7] = v[4]; H[8] = v[5];
-    bl[3 * (size_t)l] = v[6]; bl[3 * (size_t)l + 1] = v[7]; bl[3 * (size_t)l + 2] = v[8];
-    T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
-    s[0] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[0]))) : T(1);
-    s[1] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1);
-    s[2] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1);
-  }
-  if (blockIdx.x == 0 && chi2_out) {
-    __shared__ double red[4];
-    double s = 0;
-    for (int k = threadIdx.x; k < n_partials; k += TPB) s += chi2_partial[k];
-    s = block_sum_256(s, red);
-    if (threadIdx.x == 0) *chi2_out = s;
-  }
-}
-
-// chi2 of a trial step (Graph::compute_error + Graph::chi2) fused with compute_rho's
-// denominator sum dx (mu dx + b) (levenberg_marquardt.hpp:34-41).  One thread per
-// observation in CAMERA-major order (neighbouring lanes share the camera pack);
-// dscal[0] = chi2, dscal[1] = rho denominator are produced by the last block to
-// finish (ticket), so no extra reduce launch.  res_out (optional) is indexed by pm position.
-template <typename T>
-__global__ void __launch_bounds__(TPB)
-k_chi2(int No, unsigned n, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
-       const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const T *__restrict__ pts,
-       const T *__restrict__ pack, int loss_kind, T loss_delta, const T *__restrict__ dx,
-       const T *__restrict__ bu, const T *__restrict__ scales, double mu, double *__restrict__ partial,
-       unsigned *__restrict__ ticket, double *__restrict__ dscal, T *__restrict__ res_out) {
-  __shared__ double red[4];
-  __shared__ bool last;
-  using V2 = typename Vec2T<T>::type;
-  double chi2 = 0, rho = 0;
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < No; j += gridDim.x * TPB) {
-    const int c = cam_cm[j], l = pt_cm[j];
-    const T *pk = pack + PACK * (size_t)c;
-    const V2 o = reinterpret_cast<const V2 *>(obs_cm)[j];
-    T e0, e1;
-    bal_residual(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], o.x, o.y, e0, e1);
-    chi2 += (double)loss_rho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
-    if (res_out) { const size_t a = (size_t)pos_cm[j]; res_out[2 * a] = e0; res_out[2 * a + 1] = e1; }
-  }
-  if (dx) {
-    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-      const T x = dx[i];
-      rho += (double)(x * ((T)mu * x + scales[i] * bu[i]));
-    }
-  }
-  chi2 = block_sum_256(chi2, red);
-  rho = block_sum_256(rho, red);
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(&partial[2 * blockIdx.x], chi2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&partial[2 * blockIdx.x + 1], rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned tk = atomicAdd(ticket, 1u);
-    last = (tk == gridDim.x - 1);
-  }
-  __syncthreads();
-  if (last) {
-    double s0 = 0, s1 = 0;
-    for (unsigned k = threadIdx.x; k < gridDim.x; k += TPB) {
-      s0 += __hip_atomic_load(&partial[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s1 += __hip_atomic_load(&partial[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    s0 = block_sum_256(s0, red);
-    s1 = block_sum_256(s1, red);
-    if (threadIdx.x == 0) { dscal[0] = s0; dscal[1] = s1; *ticket = 0u; }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // x += dx .* s     (ops/update.hpp:11-31 with additive update)
 template <typename T>
 __global__ void k_apply_update(unsigned n, T *__restrict__ x, const T *__restrict__ dx,
-                               const T *__restrict__ scales) {
+                               const T *__restrict__ scales, T *__restrict__ backup) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] += dx[i] * scales[i];
+  if (i < n) {
+    const T xo = x[i];
+    if (backup) backup[i] = xo;
+    x[i] = xo + dx[i] * scales[i];
+  }
 }
 
 // out = a .* b
@@ -740,217 +557,6 @@ k_pcgs_direction(int Nc, T *__restrict__ x, const T *__restrict__ xb, T *__restr
     sc.done[k + 1] = (fabs((double)rz_new) < tol) ? 1 : 0;
     sc.iters[0] = k + 1;
   }
-}
-
-// ===========================================================================
-// Matrix-free PCG (PCGSolver, solver/pcg.hpp:61-232)
-// ===========================================================================
-// Operator (J^T rho' J) applied to ps = s .* p with J RECOMPUTED from the camera
-// pack (the reference streams the stored J twice per iteration, pcg.hpp:143-163).
-// ONE pass in camera-major order, one wave per chunk:
-//   u = J ps, w = rho' u;   den += rho' |u|^2
-//   camera rows: Jc^T w reduced over the wave     -> op_partial[ch][9]
-//   point rows : per-observation Jp^T w           -> g3[pm position][3]
-// p.A.p = sum_obs rho' |J ps|^2 + mu p.D.p, so the dot product needs no second pass
-// over v2; scaling, damping and the chunk / per-point sums are applied by k_pcg_update.
-// VAR (diagnostic builds only, GR_DIAG): 1 = no g3 scatter, 2 = no point gather, 4 = no ps_l gather,
-// 8 = no Jacobian math, 16 = no wave reduction.  VAR = 0 is the product kernel.
-template <typename T, int VAR = 0>
-__global__ void __launch_bounds__(TPB)
-k_pcg_operator(int Nc, int nch, const int *__restrict__ chunk_cam, const int *__restrict__ chunk_beg,
-               const int *__restrict__ pt_cm, const int *__restrict__ pos_cm, const T *__restrict__ obs_cm,
-               const T *__restrict__ pts, const T *__restrict__ pack, int loss_kind, T loss_delta,
-               const T *__restrict__ ps, T *__restrict__ g3, T *__restrict__ op_partial, PcgScalars sc, int k) {
-  if (sc.done[k]) return;
-  if (slot_sum(sc.rz, k) == 0.0) return;
-  __shared__ double red[4];
-  const int lane = threadIdx.x & 63;
-  using V2 = typename Vec2T<T>::type;
-  const size_t pose_dim = 9 * (size_t)Nc;
-  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
-  double den = 0;
-  if (ch < nch) {
-    const int c = __builtin_amdgcn_readfirstlane(chunk_cam[ch]);
-    T pk[PACK], pc[9];
-    load_pack(pack, c, pk);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) pc[i] = ps[9 * (size_t)c + i];
-    T acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = T(0);
-    const int beg = __builtin_amdgcn_readfirstlane(chunk_beg[ch]), end = __builtin_amdgcn_readfirstlane(chunk_beg[ch + 1]);
-    for (int j = beg + lane; j < end; j += 64) {
-      const int l = pt_cm[j];
-      const size_t a = (size_t)pos_cm[j];
-      const T *pl = ps + pose_dim + 3 * (size_t)((VAR & 4) ? (j & 1023) : l);
-      const V2 o = reinterpret_cast<const V2 *>(obs_cm)[j];
-      T e0, e1, Jc[18], Jp[6];
-      const size_t lp = (VAR & 2) ? (size_t)(j & 1023) : (size_t)l;
-      if (VAR & 8) {
-        e0 = o.x; e1 = o.y;
-#pragma unroll
-        for (int i = 0; i < 18; ++i) Jc[i] = pts[3 * lp + (i % 3)] + pk[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Jp[i] = pts[3 * lp + (i % 3)] - pk[i];
-      } else
-        bal_linearize(pk, pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2], o.x, o.y, e0, e1, Jc, Jp);
-      const T w = loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
-      T u0 = Jp[0] * pl[0] + Jp[2] * pl[1] + Jp[4] * pl[2];
-      T u1 = Jp[1] * pl[0] + Jp[3] * pl[1] + Jp[5] * pl[2];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { u0 += Jc[2 * i] * pc[i]; u1 += Jc[2 * i + 1] * pc[i]; }
-      den += (double)(w * (u0 * u0 + u1 * u1));
-      u0 *= w; u1 *= w;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) acc[i] += Jc[2 * i] * u0 + Jc[2 * i + 1] * u1;
-      T *g = g3 + 3 * ((VAR & 1) ? (size_t)j : a);
-      g[0] = Jp[0] * u0 + Jp[1] * u1;
-      g[1] = Jp[2] * u0 + Jp[3] * u1;
-      g[2] = Jp[4] * u0 + Jp[5] * u1;
-    }
-    const T tot = (VAR & 16) ? acc[lane & 7] + acc[8] : wave_transpose_sum<T, 16>(acc, lane);
-    if ((lane & 3) == 0 && (lane >> 2) < 9) op_partial[9 * (size_t)ch + (lane >> 2)] = tot;
-  }
-  den = block_sum_256(den, red);
-  if (threadIdx.x == 0) slot_add(sc.den, k, den);
-}
-
-// z' = Minv r for the full system (9x9 camera blocks then 3x3 point blocks).
-// MODE 0 (init): r = s .* b^u, x = 0.
-// MODE 1: v2 = s .* (operator sums) + mu d .* p formed on the fly (camera rows: fixed-order
-//         sum of the chunk partials), x_backup = x; x += alpha p; r -= alpha v2.
-// Accumulates rr[slot] = r.r and rz[slot] = r.z'  (the reference applies the
-// preconditioner to r/||r||, pcg.hpp:108-118,171-183; Minv is linear, so
-// z = z'/||r|| and r.z = (r.z')/||r|| are formed from these two sums).
-// 252 scalars per block: 28 cameras or 84 points; camera blocks first.
-template <typename T, int MODE, bool IDENTITY>
-__global__ void __launch_bounds__(TPB)
-k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ scales, T *__restrict__ x,
-             T *__restrict__ xb, T *__restrict__ r, T *__restrict__ zt, const T *__restrict__ p,
-             const T *__restrict__ g3, const int *__restrict__ pt_ptr, const T *__restrict__ op_partial,
-             const int *__restrict__ cam_chunk_ptr, const T *__restrict__ diag, double mu, int use_identity,
-             const T *__restrict__ MinvC, const T *__restrict__ MinvP, PcgScalars sc, int k) {
-  T alpha = 0;
-  if (MODE == 1) {
-    if (sc.done[k]) return;
-    const double rzs = slot_sum(sc.rz, k);
-    if (rzs == 0.0) return;
-    // reference rz = r.z with z = Minv (r/||r||)  ->  (r.z')/||r||
-    const T rz = (T)rzs * (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(sc.rr, k)));
-    // p.A.p = sum_obs rho'|J ps|^2 + mu p.D.p
-    const T den = (T)(slot_sum(sc.den, k) + mu * slot_sum(sc.pdp, k));
-    alpha = rz / den;
-  }
-  __shared__ double red[4];
-  __shared__ T rs[TPB];
-  const unsigned pose_dim = 9u * (unsigned)Nc, n = pose_dim + 3u * (unsigned)Np;
-  const unsigned cam_blocks = (pose_dim + 251u) / 252u;
-  unsigned t;
-  bool is_cam;
-  if (blockIdx.x < cam_blocks) { t = blockIdx.x * 252u + threadIdx.x; is_cam = true; }
-  else { t = pose_dim + (blockIdx.x - cam_blocks) * 252u + threadIdx.x; is_cam = false; }
-  const bool on = threadIdx.x < 252 && (is_cam ? t < pose_dim : t < n);
-  T rn = 0;
-  if (on) {
-    if (MODE == 0) { rn = scales[t] * bu[t]; x[t] = T(0); }
-    else {
-      T raw;
-      if (is_cam) {
-        const unsigned c = t / 9u, i = t % 9u;
-        raw = 0;
-        for (int ch = cam_chunk_ptr[c]; ch < cam_chunk_ptr[c + 1]; ++ch) raw += op_partial[9 * (size_t)ch + i];
-      } else {
-        const unsigned q0 = t - pose_dim, l = q0 / 3u, i = q0 % 3u;
-        raw = 0;
-        for (int a = pt_ptr[l]; a < pt_ptr[l + 1]; ++a) raw += g3[3 * (size_t)a + i];
-      }
-      const T pv = p[t];
-      const T v2 = scales[t] * raw + (use_identity ? (T)mu * pv : (T)mu * diag[t] * pv);
-      const T xo = x[t];
-      xb[t] = xo;
-      x[t] = alpha * pv + xo;
-      rn = -alpha * v2 + r[t];
-    }
-    r[t] = rn;
-  }
-  rs[threadIdx.x] = rn;
-  __syncthreads();
-  double prr = 0, prz = 0;
-  if (on) {
-    T s = 0;
-    if (IDENTITY) s = rn;
-    else if (is_cam) {
-      const T *M = MinvC + 81 * (size_t)(t / 9u);
-      const int row = (int)(t % 9u);
-      const T *rc = rs + (threadIdx.x / 9) * 9;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) s += M[row + 9 * q] * rc[q];
-    } else {
-      const unsigned q0 = t - pose_dim;
-      const T *M = MinvP + 9 * (size_t)(q0 / 3u);
-      const int row = (int)(q0 % 3u);
-      const T *rc = rs + (threadIdx.x / 3) * 3;
-      s = M[row] * rc[0] + M[row + 3] * rc[1] + M[row + 6] * rc[2];
-    }
-    zt[t] = s;
-    prr = (double)(rn * rn);
-    prz = (double)(rn * s);
-  }
-  const int slot = (MODE == 0) ? 0 : k + 1;
-  prr = block_sum_256(prr, red);
-  if (threadIdx.x == 0) slot_add(sc.rr, slot, prr);
-  prz = block_sum_256(prz, red);
-  if (threadIdx.x == 0) slot_add(sc.rz, slot, prz);
-}
-
-// Direction kernel of the matrix-free PCG (pcg.hpp:108-127 for k = -1, :184-217 otherwise).
-// sc.rz[k] holds r.z' and sc.rr[k] holds r.r; the reference's rz is rz'/sqrt(rr).
-// Also: ps = s .* p for the operator and pdp[k+1] = p.D.p.
-template <typename T>
-__global__ void __launch_bounds__(TPB)
-k_pcg_direction(unsigned n, unsigned pose_dim, T *__restrict__ x, const T *__restrict__ xb, T *__restrict__ p,
-                T *__restrict__ ps, const T *__restrict__ zt, const T *__restrict__ scales,
-                const T *__restrict__ diag, int use_identity, PcgScalars sc, int k,
-                double tol, double rejection_ratio) {
-  __shared__ double red[4];
-  const unsigned t = blockIdx.x * TPB + threadIdx.x;
-  const bool first = (t == 0);
-  T pn = 0;
-  bool wrote = false;
-  if (k < 0) { // p = z = z'/||r||
-    const T scale = (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(sc.rr, 0)));
-    if (t < n) { pn = scale * zt[t]; wrote = true; }
-  } else {
-    const double rz0 = sc.rz0[k];
-    if (sc.done[k]) { if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; } return; }
-    const double rzs = slot_sum(sc.rz, k);
-    if (rzs == 0.0) { if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; } return; }
-    const T scale_old = (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(sc.rr, k)));
-    const T scale_new = (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(sc.rr, k + 1)));
-    const T rz = (T)rzs * scale_old;
-    const T rz_new = (T)slot_sum(sc.rz, k + 1) * scale_new;
-    const bool reject = (fabs((double)rz_new) > rejection_ratio * rz0) || (rz_new != rz_new);
-    if (reject) {
-      if (t < n) x[t] = xb[t];
-      if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; sc.iters[0] = k + 1; }
-      return;
-    }
-    const T beta = rz_new / rz;
-    if (t < n) { pn = beta * p[t] + scale_new * zt[t]; wrote = true; }
-    if (first) {
-      sc.rz0[k + 1] = fmin(rz0, fabs((double)rz_new));
-      sc.done[k + 1] = (fabs((double)rz_new) < tol) ? 1 : 0;
-      sc.iters[0] = k + 1;
-    }
-  }
-  double pdp = 0;
-  if (wrote) {
-    p[t] = pn;
-    ps[t] = scales[t] * pn;
-    pdp = use_identity ? (double)(pn * pn) : (double)(diag[t] * pn * pn);
-  }
-  pdp = block_sum_256(pdp, red);
-  if (threadIdx.x == 0) slot_add(sc.pdp, k + 1, pdp);
 }
 
 } // namespace gr

@@ -1,0 +1,540 @@
+// Linearisation, chi2 and the matrix-free PCG (PCGSolver) kernels — gfx950.
+//
+// All per-observation work runs in CAMERA-major ("cm") order, ONE observation per
+// lane, flat indexing: the four per-observation streams (camera id, point id,
+// pm position, observation) are coalesced and independent, so a lane's
+// dependent-load chain is two deep (indices -> pack/point gather -> math).
+// Neighbouring lanes share the camera, so the 192-byte camera pack costs one
+// cache line per wave instead of 64 (in point-major order it was the
+// bottleneck), and camera-side sums are wave reductions.  A wave that straddles
+// a camera boundary simply reduces once per distinct camera.
+//   segment = (wave, camera) pair; seg id = cam_seg_ptr[c] + (wave - (cam_ptr[c] >> 6))
+// Point-side sums: each lane stores its contribution at the observation's pm
+// position; a point's contributions are then consecutive and are summed in
+// fixed order by the consumer kernel (no atomics, bitwise reproducible).
+//
+// Dot products: every block publishes its partial sums, the LAST block to finish
+// (ticket) adds them in fixed order and writes the PCG control record of the
+// iteration, so consumers read one small struct instead of re-reducing, and the
+// host can stop enqueueing iterations as soon as the loop has left (pinned flag).
+#pragma once
+#include "kernels.hpp"
+
+namespace gr {
+
+constexpr int TICKET_GROUPS = 64;
+
+// Control record of PCG iteration k (device memory, one per iteration).
+struct PcgCtl {
+  double rz;      // r.z at the start of iteration k (reference definition: z = Minv r/||r||)
+  double rscale;  // 1/||r|| at the start of iteration k
+  double pdp;     // p.D.p of the current direction (D = clamped diagonal or I)
+  double alpha;   // rz / p.A.p             (operator's last block)
+  double beta;    // rz_new / rz            (update's last block)
+  double rz0;     // running min of |rz_new| before iteration k
+  int done;       // loop already left before iteration k
+  int reject;     // iteration k rejected its step (restore x)
+  int stepped;    // iteration k executed an update
+  int pad;
+};
+
+struct PcgState {
+  PcgCtl *ctl;          // [cap]
+  double *partial;      // [max_grid * 2] block partials of the running kernel
+  unsigned *ticket;     // [1], returns to 0 after every kernel
+  int *iters;           // [1] number of executed iterations
+  volatile int *hflag;  // pinned host memory [cap]: 1 = iteration finished, 2 = loop left
+  volatile int *hiters; // pinned host mirror of iters
+};
+
+__global__ void k_pcg_state_init(PcgState st, int cap) {
+  for (int i = threadIdx.x; i < cap; i += blockDim.x) {
+    PcgCtl c{};
+    c.rz0 = __builtin_inf();
+    st.ctl[i] = c;
+  }
+  if (threadIdx.x == 0) st.iters[0] = 0;
+  for (int i = threadIdx.x; i < 1 + TICKET_GROUPS; i += blockDim.x) st.ticket[i] = 0u;
+}
+
+// Every block calls this once (all threads).  v0/v1: thread 0's block sums.  Returns true
+// in ALL threads of the last block, after which tot0/tot1 (thread 0 only) hold the grid totals
+// summed in fixed block order.
+// Visibility: write-through (sc1) stores, drained vmcnt, then a RELAXED ticket; the last block
+// reads with sc1 loads (cdna_hip_programming.md G16, form R1) — an agent release fence per
+// block would write back the whole L2 thousands of times.
+// Contention: returning atomics on ONE address serialise at 15-30 ns each, i.e. 40-90 us for
+// a 2,600-block grid (measured), so the ticket is two-level: 64 group counters (blockIdx % 64),
+// and only the block that completes its group touches the top counter.
+// ticket[0] = top counter, ticket[1 + g] = group counters; all return to 0.
+__device__ __forceinline__ bool grid_sum2(double v0, double v1, double *partial, unsigned *ticket,
+                                          double *red, double &tot0, double &tot1) {
+  __shared__ bool s_last;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partial[2 * blockIdx.x], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partial[2 * blockIdx.x + 1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned g = blockIdx.x % TICKET_GROUPS;
+    const unsigned ngroups = gridDim.x < TICKET_GROUPS ? gridDim.x : TICKET_GROUPS;
+    const unsigned in_group = (gridDim.x - g + TICKET_GROUPS - 1) / TICKET_GROUPS;
+    bool last = false;
+    const unsigned tk = __hip_atomic_fetch_add(&ticket[1 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == in_group - 1) {
+      __hip_atomic_store(&ticket[1 + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned top = __hip_atomic_fetch_add(&ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (top == ngroups - 1);
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return false;
+  double s0 = 0, s1 = 0;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += TPB) {
+    s0 += __hip_atomic_load(&partial[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s1 += __hip_atomic_load(&partial[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  s0 = block_sum_256(s0, red);
+  s1 = block_sum_256(s1, red);
+  if (threadIdx.x == 0) { tot0 = s0; tot1 = s1; __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// Graph::linearize + Hessian::update_values (A4-A10 of SURVEY §8a), one launch.
+//   camera side : 45 + 9 sums per (wave, camera) segment -> cam_partial[seg][54]
+//   point side  : per-observation [w Jp^T Jp (6), -w Jp^T e (3)] -> g9[pm position][9]
+//   Hcp^u       : per-observation 9x3 block -> Hcp[pm position][27]  (Schur solvers only)
+//   chi2        : block partial (summed in fixed order by k_linearize_finalize)
+template <typename T, bool WRITE_HCP>
+__global__ void __launch_bounds__(TPB)
+k_linearize(int No, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
+            const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
+            const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
+            int loss_kind, T loss_delta, T *__restrict__ g9, T *__restrict__ Hcp, T *__restrict__ cam_partial,
+            double *__restrict__ chi2_partial) {
+  __shared__ double red[4];
+  using V2 = typename Vec2T<T>::type;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * TPB + threadIdx.x;
+  const bool valid = j < No;
+  double chi2 = 0.0;
+  int c = -1, seg = 0;
+  T Jc[18], e0 = 0, e1 = 0, w = 0;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) Jc[i] = T(0);
+  if (valid) {
+    c = cam_cm[j];
+    const int l = pt_cm[j];
+    const size_t a = (size_t)pos_cm[j];
+    const V2 o = reinterpret_cast<const V2 *>(obs_cm)[j];
+    seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
+    T pk[PACK], Jp[6];
+    load_pack(pack, c, pk);
+    bal_linearize(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], o.x, o.y, e0, e1, Jc, Jp);
+    const T raw = e0 * e0 + e1 * e1;
+    w = loss_drho(loss_kind, loss_delta, raw);
+    chi2 = (double)loss_rho(loss_kind, loss_delta, raw);
+    const T wp0x = w * Jp[0], wp0y = w * Jp[1], wp1x = w * Jp[2], wp1y = w * Jp[3], wp2x = w * Jp[4], wp2y = w * Jp[5];
+    T *g = g9 + 9 * a;
+    g[0] = wp0x * Jp[0] + wp0y * Jp[1];
+    g[1] = wp0x * Jp[2] + wp0y * Jp[3];
+    g[2] = wp0x * Jp[4] + wp0y * Jp[5];
+    g[3] = wp1x * Jp[2] + wp1y * Jp[3];
+    g[4] = wp1x * Jp[4] + wp1y * Jp[5];
+    g[5] = wp2x * Jp[4] + wp2y * Jp[5];
+    g[6] = -(wp0x * e0 + wp0y * e1);
+    g[7] = -(wp1x * e0 + wp1y * e1);
+    g[8] = -(wp2x * e0 + wp2y * e1);
+    if (WRITE_HCP) {
+      T *h = Hcp + 27 * a;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        h[r] = Jc[2 * r] * wp0x + Jc[2 * r + 1] * wp0y;
+        h[r + 9] = Jc[2 * r] * wp1x + Jc[2 * r + 1] * wp1y;
+        h[r + 18] = Jc[2 * r] * wp2x + Jc[2 * r + 1] * wp2y;
+      }
+    }
+  }
+  // camera-side reduction, once per distinct camera in the wave (usually one)
+  unsigned long long remaining = __ballot(valid);
+  while (remaining) {
+    const int leader = __builtin_ctzll(remaining);
+    const int cl = __shfl(c, leader, 64);
+    const int segl = __shfl(seg, leader, 64);
+    const bool mine = valid && c == cl;
+    const T wm = mine ? w : T(0);
+    T acc[64];
+    int k = 0;
+#pragma unroll
+    for (int col = 0; col < 9; ++col) {
+      const T wx = wm * Jc[2 * col], wy = wm * Jc[2 * col + 1];
+#pragma unroll
+      for (int row = 0; row <= col; ++row) acc[k++] = Jc[2 * row] * wx + Jc[2 * row + 1] * wy;
+      acc[45 + col] = -(wx * e0 + wy * e1);
+    }
+#pragma unroll
+    for (int i = 54; i < 64; ++i) acc[i] = T(0);
+    const T tot = wave_transpose_sum<T, 64>(acc, lane);
+    if (lane < 54) cam_partial[54 * (size_t)segl + lane] = tot;
+    remaining &= ~__ballot(mine);
+  }
+  chi2 = block_sum_256(chi2, red);
+  if (threadIdx.x == 0) chi2_partial[blockIdx.x] = chi2;
+}
+
+// Finalise a linearisation:
+//   threads [0, 90 Nc)        fixed-order sum of the segment partials -> Hcc^u, bc^u, camera scales
+//   threads [90 Nc, +Np)      one per point: sum of its observations' g9 -> Hll^u, bl^u, point scales
+//   block 0                   chi2 total
+// (column scales: graph.hpp:254-270)
+template <typename T>
+__global__ void __launch_bounds__(TPB)
+k_linearize_finalize(int Nc, int Np, int scale_system, const int *__restrict__ cam_seg_ptr,
+                     const T *__restrict__ cam_partial, const int *__restrict__ pt_ptr,
+                     const T *__restrict__ g9, T *__restrict__ Hcc, T *__restrict__ bc, T *__restrict__ Hll,
+                     T *__restrict__ bl, T *__restrict__ scales, int n_partials,
+                     const double *__restrict__ chi2_partial, double *__restrict__ chi2_out) {
+  const unsigned t = blockIdx.x * TPB + threadIdx.x;
+  const unsigned ncam = 90u * (unsigned)Nc;
+  if (t < ncam) {
+    const unsigned c = t / 90u, e = t % 90u;
+    int idx;
+    unsigned row = 0, col = 0;
+    if (e < 81u) {
+      row = e % 9u; col = e / 9u;
+      const unsigned r = row < col ? row : col, cc = row < col ? col : row;
+      idx = (int)(cc * (cc + 1) / 2 + r);
+    } else idx = 45 + (int)(e - 81u);
+    T s = 0;
+    for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) s += cam_partial[54 * (size_t)sg + idx];
+    if (e < 81u) {
+      Hcc[81 * (size_t)c + e] = s;
+      if (row == col) scales[9 * c + row] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)s))) : T(1);
+    } else bc[9 * c + (e - 81u)] = s;
+  } else if (t < ncam + (unsigned)Np) {
+    const unsigned l = t - ncam;
+    T v[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = T(0);
+    for (int a = pt_ptr[l]; a < pt_ptr[l + 1]; ++a) {
+      const T *g = g9 + 9 * (size_t)a;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v[i] += g[i];
+    }
+    T *H = Hll + 9 * (size_t)l;
+    H[0] = v[0]; H[1] = v[1]; H[2] = v[2]; H[3] = v[1]; H[4] = v[3]; H[5] = v[4]; H[6] = v[2]; H[7] = v[4]; H[8] = v[5];
+    bl[3 * (size_t)l] = v[6]; bl[3 * (size_t)l + 1] = v[7]; bl[3 * (size_t)l + 2] = v[8];
+    T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
+    s[0] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[0]))) : T(1);
+    s[1] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1);
+    s[2] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1);
+  }
+  if (blockIdx.x == 0 && chi2_out) {
+    __shared__ double red[4];
+    double s = 0;
+    for (int k = threadIdx.x; k < n_partials; k += TPB) s += chi2_partial[k];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) *chi2_out = s;
+  }
+}
+
+// chi2 of a trial step (Graph::compute_error + Graph::chi2) fused with compute_rho's
+// denominator sum dx (mu dx + b) (levenberg_marquardt.hpp:34-41).  One observation per
+// thread (cm order); the first ceil(n/256) blocks also take one vector element each.
+// The last block writes dscal[0] = chi2, dscal[1] = rho denominator (fixed-order sums)
+// and mirrors them to pinned host memory (hres[0..1], then hres_seq = seq).
+template <typename T>
+__global__ void __launch_bounds__(TPB)
+k_chi2(int No, unsigned n, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
+       const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const T *__restrict__ pts,
+       const T *__restrict__ pack, int loss_kind, T loss_delta, const T *__restrict__ dx,
+       const T *__restrict__ bu, const T *__restrict__ scales, double mu, double *__restrict__ partial,
+       unsigned *__restrict__ ticket, double *__restrict__ dscal, volatile double *hres, volatile int *hres_seq,
+       int seq, T *__restrict__ res_out) {
+  __shared__ double red[4];
+  using V2 = typename Vec2T<T>::type;
+  double chi2 = 0, rho = 0;
+  const int j = blockIdx.x * TPB + threadIdx.x;
+  if (j < No) {
+    const int c = cam_cm[j], l = pt_cm[j];
+    const T *pk = pack + PACK * (size_t)c;
+    const V2 o = reinterpret_cast<const V2 *>(obs_cm)[j];
+    T e0, e1;
+    bal_residual(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], o.x, o.y, e0, e1);
+    chi2 = (double)loss_rho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
+    if (res_out) { const size_t a = (size_t)pos_cm[j]; res_out[2 * a] = e0; res_out[2 * a + 1] = e1; }
+  }
+  if (dx && (unsigned)j < n) {
+    const T x = dx[j];
+    rho = (double)(x * ((T)mu * x + scales[j] * bu[j]));
+  }
+  chi2 = block_sum_256(chi2, red);
+  rho = block_sum_256(rho, red);
+  double t0, t1;
+  if (grid_sum2(chi2, rho, partial, ticket, red, t0, t1) && threadIdx.x == 0) {
+    dscal[0] = t0; dscal[1] = t1;
+    if (hres) {
+      hres[0] = t0; hres[1] = t1;
+      __threadfence_system();
+      *hres_seq = seq;
+    }
+  }
+}
+
+// ===========================================================================
+// Matrix-free PCG (PCGSolver, solver/pcg.hpp:61-232)
+// ===========================================================================
+// Operator (J^T rho' J) applied to ps = s .* p with J RECOMPUTED from the camera
+// pack (the reference streams the stored J twice per iteration, pcg.hpp:143-163):
+//   u = J ps, w = rho' u;   den = sum rho' |u|^2   (p.A.p = den + mu p.D.p: no pass over v2)
+//   camera rows: Jc^T w reduced per (wave, camera) segment -> op_partial[seg][9]
+//   point rows : per-observation Jp^T w                    -> g3[pm position][3]
+// The last block turns the dot product into alpha (ctl[k].alpha).
+// VAR (diagnostic builds only, GR_DIAG): 1 no g3 scatter, 2 no point gather, 4 no ps_l gather,
+// 8 no Jacobian math, 16 no wave reduction.  VAR = 0 is the product kernel.
+template <typename T, int VAR = 0>
+__global__ void __launch_bounds__(TPB)
+k_pcg_operator(int No, int Nc, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
+               const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
+               const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
+               int loss_kind, T loss_delta, const T *__restrict__ ps, T *__restrict__ g3,
+               T *__restrict__ op_partial, double mu, PcgState st, int k) {
+  const PcgCtl ck = st.ctl[k];
+  if (ck.done || ck.rz == 0.0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      PcgCtl nx = st.ctl[k + 1];
+      nx.done = 1; nx.rz0 = ck.rz0;
+      st.ctl[k + 1] = nx;
+      st.hflag[k] = 2;
+      __threadfence_system();
+    }
+    return;
+  }
+  __shared__ double red[4];
+  using V2 = typename Vec2T<T>::type;
+  const int lane = threadIdx.x & 63;
+  const size_t pose_dim = 9 * (size_t)Nc;
+  const int j = blockIdx.x * TPB + threadIdx.x;
+  const bool valid = j < No;
+  double den = 0;
+  int c = -1, seg = 0;
+  T acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = T(0);
+  if (valid) {
+    c = cam_cm[j];
+    const int l = pt_cm[j];
+    const size_t a = (size_t)pos_cm[j];
+    const V2 o = reinterpret_cast<const V2 *>(obs_cm)[j];
+    seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
+    T pk[PACK], pc[9];
+    load_pack(pack, c, pk);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) pc[i] = ps[9 * (size_t)c + i];
+    const T *pl = ps + pose_dim + 3 * (size_t)((VAR & 4) ? (j & 1023) : l);
+    const size_t lp = (VAR & 2) ? (size_t)(j & 1023) : (size_t)l;
+    T e0, e1, Jc[18], Jp[6];
+    if (VAR & 8) {
+      e0 = o.x; e1 = o.y;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) Jc[i] = pts[3 * lp + (i % 3)] + pk[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Jp[i] = pts[3 * lp + (i % 3)] - pk[i];
+    } else
+      bal_linearize(pk, pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2], o.x, o.y, e0, e1, Jc, Jp);
+    const T w = loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
+    T u0 = Jp[0] * pl[0] + Jp[2] * pl[1] + Jp[4] * pl[2];
+    T u1 = Jp[1] * pl[0] + Jp[3] * pl[1] + Jp[5] * pl[2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { u0 += Jc[2 * i] * pc[i]; u1 += Jc[2 * i + 1] * pc[i]; }
+    den = (double)(w * (u0 * u0 + u1 * u1));
+    u0 *= w; u1 *= w;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = Jc[2 * i] * u0 + Jc[2 * i + 1] * u1;
+    T *g = g3 + 3 * ((VAR & 1) ? (size_t)j : a);
+    g[0] = Jp[0] * u0 + Jp[1] * u1;
+    g[1] = Jp[2] * u0 + Jp[3] * u1;
+    g[2] = Jp[4] * u0 + Jp[5] * u1;
+  }
+  if (!(VAR & 16)) {
+    unsigned long long remaining = __ballot(valid);
+    while (remaining) {
+      const int leader = __builtin_ctzll(remaining);
+      const int cl = __shfl(c, leader, 64);
+      const int segl = __shfl(seg, leader, 64);
+      const bool mine = valid && c == cl;
+      T m[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m[i] = mine ? acc[i] : T(0);
+      const T tot = wave_transpose_sum<T, 16>(m, lane);
+      if ((lane & 3) == 0 && (lane >> 2) < 9) op_partial[9 * (size_t)segl + (lane >> 2)] = tot;
+      remaining &= ~__ballot(mine);
+    }
+  }
+  den = block_sum_256(den, red);
+  double t0, t1;
+  if (grid_sum2(den, 0.0, st.partial, st.ticket, red, t0, t1) && threadIdx.x == 0)
+    st.ctl[k].alpha = ck.rz / (t0 + mu * ck.pdp);
+}
+
+// x / r / z' update of the matrix-free PCG.
+//   blocks [0, cam_blocks): 252 camera scalars (28 cameras) each — fixed-order sum of the
+//                           segment partials, 9x9 block-Jacobi through LDS
+//   other blocks          : one POINT per thread — fixed-order sum of its observations' g3,
+//                           3x3 block-Jacobi in registers
+// MODE 0 (init): r = s .* b^u, x = 0.      MODE 1: v2 = s .* sums + mu d .* p,
+//   x_backup = x; x += alpha p; r -= alpha v2.
+// z' = Minv r; the last block forms rr = r.r, rz' = r.z' and (MODE 1) takes the loop decisions
+// of pcg.hpp:184-217 into ctl[k] / ctl[k+1] (the reference applies the preconditioner to
+// r/||r||; Minv is linear so z = z'/||r|| and r.z = rz'/||r||).
+template <typename T, int MODE, bool IDENTITY>
+__global__ void __launch_bounds__(TPB)
+k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ scales, T *__restrict__ x,
+             T *__restrict__ xb, T *__restrict__ r, T *__restrict__ zt, const T *__restrict__ p,
+             const T *__restrict__ g3, const int *__restrict__ pt_ptr, const T *__restrict__ op_partial,
+             const int *__restrict__ cam_seg_ptr, const T *__restrict__ diag, double mu, int use_identity,
+             const T *__restrict__ MinvC, const T *__restrict__ MinvP, PcgState st, int k, double tol,
+             double rejection_ratio) {
+  PcgCtl ck;
+  T alpha = 0;
+  if (MODE == 1) {
+    ck = st.ctl[k];
+    if (ck.done || ck.rz == 0.0) return;
+    alpha = (T)ck.alpha;
+  }
+  __shared__ double red[4];
+  __shared__ T rs[TPB];
+  const unsigned pose_dim = 9u * (unsigned)Nc;
+  const unsigned cam_blocks = (pose_dim + 251u) / 252u;
+  double prr = 0, prz = 0;
+  if (blockIdx.x < cam_blocks) {
+    const unsigned t = blockIdx.x * 252u + threadIdx.x;
+    const bool on = threadIdx.x < 252 && t < pose_dim;
+    T rn = 0;
+    if (on) {
+      if (MODE == 0) { rn = scales[t] * bu[t]; x[t] = T(0); }
+      else {
+        const unsigned c = t / 9u, i = t % 9u;
+        T raw = 0;
+        for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) raw += op_partial[9 * (size_t)sg + i];
+        const T pv = p[t];
+        const T v2 = scales[t] * raw + (use_identity ? (T)mu * pv : (T)mu * diag[t] * pv);
+        const T xo = x[t];
+        xb[t] = xo;
+        x[t] = alpha * pv + xo;
+        rn = -alpha * v2 + r[t];
+      }
+      r[t] = rn;
+    }
+    rs[threadIdx.x] = rn;
+    __syncthreads();
+    if (on) {
+      T s = 0;
+      if (IDENTITY) s = rn;
+      else {
+        const T *M = MinvC + 81 * (size_t)(t / 9u);
+        const int row = (int)(t % 9u);
+        const T *rc = rs + (threadIdx.x / 9) * 9;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) s += M[row + 9 * q] * rc[q];
+      }
+      zt[t] = s;
+      prr = (double)(rn * rn);
+      prz = (double)(rn * s);
+    }
+  } else {
+    const unsigned l = (blockIdx.x - cam_blocks) * TPB + threadIdx.x;
+    if (l < (unsigned)Np) {
+      const size_t t = (size_t)pose_dim + 3 * (size_t)l;
+      T rn[3];
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { rn[i] = scales[t + i] * bu[t + i]; x[t + i] = T(0); }
+      } else {
+        T raw[3] = {T(0), T(0), T(0)};
+        for (int a = pt_ptr[l]; a < pt_ptr[l + 1]; ++a) {
+          const T *g = g3 + 3 * (size_t)a;
+          raw[0] += g[0]; raw[1] += g[1]; raw[2] += g[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const T pv = p[t + i];
+          const T v2 = scales[t + i] * raw[i] + (use_identity ? (T)mu * pv : (T)mu * diag[t + i] * pv);
+          const T xo = x[t + i];
+          xb[t + i] = xo;
+          x[t + i] = alpha * pv + xo;
+          rn[i] = -alpha * v2 + r[t + i];
+        }
+      }
+      const T *M = MinvP + 9 * (size_t)l;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        r[t + i] = rn[i];
+        const T s = IDENTITY ? rn[i] : M[i] * rn[0] + M[i + 3] * rn[1] + M[i + 6] * rn[2];
+        zt[t + i] = s;
+        prr += (double)(rn[i] * rn[i]);
+        prz += (double)(rn[i] * s);
+      }
+    }
+  }
+  prr = block_sum_256(prr, red);
+  prz = block_sum_256(prz, red);
+  double rr, rzp;
+  if (grid_sum2(prr, prz, st.partial, st.ticket, red, rr, rzp) && threadIdx.x == 0) {
+    const T rscale = (T)(1.0 / (double)(T)sqrt((double)(T)rr));
+    const T rz_new = (T)rzp * rscale;
+    if (MODE == 0) {
+      PcgCtl c0 = st.ctl[0];
+      c0.rz = (double)rz_new; c0.rscale = (double)rscale; c0.rz0 = __builtin_inf(); c0.done = 0;
+      st.ctl[0] = c0;
+    } else {
+      PcgCtl nx = st.ctl[k + 1];
+      const bool reject = (fabs((double)rz_new) > rejection_ratio * ck.rz0) || (rz_new != rz_new);
+      st.ctl[k].reject = reject ? 1 : 0;
+      st.ctl[k].stepped = 1;
+      st.ctl[k].beta = (double)(rz_new / (T)ck.rz);
+      nx.rz = (double)rz_new; nx.rscale = (double)rscale;
+      nx.rz0 = reject ? ck.rz0 : fmin(ck.rz0, fabs((double)rz_new));
+      nx.done = (reject || fabs((double)rz_new) < tol) ? 1 : 0;
+      st.ctl[k + 1] = nx;
+      st.iters[0] = k + 1;
+      *st.hiters = k + 1;
+      st.hflag[k] = nx.done ? 2 : 1;
+      __threadfence_system();
+    }
+  }
+}
+
+// Direction kernel (pcg.hpp:108-127 for k = -1, :198-217 otherwise): restore x on a
+// rejected step, else p = beta p + z'/||r||; ps = s .* p; the last block stores p.D.p.
+template <typename T>
+__global__ void __launch_bounds__(TPB)
+k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__restrict__ p,
+                T *__restrict__ ps, const T *__restrict__ zt, const T *__restrict__ scales,
+                const T *__restrict__ diag, int use_identity, PcgState st, int k) {
+  __shared__ double red[4];
+  const unsigned t = blockIdx.x * TPB + threadIdx.x;
+  T pn = 0;
+  bool wrote = false;
+  if (k < 0) {
+    const T scale = (T)st.ctl[0].rscale;
+    if (t < n) { pn = scale * zt[t]; wrote = true; }
+  } else {
+    const PcgCtl ck = st.ctl[k];
+    if (ck.done || !ck.stepped) return;
+    if (ck.reject) { if (t < n) x[t] = xb[t]; return; }
+    const T beta = (T)ck.beta, scale_new = (T)st.ctl[k + 1].rscale;
+    if (t < n) { pn = beta * p[t] + scale_new * zt[t]; wrote = true; }
+  }
+  double pdp = 0;
+  if (wrote) {
+    p[t] = pn;
+    ps[t] = scales[t] * pn;
+    pdp = use_identity ? (double)(pn * pn) : (double)(diag[t] * pn * pn);
+  }
+  pdp = block_sum_256(pdp, red);
+  double t0, t1;
+  if (grid_sum2(pdp, 0.0, st.partial, st.ticket, red, t0, t1) && threadIdx.x == 0) st.ctl[k + 1].pdp = t0;
+}
+
+} // namespace gr

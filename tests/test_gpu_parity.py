@@ -183,3 +183,26 @@ def test_duplicate_edge_is_rejected():
     with pytest.raises(ga._lib.GraphiteError) as e:
         ga.BalProblem(prob.cameras, prob.points, prob.obs, ci, pi)
     assert e.value.status == 4
+
+
+def test_against_committed_golden_fixtures():
+    """HIP path vs tests/golden/*.npz (oracle regression pins, see tests/golden/make_golden.py)."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(gold, "schur_2x3_f64.npz"))
+    gpu = ga.BalProblem(g["cameras"], g["points"], g["obs"], g["cam_idx"], g["pt_idx"], dtype=np.float64)
+    gpu.solver_update_structure(ga.SOLVER_PCG_SCHUR)
+    gpu.linearize()
+    gpu.solver_update_values(ga.SOLVER_PCG_SCHUR)
+    gpu.solver_set_damping(ga.SOLVER_PCG_SCHUR, 0.0)
+    gpu.schur_update_values()
+    for name, key in (("residuals", "res"), ("scales", "scales"), ("b", "b"), ("Hcc", "Hcc"), ("Hcp", "Hcp"),
+                      ("Hll", "Hll"), ("S", "S"), ("b_schur", "b_schur")):
+        assert relerr(gpu.get(name), g[key]) < 1e-12, name
+    gpu.close()
+    g = np.load(os.path.join(gold, "mini50_lm_f64.npz"))
+    for solver, key in ((ga.SOLVER_PCG_SCHUR, "chi2_pcg_schur"), (ga.SOLVER_PCG, "chi2_pcg")):
+        gpu = ga.BalProblem(g["cameras"], g["points"], g["obs"], g["cam_idx"], g["pt_idx"], dtype=np.float64)
+        ct, _, _ = gpu.levenberg_marquardt(solver=solver, iterations=8)
+        assert np.allclose(ct, g[key], rtol=1e-8), key
+        gpu.close()
