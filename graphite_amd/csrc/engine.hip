@@ -70,6 +70,7 @@ template <typename T> struct Engine final : EngineBase {
   std::vector<int> h_pt_ptr, h_cam_pm, h_pt_pm, h_cam_ptr, h_pt_cm, h_pos_cm, h_pm_of_orig;
   std::vector<int> h_chunk_cam, h_chunk_beg, h_cam_chunk_ptr, h_cam_seg_ptr;
   int nch = 0, nb_pm = 0, nseg = 0;
+  int num_cu = 256, grid_obs = 0, grid_vec = 0; // persistent grids
   // Schur structure (lazy)
   bool schur_ready = false;
   int64_t nnzb = 0, nprod = 0;
@@ -83,7 +84,8 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<unsigned> ticket;
   DevBuf<int> cam_seg_ptr;
   // matrix-free PCG control
-  DevBuf<PcgCtl> ctl;
+  DevBuf<double> ctl; // PCG slot accumulators + loop state
+  DevBuf<int> ctl_i;
   DevBuf<double> grid_partial;
   DevBuf<int> pcg_iters;
   int ctl_cap = 0;
@@ -140,6 +142,13 @@ template <typename T> struct Engine final : EngineBase {
     bu.alloc(n); bc.p = bu.p; bl.p = bu.p + pose_dim;
     scales.alloc(n);
     nb_pm = cdiv(No, TPB);
+    {
+      hipDeviceProp_t prop;
+      GR_HIP(hipGetDeviceProperties(&prop, dev));
+      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    grid_obs = std::min(nb_pm, num_cu * 4);           // 104-154 VGPR kernels: 3-4 waves / SIMD
+    grid_vec = std::min(cdiv(n, TPB), num_cu * 8);   // light vector kernels
     n_chi2_blocks = std::min(cdiv(No, TPB), 1024);
     chi2_partial.alloc(std::max<size_t>(nb_pm, 2 * (size_t)cdiv(std::max<size_t>(No, n), TPB)) + 64);
     dscalars.alloc(4);
@@ -397,13 +406,13 @@ template <typename T> struct Engine final : EngineBase {
       const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 9.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
       Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)));
       if (write_hcp)
-        k_linearize<T, true><<<nb_pm, TPB, 0, stream>>>((int)No, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p);
+        k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p);
       else
-        k_linearize<T, false><<<nb_pm, TPB, 0, stream>>>((int)No, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
+        k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
     }
     {
       Scope sc(this, "linearize_finalize", 9.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
-      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, nb_pm, chi2_partial.p, dscalars.p);
+      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p);
     }
     hcp_valid = write_hcp;
   }
@@ -422,7 +431,7 @@ template <typename T> struct Engine final : EngineBase {
   int chi2_async(T *res_out, const T *dx, double mu) {
     const int seq = ++seq_counter;
     Scope sc(this, "chi2", No * (2 * w() + 8) + (24.0 * Nc + 3.0 * Np) * w() + (dx ? 3.0 * n * w() : 0.0), No * 40.0);
-    k_chi2<T><<<cdiv(std::max<size_t>(No, n), TPB), TPB, 0, stream>>>((int)No, (unsigned)n, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, h_res, h_seq, seq, res_out);
+    k_chi2<T><<<grid_obs, TPB, 0, stream>>>((int)No, (unsigned)n, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, h_res, h_seq, seq, res_out);
     return seq;
   }
   void wait_chi2(int seq) {
@@ -564,12 +573,14 @@ template <typename T> struct Engine final : EngineBase {
   }
   void ensure_ctl(int max_iter) {
     const int cap = max_iter + 2;
-    if (cap > ctl_cap) { ctl_cap = cap; ctl.alloc(cap); }
+    if (cap > ctl_cap) { ctl_cap = cap; ctl.alloc((4 * (size_t)NS + 1) * cap); ctl_i.alloc(cap); }
     alloc_pinned(cap);
   }
   PcgState pcg_state() {
     PcgState st;
-    st.ctl = ctl.p; st.partial = grid_partial.p; st.ticket = ticket.p; st.iters = pcg_iters.p; st.hflag = h_flag; st.hiters = h_seq + 1;
+    const size_t blk = (size_t)ctl_cap * NS;
+    st.rzp = ctl.p; st.rr = ctl.p + blk; st.den = ctl.p + 2 * blk; st.pdp = ctl.p + 3 * blk; st.rz0 = ctl.p + 4 * blk;
+    st.done = ctl_i.p; st.iters = pcg_iters.p; st.hflag = h_flag; st.hiters = h_seq + 1;
     return st;
   }
   // PCGSolver::solve (solver/pcg.hpp:61-232).  Scalars stay on the device; the host only
@@ -582,21 +593,21 @@ template <typename T> struct Engine final : EngineBase {
     for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
     h_seq[1] = 0;
     k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
-    const int ublocks = cdiv(pose_dim, 252) + cdiv(Np, TPB);
-    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, tol, rej);
-    k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1);
+    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, TPB), num_cu * 8);
+    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
+    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1, 0.0, 1e30);
     auto enqueue = [&](int k) {
       {
         Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
-        k_pcg_operator<T><<<nb_pm, TPB, 0, stream>>>((int)No, (int)Nc, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k);
+        k_pcg_operator<T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k);
       }
       {
         Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 12.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
-        k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, tol, rej);
+        k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k);
       }
       {
         Scope s3(this, "pcg_direction", 7.0 * n * sizeof(T), 6.0 * n);
-        k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, k);
+        k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, k, tol, rej);
       }
     };
     if (max_iter > 0) enqueue(0);
@@ -616,27 +627,27 @@ template <typename T> struct Engine final : EngineBase {
     ensure_ctl(4);
     PcgState st = pcg_state();
     const int ui = 0;
-    const int ublocks = cdiv(pose_dim, 252) + cdiv(Np, TPB);
+    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, TPB), num_cu * 8);
     k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
-    k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, 0.0, 1e30);
-    k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1);
+    k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
+    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1, 0.0, 1e30);
     hipEvent_t a, b;
     GR_HIP(hipEventCreate(&a)); GR_HIP(hipEventCreate(&b));
     auto launch = [&] {
       switch (which) {
       case 0:
-#define GR_OP(V) k_pcg_operator<T, V><<<nb_pm, TPB, 0, stream>>>((int)No, (int)Nc, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0)
+#define GR_OP(V) k_pcg_operator<T, V><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0)
 #ifdef GR_DIAG
         switch (variant) { case 1: GR_OP(1); break; case 2: GR_OP(2); break; case 4: GR_OP(4); break; case 7: GR_OP(7); break; case 8: GR_OP(8); break; case 15: GR_OP(15); break; case 16: GR_OP(16); break; case 31: GR_OP(31); break; default: GR_OP(0); }
 #else
         GR_OP(0);
 #endif
         break;
-      case 1: k_linearize<T, false><<<nb_pm, TPB, 0, stream>>>((int)No, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); break;
+      case 1: k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); break;
       case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
-      case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, 0.0, 1e30); break;
-      case 4: k_pcg_direction<T><<<cdiv(n, TPB), TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1); break;
-      case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, nb_pm, chi2_partial.p, dscalars.p); break;
+      case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0); break;
+      case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1, 0.0, 1e30); break;
+      case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p); break;
       default: throw std::invalid_argument("diag_time: unknown kernel");
       }
     };

@@ -24,37 +24,37 @@ namespace gr {
 
 constexpr int TICKET_GROUPS = 64;
 
-// Control record of PCG iteration k (device memory, one per iteration).
-struct PcgCtl {
-  double rz;      // r.z at the start of iteration k (reference definition: z = Minv r/||r||)
-  double rscale;  // 1/||r|| at the start of iteration k
-  double pdp;     // p.D.p of the current direction (D = clamped diagonal or I)
-  double alpha;   // rz / p.A.p             (operator's last block)
-  double beta;    // rz_new / rz            (update's last block)
-  double rz0;     // running min of |rz_new| before iteration k
-  int done;       // loop already left before iteration k
-  int reject;     // iteration k rejected its step (restore x)
-  int stepped;    // iteration k executed an update
-  int pad;
-};
-
+// PCG scalars never visit the host.  Iteration k owns slot k of every array:
+//   rzp[k] r.z' and rr[k] r.r at the START of iteration k (z' = Minv r; the reference's
+//          r.z with z = Minv (r/||r||) is rzp / sqrt(rr)),  den[k] sum_obs rho'|J ps|^2,
+//          pdp[k] p.D.p of the direction used by iteration k           — NS partial sums each,
+//          filled with fire-and-forget atomics and re-summed by every consumer wave
+//          (a last-block/ticket reduction was measured to add ~10 us of tail to every kernel);
+//   rz0[k] running min of |rz_new| before iteration k, done[k] loop left before iteration k
+//          — written by thread 0 of the direction kernel of iteration k-1.
 struct PcgState {
-  PcgCtl *ctl;          // [cap]
-  double *partial;      // [max_grid * 2] block partials of the running kernel
-  unsigned *ticket;     // [1], returns to 0 after every kernel
-  int *iters;           // [1] number of executed iterations
-  volatile int *hflag;  // pinned host memory [cap]: 1 = iteration finished, 2 = loop left
-  volatile int *hiters; // pinned host mirror of iters
+  double *rzp, *rr, *den, *pdp; // [cap][NS]
+  double *rz0;                  // [cap]
+  int *done;                    // [cap]
+  int *iters;                   // [1]
+  volatile int *hflag;          // pinned host memory [cap]: 1 = iteration finished, 2 = loop left
+  volatile int *hiters;         // pinned host mirror of iters
 };
 
 __global__ void k_pcg_state_init(PcgState st, int cap) {
-  for (int i = threadIdx.x; i < cap; i += blockDim.x) {
-    PcgCtl c{};
-    c.rz0 = __builtin_inf();
-    st.ctl[i] = c;
-  }
+  for (int i = threadIdx.x; i < cap * NS; i += blockDim.x) { st.rzp[i] = 0.0; st.rr[i] = 0.0; st.den[i] = 0.0; st.pdp[i] = 0.0; }
+  for (int i = threadIdx.x; i < cap; i += blockDim.x) { st.done[i] = 0; st.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
   if (threadIdx.x == 0) st.iters[0] = 0;
-  for (int i = threadIdx.x; i < 1 + TICKET_GROUPS; i += blockDim.x) st.ticket[i] = 0u;
+}
+
+// scalars of iteration k as every wave derives them (all lanes must call)
+struct PcgIter { double rzp, rscale, rz; };
+__device__ __forceinline__ PcgIter pcg_iter(const PcgState &st, int k) {
+  PcgIter it;
+  it.rzp = slot_sum(st.rzp, k);
+  it.rscale = 1.0 / sqrt(slot_sum(st.rr, k));
+  it.rz = it.rzp * it.rscale;
+  return it;
 }
 
 // Every block calls this once (all threads).  v0/v1: thread 0's block sums.  Returns true
@@ -105,9 +105,13 @@ __device__ __forceinline__ bool grid_sum2(double v0, double v1, double *partial,
 //   point side  : per-observation [w Jp^T Jp (6), -w Jp^T e (3)] -> g9[pm position][9]
 //   Hcp^u       : per-observation 9x3 block -> Hcp[pm position][27]  (Schur solvers only)
 //   chi2        : block partial (summed in fixed order by k_linearize_finalize)
+// Persistent form: gridDim.x = min(ntiles, CUs x 4) blocks, each walks a CONTIGUOUS range of
+// 256-observation tiles and prefetches the next tile's index streams before it computes the
+// current one, so the per-block fixed costs (launch, tail, chi2 partial) are amortised and the
+// index -> gather dependency is off the critical path.
 template <typename T, bool WRITE_HCP>
 __global__ void __launch_bounds__(TPB)
-k_linearize(int No, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
+k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
             const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
             const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
             int loss_kind, T loss_delta, T *__restrict__ g9, T *__restrict__ Hcp, T *__restrict__ cam_partial,
@@ -115,68 +119,79 @@ k_linearize(int No, const int *__restrict__ cam_cm, const int *__restrict__ pt_c
   __shared__ double red[4];
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * TPB + threadIdx.x;
-  const bool valid = j < No;
+  const int t0 = (int)((long long)blockIdx.x * ntiles / gridDim.x);
+  const int t1 = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
   double chi2 = 0.0;
-  int c = -1, seg = 0;
-  T Jc[18], e0 = 0, e1 = 0, w = 0;
+  int j = t0 * TPB + threadIdx.x;
+  bool valid = t0 < t1 && j < No;
+  int c_n = -1, l_n = 0, a_n = 0;
+  V2 o_n{};
+  if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm[j]; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
+  for (int t = t0; t < t1; ++t) {
+    const int c = c_n, l = l_n;
+    const size_t a = (size_t)a_n;
+    const V2 o = o_n;
+    const int jn = j + TPB;
+    const bool validn = (t + 1 < t1) && jn < No;
+    if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm[jn]; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
+    int seg = 0;
+    T Jc[18], e0 = 0, e1 = 0, w = 0;
 #pragma unroll
-  for (int i = 0; i < 18; ++i) Jc[i] = T(0);
-  if (valid) {
-    c = cam_cm[j];
-    const int l = pt_cm[j];
-    const size_t a = (size_t)pos_cm[j];
-    const V2 o = reinterpret_cast<const V2 *>(obs_cm)[j];
-    seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
-    T pk[PACK], Jp[6];
-    load_pack(pack, c, pk);
-    bal_linearize(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], o.x, o.y, e0, e1, Jc, Jp);
-    const T raw = e0 * e0 + e1 * e1;
-    w = loss_drho(loss_kind, loss_delta, raw);
-    chi2 = (double)loss_rho(loss_kind, loss_delta, raw);
-    const T wp0x = w * Jp[0], wp0y = w * Jp[1], wp1x = w * Jp[2], wp1y = w * Jp[3], wp2x = w * Jp[4], wp2y = w * Jp[5];
-    T *g = g9 + 9 * a;
-    g[0] = wp0x * Jp[0] + wp0y * Jp[1];
-    g[1] = wp0x * Jp[2] + wp0y * Jp[3];
-    g[2] = wp0x * Jp[4] + wp0y * Jp[5];
-    g[3] = wp1x * Jp[2] + wp1y * Jp[3];
-    g[4] = wp1x * Jp[4] + wp1y * Jp[5];
-    g[5] = wp2x * Jp[4] + wp2y * Jp[5];
-    g[6] = -(wp0x * e0 + wp0y * e1);
-    g[7] = -(wp1x * e0 + wp1y * e1);
-    g[8] = -(wp2x * e0 + wp2y * e1);
-    if (WRITE_HCP) {
-      T *h = Hcp + 27 * a;
+    for (int i = 0; i < 18; ++i) Jc[i] = T(0);
+    if (valid) {
+      seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
+      T pk[PACK], Jp[6];
+      load_pack(pack, c, pk);
+      bal_linearize(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], o.x, o.y, e0, e1, Jc, Jp);
+      const T raw = e0 * e0 + e1 * e1;
+      w = loss_drho(loss_kind, loss_delta, raw);
+      chi2 += (double)loss_rho(loss_kind, loss_delta, raw);
+      const T wp0x = w * Jp[0], wp0y = w * Jp[1], wp1x = w * Jp[2], wp1y = w * Jp[3], wp2x = w * Jp[4], wp2y = w * Jp[5];
+      T *g = g9 + 9 * a;
+      g[0] = wp0x * Jp[0] + wp0y * Jp[1];
+      g[1] = wp0x * Jp[2] + wp0y * Jp[3];
+      g[2] = wp0x * Jp[4] + wp0y * Jp[5];
+      g[3] = wp1x * Jp[2] + wp1y * Jp[3];
+      g[4] = wp1x * Jp[4] + wp1y * Jp[5];
+      g[5] = wp2x * Jp[4] + wp2y * Jp[5];
+      g[6] = -(wp0x * e0 + wp0y * e1);
+      g[7] = -(wp1x * e0 + wp1y * e1);
+      g[8] = -(wp2x * e0 + wp2y * e1);
+      if (WRITE_HCP) {
+        T *h = Hcp + 27 * a;
 #pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        h[r] = Jc[2 * r] * wp0x + Jc[2 * r + 1] * wp0y;
-        h[r + 9] = Jc[2 * r] * wp1x + Jc[2 * r + 1] * wp1y;
-        h[r + 18] = Jc[2 * r] * wp2x + Jc[2 * r + 1] * wp2y;
+        for (int r = 0; r < 9; ++r) {
+          h[r] = Jc[2 * r] * wp0x + Jc[2 * r + 1] * wp0y;
+          h[r + 9] = Jc[2 * r] * wp1x + Jc[2 * r + 1] * wp1y;
+          h[r + 18] = Jc[2 * r] * wp2x + Jc[2 * r + 1] * wp2y;
+        }
       }
     }
-  }
-  // camera-side reduction, once per distinct camera in the wave (usually one)
-  unsigned long long remaining = __ballot(valid);
-  while (remaining) {
-    const int leader = __builtin_ctzll(remaining);
-    const int cl = __shfl(c, leader, 64);
-    const int segl = __shfl(seg, leader, 64);
-    const bool mine = valid && c == cl;
-    const T wm = mine ? w : T(0);
-    T acc[64];
-    int k = 0;
+    // camera-side reduction, once per distinct camera in the wave (usually one)
+    unsigned long long remaining = __ballot(valid);
+    while (remaining) {
+      const int leader = __builtin_ctzll(remaining);
+      const int cl = __shfl(c, leader, 64);
+      const int segl = __shfl(seg, leader, 64);
+      const bool mine = valid && c == cl;
+      const T wm = mine ? w : T(0);
+      T acc[64];
+      int kk = 0;
 #pragma unroll
-    for (int col = 0; col < 9; ++col) {
-      const T wx = wm * Jc[2 * col], wy = wm * Jc[2 * col + 1];
+      for (int col = 0; col < 9; ++col) {
+        const T wx = wm * Jc[2 * col], wy = wm * Jc[2 * col + 1];
 #pragma unroll
-      for (int row = 0; row <= col; ++row) acc[k++] = Jc[2 * row] * wx + Jc[2 * row + 1] * wy;
-      acc[45 + col] = -(wx * e0 + wy * e1);
+        for (int row = 0; row <= col; ++row) acc[kk++] = Jc[2 * row] * wx + Jc[2 * row + 1] * wy;
+        acc[45 + col] = -(wx * e0 + wy * e1);
+      }
+#pragma unroll
+      for (int i = 54; i < 64; ++i) acc[i] = T(0);
+      const T tot = wave_transpose_sum<T, 64>(acc, lane);
+      if (lane < 54) cam_partial[54 * (size_t)segl + lane] = tot;
+      remaining &= ~__ballot(mine);
     }
-#pragma unroll
-    for (int i = 54; i < 64; ++i) acc[i] = T(0);
-    const T tot = wave_transpose_sum<T, 64>(acc, lane);
-    if (lane < 54) cam_partial[54 * (size_t)segl + lane] = tot;
-    remaining &= ~__ballot(mine);
+    valid = validn;
+    j = jn;
   }
   chi2 = block_sum_256(chi2, red);
   if (threadIdx.x == 0) chi2_partial[blockIdx.x] = chi2;
@@ -254,19 +269,21 @@ k_chi2(int No, unsigned n, const int *__restrict__ cam_cm, const int *__restrict
   __shared__ double red[4];
   using V2 = typename Vec2T<T>::type;
   double chi2 = 0, rho = 0;
-  const int j = blockIdx.x * TPB + threadIdx.x;
-  if (j < No) {
+  const int stride = gridDim.x * TPB;
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < No; j += stride) {
     const int c = cam_cm[j], l = pt_cm[j];
     const T *pk = pack + PACK * (size_t)c;
     const V2 o = reinterpret_cast<const V2 *>(obs_cm)[j];
     T e0, e1;
     bal_residual(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], o.x, o.y, e0, e1);
-    chi2 = (double)loss_rho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
+    chi2 += (double)loss_rho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
     if (res_out) { const size_t a = (size_t)pos_cm[j]; res_out[2 * a] = e0; res_out[2 * a + 1] = e1; }
   }
-  if (dx && (unsigned)j < n) {
-    const T x = dx[j];
-    rho = (double)(x * ((T)mu * x + scales[j] * bu[j]));
+  if (dx) {
+    for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < n; i += (unsigned)stride) {
+      const T x = dx[i];
+      rho += (double)(x * ((T)mu * x + scales[i] * bu[i]));
+    }
   }
   chi2 = block_sum_256(chi2, red);
   rho = block_sum_256(rho, red);
@@ -289,126 +306,127 @@ k_chi2(int No, unsigned n, const int *__restrict__ cam_cm, const int *__restrict
 //   u = J ps, w = rho' u;   den = sum rho' |u|^2   (p.A.p = den + mu p.D.p: no pass over v2)
 //   camera rows: Jc^T w reduced per (wave, camera) segment -> op_partial[seg][9]
 //   point rows : per-observation Jp^T w                    -> g3[pm position][3]
-// The last block turns the dot product into alpha (ctl[k].alpha).
 // VAR (diagnostic builds only, GR_DIAG): 1 no g3 scatter, 2 no point gather, 4 no ps_l gather,
 // 8 no Jacobian math, 16 no wave reduction.  VAR = 0 is the product kernel.
 template <typename T, int VAR = 0>
 __global__ void __launch_bounds__(TPB)
-k_pcg_operator(int No, int Nc, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
+k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
                const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
                const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
                int loss_kind, T loss_delta, const T *__restrict__ ps, T *__restrict__ g3,
                T *__restrict__ op_partial, double mu, PcgState st, int k) {
-  const PcgCtl ck = st.ctl[k];
-  if (ck.done || ck.rz == 0.0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      PcgCtl nx = st.ctl[k + 1];
-      nx.done = 1; nx.rz0 = ck.rz0;
-      st.ctl[k + 1] = nx;
-      st.hflag[k] = 2;
-      __threadfence_system();
-    }
-    return;
-  }
+  if (st.done[k]) return;                      // direction(k-1) already told the host
+  if (slot_sum(st.rzp, k) == 0.0) return;      // rz == 0: the direction kernel of this iteration closes the loop
   __shared__ double red[4];
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
   const size_t pose_dim = 9 * (size_t)Nc;
-  const int j = blockIdx.x * TPB + threadIdx.x;
-  const bool valid = j < No;
+  const int t0 = (int)((long long)blockIdx.x * ntiles / gridDim.x);
+  const int t1 = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
   double den = 0;
-  int c = -1, seg = 0;
-  T acc[16];
+  int j = t0 * TPB + threadIdx.x;
+  bool valid = t0 < t1 && j < No;
+  int c_n = -1, l_n = 0, a_n = 0;
+  V2 o_n{};
+  if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm[j]; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
+  for (int t = t0; t < t1; ++t) {
+    const int c = c_n, l = l_n;
+    const size_t a = (size_t)a_n;
+    const V2 o = o_n;
+    const int jn = j + TPB;
+    const bool validn = (t + 1 < t1) && jn < No;
+    if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm[jn]; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
+    int seg = 0;
+    T acc[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = T(0);
-  if (valid) {
-    c = cam_cm[j];
-    const int l = pt_cm[j];
-    const size_t a = (size_t)pos_cm[j];
-    const V2 o = reinterpret_cast<const V2 *>(obs_cm)[j];
-    seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
-    T pk[PACK], pc[9];
-    load_pack(pack, c, pk);
+    for (int i = 0; i < 16; ++i) acc[i] = T(0);
+    if (valid) {
+      seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
+      T pk[PACK], pc[9];
+      load_pack(pack, c, pk);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) pc[i] = ps[9 * (size_t)c + i];
-    const T *pl = ps + pose_dim + 3 * (size_t)((VAR & 4) ? (j & 1023) : l);
-    const size_t lp = (VAR & 2) ? (size_t)(j & 1023) : (size_t)l;
-    T e0, e1, Jc[18], Jp[6];
-    if (VAR & 8) {
-      e0 = o.x; e1 = o.y;
+      for (int i = 0; i < 9; ++i) pc[i] = ps[9 * (size_t)c + i];
+      const T *pl = ps + pose_dim + 3 * (size_t)((VAR & 4) ? (j & 1023) : l);
+      const size_t lp = (VAR & 2) ? (size_t)(j & 1023) : (size_t)l;
+      T e0, e1, Jc[18], Jp[6];
+      if (VAR & 8) {
+        e0 = o.x; e1 = o.y;
 #pragma unroll
-      for (int i = 0; i < 18; ++i) Jc[i] = pts[3 * lp + (i % 3)] + pk[i];
+        for (int i = 0; i < 18; ++i) Jc[i] = pts[3 * lp + (i % 3)] + pk[i];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) Jp[i] = pts[3 * lp + (i % 3)] - pk[i];
-    } else
-      bal_linearize(pk, pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2], o.x, o.y, e0, e1, Jc, Jp);
-    const T w = loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
-    T u0 = Jp[0] * pl[0] + Jp[2] * pl[1] + Jp[4] * pl[2];
-    T u1 = Jp[1] * pl[0] + Jp[3] * pl[1] + Jp[5] * pl[2];
+        for (int i = 0; i < 6; ++i) Jp[i] = pts[3 * lp + (i % 3)] - pk[i];
+      } else
+        bal_linearize(pk, pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2], o.x, o.y, e0, e1, Jc, Jp);
+      const T w = loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
+      T u0 = Jp[0] * pl[0] + Jp[2] * pl[1] + Jp[4] * pl[2];
+      T u1 = Jp[1] * pl[0] + Jp[3] * pl[1] + Jp[5] * pl[2];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { u0 += Jc[2 * i] * pc[i]; u1 += Jc[2 * i + 1] * pc[i]; }
-    den = (double)(w * (u0 * u0 + u1 * u1));
-    u0 *= w; u1 *= w;
+      for (int i = 0; i < 9; ++i) { u0 += Jc[2 * i] * pc[i]; u1 += Jc[2 * i + 1] * pc[i]; }
+      den += (double)(w * (u0 * u0 + u1 * u1));
+      u0 *= w; u1 *= w;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) acc[i] = Jc[2 * i] * u0 + Jc[2 * i + 1] * u1;
-    T *g = g3 + 3 * ((VAR & 1) ? (size_t)j : a);
-    g[0] = Jp[0] * u0 + Jp[1] * u1;
-    g[1] = Jp[2] * u0 + Jp[3] * u1;
-    g[2] = Jp[4] * u0 + Jp[5] * u1;
-  }
-  if (!(VAR & 16)) {
-    unsigned long long remaining = __ballot(valid);
-    while (remaining) {
-      const int leader = __builtin_ctzll(remaining);
-      const int cl = __shfl(c, leader, 64);
-      const int segl = __shfl(seg, leader, 64);
-      const bool mine = valid && c == cl;
-      T m[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) m[i] = mine ? acc[i] : T(0);
-      const T tot = wave_transpose_sum<T, 16>(m, lane);
-      if ((lane & 3) == 0 && (lane >> 2) < 9) op_partial[9 * (size_t)segl + (lane >> 2)] = tot;
-      remaining &= ~__ballot(mine);
+      for (int i = 0; i < 9; ++i) acc[i] = Jc[2 * i] * u0 + Jc[2 * i + 1] * u1;
+      T *g = g3 + 3 * ((VAR & 1) ? (size_t)j : a);
+      g[0] = Jp[0] * u0 + Jp[1] * u1;
+      g[1] = Jp[2] * u0 + Jp[3] * u1;
+      g[2] = Jp[4] * u0 + Jp[5] * u1;
     }
+    if (!(VAR & 16)) {
+      unsigned long long remaining = __ballot(valid);
+      while (remaining) {
+        const int leader = __builtin_ctzll(remaining);
+        const int cl = __shfl(c, leader, 64);
+        const int segl = __shfl(seg, leader, 64);
+        const bool mine = valid && c == cl;
+        T m[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = mine ? acc[i] : T(0);
+        const T tot = wave_transpose_sum<T, 16>(m, lane);
+        if ((lane & 3) == 0 && (lane >> 2) < 9) op_partial[9 * (size_t)segl + (lane >> 2)] = tot;
+        remaining &= ~__ballot(mine);
+      }
+    }
+    valid = validn;
+    j = jn;
   }
   den = block_sum_256(den, red);
-  double t0, t1;
-  if (grid_sum2(den, 0.0, st.partial, st.ticket, red, t0, t1) && threadIdx.x == 0)
-    st.ctl[k].alpha = ck.rz / (t0 + mu * ck.pdp);
+  if (threadIdx.x == 0) slot_add(st.den, k, den);
 }
 
 // x / r / z' update of the matrix-free PCG.
-//   blocks [0, cam_blocks): 252 camera scalars (28 cameras) each — fixed-order sum of the
-//                           segment partials, 9x9 block-Jacobi through LDS
-//   other blocks          : one POINT per thread — fixed-order sum of its observations' g3,
-//                           3x3 block-Jacobi in registers
+// Persistent blocks walk contiguous ranges of
+//   camera tiles: 252 camera scalars (28 cameras) — fixed-order sum of the segment partials,
+//                 9x9 block-Jacobi through LDS
+//   point tiles : one POINT per thread — fixed-order sum of its observations' g3,
+//                 3x3 block-Jacobi in registers
 // MODE 0 (init): r = s .* b^u, x = 0.      MODE 1: v2 = s .* sums + mu d .* p,
 //   x_backup = x; x += alpha p; r -= alpha v2.
-// z' = Minv r; the last block forms rr = r.r, rz' = r.z' and (MODE 1) takes the loop decisions
-// of pcg.hpp:184-217 into ctl[k] / ctl[k+1] (the reference applies the preconditioner to
-// r/||r||; Minv is linear so z = z'/||r|| and r.z = rz'/||r||).
+// z' = Minv r; accumulates rr = r.r and rzp = r.z' (the reference applies the preconditioner to
+// r/||r||; Minv is linear so z = z'/||r|| and r.z = rzp/||r||).
 template <typename T, int MODE, bool IDENTITY>
 __global__ void __launch_bounds__(TPB)
 k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ scales, T *__restrict__ x,
              T *__restrict__ xb, T *__restrict__ r, T *__restrict__ zt, const T *__restrict__ p,
              const T *__restrict__ g3, const int *__restrict__ pt_ptr, const T *__restrict__ op_partial,
              const int *__restrict__ cam_seg_ptr, const T *__restrict__ diag, double mu, int use_identity,
-             const T *__restrict__ MinvC, const T *__restrict__ MinvP, PcgState st, int k, double tol,
-             double rejection_ratio) {
-  PcgCtl ck;
+             const T *__restrict__ MinvC, const T *__restrict__ MinvP, PcgState st, int k) {
   T alpha = 0;
   if (MODE == 1) {
-    ck = st.ctl[k];
-    if (ck.done || ck.rz == 0.0) return;
-    alpha = (T)ck.alpha;
+    if (st.done[k]) return;
+    const PcgIter it = pcg_iter(st, k);
+    if (it.rzp == 0.0) return;
+    // T-precision scalars, as the reference keeps them in T on the host;  p.A.p = den + mu p.D.p
+    alpha = (T)it.rz / (T)(slot_sum(st.den, k) + mu * slot_sum(st.pdp, k));
   }
   __shared__ double red[4];
   __shared__ T rs[TPB];
   const unsigned pose_dim = 9u * (unsigned)Nc;
-  const unsigned cam_blocks = (pose_dim + 251u) / 252u;
+  const int cam_tiles = (int)((pose_dim + 251u) / 252u), pt_tiles = (Np + TPB - 1) / TPB;
   double prr = 0, prz = 0;
-  if (blockIdx.x < cam_blocks) {
-    const unsigned t = blockIdx.x * 252u + threadIdx.x;
+  // persistent: every block walks a contiguous range of camera tiles, then of point tiles
+  const int ct0 = (int)((long long)blockIdx.x * cam_tiles / gridDim.x), ct1 = (int)((long long)(blockIdx.x + 1) * cam_tiles / gridDim.x);
+  for (int tile = ct0; tile < ct1; ++tile) {
+    const unsigned t = (unsigned)tile * 252u + threadIdx.x;
     const bool on = threadIdx.x < 252 && t < pose_dim;
     T rn = 0;
     if (on) {
@@ -426,6 +444,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
       }
       r[t] = rn;
     }
+    __syncthreads();
     rs[threadIdx.x] = rn;
     __syncthreads();
     if (on) {
@@ -439,11 +458,13 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         for (int q = 0; q < 9; ++q) s += M[row + 9 * q] * rc[q];
       }
       zt[t] = s;
-      prr = (double)(rn * rn);
-      prz = (double)(rn * s);
+      prr += (double)(rn * rn);
+      prz += (double)(rn * s);
     }
-  } else {
-    const unsigned l = (blockIdx.x - cam_blocks) * TPB + threadIdx.x;
+  }
+  const int pt0 = (int)((long long)blockIdx.x * pt_tiles / gridDim.x), pt1 = (int)((long long)(blockIdx.x + 1) * pt_tiles / gridDim.x);
+  for (int tile = pt0; tile < pt1; ++tile) {
+    const unsigned l = (unsigned)tile * TPB + threadIdx.x;
     if (l < (unsigned)Np) {
       const size_t t = (size_t)pose_dim + 3 * (size_t)l;
       T rn[3];
@@ -477,64 +498,62 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
       }
     }
   }
+  const int slot = (MODE == 0) ? 0 : k + 1;
   prr = block_sum_256(prr, red);
   prz = block_sum_256(prz, red);
-  double rr, rzp;
-  if (grid_sum2(prr, prz, st.partial, st.ticket, red, rr, rzp) && threadIdx.x == 0) {
-    const T rscale = (T)(1.0 / (double)(T)sqrt((double)(T)rr));
-    const T rz_new = (T)rzp * rscale;
-    if (MODE == 0) {
-      PcgCtl c0 = st.ctl[0];
-      c0.rz = (double)rz_new; c0.rscale = (double)rscale; c0.rz0 = __builtin_inf(); c0.done = 0;
-      st.ctl[0] = c0;
-    } else {
-      PcgCtl nx = st.ctl[k + 1];
-      const bool reject = (fabs((double)rz_new) > rejection_ratio * ck.rz0) || (rz_new != rz_new);
-      st.ctl[k].reject = reject ? 1 : 0;
-      st.ctl[k].stepped = 1;
-      st.ctl[k].beta = (double)(rz_new / (T)ck.rz);
-      nx.rz = (double)rz_new; nx.rscale = (double)rscale;
-      nx.rz0 = reject ? ck.rz0 : fmin(ck.rz0, fabs((double)rz_new));
-      nx.done = (reject || fabs((double)rz_new) < tol) ? 1 : 0;
-      st.ctl[k + 1] = nx;
-      st.iters[0] = k + 1;
-      *st.hiters = k + 1;
-      st.hflag[k] = nx.done ? 2 : 1;
-      __threadfence_system();
-    }
-  }
+  if (threadIdx.x == 0) { slot_add(st.rr, slot, prr); slot_add(st.rzp, slot, prz); }
 }
 
-// Direction kernel (pcg.hpp:108-127 for k = -1, :198-217 otherwise): restore x on a
-// rejected step, else p = beta p + z'/||r||; ps = s .* p; the last block stores p.D.p.
+// Direction kernel (pcg.hpp:108-127 for k = -1, :184-217 otherwise): rejection test, restore x
+// on a rejected step, else p = beta p + z'/||r||; ps = s .* p; pdp[k+1] = p.D.p.  Thread 0
+// publishes the loop state of iteration k+1 (device) and the host flag of iteration k.
 template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__restrict__ p,
                 T *__restrict__ ps, const T *__restrict__ zt, const T *__restrict__ scales,
-                const T *__restrict__ diag, int use_identity, PcgState st, int k) {
+                const T *__restrict__ diag, int use_identity, PcgState st, int k, double tol,
+                double rejection_ratio) {
   __shared__ double red[4];
-  const unsigned t = blockIdx.x * TPB + threadIdx.x;
-  T pn = 0;
-  bool wrote = false;
-  if (k < 0) {
-    const T scale = (T)st.ctl[0].rscale;
-    if (t < n) { pn = scale * zt[t]; wrote = true; }
-  } else {
-    const PcgCtl ck = st.ctl[k];
-    if (ck.done || !ck.stepped) return;
-    if (ck.reject) { if (t < n) x[t] = xb[t]; return; }
-    const T beta = (T)ck.beta, scale_new = (T)st.ctl[k + 1].rscale;
-    if (t < n) { pn = beta * p[t] + scale_new * zt[t]; wrote = true; }
+  const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
+  T beta = 0, scale = 0;
+  if (k < 0) scale = (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(st.rr, 0)));
+  else {
+    const double rz0 = st.rz0[k];
+    bool leave = st.done[k] != 0;
+    PcgIter it{};
+    if (!leave) { it = pcg_iter(st, k); leave = (it.rzp == 0.0); }
+    if (leave) {
+      if (first) { st.done[k + 1] = 1; st.rz0[k + 1] = rz0; st.hflag[k] = 2; __threadfence_system(); }
+      return;
+    }
+    const PcgIter nx = pcg_iter(st, k + 1);
+    const T rz = (T)it.rzp * (T)(double)(T)it.rscale, rz_new = (T)nx.rzp * (T)(double)(T)nx.rscale;
+    const bool reject = (fabs((double)rz_new) > rejection_ratio * rz0) || (rz_new != rz_new);
+    const bool done_next = reject || fabs((double)rz_new) < tol;
+    if (first) {
+      st.rz0[k + 1] = reject ? rz0 : fmin(rz0, fabs((double)rz_new));
+      st.done[k + 1] = done_next ? 1 : 0;
+      st.iters[0] = k + 1;
+      *st.hiters = k + 1;
+      st.hflag[k] = done_next ? 2 : 1;
+      __threadfence_system();
+    }
+    if (reject) {
+      for (unsigned t = blockIdx.x * TPB + threadIdx.x; t < n; t += gridDim.x * TPB) x[t] = xb[t];
+      return;
+    }
+    beta = rz_new / rz;
+    scale = (T)(double)(T)nx.rscale;
   }
   double pdp = 0;
-  if (wrote) {
+  for (unsigned t = blockIdx.x * TPB + threadIdx.x; t < n; t += gridDim.x * TPB) {
+    const T pn = (k < 0) ? scale * zt[t] : beta * p[t] + scale * zt[t];
     p[t] = pn;
     ps[t] = scales[t] * pn;
-    pdp = use_identity ? (double)(pn * pn) : (double)(diag[t] * pn * pn);
+    pdp += use_identity ? (double)(pn * pn) : (double)(diag[t] * pn * pn);
   }
   pdp = block_sum_256(pdp, red);
-  double t0, t1;
-  if (grid_sum2(pdp, 0.0, st.partial, st.ticket, red, t0, t1) && threadIdx.x == 0) st.ctl[k + 1].pdp = t0;
+  if (threadIdx.x == 0) slot_add(st.pdp, k + 1, pdp);
 }
 
 } // namespace gr
