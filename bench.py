@@ -85,8 +85,10 @@ def main():
         from graphite_amd import dist as gdist
         part = gdist.partition_by_landmark(prob, rank, world)
         gpu = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype,
-                            device=local_rank)
+                            device=local_rank, shard=True)
         gdist.init_comm(gpu, rank, world)
+        if solver_name != "pcg":
+            solver_name, solver = "pcg", ga.SOLVER_PCG  # the sharded path implements the matrix-free PCG
     else:
         part = prob
         gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype,

@@ -35,7 +35,7 @@ def _ptr(a):
 class BalProblem:
     """Device-resident BAL problem (gr_bal_problem handle)."""
 
-    def __init__(self, cameras, points, obs, cam_idx, pt_idx, dtype=np.float64, device=0, stream=None):
+    def __init__(self, cameras, points, obs, cam_idx, pt_idx, dtype=np.float64, device=0, stream=None, shard=False):
         self.lib = _lib.lib()
         self.dt = np.dtype(dtype)
         self.code = F32 if self.dt == np.float32 else F64
@@ -47,7 +47,8 @@ class BalProblem:
         self.Nc, self.Np, self.No = len(cameras), len(points), len(obs)
         self.n = 9 * self.Nc + 3 * self.Np
         self.h = C.c_void_p()
-        check(self.lib.gr_bal_create(C.byref(self.h), C.c_int(self.code), C.c_int64(self.Nc), C.c_int64(self.Np),
+        create = self.lib.gr_bal_create_shard if shard else self.lib.gr_bal_create
+        check(create(C.byref(self.h), C.c_int(self.code), C.c_int64(self.Nc), C.c_int64(self.Np),
                                      C.c_int64(self.No), _ptr(cameras), _ptr(points), _ptr(obs), _ptr(ci),
                                      _ptr(pi), C.c_int(device), C.c_void_p(stream or 0)))
 

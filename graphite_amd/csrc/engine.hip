@@ -9,6 +9,7 @@
 //   optimizer::levenberg_marquardt                                             (optimizer/levenberg_marquardt.hpp)
 // The C ABI at the bottom (include/graphite_mi355x.h) is the drop-in boundary.
 #include "../../include/graphite_mi355x.h"
+#include "comm.hpp"
 #include "kernels_mf.hpp"
 #include <algorithm>
 #include <chrono>
@@ -55,6 +56,7 @@ struct EngineBase {
   virtual void lm(const gr_lm_options &opt, gr_lm_stats &st, double *chi2_trace, double *lambda_trace) = 0;
   virtual int kernel_stats(gr_kernel_stat *out, int cap) = 0;
   virtual double diag_time(int which, int variant, int reps) = 0;
+  virtual void set_comm(std::unique_ptr<Comm> c) = 0;
   int device = 0;
 };
 
@@ -83,6 +85,14 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<int> boundary_flag;
   DevBuf<unsigned> ticket;
   DevBuf<int> cam_seg_ptr;
+  // multi-GPU: landmark shard of a larger problem (comm != null), camera rows all-reduced
+  std::unique_ptr<Comm> comm;
+  bool shard = false;
+  DevBuf<T> raw_c;
+  int cam_weight() const { return (!comm || comm->rank == 0) ? 1 : 0; }
+  void set_comm(std::unique_ptr<Comm> c) override { comm = std::move(c); raw_c.alloc(pose_dim); }
+  void allreduce_T(T *buf, size_t count) { comm->allreduce(buf, count, sizeof(T) == 8, stream); }
+  void allreduce_d(double *buf, size_t count) { comm->allreduce(buf, count, true, stream); }
   // matrix-free PCG control
   DevBuf<double> ctl; // PCG slot accumulators + loop state
   DevBuf<int> ctl_i;
@@ -119,8 +129,9 @@ template <typename T> struct Engine final : EngineBase {
   std::map<std::string, KernelProf> prof;
 
   Engine(int64_t nc, int64_t np, int64_t no, const void *c, const void *p, const void *o,
-         const int32_t *ci, const int32_t *pi, int dev, hipStream_t s) {
+         const int32_t *ci, const int32_t *pi, int dev, hipStream_t s, bool shard_ = false) {
     device = dev;
+    shard = shard_;
     stream = s;
     Nc = nc; Np = np; No = no;
     pose_dim = 9 * (size_t)Nc;
@@ -216,7 +227,7 @@ template <typename T> struct Engine final : EngineBase {
         if (h_cam_pm[a] == h_cam_pm[a - 1]) throw std::domain_error("duplicate (camera, point) edge");
     h_cam_ptr.assign(Nc + 1, 0);
     for (int64_t a = 0; a < No; ++a) h_cam_ptr[h_cam_pm[a] + 1]++;
-    for (int64_t c = 0; c < Nc; ++c) if (h_cam_ptr[c + 1] == 0) throw std::invalid_argument("camera without observations (the reference deactivates it, graph.hpp:171; remove it from the problem)");
+    for (int64_t c = 0; c < Nc && !shard; ++c) if (h_cam_ptr[c + 1] == 0) throw std::invalid_argument("camera without observations (the reference deactivates it, graph.hpp:171; remove it from the problem)");
     for (int64_t l = 0; l < Np; ++l) if (h_pt_ptr[l + 1] == h_pt_ptr[l]) throw std::invalid_argument("point without observations (the reference deactivates it, graph.hpp:171; remove it from the problem)");
     for (int64_t c = 0; c < Nc; ++c) h_cam_ptr[c + 1] += h_cam_ptr[c];
     h_pos_cm.resize(No); h_pt_cm.resize(No);
@@ -239,7 +250,7 @@ template <typename T> struct Engine final : EngineBase {
     // (wave, camera) segments of the flat camera-major kernels
     h_cam_seg_ptr.assign(Nc + 1, 0);
     for (int64_t c = 0; c < Nc; ++c)
-      h_cam_seg_ptr[c + 1] = h_cam_seg_ptr[c] + (((h_cam_ptr[c + 1] - 1) >> 6) - (h_cam_ptr[c] >> 6) + 1);
+      h_cam_seg_ptr[c + 1] = h_cam_seg_ptr[c] + (h_cam_ptr[c + 1] == h_cam_ptr[c] ? 0 : ((h_cam_ptr[c + 1] - 1) >> 6) - (h_cam_ptr[c] >> 6) + 1);
     nseg = h_cam_seg_ptr[Nc];
     cam_seg_ptr.upload(h_cam_seg_ptr, stream);
     chunk_cam.upload(h_chunk_cam, stream); chunk_beg.upload(h_chunk_beg, stream); cam_chunk_ptr.upload(h_cam_chunk_ptr, stream);
@@ -412,7 +423,15 @@ template <typename T> struct Engine final : EngineBase {
     }
     {
       Scope sc(this, "linearize_finalize", 9.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
-      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p);
+      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p);
+    }
+    if (comm) { // camera-space sums over the landmark shards
+      comm->group_start();
+      allreduce_T(Hcc.p, 81 * (size_t)Nc);
+      allreduce_T(bc.p, pose_dim);
+      allreduce_d(dscalars.p, 1);
+      comm->group_end();
+      k_camera_scales<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, scale_system ? 1 : 0, Hcc.p, scales.p);
     }
     hcp_valid = write_hcp;
   }
@@ -431,10 +450,18 @@ template <typename T> struct Engine final : EngineBase {
   int chi2_async(T *res_out, const T *dx, double mu) {
     const int seq = ++seq_counter;
     Scope sc(this, "chi2", No * (2 * w() + 8) + (24.0 * Nc + 3.0 * Np) * w() + (dx ? 3.0 * n * w() : 0.0), No * 40.0);
-    k_chi2<T><<<grid_obs, TPB, 0, stream>>>((int)No, (unsigned)n, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, h_res, h_seq, seq, res_out);
+    k_chi2<T><<<grid_obs, TPB, 0, stream>>>((int)No, (unsigned)n, (unsigned)pose_dim, cam_weight(), cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, comm ? nullptr : h_res, h_seq, seq, res_out);
+    if (comm) allreduce_d(dscalars.p, 2);
     return seq;
   }
   void wait_chi2(int seq) {
+    if (comm) { // the sums over ranks live in device memory
+      double hs[2];
+      GR_HIP(hipMemcpyAsync(hs, dscalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+      GR_HIP(hipStreamSynchronize(stream));
+      h_res[0] = hs[0]; h_res[1] = hs[1];
+      return;
+    }
     spin_until([&] { return __atomic_load_n(const_cast<const int *>(h_seq), __ATOMIC_ACQUIRE) == seq; });
   }
   double read_scalar(int idx) {
@@ -573,13 +600,13 @@ template <typename T> struct Engine final : EngineBase {
   }
   void ensure_ctl(int max_iter) {
     const int cap = max_iter + 2;
-    if (cap > ctl_cap) { ctl_cap = cap; ctl.alloc((4 * (size_t)NS + 1) * cap); ctl_i.alloc(cap); }
+    if (cap > ctl_cap) { ctl_cap = cap; ctl.alloc(((size_t)NSLOT * NS + 2) * cap); ctl_i.alloc(cap); }
     alloc_pinned(cap);
   }
   PcgState pcg_state() {
     PcgState st;
-    const size_t blk = (size_t)ctl_cap * NS;
-    st.rzp = ctl.p; st.rr = ctl.p + blk; st.den = ctl.p + 2 * blk; st.pdp = ctl.p + 3 * blk; st.rz0 = ctl.p + 4 * blk;
+    const size_t blk = (size_t)ctl_cap * NSLOT * NS;
+    st.acc = ctl.p; st.pdp = ctl.p + blk; st.rz0 = ctl.p + blk + ctl_cap;
     st.done = ctl_i.p; st.iters = pcg_iters.p; st.hflag = h_flag; st.hiters = h_seq + 1;
     return st;
   }
@@ -594,20 +621,31 @@ template <typename T> struct Engine final : EngineBase {
     h_seq[1] = 0;
     k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
     const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, TPB), num_cu * 8);
-    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
-    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1, 0.0, 1e30);
+    const T *rawc = comm ? raw_c.p : nullptr;
+    const int cw = cam_weight();
+    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
+    if (comm) allreduce_d(st.acc, 4 * (size_t)NS); // record 0: RZP, RR, PDZ, ZDZ
+    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30);
     auto enqueue = [&](int k) {
       {
         Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
         k_pcg_operator<T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k);
       }
-      {
-        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 12.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
-        k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k);
+      if (comm) { // camera rows + the p.A.p partials, summed over the landmark shards
+        k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, nullptr, k);
+        comm->group_start();
+        allreduce_T(raw_c.p, pose_dim);
+        allreduce_d(st.acc + ((size_t)k * NSLOT + DEN) * NS, NS);
+        comm->group_end();
       }
       {
-        Scope s3(this, "pcg_direction", 7.0 * n * sizeof(T), 6.0 * n);
-        k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, k, tol, rej);
+        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
+        k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k);
+      }
+      if (comm) allreduce_d(st.acc + (size_t)(k + 1) * NSLOT * NS, 4 * (size_t)NS);
+      {
+        Scope s3(this, "pcg_direction", 5.0 * n * sizeof(T), 3.0 * n);
+        k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej);
       }
     };
     if (max_iter > 0) enqueue(0);
@@ -629,8 +667,8 @@ template <typename T> struct Engine final : EngineBase {
     const int ui = 0;
     const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, TPB), num_cu * 8);
     k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
-    k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
-    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1, 0.0, 1e30);
+    k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
+    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30);
     hipEvent_t a, b;
     GR_HIP(hipEventCreate(&a)); GR_HIP(hipEventCreate(&b));
     auto launch = [&] {
@@ -645,9 +683,9 @@ template <typename T> struct Engine final : EngineBase {
         break;
       case 1: k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); break;
       case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
-      case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0); break;
-      case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, v_diag.p, ui, st, -1, 0.0, 1e30); break;
-      case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p); break;
+      case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0); break;
+      case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30); break;
+      case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p); break;
       default: throw std::invalid_argument("diag_time: unknown kernel");
       }
     };
@@ -849,9 +887,9 @@ int gr_device_count(void) {
   return nd;
 }
 
-gr_status gr_bal_create(gr_bal_problem **out, gr_dtype dtype, int64_t nc, int64_t np, int64_t no,
-                        const void *cameras, const void *points, const void *observations,
-                        const int32_t *cam_idx, const int32_t *pt_idx, int device, void *stream) {
+static gr_status create_impl(gr_bal_problem **out, gr_dtype dtype, int64_t nc, int64_t np, int64_t no,
+                             const void *cameras, const void *points, const void *observations,
+                             const int32_t *cam_idx, const int32_t *pt_idx, int device, void *stream, bool shard) {
   if (!out || nc <= 0 || np <= 0 || no <= 0 || !cameras || !points || !observations || !cam_idx || !pt_idx ||
       no >= (int64_t)std::numeric_limits<int>::max() / 27) {
     g_last_error = "gr_bal_create: bad argument";
@@ -866,14 +904,24 @@ gr_status gr_bal_create(gr_bal_problem **out, gr_dtype dtype, int64_t nc, int64_
     GR_HIP(hipSetDevice(device));
     auto *p = new gr_bal_problem();
     p->dtype = dtype;
-    if (dtype == GR_F32) p->e.reset(new Engine<float>(nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, (hipStream_t)stream));
-    else if (dtype == GR_F64) p->e.reset(new Engine<double>(nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, (hipStream_t)stream));
+    if (dtype == GR_F32) p->e.reset(new Engine<float>(nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, (hipStream_t)stream, shard));
+    else if (dtype == GR_F64) p->e.reset(new Engine<double>(nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, (hipStream_t)stream, shard));
     else { delete p; g_last_error = "bad dtype"; return GR_ERR_INVALID; }
     *out = p;
     return GR_OK;
   } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
   catch (const std::domain_error &ex) { g_last_error = ex.what(); return GR_ERR_DUPLICATE_EDGE; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
+}
+gr_status gr_bal_create(gr_bal_problem **out, gr_dtype dtype, int64_t nc, int64_t np, int64_t no,
+                        const void *cameras, const void *points, const void *observations,
+                        const int32_t *cam_idx, const int32_t *pt_idx, int device, void *stream) {
+  return create_impl(out, dtype, nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, stream, false);
+}
+gr_status gr_bal_create_shard(gr_bal_problem **out, gr_dtype dtype, int64_t nc, int64_t np, int64_t no,
+                              const void *cameras, const void *points, const void *observations,
+                              const int32_t *cam_idx, const int32_t *pt_idx, int device, void *stream) {
+  return create_impl(out, dtype, nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, stream, true);
 }
 gr_status gr_bal_destroy(gr_bal_problem *p) {
   if (!p) return GR_ERR_INVALID;
@@ -917,7 +965,35 @@ double gr_bal_diag_time(gr_bal_problem *p, int which, int variant, int reps) {
   guarded(p, [&] { us = p->e->diag_time(which, variant, reps); });
   return us;
 }
-gr_status gr_comm_unique_id(void *) { g_last_error = "RCCL path not built yet"; return GR_ERR_COMM; }
-gr_status gr_bal_comm_init(gr_bal_problem *, const void *, int, int) { g_last_error = "RCCL path not built yet"; return GR_ERR_COMM; }
+gr_status gr_comm_unique_id(void *unique_id_128) {
+  try {
+    RcclApi &api = RcclApi::get();
+    if (!api.ok()) { g_last_error = "librccl.so.1 not found"; return GR_ERR_COMM; }
+    api.check(api.GetUniqueId(unique_id_128), "ncclGetUniqueId");
+    return GR_OK;
+  } catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
+}
+gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int rank, int world_size) {
+  if (!p || !p->e || !unique_id_128 || rank < 0 || rank >= world_size) { g_last_error = "gr_bal_comm_init: bad argument"; return GR_ERR_INVALID; }
+  try {
+    GR_HIP(hipSetDevice(p->e->device));
+    p->e->set_comm(std::unique_ptr<Comm>(new RcclComm(unique_id_128, rank, world_size)));
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
+}
+// TEST ONLY: join `n` problems of THIS process (same GPU) into an in-process group; afterwards
+// every collective call (linearize, solve, levenberg_marquardt ...) must be made concurrently,
+// one host thread per problem.  Exercises the sharded algorithm on a 1-GPU box.
+gr_status gr_bal_comm_init_local(gr_bal_problem **problems, int n) {
+  if (!problems || n <= 0) { g_last_error = "gr_bal_comm_init_local: bad argument"; return GR_ERR_INVALID; }
+  try {
+    GR_HIP(hipSetDevice(problems[0]->e->device));
+    auto grp = std::make_shared<LocalGroup>(n);
+    for (int r = 0; r < n; ++r) problems[r]->e->set_comm(std::unique_ptr<Comm>(new LocalComm(grp, r)));
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
+}
 
 } // extern "C"

@@ -24,26 +24,34 @@ namespace gr {
 
 constexpr int TICKET_GROUPS = 64;
 
-// PCG scalars never visit the host.  Iteration k owns slot k of every array:
-//   rzp[k] r.z' and rr[k] r.r at the START of iteration k (z' = Minv r; the reference's
-//          r.z with z = Minv (r/||r||) is rzp / sqrt(rr)),  den[k] sum_obs rho'|J ps|^2,
-//          pdp[k] p.D.p of the direction used by iteration k           — NS partial sums each,
-//          filled with fire-and-forget atomics and re-summed by every consumer wave
-//          (a last-block/ticket reduction was measured to add ~10 us of tail to every kernel);
-//   rz0[k] running min of |rz_new| before iteration k, done[k] loop left before iteration k
-//          — written by thread 0 of the direction kernel of iteration k-1.
+// PCG scalars never visit the host.  Iteration k owns record k of `acc` ([cap][5][NS] doubles):
+//   RZP r.z' and RR r.r at the START of iteration k (z' = Minv r; the reference's r.z with
+//       z = Minv (r/||r||) is rzp / sqrt(rr)),
+//   PDZ p.D.z' and ZDZ z'.D.z' (D = clamped diagonal or I) of the same moment, from which the
+//       direction kernel gets p.D.p of the NEW direction by recurrence — no reduction of its own,
+//   DEN sum_obs rho'|J ps|^2 of iteration k
+//       — NS partial sums each, filled with fire-and-forget atomics and re-summed by every
+//       consumer wave (a last-block/ticket reduction added ~10 us of tail to every kernel);
+//   pdp[k] p.D.p of the direction used by iteration k, rz0[k] running min of |rz_new| before
+//   iteration k, done[k] loop left before iteration k — written by thread 0 of the direction
+//   kernel of iteration k-1.
+// Multi-GPU: every record is summed over ranks (RCCL) between the producing and the consuming
+// kernel; camera-space vectors are replicated, so their dot-product share is added by rank 0 only
+// (cam_weight).
+enum { RZP = 0, RR = 1, PDZ = 2, ZDZ = 3, DEN = 4, NSLOT = 5 };
 struct PcgState {
-  double *rzp, *rr, *den, *pdp; // [cap][NS]
-  double *rz0;                  // [cap]
-  int *done;                    // [cap]
-  int *iters;                   // [1]
-  volatile int *hflag;          // pinned host memory [cap]: 1 = iteration finished, 2 = loop left
-  volatile int *hiters;         // pinned host mirror of iters
+  double *acc;          // [cap][NSLOT][NS]
+  double *pdp, *rz0;    // [cap]
+  int *done;            // [cap]
+  int *iters;           // [1]
+  volatile int *hflag;  // pinned host memory [cap]: 1 = iteration finished, 2 = loop left
+  volatile int *hiters; // pinned host mirror of iters
+  __device__ __forceinline__ double *slots(int k, int which) const { return acc + ((size_t)k * NSLOT + which) * NS; }
 };
 
 __global__ void k_pcg_state_init(PcgState st, int cap) {
-  for (int i = threadIdx.x; i < cap * NS; i += blockDim.x) { st.rzp[i] = 0.0; st.rr[i] = 0.0; st.den[i] = 0.0; st.pdp[i] = 0.0; }
-  for (int i = threadIdx.x; i < cap; i += blockDim.x) { st.done[i] = 0; st.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
+  for (int i = threadIdx.x; i < cap * NSLOT * NS; i += blockDim.x) st.acc[i] = 0.0;
+  for (int i = threadIdx.x; i < cap; i += blockDim.x) { st.done[i] = 0; st.pdp[i] = 0.0; st.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
   if (threadIdx.x == 0) st.iters[0] = 0;
 }
 
@@ -51,8 +59,8 @@ __global__ void k_pcg_state_init(PcgState st, int cap) {
 struct PcgIter { double rzp, rscale, rz; };
 __device__ __forceinline__ PcgIter pcg_iter(const PcgState &st, int k) {
   PcgIter it;
-  it.rzp = slot_sum(st.rzp, k);
-  it.rscale = 1.0 / sqrt(slot_sum(st.rr, k));
+  it.rzp = slot_sum(st.slots(k, RZP), 0);
+  it.rscale = 1.0 / sqrt(slot_sum(st.slots(k, RR), 0));
   it.rz = it.rzp * it.rscale;
   return it;
 }
@@ -204,7 +212,7 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
 // (column scales: graph.hpp:254-270)
 template <typename T>
 __global__ void __launch_bounds__(TPB)
-k_linearize_finalize(int Nc, int Np, int scale_system, const int *__restrict__ cam_seg_ptr,
+k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int *__restrict__ cam_seg_ptr,
                      const T *__restrict__ cam_partial, const int *__restrict__ pt_ptr,
                      const T *__restrict__ g9, T *__restrict__ Hcc, T *__restrict__ bc, T *__restrict__ Hll,
                      T *__restrict__ bl, T *__restrict__ scales, int n_partials,
@@ -224,7 +232,7 @@ k_linearize_finalize(int Nc, int Np, int scale_system, const int *__restrict__ c
     for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) s += cam_partial[54 * (size_t)sg + idx];
     if (e < 81u) {
       Hcc[81 * (size_t)c + e] = s;
-      if (row == col) scales[9 * c + row] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)s))) : T(1);
+      if (row == col && cam_scales) scales[9 * c + row] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)s))) : T(1);
     } else bc[9 * c + (e - 81u)] = s;
   } else if (t < ncam + (unsigned)Np) {
     const unsigned l = t - ncam;
@@ -253,6 +261,15 @@ k_linearize_finalize(int Nc, int Np, int scale_system, const int *__restrict__ c
   }
 }
 
+// Multi-GPU: camera column scales from the all-reduced Hcc diagonal (graph.hpp:262-270)
+template <typename T>
+__global__ void k_camera_scales(int Nc, int scale_system, const T *__restrict__ Hcc, T *__restrict__ scales) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 9u * (unsigned)Nc) return;
+  const T d = Hcc[81 * (size_t)(t / 9u) + 10 * (t % 9u)];
+  scales[t] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)d))) : T(1);
+}
+
 // chi2 of a trial step (Graph::compute_error + Graph::chi2) fused with compute_rho's
 // denominator sum dx (mu dx + b) (levenberg_marquardt.hpp:34-41).  One observation per
 // thread (cm order); the first ceil(n/256) blocks also take one vector element each.
@@ -260,7 +277,7 @@ k_linearize_finalize(int Nc, int Np, int scale_system, const int *__restrict__ c
 // and mirrors them to pinned host memory (hres[0..1], then hres_seq = seq).
 template <typename T>
 __global__ void __launch_bounds__(TPB)
-k_chi2(int No, unsigned n, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
+k_chi2(int No, unsigned n, unsigned pose_dim, int cam_weight, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
        const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const T *__restrict__ pts,
        const T *__restrict__ pack, int loss_kind, T loss_delta, const T *__restrict__ dx,
        const T *__restrict__ bu, const T *__restrict__ scales, double mu, double *__restrict__ partial,
@@ -282,7 +299,7 @@ k_chi2(int No, unsigned n, const int *__restrict__ cam_cm, const int *__restrict
   if (dx) {
     for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < n; i += (unsigned)stride) {
       const T x = dx[i];
-      rho += (double)(x * ((T)mu * x + scales[i] * bu[i]));
+      if (i >= pose_dim || cam_weight) rho += (double)(x * ((T)mu * x + scales[i] * bu[i]));
     }
   }
   chi2 = block_sum_256(chi2, red);
@@ -316,7 +333,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
                int loss_kind, T loss_delta, const T *__restrict__ ps, T *__restrict__ g3,
                T *__restrict__ op_partial, double mu, PcgState st, int k) {
   if (st.done[k]) return;                      // direction(k-1) already told the host
-  if (slot_sum(st.rzp, k) == 0.0) return;      // rz == 0: the direction kernel of this iteration closes the loop
+  if (slot_sum(st.slots(k, RZP), 0) == 0.0) return; // rz == 0: the direction kernel of this iteration closes the loop
   __shared__ double red[4];
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
@@ -390,7 +407,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     j = jn;
   }
   den = block_sum_256(den, red);
-  if (threadIdx.x == 0) slot_add(st.den, k, den);
+  if (threadIdx.x == 0) slot_add(st.slots(k, DEN), 0, den);
 }
 
 // x / r / z' update of the matrix-free PCG.
@@ -408,7 +425,8 @@ __global__ void __launch_bounds__(TPB)
 k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ scales, T *__restrict__ x,
              T *__restrict__ xb, T *__restrict__ r, T *__restrict__ zt, const T *__restrict__ p,
              const T *__restrict__ g3, const int *__restrict__ pt_ptr, const T *__restrict__ op_partial,
-             const int *__restrict__ cam_seg_ptr, const T *__restrict__ diag, double mu, int use_identity,
+             const int *__restrict__ cam_seg_ptr, const T *__restrict__ raw_c, int cam_weight,
+             const T *__restrict__ diag, double mu, int use_identity,
              const T *__restrict__ MinvC, const T *__restrict__ MinvP, PcgState st, int k) {
   T alpha = 0;
   if (MODE == 1) {
@@ -416,13 +434,14 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
     const PcgIter it = pcg_iter(st, k);
     if (it.rzp == 0.0) return;
     // T-precision scalars, as the reference keeps them in T on the host;  p.A.p = den + mu p.D.p
-    alpha = (T)it.rz / (T)(slot_sum(st.den, k) + mu * slot_sum(st.pdp, k));
+    alpha = (T)it.rz / (T)(slot_sum(st.slots(k, DEN), 0) + mu * st.pdp[k]);
   }
   __shared__ double red[4];
   __shared__ T rs[TPB];
   const unsigned pose_dim = 9u * (unsigned)Nc;
   const int cam_tiles = (int)((pose_dim + 251u) / 252u), pt_tiles = (Np + TPB - 1) / TPB;
-  double prr = 0, prz = 0;
+  double prr = 0, prz = 0, ppz = 0, pzz = 0;
+  const double cw = (double)cam_weight;
   // persistent: every block walks a contiguous range of camera tiles, then of point tiles
   const int ct0 = (int)((long long)blockIdx.x * cam_tiles / gridDim.x), ct1 = (int)((long long)(blockIdx.x + 1) * cam_tiles / gridDim.x);
   for (int tile = ct0; tile < ct1; ++tile) {
@@ -434,7 +453,9 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
       else {
         const unsigned c = t / 9u, i = t % 9u;
         T raw = 0;
-        for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) raw += op_partial[9 * (size_t)sg + i];
+        if (raw_c) raw = raw_c[t]; // multi-GPU: camera rows already summed over segments and ranks
+        else
+          for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) raw += op_partial[9 * (size_t)sg + i];
         const T pv = p[t];
         const T v2 = scales[t] * raw + (use_identity ? (T)mu * pv : (T)mu * diag[t] * pv);
         const T xo = x[t];
@@ -458,8 +479,12 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         for (int q = 0; q < 9; ++q) s += M[row + 9 * q] * rc[q];
       }
       zt[t] = s;
-      prr += (double)(rn * rn);
-      prz += (double)(rn * s);
+      const T d = use_identity ? T(1) : diag[t];
+      const T pv = (MODE == 0) ? T(0) : p[t];
+      prr += cw * (double)(rn * rn);
+      prz += cw * (double)(rn * s);
+      ppz += cw * (double)(d * pv * s);
+      pzz += cw * (double)(d * s * s);
     }
   }
   const int pt0 = (int)((long long)blockIdx.x * pt_tiles / gridDim.x), pt1 = (int)((long long)(blockIdx.x + 1) * pt_tiles / gridDim.x);
@@ -493,31 +518,42 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         r[t + i] = rn[i];
         const T s = IDENTITY ? rn[i] : M[i] * rn[0] + M[i + 3] * rn[1] + M[i + 6] * rn[2];
         zt[t + i] = s;
+        const T d = use_identity ? T(1) : diag[t + i];
+        const T pv = (MODE == 0) ? T(0) : p[t + i];
         prr += (double)(rn[i] * rn[i]);
         prz += (double)(rn[i] * s);
+        ppz += (double)(d * pv * s);
+        pzz += (double)(d * s * s);
       }
     }
   }
   const int slot = (MODE == 0) ? 0 : k + 1;
   prr = block_sum_256(prr, red);
   prz = block_sum_256(prz, red);
-  if (threadIdx.x == 0) { slot_add(st.rr, slot, prr); slot_add(st.rzp, slot, prz); }
+  ppz = block_sum_256(ppz, red);
+  pzz = block_sum_256(pzz, red);
+  if (threadIdx.x == 0) {
+    slot_add(st.slots(slot, RR), 0, prr); slot_add(st.slots(slot, RZP), 0, prz);
+    slot_add(st.slots(slot, PDZ), 0, ppz); slot_add(st.slots(slot, ZDZ), 0, pzz);
+  }
 }
 
 // Direction kernel (pcg.hpp:108-127 for k = -1, :184-217 otherwise): rejection test, restore x
-// on a rejected step, else p = beta p + z'/||r||; ps = s .* p; pdp[k+1] = p.D.p.  Thread 0
-// publishes the loop state of iteration k+1 (device) and the host flag of iteration k.
+// on a rejected step, else p = beta p + z'/||r||; ps = s .* p.  Thread 0 publishes the loop state
+// of iteration k+1 (device) and the host flag of iteration k;  p.D.p of the new direction follows
+// from the dots the update kernel took:  pdp' = beta^2 pdp + 2 beta sigma p.D.z' + sigma^2 z'.D.z'.
 template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__restrict__ p,
-                T *__restrict__ ps, const T *__restrict__ zt, const T *__restrict__ scales,
-                const T *__restrict__ diag, int use_identity, PcgState st, int k, double tol,
-                double rejection_ratio) {
-  __shared__ double red[4];
+                T *__restrict__ ps, const T *__restrict__ zt, const T *__restrict__ scales, PcgState st,
+                int k, double tol, double rejection_ratio) {
   const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
   T beta = 0, scale = 0;
-  if (k < 0) scale = (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(st.rr, 0)));
-  else {
+  if (k < 0) {
+    scale = (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(st.slots(0, RR), 0)));
+    const double zdz = slot_sum(st.slots(0, ZDZ), 0);
+    if (first) st.pdp[0] = (double)scale * (double)scale * zdz;
+  } else {
     const double rz0 = st.rz0[k];
     bool leave = st.done[k] != 0;
     PcgIter it{};
@@ -527,12 +563,16 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
       return;
     }
     const PcgIter nx = pcg_iter(st, k + 1);
+    const double pdz = slot_sum(st.slots(k + 1, PDZ), 0), zdz = slot_sum(st.slots(k + 1, ZDZ), 0);
     const T rz = (T)it.rzp * (T)(double)(T)it.rscale, rz_new = (T)nx.rzp * (T)(double)(T)nx.rscale;
     const bool reject = (fabs((double)rz_new) > rejection_ratio * rz0) || (rz_new != rz_new);
     const bool done_next = reject || fabs((double)rz_new) < tol;
+    beta = rz_new / rz;
+    scale = (T)(double)(T)nx.rscale;
     if (first) {
       st.rz0[k + 1] = reject ? rz0 : fmin(rz0, fabs((double)rz_new));
       st.done[k + 1] = done_next ? 1 : 0;
+      st.pdp[k + 1] = (double)beta * (double)beta * st.pdp[k] + 2.0 * (double)beta * (double)scale * pdz + (double)scale * (double)scale * zdz;
       st.iters[0] = k + 1;
       *st.hiters = k + 1;
       st.hflag[k] = done_next ? 2 : 1;
@@ -542,18 +582,26 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
       for (unsigned t = blockIdx.x * TPB + threadIdx.x; t < n; t += gridDim.x * TPB) x[t] = xb[t];
       return;
     }
-    beta = rz_new / rz;
-    scale = (T)(double)(T)nx.rscale;
   }
-  double pdp = 0;
   for (unsigned t = blockIdx.x * TPB + threadIdx.x; t < n; t += gridDim.x * TPB) {
     const T pn = (k < 0) ? scale * zt[t] : beta * p[t] + scale * zt[t];
     p[t] = pn;
     ps[t] = scales[t] * pn;
-    pdp += use_identity ? (double)(pn * pn) : (double)(diag[t] * pn * pn);
   }
-  pdp = block_sum_256(pdp, red);
-  if (threadIdx.x == 0) slot_add(st.pdp, k + 1, pdp);
+}
+
+// Multi-GPU helper: camera rows of the operator summed over this rank's segments (the
+// all-reduce over ranks follows on the host side of the stream).
+template <typename T>
+__global__ void k_cam_rows(int Nc, const int *__restrict__ cam_seg_ptr, const T *__restrict__ op_partial,
+                           T *__restrict__ raw_c, const int *__restrict__ done, int k) {
+  if (done && done[k]) return;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 9u * (unsigned)Nc) return;
+  const unsigned c = t / 9u, i = t % 9u;
+  T raw = 0;
+  for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) raw += op_partial[9 * (size_t)sg + i];
+  raw_c[t] = raw;
 }
 
 } // namespace gr

@@ -107,6 +107,13 @@ gr_status gr_bal_create(gr_bal_problem **out, gr_dtype dtype, int64_t num_camera
                         int64_t num_points, int64_t num_observations, const void *cameras,
                         const void *points, const void *observations, const int32_t *cam_idx,
                         const int32_t *pt_idx, int device, void *stream);
+/* Same, for ONE landmark shard of a multi-GPU problem: all cameras (some of which may have no
+ * observation in this shard), a subset of the points and exactly their observations
+ * (point indices local to the shard).  Must be followed by gr_bal_comm_init. */
+gr_status gr_bal_create_shard(gr_bal_problem **out, gr_dtype dtype, int64_t num_cameras,
+                              int64_t num_points, int64_t num_observations, const void *cameras,
+                              const void *points, const void *observations, const int32_t *cam_idx,
+                              const int32_t *pt_idx, int device, void *stream);
 gr_status gr_bal_destroy(gr_bal_problem *p);
 
 /* FactorDescriptor::add_factor loss argument (factor.hpp:373-412), one loss for all factors */
@@ -168,12 +175,16 @@ typedef struct {
 gr_status gr_bal_kernel_stats(gr_bal_problem *p, gr_kernel_stat *out, int cap, int *n);
 
 /* ---- multi-GPU (RCCL over xGMI) ----------------------------------------------------
- * One process per GPU.  Each rank creates its problem from ITS landmark partition
- * (all cameras, a contiguous range of points and all their observations);
- * camera-space sums are all-reduced.  unique_id: 128-byte ncclUniqueId produced on
+ * One process per GPU.  Each rank creates its problem (gr_bal_create_shard) from ITS landmark
+ * partition (all cameras, a contiguous range of points and all their observations);
+ * camera-space sums are all-reduced.  Supported solvers: GR_SOLVER_PCG, GR_SOLVER_PCG_IDENTITY.  unique_id: 128-byte ncclUniqueId produced on
  * rank 0 by gr_comm_unique_id and broadcast by the caller (e.g. torch.distributed). */
 gr_status gr_comm_unique_id(void *unique_id_128);
 gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int rank, int world_size);
+/* test only: in-process group of `n` shards on one GPU, one host thread per shard */
+gr_status gr_bal_comm_init_local(gr_bal_problem **problems, int n);
+/* diagnostic: mean device time (us) of `reps` launches of one hot kernel */
+double gr_bal_diag_time(gr_bal_problem *p, int which, int variant, int reps);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,84 @@
+"""Landmark-sharded (multi-GPU) algorithm on a 1-GPU box.
+
+Several shards of one problem run concurrently in ONE process (one host thread per shard, the
+in-process test communicator of csrc/comm.hpp) and must reproduce the unsharded solve; RCCL
+itself is exercised with a 1-rank communicator.  The 8-GPU run is the driver's."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import graphite_amd as ga
+from graphite_amd import dist as gdist, synth, _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def run_sharded(prob, world, dtype, iterations, solver):
+    shards = [gdist.partition_by_landmark(prob, r, world) for r in range(world)]
+    engines = [ga.BalProblem(s.cameras, s.points, s.obs, s.cam_idx, s.pt_idx, dtype=dtype, shard=True) for s in shards]
+    gdist.init_local_group(engines)
+    out = [None] * world
+    err = []
+
+    def work(r):
+        try:
+            out[r] = engines[r].levenberg_marquardt(solver=solver, iterations=iterations)
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not err, err
+    assert all(o is not None for o in out), "a shard thread hung"
+    cams = [e.get_params()[0] for e in engines]
+    pts = np.concatenate([e.get_params()[1] for e in engines])
+    [e.close() for e in engines]
+    return out, cams, pts
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("solver", [ga.SOLVER_PCG, ga.SOLVER_PCG_IDENTITY])
+def test_sharded_lm_matches_single(world, solver):
+    prob = synth.make_config("mini-50")
+    single = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    ct, lt, st = single.levenberg_marquardt(solver=solver, iterations=8)
+    c1, p1 = single.get_params()
+    single.close()
+    out, cams, pts = run_sharded(prob, world, np.float64, 8, solver)
+    for r in range(world):
+        ct_r, lt_r, st_r = out[r]
+        assert np.allclose(ct_r, ct, rtol=1e-9), (r, ct_r, ct)       # every rank sees the global chi2
+        assert np.allclose(lt_r, lt, rtol=1e-6)
+        assert st_r["pcg_iterations"] == st["pcg_iterations"]
+        assert np.array_equal(cams[r], cams[0])                        # replicated cameras stay bit-identical
+    assert np.allclose(cams[0], c1, rtol=1e-7, atol=1e-10)
+    assert np.allclose(pts, p1, rtol=1e-7, atol=1e-10)
+
+
+def test_sharded_ladybug49_fp32():
+    prob = synth.make_config("ladybug-49")
+    single = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float32)
+    ct, _, _ = single.levenberg_marquardt(solver=ga.SOLVER_PCG, iterations=5)
+    single.close()
+    out, cams, _ = run_sharded(prob, 4, np.float32, 5, ga.SOLVER_PCG)
+    assert np.allclose(out[0][0], ct, rtol=2e-3)
+    assert all(np.array_equal(c, cams[0]) for c in cams)
+
+
+def test_rccl_single_rank_communicator():
+    """RCCL code path (dlopen, ncclCommInitRank, grouped all-reduces) with world_size = 1."""
+    lib = _lib.lib()
+    prob = synth.make_config("mini-50")
+    ref = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    ct, _, _ = ref.levenberg_marquardt(solver=ga.SOLVER_PCG, iterations=6)
+    ref.close()
+    gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64, shard=True)
+    uid = (C.c_char * 128)()
+    _lib.check(lib.gr_comm_unique_id(uid))
+    _lib.check(lib.gr_bal_comm_init(gpu.h, uid, C.c_int(0), C.c_int(1)))
+    ct1, _, _ = gpu.levenberg_marquardt(solver=ga.SOLVER_PCG, iterations=6)
+    gpu.close()
+    assert np.allclose(ct1, ct, rtol=1e-10)
