@@ -162,6 +162,43 @@ def main():
                          "simplicial LDL^T; the reference runs only the LDL^T on the CPU)",
                "seconds": round(cst["loop_seconds"], 3)}
 
+    # PMC traffic of the dominant kernel, measured offline with the same command under
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) and committed under profiles/
+    if roofline:
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = f"{args.workload} {dtype_name} {solver_name}"
+            kk = [k for k in tr.get(key, {}) if k.startswith("k_" + roofline["kernel"])]
+            if kk:
+                roofline["traffic"] = tr[key][kk[0]]["hbm_bytes"]
+                roofline["traffic_note"] = tr.get("note")
+        except Exception:
+            pass
+        # the reference ALGORITHM streams stored Jacobians: SURVEY §8(d) bytes per matrix-free PCG iteration
+        if solver_name == "pcg":
+            ref_bytes = No * (24 * w + 8) + 14 * n * w + (81 * Nc + 9 * Np) * w
+            roofline["reference_algorithm_bytes_per_pcg_iteration"] = ref_bytes
+            roofline["reference_algorithm_time_at_peak_us"] = round(ref_bytes / HBM_PEAK_GBS / 1e3, 2)
+
+    also = None
+    if world == 1 and args.workload == "ladybug-1723" and args.solver is None and args.dtype is None:
+        # BASELINE.json configs[1] next to the default configs[2]: Ladybug-49 fp32, Schur + PCG
+        p49 = synth.make_config("ladybug-49")
+        g49 = ga.BalProblem(p49.cameras, p49.points, p49.obs, p49.cam_idx, p49.pt_idx, dtype=np.float32, device=local_rank)
+        kw49 = dict(solver=ga.SOLVER_PCG_SCHUR, initial_damping=1e-4, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0)
+        g49.levenberg_marquardt(iterations=3, **kw49)
+        g49.set_params(p49.cameras, p49.points)
+        torch.cuda.synchronize()
+        t49 = time.perf_counter()
+        c49, _, s49 = g49.levenberg_marquardt(iterations=args.steps, **kw49)
+        torch.cuda.synchronize()
+        t49 = time.perf_counter() - t49
+        also = {"workload": "BAL ladybug-49 shape (49 cameras, 7776 points, 31843 observations), pcg-schur, f32",
+                "value": round(s49["iterations_run"] / t49, 2), "unit": "LM iterations/s", "steps_run": s49["iterations_run"],
+                "ms_per_step": round(t49 / max(s49["iterations_run"], 1) * 1e3, 4), "chi2_initial": float(c49[0]),
+                "chi2_final": float(c49[-1])}
+        g49.close()
+
     line = {
         "metric": "lm_iterations_per_sec", "value": round(steps_run / dt, 4), "unit": "LM iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -174,7 +211,7 @@ def main():
         "pcg_gflops": None if pcg_gflops is None else round(pcg_gflops, 2),
         "chi2_initial": float(ct[0]), "chi2_final": float(ct[-1]), "mse_final": float(ct[-1]) / No,
         "solve_seconds": round(st["solve_seconds"], 6), "loop_seconds": round(st["loop_seconds"], 6),
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "also": also,
     }
     if args.dump_kernels:
         with open(args.dump_kernels, "w") as f:
