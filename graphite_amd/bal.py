@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from ._lib import LMOptions, LMStats, KernelStat, check
 
-SOLVER_PCG_SCHUR, SOLVER_PCG, SOLVER_PCG_IDENTITY = 0, 1, 2
+SOLVER_PCG_SCHUR, SOLVER_PCG, SOLVER_PCG_IDENTITY, SOLVER_PCG_SCHUR_IMPLICIT = 0, 1, 2, 3
 LOSS_DEFAULT, LOSS_HUBER = 0, 1
 F32, F64 = 0, 1
 

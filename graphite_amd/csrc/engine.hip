@@ -10,7 +10,7 @@
 // The C ABI at the bottom (include/graphite_mi355x.h) is the drop-in boundary.
 #include "../../include/graphite_mi355x.h"
 #include "comm.hpp"
-#include "kernels_mf.hpp"
+#include "kernels_is.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -530,17 +530,20 @@ template <typename T> struct Engine final : EngineBase {
   void ensure_scalars(int max_iter) {
     const int cap = max_iter + 2;
     if (cap > sc_cap) { sc_cap = cap; sc_d.alloc((4 * (size_t)NS + 1) * cap); sc_i.alloc((size_t)cap + 1); }
+    alloc_pinned(cap);
   }
   PcgScalars scalars() {
     PcgScalars sc;
     const size_t blk = (size_t)sc_cap * NS;
     sc.rz = sc_d.p; sc.den = sc_d.p + blk; sc.rr = sc_d.p + 2 * blk; sc.pdp = sc_d.p + 3 * blk; sc.rz0 = sc_d.p + 4 * blk;
     sc.done = sc_i.p; sc.iters = sc_i.p + sc_cap;
+    sc.hflag = h_flag; sc.hiters = h_seq + 1;
     return sc;
   }
 
   void solver_update_structure(int solver) override {
     if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
+    else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) { want_hcp = false; ensure_implicit_schur(); }
     else {
       want_hcp = false;
       v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
@@ -613,20 +616,76 @@ template <typename T> struct Engine final : EngineBase {
 
   // PCGSchurSolver::solve (solver/pcg_schur.hpp:79-168); device-resident scalars,
   // no host round trip inside the loop.
+  // host side of the device-resident PCG loops: enqueue with one iteration of look-ahead and stop
+  // once the direction kernel has flagged (pinned memory) that the loop has left
+  template <typename Enqueue> void run_pcg_iterations(int max_iter, Enqueue &&enqueue) {
+    if (max_iter > 0) enqueue(0);
+    for (int k = 0; k < max_iter; ++k) {
+      if (k + 1 < max_iter) enqueue(k + 1);
+      spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
+      if (h_flag[k] == 2) break;
+    }
+  }
   int solve_pcg_schur(int max_iter, double tol, double rej, T *x) {
     schur_update_values();
     k_inv9<T, 0><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, S.p, S_diag.p, nullptr, 0.0, 0, MinvS.p, nullptr);
     ensure_scalars(max_iter);
     PcgScalars sc = scalars();
+    for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
+    h_seq[1] = 0;
     k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
-    k_pcgs_init<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, sc);
-    for (int k = 0; k < max_iter; ++k) {
+    k_pcgs_init<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, nullptr, nullptr, sc);
+    run_pcg_iterations(max_iter, [&](int k) {
       schur_matvec_dev(v_p.p, v_Ap.p, k);
       k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k);
-      k_pcgs_direction<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_p.p, v_z.p, sc, k, tol, rej);
-    }
+      k_pcgs_direction<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_p.p, v_z.p, nullptr, nullptr, sc, k, tol, rej);
+    });
     landmark_update_dev(x, x + pose_dim);
     return 0;
+  }
+
+  // Implicit Schur PCG (kernels_is.hpp): same iterates, S never formed, Jacobians recomputed.
+  DevBuf<T> Sdiag, zl, v_q;
+  void ensure_implicit_schur() {
+    Hll_inv.alloc(9 * (size_t)Np); Mp.alloc(9 * (size_t)Np); vl.alloc(3 * (size_t)Np); zl.alloc(3 * (size_t)Np);
+    Sdiag.alloc(81 * (size_t)Nc); MinvS.alloc(81 * (size_t)Nc); b_schur.alloc(pose_dim); v_q.alloc(pose_dim);
+    v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_Ap.alloc(n); v_xb.alloc(n);
+  }
+  void solve_pcg_schur_implicit(int max_iter, double tol, double rej, T *x) {
+    ensure_implicit_schur();
+    const int ui = damping_identity ? 1 : 0;
+    k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p);
+    {
+      Scope s0(this, "is_prepare", No * (2 * w() + 12.0) + (24.0 * Nc + 15.0 * Np) * w() + 54.0 * nseg * w(), No * 700.0);
+      k_is_prepare<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p);
+    }
+    k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p);
+    k_inv9<T, 2><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Sdiag.p, nullptr, nullptr, 0.0, 0, MinvS.p, nullptr);
+    ensure_scalars(max_iter);
+    PcgScalars sc = scalars();
+    for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
+    h_seq[1] = 0;
+    k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
+    k_pcgs_init<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, v_q.p, scales.p, sc);
+    const double pass_bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np + 9.0 * Nc) * w() + 3.0 * No * w();
+    run_pcg_iterations(max_iter, [&](int k) {
+      {
+        Scope s1(this, "is_pass1", pass_bytes, No * 290.0);
+        k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k);
+      }
+      k_is_points<T, 0><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, zl.p, sc, k);
+      {
+        Scope s2(this, "is_pass2", No * (2 * w() + 12.0) + (24.0 * Nc + 6.0 * Np) * w() + 9.0 * nseg * w(), No * 290.0);
+        k_is_pass2<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k);
+      }
+      k_is_apply<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, Hcc.p, scales.p, v_p.p, v_q.p, damping, ui, v_Ap.p, sc, k);
+      k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k);
+      k_pcgs_direction<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_p.p, v_z.p, v_q.p, scales.p, sc, k, tol, rej);
+    });
+    // back-substitution x_l = Hll^-1 (b_l - Hpl^T x_p): pass 1 with q = s_c .* x_c, then the per-point solve
+    k_mul<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((unsigned)pose_dim, v_q.p, scales.p, x);
+    k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1);
+    k_is_points<T, 1><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, x + pose_dim, sc, 0);
   }
 
   // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
@@ -739,7 +798,7 @@ template <typename T> struct Engine final : EngineBase {
   int last_solver = 0;
   int last_iters() {
     int it = 0;
-    const int *src = (last_solver == GR_SOLVER_PCG_SCHUR) ? sc_i.p + sc_cap : pcg_iters.p;
+    const int *src = (last_solver == GR_SOLVER_PCG_SCHUR || last_solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) ? sc_i.p + sc_cap : pcg_iters.p;
     GR_HIP(hipMemcpyAsync(&it, src, sizeof(int), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));
     return it;
@@ -750,6 +809,7 @@ template <typename T> struct Engine final : EngineBase {
     case GR_SOLVER_PCG_SCHUR: solve_pcg_schur(max_iter, tol, rej, x); return true;
     case GR_SOLVER_PCG: solve_pcg<false>(max_iter, tol, rej, x); return true;
     case GR_SOLVER_PCG_IDENTITY: solve_pcg<true>(max_iter, tol, rej, x); return true;
+    case GR_SOLVER_PCG_SCHUR_IMPLICIT: solve_pcg_schur_implicit(max_iter, tol, rej, x); return true;
     }
     throw std::invalid_argument("unknown solver");
   }
@@ -849,11 +909,8 @@ template <typename T> struct Engine final : EngineBase {
       // trial chi2 + compute_rho denominator (:20-47) in one kernel; its last block mirrors the two
       // sums into pinned host memory, so the host polls one word instead of memcpy + stream sync
       const int seq = chi2_async(nullptr, v_dx.p, (double)mu);
-      int it = 0;
-      if (opt.solver == GR_SOLVER_PCG_SCHUR) GR_HIP(hipMemcpyAsync(&it, sc_i.p + sc_cap, sizeof(int), hipMemcpyDeviceToHost, stream));
       wait_chi2(seq);
-      if (opt.solver == GR_SOLVER_PCG_SCHUR) GR_HIP(hipStreamSynchronize(stream));
-      else it = h_seq[1];
+      const int it = h_seq[1]; // every PCG variant mirrors its iteration count into pinned memory
       const double hs[2] = {h_res[0], h_res[1]};
       float ms = 0;
       (void)hipEventSynchronize(ev_b);

@@ -333,7 +333,7 @@ __global__ void k_backsub_fixup(int Np, int Nc, const T *__restrict__ Hll_inv, c
 
 // Inverse of the 9x9 diagonal blocks (block-Jacobi of S, block_jacobi_schur.hpp:114-150;
 // or of damped D Hcc^u D for the matrix-free PCG, block_jacobi.hpp:120-172).
-// MODE 0: src = S blocks via diag index.  MODE 1: src = Hcc^u, scaled + damped here;
+// MODE 0: src = S blocks via diag index (MODE 2: src[c] directly).  MODE 1: src = Hcc^u, scaled + damped here;
 // also writes the clamped scalar diagonal used by the operator damping (pcg.hpp:93-103).
 template <typename T, int MODE>
 __global__ void __launch_bounds__(64) k_inv9(int Nc, const T *__restrict__ src, const int *__restrict__ diag_blk,
@@ -342,8 +342,8 @@ __global__ void __launch_bounds__(64) k_inv9(int Nc, const T *__restrict__ src, 
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Nc) return;
   double A[81];
-  if (MODE == 0) {
-    const T *B = src + 81 * (size_t)diag_blk[c];
+  if (MODE == 0 || MODE == 2) {
+    const T *B = src + 81 * (size_t)(MODE == 0 ? diag_blk[c] : c);
 #pragma unroll
     for (int i = 0; i < 81; ++i) A[i] = (double)B[i];
   } else {
@@ -402,6 +402,8 @@ struct PcgScalars {
   double *rz, *den, *rr, *pdp; // [cap][NS]
   double *rz0;                 // [cap]
   int *done, *iters;           // [cap], [1]
+  volatile int *hflag;         // pinned host memory [cap]: 1 = iteration finished, 2 = loop left (may be null)
+  volatile int *hiters;        // pinned host mirror of iters (may be null)
 };
 
 // zero all slots, rz0[0] = +inf
@@ -466,7 +468,8 @@ k_schur_matvec(int Nc, const int *__restrict__ row_ptr, const int *__restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_pcgs_init(int Nc, const T *__restrict__ b, const T *__restrict__ Minv, T *__restrict__ r,
-            T *__restrict__ z, T *__restrict__ p, T *__restrict__ x, PcgScalars sc) {
+            T *__restrict__ z, T *__restrict__ p, T *__restrict__ x, T *__restrict__ q,
+            const T *__restrict__ scales, PcgScalars sc) {
   __shared__ double red[4];
   __shared__ T rs[TPB];
   const unsigned t = blockIdx.x * 252u + threadIdx.x;
@@ -483,6 +486,7 @@ k_pcgs_init(int Nc, const T *__restrict__ b, const T *__restrict__ Minv, T *__re
 #pragma unroll
     for (int q = 0; q < 9; ++q) s += M[row + 9 * q] * rc[q];
     r[t] = bv; z[t] = s; p[t] = s; x[t] = T(0);
+    if (q) q[t] = scales[t] * s;
     part = (double)(bv * s);
   }
   part = block_sum_256(part, red);
@@ -534,28 +538,37 @@ k_pcgs_update(int Nc, T *__restrict__ x, T *__restrict__ xb, T *__restrict__ r, 
 template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_pcgs_direction(int Nc, T *__restrict__ x, const T *__restrict__ xb, T *__restrict__ p,
-                 const T *__restrict__ z, PcgScalars sc, int k, double tol, double rejection_ratio) {
+                 const T *__restrict__ z, T *__restrict__ q, const T *__restrict__ scales, PcgScalars sc,
+                 int k, double tol, double rejection_ratio) {
   const unsigned t = blockIdx.x * TPB + threadIdx.x;
   const bool first = (t == 0);
   const double rz0 = sc.rz0[k];
-  if (sc.done[k]) { if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; } return; }
+  auto publish = [&](int flag) { if (sc.hflag) { sc.hflag[k] = flag; __threadfence_system(); } };
+  if (sc.done[k]) { if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; publish(2); } return; }
   const double rz = slot_sum(sc.rz, k);
   const double den = slot_sum(sc.den, k);
-  if (rz == 0.0 || den == 0.0 || den != den) { if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; } return; }
+  if (rz == 0.0 || den == 0.0 || den != den) { if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; publish(2); } return; }
   // T-precision scalars, as the reference keeps them in T on the host
   const T rz_new = (T)slot_sum(sc.rz, k + 1);
   const bool reject = (fabs((double)rz_new) > rejection_ratio * rz0) || (rz_new != rz_new);
   if (reject) {
     if (t < 9u * (unsigned)Nc) x[t] = xb[t];
-    if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; sc.iters[0] = k + 1; }
+    if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; sc.iters[0] = k + 1; if (sc.hiters) *sc.hiters = k + 1; publish(2); }
     return;
   }
   const T beta = rz_new / (T)rz;
-  if (t < 9u * (unsigned)Nc) p[t] = beta * p[t] + z[t];
+  if (t < 9u * (unsigned)Nc) {
+    const T pn = beta * p[t] + z[t];
+    p[t] = pn;
+    if (q) q[t] = scales[t] * pn;
+  }
   if (first) {
+    const int dn = (fabs((double)rz_new) < tol) ? 1 : 0;
     sc.rz0[k + 1] = fmin(rz0, fabs((double)rz_new));
-    sc.done[k + 1] = (fabs((double)rz_new) < tol) ? 1 : 0;
+    sc.done[k + 1] = dn;
     sc.iters[0] = k + 1;
+    if (sc.hiters) *sc.hiters = k + 1;
+    publish(dn ? 2 : 1);
   }
 }
 

@@ -46,7 +46,8 @@ typedef enum { GR_F32 = 0, GR_F64 = 1 } gr_dtype;
 typedef enum {
   GR_SOLVER_PCG_SCHUR = 0,    /* PCGSchurSolver + BlockJacobiSchurPreconditioner (solver/pcg_schur.hpp, preconditioner/block_jacobi_schur.hpp) */
   GR_SOLVER_PCG = 1,          /* PCGSolver + BlockJacobiPreconditioner (solver/pcg.hpp, preconditioner/block_jacobi.hpp)                      */
-  GR_SOLVER_PCG_IDENTITY = 2  /* PCGSolver + IdentityPreconditioner (preconditioner/identity.hpp)                                              */
+  GR_SOLVER_PCG_IDENTITY = 2, /* PCGSolver + IdentityPreconditioner (preconditioner/identity.hpp)                                              */
+  GR_SOLVER_PCG_SCHUR_IMPLICIT = 3 /* same iterates as GR_SOLVER_PCG_SCHUR, S applied as Hpp - Hpl Hll^-1 Hpl^T without forming it (kernels_is.hpp) */
 } gr_solver;
 
 typedef enum { GR_LOSS_DEFAULT = 0, GR_LOSS_HUBER = 1 } gr_loss; /* loss.hpp:15-51 */

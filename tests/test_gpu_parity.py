@@ -77,13 +77,14 @@ def test_schur_complement(oracle_mod, name, dtype):
     gpu.close()
 
 
-@pytest.mark.parametrize("solver", ["pcg_schur", "pcg", "pcg_identity"])
+@pytest.mark.parametrize("solver", ["pcg_schur", "pcg_schur_implicit", "pcg", "pcg_identity"])
 @pytest.mark.parametrize("name,dtype", [("mini-50", np.float64), ("mini-50", np.float32), ("ladybug-49", np.float64)])
 def test_solver_solve(oracle_mod, name, dtype, solver):
     prob, gpu, ref = make_pair(oracle_mod, name, dtype)
-    gs = dict(pcg_schur=ga.SOLVER_PCG_SCHUR, pcg=ga.SOLVER_PCG, pcg_identity=ga.SOLVER_PCG_IDENTITY)[solver]
+    gs = dict(pcg_schur=ga.SOLVER_PCG_SCHUR, pcg=ga.SOLVER_PCG, pcg_identity=ga.SOLVER_PCG_IDENTITY,
+              pcg_schur_implicit=ga.SOLVER_PCG_SCHUR_IMPLICIT)[solver]
     os_ = dict(pcg_schur=oracle_mod.SOLVER_PCG_SCHUR, pcg=oracle_mod.SOLVER_PCG,
-               pcg_identity=oracle_mod.SOLVER_PCG_IDENTITY)[solver]
+               pcg_identity=oracle_mod.SOLVER_PCG_IDENTITY, pcg_schur_implicit=oracle_mod.SOLVER_PCG_SCHUR)[solver]
     gpu.solver_update_structure(gs)
     gpu.linearize()
     gpu.solver_update_values(gs)
@@ -117,14 +118,15 @@ def test_pcg_schur_matches_direct_solve(oracle_mod):
     gpu.close()
 
 
-@pytest.mark.parametrize("solver", ["pcg_schur", "pcg"])
+@pytest.mark.parametrize("solver", ["pcg_schur", "pcg_schur_implicit", "pcg"])
 @pytest.mark.parametrize("name,dtype,rtol", [("mini-50", np.float64, 1e-9), ("ladybug-49", np.float64, 1e-8),
                                              ("ladybug-49", np.float32, 2e-3)])
 def test_levenberg_marquardt_trace(oracle_mod, name, dtype, rtol, solver):
     """Whole LM loop: chi2 and lambda traces against the oracle (north star: 1e-6 relative in fp64)."""
     prob, gpu, ref = make_pair(oracle_mod, name, dtype)
-    gs = dict(pcg_schur=ga.SOLVER_PCG_SCHUR, pcg=ga.SOLVER_PCG)[solver]
-    os_ = dict(pcg_schur=oracle_mod.SOLVER_PCG_SCHUR, pcg=oracle_mod.SOLVER_PCG)[solver]
+    gs = dict(pcg_schur=ga.SOLVER_PCG_SCHUR, pcg=ga.SOLVER_PCG, pcg_schur_implicit=ga.SOLVER_PCG_SCHUR_IMPLICIT)[solver]
+    os_ = dict(pcg_schur=oracle_mod.SOLVER_PCG_SCHUR, pcg=oracle_mod.SOLVER_PCG,
+               pcg_schur_implicit=oracle_mod.SOLVER_PCG_SCHUR)[solver]
     ct_g, lt_g, st = gpu.levenberg_marquardt(solver=gs, iterations=8)
     ct_r, lt_r, st_r = ref.levenberg_marquardt(solver=os_, iterations=8)
     assert len(ct_g) == len(ct_r)
