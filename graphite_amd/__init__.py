@@ -5,8 +5,8 @@ The product is ``libgraphite_mi355x.so`` (HIP kernels + C-ABI, see
 tests and ``bench.py``.  Nothing here imports ``oracle/``.
 """
 from . import _lib, synth  # noqa: F401
-from .bal import (BalProblem, SOLVER_PCG, SOLVER_PCG_IDENTITY, SOLVER_PCG_SCHUR, SOLVER_PCG_SCHUR_IMPLICIT,  # noqa: F401
+from .bal import (BalProblem, dense_cholesky_solve, SOLVER_PCG, SOLVER_PCG_IDENTITY, SOLVER_PCG_SCHUR, SOLVER_PCG_SCHUR_IMPLICIT, SOLVER_DENSE_SCHUR,  # noqa: F401
                   LOSS_DEFAULT, LOSS_HUBER)
 
-__all__ = ["BalProblem", "synth", "SOLVER_PCG", "SOLVER_PCG_IDENTITY", "SOLVER_PCG_SCHUR", "SOLVER_PCG_SCHUR_IMPLICIT",
+__all__ = ["BalProblem", "synth", "SOLVER_PCG", "SOLVER_PCG_IDENTITY", "SOLVER_PCG_SCHUR", "SOLVER_PCG_SCHUR_IMPLICIT", "SOLVER_DENSE_SCHUR", "dense_cholesky_solve",
            "LOSS_DEFAULT", "LOSS_HUBER"]

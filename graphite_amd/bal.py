@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from ._lib import LMOptions, LMStats, KernelStat, check
 
-SOLVER_PCG_SCHUR, SOLVER_PCG, SOLVER_PCG_IDENTITY, SOLVER_PCG_SCHUR_IMPLICIT = 0, 1, 2, 3
+SOLVER_PCG_SCHUR, SOLVER_PCG, SOLVER_PCG_IDENTITY, SOLVER_PCG_SCHUR_IMPLICIT, SOLVER_DENSE_SCHUR = 0, 1, 2, 3, 4
 LOSS_DEFAULT, LOSS_HUBER = 0, 1
 F32, F64 = 0, 1
 
@@ -170,3 +170,25 @@ class BalProblem:
             out[k.name.decode()] = dict(launches=k.launches, total_ms=k.total_ms,
                                         bytes_per_launch=k.bytes_per_launch, flops_per_launch=k.flops_per_launch)
         return out
+
+
+def dense_cholesky_solve(A, b, device=0):
+    """x = A^-1 b on the MFMA Cholesky of GR_SOLVER_DENSE_SCHUR (gr_dense_cholesky_solve).
+
+    A: (n, n) SPD, numpy (host) or torch CUDA tensor, row-major, lower triangle read; b: (n,).
+    Returns (x as numpy array, device seconds of the factorisation)."""
+    L = _lib.lib()
+    n = A.shape[0]
+    if isinstance(A, np.ndarray):
+        dt = A.dtype
+        A = np.ascontiguousarray(A)
+        lda = A.strides[0] // A.itemsize
+    else:
+        dt = np.float64 if A.element_size() == 8 else np.float32
+        lda = A.stride(0)
+    b = np.ascontiguousarray(np.asarray(b, dt))
+    x = np.zeros(n, dt)
+    sec = C.c_double()
+    check(L.gr_dense_cholesky_solve(C.c_int(F64 if dt == np.float64 else F32), C.c_int64(n), _ptr(A), C.c_int64(lda),
+                                    _ptr(b), _ptr(x), C.c_int(device), None, C.byref(sec)))
+    return x, sec.value

@@ -1,0 +1,480 @@
+// Dense, tile-sparse Cholesky solve of the reduced camera system S x = b_S on MFMA.
+//
+// Role in the reference: the direct inner solvers EigenSchurLDLTSolver::solve
+// (solver/eigen_schur.hpp:71-108: CPU SimplicialLDLT on the upper CSC of S) and
+// cudssSchurSolver::solve (solver/cudss_schur.hpp:190-234).  Here S is expanded into a dense
+// row-major lower triangle padded to 128x128 tiles and factorised right-looking, S = L L^T:
+//
+//   per panel k:  k_chol_potrf   L_kk = chol(A_kk), Linv_k = L_kk^-1           (one workgroup, LDS)
+//                 k_chol_gemm<0> L_ik = A_ik Linv_k^T          for tiles i in rows(k)   (MFMA)
+//                 k_chol_gemm<1> A_ij -= L_ik L_jk^T           for i >= j in rows(k)    (MFMA)
+//
+// rows(k) comes from a tile-level symbolic factorisation on the host, so a block-banded S
+// (Ladybug-like camera graphs) only touches the tiles inside its filled band, while a
+// Venice-like S degenerates to the fully dense factorisation.  The GEMM is the one true
+// contraction on the whole path and the only place MFMA is used: v_mfma_f64_16x16x4_f64 /
+// v_mfma_f32_16x16x4_f32, 128x128 tile per 256-thread workgroup, 64x64 per wave.
+#pragma once
+#include "common.hpp"
+#include <algorithm>
+#include <functional>
+
+namespace gr {
+
+constexpr int CH_NB = 128;         // panel width == tile edge
+constexpr int CH_KC = 16;          // K chunk staged through LDS per pipeline step
+constexpr int CH_LDP = CH_NB + 4;  // LDS pitch of the [k][row] operand images
+constexpr int CH_PT = 256;         // threads of the panel-factor workgroup
+constexpr int CH_LP = CH_NB + 1;   // LDS pitch of the 128x128 diagonal block
+
+template <typename T> struct MfmaTile;
+template <> struct MfmaTile<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  // v_mfma_f64_16x16x4_f64: D[row][lane & 15], row = (lane >> 4) + 4 * reg
+  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct MfmaTile<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  // v_mfma_f32_16x16x4_f32: D[row][lane & 15], row = 4 * (lane >> 4) + reg
+  static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+template <typename T> __device__ __forceinline__ void load8(const T *p, T (&v)[8]);
+template <> __device__ __forceinline__ void load8<double>(const double *p, double (&v)[8]) {
+  const double2 *q = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+}
+template <> __device__ __forceinline__ void load8<float>(const float *p, float (&v)[8]) {
+  const float4 *q = reinterpret_cast<const float4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const float4 t = q[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+}
+
+// C = P Q^T  (MODE 0, C overwrites P: the panel solve with Q = Linv_k)
+// C -= P Q^T (MODE 1, the trailing update; P, Q = panel tiles of rows ti, tj)
+// One 128x128 tile of C per workgroup; K = 128 in 8 chunks of 16, double-buffered through LDS.
+// For MODE 1 the accumulators start as C and P is negated on its way into LDS, so the epilogue
+// is a plain store and the C read overlaps the first operand fetch.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, const int *__restrict__ tiles, int k0, const T *__restrict__ Linv) {
+  extern __shared__ __align__(16) unsigned char ch_smem[];
+  T *sm = reinterpret_cast<T *>(ch_smem);
+  using M = MfmaTile<T>;
+  typedef typename M::acc_t acc_t;
+  const int ti = MODE == 0 ? tiles[blockIdx.x] : tiles[2 * blockIdx.x];
+  const int tj = MODE == 0 ? 0 : tiles[2 * blockIdx.x + 1];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+  const T *Pg = A + (size_t)ti * CH_NB * ld + k0;
+  const T *Qg = MODE == 0 ? Linv : A + (size_t)tj * CH_NB * ld + k0;
+  const int ldq = MODE == 0 ? CH_NB : ld;
+  T *Cg = MODE == 0 ? A + (size_t)ti * CH_NB * ld + k0 : A + (size_t)ti * CH_NB * ld + (size_t)tj * CH_NB;
+
+  acc_t acc[4][4];
+  const int ccol = lane & 15;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (MODE == 1) acc[mi][ni][r] = Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld + wc * 64 + ni * 16 + ccol];
+        else acc[mi][ni][r] = T(0);
+      }
+
+  const int lr = t >> 1, lk = (t & 1) * 8; // loader role: tile row, first k of its 8
+  T pp[8], pq[8];
+  load8<T>(Pg + (size_t)lr * ld + lk, pp);
+  load8<T>(Qg + (size_t)lr * ldq + lk, pq);
+  constexpr int BUF = 2 * CH_KC * CH_LDP;
+  {
+    T *Ps = sm, *Qs = sm + CH_KC * CH_LDP;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { Ps[(lk + e) * CH_LDP + lr] = MODE == 1 ? -pp[e] : pp[e]; Qs[(lk + e) * CH_LDP + lr] = pq[e]; }
+  }
+  __syncthreads();
+  constexpr int NCH = CH_NB / CH_KC;
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) {
+      load8<T>(Pg + (size_t)lr * ld + (c + 1) * CH_KC + lk, pp);
+      load8<T>(Qg + (size_t)lr * ldq + (c + 1) * CH_KC + lk, pq);
+    }
+    const T *Ps = sm + (c & 1) * BUF, *Qs = Ps + CH_KC * CH_LDP;
+#pragma unroll
+    for (int kk = 0; kk < CH_KC / 4; ++kk) {
+      const int krow = (kk * 4 + (lane >> 4)) * CH_LDP + ccol;
+      T a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = Ps[krow + wr * 64 + i * 16]; b[i] = Qs[krow + wc * 64 + i * 16]; }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(a[mi], b[ni], acc[mi][ni]);
+    }
+    if (c + 1 < NCH) {
+      T *Pn = sm + ((c + 1) & 1) * BUF, *Qn = Pn + CH_KC * CH_LDP;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { Pn[(lk + e) * CH_LDP + lr] = MODE == 1 ? -pp[e] : pp[e]; Qn[(lk + e) * CH_LDP + lr] = pq[e]; }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld + wc * 64 + ni * 16 + ccol] = acc[mi][ni][r];
+}
+constexpr size_t chol_gemm_lds(size_t w) { return 2 * 2 * CH_KC * CH_LDP * w; }
+
+template <typename T> __device__ __forceinline__ T lane_bcast(T v, int src);
+template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+template <> __device__ __forceinline__ double lane_bcast<double>(double v, int src) {
+  const int2 u = __builtin_bit_cast(int2, v);
+  int2 r;
+  r.x = __builtin_amdgcn_readlane(u.x, src);
+  r.y = __builtin_amdgcn_readlane(u.y, src);
+  return __builtin_bit_cast(double, r);
+}
+
+// Diagonal block: L = chol(A_kk) and X = L^-1, entirely in LDS, blocked by 16 so that only the eight
+// 16x16 diagonal sub-blocks are sequential (one wave, rows in registers, readlane broadcasts) and
+// everything else (sub-panel solve, trailing update, blocked inverse) is 16x16x4 MFMA on LDS data.
+// X^T lives in the unused strictly-upper part of the same LDS image; the diagonal of X in xd[].
+// Writes L back into A (lower part) and X as a full 128x128 row-major matrix (zeros above the
+// diagonal) for the panel GEMM and the solves.  A pivot that is not > 0 raises *fail and is
+// replaced by 1 so that the rest stays finite.
+template <typename T>
+__global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld, int k0, T *__restrict__ Linv, int *__restrict__ fail) {
+  extern __shared__ __align__(16) unsigned char ch_smem[];
+  using M = MfmaTile<T>;
+  typedef typename M::acc_t acc_t;
+  T *L = reinterpret_cast<T *>(ch_smem); // [128][129]
+  T *xd = L + CH_NB * CH_LP;             // diag of X
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, cl = lane & 15, g = lane >> 4;
+  constexpr int NW = CH_PT / 64, NB16 = CH_NB / 16;
+  T *Ag = A + (size_t)k0 * ld + k0;
+  for (int e = t; e < CH_NB * CH_NB; e += CH_PT) {
+    const int r = e >> 7, c = e & 127;
+    L[r * CH_LP + c] = c <= r ? Ag[(size_t)r * ld + c] : T(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < NB16; ++s) {
+    const int o = 16 * s;
+    if (wave == 0) {
+      // 16x16 Cholesky + inverse: lane r (mod 16) owns row r of the block, then column r of X
+      T a[16], x[16], rsv[16];
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = k <= cl ? L[(o + cl) * CH_LP + o + k] : T(0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        T d = lane_bcast<T>(a[j], j);
+        if (!(d > T(0))) { bad = true; d = T(1); }
+        const T sq = sqrt(d);
+        rsv[j] = T(1) / sq;
+        a[j] = cl == j ? sq : a[j] * rsv[j];
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] -= a[j] * lane_bcast<T>(a[j], k);
+      }
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        T sum = T(0);
+#pragma unroll
+        for (int k = 0; k < m; ++k) sum += lane_bcast<T>(a[k], m) * x[k];
+        x[m] = ((m == cl ? T(1) : T(0)) - sum) * rsv[m];
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          if (k <= cl) L[(o + cl) * CH_LP + o + k] = a[k];
+          if (k > cl) L[(o + cl) * CH_LP + o + k] = x[k];
+        }
+        xd[o + cl] = x[cl];
+      }
+      if (bad && lane == 0) *fail = 1;
+    }
+    __syncthreads();
+    // sub-panel solve: L_is = A_is X_ss^T for the 16-row blocks below
+    for (int bi = s + 1 + wave; bi < NB16; bi += NW) {
+      acc_t acc = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * kk + g;
+        const T av = L[(16 * bi + cl) * CH_LP + o + k];
+        const T bv = cl > k ? L[(o + k) * CH_LP + o + cl] : (cl == k ? xd[o + cl] : T(0));
+        acc = M::mma(av, bv, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L[(16 * bi + M::row(lane, r)) * CH_LP + o + cl] = acc[r];
+    }
+    __syncthreads();
+    // trailing update of the 16x16 tiles (bi >= bk > s): A_ik -= L_is L_ks^T
+    const int m = NB16 - 1 - s, ntile = m * (m + 1) / 2;
+    for (int q = wave; q < ntile; q += NW) {
+      int bi = 0, rem = q;
+      while (rem > bi) { rem -= bi + 1; ++bi; } // q -> (bi, bk) in the lower triangle
+      const int ti = s + 1 + bi, tk = s + 1 + rem;
+      acc_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = L[(16 * ti + M::row(lane, r)) * CH_LP + 16 * tk + cl];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * kk + g;
+        acc = M::mma(-L[(16 * ti + cl) * CH_LP + o + k], L[(16 * tk + cl) * CH_LP + o + k], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L[(16 * ti + M::row(lane, r)) * CH_LP + 16 * tk + cl] = acc[r];
+    }
+    __syncthreads();
+  }
+  // blocked inverse: X_ij = -X_ii sum_{k=j}^{i-1} L_ik X_kj, block row by block row
+  for (int i = 1; i < NB16; ++i) {
+    for (int j = wave; j < i; j += NW) {
+      acc_t tacc = {T(0), T(0), T(0), T(0)};
+      for (int k = j; k < i; ++k) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int kr = 4 * kk + g;
+          const T av = L[(16 * i + cl) * CH_LP + 16 * k + kr];
+          T bv;
+          if (k == j) bv = kr > cl ? L[(16 * j + cl) * CH_LP + 16 * j + kr] : (kr == cl ? xd[16 * j + cl] : T(0));
+          else bv = L[(16 * j + cl) * CH_LP + 16 * k + kr];
+          tacc = M::mma(av, bv, tacc);
+        }
+      }
+      acc_t xacc = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int kr = M::row(lane, kk); // the row of T this lane holds in register kk is the k it feeds
+        const T av = cl > kr ? L[(16 * i + kr) * CH_LP + 16 * i + cl] : (cl == kr ? xd[16 * i + cl] : T(0));
+        xacc = M::mma(av, tacc[kk], xacc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L[(16 * j + cl) * CH_LP + 16 * i + M::row(lane, r)] = -xacc[r];
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < CH_NB * CH_NB; e += CH_PT) {
+    const int r = e >> 7, cc = e & 127;
+    if (cc <= r) Ag[(size_t)r * ld + cc] = L[r * CH_LP + cc];
+    Linv[e] = cc < r ? L[cc * CH_LP + r] : (cc == r ? xd[r] : T(0));
+  }
+}
+constexpr size_t chol_potrf_lds(size_t w) { return (CH_NB * CH_LP + CH_NB) * w; }
+
+// zero the structurally non-zero lower tiles; padded diagonal entries (>= n) become 1
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_clear(T *__restrict__ A, int ld, int n, const int *__restrict__ tiles) {
+  const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
+  T *Cg = A + (size_t)ti * CH_NB * ld + (size_t)tj * CH_NB;
+  for (int e = threadIdx.x; e < CH_NB * CH_NB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    const int R = ti * CH_NB + r, C = tj * CH_NB + c;
+    Cg[(size_t)r * ld + c] = (R == C && R >= n) ? T(1) : T(0);
+  }
+}
+
+// scatter the upper 9x9 blocks of S (column-major blocks, block (i <= j)) into the dense lower triangle
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_scatter(int64_t nnzb, const int *__restrict__ rowi, const int *__restrict__ coli, const T *__restrict__ S, T *__restrict__ A, int ld) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= 81 * nnzb) return;
+  const int64_t q = e / 81;
+  const int w = (int)(e - 81 * q), c = w / 9, r = w - 9 * c; // S_q(r, c) at global (9 i + r, 9 j + c)
+  const int R = 9 * coli[q] + c, C = 9 * rowi[q] + r;          // mirrored into the lower triangle
+  if (R >= C) A[(size_t)R * ld + C] = S[e];
+}
+
+template <typename T> __global__ void k_chol_rhs(int n, int npad, const T *__restrict__ b, T *__restrict__ vb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npad) vb[i] = i < n ? b[i] : T(0);
+}
+
+// forward step k: y_k = Linv_k b_k (every workgroup, into LDS); workgroup 0 stores y_k, workgroup
+// w >= 1 applies b_i -= L_ik y_k for its tile row i = rows[w - 1]
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_fwd(const T *__restrict__ A, int ld, const T *__restrict__ Linv, int k0, const int *__restrict__ rows, T *__restrict__ b, T *__restrict__ y) {
+  __shared__ T yk[CH_NB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const T b0 = b[k0 + lane], b1 = b[k0 + 64 + lane];
+  for (int r = wave * 32; r < wave * 32 + 32; ++r) {
+    T s = Linv[r * CH_NB + lane] * b0 + Linv[r * CH_NB + 64 + lane] * b1;
+    s = wave_sum(s);
+    if (lane == 0) yk[r] = s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (t < CH_NB) y[k0 + t] = yk[t];
+    return;
+  }
+  const int ti = rows[blockIdx.x - 1];
+  const T y0 = yk[lane], y1 = yk[64 + lane];
+  const T *Lg = A + (size_t)ti * CH_NB * ld + k0;
+  for (int r = wave * 32; r < wave * 32 + 32; ++r) {
+    T s = Lg[(size_t)r * ld + lane] * y0 + Lg[(size_t)r * ld + 64 + lane] * y1;
+    s = wave_sum(s);
+    if (lane == 0) b[ti * CH_NB + r] -= s;
+  }
+}
+
+// backward step k, part 1: partial[w][c] = sum_r L_ik[r][c] x_i[r] for tile row i = rows[w]
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_bwd_partial(const T *__restrict__ A, int ld, int k0, const int *__restrict__ rows, const T *__restrict__ x, T *__restrict__ partial) {
+  __shared__ T half[CH_NB];
+  const int t = threadIdx.x, c = t & 127, h = t >> 7;
+  const int ti = rows[blockIdx.x];
+  const T *Lg = A + (size_t)(ti * CH_NB + h * 64) * ld + k0 + c;
+  const T *xg = x + ti * CH_NB + h * 64;
+  T s = T(0);
+#pragma unroll 8
+  for (int r = 0; r < 64; ++r) s += Lg[(size_t)r * ld] * xg[r];
+  if (h == 1) half[c] = s;
+  __syncthreads();
+  if (h == 0) partial[(size_t)blockIdx.x * CH_NB + c] = s + half[c];
+}
+// part 2: x_k = Linv_k^T (y_k - sum_w partial[w])
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_bwd_final(const T *__restrict__ Linv, int k0, int nrows, const T *__restrict__ partial, const T *__restrict__ y, T *__restrict__ x) {
+  __shared__ T v[CH_NB];
+  __shared__ T half[CH_NB];
+  const int t = threadIdx.x, c = t & 127, h = t >> 7;
+  if (h == 0) {
+    T s = y[k0 + c];
+    for (int w = 0; w < nrows; ++w) s -= partial[(size_t)w * CH_NB + c];
+    v[c] = s;
+  }
+  __syncthreads();
+  T s = T(0);
+#pragma unroll 8
+  for (int r = h * 64; r < h * 64 + 64; ++r) s += Linv[r * CH_NB + c] * v[r];
+  if (h == 1) half[c] = s;
+  __syncthreads();
+  if (h == 0) x[k0 + c] = s + half[c];
+}
+
+struct CholProfSink {
+  virtual void begin(const char *name, double bytes, double flops) = 0;
+  virtual void end() = 0;
+  virtual ~CholProfSink() = default;
+};
+
+// Host side: tile-level symbolic factorisation + the launch sequence.
+template <typename T> struct DenseChol {
+  hipStream_t stream = nullptr;
+  int n = 0, npad = 0, nt = 0;
+  DevBuf<T> A, Linv, vb, vy, vx, partial;
+  DevBuf<int> d_rows, d_pairs, d_nz, d_fail;
+  std::vector<int> row_off, pair_off; // per-panel offsets into d_rows / d_pairs (pairs counted in pairs)
+  int nz_tiles = 0, max_rows = 0;
+  int64_t total_pairs = 0, total_rows = 0;
+  int *h_fail = nullptr;
+  CholProfSink *sink = nullptr;
+  bool attrs_set = false;
+
+  ~DenseChol() { if (h_fail) (void)hipHostFree(h_fail); }
+
+  static size_t bytes_needed(int64_t n_) {
+    const int64_t np = (n_ + CH_NB - 1) / CH_NB * CH_NB;
+    return (size_t)np * np * sizeof(T);
+  }
+  // tile_nz: nt*nt, [i*nt + j] != 0 for structurally non-zero lower tiles (i >= j); empty = dense
+  void set_structure(int n_, std::vector<char> tile_nz, hipStream_t s) {
+    stream = s; n = n_; nt = (n + CH_NB - 1) / CH_NB; npad = nt * CH_NB;
+    if (tile_nz.empty()) tile_nz.assign((size_t)nt * nt, 1);
+    for (int i = 0; i < nt; ++i) tile_nz[(size_t)i * nt + i] = 1;
+    std::vector<int> h_rows, h_pairs, h_nz;
+    row_off.assign(nt + 1, 0); pair_off.assign(nt + 1, 0);
+    max_rows = 0;
+    std::vector<int> rk;
+    for (int k = 0; k < nt; ++k) {
+      rk.clear();
+      for (int i = k + 1; i < nt; ++i) if (tile_nz[(size_t)i * nt + k]) rk.push_back(i);
+      for (int i : rk) h_rows.push_back(i);
+      for (size_t a = 0; a < rk.size(); ++a)
+        for (size_t b = 0; b <= a; ++b) {
+          tile_nz[(size_t)rk[a] * nt + rk[b]] = 1; // fill-in
+          h_pairs.push_back(rk[a]); h_pairs.push_back(rk[b]);
+        }
+      row_off[k + 1] = (int)h_rows.size(); pair_off[k + 1] = (int)(h_pairs.size() / 2);
+      max_rows = std::max(max_rows, (int)rk.size());
+    }
+    for (int i = 0; i < nt; ++i)
+      for (int j = 0; j <= i; ++j) if (tile_nz[(size_t)i * nt + j]) { h_nz.push_back(i); h_nz.push_back(j); }
+    nz_tiles = (int)(h_nz.size() / 2);
+    total_pairs = (int64_t)h_pairs.size() / 2; total_rows = (int64_t)h_rows.size();
+    if (h_rows.empty()) h_rows.push_back(0);
+    if (h_pairs.empty()) { h_pairs.push_back(0); h_pairs.push_back(0); }
+    d_rows.upload(h_rows, stream); d_pairs.upload(h_pairs, stream); d_nz.upload(h_nz, stream);
+    A.alloc((size_t)npad * npad); Linv.alloc((size_t)nt * CH_NB * CH_NB);
+    vb.alloc(npad); vy.alloc(npad); vx.alloc(npad); partial.alloc((size_t)std::max(max_rows, 1) * CH_NB);
+    d_fail.alloc(1);
+    if (!h_fail) GR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_fail), sizeof(int), hipHostMallocDefault));
+    if (!attrs_set) {
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_gemm<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_gemm<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_potrf<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_potrf_lds(sizeof(T))));
+      attrs_set = true;
+    }
+    GR_HIP(hipStreamSynchronize(stream));
+  }
+  int ld() const { return npad; }
+  double factor_flops() const { return (total_rows + total_pairs) * 2.0 * CH_NB * CH_NB * CH_NB + nt * (2.0 / 3.0) * CH_NB * CH_NB * CH_NB; }
+
+  void clear() {
+    k_chol_clear<T><<<nz_tiles, 256, 0, stream>>>(A.p, npad, n, d_nz.p);
+  }
+  struct Sc {
+    CholProfSink *s;
+    Sc(CholProfSink *s_, const char *nm, double by, double fl) : s(s_) { if (s) s->begin(nm, by, fl); }
+    ~Sc() { if (s) s->end(); }
+  };
+  void factor() {
+    GR_HIP(hipMemsetAsync(d_fail.p, 0, sizeof(int), stream));
+    const double w = sizeof(T), tile_b = (double)CH_NB * CH_NB * w, tile_f = 2.0 * CH_NB * CH_NB * CH_NB;
+    for (int k = 0; k < nt; ++k) {
+      T *Lk = Linv.p + (size_t)k * CH_NB * CH_NB;
+      {
+        Sc sc(sink, "chol_potrf", 3 * tile_b, tile_f / 3);
+        k_chol_potrf<T><<<1, CH_PT, chol_potrf_lds(sizeof(T)), stream>>>(A.p, npad, k * CH_NB, Lk, d_fail.p);
+      }
+      const int nr = row_off[k + 1] - row_off[k], npr = pair_off[k + 1] - pair_off[k];
+      if (nr) {
+        Sc sc(sink, "chol_trsm", (2.0 * nr + 1) * tile_b, nr * tile_f);
+        k_chol_gemm<T, 0><<<nr, 256, chol_gemm_lds(sizeof(T)), stream>>>(A.p, npad, d_rows.p + row_off[k], k * CH_NB, Lk);
+      }
+      if (npr) {
+        Sc sc(sink, "chol_syrk", (2.0 * npr + nr) * tile_b, npr * tile_f);
+        k_chol_gemm<T, 1><<<npr, 256, chol_gemm_lds(sizeof(T)), stream>>>(A.p, npad, d_pairs.p + 2 * (size_t)pair_off[k], k * CH_NB, nullptr);
+      }
+    }
+  }
+  // b, x: device vectors of length n (x may alias b)
+  void solve(const T *b, T *x) {
+    Sc sc(sink, "chol_solve", 2.0 * (total_rows + 2.0 * nt) * CH_NB * CH_NB * sizeof(T), 4.0 * (total_rows + nt) * CH_NB * CH_NB);
+    k_chol_rhs<T><<<(npad + 255) / 256, 256, 0, stream>>>(n, npad, b, vb.p);
+    for (int k = 0; k < nt; ++k) {
+      const int nr = row_off[k + 1] - row_off[k];
+      k_chol_fwd<T><<<1 + nr, 256, 0, stream>>>(A.p, npad, Linv.p + (size_t)k * CH_NB * CH_NB, k * CH_NB, d_rows.p + row_off[k], vb.p, vy.p);
+    }
+    for (int k = nt - 1; k >= 0; --k) {
+      const int nr = row_off[k + 1] - row_off[k];
+      if (nr) k_chol_bwd_partial<T><<<nr, 256, 0, stream>>>(A.p, npad, k * CH_NB, d_rows.p + row_off[k], vx.p, partial.p);
+      k_chol_bwd_final<T><<<1, 256, 0, stream>>>(Linv.p + (size_t)k * CH_NB * CH_NB, k * CH_NB, nr, partial.p, vy.p, vx.p);
+    }
+    GR_HIP(hipMemcpyAsync(x, vx.p, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+  }
+  // true when every pivot was positive (synchronises the stream)
+  bool ok() {
+    GR_HIP(hipMemcpyAsync(h_fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+    return *h_fail == 0;
+  }
+};
+
+} // namespace gr

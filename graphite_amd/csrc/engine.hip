@@ -11,6 +11,7 @@
 #include "../../include/graphite_mi355x.h"
 #include "comm.hpp"
 #include "kernels_is.hpp"
+#include "chol.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -543,6 +544,7 @@ template <typename T> struct Engine final : EngineBase {
 
   void solver_update_structure(int solver) override {
     if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
+    else if (solver == GR_SOLVER_DENSE_SCHUR) { ensure_chol(); want_hcp = true; }
     else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) { want_hcp = false; ensure_implicit_schur(); }
     else {
       want_hcp = false;
@@ -553,7 +555,7 @@ template <typename T> struct Engine final : EngineBase {
   // H.update_values / preconditioner->update_values: the blocks are produced by
   // linearize() already (fused); only the Hcp blocks may have to be (re)built.
   void solver_update_values(int solver) override {
-    if (solver == GR_SOLVER_PCG_SCHUR && !hcp_valid) linearize_impl(true);
+    if ((solver == GR_SOLVER_PCG_SCHUR || solver == GR_SOLVER_DENSE_SCHUR) && !hcp_valid) linearize_impl(true);
   }
   void solver_set_damping(int solver, double mu, bool use_identity) override {
     damping = mu; damping_identity = use_identity;
@@ -642,6 +644,48 @@ template <typename T> struct Engine final : EngineBase {
     });
     landmark_update_dev(x, x + pose_dim);
     return 0;
+  }
+
+  // Direct solve of the reduced camera system (chol.hpp): the role of EigenSchurLDLTSolver::solve
+  // (solver/eigen_schur.hpp:71-108) / cudssSchurSolver::solve (cudss_schur.hpp:190-234), then
+  // compute_landmark_update (schur.hpp:279-302).
+  DenseChol<T> chol;
+  bool chol_ready = false;
+  struct CholSink : CholProfSink {
+    Engine *e; std::vector<std::unique_ptr<Scope>> open;
+    explicit CholSink(Engine *e_) : e(e_) {}
+    void begin(const char *name, double bytes, double flops) override { open.emplace_back(new Scope(e, name, bytes, flops)); }
+    void end() override { open.pop_back(); }
+  };
+  std::unique_ptr<CholSink> chol_sink;
+  void ensure_chol() {
+    build_schur_structure();
+    if (chol_ready) return;
+    if (DenseChol<T>::bytes_needed((int64_t)pose_dim) > ((size_t)96 << 30))
+      throw std::invalid_argument("dense reduced camera system does not fit (9 Nc padded squared > 96 GiB)");
+    const int nt = (int)((pose_dim + CH_NB - 1) / CH_NB);
+    std::vector<char> tz((size_t)nt * nt, 0);
+    for (int64_t q = 0; q < nnzb; ++q) {
+      const int i = h_S_rowi[q], j = h_S_coli[q]; // upper block (i <= j) -> lower rows 9j.., cols 9i..
+      const int r0 = 9 * j / CH_NB, r1 = (9 * j + 8) / CH_NB, c0 = 9 * i / CH_NB, c1 = (9 * i + 8) / CH_NB;
+      for (int r = r0; r <= r1; ++r)
+        for (int c = c0; c <= c1; ++c) if (r >= c) tz[(size_t)r * nt + c] = 1;
+    }
+    chol.set_structure((int)pose_dim, std::move(tz), stream);
+    chol_sink.reset(new CholSink(this));
+    chol.sink = chol_sink.get();
+    chol_ready = true;
+  }
+  bool solve_dense_schur(T *x) {
+    ensure_chol();
+    schur_update_values();
+    chol.clear();
+    k_chol_scatter<T><<<cdiv(81 * (size_t)nnzb, TPB), TPB, 0, stream>>>(nnzb, S_rowi.p, S_coli.p, S.p, chol.A.p, chol.ld());
+    chol.factor();
+    chol.solve(b_schur.p, x);
+    landmark_update_dev(x, x + pose_dim);
+    h_seq[1] = 0;
+    return chol.ok();
   }
 
   // Implicit Schur PCG (kernels_is.hpp): same iterates, S never formed, Jacobians recomputed.
@@ -798,6 +842,7 @@ template <typename T> struct Engine final : EngineBase {
   int last_solver = 0;
   int last_iters() {
     int it = 0;
+    if (last_solver == GR_SOLVER_DENSE_SCHUR) return 0;
     const int *src = (last_solver == GR_SOLVER_PCG_SCHUR || last_solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) ? sc_i.p + sc_cap : pcg_iters.p;
     GR_HIP(hipMemcpyAsync(&it, src, sizeof(int), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));
@@ -810,6 +855,7 @@ template <typename T> struct Engine final : EngineBase {
     case GR_SOLVER_PCG: solve_pcg<false>(max_iter, tol, rej, x); return true;
     case GR_SOLVER_PCG_IDENTITY: solve_pcg<true>(max_iter, tol, rej, x); return true;
     case GR_SOLVER_PCG_SCHUR_IMPLICIT: solve_pcg_schur_implicit(max_iter, tol, rej, x); return true;
+    case GR_SOLVER_DENSE_SCHUR: return solve_dense_schur(x);
     }
     throw std::invalid_argument("unknown solver");
   }
@@ -977,6 +1023,31 @@ template <typename F> static gr_status guarded(gr_bal_problem *p, F &&f) {
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
 }
 
+// standalone entry to the MFMA Cholesky (chol.hpp): A is n x n row-major with leading dimension lda,
+// symmetric positive definite, only its lower triangle is read
+template <typename T> static void dense_cholesky_solve_impl(int64_t n, const void *A, int64_t lda, const void *b, void *x, hipStream_t stream, double *seconds) {
+  DenseChol<T> ch;
+  ch.set_structure((int)n, {}, stream);
+  GR_HIP(hipMemsetAsync(ch.A.p, 0, ch.A.n * sizeof(T), stream));
+  ch.clear();
+  GR_HIP(hipMemcpy2DAsync(ch.A.p, (size_t)ch.ld() * sizeof(T), A, (size_t)lda * sizeof(T), (size_t)n * sizeof(T), (size_t)n, hipMemcpyDefault, stream));
+  DevBuf<T> db; db.alloc(n);
+  GR_HIP(hipMemcpyAsync(db.p, b, (size_t)n * sizeof(T), hipMemcpyDefault, stream));
+  hipEvent_t e0, e1;
+  GR_HIP(hipEventCreate(&e0)); GR_HIP(hipEventCreate(&e1));
+  GR_HIP(hipEventRecord(e0, stream));
+  ch.factor();
+  GR_HIP(hipEventRecord(e1, stream));
+  ch.solve(db.p, db.p);
+  const bool ok = ch.ok();
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (seconds) *seconds = ms * 1e-3;
+  GR_HIP(hipMemcpyAsync(x, db.p, (size_t)n * sizeof(T), hipMemcpyDefault, stream));
+  GR_HIP(hipStreamSynchronize(stream));
+  if (!ok) throw std::range_error("matrix is not positive definite");
+}
 extern "C" {
 
 const char *gr_version(void) { return "graphite-mi355x 0.1 (gfx950)"; }
@@ -1046,6 +1117,20 @@ gr_status gr_bal_solver_solve(gr_bal_problem *p, gr_solver s, int max_iter, doub
   const gr_status st = guarded(p, [&] { ok = p->e->solver_solve(s, max_iter, tol, rej, dx, iters); });
   if (st == GR_OK && !ok) return GR_ERR_SOLVE_FAILED;
   return st;
+}
+gr_status gr_dense_cholesky_solve(gr_dtype dtype, int64_t n, const void *A, int64_t lda, const void *b, void *x, int device, void *stream, double *factor_seconds) {
+  if (n <= 0 || lda < n || !A || !b || !x || n > (1 << 20)) { g_last_error = "gr_dense_cholesky_solve: bad argument"; return GR_ERR_INVALID; }
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= device || device < 0) { g_last_error = "no HIP device: the MI355X path has no CPU fallback"; return GR_ERR_NO_DEVICE; }
+  try {
+    GR_HIP(hipSetDevice(device));
+    if (dtype == GR_F64) dense_cholesky_solve_impl<double>(n, A, lda, b, x, static_cast<hipStream_t>(stream), factor_seconds);
+    else if (dtype == GR_F32) dense_cholesky_solve_impl<float>(n, A, lda, b, x, static_cast<hipStream_t>(stream), factor_seconds);
+    else { g_last_error = "bad dtype"; return GR_ERR_INVALID; }
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::range_error &ex) { g_last_error = ex.what(); return GR_ERR_SOLVE_FAILED; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
 }
 gr_status gr_bal_schur_update_values(gr_bal_problem *p) { return guarded(p, [&] { p->e->schur_update_values(); }); }
 gr_status gr_bal_schur_matvec(gr_bal_problem *p, const void *x, void *y) { return guarded(p, [&] { p->e->schur_matvec(x, y); }); }

@@ -47,7 +47,9 @@ typedef enum {
   GR_SOLVER_PCG_SCHUR = 0,    /* PCGSchurSolver + BlockJacobiSchurPreconditioner (solver/pcg_schur.hpp, preconditioner/block_jacobi_schur.hpp) */
   GR_SOLVER_PCG = 1,          /* PCGSolver + BlockJacobiPreconditioner (solver/pcg.hpp, preconditioner/block_jacobi.hpp)                      */
   GR_SOLVER_PCG_IDENTITY = 2, /* PCGSolver + IdentityPreconditioner (preconditioner/identity.hpp)                                              */
-  GR_SOLVER_PCG_SCHUR_IMPLICIT = 3 /* same iterates as GR_SOLVER_PCG_SCHUR, S applied as Hpp - Hpl Hll^-1 Hpl^T without forming it (kernels_is.hpp) */
+  GR_SOLVER_PCG_SCHUR_IMPLICIT = 3, /* same iterates as GR_SOLVER_PCG_SCHUR, S applied as Hpp - Hpl Hll^-1 Hpl^T without forming it (kernels_is.hpp) */
+  GR_SOLVER_DENSE_SCHUR = 4   /* direct solve of S x = b_S: EigenSchurLDLTSolver (solver/eigen_schur.hpp:71-108) / cudssSchurSolver
+                                 (solver/cudss_schur.hpp:190-234), as a tile-sparse dense MFMA Cholesky (chol.hpp)                         */
 } gr_solver;
 
 typedef enum { GR_LOSS_DEFAULT = 0, GR_LOSS_HUBER = 1 } gr_loss; /* loss.hpp:15-51 */
@@ -184,6 +186,13 @@ gr_status gr_comm_unique_id(void *unique_id_128);
 gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int rank, int world_size);
 /* test only: in-process group of `n` shards on one GPU, one host thread per shard */
 gr_status gr_bal_comm_init_local(gr_bal_problem **problems, int n);
+/* Dense SPD solve A x = b on the MFMA Cholesky that GR_SOLVER_DENSE_SCHUR uses (the numerical role of
+ * Eigen::SimplicialLDLT in src/eigen_solver.cpp:8-30 / cuDSS in solver/cudss.hpp:183-256 once S is dense).
+ * A: n x n row-major, leading dimension lda, lower triangle read; A, b, x host or device pointers (x may
+ * alias b).  factor_seconds (optional): device time of the factorisation alone.
+ * GR_ERR_SOLVE_FAILED when a pivot is not positive. */
+gr_status gr_dense_cholesky_solve(gr_dtype dtype, int64_t n, const void *A, int64_t lda, const void *b, void *x,
+                                  int device, void *stream, double *factor_seconds);
 /* diagnostic: mean device time (us) of `reps` launches of one hot kernel */
 double gr_bal_diag_time(gr_bal_problem *p, int which, int variant, int reps);
 

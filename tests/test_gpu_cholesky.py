@@ -1,0 +1,105 @@
+"""GPU parity for the direct inner solve: the tile-sparse MFMA Cholesky of the
+reduced camera system against (i) numpy on random SPD matrices through gr_dense_cholesky_solve and
+(ii) the oracle's LDL^T Schur solver (the restated EigenSchurLDLTSolver path) on BAL problems.
+The reference's own bar for direct solves is 1e-8 (tests/schur.cu:285-288)."""
+import numpy as np
+import pytest
+
+import graphite_amd as ga
+from graphite_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def spd(n, dtype, seed, band=None):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, n))
+    if band is not None:
+        i, j = np.indices((n, n))
+        G[np.abs(i - j) > band] = 0.0
+    A = G @ G.T / n + np.eye(n)
+    # asymmetric garbage above the diagonal must be ignored (only the lower triangle is read)
+    A = np.tril(A) + np.triu(rng.standard_normal((n, n)), 1)
+    return A.astype(dtype), rng.standard_normal(n).astype(dtype)
+
+
+@pytest.mark.parametrize("n", [1, 7, 128, 129, 441, 1000])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 2e-4)])
+def test_dense_cholesky_solve_random_spd(n, dtype, tol):
+    A, b = spd(n, dtype, seed=n)
+    x, sec = ga.dense_cholesky_solve(A, b)
+    Af = np.tril(A.astype(np.float64))
+    Af = Af + Af.T - np.diag(np.diag(Af))
+    xr = np.linalg.solve(Af, b.astype(np.float64))
+    assert relerr(x, xr) < tol
+    assert sec >= 0.0
+
+
+def test_dense_cholesky_rejects_indefinite():
+    A, b = spd(200, np.float64, seed=3)
+    A[150, 150] = -5.0
+    with pytest.raises(ga._lib.GraphiteError) as ei:
+        ga.dense_cholesky_solve(A, b)
+    assert ei.value.status == 5  # GR_ERR_SOLVE_FAILED
+
+
+def make_pair(oracle_mod, name, dtype):
+    prob = synth.schur_test_fixture(dtype) if name == "schur-2x3" else synth.make_config(name)
+    gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+    ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+    return prob, gpu, ref
+
+
+@pytest.mark.parametrize("name,dtype,tol", [("schur-2x3", np.float64, 1e-9), ("mini-50", np.float64, 1e-9),
+                                            ("ladybug-49", np.float64, 1e-8), ("ladybug-49", np.float32, 2e-2)])
+def test_dense_schur_solve_matches_ldlt(oracle_mod, name, dtype, tol):
+    """delta_x of GR_SOLVER_DENSE_SCHUR against the oracle's Schur LDL^T (solver/eigen_schur.hpp:71-108)."""
+    prob, gpu, ref = make_pair(oracle_mod, name, dtype)
+    gs, os_ = ga.SOLVER_DENSE_SCHUR, oracle_mod.SOLVER_LDLT_SCHUR
+    gpu.solver_update_structure(gs)
+    gpu.linearize()
+    gpu.solver_update_values(gs)
+    gpu.solver_set_damping(gs, 1e-4)
+    ref.linearize()
+    ref.solver_update_values(os_)
+    ref.solver_set_damping(os_, 1e-4)
+    dx_g, it_g = gpu.solver_solve(gs)
+    dx_r, _ = ref.solver_solve(os_)
+    assert it_g == 0
+    assert relerr(dx_g, dx_r) < tol
+    gpu.close()
+
+
+@pytest.mark.parametrize("name,dtype,rtol", [("mini-50", np.float64, 1e-9), ("ladybug-49", np.float64, 1e-8),
+                                             ("ladybug-49", np.float32, 2e-3)])
+def test_levenberg_marquardt_trace_dense_schur(oracle_mod, name, dtype, rtol):
+    """LM with the direct Schur solve: chi2 / lambda traces against the oracle's LDL^T-Schur LM."""
+    prob, gpu, ref = make_pair(oracle_mod, name, dtype)
+    ct_g, lt_g, st = gpu.levenberg_marquardt(solver=ga.SOLVER_DENSE_SCHUR, iterations=8)
+    ct_r, lt_r, st_r = ref.levenberg_marquardt(solver=oracle_mod.SOLVER_LDLT_SCHUR, iterations=8)
+    if np.dtype(dtype) == np.float32:
+        # converged fp32 runs stop on rho == 0 (levenberg_marquardt.hpp:229) at a rounding-dependent trip
+        m = min(len(ct_g), len(ct_r))
+        assert m >= 4
+        ct_g, lt_g, ct_r, lt_r = ct_g[:m], lt_g[:m], ct_r[:m], lt_r[:m]
+    assert len(ct_g) == len(ct_r)
+    assert np.abs(ct_g - ct_r).max() / ct_r.max() < rtol
+    if np.dtype(dtype) == np.float64:
+        assert np.allclose(ct_g, ct_r, rtol=1e-6)
+        assert np.allclose(lt_g, lt_r, rtol=1e-3)
+        cg, pg = gpu.get_params()
+        cr, pr = ref.get_params()
+        assert relerr(cg, cr) < 1e-6 and relerr(pg, pr) < 1e-6
+    else:
+        moving = np.abs(np.diff(ct_r)) / ct_r[:-1] > 1e-4
+        k = int(np.argmin(moving)) if not moving.all() else len(moving)
+        assert np.allclose(lt_g[:k + 1], lt_r[:k + 1], rtol=1e-3)
+    assert ct_g[-1] < 0.1 * ct_g[0]
+    assert st["pcg_iterations"] == 0
+    gpu.close()
