@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ladybug-1723")
-    ap.add_argument("--solver", default=None, choices=[None, "pcg", "pcg-schur", "pcg-schur-implicit"])
+    ap.add_argument("--solver", default=None, choices=[None, "pcg", "pcg-schur", "pcg-schur-implicit", "dense-schur"])
     ap.add_argument("--dtype", default=None, choices=[None, "f32", "f64"])
     ap.add_argument("--pcg-iterations", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,7 +77,7 @@ def main():
     solver_name = args.solver or dsolver
     dtype_name = args.dtype or ddtype
     dtype = np.float64 if dtype_name == "f64" else np.float32
-    solver = {"pcg": ga.SOLVER_PCG, "pcg-schur": ga.SOLVER_PCG_SCHUR, "pcg-schur-implicit": ga.SOLVER_PCG_SCHUR_IMPLICIT}[solver_name]
+    solver = {"pcg": ga.SOLVER_PCG, "pcg-schur": ga.SOLVER_PCG_SCHUR, "pcg-schur-implicit": ga.SOLVER_PCG_SCHUR_IMPLICIT, "dense-schur": ga.SOLVER_DENSE_SCHUR}[solver_name]
 
     prob = synth.make_config(args.workload)
     Nc, Np, No = prob.shape

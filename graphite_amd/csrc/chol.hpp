@@ -17,6 +17,8 @@
 #pragma once
 #include "common.hpp"
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <functional>
 
 namespace gr {
@@ -55,11 +57,12 @@ template <> __device__ __forceinline__ void load8<float>(const float *p, float (
 
 // C = P Q^T  (MODE 0, C overwrites P: the panel solve with Q = Linv_k)
 // C -= P Q^T (MODE 1, the trailing update; P, Q = panel tiles of rows ti, tj)
-// One 128x128 tile of C per workgroup; K = 128 in 8 chunks of 16, double-buffered through LDS.
+// One 128x128 tile of C per workgroup; K = 16 nch (one or two panels) in chunks of 16, double-buffered
+// through LDS.
 // For MODE 1 the accumulators start as C and P is negated on its way into LDS, so the epilogue
 // is a plain store and the C read overlaps the first operand fetch.
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, const int *__restrict__ tiles, int k0, const T *__restrict__ Linv) {
+__global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, const int *__restrict__ tiles, int k0, const T *__restrict__ Linv, int nch) {
   extern __shared__ __align__(16) unsigned char ch_smem[];
   T *sm = reinterpret_cast<T *>(ch_smem);
   using M = MfmaTile<T>;
@@ -95,9 +98,9 @@ __global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, co
     for (int e = 0; e < 8; ++e) { Ps[(lk + e) * CH_LDP + lr] = MODE == 1 ? -pp[e] : pp[e]; Qs[(lk + e) * CH_LDP + lr] = pq[e]; }
   }
   __syncthreads();
-  constexpr int NCH = CH_NB / CH_KC;
-  for (int c = 0; c < NCH; ++c) {
-    if (c + 1 < NCH) {
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) {
       load8<T>(Pg + (size_t)lr * ld + (c + 1) * CH_KC + lk, pp);
       load8<T>(Qg + (size_t)lr * ldq + (c + 1) * CH_KC + lk, pq);
     }
@@ -113,20 +116,24 @@ __global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, co
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(a[mi], b[ni], acc[mi][ni]);
     }
-    if (c + 1 < NCH) {
+    if (c + 1 < nch) {
       T *Pn = sm + ((c + 1) & 1) * BUF, *Qn = Pn + CH_KC * CH_LDP;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { Pn[(lk + e) * CH_LDP + lr] = MODE == 1 ? -pp[e] : pp[e]; Qn[(lk + e) * CH_LDP + lr] = pq[e]; }
     }
     __syncthreads();
   }
+  // keep the 64 store addresses from being hoisted above the K loop (they would cost 128 VGPRs and
+  // with them the second workgroup per CU that overlaps this epilogue with MFMA work)
+  int ld2 = ld;
+  asm volatile("" : "+v"(ld2));
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld + wc * 64 + ni * 16 + ccol] = acc[mi][ni][r];
+        Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld2 + wc * 64 + ni * 16 + ccol] = acc[mi][ni][r];
 }
 constexpr size_t chol_gemm_lds(size_t w) { return 2 * 2 * CH_KC * CH_LDP * w; }
 
@@ -150,7 +157,7 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
 // diagonal) for the panel GEMM and the solves.  A pivot that is not > 0 raises *fail and is
 // replaced by 1 so that the rest stays finite.
 template <typename T>
-__global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld, int k0, T *__restrict__ Linv, int *__restrict__ fail) {
+__global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld, int k0, T *__restrict__ Linv, int *__restrict__ fail, int skip = 0) {
   extern __shared__ __align__(16) unsigned char ch_smem[];
   using M = MfmaTile<T>;
   typedef typename M::acc_t acc_t;
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld,
   __syncthreads();
   for (int s = 0; s < NB16; ++s) {
     const int o = 16 * s;
-    if (wave == 0) {
+    if (wave == 0 && !(skip & 1)) {
       // 16x16 Cholesky + inverse: lane r (mod 16) owns row r of the block, then column r of X
       T a[16], x[16], rsv[16];
       bool bad = false;
@@ -176,9 +183,8 @@ __global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld,
       for (int j = 0; j < 16; ++j) {
         T d = lane_bcast<T>(a[j], j);
         if (!(d > T(0))) { bad = true; d = T(1); }
-        const T sq = sqrt(d);
-        rsv[j] = T(1) / sq;
-        a[j] = cl == j ? sq : a[j] * rsv[j];
+        rsv[j] = rsqrt(d);
+        a[j] = cl == j ? d * rsv[j] : a[j] * rsv[j];
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) a[k] -= a[j] * lane_bcast<T>(a[j], k);
       }
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld,
     }
     __syncthreads();
     // sub-panel solve: L_is = A_is X_ss^T for the 16-row blocks below
-    for (int bi = s + 1 + wave; bi < NB16; bi += NW) {
+    for (int bi = s + 1 + wave; bi < NB16 && !(skip & 2); bi += NW) {
       acc_t acc = {T(0), T(0), T(0), T(0)};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld,
     __syncthreads();
     // trailing update of the 16x16 tiles (bi >= bk > s): A_ik -= L_is L_ks^T
     const int m = NB16 - 1 - s, ntile = m * (m + 1) / 2;
-    for (int q = wave; q < ntile; q += NW) {
+    for (int q = wave; q < ntile && !(skip & 2); q += NW) {
       int bi = 0, rem = q;
       while (rem > bi) { rem -= bi + 1; ++bi; } // q -> (bi, bk) in the lower triangle
       const int ti = s + 1 + bi, tk = s + 1 + rem;
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld,
     __syncthreads();
   }
   // blocked inverse: X_ij = -X_ii sum_{k=j}^{i-1} L_ik X_kj, block row by block row
-  for (int i = 1; i < NB16; ++i) {
+  for (int i = 1; i < NB16 && !(skip & 4); ++i) {
     for (int j = wave; j < i; j += NW) {
       acc_t tacc = {T(0), T(0), T(0), T(0)};
       for (int k = j; k < i; ++k) {
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld,
     }
     __syncthreads();
   }
+  if (skip & 8) return;
   for (int e = t; e < CH_NB * CH_NB; e += CH_PT) {
     const int r = e >> 7, cc = e & 127;
     if (cc <= r) Ag[(size_t)r * ld + cc] = L[r * CH_LP + cc];
@@ -296,6 +303,15 @@ template <typename T> __global__ void k_chol_rhs(int n, int npad, const T *__res
   if (i < npad) vb[i] = i < n ? b[i] : T(0);
 }
 
+// 16 rows x 128 columns times a 128-vector held as (v0 = y[lane], v1 = y[64 + lane]): all 32 loads are
+// issued before the cross-lane reduction; lane L returns the dot product of row (L >> 2)
+template <typename T> __device__ __forceinline__ T rows16_dot(const T *__restrict__ base, size_t ld, T v0, T v1, int lane) {
+  T v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = base[i * ld + lane] * v0 + base[i * ld + 64 + lane] * v1;
+  return wave_transpose_sum<T, 16>(v, lane);
+}
+
 // forward step k: y_k = Linv_k b_k (every workgroup, into LDS); workgroup 0 stores y_k, workgroup
 // w >= 1 applies b_i -= L_ik y_k for its tile row i = rows[w - 1]
 template <typename T>
@@ -303,10 +319,11 @@ __global__ __launch_bounds__(256) void k_chol_fwd(const T *__restrict__ A, int l
   __shared__ T yk[CH_NB];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const T b0 = b[k0 + lane], b1 = b[k0 + 64 + lane];
-  for (int r = wave * 32; r < wave * 32 + 32; ++r) {
-    T s = Linv[r * CH_NB + lane] * b0 + Linv[r * CH_NB + 64 + lane] * b1;
-    s = wave_sum(s);
-    if (lane == 0) yk[r] = s;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r0 = wave * 32 + h * 16;
+    const T s = rows16_dot<T>(Linv + r0 * CH_NB, CH_NB, b0, b1, lane);
+    if ((lane & 3) == 0) yk[r0 + (lane >> 2)] = s;
   }
   __syncthreads();
   if (blockIdx.x == 0) {
@@ -316,10 +333,11 @@ __global__ __launch_bounds__(256) void k_chol_fwd(const T *__restrict__ A, int l
   const int ti = rows[blockIdx.x - 1];
   const T y0 = yk[lane], y1 = yk[64 + lane];
   const T *Lg = A + (size_t)ti * CH_NB * ld + k0;
-  for (int r = wave * 32; r < wave * 32 + 32; ++r) {
-    T s = Lg[(size_t)r * ld + lane] * y0 + Lg[(size_t)r * ld + 64 + lane] * y1;
-    s = wave_sum(s);
-    if (lane == 0) b[ti * CH_NB + r] -= s;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r0 = wave * 32 + h * 16;
+    const T s = rows16_dot<T>(Lg + (size_t)r0 * ld, (size_t)ld, y0, y1, lane);
+    if ((lane & 3) == 0) b[ti * CH_NB + r0 + (lane >> 2)] -= s;
   }
 }
 
@@ -346,6 +364,7 @@ __global__ __launch_bounds__(256) void k_chol_bwd_final(const T *__restrict__ Li
   const int t = threadIdx.x, c = t & 127, h = t >> 7;
   if (h == 0) {
     T s = y[k0 + c];
+#pragma unroll 8
     for (int w = 0; w < nrows; ++w) s -= partial[(size_t)w * CH_NB + c];
     v[c] = s;
   }
@@ -365,19 +384,34 @@ struct CholProfSink {
 };
 
 // Host side: tile-level symbolic factorisation + the launch sequence.
+//
+// Panels are paired into super-panels (a, b = a + 1): both are factored and solved first (the update
+// of tile column b by panel a is a narrow K = 128 pass), then the trailing matrix is updated ONCE with
+// K = 256, which halves the read-modify-write traffic of the C tiles.  With look-ahead the tiles of
+// the next super-panel's two columns are updated first, and its panel phase then runs on a second
+// stream underneath the rest of the trailing update.
 template <typename T> struct DenseChol {
-  hipStream_t stream = nullptr;
-  int n = 0, npad = 0, nt = 0;
+  hipStream_t stream = nullptr, side = nullptr;
+  int n = 0, npad = 0, nt = 0, nsp = 0;
   DevBuf<T> A, Linv, vb, vy, vx, partial;
   DevBuf<int> d_rows, d_pairs, d_nz, d_fail;
-  std::vector<int> row_off, pair_off; // per-panel offsets into d_rows / d_pairs (pairs counted in pairs)
+  std::vector<int> row_beg, row_end;                // per panel: rows below the diagonal tile (into d_rows)
+  std::vector<int> col_off, next_off, rest_off;     // per super-panel: pair ranges (into d_pairs, in pairs)
   int nz_tiles = 0, max_rows = 0;
-  int64_t total_pairs = 0, total_rows = 0;
+  int64_t total_pairs = 0, total_rows = 0, total_pairs128 = 0;
   int *h_fail = nullptr;
   CholProfSink *sink = nullptr;
-  bool attrs_set = false;
+  bool attrs_set = false, lookahead = !(getenv("GR_CHOL_LOOKAHEAD") && atoi(getenv("GR_CHOL_LOOKAHEAD")) == 0);
+  std::vector<hipEvent_t> ev;
+  int potrf_skip = getenv("GR_CHOL_POTRF_SKIP") ? atoi(getenv("GR_CHOL_POTRF_SKIP")) : 0; // timing ablation only
 
-  ~DenseChol() { if (h_fail) (void)hipHostFree(h_fail); }
+  DenseChol() = default;
+  DenseChol(const DenseChol &) = delete;
+  ~DenseChol() {
+    if (h_fail) (void)hipHostFree(h_fail);
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (side) (void)hipStreamDestroy(side);
+  }
 
   static size_t bytes_needed(int64_t n_) {
     const int64_t np = (n_ + CH_NB - 1) / CH_NB * CH_NB;
@@ -385,29 +419,59 @@ template <typename T> struct DenseChol {
   }
   // tile_nz: nt*nt, [i*nt + j] != 0 for structurally non-zero lower tiles (i >= j); empty = dense
   void set_structure(int n_, std::vector<char> tile_nz, hipStream_t s) {
-    stream = s; n = n_; nt = (n + CH_NB - 1) / CH_NB; npad = nt * CH_NB;
+    stream = s; n = n_; nt = (n + CH_NB - 1) / CH_NB; npad = nt * CH_NB; nsp = (nt + 1) / 2;
     if (tile_nz.empty()) tile_nz.assign((size_t)nt * nt, 1);
-    for (int i = 0; i < nt; ++i) tile_nz[(size_t)i * nt + i] = 1;
+    auto nz = [&](int i, int j) -> char & { return tile_nz[(size_t)i * nt + j]; };
+    for (int i = 0; i < nt; ++i) nz(i, i) = 1;
     std::vector<int> h_rows, h_pairs, h_nz;
-    row_off.assign(nt + 1, 0); pair_off.assign(nt + 1, 0);
-    max_rows = 0;
-    std::vector<int> rk;
-    for (int k = 0; k < nt; ++k) {
-      rk.clear();
-      for (int i = k + 1; i < nt; ++i) if (tile_nz[(size_t)i * nt + k]) rk.push_back(i);
-      for (int i : rk) h_rows.push_back(i);
-      for (size_t a = 0; a < rk.size(); ++a)
-        for (size_t b = 0; b <= a; ++b) {
-          tile_nz[(size_t)rk[a] * nt + rk[b]] = 1; // fill-in
-          h_pairs.push_back(rk[a]); h_pairs.push_back(rk[b]);
+    row_beg.assign(nt, 0); row_end.assign(nt, 0);
+    col_off.assign(nsp + 1, 0); next_off.assign(nsp + 1, 0); rest_off.assign(nsp + 1, 0);
+    std::vector<int> col_end(nsp, 0), next_end(nsp, 0);
+    max_rows = 0; total_pairs = 0; total_pairs128 = 0;
+    std::vector<int> U;
+    for (int p = 0; p < nsp; ++p) {
+      const int a = 2 * p, b = a + 1, an = a + 2, bn = a + 3;
+      U.clear();
+      if (b < nt) {
+        nz(b, a) = 1;
+        for (int i = b + 1; i < nt; ++i) if (nz(i, a) || nz(i, b)) { U.push_back(i); nz(i, a) = nz(i, b) = 1; }
+      }
+      // rows of panel a: [b] + U; rows of panel b: U
+      row_beg[a] = row_end[a] = (int)h_rows.size();
+      if (b < nt) {
+        h_rows.push_back(b);
+        row_beg[b] = (int)h_rows.size();
+        for (int i : U) h_rows.push_back(i);
+        row_end[a] = row_end[b] = (int)h_rows.size();
+      }
+      max_rows = std::max(max_rows, (int)U.size() + 1);
+      // pairs: column b from panel a (K = 128), then the trailing tiles (K = 256): next two columns first
+      col_off[p] = (int)(h_pairs.size() / 2);
+      if (b < nt) {
+        h_pairs.push_back(b); h_pairs.push_back(b);
+        for (int i : U) { h_pairs.push_back(i); h_pairs.push_back(b); }
+      }
+      col_end[p] = (int)(h_pairs.size() / 2);
+      total_pairs128 += col_end[p] - col_off[p];
+      next_off[p] = col_end[p];
+      for (size_t x = 0; x < U.size(); ++x)
+        for (size_t y = 0; y <= x; ++y) {
+          nz(U[x], U[y]) = 1; // fill-in
+          if (U[y] == an || U[y] == bn) { h_pairs.push_back(U[x]); h_pairs.push_back(U[y]); }
         }
-      row_off[k + 1] = (int)h_rows.size(); pair_off[k + 1] = (int)(h_pairs.size() / 2);
-      max_rows = std::max(max_rows, (int)rk.size());
+      next_end[p] = (int)(h_pairs.size() / 2);
+      rest_off[p] = next_end[p];
+      for (size_t x = 0; x < U.size(); ++x)
+        for (size_t y = 0; y <= x; ++y)
+          if (U[y] > bn) { h_pairs.push_back(U[x]); h_pairs.push_back(U[y]); }
+      total_pairs += (int64_t)(h_pairs.size() / 2) - next_off[p];
     }
+    col_off[nsp] = next_off[nsp] = rest_off[nsp] = (int)(h_pairs.size() / 2);
+    col_end_ = col_end; next_end_ = next_end;
     for (int i = 0; i < nt; ++i)
-      for (int j = 0; j <= i; ++j) if (tile_nz[(size_t)i * nt + j]) { h_nz.push_back(i); h_nz.push_back(j); }
+      for (int j = 0; j <= i; ++j) if (nz(i, j)) { h_nz.push_back(i); h_nz.push_back(j); }
     nz_tiles = (int)(h_nz.size() / 2);
-    total_pairs = (int64_t)h_pairs.size() / 2; total_rows = (int64_t)h_rows.size();
+    total_rows = (int64_t)h_rows.size();
     if (h_rows.empty()) h_rows.push_back(0);
     if (h_pairs.empty()) { h_pairs.push_back(0); h_pairs.push_back(0); }
     d_rows.upload(h_rows, stream); d_pairs.upload(h_pairs, stream); d_nz.upload(h_nz, stream);
@@ -419,12 +483,19 @@ template <typename T> struct DenseChol {
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_gemm<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_gemm<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_potrf<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_potrf_lds(sizeof(T))));
+      GR_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       attrs_set = true;
+    }
+    while ((int)ev.size() < 2 * nsp + 2) {
+      hipEvent_t e;
+      GR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ev.push_back(e);
     }
     GR_HIP(hipStreamSynchronize(stream));
   }
+  std::vector<int> col_end_, next_end_;
   int ld() const { return npad; }
-  double factor_flops() const { return (total_rows + total_pairs) * 2.0 * CH_NB * CH_NB * CH_NB + nt * (2.0 / 3.0) * CH_NB * CH_NB * CH_NB; }
+  double factor_flops() const { return (total_rows + total_pairs128 + 2.0 * total_pairs) * 2.0 * CH_NB * CH_NB * CH_NB + nt * (2.0 / 3.0) * CH_NB * CH_NB * CH_NB; }
 
   void clear() {
     k_chol_clear<T><<<nz_tiles, 256, 0, stream>>>(A.p, npad, n, d_nz.p);
@@ -434,24 +505,65 @@ template <typename T> struct DenseChol {
     Sc(CholProfSink *s_, const char *nm, double by, double fl) : s(s_) { if (s) s->begin(nm, by, fl); }
     ~Sc() { if (s) s->end(); }
   };
+  static constexpr double tile_b() { return (double)CH_NB * CH_NB * sizeof(T); }
+  static constexpr double tile_f() { return 2.0 * CH_NB * CH_NB * CH_NB; }
+  // panel phase of super-panel p on stream q: potrf(a), solve(a), column b update, potrf(b), solve(b)
+  void panel_phase(int p, hipStream_t q, CholProfSink *sk) {
+    const int a = 2 * p, b = a + 1;
+    const size_t lds_g = chol_gemm_lds(sizeof(T)), lds_p = chol_potrf_lds(sizeof(T));
+    T *La = Linv.p + (size_t)a * CH_NB * CH_NB, *Lb = La + CH_NB * CH_NB;
+    {
+      Sc sc(sk, "chol_potrf", 3 * tile_b(), tile_f() / 3);
+      k_chol_potrf<T><<<1, CH_PT, lds_p, q>>>(A.p, npad, a * CH_NB, La, d_fail.p, potrf_skip);
+    }
+    if (b >= nt) return;
+    const int nra = row_end[a] - row_beg[a], nrb = row_end[b] - row_beg[b], ncol = col_end_[p] - col_off[p];
+    {
+      Sc sc(sk, "chol_trsm", (2.0 * nra + 1) * tile_b(), nra * tile_f());
+      k_chol_gemm<T, 0><<<nra, 256, lds_g, q>>>(A.p, npad, d_rows.p + row_beg[a], a * CH_NB, La, CH_NB / CH_KC);
+    }
+    {
+      Sc sc(sk, "chol_syrk_col", (3.0 * ncol) * tile_b(), ncol * tile_f());
+      k_chol_gemm<T, 1><<<ncol, 256, lds_g, q>>>(A.p, npad, d_pairs.p + 2 * (size_t)col_off[p], a * CH_NB, nullptr, CH_NB / CH_KC);
+    }
+    {
+      Sc sc(sk, "chol_potrf", 3 * tile_b(), tile_f() / 3);
+      k_chol_potrf<T><<<1, CH_PT, lds_p, q>>>(A.p, npad, b * CH_NB, Lb, d_fail.p, potrf_skip);
+    }
+    if (nrb) {
+      Sc sc(sk, "chol_trsm", (2.0 * nrb + 1) * tile_b(), nrb * tile_f());
+      k_chol_gemm<T, 0><<<nrb, 256, lds_g, q>>>(A.p, npad, d_rows.p + row_beg[b], b * CH_NB, Lb, CH_NB / CH_KC);
+    }
+  }
+  void update(int p, int beg, int end, hipStream_t q, CholProfSink *sk) {
+    if (end <= beg) return;
+    const int np_ = end - beg;
+    Sc sc(sk, "chol_syrk", (2.0 * np_ + 2.0 * std::sqrt(2.0 * np_)) * tile_b(), 2.0 * np_ * tile_f());
+    k_chol_gemm<T, 1><<<np_, 256, chol_gemm_lds(sizeof(T)), q>>>(A.p, npad, d_pairs.p + 2 * (size_t)beg, 2 * p * CH_NB, nullptr, 2 * CH_NB / CH_KC);
+  }
   void factor() {
     GR_HIP(hipMemsetAsync(d_fail.p, 0, sizeof(int), stream));
-    const double w = sizeof(T), tile_b = (double)CH_NB * CH_NB * w, tile_f = 2.0 * CH_NB * CH_NB * CH_NB;
-    for (int k = 0; k < nt; ++k) {
-      T *Lk = Linv.p + (size_t)k * CH_NB * CH_NB;
-      {
-        Sc sc(sink, "chol_potrf", 3 * tile_b, tile_f / 3);
-        k_chol_potrf<T><<<1, CH_PT, chol_potrf_lds(sizeof(T)), stream>>>(A.p, npad, k * CH_NB, Lk, d_fail.p);
+    const bool la = lookahead && !sink && nsp > 2;
+    if (!la) {
+      for (int p = 0; p < nsp; ++p) {
+        panel_phase(p, stream, sink);
+        update(p, next_off[p], col_off[p + 1], stream, sink);
       }
-      const int nr = row_off[k + 1] - row_off[k], npr = pair_off[k + 1] - pair_off[k];
-      if (nr) {
-        Sc sc(sink, "chol_trsm", (2.0 * nr + 1) * tile_b, nr * tile_f);
-        k_chol_gemm<T, 0><<<nr, 256, chol_gemm_lds(sizeof(T)), stream>>>(A.p, npad, d_rows.p + row_off[k], k * CH_NB, Lk);
+      return;
+    }
+    // main stream: update-next(p) -> E1(p) -> update-rest(p) -> wait E2(p+1) -> ...
+    // side stream: wait E1(p) -> panel phase(p+1) -> E2(p+1)
+    panel_phase(0, stream, nullptr);
+    for (int p = 0; p < nsp; ++p) {
+      update(p, next_off[p], rest_off[p], stream, nullptr);
+      if (p + 1 < nsp) {
+        GR_HIP(hipEventRecord(ev[2 * p], stream));
+        GR_HIP(hipStreamWaitEvent(side, ev[2 * p], 0));
+        panel_phase(p + 1, side, nullptr);
+        GR_HIP(hipEventRecord(ev[2 * p + 1], side));
       }
-      if (npr) {
-        Sc sc(sink, "chol_syrk", (2.0 * npr + nr) * tile_b, npr * tile_f);
-        k_chol_gemm<T, 1><<<npr, 256, chol_gemm_lds(sizeof(T)), stream>>>(A.p, npad, d_pairs.p + 2 * (size_t)pair_off[k], k * CH_NB, nullptr);
-      }
+      update(p, rest_off[p], col_off[p + 1], stream, nullptr);
+      if (p + 1 < nsp) GR_HIP(hipStreamWaitEvent(stream, ev[2 * p + 1], 0));
     }
   }
   // b, x: device vectors of length n (x may alias b)
@@ -459,12 +571,12 @@ template <typename T> struct DenseChol {
     Sc sc(sink, "chol_solve", 2.0 * (total_rows + 2.0 * nt) * CH_NB * CH_NB * sizeof(T), 4.0 * (total_rows + nt) * CH_NB * CH_NB);
     k_chol_rhs<T><<<(npad + 255) / 256, 256, 0, stream>>>(n, npad, b, vb.p);
     for (int k = 0; k < nt; ++k) {
-      const int nr = row_off[k + 1] - row_off[k];
-      k_chol_fwd<T><<<1 + nr, 256, 0, stream>>>(A.p, npad, Linv.p + (size_t)k * CH_NB * CH_NB, k * CH_NB, d_rows.p + row_off[k], vb.p, vy.p);
+      const int nr = row_end[k] - row_beg[k];
+      k_chol_fwd<T><<<1 + nr, 256, 0, stream>>>(A.p, npad, Linv.p + (size_t)k * CH_NB * CH_NB, k * CH_NB, d_rows.p + row_beg[k], vb.p, vy.p);
     }
     for (int k = nt - 1; k >= 0; --k) {
-      const int nr = row_off[k + 1] - row_off[k];
-      if (nr) k_chol_bwd_partial<T><<<nr, 256, 0, stream>>>(A.p, npad, k * CH_NB, d_rows.p + row_off[k], vx.p, partial.p);
+      const int nr = row_end[k] - row_beg[k];
+      if (nr) k_chol_bwd_partial<T><<<nr, 256, 0, stream>>>(A.p, npad, k * CH_NB, d_rows.p + row_beg[k], vx.p, partial.p);
       k_chol_bwd_final<T><<<1, 256, 0, stream>>>(Linv.p + (size_t)k * CH_NB * CH_NB, k * CH_NB, nr, partial.p, vy.p, vx.p);
     }
     GR_HIP(hipMemcpyAsync(x, vx.p, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, stream));

@@ -2,8 +2,9 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch, time, sys
 import graphite_amd as ga
+sizes = [int(a) for a in sys.argv[1:]] or [2048, 8192, 15507]
 for dt in (torch.float64, torch.float32):
-    for n in (2048, 8192, 15507):
+    for n in sizes:
         G = torch.randn(n, n, device="cuda", dtype=dt)
         A = G @ G.T / n + torch.eye(n, device="cuda", dtype=dt)
         del G
