@@ -61,7 +61,7 @@ template <> __device__ __forceinline__ void load8<float>(const float *p, float (
 // through LDS.
 // For MODE 1 the accumulators start as C and P is negated on its way into LDS, so the epilogue
 // is a plain store and the C read overlaps the first operand fetch.
-template <typename T, int MODE>
+template <typename T, int MODE, int PIN = 0, int KC = CH_KC>
 __global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, const int *__restrict__ tiles, int k0, const T *__restrict__ Linv, int nch) {
   extern __shared__ __align__(16) unsigned char ch_smem[];
   T *sm = reinterpret_cast<T *>(ch_smem);
@@ -87,26 +87,47 @@ __global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, co
         else acc[mi][ni][r] = T(0);
       }
 
-  const int lr = t >> 1, lk = (t & 1) * 8; // loader role: tile row, first k of its 8
-  T pp[8], pq[8];
-  load8<T>(Pg + (size_t)lr * ld + lk, pp);
-  load8<T>(Qg + (size_t)lr * ldq + lk, pq);
-  constexpr int BUF = 2 * CH_KC * CH_LDP;
-  {
-    T *Ps = sm, *Qs = sm + CH_KC * CH_LDP;
+  // loader role: KC / 8 threads per tile row, 8 consecutive k each; NPASS row groups per chunk
+  constexpr int TPR = KC / 8, RPP = 256 / TPR, NPASS = CH_NB / RPP;
+  const int lr = t / TPR, lk = (t % TPR) * 8;
+  T pp[NPASS][8], pq[NPASS][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { Ps[(lk + e) * CH_LDP + lr] = MODE == 1 ? -pp[e] : pp[e]; Qs[(lk + e) * CH_LDP + lr] = pq[e]; }
+  for (int u = 0; u < NPASS; ++u) {
+    load8<T>(Pg + (size_t)(lr + u * RPP) * ld + lk, pp[u]);
+    load8<T>(Qg + (size_t)(lr + u * RPP) * ldq + lk, pq[u]);
+  }
+  constexpr int BUF = 2 * KC * CH_LDP;
+  {
+    T *Ps = sm, *Qs = sm + KC * CH_LDP;
+#pragma unroll
+    for (int u = 0; u < NPASS; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { Ps[(lk + e) * CH_LDP + lr + u * RPP] = MODE == 1 ? -pp[u][e] : pp[u][e]; Qs[(lk + e) * CH_LDP + lr + u * RPP] = pq[u][e]; }
   }
   __syncthreads();
+  if (MODE == 1) {
+    // pin the C loads before the loop: otherwise their s_waitcnt lands inside the loop body and, in
+    // steady state, makes every iteration wait for its own operand prefetch half-way through
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        if (PIN == 0) asm volatile("" : "+a"(acc[mi][ni]));
+        else asm volatile("" : "+v"(acc[mi][ni]));
+      }
+  }
 #pragma unroll 1
   for (int c = 0; c < nch; ++c) {
     if (c + 1 < nch) {
-      load8<T>(Pg + (size_t)lr * ld + (c + 1) * CH_KC + lk, pp);
-      load8<T>(Qg + (size_t)lr * ldq + (c + 1) * CH_KC + lk, pq);
-    }
-    const T *Ps = sm + (c & 1) * BUF, *Qs = Ps + CH_KC * CH_LDP;
 #pragma unroll
-    for (int kk = 0; kk < CH_KC / 4; ++kk) {
+      for (int u = 0; u < NPASS; ++u) {
+        load8<T>(Pg + (size_t)(lr + u * RPP) * ld + (c + 1) * KC + lk, pp[u]);
+        load8<T>(Qg + (size_t)(lr + u * RPP) * ldq + (c + 1) * KC + lk, pq[u]);
+      }
+    }
+    const T *Ps = sm + (c & 1) * BUF, *Qs = Ps + KC * CH_LDP;
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
       const int krow = (kk * 4 + (lane >> 4)) * CH_LDP + ccol;
       T a[4], b[4];
 #pragma unroll
@@ -117,9 +138,11 @@ __global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, co
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(a[mi], b[ni], acc[mi][ni]);
     }
     if (c + 1 < nch) {
-      T *Pn = sm + ((c + 1) & 1) * BUF, *Qn = Pn + CH_KC * CH_LDP;
+      T *Pn = sm + ((c + 1) & 1) * BUF, *Qn = Pn + KC * CH_LDP;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { Pn[(lk + e) * CH_LDP + lr] = MODE == 1 ? -pp[e] : pp[e]; Qn[(lk + e) * CH_LDP + lr] = pq[e]; }
+      for (int u = 0; u < NPASS; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { Pn[(lk + e) * CH_LDP + lr + u * RPP] = MODE == 1 ? -pp[u][e] : pp[u][e]; Qn[(lk + e) * CH_LDP + lr + u * RPP] = pq[u][e]; }
     }
     __syncthreads();
   }
@@ -135,7 +158,7 @@ __global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, co
       for (int r = 0; r < 4; ++r)
         Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld2 + wc * 64 + ni * 16 + ccol] = acc[mi][ni][r];
 }
-constexpr size_t chol_gemm_lds(size_t w) { return 2 * 2 * CH_KC * CH_LDP * w; }
+constexpr size_t chol_gemm_lds(size_t w, int kc = CH_KC) { return (size_t)2 * 2 * kc * CH_LDP * w; }
 
 template <typename T> __device__ __forceinline__ T lane_bcast(T v, int src);
 template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) {
@@ -403,6 +426,9 @@ template <typename T> struct DenseChol {
   CholProfSink *sink = nullptr;
   bool attrs_set = false, lookahead = !(getenv("GR_CHOL_LOOKAHEAD") && atoi(getenv("GR_CHOL_LOOKAHEAD")) == 0);
   std::vector<hipEvent_t> ev;
+  // PIN = 1 keeps the C tile in VGPRs until the loop (one workgroup per CU in fp64): measured 7 % faster in
+  // fp64 and on par in fp32 against the AGPR-pinned, two-workgroup variant (A/B in one run, n = 15507)
+  int pin_variant = getenv("GR_CHOL_PIN") ? atoi(getenv("GR_CHOL_PIN")) : 1;
   int potrf_skip = getenv("GR_CHOL_POTRF_SKIP") ? atoi(getenv("GR_CHOL_POTRF_SKIP")) : 0; // timing ablation only
 
   DenseChol() = default;
@@ -482,6 +508,7 @@ template <typename T> struct DenseChol {
     if (!attrs_set) {
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_gemm<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_gemm<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_gemm<T, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_potrf<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_potrf_lds(sizeof(T))));
       GR_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       attrs_set = true;
@@ -539,7 +566,8 @@ template <typename T> struct DenseChol {
     if (end <= beg) return;
     const int np_ = end - beg;
     Sc sc(sk, "chol_syrk", (2.0 * np_ + 2.0 * std::sqrt(2.0 * np_)) * tile_b(), 2.0 * np_ * tile_f());
-    k_chol_gemm<T, 1><<<np_, 256, chol_gemm_lds(sizeof(T)), q>>>(A.p, npad, d_pairs.p + 2 * (size_t)beg, 2 * p * CH_NB, nullptr, 2 * CH_NB / CH_KC);
+    if (pin_variant) k_chol_gemm<T, 1, 1><<<np_, 256, chol_gemm_lds(sizeof(T)), q>>>(A.p, npad, d_pairs.p + 2 * (size_t)beg, 2 * p * CH_NB, nullptr, 2 * CH_NB / CH_KC);
+    else k_chol_gemm<T, 1><<<np_, 256, chol_gemm_lds(sizeof(T)), q>>>(A.p, npad, d_pairs.p + 2 * (size_t)beg, 2 * p * CH_NB, nullptr, 2 * CH_NB / CH_KC);
   }
   void factor() {
     GR_HIP(hipMemsetAsync(d_fail.p, 0, sizeof(int), stream));
