@@ -51,7 +51,7 @@ class LMStats(C.Structure):
 
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
-                ("bytes_per_launch", C.c_double), ("flops_per_launch", C.c_double)]
+                ("bytes_per_launch", C.c_double), ("flops_per_launch", C.c_double), ("active_launches", C.c_int64)]
 
 
 def build(force: bool = False) -> str:

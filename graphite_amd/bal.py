@@ -167,7 +167,7 @@ class BalProblem:
         out = {}
         for i in range(min(n.value, 64)):
             k = arr[i]
-            out[k.name.decode()] = dict(launches=k.launches, total_ms=k.total_ms,
+            out[k.name.decode()] = dict(launches=k.launches, active_launches=k.active_launches, total_ms=k.total_ms,
                                         bytes_per_launch=k.bytes_per_launch, flops_per_launch=k.flops_per_launch)
         return out
 

@@ -29,8 +29,9 @@ static inline int cdiv(size_t a, size_t b) { return (int)((a + b - 1) / b); }
 
 struct KernelProf {
   std::string name;
-  int64_t launches = 0;
-  double total_ms = 0, bytes = 0, flops = 0;
+  int64_t launches = 0, noop = 0; // noop: look-ahead launches that found the PCG loop already finished
+  double total_ms = 0, bytes = 0, flops = 0; // bytes / flops: summed over the scoped launches
+  int64_t scoped = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
@@ -373,7 +374,7 @@ template <typename T> struct Engine final : EngineBase {
     Scope(Engine *e_, const char *name, double bytes, double flops) : e(e_) {
       if (!e->profiling) return;
       kp = &e->prof[name];
-      kp->name = name; kp->bytes = bytes; kp->flops = flops;
+      kp->name = name; kp->bytes += bytes; kp->flops += flops; kp->scoped++;
       (void)hipEventCreate(&a); (void)hipEventCreate(&b);
       (void)hipEventRecord(a, e->stream);
     }
@@ -403,7 +404,9 @@ template <typename T> struct Engine final : EngineBase {
         std::memset(&out[k], 0, sizeof(gr_kernel_stat));
         std::strncpy(out[k].name, it.second.name.c_str(), sizeof(out[k].name) - 1);
         out[k].launches = it.second.launches; out[k].total_ms = it.second.total_ms;
-        out[k].bytes_per_launch = it.second.bytes; out[k].flops_per_launch = it.second.flops;
+        const double sc = (double)std::max<int64_t>(it.second.scoped, 1);
+        out[k].bytes_per_launch = it.second.bytes / sc; out[k].flops_per_launch = it.second.flops / sc;
+        out[k].active_launches = it.second.launches - it.second.noop;
       }
       ++k;
     }
@@ -620,12 +623,24 @@ template <typename T> struct Engine final : EngineBase {
   // no host round trip inside the loop.
   // host side of the device-resident PCG loops: enqueue with one iteration of look-ahead and stop
   // once the direction kernel has flagged (pinned memory) that the loop has left
-  template <typename Enqueue> void run_pcg_iterations(int max_iter, Enqueue &&enqueue) {
-    if (max_iter > 0) enqueue(0);
+  // returns the number of look-ahead enqueues that ran as no-ops (the loop had already left)
+  template <typename Enqueue> int run_pcg_iterations(int max_iter, Enqueue &&enqueue) {
+    int enqueued = 0;
+    bool left = false;
+    if (max_iter > 0) { enqueue(0); ++enqueued; }
     for (int k = 0; k < max_iter; ++k) {
-      if (k + 1 < max_iter) enqueue(k + 1);
+      if (k + 1 < max_iter) { enqueue(k + 1); ++enqueued; }
       spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
-      if (h_flag[k] == 2) break;
+      if (h_flag[k] == 2) { left = true; break; }
+    }
+    const int active = left ? std::min((int)h_seq[1], enqueued) : enqueued;
+    return enqueued - active;
+  }
+  void note_noop(std::initializer_list<const char *> names, int count) {
+    if (!profiling || count <= 0) return;
+    for (const char *nm : names) {
+      auto it = prof.find(nm);
+      if (it != prof.end()) it->second.noop += count;
     }
   }
   int solve_pcg_schur(int max_iter, double tol, double rej, T *x) {
@@ -637,11 +652,12 @@ template <typename T> struct Engine final : EngineBase {
     h_seq[1] = 0;
     k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
     k_pcgs_init<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, nullptr, nullptr, sc);
-    run_pcg_iterations(max_iter, [&](int k) {
+    const int noop = run_pcg_iterations(max_iter, [&](int k) {
       schur_matvec_dev(v_p.p, v_Ap.p, k);
       k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k);
       k_pcgs_direction<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_p.p, v_z.p, nullptr, nullptr, sc, k, tol, rej);
     });
+    note_noop({"schur_matvec"}, noop);
     landmark_update_dev(x, x + pose_dim);
     return 0;
   }
@@ -712,7 +728,7 @@ template <typename T> struct Engine final : EngineBase {
     k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
     k_pcgs_init<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, v_q.p, scales.p, sc);
     const double pass_bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np + 9.0 * Nc) * w() + 3.0 * No * w();
-    run_pcg_iterations(max_iter, [&](int k) {
+    const int noop = run_pcg_iterations(max_iter, [&](int k) {
       {
         Scope s1(this, "is_pass1", pass_bytes, No * 290.0);
         k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k);
@@ -726,6 +742,7 @@ template <typename T> struct Engine final : EngineBase {
       k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k);
       k_pcgs_direction<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_p.p, v_z.p, v_q.p, scales.p, sc, k, tol, rej);
     });
+    note_noop({"is_pass1", "is_pass2"}, noop);
     // back-substitution x_l = Hll^-1 (b_l - Hpl^T x_p): pass 1 with q = s_c .* x_c, then the per-point solve
     k_mul<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((unsigned)pose_dim, v_q.p, scales.p, x);
     k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1);
@@ -787,12 +804,7 @@ template <typename T> struct Engine final : EngineBase {
         k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej);
       }
     };
-    if (max_iter > 0) enqueue(0);
-    for (int k = 0; k < max_iter; ++k) {
-      if (k + 1 < max_iter) enqueue(k + 1); // look-ahead
-      spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
-      if (h_flag[k] == 2) break;
-    }
+    note_noop({"pcg_operator", "pcg_update", "pcg_direction"}, run_pcg_iterations(max_iter, enqueue));
   }
 
   // Diagnostic: average device time (us) of `reps` back-to-back launches of one hot kernel

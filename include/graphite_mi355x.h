@@ -174,6 +174,8 @@ typedef struct {
   double total_ms;
   double bytes_per_launch; /* algorithmic HBM bytes per launch */
   double flops_per_launch;
+  int64_t active_launches; /* launches minus the look-ahead launches that found the PCG loop already finished
+                              (those return at once and move no data); rooflines are priced on these */
 } gr_kernel_stat;
 gr_status gr_bal_kernel_stats(gr_bal_problem *p, gr_kernel_stat *out, int cap, int *n);
 
