@@ -450,7 +450,11 @@ template <typename T> struct Engine final : EngineBase {
   // Graph::linearize (graph.hpp:236-290) fused with Hessian::update_values
   // (hessian.hpp:290-307): ONE launch over the observations (pm blocks + cm chunks)
   // followed by the finalize kernel (chunk sums, scales, chi2).
-  void linearize_impl(bool write_hcp, bool pack_valid = false) {
+  // spec_seq != 0: speculative trial linearisation of the LM loop; the finalize kernel also folds the
+  // rho-denominator partials and publishes (chi2, denominator, spec_seq) to pinned host memory
+  DevBuf<double> rho_partial;
+  static constexpr int RHO_BLOCKS = 256;
+  void linearize_impl(bool write_hcp, bool pack_valid = false, int spec_seq = 0) {
     if (!pack_valid) campack();
     {
       // algorithmic bytes: every array touched once (obs, 3 index streams, points, packs, g9 out, partials, Hcp)
@@ -463,13 +467,14 @@ template <typename T> struct Engine final : EngineBase {
     }
     {
       Scope sc(this, "linearize_finalize", 9.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
-      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p);
+      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
+                                                                                                    spec_seq ? rho_partial.p : nullptr, spec_seq ? RHO_BLOCKS : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq);
     }
     if (comm) { // camera-space sums over the landmark shards
       comm->group_start();
       allreduce_T(Hcc.p, 81 * (size_t)Nc);
       allreduce_T(bc.p, pose_dim);
-      allreduce_d(dscalars.p, 1);
+      allreduce_d(dscalars.p, spec_seq ? 2 : 1);
       comm->group_end();
       k_camera_scales<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, scale_system ? 1 : 0, Hcc.p, scales.p);
     }
@@ -951,6 +956,8 @@ template <typename T> struct Engine final : EngineBase {
     solver_update_values(opt.solver);
     T chi2v = (T)read_scalar(0);
     bool run = true;
+    int accept_streak = 2; // consecutive accepted iterations (saturating): speculate only on a streak
+    const bool spec_enabled = !(getenv("GR_LM_SPECULATE") && atoi(getenv("GR_LM_SPECULATE")) == 0);
     if (chi2_trace) chi2_trace[0] = (double)chi2v;
     if (lambda_trace) lambda_trace[0] = (double)mu;
     hipEvent_t ev_a, ev_b;
@@ -963,10 +970,25 @@ template <typename T> struct Engine final : EngineBase {
       GR_HIP(hipEventRecord(ev_a, stream));
       const bool solve_ok = solver_solve_dev(opt.solver, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, v_dx.p);
       GR_HIP(hipEventRecord(ev_b, stream));
-      apply_update_dev(v_dx.p, /*with_backup=*/true); // backup_parameters + apply_update fused
-      // trial chi2 + compute_rho denominator (:20-47) in one kernel; its last block mirrors the two
-      // sums into pinned host memory, so the host polls one word instead of memcpy + stream sync
-      const int seq = chi2_async(nullptr, v_dx.p, (double)mu);
+      // Trial step.  After two accepted iterations the next one is expected to be accepted too, so the
+      // trial chi2 is taken from a SPECULATIVE linearisation at the trial point (its chi2 is the same
+      // sum): on acceptance the iteration is already linearised and the separate chi2 pass is saved;
+      // on rejection the old linearisation is re-created from the reverted vertices (same bits: all
+      // sums are fixed-order).  After a rejection the plain chi2 pass is used.
+      int seq;
+      const bool speculate = accept_streak >= 2 && spec_enabled;
+      if (speculate) {
+        rho_partial.alloc(RHO_BLOCKS);
+        k_rho_denominator<T><<<RHO_BLOCKS, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cam_weight(), v_dx.p, bu.p, scales.p, (double)mu, rho_partial.p);
+        apply_update_dev(v_dx.p, /*with_backup=*/true); // backup_parameters + apply_update fused
+        seq = ++seq_counter;
+        linearize_impl(want_hcp, /*pack_valid=*/true, seq);
+      } else {
+        apply_update_dev(v_dx.p, /*with_backup=*/true);
+        // trial chi2 + compute_rho denominator (:20-47) in one kernel; its last block mirrors the two
+        // sums into pinned host memory, so the host polls one word instead of memcpy + stream sync
+        seq = chi2_async(nullptr, v_dx.p, (double)mu);
+      }
       wait_chi2(seq);
       const int it = h_seq[1]; // every PCG variant mirrors its iteration count into pinned memory
       const double hs[2] = {h_res[0], h_res[1]};
@@ -984,11 +1006,14 @@ template <typename T> struct Engine final : EngineBase {
         alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
         mu *= (T)alpha;
         nu = 2;
-        linearize_impl(want_hcp, /*pack_valid=*/true);
+        if (!speculate) linearize_impl(want_hcp, /*pack_valid=*/true);
         solver_update_values(opt.solver);
         st.accepted++;
+        accept_streak = std::min(accept_streak + 1, 2);
       } else {
         revert();
+        if (speculate) linearize_impl(want_hcp, /*pack_valid=*/true); // restore H, b, scales of the kept point
+        accept_streak = 0;
         // the reference recomputes error + chi2 here (:199-201); every consumer below
         // recomputes residuals from the reverted vertices, so nothing is stale.
         mu *= nu;
