@@ -1,9 +1,11 @@
 // bal.cpp — the BAL driver of the reference (examples/bal.cu:43-360) on the MI355X library.
 // Same file format, same options (--lambda --iterations --verbose --pcg_iterations --pcg_tolerance
-// --rejection_ratio --precision {FP64-FP64,FP32-FP32} --solver {pcg,pcg-schur} --identity_damping),
+// --rejection_ratio --precision {FP64-FP64,FP32-FP32} --solver {pcg,pcg-schur,pcg-schur-implicit,eigen-schur,
+// cudss-schur} --identity_damping --hybrid_memory),
 // same printed summary (MSE / Half MSE).  Host-only C++17: g++ -Iinclude examples/bal.cpp
 // -Lgraphite_amd -lgraphite_mi355x -Wl,-rpath,$PWD/graphite_amd -o bal
 #include "graphite_mi355x.hpp"
+#include <charconv>
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -32,12 +34,13 @@ static Args parse(int argc, char **argv) {
     else if (s == "--precision") a.precision = next();
     else if (s == "--solver") a.solver = next();
     else if (s == "--identity_damping") a.identity_damping = true;
+    else if (s == "--hybrid_memory") (void)next(); // cuDSS option of the reference: accepted, unused
     else if (s.rfind("--", 0) == 0) throw std::runtime_error("unknown option " + s);
     else a.file = s;
   }
   if (a.file.empty()) throw std::runtime_error("usage: bal <file> [--lambda 1e-4] [--iterations 50] [--verbose] [--pcg_iterations 10] "
                                                "[--pcg_tolerance 1.0] [--rejection_ratio 5.0] [--precision FP64-FP64|FP32-FP32] "
-                                               "[--solver pcg|pcg-schur] [--identity_damping]");
+                                               "[--solver pcg|pcg-schur|pcg-schur-implicit|eigen-schur|cudss-schur] [--identity_damping] [--hybrid_memory MB]");
   return a;
 }
 
@@ -45,20 +48,46 @@ template <typename FP> void bundle_adjustment(const Args &a) {
   using namespace graphite;
   std::cout << "Running bundle adjustment with graph precision = " << (sizeof(FP) == 8 ? "double" : "float")
             << " and solver precision = " << (sizeof(FP) == 8 ? "double" : "float") << std::endl;
-  std::ifstream file(a.file);
+  // The reference reads the file with operator>> and one managed-memory push_back per line
+  // (bal.cu:96-109); at Final-13682 scale (29 M observation lines) that is minutes of host time.
+  // Here: one read of the whole file, std::from_chars over the buffer.
+  std::ifstream file(a.file, std::ios::binary | std::ios::ate);
   if (!file.is_open()) { std::cerr << "Error: Unable to open file " << a.file << std::endl; throw std::runtime_error("File open error"); }
-  size_t num_cameras = 0, num_points = 0, num_observations = 0;
-  file >> num_cameras >> num_points >> num_observations;
+  auto start = std::chrono::steady_clock::now();
+  std::string buf((size_t)file.tellg(), '\0');
+  file.seekg(0);
+  file.read(buf.data(), (std::streamsize)buf.size());
+  const char *cur = buf.data(), *end = buf.data() + buf.size();
+  auto skip = [&] { while (cur < end && (*cur == ' ' || *cur == '\n' || *cur == '\r' || *cur == '\t')) ++cur; };
+  auto next_u = [&]() -> size_t {
+    skip();
+    size_t v = 0;
+    auto r = std::from_chars(cur, end, v);
+    if (r.ec != std::errc()) throw std::runtime_error("truncated BAL file");
+    cur = r.ptr;
+    return v;
+  };
+  auto next_f = [&]() -> double {
+    skip();
+    if (cur < end && *cur == '+') ++cur;
+    double v = 0;
+    auto r = std::from_chars(cur, end, v);
+    if (r.ec != std::errc()) throw std::runtime_error("truncated BAL file");
+    cur = r.ptr;
+    return v;
+  };
+  const size_t num_cameras = next_u(), num_points = next_u(), num_observations = next_u();
   std::cout << "Number of cameras: " << num_cameras << std::endl;
   std::cout << "Number of points: " << num_points << std::endl;
   std::cout << "Number of observations: " << num_observations << std::endl;
-  auto start = std::chrono::steady_clock::now();
   std::vector<int32_t> cam_idx(num_observations), pt_idx(num_observations);
   std::vector<FP> obs(2 * num_observations), cameras(9 * num_cameras), points(3 * num_points);
-  for (size_t i = 0; i < num_observations; ++i) file >> cam_idx[i] >> pt_idx[i] >> obs[2 * i] >> obs[2 * i + 1];
-  for (auto &v : cameras) file >> v;
-  for (auto &v : points) file >> v;
-  if (!file) throw std::runtime_error("truncated BAL file");
+  for (size_t i = 0; i < num_observations; ++i) {
+    cam_idx[i] = (int32_t)next_u(); pt_idx[i] = (int32_t)next_u();
+    obs[2 * i] = (FP)next_f(); obs[2 * i + 1] = (FP)next_f();
+  }
+  for (auto &v : cameras) v = (FP)next_f();
+  for (auto &v : points) v = (FP)next_f();
   std::cout << "Reading the problem took " << std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() << " seconds." << std::endl;
 
   start = std::chrono::steady_clock::now();
@@ -75,7 +104,17 @@ template <typename FP> void bundle_adjustment(const Args &a) {
   } else if (a.solver == "pcg-schur") {
     std::cout << "Using PCG Schur solver." << std::endl;
     solver_ptr = std::make_unique<PCGSchurSolver<FP>>(a.pcg_iterations, (FP)a.pcg_tolerance, (FP)a.rejection_ratio, &schur_preconditioner);
-  } else throw std::runtime_error("Unsupported solver option (pcg | pcg-schur; eigen/cudss variants are not provided)");
+  } else if (a.solver == "pcg-schur-implicit") {
+    std::cout << "Using PCG Schur solver (implicit Schur complement)." << std::endl;
+    solver_ptr = std::make_unique<PCGImplicitSchurSolver<FP>>(a.pcg_iterations, (FP)a.pcg_tolerance, (FP)a.rejection_ratio, &schur_preconditioner);
+  } else if (a.solver == "eigen-schur") {
+    std::cout << "Using Eigen Schur LDLT solver." << std::endl; // the reference's line; here: dense MFMA Cholesky of S
+    solver_ptr = std::make_unique<EigenSchurLDLTSolver<FP>>();
+  } else if (a.solver == "cudss-schur") {
+    std::cout << "Using cuDSS Schur solver." << std::endl;
+    solver_ptr = std::make_unique<cudssSchurSolver<FP>>();
+  } else throw std::runtime_error("Unsupported solver option (pcg | pcg-schur | pcg-schur-implicit | eigen-schur | cudss-schur; "
+                                  "the full-system direct solvers eigen / cudss are not provided)");
 
   std::cout << "Optimizing!" << std::endl;
   StreamPool streams(8);

@@ -157,6 +157,27 @@ public:
   }
 };
 
+// PCGSchurSolver with S applied implicitly (Hpp - Hpl Hll^-1 Hpl^T, never formed): same iterates, no
+// Pi-sized product list; the choice for Venice/Final-sized graphs (mode 2b)
+template <typename T, typename S = T> class PCGImplicitSchurSolver : public CApiSolver<T, S> {
+public:
+  PCGImplicitSchurSolver(size_t max_iter, T tol, T rejection_ratio, SchurPreconditioner<T, S> *preconditioner)
+      : CApiSolver<T, S>(GR_SOLVER_PCG_SCHUR_IMPLICIT, max_iter, tol, rejection_ratio) {
+    if (!preconditioner) throw std::invalid_argument("PCGImplicitSchurSolver: preconditioner is null");
+  }
+};
+// Direct solve of the reduced camera system: EigenSchurLDLTSolver (solver/eigen_schur.hpp:16-110) and
+// cudssSchurSolver (solver/cudss_schur.hpp:29-236) both map to the dense MFMA Cholesky of S.
+template <typename T, typename S = T> class EigenSchurLDLTSolver : public CApiSolver<T, S> {
+public:
+  EigenSchurLDLTSolver() : CApiSolver<T, S>(GR_SOLVER_DENSE_SCHUR, 0, T(0), T(0)) {}
+};
+struct cudssSolverOptions { int64_t hybrid_memory = 0; }; // accepted, unused (solver/cudss.hpp:19-27)
+template <typename T, typename S = T> class cudssSchurSolver : public CApiSolver<T, S> {
+public:
+  explicit cudssSchurSolver(const cudssSolverOptions & = {}) : CApiSolver<T, S>(GR_SOLVER_DENSE_SCHUR, 0, T(0), T(0)) {}
+};
+
 namespace optimizer {
 
 // optimizer/levenberg_marquardt.hpp:52-98

@@ -36,13 +36,15 @@ def test_cpp_mirror_runs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("solver,precision", [("pcg", "FP64-FP64"), ("pcg-schur", "FP32-FP32")])
+@pytest.mark.parametrize("solver,precision", [("pcg", "FP64-FP64"), ("pcg-schur", "FP32-FP32"), ("pcg-schur-implicit", "FP64-FP64"),
+                                              ("eigen-schur", "FP64-FP64"), ("cudss-schur", "FP32-FP32")])
 def test_bal_driver_on_a_bal_file(tmp_path, solver, precision):
     exe = compile_cpp(os.path.join(ROOT, "examples", "bal.cpp"), os.path.join(BUILD, "bal"))
     prob = synth.make_config("mini-50")
     f = tmp_path / "problem-50-2000-pre.txt"
     synth.write_bal(f, prob)
-    r = subprocess.run([exe, str(f), "--iterations", "10", "--solver", solver, "--precision", precision, "--verbose"],
+    r = subprocess.run([exe, str(f), "--iterations", "10", "--solver", solver, "--precision", precision, "--verbose",
+                        "--hybrid_memory", "0"],
                        capture_output=True, text=True, timeout=120)
     print(r.stdout[-1500:], r.stderr)
     assert r.returncode == 0
