@@ -550,7 +550,13 @@ template <typename T> struct Engine final : EngineBase {
     return sc;
   }
 
+  void check_sharded_solver(int solver) const {
+    if (comm && (solver == GR_SOLVER_PCG_SCHUR || solver == GR_SOLVER_DENSE_SCHUR))
+      throw std::invalid_argument("landmark-sharded problems support GR_SOLVER_PCG, GR_SOLVER_PCG_IDENTITY and GR_SOLVER_PCG_SCHUR_IMPLICIT "
+                                  "(the explicit Schur complement is not all-reduced)");
+  }
   void solver_update_structure(int solver) override {
+    check_sharded_solver(solver);
     if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
     else if (solver == GR_SOLVER_DENSE_SCHUR) { ensure_chol(); want_hcp = true; }
     else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) { want_hcp = false; ensure_implicit_schur(); }
@@ -710,7 +716,7 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   // Implicit Schur PCG (kernels_is.hpp): same iterates, S never formed, Jacobians recomputed.
-  DevBuf<T> Sdiag, zl, v_q;
+  DevBuf<T> Sdiag, zl, v_q, is_raw;
   void ensure_implicit_schur() {
     Hll_inv.alloc(9 * (size_t)Np); Mp.alloc(9 * (size_t)Np); vl.alloc(3 * (size_t)Np); zl.alloc(3 * (size_t)Np);
     Sdiag.alloc(81 * (size_t)Nc); MinvS.alloc(81 * (size_t)Nc); b_schur.alloc(pose_dim); v_q.alloc(pose_dim);
@@ -724,7 +730,13 @@ template <typename T> struct Engine final : EngineBase {
       Scope s0(this, "is_prepare", No * (2 * w() + 12.0) + (24.0 * Nc + 15.0 * Np) * w() + 54.0 * nseg * w(), No * 700.0);
       k_is_prepare<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p);
     }
-    k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p);
+    if (comm) { // diagonal blocks of S and b_S: this shard's sums, all-reduced, then combined with the global Hcc, bc
+      is_raw.alloc(90 * (size_t)Nc);
+      k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p, nullptr, is_raw.p);
+      allreduce_T(is_raw.p, 90 * (size_t)Nc);
+      k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p, is_raw.p, nullptr);
+    } else
+      k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p);
     k_inv9<T, 2><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Sdiag.p, nullptr, nullptr, 0.0, 0, MinvS.p, nullptr);
     ensure_scalars(max_iter);
     PcgScalars sc = scalars();
@@ -743,7 +755,11 @@ template <typename T> struct Engine final : EngineBase {
         Scope s2(this, "is_pass2", No * (2 * w() + 12.0) + (24.0 * Nc + 6.0 * Np) * w() + 9.0 * nseg * w(), No * 290.0);
         k_is_pass2<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k);
       }
-      k_is_apply<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, Hcc.p, scales.p, v_p.p, v_q.p, damping, ui, v_Ap.p, sc, k);
+      if (comm) { // one all-reduce of the 9 Nc vector per iteration; r, z, p are replicated, so no dot crosses ranks
+        k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, sc.done, k);
+        allreduce_T(raw_c.p, pose_dim);
+      }
+      k_is_apply<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, Hcc.p, scales.p, v_p.p, v_q.p, damping, ui, v_Ap.p, sc, k, comm ? raw_c.p : nullptr);
       k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k);
       k_pcgs_direction<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_p.p, v_z.p, v_q.p, scales.p, sc, k, tol, rej);
     });
@@ -867,6 +883,7 @@ template <typename T> struct Engine final : EngineBase {
   }
   bool solver_solve_dev(int solver, int max_iter, double tol, double rej, T *x) {
     last_solver = solver;
+    check_sharded_solver(solver);
     switch (solver) {
     case GR_SOLVER_PCG_SCHUR: solve_pcg_schur(max_iter, tol, rej, x); return true;
     case GR_SOLVER_PCG: solve_pcg<false>(max_iter, tol, rej, x); return true;

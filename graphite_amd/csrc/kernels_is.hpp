@@ -126,7 +126,10 @@ k_is_prepare(int No, int ntiles, const int *__restrict__ cam_cm, const int *__re
 template <typename T>
 __global__ void k_is_finalize(int Nc, const int *__restrict__ cam_seg_ptr, const T *__restrict__ cam_partial,
                               const T *__restrict__ Hcc, const T *__restrict__ bc, const T *__restrict__ scales,
-                              double mu, int use_identity, T *__restrict__ Sdiag, T *__restrict__ b_schur) {
+                              double mu, int use_identity, T *__restrict__ Sdiag, T *__restrict__ b_schur,
+                              const T *__restrict__ raw_in = nullptr, T *__restrict__ raw_out = nullptr) {
+  // multi-GPU: stage 1 (raw_out) leaves this shard's 90 sums per camera for the all-reduce,
+  // stage 2 (raw_in) combines the all-reduced sums with the (already global) Hcc, bc
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 90u * (unsigned)Nc) return;
   const unsigned c = t / 90u, e = t % 90u;
@@ -138,7 +141,9 @@ __global__ void k_is_finalize(int Nc, const int *__restrict__ cam_seg_ptr, const
     idx = (int)(cc * (cc + 1) / 2 + r);
   } else idx = 45 + (int)(e - 81u);
   T s = 0;
-  for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) s += cam_partial[54 * (size_t)sg + idx];
+  if (raw_in) s = raw_in[t];
+  else for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) s += cam_partial[54 * (size_t)sg + idx];
+  if (raw_out) { raw_out[t] = s; return; }
   if (e < 81u) {
     const T sr = scales[9 * c + row], sc = scales[9 * c + col];
     T hh = sr * Hcc[81 * (size_t)c + e] * sc;
@@ -248,7 +253,8 @@ template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_is_apply(int Nc, const int *__restrict__ cam_seg_ptr, const T *__restrict__ op_partial,
            const T *__restrict__ Hcc, const T *__restrict__ scales, const T *__restrict__ p,
-           const T *__restrict__ q, double mu, int use_identity, T *__restrict__ Ap, PcgScalars sc, int k) {
+           const T *__restrict__ q, double mu, int use_identity, T *__restrict__ Ap, PcgScalars sc, int k,
+           const T *__restrict__ rawc = nullptr) {
   if (sc.done[k]) return;
   if (slot_sum(sc.rz, k) == 0.0) return;
   __shared__ double red[4];
@@ -266,7 +272,8 @@ k_is_apply(int Nc, const int *__restrict__ cam_seg_ptr, const T *__restrict__ op
 #pragma unroll
     for (int i = 0; i < 9; ++i) hq += H[r + 9 * i] * qc[i];
     T sub = 0;
-    for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) sub += op_partial[9 * (size_t)sg + r];
+    if (rawc) sub = rawc[t]; // multi-GPU: segment sums all-reduced over the landmark shards
+    else for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) sub += op_partial[9 * (size_t)sg + r];
     const T s = scales[t], pv = p[t];
     const T d = s * H[10 * r] * s; // scaled diagonal of Hcc (prev_diag of hessian.hpp:102-134)
     const T damp = use_identity ? (T)mu * pv : (T)(mu * clampd((double)d, 1.0e-6, 1.0e32)) * pv;

@@ -40,7 +40,7 @@ def run_sharded(prob, world, dtype, iterations, solver):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("solver", [ga.SOLVER_PCG, ga.SOLVER_PCG_IDENTITY])
+@pytest.mark.parametrize("solver", [ga.SOLVER_PCG, ga.SOLVER_PCG_IDENTITY, ga.SOLVER_PCG_SCHUR_IMPLICIT])
 def test_sharded_lm_matches_single(world, solver):
     prob = synth.make_config("mini-50")
     single = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
@@ -66,6 +66,16 @@ def test_sharded_ladybug49_fp32():
     out, cams, _ = run_sharded(prob, 4, np.float32, 5, ga.SOLVER_PCG)
     assert np.allclose(out[0][0], ct, rtol=2e-3)
     assert all(np.array_equal(c, cams[0]) for c in cams)
+
+
+def test_sharded_explicit_schur_is_refused():
+    prob = synth.make_config("mini-50")
+    shards = [gdist.partition_by_landmark(prob, r, 2) for r in range(2)]
+    engines = [ga.BalProblem(s.cameras, s.points, s.obs, s.cam_idx, s.pt_idx, dtype=np.float64, shard=True) for s in shards]
+    gdist.init_local_group(engines)
+    with pytest.raises(_lib.GraphiteError):
+        engines[0].levenberg_marquardt(solver=ga.SOLVER_PCG_SCHUR, iterations=1)
+    [e.close() for e in engines]
 
 
 def test_rccl_single_rank_communicator():
