@@ -1,6 +1,6 @@
 // bal.cpp — the BAL driver of the reference (examples/bal.cu:43-360) on the MI355X library.
 // Same file format, same options (--lambda --iterations --verbose --pcg_iterations --pcg_tolerance
-// --rejection_ratio --precision {FP64-FP64,FP32-FP32} --solver {pcg,pcg-schur,pcg-schur-implicit,eigen-schur,
+// --rejection_ratio --precision {FP64-FP64,FP64-FP32,FP32-FP32} --solver {pcg,pcg-schur,pcg-schur-implicit,eigen-schur,
 // cudss-schur} --identity_damping --hybrid_memory),
 // same printed summary (MSE / Half MSE).  Host-only C++17: g++ -Iinclude examples/bal.cpp
 // -Lgraphite_amd -lgraphite_mi355x -Wl,-rpath,$PWD/graphite_amd -o bal
@@ -39,15 +39,15 @@ static Args parse(int argc, char **argv) {
     else a.file = s;
   }
   if (a.file.empty()) throw std::runtime_error("usage: bal <file> [--lambda 1e-4] [--iterations 50] [--verbose] [--pcg_iterations 10] "
-                                               "[--pcg_tolerance 1.0] [--rejection_ratio 5.0] [--precision FP64-FP64|FP32-FP32] "
+                                               "[--pcg_tolerance 1.0] [--rejection_ratio 5.0] [--precision FP64-FP64|FP64-FP32|FP32-FP32] "
                                                "[--solver pcg|pcg-schur|pcg-schur-implicit|eigen-schur|cudss-schur] [--identity_damping] [--hybrid_memory MB]");
   return a;
 }
 
-template <typename FP> void bundle_adjustment(const Args &a) {
+template <typename FP, typename SP = FP> void bundle_adjustment(const Args &a) {
   using namespace graphite;
   std::cout << "Running bundle adjustment with graph precision = " << (sizeof(FP) == 8 ? "double" : "float")
-            << " and solver precision = " << (sizeof(FP) == 8 ? "double" : "float") << std::endl;
+            << " and solver precision = " << (sizeof(SP) == 8 ? "double" : "float") << std::endl;
   // The reference reads the file with operator>> and one managed-memory push_back per line
   // (bal.cu:96-109); at Final-13682 scale (29 M observation lines) that is minutes of host time.
   // Here: one read of the whole file, std::from_chars over the buffer.
@@ -92,6 +92,7 @@ template <typename FP> void bundle_adjustment(const Args &a) {
 
   start = std::chrono::steady_clock::now();
   BalGraph<FP> graph(cameras, points, obs, cam_idx, pt_idx);
+  if (sizeof(SP) < sizeof(FP)) graph.set_jacobian_precision_f32(true);
   std::cout << "Graph built with " << num_cameras << " cameras, " << num_points << " points, and " << num_observations
             << " observations (" << std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() << " s)." << std::endl;
 
@@ -143,7 +144,8 @@ int main(int argc, char *argv[]) {
     const Args a = parse(argc, argv);
     if (a.precision == "FP64-FP64") bundle_adjustment<double>(a);
     else if (a.precision == "FP32-FP32") bundle_adjustment<float>(a);
-    else throw std::runtime_error("Unsupported precision option (FP64-FP64 | FP32-FP32)");
+    else if (a.precision == "FP64-FP32") bundle_adjustment<double, float>(a);
+    else throw std::runtime_error("Unsupported precision option (FP64-FP64 | FP64-FP32 | FP32-FP32; the BF16 storage modes are not provided)");
   } catch (const std::exception &e) {
     std::cerr << "Error during bundle adjustment: " << e.what() << std::endl;
     return 1;

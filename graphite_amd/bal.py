@@ -70,6 +70,10 @@ class BalProblem:
     def scale_system(self, on):
         check(self.lib.gr_bal_set_scale_system(self.h, C.c_int(int(on))))
 
+    def set_jacobian_precision(self, dtype):
+        """np.float32 on an fp64 problem: Jacobian entries in fp32 (the reference's FP64-FP32 mode)."""
+        check(self.lib.gr_bal_set_jacobian_precision(self.h, C.c_int(F64 if np.dtype(dtype) == np.float64 else F32)))
+
     def set_params(self, cameras, points):
         c = np.ascontiguousarray(cameras, dtype=self.dt)
         p = np.ascontiguousarray(points, dtype=self.dt)

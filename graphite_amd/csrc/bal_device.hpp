@@ -127,6 +127,26 @@ __device__ __forceinline__ void bal_linearize(const T *pk, T X, T Y, T Z, T ox, 
   Jc[16] = f * r2 * r2 * px; Jc[17] = f * r2 * r2 * py;
 }
 
+// Mixed precision (the reference's Graph<T = double, S = float>, bal.cu --precision FP64-FP32): the
+// residual stays in T (ops/error.hpp evaluates the error in the graph precision), the Jacobian
+// entries are evaluated in JT and promoted; every accumulation downstream stays in T.
+template <typename T, typename JT>
+__device__ __forceinline__ void bal_linearize_j(const T *pk, T X, T Y, T Z, T ox, T oy, T &e0, T &e1, T *Jc, T *Jp) {
+  if constexpr (sizeof(JT) == sizeof(T)) {
+    bal_linearize<T>(pk, X, Y, Z, ox, oy, e0, e1, Jc, Jp);
+  } else {
+    bal_residual<T>(pk, X, Y, Z, ox, oy, e0, e1);
+    JT pj[PACK], f0, f1, Jcj[18], Jpj[6];
+#pragma unroll
+    for (int i = 0; i < PACK; ++i) pj[i] = (JT)pk[i];
+    bal_linearize<JT>(pj, (JT)X, (JT)Y, (JT)Z, (JT)ox, (JT)oy, f0, f1, Jcj, Jpj);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) Jc[i] = (T)Jcj[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Jp[i] = (T)Jpj[i];
+  }
+}
+
 // rho'(raw chi2)  — loss.hpp:15-51 (DefaultLoss kind 0, HuberLoss kind 1)
 template <typename T> __device__ __forceinline__ T loss_rho(int kind, T delta, T raw) {
   if (kind == 1 && !(raw <= delta * delta)) return T(2) * t_sqrt(raw) * delta - delta * delta;

@@ -39,6 +39,7 @@ struct EngineBase {
   virtual ~EngineBase() = default;
   virtual void set_loss(int kind, double delta) = 0;
   virtual void set_scale_system(bool on) = 0;
+  virtual void set_jacobian_precision(int dtype) = 0;
   virtual void set_params(const void *c, const void *p) = 0;
   virtual void get_params(void *c, void *p) = 0;
   virtual void linearize() = 0;
@@ -69,6 +70,7 @@ template <typename T> struct Engine final : EngineBase {
   int loss_kind = 0;
   T loss_delta = 0;
   bool scale_system = true;
+  bool jac32 = false; // Jacobian entries evaluated in fp32 and promoted (Graph<double, float>); T = double only
 
   // host structure
   std::vector<int> h_pt_ptr, h_cam_pm, h_pt_pm, h_cam_ptr, h_pt_cm, h_pos_cm, h_pm_of_orig;
@@ -416,6 +418,13 @@ template <typename T> struct Engine final : EngineBase {
   // ---- Graph --------------------------------------------------------------------
   void set_loss(int kind, double delta) override { loss_kind = kind; loss_delta = (T)delta; }
   void set_scale_system(bool on) override { scale_system = on; }
+  void set_jacobian_precision(int dtype) override {
+    if (dtype == GR_F32 && sizeof(T) == 4) { jac32 = false; return; } // already fp32 throughout
+    if (dtype != GR_F32 && dtype != GR_F64) throw std::invalid_argument("jacobian precision: GR_F32 or GR_F64");
+    if (dtype == GR_F64 && sizeof(T) == 4) throw std::invalid_argument("an fp32 problem cannot evaluate fp64 Jacobians");
+    jac32 = dtype == GR_F32;
+    hcp_valid = false;
+  }
   // user point order <-> internal point order at the API boundary (width scalars per point)
   void points_in(const void *user_src, T *dev_dst, int width) {
     std::vector<T> a((size_t)Np * width), b((size_t)Np * width);
@@ -460,11 +469,12 @@ template <typename T> struct Engine final : EngineBase {
       // algorithmic bytes: every array touched once (obs, 3 index streams, points, packs, g9 out, partials, Hcp)
       const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 9.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
       Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)));
-      if (write_hcp)
-        k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p);
-      else
-        k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
+      if (write_hcp) {
+        if (jac32) { k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); } else { k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); }
+      } else {
+        if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); } else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); }
     }
+      }
     {
       Scope sc(this, "linearize_finalize", 9.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
       k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
@@ -728,7 +738,7 @@ template <typename T> struct Engine final : EngineBase {
     k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p);
     {
       Scope s0(this, "is_prepare", No * (2 * w() + 12.0) + (24.0 * Nc + 15.0 * Np) * w() + 54.0 * nseg * w(), No * 700.0);
-      k_is_prepare<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p);
+      if (jac32) { k_is_prepare<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); } else { k_is_prepare<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); }
     }
     if (comm) { // diagonal blocks of S and b_S: this shard's sums, all-reduced, then combined with the global Hcc, bc
       is_raw.alloc(90 * (size_t)Nc);
@@ -748,12 +758,12 @@ template <typename T> struct Engine final : EngineBase {
     const int noop = run_pcg_iterations(max_iter, [&](int k) {
       {
         Scope s1(this, "is_pass1", pass_bytes, No * 290.0);
-        k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k);
+        if (jac32) { k_is_pass1<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k); } else { k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k); }
       }
       k_is_points<T, 0><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, zl.p, sc, k);
       {
         Scope s2(this, "is_pass2", No * (2 * w() + 12.0) + (24.0 * Nc + 6.0 * Np) * w() + 9.0 * nseg * w(), No * 290.0);
-        k_is_pass2<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k);
+        if (jac32) { k_is_pass2<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k); } else { k_is_pass2<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k); }
       }
       if (comm) { // one all-reduce of the 9 Nc vector per iteration; r, z, p are replicated, so no dot crosses ranks
         k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, sc.done, k);
@@ -766,7 +776,7 @@ template <typename T> struct Engine final : EngineBase {
     note_noop({"is_pass1", "is_pass2"}, noop);
     // back-substitution x_l = Hll^-1 (b_l - Hpl^T x_p): pass 1 with q = s_c .* x_c, then the per-point solve
     k_mul<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((unsigned)pose_dim, v_q.p, scales.p, x);
-    k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1);
+    if (jac32) { k_is_pass1<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1); } else { k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1); }
     k_is_points<T, 1><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, x + pose_dim, sc, 0);
   }
 
@@ -806,7 +816,7 @@ template <typename T> struct Engine final : EngineBase {
     auto enqueue = [&](int k) {
       {
         Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
-        k_pcg_operator<T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k);
+        if (jac32) { k_pcg_operator<T, 0, float><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k); } else { k_pcg_operator<T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k); }
       }
       if (comm) { // camera rows + the p.A.p partials, summed over the landmark shards
         k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, nullptr, k);
@@ -1156,6 +1166,7 @@ gr_status gr_bal_destroy(gr_bal_problem *p) {
 }
 gr_status gr_bal_set_loss(gr_bal_problem *p, gr_loss kind, double delta) { return guarded(p, [&] { p->e->set_loss(kind, delta); }); }
 gr_status gr_bal_set_scale_system(gr_bal_problem *p, int enable) { return guarded(p, [&] { p->e->set_scale_system(enable != 0); }); }
+gr_status gr_bal_set_jacobian_precision(gr_bal_problem *p, gr_dtype dtype) { return guarded(p, [&] { p->e->set_jacobian_precision((int)dtype); }); }
 gr_status gr_bal_set_params(gr_bal_problem *p, const void *c, const void *q) { return guarded(p, [&] { p->e->set_params(c, q); }); }
 gr_status gr_bal_get_params(gr_bal_problem *p, void *c, void *q) { return guarded(p, [&] { p->e->get_params(c, q); }); }
 gr_status gr_bal_linearize(gr_bal_problem *p) { return guarded(p, [&] { p->e->linearize(); }); }

@@ -67,7 +67,7 @@ __device__ __forceinline__ void reduce_by_camera(bool valid, int c, int seg, int
 //   D   = sum_obs Hcp_o M'_l Hcp_o^T   (45 unique)      -> diagonal blocks of S
 //   rhs = sum_obs Hcp_o v_l            (9),  v_l = M'_l bl^u  -> b_S
 // with Hcp_o = w Jc^T Jp recomputed.  (schur.hpp:649-734 restricted to i == j, :901-920)
-template <typename T>
+template <typename T, typename JT = T>
 __global__ void __launch_bounds__(TPB)
 k_is_prepare(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
              const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
@@ -86,7 +86,7 @@ k_is_prepare(int No, int ntiles, const int *__restrict__ cam_cm, const int *__re
       seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
       T pk[PACK], e0, e1, Jc[18], Jp[6];
       load_pack(pack, c, pk);
-      bal_linearize(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], ox, oy, e0, e1, Jc, Jp);
+      bal_linearize_j<T, JT>(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], ox, oy, e0, e1, Jc, Jp);
       const T w = loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
       const T *m = Mp + 9 * (size_t)l;
       const T *v = vl + 3 * (size_t)l;
@@ -156,7 +156,7 @@ __global__ void k_is_finalize(int Nc, const int *__restrict__ cam_seg_ptr, const
 }
 
 // pass 1:  g3[pm slot] = Jp^T w (Jc q_c)      (Hpl^T p, one observation's share)
-template <typename T>
+template <typename T, typename JT = T>
 __global__ void __launch_bounds__(TPB)
 k_is_pass1(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
            const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const T *__restrict__ pts,
@@ -170,7 +170,7 @@ k_is_pass1(int No, int ntiles, const int *__restrict__ cam_cm, const int *__rest
     if (!valid) return;
     T pk[PACK], e0, e1, Jc[18], Jp[6];
     load_pack(pack, c, pk);
-    bal_linearize(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], ox, oy, e0, e1, Jc, Jp);
+    bal_linearize_j<T, JT>(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], ox, oy, e0, e1, Jc, Jp);
     const T w = loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
     const T *qc = q + 9 * (size_t)c;
     T t0 = 0, t1 = 0;
@@ -212,7 +212,7 @@ __global__ void k_is_points(int Np, int Nc, const int *__restrict__ pt_ptr, cons
 }
 
 // pass 2: per (wave, camera) segment partial of  sum_obs Jc^T w Jp z_l
-template <typename T>
+template <typename T, typename JT = T>
 __global__ void __launch_bounds__(TPB)
 k_is_pass2(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
            const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
@@ -230,7 +230,7 @@ k_is_pass2(int No, int ntiles, const int *__restrict__ cam_cm, const int *__rest
       seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
       T pk[PACK], e0, e1, Jc[18], Jp[6];
       load_pack(pack, c, pk);
-      bal_linearize(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], ox, oy, e0, e1, Jc, Jp);
+      bal_linearize_j<T, JT>(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], ox, oy, e0, e1, Jc, Jp);
       const T w = loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
       const T *z = zl + 3 * (size_t)l;
       const T v0 = w * (Jp[0] * z[0] + Jp[2] * z[1] + Jp[4] * z[2]);

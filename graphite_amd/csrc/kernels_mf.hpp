@@ -129,7 +129,7 @@ __device__ __forceinline__ bool grid_sum2(double v0, double v1, double *partial,
 // 256-observation tiles and prefetches the next tile's index streams before it computes the
 // current one, so the per-block fixed costs (launch, tail, chi2 partial) are amortised and the
 // index -> gather dependency is off the critical path.
-template <typename T, bool WRITE_HCP>
+template <typename T, bool WRITE_HCP, typename JT = T>
 __global__ void __launch_bounds__(TPB)
 k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
             const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
@@ -162,7 +162,7 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
       seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
       T pk[PACK], Jp[6];
       load_pack(pack, c, pk);
-      bal_linearize(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], o.x, o.y, e0, e1, Jc, Jp);
+      bal_linearize_j<T, JT>(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], o.x, o.y, e0, e1, Jc, Jp);
       const T raw = e0 * e0 + e1 * e1;
       w = loss_drho(loss_kind, loss_delta, raw);
       chi2 += (double)loss_rho(loss_kind, loss_delta, raw);
@@ -368,7 +368,7 @@ k_chi2(int No, unsigned n, unsigned pose_dim, int cam_weight, const int *__restr
 //   point rows : per-observation Jp^T w                    -> g3[pm position][3]
 // VAR (diagnostic builds only, GR_DIAG): 1 no g3 scatter, 2 no point gather, 4 no ps_l gather,
 // 8 no Jacobian math, 16 no wave reduction.  VAR = 0 is the product kernel.
-template <typename T, int VAR = 0>
+template <typename T, int VAR = 0, typename JT = T>
 __global__ void __launch_bounds__(TPB)
 k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
                const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
@@ -416,7 +416,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
 #pragma unroll
         for (int i = 0; i < 6; ++i) Jp[i] = pts[3 * lp + (i % 3)] - pk[i];
       } else
-        bal_linearize(pk, pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2], o.x, o.y, e0, e1, Jc, Jp);
+        bal_linearize_j<T, JT>(pk, pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2], o.x, o.y, e0, e1, Jc, Jp);
       const T w = loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
       T u0 = Jp[0] * pl[0] + Jp[2] * pl[1] + Jp[4] * pl[2];
       T u1 = Jp[1] * pl[0] + Jp[3] * pl[1] + Jp[5] * pl[2];

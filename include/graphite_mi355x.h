@@ -123,6 +123,11 @@ gr_status gr_bal_destroy(gr_bal_problem *p);
 gr_status gr_bal_set_loss(gr_bal_problem *p, gr_loss kind, double delta);
 /* Graph::scale_system (graph.hpp:331) */
 gr_status gr_bal_set_scale_system(gr_bal_problem *p, int enable);
+/* Mixed precision, the reference's Graph<T = double, S = float> (examples/bal.cu:338-345, --precision FP64-FP32):
+ * on a GR_F64 problem, GR_F32 makes every kernel evaluate the Jacobian entries in fp32 (residuals, all sums,
+ * the PCG vectors and dot products stay fp64).  Jacobians are never stored here, so this changes arithmetic,
+ * not memory traffic.  GR_F64 restores the default. */
+gr_status gr_bal_set_jacobian_precision(gr_bal_problem *p, gr_dtype dtype);
 
 /* vertex values (user-owned Vertex* in the reference, vertex.hpp:65) */
 gr_status gr_bal_set_params(gr_bal_problem *p, const void *cameras, const void *points);

@@ -72,6 +72,8 @@ public:
   bool initialize_optimization(uint8_t /*level*/ = 0) { return true; }          // done at construction
   bool build_structure() { return true; }
   void scale_system(bool enable) { ok(gr_bal_set_scale_system(p_, enable)); }   // graph.hpp:331
+  // Graph<double, float>: Jacobian entries in fp32 (bal.cu --precision FP64-FP32)
+  void set_jacobian_precision_f32(bool on) { ok(gr_bal_set_jacobian_precision(p_, on ? GR_F32 : GR_F64)); }
   template <int E> void set_loss(const DefaultLoss<T, E> &) { ok(gr_bal_set_loss(p_, GR_LOSS_DEFAULT, 0.0)); }
   template <int E> void set_loss(const HuberLoss<T, E> &l) { ok(gr_bal_set_loss(p_, GR_LOSS_HUBER, (double)l.delta)); }
 

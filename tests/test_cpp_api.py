@@ -37,7 +37,7 @@ def test_cpp_mirror_runs():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("solver,precision", [("pcg", "FP64-FP64"), ("pcg-schur", "FP32-FP32"), ("pcg-schur-implicit", "FP64-FP64"),
-                                              ("eigen-schur", "FP64-FP64"), ("cudss-schur", "FP32-FP32")])
+                                              ("eigen-schur", "FP64-FP64"), ("cudss-schur", "FP32-FP32"), ("pcg", "FP64-FP32")])
 def test_bal_driver_on_a_bal_file(tmp_path, solver, precision):
     exe = compile_cpp(os.path.join(ROOT, "examples", "bal.cpp"), os.path.join(BUILD, "bal"))
     prob = synth.make_config("mini-50")
