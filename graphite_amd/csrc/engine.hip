@@ -77,7 +77,7 @@ template <typename T> struct Engine final : EngineBase {
   std::vector<int> h_chunk_cam, h_chunk_beg, h_cam_chunk_ptr, h_cam_seg_ptr;
   std::vector<int> h_pt_new2old, h_pt_old2new; // internal point order: sorted by first observing camera
   int nch = 0, nb_pm = 0, nseg = 0;
-  int num_cu = 256, grid_obs = 0, grid_vec = 0; // persistent grids
+  int num_cu = 256, grid_obs = 0, grid_vec = 0, grid_chi2 = 0; // persistent grids
   // Schur structure (lazy)
   bool schur_ready = false;
   int64_t nnzb = 0, nprod = 0;
@@ -183,8 +183,10 @@ template <typename T> struct Engine final : EngineBase {
       GR_HIP(hipGetDeviceProperties(&prop, dev));
       num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    grid_obs = std::max(8, std::min(nb_pm, num_cu * 4) & ~7); // multiple of 8: one contiguous tile range per XCD
+    const int grid_mult = getenv("GR_GRID_MULT") ? atoi(getenv("GR_GRID_MULT")) : 4; // tuning knob (blocks per CU)
+    grid_obs = std::max(8, std::min(nb_pm, num_cu * grid_mult) & ~7); // multiple of 8: one contiguous tile range per XCD
     grid_vec = std::min(cdiv(n, TPB), num_cu * 8);   // light vector kernels
+    grid_chi2 = std::max(8, std::min(nb_pm, num_cu * 2) & ~7); // measured: the light chi2 pass prefers 2 long blocks per CU (16 vs 22 us at 8)
     n_chi2_blocks = std::min(cdiv(No, TPB), 1024);
     chi2_partial.alloc(std::max<size_t>(nb_pm, 2 * (size_t)cdiv(std::max<size_t>(No, n), TPB)) + 64);
     dscalars.alloc(4);
@@ -505,7 +507,7 @@ template <typename T> struct Engine final : EngineBase {
   int chi2_async(T *res_out, const T *dx, double mu) {
     const int seq = ++seq_counter;
     Scope sc(this, "chi2", No * (2 * w() + 8) + (24.0 * Nc + 3.0 * Np) * w() + (dx ? 3.0 * n * w() : 0.0), No * 40.0);
-    k_chi2<T><<<grid_obs, TPB, 0, stream>>>((int)No, (unsigned)n, (unsigned)pose_dim, cam_weight(), cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, comm ? nullptr : h_res, h_seq, seq, res_out);
+    k_chi2<T><<<grid_chi2, TPB, 0, stream>>>((int)No, (unsigned)n, (unsigned)pose_dim, cam_weight(), cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, comm ? nullptr : h_res, h_seq, seq, res_out);
     if (comm) allreduce_d(dscalars.p, 2);
     return seq;
   }

@@ -369,7 +369,7 @@ k_chi2(int No, unsigned n, unsigned pose_dim, int cam_weight, const int *__restr
 // VAR (diagnostic builds only, GR_DIAG): 1 no g3 scatter, 2 no point gather, 4 no ps_l gather,
 // 8 no Jacobian math, 16 no wave reduction.  VAR = 0 is the product kernel.
 template <typename T, int VAR = 0, typename JT = T>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB, 4)
 k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
                const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
                const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
