@@ -103,7 +103,7 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<int> ctl_i;
   DevBuf<double> grid_partial;
   DevBuf<int> pcg_iters;
-  int ctl_cap = 0;
+  int ctl_cap = 0, state_fresh_cap = -1; // state_fresh_cap == ctl_cap: the loop state was reset by the last set_damping
   // pinned host mirror: [0..1] chi2 / rho doubles, then ints: seq, flags[]
   double *h_res = nullptr;
   volatile int *h_seq = nullptr, *h_flag = nullptr;
@@ -464,7 +464,7 @@ template <typename T> struct Engine final : EngineBase {
   // spec_seq != 0: speculative trial linearisation of the LM loop; the finalize kernel also folds the
   // rho-denominator partials and publishes (chi2, denominator, spec_seq) to pinned host memory
   DevBuf<double> rho_partial;
-  static constexpr int RHO_BLOCKS = 256;
+  int rho_blocks = 0;
   void linearize_impl(bool write_hcp, bool pack_valid = false, int spec_seq = 0) {
     if (!pack_valid) campack();
     {
@@ -480,7 +480,7 @@ template <typename T> struct Engine final : EngineBase {
     {
       Scope sc(this, "linearize_finalize", 9.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
       k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
-                                                                                                    spec_seq ? rho_partial.p : nullptr, spec_seq ? RHO_BLOCKS : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq);
+                                                                                                    spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq);
     }
     if (comm) { // camera-space sums over the landmark shards
       comm->group_start();
@@ -588,8 +588,12 @@ template <typename T> struct Engine final : EngineBase {
     if (solver == GR_SOLVER_PCG || solver == GR_SOLVER_PCG_IDENTITY) {
       // BlockJacobiPreconditioner::set_damping_factor (block_jacobi.hpp:120-172); the identity
       // variant only needs the clamped diagonal (pcg.hpp:93-103)
-      k_inv9<T, 1><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Hcc.p, nullptr, scales.p, mu, use_identity ? 1 : 0, MinvC.p, v_diag.p);
-      k_inv3_points<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, scales.p, mu, use_identity ? 1 : 0, MinvP.p, v_diag.p);
+      // one launch: camera inverses, point inverses and (when the loop state exists) its reset
+      PcgState st{};
+      if (ctl_cap > 0) st = pcg_state();
+      const int nbc = cdiv(Nc, 64), nbp = cdiv(Np, 64);
+      k_block_jacobi<T><<<nbc + nbp + 1, 64, 0, stream>>>((int)Nc, (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, mu, use_identity ? 1 : 0, MinvC.p, MinvP.p, v_diag.p, st, ctl_cap);
+      state_fresh_cap = ctl_cap;
     }
   }
 
@@ -808,7 +812,8 @@ template <typename T> struct Engine final : EngineBase {
     const int ui = damping_identity ? 1 : 0;
     for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
     h_seq[1] = 0;
-    k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
+    if (state_fresh_cap != ctl_cap) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap); // else reset by k_block_jacobi
+    state_fresh_cap = -1;
     const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, TPB), num_cu * 8);
     const T *rawc = comm ? raw_c.p : nullptr;
     const int cw = cam_weight();
@@ -1007,9 +1012,11 @@ template <typename T> struct Engine final : EngineBase {
       int seq;
       const bool speculate = accept_streak >= 2 && spec_enabled;
       if (speculate) {
-        rho_partial.alloc(RHO_BLOCKS);
-        k_rho_denominator<T><<<RHO_BLOCKS, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cam_weight(), v_dx.p, bu.p, scales.p, (double)mu, rho_partial.p);
-        apply_update_dev(v_dx.p, /*with_backup=*/true); // backup_parameters + apply_update fused
+        // backup_parameters + apply_update + rho-denominator partials in one pass, then the camera packs
+        rho_blocks = cdiv(n, TPB);
+        rho_partial.alloc(rho_blocks);
+        k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p);
+        campack();
         seq = ++seq_counter;
         linearize_impl(want_hcp, /*pack_valid=*/true, seq);
       } else {

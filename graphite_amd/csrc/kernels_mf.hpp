@@ -21,6 +21,12 @@
 #include "kernels.hpp"
 
 namespace gr {
+#ifndef LIN_WAVES
+#define LIN_WAVES 3
+#endif
+#ifndef OP_WAVES
+#define OP_WAVES 4
+#endif
 
 constexpr int TICKET_GROUPS = 64;
 
@@ -53,6 +59,84 @@ __global__ void k_pcg_state_init(PcgState st, int cap) {
   for (int i = threadIdx.x; i < cap * NSLOT * NS; i += blockDim.x) st.acc[i] = 0.0;
   for (int i = threadIdx.x; i < cap; i += blockDim.x) { st.done[i] = 0; st.pdp[i] = 0.0; st.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
   if (threadIdx.x == 0) st.iters[0] = 0;
+}
+
+// BlockJacobiPreconditioner::set_damping_factor (block_jacobi.hpp:120-172) for cameras AND points in one
+// launch of 64-thread blocks ([0, nbc) camera blocks, then point blocks); with st.acc != nullptr the last
+// block also resets the PCG loop state, so a solve starts without its own init launch.
+template <typename T>
+__global__ void __launch_bounds__(64)
+k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, const T *__restrict__ Hll,
+               const T *__restrict__ scales, double mu, int use_identity, T *__restrict__ MinvC,
+               T *__restrict__ MinvP, T *__restrict__ diag_clamped, PcgState st, int cap) {
+  const int b = blockIdx.x;
+  if (b < nbc) {
+    const int c = b * 64 + threadIdx.x;
+    if (c >= Nc) return;
+    double A[81];
+    const T *B = Hcc + 81 * (size_t)c;
+    const T *s = scales + 9 * (size_t)c;
+#pragma unroll
+    for (int col = 0; col < 9; ++col)
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const T v = s[r] * B[r + 9 * col] * s[col];
+        if (r == col) {
+          A[r + 9 * col] = (double)damp_diag(v, mu, use_identity);
+          diag_clamped[9 * (size_t)c + r] = (T)clampd((double)v, 1.0e-6, 1.0e32);
+        } else A[r + 9 * col] = (double)v;
+      }
+    spd_inverse<9>(A);
+#pragma unroll
+    for (int i = 0; i < 81; ++i) MinvC[81 * (size_t)c + i] = (T)A[i];
+  } else if (b < nbc + nbp) {
+    const int l = (b - nbc) * 64 + threadIdx.x;
+    if (l >= Np) return;
+    const T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
+    const T *H = Hll + 9 * (size_t)l;
+    double A[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const T v = s[r] * H[r + 3 * c] * s[c];
+        if (r == c) {
+          A[r + 3 * c] = (double)damp_diag(v, mu, use_identity);
+          diag_clamped[9 * (size_t)Nc + 3 * (size_t)l + r] = (T)clampd((double)v, 1.0e-6, 1.0e32);
+        } else A[r + 3 * c] = (double)v;
+      }
+    spd_inverse<3>(A);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) MinvP[9 * (size_t)l + i] = (T)A[i];
+  } else if (st.acc) {
+    for (int i = threadIdx.x; i < cap * NSLOT * NS; i += 64) st.acc[i] = 0.0;
+    for (int i = threadIdx.x; i < cap; i += 64) { st.done[i] = 0; st.pdp[i] = 0.0; st.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
+    if (threadIdx.x == 0) st.iters[0] = 0;
+  }
+}
+
+// Graph::backup_parameters + Graph::apply_update (graph.hpp:292-309, ops/update.hpp:11-31) over cameras and
+// points in one pass, plus this block's share of the compute_rho denominator sum dx (mu dx + b)
+// (levenberg_marquardt.hpp:34-41) while dx and the scales are in registers anyway.
+template <typename T>
+__global__ void __launch_bounds__(TPB)
+k_apply_update_rho(unsigned n, unsigned pose_dim, int cam_weight, T *__restrict__ cams, T *__restrict__ pts,
+                   T *__restrict__ cams_bak, T *__restrict__ pts_bak, const T *__restrict__ dx,
+                   const T *__restrict__ scales, const T *__restrict__ bu, double mu, double *__restrict__ rho_partial) {
+  __shared__ double red[4];
+  const unsigned i = blockIdx.x * TPB + threadIdx.x;
+  double rho = 0;
+  if (i < n) {
+    const T d = dx[i], s = scales[i];
+    T *x = i < pose_dim ? cams + i : pts + (i - pose_dim);
+    T *bk = i < pose_dim ? cams_bak + i : pts_bak + (i - pose_dim);
+    const T xo = *x;
+    *bk = xo;
+    *x = xo + d * s;
+    if (i >= pose_dim || cam_weight) rho = (double)(d * ((T)mu * d + s * bu[i]));
+  }
+  rho = block_sum_256(rho, red);
+  if (threadIdx.x == 0) rho_partial[blockIdx.x] = rho;
 }
 
 // XCD-aware tile ranges for the persistent per-observation kernels.  Workgroups are dealt
@@ -130,7 +214,7 @@ __device__ __forceinline__ bool grid_sum2(double v0, double v1, double *partial,
 // current one, so the per-block fixed costs (launch, tail, chi2 partial) are amortised and the
 // index -> gather dependency is off the critical path.
 template <typename T, bool WRITE_HCP, typename JT = T>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB, LIN_WAVES)
 k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
             const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
             const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
@@ -369,7 +453,7 @@ k_chi2(int No, unsigned n, unsigned pose_dim, int cam_weight, const int *__restr
 // VAR (diagnostic builds only, GR_DIAG): 1 no g3 scatter, 2 no point gather, 4 no ps_l gather,
 // 8 no Jacobian math, 16 no wave reduction.  VAR = 0 is the product kernel.
 template <typename T, int VAR = 0, typename JT = T>
-__global__ void __launch_bounds__(TPB, 4)
+__global__ void __launch_bounds__(TPB, OP_WAVES)
 k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
                const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
                const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
