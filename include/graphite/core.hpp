@@ -1,0 +1,840 @@
+// graphite/core.hpp — the generic vertex / factor layer of sfu-rsl/graphite for gfx950 (MI355X).
+//
+// Header-only; instantiated by hipcc in the USER's translation unit, because everything here
+// calls the user's traits (`parameters`, `update`, `error`, `jacobian`) from device code — the
+// reference has the same constraint ("Graphite code should be called inside a .cu file",
+// docs/markdown/main.md:54-55).  Names, template parameters and member functions follow
+//   vertex.hpp:54-392 (VertexDescriptor), factor.hpp:120-830 (FactorDescriptor), graph.hpp:30-340
+//   (Graph), solver/pcg.hpp (PCGSolver), preconditioner/*.hpp, optimizer/levenberg_marquardt.hpp,
+//   loss.hpp, dual.hpp, differentiation.hpp, stream.hpp, vector.hpp (managed_vector)
+// of the reference, so that a problem definition written against it (docs/markdown/main.md:89-315,
+// examples/circle.cu) is source compatible apart from the matrix library it uses.
+//
+// Scope: this is the CALLER side of the hot path.  It is a small-graph,
+// one-thread-per-factor implementation with stored Jacobians, atomics for the vertex-side sums and a
+// matrix-free PCG; the BAL-specialised kernels of libgraphite_mi355x.so are what carry
+// the performance claims.  Differences from the reference, all deliberate:
+//   * user vertices must live in device-visible memory (managed_vector = pinned, mapped host memory;
+//     the reference uses CUDA managed memory, vertex.hpp:65) and are dereferenced in place;
+//   * losses are plain structs with inline member functions (no device-side virtual dispatch,
+//     ops/chi2.hpp:34-44);
+//   * the direct solver role (EigenLDLTSolver) is a dense assembly + the MFMA Cholesky exported by
+//     libgraphite_mi355x.so (gr_dense_cholesky_solve) instead of Eigen::SimplicialLDLT on the host.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#define d_fn __device__
+#define hd_fn __host__ __device__
+
+namespace graphite {
+
+#define GRAPHITE_HIP(expr)                                                                              \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess)                                                                               \
+      throw std::runtime_error(std::string(#expr) + " -> " + hipGetErrorString(_e) + " @" + __FILE__ +  \
+                               ":" + std::to_string(__LINE__));                                         \
+  } while (0)
+
+struct Empty {};
+
+struct DifferentiationMode {
+  struct Auto {};
+  struct Manual {};
+};
+
+// ---- loss.hpp:15-51 ---------------------------------------------------------------------------
+template <typename T, int E> struct DefaultLoss {
+  hd_fn T loss(const T &x) const { return x; }
+  hd_fn T loss_derivative(const T &) const { return T(1); }
+};
+template <typename T, int E> struct HuberLoss {
+  T delta = T(100);
+  hd_fn HuberLoss() {}
+  hd_fn explicit HuberLoss(T d) : delta(d) {}
+  hd_fn T loss(const T &x) const { return x <= delta * delta ? x : 2 * sqrt(x) * delta - delta * delta; }
+  hd_fn T loss_derivative(const T &x) const { return x <= delta * delta ? T(1) : delta / sqrt(x); }
+};
+
+// ---- dual.hpp: forward-mode dual number, one derivative direction --------------------------------
+template <typename T, typename D = T> struct Dual {
+  T real;
+  D dual;
+  using DT = Dual<T, D>;
+  hd_fn Dual() : real(0), dual(0) {}
+  hd_fn Dual(T r, D d) : real(r), dual(d) {}
+  hd_fn Dual(T r) : real(r), dual(0) {}
+  hd_fn DT operator+(const DT &o) const { return DT(real + o.real, dual + o.dual); }
+  hd_fn DT operator-(const DT &o) const { return DT(real - o.real, dual - o.dual); }
+  hd_fn DT operator-() const { return DT(-real, -dual); }
+  hd_fn DT operator*(const DT &o) const { return DT(real * o.real, real * o.dual + dual * o.real); }
+  hd_fn DT operator/(const DT &o) const {
+    if (o.real == 0) return DT(std::numeric_limits<T>::infinity(), std::numeric_limits<D>::infinity());
+    const T den = o.real * o.real;
+    return DT(real / o.real, (dual * o.real - real * o.dual) / den);
+  }
+  hd_fn DT &operator+=(const DT &o) { return *this = *this + o; }
+  hd_fn DT &operator-=(const DT &o) { return *this = *this - o; }
+  hd_fn DT &operator*=(const DT &o) { return *this = *this * o; }
+  hd_fn DT &operator/=(const DT &o) { return *this = *this / o; }
+  hd_fn bool operator<(const DT &o) const { return real < o.real; }
+  hd_fn bool operator>(const DT &o) const { return real > o.real; }
+  hd_fn bool operator<=(const DT &o) const { return real <= o.real; }
+  hd_fn bool operator>=(const DT &o) const { return real >= o.real; }
+  hd_fn bool operator==(const DT &o) const { return real == o.real; }
+  hd_fn bool operator!=(const DT &o) const { return real != o.real; }
+  hd_fn friend DT operator+(T a, const DT &b) { return DT(a) + b; }
+  hd_fn friend DT operator-(T a, const DT &b) { return DT(a) - b; }
+  hd_fn friend DT operator*(T a, const DT &b) { return DT(a) * b; }
+  hd_fn friend DT operator/(T a, const DT &b) { return DT(a) / b; }
+  hd_fn friend DT sin(const DT &x) { return DT(::sin(x.real), x.dual * ::cos(x.real)); }
+  hd_fn friend DT cos(const DT &x) { return DT(::cos(x.real), -x.dual * ::sin(x.real)); }
+  hd_fn friend DT tan(const DT &x) { const T c = ::cos(x.real); return DT(::tan(x.real), x.dual / (c * c)); }
+  hd_fn friend DT exp(const DT &x) { const T e = ::exp(x.real); return DT(e, x.dual * e); }
+  hd_fn friend DT log(const DT &x) { return DT(::log(x.real), x.dual / x.real); }
+  hd_fn friend DT sqrt(const DT &x) { const T s = ::sqrt(x.real); return DT(s, s == 0 ? D(0) : x.dual / (2 * s)); }
+  hd_fn friend DT abs(const DT &x) { return x.real < 0 ? -x : x; }
+  hd_fn friend DT atan2(const DT &y, const DT &x) {
+    const T den = x.real * x.real + y.real * y.real;
+    return DT(::atan2(y.real, x.real), (x.real * y.dual - y.real * x.dual) / den);
+  }
+  hd_fn friend DT acos(const DT &x) { return DT(::acos(x.real), -x.dual / ::sqrt(1 - x.real * x.real)); }
+  hd_fn friend DT asin(const DT &x) { return DT(::asin(x.real), x.dual / ::sqrt(1 - x.real * x.real)); }
+};
+
+// ---- vector.hpp:25-60 — device-visible storage with the std::vector surface the examples use -----
+// Pinned, mapped host memory: one virtual address on host and device.  Like the reference's
+// managed_vector it is neither copyable nor movable; growth re-allocates (reserve first when
+// addresses must stay fixed, circle.cu:106).
+template <typename T> class managed_vector {
+  T *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+  void grow(size_t cap) {
+    if (cap <= cap_) return;
+    T *q = nullptr;
+    GRAPHITE_HIP(hipHostMalloc(reinterpret_cast<void **>(&q), std::max<size_t>(cap, 1) * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent));
+    for (size_t i = 0; i < n_; ++i) new (q + i) T(p_[i]);
+    if (p_) (void)hipHostFree(p_);
+    p_ = q; cap_ = cap;
+  }
+public:
+  struct pointer { T *p; T *get() const { return p; } };
+  managed_vector() = default;
+  explicit managed_vector(size_t n) { resize(n); }
+  managed_vector(const managed_vector &) = delete;
+  managed_vector &operator=(const managed_vector &) = delete;
+  ~managed_vector() { if (p_) (void)hipHostFree(p_); }
+  void reserve(size_t cap) { grow(cap); }
+  void resize(size_t n, const T &v = T()) {
+    if (n > cap_) grow(std::max(n, 2 * cap_));
+    for (size_t i = n_; i < n; ++i) new (p_ + i) T(v);
+    n_ = n;
+  }
+  void push_back(const T &v) {
+    if (n_ == cap_) grow(std::max<size_t>(2 * cap_, 8));
+    new (p_ + n_++) T(v);
+  }
+  void pop_back() { --n_; }
+  void clear() { n_ = 0; }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  T &operator[](size_t i) { return p_[i]; }
+  const T &operator[](size_t i) const { return p_[i]; }
+  T &back() { return p_[n_ - 1]; }
+  pointer data() const { return pointer{p_}; } // .data().get(), as with thrust::universal_vector
+  T *raw() const { return p_; }
+  T *begin() const { return p_; }
+  T *end() const { return p_ + n_; }
+};
+
+// ---- stream.hpp:7-24 ---------------------------------------------------------------------------
+class StreamPool {
+  std::vector<hipStream_t> s_;
+public:
+  explicit StreamPool(size_t n) : s_(std::max<size_t>(n, 1)) { for (auto &s : s_) GRAPHITE_HIP(hipStreamCreate(&s)); }
+  StreamPool(const StreamPool &) = delete;
+  ~StreamPool() { for (auto s : s_) (void)hipStreamDestroy(s); }
+  hipStream_t &select(size_t i) { return s_[i % s_.size()]; }
+  void sync_all() { for (auto s : s_) (void)hipStreamSynchronize(s); }
+  void sync_n(size_t n) { for (size_t i = 0; i < std::min(n, s_.size()); ++i) (void)hipStreamSynchronize(s_[i]); }
+};
+
+namespace detail {
+constexpr int TPB = 256;
+inline int blocks(size_t n) { return (int)((n + TPB - 1) / TPB); }
+inline void sync() { GRAPHITE_HIP(hipDeviceSynchronize()); }
+
+// active.hpp:11-21
+hd_fn inline bool is_factor_active(uint8_t v, uint8_t level) { return (v & 0x7F) <= level && (v & 0x80) == 0; }
+hd_fn inline bool is_vertex_active(const uint8_t *state, size_t id) { return state[id] == 0; }
+
+template <typename T> __global__ void k_fill(T *p, size_t n, T v) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+template <typename T> inline void fill(T *p, size_t n, T v) { if (n) k_fill<T><<<blocks(n), TPB>>>(p, n, v); }
+
+// detection of the optional State / get_state / set_state of vertex traits (main.md:100-111)
+template <typename Tr, typename = void> struct state_of { using type = typename Tr::Vertex; static constexpr bool custom = false; };
+template <typename Tr> struct state_of<Tr, std::void_t<typename Tr::State>> { using type = typename Tr::State; static constexpr bool custom = true; };
+
+template <typename Fn, typename... A> struct invocable {
+  template <typename F, typename = decltype(std::declval<F>()(std::declval<A>()...))> static std::true_type test(int);
+  template <typename> static std::false_type test(...);
+  static constexpr bool value = decltype(test<Fn>(0))::value;
+};
+} // namespace detail
+
+// =================================================================================================
+// VertexDescriptor (vertex.hpp:28-392)
+// =================================================================================================
+template <typename T, typename S> class BaseVertexDescriptor {
+public:
+  virtual ~BaseVertexDescriptor() = default;
+  virtual size_t dimension() const = 0;
+  virtual size_t count() const = 0;
+  virtual bool is_fixed(size_t id) const = 0;
+  virtual bool is_active(size_t id) const = 0;
+  virtual bool exists(size_t id) const = 0;
+  virtual size_t get_local_id(size_t id) const = 0;
+  virtual uint8_t *get_active_state() const = 0;
+  virtual size_t *get_hessian_ids() const = 0;
+  virtual const std::vector<size_t> &local_to_global() const = 0;
+  virtual void apply_update(const T *delta_x, const T *scales) = 0;
+  virtual void backup_parameters() = 0;
+  virtual void restore_parameters() = 0;
+  bool eliminate = false; // set_eliminate (vertex.hpp:98): kept for API parity, the PCG path ignores it
+  void set_eliminate(bool e) { eliminate = e; }
+};
+
+namespace detail {
+template <typename T, typename Tr>
+__global__ void k_vertex_update(typename Tr::Vertex **x, const uint8_t *state, const size_t *hid, size_t n,
+                                const T *dx, const T *scales) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n || !is_vertex_active(state, i)) return;
+  T d[Tr::dimension];
+  for (size_t k = 0; k < Tr::dimension; ++k) d[k] = dx[hid[i] + k] * (scales ? scales[hid[i] + k] : T(1)); // ops/update.hpp:26
+  Tr::update(*x[i], d);
+}
+template <typename Tr, typename St>
+__global__ void k_vertex_backup(typename Tr::Vertex **x, const uint8_t *state, size_t n, St *bak) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n || !is_vertex_active(state, i)) return;
+  if constexpr (state_of<Tr>::custom) bak[i] = Tr::get_state(*x[i]);
+  else bak[i] = *x[i];
+}
+template <typename Tr, typename St>
+__global__ void k_vertex_restore(typename Tr::Vertex **x, const uint8_t *state, size_t n, const St *bak) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n || !is_vertex_active(state, i)) return;
+  if constexpr (state_of<Tr>::custom) Tr::set_state(*x[i], bak[i]);
+  else *x[i] = bak[i];
+}
+} // namespace detail
+
+template <typename T, typename S, typename VTraits> class VertexDescriptor : public BaseVertexDescriptor<T, S> {
+public:
+  using Traits = VTraits;
+  using VertexType = typename Traits::Vertex;
+  using StateType = typename detail::state_of<Traits>::type;
+  static constexpr size_t dim = Traits::dimension;
+
+  managed_vector<VertexType *> x_device;  // pointers into user memory (vertex.hpp:65)
+  managed_vector<uint8_t> active_state;   // bit0 fixed, bit7 not used by an active factor
+  managed_vector<size_t> hessian_ids;     // scalar column of each vertex
+  managed_vector<StateType> backup_state;
+  std::unordered_map<size_t, size_t> global_to_local_map;
+  std::vector<size_t> local_to_global_map;
+
+  void reserve(size_t n) { x_device.reserve(n); active_state.reserve(n); hessian_ids.reserve(n); backup_state.reserve(n); local_to_global_map.reserve(n); }
+  void add_vertex(size_t id, VertexType *vertex, bool fixed = false) { // vertex.hpp:241-256
+    global_to_local_map[id] = x_device.size();
+    local_to_global_map.push_back(id);
+    x_device.push_back(vertex);
+    active_state.push_back(static_cast<uint8_t>(fixed));
+    hessian_ids.push_back(0);
+    backup_state.resize(x_device.size());
+  }
+  void remove_vertex(size_t id) { // swap with last, vertex.hpp:185-215
+    auto it = global_to_local_map.find(id);
+    if (it == global_to_local_map.end()) { std::cerr << "Vertex with id " << id << " not found." << std::endl; return; }
+    const size_t l = it->second, last = x_device.size() - 1;
+    x_device[l] = x_device[last]; active_state[l] = active_state[last]; hessian_ids[l] = hessian_ids[last];
+    const size_t moved = local_to_global_map[last];
+    local_to_global_map[l] = moved; global_to_local_map[moved] = l;
+    global_to_local_map.erase(id);
+    x_device.pop_back(); active_state.pop_back(); hessian_ids.pop_back(); local_to_global_map.pop_back();
+    backup_state.resize(x_device.size());
+  }
+  void replace_vertex(size_t id, VertexType *vertex) {
+    auto it = global_to_local_map.find(id);
+    if (it == global_to_local_map.end()) { std::cerr << "Vertex with id " << id << " not found." << std::endl; return; }
+    x_device[it->second] = vertex;
+  }
+  void set_fixed(size_t id, bool fixed) { active_state[global_to_local_map.at(id)] = static_cast<uint8_t>(fixed); }
+  bool is_fixed(size_t id) const override { return (active_state[global_to_local_map.at(id)] & 0x1) > 0; }
+  bool is_active(size_t id) const override { return detail::is_vertex_active(active_state.raw(), global_to_local_map.at(id)); }
+  bool exists(size_t id) const override { return global_to_local_map.count(id) > 0; }
+  VertexType *get_vertex(size_t id) { return x_device[global_to_local_map.at(id)]; }
+  size_t get_local_id(size_t id) const override { return global_to_local_map.at(id); }
+  size_t dimension() const override { return dim; }
+  size_t count() const override { return x_device.size(); }
+  VertexType **vertices() const { return x_device.raw(); }
+  uint8_t *get_active_state() const override { return active_state.raw(); }
+  size_t *get_hessian_ids() const override { return hessian_ids.raw(); }
+  const std::vector<size_t> &local_to_global() const override { return local_to_global_map; }
+  void to_device() {}
+  void clear() { x_device.clear(); active_state.clear(); hessian_ids.clear(); backup_state.clear(); global_to_local_map.clear(); local_to_global_map.clear(); }
+
+  void apply_update(const T *delta_x, const T *scales) override {
+    if (count()) detail::k_vertex_update<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), get_active_state(), get_hessian_ids(), count(), delta_x, scales);
+  }
+  void backup_parameters() override {
+    if (count()) detail::k_vertex_backup<Traits, StateType><<<detail::blocks(count()), detail::TPB>>>(vertices(), get_active_state(), count(), backup_state.raw());
+  }
+  void restore_parameters() override {
+    if (count()) detail::k_vertex_restore<Traits, StateType><<<detail::blocks(count()), detail::TPB>>>(vertices(), get_active_state(), count(), backup_state.raw());
+  }
+};
+
+// =================================================================================================
+// FactorDescriptor (factor.hpp:120-830)
+// =================================================================================================
+template <typename T, typename S> class BaseFactorDescriptor {
+public:
+  virtual ~BaseFactorDescriptor() = default;
+  virtual size_t internal_count() const = 0;
+  virtual size_t active_count() const = 0;
+  virtual void initialize(uint8_t level) = 0;     // active list, local ids, vertex use flags
+  virtual void flag_active_vertices() = 0;
+  virtual void compute_error() = 0;
+  virtual void compute_jacobians() = 0;
+  virtual void compute_chi2() = 0;
+  virtual T chi2() = 0;
+  virtual void scalar_diagonal(T *diag) = 0;      // ops/hessian.hpp:419-474
+  virtual void scale_jacobians(const T *scales) = 0;
+  virtual void compute_b(T *b) = 0;               // ops/linearize.hpp:240-303
+  virtual void compute_Jv(T *res, const T *x) = 0;   // ops/product.hpp:195
+  virtual void compute_Jtv(T *out, const T *res) = 0; // ops/product.hpp:405
+  virtual T *work_residual() = 0;                 // [internal_count * E] scratch for J v
+  virtual size_t error_dimension() const = 0;
+  virtual void block_diagonal(size_t slot, T *blocks) = 0; // ops/hessian.hpp:171-270
+  virtual size_t num_slots() const = 0;
+  virtual BaseVertexDescriptor<T, S> *slot_descriptor(size_t slot) const = 0;
+  virtual void dense_hessian(T *H, size_t n) = 0; // upper + lower, for the direct solver
+};
+
+namespace detail {
+// Everything a per-factor kernel needs, by value.
+template <typename F> struct FactorView {
+  using T = typename F::Scalar;
+  using S = typename F::Storage;
+  static constexpr size_t N = F::N, E = F::E;
+  const size_t *active_ids;
+  size_t n_active;
+  const size_t *ids; // [nf][N] local vertex ids
+  const typename F::ObservationType *obs;
+  const typename F::ConstraintDataType *data;
+  const typename F::LossType *loss;
+  const S *pmat; // [nf][E*E]
+  T *residuals;  // [nf][E]
+  T *chi2;       // [nf]
+  S *dchi2;      // [nf]
+  std::array<S *, N> jac;
+  std::array<void *, N> verts; // Vertex** of each slot
+  std::array<const uint8_t *, N> vstate;
+  std::array<const size_t *, N> hid;
+};
+
+template <typename F, size_t I> using slot_traits = typename std::tuple_element<I, typename F::Traits::VertexDescriptors>::type::Traits;
+template <typename F, size_t I> using slot_vertex = typename slot_traits<F, I>::Vertex;
+template <typename F, size_t I> constexpr size_t slot_dim() { return slot_traits<F, I>::dimension; }
+
+// call Traits::error in whichever of the documented argument orders it was written (main.md:283-291):
+// (vertices..., params..., [obs], [data], err) | (params..., [obs], [data], err) | (vertices..., [obs], [data], err)
+template <typename Fn, typename Tup> struct applicable;
+template <typename Fn, typename... A> struct applicable<Fn, std::tuple<A...>> : std::integral_constant<bool, invocable<Fn, A...>::value> {};
+template <typename Fn, typename Tup, size_t... Ks> __device__ inline void apply_tuple(Fn &fn, Tup &&t, std::index_sequence<Ks...>) { fn(std::get<Ks>(t)...); }
+template <typename Fn, typename Tup> __device__ inline void apply_tuple(Fn &fn, Tup &&t) {
+  apply_tuple(fn, t, std::make_index_sequence<std::tuple_size<typename std::decay<Tup>::type>::value>{});
+}
+
+template <typename F, typename D, typename VT, typename PT, size_t... Is>
+__device__ inline void call_error(const VT &v, PT &p, const typename F::ObservationType &obs,
+                                  const typename F::ConstraintDataType &data, D *err, std::index_sequence<Is...>) {
+  using Tr = typename F::Traits;
+  constexpr bool has_obs = !std::is_empty<typename F::ObservationType>::value, has_dat = !std::is_empty<typename F::ConstraintDataType>::value;
+  auto fn = [](auto &&...a) -> decltype(Tr::template error<D>(std::forward<decltype(a)>(a)...)) { return Tr::template error<D>(std::forward<decltype(a)>(a)...); };
+  using Fn = decltype(fn);
+  auto verts = std::forward_as_tuple(*std::get<Is>(v)...);
+  auto params = std::make_tuple(static_cast<const D *>(std::get<Is>(p))...);
+  auto tail = [&] {
+    if constexpr (has_obs && has_dat) return std::tuple<const typename F::ObservationType &, const typename F::ConstraintDataType &, D *>(obs, data, err);
+    else if constexpr (has_obs) return std::tuple<const typename F::ObservationType &, D *>(obs, err);
+    else if constexpr (has_dat) return std::tuple<const typename F::ConstraintDataType &, D *>(data, err);
+    else return std::tuple<D *>(err);
+  }();
+  auto both = std::tuple_cat(verts, params, tail);
+  auto ponly = std::tuple_cat(params, tail);
+  auto vonly = std::tuple_cat(verts, tail);
+  if constexpr (applicable<Fn, decltype(both)>::value) apply_tuple(fn, both);
+  else if constexpr (applicable<Fn, decltype(ponly)>::value) apply_tuple(fn, ponly);
+  else {
+    static_assert(applicable<Fn, decltype(vonly)>::value, "Traits::error<D> matches none of the documented argument orders");
+    apply_tuple(fn, vonly);
+  }
+}
+
+// Traits::jacobian<S, I>(vertices..., [obs], [data], S *jac)  (main.md:294-315)
+template <typename F, size_t I, typename VT, size_t... Is>
+__device__ inline void call_jacobian(const VT &v, const typename F::ObservationType &obs, const typename F::ConstraintDataType &data,
+                                     typename F::Storage *jac, std::index_sequence<Is...>) {
+  using Tr = typename F::Traits;
+  using Sj = typename F::Storage;
+  constexpr bool has_obs = !std::is_empty<typename F::ObservationType>::value, has_dat = !std::is_empty<typename F::ConstraintDataType>::value;
+  if constexpr (has_obs && has_dat) Tr::template jacobian<Sj, I>(*std::get<Is>(v)..., obs, data, jac);
+  else if constexpr (has_obs) Tr::template jacobian<Sj, I>(*std::get<Is>(v)..., obs, jac);
+  else if constexpr (has_dat) Tr::template jacobian<Sj, I>(*std::get<Is>(v)..., data, jac);
+  else Tr::template jacobian<Sj, I>(*std::get<Is>(v)..., jac);
+}
+
+template <typename F, typename D, size_t... Is>
+__device__ inline auto gather_vertices(const FactorView<F> &fv, size_t f, std::index_sequence<Is...>) {
+  return std::make_tuple((reinterpret_cast<slot_vertex<F, Is> **>(fv.verts[Is])[fv.ids[f * F::N + Is]])...);
+}
+
+// residual of every active factor (ops/error.hpp:253-323)
+template <typename F, size_t... Is>
+__global__ void k_error(FactorView<F> fv, std::index_sequence<Is...> seq) {
+  using T = typename F::Scalar;
+  const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (a >= fv.n_active) return;
+  const size_t f = fv.active_ids[a];
+  auto v = gather_vertices<F, T>(fv, f, seq);
+  std::tuple<T[slot_dim<F, Is>()]...> p;
+  ((slot_traits<F, Is>::parameters(*std::get<Is>(v), (T *)std::get<Is>(p))), ...);
+  T err[F::E];
+  call_error<F, T>(v, p, fv.obs[f], fv.data[f], err, seq);
+  for (size_t i = 0; i < F::E; ++i) fv.residuals[f * F::E + i] = err[i];
+}
+
+// Jacobian block of slot I: analytic (one thread per factor) or dual numbers (one thread per column)
+template <typename F, size_t I, size_t... Is>
+__global__ void k_jacobian(FactorView<F> fv, std::index_sequence<Is...> seq) {
+  using T = typename F::Scalar;
+  using Sj = typename F::Storage;
+  constexpr size_t d = slot_dim<F, I>();
+  constexpr bool manual = std::is_same<typename F::Traits::Differentiation, DifferentiationMode::Manual>::value;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if constexpr (manual) {
+    if (t >= fv.n_active) return;
+    const size_t f = fv.active_ids[t];
+    if (!is_vertex_active(fv.vstate[I], fv.ids[f * F::N + I])) return;
+    auto v = gather_vertices<F, T>(fv, f, seq);
+    call_jacobian<F, I>(v, fv.obs[f], fv.data[f], fv.jac[I] + f * F::E * d, seq);
+  } else {
+    if (t >= fv.n_active * d) return;
+    const size_t f = fv.active_ids[t / d], col = t % d;
+    if (!is_vertex_active(fv.vstate[I], fv.ids[f * F::N + I])) return;
+    using D = Dual<T, T>;
+    auto v = gather_vertices<F, T>(fv, f, seq);
+    std::tuple<D[slot_dim<F, Is>()]...> p;
+    ((slot_traits<F, Is>::parameters(*std::get<Is>(v), (D *)std::get<Is>(p))), ...);
+    std::get<I>(p)[col].dual = T(1);
+    D err[F::E];
+    call_error<F, D>(v, p, fv.obs[f], fv.data[f], err, seq);
+    for (size_t i = 0; i < F::E; ++i) fv.jac[I][f * F::E * d + col * F::E + i] = (Sj)err[i].dual;
+  }
+}
+
+// chi2 = rho(r^T P r), dchi2 = rho'  (ops/chi2.hpp:10-44)
+template <typename F> __global__ void k_chi2(FactorView<F> fv) {
+  using T = typename F::Scalar;
+  const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (a >= fv.n_active) return;
+  const size_t f = fv.active_ids[a];
+  T value = 0;
+  for (size_t i = 0; i < F::E; ++i) {
+    T r2 = 0;
+    for (size_t j = 0; j < F::E; ++j) r2 += (T)fv.pmat[f * F::E * F::E + i * F::E + j] * fv.residuals[f * F::E + j];
+    value += r2 * fv.residuals[f * F::E + i];
+  }
+  fv.chi2[f] = fv.loss[f].loss(value);
+  fv.dchi2[f] = (typename F::Storage)fv.loss[f].loss_derivative(value);
+}
+
+template <typename T> __global__ void k_sum_active(const T *v, const size_t *active, size_t n, T *out) {
+  // small graphs: one block, fixed order per thread, tree in LDS
+  __shared__ T red[TPB];
+  T s = 0;
+  for (size_t i = threadIdx.x; i < n; i += TPB) s += v[active[i]];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = red[0];
+}
+
+// J_c^T P J_c' of two columns of (possibly different) slots
+template <typename F> __device__ inline typename F::Scalar jtpj(const FactorView<F> &fv, size_t f, const typename F::Storage *Ja, const typename F::Storage *Jb) {
+  using T = typename F::Scalar;
+  T value = 0;
+  for (size_t i = 0; i < F::E; ++i) {
+    T pj = 0;
+    for (size_t j = 0; j < F::E; ++j) pj += (T)fv.pmat[f * F::E * F::E + i * F::E + j] * (T)Jb[j];
+    value += (T)Ja[i] * pj;
+  }
+  return value;
+}
+
+// which: 0 scalar diagonal, 1 scale Jacobians, 2 b -= J^T rho' P r, 3 J^T v, 4 block diagonal
+template <typename F, size_t I, int WHICH>
+__global__ void k_slot(FactorView<F> fv, typename F::Scalar *out, const typename F::Scalar *in) {
+  using T = typename F::Scalar;
+  constexpr size_t d = slot_dim<F, I>(), E = F::E;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= fv.n_active * d) return;
+  const size_t f = fv.active_ids[t / d], c = t % d;
+  const size_t v = fv.ids[f * F::N + I];
+  if (!is_vertex_active(fv.vstate[I], v)) return;
+  auto *J = fv.jac[I] + f * E * d + c * E;
+  const size_t col = fv.hid[I][v] + c;
+  if constexpr (WHICH == 0) {
+    atomicAdd(&out[col], jtpj(fv, f, J, J) * (T)fv.dchi2[f]);
+  } else if constexpr (WHICH == 1) {
+    for (size_t i = 0; i < E; ++i) J[i] = (typename F::Storage)((T)J[i] * in[col]);
+  } else if constexpr (WHICH == 2) {
+    T s = 0;
+    for (size_t i = 0; i < E; ++i) {
+      T pr = 0;
+      for (size_t j = 0; j < E; ++j) pr += (T)fv.pmat[f * E * E + i * E + j] * fv.residuals[f * E + j];
+      s += (T)J[i] * pr;
+    }
+    atomicAdd(&out[col], -s * (T)fv.dchi2[f]);
+  } else if constexpr (WHICH == 3) { // out[col] += J[:,c]^T (rho' P in_f)
+    T s = 0;
+    for (size_t i = 0; i < E; ++i) {
+      T pr = 0;
+      for (size_t j = 0; j < E; ++j) pr += (T)fv.pmat[f * E * E + i * E + j] * in[f * E + j];
+      s += (T)J[i] * pr;
+    }
+    atomicAdd(&out[col], s * (T)fv.dchi2[f]);
+  } else { // per-vertex d x d block, column-major: block(row, c) += rho' J_row^T P J_c
+    const auto *Jb = fv.jac[I] + f * E * d;
+    for (size_t row = 0; row < d; ++row) atomicAdd(&out[v * d * d + row + c * d], jtpj(fv, f, Jb + row * E, J) * (T)fv.dchi2[f]);
+  }
+}
+
+// res_f += J_I x_v  (ops/product.hpp:195-300), one thread per (factor, residual row)
+template <typename F, size_t I> __global__ void k_Jv(FactorView<F> fv, typename F::Scalar *res, const typename F::Scalar *x) {
+  using T = typename F::Scalar;
+  constexpr size_t d = slot_dim<F, I>(), E = F::E;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= fv.n_active * E) return;
+  const size_t f = fv.active_ids[t / E], i = t % E;
+  const size_t v = fv.ids[f * F::N + I];
+  if (!is_vertex_active(fv.vstate[I], v)) return;
+  T s = 0;
+  for (size_t c = 0; c < d; ++c) s += (T)fv.jac[I][f * E * d + c * E + i] * x[fv.hid[I][v] + c];
+  res[f * E + i] += s; // slots are launched one after the other on one stream: no race
+}
+
+// dense H(col_a, col_b) += rho' J_a^T P J_b for every pair of slots (direct solver only)
+template <typename F, size_t I, size_t K> __global__ void k_dense_pair(FactorView<F> fv, typename F::Scalar *H, size_t n) {
+  using T = typename F::Scalar;
+  constexpr size_t di = slot_dim<F, I>(), dk = slot_dim<F, K>(), E = F::E;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= fv.n_active * di * dk) return;
+  const size_t f = fv.active_ids[t / (di * dk)], r = (t / dk) % di, c = t % dk;
+  const size_t vi = fv.ids[f * F::N + I], vk = fv.ids[f * F::N + K];
+  if (!is_vertex_active(fv.vstate[I], vi) || !is_vertex_active(fv.vstate[K], vk)) return;
+  const T val = jtpj(fv, f, fv.jac[I] + f * E * di + r * E, fv.jac[K] + f * E * dk + c * E) * (T)fv.dchi2[f];
+  atomicAdd(&H[(fv.hid[I][vi] + r) * n + fv.hid[K][vk] + c], val);
+}
+
+template <typename VD> __global__ void k_flag_vertices(const size_t *active_ids, size_t n_active, const size_t *ids, size_t N, size_t I, uint8_t *state) {
+  const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (a >= n_active) return;
+  state[ids[active_ids[a] * N + I]] |= 0x80; // ops/active.hpp:14-30 (XOR'd afterwards by the graph)
+}
+} // namespace detail
+
+template <typename T, typename S, typename FTraits> class FactorDescriptor : public BaseFactorDescriptor<T, S> {
+public:
+  using Traits = FTraits;
+  using Scalar = T;
+  using Storage = S;
+  using ObservationType = typename Traits::Observation;
+  using ConstraintDataType = typename Traits::Data;
+  using LossType = typename Traits::Loss;
+  using VDTuple = typename Traits::VertexDescriptors;
+  static constexpr size_t N = std::tuple_size<VDTuple>::value;
+  static constexpr size_t E = Traits::dimension;
+  static constexpr size_t error_dim = E;
+  static constexpr size_t get_num_vertices() { return N; }
+
+  struct JacobianStorage { managed_vector<S> data; size_t dimensions[2] = {0, 0}; };
+
+  std::array<BaseVertexDescriptor<T, S> *, N> vertex_descriptors{};
+  std::array<void *, N> typed_descriptors{};
+  std::vector<size_t> host_ids;            // global ids, N per factor
+  managed_vector<size_t> device_ids;       // local ids, N per factor
+  managed_vector<ObservationType> device_obs;
+  managed_vector<ConstraintDataType> data;
+  managed_vector<LossType> loss;
+  managed_vector<S> precision_matrices;    // E*E per factor, read row-major
+  managed_vector<uint8_t> active;
+  managed_vector<size_t> active_indices;
+  managed_vector<T> residuals, chi2_vec, work;
+  managed_vector<S> chi2_derivative;
+  std::array<JacobianStorage, N> jacobians;
+  managed_vector<T> scalar;                // device scalar for reductions
+  bool store_jacobians = true;
+
+  template <typename... VDs> explicit FactorDescriptor(VDs *...vds) {
+    static_assert(sizeof...(VDs) == N, "one vertex descriptor per slot");
+    size_t i = 0;
+    ((vertex_descriptors[i] = vds, typed_descriptors[i] = vds, ++i), ...);
+    scalar.resize(1);
+  }
+  void reserve(size_t n) {
+    host_ids.reserve(N * n); device_ids.reserve(N * n); device_obs.reserve(n); data.reserve(n); loss.reserve(n);
+    precision_matrices.reserve(E * E * n); active.reserve(n); residuals.reserve(E * n); chi2_vec.reserve(n); chi2_derivative.reserve(n);
+  }
+  // factor.hpp:373-412; precision_matrix == nullptr -> identity
+  size_t add_factor(const std::array<size_t, N> &ids, const ObservationType &obs, const S *precision_matrix,
+                    const ConstraintDataType &constraint_data, const LossType &loss_function) {
+    const size_t id = internal_count();
+    for (size_t i = 0; i < N; ++i) { host_ids.push_back(ids[i]); device_ids.push_back(0); }
+    device_obs.push_back(obs); data.push_back(constraint_data); loss.push_back(loss_function);
+    for (size_t i = 0; i < E; ++i)
+      for (size_t j = 0; j < E; ++j) precision_matrices.push_back(precision_matrix ? precision_matrix[i * E + j] : (i == j ? S(1) : S(0)));
+    active.push_back(0);
+    residuals.resize(E * (id + 1)); chi2_vec.resize(id + 1); chi2_derivative.resize(id + 1); work.resize(E * (id + 1));
+    return id;
+  }
+  void remove_factor(size_t id) { // swap with last (factor.hpp:336-371)
+    const size_t last = internal_count() - 1;
+    if (id > last) { std::cerr << "Factor with id " << id << " not found." << std::endl; return; }
+    for (size_t i = 0; i < N; ++i) host_ids[id * N + i] = host_ids[last * N + i];
+    device_obs[id] = device_obs[last]; data[id] = data[last]; loss[id] = loss[last]; active[id] = active[last];
+    for (size_t i = 0; i < E * E; ++i) precision_matrices[id * E * E + i] = precision_matrices[last * E * E + i];
+    host_ids.resize(last * N); device_ids.resize(last * N); device_obs.pop_back(); data.pop_back(); loss.pop_back(); active.pop_back();
+    precision_matrices.resize(last * E * E); residuals.resize(E * last); chi2_vec.resize(last); chi2_derivative.resize(last); work.resize(E * last);
+  }
+  void set_active(size_t id, uint8_t active_value) { active[id] = (active[id] & 0x80) | (active_value & 0x7F); } // factor.hpp:419-431
+  void reset_active() { for (size_t i = 0; i < active.size(); ++i) active[i] = 0; }
+  void set_jacobian_storage(bool on) { store_jacobians = on; } // accepted; Jacobians are always stored here
+  size_t internal_count() const override { return device_obs.size(); }
+  size_t active_count() const override { return active_indices.size(); }
+  std::array<size_t, N> get_vertex_ids(size_t id) const { std::array<size_t, N> r; for (size_t i = 0; i < N; ++i) r[i] = host_ids[id * N + i]; return r; }
+  const ObservationType &get_observation(size_t id) const { return device_obs[id]; }
+  const ConstraintDataType &get_constraint_data(size_t id) const { return data[id]; }
+
+  size_t num_slots() const override { return N; }
+  size_t error_dimension() const override { return E; }
+  BaseVertexDescriptor<T, S> *slot_descriptor(size_t s) const override { return vertex_descriptors[s]; }
+
+  void initialize(uint8_t level) override {
+    active_indices.clear();
+    for (size_t f = 0; f < internal_count(); ++f) {
+      for (size_t i = 0; i < N; ++i) device_ids[f * N + i] = vertex_descriptors[i]->get_local_id(host_ids[f * N + i]);
+      if (detail::is_factor_active(active[f], level)) active_indices.push_back(f);
+    }
+    init_jacobians(std::make_index_sequence<N>{});
+  }
+  void flag_active_vertices() override {
+    for (size_t i = 0; i < N; ++i)
+      if (active_count()) detail::k_flag_vertices<void><<<detail::blocks(active_count()), detail::TPB>>>(active_indices.raw(), active_count(), device_ids.raw(), N, i, vertex_descriptors[i]->get_active_state());
+  }
+
+  detail::FactorView<FactorDescriptor> view() {
+    detail::FactorView<FactorDescriptor> fv;
+    fv.active_ids = active_indices.raw(); fv.n_active = active_count(); fv.ids = device_ids.raw(); fv.obs = device_obs.raw();
+    fv.data = data.raw(); fv.loss = loss.raw(); fv.pmat = precision_matrices.raw(); fv.residuals = residuals.raw();
+    fv.chi2 = chi2_vec.raw(); fv.dchi2 = chi2_derivative.raw();
+    fill_view(fv, std::make_index_sequence<N>{});
+    return fv;
+  }
+  void compute_error() override {
+    if (!active_count()) return;
+    detail::k_error<FactorDescriptor><<<detail::blocks(active_count()), detail::TPB>>>(view(), std::make_index_sequence<N>{});
+  }
+  void compute_jacobians() override { jac_all(std::make_index_sequence<N>{}); }
+  void compute_chi2() override {
+    if (active_count()) detail::k_chi2<FactorDescriptor><<<detail::blocks(active_count()), detail::TPB>>>(view());
+  }
+  T chi2() override { // factor.hpp:551-557
+    compute_chi2();
+    if (!active_count()) return T(0);
+    detail::k_sum_active<T><<<1, detail::TPB>>>(chi2_vec.raw(), active_indices.raw(), active_count(), scalar.raw());
+    detail::sync();
+    return scalar[0];
+  }
+  T chi2(size_t id) { detail::sync(); return chi2_vec[id]; }
+  void scalar_diagonal(T *diag) override { slot_all<0>(diag, nullptr, std::make_index_sequence<N>{}); }
+  void scale_jacobians(const T *scales) override { slot_all<1>(nullptr, scales, std::make_index_sequence<N>{}); }
+  void compute_b(T *b) override { slot_all<2>(b, nullptr, std::make_index_sequence<N>{}); }
+  void compute_Jtv(T *out, const T *res) override { slot_all<3>(out, res, std::make_index_sequence<N>{}); }
+  void compute_Jv(T *res, const T *x) override { jv_all(res, x, std::make_index_sequence<N>{}); }
+  T *work_residual() override { return work.raw(); }
+  void block_diagonal(size_t slot, T *blocks) override { block_one(slot, blocks, std::make_index_sequence<N>{}); }
+  void dense_hessian(T *H, size_t n) override { dense_all(H, n, std::make_index_sequence<N>{}); }
+
+private:
+  template <size_t... Is> void init_jacobians(std::index_sequence<Is...>) {
+    ((jacobians[Is].dimensions[0] = E, jacobians[Is].dimensions[1] = detail::slot_dim<FactorDescriptor, Is>(),
+      jacobians[Is].data.resize(E * detail::slot_dim<FactorDescriptor, Is>() * internal_count())), ...);
+  }
+  template <size_t... Is> void fill_view(detail::FactorView<FactorDescriptor> &fv, std::index_sequence<Is...>) {
+    ((fv.jac[Is] = jacobians[Is].data.raw(),
+      fv.verts[Is] = static_cast<typename std::tuple_element<Is, VDTuple>::type *>(typed_descriptors[Is])->vertices(),
+      fv.vstate[Is] = vertex_descriptors[Is]->get_active_state(), fv.hid[Is] = vertex_descriptors[Is]->get_hessian_ids()), ...);
+  }
+  template <size_t... Is> void jac_all(std::index_sequence<Is...> seq) {
+    if (!active_count()) return;
+    constexpr bool manual = std::is_same<typename Traits::Differentiation, DifferentiationMode::Manual>::value;
+    auto fv = view();
+    // the reference clears the Jacobian storage first (ops/linearize.hpp:127): fixed vertices keep zeros
+    ((detail::fill<S>(jacobians[Is].data.raw(), jacobians[Is].data.size(), S(0)),
+      detail::k_jacobian<FactorDescriptor, Is><<<detail::blocks(active_count() * (manual ? 1 : detail::slot_dim<FactorDescriptor, Is>())), detail::TPB>>>(fv, seq)), ...);
+  }
+  template <int WHICH, size_t... Is> void slot_all(T *out, const T *in, std::index_sequence<Is...>) {
+    if (!active_count()) return;
+    auto fv = view();
+    ((detail::k_slot<FactorDescriptor, Is, WHICH><<<detail::blocks(active_count() * detail::slot_dim<FactorDescriptor, Is>()), detail::TPB>>>(fv, out, in)), ...);
+  }
+  template <size_t... Is> void jv_all(T *res, const T *x, std::index_sequence<Is...>) {
+    if (!active_count()) return;
+    auto fv = view();
+    ((detail::k_Jv<FactorDescriptor, Is><<<detail::blocks(active_count() * E), detail::TPB>>>(fv, res, x)), ...);
+  }
+  template <size_t... Is> void block_one(size_t slot, T *blocks, std::index_sequence<Is...>) {
+    if (!active_count()) return;
+    auto fv = view();
+    ((slot == Is ? (void)(detail::k_slot<FactorDescriptor, Is, 4><<<detail::blocks(active_count() * detail::slot_dim<FactorDescriptor, Is>()), detail::TPB>>>(fv, blocks, nullptr)) : (void)0), ...);
+  }
+  template <size_t I, size_t... Ks> void dense_row(detail::FactorView<FactorDescriptor> &fv, T *H, size_t n, std::index_sequence<Ks...>) {
+    ((detail::k_dense_pair<FactorDescriptor, I, Ks><<<detail::blocks(active_count() * detail::slot_dim<FactorDescriptor, I>() * detail::slot_dim<FactorDescriptor, Ks>()), detail::TPB>>>(fv, H, n)), ...);
+  }
+  template <size_t... Is> void dense_all(T *H, size_t n, std::index_sequence<Is...> seq) {
+    if (!active_count()) return;
+    auto fv = view();
+    ((dense_row<Is>(fv, H, n, seq)), ...);
+  }
+};
+
+// =================================================================================================
+// Graph (graph.hpp:30-340)
+// =================================================================================================
+namespace detail {
+template <typename T> __global__ void k_scales(T *diag_to_scale, size_t n) { // graph.hpp:262-270
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) diag_to_scale[i] = (T)(1.0 / (std::numeric_limits<double>::epsilon() + ::sqrt((double)diag_to_scale[i])));
+}
+template <typename T> __global__ void k_xor_msb(uint8_t *s, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) s[i] ^= 0x80;
+}
+template <typename T> __global__ void k_clear_msb(uint8_t *s, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) s[i] &= 0x7F;
+}
+} // namespace detail
+
+template <typename T, typename S> class Graph {
+  std::vector<BaseVertexDescriptor<T, S> *> vertex_descriptors;
+  std::vector<BaseFactorDescriptor<T, S> *> factor_descriptors;
+  managed_vector<T> b, jacobian_scales;
+  size_t hessian_dim = 0;
+  bool scale_jacobians_ = true;
+public:
+  void add_descriptor(BaseVertexDescriptor<T, S> *d) { vertex_descriptors.push_back(d); }
+  void add_descriptor(BaseFactorDescriptor<T, S> *d) { factor_descriptors.push_back(d); }
+  void add_vertex_descriptor(BaseVertexDescriptor<T, S> *d) { add_descriptor(d); }
+  void add_factor_descriptor(BaseFactorDescriptor<T, S> *d) { add_descriptor(d); }
+  std::vector<BaseVertexDescriptor<T, S> *> &get_vertex_descriptors() { return vertex_descriptors; }
+  std::vector<BaseFactorDescriptor<T, S> *> &get_factor_descriptors() { return factor_descriptors; }
+  void scale_system(bool on) { scale_jacobians_ = on; }
+  size_t get_hessian_dimension() const { return hessian_dim; }
+  managed_vector<T> &get_b() { return b; }
+  managed_vector<T> &get_jacobian_scales() { return jacobian_scales; }
+  void clear() { vertex_descriptors.clear(); factor_descriptors.clear(); }
+
+  // graph.hpp:92-167: active factors, which vertices they use, then one scalar column range per
+  // active vertex, descriptors in the order they were added, vertices by ascending global id
+  bool initialize_optimization(uint8_t level = 0) {
+    for (auto *vd : vertex_descriptors)
+      if (vd->count()) detail::k_clear_msb<T><<<detail::blocks(vd->count()), detail::TPB>>>(vd->get_active_state(), vd->count());
+    for (auto *fd : factor_descriptors) fd->initialize(level);
+    for (auto *fd : factor_descriptors) fd->flag_active_vertices();
+    for (auto *vd : vertex_descriptors)
+      if (vd->count()) detail::k_xor_msb<T><<<detail::blocks(vd->count()), detail::TPB>>>(vd->get_active_state(), vd->count());
+    detail::sync();
+    size_t col = 0;
+    for (int pass = 0; pass < 2; ++pass) // non-eliminated descriptors first, eliminated ones last (graph.hpp:100-149)
+      for (auto *vd : vertex_descriptors) {
+        if ((int)vd->eliminate != pass) continue;
+        std::vector<std::pair<size_t, size_t>> order;
+        const auto &l2g = vd->local_to_global();
+        for (size_t l = 0; l < vd->count(); ++l) order.emplace_back(l2g[l], l);
+        std::sort(order.begin(), order.end());
+        for (auto &e : order)
+          if (detail::is_vertex_active(vd->get_active_state(), e.second)) { vd->get_hessian_ids()[e.second] = col; col += vd->dimension(); }
+      }
+    hessian_dim = col;
+    b.resize(col); jacobian_scales.resize(col);
+    return col > 0;
+  }
+  bool build_structure() { return true; }
+
+  void compute_error() { for (auto *fd : factor_descriptors) fd->compute_error(); }
+  T chi2() { T c = 0; for (auto *fd : factor_descriptors) c += fd->chi2(); return c; } // graph.hpp:212-225
+  // graph.hpp:236-290
+  void linearize(StreamPool &) { linearize(); }
+  void linearize() {
+    for (auto *fd : factor_descriptors) { fd->compute_error(); fd->compute_jacobians(); fd->compute_chi2(); }
+    if (scale_jacobians_) {
+      detail::fill<T>(jacobian_scales.raw(), hessian_dim, T(0));
+      for (auto *fd : factor_descriptors) fd->scalar_diagonal(jacobian_scales.raw());
+      if (hessian_dim) detail::k_scales<T><<<detail::blocks(hessian_dim), detail::TPB>>>(jacobian_scales.raw(), hessian_dim);
+      for (auto *fd : factor_descriptors) fd->scale_jacobians(jacobian_scales.raw());
+    } else detail::fill<T>(jacobian_scales.raw(), hessian_dim, T(1));
+    detail::fill<T>(b.raw(), hessian_dim, T(0));
+    for (auto *fd : factor_descriptors) fd->compute_b(b.raw());
+    detail::sync();
+  }
+  void apply_update(const T *delta_x, StreamPool &) { apply_update(delta_x); }
+  void apply_update(const T *delta_x) { for (auto *vd : vertex_descriptors) vd->apply_update(delta_x, jacobian_scales.raw()); detail::sync(); }
+  void backup_parameters() { for (auto *vd : vertex_descriptors) vd->backup_parameters(); detail::sync(); }
+  void revert_parameters() { for (auto *vd : vertex_descriptors) vd->restore_parameters(); detail::sync(); }
+  // (J^T rho' P J) x, matrix-free (solver/pcg.hpp:143-163)
+  void hessian_matvec(T *out, const T *x) {
+    detail::fill<T>(out, hessian_dim, T(0));
+    for (auto *fd : factor_descriptors) {
+      detail::fill<T>(fd->work_residual(), fd->internal_count() * fd->error_dimension(), T(0));
+      fd->compute_Jv(fd->work_residual(), x);
+      fd->compute_Jtv(out, fd->work_residual());
+    }
+  }
+};
+
+} // namespace graphite

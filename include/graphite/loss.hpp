@@ -1,0 +1,3 @@
+// forwarding header: the generic layer lives in core.hpp (reference path: include/graphite/loss.hpp)
+#pragma once
+#include "core.hpp"

@@ -1,0 +1,363 @@
+// graphite/solve.hpp — solvers, preconditioners and the Levenberg–Marquardt driver of the generic layer
+// (see core.hpp for scope).  Mirrors solver/solver.hpp:12-25, solver/pcg.hpp:35-232,
+// preconditioner/{preconditioner,identity,block_jacobi}.hpp, solver/eigen.hpp:16-100 and
+// optimizer/levenberg_marquardt.hpp:20-242 of the reference.
+#pragma once
+#include "core.hpp"
+#include "../graphite_mi355x.h"
+
+namespace graphite {
+
+namespace detail {
+template <typename T> __global__ void k_axpy(T *y, T a, const T *x, size_t n) { // y = a x + y
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i] + y[i];
+}
+template <typename T> __global__ void k_xpby(T *y, const T *x, T b, size_t n) { // y = x + b y
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) y[i] = x[i] + b * y[i];
+}
+template <typename T> __global__ void k_scale_copy(T *y, T a, const T *x, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a * x[i];
+}
+template <typename T> __global__ void k_damp(T *v2, const T *p, const T *diag, T mu, int identity, size_t n) { // ops/vector.hpp:25-41
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) v2[i] += identity ? mu * p[i] : mu * diag[i] * p[i];
+}
+template <typename T> __global__ void k_clamp(T *d, T lo, T hi, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) d[i] = d[i] < lo ? lo : (d[i] > hi ? hi : d[i]);
+}
+template <typename T> __global__ void k_dot(const T *a, const T *b, size_t n, T *out) {
+  __shared__ T red[TPB];
+  T s = 0;
+  for (size_t i = threadIdx.x; i < n; i += TPB) s += a[i] * b[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = red[0];
+}
+// in-place inverse of `count` d x d blocks (column-major) after damping the diagonal
+// (block_jacobi.hpp:120-172; the reference uses cuBLAS matinvBatched = Gauss-Jordan with pivoting)
+template <typename T> __global__ void k_block_inverse(const T *blocks, T *inv, size_t count, int d, T mu, int identity, const uint8_t *state) {
+  const size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (v >= count || !is_vertex_active(state, v)) return;
+  const T *B = blocks + v * d * d;
+  T *X = inv + v * d * d;
+  constexpr int MAXD = 16;
+  double A[MAXD * MAXD], R[MAXD * MAXD];
+  for (int c = 0; c < d; ++c)
+    for (int r = 0; r < d; ++r) {
+      double val = (double)B[r + c * d];
+      if (r == c) { const double cl = val < 1.0e-6 ? 1.0e-6 : (val > 1.0e32 ? 1.0e32 : val); val += identity ? (double)mu : (double)mu * cl; }
+      A[r + c * d] = val;
+      R[r + c * d] = r == c ? 1.0 : 0.0;
+    }
+  for (int k = 0; k < d; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < d; ++r) if (fabs(A[r + k * d]) > fabs(A[piv + k * d])) piv = r;
+    if (piv != k)
+      for (int c = 0; c < d; ++c) { double t = A[k + c * d]; A[k + c * d] = A[piv + c * d]; A[piv + c * d] = t; t = R[k + c * d]; R[k + c * d] = R[piv + c * d]; R[piv + c * d] = t; }
+    const double ip = 1.0 / A[k + k * d];
+    for (int c = 0; c < d; ++c) { A[k + c * d] *= ip; R[k + c * d] *= ip; }
+    for (int r = 0; r < d; ++r) {
+      if (r == k) continue;
+      const double f = A[r + k * d];
+      for (int c = 0; c < d; ++c) { A[r + c * d] -= f * A[k + c * d]; R[r + c * d] -= f * R[k + c * d]; }
+    }
+  }
+  for (int i = 0; i < d * d; ++i) X[i] = (T)R[i];
+}
+template <typename T> __global__ void k_block_apply(const T *inv, const size_t *hid, const uint8_t *state, size_t count, int d, T *z, const T *r) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= count * d) return;
+  const size_t v = t / d, row = t % d;
+  if (!is_vertex_active(state, v)) return;
+  T s = 0;
+  for (int c = 0; c < d; ++c) s += inv[v * d * d + row + c * d] * r[hid[v] + c];
+  z[hid[v] + row] = s;
+}
+template <typename T> __global__ void k_damp_dense(T *H, size_t n, T mu, int identity) { // hessian.hpp:136-176
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double d = (double)H[i * n + i];
+  const double cl = d < 1.0e-6 ? 1.0e-6 : (d > 1.0e32 ? 1.0e32 : d);
+  H[i * n + i] = (T)(identity ? d + (double)mu : d + (double)mu * cl);
+}
+template <typename T> inline T dot(const T *a, const T *b, size_t n, T *scratch) {
+  k_dot<T><<<1, TPB>>>(a, b, n, scratch);
+  sync();
+  return *scratch;
+}
+} // namespace detail
+
+// ---- preconditioner/preconditioner.hpp:8-20 ------------------------------------------------------
+template <typename T, typename S> class Preconditioner {
+public:
+  virtual ~Preconditioner() = default;
+  virtual void update_structure(Graph<T, S> *graph, StreamPool &streams) = 0;
+  virtual void update_values(Graph<T, S> *graph, StreamPool &streams) = 0;
+  virtual void set_damping_factor(Graph<T, S> *graph, T damping_factor, const bool use_identity, StreamPool &streams) = 0;
+  virtual void apply(Graph<T, S> *graph, T *z, const T *r, StreamPool &streams) = 0;
+};
+
+template <typename T, typename S> class IdentityPreconditioner : public Preconditioner<T, S> {
+public:
+  void update_structure(Graph<T, S> *, StreamPool &) override {}
+  void update_values(Graph<T, S> *, StreamPool &) override {}
+  void set_damping_factor(Graph<T, S> *, T, const bool, StreamPool &) override {}
+  void apply(Graph<T, S> *graph, T *z, const T *r, StreamPool &) override {
+    GRAPHITE_HIP(hipMemcpy(z, r, graph->get_hessian_dimension() * sizeof(T), hipMemcpyDefault));
+  }
+};
+
+// preconditioner/block_jacobi.hpp:79-186: one d x d block of J^T rho' P J per vertex, damped and inverted
+template <typename T, typename S> class BlockJacobiPreconditioner : public Preconditioner<T, S> {
+  std::vector<std::unique_ptr<managed_vector<T>>> blocks, inverses;
+public:
+  void update_structure(Graph<T, S> *graph, StreamPool &) override {
+    auto &vds = graph->get_vertex_descriptors();
+    blocks.clear(); inverses.clear();
+    for (auto *vd : vds) {
+      if (vd->dimension() > 16) throw std::invalid_argument("BlockJacobiPreconditioner: vertex dimension > 16");
+      blocks.emplace_back(new managed_vector<T>(vd->count() * vd->dimension() * vd->dimension()));
+      inverses.emplace_back(new managed_vector<T>(vd->count() * vd->dimension() * vd->dimension()));
+    }
+  }
+  void update_values(Graph<T, S> *graph, StreamPool &) override {
+    auto &vds = graph->get_vertex_descriptors();
+    for (auto &b : blocks) detail::fill<T>(b->raw(), b->size(), T(0));
+    for (auto *fd : graph->get_factor_descriptors())
+      for (size_t s = 0; s < fd->num_slots(); ++s) {
+        const size_t k = std::find(vds.begin(), vds.end(), fd->slot_descriptor(s)) - vds.begin();
+        if (k < vds.size()) fd->block_diagonal(s, blocks[k]->raw());
+      }
+    detail::sync();
+  }
+  void set_damping_factor(Graph<T, S> *graph, T mu, const bool use_identity, StreamPool &) override {
+    auto &vds = graph->get_vertex_descriptors();
+    for (size_t k = 0; k < vds.size(); ++k)
+      if (vds[k]->count())
+        detail::k_block_inverse<T><<<detail::blocks(vds[k]->count()), detail::TPB>>>(blocks[k]->raw(), inverses[k]->raw(), vds[k]->count(), (int)vds[k]->dimension(), mu, use_identity ? 1 : 0, vds[k]->get_active_state());
+    detail::sync();
+  }
+  void apply(Graph<T, S> *graph, T *z, const T *r, StreamPool &) override {
+    auto &vds = graph->get_vertex_descriptors();
+    for (size_t k = 0; k < vds.size(); ++k)
+      if (vds[k]->count())
+        detail::k_block_apply<T><<<detail::blocks(vds[k]->count() * vds[k]->dimension()), detail::TPB>>>(inverses[k]->raw(), vds[k]->get_hessian_ids(), vds[k]->get_active_state(), vds[k]->count(), (int)vds[k]->dimension(), z, r);
+  }
+};
+
+// ---- solver/solver.hpp:12-25 ---------------------------------------------------------------------
+template <typename T, typename S> class Solver {
+public:
+  virtual ~Solver() = default;
+  virtual void update_structure(Graph<T, S> *graph, StreamPool &streams) = 0;
+  virtual void update_values(Graph<T, S> *graph, StreamPool &streams) = 0;
+  virtual void set_damping_factor(Graph<T, S> *graph, T damping_factor, const bool use_identity, StreamPool &streams) = 0;
+  virtual bool solve(Graph<T, S> *graph, T *delta_x, StreamPool &streams) = 0;
+};
+
+// solver/pcg.hpp:35-232: matrix-free PCG on (J^T rho' P J + mu D) x = b; same iterates, stopping and
+// rejection rules (the preconditioner is applied to r / ||r||)
+template <typename T, typename S> class PCGSolver : public Solver<T, S> {
+  size_t max_iter;
+  T tol, rejection_ratio;
+  Preconditioner<T, S> *preconditioner;
+  managed_vector<T> r, p, z, v2, diag, y, xb, scratch;
+  T damping = 0;
+  bool damping_identity = false;
+  size_t iterations_ = 0;
+public:
+  PCGSolver(size_t max_iter_, T tol_, T rejection_ratio_, Preconditioner<T, S> *preconditioner_)
+      : max_iter(max_iter_), tol(tol_), rejection_ratio(rejection_ratio_), preconditioner(preconditioner_) { scratch.resize(1); }
+  size_t last_iterations() const { return iterations_; }
+  void update_structure(Graph<T, S> *graph, StreamPool &streams) override {
+    const size_t n = graph->get_hessian_dimension();
+    r.resize(n); p.resize(n); z.resize(n); v2.resize(n); diag.resize(n); y.resize(n); xb.resize(n);
+    preconditioner->update_structure(graph, streams);
+  }
+  void update_values(Graph<T, S> *graph, StreamPool &streams) override {
+    const size_t n = graph->get_hessian_dimension();
+    detail::fill<T>(diag.raw(), n, T(0)); // pcg.hpp:93-103: clamped scalar diagonal of the (scaled) J^T rho' P J
+    for (auto *fd : graph->get_factor_descriptors()) fd->scalar_diagonal(diag.raw());
+    if (n) detail::k_clamp<T><<<detail::blocks(n), detail::TPB>>>(diag.raw(), T(1.0e-6), T(1.0e32), n);
+    preconditioner->update_values(graph, streams);
+  }
+  void set_damping_factor(Graph<T, S> *graph, T mu, const bool use_identity, StreamPool &streams) override {
+    damping = mu; damping_identity = use_identity;
+    preconditioner->set_damping_factor(graph, mu, use_identity, streams);
+  }
+  bool solve(Graph<T, S> *graph, T *x, StreamPool &streams) override {
+    using namespace detail;
+    const size_t n = graph->get_hessian_dimension();
+    if (!n) return true;
+    const int nb = blocks(n);
+    fill<T>(x, n, T(0));
+    GRAPHITE_HIP(hipMemcpy(r.raw(), graph->get_b().raw(), n * sizeof(T), hipMemcpyDefault));
+    T rnorm = std::sqrt(dot(r.raw(), r.raw(), n, scratch.raw()));
+    k_scale_copy<T><<<nb, TPB>>>(y.raw(), (T)(1.0 / rnorm), r.raw(), n);
+    preconditioner->apply(graph, z.raw(), y.raw(), streams);
+    sync();
+    GRAPHITE_HIP(hipMemcpy(p.raw(), z.raw(), n * sizeof(T), hipMemcpyDefault));
+    T rz = dot(r.raw(), z.raw(), n, scratch.raw());
+    T rz_0 = std::numeric_limits<T>::infinity();
+    iterations_ = 0;
+    for (size_t k = 0; k < max_iter; ++k) {
+      if (rz == 0) break;
+      graph->hessian_matvec(v2.raw(), p.raw());
+      k_damp<T><<<nb, TPB>>>(v2.raw(), p.raw(), diag.raw(), damping, damping_identity ? 1 : 0, n);
+      ++iterations_;
+      const T alpha = rz / dot(p.raw(), v2.raw(), n, scratch.raw());
+      GRAPHITE_HIP(hipMemcpy(xb.raw(), x, n * sizeof(T), hipMemcpyDefault));
+      k_axpy<T><<<nb, TPB>>>(x, alpha, p.raw(), n);
+      k_axpy<T><<<nb, TPB>>>(r.raw(), -alpha, v2.raw(), n);
+      rnorm = std::sqrt(dot(r.raw(), r.raw(), n, scratch.raw()));
+      k_scale_copy<T><<<nb, TPB>>>(y.raw(), (T)(1.0 / rnorm), r.raw(), n);
+      preconditioner->apply(graph, z.raw(), y.raw(), streams);
+      const T rz_new = dot(r.raw(), z.raw(), n, scratch.raw());
+      if (std::abs(rz_new) > rejection_ratio * rz_0 || std::isnan(rz_new)) {
+        GRAPHITE_HIP(hipMemcpy(x, xb.raw(), n * sizeof(T), hipMemcpyDefault));
+        break;
+      }
+      rz_0 = std::min(rz_0, std::abs(rz_new));
+      const T beta = rz_new / rz;
+      rz = rz_new;
+      k_xpby<T><<<nb, TPB>>>(p.raw(), z.raw(), beta, n);
+      if (std::abs(rz_new) < tol) break;
+    }
+    sync();
+    return true;
+  }
+};
+
+// solver/eigen.hpp:16-100 (EigenLDLTSolver): direct solve of (J^T rho' P J damped) x = b.  Here the
+// matrix is assembled densely on the device and handed to the MFMA Cholesky of libgraphite_mi355x.so.
+template <typename T, typename S> class EigenLDLTSolver : public Solver<T, S> {
+  managed_vector<T> H, Hd;
+  T damping = 0;
+  bool damping_identity = false;
+public:
+  void update_structure(Graph<T, S> *graph, StreamPool &) override {
+    const size_t n = graph->get_hessian_dimension();
+    H.resize(n * n); Hd.resize(n * n);
+  }
+  void update_values(Graph<T, S> *graph, StreamPool &) override {
+    const size_t n = graph->get_hessian_dimension();
+    detail::fill<T>(H.raw(), n * n, T(0));
+    for (auto *fd : graph->get_factor_descriptors()) fd->dense_hessian(H.raw(), n);
+    detail::sync();
+  }
+  void set_damping_factor(Graph<T, S> *, T mu, const bool use_identity, StreamPool &) override { damping = mu; damping_identity = use_identity; }
+  bool solve(Graph<T, S> *graph, T *x, StreamPool &) override {
+    const size_t n = graph->get_hessian_dimension();
+    if (!n) return true;
+    GRAPHITE_HIP(hipMemcpy(Hd.raw(), H.raw(), n * n * sizeof(T), hipMemcpyDefault));
+    detail::k_damp_dense<T><<<detail::blocks(n), detail::TPB>>>(Hd.raw(), n, damping, damping_identity ? 1 : 0);
+    detail::sync();
+    int dev = 0;
+    GRAPHITE_HIP(hipGetDevice(&dev));
+    const gr_status st = gr_dense_cholesky_solve(sizeof(T) == 8 ? GR_F64 : GR_F32, (int64_t)n, Hd.raw(), (int64_t)n, graph->get_b().raw(), x, dev, nullptr, nullptr);
+    return st == GR_OK;
+  }
+};
+template <typename T, typename S> using EigenSchurLDLTSolver = EigenLDLTSolver<T, S>; // no elimination in the generic layer
+
+// ---- optimizer/levenberg_marquardt.hpp -----------------------------------------------------------
+namespace optimizer {
+
+template <typename T, typename S> class LevenbergMarquardtOptions {
+public:
+  Solver<T, S> *solver = nullptr;
+  size_t iterations = 10;
+  double initial_damping = 1e-4;
+  uint8_t optimization_level = 0;
+  bool verbose = false;
+  bool *stop_flag = nullptr;
+  bool use_identity = false;
+  StreamPool *streams = nullptr;
+  bool validate() const {
+    if (!solver) { if (verbose) std::cerr << "Levenberg-Marquardt options invalid: solver is null" << std::endl; return false; }
+    if (!streams) { if (verbose) std::cerr << "Levenberg-Marquardt options invalid: streams is null" << std::endl; return false; }
+    return true;
+  }
+};
+
+// :20-47
+template <typename T, typename S> T compute_rho(Graph<T, S> *graph, const T *delta_x, T chi2, T new_chi2, T mu, bool step_is_good) {
+  T num = chi2 - new_chi2, denom = 1;
+  if (step_is_good) {
+    const size_t n = graph->get_hessian_dimension();
+    const T *b = graph->get_b().raw();
+    denom = 0;
+    for (size_t k = 0; k < n; ++k) denom += delta_x[k] * (mu * delta_x[k] + b[k]); // mapped memory: small graphs
+    denom += T(1.0e-3);
+  }
+  return num / denom;
+}
+
+// :110-242
+template <typename T, typename S> bool levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {
+  if (!options->validate()) return false;
+  using clk = std::chrono::steady_clock;
+  auto start = clk::now();
+  if (!graph->initialize_optimization(options->optimization_level)) return false;
+  graph->build_structure();
+  StreamPool &streams = *options->streams;
+  Solver<T, S> *solver = options->solver;
+  T mu = static_cast<T>(options->initial_damping), nu = 2;
+  solver->update_structure(graph, streams);
+  graph->linearize(streams);
+  solver->update_values(graph, streams);
+  T chi2 = graph->chi2();
+  managed_vector<T> delta_x(graph->get_hessian_dimension());
+  bool run = true;
+  if (options->verbose) {
+    std::cout << std::setprecision(12) << std::setw(18) << "Iteration" << std::setw(24) << "Initial Chi2" << std::setw(24)
+              << "Current Chi2" << std::setw(24) << "Lambda" << std::setw(24) << "Time" << std::setw(24) << "Total Time" << std::endl;
+    std::cout << std::string(138, '-') << std::endl;
+  }
+  double time = std::chrono::duration<double>(clk::now() - start).count();
+  for (size_t i = 0; i < options->iterations && run; ++i) {
+    auto t0 = clk::now();
+    solver->set_damping_factor(graph, mu, options->use_identity, streams);
+    const bool solve_ok = solver->solve(graph, delta_x.raw(), streams);
+    graph->backup_parameters();
+    graph->apply_update(delta_x.raw(), streams);
+    graph->compute_error();
+    T new_chi2 = graph->chi2();
+    if (!solve_ok) new_chi2 = std::numeric_limits<T>::max();
+    const T rho = compute_rho(graph, delta_x.raw(), chi2, new_chi2, mu, solve_ok);
+    const T chi2_before = chi2;
+    if (solve_ok && std::isfinite(new_chi2) && rho > 0) {
+      double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3);
+      alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
+      mu *= static_cast<T>(alpha);
+      nu = 2;
+      chi2 = new_chi2;
+      graph->linearize(streams);
+      solver->update_values(graph, streams);
+    } else {
+      graph->revert_parameters();
+      graph->compute_error();
+      (void)graph->chi2();
+      mu *= nu;
+      nu *= 2;
+      new_chi2 = chi2;
+    }
+    const double it_time = std::chrono::duration<double>(clk::now() - t0).count();
+    time += it_time;
+    if (options->verbose)
+      std::cout << std::setprecision(12) << std::setw(18) << i << std::setw(24) << chi2_before << std::setw(24) << new_chi2 << std::setw(24)
+                << mu << std::setw(24) << it_time << std::setw(24) << time << std::endl;
+    if (!std::isfinite(mu)) { std::cout << "Damping factor is infinite, terminating optimization" << std::endl; run = false; }
+    if (rho == 0) { std::cout << "Rho is zero, terminating optimization" << std::endl; break; }
+    if (options->stop_flag && *options->stop_flag) { std::cout << "Stopping optimization due to stop flag" << std::endl; break; }
+  }
+  return run;
+}
+
+} // namespace optimizer
+} // namespace graphite

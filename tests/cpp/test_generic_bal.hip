@@ -1,0 +1,130 @@
+// Generic-layer BAL: the reprojection factor of docs/markdown/main.md:230-262 written as USER traits
+// (camera 9, point 3, error dimension 2, automatic differentiation) and optimised with the generic
+// Graph / PCGSolver / EigenLDLTSolver / levenberg_marquardt.  Prints the chi2 trace; tests/test_generic_api.py
+// compares it with the CPU oracle's LM on the same file.
+//   usage: test_generic_bal <bal file> <pcg|pcg-identity|eigen> <iterations>
+#include <fstream>
+#include <graphite/optimizer/levenberg_marquardt.hpp>
+#include <graphite/preconditioner/block_jacobi.hpp>
+#include <graphite/preconditioner/identity.hpp>
+#include <graphite/solver/eigen.hpp>
+#include <graphite/solver/pcg.hpp>
+#include <iostream>
+#include <memory>
+#include <string>
+
+namespace graphite {
+
+template <typename T, int N> struct Vec {
+  T v[N];
+  hd_fn T operator()(int i) const { return v[i]; }
+  hd_fn T &operator()(int i) { return v[i]; }
+};
+template <typename T> using Camera = Vec<T, 9>;
+template <typename T> using Point3 = Vec<T, 3>;
+template <typename T> using Pixel = Vec<T, 2>;
+
+template <typename T, int N> struct VecTraits {
+  static constexpr size_t dimension = N;
+  using Vertex = Vec<T, N>;
+  template <typename P> d_fn static void parameters(const Vertex &x, P *p) { for (int i = 0; i < N; ++i) p[i] = P(x(i)); }
+  d_fn static void update(Vertex &x, const T *d) { for (int i = 0; i < N; ++i) x(i) += d[i]; }
+};
+template <typename T, typename S> using CameraDescriptor = VertexDescriptor<T, S, VecTraits<T, 9>>;
+template <typename T, typename S> using PointDescriptor = VertexDescriptor<T, S, VecTraits<T, 3>>;
+
+// Snavely camera, angle-axis rotation as a Rodrigues matrix; theta == 0 -> identity (no rotation derivative)
+template <typename D, typename T> d_fn void reprojection(const D *cam, const D *pt, const Pixel<T> &obs, D *err) {
+  const D rx = cam[0], ry = cam[1], rz = cam[2];
+  const D theta2 = rx * rx + ry * ry + rz * rz;
+  D P[3];
+  if (theta2 > D(T(0))) {
+    const D theta = sqrt(theta2);
+    const D ax = rx / theta, ay = ry / theta, az = rz / theta;
+    const D s = sin(theta), c = cos(theta), k = D(T(1)) - c;
+    const D R[9] = {k * ax * ax + c,      k * ax * ay - s * az, k * ax * az + s * ay,
+                    k * ax * ay + s * az, k * ay * ay + c,      k * ay * az - s * ax,
+                    k * ax * az - s * ay, k * ay * az + s * ax, k * az * az + c};
+    for (int i = 0; i < 3; ++i) P[i] = R[3 * i] * pt[0] + R[3 * i + 1] * pt[1] + R[3 * i + 2] * pt[2] + cam[3 + i];
+  } else {
+    for (int i = 0; i < 3; ++i) P[i] = pt[i] + cam[3 + i];
+  }
+  const D px = -P[0] / P[2], py = -P[1] / P[2];
+  const D r2 = px * px + py * py;
+  const D d = D(T(1)) + cam[7] * r2 + cam[8] * r2 * r2;
+  err[0] = cam[6] * d * px - D(obs(0));
+  err[1] = cam[6] * d * py - D(obs(1));
+}
+
+template <typename T, typename S> struct ReprojectionErrorTraits {
+  static constexpr size_t dimension = 2;
+  using VertexDescriptors = std::tuple<CameraDescriptor<T, S>, PointDescriptor<T, S>>;
+  using Observation = Pixel<T>;
+  using Data = Empty;
+  using Loss = DefaultLoss<T, dimension>;
+  using Differentiation = DifferentiationMode::Auto;
+  template <typename D> d_fn static void error(const D *camera, const D *point, const Observation &obs, D *error) {
+    reprojection<D, T>(camera, point, obs, error);
+  }
+};
+template <typename T, typename S> using ReprojectionError = FactorDescriptor<T, S, ReprojectionErrorTraits<T, S>>;
+
+} // namespace graphite
+
+int main(int argc, char **argv) {
+  using namespace graphite;
+  using FP = double;
+  using SP = double;
+  if (argc < 4) { std::cerr << "usage: test_generic_bal <file> <pcg|pcg-identity|eigen> <iterations>" << std::endl; return 2; }
+  (void)hipSetDevice(0);
+  std::ifstream file(argv[1]);
+  size_t nc = 0, np = 0, no = 0;
+  file >> nc >> np >> no;
+  std::vector<size_t> ci(no), pi(no);
+  std::vector<Pixel<FP>> ob(no);
+  for (size_t i = 0; i < no; ++i) file >> ci[i] >> pi[i] >> ob[i](0) >> ob[i](1);
+  managed_vector<Camera<FP>> cams(nc);
+  managed_vector<Point3<FP>> pts(np);
+  for (size_t c = 0; c < nc; ++c) for (int k = 0; k < 9; ++k) file >> cams[c](k);
+  for (size_t p = 0; p < np; ++p) for (int k = 0; k < 3; ++k) file >> pts[p](k);
+  if (!file) { std::cerr << "bad BAL file" << std::endl; return 2; }
+
+  Graph<FP, SP> graph;
+  CameraDescriptor<FP, SP> cam_desc;
+  PointDescriptor<FP, SP> pt_desc;
+  cam_desc.reserve(nc); pt_desc.reserve(np);
+  graph.add_descriptor(&cam_desc);
+  graph.add_descriptor(&pt_desc);
+  for (size_t c = 0; c < nc; ++c) cam_desc.add_vertex(c, &cams[c]);
+  for (size_t p = 0; p < np; ++p) pt_desc.add_vertex(nc + p, &pts[p]); // ids are global across descriptors
+  pt_desc.set_eliminate(true);
+  ReprojectionError<FP, SP> r_desc(&cam_desc, &pt_desc);
+  r_desc.reserve(no);
+  graph.add_descriptor(&r_desc);
+  const DefaultLoss<FP, 2> loss;
+  for (size_t i = 0; i < no; ++i) r_desc.add_factor({ci[i], nc + pi[i]}, ob[i], nullptr, Empty(), loss);
+
+  const std::string kind = argv[2];
+  BlockJacobiPreconditioner<FP, SP> bj;
+  IdentityPreconditioner<FP, SP> id;
+  std::unique_ptr<Solver<FP, SP>> solver;
+  if (kind == "pcg") solver.reset(new PCGSolver<FP, SP>(10, 1.0, 5.0, &bj));
+  else if (kind == "pcg-identity") solver.reset(new PCGSolver<FP, SP>(10, 1.0, 5.0, &id));
+  else if (kind == "eigen") solver.reset(new EigenLDLTSolver<FP, SP>());
+  else return 2;
+
+  StreamPool streams(2);
+  optimizer::LevenbergMarquardtOptions<FP, SP> options;
+  options.solver = solver.get();
+  options.initial_damping = 1e-4;
+  options.iterations = std::stoul(argv[3]);
+  options.verbose = true; // the table is the chi2 / lambda trace the test parses
+  options.streams = &streams;
+  const bool ok = optimizer::levenberg_marquardt<FP, SP>(&graph, &options);
+  std::cout << std::setprecision(17) << "FINAL_CHI2 " << graph.chi2() << std::endl;
+  std::cout << "CAM0";
+  for (int k = 0; k < 9; ++k) std::cout << " " << cams[0](k);
+  std::cout << std::endl << (ok ? "OK" : "STOPPED") << std::endl;
+  solver.reset();
+  return 0;
+}
