@@ -139,6 +139,7 @@ public:
   struct pointer { T *p; T *get() const { return p; } };
   managed_vector() = default;
   explicit managed_vector(size_t n) { resize(n); }
+  managed_vector(size_t n, const T &v) { resize(n, v); }
   managed_vector(const managed_vector &) = delete;
   managed_vector &operator=(const managed_vector &) = delete;
   ~managed_vector() { if (p_) (void)hipHostFree(p_); }
@@ -291,6 +292,7 @@ public:
     x_device[it->second] = vertex;
   }
   void set_fixed(size_t id, bool fixed) { active_state[global_to_local_map.at(id)] = static_cast<uint8_t>(fixed); }
+  void set_hessian_column(size_t id, size_t column, size_t /*block*/) { hessian_ids[global_to_local_map.at(id)] = column; } // vertex.hpp:288-296
   bool is_fixed(size_t id) const override { return (active_state[global_to_local_map.at(id)] & 0x1) > 0; }
   bool is_active(size_t id) const override { return detail::is_vertex_active(active_state.raw(), global_to_local_map.at(id)); }
   bool exists(size_t id) const override { return global_to_local_map.count(id) > 0; }
@@ -643,6 +645,13 @@ public:
   void set_active(size_t id, uint8_t active_value) { active[id] = (active[id] & 0x80) | (active_value & 0x7F); } // factor.hpp:419-431
   void reset_active() { for (size_t i = 0; i < active.size(); ++i) active[i] = 0; }
   void set_jacobian_storage(bool on) { store_jacobians = on; } // accepted; Jacobians are always stored here
+  size_t add_factor(const std::array<size_t, N> &ids, const ObservationType &obs) { return add_factor(ids, obs, nullptr, ConstraintDataType(), LossType()); }
+  static constexpr bool use_autodiff() { return std::is_same<typename Traits::Differentiation, DifferentiationMode::Auto>::value; }
+  static constexpr bool supports_dynamic_jacobians() { return !use_autodiff(); }
+  void initialize_device_ids(uint8_t level) { initialize(level); } // factor.hpp:439-470
+  void to_device() {}
+  void initialize_jacobian_storage() {}
+  void compute_jacobians(StreamPool &) { compute_jacobians(); }
   size_t internal_count() const override { return device_obs.size(); }
   size_t active_count() const override { return active_indices.size(); }
   std::array<size_t, N> get_vertex_ids(size_t id) const { std::array<size_t, N> r; for (size_t i = 0; i < N; ++i) r[i] = host_ids[id * N + i]; return r; }

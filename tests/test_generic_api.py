@@ -36,7 +36,8 @@ def hipcc(src, out, *flags):
 def build_all():
     return (hipcc(os.path.join(ROOT, "examples", "circle.hip"), os.path.join(BUILD, "circle")),
             hipcc(os.path.join(ROOT, "examples", "circle.hip"), os.path.join(BUILD, "circle_ad"), "-DCIRCLE_AUTODIFF"),
-            hipcc(os.path.join(ROOT, "tests", "cpp", "test_generic_bal.hip"), os.path.join(BUILD, "test_generic_bal")))
+            hipcc(os.path.join(ROOT, "tests", "cpp", "test_generic_bal.hip"), os.path.join(BUILD, "test_generic_bal")),
+            hipcc(os.path.join(ROOT, "tests", "cpp", "test_generic_known_answers.hip"), os.path.join(BUILD, "test_generic_known_answers")))
 
 
 def test_generic_layer_compiles_for_gfx950():
@@ -51,6 +52,15 @@ def test_circle_example(which):
     print(r.stdout[-2000:], r.stderr[-500:])
     assert r.returncode == 0 and "OK (0 failures)" in r.stdout
     assert "Iteration" in r.stdout and "Lambda" in r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_known_answers_on_the_generic_kernels():
+    """tests/factor.cu / tests/vertex.cu literal expectations (EXPECT_FLOAT_EQ, 4 ULP) on the HIP generic layer."""
+    exe = build_all()[3]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout[-3000:], r.stderr[-500:])
+    assert r.returncode == 0 and "OK (0 failures" in r.stdout
 
 
 def parse_trace(out):
