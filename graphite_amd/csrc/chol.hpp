@@ -55,111 +55,6 @@ template <> __device__ __forceinline__ void load8<float>(const float *p, float (
   for (int i = 0; i < 2; ++i) { const float4 t = q[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
 }
 
-// C = P Q^T  (MODE 0, C overwrites P: the panel solve with Q = Linv_k)
-// C -= P Q^T (MODE 1, the trailing update; P, Q = panel tiles of rows ti, tj)
-// One 128x128 tile of C per workgroup; K = 16 nch (one or two panels) in chunks of 16, double-buffered
-// through LDS.
-// For MODE 1 the accumulators start as C and P is negated on its way into LDS, so the epilogue
-// is a plain store and the C read overlaps the first operand fetch.
-template <typename T, int MODE, int PIN = 0, int KC = CH_KC>
-__global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, const int *__restrict__ tiles, int k0, const T *__restrict__ Linv, int nch) {
-  extern __shared__ __align__(16) unsigned char ch_smem[];
-  T *sm = reinterpret_cast<T *>(ch_smem);
-  using M = MfmaTile<T>;
-  typedef typename M::acc_t acc_t;
-  const int ti = MODE == 0 ? tiles[blockIdx.x] : tiles[2 * blockIdx.x];
-  const int tj = MODE == 0 ? 0 : tiles[2 * blockIdx.x + 1];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-  const T *Pg = A + (size_t)ti * CH_NB * ld + k0;
-  const T *Qg = MODE == 0 ? Linv : A + (size_t)tj * CH_NB * ld + k0;
-  const int ldq = MODE == 0 ? CH_NB : ld;
-  T *Cg = MODE == 0 ? A + (size_t)ti * CH_NB * ld + k0 : A + (size_t)ti * CH_NB * ld + (size_t)tj * CH_NB;
-
-  acc_t acc[4][4];
-  const int ccol = lane & 15;
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (MODE == 1) acc[mi][ni][r] = Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld + wc * 64 + ni * 16 + ccol];
-        else acc[mi][ni][r] = T(0);
-      }
-
-  // loader role: KC / 8 threads per tile row, 8 consecutive k each; NPASS row groups per chunk
-  constexpr int TPR = KC / 8, RPP = 256 / TPR, NPASS = CH_NB / RPP;
-  const int lr = t / TPR, lk = (t % TPR) * 8;
-  T pp[NPASS][8], pq[NPASS][8];
-#pragma unroll
-  for (int u = 0; u < NPASS; ++u) {
-    load8<T>(Pg + (size_t)(lr + u * RPP) * ld + lk, pp[u]);
-    load8<T>(Qg + (size_t)(lr + u * RPP) * ldq + lk, pq[u]);
-  }
-  constexpr int BUF = 2 * KC * CH_LDP;
-  {
-    T *Ps = sm, *Qs = sm + KC * CH_LDP;
-#pragma unroll
-    for (int u = 0; u < NPASS; ++u)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { Ps[(lk + e) * CH_LDP + lr + u * RPP] = MODE == 1 ? -pp[u][e] : pp[u][e]; Qs[(lk + e) * CH_LDP + lr + u * RPP] = pq[u][e]; }
-  }
-  __syncthreads();
-  if (MODE == 1) {
-    // pin the C loads before the loop: otherwise their s_waitcnt lands inside the loop body and, in
-    // steady state, makes every iteration wait for its own operand prefetch half-way through
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        if (PIN == 0) asm volatile("" : "+a"(acc[mi][ni]));
-        else asm volatile("" : "+v"(acc[mi][ni]));
-      }
-  }
-#pragma unroll 1
-  for (int c = 0; c < nch; ++c) {
-    if (c + 1 < nch) {
-#pragma unroll
-      for (int u = 0; u < NPASS; ++u) {
-        load8<T>(Pg + (size_t)(lr + u * RPP) * ld + (c + 1) * KC + lk, pp[u]);
-        load8<T>(Qg + (size_t)(lr + u * RPP) * ldq + (c + 1) * KC + lk, pq[u]);
-      }
-    }
-    const T *Ps = sm + (c & 1) * BUF, *Qs = Ps + KC * CH_LDP;
-#pragma unroll
-    for (int kk = 0; kk < KC / 4; ++kk) {
-      const int krow = (kk * 4 + (lane >> 4)) * CH_LDP + ccol;
-      T a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = Ps[krow + wr * 64 + i * 16]; b[i] = Qs[krow + wc * 64 + i * 16]; }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(a[mi], b[ni], acc[mi][ni]);
-    }
-    if (c + 1 < nch) {
-      T *Pn = sm + ((c + 1) & 1) * BUF, *Qn = Pn + KC * CH_LDP;
-#pragma unroll
-      for (int u = 0; u < NPASS; ++u)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { Pn[(lk + e) * CH_LDP + lr + u * RPP] = MODE == 1 ? -pp[u][e] : pp[u][e]; Qn[(lk + e) * CH_LDP + lr + u * RPP] = pq[u][e]; }
-    }
-    __syncthreads();
-  }
-  // keep the 64 store addresses from being hoisted above the K loop (they would cost 128 VGPRs and
-  // with them the second workgroup per CU that overlaps this epilogue with MFMA work)
-  int ld2 = ld;
-  asm volatile("" : "+v"(ld2));
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld2 + wc * 64 + ni * 16 + ccol] = acc[mi][ni][r];
-}
-constexpr size_t chol_gemm_lds(size_t w, int kc = CH_KC) { return (size_t)2 * 2 * kc * CH_LDP * w; }
-
 template <typename T> __device__ __forceinline__ T lane_bcast(T v, int src);
 template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
@@ -179,20 +74,20 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
 // Writes L back into A (lower part) and X as a full 128x128 row-major matrix (zeros above the
 // diagonal) for the panel GEMM and the solves.  A pivot that is not > 0 raises *fail and is
 // replaced by 1 so that the rest stays finite.
+// `L` is the LDS image [128][129] (+128 for the diagonal of X); with `load` it is filled from the global
+// tile first, otherwise the caller has already put the lower triangle (zeros above) there.
 template <typename T>
-__global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld, int k0, T *__restrict__ Linv, int *__restrict__ fail, int skip = 0) {
-  extern __shared__ __align__(16) unsigned char ch_smem[];
+__device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restrict__ Ag, int ld, T *__restrict__ Linv, int *__restrict__ fail, bool load, int skip) {
   using M = MfmaTile<T>;
   typedef typename M::acc_t acc_t;
-  T *L = reinterpret_cast<T *>(ch_smem); // [128][129]
-  T *xd = L + CH_NB * CH_LP;             // diag of X
+  T *xd = L + CH_NB * CH_LP; // diag of X
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, cl = lane & 15, g = lane >> 4;
   constexpr int NW = CH_PT / 64, NB16 = CH_NB / 16;
-  T *Ag = A + (size_t)k0 * ld + k0;
-  for (int e = t; e < CH_NB * CH_NB; e += CH_PT) {
-    const int r = e >> 7, c = e & 127;
-    L[r * CH_LP + c] = c <= r ? Ag[(size_t)r * ld + c] : T(0);
-  }
+  if (load)
+    for (int e = t; e < CH_NB * CH_NB; e += CH_PT) {
+      const int r = e >> 7, c = e & 127;
+      L[r * CH_LP + c] = c <= r ? Ag[(size_t)r * ld + c] : T(0);
+    }
   __syncthreads();
   for (int s = 0; s < NB16; ++s) {
     const int o = 16 * s;
@@ -296,7 +191,138 @@ __global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld,
     Linv[e] = cc < r ? L[cc * CH_LP + r] : (cc == r ? xd[r] : T(0));
   }
 }
+template <typename T>
+__global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld, int k0, T *__restrict__ Linv, int *__restrict__ fail, int skip = 0) {
+  extern __shared__ __align__(16) unsigned char ch_smem[];
+  chol_potrf_block<T>(reinterpret_cast<T *>(ch_smem), A + (size_t)k0 * ld + k0, ld, Linv, fail, true, skip);
+}
+
 constexpr size_t chol_potrf_lds(size_t w) { return (CH_NB * CH_LP + CH_NB) * w; }
+
+// C = P Q^T  (MODE 0, C overwrites P: the panel solve with Q = Linv_k)
+// C -= P Q^T (MODE 1, the trailing update; P, Q = panel tiles of rows ti, tj)
+// One 128x128 tile of C per workgroup; K = 16 nch (one or two panels) in chunks of 16, double-buffered
+// through LDS.
+// For MODE 1 the accumulators start as C and P is negated on its way into LDS, so the epilogue
+// is a plain store and the C read overlaps the first operand fetch.
+// FUSE (MODE 1 only): workgroup 0's tile is the NEXT diagonal tile; once updated it is factorised on the
+// spot (chol_potrf_block, from its accumulators through LDS) while the other workgroups keep updating,
+// which takes one of the two sequential panel factorisations per 256 columns off the critical path.
+template <typename T, int MODE, int PIN = 0, int KC = CH_KC, bool FUSE = false>
+__global__ __launch_bounds__(256) void k_chol_gemm(T *__restrict__ A, int ld, const int *__restrict__ tiles, int k0, const T *__restrict__ Linv, int nch,
+                                                   T *__restrict__ Linv_next = nullptr, int *__restrict__ fail = nullptr) {
+  extern __shared__ __align__(16) unsigned char ch_smem[];
+  T *sm = reinterpret_cast<T *>(ch_smem);
+  using M = MfmaTile<T>;
+  typedef typename M::acc_t acc_t;
+  const int ti = MODE == 0 ? tiles[blockIdx.x] : tiles[2 * blockIdx.x];
+  const int tj = MODE == 0 ? 0 : tiles[2 * blockIdx.x + 1];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+  const T *Pg = A + (size_t)ti * CH_NB * ld + k0;
+  const T *Qg = MODE == 0 ? Linv : A + (size_t)tj * CH_NB * ld + k0;
+  const int ldq = MODE == 0 ? CH_NB : ld;
+  T *Cg = MODE == 0 ? A + (size_t)ti * CH_NB * ld + k0 : A + (size_t)ti * CH_NB * ld + (size_t)tj * CH_NB;
+
+  acc_t acc[4][4];
+  const int ccol = lane & 15;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (MODE == 1) acc[mi][ni][r] = Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld + wc * 64 + ni * 16 + ccol];
+        else acc[mi][ni][r] = T(0);
+      }
+
+  // loader role: KC / 8 threads per tile row, 8 consecutive k each; NPASS row groups per chunk
+  constexpr int TPR = KC / 8, RPP = 256 / TPR, NPASS = CH_NB / RPP;
+  const int lr = t / TPR, lk = (t % TPR) * 8;
+  T pp[NPASS][8], pq[NPASS][8];
+#pragma unroll
+  for (int u = 0; u < NPASS; ++u) {
+    load8<T>(Pg + (size_t)(lr + u * RPP) * ld + lk, pp[u]);
+    load8<T>(Qg + (size_t)(lr + u * RPP) * ldq + lk, pq[u]);
+  }
+  constexpr int BUF = 2 * KC * CH_LDP;
+  {
+    T *Ps = sm, *Qs = sm + KC * CH_LDP;
+#pragma unroll
+    for (int u = 0; u < NPASS; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { Ps[(lk + e) * CH_LDP + lr + u * RPP] = MODE == 1 ? -pp[u][e] : pp[u][e]; Qs[(lk + e) * CH_LDP + lr + u * RPP] = pq[u][e]; }
+  }
+  __syncthreads();
+  if (MODE == 1) {
+    // pin the C loads before the loop: otherwise their s_waitcnt lands inside the loop body and, in
+    // steady state, makes every iteration wait for its own operand prefetch half-way through
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        if (PIN == 0) asm volatile("" : "+a"(acc[mi][ni]));
+        else asm volatile("" : "+v"(acc[mi][ni]));
+      }
+  }
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) {
+#pragma unroll
+      for (int u = 0; u < NPASS; ++u) {
+        load8<T>(Pg + (size_t)(lr + u * RPP) * ld + (c + 1) * KC + lk, pp[u]);
+        load8<T>(Qg + (size_t)(lr + u * RPP) * ldq + (c + 1) * KC + lk, pq[u]);
+      }
+    }
+    const T *Ps = sm + (c & 1) * BUF, *Qs = Ps + KC * CH_LDP;
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      const int krow = (kk * 4 + (lane >> 4)) * CH_LDP + ccol;
+      T a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = Ps[krow + wr * 64 + i * 16]; b[i] = Qs[krow + wc * 64 + i * 16]; }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(a[mi], b[ni], acc[mi][ni]);
+    }
+    if (c + 1 < nch) {
+      T *Pn = sm + ((c + 1) & 1) * BUF, *Qn = Pn + KC * CH_LDP;
+#pragma unroll
+      for (int u = 0; u < NPASS; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { Pn[(lk + e) * CH_LDP + lr + u * RPP] = MODE == 1 ? -pp[u][e] : pp[u][e]; Qn[(lk + e) * CH_LDP + lr + u * RPP] = pq[u][e]; }
+    }
+    __syncthreads();
+  }
+  // keep the 64 store addresses from being hoisted above the K loop (they would cost 128 VGPRs and
+  // with them the second workgroup per CU that overlaps this epilogue with MFMA work)
+  if (FUSE && blockIdx.x == 0) {
+    // (ti, tj) == the next diagonal tile: lower triangle of the updated tile -> LDS image, then factorise it
+    T *L = sm; // the operand buffers are free: every wave passed the barrier that ends the K loop
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr * 64 + mi * 16 + M::row(lane, r), col = wc * 64 + ni * 16 + ccol;
+          L[row * CH_LP + col] = col <= row ? acc[mi][ni][r] : T(0);
+        }
+    chol_potrf_block<T>(L, Cg, ld, Linv_next, fail, false, 0);
+    return;
+  }
+  int ld2 = ld;
+  asm volatile("" : "+v"(ld2));
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld2 + wc * 64 + ni * 16 + ccol] = acc[mi][ni][r];
+}
+constexpr size_t chol_gemm_lds(size_t w, int kc = CH_KC) { return (size_t)2 * 2 * kc * CH_LDP * w; }
+
 
 // zero the structurally non-zero lower tiles; padded diagonal entries (>= n) become 1
 template <typename T>
@@ -410,11 +436,14 @@ struct CholProfSink {
 //
 // Panels are paired into super-panels (a, b = a + 1): both are factored and solved first (the update
 // of tile column b by panel a is a narrow K = 128 pass), then the trailing matrix is updated ONCE with
-// K = 256, which halves the read-modify-write traffic of the C tiles.  With look-ahead the tiles of
-// the next super-panel's two columns are updated first, and its panel phase then runs on a second
-// stream underneath the rest of the trailing update.
+// K = 256, which halves the read-modify-write traffic of the C tiles.  The first workgroup of that
+// update owns the next diagonal tile and factorises it in place (k_chol_gemm<..., FUSE>) while the
+// other ~7000 tiles are still being updated, so only one of the two panel factorisations per 256
+// columns is on the critical path.  (A two-stream look-ahead of the whole panel phase was tried first:
+// an update workgroup leaves neither the registers nor the LDS for a panel workgroup on the same CU,
+// so nothing overlapped.)
 template <typename T> struct DenseChol {
-  hipStream_t stream = nullptr, side = nullptr;
+  hipStream_t stream = nullptr;
   int n = 0, npad = 0, nt = 0, nsp = 0;
   DevBuf<T> A, Linv, vb, vy, vx, partial;
   DevBuf<int> d_rows, d_pairs, d_nz, d_fail;
@@ -424,8 +453,8 @@ template <typename T> struct DenseChol {
   int64_t total_pairs = 0, total_rows = 0, total_pairs128 = 0;
   int *h_fail = nullptr;
   CholProfSink *sink = nullptr;
-  bool attrs_set = false, lookahead = !(getenv("GR_CHOL_LOOKAHEAD") && atoi(getenv("GR_CHOL_LOOKAHEAD")) == 0);
-  std::vector<hipEvent_t> ev;
+  bool attrs_set = false;
+  bool fuse_potrf = !(getenv("GR_CHOL_FUSE") && atoi(getenv("GR_CHOL_FUSE")) == 0); // A/B knob
   // PIN = 1 keeps the C tile in VGPRs until the loop (one workgroup per CU in fp64): measured 7 % faster in
   // fp64 and on par in fp32 against the AGPR-pinned, two-workgroup variant (A/B in one run, n = 15507)
   int pin_variant = getenv("GR_CHOL_PIN") ? atoi(getenv("GR_CHOL_PIN")) : 1;
@@ -435,8 +464,6 @@ template <typename T> struct DenseChol {
   DenseChol(const DenseChol &) = delete;
   ~DenseChol() {
     if (h_fail) (void)hipHostFree(h_fail);
-    for (auto e : ev) (void)hipEventDestroy(e);
-    if (side) (void)hipStreamDestroy(side);
   }
 
   static size_t bytes_needed(int64_t n_) {
@@ -453,6 +480,7 @@ template <typename T> struct DenseChol {
     row_beg.assign(nt, 0); row_end.assign(nt, 0);
     col_off.assign(nsp + 1, 0); next_off.assign(nsp + 1, 0); rest_off.assign(nsp + 1, 0);
     std::vector<int> col_end(nsp, 0), next_end(nsp, 0);
+    fused_next.assign(nsp, 0);
     max_rows = 0; total_pairs = 0; total_pairs128 = 0;
     std::vector<int> U;
     for (int p = 0; p < nsp; ++p) {
@@ -480,10 +508,13 @@ template <typename T> struct DenseChol {
       col_end[p] = (int)(h_pairs.size() / 2);
       total_pairs128 += col_end[p] - col_off[p];
       next_off[p] = col_end[p];
+      // the tile the next panel factorisation needs, (an, an), leads the list: workgroup 0 of the fused update
+      fused_next[p] = !U.empty() && U[0] == an;
+      if (fused_next[p]) { h_pairs.push_back(an); h_pairs.push_back(an); }
       for (size_t x = 0; x < U.size(); ++x)
         for (size_t y = 0; y <= x; ++y) {
           nz(U[x], U[y]) = 1; // fill-in
-          if (U[y] == an || U[y] == bn) { h_pairs.push_back(U[x]); h_pairs.push_back(U[y]); }
+          if ((U[y] == an || U[y] == bn) && !(fused_next[p] && U[x] == an && U[y] == an)) { h_pairs.push_back(U[x]); h_pairs.push_back(U[y]); }
         }
       next_end[p] = (int)(h_pairs.size() / 2);
       rest_off[p] = next_end[p];
@@ -510,17 +541,13 @@ template <typename T> struct DenseChol {
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_gemm<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_gemm<T, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_potrf<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_potrf_lds(sizeof(T))));
-      GR_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_gemm<T, 1, 1, CH_KC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(chol_gemm_lds(sizeof(T)), chol_potrf_lds(sizeof(T)))));
       attrs_set = true;
-    }
-    while ((int)ev.size() < 2 * nsp + 2) {
-      hipEvent_t e;
-      GR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      ev.push_back(e);
     }
     GR_HIP(hipStreamSynchronize(stream));
   }
   std::vector<int> col_end_, next_end_;
+  std::vector<char> fused_next; // super-panel p's update also factorises diagonal tile 2(p+1)
   int ld() const { return npad; }
   double factor_flops() const { return (total_rows + total_pairs128 + 2.0 * total_pairs) * 2.0 * CH_NB * CH_NB * CH_NB + nt * (2.0 / 3.0) * CH_NB * CH_NB * CH_NB; }
 
@@ -535,11 +562,13 @@ template <typename T> struct DenseChol {
   static constexpr double tile_b() { return (double)CH_NB * CH_NB * sizeof(T); }
   static constexpr double tile_f() { return 2.0 * CH_NB * CH_NB * CH_NB; }
   // panel phase of super-panel p on stream q: potrf(a), solve(a), column b update, potrf(b), solve(b)
-  void panel_phase(int p, hipStream_t q, CholProfSink *sk) {
+  // panel phase of super-panel p: [potrf(a) unless the previous update already did it], solve(a), column b
+  // update, potrf(b), solve(b)
+  void panel_phase(int p, hipStream_t q, CholProfSink *sk, bool a_done) {
     const int a = 2 * p, b = a + 1;
     const size_t lds_g = chol_gemm_lds(sizeof(T)), lds_p = chol_potrf_lds(sizeof(T));
     T *La = Linv.p + (size_t)a * CH_NB * CH_NB, *Lb = La + CH_NB * CH_NB;
-    {
+    if (!a_done) {
       Sc sc(sk, "chol_potrf", 3 * tile_b(), tile_f() / 3);
       k_chol_potrf<T><<<1, CH_PT, lds_p, q>>>(A.p, npad, a * CH_NB, La, d_fail.p, potrf_skip);
     }
@@ -562,36 +591,27 @@ template <typename T> struct DenseChol {
       k_chol_gemm<T, 0><<<nrb, 256, lds_g, q>>>(A.p, npad, d_rows.p + row_beg[b], b * CH_NB, Lb, CH_NB / CH_KC);
     }
   }
-  void update(int p, int beg, int end, hipStream_t q, CholProfSink *sk) {
-    if (end <= beg) return;
+  // trailing update of super-panel p (K = 256); returns true when it also factorised diagonal tile 2(p+1)
+  bool update(int p, hipStream_t q, CholProfSink *sk) {
+    const int beg = next_off[p], end = col_off[p + 1];
+    if (end <= beg) return false;
     const int np_ = end - beg;
-    Sc sc(sk, "chol_syrk", (2.0 * np_ + 2.0 * std::sqrt(2.0 * np_)) * tile_b(), 2.0 * np_ * tile_f());
-    if (pin_variant) k_chol_gemm<T, 1, 1><<<np_, 256, chol_gemm_lds(sizeof(T)), q>>>(A.p, npad, d_pairs.p + 2 * (size_t)beg, 2 * p * CH_NB, nullptr, 2 * CH_NB / CH_KC);
-    else k_chol_gemm<T, 1><<<np_, 256, chol_gemm_lds(sizeof(T)), q>>>(A.p, npad, d_pairs.p + 2 * (size_t)beg, 2 * p * CH_NB, nullptr, 2 * CH_NB / CH_KC);
+    const bool fuse = fuse_potrf && fused_next[p];
+    Sc sc(sk, "chol_syrk", (2.0 * np_ + 2.0 * std::sqrt(2.0 * np_)) * tile_b(), 2.0 * np_ * tile_f() + (fuse ? tile_f() / 3 : 0.0));
+    const int *pairs = d_pairs.p + 2 * (size_t)beg;
+    if (fuse) {
+      const size_t lds = std::max(chol_gemm_lds(sizeof(T)), chol_potrf_lds(sizeof(T)));
+      k_chol_gemm<T, 1, 1, CH_KC, true><<<np_, 256, lds, q>>>(A.p, npad, pairs, 2 * p * CH_NB, nullptr, 2 * CH_NB / CH_KC, Linv.p + (size_t)(2 * p + 2) * CH_NB * CH_NB, d_fail.p);
+    } else if (pin_variant) k_chol_gemm<T, 1, 1><<<np_, 256, chol_gemm_lds(sizeof(T)), q>>>(A.p, npad, pairs, 2 * p * CH_NB, nullptr, 2 * CH_NB / CH_KC);
+    else k_chol_gemm<T, 1><<<np_, 256, chol_gemm_lds(sizeof(T)), q>>>(A.p, npad, pairs, 2 * p * CH_NB, nullptr, 2 * CH_NB / CH_KC);
+    return fuse;
   }
   void factor() {
     GR_HIP(hipMemsetAsync(d_fail.p, 0, sizeof(int), stream));
-    const bool la = lookahead && !sink && nsp > 2;
-    if (!la) {
-      for (int p = 0; p < nsp; ++p) {
-        panel_phase(p, stream, sink);
-        update(p, next_off[p], col_off[p + 1], stream, sink);
-      }
-      return;
-    }
-    // main stream: update-next(p) -> E1(p) -> update-rest(p) -> wait E2(p+1) -> ...
-    // side stream: wait E1(p) -> panel phase(p+1) -> E2(p+1)
-    panel_phase(0, stream, nullptr);
+    bool a_done = false;
     for (int p = 0; p < nsp; ++p) {
-      update(p, next_off[p], rest_off[p], stream, nullptr);
-      if (p + 1 < nsp) {
-        GR_HIP(hipEventRecord(ev[2 * p], stream));
-        GR_HIP(hipStreamWaitEvent(side, ev[2 * p], 0));
-        panel_phase(p + 1, side, nullptr);
-        GR_HIP(hipEventRecord(ev[2 * p + 1], side));
-      }
-      update(p, rest_off[p], col_off[p + 1], stream, nullptr);
-      if (p + 1 < nsp) GR_HIP(hipStreamWaitEvent(stream, ev[2 * p + 1], 0));
+      panel_phase(p, stream, sink, a_done);
+      a_done = update(p, stream, sink);
     }
   }
   // b, x: device vectors of length n (x may alias b)

@@ -2,7 +2,6 @@
 # MFMA-utilisation counters of the Cholesky GEMM kernels (on the GPU box): tools/pmc_chol.sh TAG n
 TAG=$1; shift
 export TMPDIR=/tmp
-export GR_CHOL_LOOKAHEAD=0
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_chol_$TAG -o p -- python3 tools/chol_bench.py "$@" > gpurun_out/pmc_chol_$TAG.log 2>&1
 find gpurun_out/pmc_chol_$TAG -name "*counter_collection.csv" -exec cp {} gpurun_out/pmc_chol_$TAG.csv \;
 rm -rf gpurun_out/pmc_chol_$TAG
