@@ -598,11 +598,14 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   // SchurComplement::update_values (schur.hpp:227-235)
-  void schur_update_values() override {
+  void schur_update_values() override { schur_update_values_impl(false); }
+  // for_solve: the PCG scalars are reset by the first kernel and b_S is left to k_schur_pcg_prepare
+  void schur_update_values_impl(bool for_solve) {
     build_schur_structure();
     if (!hcp_valid) linearize_impl(true);
     const int ui = damping_identity ? 1 : 0;
-    k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p);
+    if (for_solve) k_point_prepare<T><<<cdiv(Np, TPB) + 1, TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, scalars(), sc_cap);
+    else k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p);
     if (nmulti) k_schur_multi<T, 0><<<cdiv(9 * (size_t)nmulti, TPB), TPB, 0, stream>>>(nmulti, multi_blk.p, S_rowi.p, S_coli.p, Hcc.p, scales.p, damping, ui, S.p);
     {
       Scope sc(this, "schur_products", nprod * (54.0 * w() + 8) + 9.0 * Np * w() + 81.0 * nnzb * w(), nprod * 342.0);
@@ -613,7 +616,7 @@ template <typename T> struct Engine final : EngineBase {
       Scope sc(this, "b_schur", No * (27.0 * w() + 8) + 3.0 * Np * w(), No * 54.0);
       k_bschur_partial<T><<<cdiv(nch, 4), TPB, 0, stream>>>(nch, chunk_beg.p, pt_cm.p, pos_cm.p, Hcp.p, vl.p, part9.p);
     }
-    k_bschur_finalize<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p);
+    if (!for_solve) k_bschur_finalize<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p);
   }
   void schur_matvec_dev(const T *x, T *y, int k) {
     Scope sc(this, "schur_matvec", (2.0 * nnzb - Nc) * 81.0 * w(), (2.0 * nnzb - Nc) * 162.0);
@@ -671,14 +674,13 @@ template <typename T> struct Engine final : EngineBase {
     }
   }
   int solve_pcg_schur(int max_iter, double tol, double rej, T *x) {
-    schur_update_values();
-    k_inv9<T, 0><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, S.p, S_diag.p, nullptr, 0.0, 0, MinvS.p, nullptr);
+    build_schur_structure();
     ensure_scalars(max_iter);
     PcgScalars sc = scalars();
     for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
     h_seq[1] = 0;
-    k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
-    k_pcgs_init<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, nullptr, nullptr, sc);
+    schur_update_values_impl(true);
+    k_schur_pcg_prepare<T, 0><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, S.p, S_diag.p, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, nullptr, sc);
     const int noop = run_pcg_iterations(max_iter, [&](int k) {
       schur_matvec_dev(v_p.p, v_Ap.p, k);
       k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k);
@@ -741,7 +743,9 @@ template <typename T> struct Engine final : EngineBase {
   void solve_pcg_schur_implicit(int max_iter, double tol, double rej, T *x) {
     ensure_implicit_schur();
     const int ui = damping_identity ? 1 : 0;
-    k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p);
+    ensure_scalars(max_iter);
+    PcgScalars sc = scalars();
+    k_point_prepare<T><<<cdiv(Np, TPB) + 1, TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, sc, sc_cap);
     {
       Scope s0(this, "is_prepare", No * (2 * w() + 12.0) + (24.0 * Nc + 15.0 * Np) * w() + 54.0 * nseg * w(), No * 700.0);
       if (jac32) { k_is_prepare<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); } else { k_is_prepare<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); }
@@ -753,13 +757,9 @@ template <typename T> struct Engine final : EngineBase {
       k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p, is_raw.p, nullptr);
     } else
       k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p);
-    k_inv9<T, 2><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Sdiag.p, nullptr, nullptr, 0.0, 0, MinvS.p, nullptr);
-    ensure_scalars(max_iter);
-    PcgScalars sc = scalars();
     for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
     h_seq[1] = 0;
-    k_pcg_scalars_init<<<1, TPB, 0, stream>>>(sc, sc_cap);
-    k_pcgs_init<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, v_q.p, scales.p, sc);
+    k_schur_pcg_prepare<T, 2><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Sdiag.p, nullptr, nullptr, nullptr, nullptr, scales.p, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, v_q.p, sc);
     const double pass_bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np + 9.0 * Nc) * w() + 3.0 * No * w();
     const int noop = run_pcg_iterations(max_iter, [&](int k) {
       {

@@ -105,13 +105,37 @@ __global__ void k_export_blocks(size_t nblocks, int rows, int cols, const T *__r
 // Schur path (PCGSchurSolver)
 // ===========================================================================
 
+// ---------------------------------------------------------------------------
+// PCG scalars never visit the host.  Iteration k owns slot k of every array:
+//   rz[k]  (NS partials) r.z at the start of iteration k (slot 0 filled by the init kernel)
+//   den[k] (NS partials) p.Ap of iteration k
+//   rr[k]  (NS partials) r.r (matrix-free variant only), pdp[k]: p.D.p
+//   rz0[k] running min of |rz_new| before iteration k (inf at k = 0); done[k] loop left before k
+// Kernels of iteration k only READ slots written by earlier launches and accumulate
+// into slot k / k+1, so there are no intra-launch races.
+struct PcgScalars {
+  double *rz, *den, *rr, *pdp; // [cap][NS]
+  double *rz0;                 // [cap]
+  int *done, *iters;           // [cap], [1]
+  volatile int *hflag;         // pinned host memory [cap]: 1 = iteration finished, 2 = loop left (may be null)
+  volatile int *hiters;        // pinned host mirror of iters (may be null)
+};
+
+
 // Per point: scaled + damped Hll, its inverse (scaled space, kept for
 // back-substitution and parity), M' = Dp Hll^-1 Dp and v = M' bl^u.
 // (schur.hpp:1067-1114 batched inverse; hessian.hpp:136-176 damping)
 template <typename T>
 __global__ void k_point_prepare(int Np, int Nc, const T *__restrict__ Hll, const T *__restrict__ bl,
                                 const T *__restrict__ scales, double mu, int use_identity,
-                                T *__restrict__ Hll_inv, T *__restrict__ Mp, T *__restrict__ vl) {
+                                T *__restrict__ Hll_inv, T *__restrict__ Mp, T *__restrict__ vl,
+                                PcgScalars pcg = PcgScalars{}, int cap = 0) {
+  if (pcg.rz && blockIdx.x == gridDim.x - 1) { // one extra block: reset of the PCG scalars of the solve that follows
+    for (int i = threadIdx.x; i < cap * NS; i += blockDim.x) { pcg.rz[i] = 0.0; pcg.den[i] = 0.0; pcg.rr[i] = 0.0; pcg.pdp[i] = 0.0; }
+    for (int i = threadIdx.x; i < cap; i += blockDim.x) { pcg.done[i] = 0; pcg.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
+    if (threadIdx.x == 0) pcg.iters[0] = 0;
+    return;
+  }
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= Np) return;
   const T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
@@ -331,87 +355,6 @@ __global__ void k_backsub_fixup(int Np, int Nc, const T *__restrict__ Hll_inv, c
   for (int r = 0; r < 3; ++r) xl[3 * (size_t)l + r] = inv[r] * r0 + inv[r + 3] * r1 + inv[r + 6] * r2;
 }
 
-// Inverse of the 9x9 diagonal blocks (block-Jacobi of S, block_jacobi_schur.hpp:114-150;
-// or of damped D Hcc^u D for the matrix-free PCG, block_jacobi.hpp:120-172).
-// MODE 0: src = S blocks via diag index (MODE 2: src[c] directly).  MODE 1: src = Hcc^u, scaled + damped here;
-// also writes the clamped scalar diagonal used by the operator damping (pcg.hpp:93-103).
-template <typename T, int MODE>
-__global__ void __launch_bounds__(64) k_inv9(int Nc, const T *__restrict__ src, const int *__restrict__ diag_blk,
-                                             const T *__restrict__ scales, double mu, int use_identity,
-                                             T *__restrict__ Minv, T *__restrict__ diag_clamped) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Nc) return;
-  double A[81];
-  if (MODE == 0 || MODE == 2) {
-    const T *B = src + 81 * (size_t)(MODE == 0 ? diag_blk[c] : c);
-#pragma unroll
-    for (int i = 0; i < 81; ++i) A[i] = (double)B[i];
-  } else {
-    const T *B = src + 81 * (size_t)c;
-    const T *s = scales + 9 * (size_t)c;
-#pragma unroll
-    for (int col = 0; col < 9; ++col)
-#pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        const T v = s[r] * B[r + 9 * col] * s[col];
-        if (r == col) {
-          A[r + 9 * col] = (double)damp_diag(v, mu, use_identity);
-          diag_clamped[9 * (size_t)c + r] = (T)clampd((double)v, 1.0e-6, 1.0e32);
-        } else A[r + 9 * col] = (double)v;
-      }
-  }
-  spd_inverse<9>(A);
-#pragma unroll
-  for (int i = 0; i < 81; ++i) Minv[81 * (size_t)c + i] = (T)A[i];
-}
-
-// 3x3 point blocks of the matrix-free block-Jacobi (block_jacobi.hpp:120-172)
-template <typename T>
-__global__ void k_inv3_points(int Np, int Nc, const T *__restrict__ Hll, const T *__restrict__ scales,
-                              double mu, int use_identity, T *__restrict__ Minv,
-                              T *__restrict__ diag_clamped) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= Np) return;
-  const T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
-  const T *H = Hll + 9 * (size_t)l;
-  double A[9];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const T v = s[r] * H[r + 3 * c] * s[c];
-      if (r == c) {
-        A[r + 3 * c] = (double)damp_diag(v, mu, use_identity);
-        diag_clamped[9 * (size_t)Nc + 3 * (size_t)l + r] = (T)clampd((double)v, 1.0e-6, 1.0e32);
-      } else A[r + 3 * c] = (double)v;
-    }
-  spd_inverse<3>(A);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) Minv[9 * (size_t)l + i] = (T)A[i];
-}
-
-// ---------------------------------------------------------------------------
-// PCG scalars never visit the host.  Iteration k owns slot k of every array:
-//   rz[k]  (NS partials) r.z at the start of iteration k (slot 0 filled by the init kernel)
-//   den[k] (NS partials) p.Ap of iteration k
-//   rr[k]  (NS partials) r.r (matrix-free variant only), pdp[k]: p.D.p
-//   rz0[k] running min of |rz_new| before iteration k (inf at k = 0); done[k] loop left before k
-// Kernels of iteration k only READ slots written by earlier launches and accumulate
-// into slot k / k+1, so there are no intra-launch races.
-struct PcgScalars {
-  double *rz, *den, *rr, *pdp; // [cap][NS]
-  double *rz0;                 // [cap]
-  int *done, *iters;           // [cap], [1]
-  volatile int *hflag;         // pinned host memory [cap]: 1 = iteration finished, 2 = loop left (may be null)
-  volatile int *hiters;        // pinned host mirror of iters (may be null)
-};
-
-// zero all slots, rz0[0] = +inf
-__global__ void k_pcg_scalars_init(PcgScalars sc, int cap) {
-  for (int i = threadIdx.x; i < cap * NS; i += blockDim.x) { sc.rz[i] = 0.0; sc.den[i] = 0.0; sc.rr[i] = 0.0; sc.pdp[i] = 0.0; }
-  for (int i = threadIdx.x; i < cap; i += blockDim.x) { sc.done[i] = 0; sc.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
-  if (threadIdx.x == 0) sc.iters[0] = 0;
-}
 
 // ===========================================================================
 // PCG on the explicit Schur complement (solver/pcg_schur.hpp:79-168)
@@ -463,33 +406,53 @@ k_schur_matvec(int Nc, const int *__restrict__ row_ptr, const int *__restrict__ 
   }
 }
 
-// init: r = b_S, z = Minv r, p = z, x = 0, rz[0] = r.z (pcg_schur.hpp:93-105).
-// 252 scalars (28 cameras) per block.
-template <typename T>
-__global__ void __launch_bounds__(TPB)
-k_pcgs_init(int Nc, const T *__restrict__ b, const T *__restrict__ Minv, T *__restrict__ r,
-            T *__restrict__ z, T *__restrict__ p, T *__restrict__ x, T *__restrict__ q,
-            const T *__restrict__ scales, PcgScalars sc) {
-  __shared__ double red[4];
-  __shared__ T rs[TPB];
-  const unsigned t = blockIdx.x * 252u + threadIdx.x;
-  const bool on = threadIdx.x < 252 && t < 9u * (unsigned)Nc;
-  const T bv = on ? b[t] : T(0);
-  rs[threadIdx.x] = bv;
-  __syncthreads();
+
+// One launch, thread per camera, for everything between "S is complete" and the first iteration:
+//   MODE 0: b_S = Dc (bc^u - chunk partials) (schur.hpp:901-920), M = (S diagonal block)^-1
+//   MODE 2: b_S given (implicit Schur), M = Sdiag_c^-1
+// then r = b_S, z = p = M r, x = 0, q = s .* p (implicit only), rz[0] += r.z
+// (block_jacobi_schur.hpp:114-178, pcg_schur.hpp:79-104).  The PCG scalars were reset by k_point_prepare.
+template <typename T, int MODE>
+__global__ void __launch_bounds__(64)
+k_schur_pcg_prepare(int Nc, const T *__restrict__ Ssrc, const int *__restrict__ diag_blk,
+                    const int *__restrict__ cam_chunk_ptr, const T *__restrict__ partial9, const T *__restrict__ bc,
+                    const T *__restrict__ scales, T *__restrict__ b_schur, T *__restrict__ Minv, T *__restrict__ r,
+                    T *__restrict__ z, T *__restrict__ p, T *__restrict__ x, T *__restrict__ q, PcgScalars sc) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
   double part = 0;
-  if (on) {
-    const T *M = Minv + 81 * (size_t)(t / 9u);
-    const int row = (int)(t % 9u);
-    const T *rc = rs + (threadIdx.x / 9) * 9;
-    T s = 0;
+  if (c < Nc) {
+    T b[9];
+    if (MODE == 0) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) s += M[row + 9 * q] * rc[q];
-    r[t] = bv; z[t] = s; p[t] = s; x[t] = T(0);
-    if (q) q[t] = scales[t] * s;
-    part = (double)(bv * s);
+      for (int i = 0; i < 9; ++i) b[i] = T(0);
+      for (int ch = cam_chunk_ptr[c]; ch < cam_chunk_ptr[c + 1]; ++ch)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) b[i] += partial9[9 * (size_t)ch + i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { b[i] = scales[9 * (size_t)c + i] * (bc[9 * (size_t)c + i] - b[i]); b_schur[9 * (size_t)c + i] = b[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) b[i] = b_schur[9 * (size_t)c + i];
+    }
+    double A[81];
+    const T *B = Ssrc + 81 * (size_t)(MODE == 0 ? diag_blk[c] : c);
+#pragma unroll
+    for (int i = 0; i < 81; ++i) A[i] = (double)B[i];
+    spd_inverse<9>(A);
+#pragma unroll
+    for (int row = 0; row < 9; ++row) {
+      T s = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s += (T)A[row + 9 * k] * b[k];
+      const size_t t = 9 * (size_t)c + row;
+      r[t] = b[row]; z[t] = s; p[t] = s; x[t] = T(0);
+      if (q) q[t] = scales[t] * s;
+      part += (double)(b[row] * s);
+    }
+#pragma unroll
+    for (int i = 0; i < 81; ++i) Minv[81 * (size_t)c + i] = (T)A[i];
   }
-  part = block_sum_256(part, red);
+  part = wave_sum(part);
   if (threadIdx.x == 0) slot_add(sc.rz, 0, part);
 }
 

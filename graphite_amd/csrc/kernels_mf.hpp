@@ -356,7 +356,7 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
     for (int k = threadIdx.x; k < n_partials; k += TPB) s += chi2_partial[k];
     s = block_sum_256(s, red);
     // speculative LM step: the trial chi2 is this linearisation's chi2; the rho denominator was left
-    // as block partials by k_rho_denominator; both are mirrored to pinned host memory, then `seq`
+    // as block partials by k_apply_update_rho; both are mirrored to pinned host memory, then `seq`
     double r = 0;
     for (int k = threadIdx.x; k < n_rho; k += TPB) r += rho_partial[k];
     r = block_sum_256(r, red);
@@ -372,21 +372,6 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
   }
 }
 
-// compute_rho denominator sum dx (mu dx + b) (levenberg_marquardt.hpp:34-41) as fixed-order block
-// partials; must run BEFORE the speculative linearisation overwrites b and the column scales.
-template <typename T>
-__global__ void __launch_bounds__(TPB)
-k_rho_denominator(unsigned n, unsigned pose_dim, int cam_weight, const T *__restrict__ dx, const T *__restrict__ bu,
-                  const T *__restrict__ scales, double mu, double *__restrict__ rho_partial) {
-  __shared__ double red[4];
-  double rho = 0;
-  for (unsigned i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-    const T x = dx[i];
-    if (i >= pose_dim || cam_weight) rho += (double)(x * ((T)mu * x + scales[i] * bu[i]));
-  }
-  rho = block_sum_256(rho, red);
-  if (threadIdx.x == 0) rho_partial[blockIdx.x] = rho;
-}
 
 // Multi-GPU: camera column scales from the all-reduced Hcc diagonal (graph.hpp:262-270)
 template <typename T>
