@@ -27,6 +27,9 @@ namespace gr {
 #ifndef OP_WAVES
 #define OP_WAVES 4
 #endif
+#ifndef OP_SGPR
+#define OP_SGPR 1
+#endif
 
 constexpr int TICKET_GROUPS = 64;
 
@@ -465,6 +468,49 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     const int jn = j + TPB;
     const bool validn = (t + 1 < t1) && jn < No;
     if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm[jn]; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
+#if OP_SGPR
+    // Wave-uniform camera data (24-scalar pack, 9 direction scalars, segment id) are fetched per DISTINCT
+    // camera of the wave through a uniform index, i.e. with scalar loads into SGPRs: the kernel keeps its
+    // VGPRs for the per-observation state and more waves fit per SIMD.  Almost every wave has one camera.
+    const size_t lp = (size_t)(valid ? l : 0);
+    const T X = pts[3 * lp], Y = pts[3 * lp + 1], Z = pts[3 * lp + 2];
+    const T *pl = ps + pose_dim + 3 * lp;
+    const T pl0 = pl[0], pl1 = pl[1], pl2 = pl[2];
+    unsigned long long remaining = __ballot(valid);
+    while (remaining) {
+      const int leader = __builtin_ctzll(remaining);
+      const int cl = __builtin_amdgcn_readfirstlane(__shfl(c, leader, 64));
+      const bool mine = valid && c == cl;
+      const int segl = cam_seg_ptr[cl] + (__builtin_amdgcn_readfirstlane(__shfl(j, leader, 64) >> 6) - (cam_ptr[cl] >> 6));
+      T pk[PACK], pc[9];
+      load_pack(pack, cl, pk);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pc[i] = ps[9 * (size_t)cl + i];
+      T e0, e1, Jc[18], Jp[6];
+      bal_linearize_j<T, JT>(pk, X, Y, Z, o.x, o.y, e0, e1, Jc, Jp);
+      const T w = mine ? loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1) : T(0);
+      T u0 = Jp[0] * pl0 + Jp[2] * pl1 + Jp[4] * pl2;
+      T u1 = Jp[1] * pl0 + Jp[3] * pl1 + Jp[5] * pl2;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { u0 += Jc[2 * i] * pc[i]; u1 += Jc[2 * i + 1] * pc[i]; }
+      if (mine) den += (double)(w * (u0 * u0 + u1 * u1));
+      u0 *= w; u1 *= w;
+      T m[16];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) m[i] = mine ? Jc[2 * i] * u0 + Jc[2 * i + 1] * u1 : T(0);
+#pragma unroll
+      for (int i = 9; i < 16; ++i) m[i] = T(0);
+      if (mine) {
+        T *g = g3 + 3 * a;
+        g[0] = Jp[0] * u0 + Jp[1] * u1;
+        g[1] = Jp[2] * u0 + Jp[3] * u1;
+        g[2] = Jp[4] * u0 + Jp[5] * u1;
+      }
+      const T tot = wave_transpose_sum<T, 16>(m, lane);
+      if ((lane & 3) == 0 && (lane >> 2) < 9) op_partial[9 * (size_t)segl + (lane >> 2)] = tot;
+      remaining &= ~__ballot(mine);
+    }
+#else
     int seg = 0;
     T acc[16];
 #pragma unroll
@@ -515,6 +561,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
         remaining &= ~__ballot(mine);
       }
     }
+#endif
     valid = validn;
     j = jn;
   }

