@@ -195,7 +195,7 @@ template <typename T> struct Engine final : EngineBase {
     grid_partial.alloc(2 * (size_t)std::max(cdiv(std::max<size_t>(No, n), TPB), cdiv(n, 252) + cdiv(Np, TPB)) + 64);
     pcg_iters.alloc(1);
     alloc_pinned(64);
-    g9.alloc(9 * (size_t)No); g3.alloc(3 * (size_t)No);
+    g9.alloc(8 * (size_t)No); g3.alloc(3 * (size_t)No);
     v_dx.alloc(n);
     tmp.alloc(std::max<size_t>(n, 27 * (size_t)No));
     GR_HIP(hipStreamSynchronize(stream));
@@ -469,7 +469,7 @@ template <typename T> struct Engine final : EngineBase {
     if (!pack_valid) campack();
     {
       // algorithmic bytes: every array touched once (obs, 3 index streams, points, packs, g9 out, partials, Hcp)
-      const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 9.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
+      const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
       Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)));
       if (write_hcp) {
         if (jac32) { k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); } else { k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); }
@@ -478,7 +478,7 @@ template <typename T> struct Engine final : EngineBase {
     }
       }
     {
-      Scope sc(this, "linearize_finalize", 9.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
+      Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
       k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
                                                                                                     spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq);
     }

@@ -209,7 +209,7 @@ __device__ __forceinline__ bool grid_sum2(double v0, double v1, double *partial,
 // ---------------------------------------------------------------------------
 // Graph::linearize + Hessian::update_values (A4-A10 of SURVEY §8a), one launch.
 //   camera side : 45 + 9 sums per (wave, camera) segment -> cam_partial[seg][54]
-//   point side  : per-observation [w Jp^T Jp (6), -w Jp^T e (3)] -> g9[pm position][9]
+//   point side  : per-observation sqrt(w) [Jp (6), e (2)]        -> g9[pm position][8]
 //   Hcp^u       : per-observation 9x3 block -> Hcp[pm position][27]  (Schur solvers only)
 //   chi2        : block partial (summed in fixed order by k_linearize_finalize)
 // Persistent form: gridDim.x = min(ntiles, CUs x 4) blocks, each walks a CONTIGUOUS range of
@@ -254,16 +254,18 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
       w = loss_drho(loss_kind, loss_delta, raw);
       chi2 += (double)loss_rho(loss_kind, loss_delta, raw);
       const T wp0x = w * Jp[0], wp0y = w * Jp[1], wp1x = w * Jp[2], wp1y = w * Jp[3], wp2x = w * Jp[4], wp2y = w * Jp[5];
-      T *g = g9 + 9 * a;
-      g[0] = wp0x * Jp[0] + wp0y * Jp[1];
-      g[1] = wp0x * Jp[2] + wp0y * Jp[3];
-      g[2] = wp0x * Jp[4] + wp0y * Jp[5];
-      g[3] = wp1x * Jp[2] + wp1y * Jp[3];
-      g[4] = wp1x * Jp[4] + wp1y * Jp[5];
-      g[5] = wp2x * Jp[4] + wp2y * Jp[5];
-      g[6] = -(wp0x * e0 + wp0y * e1);
-      g[7] = -(wp1x * e0 + wp1y * e1);
-      g[8] = -(wp2x * e0 + wp2y * e1);
+      // point-side record: sqrt(w) [Jp (6), e (2)] = 8 scalars = one aligned 64-byte (fp64) / 32-byte (fp32)
+      // sector per observation, written with vector stores; the per-point kernel forms Jp^T Jp and Jp^T e
+      // from it.  (The 9-scalar [w Jp^T Jp, -w Jp^T e] record it replaces straddled sectors: 72 MB of HBM
+      // writes for 49 MB of payload on Ladybug-1723.)
+      {
+        const T sw = t_sqrt(w);
+        V2 *g = reinterpret_cast<V2 *>(g9 + 8 * a);
+        V2 q0, q1, q2, q3;
+        q0.x = sw * Jp[0]; q0.y = sw * Jp[1]; q1.x = sw * Jp[2]; q1.y = sw * Jp[3];
+        q2.x = sw * Jp[4]; q2.y = sw * Jp[5]; q3.x = sw * e0; q3.y = sw * e1;
+        g[0] = q0; g[1] = q1; g[2] = q2; g[3] = q3;
+      }
       if (WRITE_HCP) {
         T *h = Hcp + 27 * a;
 #pragma unroll
@@ -306,7 +308,7 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
 
 // Finalise a linearisation:
 //   threads [0, 90 Nc)        fixed-order sum of the segment partials -> Hcc^u, bc^u, camera scales
-//   threads [90 Nc, +Np)      one per point: sum of its observations' g9 -> Hll^u, bl^u, point scales
+//   threads [90 Nc, +Np)      one per point: sum over its observations' records of Jp^T Jp, -Jp^T e -> Hll^u, bl^u, point scales
 //   block 0                   chi2 total
 // (column scales: graph.hpp:254-270)
 template <typename T>
@@ -340,10 +342,19 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
     T v[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) v[i] = T(0);
+    using V2 = typename Vec2T<T>::type;
     for (int a = pt_ptr[l]; a < pt_ptr[l + 1]; ++a) {
-      const T *g = g9 + 9 * (size_t)a;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) v[i] += g[i];
+      const V2 *g = reinterpret_cast<const V2 *>(g9 + 8 * (size_t)a);
+      const V2 c0 = g[0], c1 = g[1], c2 = g[2], e = g[3]; // sqrt(w) Jp columns, sqrt(w) e
+      v[0] += c0.x * c0.x + c0.y * c0.y;
+      v[1] += c0.x * c1.x + c0.y * c1.y;
+      v[2] += c0.x * c2.x + c0.y * c2.y;
+      v[3] += c1.x * c1.x + c1.y * c1.y;
+      v[4] += c1.x * c2.x + c1.y * c2.y;
+      v[5] += c2.x * c2.x + c2.y * c2.y;
+      v[6] -= c0.x * e.x + c0.y * e.y;
+      v[7] -= c1.x * e.x + c1.y * e.y;
+      v[8] -= c2.x * e.x + c2.y * e.y;
     }
     T *H = Hll + 9 * (size_t)l;
     H[0] = v[0]; H[1] = v[1]; H[2] = v[2]; H[3] = v[1]; H[4] = v[3]; H[5] = v[4]; H[6] = v[2]; H[7] = v[4]; H[8] = v[5];
