@@ -105,14 +105,39 @@ template <typename T, int NV> __device__ __forceinline__ void seg_scan(T (&v)[NV
 // other half to its partner (lane ^ offset).  On return lane L holds the wave total of
 // value index (NV == 64 ? L : L >> 2).  Template recursion keeps every array index a
 // compile-time constant (the array must stay in VGPRs).
+// gfx950 half / row exchanges: v_permlane32_swap swaps lanes 32-63 of `a` with lanes 0-31 of `b`,
+// v_permlane16_swap the odd 16-lane rows of `a` with the even rows of `b`.  After the swap every lane
+// holds (its kept value, its partner's copy of the same value) in (a, b) or (b, a): the transpose step is
+// the swap plus one add, without the two selects and the crossbar shuffle of the generic form.
+template <int OFFSET> __device__ __forceinline__ void lane_swap(unsigned &a, unsigned &b) {
+  if constexpr (OFFSET == 32) { const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r[0]; b = r[1]; }
+  else { const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r[0]; b = r[1]; }
+}
+template <int OFFSET> __device__ __forceinline__ float swap_add(float a, float b) {
+  unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+  lane_swap<OFFSET>(ua, ub);
+  return __builtin_bit_cast(float, ua) + __builtin_bit_cast(float, ub);
+}
+template <int OFFSET> __device__ __forceinline__ double swap_add(double a, double b) {
+  uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  lane_swap<OFFSET>(ua.x, ub.x);
+  lane_swap<OFFSET>(ua.y, ub.y);
+  return __builtin_bit_cast(double, ua) + __builtin_bit_cast(double, ub);
+}
+
 template <typename T, int NV, int HALF, int OFFSET> struct TransposeStep {
   static __device__ __forceinline__ void run(T (&v)[NV], int lane) {
-    const bool hi = (lane & OFFSET) != 0;
+    if constexpr (OFFSET == 32 || OFFSET == 16) {
 #pragma unroll
-    for (int i = 0; i < HALF; ++i) {
-      const T keep = hi ? v[i + HALF] : v[i];
-      const T send = hi ? v[i] : v[i + HALF];
-      v[i] = keep + __shfl_xor(send, OFFSET, 64);
+      for (int i = 0; i < HALF; ++i) v[i] = swap_add<OFFSET>(v[i], v[i + HALF]);
+    } else {
+      const bool hi = (lane & OFFSET) != 0;
+#pragma unroll
+      for (int i = 0; i < HALF; ++i) {
+        const T keep = hi ? v[i + HALF] : v[i];
+        const T send = hi ? v[i] : v[i + HALF];
+        v[i] = keep + __shfl_xor(send, OFFSET, 64);
+      }
     }
     TransposeStep<T, NV, HALF / 2, OFFSET / 2>::run(v, lane);
   }

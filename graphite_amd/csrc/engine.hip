@@ -870,7 +870,14 @@ template <typename T> struct Engine final : EngineBase {
         GR_OP(0);
 #endif
         break;
-      case 1: k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); break;
+      case 1:
+#ifdef GR_DIAG
+#define GR_LIN(V) k_linearize<T, false, T, V><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p)
+        switch (variant) { case 1: GR_LIN(1); break; case 2: GR_LIN(2); break; case 3: GR_LIN(3); break; case 4: GR_LIN(4); break; case 7: GR_LIN(7); break; case 8: GR_LIN(8); break; case 15: GR_LIN(15); break; default: GR_LIN(0); }
+#else
+        k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
+#endif
+        break;
       case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
       case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0); break;
       case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30); break;

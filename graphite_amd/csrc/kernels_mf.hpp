@@ -216,7 +216,8 @@ __device__ __forceinline__ bool grid_sum2(double v0, double v1, double *partial,
 // 256-observation tiles and prefetches the next tile's index streams before it computes the
 // current one, so the per-block fixed costs (launch, tail, chi2 partial) are amortised and the
 // index -> gather dependency is off the critical path.
-template <typename T, bool WRITE_HCP, typename JT = T>
+// LV (diagnostic builds only, GR_DIAG): 1 no point-record write, 2 no camera reduction, 4 no point gather, 8 no Jacobian math
+template <typename T, bool WRITE_HCP, typename JT = T, int LV = 0>
 __global__ void __launch_bounds__(TPB, LIN_WAVES)
 k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
             const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
@@ -249,7 +250,15 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
       seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
       T pk[PACK], Jp[6];
       load_pack(pack, c, pk);
-      bal_linearize_j<T, JT>(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], o.x, o.y, e0, e1, Jc, Jp);
+      const size_t lp = (LV & 4) ? (size_t)(j & 1023) : (size_t)l;
+      if (LV & 8) {
+        e0 = o.x; e1 = o.y;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) Jc[i] = pts[3 * lp + (i % 3)] + pk[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Jp[i] = pts[3 * lp + (i % 3)] - pk[i];
+      } else
+        bal_linearize_j<T, JT>(pk, pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2], o.x, o.y, e0, e1, Jc, Jp);
       const T raw = e0 * e0 + e1 * e1;
       w = loss_drho(loss_kind, loss_delta, raw);
       chi2 += (double)loss_rho(loss_kind, loss_delta, raw);
@@ -258,7 +267,7 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
       // sector per observation, written with vector stores; the per-point kernel forms Jp^T Jp and Jp^T e
       // from it.  (The 9-scalar [w Jp^T Jp, -w Jp^T e] record it replaces straddled sectors: 72 MB of HBM
       // writes for 49 MB of payload on Ladybug-1723.)
-      {
+      if (!(LV & 1)) {
         const T sw = t_sqrt(w);
         V2 *g = reinterpret_cast<V2 *>(g9 + 8 * a);
         V2 q0, q1, q2, q3;
@@ -277,7 +286,8 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
       }
     }
     // camera-side reduction, once per distinct camera in the wave (usually one)
-    unsigned long long remaining = __ballot(valid);
+    unsigned long long remaining = (LV & 2) ? 0ull : __ballot(valid);
+    if (LV & 2) chi2 += (double)(Jc[0] + Jc[17] + w);
     while (remaining) {
       const int leader = __builtin_ctzll(remaining);
       const int cl = __shfl(c, leader, 64);
