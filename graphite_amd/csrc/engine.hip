@@ -479,7 +479,7 @@ template <typename T> struct Engine final : EngineBase {
       }
     {
       Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
-      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
+      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
                                                                                                     spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq);
     }
     if (comm) { // camera-space sums over the landmark shards
@@ -881,7 +881,7 @@ template <typename T> struct Engine final : EngineBase {
       case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
       case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0); break;
       case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30); break;
-      case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc + (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p); break;
+      case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p); break;
       default: throw std::invalid_argument("diag_time: unknown kernel");
       }
     };

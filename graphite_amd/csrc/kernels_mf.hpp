@@ -30,6 +30,9 @@ namespace gr {
 #ifndef OP_SGPR
 #define OP_SGPR 1
 #endif
+#ifndef FIN_PL
+#define FIN_PL 4 // lanes per point in the finalize kernel (power of two; TPB and 90 Nc keep groups inside a wave)
+#endif
 
 constexpr int TICKET_GROUPS = 64;
 
@@ -331,7 +334,7 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
                      const double *__restrict__ rho_partial = nullptr, int n_rho = 0,
                      volatile double *hres = nullptr, volatile int *hres_seq = nullptr, int seq = 0) {
   const unsigned t = blockIdx.x * TPB + threadIdx.x;
-  const unsigned ncam = 90u * (unsigned)Nc;
+  const unsigned ncam = 90u * (unsigned)Nc, ncam_pad = (ncam + TPB - 1) / TPB * TPB;
   if (t < ncam) {
     const unsigned c = t / 90u, e = t % 90u;
     int idx;
@@ -347,13 +350,15 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
       Hcc[81 * (size_t)c + e] = s;
       if (row == col && cam_scales) scales[9 * c + row] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)s))) : T(1);
     } else bc[9 * c + (e - 81u)] = s;
-  } else if (t < ncam + (unsigned)Np) {
-    const unsigned l = t - ncam;
+  } else if (t >= ncam_pad && t < ncam_pad + FIN_PL * (unsigned)Np) { // point part starts on a block boundary
+    // FIN_PL lanes share a point (records j, j + FIN_PL, ...): the serial chain of dependent record loads is
+    // ~deg / FIN_PL long; then a butterfly over the FIN_PL lanes (fixed order)
+    const unsigned l = (t - ncam_pad) / FIN_PL, jl = (t - ncam_pad) % FIN_PL;
     T v[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) v[i] = T(0);
     using V2 = typename Vec2T<T>::type;
-    for (int a = pt_ptr[l]; a < pt_ptr[l + 1]; ++a) {
+    for (int a = pt_ptr[l] + (int)jl; a < pt_ptr[l + 1]; a += FIN_PL) {
       const V2 *g = reinterpret_cast<const V2 *>(g9 + 8 * (size_t)a);
       const V2 c0 = g[0], c1 = g[1], c2 = g[2], e = g[3]; // sqrt(w) Jp columns, sqrt(w) e
       v[0] += c0.x * c0.x + c0.y * c0.y;
@@ -366,13 +371,19 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
       v[7] -= c1.x * e.x + c1.y * e.y;
       v[8] -= c2.x * e.x + c2.y * e.y;
     }
-    T *H = Hll + 9 * (size_t)l;
-    H[0] = v[0]; H[1] = v[1]; H[2] = v[2]; H[3] = v[1]; H[4] = v[3]; H[5] = v[4]; H[6] = v[2]; H[7] = v[4]; H[8] = v[5];
-    bl[3 * (size_t)l] = v[6]; bl[3 * (size_t)l + 1] = v[7]; bl[3 * (size_t)l + 2] = v[8];
-    T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
-    s[0] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[0]))) : T(1);
-    s[1] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1);
-    s[2] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1);
+#pragma unroll
+    for (int o = 1; o < FIN_PL; o <<= 1)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v[i] += __shfl_xor(v[i], o, 64);
+    if (jl == 0) {
+      T *H = Hll + 9 * (size_t)l;
+      H[0] = v[0]; H[1] = v[1]; H[2] = v[2]; H[3] = v[1]; H[4] = v[3]; H[5] = v[4]; H[6] = v[2]; H[7] = v[4]; H[8] = v[5];
+      bl[3 * (size_t)l] = v[6]; bl[3 * (size_t)l + 1] = v[7]; bl[3 * (size_t)l + 2] = v[8];
+      T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
+      s[0] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[0]))) : T(1);
+      s[1] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1);
+      s[2] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1);
+    }
   }
   if (blockIdx.x == 0 && chi2_out) {
     __shared__ double red[4];
