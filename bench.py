@@ -172,6 +172,12 @@ def main():
                          "of the reference's eigen-schur path (all stages on one host core: linearise, Schur, "
                          "simplicial LDL^T; the reference runs only the LDL^T on the CPU)",
                "seconds": round(cst["loop_seconds"], 3)}
+        if solver_name == "pcg":
+            # like for like: the same block-Jacobi PCG algorithm (10 inner iterations, tol 1.0) on the same core
+            _, _, pst = ref.levenberg_marquardt(solver=oracle.SOLVER_PCG, iterations=2 * it, initial_damping=1e-4)
+            cpu["same_algorithm"] = {"value": round(pst["iterations_run"] / pst["loop_seconds"], 5), "unit": "LM iterations/s",
+                                     "cores": 1, "kind": "port", "sample": f"{2 * it} LM iterations, matrix-free block-Jacobi PCG",
+                                     "seconds": round(pst["loop_seconds"], 3)}
 
     # PMC traffic of the dominant kernel, measured offline with the same command under
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) and committed under profiles/
