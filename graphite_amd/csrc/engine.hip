@@ -653,17 +653,24 @@ template <typename T> struct Engine final : EngineBase {
   // no host round trip inside the loop.
   // host side of the device-resident PCG loops: enqueue with one iteration of look-ahead and stop
   // once the direction kernel has flagged (pinned memory) that the loop has left
-  // returns the number of look-ahead enqueues that ran as no-ops (the loop had already left)
+  // Host side of the device-resident PCG loops.  Iteration k + 1 is enqueued BEFORE the flag of iteration k
+  // is read only while k + 1 is still below the iteration count of the previous solve (the loop is expected
+  // to continue: no bubble); past that the host first waits for the flag, so a loop that leaves where the last
+  // one did costs neither a bubble nor no-op launches.  Returns the number of enqueued iterations that ran as
+  // no-ops (the loop had already left).
+  int predicted_iters = 0;
   template <typename Enqueue> int run_pcg_iterations(int max_iter, Enqueue &&enqueue) {
     int enqueued = 0;
     bool left = false;
     if (max_iter > 0) { enqueue(0); ++enqueued; }
     for (int k = 0; k < max_iter; ++k) {
-      if (k + 1 < max_iter) { enqueue(k + 1); ++enqueued; }
+      if (k + 1 < max_iter && k + 1 < predicted_iters && enqueued == k + 1) { enqueue(k + 1); ++enqueued; }
       spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
       if (h_flag[k] == 2) { left = true; break; }
+      if (k + 1 < max_iter && enqueued == k + 1) { enqueue(k + 1); ++enqueued; }
     }
     const int active = left ? std::min((int)h_seq[1], enqueued) : enqueued;
+    predicted_iters = active;
     return enqueued - active;
   }
   void note_noop(std::initializer_list<const char *> names, int count) {
