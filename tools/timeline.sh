@@ -9,7 +9,7 @@ import csv, re, collections
 rows = list(csv.DictReader(open("gpurun_out/timeline.csv")))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"^void gr::|^gr::|<.*", "", r["Kernel_Name"])[:24]) for r in rows)
 # find LM steps by k_chi2 launches; take the middle 30
-chi = [i for i, e in enumerate(ev) if e[2].startswith("k_chi2")]
+chi = [i for i, e in enumerate(ev) if e[2].startswith("k_apply_update_rho")]
 a, b = chi[len(chi)//2 - 15], chi[len(chi)//2 + 15]
 seg = ev[a:b + 1]
 wall = seg[-1][0] - seg[0][0]
