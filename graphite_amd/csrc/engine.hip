@@ -118,6 +118,29 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<T> S, b_schur, Hll_inv, Mp, vl, MinvS;
   // PCG work vectors
   DevBuf<T> v_r, v_p, v_z, v_Ap, v_xb, v_dx, v_ps, v_diag, MinvC, MinvP;
+  DevBuf<T> xp;          // point records of the matrix-free operator [X Y Z ps(3) pad(2)]
+  bool xp_valid = false; // X part in step with pts
+  // the records pay where the point / direction gathers miss L2 (Venice / Final shapes: -27 % operator time)
+  // and cost a few % where they hit (banded Ladybug): decided ONCE per problem by timing the operator both
+  // ways (same arithmetic either way, so results do not depend on the choice).  GR_POINT_RECORDS=0/1 forces it.
+  bool use_records = false, records_tuned = false;
+  void tune_point_records() {
+    if (records_tuned) return;
+    records_tuned = true;
+    if (const char *e = getenv("GR_POINT_RECORDS")) { use_records = atoi(e) != 0; return; }
+    use_records = false;
+    const double t_plain = diag_time(0, 0, 5);
+    use_records = true;
+    const double t_rec = diag_time(0, 0, 5);
+    use_records = t_rec < 0.97 * t_plain;
+    xp_valid = false;
+    if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] operator %.1f us plain, %.1f us with point records -> %s\n", t_plain, t_rec, use_records ? "records" : "plain");
+  }
+  void ensure_point_records() {
+    if (!use_records) return;
+    if (xp.n != 8 * (size_t)Np) { xp.alloc(8 * (size_t)Np); xp.zero(stream); xp_valid = false; }
+    if (!xp_valid) { k_points_to_records<T><<<cdiv(3 * (size_t)Np, TPB), TPB, 0, stream>>>((int)Np, pts.p, xp.p); xp_valid = true; }
+  }
   DevBuf<double> sc_d;
   DevBuf<int> sc_i;
   int sc_cap = 0;
@@ -447,6 +470,7 @@ template <typename T> struct Engine final : EngineBase {
   void set_params(const void *c, const void *p) override {
     GR_HIP(hipMemcpyAsync(cams.p, c, cams.n * sizeof(T), hipMemcpyDefault, stream));
     points_in(p, pts.p, 3);
+    xp_valid = false;
   }
   void get_params(void *c, void *p) override {
     GR_HIP(hipMemcpyAsync(c, cams.p, cams.n * sizeof(T), hipMemcpyDefault, stream));
@@ -535,11 +559,13 @@ template <typename T> struct Engine final : EngineBase {
   void revert() override { // graph.hpp:311-318
     GR_HIP(hipMemcpyAsync(cams.p, cams_bak.p, cams.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
     GR_HIP(hipMemcpyAsync(pts.p, pts_bak.p, pts.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    xp_valid = false;
     campack(); // the matrix-free operator recomputes J from the pack: keep it in step with the vertices
   }
   void apply_update_dev(const T *dx, bool with_backup = false) { // graph.hpp:292-300, ops/update.hpp:11-31
     campack(dx, with_backup ? cams_bak.p : nullptr); // cameras: x += dx .* s fused with backup + pack rebuild
     k_apply_update<T><<<cdiv(3 * Np, TPB), TPB, 0, stream>>>((unsigned)(3 * Np), pts.p, dx + pose_dim, scales.p + pose_dim, with_backup ? pts_bak.p : nullptr);
+    xp_valid = false;
   }
   void apply_update(const void *dx) override {
     GR_HIP(hipMemcpyAsync(v_dx.p, dx, pose_dim * sizeof(T), hipMemcpyDefault, stream));
@@ -576,6 +602,7 @@ template <typename T> struct Engine final : EngineBase {
       want_hcp = false;
       v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
       MinvC.alloc(81 * (size_t)Nc); MinvP.alloc(9 * (size_t)Np);
+      if (!records_tuned) tune_point_records();
     }
   }
   // H.update_values / preconditioner->update_values: the blocks are produced by
@@ -815,6 +842,8 @@ template <typename T> struct Engine final : EngineBase {
   // (one iteration of look-ahead keeps the queue full).
   template <bool IDENTITY> void solve_pcg(int max_iter, double tol, double rej, T *x) {
     ensure_ctl(max_iter);
+    ensure_point_records();
+    T *rec = use_records ? xp.p : nullptr;
     PcgState st = pcg_state();
     const int ui = damping_identity ? 1 : 0;
     for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
@@ -826,11 +855,11 @@ template <typename T> struct Engine final : EngineBase {
     const int cw = cam_weight();
     k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
     if (comm) allreduce_d(st.acc, 4 * (size_t)NS); // record 0: RZP, RR, PDZ, ZDZ
-    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30);
+    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, rec);
     auto enqueue = [&](int k) {
       {
         Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
-        if (jac32) { k_pcg_operator<T, 0, float><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k); } else { k_pcg_operator<T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k); }
+        if (jac32) { k_pcg_operator<T, 0, float><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k, rec); } else { k_pcg_operator<T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k, rec); }
       }
       if (comm) { // camera rows + the p.A.p partials, summed over the landmark shards
         k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, nullptr, k);
@@ -846,7 +875,7 @@ template <typename T> struct Engine final : EngineBase {
       if (comm) allreduce_d(st.acc + (size_t)(k + 1) * NSLOT * NS, 4 * (size_t)NS);
       {
         Scope s3(this, "pcg_direction", 5.0 * n * sizeof(T), 3.0 * n);
-        k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej);
+        k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej, (unsigned)pose_dim, rec);
       }
     };
     note_noop({"pcg_operator", "pcg_update", "pcg_direction"}, run_pcg_iterations(max_iter, enqueue));
@@ -855,22 +884,26 @@ template <typename T> struct Engine final : EngineBase {
   // Diagnostic: average device time (us) of `reps` back-to-back launches of one hot kernel
   // (which: 0 operator, 1 linearize, 2 chi2, 3 pcg_update, 4 pcg_direction, 5 linearize_finalize).
   double diag_time(int which, int variant, int reps) override {
+    const bool was_tuned = records_tuned;
+    records_tuned = true; // no recursion through solver_update_structure
     solver_update_structure(GR_SOLVER_PCG);
+    records_tuned = was_tuned;
     linearize_impl(false);
     solver_set_damping(GR_SOLVER_PCG, 1e-4, false);
     ensure_ctl(4);
+    ensure_point_records();
     PcgState st = pcg_state();
     const int ui = 0;
     const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, TPB), num_cu * 8);
     k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
     k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
-    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30);
+    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr);
     hipEvent_t a, b;
     GR_HIP(hipEventCreate(&a)); GR_HIP(hipEventCreate(&b));
     auto launch = [&] {
       switch (which) {
       case 0:
-#define GR_OP(V) k_pcg_operator<T, V><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0)
+#define GR_OP(V) k_pcg_operator<T, V><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0, use_records ? xp.p : nullptr)
 #ifdef GR_DIAG
         switch (variant) { case 1: GR_OP(1); break; case 2: GR_OP(2); break; case 4: GR_OP(4); break; case 7: GR_OP(7); break; case 8: GR_OP(8); break; case 15: GR_OP(15); break; case 16: GR_OP(16); break; case 31: GR_OP(31); break; default: GR_OP(0); }
 #else
@@ -887,7 +920,7 @@ template <typename T> struct Engine final : EngineBase {
         break;
       case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
       case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0); break;
-      case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30); break;
+      case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr); break;
       case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p); break;
       default: throw std::invalid_argument("diag_time: unknown kernel");
       }
@@ -1029,7 +1062,8 @@ template <typename T> struct Engine final : EngineBase {
         // backup_parameters + apply_update + rho-denominator partials in one pass, then the camera packs
         rho_blocks = cdiv(n, TPB);
         rho_partial.alloc(rho_blocks);
-        k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p);
+        k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr);
+        if (!(use_records && xp.n && xp_valid)) xp_valid = false;
         campack();
         seq = ++seq_counter;
         linearize_impl(want_hcp, /*pack_valid=*/true, seq);

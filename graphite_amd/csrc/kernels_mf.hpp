@@ -128,7 +128,8 @@ template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_apply_update_rho(unsigned n, unsigned pose_dim, int cam_weight, T *__restrict__ cams, T *__restrict__ pts,
                    T *__restrict__ cams_bak, T *__restrict__ pts_bak, const T *__restrict__ dx,
-                   const T *__restrict__ scales, const T *__restrict__ bu, double mu, double *__restrict__ rho_partial) {
+                   const T *__restrict__ scales, const T *__restrict__ bu, double mu, double *__restrict__ rho_partial,
+                   T *__restrict__ xp = nullptr) {
   __shared__ double red[4];
   const unsigned i = blockIdx.x * TPB + threadIdx.x;
   double rho = 0;
@@ -138,11 +139,22 @@ k_apply_update_rho(unsigned n, unsigned pose_dim, int cam_weight, T *__restrict_
     T *bk = i < pose_dim ? cams_bak + i : pts_bak + (i - pose_dim);
     const T xo = *x;
     *bk = xo;
-    *x = xo + d * s;
+    const T xn = xo + d * s;
+    *x = xn;
+    if (xp && i >= pose_dim) { const unsigned q = i - pose_dim; xp[8 * (size_t)(q / 3u) + q % 3u] = xn; } // operator's point records
     if (i >= pose_dim || cam_weight) rho = (double)(d * ((T)mu * d + s * bu[i]));
   }
   rho = block_sum_256(rho, red);
   if (threadIdx.x == 0) rho_partial[blockIdx.x] = rho;
+}
+
+// Point records of the matrix-free operator: [X Y Z | ps_x ps_y ps_z | pad pad] per point, one aligned
+// 64-byte (fp64) / 32-byte (fp32) sector.  The operator's two per-observation gathers (point, scaled
+// direction) become ONE sector; on Venice/Final-shaped graphs, where every such gather is a cache-line
+// miss, that halves the line traffic that bounds the kernel.
+template <typename T> __global__ void k_points_to_records(int Np, const T *__restrict__ pts, T *__restrict__ xp) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 3u * (unsigned)Np) xp[8 * (size_t)(t / 3u) + t % 3u] = pts[t];
 }
 
 // XCD-aware tile ranges for the persistent per-observation kernels.  Workgroups are dealt
@@ -478,7 +490,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
                const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
                const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
                int loss_kind, T loss_delta, const T *__restrict__ ps, T *__restrict__ g3,
-               T *__restrict__ op_partial, double mu, PcgState st, int k) {
+               T *__restrict__ op_partial, double mu, PcgState st, int k, const T *__restrict__ xp = nullptr) {
   if (st.done[k]) return;                      // direction(k-1) already told the host
   if (slot_sum(st.slots(k, RZP), 0) == 0.0) return; // rz == 0: the direction kernel of this iteration closes the loop
   __shared__ double red[4];
@@ -505,9 +517,16 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     // camera of the wave through a uniform index, i.e. with scalar loads into SGPRs: the kernel keeps its
     // VGPRs for the per-observation state and more waves fit per SIMD.  Almost every wave has one camera.
     const size_t lp = (size_t)(valid ? l : 0);
-    const T X = pts[3 * lp], Y = pts[3 * lp + 1], Z = pts[3 * lp + 2];
-    const T *pl = ps + pose_dim + 3 * lp;
-    const T pl0 = pl[0], pl1 = pl[1], pl2 = pl[2];
+    T X, Y, Z, pl0, pl1, pl2;
+    if (xp) { // one aligned record: [X Y Z ps_x ps_y ps_z . .]
+      const V2 *rec = reinterpret_cast<const V2 *>(xp + 8 * lp);
+      const V2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+      X = r0.x; Y = r0.y; Z = r1.x; pl0 = r1.y; pl1 = r2.x; pl2 = r2.y;
+    } else {
+      X = pts[3 * lp]; Y = pts[3 * lp + 1]; Z = pts[3 * lp + 2];
+      const T *pl = ps + pose_dim + 3 * lp;
+      pl0 = pl[0]; pl1 = pl[1]; pl2 = pl[2];
+    }
     unsigned long long remaining = __ballot(valid);
     while (remaining) {
       const int leader = __builtin_ctzll(remaining);
@@ -747,7 +766,7 @@ template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__restrict__ p,
                 T *__restrict__ ps, const T *__restrict__ zt, const T *__restrict__ scales, PcgState st,
-                int k, double tol, double rejection_ratio) {
+                int k, double tol, double rejection_ratio, unsigned pose_dim = 0, T *__restrict__ xp = nullptr) {
   const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
   T beta = 0, scale = 0;
   if (k < 0) {
@@ -787,7 +806,8 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
   for (unsigned t = blockIdx.x * TPB + threadIdx.x; t < n; t += gridDim.x * TPB) {
     const T pn = (k < 0) ? scale * zt[t] : beta * p[t] + scale * zt[t];
     p[t] = pn;
-    ps[t] = scales[t] * pn;
+    if (xp && t >= pose_dim) { const unsigned q = t - pose_dim; xp[8 * (size_t)(q / 3u) + 3 + q % 3u] = scales[t] * pn; }
+    else ps[t] = scales[t] * pn;
   }
 }
 
