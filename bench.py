@@ -46,7 +46,7 @@ def parse():
 DEFAULTS = {  # workload -> (solver, dtype) as BASELINE.json configs name them
     "ladybug-49": ("pcg-schur", "f32"),
     "ladybug-1723": ("pcg", "f64"),
-    "venice-1778": ("pcg-schur", "f32"),
+    "venice-1778": ("pcg-schur-implicit", "f32"),  # same iterates as pcg-schur, S never formed (3.5x faster here)
     "final-13682": ("pcg", "f64"),
 }
 
