@@ -157,8 +157,10 @@ def main():
     n = 9 * Nc + 3 * Np
     flops_pcg_iter = (104.0 * No + 2 * (81 * Nc + 9 * Np) + 12 * n) if solver_name == "pcg" else None
     pcg_gflops = None
-    if flops_pcg_iter and st["solve_seconds"] > 0:
-        pcg_gflops = flops_pcg_iter * st["pcg_iterations"] / st["solve_seconds"] / 1e9
+    # inner-solve time is measured in the profiled pass (the timed pass replays whole LM iterations as hipGraphs,
+    # which have no per-solve events)
+    if flops_pcg_iter and st2["solve_seconds"] > 0:
+        pcg_gflops = flops_pcg_iter * st2["pcg_iterations"] / st2["solve_seconds"] / 1e9
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:

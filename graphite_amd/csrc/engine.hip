@@ -10,6 +10,7 @@
 // The C ABI at the bottom (include/graphite_mi355x.h) is the drop-in boundary.
 #include "../../include/graphite_mi355x.h"
 #include "comm.hpp"
+#include <functional>
 #include "kernels_is.hpp"
 #include "chol.hpp"
 #include <algorithm>
@@ -237,6 +238,10 @@ template <typename T> struct Engine final : EngineBase {
   }
   ~Engine() override {
     if (h_res) (void)hipHostFree(h_res);
+    lm_graph_release();
+    if (lmg_stream) (void)hipStreamDestroy(lmg_stream);
+    if (h_lm) (void)hipHostFree(const_cast<int *>(h_lm));
+    if (h_trace) (void)hipHostFree(const_cast<double *>(h_trace));
   }
   // spin on a pinned word written by a kernel (system-scope fence on the device side)
   template <typename Pred> void spin_until(Pred pred) {
@@ -1024,6 +1029,156 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   // ---- optimizer::levenberg_marquardt (optimizer/levenberg_marquardt.hpp:110-242) -----
+  // ---- graph-replayed LM iterations ---------------------------------------------------------------
+  // One accepted LM iteration of the matrix-free PCG solvers as ONE hipGraph: block-Jacobi + PCG start,
+  // `unroll` PCG iterations, update + backup, camera packs, the (speculative) linearisation and the
+  // finalize kernel, which takes the accept decision on the device (LmDev).  The host replays the graph
+  // a few iterations ahead and only reads the traces; the first iteration that is not a plain
+  // acceptance (PCG needs more iterations, rejected step, rho == 0, non-finite value) makes every later
+  // replay a no-op and is redone by the host loop.  1.8 us per node instead of 3.1 us per stream launch
+  // and no host round trip inside the iteration.
+  struct LmGraphKey {
+    int solver = -1, max_iter = 0, use_identity = 0, jac32 = 0, loss_kind = 0, records = 0, cap = 0;
+    double tol = 0, rej = 0, loss_delta = 0;
+    const void *xp = nullptr;
+    bool operator==(const LmGraphKey &o) const {
+      return solver == o.solver && max_iter == o.max_iter && use_identity == o.use_identity && jac32 == o.jac32 && loss_kind == o.loss_kind &&
+             records == o.records && cap == o.cap && tol == o.tol && rej == o.rej && loss_delta == o.loss_delta && xp == o.xp;
+    }
+  };
+  LmGraphKey lmg_key;
+  hipGraphExec_t lmg_exec = nullptr;
+  hipStream_t lmg_stream = nullptr; // capture / replay stream when the engine runs on the legacy default stream
+  DevBuf<LmDev> lmdev;
+  volatile int *h_lm = nullptr;      // pinned: [0] accepted steps, [1] stop code
+  volatile double *h_trace = nullptr; // pinned: chi2[cap], lambda[cap]
+  int h_trace_cap = 0;
+  // GR_LM_GRAPH: 0 off (default), 1 hipGraph replay, 2 the same device-decided iteration enqueued ahead with plain
+  // stream launches.  Measured on Ladybug-1723 fp64 (A/B in one run): host loop 5 550-5 630 LM it/s, mode 1 4 900,
+  // mode 2 5 170-5 230: the host loop with its look-ahead predictor is kept as the product path.
+  int lm_graph_mode = getenv("GR_LM_GRAPH") ? atoi(getenv("GR_LM_GRAPH")) : 0;
+  bool lm_graph_enabled = lm_graph_mode != 0;
+  std::function<void()> lm_enqueue_fn;
+  int lm_unroll = getenv("GR_LM_UNROLL") ? atoi(getenv("GR_LM_UNROLL")) : 2;
+
+  void lm_graph_release() {
+    if (lmg_exec) { (void)hipGraphExecDestroy(lmg_exec); lmg_exec = nullptr; }
+  }
+  template <bool IDENTITY> void lm_graph_enqueue(int max_iter, double tol, double rej) {
+    // the launch sequence of one iteration, every kernel in its LmDev form (captured, never run directly)
+    const int ui = damping_identity ? 1 : 0;
+    PcgState stt = pcg_state();
+    LmDev *lm = lmdev.p;
+    T *rec = use_records ? xp.p : nullptr;
+    const int nbc = cdiv(Nc, 64), nbp = cdiv(Np, 64);
+    k_block_jacobi<T><<<nbc + nbp + 1, 64, 0, stream>>>((int)Nc, (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, 0.0, ui, MinvC.p, MinvP.p, v_diag.p, stt, ctl_cap, lm);
+    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, TPB), num_cu * 8);
+    T *x = v_dx.p;
+    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, 0.0, ui, MinvC.p, MinvP.p, stt, 0, lm);
+    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, -1, 0.0, 1e30, (unsigned)pose_dim, rec, lm, 0, nullptr);
+    const int unroll = std::max(1, std::min(lm_unroll, max_iter));
+    for (int k = 0; k < unroll; ++k) {
+      if (jac32) { k_pcg_operator<T, 0, float><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, 0.0, stt, k, rec, lm); }
+      else { k_pcg_operator<T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, 0.0, stt, k, rec, lm); }
+      k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, 0.0, ui, MinvC.p, MinvP.p, stt, k, lm);
+      // past the unrolled iterations the loop must have left, unless max_iter itself ends it
+      k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, k, tol, rej, (unsigned)pose_dim, rec, lm, (k == unroll - 1 && unroll < max_iter) ? 1 : 0, h_lm + 1);
+    }
+    k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, 1, cams.p, pts.p, cams_bak.p, pts_bak.p, x, scales.p, bu.p, 0.0, rho_partial.p, rec, lm);
+    k_campack<T><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, cams.p, pack.p, nullptr, scales.p, nullptr, lm);
+    if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
+    else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
+    k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
+                                                                                                    rho_partial.p, rho_blocks, nullptr, nullptr, 0, lm, pcg_iters.p, h_trace, h_trace + h_trace_cap, h_lm, h_lm + 1);
+  }
+  bool lm_graph_prepare(const gr_lm_options &opt) {
+    if (!lm_graph_enabled || comm || profiling || opt.iterations < 2 || opt.pcg_max_iter < 1) return false;
+    if (opt.solver != GR_SOLVER_PCG && opt.solver != GR_SOLVER_PCG_IDENTITY) return false;
+    if (getenv("GR_LM_SPECULATE") && atoi(getenv("GR_LM_SPECULATE")) == 0) return false;
+    ensure_ctl(opt.pcg_max_iter);
+    ensure_point_records();
+    rho_blocks = cdiv(n, TPB);
+    rho_partial.alloc(rho_blocks);
+    lmdev.alloc(1);
+    if (!h_lm) { void *q = nullptr; GR_HIP(hipHostMalloc(&q, 64, hipHostMallocCoherent | hipHostMallocMapped)); h_lm = static_cast<volatile int *>(q); }
+    LmGraphKey key;
+    if (opt.iterations + 2 > h_trace_cap) {
+      if (h_trace) (void)hipHostFree(const_cast<double *>(h_trace));
+      h_trace_cap = opt.iterations + 2;
+      void *q = nullptr;
+      GR_HIP(hipHostMalloc(&q, 2 * sizeof(double) * (size_t)h_trace_cap, hipHostMallocCoherent | hipHostMallocMapped));
+      h_trace = static_cast<volatile double *>(q);
+      lm_graph_release();
+    }
+    damping_identity = opt.use_identity != 0;
+    key.solver = opt.solver; key.max_iter = opt.pcg_max_iter; key.use_identity = opt.use_identity; key.jac32 = jac32 ? 1 : 0;
+    key.loss_kind = loss_kind; key.records = use_records ? 1 : 0; key.cap = ctl_cap; key.tol = opt.pcg_tol; key.rej = opt.pcg_rejection_ratio;
+    key.loss_delta = (double)loss_delta; key.xp = xp.p;
+    const int mi = opt.pcg_max_iter; const double tl_ = opt.pcg_tol, rj_ = opt.pcg_rejection_ratio;
+    if (opt.solver == GR_SOLVER_PCG_IDENTITY) lm_enqueue_fn = [this, mi, tl_, rj_] { lm_graph_enqueue<true>(mi, tl_, rj_); };
+    else lm_enqueue_fn = [this, mi, tl_, rj_] { lm_graph_enqueue<false>(mi, tl_, rj_); };
+    if (lm_graph_mode == 2) return true; // no capture: the iteration is enqueued ahead with stream launches
+    if (lmg_exec && key == lmg_key) return true;
+    lm_graph_release();
+    if (!stream && !lmg_stream) GR_HIP(hipStreamCreate(&lmg_stream));
+    hipStream_t cap = stream ? stream : lmg_stream, saved = stream;
+    GR_HIP(hipStreamSynchronize(saved));
+    stream = cap;
+    hipGraph_t graph = nullptr;
+    GR_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    if (opt.solver == GR_SOLVER_PCG_IDENTITY) lm_graph_enqueue<true>(opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio);
+    else lm_graph_enqueue<false>(opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio);
+    const hipError_t ce = hipStreamEndCapture(cap, &graph);
+    stream = saved;
+    if (ce != hipSuccess || !graph) { (void)hipGetLastError(); return false; }
+    const hipError_t ie = hipGraphInstantiate(&lmg_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { lmg_exec = nullptr; (void)hipGetLastError(); return false; }
+    lmg_key = key;
+    return true;
+  }
+  // replays up to `maxsteps` iterations; returns the number accepted on the device, `stop` = why it ended
+  int lm_graph_run(int maxsteps, T &mu, T &nu, T &chi2v, int &pcg_its, double *chi2_out, double *lambda_out, int &stop) {
+    hipStream_t q = (lm_graph_mode == 2) ? stream : (stream ? stream : lmg_stream);
+    LmDev init{};
+    init.mu = (double)mu; init.nu = (double)nu; init.chi2 = (double)chi2v;
+    GR_HIP(hipStreamSynchronize(stream));
+    GR_HIP(hipMemcpy(lmdev.p, &init, sizeof(LmDev), hipMemcpyHostToDevice));
+    h_lm[0] = 0; h_lm[1] = 0;
+    int launched = 0;
+    const int DEPTH = getenv("GR_LM_DEPTH") ? atoi(getenv("GR_LM_DEPTH")) : 3;
+    for (;;) {
+      const int done = __atomic_load_n(const_cast<const int *>(&h_lm[0]), __ATOMIC_ACQUIRE);
+      const int stp = __atomic_load_n(const_cast<const int *>(&h_lm[1]), __ATOMIC_ACQUIRE);
+      if (stp != 0 || done >= maxsteps) break;
+      if (launched < maxsteps && launched - done < DEPTH) {
+        if (lm_graph_mode == 2) lm_enqueue_fn(); else GR_HIP(hipGraphLaunch(lmg_exec, q));
+        ++launched;
+        continue;
+      }
+      if (launched >= maxsteps || launched - done >= DEPTH) {
+        // wait for progress (bounded: a wedged GPU must not hang the caller)
+        const auto t0 = std::chrono::steady_clock::now();
+        while (__atomic_load_n(const_cast<const int *>(&h_lm[0]), __ATOMIC_ACQUIRE) == done && __atomic_load_n(const_cast<const int *>(&h_lm[1]), __ATOMIC_ACQUIRE) == 0) {
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) throw std::runtime_error("graph-replayed LM iteration did not finish within 20 s");
+        }
+      }
+    }
+    GR_HIP(hipStreamSynchronize(q)); // the replays issued past a stop are no-ops
+    LmDev fin{};
+    GR_HIP(hipMemcpy(&fin, lmdev.p, sizeof(LmDev), hipMemcpyDeviceToHost));
+    const int steps = fin.step;
+    for (int sidx = 1; sidx <= steps; ++sidx) {
+      if (chi2_out) chi2_out[sidx] = h_trace[sidx];
+      if (lambda_out) lambda_out[sidx] = h_trace[h_trace_cap + sidx];
+    }
+    mu = (T)fin.mu; nu = (T)fin.nu; chi2v = (T)fin.chi2;
+    pcg_its = fin.pcg_iters;
+    stop = fin.stop;
+    state_fresh_cap = -1;
+    return steps;
+  }
+
   void lm(const gr_lm_options &opt, gr_lm_stats &st, double *chi2_trace, double *lambda_trace) override {
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
@@ -1043,10 +1198,46 @@ template <typename T> struct Engine final : EngineBase {
     if (lambda_trace) lambda_trace[0] = (double)mu;
     hipEvent_t ev_a, ev_b;
     GR_HIP(hipEventCreate(&ev_a)); GR_HIP(hipEventCreate(&ev_b));
+    const bool graph_mode = lm_graph_prepare(opt);
     GR_HIP(hipStreamSynchronize(stream));
     st.setup_seconds = std::chrono::duration<double>(clk::now() - t0).count();
     auto tl = clk::now();
-    for (int i = 0; i < opt.iterations && run; ++i) {
+
+    // accept / reject bookkeeping of one trial step (levenberg_marquardt.hpp:184-233); false = leave the loop
+    auto decide = [&](int i, bool solve_ok, bool speculate, int it, const double *hs) -> bool {
+      st.pcg_iterations += it;
+      T new_chi2 = (T)hs[0];
+      if (!solve_ok) new_chi2 = std::numeric_limits<T>::max();
+      T denom = solve_ok ? (T)hs[1] + (T)1.0e-3 : T(1);
+      const T rho = (chi2v - new_chi2) / denom;
+      if (solve_ok && std::isfinite(new_chi2) && rho > 0) {
+        double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3);
+        alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
+        mu *= (T)alpha;
+        nu = 2;
+        if (!speculate) linearize_impl(want_hcp, /*pack_valid=*/true);
+        solver_update_values(opt.solver);
+        st.accepted++;
+        accept_streak = std::min(accept_streak + 1, 2);
+      } else {
+        revert();
+        if (speculate) linearize_impl(want_hcp, /*pack_valid=*/true); // restore H, b, scales of the kept point
+        accept_streak = 0;
+        // the reference recomputes error + chi2 here (:199-201); every consumer below
+        // recomputes residuals from the reverted vertices, so nothing is stale.
+        mu *= nu;
+        nu *= 2;
+        new_chi2 = chi2v;
+      }
+      chi2v = new_chi2;
+      st.iterations_run++;
+      if (chi2_trace) chi2_trace[i + 1] = (double)chi2v;
+      if (lambda_trace) lambda_trace[i + 1] = (double)mu;
+      if (!std::isfinite(mu)) run = false;
+      return rho != 0;
+    };
+    // one host-driven iteration: solve, trial step, hand-shake, decision
+    auto host_iteration = [&](int i) -> bool {
       solver_set_damping(opt.solver, (double)mu, opt.use_identity != 0);
       GR_HIP(hipEventRecord(ev_a, stream));
       const bool solve_ok = solver_solve_dev(opt.solver, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, v_dx.p);
@@ -1080,41 +1271,41 @@ template <typename T> struct Engine final : EngineBase {
       (void)hipEventSynchronize(ev_b);
       (void)hipEventElapsedTime(&ms, ev_a, ev_b);
       st.solve_seconds += ms * 1e-3;
-      st.pcg_iterations += it;
-      T new_chi2 = (T)hs[0];
-      if (!solve_ok) new_chi2 = std::numeric_limits<T>::max();
-      T denom = solve_ok ? (T)hs[1] + (T)1.0e-3 : T(1);
-      const T rho = (chi2v - new_chi2) / denom;
-      if (solve_ok && std::isfinite(new_chi2) && rho > 0) {
-        double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3);
-        alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
-        mu *= (T)alpha;
-        nu = 2;
-        if (!speculate) linearize_impl(want_hcp, /*pack_valid=*/true);
-        solver_update_values(opt.solver);
-        st.accepted++;
-        accept_streak = std::min(accept_streak + 1, 2);
-      } else {
-        revert();
-        if (speculate) linearize_impl(want_hcp, /*pack_valid=*/true); // restore H, b, scales of the kept point
-        accept_streak = 0;
-        // the reference recomputes error + chi2 here (:199-201); every consumer below
-        // recomputes residuals from the reverted vertices, so nothing is stale.
-        mu *= nu;
-        nu *= 2;
-        new_chi2 = chi2v;
+      return decide(i, solve_ok, speculate, it, hs);
+    };
+
+    int i = 0, g_steps = 0, g_stop1 = 0, g_stop2 = 0, g_runs = 0;
+    while (i < opt.iterations && run) {
+      if (graph_mode && accept_streak >= 2 && opt.iterations - i >= 2) {
+        int its = 0, stop = 0;
+        const int steps = lm_graph_run(opt.iterations - i, mu, nu, chi2v, its, chi2_trace ? chi2_trace + i : nullptr, lambda_trace ? lambda_trace + i : nullptr, stop);
+        st.accepted += steps; st.iterations_run += steps; st.pcg_iterations += its;
+        i += steps;
+        g_steps += steps; (stop == 1 ? g_stop1 : stop == 2 ? g_stop2 : g_runs)++;
+        if (i >= opt.iterations) break;
+        if (stop == 2) {
+          // the device evaluated trial step i (speculative linearisation done) and did not accept it
+          double hs[2];
+          GR_HIP(hipMemcpy(hs, dscalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost));
+          int it = 0;
+          GR_HIP(hipMemcpy(&it, pcg_iters.p, sizeof(int), hipMemcpyDeviceToHost));
+          const bool go = decide(i, true, true, it, hs);
+          ++i;
+          if (!go) break;
+          continue;
+        }
+        // stop == 1: the PCG loop wants more than the unrolled iterations; nothing of step i was applied
       }
-      chi2v = new_chi2;
-      st.iterations_run++;
-      if (chi2_trace) chi2_trace[i + 1] = (double)chi2v;
-      if (lambda_trace) lambda_trace[i + 1] = (double)mu;
-      if (!std::isfinite(mu)) run = false;
-      if (rho == 0) break;
+      const bool go = host_iteration(i);
+      ++i;
+      if (!go) break;
     }
     GR_HIP(hipStreamSynchronize(stream));
     st.loop_seconds = std::chrono::duration<double>(clk::now() - tl).count();
     st.ok = run ? 1 : 0;
     st.final_chi2 = (double)chi2v;
+    if (getenv("GR_VERBOSE") && graph_mode)
+      std::fprintf(stderr, "[graphite-mi355x] LM: %d of %d iterations replayed as graphs; handed back: %d (PCG iterations), %d (not accepted)\n", g_steps, st.iterations_run, g_stop1, g_stop2);
     (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b);
     if (profiling) flush_prof();
     profiling = false;

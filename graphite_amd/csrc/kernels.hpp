@@ -34,6 +34,19 @@ template <typename T> struct Vec2T;
 template <> struct Vec2T<float> { using type = float2; };
 template <> struct Vec2T<double> { using type = double2; };
 
+// Device-resident Levenberg-Marquardt state of the graph-replayed LM iteration (Engine::lm_graph): the
+// kernels of one iteration read the damping from here and return at once when `stop` is set, so the
+// host can replay the captured iteration back to back without a round trip; the finalize kernel takes
+// the accept decision (optimizer/levenberg_marquardt.hpp:184-197) and everything else is handed
+// back to the host loop.
+struct LmDev {
+  double mu, nu, chi2;
+  int stop;      // 0 run | 1 the PCG loop needs more than the unrolled iterations | 2 the step was not accepted
+  int step;      // accepted steps completed in graph mode
+  int pcg_iters; // their inner iterations
+  int pad;
+};
+
 template <typename T> __device__ __forceinline__ void load_pack(const T *__restrict__ pack, int c, T *pk) {
   const T *src = pack + PACK * (size_t)c;
 #pragma unroll
@@ -44,7 +57,8 @@ template <typename T> __device__ __forceinline__ void load_pack(const T *__restr
 // camera pack (+ optional x += dx .* s on the cameras first): Nc threads
 template <typename T>
 __global__ void k_campack(int Nc, T *__restrict__ cams, T *__restrict__ pack, const T *__restrict__ dx,
-                          const T *__restrict__ scales, T *__restrict__ backup) {
+                          const T *__restrict__ scales, T *__restrict__ backup, const LmDev *__restrict__ lm = nullptr) {
+  if (lm && lm->stop) return;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Nc) return;
   T cam[9], pk[PACK];

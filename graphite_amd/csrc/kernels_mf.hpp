@@ -74,7 +74,9 @@ template <typename T>
 __global__ void __launch_bounds__(64)
 k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, const T *__restrict__ Hll,
                const T *__restrict__ scales, double mu, int use_identity, T *__restrict__ MinvC,
-               T *__restrict__ MinvP, T *__restrict__ diag_clamped, PcgState st, int cap) {
+               T *__restrict__ MinvP, T *__restrict__ diag_clamped, PcgState st, int cap,
+               const LmDev *__restrict__ lm = nullptr) {
+  if (lm) { if (lm->stop) return; mu = lm->mu; }
   const int b = blockIdx.x;
   if (b < nbc) {
     const int c = b * 64 + threadIdx.x;
@@ -129,7 +131,8 @@ __global__ void __launch_bounds__(TPB)
 k_apply_update_rho(unsigned n, unsigned pose_dim, int cam_weight, T *__restrict__ cams, T *__restrict__ pts,
                    T *__restrict__ cams_bak, T *__restrict__ pts_bak, const T *__restrict__ dx,
                    const T *__restrict__ scales, const T *__restrict__ bu, double mu, double *__restrict__ rho_partial,
-                   T *__restrict__ xp = nullptr) {
+                   T *__restrict__ xp = nullptr, const LmDev *__restrict__ lm = nullptr) {
+  if (lm) { if (lm->stop) return; mu = lm->mu; }
   __shared__ double red[4];
   const unsigned i = blockIdx.x * TPB + threadIdx.x;
   double rho = 0;
@@ -238,7 +241,8 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
             const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
             const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
             int loss_kind, T loss_delta, T *__restrict__ g9, T *__restrict__ Hcp, T *__restrict__ cam_partial,
-            double *__restrict__ chi2_partial) {
+            double *__restrict__ chi2_partial, const LmDev *__restrict__ lm = nullptr) {
+  if (lm && lm->stop) return;
   __shared__ double red[4];
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
@@ -344,7 +348,11 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
                      T *__restrict__ bl, T *__restrict__ scales, int n_partials,
                      const double *__restrict__ chi2_partial, double *__restrict__ chi2_out,
                      const double *__restrict__ rho_partial = nullptr, int n_rho = 0,
-                     volatile double *hres = nullptr, volatile int *hres_seq = nullptr, int seq = 0) {
+                     volatile double *hres = nullptr, volatile int *hres_seq = nullptr, int seq = 0,
+                     LmDev *__restrict__ lm = nullptr, const int *__restrict__ pcg_iters = nullptr,
+                     volatile double *h_chi2_trace = nullptr, volatile double *h_lambda_trace = nullptr,
+                     volatile int *h_steps = nullptr, volatile int *h_stop = nullptr) {
+  if (lm && lm->stop) return;
   const unsigned t = blockIdx.x * TPB + threadIdx.x;
   const unsigned ncam = 90u * (unsigned)Nc, ncam_pad = (ncam + TPB - 1) / TPB * TPB;
   if (t < ncam) {
@@ -410,7 +418,29 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
     if (threadIdx.x == 0) {
       chi2_out[0] = s;
       if (rho_partial) chi2_out[1] = r;
-      if (hres) {
+      if (lm) {
+        // graph mode: the accept decision of optimizer/levenberg_marquardt.hpp:184-197, in T like the host loop;
+        // anything but a plain acceptance is handed back to the host (stop = 2)
+        const T chi2v = (T)lm->chi2, new_chi2 = (T)s;
+        const T denom = (T)r + (T)1.0e-3;
+        const T rho = (chi2v - new_chi2) / denom;
+        if (isfinite((double)new_chi2) && rho > T(0)) {
+          double alpha = 1.0 - pow(2.0 * (double)rho - 1.0, 3.0);
+          alpha = fmax(fmin(alpha, 2.0 / 3.0), 1.0 / 3.0);
+          const T mu = (T)lm->mu * (T)alpha;
+          const int step = lm->step + 1;
+          lm->mu = (double)mu; lm->nu = 2.0; lm->chi2 = (double)new_chi2; lm->step = step;
+          lm->pcg_iters += pcg_iters[0];
+          h_chi2_trace[step] = (double)new_chi2;
+          h_lambda_trace[step] = (double)mu;
+          __threadfence_system();
+          *h_steps = step;
+        } else {
+          lm->stop = 2;
+          __threadfence_system();
+          *h_stop = 2;
+        }
+      } else if (hres) {
         hres[0] = s; hres[1] = r;
         __threadfence_system();
         *hres_seq = seq;
@@ -490,7 +520,9 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
                const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
                const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
                int loss_kind, T loss_delta, const T *__restrict__ ps, T *__restrict__ g3,
-               T *__restrict__ op_partial, double mu, PcgState st, int k, const T *__restrict__ xp = nullptr) {
+               T *__restrict__ op_partial, double mu, PcgState st, int k, const T *__restrict__ xp = nullptr,
+               const LmDev *__restrict__ lm = nullptr) {
+  if (lm && lm->stop) return;
   if (st.done[k]) return;                      // direction(k-1) already told the host
   if (slot_sum(st.slots(k, RZP), 0) == 0.0) return; // rz == 0: the direction kernel of this iteration closes the loop
   __shared__ double red[4];
@@ -637,7 +669,9 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
              const T *__restrict__ g3, const int *__restrict__ pt_ptr, const T *__restrict__ op_partial,
              const int *__restrict__ cam_seg_ptr, const T *__restrict__ raw_c, int cam_weight,
              const T *__restrict__ diag, double mu, int use_identity,
-             const T *__restrict__ MinvC, const T *__restrict__ MinvP, PcgState st, int k) {
+             const T *__restrict__ MinvC, const T *__restrict__ MinvP, PcgState st, int k,
+             const LmDev *__restrict__ lm = nullptr) {
+  if (lm) { if (lm->stop) return; mu = lm->mu; }
   T alpha = 0;
   if (MODE == 1) {
     if (st.done[k]) return;
@@ -766,7 +800,9 @@ template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__restrict__ p,
                 T *__restrict__ ps, const T *__restrict__ zt, const T *__restrict__ scales, PcgState st,
-                int k, double tol, double rejection_ratio, unsigned pose_dim = 0, T *__restrict__ xp = nullptr) {
+                int k, double tol, double rejection_ratio, unsigned pose_dim = 0, T *__restrict__ xp = nullptr,
+                LmDev *__restrict__ lm = nullptr, int last_unrolled = 0, volatile int *h_stop = nullptr) {
+  if (lm && lm->stop) return;
   const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
   T beta = 0, scale = 0;
   if (k < 0) {
@@ -796,6 +832,7 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
       st.iters[0] = k + 1;
       *st.hiters = k + 1;
       st.hflag[k] = done_next ? 2 : 1;
+      if (lm && last_unrolled && !done_next) { lm->stop = 1; if (h_stop) *h_stop = 1; } // graph mode: the host takes this step over
       __threadfence_system();
     }
     if (reject) {

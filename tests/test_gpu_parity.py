@@ -214,3 +214,23 @@ def test_against_committed_golden_fixtures():
         ct, _, _ = gpu.levenberg_marquardt(solver=solver, iterations=8)
         assert np.allclose(ct, g[key], rtol=1e-8), key
         gpu.close()
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("name,dtype,rtol", [("mini-50", np.float64, 1e-9), ("ladybug-49", np.float64, 1e-8)])
+def test_levenberg_marquardt_graph_replay(oracle_mod, monkeypatch, name, dtype, rtol, mode):
+    """The opt-in device-decided LM iteration (GR_LM_GRAPH=1: hipGraph replay, =2: enqueued ahead): same
+    chi2 / lambda trace as the oracle, including the iterations it hands back to the host loop."""
+    monkeypatch.setenv("GR_LM_GRAPH", mode)
+    prob, gpu, ref = make_pair(oracle_mod, name, dtype)
+    for solver, osolver in ((ga.SOLVER_PCG, oracle_mod.SOLVER_PCG), (ga.SOLVER_PCG_IDENTITY, oracle_mod.SOLVER_PCG_IDENTITY)):
+        gpu.set_params(prob.cameras, prob.points)
+        ref.set_params(prob.cameras, prob.points)
+        ct_g, lt_g, st = gpu.levenberg_marquardt(solver=solver, iterations=10)
+        ct_r, lt_r, st_r = ref.levenberg_marquardt(solver=osolver, iterations=10)
+        assert len(ct_g) == len(ct_r)
+        assert np.allclose(ct_g, ct_r, rtol=max(rtol, 1e-6))
+        assert np.allclose(lt_g, lt_r, rtol=1e-3)
+        assert st["pcg_iterations"] == st_r["pcg_iterations"]
+        assert st["iterations_run"] == st_r["iterations_run"] and st["accepted"] == st_r["accepted"]
+    gpu.close()
