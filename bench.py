@@ -66,8 +66,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # GR_BENCH_FORCE_COMM=1 (testing): run the sharded code path (process group, RCCL communicator, all-reduces)
+    # even with a single rank, e.g. under `python -m torch.distributed.run --nproc-per-node 1`
+    sharded = world > 1 or os.environ.get("GR_BENCH_FORCE_COMM") == "1"
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import graphite_amd as ga
@@ -81,7 +87,7 @@ def main():
 
     prob = synth.make_config(args.workload)
     Nc, Np, No = prob.shape
-    if world > 1:
+    if sharded:
         from graphite_amd import dist as gdist
         part = gdist.partition_by_landmark(prob, rank, world)
         gpu = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype,
@@ -98,7 +104,7 @@ def main():
     lm_kw = dict(solver=solver, initial_damping=1e-4, pcg_max_iter=args.pcg_iterations, pcg_tol=1.0, pcg_rej=5.0)
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -112,7 +118,7 @@ def main():
     ct, lt, st = gpu.levenberg_marquardt(iterations=args.steps, profile=False, **lm_kw)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -125,7 +131,7 @@ def main():
     ks = gpu.kernel_stats()
 
     if rank != 0:
-        if world > 1:
+        if sharded:
             dist.destroy_process_group()
         return
 
@@ -236,7 +242,7 @@ def main():
         with open(args.dump_kernels, "w") as f:
             json.dump({"kernels": ks, "line": line}, f, indent=1)
     print(json.dumps(line))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 
