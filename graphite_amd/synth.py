@@ -71,6 +71,7 @@ def project(cameras, points, cam_idx, pt_idx):
 def _degrees(rng, Np, No, Nc):
     """k_l = 2 + Geometric, clipped to Nc, adjusted so that sum == No exactly."""
     assert No >= 2 * Np, "need at least two observations per point"
+    assert No <= Np * Nc, "more observations than (camera, point) pairs"
     mean_extra = No / Np - 2.0
     if mean_extra <= 0:
         k = np.full(Np, 2, np.int64)
