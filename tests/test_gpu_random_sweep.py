@@ -88,3 +88,22 @@ def test_fp32_stages(oracle_mod, shape):
     m = min(len(ct_g), len(ct_r))
     assert np.allclose(ct_g[:m], ct_r[:m], rtol=5e-3)
     gpu.close()
+
+
+@pytest.mark.parametrize("shape", [SHAPES[7], SHAPES[9]], ids=lambda s: "x".join(map(str, s[:3])))
+def test_huber_loss_all_solvers(oracle_mod, shape):
+    """HuberLoss (loss.hpp:32-51) through every solver: the robust weights enter b, H, S and the operators."""
+    Nc, Np, No, window, seed = shape
+    prob = synth.make_problem(Nc, Np, No, seed=seed, window=window, noise_px=2.0)
+    gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    gpu.set_loss(ga.LOSS_HUBER, 1.5)
+    ref.set_loss(oracle_mod.LOSS_HUBER, 1.5)
+    for gs, os_ in ((ga.SOLVER_PCG, oracle_mod.SOLVER_PCG), (ga.SOLVER_PCG_SCHUR, oracle_mod.SOLVER_PCG_SCHUR),
+                    (ga.SOLVER_PCG_SCHUR_IMPLICIT, oracle_mod.SOLVER_PCG_SCHUR), (ga.SOLVER_DENSE_SCHUR, oracle_mod.SOLVER_LDLT_SCHUR)):
+        gpu.set_params(prob.cameras, prob.points); ref.set_params(prob.cameras, prob.points)
+        ct_g, lt_g, _ = gpu.levenberg_marquardt(solver=gs, iterations=5)
+        ct_r, lt_r, _ = ref.levenberg_marquardt(solver=os_, iterations=5)
+        assert len(ct_g) == len(ct_r) and np.allclose(ct_g, ct_r, rtol=1e-7), gs
+        assert np.allclose(lt_g, lt_r, rtol=1e-3)
+    gpu.close()
