@@ -93,9 +93,6 @@ def main():
         gpu = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype,
                             device=local_rank, shard=True)
         gdist.init_comm(gpu, rank, world)
-        if solver_name not in ("pcg", "pcg-schur-implicit"):
-            # sharded solvers: matrix-free PCG and implicit-Schur PCG; an explicit / dense Schur request maps to the implicit one
-            solver_name, solver = ("pcg-schur-implicit", ga.SOLVER_PCG_SCHUR_IMPLICIT) if "schur" in solver_name else ("pcg", ga.SOLVER_PCG)
     else:
         part = prob
         gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype,

@@ -333,6 +333,29 @@ template <typename T> struct Engine final : EngineBase {
     }
     if (np >= (int64_t)std::numeric_limits<int>::max()) throw std::invalid_argument("too many Schur products for 32-bit indices");
     nprod = np;
+    if (comm) {
+      // Landmark shards: every rank holds the products of its own points but the block list must be the
+      // union over all ranks (S is all-reduced).  Presence flags travel 6 x 8 bits per double: integer
+      // sums below 2^53 are exact in the all-reduce, one flag counts at most `size` <= 255.
+      if (comm->size > 255) throw std::invalid_argument("explicit Schur complement: at most 255 landmark shards");
+      const size_t ntri = (size_t)Nc * (Nc + 1) / 2;
+      std::vector<double> packed((ntri + 5) / 6, 0.0);
+      for (int64_t j = 0; j < Nc; ++j)
+        for (int64_t i = 0; i <= j; ++i)
+          if (map[(size_t)j * Nc + i] == 0) {
+            const size_t idx = (size_t)j * (j + 1) / 2 + i;
+            packed[idx / 6] += (double)(1ull << (8 * (idx % 6)));
+          }
+      DevBuf<double> flags;
+      flags.upload(packed, stream);
+      allreduce_d(flags.p, packed.size());
+      packed = flags.download(stream);
+      for (int64_t j = 0; j < Nc; ++j)
+        for (int64_t i = 0; i <= j; ++i) {
+          const size_t idx = (size_t)j * (j + 1) / 2 + i;
+          if (((unsigned long long)packed[idx / 6] >> (8 * (idx % 6))) & 255ull) map[(size_t)j * Nc + i] = 0;
+        }
+    }
     h_S_colptr.assign(Nc + 1, 0); h_S_rowi.clear(); h_S_coli.clear(); h_S_diag.assign(Nc, -1);
     for (int64_t j = 0; j < Nc; ++j) {
       for (int64_t i = 0; i <= j; ++i)
@@ -593,13 +616,7 @@ template <typename T> struct Engine final : EngineBase {
     return sc;
   }
 
-  void check_sharded_solver(int solver) const {
-    if (comm && (solver == GR_SOLVER_PCG_SCHUR || solver == GR_SOLVER_DENSE_SCHUR))
-      throw std::invalid_argument("landmark-sharded problems support GR_SOLVER_PCG, GR_SOLVER_PCG_IDENTITY and GR_SOLVER_PCG_SCHUR_IMPLICIT "
-                                  "(the explicit Schur complement is not all-reduced)");
-  }
   void solver_update_structure(int solver) override {
-    check_sharded_solver(solver);
     if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
     else if (solver == GR_SOLVER_DENSE_SCHUR) { ensure_chol(); want_hcp = true; }
     else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) { want_hcp = false; ensure_implicit_schur(); }
@@ -636,19 +653,36 @@ template <typename T> struct Engine final : EngineBase {
     build_schur_structure();
     if (!hcp_valid) linearize_impl(true);
     const int ui = damping_identity ? 1 : 0;
+    const T *hcc_w = cam_weight() ? Hcc.p : nullptr; // the (global) camera blocks enter the all-reduced S once
     if (for_solve) k_point_prepare<T><<<cdiv(Np, TPB) + 1, TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, scalars(), sc_cap);
     else k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p);
-    if (nmulti) k_schur_multi<T, 0><<<cdiv(9 * (size_t)nmulti, TPB), TPB, 0, stream>>>(nmulti, multi_blk.p, S_rowi.p, S_coli.p, Hcc.p, scales.p, damping, ui, S.p);
+    if (nmulti) k_schur_multi<T, 0><<<cdiv(9 * (size_t)nmulti, TPB), TPB, 0, stream>>>(nmulti, multi_blk.p, S_rowi.p, S_coli.p, hcc_w, scales.p, damping, ui, S.p);
     {
       Scope sc(this, "schur_products", nprod * (54.0 * w() + 8) + 9.0 * Np * w() + 81.0 * nnzb * w(), nprod * 342.0);
-      k_schur_products<T><<<cdiv(nitems, 4), TPB, 0, stream>>>(nitems, item_blk.p, item_beg.p, item_end.p, item_single.p, prod_a.p, prod_b.p, S_rowi.p, S_coli.p, pt_pm.p, Hcp.p, Mp.p, Hcc.p, scales.p, damping, ui, S.p);
+      k_schur_products<T><<<cdiv(nitems, 4), TPB, 0, stream>>>(nitems, item_blk.p, item_beg.p, item_end.p, item_single.p, prod_a.p, prod_b.p, S_rowi.p, S_coli.p, pt_pm.p, Hcp.p, Mp.p, hcc_w, scales.p, damping, ui, S.p);
     }
-    if (nmulti) k_schur_multi<T, 1><<<cdiv(9 * (size_t)nmulti, TPB), TPB, 0, stream>>>(nmulti, multi_blk.p, S_rowi.p, S_coli.p, Hcc.p, scales.p, damping, ui, S.p);
+    if (nmulti) k_schur_multi<T, 1><<<cdiv(9 * (size_t)nmulti, TPB), TPB, 0, stream>>>(nmulti, multi_blk.p, S_rowi.p, S_coli.p, hcc_w, scales.p, damping, ui, S.p);
     {
       Scope sc(this, "b_schur", No * (27.0 * w() + 8) + 3.0 * Np * w(), No * 54.0);
       k_bschur_partial<T><<<cdiv(nch, 4), TPB, 0, stream>>>(nch, chunk_beg.p, pt_cm.p, pos_cm.p, Hcp.p, vl.p, part9.p);
     }
-    if (!for_solve) k_bschur_finalize<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p);
+    if (!for_solve || comm) k_bschur_finalize<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p, cam_weight());
+    if (comm) {
+      // every rank reduced over its own points (rank 0 also carries the damped Hcc and bc, which are global already):
+      // one grouped all-reduce makes S and b_S global, the solve that follows is replicated
+      Scope sc(this, "allreduce_schur", 0, 0);
+      comm->group_start();
+      allreduce_T(S.p, 81 * (size_t)nnzb);
+      allreduce_T(b_schur.p, (size_t)pose_dim);
+      comm->group_end();
+    }
+  }
+  // replicated reduced solves: rank 0's camera step is the one every rank applies (the per-rank copies agree
+  // only up to the order of the atomic dot-product partials, which must not leak into the replicated cameras)
+  void broadcast_camera_step(T *x) {
+    if (!comm) return;
+    if (comm->rank != 0) GR_HIP(hipMemsetAsync(x, 0, pose_dim * sizeof(T), stream));
+    allreduce_T(x, (size_t)pose_dim);
   }
   void schur_matvec_dev(const T *x, T *y, int k) {
     Scope sc(this, "schur_matvec", (2.0 * nnzb - Nc) * 81.0 * w(), (2.0 * nnzb - Nc) * 162.0);
@@ -719,13 +753,15 @@ template <typename T> struct Engine final : EngineBase {
     for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
     h_seq[1] = 0;
     schur_update_values_impl(true);
-    k_schur_pcg_prepare<T, 0><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, S.p, S_diag.p, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, nullptr, sc);
+    if (comm) k_schur_pcg_prepare<T, 1><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, S.p, S_diag.p, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, nullptr, sc);
+    else k_schur_pcg_prepare<T, 0><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, S.p, S_diag.p, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, nullptr, sc);
     const int noop = run_pcg_iterations(max_iter, [&](int k) {
       schur_matvec_dev(v_p.p, v_Ap.p, k);
       k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k);
       k_pcgs_direction<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_p.p, v_z.p, nullptr, nullptr, sc, k, tol, rej);
     });
     note_noop({"schur_matvec"}, noop);
+    broadcast_camera_step(x);
     landmark_update_dev(x, x + pose_dim);
     return 0;
   }
@@ -767,6 +803,7 @@ template <typename T> struct Engine final : EngineBase {
     k_chol_scatter<T><<<cdiv(81 * (size_t)nnzb, TPB), TPB, 0, stream>>>(nnzb, S_rowi.p, S_coli.p, S.p, chol.A.p, chol.ld());
     chol.factor();
     chol.solve(b_schur.p, x);
+    broadcast_camera_step(x);
     landmark_update_dev(x, x + pose_dim);
     h_seq[1] = 0;
     return chol.ok();
@@ -952,7 +989,6 @@ template <typename T> struct Engine final : EngineBase {
   }
   bool solver_solve_dev(int solver, int max_iter, double tol, double rej, T *x) {
     last_solver = solver;
-    check_sharded_solver(solver);
     switch (solver) {
     case GR_SOLVER_PCG_SCHUR: solve_pcg_schur(max_iter, tol, rej, x); return true;
     case GR_SOLVER_PCG: solve_pcg<false>(max_iter, tol, rej, x); return true;

@@ -192,7 +192,7 @@ __device__ __forceinline__ void schur_epilogue(int i, int j, int c, const T *acc
                                                T *__restrict__ out) {
   const T *si = scales + 9 * (size_t)i;
   const T sjc = scales[9 * (size_t)j + c];
-  if (i == j) {
+  if (i == j && Hcc) { // Hcc == nullptr: a landmark shard other than rank 0 (the camera blocks are added once)
     const T *H = Hcc + 81 * (size_t)i + 9 * c;
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
@@ -303,13 +303,14 @@ k_bschur_partial(int nch, const int *__restrict__ chunk_beg, const int *__restri
 }
 template <typename T>
 __global__ void k_bschur_finalize(int Nc, const int *__restrict__ cam_chunk_ptr, const T *__restrict__ partial9,
-                                  const T *__restrict__ bc, const T *__restrict__ scales, T *__restrict__ b_schur) {
+                                  const T *__restrict__ bc, const T *__restrict__ scales, T *__restrict__ b_schur,
+                                  int cam_weight = 1) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 9u * (unsigned)Nc) return;
   const unsigned c = t / 9u, r = t % 9u;
   T y = 0;
   for (int ch = cam_chunk_ptr[c]; ch < cam_chunk_ptr[c + 1]; ++ch) y += partial9[9 * (size_t)ch + r];
-  b_schur[t] = scales[t] * (bc[t] - y);
+  b_schur[t] = scales[t] * ((cam_weight ? bc[t] : T(0)) - y);
 }
 
 // x_l = Hll^-1 (b_l - Hpl^T x_p)     (schur.hpp:279-302): thread per observation (pm),
@@ -423,6 +424,7 @@ k_schur_matvec(int Nc, const int *__restrict__ row_ptr, const int *__restrict__ 
 
 // One launch, thread per camera, for everything between "S is complete" and the first iteration:
 //   MODE 0: b_S = Dc (bc^u - chunk partials) (schur.hpp:901-920), M = (S diagonal block)^-1
+//   MODE 1: b_S given (all-reduced over landmark shards), M = (S diagonal block)^-1
 //   MODE 2: b_S given (implicit Schur), M = Sdiag_c^-1
 // then r = b_S, z = p = M r, x = 0, q = s .* p (implicit only), rz[0] += r.z
 // (block_jacobi_schur.hpp:114-178, pcg_schur.hpp:79-104).  The PCG scalars were reset by k_point_prepare.
@@ -449,7 +451,7 @@ k_schur_pcg_prepare(int Nc, const T *__restrict__ Ssrc, const int *__restrict__ 
       for (int i = 0; i < 9; ++i) b[i] = b_schur[9 * (size_t)c + i];
     }
     double A[81];
-    const T *B = Ssrc + 81 * (size_t)(MODE == 0 ? diag_blk[c] : c);
+    const T *B = Ssrc + 81 * (size_t)(MODE != 2 ? diag_blk[c] : c);
 #pragma unroll
     for (int i = 0; i < 81; ++i) A[i] = (double)B[i];
     spd_inverse<9>(A);

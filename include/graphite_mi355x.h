@@ -187,8 +187,12 @@ gr_status gr_bal_kernel_stats(gr_bal_problem *p, gr_kernel_stat *out, int cap, i
 /* ---- multi-GPU (RCCL over xGMI) ----------------------------------------------------
  * One process per GPU.  Each rank creates its problem (gr_bal_create_shard) from ITS landmark
  * partition (all cameras, a contiguous range of points and all their observations);
- * camera-space sums are all-reduced.  Supported solvers: GR_SOLVER_PCG, GR_SOLVER_PCG_IDENTITY,
- * GR_SOLVER_PCG_SCHUR_IMPLICIT (one all-reduce of a 9 Nc vector per inner iteration).  unique_id: 128-byte ncclUniqueId produced on
+ * camera-space sums are all-reduced.  Every solver runs sharded: GR_SOLVER_PCG / _IDENTITY (two small
+ * all-reduces per inner iteration), GR_SOLVER_PCG_SCHUR_IMPLICIT (one all-reduce of a 9 Nc vector per inner
+ * iteration), GR_SOLVER_PCG_SCHUR / GR_SOLVER_DENSE_SCHUR (S and b_S all-reduced once per LM iteration,
+ * the reduced solve replicated; for small camera counts).  Calls that involve a collective
+ * (linearize, solver_update_structure, schur_update_values, solver_solve, chi2, levenberg_marquardt)
+ * must be made by all ranks in the same order.  unique_id: 128-byte ncclUniqueId produced on
  * rank 0 by gr_comm_unique_id and broadcast by the caller (e.g. torch.distributed). */
 gr_status gr_comm_unique_id(void *unique_id_128);
 gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int rank, int world_size);

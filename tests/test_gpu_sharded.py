@@ -68,13 +68,66 @@ def test_sharded_ladybug49_fp32():
     assert all(np.array_equal(c, cams[0]) for c in cams)
 
 
-def test_sharded_explicit_schur_is_refused():
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("solver", [ga.SOLVER_PCG_SCHUR, ga.SOLVER_DENSE_SCHUR])
+def test_sharded_explicit_schur_matches_single(world, solver):
+    """S and b_S are reduced over each shard's points and all-reduced; the replicated reduced solve
+    applies rank 0's camera step everywhere."""
     prob = synth.make_config("mini-50")
-    shards = [gdist.partition_by_landmark(prob, r, 2) for r in range(2)]
+    single = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    ct, lt, st = single.levenberg_marquardt(solver=solver, iterations=8)
+    c1, p1 = single.get_params()
+    single.close()
+    out, cams, pts = run_sharded(prob, world, np.float64, 8, solver)
+    for r in range(world):
+        ct_r, lt_r, st_r = out[r]
+        assert np.allclose(ct_r, ct, rtol=1e-9), (r, ct_r, ct)
+        assert np.allclose(lt_r, lt, rtol=1e-6)
+        assert np.array_equal(cams[r], cams[0])
+    assert out[0][2]["pcg_iterations"] == st["pcg_iterations"]
+    assert np.allclose(cams[0], c1, rtol=1e-7, atol=1e-10)
+    assert np.allclose(pts, p1, rtol=1e-7, atol=1e-10)
+
+
+def _schur_blocks(e, mu):
+    e.solver_update_structure(ga.SOLVER_PCG_SCHUR)
+    e.linearize()
+    e.solver_update_values(ga.SOLVER_PCG_SCHUR)
+    e.solver_set_damping(ga.SOLVER_PCG_SCHUR, mu)
+    e.schur_update_values()
+    cp, ri = e.schur_structure()
+    return cp, ri, e.get("S"), e.get("b_schur")
+
+
+def test_sharded_schur_complement_is_global():
+    """gr_bal_schur_update_values on shards: every rank ends with the S, b_S and block structure of the
+    unsharded problem (a shard alone only sees the co-observations of its own points)."""
+    prob = synth.make_problem(9, 300, 2400, seed=21)
+    single = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    colptr, rowidx, S1, b1 = _schur_blocks(single, 1e-3)
+    single.close()
+    world = 3
+    shards = [gdist.partition_by_landmark(prob, r, world) for r in range(world)]
     engines = [ga.BalProblem(s.cameras, s.points, s.obs, s.cam_idx, s.pt_idx, dtype=np.float64, shard=True) for s in shards]
     gdist.init_local_group(engines)
-    with pytest.raises(_lib.GraphiteError):
-        engines[0].levenberg_marquardt(solver=ga.SOLVER_PCG_SCHUR, iterations=1)
+    res = [None] * world
+    err = []
+
+    def work(r):
+        try:
+            res[r] = _schur_blocks(engines[r], 1e-3)
+        except Exception as ex:  # pragma: no cover
+            err.append(ex)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not err, err
+    for r in range(world):
+        cp, ri, S, b = res[r]
+        assert np.array_equal(cp, colptr) and np.array_equal(ri, rowidx)
+        assert np.allclose(S, S1, rtol=1e-10, atol=1e-12 * np.abs(S1).max())
+        assert np.allclose(b, b1, rtol=1e-10, atol=1e-12 * np.abs(b1).max())
     [e.close() for e in engines]
 
 
