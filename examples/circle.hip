@@ -5,6 +5,7 @@
 #include <array>
 #include <chrono>
 #include <graphite/optimizer/levenberg_marquardt.hpp>
+#include <string>
 #include <graphite/preconditioner/identity.hpp>
 #include <graphite/solver/pcg.hpp>
 #include <iostream>
@@ -139,7 +140,8 @@ int main(int argc, char **argv) {
   options.streams = &streams;
 
   auto start = std::chrono::steady_clock::now();
-  optimizer::levenberg_marquardt<FP, SP>(&graph, &options);
+  if (argc > 3 && std::string(argv[3]) == "lm2") optimizer::levenberg_marquardt2<FP, SP>(&graph, &options); // early termination variant
+  else optimizer::levenberg_marquardt<FP, SP>(&graph, &options);
   std::chrono::duration<double> elapsed = std::chrono::steady_clock::now() - start;
   std::cout << "Optimization took " << elapsed.count() << " seconds." << std::endl;
 

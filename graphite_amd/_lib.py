@@ -40,7 +40,7 @@ class GraphiteError(RuntimeError):
 class LMOptions(C.Structure):
     _fields_ = [("solver", C.c_int32), ("iterations", C.c_int32), ("initial_damping", C.c_double),
                 ("use_identity", C.c_int32), ("pcg_max_iter", C.c_int32), ("pcg_tol", C.c_double),
-                ("pcg_rejection_ratio", C.c_double), ("profile", C.c_int32), ("reserved", C.c_int32)]
+                ("pcg_rejection_ratio", C.c_double), ("profile", C.c_int32), ("early_stop", C.c_int32)]
 
 
 class LMStats(C.Structure):

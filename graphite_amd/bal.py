@@ -153,9 +153,9 @@ class BalProblem:
 
     # --- optimizer ------------------------------------------------------------------------
     def levenberg_marquardt(self, solver=SOLVER_PCG_SCHUR, iterations=10, initial_damping=1e-4,
-                            use_identity=False, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0, profile=False):
+                            use_identity=False, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0, profile=False, early_stop=False):
         opt = LMOptions(solver, iterations, initial_damping, int(use_identity), pcg_max_iter, pcg_tol, pcg_rej,
-                        int(profile), 0)
+                        int(profile), int(early_stop))
         st = LMStats()
         ct = np.full(iterations + 1, np.nan)
         lt = np.full(iterations + 1, np.nan)

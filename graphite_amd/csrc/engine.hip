@@ -1128,7 +1128,7 @@ template <typename T> struct Engine final : EngineBase {
                                                                                                     rho_partial.p, rho_blocks, nullptr, nullptr, 0, lm, pcg_iters.p, h_trace, h_trace + h_trace_cap, h_lm, h_lm + 1);
   }
   bool lm_graph_prepare(const gr_lm_options &opt) {
-    if (!lm_graph_enabled || comm || profiling || opt.iterations < 2 || opt.pcg_max_iter < 1) return false;
+    if (!lm_graph_enabled || comm || profiling || opt.early_stop || opt.iterations < 2 || opt.pcg_max_iter < 1) return false;
     if (opt.solver != GR_SOLVER_PCG && opt.solver != GR_SOLVER_PCG_IDENTITY) return false;
     if (getenv("GR_LM_SPECULATE") && atoi(getenv("GR_LM_SPECULATE")) == 0) return false;
     ensure_ctl(opt.pcg_max_iter);
@@ -1229,6 +1229,7 @@ template <typename T> struct Engine final : EngineBase {
     T chi2v = (T)read_scalar(0);
     bool run = true;
     int accept_streak = 2; // consecutive accepted iterations (saturating): speculate only on a streak
+    int num_bad = 0;       // levenberg_marquardt2 (:404-414): consecutive accepted iterations gaining < 0.1 %
     const bool spec_enabled = !(getenv("GR_LM_SPECULATE") && atoi(getenv("GR_LM_SPECULATE")) == 0);
     if (chi2_trace) chi2_trace[0] = (double)chi2v;
     if (lambda_trace) lambda_trace[0] = (double)mu;
@@ -1246,7 +1247,10 @@ template <typename T> struct Engine final : EngineBase {
       if (!solve_ok) new_chi2 = std::numeric_limits<T>::max();
       T denom = solve_ok ? (T)hs[1] + (T)1.0e-3 : T(1);
       const T rho = (chi2v - new_chi2) / denom;
+      const T initial_chi2 = chi2v;
+      bool step_accepted = false;
       if (solve_ok && std::isfinite(new_chi2) && rho > 0) {
+        step_accepted = true;
         double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3);
         alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
         mu *= (T)alpha;
@@ -1270,7 +1274,13 @@ template <typename T> struct Engine final : EngineBase {
       if (chi2_trace) chi2_trace[i + 1] = (double)chi2v;
       if (lambda_trace) lambda_trace[i + 1] = (double)mu;
       if (!std::isfinite(mu)) run = false;
-      return rho != 0;
+      if (rho == 0) return false;
+      if (opt.early_stop && step_accepted) {
+        if (((initial_chi2 - chi2v) * 1.0e3) < initial_chi2) num_bad++;
+        else num_bad = 0;
+        if (num_bad >= 3) return false;
+      }
+      return true;
     };
     // one host-driven iteration: solve, trial step, hand-shake, decision
     auto host_iteration = [&](int i) -> bool {

@@ -298,8 +298,9 @@ template <typename T, typename S> T compute_rho(Graph<T, S> *graph, const T *del
   return num / denom;
 }
 
-// :110-242
-template <typename T, typename S> bool levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {
+// :110-242 (EARLY = false) and :255-418 (EARLY = true: levenberg_marquardt2)
+namespace detail {
+template <bool EARLY, typename T, typename S> bool lm_loop(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {
   if (!options->validate()) return false;
   using clk = std::chrono::steady_clock;
   auto start = clk::now();
@@ -314,6 +315,8 @@ template <typename T, typename S> bool levenberg_marquardt(Graph<T, S> *graph, L
   T chi2 = graph->chi2();
   managed_vector<T> delta_x(graph->get_hessian_dimension());
   bool run = true;
+  int num_bad = 0;
+  constexpr int prec = EARLY ? 4 : 12, w0 = EARLY ? 10 : 18, w = EARLY ? 16 : 24; // table rows of :216-221 / :382-387
   if (options->verbose) {
     std::cout << std::setprecision(12) << std::setw(18) << "Iteration" << std::setw(24) << "Initial Chi2" << std::setw(24)
               << "Current Chi2" << std::setw(24) << "Lambda" << std::setw(24) << "Time" << std::setw(24) << "Total Time" << std::endl;
@@ -331,7 +334,9 @@ template <typename T, typename S> bool levenberg_marquardt(Graph<T, S> *graph, L
     if (!solve_ok) new_chi2 = std::numeric_limits<T>::max();
     const T rho = compute_rho(graph, delta_x.raw(), chi2, new_chi2, mu, solve_ok);
     const T chi2_before = chi2;
+    bool step_accepted = false;
     if (solve_ok && std::isfinite(new_chi2) && rho > 0) {
+      step_accepted = true;
       double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3);
       alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
       mu *= static_cast<T>(alpha);
@@ -350,13 +355,25 @@ template <typename T, typename S> bool levenberg_marquardt(Graph<T, S> *graph, L
     const double it_time = std::chrono::duration<double>(clk::now() - t0).count();
     time += it_time;
     if (options->verbose)
-      std::cout << std::setprecision(12) << std::setw(18) << i << std::setw(24) << chi2_before << std::setw(24) << new_chi2 << std::setw(24)
-                << mu << std::setw(24) << it_time << std::setw(24) << time << std::endl;
+      std::cout << std::setprecision(prec) << std::setw(w0) << i << std::setw(w) << chi2_before << std::setw(w) << new_chi2 << std::setw(w)
+                << mu << std::setw(w) << it_time << std::setw(w) << time << std::endl;
     if (!std::isfinite(mu)) { std::cout << "Damping factor is infinite, terminating optimization" << std::endl; run = false; }
     if (rho == 0) { std::cout << "Rho is zero, terminating optimization" << std::endl; break; }
     if (options->stop_flag && *options->stop_flag) { std::cout << "Stopping optimization due to stop flag" << std::endl; break; }
+    if (EARLY && step_accepted) { // :404-414
+      if (((chi2_before - new_chi2) * 1.0e3) < chi2_before) num_bad++;
+      else num_bad = 0;
+      if (num_bad >= 3) break;
+    }
   }
   return run;
+}
+} // namespace detail
+template <typename T, typename S> bool levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {
+  return detail::lm_loop<false>(graph, options);
+}
+template <typename T, typename S> bool levenberg_marquardt2(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {
+  return detail::lm_loop<true>(graph, options);
 }
 
 } // namespace optimizer

@@ -80,7 +80,8 @@ typedef struct {
   double pcg_tol;           /* bal.cu default 1.0 */
   double pcg_rejection_ratio; /* bal.cu default 5.0 */
   int32_t profile;          /* record HIP events around the dominant kernels */
-  int32_t reserved;
+  int32_t early_stop;       /* levenberg_marquardt2 (:255-418): also leave after 3 consecutive accepted
+                               iterations that each lower chi2 by less than 0.1 % */
 } gr_lm_options;
 
 typedef struct {

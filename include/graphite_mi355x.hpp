@@ -205,8 +205,9 @@ public:
 // options->verbose the reference's iteration table (:153-163, :216-221) is printed afterwards from
 // the recorded traces (per-iteration wall times are not recorded: the Time column shows the mean).
 // stop_flag is polled before the call only.
+namespace detail {
 template <typename T, typename S>
-bool levenberg_marquardt(BalGraph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, gr_lm_stats *stats_out = nullptr) {
+bool lm_call(BalGraph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, gr_lm_stats *stats_out, bool early_stop) {
   if (!options->validate()) {
     if (options->verbose) std::cerr << "Levenberg-Marquardt options invalid" << std::endl;
     return false;
@@ -217,6 +218,7 @@ bool levenberg_marquardt(BalGraph<T, S> *graph, LevenbergMarquardtOptions<T, S> 
   o.iterations = (int32_t)options->iterations;
   o.initial_damping = options->initial_damping;
   o.use_identity = options->use_identity;
+  o.early_stop = early_stop ? 1 : 0;
   int m; double t, r;
   options->solver->pcg_parameters(m, t, r);
   o.pcg_max_iter = m; o.pcg_tol = t; o.pcg_rejection_ratio = r;
@@ -228,12 +230,25 @@ bool levenberg_marquardt(BalGraph<T, S> *graph, LevenbergMarquardtOptions<T, S> 
               << "Current Chi2" << std::setw(24) << "Lambda" << std::setw(24) << "Time" << std::setw(24) << "Total Time" << std::endl;
     std::cout << std::string(138, '-') << std::endl;
     const double per_it = st.iterations_run ? st.loop_seconds / st.iterations_run : 0.0;
+    const int prec = early_stop ? 4 : 12, w0 = early_stop ? 10 : 18, w = early_stop ? 16 : 24; // the rows of :216-221 / :382-387
     for (int i = 0; i < st.iterations_run; ++i)
-      std::cout << std::setprecision(12) << std::setw(18) << i << std::setw(24) << chi2[i] << std::setw(24) << chi2[i + 1]
-                << std::setw(24) << lambda[i + 1] << std::setw(24) << per_it << std::setw(24) << st.setup_seconds + per_it * (i + 1) << std::endl;
+      std::cout << std::setprecision(prec) << std::setw(w0) << i << std::setw(w) << chi2[i] << std::setw(w) << chi2[i + 1]
+                << std::setw(w) << lambda[i + 1] << std::setw(w) << per_it << std::setw(w) << st.setup_seconds + per_it * (i + 1) << std::endl;
   }
   if (stats_out) *stats_out = st;
   return st.ok != 0;
+}
+} // namespace detail
+
+template <typename T, typename S>
+bool levenberg_marquardt(BalGraph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, gr_lm_stats *stats_out = nullptr) {
+  return detail::lm_call(graph, options, stats_out, false);
+}
+// optimizer/levenberg_marquardt.hpp:255-418: the same iteration, leaving early once three consecutive accepted
+// steps each lowered chi2 by less than 0.1 % (:404-414)
+template <typename T, typename S>
+bool levenberg_marquardt2(BalGraph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, gr_lm_stats *stats_out = nullptr) {
+  return detail::lm_call(graph, options, stats_out, true);
 }
 
 } // namespace optimizer

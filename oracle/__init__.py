@@ -298,13 +298,13 @@ class BalOracle:
         self._call("gro_bal_revert")
 
     def levenberg_marquardt(self, solver=SOLVER_PCG_SCHUR, iterations=10, initial_damping=1e-4,
-                            use_identity=False, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0):
+                            use_identity=False, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0, early_stop=False):
         ct = np.zeros(iterations + 1, np.float64)
         lt = np.zeros(iterations + 1, np.float64)
         st = np.zeros(6, np.float64)
         run = self._call("gro_bal_lm", C.c_int(solver), C.c_int(iterations), C.c_double(initial_damping),
                          C.c_int(int(use_identity)), C.c_int(pcg_max_iter), C.c_double(pcg_tol),
-                         C.c_double(pcg_rej), _p(ct), _p(lt), _p(st), restype=C.c_int)
+                         C.c_double(pcg_rej), _p(ct), _p(lt), _p(st), C.c_int(int(early_stop)), restype=C.c_int)
         k = int(st[0]) + 1
         stats = dict(iterations_run=int(st[0]), accepted=int(st[1]), pcg_iterations=int(st[2]),
                      solve_seconds=st[3], loop_seconds=st[4], setup_seconds=st[5], ok=bool(run))

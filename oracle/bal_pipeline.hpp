@@ -46,6 +46,7 @@ struct LMOptions {
   int pcg_max_iter = 10;
   double pcg_tol = 1.0;
   double pcg_rejection_ratio = 5.0;
+  int early_stop = 0; // levenberg_marquardt2 (:255-418): leave after 3 accepted steps that each gain < 0.1 %
 };
 
 struct LMStats {
@@ -640,7 +641,8 @@ template <typename T> struct BalOracle {
     return false;
   }
 
-  // optimizer/levenberg_marquardt.hpp:110-242.  chi2_trace gets the "Current
+  // optimizer/levenberg_marquardt.hpp:110-242 (and levenberg_marquardt2, :255-418, with opt.early_stop:
+  // the same iteration plus the ORB-SLAM-style termination of :404-414).  chi2_trace gets the "Current
   // Chi2" column (one entry per LM iteration), lambda_trace the damping after it.
   bool levenberg_marquardt(const LMOptions &opt, std::vector<double> &chi2_trace,
                            std::vector<double> &lambda_trace, LMStats &st) {
@@ -654,6 +656,7 @@ template <typename T> struct BalOracle {
     T chi2v = chi2();
     std::vector<T> dx(n, 0);
     bool run = true;
+    int num_bad = 0;
     st = LMStats();
     st.setup_seconds = std::chrono::duration<double>(clk::now() - t0).count();
     chi2_trace.clear(); lambda_trace.clear();
@@ -678,7 +681,10 @@ template <typename T> struct BalOracle {
         denom += T(1.0e-3);
       }
       const T rho = num / denom;
+      const T initial_chi2 = chi2v;
+      bool step_accepted = false;
       if (solve_ok && std::isfinite(new_chi2) && rho > 0) {
+        step_accepted = true;
         double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3);
         alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
         mu *= static_cast<T>(alpha);
@@ -699,6 +705,11 @@ template <typename T> struct BalOracle {
       chi2_trace.push_back((double)chi2v); lambda_trace.push_back((double)mu);
       if (!std::isfinite(mu)) run = false;
       if (rho == 0) break;
+      if (opt.early_stop && step_accepted) { // :404-414
+        if (((initial_chi2 - chi2v) * 1.0e3) < initial_chi2) num_bad++;
+        else num_bad = 0;
+        if (num_bad >= 3) break;
+      }
     }
     st.loop_seconds = std::chrono::duration<double>(clk::now() - tl).count();
     return run;

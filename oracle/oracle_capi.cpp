@@ -177,10 +177,11 @@ extern "C" {
   /* stats: [iterations_run, accepted, pcg_iterations, solve_s, loop_s, setup_s] */                 \
   int gro_bal_lm_##SFX(void *h, int solver, int iterations, double initial_damping,                 \
                        int use_identity, int pcg_max_iter, double pcg_tol, double pcg_rej,          \
-                       double *chi2_trace, double *lambda_trace, double *stats) {                   \
+                       double *chi2_trace, double *lambda_trace, double *stats, int early_stop) {   \
     LMOptions opt; opt.solver = solver; opt.iterations = iterations;                                \
     opt.initial_damping = initial_damping; opt.use_identity = use_identity;                         \
     opt.pcg_max_iter = pcg_max_iter; opt.pcg_tol = pcg_tol; opt.pcg_rejection_ratio = pcg_rej;      \
+    opt.early_stop = early_stop;                                                                    \
     std::vector<double> ct, lt; LMStats st;                                                         \
     const bool run = static_cast<BalOracle<T> *>(h)->levenberg_marquardt(opt, ct, lt, st);          \
     for (size_t k = 0; k < ct.size(); ++k) { chi2_trace[k] = ct[k]; lambda_trace[k] = lt[k]; }      \

@@ -55,6 +55,23 @@ def test_circle_example(which):
 
 
 @pytest.mark.gpu
+def test_circle_example_levenberg_marquardt2():
+    """optimizer::levenberg_marquardt2 (levenberg_marquardt.hpp:255-418): same answer, leaves once three accepted
+    steps in a row gain < 0.1 % instead of running all 100 iterations."""
+    exe = build_all()[0]
+    full = subprocess.run([exe, "5", "verbose"], capture_output=True, text=True, timeout=120)
+    early = subprocess.run([exe, "5", "verbose", "lm2"], capture_output=True, text=True, timeout=120)
+    print(early.stdout[-2000:], early.stderr[-500:])
+    assert early.returncode == 0 and "OK (0 failures)" in early.stdout
+    rows = lambda out: [ln.split() for ln in out.splitlines() if len(ln.split()) == 6 and ln.split()[0].isdigit()]
+    r_full, r_early = rows(full.stdout), rows(early.stdout)
+    assert 3 <= len(r_early) < len(r_full)
+    # the shared prefix is the same iteration (4 significant digits are printed by the early-stop table)
+    for a, b in zip(r_early[:-1], r_full):
+        assert np.isclose(float(a[2]), float(b[2]), rtol=2e-3, atol=1e-9)
+
+
+@pytest.mark.gpu
 def test_reference_known_answers_on_the_generic_kernels():
     """tests/factor.cu / tests/vertex.cu literal expectations (EXPECT_FLOAT_EQ, 4 ULP) on the HIP generic layer."""
     exe = build_all()[3]

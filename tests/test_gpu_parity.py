@@ -234,3 +234,23 @@ def test_levenberg_marquardt_graph_replay(oracle_mod, monkeypatch, name, dtype, 
         assert st["pcg_iterations"] == st_r["pcg_iterations"]
         assert st["iterations_run"] == st_r["iterations_run"] and st["accepted"] == st_r["accepted"]
     gpu.close()
+
+
+@pytest.mark.parametrize("solver", ["pcg", "pcg_schur", "pcg_schur_implicit", "dense_schur"])
+def test_levenberg_marquardt2_early_termination(oracle_mod, solver):
+    """gr_lm_options.early_stop = optimizer::levenberg_marquardt2 (levenberg_marquardt.hpp:255-418): the loop
+    leaves at the same iteration as the oracle's, with the same trace up to there."""
+    prob, gpu, ref = make_pair(oracle_mod, "mini-50", np.float64)
+    gs = dict(pcg=ga.SOLVER_PCG, pcg_schur=ga.SOLVER_PCG_SCHUR, pcg_schur_implicit=ga.SOLVER_PCG_SCHUR_IMPLICIT,
+              dense_schur=ga.SOLVER_DENSE_SCHUR)[solver]
+    os_ = dict(pcg=oracle_mod.SOLVER_PCG, pcg_schur=oracle_mod.SOLVER_PCG_SCHUR, pcg_schur_implicit=oracle_mod.SOLVER_PCG_SCHUR,
+               dense_schur=oracle_mod.SOLVER_LDLT_SCHUR)[solver]
+    ct_g, lt_g, st = gpu.levenberg_marquardt(solver=gs, iterations=40, early_stop=True)
+    ct_r, lt_r, st_r = ref.levenberg_marquardt(solver=os_, iterations=40, early_stop=True)
+    assert st["iterations_run"] == st_r["iterations_run"] < 40
+    assert np.allclose(ct_g, ct_r, rtol=1e-6) and np.allclose(lt_g, lt_r, rtol=1e-3)
+    gpu.set_params(prob.cameras, prob.points)
+    ct_full, _, st_full = gpu.levenberg_marquardt(solver=gs, iterations=40)
+    assert st_full["iterations_run"] > st["iterations_run"]
+    assert np.allclose(ct_full[:len(ct_g)], ct_g, rtol=1e-9)
+    gpu.close()
