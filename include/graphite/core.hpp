@@ -362,6 +362,8 @@ template <typename F> struct FactorView {
   T *chi2;       // [nf]
   S *dchi2;      // [nf]
   std::array<S *, N> jac;
+  bool dynamic;    // set_jacobian_storage(false): no stored blocks, every consumer recomputes them
+  const T *scales; // column scales applied to recomputed blocks (nullptr = unscaled)
   std::array<void *, N> verts; // Vertex** of each slot
   std::array<const uint8_t *, N> vstate;
   std::array<const size_t *, N> hid;
@@ -468,6 +470,30 @@ __global__ void k_jacobian(FactorView<F> fv, std::index_sequence<Is...> seq) {
   }
 }
 
+// Jacobian block of slot I of factor f: the stored (already scaled) block, or with set_jacobian_storage(false)
+// (factor.hpp:626-640; the *_dynamic kernels of ops/linearize.hpp:308, ops/hessian.hpp:272,478, ops/product.hpp:103,292)
+// the analytic block recomputed into `buf` and scaled the way the stored one would have been.
+template <typename F, size_t I, size_t... Is>
+__device__ inline const typename F::Storage *jac_block(const FactorView<F> &fv, size_t f, typename F::Storage *buf, std::index_sequence<Is...> seq) {
+  using T = typename F::Scalar;
+  using Sj = typename F::Storage;
+  constexpr size_t d = slot_dim<F, I>(), E = F::E;
+  if constexpr (std::is_same<typename F::Traits::Differentiation, DifferentiationMode::Manual>::value) {
+    if (fv.dynamic) {
+      auto v = gather_vertices<F, T>(fv, f, seq);
+      for (size_t k = 0; k < E * d; ++k) buf[k] = Sj(0);
+      call_jacobian<F, I>(v, fv.obs[f], fv.data[f], buf, seq);
+      if (fv.scales) {
+        const size_t col0 = fv.hid[I][fv.ids[f * F::N + I]];
+        for (size_t c = 0; c < d; ++c)
+          for (size_t i = 0; i < E; ++i) buf[c * E + i] = (Sj)((T)buf[c * E + i] * fv.scales[col0 + c]);
+      }
+      return buf;
+    }
+  }
+  return fv.jac[I] + f * E * d;
+}
+
 // chi2 = rho(r^T P r), dchi2 = rho'  (ops/chi2.hpp:10-44)
 template <typename F> __global__ void k_chi2(FactorView<F> fv) {
   using T = typename F::Scalar;
@@ -517,12 +543,15 @@ __global__ void k_slot(FactorView<F> fv, typename F::Scalar *out, const typename
   const size_t f = fv.active_ids[t / d], c = t % d;
   const size_t v = fv.ids[f * F::N + I];
   if (!is_vertex_active(fv.vstate[I], v)) return;
-  auto *J = fv.jac[I] + f * E * d + c * E;
+  typename F::Storage buf[E * d];
+  const auto *Jb = jac_block<F, I>(fv, f, buf, std::make_index_sequence<F::N>{});
+  const auto *J = Jb + c * E;
   const size_t col = fv.hid[I][v] + c;
   if constexpr (WHICH == 0) {
     atomicAdd(&out[col], jtpj(fv, f, J, J) * (T)fv.dchi2[f]);
-  } else if constexpr (WHICH == 1) {
-    for (size_t i = 0; i < E; ++i) J[i] = (typename F::Storage)((T)J[i] * in[col]);
+  } else if constexpr (WHICH == 1) { // stored blocks only
+    auto *Jw = fv.jac[I] + f * E * d + c * E;
+    for (size_t i = 0; i < E; ++i) Jw[i] = (typename F::Storage)((T)Jw[i] * in[col]);
   } else if constexpr (WHICH == 2) {
     T s = 0;
     for (size_t i = 0; i < E; ++i) {
@@ -540,7 +569,6 @@ __global__ void k_slot(FactorView<F> fv, typename F::Scalar *out, const typename
     }
     atomicAdd(&out[col], s * (T)fv.dchi2[f]);
   } else { // per-vertex d x d block, column-major: block(row, c) += rho' J_row^T P J_c
-    const auto *Jb = fv.jac[I] + f * E * d;
     for (size_t row = 0; row < d; ++row) atomicAdd(&out[v * d * d + row + c * d], jtpj(fv, f, Jb + row * E, J) * (T)fv.dchi2[f]);
   }
 }
@@ -554,8 +582,10 @@ template <typename F, size_t I> __global__ void k_Jv(FactorView<F> fv, typename 
   const size_t f = fv.active_ids[t / E], i = t % E;
   const size_t v = fv.ids[f * F::N + I];
   if (!is_vertex_active(fv.vstate[I], v)) return;
+  typename F::Storage buf[E * d];
+  const auto *Jb = jac_block<F, I>(fv, f, buf, std::make_index_sequence<F::N>{});
   T s = 0;
-  for (size_t c = 0; c < d; ++c) s += (T)fv.jac[I][f * E * d + c * E + i] * x[fv.hid[I][v] + c];
+  for (size_t c = 0; c < d; ++c) s += (T)Jb[c * E + i] * x[fv.hid[I][v] + c];
   res[f * E + i] += s; // slots are launched one after the other on one stream: no race
 }
 
@@ -568,7 +598,10 @@ template <typename F, size_t I, size_t K> __global__ void k_dense_pair(FactorVie
   const size_t f = fv.active_ids[t / (di * dk)], r = (t / dk) % di, c = t % dk;
   const size_t vi = fv.ids[f * F::N + I], vk = fv.ids[f * F::N + K];
   if (!is_vertex_active(fv.vstate[I], vi) || !is_vertex_active(fv.vstate[K], vk)) return;
-  const T val = jtpj(fv, f, fv.jac[I] + f * E * di + r * E, fv.jac[K] + f * E * dk + c * E) * (T)fv.dchi2[f];
+  typename F::Storage bi[E * di], bk[E * dk];
+  const auto *Ji = jac_block<F, I>(fv, f, bi, std::make_index_sequence<F::N>{});
+  const auto *Jk = jac_block<F, K>(fv, f, bk, std::make_index_sequence<F::N>{});
+  const T val = jtpj(fv, f, Ji + r * E, Jk + c * E) * (T)fv.dchi2[f];
   atomicAdd(&H[(fv.hid[I][vi] + r) * n + fv.hid[K][vk] + c], val);
 }
 
@@ -610,6 +643,7 @@ public:
   std::array<JacobianStorage, N> jacobians;
   managed_vector<T> scalar;                // device scalar for reductions
   bool store_jacobians = true;
+  const T *dynamic_scales = nullptr; // column scales of the current linearisation (dynamic Jacobians only)
 
   template <typename... VDs> explicit FactorDescriptor(VDs *...vds) {
     static_assert(sizeof...(VDs) == N, "one vertex descriptor per slot");
@@ -644,7 +678,10 @@ public:
   }
   void set_active(size_t id, uint8_t active_value) { active[id] = (active[id] & 0x80) | (active_value & 0x7F); } // factor.hpp:419-431
   void reset_active() { for (size_t i = 0; i < active.size(); ++i) active[i] = 0; }
-  void set_jacobian_storage(bool on) { store_jacobians = on; } // accepted; Jacobians are always stored here
+  // factor.hpp:626-640: false = no stored Jacobians, every product recomputes the analytic blocks (Manual
+  // differentiation only; an Auto factor keeps storing, ops/linearize.hpp:109)
+  void set_jacobian_storage(bool on) { store_jacobians = on; }
+  bool dynamic_jacobians() const { return !store_jacobians && supports_dynamic_jacobians(); }
   size_t add_factor(const std::array<size_t, N> &ids, const ObservationType &obs) { return add_factor(ids, obs, nullptr, ConstraintDataType(), LossType()); }
   static constexpr bool use_autodiff() { return std::is_same<typename Traits::Differentiation, DifferentiationMode::Auto>::value; }
   static constexpr bool supports_dynamic_jacobians() { return !use_autodiff(); }
@@ -680,6 +717,7 @@ public:
     fv.active_ids = active_indices.raw(); fv.n_active = active_count(); fv.ids = device_ids.raw(); fv.obs = device_obs.raw();
     fv.data = data.raw(); fv.loss = loss.raw(); fv.pmat = precision_matrices.raw(); fv.residuals = residuals.raw();
     fv.chi2 = chi2_vec.raw(); fv.dchi2 = chi2_derivative.raw();
+    fv.dynamic = dynamic_jacobians(); fv.scales = dynamic_scales;
     fill_view(fv, std::make_index_sequence<N>{});
     return fv;
   }
@@ -687,7 +725,10 @@ public:
     if (!active_count()) return;
     detail::k_error<FactorDescriptor><<<detail::blocks(active_count()), detail::TPB>>>(view(), std::make_index_sequence<N>{});
   }
-  void compute_jacobians() override { jac_all(std::make_index_sequence<N>{}); }
+  void compute_jacobians() override {
+    dynamic_scales = nullptr; // a new linearisation: the scalar diagonal is taken from unscaled blocks
+    if (!dynamic_jacobians()) jac_all(std::make_index_sequence<N>{});
+  }
   void compute_chi2() override {
     if (active_count()) detail::k_chi2<FactorDescriptor><<<detail::blocks(active_count()), detail::TPB>>>(view());
   }
@@ -700,7 +741,10 @@ public:
   }
   T chi2(size_t id) { detail::sync(); return chi2_vec[id]; }
   void scalar_diagonal(T *diag) override { slot_all<0>(diag, nullptr, std::make_index_sequence<N>{}); }
-  void scale_jacobians(const T *scales) override { slot_all<1>(nullptr, scales, std::make_index_sequence<N>{}); }
+  void scale_jacobians(const T *scales) override {
+    if (dynamic_jacobians()) dynamic_scales = scales;
+    else slot_all<1>(nullptr, scales, std::make_index_sequence<N>{});
+  }
   void compute_b(T *b) override { slot_all<2>(b, nullptr, std::make_index_sequence<N>{}); }
   void compute_Jtv(T *out, const T *res) override { slot_all<3>(out, res, std::make_index_sequence<N>{}); }
   void compute_Jv(T *res, const T *x) override { jv_all(res, x, std::make_index_sequence<N>{}); }
@@ -711,7 +755,7 @@ public:
 private:
   template <size_t... Is> void init_jacobians(std::index_sequence<Is...>) {
     ((jacobians[Is].dimensions[0] = E, jacobians[Is].dimensions[1] = detail::slot_dim<FactorDescriptor, Is>(),
-      jacobians[Is].data.resize(E * detail::slot_dim<FactorDescriptor, Is>() * internal_count())), ...);
+      jacobians[Is].data.resize(dynamic_jacobians() ? 0 : E * detail::slot_dim<FactorDescriptor, Is>() * internal_count())), ...);
   }
   template <size_t... Is> void fill_view(detail::FactorView<FactorDescriptor> &fv, std::index_sequence<Is...>) {
     ((fv.jac[Is] = jacobians[Is].data.raw(),

@@ -2,7 +2,7 @@
 // (camera 9, point 3, error dimension 2, automatic differentiation) and optimised with the generic
 // Graph / PCGSolver / EigenLDLTSolver / levenberg_marquardt.  Prints the chi2 trace; tests/test_generic_api.py
 // compares it with the CPU oracle's LM on the same file.
-//   usage: test_generic_bal <bal file> <pcg|pcg-identity|eigen> <iterations>
+//   usage: test_generic_bal <bal file> <pcg|pcg-identity|eigen> <iterations> [auto|stored|dynamic]
 #include <fstream>
 #include <graphite/optimizer/levenberg_marquardt.hpp>
 #include <graphite/preconditioner/block_jacobi.hpp>
@@ -69,13 +69,34 @@ template <typename T, typename S> struct ReprojectionErrorTraits {
 };
 template <typename T, typename S> using ReprojectionError = FactorDescriptor<T, S, ReprojectionErrorTraits<T, S>>;
 
+// The same factor with a user-written Traits::jacobian (Manual differentiation, main.md:294-315) — the only
+// kind that can run without stored Jacobians (factor.hpp:626-647).  The blocks are E x d column-major.
+template <typename T, typename S> struct ReprojectionErrorManualTraits : ReprojectionErrorTraits<T, S> {
+  using Differentiation = DifferentiationMode::Manual;
+  template <typename Sj, size_t I>
+  d_fn static void jacobian(const Camera<T> &cam, const Point3<T> &pt, const Pixel<T> &obs, Sj *jac) {
+    using D = Dual<T, T>;
+    constexpr int d = I == 0 ? 9 : 3;
+    for (int c = 0; c < d; ++c) {
+      D cp[9], pp[3], err[2];
+      for (int k = 0; k < 9; ++k) cp[k] = D(cam(k));
+      for (int k = 0; k < 3; ++k) pp[k] = D(pt(k));
+      (I == 0 ? cp[c] : pp[c]).dual = T(1);
+      reprojection<D, T>(cp, pp, obs, err);
+      jac[2 * c] = (Sj)err[0].dual;
+      jac[2 * c + 1] = (Sj)err[1].dual;
+    }
+  }
+};
+template <typename T, typename S> using ReprojectionErrorManual = FactorDescriptor<T, S, ReprojectionErrorManualTraits<T, S>>;
+
 } // namespace graphite
 
-int main(int argc, char **argv) {
+template <template <typename, typename> class Factor> static int run(int argc, char **argv) {
   using namespace graphite;
   using FP = double;
   using SP = double;
-  if (argc < 4) { std::cerr << "usage: test_generic_bal <file> <pcg|pcg-identity|eigen> <iterations>" << std::endl; return 2; }
+  if (argc < 4) { std::cerr << "usage: test_generic_bal <file> <pcg|pcg-identity|eigen> <iterations> [auto|stored|dynamic]" << std::endl; return 2; }
   (void)hipSetDevice(0);
   std::ifstream file(argv[1]);
   size_t nc = 0, np = 0, no = 0;
@@ -98,9 +119,12 @@ int main(int argc, char **argv) {
   for (size_t c = 0; c < nc; ++c) cam_desc.add_vertex(c, &cams[c]);
   for (size_t p = 0; p < np; ++p) pt_desc.add_vertex(nc + p, &pts[p]); // ids are global across descriptors
   pt_desc.set_eliminate(true);
-  ReprojectionError<FP, SP> r_desc(&cam_desc, &pt_desc);
+  Factor<FP, SP> r_desc(&cam_desc, &pt_desc);
   r_desc.reserve(no);
   graph.add_descriptor(&r_desc);
+  const std::string jmode = argc > 4 ? argv[4] : "auto";
+  if (jmode == "dynamic") r_desc.set_jacobian_storage(false); // factor.hpp:626-640
+  std::cout << "JACOBIANS " << (r_desc.dynamic_jacobians() ? "dynamic" : r_desc.use_autodiff() ? "auto" : "stored") << std::endl;
   const DefaultLoss<FP, 2> loss;
   for (size_t i = 0; i < no; ++i) r_desc.add_factor({ci[i], nc + pi[i]}, ob[i], nullptr, Empty(), loss);
 
@@ -127,4 +151,10 @@ int main(int argc, char **argv) {
   std::cout << std::endl << (ok ? "OK" : "STOPPED") << std::endl;
   solver.reset();
   return 0;
+}
+
+int main(int argc, char **argv) {
+  // auto: dual-number Jacobians (stored); stored | dynamic: the Manual factor with / without Jacobian storage
+  const std::string jmode = argc > 4 ? argv[4] : "auto";
+  return jmode == "auto" ? run<graphite::ReprojectionError>(argc, argv) : run<graphite::ReprojectionErrorManual>(argc, argv);
 }

@@ -189,6 +189,30 @@ int main() {
     EXPECT_FLOAT_EQ(blk[0], 8.0f); EXPECT_FLOAT_EQ(blk[1], 12.0f); EXPECT_FLOAT_EQ(blk[2], 12.0f); EXPECT_FLOAT_EQ(blk[3], 18.0f);
     EXPECT_FLOAT_EQ(diag[0], 8.0f); EXPECT_FLOAT_EQ(diag[1], 18.0f);
   }
+  { // the same expectations with set_jacobian_storage(false) (factor.hpp:626-640): nothing stored, blocks recomputed
+    Fixture fx; CoupledManualFactor factor(&fx.vertex_desc);
+    factor.set_jacobian_storage(false);
+    EXPECT_EQ(factor.dynamic_jacobians(), true);
+    factor.add_factor({10}, 2.5f); factor.add_factor({10}, 2.5f);
+    factor.initialize_device_ids(0);
+    factor.compute_jacobians(); factor.compute_error(); factor.chi2();
+    EXPECT_EQ(factor.jacobians[0].data.size(), 0u);
+    graphite::managed_vector<float> blk(4, 0.0f), diag(2, 0.0f), b(2, 0.0f), sc(2);
+    factor.block_diagonal(0, blk.data().get()); factor.scalar_diagonal(diag.data().get()); factor.compute_b(b.data().get()); dsync();
+    EXPECT_FLOAT_EQ(blk[0], 8.0f); EXPECT_FLOAT_EQ(blk[1], 12.0f); EXPECT_FLOAT_EQ(blk[2], 12.0f); EXPECT_FLOAT_EQ(blk[3], 18.0f);
+    EXPECT_FLOAT_EQ(diag[0], 8.0f); EXPECT_FLOAT_EQ(diag[1], 18.0f);
+    const float r = 2.0f * 7.0f + 3.0f * 0.0f - 2.5f; // CoupledUnaryFactorTraits: J = [2 3]
+    EXPECT_FLOAT_EQ(b[0], -2.0f * 2.0f * r); EXPECT_FLOAT_EQ(b[1], -2.0f * 3.0f * r);
+    // column scales act on the recomputed blocks exactly as they would on stored ones
+    sc[0] = 0.5f; sc[1] = 2.0f;
+    factor.scale_jacobians(sc.data().get());
+    blk[0] = blk[1] = blk[2] = blk[3] = 0.0f;
+    factor.block_diagonal(0, blk.data().get()); dsync();
+    EXPECT_FLOAT_EQ(blk[0], 8.0f * 0.25f); EXPECT_FLOAT_EQ(blk[1], 12.0f); EXPECT_FLOAT_EQ(blk[3], 18.0f * 4.0f);
+    // an Auto factor keeps storing (ops/linearize.hpp:109)
+    CoupledAutoFactor af(&fx.vertex_desc); af.set_jacobian_storage(false);
+    EXPECT_EQ(af.dynamic_jacobians(), false);
+  }
   { // ComputeJvHuberLoss / ComputeJtvHuberLoss (factor.cu:597-756)
     Fixture fx; ManualHuberFactor factor(&fx.vertex_desc);
     const HuberLoss<float, 1> huber(1.0f);

@@ -90,16 +90,19 @@ def parse_trace(out):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("jacobians", ["auto", "stored", "dynamic"])
 @pytest.mark.parametrize("solver", ["pcg", "pcg-identity", "eigen"])
-def test_generic_bal_matches_oracle(oracle_mod, tmp_path, solver):
+def test_generic_bal_matches_oracle(oracle_mod, tmp_path, solver, jacobians):
+    """"dynamic": FactorDescriptor::set_jacobian_storage(false) (factor.hpp:626-640), every product recomputes
+    the analytic blocks; the iterates are those of the stored mode."""
     exe = build_all()[2]
     prob = synth.make_config("mini-50")
     f = tmp_path / "problem.txt"
     synth.write_bal(f, prob)
     prob = synth.read_bal(f)  # the text round trip is what the executable sees
-    r = subprocess.run([exe, str(f), solver, "8"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(f), solver, "8", jacobians], capture_output=True, text=True, timeout=300)
     print(r.stdout[-3000:], r.stderr[-500:])
-    assert r.returncode == 0
+    assert r.returncode == 0 and f"JACOBIANS {jacobians}" in r.stdout
     tr = parse_trace(r.stdout)
     ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
     os_ = {"pcg": oracle_mod.SOLVER_PCG, "pcg-identity": oracle_mod.SOLVER_PCG_IDENTITY, "eigen": oracle_mod.SOLVER_LDLT}[solver]
