@@ -817,7 +817,7 @@ template <typename T, typename S> class Graph {
   std::vector<BaseVertexDescriptor<T, S> *> vertex_descriptors;
   std::vector<BaseFactorDescriptor<T, S> *> factor_descriptors;
   managed_vector<T> b, jacobian_scales;
-  size_t hessian_dim = 0;
+  size_t hessian_dim = 0, pose_dim = 0;
   bool scale_jacobians_ = true;
 public:
   void add_descriptor(BaseVertexDescriptor<T, S> *d) { vertex_descriptors.push_back(d); }
@@ -828,6 +828,8 @@ public:
   std::vector<BaseFactorDescriptor<T, S> *> &get_factor_descriptors() { return factor_descriptors; }
   void scale_system(bool on) { scale_jacobians_ = on; }
   size_t get_hessian_dimension() const { return hessian_dim; }
+  // first column of the eliminated (set_eliminate) descriptors = dimension of the reduced system (pcg_schur.hpp:60-61)
+  size_t get_pose_dimension() const { return pose_dim; }
   managed_vector<T> &get_b() { return b; }
   managed_vector<T> &get_jacobian_scales() { return jacobian_scales; }
   void clear() { vertex_descriptors.clear(); factor_descriptors.clear(); }
@@ -843,7 +845,8 @@ public:
       if (vd->count()) detail::k_xor_msb<T><<<detail::blocks(vd->count()), detail::TPB>>>(vd->get_active_state(), vd->count());
     detail::sync();
     size_t col = 0;
-    for (int pass = 0; pass < 2; ++pass) // non-eliminated descriptors first, eliminated ones last (graph.hpp:100-149)
+    for (int pass = 0; pass < 2; ++pass) { // non-eliminated descriptors first, eliminated ones last (graph.hpp:100-149)
+      if (pass == 1) pose_dim = col;
       for (auto *vd : vertex_descriptors) {
         if ((int)vd->eliminate != pass) continue;
         std::vector<std::pair<size_t, size_t>> order;
@@ -853,6 +856,7 @@ public:
         for (auto &e : order)
           if (detail::is_vertex_active(vd->get_active_state(), e.second)) { vd->get_hessian_ids()[e.second] = col; col += vd->dimension(); }
       }
+    }
     hessian_dim = col;
     b.resize(col); jacobian_scales.resize(col);
     return col > 0;

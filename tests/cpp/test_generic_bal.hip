@@ -2,13 +2,16 @@
 // (camera 9, point 3, error dimension 2, automatic differentiation) and optimised with the generic
 // Graph / PCGSolver / EigenLDLTSolver / levenberg_marquardt.  Prints the chi2 trace; tests/test_generic_api.py
 // compares it with the CPU oracle's LM on the same file.
-//   usage: test_generic_bal <bal file> <pcg|pcg-identity|eigen> <iterations> [auto|stored|dynamic]
+//   usage: test_generic_bal <bal file> <pcg|pcg-identity|eigen|pcg-schur|eigen-schur> <iterations> [auto|stored|dynamic]
 #include <fstream>
 #include <graphite/optimizer/levenberg_marquardt.hpp>
 #include <graphite/preconditioner/block_jacobi.hpp>
 #include <graphite/preconditioner/identity.hpp>
+#include <graphite/preconditioner/block_jacobi_schur.hpp>
 #include <graphite/solver/eigen.hpp>
+#include <graphite/solver/eigen_schur.hpp>
 #include <graphite/solver/pcg.hpp>
+#include <graphite/solver/pcg_schur.hpp>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -96,7 +99,7 @@ template <template <typename, typename> class Factor> static int run(int argc, c
   using namespace graphite;
   using FP = double;
   using SP = double;
-  if (argc < 4) { std::cerr << "usage: test_generic_bal <file> <pcg|pcg-identity|eigen> <iterations> [auto|stored|dynamic]" << std::endl; return 2; }
+  if (argc < 4) { std::cerr << "usage: test_generic_bal <file> <pcg|pcg-identity|eigen|pcg-schur|eigen-schur> <iterations> [auto|stored|dynamic]" << std::endl; return 2; }
   (void)hipSetDevice(0);
   std::ifstream file(argv[1]);
   size_t nc = 0, np = 0, no = 0;
@@ -131,10 +134,13 @@ template <template <typename, typename> class Factor> static int run(int argc, c
   const std::string kind = argv[2];
   BlockJacobiPreconditioner<FP, SP> bj;
   IdentityPreconditioner<FP, SP> id;
+  BlockJacobiSchurPreconditioner<FP, SP> bjs;
   std::unique_ptr<Solver<FP, SP>> solver;
   if (kind == "pcg") solver.reset(new PCGSolver<FP, SP>(10, 1.0, 5.0, &bj));
   else if (kind == "pcg-identity") solver.reset(new PCGSolver<FP, SP>(10, 1.0, 5.0, &id));
   else if (kind == "eigen") solver.reset(new EigenLDLTSolver<FP, SP>());
+  else if (kind == "pcg-schur") solver.reset(new PCGSchurSolver<FP, SP>(10, 1.0, 5.0, &bjs)); // points are set_eliminate(true)
+  else if (kind == "eigen-schur") solver.reset(new EigenSchurLDLTSolver<FP, SP>());
   else return 2;
 
   StreamPool streams(2);

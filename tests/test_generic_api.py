@@ -91,7 +91,7 @@ def parse_trace(out):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("jacobians", ["auto", "stored", "dynamic"])
-@pytest.mark.parametrize("solver", ["pcg", "pcg-identity", "eigen"])
+@pytest.mark.parametrize("solver", ["pcg", "pcg-identity", "eigen", "pcg-schur", "eigen-schur"])
 def test_generic_bal_matches_oracle(oracle_mod, tmp_path, solver, jacobians):
     """"dynamic": FactorDescriptor::set_jacobian_storage(false) (factor.hpp:626-640), every product recomputes
     the analytic blocks; the iterates are those of the stored mode."""
@@ -105,7 +105,8 @@ def test_generic_bal_matches_oracle(oracle_mod, tmp_path, solver, jacobians):
     assert r.returncode == 0 and f"JACOBIANS {jacobians}" in r.stdout
     tr = parse_trace(r.stdout)
     ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
-    os_ = {"pcg": oracle_mod.SOLVER_PCG, "pcg-identity": oracle_mod.SOLVER_PCG_IDENTITY, "eigen": oracle_mod.SOLVER_LDLT}[solver]
+    os_ = {"pcg": oracle_mod.SOLVER_PCG, "pcg-identity": oracle_mod.SOLVER_PCG_IDENTITY, "eigen": oracle_mod.SOLVER_LDLT,
+           "pcg-schur": oracle_mod.SOLVER_PCG_SCHUR, "eigen-schur": oracle_mod.SOLVER_LDLT_SCHUR}[solver]
     ct, lt, _ = ref.levenberg_marquardt(solver=os_, iterations=8)
     assert len(tr) == len(ct) - 1
     assert np.allclose(tr[:, 0], ct[:-1], rtol=1e-7)   # "Initial Chi2" column
