@@ -222,6 +222,9 @@ public:
   virtual void apply_update(const T *delta_x, const T *scales) = 0;
   virtual void backup_parameters() = 0;
   virtual void restore_parameters() = 0;
+  // parameter blocks of all vertices in local order, [count x dimension] (engine hand-over, see solve.hpp)
+  virtual void gather_parameters(T *out) = 0;
+  virtual void scatter_parameters(const T *in) = 0;
   bool eliminate = false; // set_eliminate (vertex.hpp:98): kept for API parity, the PCG path ignores it
   void set_eliminate(bool e) { eliminate = e; }
 };
@@ -235,6 +238,24 @@ __global__ void k_vertex_update(typename Tr::Vertex **x, const uint8_t *state, c
   T d[Tr::dimension];
   for (size_t k = 0; k < Tr::dimension; ++k) d[k] = dx[hid[i] + k] * (scales ? scales[hid[i] + k] : T(1)); // ops/update.hpp:26
   Tr::update(*x[i], d);
+}
+template <typename T, typename Tr>
+__global__ void k_vertex_gather(typename Tr::Vertex **x, size_t n, T *out) {
+  const size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  T p[Tr::dimension];
+  Tr::parameters(*x[v], p);
+  for (size_t k = 0; k < Tr::dimension; ++k) out[v * Tr::dimension + k] = p[k];
+}
+// moves every vertex onto the given parameters through Traits::update (the only write access the traits offer)
+template <typename T, typename Tr>
+__global__ void k_vertex_scatter(typename Tr::Vertex **x, size_t n, const T *in) {
+  const size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  T p[Tr::dimension], d[Tr::dimension];
+  Tr::parameters(*x[v], p);
+  for (size_t k = 0; k < Tr::dimension; ++k) d[k] = in[v * Tr::dimension + k] - p[k];
+  Tr::update(*x[v], d);
 }
 template <typename Tr, typename St>
 __global__ void k_vertex_backup(typename Tr::Vertex **x, const uint8_t *state, size_t n, St *bak) {
@@ -316,6 +337,12 @@ public:
   void restore_parameters() override {
     if (count()) detail::k_vertex_restore<Traits, StateType><<<detail::blocks(count()), detail::TPB>>>(vertices(), get_active_state(), count(), backup_state.raw());
   }
+  void gather_parameters(T *out) override {
+    if (count()) detail::k_vertex_gather<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), count(), out);
+  }
+  void scatter_parameters(const T *in) override {
+    if (count()) detail::k_vertex_scatter<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), count(), in);
+  }
 };
 
 // =================================================================================================
@@ -343,6 +370,11 @@ public:
   virtual size_t num_slots() const = 0;
   virtual BaseVertexDescriptor<T, S> *slot_descriptor(size_t slot) const = 0;
   virtual void dense_hessian(T *H, size_t n) = 0; // upper + lower, for the direct solver
+  // A factor descriptor whose traits declare `static constexpr bool bal_reprojection_model = true` (camera 9 =
+  // [angle-axis, t, f, k1, k2], point 3, pixel residual of examples/reprojection_error.cuh) can hand its active
+  // factors to the specialised BAL engine: local camera / point ids, 2 observation scalars per factor, loss.
+  // false = not that model, or something the engine does not represent (precision matrices, mixed losses...).
+  virtual bool export_bal(std::vector<int32_t> &, std::vector<int32_t> &, std::vector<T> &, int &, double &) { return false; }
 };
 
 namespace detail {
@@ -369,6 +401,10 @@ template <typename F> struct FactorView {
   std::array<const size_t *, N> hid;
 };
 
+template <typename Tr, typename = void> struct has_bal_tag : std::false_type {};
+template <typename Tr> struct has_bal_tag<Tr, std::enable_if_t<Tr::bal_reprojection_model>> : std::true_type {};
+template <typename O> auto obs_component(const O &o, int i, int) -> decltype((double)o(i)) { return (double)o(i); }
+template <typename O> auto obs_component(const O &o, int i, long) -> decltype((double)o[i]) { return (double)o[i]; }
 template <typename F, size_t I> using slot_traits = typename std::tuple_element<I, typename F::Traits::VertexDescriptors>::type::Traits;
 template <typename F, size_t I> using slot_vertex = typename slot_traits<F, I>::Vertex;
 template <typename F, size_t I> constexpr size_t slot_dim() { return slot_traits<F, I>::dimension; }
@@ -751,6 +787,31 @@ public:
   T *work_residual() override { return work.raw(); }
   void block_diagonal(size_t slot, T *blocks) override { block_one(slot, blocks, std::make_index_sequence<N>{}); }
   void dense_hessian(T *H, size_t n) override { dense_all(H, n, std::make_index_sequence<N>{}); }
+  bool export_bal(std::vector<int32_t> &cam, std::vector<int32_t> &pt, std::vector<T> &obs, int &loss_kind, double &loss_delta) override {
+    if constexpr (detail::has_bal_tag<Traits>::value && N == 2 && E == 2) {
+      constexpr bool plain = std::is_same<LossType, DefaultLoss<T, 2>>::value, huber = std::is_same<LossType, HuberLoss<T, 2>>::value;
+      if constexpr ((plain || huber) && detail::slot_dim<FactorDescriptor, 0>() == 9 && detail::slot_dim<FactorDescriptor, 1>() == 3) {
+        const size_t nf = internal_count();
+        if (!nf || active_count() != nf) return false; // the engine optimises every factor it is given
+        detail::sync();
+        loss_kind = huber ? 1 : 0; loss_delta = 0;
+        cam.resize(nf); pt.resize(nf); obs.resize(2 * nf);
+        for (size_t f = 0; f < nf; ++f) {
+          for (size_t i = 0; i < 2; ++i)
+            for (size_t j = 0; j < 2; ++j)
+              if (precision_matrices[f * 4 + i * 2 + j] != (i == j ? S(1) : S(0))) return false;
+          if constexpr (huber) {
+            if (f == 0) loss_delta = (double)loss[0].delta;
+            else if ((double)loss[f].delta != loss_delta) return false;
+          }
+          cam[f] = (int32_t)device_ids[2 * f]; pt[f] = (int32_t)device_ids[2 * f + 1];
+          obs[2 * f] = (T)detail::obs_component(device_obs[f], 0, 0); obs[2 * f + 1] = (T)detail::obs_component(device_obs[f], 1, 0);
+        }
+        return true;
+      }
+    }
+    return false;
+  }
 
 private:
   template <size_t... Is> void init_jacobians(std::index_sequence<Is...>) {
@@ -827,6 +888,7 @@ public:
   std::vector<BaseVertexDescriptor<T, S> *> &get_vertex_descriptors() { return vertex_descriptors; }
   std::vector<BaseFactorDescriptor<T, S> *> &get_factor_descriptors() { return factor_descriptors; }
   void scale_system(bool on) { scale_jacobians_ = on; }
+  bool scales_system() const { return scale_jacobians_; }
   size_t get_hessian_dimension() const { return hessian_dim; }
   // first column of the eliminated (set_eliminate) descriptors = dimension of the reduced system (pcg_schur.hpp:60-61)
   size_t get_pose_dimension() const { return pose_dim; }

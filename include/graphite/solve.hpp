@@ -100,10 +100,12 @@ public:
   virtual void update_values(Graph<T, S> *graph, StreamPool &streams) = 0;
   virtual void set_damping_factor(Graph<T, S> *graph, T damping_factor, const bool use_identity, StreamPool &streams) = 0;
   virtual void apply(Graph<T, S> *graph, T *z, const T *r, StreamPool &streams) = 0;
+  virtual int engine_kind() const { return -1; } // gr_solver this preconditioner turns PCGSolver into, -1 = none
 };
 
 template <typename T, typename S> class IdentityPreconditioner : public Preconditioner<T, S> {
 public:
+  int engine_kind() const override { return GR_SOLVER_PCG_IDENTITY; }
   void update_structure(Graph<T, S> *, StreamPool &) override {}
   void update_values(Graph<T, S> *, StreamPool &) override {}
   void set_damping_factor(Graph<T, S> *, T, const bool, StreamPool &) override {}
@@ -116,6 +118,7 @@ public:
 template <typename T, typename S> class BlockJacobiPreconditioner : public Preconditioner<T, S> {
   std::vector<std::unique_ptr<managed_vector<T>>> blocks, inverses;
 public:
+  int engine_kind() const override { return GR_SOLVER_PCG; }
   void update_structure(Graph<T, S> *graph, StreamPool &) override {
     auto &vds = graph->get_vertex_descriptors();
     blocks.clear(); inverses.clear();
@@ -158,6 +161,10 @@ public:
   virtual void update_values(Graph<T, S> *graph, StreamPool &streams) = 0;
   virtual void set_damping_factor(Graph<T, S> *graph, T damping_factor, const bool use_identity, StreamPool &streams) = 0;
   virtual bool solve(Graph<T, S> *graph, T *delta_x, StreamPool &streams) = 0;
+  // the gr_solver of libgraphite_mi355x.so that runs the same algorithm on a BAL-model graph (-1 = none), and its
+  // PCG parameters: used by the optimizer to hand tagged bundle-adjustment graphs to the specialised engine
+  virtual int engine_kind(size_t /*num_cameras*/) const { return -1; }
+  virtual void engine_pcg_parameters(int &max_iter, double &tol, double &rejection_ratio) const { max_iter = 10; tol = 1.0; rejection_ratio = 5.0; }
 };
 
 // solver/pcg.hpp:35-232: matrix-free PCG on (J^T rho' P J + mu D) x = b; same iterates, stopping and
@@ -174,6 +181,8 @@ public:
   PCGSolver(size_t max_iter_, T tol_, T rejection_ratio_, Preconditioner<T, S> *preconditioner_)
       : max_iter(max_iter_), tol(tol_), rejection_ratio(rejection_ratio_), preconditioner(preconditioner_) { scratch.resize(1); }
   size_t last_iterations() const { return iterations_; }
+  int engine_kind(size_t) const override { return preconditioner->engine_kind(); }
+  void engine_pcg_parameters(int &m, double &t, double &rj) const override { m = (int)max_iter; t = (double)tol; rj = (double)rejection_ratio; }
   void update_structure(Graph<T, S> *graph, StreamPool &streams) override {
     const size_t n = graph->get_hessian_dimension();
     r.resize(n); p.resize(n); z.resize(n); v2.resize(n); diag.resize(n); y.resize(n); xb.resize(n);
@@ -410,10 +419,12 @@ public:
   virtual void update_values(Graph<T, S> *graph, DenseSchurComplement<T, S> *schur, StreamPool &streams) = 0;
   virtual void set_damping_factor(Graph<T, S> *graph, DenseSchurComplement<T, S> *schur, T damping_factor, const bool use_identity, StreamPool &streams) = 0;
   virtual void apply(Graph<T, S> *graph, DenseSchurComplement<T, S> *schur, T *z, const T *r, StreamPool &streams) = 0;
+  virtual bool is_block_jacobi() const { return false; }
 };
 template <typename T, typename S> class BlockJacobiSchurPreconditioner : public SchurPreconditioner<T, S> {
   std::vector<std::unique_ptr<managed_vector<T>>> blocks, inverses;
 public:
+  bool is_block_jacobi() const override { return true; }
   void update_structure(Graph<T, S> *graph, DenseSchurComplement<T, S> *, StreamPool &) override {
     blocks.clear(); inverses.clear();
     for (auto *vd : graph->get_vertex_descriptors()) {
@@ -453,6 +464,11 @@ public:
   PCGSchurSolver(size_t max_iter_, T tol_, T rejection_ratio_, SchurPreconditioner<T, S> *preconditioner_)
       : preconditioner(preconditioner_), max_iter(max_iter_), tol(tol_), rejection_ratio(rejection_ratio_) { scratch.resize(1); }
   size_t last_iterations() const { return iterations_; }
+  // explicit S while its dense block map fits the engine (16384 cameras), the implicit form (same iterates) beyond
+  int engine_kind(size_t num_cameras) const override {
+    return !preconditioner->is_block_jacobi() ? -1 : num_cameras <= 16384 ? GR_SOLVER_PCG_SCHUR : GR_SOLVER_PCG_SCHUR_IMPLICIT;
+  }
+  void engine_pcg_parameters(int &m, double &t, double &rj) const override { m = (int)max_iter; t = (double)tol; rj = (double)rejection_ratio; }
   void update_structure(Graph<T, S> *graph, StreamPool &streams) override {
     schur.update_structure(graph);
     const size_t pd = schur.pose_dimension();
@@ -511,6 +527,7 @@ public:
 template <typename T, typename S> class EigenSchurLDLTSolver : public Solver<T, S> {
   DenseSchurComplement<T, S> schur;
 public:
+  int engine_kind(size_t) const override { return GR_SOLVER_DENSE_SCHUR; }
   void update_structure(Graph<T, S> *graph, StreamPool &) override { schur.update_structure(graph); }
   void update_values(Graph<T, S> *graph, StreamPool &) override { schur.update_values(graph); }
   void set_damping_factor(Graph<T, S> *, T mu, const bool use_identity, StreamPool &) override { schur.set_damping(mu, use_identity); }
@@ -563,8 +580,86 @@ template <typename T, typename S> T compute_rho(Graph<T, S> *graph, const T *del
 
 // :110-242 (EARLY = false) and :255-418 (EARLY = true: levenberg_marquardt2)
 namespace detail {
+// Bundle-adjustment graphs built with the generic descriptors — one camera descriptor (9), one point descriptor (3,
+// set_eliminate or not), one factor descriptor whose traits carry `bal_reprojection_model` — are optimised by the
+// specialised engine of libgraphite_mi355x.so (gr_bal_*: matrix-free kernels, device-resident loop) instead of
+// the generic stored-Jacobian kernels: same algorithm, same trace.  Returns false when the graph or the solver
+// is anything else (fixed or unused vertices, inactive factors, precision matrices, a solver without an engine
+// counterpart, GRAPHITE_GENERIC_ONLY=1): the caller then runs the generic loop.
+template <typename T, typename S>
+bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, bool early_stop, bool &result) {
+  if (getenv("GRAPHITE_GENERIC_ONLY") && atoi(getenv("GRAPHITE_GENERIC_ONLY")) != 0) return false;
+  if (!(std::is_same<T, S>::value || (std::is_same<T, double>::value && std::is_same<S, float>::value))) return false;
+  auto &vds = graph->get_vertex_descriptors();
+  auto &fds = graph->get_factor_descriptors();
+  if (vds.size() != 2 || fds.size() != 1 || fds[0]->num_slots() != 2) return false;
+  auto *cd = fds[0]->slot_descriptor(0), *pd = fds[0]->slot_descriptor(1);
+  if (cd == pd || cd->dimension() != 9 || pd->dimension() != 3 || cd->eliminate) return false;
+  if (!((vds[0] == cd && vds[1] == pd) || (vds[0] == pd && vds[1] == cd))) return false;
+  const int kind = options->solver->engine_kind(cd->count());
+  if (kind < 0) return false;
+  if (!graph->initialize_optimization(options->optimization_level)) return false;
+  for (auto *vd : {cd, pd}) {
+    const uint8_t *st = vd->get_active_state();
+    for (size_t v = 0; v < vd->count(); ++v)
+      if (!graphite::detail::is_vertex_active(st, v)) return false; // fixed, or not touched by a factor: not an engine graph
+  }
+  std::vector<int32_t> ci, pi;
+  std::vector<T> obs;
+  int loss_kind = 0; double loss_delta = 0;
+  if (!fds[0]->export_bal(ci, pi, obs, loss_kind, loss_delta)) return false;
+
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  managed_vector<T> cams(9 * cd->count()), pts(3 * pd->count());
+  cd->gather_parameters(cams.raw()); pd->gather_parameters(pts.raw());
+  graphite::detail::sync();
+  int dev = 0;
+  GRAPHITE_HIP(hipGetDevice(&dev));
+  gr_bal_problem *prob = nullptr;
+  const gr_dtype dt = sizeof(T) == 8 ? GR_F64 : GR_F32;
+  auto fail = [&](const char *what) { std::cerr << "graphite: engine hand-over failed in " << what << ": " << gr_last_error_string() << "; using the generic kernels" << std::endl; if (prob) gr_bal_destroy(prob); return false; };
+  if (gr_bal_create(&prob, dt, (int64_t)cd->count(), (int64_t)pd->count(), (int64_t)ci.size(), cams.raw(), pts.raw(), obs.data(), ci.data(), pi.data(), dev, nullptr) != GR_OK) return fail("gr_bal_create");
+  if (gr_bal_set_loss(prob, loss_kind ? GR_LOSS_HUBER : GR_LOSS_DEFAULT, loss_delta) != GR_OK) return fail("gr_bal_set_loss");
+  if (gr_bal_set_scale_system(prob, graph->scales_system() ? 1 : 0) != GR_OK) return fail("gr_bal_set_scale_system");
+  if (!std::is_same<T, S>::value && gr_bal_set_jacobian_precision(prob, GR_F32) != GR_OK) return fail("gr_bal_set_jacobian_precision");
+  gr_lm_options o{};
+  o.solver = kind; o.iterations = (int32_t)options->iterations; o.initial_damping = options->initial_damping;
+  o.use_identity = options->use_identity ? 1 : 0; o.early_stop = early_stop ? 1 : 0;
+  int m; double tl, rj;
+  options->solver->engine_pcg_parameters(m, tl, rj);
+  o.pcg_max_iter = m; o.pcg_tol = tl; o.pcg_rejection_ratio = rj;
+  gr_lm_stats st{};
+  std::vector<double> chi2(options->iterations + 1), lambda(options->iterations + 1);
+  if (getenv("GR_VERBOSE")) std::cerr << "[graphite] bundle-adjustment graph (" << cd->count() << " cameras, " << pd->count() << " points, " << ci.size()
+                                      << " factors) handed to the gr_bal engine, gr_solver " << kind << std::endl;
+  if (gr_bal_levenberg_marquardt(prob, &o, &st, chi2.data(), lambda.data()) != GR_OK) return fail("gr_bal_levenberg_marquardt");
+  if (gr_bal_get_params(prob, cams.raw(), pts.raw()) != GR_OK) return fail("gr_bal_get_params");
+  cd->scatter_parameters(cams.raw()); pd->scatter_parameters(pts.raw());
+  graph->compute_error(); // leave the residuals of the optimised vertices behind, as the generic loop does (graph->chi2() is valid)
+  graphite::detail::sync();
+  gr_bal_destroy(prob);
+  if (options->verbose) {
+    const double total = std::chrono::duration<double>(clk::now() - t0).count();
+    const double per_it = st.iterations_run ? st.loop_seconds / st.iterations_run : 0.0, setup = total - st.loop_seconds;
+    const int prec = early_stop ? 4 : 12, w0 = early_stop ? 10 : 18, w = early_stop ? 16 : 24;
+    std::cout << std::setprecision(12) << std::setw(18) << "Iteration" << std::setw(24) << "Initial Chi2" << std::setw(24)
+              << "Current Chi2" << std::setw(24) << "Lambda" << std::setw(24) << "Time" << std::setw(24) << "Total Time" << std::endl;
+    std::cout << std::string(138, '-') << std::endl;
+    for (int i = 0; i < st.iterations_run; ++i)
+      std::cout << std::setprecision(prec) << std::setw(w0) << i << std::setw(w) << chi2[i] << std::setw(w) << chi2[i + 1] << std::setw(w)
+                << lambda[i + 1] << std::setw(w) << per_it << std::setw(w) << setup + per_it * (i + 1) << std::endl;
+  }
+  result = st.ok != 0;
+  return true;
+}
+
 template <bool EARLY, typename T, typename S> bool lm_loop(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {
   if (!options->validate()) return false;
+  if (!(options->stop_flag && *options->stop_flag)) { // the engine runs the whole loop in one call: the flag is polled here only
+    bool result = false;
+    if (engine_levenberg_marquardt(graph, options, EARLY, result)) return result;
+  }
   using clk = std::chrono::steady_clock;
   auto start = clk::now();
   if (!graph->initialize_optimization(options->optimization_level)) return false;

@@ -93,6 +93,12 @@ template <typename T, typename S> struct ReprojectionErrorManualTraits : Reproje
 };
 template <typename T, typename S> using ReprojectionErrorManual = FactorDescriptor<T, S, ReprojectionErrorManualTraits<T, S>>;
 
+// ... and declared to be THE BAL reprojection model: levenberg_marquardt hands such a graph to the gr_bal_* engine
+template <typename T, typename S> struct ReprojectionErrorEngineTraits : ReprojectionErrorManualTraits<T, S> {
+  static constexpr bool bal_reprojection_model = true;
+};
+template <typename T, typename S> using ReprojectionErrorEngine = FactorDescriptor<T, S, ReprojectionErrorEngineTraits<T, S>>;
+
 } // namespace graphite
 
 template <template <typename, typename> class Factor> static int run(int argc, char **argv) {
@@ -131,6 +137,7 @@ template <template <typename, typename> class Factor> static int run(int argc, c
   const DefaultLoss<FP, 2> loss;
   for (size_t i = 0; i < no; ++i) r_desc.add_factor({ci[i], nc + pi[i]}, ob[i], nullptr, Empty(), loss);
 
+  if (jmode == "engine-fixed") cam_desc.set_fixed(0, true);
   const std::string kind = argv[2];
   BlockJacobiPreconditioner<FP, SP> bj;
   IdentityPreconditioner<FP, SP> id;
@@ -162,5 +169,7 @@ template <template <typename, typename> class Factor> static int run(int argc, c
 int main(int argc, char **argv) {
   // auto: dual-number Jacobians (stored); stored | dynamic: the Manual factor with / without Jacobian storage
   const std::string jmode = argc > 4 ? argv[4] : "auto";
+  // engine: the tagged factor (dispatched to gr_bal_*); engine-fixed: the same with one camera fixed (must fall back)
+  if (jmode == "engine" || jmode == "engine-fixed") return run<graphite::ReprojectionErrorEngine>(argc, argv);
   return jmode == "auto" ? run<graphite::ReprojectionError>(argc, argv) : run<graphite::ReprojectionErrorManual>(argc, argv);
 }
