@@ -1120,8 +1120,7 @@ template <typename T> struct Engine final : EngineBase {
       // past the unrolled iterations the loop must have left, unless max_iter itself ends it
       k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, k, tol, rej, (unsigned)pose_dim, rec, lm, (k == unroll - 1 && unroll < max_iter) ? 1 : 0, h_lm + 1);
     }
-    k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, 1, cams.p, pts.p, cams_bak.p, pts_bak.p, x, scales.p, bu.p, 0.0, rho_partial.p, rec, lm);
-    k_campack<T><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, cams.p, pack.p, nullptr, scales.p, nullptr, lm);
+    k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, TPB), 1, cams.p, pts.p, cams_bak.p, pts_bak.p, x, scales.p, bu.p, 0.0, rho_partial.p, pack.p, rec, lm);
     if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
     else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
     k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
@@ -1133,7 +1132,7 @@ template <typename T> struct Engine final : EngineBase {
     if (getenv("GR_LM_SPECULATE") && atoi(getenv("GR_LM_SPECULATE")) == 0) return false;
     ensure_ctl(opt.pcg_max_iter);
     ensure_point_records();
-    rho_blocks = cdiv(n, TPB);
+    rho_blocks = cdiv(Nc, TPB) + cdiv(3 * Np, TPB);
     rho_partial.alloc(rho_blocks);
     lmdev.alloc(1);
     if (!h_lm) { void *q = nullptr; GR_HIP(hipHostMalloc(&q, 64, hipHostMallocCoherent | hipHostMallocMapped)); h_lm = static_cast<volatile int *>(q); }
@@ -1296,12 +1295,11 @@ template <typename T> struct Engine final : EngineBase {
       int seq;
       const bool speculate = accept_streak >= 2 && spec_enabled;
       if (speculate) {
-        // backup_parameters + apply_update + rho-denominator partials in one pass, then the camera packs
-        rho_blocks = cdiv(n, TPB);
+        // backup_parameters + apply_update + rho-denominator partials + the camera packs in one launch
+        rho_blocks = cdiv(Nc, TPB) + cdiv(3 * Np, TPB);
         rho_partial.alloc(rho_blocks);
-        k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr);
+        k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, TPB), cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, pack.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr);
         if (!(use_records && xp.n && xp_valid)) xp_valid = false;
-        campack();
         seq = ++seq_counter;
         linearize_impl(want_hcp, /*pack_valid=*/true, seq);
       } else {

@@ -125,27 +125,46 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
 
 // Graph::backup_parameters + Graph::apply_update (graph.hpp:292-309, ops/update.hpp:11-31) over cameras and
 // points in one pass, plus this block's share of the compute_rho denominator sum dx (mu dx + b)
-// (levenberg_marquardt.hpp:34-41) while dx and the scales are in registers anyway.
+// (levenberg_marquardt.hpp:34-41) while dx and the scales are in registers anyway, plus the camera packs of
+// the moved cameras.  Blocks [0, nbc): one thread per camera (its 9 parameters, then make_campack);
+// blocks [nbc, ...): one thread per point scalar.
 template <typename T>
 __global__ void __launch_bounds__(TPB)
-k_apply_update_rho(unsigned n, unsigned pose_dim, int cam_weight, T *__restrict__ cams, T *__restrict__ pts,
+k_apply_update_rho(unsigned n, unsigned pose_dim, int nbc, int cam_weight, T *__restrict__ cams, T *__restrict__ pts,
                    T *__restrict__ cams_bak, T *__restrict__ pts_bak, const T *__restrict__ dx,
                    const T *__restrict__ scales, const T *__restrict__ bu, double mu, double *__restrict__ rho_partial,
-                   T *__restrict__ xp = nullptr, const LmDev *__restrict__ lm = nullptr) {
+                   T *__restrict__ pack, T *__restrict__ xp = nullptr, const LmDev *__restrict__ lm = nullptr) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
   __shared__ double red[4];
-  const unsigned i = blockIdx.x * TPB + threadIdx.x;
   double rho = 0;
-  if (i < n) {
-    const T d = dx[i], s = scales[i];
-    T *x = i < pose_dim ? cams + i : pts + (i - pose_dim);
-    T *bk = i < pose_dim ? cams_bak + i : pts_bak + (i - pose_dim);
-    const T xo = *x;
-    *bk = xo;
-    const T xn = xo + d * s;
-    *x = xn;
-    if (xp && i >= pose_dim) { const unsigned q = i - pose_dim; xp[8 * (size_t)(q / 3u) + q % 3u] = xn; } // operator's point records
-    if (i >= pose_dim || cam_weight) rho = (double)(d * ((T)mu * d + s * bu[i]));
+  if ((int)blockIdx.x < nbc) {
+    const unsigned c = blockIdx.x * TPB + threadIdx.x;
+    if (9u * c < pose_dim) {
+      T cam[9], pk[PACK];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const unsigned i = 9u * c + k;
+        const T d = dx[i], s = scales[i], xo = cams[i];
+        cams_bak[i] = xo;
+        cam[k] = xo + d * s;
+        cams[i] = cam[k];
+        if (cam_weight) rho += (double)(d * ((T)mu * d + s * bu[i]));
+      }
+      make_campack(cam, pk);
+#pragma unroll
+      for (int k = 0; k < PACK; ++k) pack[PACK * (size_t)c + k] = pk[k];
+    }
+  } else {
+    const unsigned q = (blockIdx.x - nbc) * TPB + threadIdx.x, i = pose_dim + q;
+    if (i < n) {
+      const T d = dx[i], s = scales[i];
+      const T xo = pts[q];
+      pts_bak[q] = xo;
+      const T xn = xo + d * s;
+      pts[q] = xn;
+      if (xp) xp[8 * (size_t)(q / 3u) + q % 3u] = xn; // operator's point records
+      rho = (double)(d * ((T)mu * d + s * bu[i]));
+    }
   }
   rho = block_sum_256(rho, red);
   if (threadIdx.x == 0) rho_partial[blockIdx.x] = rho;
