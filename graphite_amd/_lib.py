@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgraphite_mi355x.so")
+LIB_PATH = os.environ.get("GR_LIB_PATH") or os.path.join(_HERE, "libgraphite_mi355x.so")  # GR_LIB_PATH: diagnostic builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 GR_OK = 0

@@ -157,13 +157,20 @@ template <typename T, int NV> __device__ __forceinline__ T wave_transpose_sum(T 
 // serialise at ~12 ns per atomic (MI355X_MICROARCH.md "fanin"), which is longer
 // than the kernels themselves; every logical scalar is therefore NS partial
 // sums, picked by blockIdx, and re-summed (fixed order) by its readers.
-constexpr int NS = 64;
+// SS = doubles between two partials.  One 128-byte line per partial (SS = 16) was measured against the packed
+// layout (SS = 1) on the 1 900-block update kernel with its 4 sums: no difference (the fire-and-forget atomics
+// of a finishing block are not what bounds these kernels), so the partials stay packed.
+constexpr int NS = 64;        // partial sums per logical scalar
+constexpr int SS = 1;         // doubles between partials
+constexpr int NSW = NS * SS;  // doubles per logical scalar
 __device__ __forceinline__ void slot_add(double *base, int k, double v) {
-  atomicAdd(&base[(size_t)k * NS + (blockIdx.x & (NS - 1))], v);
+  atomicAdd(&base[(size_t)k * NSW + (size_t)(blockIdx.x & (NS - 1)) * SS], v);
 }
 __device__ __forceinline__ double slot_sum(const double *base, int k) { // whole wave must call
-  return wave_allsum(base[(size_t)k * NS + (threadIdx.x & 63)]);
+  return wave_allsum(base[(size_t)k * NSW + (size_t)(threadIdx.x & 63) * SS]);
 }
+// index of partial i (0 <= i < count * NS) of an array of logical scalars, for the loops that clear them
+__device__ __forceinline__ size_t slot_word(int i) { return (size_t)(i / NS) * NSW + (size_t)(i % NS) * SS; }
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) {
   return x < lo ? lo : (x > hi ? hi : x);

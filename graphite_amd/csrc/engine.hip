@@ -604,12 +604,12 @@ template <typename T> struct Engine final : EngineBase {
   // ---- Solver interface ---------------------------------------------------------
   void ensure_scalars(int max_iter) {
     const int cap = max_iter + 2;
-    if (cap > sc_cap) { sc_cap = cap; sc_d.alloc((4 * (size_t)NS + 1) * cap); sc_i.alloc((size_t)cap + 1); }
+    if (cap > sc_cap) { sc_cap = cap; sc_d.alloc((4 * (size_t)NSW + 1) * cap); sc_i.alloc((size_t)cap + 1); }
     alloc_pinned(cap);
   }
   PcgScalars scalars() {
     PcgScalars sc;
-    const size_t blk = (size_t)sc_cap * NS;
+    const size_t blk = (size_t)sc_cap * NSW;
     sc.rz = sc_d.p; sc.den = sc_d.p + blk; sc.rr = sc_d.p + 2 * blk; sc.pdp = sc_d.p + 3 * blk; sc.rz0 = sc_d.p + 4 * blk;
     sc.done = sc_i.p; sc.iters = sc_i.p + sc_cap;
     sc.hflag = h_flag; sc.hiters = h_seq + 1;
@@ -869,12 +869,12 @@ template <typename T> struct Engine final : EngineBase {
   }
   void ensure_ctl(int max_iter) {
     const int cap = max_iter + 2;
-    if (cap > ctl_cap) { ctl_cap = cap; ctl.alloc(((size_t)NSLOT * NS + 2) * cap); ctl_i.alloc(cap); }
+    if (cap > ctl_cap) { ctl_cap = cap; ctl.alloc(((size_t)NSLOT * NSW + 2) * cap); ctl_i.alloc(cap); }
     alloc_pinned(cap);
   }
   PcgState pcg_state() {
     PcgState st;
-    const size_t blk = (size_t)ctl_cap * NSLOT * NS;
+    const size_t blk = (size_t)ctl_cap * NSLOT * NSW;
     st.acc = ctl.p; st.pdp = ctl.p + blk; st.rz0 = ctl.p + blk + ctl_cap;
     st.done = ctl_i.p; st.iters = pcg_iters.p; st.hflag = h_flag; st.hiters = h_seq + 1;
     return st;
@@ -892,11 +892,11 @@ template <typename T> struct Engine final : EngineBase {
     h_seq[1] = 0;
     if (state_fresh_cap != ctl_cap) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap); // else reset by k_block_jacobi
     state_fresh_cap = -1;
-    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, TPB), num_cu * 8);
+    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, 85), num_cu * 8);
     const T *rawc = comm ? raw_c.p : nullptr;
     const int cw = cam_weight();
     k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
-    if (comm) allreduce_d(st.acc, 4 * (size_t)NS); // record 0: RZP, RR, PDZ, ZDZ
+    if (comm) allreduce_d(st.acc, 4 * (size_t)NSW); // record 0: RZP, RR, PDZ, ZDZ
     k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, rec);
     auto enqueue = [&](int k) {
       {
@@ -907,14 +907,14 @@ template <typename T> struct Engine final : EngineBase {
         k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, nullptr, k);
         comm->group_start();
         allreduce_T(raw_c.p, pose_dim);
-        allreduce_d(st.acc + ((size_t)k * NSLOT + DEN) * NS, NS);
+        allreduce_d(st.acc + ((size_t)k * NSLOT + DEN) * NSW, NSW);
         comm->group_end();
       }
       {
         Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
         k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k);
       }
-      if (comm) allreduce_d(st.acc + (size_t)(k + 1) * NSLOT * NS, 4 * (size_t)NS);
+      if (comm) allreduce_d(st.acc + (size_t)(k + 1) * NSLOT * NSW, 4 * (size_t)NSW);
       {
         Scope s3(this, "pcg_direction", 5.0 * n * sizeof(T), 3.0 * n);
         k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej, (unsigned)pose_dim, rec);
@@ -936,7 +936,7 @@ template <typename T> struct Engine final : EngineBase {
     ensure_point_records();
     PcgState st = pcg_state();
     const int ui = 0;
-    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, TPB), num_cu * 8);
+    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, 85), num_cu * 8);
     k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
     k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
     k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr);
@@ -961,7 +961,12 @@ template <typename T> struct Engine final : EngineBase {
 #endif
         break;
       case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
-      case 3: k_pcg_update<T, 1, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0); break;
+      case 3: { // variant 1: camera part only, 2: point part only, >= 8: that many blocks
+        const int nc_v = variant == 2 ? 0 : (int)Nc, np_v = variant == 1 ? 0 : (int)Np;
+        const int ub = variant >= 8 ? variant : std::max(1, std::min(cdiv(9 * (size_t)nc_v, 252) + cdiv(np_v, 85), num_cu * 8));
+        k_pcg_update<T, 1, false><<<ub, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
+        break;
+      }
       case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr); break;
       case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p); break;
       default: throw std::invalid_argument("diag_time: unknown kernel");
@@ -1108,7 +1113,7 @@ template <typename T> struct Engine final : EngineBase {
     T *rec = use_records ? xp.p : nullptr;
     const int nbc = cdiv(Nc, 64), nbp = cdiv(Np, 64);
     k_block_jacobi<T><<<nbc + nbp + 1, 64, 0, stream>>>((int)Nc, (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, 0.0, ui, MinvC.p, MinvP.p, v_diag.p, stt, ctl_cap, lm);
-    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, TPB), num_cu * 8);
+    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, 85), num_cu * 8);
     T *x = v_dx.p;
     k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, 0.0, ui, MinvC.p, MinvP.p, stt, 0, lm);
     k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, -1, 0.0, 1e30, (unsigned)pose_dim, rec, lm, 0, nullptr);

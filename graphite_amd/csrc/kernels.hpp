@@ -128,7 +128,7 @@ __global__ void k_export_blocks(size_t nblocks, int rows, int cols, const T *__r
 // Kernels of iteration k only READ slots written by earlier launches and accumulate
 // into slot k / k+1, so there are no intra-launch races.
 struct PcgScalars {
-  double *rz, *den, *rr, *pdp; // [cap][NS]
+  double *rz, *den, *rr, *pdp; // [cap][NSW] (NS partials, one L2 line each)
   double *rz0;                 // [cap]
   int *done, *iters;           // [cap], [1]
   volatile int *hflag;         // pinned host memory [cap]: 1 = iteration finished, 2 = loop left (may be null)
@@ -145,7 +145,7 @@ __global__ void k_point_prepare(int Np, int Nc, const T *__restrict__ Hll, const
                                 T *__restrict__ Hll_inv, T *__restrict__ Mp, T *__restrict__ vl,
                                 PcgScalars pcg = PcgScalars{}, int cap = 0) {
   if (pcg.rz && blockIdx.x == gridDim.x - 1) { // one extra block: reset of the PCG scalars of the solve that follows
-    for (int i = threadIdx.x; i < cap * NS; i += blockDim.x) { pcg.rz[i] = 0.0; pcg.den[i] = 0.0; pcg.rr[i] = 0.0; pcg.pdp[i] = 0.0; }
+    for (int i = threadIdx.x; i < cap * NS; i += blockDim.x) { const size_t q = slot_word(i); pcg.rz[q] = 0.0; pcg.den[q] = 0.0; pcg.rr[q] = 0.0; pcg.pdp[q] = 0.0; }
     for (int i = threadIdx.x; i < cap; i += blockDim.x) { pcg.done[i] = 0; pcg.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
     if (threadIdx.x == 0) pcg.iters[0] = 0;
     return;

@@ -31,6 +31,9 @@ namespace gr {
 #define OP_SGPR 1
 #endif
 #ifndef FIN_PL
+#ifndef UPD_VAR
+#define UPD_VAR 0 // diagnostic builds only: ablations of the update kernel's point part
+#endif
 #define FIN_PL 4 // lanes per point in the finalize kernel (power of two; TPB and 90 Nc keep groups inside a wave)
 #endif
 
@@ -52,17 +55,17 @@ constexpr int TICKET_GROUPS = 64;
 // (cam_weight).
 enum { RZP = 0, RR = 1, PDZ = 2, ZDZ = 3, DEN = 4, NSLOT = 5 };
 struct PcgState {
-  double *acc;          // [cap][NSLOT][NS]
+  double *acc;          // [cap][NSLOT][NSW]
   double *pdp, *rz0;    // [cap]
   int *done;            // [cap]
   int *iters;           // [1]
   volatile int *hflag;  // pinned host memory [cap]: 1 = iteration finished, 2 = loop left
   volatile int *hiters; // pinned host mirror of iters
-  __device__ __forceinline__ double *slots(int k, int which) const { return acc + ((size_t)k * NSLOT + which) * NS; }
+  __device__ __forceinline__ double *slots(int k, int which) const { return acc + ((size_t)k * NSLOT + which) * NSW; }
 };
 
 __global__ void k_pcg_state_init(PcgState st, int cap) {
-  for (int i = threadIdx.x; i < cap * NSLOT * NS; i += blockDim.x) st.acc[i] = 0.0;
+  for (int i = threadIdx.x; i < cap * NSLOT * NS; i += blockDim.x) st.acc[slot_word(i)] = 0.0;
   for (int i = threadIdx.x; i < cap; i += blockDim.x) { st.done[i] = 0; st.pdp[i] = 0.0; st.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
   if (threadIdx.x == 0) st.iters[0] = 0;
 }
@@ -117,7 +120,7 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
 #pragma unroll
     for (int i = 0; i < 9; ++i) MinvP[9 * (size_t)l + i] = (T)A[i];
   } else if (st.acc) {
-    for (int i = threadIdx.x; i < cap * NSLOT * NS; i += 64) st.acc[i] = 0.0;
+    for (int i = threadIdx.x; i < cap * NSLOT * NS; i += 64) st.acc[slot_word(i)] = 0.0;
     for (int i = threadIdx.x; i < cap; i += 64) { st.done[i] = 0; st.pdp[i] = 0.0; st.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
     if (threadIdx.x == 0) st.iters[0] = 0;
   }
@@ -675,8 +678,8 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
 // Persistent blocks walk contiguous ranges of
 //   camera tiles: 252 camera scalars (28 cameras) — fixed-order sum of the segment partials,
 //                 9x9 block-Jacobi through LDS
-//   point tiles : one POINT per thread — fixed-order sum of its observations' g3,
-//                 3x3 block-Jacobi in registers
+//   point tiles : 255 point scalars (85 points) — fixed-order sum of the observations' g3 per scalar,
+//                 3x3 block-Jacobi through LDS
 // MODE 0 (init): r = s .* b^u, x = 0.      MODE 1: v2 = s .* sums + mu d .* p,
 //   x_backup = x; x += alpha p; r -= alpha v2.
 // z' = Minv r; accumulates rr = r.r and rzp = r.z' (the reference applies the preconditioner to
@@ -702,7 +705,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
   __shared__ double red[4];
   __shared__ T rs[TPB];
   const unsigned pose_dim = 9u * (unsigned)Nc;
-  const int cam_tiles = (int)((pose_dim + 251u) / 252u), pt_tiles = (Np + TPB - 1) / TPB;
+  const int cam_tiles = (int)((pose_dim + 251u) / 252u), pt_tiles = (Np + 84) / 85;
   double prr = 0, prz = 0, ppz = 0, pzz = 0;
   const double cw = (double)cam_weight;
   // persistent: every block walks a contiguous range of camera tiles, then of point tiles
@@ -750,64 +753,82 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
       pzz += cw * (double)(d * s * s);
     }
   }
+  // point tiles: 85 points = 255 scalars per tile, one thread per SCALAR so that every load and store is a
+  // contiguous run over the wave (a thread per point reads 3-scalar groups 24 bytes apart: three times the
+  // address-processing work for the same bytes); the 3 x 3 block-Jacobi goes through LDS like the camera part
   const int pt0 = (int)((long long)blockIdx.x * pt_tiles / gridDim.x), pt1 = (int)((long long)(blockIdx.x + 1) * pt_tiles / gridDim.x);
+  const unsigned lt = threadIdx.x / 3u, li = threadIdx.x % 3u;
   for (int tile = pt0; tile < pt1; ++tile) {
-    const unsigned l = (unsigned)tile * TPB + threadIdx.x;
-    if (l < (unsigned)Np) {
-      const size_t t = (size_t)pose_dim + 3 * (size_t)l;
-      T rn[3];
-      if (MODE == 0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { rn[i] = scales[t + i] * bu[t + i]; x[t + i] = T(0); }
-      } else {
-        T raw[3] = {T(0), T(0), T(0)};
+    const unsigned l = (unsigned)tile * 85u + lt;
+    const bool on = threadIdx.x < 255 && l < (unsigned)Np;
+    const size_t t = (size_t)pose_dim + 3 * (size_t)l + li;
+    T rn = 0, pv = 0, m0 = 0, m1 = 0, m2 = 0, dg = T(1);
+    if (on) {
+      // everything that does not depend on the observation range is requested first, so the kernel pays
+      // two memory round trips (indices + vectors, then the g3 run) instead of one per stage
+      const T sc = scales[t];
+      if (!IDENTITY) { const T *M = MinvP + 9 * (size_t)l; m0 = M[li]; m1 = M[li + 3]; m2 = M[li + 6]; }
+      if (!use_identity) dg = diag[t];
+      if (MODE == 0) { rn = sc * bu[t]; x[t] = T(0); }
+      else {
         int a = pt_ptr[l];
         const int a_end = pt_ptr[l + 1];
-        for (; a + 4 <= a_end; a += 4) { // 12 independent loads in flight, the sums stay in observation order
-          T g[12];
-          const T *gp = g3 + 3 * (size_t)a;
-#pragma unroll
-          for (int i = 0; i < 12; ++i) g[i] = gp[i];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { raw[0] += g[3 * q]; raw[1] += g[3 * q + 1]; raw[2] += g[3 * q + 2]; }
+        pv = p[t];
+        const T xo = x[t], ro = r[t];
+        T raw = 0;
+#if UPD_VAR != 1
+        for (; a + 4 <= a_end; a += 4) { // 4 independent loads in flight, the sum stays in observation order
+          const T *gp = g3 + 3 * (size_t)a + li;
+          const T g0 = gp[0], g1 = gp[3], g2 = gp[6], g3v = gp[9];
+          raw += g0; raw += g1; raw += g2; raw += g3v;
         }
-        for (; a < a_end; ++a) {
-          const T *g = g3 + 3 * (size_t)a;
-          raw[0] += g[0]; raw[1] += g[1]; raw[2] += g[2];
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const T pv = p[t + i];
-          const T v2 = scales[t + i] * raw[i] + (use_identity ? (T)mu * pv : (T)mu * diag[t + i] * pv);
-          const T xo = x[t + i];
-          xb[t + i] = xo;
-          x[t + i] = alpha * pv + xo;
-          rn[i] = -alpha * v2 + r[t + i];
-        }
+        for (; a < a_end; ++a) raw += g3[3 * (size_t)a + li];
+#else
+        raw = (T)(a_end - a);
+#endif
+        const T v2 = sc * raw + (use_identity ? (T)mu * pv : (T)mu * dg * pv);
+        xb[t] = xo;
+        x[t] = alpha * pv + xo;
+        rn = -alpha * v2 + ro;
       }
-      const T *M = MinvP + 9 * (size_t)l;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        r[t + i] = rn[i];
-        const T s = IDENTITY ? rn[i] : M[i] * rn[0] + M[i + 3] * rn[1] + M[i + 6] * rn[2];
-        zt[t + i] = s;
-        const T d = use_identity ? T(1) : diag[t + i];
-        const T pv = (MODE == 0) ? T(0) : p[t + i];
-        prr += (double)(rn[i] * rn[i]);
-        prz += (double)(rn[i] * s);
-        ppz += (double)(d * pv * s);
-        pzz += (double)(d * s * s);
+      r[t] = rn;
+    }
+#if UPD_VAR != 3
+    __syncthreads();
+    rs[threadIdx.x] = rn;
+    __syncthreads();
+#endif
+    if (on) {
+      T s;
+      if (IDENTITY) s = rn;
+      else {
+#if UPD_VAR != 3
+        const T *rc = rs + 3 * lt;
+        s = m0 * rc[0] + m1 * rc[1] + m2 * rc[2];
+#else
+        s = m0 * rn + m1 * rn + m2 * rn;
+#endif
       }
+      zt[t] = s;
+      prr += (double)(rn * rn);
+      prz += (double)(rn * s);
+      ppz += (double)(dg * pv * s);
+      pzz += (double)(dg * s * s);
     }
   }
   const int slot = (MODE == 0) ? 0 : k + 1;
-  prr = block_sum_256(prr, red);
-  prz = block_sum_256(prz, red);
-  ppz = block_sum_256(ppz, red);
-  pzz = block_sum_256(pzz, red);
-  if (threadIdx.x == 0) {
-    slot_add(st.slots(slot, RR), 0, prr); slot_add(st.slots(slot, RZP), 0, prz);
-    slot_add(st.slots(slot, PDZ), 0, ppz); slot_add(st.slots(slot, ZDZ), 0, pzz);
+#if UPD_VAR == 2
+  if (MODE == 1) { if (prr + prz + ppz + pzz == 1.2345) st.pdp[0] = prr; return; }
+#endif
+  // the four dots in one block reduction (one barrier pair instead of four)
+  __shared__ double red4[4][4];
+  prr = wave_sum(prr); prz = wave_sum(prz); ppz = wave_sum(ppz); pzz = wave_sum(pzz);
+  if ((threadIdx.x & 63) == 0) { double *q = red4[threadIdx.x >> 6]; q[0] = prr; q[1] = prz; q[2] = ppz; q[3] = pzz; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const double v = red4[0][threadIdx.x] + red4[1][threadIdx.x] + red4[2][threadIdx.x] + red4[3][threadIdx.x];
+    const int which = threadIdx.x == 0 ? RR : threadIdx.x == 1 ? RZP : threadIdx.x == 2 ? PDZ : ZDZ;
+    slot_add(st.slots(slot, which), 0, v);
   }
 }
 
