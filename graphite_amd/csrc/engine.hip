@@ -105,6 +105,11 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<double> grid_partial;
   DevBuf<int> pcg_iters;
   int ctl_cap = 0, state_fresh_cap = -1; // state_fresh_cap == ctl_cap: the loop state was reset by the last set_damping
+  // LM host loop: lm_x = its step vector; state_clean_cap == ctl_cap: the loop state was cleared by the trial-step kernel and
+  // no solve ran since, so set_damping may start the next PCG loop inside k_block_jacobi (update0_done)
+  T *lm_x = nullptr;
+  int state_clean_cap = -1;
+  bool update0_done = false, update0_identity = false;
   // pinned host mirror: [0..1] chi2 / rho doubles, then ints: seq, flags[]
   double *h_res = nullptr;
   volatile int *h_seq = nullptr, *h_flag = nullptr;
@@ -641,8 +646,17 @@ template <typename T> struct Engine final : EngineBase {
       PcgState st{};
       if (ctl_cap > 0) st = pcg_state();
       const int nbc = cdiv(Nc, 64), nbp = cdiv(Np, 64);
-      k_block_jacobi<T><<<nbc + nbp + 1, 64, 0, stream>>>((int)Nc, (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, mu, use_identity ? 1 : 0, MinvC.p, MinvP.p, v_diag.p, st, ctl_cap);
-      state_fresh_cap = ctl_cap;
+      const bool fuse = lm_x && !comm && ctl_cap > 0 && state_clean_cap == ctl_cap;
+      if (fuse) {
+        k_block_jacobi<T><<<nbc + nbp, 64, 0, stream>>>((int)Nc, (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, mu, use_identity ? 1 : 0, MinvC.p, MinvP.p, v_diag.p, st, ctl_cap, nullptr,
+                                                         bu.p, lm_x, v_r.p, v_z.p, solver == GR_SOLVER_PCG_IDENTITY ? 1 : 0);
+        update0_done = true; update0_identity = solver == GR_SOLVER_PCG_IDENTITY;
+        state_clean_cap = -1; state_fresh_cap = -1;
+      } else {
+        k_block_jacobi<T><<<nbc + nbp + 1, 64, 0, stream>>>((int)Nc, (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, mu, use_identity ? 1 : 0, MinvC.p, MinvP.p, v_diag.p, st, ctl_cap);
+        state_fresh_cap = ctl_cap;
+        update0_done = false;
+      }
     }
   }
 
@@ -883,19 +897,23 @@ template <typename T> struct Engine final : EngineBase {
   // watches a pinned flag per iteration so that it stops enqueueing once the loop has left
   // (one iteration of look-ahead keeps the queue full).
   template <bool IDENTITY> void solve_pcg(int max_iter, double tol, double rej, T *x) {
+    const int cap_before = ctl_cap;
     ensure_ctl(max_iter);
+    const bool started = update0_done && ctl_cap == cap_before && x == lm_x && update0_identity == IDENTITY; // by k_block_jacobi
+    update0_done = false;
+    state_clean_cap = -1;
     ensure_point_records();
     T *rec = use_records ? xp.p : nullptr;
     PcgState st = pcg_state();
     const int ui = damping_identity ? 1 : 0;
     for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
     h_seq[1] = 0;
-    if (state_fresh_cap != ctl_cap) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap); // else reset by k_block_jacobi
+    if (!started && state_fresh_cap != ctl_cap) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap); // else reset by k_block_jacobi
     state_fresh_cap = -1;
     const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, 85), num_cu * 8);
     const T *rawc = comm ? raw_c.p : nullptr;
     const int cw = cam_weight();
-    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
+    if (!started) k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
     if (comm) allreduce_d(st.acc, 4 * (size_t)NSW); // record 0: RZP, RR, PDZ, ZDZ
     k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, rec);
     auto enqueue = [&](int k) {
@@ -1125,7 +1143,7 @@ template <typename T> struct Engine final : EngineBase {
       // past the unrolled iterations the loop must have left, unless max_iter itself ends it
       k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, k, tol, rej, (unsigned)pose_dim, rec, lm, (k == unroll - 1 && unroll < max_iter) ? 1 : 0, h_lm + 1);
     }
-    k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, TPB), 1, cams.p, pts.p, cams_bak.p, pts_bak.p, x, scales.p, bu.p, 0.0, rho_partial.p, pack.p, rec, lm);
+    k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), 1, cams.p, pts.p, cams_bak.p, pts_bak.p, x, scales.p, bu.p, 0.0, rho_partial.p, pack.p, rec, lm);
     if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
     else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
     k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
@@ -1137,7 +1155,7 @@ template <typename T> struct Engine final : EngineBase {
     if (getenv("GR_LM_SPECULATE") && atoi(getenv("GR_LM_SPECULATE")) == 0) return false;
     ensure_ctl(opt.pcg_max_iter);
     ensure_point_records();
-    rho_blocks = cdiv(Nc, TPB) + cdiv(3 * Np, TPB);
+    rho_blocks = cdiv(Nc, 28) + cdiv(3 * Np, TPB);
     rho_partial.alloc(rho_blocks);
     lmdev.alloc(1);
     if (!h_lm) { void *q = nullptr; GR_HIP(hipHostMalloc(&q, 64, hipHostMallocCoherent | hipHostMallocMapped)); h_lm = static_cast<volatile int *>(q); }
@@ -1225,6 +1243,11 @@ template <typename T> struct Engine final : EngineBase {
     profiling = opt.profile != 0;
     if (profiling) { flush_prof(); prof.clear(); }
     std::memset(&st, 0, sizeof(st));
+    struct LmScope { // the fused PCG start (solver_set_damping) is only armed inside this loop
+      Engine *e;
+      explicit LmScope(Engine *e_) : e(e_) { e->lm_x = e->v_dx.p; e->state_clean_cap = -1; e->update0_done = false; }
+      ~LmScope() { e->lm_x = nullptr; e->state_clean_cap = -1; e->update0_done = false; }
+    } lm_scope(this);
     T mu = (T)opt.initial_damping;
     T nu = 2;
     solver_update_structure(opt.solver);
@@ -1301,9 +1324,12 @@ template <typename T> struct Engine final : EngineBase {
       const bool speculate = accept_streak >= 2 && spec_enabled;
       if (speculate) {
         // backup_parameters + apply_update + rho-denominator partials + the camera packs in one launch
-        rho_blocks = cdiv(Nc, TPB) + cdiv(3 * Np, TPB);
+        rho_blocks = cdiv(Nc, 28) + cdiv(3 * Np, TPB);
         rho_partial.alloc(rho_blocks);
-        k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, TPB), cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, pack.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr);
+        const bool clear_state = !comm && ctl_cap > 0 && (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY);
+        k_apply_update_rho<T><<<rho_blocks + (clear_state ? 1 : 0), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, pack.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr,
+                                                                                       nullptr, clear_state ? pcg_state() : PcgState{}, clear_state ? ctl_cap : 0);
+        if (clear_state) state_clean_cap = ctl_cap;
         if (!(use_records && xp.n && xp_valid)) xp_valid = false;
         seq = ++seq_counter;
         linearize_impl(want_hcp, /*pack_valid=*/true, seq);
@@ -1327,6 +1353,7 @@ template <typename T> struct Engine final : EngineBase {
     while (i < opt.iterations && run) {
       if (graph_mode && accept_streak >= 2 && opt.iterations - i >= 2) {
         int its = 0, stop = 0;
+        state_clean_cap = -1; update0_done = false; // the replayed iterations run their own solves on the loop state
         const int steps = lm_graph_run(opt.iterations - i, mu, nu, chi2v, its, chi2_trace ? chi2_trace + i : nullptr, lambda_trace ? lambda_trace + i : nullptr, stop);
         st.accepted += steps; st.iterations_run += steps; st.pcg_iterations += its;
         i += steps;

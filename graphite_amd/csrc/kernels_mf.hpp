@@ -78,81 +78,143 @@ __global__ void __launch_bounds__(64)
 k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, const T *__restrict__ Hll,
                const T *__restrict__ scales, double mu, int use_identity, T *__restrict__ MinvC,
                T *__restrict__ MinvP, T *__restrict__ diag_clamped, PcgState st, int cap,
-               const LmDev *__restrict__ lm = nullptr) {
+               const LmDev *__restrict__ lm = nullptr,
+               // start of the PCG loop fused in (the loop state must already be clean): r = s .* b^u, x = 0,
+               // z' = Minv r (identity_precond: z' = r), record 0 of the dots  (k_pcg_update MODE 0)
+               const T *__restrict__ bu = nullptr, T *__restrict__ x = nullptr, T *__restrict__ r = nullptr,
+               T *__restrict__ zt = nullptr, int identity_precond = 0) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
   const int b = blockIdx.x;
+  double prr = 0, prz = 0, pzz = 0;
   if (b < nbc) {
     const int c = b * 64 + threadIdx.x;
-    if (c >= Nc) return;
-    double A[81];
-    const T *B = Hcc + 81 * (size_t)c;
-    const T *s = scales + 9 * (size_t)c;
+    if (c < Nc) {
+      double A[81];
+      T dcl[9];
+      const T *B = Hcc + 81 * (size_t)c;
+      const T *s = scales + 9 * (size_t)c;
 #pragma unroll
-    for (int col = 0; col < 9; ++col)
+      for (int col = 0; col < 9; ++col)
 #pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        const T v = s[r] * B[r + 9 * col] * s[col];
-        if (r == col) {
-          A[r + 9 * col] = (double)damp_diag(v, mu, use_identity);
-          diag_clamped[9 * (size_t)c + r] = (T)clampd((double)v, 1.0e-6, 1.0e32);
-        } else A[r + 9 * col] = (double)v;
+        for (int rw = 0; rw < 9; ++rw) {
+          const T v = s[rw] * B[rw + 9 * col] * s[col];
+          if (rw == col) {
+            A[rw + 9 * col] = (double)damp_diag(v, mu, use_identity);
+            dcl[rw] = (T)clampd((double)v, 1.0e-6, 1.0e32);
+            diag_clamped[9 * (size_t)c + rw] = dcl[rw];
+          } else A[rw + 9 * col] = (double)v;
+        }
+      spd_inverse<9>(A);
+#pragma unroll
+      for (int i = 0; i < 81; ++i) MinvC[81 * (size_t)c + i] = (T)A[i];
+      if (x) {
+        T rv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rv[i] = s[i] * bu[9 * (size_t)c + i];
+#pragma unroll
+        for (int row = 0; row < 9; ++row) {
+          T z = 0;
+          if (identity_precond) z = rv[row];
+          else {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) z += (T)A[row + 9 * q] * rv[q];
+          }
+          const size_t t = 9 * (size_t)c + row;
+          x[t] = T(0); r[t] = rv[row]; zt[t] = z;
+          const T d = use_identity ? T(1) : dcl[row];
+          prr += (double)(rv[row] * rv[row]); prz += (double)(rv[row] * z); pzz += (double)(d * z * z);
+        }
       }
-    spd_inverse<9>(A);
-#pragma unroll
-    for (int i = 0; i < 81; ++i) MinvC[81 * (size_t)c + i] = (T)A[i];
+    }
   } else if (b < nbc + nbp) {
     const int l = (b - nbc) * 64 + threadIdx.x;
-    if (l >= Np) return;
-    const T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
-    const T *H = Hll + 9 * (size_t)l;
-    double A[9];
+    if (l < Np) {
+      const size_t t0 = 9 * (size_t)Nc + 3 * (size_t)l;
+      const T *s = scales + t0;
+      const T *H = Hll + 9 * (size_t)l;
+      double A[9];
+      T dcl[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const T v = s[r] * H[r + 3 * c] * s[c];
-        if (r == c) {
-          A[r + 3 * c] = (double)damp_diag(v, mu, use_identity);
-          diag_clamped[9 * (size_t)Nc + 3 * (size_t)l + r] = (T)clampd((double)v, 1.0e-6, 1.0e32);
-        } else A[r + 3 * c] = (double)v;
+        for (int rw = 0; rw < 3; ++rw) {
+          const T v = s[rw] * H[rw + 3 * c] * s[c];
+          if (rw == c) {
+            A[rw + 3 * c] = (double)damp_diag(v, mu, use_identity);
+            dcl[rw] = (T)clampd((double)v, 1.0e-6, 1.0e32);
+            diag_clamped[t0 + rw] = dcl[rw];
+          } else A[rw + 3 * c] = (double)v;
+        }
+      spd_inverse<3>(A);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) MinvP[9 * (size_t)l + i] = (T)A[i];
+      if (x) {
+        T rv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = s[i] * bu[t0 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const T z = identity_precond ? rv[i] : (T)A[i] * rv[0] + (T)A[i + 3] * rv[1] + (T)A[i + 6] * rv[2];
+          x[t0 + i] = T(0); r[t0 + i] = rv[i]; zt[t0 + i] = z;
+          const T d = use_identity ? T(1) : dcl[i];
+          prr += (double)(rv[i] * rv[i]); prz += (double)(rv[i] * z); pzz += (double)(d * z * z);
+        }
       }
-    spd_inverse<3>(A);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) MinvP[9 * (size_t)l + i] = (T)A[i];
+    }
   } else if (st.acc) {
     for (int i = threadIdx.x; i < cap * NSLOT * NS; i += 64) st.acc[slot_word(i)] = 0.0;
     for (int i = threadIdx.x; i < cap; i += 64) { st.done[i] = 0; st.pdp[i] = 0.0; st.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
     if (threadIdx.x == 0) st.iters[0] = 0;
+    return;
+  }
+  if (x) { // one wave per block
+    prr = wave_sum(prr); prz = wave_sum(prz); pzz = wave_sum(pzz);
+    if (threadIdx.x == 0) { slot_add(st.slots(0, RR), 0, prr); slot_add(st.slots(0, RZP), 0, prz); slot_add(st.slots(0, ZDZ), 0, pzz); }
   }
 }
 
 // Graph::backup_parameters + Graph::apply_update (graph.hpp:292-309, ops/update.hpp:11-31) over cameras and
 // points in one pass, plus this block's share of the compute_rho denominator sum dx (mu dx + b)
 // (levenberg_marquardt.hpp:34-41) while dx and the scales are in registers anyway, plus the camera packs of
-// the moved cameras.  Blocks [0, nbc): one thread per camera (its 9 parameters, then make_campack);
+// the moved cameras.  Blocks [0, nbc): 28 cameras each (252 scalars, then the 28 packs);
 // blocks [nbc, ...): one thread per point scalar.
 template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_apply_update_rho(unsigned n, unsigned pose_dim, int nbc, int cam_weight, T *__restrict__ cams, T *__restrict__ pts,
                    T *__restrict__ cams_bak, T *__restrict__ pts_bak, const T *__restrict__ dx,
                    const T *__restrict__ scales, const T *__restrict__ bu, double mu, double *__restrict__ rho_partial,
-                   T *__restrict__ pack, T *__restrict__ xp = nullptr, const LmDev *__restrict__ lm = nullptr) {
+                   T *__restrict__ pack, T *__restrict__ xp = nullptr, const LmDev *__restrict__ lm = nullptr,
+                   PcgState rst = PcgState{}, int rst_cap = 0) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
+  if (blockIdx.x == gridDim.x - 1 && rst_cap > 0) {
+    // one extra block: the PCG loop state of the solve that produced dx is spent; clearing it here lets the next
+    // k_block_jacobi start the next loop itself (no separate init / first-update launches)
+    for (int i = threadIdx.x; i < rst_cap * NSLOT * NS; i += TPB) rst.acc[slot_word(i)] = 0.0;
+    for (int i = threadIdx.x; i < rst_cap; i += TPB) { rst.done[i] = 0; rst.pdp[i] = 0.0; rst.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
+    if (threadIdx.x == 0) rst.iters[0] = 0;
+    return;
+  }
   __shared__ double red[4];
   double rho = 0;
   if ((int)blockIdx.x < nbc) {
-    const unsigned c = blockIdx.x * TPB + threadIdx.x;
-    if (9u * c < pose_dim) {
+    // 28 cameras = 252 scalars per block, one thread per scalar (coalesced), the new values go through LDS to
+    // the 28 threads that rebuild the packs
+    __shared__ T cs[252];
+    const unsigned i = blockIdx.x * 252u + threadIdx.x;
+    if (threadIdx.x < 252 && i < pose_dim) {
+      const T d = dx[i], s = scales[i], xo = cams[i];
+      cams_bak[i] = xo;
+      const T xn = xo + d * s;
+      cams[i] = xn;
+      cs[threadIdx.x] = xn;
+      if (cam_weight) rho = (double)(d * ((T)mu * d + s * bu[i]));
+    }
+    __syncthreads();
+    const unsigned c = blockIdx.x * 28u + threadIdx.x;
+    if (threadIdx.x < 28 && 9u * c < pose_dim) {
       T cam[9], pk[PACK];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const unsigned i = 9u * c + k;
-        const T d = dx[i], s = scales[i], xo = cams[i];
-        cams_bak[i] = xo;
-        cam[k] = xo + d * s;
-        cams[i] = cam[k];
-        if (cam_weight) rho += (double)(d * ((T)mu * d + s * bu[i]));
-      }
+      for (int k = 0; k < 9; ++k) cam[k] = cs[9 * threadIdx.x + k];
       make_campack(cam, pk);
 #pragma unroll
       for (int k = 0; k < PACK; ++k) pack[PACK * (size_t)c + k] = pk[k];
