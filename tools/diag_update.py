@@ -11,4 +11,5 @@ f = g.lib.gr_bal_diag_time; f.restype = C.c_double
 def t(which, var=0, reps=100): return f(g.h, C.c_int(which), C.c_int(var), C.c_int(reps))
 print('update whole', round(t(3), 2), 'cam only', round(t(3, 1), 2), 'points only', round(t(3, 2), 2))
 for nb in (128, 256, 512, 1024, 2048): print('  blocks', nb, round(t(3, nb), 2))
+print('block_jacobi', round(t(6), 2), 'cameras only', round(t(6, 1), 2), 'points only', round(t(6, 2), 2), 'with PCG start', round(t(6, 3), 2))
 print('direction', round(t(4), 2), 'finalize', round(t(5), 2), 'operator', round(t(0), 2), 'linearize', round(t(1), 2))
