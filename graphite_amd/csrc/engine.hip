@@ -522,7 +522,7 @@ template <typename T> struct Engine final : EngineBase {
   // rho-denominator partials and publishes (chi2, denominator, spec_seq) to pinned host memory
   DevBuf<double> rho_partial;
   int rho_blocks = 0;
-  void linearize_impl(bool write_hcp, bool pack_valid = false, int spec_seq = 0) {
+  void linearize_impl(bool write_hcp, bool pack_valid = false, int spec_seq = 0, const int *gate = nullptr) {
     if (!pack_valid) campack();
     {
       // algorithmic bytes: every array touched once (obs, 3 index streams, points, packs, g9 out, partials, Hcp)
@@ -531,13 +531,14 @@ template <typename T> struct Engine final : EngineBase {
       if (write_hcp) {
         if (jac32) { k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); } else { k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); }
       } else {
-        if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); } else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p); }
+        if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate); } else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate); }
     }
       }
     {
       Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
       k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
-                                                                                                    spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq);
+                                                                                                    spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq,
+                                                                                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gate);
     }
     if (comm) { // camera-space sums over the landmark shards
       comm->group_start();
@@ -739,15 +740,32 @@ template <typename T> struct Engine final : EngineBase {
   // one did costs neither a bubble nor no-op launches.  Returns the number of enqueued iterations that ran as
   // no-ops (the loop had already left).
   int predicted_iters = 0;
+  // LM host loop, speculative trial step: at the iteration where the loop is PREDICTED to leave, the trial-step
+  // kernels (backup/update/rho, linearise, finalize) are enqueued before the exit flag has been seen, gated on the
+  // device by PcgState::left.  Right prediction: the round trip between the last direction kernel and the
+  // trial step disappears; wrong: three kernels return at once and the trial step is enqueued again later.
+  std::function<void(const int *gate)> trial_hook;
+  bool trial_done = false;
+  DevBuf<int> loop_left;
   template <typename Enqueue> int run_pcg_iterations(int max_iter, Enqueue &&enqueue) {
-    int enqueued = 0;
+    int enqueued = 0, hook_at = -1;
     bool left = false;
+    trial_done = false;
     if (max_iter > 0) { enqueue(0); ++enqueued; }
     for (int k = 0; k < max_iter; ++k) {
       if (k + 1 < max_iter && k + 1 < predicted_iters && enqueued == k + 1) { enqueue(k + 1); ++enqueued; }
+      if (trial_hook && hook_at < 0 && predicted_iters > 0 && k + 1 >= predicted_iters && enqueued == k + 1) {
+        trial_hook(k + 1 < max_iter ? loop_left.p : nullptr); // the iteration cap ends the loop whatever the flag says
+        hook_at = k;
+      }
       spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
       if (h_flag[k] == 2) { left = true; break; }
       if (k + 1 < max_iter && enqueued == k + 1) { enqueue(k + 1); ++enqueued; }
+    }
+    if (hook_at >= 0) {
+      const int last = left ? std::min((int)h_seq[1], enqueued) - 1 : enqueued - 1; // last iteration that ran
+      trial_done = (left && last <= hook_at) || hook_at + 1 == max_iter;
+      if (!trial_done) note_noop({"linearize", "linearize_finalize"}, 1);
     }
     const int active = left ? std::min((int)h_seq[1], enqueued) : enqueued;
     predicted_iters = active;
@@ -891,6 +909,7 @@ template <typename T> struct Engine final : EngineBase {
     const size_t blk = (size_t)ctl_cap * NSLOT * NSW;
     st.acc = ctl.p; st.pdp = ctl.p + blk; st.rz0 = ctl.p + blk + ctl_cap;
     st.done = ctl_i.p; st.iters = pcg_iters.p; st.hflag = h_flag; st.hiters = h_seq + 1;
+    loop_left.alloc(1); st.left = loop_left.p;
     return st;
   }
   // PCGSolver::solve (solver/pcg.hpp:61-232).  Scalars stay on the device; the host only
@@ -1273,6 +1292,7 @@ template <typename T> struct Engine final : EngineBase {
     st.setup_seconds = std::chrono::duration<double>(clk::now() - t0).count();
     auto tl = clk::now();
 
+    int ahead_hits = 0, ahead_misses = 0;
     // accept / reject bookkeeping of one trial step (levenberg_marquardt.hpp:184-233); false = leave the loop
     auto decide = [&](int i, bool solve_ok, bool speculate, int it, const double *hs) -> bool {
       st.pcg_iterations += it;
@@ -1319,27 +1339,39 @@ template <typename T> struct Engine final : EngineBase {
     auto host_iteration = [&](int i) -> bool {
       solver_set_damping(opt.solver, (double)mu, opt.use_identity != 0);
       GR_HIP(hipEventRecord(ev_a, stream));
+      const bool speculate = accept_streak >= 2 && spec_enabled;
+      int seq = 0;
+      // backup_parameters + apply_update + rho-denominator partials + the camera packs in one launch, then the
+      // speculative linearisation; `gate` != nullptr: enqueued ahead of the PCG exit flag (run_pcg_iterations)
+      auto enqueue_trial = [&](const int *gate) {
+        GR_HIP(hipEventRecord(ev_b, stream));
+        rho_blocks = cdiv(Nc, 28) + cdiv(3 * Np, TPB);
+        rho_partial.alloc(rho_blocks);
+        const bool clear_state = !comm && ctl_cap > 0 && (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY);
+        k_apply_update_rho<T><<<rho_blocks + (clear_state ? 1 : 0), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, pack.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr,
+                                                                                       nullptr, clear_state ? pcg_state() : PcgState{}, clear_state ? ctl_cap : 0, gate);
+        seq = ++seq_counter;
+        linearize_impl(want_hcp, /*pack_valid=*/true, seq, gate);
+      };
+      const bool ahead = speculate && !comm && !profiling && !(getenv("GR_LM_AHEAD") && atoi(getenv("GR_LM_AHEAD")) == 0) &&
+                         (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY);
+      if (ahead) trial_hook = enqueue_trial;
+      trial_done = false;
       const bool solve_ok = solver_solve_dev(opt.solver, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, v_dx.p);
-      GR_HIP(hipEventRecord(ev_b, stream));
+      trial_hook = nullptr;
+      const bool trial_ahead = ahead && trial_done;
+      if (ahead) (trial_ahead ? ahead_hits : ahead_misses)++;
       // Trial step.  After two accepted iterations the next one is expected to be accepted too, so the
       // trial chi2 is taken from a SPECULATIVE linearisation at the trial point (its chi2 is the same
       // sum): on acceptance the iteration is already linearised and the separate chi2 pass is saved;
       // on rejection the old linearisation is re-created from the reverted vertices (same bits: all
       // sums are fixed-order).  After a rejection the plain chi2 pass is used.
-      int seq;
-      const bool speculate = accept_streak >= 2 && spec_enabled;
       if (speculate) {
-        // backup_parameters + apply_update + rho-denominator partials + the camera packs in one launch
-        rho_blocks = cdiv(Nc, 28) + cdiv(3 * Np, TPB);
-        rho_partial.alloc(rho_blocks);
-        const bool clear_state = !comm && ctl_cap > 0 && (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY);
-        k_apply_update_rho<T><<<rho_blocks + (clear_state ? 1 : 0), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, pack.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr,
-                                                                                       nullptr, clear_state ? pcg_state() : PcgState{}, clear_state ? ctl_cap : 0);
-        if (clear_state) state_clean_cap = ctl_cap;
+        if (!trial_ahead) enqueue_trial(nullptr);
+        if (!comm && ctl_cap > 0 && (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY)) state_clean_cap = ctl_cap;
         if (!(use_records && xp.n && xp_valid)) xp_valid = false;
-        seq = ++seq_counter;
-        linearize_impl(want_hcp, /*pack_valid=*/true, seq);
       } else {
+        GR_HIP(hipEventRecord(ev_b, stream));
         apply_update_dev(v_dx.p, /*with_backup=*/true);
         // trial chi2 + compute_rho denominator (:20-47) in one kernel; its last block mirrors the two
         // sums into pinned host memory, so the host polls one word instead of memcpy + stream sync
@@ -1386,6 +1418,7 @@ template <typename T> struct Engine final : EngineBase {
     st.loop_seconds = std::chrono::duration<double>(clk::now() - tl).count();
     st.ok = run ? 1 : 0;
     st.final_chi2 = (double)chi2v;
+    if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] LM: trial step enqueued ahead of the PCG exit flag in %d iterations, not ahead in %d\n", ahead_hits, ahead_misses);
     if (getenv("GR_VERBOSE") && graph_mode)
       std::fprintf(stderr, "[graphite-mi355x] LM: %d of %d iterations replayed as graphs; handed back: %d (PCG iterations), %d (not accepted)\n", g_steps, st.iterations_run, g_stop1, g_stop2);
     (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b);

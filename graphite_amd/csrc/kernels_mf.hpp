@@ -61,13 +61,15 @@ struct PcgState {
   int *iters;           // [1]
   volatile int *hflag;  // pinned host memory [cap]: 1 = iteration finished, 2 = loop left
   volatile int *hiters; // pinned host mirror of iters
+  int *left;            // [1] 1 once the loop has left (set by the direction kernel, cleared by k_block_jacobi / the init kernel):
+                        // the gate of the trial-step kernels that the host enqueues BEFORE it has seen the exit flag
   __device__ __forceinline__ double *slots(int k, int which) const { return acc + ((size_t)k * NSLOT + which) * NSW; }
 };
 
 __global__ void k_pcg_state_init(PcgState st, int cap) {
   for (int i = threadIdx.x; i < cap * NSLOT * NS; i += blockDim.x) st.acc[slot_word(i)] = 0.0;
   for (int i = threadIdx.x; i < cap; i += blockDim.x) { st.done[i] = 0; st.pdp[i] = 0.0; st.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
-  if (threadIdx.x == 0) st.iters[0] = 0;
+  if (threadIdx.x == 0) { st.iters[0] = 0; if (st.left) *st.left = 0; }
 }
 
 // BlockJacobiPreconditioner::set_damping_factor (block_jacobi.hpp:120-172) for cameras AND points in one
@@ -85,6 +87,7 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
                T *__restrict__ zt = nullptr, int identity_precond = 0) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
   const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0 && st.left) *st.left = 0; // a new loop starts
   double prr = 0, prz = 0, pzz = 0;
   if (b < nbc) {
     const int c = b * 64 + threadIdx.x;
@@ -184,8 +187,9 @@ k_apply_update_rho(unsigned n, unsigned pose_dim, int nbc, int cam_weight, T *__
                    T *__restrict__ cams_bak, T *__restrict__ pts_bak, const T *__restrict__ dx,
                    const T *__restrict__ scales, const T *__restrict__ bu, double mu, double *__restrict__ rho_partial,
                    T *__restrict__ pack, T *__restrict__ xp = nullptr, const LmDev *__restrict__ lm = nullptr,
-                   PcgState rst = PcgState{}, int rst_cap = 0) {
+                   PcgState rst = PcgState{}, int rst_cap = 0, const int *__restrict__ gate = nullptr) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
+  if (gate && !*gate) return; // enqueued ahead of the PCG exit flag and the loop has not left: nothing to do
   if (blockIdx.x == gridDim.x - 1 && rst_cap > 0) {
     // one extra block: the PCG loop state of the solve that produced dx is spent; clearing it here lets the next
     // k_block_jacobi start the next loop itself (no separate init / first-update launches)
@@ -325,8 +329,10 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
             const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
             const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
             int loss_kind, T loss_delta, T *__restrict__ g9, T *__restrict__ Hcp, T *__restrict__ cam_partial,
-            double *__restrict__ chi2_partial, const LmDev *__restrict__ lm = nullptr) {
+            double *__restrict__ chi2_partial, const LmDev *__restrict__ lm = nullptr,
+            const int *__restrict__ gate = nullptr) {
   if (lm && lm->stop) return;
+  if (gate && !*gate) return;
   __shared__ double red[4];
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
@@ -435,8 +441,10 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
                      volatile double *hres = nullptr, volatile int *hres_seq = nullptr, int seq = 0,
                      LmDev *__restrict__ lm = nullptr, const int *__restrict__ pcg_iters = nullptr,
                      volatile double *h_chi2_trace = nullptr, volatile double *h_lambda_trace = nullptr,
-                     volatile int *h_steps = nullptr, volatile int *h_stop = nullptr) {
+                     volatile int *h_steps = nullptr, volatile int *h_stop = nullptr,
+                     const int *__restrict__ gate = nullptr) {
   if (lm && lm->stop) return;
+  if (gate && !*gate) return;
   const unsigned t = blockIdx.x * TPB + threadIdx.x;
   const unsigned ncam = 90u * (unsigned)Nc, ncam_pad = (ncam + TPB - 1) / TPB * TPB;
   if (t < ncam) {
@@ -917,7 +925,7 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
     PcgIter it{};
     if (!leave) { it = pcg_iter(st, k); leave = (it.rzp == 0.0); }
     if (leave) {
-      if (first) { st.done[k + 1] = 1; st.rz0[k + 1] = rz0; st.hflag[k] = 2; __threadfence_system(); }
+      if (first) { st.done[k + 1] = 1; st.rz0[k + 1] = rz0; if (st.left) *st.left = 1; st.hflag[k] = 2; __threadfence_system(); }
       return;
     }
     const PcgIter nx = pcg_iter(st, k + 1);
@@ -933,6 +941,7 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
       st.pdp[k + 1] = (double)beta * (double)beta * st.pdp[k] + 2.0 * (double)beta * (double)scale * pdz + (double)scale * (double)scale * zdz;
       st.iters[0] = k + 1;
       *st.hiters = k + 1;
+      if (done_next && st.left) *st.left = 1;
       st.hflag[k] = done_next ? 2 : 1;
       if (lm && last_unrolled && !done_next) { lm->stop = 1; if (h_stop) *h_stop = 1; } // graph mode: the host takes this step over
       __threadfence_system();
