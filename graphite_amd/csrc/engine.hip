@@ -647,10 +647,10 @@ template <typename T> struct Engine final : EngineBase {
       PcgState st{};
       if (ctl_cap > 0) st = pcg_state();
       const int nbc = cdiv(Nc, 64), nbp = cdiv(Np, 64);
-      const bool fuse = lm_x && !comm && ctl_cap > 0 && state_clean_cap == ctl_cap;
+      const bool fuse = lm_x && ctl_cap > 0 && state_clean_cap == ctl_cap;
       if (fuse) {
         k_block_jacobi<T><<<nbc + nbp, 64, 0, stream>>>((int)Nc, (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, mu, use_identity ? 1 : 0, MinvC.p, MinvP.p, v_diag.p, st, ctl_cap, nullptr,
-                                                         bu.p, lm_x, v_r.p, v_z.p, solver == GR_SOLVER_PCG_IDENTITY ? 1 : 0);
+                                                         bu.p, lm_x, v_r.p, v_z.p, solver == GR_SOLVER_PCG_IDENTITY ? 1 : 0, cam_weight());
         update0_done = true; update0_identity = solver == GR_SOLVER_PCG_IDENTITY;
         state_clean_cap = -1; state_fresh_cap = -1;
       } else {
@@ -1347,7 +1347,7 @@ template <typename T> struct Engine final : EngineBase {
         GR_HIP(hipEventRecord(ev_b, stream));
         rho_blocks = cdiv(Nc, 28) + cdiv(3 * Np, TPB);
         rho_partial.alloc(rho_blocks);
-        const bool clear_state = !comm && ctl_cap > 0 && (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY);
+        const bool clear_state = ctl_cap > 0 && (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY);
         k_apply_update_rho<T><<<rho_blocks + (clear_state ? 1 : 0), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, pack.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr,
                                                                                        nullptr, clear_state ? pcg_state() : PcgState{}, clear_state ? ctl_cap : 0, gate);
         seq = ++seq_counter;
@@ -1368,7 +1368,7 @@ template <typename T> struct Engine final : EngineBase {
       // sums are fixed-order).  After a rejection the plain chi2 pass is used.
       if (speculate) {
         if (!trial_ahead) enqueue_trial(nullptr);
-        if (!comm && ctl_cap > 0 && (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY)) state_clean_cap = ctl_cap;
+        if (ctl_cap > 0 && (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY)) state_clean_cap = ctl_cap;
         if (!(use_records && xp.n && xp_valid)) xp_valid = false;
       } else {
         GR_HIP(hipEventRecord(ev_b, stream));

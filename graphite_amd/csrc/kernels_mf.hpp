@@ -84,7 +84,8 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
                // start of the PCG loop fused in (the loop state must already be clean): r = s .* b^u, x = 0,
                // z' = Minv r (identity_precond: z' = r), record 0 of the dots  (k_pcg_update MODE 0)
                const T *__restrict__ bu = nullptr, T *__restrict__ x = nullptr, T *__restrict__ r = nullptr,
-               T *__restrict__ zt = nullptr, int identity_precond = 0) {
+               T *__restrict__ zt = nullptr, int identity_precond = 0,
+               int cam_weight = 1 /* landmark shards: the replicated camera part of the dots counts on rank 0 only */) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0 && st.left) *st.left = 0; // a new loop starts
@@ -125,7 +126,7 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
           const size_t t = 9 * (size_t)c + row;
           x[t] = T(0); r[t] = rv[row]; zt[t] = z;
           const T d = use_identity ? T(1) : dcl[row];
-          prr += (double)(rv[row] * rv[row]); prz += (double)(rv[row] * z); pzz += (double)(d * z * z);
+          if (cam_weight) { prr += (double)(rv[row] * rv[row]); prz += (double)(rv[row] * z); pzz += (double)(d * z * z); }
         }
       }
     }
