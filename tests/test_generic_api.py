@@ -37,7 +37,8 @@ def build_all():
     return (hipcc(os.path.join(ROOT, "examples", "circle.hip"), os.path.join(BUILD, "circle")),
             hipcc(os.path.join(ROOT, "examples", "circle.hip"), os.path.join(BUILD, "circle_ad"), "-DCIRCLE_AUTODIFF"),
             hipcc(os.path.join(ROOT, "tests", "cpp", "test_generic_bal.hip"), os.path.join(BUILD, "test_generic_bal")),
-            hipcc(os.path.join(ROOT, "tests", "cpp", "test_generic_known_answers.hip"), os.path.join(BUILD, "test_generic_known_answers")))
+            hipcc(os.path.join(ROOT, "tests", "cpp", "test_generic_known_answers.hip"), os.path.join(BUILD, "test_generic_known_answers")),
+            hipcc(os.path.join(ROOT, "tests", "cpp", "test_generic_schur_mixed.hip"), os.path.join(BUILD, "test_generic_schur_mixed")))
 
 
 def test_generic_layer_compiles_for_gfx950():
@@ -112,6 +113,16 @@ def test_tagged_bal_graph_runs_on_the_engine(oracle_mod, tmp_path, monkeypatch, 
         fx = subprocess.run([exe, str(f), solver, "3", "engine-fixed"], capture_output=True, text=True, timeout=300)
         assert fx.returncode == 0 and "handed to the gr_bal engine" not in fx.stderr
         assert len(parse_trace(fx.stdout)) == 3
+
+
+@pytest.mark.gpu
+def test_generic_schur_elimination_on_a_mixed_dimension_graph():
+    """2-D SLAM (poses of dimension 3, eliminated landmarks of dimension 2; prior, odometry and Huber sighting
+    factors): EigenSchurLDLTSolver and PCGSchurSolver reproduce the full EigenLDLTSolver optimisation."""
+    exe = build_all()[4]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-3000:], r.stderr[-500:])
+    assert r.returncode == 0 and "OK (0 failures)" in r.stdout
 
 
 def parse_trace(out):
