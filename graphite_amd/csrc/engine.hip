@@ -1005,7 +1005,11 @@ template <typename T> struct Engine final : EngineBase {
         break;
       }
       case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr); break;
-      case 5: k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, 1, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p); break;
+      case 5: { // variant 1: camera part (+ chi2 block) only, 2: point part only (the blocks of the other part return at once)
+        const int nc_v = variant == 2 ? 0 : (int)Nc, np_v = variant == 1 ? 0 : (int)Np;
+        k_linearize_finalize<T><<<cdiv(90 * (size_t)nc_v, TPB) + cdiv(FIN_PL * (size_t)np_v, TPB), TPB, 0, stream>>>(nc_v, np_v, 1, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, variant == 2 ? nullptr : dscalars.p);
+        break;
+      }
       case 6: { // block-Jacobi inverses: variant 1 cameras only, 2 points only, 3 with the fused PCG start
         const int nbc = variant == 2 ? 0 : cdiv(Nc, 64), nbp = variant == 1 ? 0 : cdiv(Np, 64);
         if (variant == 3) k_block_jacobi<T><<<nbc + nbp, 64, 0, stream>>>((int)Nc, (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, 1e-4, 0, MinvC.p, MinvP.p, v_diag.p, st, ctl_cap, nullptr, bu.p, v_dx.p, v_r.p, v_z.p, 0);

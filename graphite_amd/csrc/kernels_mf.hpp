@@ -488,6 +488,23 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
     for (int o = 1; o < FIN_PL; o <<= 1)
 #pragma unroll
       for (int i = 0; i < 9; ++i) v[i] += __shfl_xor(v[i], o, 64);
+#if FIN_PL == 4
+    { // every lane of the group holds the sums: the 15 outputs are written 4 lanes wide (lane jl: outputs jl, jl+4, ...)
+      const T out[16] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5], v[6], v[7], v[8],
+                         scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[0]))) : T(1),
+                         scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1),
+                         scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1), T(0)};
+      T *H = Hll + 9 * (size_t)l, *b3 = bl + 3 * (size_t)l, *s3 = scales + 9 * (size_t)Nc + 3 * (size_t)l;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const T val = jl == 0 ? out[4 * m] : jl == 1 ? out[4 * m + 1] : jl == 2 ? out[4 * m + 2] : out[4 * m + 3];
+        const unsigned idx = 4u * m + jl;
+        if (idx < 9u) H[idx] = val;
+        else if (idx < 12u) b3[idx - 9u] = val;
+        else if (idx < 15u) s3[idx - 12u] = val;
+      }
+    }
+#else
     if (jl == 0) {
       T *H = Hll + 9 * (size_t)l;
       H[0] = v[0]; H[1] = v[1]; H[2] = v[2]; H[3] = v[1]; H[4] = v[3]; H[5] = v[4]; H[6] = v[2]; H[7] = v[4]; H[8] = v[5];
@@ -497,6 +514,7 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
       s[1] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1);
       s[2] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1);
     }
+#endif
   }
   if (blockIdx.x == 0 && chi2_out) {
     __shared__ double red[4];

@@ -12,4 +12,5 @@ def t(which, var=0, reps=100): return f(g.h, C.c_int(which), C.c_int(var), C.c_i
 print('update whole', round(t(3), 2), 'cam only', round(t(3, 1), 2), 'points only', round(t(3, 2), 2))
 for nb in (128, 256, 512, 1024, 2048): print('  blocks', nb, round(t(3, nb), 2))
 print('block_jacobi', round(t(6), 2), 'cameras only', round(t(6, 1), 2), 'points only', round(t(6, 2), 2), 'with PCG start', round(t(6, 3), 2))
+print('finalize', round(t(5), 2), 'camera part', round(t(5, 1), 2), 'point part', round(t(5, 2), 2))
 print('direction', round(t(4), 2), 'finalize', round(t(5), 2), 'operator', round(t(0), 2), 'linearize', round(t(1), 2))
