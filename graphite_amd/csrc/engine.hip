@@ -384,15 +384,20 @@ template <typename T> struct Engine final : EngineBase {
           const int q = w[map[(size_t)h_cam_pm[b] * Nc + h_cam_pm[a]]]++;
           h_prod_a[q] = a; h_prod_b[q] = b;
         }
-    // work items: <= 56 products of one block per wave
+    // work items: <= `isz` products of one block per wave (7 lane groups, so a multiple of 7).  Measured on
+    // Ladybug-49 (82 K products over 1 225 blocks): 7 / 14 / 28 / 56 / 84 / 112 / 168 / 336 products per item ->
+    // 118 / 60 / 34 / 23.3 / 23.5 / 27 / 35 / 53 us: smaller items turn every block into a multi-item block (81 atomics
+    // per item), larger ones lengthen the serial product loop of a wave.
+    int isz = 56;
+    if (getenv("GR_SCHUR_ITEM")) isz = std::max(7, atoi(getenv("GR_SCHUR_ITEM")) / 7 * 7);
     std::vector<int> h_item_blk, h_item_beg, h_item_end, h_item_single, h_multi;
     for (int64_t q = 0; q < nnzb; ++q) {
       const int beg = h_prod_ptr[q], end = h_prod_ptr[q + 1];
-      const bool single = (end - beg) <= 56;
+      const bool single = (end - beg) <= isz;
       if (!single) h_multi.push_back((int)q);
       int b0 = beg;
       do {
-        const int e0 = std::min(b0 + 56, end);
+        const int e0 = std::min(b0 + isz, end);
         h_item_blk.push_back((int)q); h_item_beg.push_back(b0); h_item_end.push_back(e0); h_item_single.push_back(single ? 1 : 0);
         b0 = e0;
       } while (b0 < end);
