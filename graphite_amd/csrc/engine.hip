@@ -387,7 +387,9 @@ template <typename T> struct Engine final : EngineBase {
     // work items: <= `isz` products of one block per wave (7 lane groups, so a multiple of 7).  Measured on
     // Ladybug-49 (82 K products over 1 225 blocks): 7 / 14 / 28 / 56 / 84 / 112 / 168 / 336 products per item ->
     // 118 / 60 / 34 / 23.3 / 23.5 / 27 / 35 / 53 us: smaller items turn every block into a multi-item block (81 atomics
-    // per item), larger ones lengthen the serial product loop of a wave.
+    // per item), larger ones lengthen the serial product loop of a wave.  Per-item partials in a scratch array summed by
+    // the finishing pass instead of atomics: 19 us at 56, 17 us at 7..28, but the heavier finishing pass gives it back
+    // (8 765 vs 8 839 LM it/s): the kernel's floor is its chain of dependent index loads, not the atomics.
     int isz = 56;
     if (getenv("GR_SCHUR_ITEM")) isz = std::max(7, atoi(getenv("GR_SCHUR_ITEM")) / 7 * 7);
     std::vector<int> h_item_blk, h_item_beg, h_item_end, h_item_single, h_multi;
