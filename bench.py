@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--dtype", default=None, choices=[None, "f32", "f64"])
     ap.add_argument("--pcg-iterations", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-iters", type=int, default=2)
+    ap.add_argument("--cpu-baseline-iters", type=int, default=6)  # ~12 s of host work on Ladybug-1723
     ap.add_argument("--dump-kernels", default=None, help="write per-kernel HIP-event table to this JSON file")
     return ap.parse_args()
 
