@@ -159,6 +159,40 @@ def test_sharded_4way_reproduces_single_gpu_ladybug1723(ladybug1723):
     [e.close() for e in eng]
 
 
+@pytest.mark.parametrize("solver", [ga.SOLVER_PCG, ga.SOLVER_PCG_SCHUR_IMPLICIT])
+def test_sharded_2way_venice1778_fp32(venice1778, solver):
+    """BASELINE configs[3] at its full size, two landmark shards in one process: every rank sees the chi2 of the
+    unsharded run (fp32: the sums are re-associated, so to fp32 accuracy) and the replicated cameras stay bit-identical."""
+    single = ga.BalProblem(venice1778.cameras, venice1778.points, venice1778.obs, venice1778.cam_idx, venice1778.pt_idx, dtype=np.float32)
+    ct, _, _ = single.levenberg_marquardt(solver=solver, iterations=3)
+    single.close()
+    world = 2
+    shards = [gdist.partition_by_landmark(venice1778, r, world) for r in range(world)]
+    assert sum(len(s.obs) for s in shards) == len(venice1778.obs)
+    eng = [ga.BalProblem(s.cameras, s.points, s.obs, s.cam_idx, s.pt_idx, dtype=np.float32, shard=True) for s in shards]
+    gdist.init_local_group(eng)
+    out, err = [None] * world, []
+
+    def work(r):
+        try:
+            out[r] = eng[r].levenberg_marquardt(solver=solver, iterations=3)
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not err and all(o is not None for o in out)
+    m = min(len(ct), len(out[0][0]))
+    assert m >= 3
+    for r in range(world):
+        assert np.allclose(out[r][0][:m], ct[:m], rtol=2e-3)
+        assert np.array_equal(out[r][0], out[0][0])
+    cams = [e.get_params()[0] for e in eng]
+    assert all(np.array_equal(c, cams[0]) for c in cams)
+    [e.close() for e in eng]
+
+
 # ---- edge cases of the domain (small) -------------------------------------------------------------
 def edge_problem(seed=7):
     """ragged degrees: one point seen by every camera, many seen by exactly two; one camera with a single
