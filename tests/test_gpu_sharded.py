@@ -145,3 +145,26 @@ def test_rccl_single_rank_communicator():
     ct1, _, _ = gpu.levenberg_marquardt(solver=ga.SOLVER_PCG, iterations=6)
     gpu.close()
     assert np.allclose(ct1, ct, rtol=1e-10)
+
+
+# boundary shapes of the kernels' tilings, cut into 2 and 3 landmark shards (a shard may leave cameras without
+# any observation, end inside a wave, or hold a single point): (Nc, Np, No, window, seed)
+SHARD_SHAPES = [(3, 30, 65, 3, 3), (5, 60, 257, 5, 7), (29, 300, 1025, 8, 9), (70, 40, 2000, 70, 10), (64, 5000, 12000, 4, 13)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("shape", SHARD_SHAPES, ids=lambda s: "x".join(map(str, s[:3])))
+def test_sharded_boundary_shapes_all_solvers(shape, world):
+    Nc, Np, No, window, seed = shape
+    prob = synth.make_problem(Nc, Np, No, seed=seed, window=window)
+    for solver in (ga.SOLVER_PCG, ga.SOLVER_PCG_SCHUR_IMPLICIT, ga.SOLVER_PCG_SCHUR, ga.SOLVER_DENSE_SCHUR):
+        single = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+        ct, lt, st = single.levenberg_marquardt(solver=solver, iterations=6)
+        c1, p1 = single.get_params()
+        single.close()
+        out, cams, pts = run_sharded(prob, world, np.float64, 6, solver)
+        for r in range(world):
+            assert len(out[r][0]) == len(ct), (solver, r)
+            assert np.allclose(out[r][0], ct, rtol=1e-8), (solver, r, out[r][0], ct)
+            assert np.array_equal(cams[r], cams[0])
+        assert np.allclose(cams[0], c1, rtol=1e-6, atol=1e-9) and np.allclose(pts, p1, rtol=1e-6, atol=1e-9), solver
