@@ -26,9 +26,11 @@ EXPORTS = [
     "gr_bal_solver_update_structure", "gr_bal_solver_update_values", "gr_bal_solver_set_damping",
     "gr_bal_solver_solve", "gr_bal_schur_update_values", "gr_bal_schur_matvec",
     "gr_bal_landmark_update", "gr_bal_schur_structure", "gr_bal_get",
-    "gr_bal_levenberg_marquardt", "gr_bal_kernel_stats", "gr_comm_unique_id", "gr_bal_comm_init", "gr_bal_comm_init_local",
-    "gr_dense_cholesky_solve", "gr_bal_diag_time",
+    "gr_bal_levenberg_marquardt", "gr_bal_kernel_stats", "gr_comm_unique_id", "gr_bal_comm_init",
+    "gr_dense_cholesky_solve",
 ]
+# include/graphite_mi355x_test.h (test / diagnostic entry points, not part of the drop-in boundary)
+TEST_EXPORTS = ["gr_bal_comm_init_local", "gr_bal_diag_time"]
 
 
 class GraphiteError(RuntimeError):
@@ -40,13 +42,14 @@ class GraphiteError(RuntimeError):
 class LMOptions(C.Structure):
     _fields_ = [("solver", C.c_int32), ("iterations", C.c_int32), ("initial_damping", C.c_double),
                 ("use_identity", C.c_int32), ("pcg_max_iter", C.c_int32), ("pcg_tol", C.c_double),
-                ("pcg_rejection_ratio", C.c_double), ("profile", C.c_int32), ("early_stop", C.c_int32)]
+                ("pcg_rejection_ratio", C.c_double), ("profile", C.c_int32), ("early_stop", C.c_int32),
+                ("stop_flag", C.c_void_p)]
 
 
 class LMStats(C.Structure):
     _fields_ = [("iterations_run", C.c_int32), ("accepted", C.c_int32), ("pcg_iterations", C.c_int32),
                 ("ok", C.c_int32), ("setup_seconds", C.c_double), ("loop_seconds", C.c_double),
-                ("solve_seconds", C.c_double), ("final_chi2", C.c_double)]
+                ("solve_seconds", C.c_double), ("final_chi2", C.c_double), ("collectives", C.c_int64)]
 
 
 class KernelStat(C.Structure):

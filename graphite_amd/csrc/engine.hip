@@ -8,7 +8,7 @@
 //   PCGSchurSolver, PCGSolver + block-Jacobi preconditioners                   (solver/, preconditioner/)
 //   optimizer::levenberg_marquardt                                             (optimizer/levenberg_marquardt.hpp)
 // The C ABI at the bottom (include/graphite_mi355x.h) is the drop-in boundary.
-#include "../../include/graphite_mi355x.h"
+#include "../../include/graphite_mi355x_test.h"
 #include "comm.hpp"
 #include <functional>
 #include "kernels_is.hpp"
@@ -97,8 +97,12 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<T> raw_c;
   int cam_weight() const { return (!comm || comm->rank == 0) ? 1 : 0; }
   void set_comm(std::unique_ptr<Comm> c) override { comm = std::move(c); raw_c.alloc(pose_dim); }
-  void allreduce_T(T *buf, size_t count) { comm->allreduce(buf, count, sizeof(T) == 8, stream); }
-  void allreduce_d(double *buf, size_t count) { comm->allreduce(buf, count, true, stream); }
+  int64_t coll_count = 0; // collectives issued (a group counts once): gr_lm_stats.collectives
+  bool coll_in_group = false;
+  void allreduce_T(T *buf, size_t count) { if (!coll_in_group) ++coll_count; comm->allreduce(buf, count, sizeof(T) == 8, stream); }
+  void allreduce_d(double *buf, size_t count) { if (!coll_in_group) ++coll_count; comm->allreduce(buf, count, true, stream); }
+  void group_start() { ++coll_count; coll_in_group = true; comm->group_start(); }
+  void group_end() { comm->group_end(); coll_in_group = false; }
   // matrix-free PCG control
   DevBuf<double> ctl; // PCG slot accumulators + loop state
   DevBuf<int> ctl_i;
@@ -226,7 +230,7 @@ template <typename T> struct Engine final : EngineBase {
     alloc_pinned(64);
     g9.alloc(8 * (size_t)No); g3.alloc(3 * (size_t)No);
     v_dx.alloc(n);
-    tmp.alloc(std::max<size_t>(n, 27 * (size_t)No));
+    tmp.alloc(std::max({n, 27 * (size_t)No, 81 * (size_t)Nc})); // get(): b (n), Hcp (27 No), Hcc (81 Nc)
     GR_HIP(hipStreamSynchronize(stream));
   }
 
@@ -336,7 +340,10 @@ template <typename T> struct Engine final : EngineBase {
       for (int a = h_pt_ptr[l]; a < h_pt_ptr[l + 1]; ++a)
         for (int b = a; b < h_pt_ptr[l + 1]; ++b) map[(size_t)h_cam_pm[b] * Nc + h_cam_pm[a]] = 0;
     }
-    if (np >= (int64_t)std::numeric_limits<int>::max()) throw std::invalid_argument("too many Schur products for 32-bit indices");
+    // rank-local condition: with a communicator it is agreed on through the flags all-reduce below, so that
+    // either every rank throws or none does (a rank that left early would leave its peers in the collective)
+    bool too_many = np >= (int64_t)std::numeric_limits<int>::max();
+    if (too_many && !comm) throw std::invalid_argument("too many Schur products for 32-bit indices");
     nprod = np;
     if (comm) {
       // Landmark shards: every rank holds the products of its own points but the block list must be the
@@ -351,10 +358,14 @@ template <typename T> struct Engine final : EngineBase {
             const size_t idx = (size_t)j * (j + 1) / 2 + i;
             packed[idx / 6] += (double)(1ull << (8 * (idx % 6)));
           }
+      packed.push_back(too_many ? 1.0 : 0.0);
       DevBuf<double> flags;
       flags.upload(packed, stream);
       allreduce_d(flags.p, packed.size());
       packed = flags.download(stream);
+      too_many = packed.back() != 0.0;
+      packed.pop_back();
+      if (too_many) throw std::invalid_argument("too many Schur products for 32-bit indices (on at least one landmark shard)");
       for (int64_t j = 0; j < Nc; ++j)
         for (int64_t i = 0; i <= j; ++i) {
           const size_t idx = (size_t)j * (j + 1) / 2 + i;
@@ -548,11 +559,11 @@ template <typename T> struct Engine final : EngineBase {
                                                                                                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gate);
     }
     if (comm) { // camera-space sums over the landmark shards
-      comm->group_start();
+      group_start();
       allreduce_T(Hcc.p, 81 * (size_t)Nc);
       allreduce_T(bc.p, pose_dim);
       allreduce_d(dscalars.p, spec_seq ? 2 : 1);
-      comm->group_end();
+      group_end();
       k_camera_scales<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, scale_system ? 1 : 0, Hcc.p, scales.p);
     }
     hcp_valid = write_hcp;
@@ -615,15 +626,18 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   // ---- Solver interface ---------------------------------------------------------
+  // per-block partials of the Schur-PCG scalars (kernels.hpp PcgScalars): one slot per block of the largest producer grid
+  int sc_np() const { return (std::max({cdiv(Nc, 64), cdiv(pose_dim, 252), cdiv(Nc, 4)}) + 63) / 64 * 64; }
   void ensure_scalars(int max_iter) {
     const int cap = max_iter + 2;
-    if (cap > sc_cap) { sc_cap = cap; sc_d.alloc((4 * (size_t)NSW + 1) * cap); sc_i.alloc((size_t)cap + 1); }
+    if (cap > sc_cap) { sc_cap = cap; sc_d.alloc((2 * (size_t)sc_np() + 1) * cap); sc_i.alloc((size_t)cap + 1); }
     alloc_pinned(cap);
   }
   PcgScalars scalars() {
     PcgScalars sc;
-    const size_t blk = (size_t)sc_cap * NSW;
-    sc.rz = sc_d.p; sc.den = sc_d.p + blk; sc.rr = sc_d.p + 2 * blk; sc.pdp = sc_d.p + 3 * blk; sc.rz0 = sc_d.p + 4 * blk;
+    sc.np = sc_np();
+    const size_t blk = (size_t)sc_cap * sc.np;
+    sc.rz = sc_d.p; sc.den = sc_d.p + blk; sc.rz0 = sc_d.p + 2 * blk;
     sc.done = sc_i.p; sc.iters = sc_i.p + sc_cap;
     sc.hflag = h_flag; sc.hiters = h_seq + 1;
     return sc;
@@ -693,10 +707,10 @@ template <typename T> struct Engine final : EngineBase {
       // every rank reduced over its own points (rank 0 also carries the damped Hcc and bc, which are global already):
       // one grouped all-reduce makes S and b_S global, the solve that follows is replicated
       Scope sc(this, "allreduce_schur", 0, 0);
-      comm->group_start();
+      group_start();
       allreduce_T(S.p, 81 * (size_t)nnzb);
       allreduce_T(b_schur.p, (size_t)pose_dim);
-      comm->group_end();
+      group_end();
     }
   }
   // replicated reduced solves: rank 0's camera step is the one every rank applies (the per-rank copies agree
@@ -949,10 +963,10 @@ template <typename T> struct Engine final : EngineBase {
       }
       if (comm) { // camera rows + the p.A.p partials, summed over the landmark shards
         k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, nullptr, k);
-        comm->group_start();
+        group_start();
         allreduce_T(raw_c.p, pose_dim);
         allreduce_d(st.acc + ((size_t)k * NSLOT + DEN) * NSW, NSW);
-        comm->group_end();
+        group_end();
       }
       {
         Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
@@ -1135,10 +1149,10 @@ template <typename T> struct Engine final : EngineBase {
   struct LmGraphKey {
     int solver = -1, max_iter = 0, use_identity = 0, jac32 = 0, loss_kind = 0, records = 0, cap = 0;
     double tol = 0, rej = 0, loss_delta = 0;
-    const void *xp = nullptr;
+    const void *xp = nullptr, *pinned = nullptr; // pinned: h_res block baked into the captured PcgState
     bool operator==(const LmGraphKey &o) const {
       return solver == o.solver && max_iter == o.max_iter && use_identity == o.use_identity && jac32 == o.jac32 && loss_kind == o.loss_kind &&
-             records == o.records && cap == o.cap && tol == o.tol && rej == o.rej && loss_delta == o.loss_delta && xp == o.xp;
+             records == o.records && cap == o.cap && tol == o.tol && rej == o.rej && loss_delta == o.loss_delta && xp == o.xp && pinned == o.pinned;
     }
   };
   LmGraphKey lmg_key;
@@ -1186,7 +1200,7 @@ template <typename T> struct Engine final : EngineBase {
                                                                                                     rho_partial.p, rho_blocks, nullptr, nullptr, 0, lm, pcg_iters.p, h_trace, h_trace + h_trace_cap, h_lm, h_lm + 1);
   }
   bool lm_graph_prepare(const gr_lm_options &opt) {
-    if (!lm_graph_enabled || comm || profiling || opt.early_stop || opt.iterations < 2 || opt.pcg_max_iter < 1) return false;
+    if (!lm_graph_enabled || comm || profiling || opt.early_stop || opt.stop_flag || opt.iterations < 2 || opt.pcg_max_iter < 1) return false;
     if (opt.solver != GR_SOLVER_PCG && opt.solver != GR_SOLVER_PCG_IDENTITY) return false;
     if (getenv("GR_LM_SPECULATE") && atoi(getenv("GR_LM_SPECULATE")) == 0) return false;
     ensure_ctl(opt.pcg_max_iter);
@@ -1207,7 +1221,7 @@ template <typename T> struct Engine final : EngineBase {
     damping_identity = opt.use_identity != 0;
     key.solver = opt.solver; key.max_iter = opt.pcg_max_iter; key.use_identity = opt.use_identity; key.jac32 = jac32 ? 1 : 0;
     key.loss_kind = loss_kind; key.records = use_records ? 1 : 0; key.cap = ctl_cap; key.tol = opt.pcg_tol; key.rej = opt.pcg_rejection_ratio;
-    key.loss_delta = (double)loss_delta; key.xp = xp.p;
+    key.loss_delta = (double)loss_delta; key.xp = xp.p; key.pinned = h_res;
     const int mi = opt.pcg_max_iter; const double tl_ = opt.pcg_tol, rj_ = opt.pcg_rejection_ratio;
     if (opt.solver == GR_SOLVER_PCG_IDENTITY) lm_enqueue_fn = [this, mi, tl_, rj_] { lm_graph_enqueue<true>(mi, tl_, rj_); };
     else lm_enqueue_fn = [this, mi, tl_, rj_] { lm_graph_enqueue<false>(mi, tl_, rj_); };
@@ -1294,6 +1308,8 @@ template <typename T> struct Engine final : EngineBase {
     int accept_streak = 2; // consecutive accepted iterations (saturating): speculate only on a streak
     int num_bad = 0;       // levenberg_marquardt2 (:404-414): consecutive accepted iterations gaining < 0.1 %
     const bool spec_enabled = !(getenv("GR_LM_SPECULATE") && atoi(getenv("GR_LM_SPECULATE")) == 0);
+    const bool ahead_enabled = !(getenv("GR_LM_AHEAD") && atoi(getenv("GR_LM_AHEAD")) == 0);
+    const int64_t coll0 = coll_count;
     if (chi2_trace) chi2_trace[0] = (double)chi2v;
     if (lambda_trace) lambda_trace[0] = (double)mu;
     hipEvent_t ev_a, ev_b;
@@ -1364,7 +1380,7 @@ template <typename T> struct Engine final : EngineBase {
         seq = ++seq_counter;
         linearize_impl(want_hcp, /*pack_valid=*/true, seq, gate);
       };
-      const bool ahead = speculate && !comm && !profiling && !(getenv("GR_LM_AHEAD") && atoi(getenv("GR_LM_AHEAD")) == 0) &&
+      const bool ahead = speculate && !comm && !profiling && ahead_enabled &&
                          (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY);
       if (ahead) trial_hook = enqueue_trial;
       trial_done = false;
@@ -1424,11 +1440,13 @@ template <typename T> struct Engine final : EngineBase {
       const bool go = host_iteration(i);
       ++i;
       if (!go) break;
+      if (opt.stop_flag && *opt.stop_flag) break; // levenberg_marquardt.hpp:233-238: polled once per iteration
     }
     GR_HIP(hipStreamSynchronize(stream));
     st.loop_seconds = std::chrono::duration<double>(clk::now() - tl).count();
     st.ok = run ? 1 : 0;
     st.final_chi2 = (double)chi2v;
+    st.collectives = coll_count - coll0;
     if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] LM: trial step enqueued ahead of the PCG exit flag in %d iterations, not ahead in %d\n", ahead_hits, ahead_misses);
     if (getenv("GR_VERBOSE") && graph_mode)
       std::fprintf(stderr, "[graphite-mi355x] LM: %d of %d iterations replayed as graphs; handed back: %d (PCG iterations), %d (not accepted)\n", g_steps, st.iterations_run, g_stop1, g_stop2);

@@ -127,14 +127,26 @@ __global__ void k_export_blocks(size_t nblocks, int rows, int cols, const T *__r
 //   rz0[k] running min of |rz_new| before iteration k (inf at k = 0); done[k] loop left before k
 // Kernels of iteration k only READ slots written by earlier launches and accumulate
 // into slot k / k+1, so there are no intra-launch races.
+// The partial sums of rz / den are ONE PER BLOCK of the producing kernel, stored (not atomically added)
+// at partial index blockIdx.x and re-summed by every consumer wave in a fixed order: the scalars are then
+// bit-reproducible, and identical on every rank of a landmark-sharded run whose camera-space vectors are
+// replicated — the loop decisions (and with them the collectives each rank enqueues) cannot diverge.
 struct PcgScalars {
-  double *rz, *den, *rr, *pdp; // [cap][NSW] (NS partials, one L2 line each)
+  double *rz, *den;            // [cap][np] per-block partials
+  int np;                      // partials per scalar: multiple of 64, >= the largest producer grid
   double *rz0;                 // [cap]
   int *done, *iters;           // [cap], [1]
   volatile int *hflag;         // pinned host memory [cap]: 1 = iteration finished, 2 = loop left (may be null)
   volatile int *hiters;        // pinned host mirror of iters (may be null)
 };
 
+__device__ __forceinline__ void part_store(double *base, int np, int k, double v) { base[(size_t)k * np + blockIdx.x] = v; }
+__device__ __forceinline__ double part_sum(const double *base, int np, int k) { // whole wave must call; fixed order
+  double s = 0;
+  const double *q = base + (size_t)k * np;
+  for (int i = threadIdx.x & 63; i < np; i += 64) s += q[i];
+  return wave_allsum(s);
+}
 
 // Per point: scaled + damped Hll, its inverse (scaled space, kept for
 // back-substitution and parity), M' = Dp Hll^-1 Dp and v = M' bl^u.
@@ -145,7 +157,7 @@ __global__ void k_point_prepare(int Np, int Nc, const T *__restrict__ Hll, const
                                 T *__restrict__ Hll_inv, T *__restrict__ Mp, T *__restrict__ vl,
                                 PcgScalars pcg = PcgScalars{}, int cap = 0) {
   if (pcg.rz && blockIdx.x == gridDim.x - 1) { // one extra block: reset of the PCG scalars of the solve that follows
-    for (int i = threadIdx.x; i < cap * NS; i += blockDim.x) { const size_t q = slot_word(i); pcg.rz[q] = 0.0; pcg.den[q] = 0.0; pcg.rr[q] = 0.0; pcg.pdp[q] = 0.0; }
+    for (int i = threadIdx.x; i < cap * pcg.np; i += blockDim.x) { pcg.rz[i] = 0.0; pcg.den[i] = 0.0; }
     for (int i = threadIdx.x; i < cap; i += blockDim.x) { pcg.done[i] = 0; pcg.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
     if (threadIdx.x == 0) pcg.iters[0] = 0;
     return;
@@ -385,14 +397,14 @@ k_schur_matvec(int Nc, const int *__restrict__ row_ptr, const int *__restrict__ 
                T *__restrict__ y, PcgScalars sc, int k) {
   if (k >= 0) {
     if (sc.done[k]) return;
-    if (slot_sum(sc.rz, k) == 0.0) return;
+    if (part_sum(sc.rz, sc.np, k) == 0.0) return;
   }
+  __shared__ double wdot[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
-  if (i >= Nc) return;
   const int g = lane / 9, r = lane % 9;
   T acc = 0;
-  if (g < 7) {
+  if (g < 7 && i < Nc) {
     for (int e = row_ptr[i] + g; e < row_ptr[i + 1]; e += 7) {
       const int blk = row_blk[e], j = row_col[e];
       const bool transposed = blk < 0; // encoded as ~blk
@@ -411,13 +423,15 @@ k_schur_matvec(int Nc, const int *__restrict__ row_ptr, const int *__restrict__ 
 #pragma unroll
   for (int gg = 1; gg < 7; ++gg) tot += __shfl(acc, gg * 9 + r, 64);
   T dot = 0;
-  if (lane < 9) {
+  if (lane < 9 && i < Nc) {
     y[9 * (size_t)i + r] = tot;
     dot = tot * x[9 * (size_t)i + r];
   }
-  if (k >= 0) {
-    dot = wave_sum(dot);
-    if (lane == 0) slot_add(sc.den, k, (double)dot);
+  if (k >= 0) { // one partial per block (4 rows), the waves summed in fixed order
+    const double dw = wave_sum((double)dot);
+    if (lane == 0) wdot[wave] = dw;
+    __syncthreads();
+    if (threadIdx.x == 0) part_store(sc.den, sc.np, k, wdot[0] + wdot[1] + wdot[2] + wdot[3]);
   }
 }
 
@@ -469,7 +483,7 @@ k_schur_pcg_prepare(int Nc, const T *__restrict__ Ssrc, const int *__restrict__ 
     for (int i = 0; i < 81; ++i) Minv[81 * (size_t)c + i] = (T)A[i];
   }
   part = wave_sum(part);
-  if (threadIdx.x == 0) slot_add(sc.rz, 0, part);
+  if (threadIdx.x == 0) part_store(sc.rz, sc.np, 0, part);
 }
 
 // x_backup = x; x += alpha p; r -= alpha Ap; z = Minv r; rz[k+1] += r.z   (:125-142)
@@ -479,9 +493,9 @@ k_pcgs_update(int Nc, T *__restrict__ x, T *__restrict__ xb, T *__restrict__ r, 
               const T *__restrict__ p, const T *__restrict__ Ap, const T *__restrict__ Minv,
               PcgScalars sc, int k) {
   if (sc.done[k]) return;
-  const double rz = slot_sum(sc.rz, k);
+  const double rz = part_sum(sc.rz, sc.np, k);
   if (rz == 0.0) return;
-  const double den = slot_sum(sc.den, k);
+  const double den = part_sum(sc.den, sc.np, k);
   if (den == 0.0 || den != den) return;
   __shared__ double red[4];
   __shared__ T rs[TPB];
@@ -510,7 +524,7 @@ k_pcgs_update(int Nc, T *__restrict__ x, T *__restrict__ xb, T *__restrict__ r, 
     part = (double)(rn * s);
   }
   part = block_sum_256(part, red);
-  if (threadIdx.x == 0) slot_add(sc.rz, k + 1, part);
+  if (threadIdx.x == 0) part_store(sc.rz, sc.np, k + 1, part);
 }
 
 // rejection / beta / p update / tolerance (:143-163); thread 0 publishes slot k+1
@@ -524,11 +538,11 @@ k_pcgs_direction(int Nc, T *__restrict__ x, const T *__restrict__ xb, T *__restr
   const double rz0 = sc.rz0[k];
   auto publish = [&](int flag) { if (sc.hflag) { sc.hflag[k] = flag; __threadfence_system(); } };
   if (sc.done[k]) { if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; publish(2); } return; }
-  const double rz = slot_sum(sc.rz, k);
-  const double den = slot_sum(sc.den, k);
+  const double rz = part_sum(sc.rz, sc.np, k);
+  const double den = part_sum(sc.den, sc.np, k);
   if (rz == 0.0 || den == 0.0 || den != den) { if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; publish(2); } return; }
   // T-precision scalars, as the reference keeps them in T on the host
-  const T rz_new = (T)slot_sum(sc.rz, k + 1);
+  const T rz_new = (T)part_sum(sc.rz, sc.np, k + 1);
   const bool reject = (fabs((double)rz_new) > rejection_ratio * rz0) || (rz_new != rz_new);
   if (reject) {
     if (t < 9u * (unsigned)Nc) x[t] = xb[t];

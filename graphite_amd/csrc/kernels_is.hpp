@@ -164,7 +164,7 @@ k_is_pass1(int No, int ntiles, const int *__restrict__ cam_cm, const int *__rest
            PcgScalars sc, int k) {
   if (k >= 0) {
     if (sc.done[k]) return;
-    if (slot_sum(sc.rz, k) == 0.0) return;
+    if (part_sum(sc.rz, sc.np, k) == 0.0) return;
   }
   cm_tiles<T>(No, ntiles, cam_cm, pt_cm, pos_cm, obs_cm, [&](int, bool valid, int c, int l, int a, T ox, T oy) {
     if (!valid) return;
@@ -193,7 +193,7 @@ __global__ void k_is_points(int Np, int Nc, const int *__restrict__ pt_ptr, cons
                             const T *__restrict__ scales, T *__restrict__ out, PcgScalars sc, int k) {
   if (MODE == 0) {
     if (sc.done[k]) return;
-    if (slot_sum(sc.rz, k) == 0.0) return;
+    if (part_sum(sc.rz, sc.np, k) == 0.0) return;
   }
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= Np) return;
@@ -219,7 +219,7 @@ k_is_pass2(int No, int ntiles, const int *__restrict__ cam_cm, const int *__rest
            const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
            int loss_kind, T loss_delta, const T *__restrict__ zl, T *__restrict__ op_partial, PcgScalars sc, int k) {
   if (sc.done[k]) return;
-  if (slot_sum(sc.rz, k) == 0.0) return;
+  if (part_sum(sc.rz, sc.np, k) == 0.0) return;
   const int lane = threadIdx.x & 63;
   cm_tiles<T>(No, ntiles, cam_cm, pt_cm, pos_cm, obs_cm, [&](int j, bool valid, int c, int l, int, T ox, T oy) {
     int seg = 0;
@@ -256,7 +256,7 @@ k_is_apply(int Nc, const int *__restrict__ cam_seg_ptr, const T *__restrict__ op
            const T *__restrict__ q, double mu, int use_identity, T *__restrict__ Ap, PcgScalars sc, int k,
            const T *__restrict__ rawc = nullptr) {
   if (sc.done[k]) return;
-  if (slot_sum(sc.rz, k) == 0.0) return;
+  if (part_sum(sc.rz, sc.np, k) == 0.0) return;
   __shared__ double red[4];
   __shared__ T qs[TPB];
   const unsigned t = blockIdx.x * 252u + threadIdx.x;
@@ -282,7 +282,7 @@ k_is_apply(int Nc, const int *__restrict__ cam_seg_ptr, const T *__restrict__ op
     part = (double)(out * pv);
   }
   part = block_sum_256(part, red);
-  if (threadIdx.x == 0) slot_add(sc.den, k, part);
+  if (threadIdx.x == 0) part_store(sc.den, sc.np, k, part);
 }
 
 } // namespace gr

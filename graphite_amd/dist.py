@@ -30,9 +30,13 @@ def partition_by_landmark(prob: HostProblem, rank: int, world: int) -> HostProbl
     """The shard of `prob` owned by `rank`: all cameras, points [p0, p1) renumbered from 0 and
     exactly their observations (original relative order kept)."""
     Nc, Np, No = prob.shape
-    p0, p1 = point_ranges(prob.pt_idx, Np, world)[rank]
-    if p1 <= p0:
-        raise ValueError(f"rank {rank} of {world} owns no points")
+    ranges = point_ranges(prob.pt_idx, Np, world)
+    # validated for EVERY rank on every rank: all of them raise, or none does (a rank that raised alone would
+    # leave its peers waiting in init_comm's broadcast)
+    empty = [r for r, (a, b) in enumerate(ranges) if b <= a]
+    if empty:
+        raise ValueError(f"ranks {empty} of {world} would own no points ({Np} points)")
+    p0, p1 = ranges[rank]
     sel = np.nonzero((prob.pt_idx >= p0) & (prob.pt_idx < p1))[0]
     shard = HostProblem(prob.cameras, prob.points[p0:p1].copy(), prob.obs[sel].copy(),
                         prob.cam_idx[sel].copy(), (prob.pt_idx[sel] - p0).astype(np.int32), f"{prob.name}[{rank}/{world}]")

@@ -626,6 +626,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   gr_lm_options o{};
   o.solver = kind; o.iterations = (int32_t)options->iterations; o.initial_damping = options->initial_damping;
   o.use_identity = options->use_identity ? 1 : 0; o.early_stop = early_stop ? 1 : 0;
+  o.stop_flag = reinterpret_cast<const volatile unsigned char *>(options->stop_flag); // polled per iteration by the engine
   int m; double tl, rj;
   options->solver->engine_pcg_parameters(m, tl, rj);
   o.pcg_max_iter = m; o.pcg_tol = tl; o.pcg_rejection_ratio = rj;
@@ -656,7 +657,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
 
 template <bool EARLY, typename T, typename S> bool lm_loop(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {
   if (!options->validate()) return false;
-  if (!(options->stop_flag && *options->stop_flag)) { // the engine runs the whole loop in one call: the flag is polled here only
+  {
     bool result = false;
     if (engine_levenberg_marquardt(graph, options, EARLY, result)) return result;
   }

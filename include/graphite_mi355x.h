@@ -82,6 +82,8 @@ typedef struct {
   int32_t profile;          /* record HIP events around the dominant kernels */
   int32_t early_stop;       /* levenberg_marquardt2 (:255-418): also leave after 3 consecutive accepted
                                iterations that each lower chi2 by less than 0.1 % */
+  const volatile unsigned char *stop_flag; /* LevenbergMarquardtOptions::stop_flag (a host `bool *`, may be NULL):
+                               polled once per LM iteration, after it, as levenberg_marquardt.hpp:233-238 does */
 } gr_lm_options;
 
 typedef struct {
@@ -93,6 +95,8 @@ typedef struct {
   double loop_seconds;      /* the LM for-loop (host wall clock, stream synchronised) */
   double solve_seconds;     /* device time inside solver->solve (HIP events)          */
   double final_chi2;
+  int64_t collectives;      /* landmark-sharded runs: collective operations (grouped calls count once) issued inside
+                               the LM loop by this rank; 0 without a communicator */
 } gr_lm_stats;
 
 const char *gr_version(void);
@@ -197,8 +201,6 @@ gr_status gr_bal_kernel_stats(gr_bal_problem *p, gr_kernel_stat *out, int cap, i
  * rank 0 by gr_comm_unique_id and broadcast by the caller (e.g. torch.distributed). */
 gr_status gr_comm_unique_id(void *unique_id_128);
 gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int rank, int world_size);
-/* test only: in-process group of `n` shards on one GPU, one host thread per shard */
-gr_status gr_bal_comm_init_local(gr_bal_problem **problems, int n);
 /* Dense SPD solve A x = b on the MFMA Cholesky that GR_SOLVER_DENSE_SCHUR uses (the numerical role of
  * Eigen::SimplicialLDLT in src/eigen_solver.cpp:8-30 / cuDSS in solver/cudss.hpp:183-256 once S is dense).
  * A: n x n row-major, leading dimension lda, lower triangle read; A, b, x host or device pointers (x may
@@ -206,8 +208,6 @@ gr_status gr_bal_comm_init_local(gr_bal_problem **problems, int n);
  * GR_ERR_SOLVE_FAILED when a pivot is not positive. */
 gr_status gr_dense_cholesky_solve(gr_dtype dtype, int64_t n, const void *A, int64_t lda, const void *b, void *x,
                                   int device, void *stream, double *factor_seconds);
-/* diagnostic: mean device time (us) of `reps` launches of one hot kernel */
-double gr_bal_diag_time(gr_bal_problem *p, int which, int variant, int reps);
 
 #ifdef __cplusplus
 }

@@ -204,7 +204,7 @@ public:
 // optimizer/levenberg_marquardt.hpp:110-242.  The loop runs inside the library (one call); with
 // options->verbose the reference's iteration table (:153-163, :216-221) is printed afterwards from
 // the recorded traces (per-iteration wall times are not recorded: the Time column shows the mean).
-// stop_flag is polled before the call only.
+// stop_flag is handed to the library, which polls it after every iteration as the reference does (:233-238).
 namespace detail {
 template <typename T, typename S>
 bool lm_call(BalGraph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, gr_lm_stats *stats_out, bool early_stop) {
@@ -212,13 +212,13 @@ bool lm_call(BalGraph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, gr
     if (options->verbose) std::cerr << "Levenberg-Marquardt options invalid" << std::endl;
     return false;
   }
-  if (options->stop_flag && *(options->stop_flag)) return true;
   gr_lm_options o{};
   o.solver = options->solver->kind();
   o.iterations = (int32_t)options->iterations;
   o.initial_damping = options->initial_damping;
   o.use_identity = options->use_identity;
   o.early_stop = early_stop ? 1 : 0;
+  o.stop_flag = reinterpret_cast<const volatile unsigned char *>(options->stop_flag);
   int m; double t, r;
   options->solver->pcg_parameters(m, t, r);
   o.pcg_max_iter = m; o.pcg_tol = t; o.pcg_rejection_ratio = r;

@@ -1,0 +1,19 @@
+/* graphite_mi355x_test.h — TEST / DIAGNOSTIC entry points of libgraphite_mi355x.so.
+ *
+ * Not part of the drop-in boundary (include/graphite_mi355x.h): nothing here replaces a reference
+ * interface.  Used by tests/ and tools/ only. */
+#ifndef GRAPHITE_MI355X_TEST_H
+#define GRAPHITE_MI355X_TEST_H
+#include "graphite_mi355x.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* in-process group of `n` landmark shards on ONE GPU, one host thread per shard afterwards: exercises the
+ * sharded algorithm on a 1-GPU box (the product communicator is gr_bal_comm_init, RCCL) */
+gr_status gr_bal_comm_init_local(gr_bal_problem **problems, int n);
+/* mean device time (us) of `reps` back-to-back launches of one hot kernel (tools/diag_*.py) */
+double gr_bal_diag_time(gr_bal_problem *p, int which, int variant, int reps);
+#ifdef __cplusplus
+}
+#endif
+#endif

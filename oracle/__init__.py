@@ -309,3 +309,50 @@ class BalOracle:
         stats = dict(iterations_run=int(st[0]), accepted=int(st[1]), pcg_iterations=int(st[2]),
                      solve_seconds=st[3], loop_seconds=st[4], setup_seconds=st[5], ok=bool(run))
         return ct[:k], lt[:k], stats
+
+
+class CpuBaseline:
+    """Timed CPU comparator (oracle/cpu_baseline.hpp): the oracle's LM with OpenMP-parallel assembly and the
+    single-thread simplicial LDL^T (full H or Schur), or the all-cores block-Jacobi PCG."""
+
+    TIME_KEYS = ("linearize", "hessian", "schur", "export_csc", "ldlt_analyze", "ldlt_factor", "ldlt_solve",
+                 "backsub", "pcg", "update_chi2", "loop", "setup", "ldlt_nnz", "threads")
+
+    def __init__(self, cams, pts, obs, cam_idx, pt_idx, dtype=np.float64):
+        self.dt = np.dtype(dtype)
+        cams = np.ascontiguousarray(cams, dtype=self.dt).reshape(-1, 9)
+        pts = np.ascontiguousarray(pts, dtype=self.dt).reshape(-1, 3)
+        obs = np.ascontiguousarray(obs, dtype=self.dt).reshape(-1, 2)
+        ci = np.ascontiguousarray(cam_idx, dtype=np.int32)
+        pi = np.ascontiguousarray(pt_idx, dtype=np.int32)
+        self._init = (cams, pts)
+        f = _fn("gro_baseline_create", self.dt, C.c_void_p)
+        self.h = C.c_void_p(f(C.c_size_t(len(cams)), C.c_size_t(len(pts)), C.c_size_t(len(obs)), _p(cams), _p(pts),
+                              _p(obs), _p(ci), _p(pi)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _fn("gro_baseline_destroy", self.dt)(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def reset(self):
+        _fn("gro_bal_set_params", self.dt)(self.h, _p(self._init[0]), _p(self._init[1]))
+
+    def levenberg_marquardt(self, solver, iterations, threads=0, ordering=1, initial_damping=1e-4, pcg_max_iter=10,
+                            pcg_tol=1.0, pcg_rej=5.0):
+        """threads: 0 = all host cores; ordering: 1 = minimum degree (the AMD role), 0 = reverse Cuthill-McKee."""
+        ct = np.zeros(iterations + 1)
+        lt = np.zeros(iterations + 1)
+        st = np.zeros(6)
+        tm = np.zeros(14)
+        f = _fn("gro_baseline_lm", self.dt, C.c_int)
+        f(self.h, C.c_int(solver), C.c_int(iterations), C.c_double(initial_damping), C.c_int(pcg_max_iter),
+          C.c_double(pcg_tol), C.c_double(pcg_rej), C.c_int(threads), C.c_int(ordering), _p(ct), _p(lt), _p(st), _p(tm))
+        k = int(st[0]) + 1
+        stats = dict(iterations_run=int(st[0]), accepted=int(st[1]), pcg_iterations=int(st[2]), solve_seconds=st[3],
+                     loop_seconds=st[4], setup_seconds=st[5])
+        times = dict(zip(self.TIME_KEYS, (float(x) for x in tm)))
+        return ct[:k], lt[:k], stats, times

@@ -16,7 +16,12 @@
 //   EigenLDLTSolver / EigenSchurLDLTSolver    solver/eigen.hpp:49-98, eigen_schur.hpp:52-108
 //   levenberg_marquardt / compute_rho         optimizer/levenberg_marquardt.hpp:20-47,110-242
 // Everything lives in the column-SCALED space exactly as the reference does it
-// (scale stored J in place, then multiply), sums sequential in factor order.
+// (scale stored J in place, then multiply), per-vertex sums sequential in factor order.
+// The GLOBAL reductions (chi2, the PCG dot products, compute_rho's denominator) are
+// thrust::reduce / thrust::inner_product in the reference (ops/chi2.hpp:61-64,
+// ops/vector.hpp), i.e. tree reductions in T whose order is not pinned; they are restated
+// as pairwise (tree) sums in T.  A sequential fp32 accumulation of the 5 M chi2 terms of
+// Venice-1778 is off by 0.4 %, which no tree reduction is.
 #pragma once
 #include "bal_model.hpp"
 #include "generic_ops.hpp"
@@ -57,6 +62,13 @@ struct LMStats {
   double loop_seconds = 0;  // time of the LM for-loop
   double setup_seconds = 0; // structure + first linearize
 };
+
+// pairwise (tree) sum in T of f(0..m-1): the summation shape of thrust::reduce
+template <typename T, typename F> static T tree_sum(size_t lo, size_t hi, F &&f) {
+  if (hi - lo <= 32) { T s = 0; for (size_t i = lo; i < hi; ++i) s += f(i); return s; }
+  const size_t mid = lo + (hi - lo) / 2;
+  return tree_sum<T>(lo, mid, f) + tree_sum<T>(mid, hi, f);
+}
 
 template <typename T> struct BalOracle {
   size_t Nc = 0, Np = 0, No = 0, n = 0, pose_dim = 0;
@@ -153,14 +165,12 @@ template <typename T> struct BalOracle {
       bal_residual(&cams[9 * cam_idx[o]], &pts[3 * pt_idx[o]], &obs[2 * o], &res[2 * o]);
   }
   T chi2() { // graph.hpp:219-225, factor.hpp:551-557, ops/chi2.hpp:34-44 (P = I)
-    T total = 0;
     for (size_t o = 0; o < No; ++o) {
       const T raw = res[2 * o] * res[2 * o] + res[2 * o + 1] * res[2 * o + 1];
       chi2_vec[o] = loss_value(loss_kind, loss_delta, raw);
       dchi2[o] = loss_derivative(loss_kind, loss_delta, raw);
-      total += chi2_vec[o];
     }
-    return total;
+    return tree_sum<T>(0, No, [&](size_t o) { return chi2_vec[o]; }); // thrust::reduce, ops/chi2.hpp:61-64
   }
   void linearize() { // graph.hpp:236-290
     for (size_t o = 0; o < No; ++o)
@@ -383,7 +393,7 @@ template <typename T> struct BalOracle {
   }
 
   // ---- solvers -----------------------------------------------------------
-  static T dot(size_t m, const T *a, const T *c) { T s = 0; for (size_t i = 0; i < m; ++i) s += a[i] * c[i]; return s; }
+  static T dot(size_t m, const T *a, const T *c) { return tree_sum<T>(0, m, [&](size_t i) { return a[i] * c[i]; }); } // thrust::inner_product
 
   // PCGSchurSolver::solve, solver/pcg_schur.hpp:79-168
   bool solve_pcg_schur(T *x, int max_iter, T tol, T rejection_ratio) {
@@ -676,8 +686,7 @@ template <typename T> struct BalOracle {
       // compute_rho :20-47
       T num = chi2v - new_chi2, denom = 1.0;
       if (solve_ok) {
-        denom = 0;
-        for (size_t k = 0; k < n; ++k) denom += dx[k] * (mu * dx[k] + b[k]);
+        denom = tree_sum<T>(0, n, [&](size_t k) { return dx[k] * (mu * dx[k] + b[k]); });
         denom += T(1.0e-3);
       }
       const T rho = num / denom;

@@ -1,6 +1,7 @@
 // ORACLE — test infrastructure only (see bal_model.hpp header).
 // extern "C" surface for ctypes (oracle/__init__.py).  _f32 / _f64 variants.
 #include "bal_pipeline.hpp"
+#include "cpu_baseline.hpp"
 
 using namespace gro;
 
@@ -188,6 +189,38 @@ extern "C" {
     for (size_t k = ct.size(); k < (size_t)iterations + 1; ++k) { chi2_trace[k] = std::nan(""); lambda_trace[k] = std::nan(""); } \
     stats[0] = st.iterations_run; stats[1] = st.accepted; stats[2] = st.pcg_iterations;             \
     stats[3] = st.solve_seconds; stats[4] = st.loop_seconds; stats[5] = st.setup_seconds;           \
+    return run ? 1 : 0;                                                                             \
+  }
+GRO_FOR_T(X)
+#undef X
+
+/* ---- timed CPU baseline (cpu_baseline.hpp): OpenMP assembly + single-thread LDL^T, or all-cores PCG ---- */
+#define X(T, SFX)                                                                                   \
+  void *gro_baseline_create_##SFX(size_t nc, size_t np, size_t no, const T *c, const T *p, const T *o, \
+                                  const int32_t *ci, const int32_t *pi) {                           \
+    auto *b = new CpuBaseline<T>();                                                                 \
+    b->init(nc, np, no, c, p, o, ci, pi);                                                           \
+    return b;                                                                                       \
+  }                                                                                                 \
+  void gro_baseline_destroy_##SFX(void *h) { delete static_cast<CpuBaseline<T> *>(h); }             \
+  /* stats: as gro_bal_lm; times[14]: linearize hessian schur export_csc ldlt_analyze ldlt_factor ldlt_solve backsub pcg update_chi2 loop setup ldlt_nnz threads */ \
+  int gro_baseline_lm_##SFX(void *h, int solver, int iterations, double initial_damping, int pcg_max_iter, \
+                            double pcg_tol, double pcg_rej, int threads, int ordering, double *chi2_trace,  \
+                            double *lambda_trace, double *stats, double *times) {                   \
+    auto *b = static_cast<CpuBaseline<T> *>(h);                                                     \
+    if (threads <= 0) threads = omp_get_num_procs();                                                \
+    b->prepare(threads, ordering);                                                                  \
+    LMOptions opt; opt.solver = solver; opt.iterations = iterations; opt.initial_damping = initial_damping; \
+    opt.pcg_max_iter = pcg_max_iter; opt.pcg_tol = pcg_tol; opt.pcg_rejection_ratio = pcg_rej;      \
+    std::vector<double> ct, lt; LMStats st;                                                         \
+    const bool run = b->levenberg_marquardt_mt(opt, ct, lt, st);                                    \
+    for (size_t k = 0; k < ct.size(); ++k) { chi2_trace[k] = ct[k]; lambda_trace[k] = lt[k]; }      \
+    stats[0] = st.iterations_run; stats[1] = st.accepted; stats[2] = st.pcg_iterations;             \
+    stats[3] = st.solve_seconds; stats[4] = st.loop_seconds; stats[5] = st.setup_seconds;           \
+    const BaselineTimes &m = b->tm;                                                                 \
+    const double tv[14] = {m.linearize, m.hessian, m.schur, m.export_csc, m.ldlt_analyze, m.ldlt_factor, m.ldlt_solve, \
+                           m.backsub, m.pcg, m.update_chi2, m.loop, m.setup, (double)m.ldlt_nnz, (double)threads}; \
+    for (int k = 0; k < 14; ++k) times[k] = tv[k];                                                  \
     return run ? 1 : 0;                                                                             \
   }
 GRO_FOR_T(X)

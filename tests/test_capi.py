@@ -27,6 +27,10 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(_lib.EXPORTS) == syms
     assert b"gfx950" in lib.gr_version()
+    # test / diagnostic entry points live in their own header, outside the drop-in boundary
+    test_text = open(os.path.join(ROOT, "include", "graphite_mi355x_test.h")).read()
+    for s in _lib.TEST_EXPORTS:
+        assert s in test_text and s not in syms and hasattr(lib, s)
 
 
 def test_header_is_plain_c(tmp_path):

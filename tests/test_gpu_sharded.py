@@ -168,3 +168,32 @@ def test_sharded_boundary_shapes_all_solvers(shape, world):
             assert np.allclose(out[r][0], ct, rtol=1e-8), (solver, r, out[r][0], ct)
             assert np.array_equal(cams[r], cams[0])
         assert np.allclose(cams[0], c1, rtol=1e-6, atol=1e-9) and np.allclose(pts, p1, rtol=1e-6, atol=1e-9), solver
+
+
+@pytest.mark.parametrize("solver", [ga.SOLVER_PCG_SCHUR_IMPLICIT, ga.SOLVER_PCG])
+def test_sharded_many_cameras_replicas_stay_identical(solver):
+    """4 000 cameras = 143 blocks of the 252-scalar camera kernels, i.e. more blocks than the 64 atomic slots of
+    the matrix-free dots: the implicit-Schur scalars are per-block partials summed in a fixed order, so the
+    replicated camera vectors, the loop decisions (one collective per inner iteration hangs if ranks disagree)
+    and the iteration counts are identical on every rank."""
+    prob = synth.make_problem(4000, 30000, 140000, seed=31, window=64)
+    out, cams, _ = run_sharded(prob, 3, np.float64, 4, solver)
+    for r in range(3):
+        assert np.array_equal(cams[r], cams[0])
+        assert out[r][2]["pcg_iterations"] == out[0][2]["pcg_iterations"]
+        assert np.array_equal(out[r][0], out[0][0]) and np.array_equal(out[r][1], out[0][1])
+        assert out[r][2]["collectives"] == out[0][2]["collectives"] > 0
+
+
+def test_sharded_implicit_schur_solve_is_reproducible():
+    """same solve twice on the same engine: identical bits (no atomics on the Schur-PCG path)."""
+    prob = synth.make_problem(4000, 30000, 140000, seed=31, window=64)
+    g = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    g.solver_update_structure(ga.SOLVER_PCG_SCHUR_IMPLICIT)
+    g.linearize()
+    g.solver_update_values(ga.SOLVER_PCG_SCHUR_IMPLICIT)
+    g.solver_set_damping(ga.SOLVER_PCG_SCHUR_IMPLICIT, 1e-4)
+    a, ia = g.solver_solve(ga.SOLVER_PCG_SCHUR_IMPLICIT, max_iter=8, tol=0.0, rej=1e9)
+    b, ib = g.solver_solve(ga.SOLVER_PCG_SCHUR_IMPLICIT, max_iter=8, tol=0.0, rej=1e9)
+    assert ia == ib and np.array_equal(a, b)
+    g.close()
