@@ -915,6 +915,25 @@ template <typename T> struct Engine final : EngineBase {
     k_is_points<T, 1><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, x + pose_dim, sc, 0);
   }
 
+  // matrix-free operator launcher: K = op_k 64-observation sub-tiles per wave and trip (kernels_mf.hpp k_pcg_operator_k)
+  int op_k = getenv("GR_OP_K") ? std::max(1, std::min(4, atoi(getenv("GR_OP_K")))) : 1;
+  template <int K, typename JT> void launch_operator_k(PcgState st, int k, const T *rec, const LmDev *lm, double mu) {
+    const int nt = cdiv(No, (size_t)TPB * K);
+    const int grid = std::max(8, std::min(nt, num_cu * 4) & ~7);
+    k_pcg_operator_k<T, K, JT><<<grid, TPB, 0, stream>>>((int)No, (int)Nc, nt, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
+  }
+  template <typename JT> void launch_operator_j(PcgState st, int k, const T *rec, const LmDev *lm, double mu) {
+    switch (op_k) {
+    case 2: launch_operator_k<2, JT>(st, k, rec, lm, mu); break;
+    case 3: launch_operator_k<3, JT>(st, k, rec, lm, mu); break;
+    case 4: launch_operator_k<4, JT>(st, k, rec, lm, mu); break;
+    default: k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
+    }
+  }
+  void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
+    if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
+    launch_operator_j<T>(st, k, rec, lm, mu);
+  }
   // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
   // touched once): obs + 3 index streams, ps, packs, points, g3 out, segment partials
   double operator_bytes() const {
@@ -959,7 +978,7 @@ template <typename T> struct Engine final : EngineBase {
     auto enqueue = [&](int k) {
       {
         Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
-        if (jac32) { k_pcg_operator<T, 0, float><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k, rec); } else { k_pcg_operator<T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, k, rec); }
+        launch_operator(st, k, rec, nullptr, damping);
       }
       if (comm) { // camera rows + the p.A.p partials, summed over the landmark shards
         k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, nullptr, k);
@@ -1005,9 +1024,10 @@ template <typename T> struct Engine final : EngineBase {
       case 0:
 #define GR_OP(V) k_pcg_operator<T, V><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0, use_records ? xp.p : nullptr)
 #ifdef GR_DIAG
-        switch (variant) { case 1: GR_OP(1); break; case 2: GR_OP(2); break; case 4: GR_OP(4); break; case 7: GR_OP(7); break; case 8: GR_OP(8); break; case 15: GR_OP(15); break; case 16: GR_OP(16); break; case 31: GR_OP(31); break; default: GR_OP(0); }
+        switch (variant) { case 1: GR_OP(1); break; case 2: GR_OP(2); break; case 4: GR_OP(4); break; case 7: GR_OP(7); break; case 8: GR_OP(8); break; case 15: GR_OP(15); break; case 16: GR_OP(16); break; case 31: GR_OP(31); break;
+                           case 32: GR_OP(32); break; case 64: GR_OP(64); break; case 128: GR_OP(128); break; case 3: GR_OP(3); break; case 95: GR_OP(95); break; case 255: GR_OP(255); break; case 224: GR_OP(224); break; default: GR_OP(0); }
 #else
-        GR_OP(0);
+        launch_operator(st, 0, use_records ? xp.p : nullptr, nullptr, damping);
 #endif
         break;
       case 1:
@@ -1187,8 +1207,7 @@ template <typename T> struct Engine final : EngineBase {
     k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, -1, 0.0, 1e30, (unsigned)pose_dim, rec, lm, 0, nullptr);
     const int unroll = std::max(1, std::min(lm_unroll, max_iter));
     for (int k = 0; k < unroll; ++k) {
-      if (jac32) { k_pcg_operator<T, 0, float><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, 0.0, stt, k, rec, lm); }
-      else { k_pcg_operator<T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, 0.0, stt, k, rec, lm); }
+      launch_operator(stt, k, rec, lm, 0.0);
       k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, 0.0, ui, MinvC.p, MinvP.p, stt, k, lm);
       // past the unrolled iterations the loop must have left, unless max_iter itself ends it
       k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, k, tol, rej, (unsigned)pose_dim, rec, lm, (k == unroll - 1 && unroll < max_iter) ? 1 : 0, h_lm + 1);

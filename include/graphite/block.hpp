@@ -1,0 +1,3 @@
+// forwarding header: the block-sparse Hessian / Schur complement / CSC export live in sparse.hpp (reference path: include/graphite/block.hpp)
+#pragma once
+#include "sparse.hpp"

@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <iomanip>
 #include <iostream>
 #include <limits>
@@ -53,6 +54,51 @@ namespace graphite {
       throw std::runtime_error(std::string(#expr) + " -> " + hipGetErrorString(_e) + " @" + __FILE__ +  \
                                ":" + std::to_string(__LINE__));                                         \
   } while (0)
+
+// types.hpp:8-43: 16-bit STORAGE types for the Jacobians (Graph<T, S> with S = __nv_bfloat16, bal.cu --precision *-BF16).
+// The reference takes them from cuda_bf16.h; here a storage-only bfloat16 (round to nearest even) that converts
+// implicitly to float, so every expression that reads a stored Jacobian computes in float or wider.
+struct bfloat16 {
+  uint16_t bits;
+  bfloat16() = default;
+  template <typename V, typename = std::enable_if_t<std::is_arithmetic<V>::value>> hd_fn bfloat16(V v) {
+    const float f = (float)v;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) bits = (uint16_t)((u >> 16) | 0x40); // NaN stays NaN
+    else bits = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+  hd_fn operator float() const { const uint32_t u = (uint32_t)bits << 16; float f; memcpy(&f, &u, 4); return f; }
+};
+template <typename T> struct is_half_or_bfloat16 : std::false_type {};
+template <> struct is_half_or_bfloat16<bfloat16> : std::true_type {};
+template <typename T> using is_low_precision = is_half_or_bfloat16<T>;
+template <typename T, typename S> using InvP = std::conditional_t<is_low_precision<S>::value, T, S>; // types.hpp:19-20
+
+// block.hpp:5-17
+class BlockCoordinates {
+public:
+  size_t row;
+  size_t col;
+  hd_fn bool operator==(const BlockCoordinates &other) const { return (row == other.row) && (col == other.col); }
+};
+using BlockDimension = BlockCoordinates;
+
+// utils.hpp:79-103: ids handed out by add_factor stay valid until released; a released id is re-used first
+template <typename H> class HandleManager {
+  std::vector<H> handles;
+  H last_handle;
+public:
+  HandleManager() : last_handle(0) {}
+  H get() {
+    if (handles.empty()) return last_handle++;
+    H handle = handles.back();
+    handles.pop_back();
+    return handle;
+  }
+  void release(H handle) { handles.push_back(handle); }
+  void clear() { handles.clear(); last_handle = 0; }
+};
 
 struct Empty {};
 
@@ -370,6 +416,11 @@ public:
   virtual size_t num_slots() const = 0;
   virtual BaseVertexDescriptor<T, S> *slot_descriptor(size_t slot) const = 0;
   virtual void dense_hessian(T *H, size_t n) = 0; // upper + lower, for the direct solver
+  // block-sparse Hessian (sparse.hpp, hessian.hpp:45-330): upper block coordinates touched by the active factors
+  // (scalar_to_block: Hessian column -> block column), where each (factor, vertex pair) block lives, accumulation
+  virtual void block_pairs(std::vector<BlockCoordinates> &coords, const std::vector<size_t> &scalar_to_block) = 0;
+  virtual void sparse_setup(const std::function<size_t(size_t, size_t)> &value_offset_of, const std::vector<size_t> &scalar_to_block) = 0;
+  virtual void sparse_hessian(S *values) = 0;
   // A factor descriptor whose traits declare `static constexpr bool bal_reprojection_model = true` (camera 9 =
   // [angle-axis, t, f, k1, k2], point 3, pixel residual of examples/reprojection_error.cuh) can hand its active
   // factors to the specialised BAL engine: local camera / point ids, 2 observation scalars per factor, loss.
@@ -444,17 +495,32 @@ __device__ inline void call_error(const VT &v, PT &p, const typename F::Observat
   }
 }
 
-// Traits::jacobian<S, I>(vertices..., [obs], [data], S *jac)  (main.md:294-315)
+// Traits::jacobian<T, I>(vertices..., [obs], [data], T *jac)  (main.md:294-315).  As ops/linearize.hpp:43-79 does it:
+// the user function is always instantiated in the GRAPH precision T; with S != T the block is evaluated into a T
+// buffer and converted on the way into the storage.
+template <typename F, size_t I, typename Jt, typename VT, size_t... Is>
+__device__ inline void call_jacobian_t(const VT &v, const typename F::ObservationType &obs, const typename F::ConstraintDataType &data,
+                                       Jt *jac, std::index_sequence<Is...>) {
+  using Tr = typename F::Traits;
+  constexpr bool has_obs = !std::is_empty<typename F::ObservationType>::value, has_dat = !std::is_empty<typename F::ConstraintDataType>::value;
+  if constexpr (has_obs && has_dat) Tr::template jacobian<Jt, I>(*std::get<Is>(v)..., obs, data, jac);
+  else if constexpr (has_obs) Tr::template jacobian<Jt, I>(*std::get<Is>(v)..., obs, jac);
+  else if constexpr (has_dat) Tr::template jacobian<Jt, I>(*std::get<Is>(v)..., data, jac);
+  else Tr::template jacobian<Jt, I>(*std::get<Is>(v)..., jac);
+}
 template <typename F, size_t I, typename VT, size_t... Is>
 __device__ inline void call_jacobian(const VT &v, const typename F::ObservationType &obs, const typename F::ConstraintDataType &data,
-                                     typename F::Storage *jac, std::index_sequence<Is...>) {
-  using Tr = typename F::Traits;
+                                     typename F::Storage *jac, std::index_sequence<Is...> seq) {
+  using T = typename F::Scalar;
   using Sj = typename F::Storage;
-  constexpr bool has_obs = !std::is_empty<typename F::ObservationType>::value, has_dat = !std::is_empty<typename F::ConstraintDataType>::value;
-  if constexpr (has_obs && has_dat) Tr::template jacobian<Sj, I>(*std::get<Is>(v)..., obs, data, jac);
-  else if constexpr (has_obs) Tr::template jacobian<Sj, I>(*std::get<Is>(v)..., obs, jac);
-  else if constexpr (has_dat) Tr::template jacobian<Sj, I>(*std::get<Is>(v)..., data, jac);
-  else Tr::template jacobian<Sj, I>(*std::get<Is>(v)..., jac);
+  if constexpr (std::is_same<T, Sj>::value) call_jacobian_t<F, I, T>(v, obs, data, jac, seq);
+  else {
+    constexpr size_t sz = F::E * slot_dim<F, I>();
+    T tmp[sz];
+    for (size_t i = 0; i < sz; ++i) tmp[i] = T(0);
+    call_jacobian_t<F, I, T>(v, obs, data, tmp, seq);
+    for (size_t i = 0; i < sz; ++i) jac[i] = (Sj)tmp[i];
+  }
 }
 
 template <typename F, typename D, size_t... Is>
@@ -641,6 +707,26 @@ template <typename F, size_t I, size_t K> __global__ void k_dense_pair(FactorVie
   atomicAdd(&H[(fv.hid[I][vi] + r) * n + fv.hid[K][vk] + c], val);
 }
 
+// block-sparse H: the (I, K) vertex pair of every active factor adds rho' J_I^T P J_K into its block (column-major,
+// rows = the vertex with the lower block index; `dst` = value offset, top bit set when that vertex is slot K)
+template <typename F, size_t I, size_t K> __global__ void k_sparse_pair(FactorView<F> fv, typename F::Storage *values, const size_t *dst, size_t pair_index, size_t num_pairs) {
+  using T = typename F::Scalar;
+  constexpr size_t di = slot_dim<F, I>(), dk = slot_dim<F, K>(), E = F::E;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= fv.n_active * di * dk) return;
+  const size_t a = t / (di * dk), f = fv.active_ids[a], r = (t / dk) % di, c = t % dk;
+  const size_t d = dst[a * num_pairs + pair_index];
+  if (d == ~size_t(0)) return; // a fixed / inactive vertex: no block
+  const bool transposed = (d >> 63) != 0;
+  const size_t off = d & ~(size_t(1) << 63);
+  typename F::Storage bi[E * di], bk[E * dk];
+  const auto *Ji = jac_block<F, I>(fv, f, bi, std::make_index_sequence<F::N>{});
+  const auto *Jk = jac_block<F, K>(fv, f, bk, std::make_index_sequence<F::N>{});
+  const T val = jtpj(fv, f, Ji + r * E, Jk + c * E) * (T)fv.dchi2[f];
+  const size_t idx = transposed ? (c + dk * r) : (r + di * c);
+  atomicAdd(&values[off + idx], (typename F::Storage)val);
+}
+
 template <typename VD> __global__ void k_flag_vertices(const size_t *active_ids, size_t n_active, const size_t *ids, size_t N, size_t I, uint8_t *state) {
   const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (a >= n_active) return;
@@ -678,6 +764,10 @@ public:
   managed_vector<S> chi2_derivative;
   std::array<JacobianStorage, N> jacobians;
   managed_vector<T> scalar;                // device scalar for reductions
+  managed_vector<size_t> sparse_dst;       // [active factor][vertex pair] -> value offset in the block-sparse Hessian
+  HandleManager<size_t> hm;                // factor.hpp:158-174: ids returned by add_factor are stable handles
+  std::unordered_map<size_t, size_t> global_to_local_map;
+  std::vector<size_t> local_to_global_map;
   bool store_jacobians = true;
   const T *dynamic_scales = nullptr; // column scales of the current linearisation (dynamic Jacobians only)
 
@@ -694,25 +784,36 @@ public:
   // factor.hpp:373-412; precision_matrix == nullptr -> identity
   size_t add_factor(const std::array<size_t, N> &ids, const ObservationType &obs, const S *precision_matrix,
                     const ConstraintDataType &constraint_data, const LossType &loss_function) {
-    const size_t id = internal_count();
+    const size_t handle = hm.get(), id = internal_count(); // id: local index
+    global_to_local_map.insert({handle, id});
+    local_to_global_map.push_back(handle);
     for (size_t i = 0; i < N; ++i) { host_ids.push_back(ids[i]); device_ids.push_back(0); }
     device_obs.push_back(obs); data.push_back(constraint_data); loss.push_back(loss_function);
     for (size_t i = 0; i < E; ++i)
       for (size_t j = 0; j < E; ++j) precision_matrices.push_back(precision_matrix ? precision_matrix[i * E + j] : (i == j ? S(1) : S(0)));
     active.push_back(0);
     residuals.resize(E * (id + 1)); chi2_vec.resize(id + 1); chi2_derivative.resize(id + 1); work.resize(E * (id + 1));
-    return id;
+    return handle; // only global within this descriptor (factor.hpp:411)
   }
-  void remove_factor(size_t id) { // swap with last (factor.hpp:336-371)
-    const size_t last = internal_count() - 1;
-    if (id > last) { std::cerr << "Factor with id " << id << " not found." << std::endl; return; }
+  // local index of a factor handle; std::out_of_range for an unknown id, like the reference's .at() (factor.hpp:460)
+  size_t local_id(size_t handle) const { return global_to_local_map.at(handle); }
+  void remove_factor(size_t handle) { // swap with last, fix the id maps, release the handle (factor.hpp:308-371)
+    auto it = global_to_local_map.find(handle);
+    if (it == global_to_local_map.end()) { std::cerr << "Factor with id " << handle << " not found." << std::endl; return; }
+    const size_t id = it->second, last = internal_count() - 1;
+    const size_t last_handle = local_to_global_map[last];
+    global_to_local_map[last_handle] = id;
+    local_to_global_map[id] = last_handle;
+    global_to_local_map.erase(handle);
+    local_to_global_map.pop_back();
+    hm.release(handle);
     for (size_t i = 0; i < N; ++i) host_ids[id * N + i] = host_ids[last * N + i];
     device_obs[id] = device_obs[last]; data[id] = data[last]; loss[id] = loss[last]; active[id] = active[last];
     for (size_t i = 0; i < E * E; ++i) precision_matrices[id * E * E + i] = precision_matrices[last * E * E + i];
     host_ids.resize(last * N); device_ids.resize(last * N); device_obs.pop_back(); data.pop_back(); loss.pop_back(); active.pop_back();
     precision_matrices.resize(last * E * E); residuals.resize(E * last); chi2_vec.resize(last); chi2_derivative.resize(last); work.resize(E * last);
   }
-  void set_active(size_t id, uint8_t active_value) { active[id] = (active[id] & 0x80) | (active_value & 0x7F); } // factor.hpp:419-431
+  void set_active(size_t handle, uint8_t active_value) { const size_t id = local_id(handle); active[id] = (active[id] & 0x80) | (active_value & 0x7F); } // factor.hpp:419-431
   void reset_active() { for (size_t i = 0; i < active.size(); ++i) active[i] = 0; }
   // factor.hpp:626-640: false = no stored Jacobians, every product recomputes the analytic blocks (Manual
   // differentiation only; an Auto factor keeps storing, ops/linearize.hpp:109)
@@ -727,9 +828,14 @@ public:
   void compute_jacobians(StreamPool &) { compute_jacobians(); }
   size_t internal_count() const override { return device_obs.size(); }
   size_t active_count() const override { return active_indices.size(); }
-  std::array<size_t, N> get_vertex_ids(size_t id) const { std::array<size_t, N> r; for (size_t i = 0; i < N; ++i) r[i] = host_ids[id * N + i]; return r; }
-  const ObservationType &get_observation(size_t id) const { return device_obs[id]; }
-  const ConstraintDataType &get_constraint_data(size_t id) const { return data[id]; }
+  std::array<size_t, N> get_vertex_ids(size_t handle) const { const size_t id = local_id(handle); std::array<size_t, N> r; for (size_t i = 0; i < N; ++i) r[i] = host_ids[id * N + i]; return r; }
+  const ObservationType &get_observation(size_t handle) const { return device_obs[local_id(handle)]; }
+  const ConstraintDataType &get_constraint_data(size_t handle) const { return data[local_id(handle)]; }
+  void clear() {
+    host_ids.clear(); device_ids.clear(); device_obs.clear(); data.clear(); loss.clear(); precision_matrices.clear(); active.clear();
+    active_indices.clear(); residuals.clear(); chi2_vec.clear(); chi2_derivative.clear(); work.clear();
+    global_to_local_map.clear(); local_to_global_map.clear(); hm.clear();
+  }
 
   size_t num_slots() const override { return N; }
   size_t error_dimension() const override { return E; }
@@ -775,7 +881,7 @@ public:
     detail::sync();
     return scalar[0];
   }
-  T chi2(size_t id) { detail::sync(); return chi2_vec[id]; }
+  T chi2(size_t handle) { detail::sync(); return chi2_vec[local_id(handle)]; }
   void scalar_diagonal(T *diag) override { slot_all<0>(diag, nullptr, std::make_index_sequence<N>{}); }
   void scale_jacobians(const T *scales) override {
     if (dynamic_jacobians()) dynamic_scales = scales;
@@ -787,6 +893,49 @@ public:
   T *work_residual() override { return work.raw(); }
   void block_diagonal(size_t slot, T *blocks) override { block_one(slot, blocks, std::make_index_sequence<N>{}); }
   void dense_hessian(T *H, size_t n) override { dense_all(H, n, std::make_index_sequence<N>{}); }
+  // ---- block-sparse Hessian (sparse.hpp) ------------------------------------------------------
+  static constexpr size_t NUM_PAIRS = N * (N + 1) / 2;
+  // block column of slot i of local factor f, or npos when that vertex has no column (fixed / unused)
+  size_t slot_block(size_t f, size_t i, const std::vector<size_t> &s2b) const {
+    const size_t v = device_ids[f * N + i];
+    if (!detail::is_vertex_active(vertex_descriptors[i]->get_active_state(), v)) return ~size_t(0);
+    return s2b[vertex_descriptors[i]->get_hessian_ids()[v]];
+  }
+  void block_pairs(std::vector<BlockCoordinates> &coords, const std::vector<size_t> &s2b) override {
+    detail::sync();
+    for (size_t a = 0; a < active_count(); ++a) {
+      const size_t f = active_indices[a];
+      for (size_t i = 0; i < N; ++i)
+        for (size_t k = i + 1; k < N; ++k) {
+          const size_t bi = slot_block(f, i, s2b), bk = slot_block(f, k, s2b);
+          if (bi == ~size_t(0) || bk == ~size_t(0) || bi == bk) continue;
+          coords.push_back(BlockCoordinates{std::min(bi, bk), std::max(bi, bk)});
+        }
+    }
+  }
+  void sparse_setup(const std::function<size_t(size_t, size_t)> &value_offset_of, const std::vector<size_t> &s2b) override {
+    detail::sync();
+    sparse_dst.resize(active_count() * NUM_PAIRS);
+    for (size_t a = 0; a < active_count(); ++a) {
+      const size_t f = active_indices[a];
+      size_t p = 0;
+      for (size_t i = 0; i < N; ++i)
+        for (size_t k = i; k < N; ++k, ++p) {
+          const size_t bi = slot_block(f, i, s2b), bk = slot_block(f, k, s2b);
+          size_t d = ~size_t(0);
+          if (bi != ~size_t(0) && bk != ~size_t(0) && (i == k || bi != bk)) {
+            d = value_offset_of(std::min(bi, bk), std::max(bi, bk));
+            if (bk < bi) d |= size_t(1) << 63; // the block's rows belong to slot k: store the transpose
+          }
+          sparse_dst[a * NUM_PAIRS + p] = d;
+        }
+    }
+  }
+  void sparse_hessian(S *values) override {
+    if constexpr (is_low_precision<S>::value) { (void)values; throw std::invalid_argument("block-sparse Hessian: 16-bit storage types are not supported (the reference refuses them too, bal.cu:181-203)"); }
+    else sparse_all(values, std::make_index_sequence<N>{});
+  }
+
   bool export_bal(std::vector<int32_t> &cam, std::vector<int32_t> &pt, std::vector<T> &obs, int &loss_kind, double &loss_delta) override {
     if constexpr (detail::has_bal_tag<Traits>::value && N == 2 && E == 2) {
       constexpr bool plain = std::is_same<LossType, DefaultLoss<T, 2>>::value, huber = std::is_same<LossType, HuberLoss<T, 2>>::value;
@@ -849,6 +998,17 @@ private:
   template <size_t I, size_t... Ks> void dense_row(detail::FactorView<FactorDescriptor> &fv, T *H, size_t n, std::index_sequence<Ks...>) {
     ((detail::k_dense_pair<FactorDescriptor, I, Ks><<<detail::blocks(active_count() * detail::slot_dim<FactorDescriptor, I>() * detail::slot_dim<FactorDescriptor, Ks>()), detail::TPB>>>(fv, H, n)), ...);
   }
+  template <size_t I, size_t... Ks> void sparse_row(detail::FactorView<FactorDescriptor> &fv, S *values, std::index_sequence<Ks...>) {
+    // pair index of (I, K), K >= I, in the row-major upper enumeration used by sparse_setup
+    ((Ks >= I ? (void)(detail::k_sparse_pair<FactorDescriptor, I, (Ks >= I ? Ks : I)><<<detail::blocks(active_count() * detail::slot_dim<FactorDescriptor, I>() * detail::slot_dim<FactorDescriptor, (Ks >= I ? Ks : I)>()), detail::TPB>>>(
+                     fv, values, sparse_dst.raw(), I * N - I * (I - 1) / 2 + (Ks - I), NUM_PAIRS))
+               : (void)0), ...);
+  }
+  template <size_t... Is> void sparse_all(S *values, std::index_sequence<Is...> seq) {
+    if (!active_count()) return;
+    auto fv = view();
+    ((sparse_row<Is>(fv, values, seq)), ...);
+  }
   template <size_t... Is> void dense_all(T *H, size_t n, std::index_sequence<Is...> seq) {
     if (!active_count()) return;
     auto fv = view();
@@ -878,9 +1038,15 @@ template <typename T, typename S> class Graph {
   std::vector<BaseVertexDescriptor<T, S> *> vertex_descriptors;
   std::vector<BaseFactorDescriptor<T, S> *> factor_descriptors;
   managed_vector<T> b, jacobian_scales;
-  size_t hessian_dim = 0, pose_dim = 0;
+  size_t hessian_dim = 0, pose_dim = 0, elimination_block = 0;
+  std::vector<size_t> hessian_offsets; // scalar column of every block column (+ the dimension at the end), graph.hpp:40
   bool scale_jacobians_ = true;
 public:
+  // graph.hpp:48-55, :90
+  size_t get_variable_dimension(const size_t block_index) const { return hessian_offsets[block_index + 1] - hessian_offsets[block_index]; }
+  size_t get_num_block_columns() const { return hessian_offsets.empty() ? 0 : hessian_offsets.size() - 1; }
+  const std::vector<size_t> &get_offset_vector() const { return hessian_offsets; }
+  size_t get_elimination_block_column() const { return elimination_block; }
   void add_descriptor(BaseVertexDescriptor<T, S> *d) { vertex_descriptors.push_back(d); }
   void add_descriptor(BaseFactorDescriptor<T, S> *d) { factor_descriptors.push_back(d); }
   void add_vertex_descriptor(BaseVertexDescriptor<T, S> *d) { add_descriptor(d); }
@@ -907,8 +1073,9 @@ public:
       if (vd->count()) detail::k_xor_msb<T><<<detail::blocks(vd->count()), detail::TPB>>>(vd->get_active_state(), vd->count());
     detail::sync();
     size_t col = 0;
+    hessian_offsets.clear();
     for (int pass = 0; pass < 2; ++pass) { // non-eliminated descriptors first, eliminated ones last (graph.hpp:100-149)
-      if (pass == 1) pose_dim = col;
+      if (pass == 1) { pose_dim = col; elimination_block = hessian_offsets.size(); }
       for (auto *vd : vertex_descriptors) {
         if ((int)vd->eliminate != pass) continue;
         std::vector<std::pair<size_t, size_t>> order;
@@ -916,9 +1083,10 @@ public:
         for (size_t l = 0; l < vd->count(); ++l) order.emplace_back(l2g[l], l);
         std::sort(order.begin(), order.end());
         for (auto &e : order)
-          if (detail::is_vertex_active(vd->get_active_state(), e.second)) { vd->get_hessian_ids()[e.second] = col; col += vd->dimension(); }
+          if (detail::is_vertex_active(vd->get_active_state(), e.second)) { vd->get_hessian_ids()[e.second] = col; hessian_offsets.push_back(col); col += vd->dimension(); }
       }
     }
+    hessian_offsets.push_back(col);
     hessian_dim = col;
     b.resize(col); jacobian_scales.resize(col);
     return col > 0;

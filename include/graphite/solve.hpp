@@ -4,6 +4,7 @@
 // optimizer/levenberg_marquardt.hpp:20-242 of the reference.
 #pragma once
 #include "core.hpp"
+#include "sparse.hpp"
 #include "../graphite_mi355x.h"
 
 namespace graphite {
@@ -274,21 +275,20 @@ public:
 };
 
 // ---- Schur elimination for the generic layer ------------------------------------------------------
-// The reference reduces H = [Hpp Hpl; Hlp Hll] over the vertices marked set_eliminate (schur.hpp:194-302,
-// block-sparse, hash-indexed).  The generic layer is the small-graph path: H is assembled densely (as for
-// EigenLDLTSolver) and S = Hpp - Hpl Hll^-1 Hlp, b_S = b_p - Hpl Hll^-1 b_l are formed densely from it, which is
-// exact for any mix of vertex dimensions and any number of factors per vertex pair.  Eliminated vertices must
-// not share a factor (Hll block diagonal), as in the reference.
+// H = [Hpp Hpl; Hlp Hll] is reduced over the vertices marked set_eliminate exactly as the reference does it
+// (schur.hpp:194-302): block-sparse Hessian<T,S> (upper block-CSC), SchurComplement<T,S> built from its structure
+// (sparse.hpp).  Memory is O(blocks), not n^2: pose graphs and bundle-adjustment graphs of any size fit; eliminated
+// vertices must not share a factor (Hll block diagonal), as in the reference.
 namespace detail {
-// inverse of the d x d diagonal block of the damped H at column `off` of every active eliminated vertex
-template <typename T> __global__ void k_hll_inverse(const T *H, size_t n, const size_t *hid, const uint8_t *state, size_t count, int d, T *inv) {
-  const size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (v >= count || !is_vertex_active(state, v)) return;
+// d x d diagonal blocks of the sparse S, one per pose block (block_jacobi_schur.hpp:114-150): copy + invert
+template <typename T, typename S> __global__ void k_schur_diag_inverse(size_t nblocks, const size_t *diag_off, const size_t *soff, const S *Sv, T *inv, const size_t *inv_off) {
+  const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
   constexpr int MAXD = 16;
+  const int d = (int)(soff[b + 1] - soff[b]);
   double A[MAXD * MAXD], R[MAXD * MAXD];
-  const size_t off = hid[v];
-  for (int c = 0; c < d; ++c)
-    for (int r = 0; r < d; ++r) { A[r + c * d] = (double)H[(off + r) * n + off + c]; R[r + c * d] = r == c ? 1.0 : 0.0; }
+  const S *B = Sv + diag_off[b];
+  for (int i = 0; i < d * d; ++i) { A[i] = (double)B[i]; R[i] = (i % d == i / d) ? 1.0 : 0.0; }
   for (int k = 0; k < d; ++k) {
     int piv = k;
     for (int r = k + 1; r < d; ++r) if (fabs(A[r + k * d]) > fabs(A[piv + k * d])) piv = r;
@@ -302,167 +302,70 @@ template <typename T> __global__ void k_hll_inverse(const T *H, size_t n, const 
       for (int c = 0; c < d; ++c) { A[r + c * d] -= f * A[k + c * d]; R[r + c * d] -= f * R[k + c * d]; }
     }
   }
-  for (int i = 0; i < d * d; ++i) inv[v * d * d + i] = (T)R[i];
+  for (int i = 0; i < d * d; ++i) inv[inv_off[b] + i] = (T)R[i];
 }
-// W rows of one eliminated descriptor: W[(off_v - pd) + r][j] = sum_c inv_v[r][c] H[off_v + c][j], j < pd; same for the vector b
-template <typename T> __global__ void k_schur_w(const T *H, size_t n, size_t pd, const size_t *hid, const uint8_t *state, size_t count, int d, const T *inv, T *W, const T *b, T *wb) {
-  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (t >= count * d * (pd + 1)) return;
-  const size_t j = t % (pd + 1), vr = t / (pd + 1), v = vr / d;
-  const int r = (int)(vr % d);
-  if (!is_vertex_active(state, v)) return;
-  const size_t off = hid[v];
+template <typename T> __global__ void k_schur_diag_apply(size_t pose_dim, const size_t *s2b_start, const size_t *soff, const T *inv, const size_t *inv_off, const size_t *s2b, T *z, const T *r) {
+  const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (row >= pose_dim) return;
+  const size_t b = s2b[row], r0 = soff[b], d = soff[b + 1] - r0, i = row - r0;
   T s = 0;
-  if (j < pd) {
-    for (int c = 0; c < d; ++c) s += inv[v * d * d + r + c * d] * H[(off + c) * n + j];
-    W[(off - pd + r) * pd + j] = s;
-  } else {
-    for (int c = 0; c < d; ++c) s += inv[v * d * d + r + c * d] * b[off + c];
-    wb[off - pd + r] = s;
-  }
-}
-// S = Hpp - Hpl W (column pd of the launch: b_S = b_p - Hpl wb)
-template <typename T> __global__ void k_schur_s(const T *H, size_t n, size_t pd, const T *W, const T *b, const T *wb, T *Sm, T *bS) {
-  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (t >= pd * (pd + 1)) return;
-  const size_t i = t / (pd + 1), j = t % (pd + 1), nl = n - pd;
-  const T *hrow = H + i * n + pd;
-  T s = 0;
-  if (j < pd) {
-    for (size_t k = 0; k < nl; ++k) s += hrow[k] * W[k * pd + j];
-    Sm[i * pd + j] = H[i * n + j] - s;
-  } else {
-    for (size_t k = 0; k < nl; ++k) s += hrow[k] * wb[k];
-    bS[i] = b[i] - s;
-  }
-}
-template <typename T> __global__ void k_dense_matvec(const T *A, size_t n, const T *x, T *y) {
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  T s = 0;
-  for (size_t j = 0; j < n; ++j) s += A[i * n + j] * x[j];
-  y[i] = s;
-}
-// x_l = Hll^-1 b_l - W x_p   (schur.hpp:279-302)
-template <typename T> __global__ void k_schur_backsub(const T *W, size_t pd, size_t nl, const T *wb, const T *xp, T *xl) {
-  const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (k >= nl) return;
-  T s = 0;
-  for (size_t j = 0; j < pd; ++j) s += W[k * pd + j] * xp[j];
-  xl[k] = wb[k] - s;
-}
-// d x d diagonal blocks of the dense S, column-major per vertex (block_jacobi_schur.hpp:114-178)
-template <typename T> __global__ void k_take_diag_blocks(const T *Sm, size_t pd, const size_t *hid, const uint8_t *state, size_t count, int d, T *blocks) {
-  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (t >= count * d * d) return;
-  const size_t v = t / (d * d);
-  if (!is_vertex_active(state, v)) return;
-  const int r = (int)(t % d), c = (int)((t / d) % d);
-  blocks[v * d * d + r + c * d] = Sm[(hid[v] + r) * pd + hid[v] + c];
+  for (size_t c = 0; c < d; ++c) s += inv[inv_off[b] + i + d * c] * r[r0 + c];
+  z[row] = s;
 }
 } // namespace detail
 
-template <typename T, typename S> class DenseSchurComplement {
-  managed_vector<T> H, Hd, W, wb, Sm, bS;
-  std::vector<std::unique_ptr<managed_vector<T>>> inv;
-  size_t n = 0, pd = 0;
-  T damping = 0;
-  bool damping_identity = false;
-public:
-  size_t pose_dimension() const { return pd; }
-  T *S_matrix() { return Sm.raw(); }
-  T *b_schur() { return bS.raw(); }
-  void update_structure(Graph<T, S> *graph) {
-    n = graph->get_hessian_dimension(); pd = graph->get_pose_dimension();
-    if (pd == 0 || pd > n) throw std::invalid_argument("Schur solver: no vertex descriptor left after elimination");
-    H.resize(n * n); Hd.resize(n * n); W.resize((n - pd) * pd); wb.resize(n - pd); Sm.resize(pd * pd); bS.resize(pd);
-    inv.clear();
-    for (auto *vd : graph->get_vertex_descriptors()) {
-      if (vd->eliminate && vd->dimension() > 16) throw std::invalid_argument("Schur solver: eliminated vertex dimension > 16");
-      inv.emplace_back(new managed_vector<T>(vd->eliminate ? vd->count() * vd->dimension() * vd->dimension() : 0));
-    }
-  }
-  void update_values(Graph<T, S> *graph) { // Hessian::update_values (hessian.hpp:257-307), dense
-    detail::fill<T>(H.raw(), n * n, T(0));
-    for (auto *fd : graph->get_factor_descriptors()) fd->dense_hessian(H.raw(), n);
-    detail::sync();
-  }
-  void set_damping(T mu, bool identity) { damping = mu; damping_identity = identity; }
-  // SchurComplement::update_values (schur.hpp:227-235) on the damped H
-  void reduce(Graph<T, S> *graph) {
-    using namespace detail;
-    GRAPHITE_HIP(hipMemcpy(Hd.raw(), H.raw(), n * n * sizeof(T), hipMemcpyDefault));
-    k_damp_dense<T><<<blocks(n), TPB>>>(Hd.raw(), n, damping, damping_identity ? 1 : 0);
-    fill<T>(W.raw(), W.size(), T(0)); fill<T>(wb.raw(), wb.size(), T(0));
-    auto &vds = graph->get_vertex_descriptors();
-    for (size_t k = 0; k < vds.size(); ++k) {
-      auto *vd = vds[k];
-      if (!vd->eliminate || !vd->count()) continue;
-      const int d = (int)vd->dimension();
-      k_hll_inverse<T><<<blocks(vd->count()), TPB>>>(Hd.raw(), n, vd->get_hessian_ids(), vd->get_active_state(), vd->count(), d, inv[k]->raw());
-      k_schur_w<T><<<blocks(vd->count() * d * (pd + 1)), TPB>>>(Hd.raw(), n, pd, vd->get_hessian_ids(), vd->get_active_state(), vd->count(), d, inv[k]->raw(), W.raw(), graph->get_b().raw(), wb.raw());
-    }
-    k_schur_s<T><<<blocks(pd * (pd + 1)), TPB>>>(Hd.raw(), n, pd, W.raw(), graph->get_b().raw(), wb.raw(), Sm.raw(), bS.raw());
-    sync();
-  }
-  void multiply(T *y, const T *x) { detail::k_dense_matvec<T><<<detail::blocks(pd), detail::TPB>>>(Sm.raw(), pd, x, y); }
-  void landmark_update(T *xl, const T *xp) { // compute_landmark_update (schur.hpp:279-302)
-    if (n > pd) detail::k_schur_backsub<T><<<detail::blocks(n - pd), detail::TPB>>>(W.raw(), pd, n - pd, wb.raw(), xp, xl);
-  }
-};
-
-// preconditioner/block_jacobi_schur.hpp:114-178: inverse diagonal blocks of S
+// preconditioner/schur_preconditioner.hpp:10-28
 template <typename T, typename S> class SchurPreconditioner {
 public:
   virtual ~SchurPreconditioner() = default;
-  virtual void update_structure(Graph<T, S> *graph, DenseSchurComplement<T, S> *schur, StreamPool &streams) = 0;
-  virtual void update_values(Graph<T, S> *graph, DenseSchurComplement<T, S> *schur, StreamPool &streams) = 0;
-  virtual void set_damping_factor(Graph<T, S> *graph, DenseSchurComplement<T, S> *schur, T damping_factor, const bool use_identity, StreamPool &streams) = 0;
-  virtual void apply(Graph<T, S> *graph, DenseSchurComplement<T, S> *schur, T *z, const T *r, StreamPool &streams) = 0;
+  virtual void update_structure(Graph<T, S> *graph, SchurComplement<T, S> *schur, StreamPool &streams) = 0;
+  virtual void update_values(Graph<T, S> *graph, SchurComplement<T, S> *schur, StreamPool &streams) = 0;
+  virtual void set_damping_factor(Graph<T, S> *graph, SchurComplement<T, S> *schur, T damping_factor, const bool use_identity, StreamPool &streams) = 0;
+  virtual void apply(Graph<T, S> *graph, SchurComplement<T, S> *schur, T *z, const T *r, StreamPool &streams) = 0;
   virtual bool is_block_jacobi() const { return false; }
 };
+// preconditioner/block_jacobi_schur.hpp:114-178: inverse diagonal blocks of S
 template <typename T, typename S> class BlockJacobiSchurPreconditioner : public SchurPreconditioner<T, S> {
-  std::vector<std::unique_ptr<managed_vector<T>>> blocks, inverses;
+  device_vector<T> inverses;
+  device_vector<size_t> d_diag_off, d_soff, d_inv_off, d_s2b;
+  size_t nblocks = 0, pose_dim = 0;
 public:
   bool is_block_jacobi() const override { return true; }
-  void update_structure(Graph<T, S> *graph, DenseSchurComplement<T, S> *, StreamPool &) override {
-    blocks.clear(); inverses.clear();
-    for (auto *vd : graph->get_vertex_descriptors()) {
-      if (!vd->eliminate && vd->dimension() > 16) throw std::invalid_argument("BlockJacobiSchurPreconditioner: vertex dimension > 16");
-      const size_t sz = vd->eliminate ? 0 : vd->count() * vd->dimension() * vd->dimension();
-      blocks.emplace_back(new managed_vector<T>(sz)); inverses.emplace_back(new managed_vector<T>(sz));
+  void update_structure(Graph<T, S> *, SchurComplement<T, S> *schur, StreamPool &) override {
+    const auto &soff = schur->host_pose_offsets();
+    nblocks = schur->num_pose_blocks(); pose_dim = schur->get_pose_dimension();
+    std::vector<size_t> inv_off(nblocks), s2b(pose_dim);
+    size_t total = 0;
+    for (size_t b = 0; b < nblocks; ++b) {
+      const size_t d = soff[b + 1] - soff[b];
+      if (d > 16) throw std::invalid_argument("BlockJacobiSchurPreconditioner: vertex dimension > 16");
+      inv_off[b] = total; total += d * d;
+      for (size_t c = soff[b]; c < soff[b + 1]; ++c) s2b[c] = b;
     }
+    inverses.resize(total);
+    d_diag_off = schur->host_diag_offsets(); d_soff = soff; d_inv_off = inv_off; d_s2b = s2b;
   }
   // S already carries the damping (it is reduced from the damped H), so the blocks are inverted as they are
-  void update_values(Graph<T, S> *graph, DenseSchurComplement<T, S> *schur, StreamPool &) override {
-    auto &vds = graph->get_vertex_descriptors();
-    for (size_t k = 0; k < vds.size(); ++k) {
-      auto *vd = vds[k];
-      if (vd->eliminate || !vd->count()) continue;
-      const int d = (int)vd->dimension();
-      detail::k_take_diag_blocks<T><<<detail::blocks(vd->count() * d * d), detail::TPB>>>(schur->S_matrix(), schur->pose_dimension(), vd->get_hessian_ids(), vd->get_active_state(), vd->count(), d, blocks[k]->raw());
-      detail::k_block_inverse<T><<<detail::blocks(vd->count()), detail::TPB>>>(blocks[k]->raw(), inverses[k]->raw(), vd->count(), d, T(0), 1, vd->get_active_state());
-    }
+  void update_values(Graph<T, S> *, SchurComplement<T, S> *schur, StreamPool &) override {
+    if (nblocks) detail::k_schur_diag_inverse<T, S><<<detail::blocks(nblocks), detail::TPB>>>(nblocks, d_diag_off.raw(), d_soff.raw(), schur->get_values_ptr(), inverses.raw(), d_inv_off.raw());
   }
-  void set_damping_factor(Graph<T, S> *, DenseSchurComplement<T, S> *, T, const bool, StreamPool &) override {}
-  void apply(Graph<T, S> *graph, DenseSchurComplement<T, S> *, T *z, const T *r, StreamPool &) override {
-    auto &vds = graph->get_vertex_descriptors();
-    for (size_t k = 0; k < vds.size(); ++k)
-      if (!vds[k]->eliminate && vds[k]->count())
-        detail::k_block_apply<T><<<detail::blocks(vds[k]->count() * vds[k]->dimension()), detail::TPB>>>(inverses[k]->raw(), vds[k]->get_hessian_ids(), vds[k]->get_active_state(), vds[k]->count(), (int)vds[k]->dimension(), z, r);
+  void set_damping_factor(Graph<T, S> *, SchurComplement<T, S> *, T, const bool, StreamPool &) override {}
+  void apply(Graph<T, S> *, SchurComplement<T, S> *, T *z, const T *r, StreamPool &) override {
+    if (pose_dim) detail::k_schur_diag_apply<T><<<detail::blocks(pose_dim), detail::TPB>>>(pose_dim, nullptr, d_soff.raw(), inverses.raw(), d_inv_off.raw(), d_s2b.raw(), z, r);
   }
 };
 
 // solver/pcg_schur.hpp:42-168: PCG on the reduced system, then the landmark back-substitution
 template <typename T, typename S> class PCGSchurSolver : public Solver<T, S> {
-  DenseSchurComplement<T, S> schur;
+  Hessian<T, S> H;
+  SchurComplement<T, S> schur;
   SchurPreconditioner<T, S> *preconditioner;
   managed_vector<T> r, p, z, Ap, xb, scratch;
   size_t max_iter, iterations_ = 0;
   T tol, rejection_ratio;
 public:
   PCGSchurSolver(size_t max_iter_, T tol_, T rejection_ratio_, SchurPreconditioner<T, S> *preconditioner_)
-      : preconditioner(preconditioner_), max_iter(max_iter_), tol(tol_), rejection_ratio(rejection_ratio_) { scratch.resize(1); }
+      : schur(H), preconditioner(preconditioner_), max_iter(max_iter_), tol(tol_), rejection_ratio(rejection_ratio_) { scratch.resize(1); }
   size_t last_iterations() const { return iterations_; }
   // explicit S while its dense block map fits the engine (16384 cameras), the implicit form (same iterates) beyond
   int engine_kind(size_t num_cameras) const override {
@@ -470,25 +373,28 @@ public:
   }
   void engine_pcg_parameters(int &m, double &t, double &rj) const override { m = (int)max_iter; t = (double)tol; rj = (double)rejection_ratio; }
   void update_structure(Graph<T, S> *graph, StreamPool &streams) override {
-    schur.update_structure(graph);
-    const size_t pd = schur.pose_dimension();
+    if (graph->get_pose_dimension() == 0 || graph->get_pose_dimension() > graph->get_hessian_dimension())
+      throw std::invalid_argument("Schur solver: no vertex descriptor left after elimination");
+    H.build_structure(graph, streams);
+    schur.build_structure(graph, streams);
+    const size_t pd = schur.get_pose_dimension();
     r.resize(pd); p.resize(pd); z.resize(pd); Ap.resize(pd); xb.resize(pd);
     preconditioner->update_structure(graph, &schur, streams);
   }
-  void update_values(Graph<T, S> *graph, StreamPool &) override { schur.update_values(graph); }
+  void update_values(Graph<T, S> *graph, StreamPool &streams) override { H.update_values(graph, streams); }
   void set_damping_factor(Graph<T, S> *graph, T mu, const bool use_identity, StreamPool &streams) override {
-    schur.set_damping(mu, use_identity);
+    H.apply_damping(graph, mu, use_identity, streams);
     preconditioner->set_damping_factor(graph, &schur, mu, use_identity, streams);
   }
   bool solve(Graph<T, S> *graph, T *x, StreamPool &streams) override {
     using namespace detail;
-    const size_t n = graph->get_hessian_dimension(), pd = schur.pose_dimension();
+    const size_t n = graph->get_hessian_dimension(), pd = schur.get_pose_dimension();
     if (!n) return true;
-    schur.reduce(graph);
+    schur.update_values(graph, streams); // S depends on the damping: reduced here, as pcg_schur.hpp:84 does
     preconditioner->update_values(graph, &schur, streams);
     const int nb = blocks(pd);
     fill<T>(x, n, T(0));
-    GRAPHITE_HIP(hipMemcpy(r.raw(), schur.b_schur(), pd * sizeof(T), hipMemcpyDefault));
+    GRAPHITE_HIP(hipMemcpy(r.raw(), schur.get_b_Schur().raw(), pd * sizeof(T), hipMemcpyDefault));
     preconditioner->apply(graph, &schur, z.raw(), r.raw(), streams);
     sync();
     GRAPHITE_HIP(hipMemcpy(p.raw(), z.raw(), pd * sizeof(T), hipMemcpyDefault));
@@ -497,7 +403,7 @@ public:
     iterations_ = 0;
     for (size_t k = 0; k < max_iter; ++k) {
       if (rz == 0) break;
-      schur.multiply(Ap.raw(), p.raw());
+      schur.execute_schur_vector_multiply(graph, streams, Ap.raw(), p.raw());
       const T denom = dot(p.raw(), Ap.raw(), pd, scratch.raw());
       if (denom == 0 || std::isnan(denom)) break;
       ++iterations_;
@@ -517,7 +423,7 @@ public:
       k_xpby<T><<<nb, TPB>>>(p.raw(), z.raw(), beta, pd);
       if (std::abs(rz_new) < tol) break;
     }
-    schur.landmark_update(x + pd, x);
+    schur.compute_landmark_update(graph, streams, x + pd, x);
     sync();
     return true;
   }
@@ -525,21 +431,32 @@ public:
 
 // solver/eigen_schur.hpp:20-108: direct solve of the reduced system (here: the MFMA Cholesky), then the back-substitution
 template <typename T, typename S> class EigenSchurLDLTSolver : public Solver<T, S> {
-  DenseSchurComplement<T, S> schur;
+  Hessian<T, S> H;
+  SchurComplement<T, S> schur;
+  device_vector<T> dense;
 public:
+  EigenSchurLDLTSolver() : schur(H) {}
   int engine_kind(size_t) const override { return GR_SOLVER_DENSE_SCHUR; }
-  void update_structure(Graph<T, S> *graph, StreamPool &) override { schur.update_structure(graph); }
-  void update_values(Graph<T, S> *graph, StreamPool &) override { schur.update_values(graph); }
-  void set_damping_factor(Graph<T, S> *, T mu, const bool use_identity, StreamPool &) override { schur.set_damping(mu, use_identity); }
-  bool solve(Graph<T, S> *graph, T *x, StreamPool &) override {
-    const size_t n = graph->get_hessian_dimension(), pd = schur.pose_dimension();
+  void update_structure(Graph<T, S> *graph, StreamPool &streams) override {
+    if (graph->get_pose_dimension() == 0 || graph->get_pose_dimension() > graph->get_hessian_dimension())
+      throw std::invalid_argument("Schur solver: no vertex descriptor left after elimination");
+    H.build_structure(graph, streams);
+    schur.build_structure(graph, streams);
+    dense.resize(schur.get_pose_dimension() * schur.get_pose_dimension());
+  }
+  void update_values(Graph<T, S> *graph, StreamPool &streams) override { H.update_values(graph, streams); }
+  void set_damping_factor(Graph<T, S> *graph, T mu, const bool use_identity, StreamPool &streams) override { H.apply_damping(graph, mu, use_identity, streams); }
+  bool solve(Graph<T, S> *graph, T *x, StreamPool &streams) override {
+    const size_t n = graph->get_hessian_dimension(), pd = schur.get_pose_dimension();
     if (!n) return true;
-    schur.reduce(graph);
+    schur.update_values(graph, streams);
+    schur.to_dense(dense.raw());
     int dev = 0;
     GRAPHITE_HIP(hipGetDevice(&dev));
-    const gr_status st = gr_dense_cholesky_solve(sizeof(T) == 8 ? GR_F64 : GR_F32, (int64_t)pd, schur.S_matrix(), (int64_t)pd, schur.b_schur(), x, dev, nullptr, nullptr);
+    detail::fill<T>(x, n, T(0));
+    const gr_status st = gr_dense_cholesky_solve(sizeof(T) == 8 ? GR_F64 : GR_F32, (int64_t)pd, dense.raw(), (int64_t)pd, schur.get_b_Schur().raw(), x, dev, nullptr, nullptr);
     if (st != GR_OK) return false;
-    schur.landmark_update(x + pd, x);
+    schur.compute_landmark_update(graph, streams, x + pd, x);
     detail::sync();
     return true;
   }

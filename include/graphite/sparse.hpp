@@ -1,0 +1,486 @@
+// graphite/sparse.hpp — block-sparse Hessian, Schur complement and scalar CSC export of the generic layer.
+//
+// Same public types, layouts and call flow as the reference:
+//   CSCMatrix<S, I>          hessian.hpp:15-20      d_pointers / d_indices / d_values (scalar CSC, upper triangle)
+//   Hessian<T, S>            hessian.hpp:45-330     unique UPPER block coordinates sorted column-major (row inside a
+//                                                   column), every block rows x cols COLUMN-major, the diagonal block
+//                                                   stored FULL and last in its column (:123-126); block-CSC indices
+//                                                   (csc_utils.hpp:16-50); backup_diagonal / apply_damping (:102-176)
+//   SchurComplement<T, S>    schur.hpp:87-1120      S = Hpp - Hpl Hll^-1 Hpl^T over the upper pose blocks, b_S, the
+//                                                   landmark back-substitution (:279-302), S x (:347-393), CSC export
+// exercised the way tests/schur.cu:113-240 drives them.  What differs is how they are built: the reference walks hash
+// maps of block coordinates on the host and fills per-dimension MulOp pointer tables (schur.hpp:484-585); here the
+// structure is a sorted coordinate list, the products are plain index records and one generic kernel handles every
+// (dim_a, dim_b, dim_c) combination.  Correctness-first like the rest of the generic layer (one thread per output
+// scalar, atomics where several factors / products meet in one block); bundle-adjustment graphs that carry the
+// bal_reprojection_model tag are optimised by the gr_bal engine instead (solve.hpp).
+#pragma once
+#include "core.hpp"
+#include <functional>
+#include <unordered_map>
+
+namespace graphite {
+
+// ---- thrust::device_vector look-alike (hipMalloc storage; element reads copy one value to the host) ------------------
+template <typename T> class device_vector {
+  T *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+public:
+  struct pointer { T *p; T *get() const { return p; } };
+  device_vector() = default;
+  explicit device_vector(size_t n) { resize(n); }
+  device_vector(const device_vector &) = delete;
+  device_vector &operator=(const device_vector &) = delete;
+  ~device_vector() { if (p_) (void)hipFree(p_); }
+  void resize(size_t n) {
+    if (n > cap_) {
+      T *q = nullptr;
+      GRAPHITE_HIP(hipMalloc(reinterpret_cast<void **>(&q), n * sizeof(T)));
+      if (n_) GRAPHITE_HIP(hipMemcpy(q, p_, n_ * sizeof(T), hipMemcpyDeviceToDevice));
+      if (p_) (void)hipFree(p_);
+      p_ = q; cap_ = n;
+    }
+    n_ = n;
+  }
+  void clear() { n_ = 0; }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  pointer data() const { return pointer{p_}; }
+  T *raw() const { return p_; }
+  device_vector &operator=(const std::vector<T> &h) {
+    resize(h.size());
+    if (!h.empty()) GRAPHITE_HIP(hipMemcpy(p_, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return *this;
+  }
+  std::vector<T> to_host() const {
+    std::vector<T> h(n_);
+    if (n_) GRAPHITE_HIP(hipMemcpy(h.data(), p_, n_ * sizeof(T), hipMemcpyDeviceToHost));
+    return h;
+  }
+  T operator[](size_t i) const { T v; GRAPHITE_HIP(hipMemcpy(&v, p_ + i, sizeof(T), hipMemcpyDeviceToHost)); return v; }
+  void zero() { if (n_) GRAPHITE_HIP(hipMemset(p_, 0, n_ * sizeof(T))); }
+};
+
+// hessian.hpp:15-20
+template <typename T, typename I> class CSCMatrix {
+public:
+  device_vector<I> d_pointers;
+  device_vector<I> d_indices;
+  device_vector<T> d_values;
+};
+
+namespace detail {
+inline uint64_t block_key(size_t row, size_t col) { return ((uint64_t)col << 32) | (uint64_t)row; }
+
+// number of stored scalars of scalar column `col` (rows <= col), csc_utils.hpp:87-113
+template <typename I> __global__ void k_csc_count(size_t dim, const size_t *s2b, const size_t *colp, const size_t *rowi, const size_t *soff, I *count) {
+  const size_t col = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (col >= dim) return;
+  const size_t bc = s2b[col];
+  size_t nv = 0;
+  for (size_t b = colp[bc]; b < colp[bc + 1]; ++b) {
+    const size_t br = rowi[b], nr = soff[br + 1] - soff[br], r0 = soff[br];
+    for (size_t r = 0; r < nr && r0 + r <= col; ++r) ++nv;
+  }
+  count[col] = (I)nv;
+}
+// row indices (values == nullptr) or values of the scalar upper CSC, csc_utils.hpp:123-193
+template <typename S, typename I> __global__ void k_csc_fill(size_t dim, const size_t *s2b, const size_t *colp, const size_t *rowi, const size_t *boff, const size_t *soff,
+                                                              const I *ptr, const S *values, I *out_idx, S *out_val) {
+  const size_t col = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (col >= dim) return;
+  const size_t bc = s2b[col], cin = col - soff[bc];
+  size_t w = (size_t)ptr[col];
+  for (size_t b = colp[bc]; b < colp[bc + 1]; ++b) {
+    const size_t br = rowi[b], nr = soff[br + 1] - soff[br], r0 = soff[br];
+    for (size_t r = 0; r < nr && r0 + r <= col; ++r, ++w) {
+      if (out_idx) out_idx[w] = (I)(r0 + r);
+      if (out_val) out_val[w] = values[boff[b] + cin * nr + r];
+    }
+  }
+}
+template <typename S, typename I>
+void build_scalar_csc(size_t dim, const device_vector<size_t> &s2b, const device_vector<size_t> &colp, const device_vector<size_t> &rowi,
+                      const device_vector<size_t> &boff, const device_vector<size_t> &soff, CSCMatrix<S, I> &m) {
+  m.d_pointers.resize(dim + 1);
+  m.d_pointers.zero();
+  if (dim) k_csc_count<I><<<blocks(dim), TPB>>>(dim, s2b.raw(), colp.raw(), rowi.raw(), soff.raw(), m.d_pointers.raw());
+  std::vector<I> cnt = m.d_pointers.to_host(); // exclusive scan (the reference: thrust::exclusive_scan)
+  I run = 0;
+  for (size_t c = 0; c <= dim; ++c) { const I v = cnt[c]; cnt[c] = run; run += v; }
+  m.d_pointers = cnt;
+  const size_t nnz = (size_t)cnt[dim];
+  m.d_indices.resize(nnz); m.d_values.resize(nnz);
+  if (dim) k_csc_fill<S, I><<<blocks(dim), TPB>>>(dim, s2b.raw(), colp.raw(), rowi.raw(), boff.raw(), soff.raw(), m.d_pointers.raw(), (const S *)nullptr, m.d_indices.raw(), (S *)nullptr);
+  sync();
+}
+template <typename S, typename I>
+void update_scalar_csc(size_t dim, const device_vector<S> &values, const device_vector<size_t> &s2b, const device_vector<size_t> &colp, const device_vector<size_t> &rowi,
+                       const device_vector<size_t> &boff, const device_vector<size_t> &soff, CSCMatrix<S, I> &m) {
+  if (dim) k_csc_fill<S, I><<<blocks(dim), TPB>>>(dim, s2b.raw(), colp.raw(), rowi.raw(), boff.raw(), soff.raw(), m.d_pointers.raw(), values.raw(), (I *)nullptr, m.d_values.raw());
+  sync();
+}
+
+// prev_diag <- diagonal of the diagonal blocks (hessian.hpp:102-134); or H diag <- damped prev_diag (:136-176)
+template <typename T, typename S, int MODE> __global__ void k_hessian_diag(size_t nb, const size_t *colp, const size_t *boff, const size_t *soff, S *values, S *prev, T mu, int identity) {
+  const size_t bc = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (bc >= nb) return;
+  const size_t b = colp[bc + 1] - 1; // the diagonal block is the last of its column
+  const size_t d = soff[bc + 1] - soff[bc];
+  S *blk = values + boff[b];
+  for (size_t i = 0; i < d; ++i) {
+    if (MODE == 0) prev[soff[bc] + i] = blk[i * d + i];
+    else {
+      const double h = (double)prev[soff[bc] + i];
+      const double cl = h < 1.0e-6 ? 1.0e-6 : (h > 1.0e32 ? 1.0e32 : h);
+      blk[i * d + i] = (S)(identity ? h + (double)mu : h + (double)mu * cl);
+    }
+  }
+}
+} // namespace detail
+
+// =================================================================================================
+// Hessian (hessian.hpp:45-330)
+// =================================================================================================
+template <typename T, typename S> class Hessian {
+  std::unordered_map<uint64_t, size_t> block_indices; // (row, col) -> value offset
+  std::vector<size_t> h_col_pointers, h_row_indices, h_offsets, h_scalar_offsets;
+  device_vector<size_t> d_col_pointers, d_row_indices, d_offsets, d_hessian_offsets, scalar_to_block_map;
+  device_vector<S> d_hessian, d_prev_diag;
+public:
+  Hessian() = default;
+  const device_vector<size_t> &get_block_col_pointers() const { return d_col_pointers; }
+  const device_vector<size_t> &get_block_row_indices() const { return d_row_indices; }
+  const device_vector<size_t> &get_block_value_offsets() const { return d_offsets; }
+  const device_vector<S> &get_values() const { return d_hessian; }
+  S *get_values_ptr() { return d_hessian.raw(); }
+  const S *get_values_ptr() const { return d_hessian.raw(); }
+  // host copies of the block-CSC (what SchurComplement::build_structure walks)
+  const std::vector<size_t> &host_col_pointers() const { return h_col_pointers; }
+  const std::vector<size_t> &host_row_indices() const { return h_row_indices; }
+  const std::vector<size_t> &host_value_offsets() const { return h_offsets; }
+  const std::vector<size_t> &host_scalar_offsets() const { return h_scalar_offsets; }
+  bool has_block(size_t row, size_t col) const { return block_indices.count(detail::block_key(row, col)) != 0; }
+  size_t block_offset(size_t row, size_t col) const { return block_indices.at(detail::block_key(row, col)); }
+
+  void build_structure(Graph<T, S> *graph, StreamPool &) {
+    h_scalar_offsets = graph->get_offset_vector();
+    const size_t nb = graph->get_num_block_columns(), dim = graph->get_hessian_dimension();
+    std::vector<size_t> s2b(dim);
+    for (size_t b = 0; b < nb; ++b)
+      for (size_t c = h_scalar_offsets[b]; c < h_scalar_offsets[b + 1]; ++c) s2b[c] = b;
+    // unique upper block coordinates: every active vertex's diagonal block + one block per vertex pair of a factor
+    std::vector<BlockCoordinates> coords;
+    for (size_t b = 0; b < nb; ++b) coords.push_back(BlockCoordinates{b, b});
+    for (auto *fd : graph->get_factor_descriptors()) fd->block_pairs(coords, s2b);
+    std::sort(coords.begin(), coords.end(), [](const BlockCoordinates &a, const BlockCoordinates &b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
+    coords.erase(std::unique(coords.begin(), coords.end()), coords.end());
+    block_indices.clear();
+    h_col_pointers.assign(nb + 1, 0); h_row_indices.clear(); h_offsets.clear();
+    size_t nvalues = 0;
+    for (const auto &c : coords) {
+      block_indices[detail::block_key(c.row, c.col)] = nvalues;
+      h_col_pointers[c.col + 1]++;
+      h_row_indices.push_back(c.row); h_offsets.push_back(nvalues);
+      nvalues += graph->get_variable_dimension(c.row) * graph->get_variable_dimension(c.col);
+    }
+    for (size_t b = 0; b < nb; ++b) h_col_pointers[b + 1] += h_col_pointers[b];
+    d_hessian.resize(nvalues); d_prev_diag.resize(dim);
+    d_col_pointers = h_col_pointers; d_row_indices = h_row_indices; d_offsets = h_offsets;
+    d_hessian_offsets = h_scalar_offsets; scalar_to_block_map = s2b;
+    // per factor and vertex pair: where its block lives (the role of setup_hessian_computation, hessian.hpp:178-208)
+    const auto lookup = [this](size_t row, size_t col) { return block_indices.at(detail::block_key(row, col)); };
+    for (auto *fd : graph->get_factor_descriptors()) fd->sparse_setup(lookup, s2b);
+  }
+  void update_values(Graph<T, S> *graph, StreamPool &) { // hessian.hpp:290-307
+    d_hessian.zero();
+    for (auto *fd : graph->get_factor_descriptors()) fd->sparse_hessian(d_hessian.raw());
+    const size_t nb = graph->get_num_block_columns();
+    if (nb) detail::k_hessian_diag<T, S, 0><<<detail::blocks(nb), detail::TPB>>>(nb, d_col_pointers.raw(), d_offsets.raw(), d_hessian_offsets.raw(), d_hessian.raw(), d_prev_diag.raw(), T(0), 0);
+    detail::sync();
+  }
+  void apply_damping(Graph<T, S> *graph, T damping_factor, const bool use_identity, StreamPool &) { // hessian.hpp:136-176
+    const size_t nb = graph->get_num_block_columns();
+    if (nb) detail::k_hessian_diag<T, S, 1><<<detail::blocks(nb), detail::TPB>>>(nb, d_col_pointers.raw(), d_offsets.raw(), d_hessian_offsets.raw(), d_hessian.raw(), d_prev_diag.raw(), damping_factor, use_identity ? 1 : 0);
+    detail::sync();
+  }
+  template <typename I> void build_csc_structure(Graph<T, S> *graph, CSCMatrix<S, I> &matrix) {
+    detail::build_scalar_csc<S, I>(graph->get_hessian_dimension(), scalar_to_block_map, d_col_pointers, d_row_indices, d_offsets, d_hessian_offsets, matrix);
+  }
+  template <typename I> void update_csc_values(Graph<T, S> *graph, CSCMatrix<S, I> &matrix) {
+    detail::update_scalar_csc<S, I>(graph->get_hessian_dimension(), d_hessian, scalar_to_block_map, d_col_pointers, d_row_indices, d_offsets, d_hessian_offsets, matrix);
+  }
+};
+
+// =================================================================================================
+// SchurComplement (schur.hpp:87-1120)
+// =================================================================================================
+namespace detail {
+struct SchurMulOp { size_t dst, left, right, mid; uint32_t da, db, dl, pad; };       // S_dst -= L M R^T       (schur.hpp:484-585)
+struct SchurHplOp { size_t blk, inv, prow, lrow; uint32_t da, dl; };                  // one Hpl block (pose rows prow.., landmark rows lrow..)
+struct SchurCopyOp { size_t src, dst, count; };                                       // Hpp block -> S block  (:587)
+struct SchurInvOp { size_t blk, inv; uint32_t d, pad; };                              // Hll block -> inverse  (:1067)
+struct SchurVecOp { size_t blk, xoff, yoff; uint32_t rows, cols, transposed, pad; };  // y += A x or A^T x     (:307-393)
+
+template <typename S> __global__ void k_schur_copy(const SchurCopyOp *ops, size_t nops, const S *H, S *Sv) {
+  const size_t op = blockIdx.x;
+  if (op >= nops) return;
+  for (size_t i = threadIdx.x; i < ops[op].count; i += blockDim.x) Sv[ops[op].dst + i] = H[ops[op].src + i];
+}
+template <typename S> __global__ void k_schur_invert(const SchurInvOp *ops, size_t nops, const S *H, S *inv) {
+  const size_t op = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (op >= nops) return;
+  constexpr int MAXD = 16;
+  const int d = (int)ops[op].d;
+  double A[MAXD * MAXD], R[MAXD * MAXD];
+  const S *B = H + ops[op].blk;
+  for (int i = 0; i < d * d; ++i) { A[i] = (double)B[i]; R[i] = (i % d == i / d) ? 1.0 : 0.0; }
+  for (int k = 0; k < d; ++k) { // Gauss-Jordan with partial pivoting: the role of cublas<t>matinvBatched (:1101)
+    int piv = k;
+    for (int r = k + 1; r < d; ++r) if (fabs(A[r + k * d]) > fabs(A[piv + k * d])) piv = r;
+    if (piv != k)
+      for (int c = 0; c < d; ++c) { double t = A[k + c * d]; A[k + c * d] = A[piv + c * d]; A[piv + c * d] = t; t = R[k + c * d]; R[k + c * d] = R[piv + c * d]; R[piv + c * d] = t; }
+    const double ip = 1.0 / A[k + k * d];
+    for (int c = 0; c < d; ++c) { A[k + c * d] *= ip; R[k + c * d] *= ip; }
+    for (int r = 0; r < d; ++r) {
+      if (r == k) continue;
+      const double f = A[r + k * d];
+      for (int c = 0; c < d; ++c) { A[r + c * d] -= f * A[k + c * d]; R[r + c * d] -= f * R[k + c * d]; }
+    }
+  }
+  for (int i = 0; i < d * d; ++i) inv[ops[op].inv + i] = (S)R[i];
+}
+// one thread per (product, output scalar): value = sum_k L(row,k) sum_j M(k,j) R(col,j)   (ops/schur.hpp:155-188)
+template <typename S> __global__ void k_schur_mul(const SchurMulOp *ops, const size_t *first_thread, size_t nops, size_t nthreads, const S *H, const S *inv, S *Sv) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= nthreads) return;
+  size_t lo = 0, hi = nops; // op = last with first_thread[op] <= t
+  while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (first_thread[mid] <= t) lo = mid; else hi = mid; }
+  const SchurMulOp o = ops[lo];
+  const size_t e = t - first_thread[lo], row = e % o.da, col = e / o.da;
+  const S *L = H + o.left, *R = H + o.right, *M = inv + o.mid;
+  S value = 0;
+  for (uint32_t k = 0; k < o.dl; ++k) {
+    S mrt = 0;
+    for (uint32_t j = 0; j < o.dl; ++j) mrt += M[k + o.dl * j] * R[col + o.db * j];
+    value += L[row + o.da * k] * mrt;
+  }
+  atomicAdd(&Sv[o.dst + row + o.da * col], -value);
+}
+// w_l = Hll^-1 v_l for every landmark block (v = b_l, or b_l - Hpl^T x_p)
+template <typename T, typename S> __global__ void k_schur_apply_inverse(const SchurInvOp *ops, size_t nops, const size_t *lrow, const S *inv, const T *v, T *w) {
+  const size_t op = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (op >= nops) return;
+  const int d = (int)ops[op].d;
+  const S *M = inv + ops[op].inv;
+  const size_t r0 = lrow[op];
+  for (int r = 0; r < d; ++r) {
+    T s = 0;
+    for (int c = 0; c < d; ++c) s += (T)M[r + d * c] * v[r0 + c];
+    w[r0 + r] = s;
+  }
+}
+// MODE 0: out_p[prow..] -= Hpl w_l  (b_S, schur.hpp:901-920);  MODE 1: out_l[lrow..] -= Hpl^T x_p  (back-substitution, :279-302)
+template <typename T, typename S, int MODE> __global__ void k_schur_hpl(const SchurHplOp *ops, size_t nops, const S *H, const T *in, T *out) {
+  const size_t op = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (op >= nops) return;
+  const SchurHplOp o = ops[op];
+  const S *A = H + o.blk; // da x dl, column-major
+  if (MODE == 0) {
+    for (uint32_t r = 0; r < o.da; ++r) {
+      T s = 0;
+      for (uint32_t c = 0; c < o.dl; ++c) s += (T)A[r + o.da * c] * in[o.lrow + c];
+      atomicAdd(&out[o.prow + r], -s);
+    }
+  } else {
+    for (uint32_t c = 0; c < o.dl; ++c) {
+      T s = 0;
+      for (uint32_t r = 0; r < o.da; ++r) s += (T)A[r + o.da * c] * in[o.prow + r];
+      atomicAdd(&out[o.lrow + c], -s);
+    }
+  }
+}
+template <typename T, typename S> __global__ void k_schur_vec(const SchurVecOp *ops, size_t nops, const S *Sv, const T *x, T *y) {
+  const size_t op = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (op >= nops) return;
+  const SchurVecOp o = ops[op];
+  const S *A = Sv + o.blk; // rows x cols, column-major
+  if (!o.transposed) {
+    for (uint32_t r = 0; r < o.rows; ++r) { T s = 0; for (uint32_t c = 0; c < o.cols; ++c) s += (T)A[r + o.rows * c] * x[o.xoff + c]; atomicAdd(&y[o.yoff + r], s); }
+  } else {
+    for (uint32_t c = 0; c < o.cols; ++c) { T s = 0; for (uint32_t r = 0; r < o.rows; ++r) s += (T)A[r + o.rows * c] * x[o.xoff + r]; atomicAdd(&y[o.yoff + c], s); }
+  }
+}
+template <typename T> __global__ void k_sub(T *out, const T *a, const T *b, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] - b[i];
+}
+// dense symmetric image of the upper block-CSC (for the direct solve of the reduced system)
+template <typename T, typename S> __global__ void k_blocks_to_dense(size_t nblk, const size_t *colp_of_blk, const size_t *rowi, const size_t *boff, const size_t *soff, const S *Sv, T *D, size_t ld) {
+  const size_t b = blockIdx.x;
+  if (b >= nblk) return;
+  const size_t bc = colp_of_blk[b], br = rowi[b];
+  const size_t nr = soff[br + 1] - soff[br], nc = soff[bc + 1] - soff[bc];
+  for (size_t e = threadIdx.x; e < nr * nc; e += blockDim.x) {
+    const size_t r = e % nr, c = e / nr;
+    const T v = (T)Sv[boff[b] + e];
+    D[(soff[br] + r) * ld + soff[bc] + c] = v;
+    D[(soff[bc] + c) * ld + soff[br] + r] = v;
+  }
+}
+} // namespace detail
+
+template <typename T, typename S> class SchurComplement {
+  Hessian<T, S> &H;
+  // structure of S: upper pose blocks, column-major sorted, blocks column-major (same layout as H)
+  std::unordered_map<uint64_t, size_t> block_indices;
+  std::vector<size_t> h_col_pointers, h_row_indices, h_offsets, h_block_col, h_pose_offsets, h_diag_offsets;
+  device_vector<size_t> d_col_pointers, d_row_indices, d_offsets, d_block_col, d_schur_offsets, scalar_to_block_map, d_mul_first, d_inv_lrow;
+  device_vector<S> d_schur, d_hll_inv;
+  device_vector<T> b_Schur, l_workspace, l_rhs;
+  device_vector<detail::SchurMulOp> d_mul_ops;
+  device_vector<detail::SchurHplOp> d_hpl_ops;
+  device_vector<detail::SchurCopyOp> d_copy_ops;
+  device_vector<detail::SchurInvOp> d_inv_ops;
+  device_vector<detail::SchurVecOp> d_vec_ops;
+  size_t landmark_col_start = 0, num_block_columns = 0, pose_dim = 0, landmark_dim = 0, mul_threads = 0;
+public:
+  explicit SchurComplement(Hessian<T, S> &H_) : H(H_) {}
+  size_t get_pose_dimension() const { return pose_dim; }
+  size_t get_landmark_dimension() const { return landmark_dim; }
+  size_t num_pose_blocks() const { return landmark_col_start; }
+  const std::vector<size_t> &host_pose_offsets() const { return h_pose_offsets; }   // scalar start of every pose block (+ end)
+  const std::vector<size_t> &host_diag_offsets() const { return h_diag_offsets; }   // value offset of S(b, b)
+  const std::vector<size_t> &host_col_pointers() const { return h_col_pointers; }
+  const std::vector<size_t> &host_row_indices() const { return h_row_indices; }
+  const device_vector<S> &get_values() const { return d_schur; }
+  S *get_values_ptr() { return d_schur.raw(); }
+  device_vector<T> &get_b_Schur() { return b_Schur; }
+
+  void build_structure(Graph<T, S> *graph, StreamPool &) { // schur.hpp:194-225
+    using namespace detail;
+    num_block_columns = graph->get_num_block_columns();
+    landmark_col_start = graph->get_elimination_block_column();
+    const auto &soff = H.host_scalar_offsets();
+    pose_dim = soff[landmark_col_start];
+    landmark_dim = soff[num_block_columns] - pose_dim;
+    const auto &hcp = H.host_col_pointers();
+    const auto &hri = H.host_row_indices();
+    const auto &hof = H.host_value_offsets();
+    auto dim = [&](size_t b) { return soff[b + 1] - soff[b]; };
+    // symbolic S: Hpp pattern U {(i, j): i <= j both meet a landmark} (schur.hpp:397-476)
+    std::vector<BlockCoordinates> coords;
+    for (size_t col = 0; col < landmark_col_start; ++col)
+      for (size_t k = hcp[col]; k < hcp[col + 1]; ++k) coords.push_back(BlockCoordinates{hri[k], col});
+    for (size_t l = landmark_col_start; l < num_block_columns; ++l) {
+      const size_t k0 = hcp[l], k1 = hcp[l + 1] - 1; // the last block of the column is Hll
+      for (size_t a = k0; a < k1; ++a) {
+        if (hri[a] >= landmark_col_start) throw std::invalid_argument("SchurComplement: eliminated vertices share a factor (Hll must be block diagonal)");
+        for (size_t bq = a; bq < k1; ++bq) coords.push_back(BlockCoordinates{hri[a], hri[bq]});
+      }
+    }
+    std::sort(coords.begin(), coords.end(), [](const BlockCoordinates &a, const BlockCoordinates &b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
+    coords.erase(std::unique(coords.begin(), coords.end()), coords.end());
+    block_indices.clear();
+    h_col_pointers.assign(landmark_col_start + 1, 0); h_row_indices.clear(); h_offsets.clear(); h_block_col.clear();
+    h_diag_offsets.assign(landmark_col_start, 0);
+    size_t nvalues = 0;
+    for (const auto &c : coords) {
+      block_indices[block_key(c.row, c.col)] = nvalues;
+      if (c.row == c.col) h_diag_offsets[c.col] = nvalues;
+      h_col_pointers[c.col + 1]++;
+      h_row_indices.push_back(c.row); h_offsets.push_back(nvalues); h_block_col.push_back(c.col);
+      nvalues += dim(c.row) * dim(c.col);
+    }
+    for (size_t b = 0; b < landmark_col_start; ++b) h_col_pointers[b + 1] += h_col_pointers[b];
+    h_pose_offsets.assign(soff.begin(), soff.begin() + landmark_col_start + 1);
+    std::vector<size_t> s2b(pose_dim);
+    for (size_t b = 0; b < landmark_col_start; ++b)
+      for (size_t c = soff[b]; c < soff[b + 1]; ++c) s2b[c] = b;
+    d_schur.resize(nvalues);
+    d_col_pointers = h_col_pointers; d_row_indices = h_row_indices; d_offsets = h_offsets; d_block_col = h_block_col;
+    d_schur_offsets = h_pose_offsets; scalar_to_block_map = s2b;
+    // operation lists
+    std::vector<SchurCopyOp> copy_ops;
+    std::vector<SchurInvOp> inv_ops;
+    std::vector<SchurMulOp> mul_ops;
+    std::vector<SchurHplOp> hpl_ops;
+    std::vector<SchurVecOp> vec_ops;
+    std::vector<size_t> mul_first, inv_lrow;
+    for (size_t col = 0; col < landmark_col_start; ++col) // Hpp copy (:587)
+      for (size_t k = hcp[col]; k < hcp[col + 1]; ++k) copy_ops.push_back(SchurCopyOp{hof[k], block_indices.at(block_key(hri[k], col)), dim(hri[k]) * dim(col)});
+    size_t inv_values = 0;
+    mul_threads = 0;
+    for (size_t l = landmark_col_start; l < num_block_columns; ++l) {
+      const size_t k0 = hcp[l], k1 = hcp[l + 1] - 1, dl = dim(l);
+      if (dl > 16) throw std::invalid_argument("SchurComplement: eliminated vertex dimension > 16");
+      inv_ops.push_back(SchurInvOp{hof[k1], inv_values, (uint32_t)dl, 0});
+      inv_lrow.push_back(soff[l] - pose_dim);
+      for (size_t a = k0; a < k1; ++a) {
+        hpl_ops.push_back(SchurHplOp{hof[a], inv_values, soff[hri[a]], soff[l] - pose_dim, (uint32_t)dim(hri[a]), (uint32_t)dl});
+        for (size_t bq = a; bq < k1; ++bq) {
+          mul_first.push_back(mul_threads);
+          mul_ops.push_back(SchurMulOp{block_indices.at(block_key(hri[a], hri[bq])), hof[a], hof[bq], inv_values, (uint32_t)dim(hri[a]), (uint32_t)dim(hri[bq]), (uint32_t)dl, 0});
+          mul_threads += dim(hri[a]) * dim(hri[bq]);
+        }
+      }
+      inv_values += dl * dl;
+    }
+    for (size_t q = 0; q < h_row_indices.size(); ++q) { // S x: upper blocks, and their transposes below the diagonal (:307-345)
+      const size_t r = h_row_indices[q], c = h_block_col[q];
+      vec_ops.push_back(SchurVecOp{h_offsets[q], soff[c], soff[r], (uint32_t)dim(r), (uint32_t)dim(c), 0, 0});
+      if (r != c) vec_ops.push_back(SchurVecOp{h_offsets[q], soff[r], soff[c], (uint32_t)dim(r), (uint32_t)dim(c), 1, 0});
+    }
+    d_hll_inv.resize(inv_values);
+    d_copy_ops = copy_ops; d_inv_ops = inv_ops; d_mul_ops = mul_ops; d_hpl_ops = hpl_ops; d_vec_ops = vec_ops; d_mul_first = mul_first; d_inv_lrow = inv_lrow;
+    b_Schur.resize(pose_dim); l_workspace.resize(landmark_dim); l_rhs.resize(landmark_dim);
+  }
+
+  void update_values(Graph<T, S> *graph, StreamPool &) { // schur.hpp:227-235
+    using namespace detail;
+    d_schur.zero();
+    if (d_copy_ops.size()) k_schur_copy<S><<<(unsigned)d_copy_ops.size(), 64>>>(d_copy_ops.raw(), d_copy_ops.size(), H.get_values_ptr(), d_schur.raw());
+    if (d_inv_ops.size()) k_schur_invert<S><<<blocks(d_inv_ops.size()), TPB>>>(d_inv_ops.raw(), d_inv_ops.size(), H.get_values_ptr(), d_hll_inv.raw());
+    if (mul_threads) k_schur_mul<S><<<blocks(mul_threads), TPB>>>(d_mul_ops.raw(), d_mul_first.raw(), d_mul_ops.size(), mul_threads, H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw());
+    // b_S = b_p - Hpl Hll^-1 b_l (:901-920)
+    const T *b = graph->get_b().raw();
+    GRAPHITE_HIP(hipMemcpy(b_Schur.raw(), b, pose_dim * sizeof(T), hipMemcpyDefault));
+    if (d_inv_ops.size()) {
+      k_schur_apply_inverse<T, S><<<blocks(d_inv_ops.size()), TPB>>>(d_inv_ops.raw(), d_inv_ops.size(), d_inv_lrow.raw(), d_hll_inv.raw(), b + pose_dim, l_workspace.raw());
+      if (d_hpl_ops.size()) k_schur_hpl<T, S, 0><<<blocks(d_hpl_ops.size()), TPB>>>(d_hpl_ops.raw(), d_hpl_ops.size(), H.get_values_ptr(), l_workspace.raw(), b_Schur.raw());
+    }
+    sync();
+  }
+  template <typename I> void build_csc_structure(Graph<T, S> *, CSCMatrix<S, I> &matrix) {
+    detail::build_scalar_csc<S, I>(pose_dim, scalar_to_block_map, d_col_pointers, d_row_indices, d_offsets, d_schur_offsets, matrix);
+  }
+  template <typename I> void update_csc_values(Graph<T, S> *, CSCMatrix<S, I> &matrix) {
+    detail::update_scalar_csc<S, I>(pose_dim, d_schur, scalar_to_block_map, d_col_pointers, d_row_indices, d_offsets, d_schur_offsets, matrix);
+  }
+  // x_l = Hll^-1 (b_l - Hpl^T x_p)  (schur.hpp:279-302); xl, xp: device pointers
+  void compute_landmark_update(Graph<T, S> *graph, StreamPool &, T *xl, const T *xp) {
+    using namespace detail;
+    if (landmark_col_start >= num_block_columns) return;
+    const T *b = graph->get_b().raw();
+    GRAPHITE_HIP(hipMemcpy(l_rhs.raw(), b + pose_dim, landmark_dim * sizeof(T), hipMemcpyDefault));
+    if (d_hpl_ops.size()) k_schur_hpl<T, S, 1><<<blocks(d_hpl_ops.size()), TPB>>>(d_hpl_ops.raw(), d_hpl_ops.size(), H.get_values_ptr(), xp, l_rhs.raw());
+    k_schur_apply_inverse<T, S><<<blocks(d_inv_ops.size()), TPB>>>(d_inv_ops.raw(), d_inv_ops.size(), d_inv_lrow.raw(), d_hll_inv.raw(), l_rhs.raw(), xl);
+    sync();
+  }
+  // vec_out = S vec_in (schur.hpp:347-393)
+  void execute_schur_vector_multiply(Graph<T, S> *, StreamPool &, T *vec_out, const T *vec_in) {
+    using namespace detail;
+    fill<T>(vec_out, pose_dim, T(0));
+    if (d_vec_ops.size()) k_schur_vec<T, S><<<blocks(d_vec_ops.size()), TPB>>>(d_vec_ops.raw(), d_vec_ops.size(), d_schur.raw(), vec_in, vec_out);
+    sync();
+  }
+  // dense row-major image of S (both triangles), leading dimension pose_dim: input of the direct reduced solve
+  void to_dense(T *D) {
+    using namespace detail;
+    fill<T>(D, pose_dim * pose_dim, T(0));
+    if (h_row_indices.size()) k_blocks_to_dense<T, S><<<(unsigned)h_row_indices.size(), 64>>>(h_row_indices.size(), d_block_col.raw(), d_row_indices.raw(), d_offsets.raw(), d_schur_offsets.raw(), d_schur.raw(), D, pose_dim);
+    sync();
+  }
+};
+
+} // namespace graphite

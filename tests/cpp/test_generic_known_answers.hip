@@ -108,10 +108,13 @@ int main() {
     EXPECT_EQ(factor.internal_count(), 3u);
     EXPECT_FLOAT_EQ(factor.device_obs[0], 1.5f); EXPECT_FLOAT_EQ(factor.device_obs[1], 2.5f); EXPECT_FLOAT_EQ(factor.device_obs[2], 3.5f);
     EXPECT_EQ(factor.get_vertex_ids(f0)[0], 10u); EXPECT_EQ(factor.get_vertex_ids(f1)[0], 20u); EXPECT_EQ(factor.get_vertex_ids(f2)[0], 30u);
-    factor.remove_factor(f1); // the last factor takes the freed slot
+    factor.remove_factor(f1); // RemoveFactorFromMiddle (factor.cu:212-236): the other handles keep naming their factors
     EXPECT_EQ(factor.internal_count(), 2u);
-    EXPECT_EQ(factor.get_vertex_ids(0)[0], 10u); EXPECT_EQ(factor.get_vertex_ids(1)[0], 30u);
-    factor.remove_factor(1); factor.remove_factor(0);
+    EXPECT_EQ(factor.get_vertex_ids(f0)[0], 10u); EXPECT_EQ(factor.get_vertex_ids(f2)[0], 30u);
+    EXPECT_FLOAT_EQ(factor.device_obs[1], 3.5f); // the last factor took the freed slot (factor.hpp:318-355)
+    const auto f3 = factor.add_factor({20}, 4.5f); // the released handle is re-used (utils.hpp:88-96)
+    EXPECT_EQ(f3, f1); EXPECT_EQ(factor.get_vertex_ids(f3)[0], 20u);
+    factor.remove_factor(f0); factor.remove_factor(f3); factor.remove_factor(f2); // RemoveAllFactors (factor.cu:264-294)
     EXPECT_EQ(factor.internal_count(), 0u);
     factor.initialize_device_ids(0);
     EXPECT_EQ(factor.active_count(), 0u);

@@ -1,0 +1,95 @@
+"""The reference's own example clients compile UNMODIFIED against include/graphite (+ the Eigen look-alike of
+include/compat for images without Eigen) and, on a GPU box, optimise the same problem to the oracle's result.
+
+Nothing of the reference is copied: the sources are compiled where they lie (/root/reference/examples, only present
+in the build container); the binaries live under the git-ignored build/ and travel to the GPU box with the snapshot.
+The only command-line shim is -DcudaSetDevice=hipSetDevice for the one CUDA runtime call the examples make."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from graphite_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/examples"
+OUT = os.path.join(ROOT, "build", "ref_examples")
+
+
+def _compile(name):
+    lib = os.path.join(ROOT, "graphite_amd")
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, name)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O2", "-x", "hip", "-DcudaSetDevice=hipSetDevice",
+                           f"-I{ROOT}/include", f"-I{ROOT}/include/compat", os.path.join(REF, name + ".cu"),
+                           f"-L{lib}", "-lgraphite_mi355x", f"-Wl,-rpath,{lib}", "-o", exe])
+    return exe
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
+@pytest.mark.parametrize("name", ["circle", "bal"])
+def test_reference_example_compiles_unmodified(name):
+    """examples/circle.cu and examples/bal.cu (with bal.cuh, reprojection_error.cuh, projection_jacobians.cuh, argparse
+    and every graphite/... include they name, all five --precision instantiations including *-BF16)."""
+    from graphite_amd import _lib
+    _lib.build()
+    assert os.path.exists(_compile(name))
+
+
+def _need(name):
+    exe = os.path.join(OUT, name)
+    if not os.path.exists(exe):
+        pytest.skip("build/ref_examples was not built (no reference tree at build time)")
+    return exe
+
+
+@pytest.mark.gpu
+def test_reference_circle_runs():
+    out = subprocess.run([_need("circle")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    # circle.cu prints the optimised points with their radius: every free point ends on the circle of radius 4
+    before = {int(k): float(r) for k, r in re.findall(r"Adding point (\d+)=.*radius=([0-9.eE+-]+)", out.stdout)}
+    after = {int(k): float(r) for k, r in re.findall(r"Optimized point (\d+)=.*radius=([0-9.eE+-]+)", out.stdout)}
+    assert sorted(after) == [0, 1, 2, 3, 4], out.stdout[-1500:]
+    for k in (0, 1, 3):
+        # free points with an active factor end on the circle (random start, std::random_device: the LM loop may leave
+        # on "Rho is zero" a step early, levenberg_marquardt.hpp:228-231)
+        assert abs(after[k] - 4.0) < 0.05 and abs(after[k] - 4.0) <= abs(before[k] - 4.0)
+    for k in (2, 4):
+        assert abs(after[k] - before[k]) < 1e-5    # "points 2 and 4 should remain unchanged" (factor off / vertex fixed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,osolver", [("pcg", "SOLVER_PCG"), ("pcg-schur", "SOLVER_PCG_SCHUR"), ("eigen-schur", "SOLVER_LDLT_SCHUR"),
+                                            ("cudss-schur", "SOLVER_LDLT_SCHUR"), ("eigen", "SOLVER_LDLT")])
+def test_reference_bal_driver_matches_oracle(oracle_mod, tmp_path, solver, osolver):
+    """the reference's bal.cu, unmodified, on a BAL file: its printed MSE against the oracle's LM with the same solver."""
+    exe = _need("bal")
+    prob = synth.make_config("mini-50")
+    path = str(tmp_path / "mini50.txt")
+    synth.write_bal(path, prob)
+    out = subprocess.run([exe, path, "--solver", solver, "--iterations", "6", "--verbose"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    mse = float(re.search(r"^MSE: ([0-9.eE+-]+)", out.stdout, re.M).group(1))
+    ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx)
+    ct, _, _ = ref.levenberg_marquardt(solver=getattr(oracle_mod, osolver), iterations=6)
+    assert abs(mse - ct[-1] / prob.shape[2]) / (ct[-1] / prob.shape[2]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["FP64-FP32", "FP32-FP32", "FP64-BF16"])
+def test_reference_bal_driver_precisions(tmp_path, precision):
+    """--precision pairs of bal.cu:338-345 (graph T, Jacobian storage S), PCG: converges to the fp64 optimum within
+    the storage precision."""
+    exe = _need("bal")
+    prob = synth.make_config("mini-50")
+    path = str(tmp_path / "mini50.txt")
+    synth.write_bal(path, prob)
+    out = subprocess.run([exe, path, "--solver", "pcg", "--iterations", "8", "--precision", precision], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    mse = float(re.search(r"^MSE: ([0-9.eE+-]+)", out.stdout, re.M).group(1))
+    ref = subprocess.run([exe, path, "--solver", "pcg", "--iterations", "8"], capture_output=True, text=True, timeout=600)
+    mse64 = float(re.search(r"^MSE: ([0-9.eE+-]+)", ref.stdout, re.M).group(1))
+    assert abs(mse - mse64) / mse64 < {"FP64-FP32": 1e-5, "FP32-FP32": 1e-3, "FP64-BF16": 1e-2}[precision]
