@@ -20,7 +20,7 @@ SOLVER_PCG_SCHUR, SOLVER_PCG, SOLVER_PCG_IDENTITY, SOLVER_PCG_SCHUR_IMPLICIT, SO
 LOSS_DEFAULT, LOSS_HUBER = 0, 1
 F32, F64 = 0, 1
 
-_GET = dict(scales=0, b=1, Hcc=2, Hcp=3, Hll=4, S=5, b_schur=6, Hll_inv=7, residuals=8)
+_GET = dict(scales=0, b=1, Hcc=2, Hcp=3, Hll=4, S=5, b_schur=6, Hll_inv=7, residuals=8, H=9)
 
 
 def _ptr(a):
@@ -150,6 +150,28 @@ class BalProblem:
         out = np.zeros(cnt.value, self.dt)
         check(self.lib.gr_bal_get(self.h, C.c_int(_GET[name]), _ptr(out), C.byref(cnt)))
         return out
+
+    def hessian_structure(self):
+        """block-CSC of the upper Hessian in the reference's layout: (colptr, rowidx, value offsets)"""
+        nb = C.c_int64()
+        check(self.lib.gr_bal_hessian_structure(self.h, C.byref(nb), None, None, None))
+        colptr = np.zeros(self.Nc + self.Np + 1, np.int64)
+        rowidx = np.zeros(nb.value, np.int64)
+        offsets = np.zeros(nb.value, np.int64)
+        check(self.lib.gr_bal_hessian_structure(self.h, C.byref(nb), _ptr(colptr), _ptr(rowidx), _ptr(offsets)))
+        return colptr, rowidx, offsets
+
+    def export_csc(self, which):
+        """which: 'H' or 'S' -> (indptr, indices, data): scalar CSC of the upper triangle (csc_utils.hpp:74-193)"""
+        w = C.c_int(0 if which == "H" else 1)
+        nnz = C.c_int64()
+        check(self.lib.gr_bal_export_csc(self.h, w, C.byref(nnz), None, None, None))
+        dim = self.n if which == "H" else 9 * self.Nc
+        p = np.zeros(dim + 1, np.int64)
+        i = np.zeros(nnz.value, np.int64)
+        x = np.zeros(nnz.value, self.dt)
+        check(self.lib.gr_bal_export_csc(self.h, w, C.byref(nnz), _ptr(p), _ptr(i), _ptr(x)))
+        return p, i, x
 
     # --- optimizer ------------------------------------------------------------------------
     def levenberg_marquardt(self, solver=SOLVER_PCG_SCHUR, iterations=10, initial_damping=1e-4,

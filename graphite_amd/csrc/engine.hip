@@ -13,6 +13,7 @@
 #include <functional>
 #include "kernels_is.hpp"
 #include "chol.hpp"
+#include "sparse_chol.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -57,6 +58,8 @@ struct EngineBase {
   virtual void landmark_update(const void *xp, void *xl) = 0;
   virtual void schur_structure(int64_t *nnzb, int64_t *colptr, int64_t *rowidx) = 0;
   virtual void get(int which, void *out, int64_t *count) = 0;
+  virtual void hessian_structure(int64_t *nblocks, int64_t *colptr, int64_t *rowidx, int64_t *offsets) = 0;
+  virtual void export_csc(int which, int64_t *nnz, int64_t *indptr, int64_t *indices, void *values) = 0;
   virtual void lm(const gr_lm_options &opt, gr_lm_stats &st, double *chi2_trace, double *lambda_trace) = 0;
   virtual int kernel_stats(gr_kernel_stat *out, int cap) = 0;
   virtual double diag_time(int which, int variant, int reps) = 0;
@@ -831,9 +834,32 @@ template <typename T> struct Engine final : EngineBase {
     void end() override { open.pop_back(); }
   };
   std::unique_ptr<CholSink> chol_sink;
+  // sparse direct path (sparse_chol.hpp): nested dissection + level-scheduled tile Cholesky; used when the camera graph
+  // dissects (the tile elimination tree is clearly shorter than the chain of tile columns), DenseChol otherwise.
+  // GR_SPARSE_CHOL=0 / 1 forces the choice.
+  SparseChol<T> spchol;
+  bool use_spchol = false;
   void ensure_chol() {
     build_schur_structure();
     if (chol_ready) return;
+    {
+      const char *e = getenv("GR_SPARSE_CHOL");
+      const int force = e ? atoi(e) : -1;
+      if (force != 0 && spchol.set_structure((int)Nc, h_S_rowi, h_S_coli, stream)) {
+        use_spchol = force == 1 || 2 * spchol.nlevels < spchol.nt;
+        if (spchol.bytes() > ((size_t)96 << 30)) use_spchol = false;
+        if (getenv("GR_VERBOSE"))
+          std::fprintf(stderr, "[graphite-mi355x] sparse Cholesky: %d supernodes, %d tile columns (padded n = %d), elimination-tree height %d, %lld factor tiles -> %s\n",
+                       spchol.nsuper, spchol.nt, spchol.npad, spchol.nlevels, (long long)spchol.factor_tiles, use_spchol ? "nested dissection, level-scheduled" : "dense tile Cholesky");
+      }
+      if (use_spchol) {
+        chol_sink.reset(new CholSink(this));
+        spchol.sink = chol_sink.get();
+        chol_ready = true;
+        return;
+      }
+      spchol.A.release(); // not used: give the memory back
+    }
     if (DenseChol<T>::bytes_needed((int64_t)pose_dim) > ((size_t)96 << 30))
       throw std::invalid_argument("dense reduced camera system does not fit (9 Nc padded squared > 96 GiB)");
     const int nt = (int)((pose_dim + CH_NB - 1) / CH_NB);
@@ -852,6 +878,15 @@ template <typename T> struct Engine final : EngineBase {
   bool solve_dense_schur(T *x) {
     ensure_chol();
     schur_update_values();
+    if (use_spchol) {
+      spchol.load(nnzb, S_rowi.p, S_coli.p, S.p);
+      spchol.factor();
+      spchol.solve(b_schur.p, x);
+      broadcast_camera_step(x);
+      landmark_update_dev(x, x + pose_dim);
+      h_seq[1] = 0;
+      return spchol.ok();
+    }
     chol.clear();
     k_chol_scatter<T><<<cdiv(81 * (size_t)nnzb, TPB), TPB, 0, stream>>>(nnzb, S_rowi.p, S_coli.p, S.p, chol.A.p, chol.ld());
     chol.factor();
@@ -1131,6 +1166,12 @@ template <typename T> struct Engine final : EngineBase {
     case GR_GET_S: build_schur_structure(); cnt = 81 * nnzb; src = S.p; break;
     case GR_GET_B_SCHUR: build_schur_structure(); cnt = (int64_t)pose_dim; src = b_schur.p; break;
     case GR_GET_HLL_INV: build_schur_structure(); cnt = 9 * Np; src = Hll_inv.p; break;
+    case GR_GET_H: {
+      cnt = 81 * Nc + 27 * No + 9 * Np;
+      if (out) { const std::vector<T> v = hessian_values(); GR_HIP(hipMemcpy(out, v.data(), v.size() * sizeof(T), hipMemcpyDefault)); }
+      if (count) *count = cnt;
+      return;
+    }
     case GR_GET_RESIDUALS: {
       cnt = 2 * No;
       DevBuf<T> rpm; rpm.alloc(2 * (size_t)No);
@@ -1155,6 +1196,89 @@ template <typename T> struct Engine final : EngineBase {
         GR_HIP(hipStreamSynchronize(stream));
       }
     }
+  }
+
+  // ---- Hessian in the reference's layouts (hessian.hpp:257-324, csc_utils.hpp:16-193): export API, host side ----------
+  // block columns = cameras, then points in the CALLER's order; per point column the Hcp blocks by ascending camera, Hll last
+  void hessian_structure(int64_t *nblocks, int64_t *colptr, int64_t *rowidx, int64_t *offsets) override {
+    if (nblocks) *nblocks = Nc + No + Np;
+    if (!colptr && !rowidx && !offsets) return;
+    int64_t blk = 0, off = 0;
+    for (int64_t c = 0; c < Nc; ++c) {
+      if (colptr) colptr[c] = blk;
+      if (rowidx) rowidx[blk] = c;
+      if (offsets) offsets[blk] = off;
+      ++blk; off += 81;
+    }
+    for (int64_t l = 0; l < Np; ++l) {
+      const int q = h_pt_old2new[l];
+      if (colptr) colptr[Nc + l] = blk;
+      for (int a = h_pt_ptr[q]; a < h_pt_ptr[q + 1]; ++a) {
+        if (rowidx) rowidx[blk] = h_cam_pm[a];
+        if (offsets) offsets[blk] = off;
+        ++blk; off += 27;
+      }
+      if (rowidx) rowidx[blk] = Nc + l;
+      if (offsets) offsets[blk] = off;
+      ++blk; off += 9;
+    }
+    if (colptr) colptr[Nc + Np] = blk;
+  }
+  std::vector<T> hessian_values() { // GR_GET_H, assembled on the host from the three scaled block arrays
+    std::vector<T> hcc(81 * (size_t)Nc), hll(9 * (size_t)Np), hcp(27 * (size_t)No), v;
+    int64_t cnt = 0;
+    get(GR_GET_HCC, hcc.data(), &cnt); get(GR_GET_HLL, hll.data(), &cnt); get(GR_GET_HCP, hcp.data(), &cnt); // Hcp: INPUT observation order
+    std::vector<int> orig_of_pm(No);
+    for (int64_t o = 0; o < No; ++o) orig_of_pm[h_pm_of_orig[o]] = (int)o;
+    v.reserve(81 * (size_t)Nc + 27 * (size_t)No + 9 * (size_t)Np);
+    v.insert(v.end(), hcc.begin(), hcc.end());
+    for (int64_t l = 0; l < Np; ++l) {
+      const int q = h_pt_old2new[l];
+      for (int a = h_pt_ptr[q]; a < h_pt_ptr[q + 1]; ++a) { const T *b = &hcp[27 * (size_t)orig_of_pm[a]]; v.insert(v.end(), b, b + 27); }
+      v.insert(v.end(), &hll[9 * (size_t)l], &hll[9 * (size_t)l] + 9);
+    }
+    return v;
+  }
+  void export_csc(int which, int64_t *nnz, int64_t *indptr, int64_t *indices, void *values) override {
+    // scalar upper CSC from a block-CSC (csc_utils.hpp:74-193): per scalar column the rows <= column of every block of its block column
+    std::vector<int64_t> bcolptr, browidx, boffsets, soff;
+    std::vector<T> bvalues;
+    int64_t nbcol = 0;
+    if (which == 0) {
+      nbcol = Nc + Np;
+      bcolptr.resize(nbcol + 1); browidx.resize(Nc + No + Np); boffsets.resize(Nc + No + Np);
+      hessian_structure(nullptr, bcolptr.data(), browidx.data(), boffsets.data());
+      if (values) bvalues = hessian_values();
+      soff.resize(nbcol + 1);
+      for (int64_t b = 0; b <= nbcol; ++b) soff[b] = b <= Nc ? 9 * b : 9 * Nc + 3 * (b - Nc);
+    } else if (which == 1) {
+      build_schur_structure();
+      nbcol = Nc;
+      bcolptr.assign(h_S_colptr.begin(), h_S_colptr.end()); browidx.assign(h_S_rowi.begin(), h_S_rowi.end());
+      boffsets.resize(nnzb);
+      for (int64_t q = 0; q < nnzb; ++q) boffsets[q] = 81 * q;
+      if (values) bvalues = S.download(stream);
+      soff.resize(nbcol + 1);
+      for (int64_t b = 0; b <= nbcol; ++b) soff[b] = 9 * b;
+    } else throw std::invalid_argument("gr_bal_export_csc: which = 0 (H) or 1 (S)");
+    int64_t count = 0;
+    T *vout = static_cast<T *>(values);
+    for (int64_t bc = 0; bc < nbcol; ++bc) {
+      const int64_t ncols = soff[bc + 1] - soff[bc];
+      for (int64_t cin = 0; cin < ncols; ++cin) {
+        const int64_t col = soff[bc] + cin;
+        if (indptr) indptr[col] = count;
+        for (int64_t b = bcolptr[bc]; b < bcolptr[bc + 1]; ++b) {
+          const int64_t br = browidx[b], nr = soff[br + 1] - soff[br], r0 = soff[br];
+          for (int64_t r = 0; r < nr && r0 + r <= col; ++r, ++count) {
+            if (indices) indices[count] = r0 + r;
+            if (vout) vout[count] = bvalues[boffsets[b] + cin * nr + r];
+          }
+        }
+      }
+    }
+    if (indptr) indptr[soff[nbcol]] = count;
+    if (nnz) *nnz = count;
   }
 
   // ---- optimizer::levenberg_marquardt (optimizer/levenberg_marquardt.hpp:110-242) -----
@@ -1613,6 +1737,12 @@ gr_status gr_bal_schur_matvec(gr_bal_problem *p, const void *x, void *y) { retur
 gr_status gr_bal_landmark_update(gr_bal_problem *p, const void *xp, void *xl) { return guarded(p, [&] { p->e->landmark_update(xp, xl); }); }
 gr_status gr_bal_schur_structure(gr_bal_problem *p, int64_t *nnzb, int64_t *colptr, int64_t *rowidx) { return guarded(p, [&] { p->e->schur_structure(nnzb, colptr, rowidx); }); }
 gr_status gr_bal_get(gr_bal_problem *p, gr_bal_array which, void *out, int64_t *count) { return guarded(p, [&] { p->e->get(which, out, count); }); }
+gr_status gr_bal_hessian_structure(gr_bal_problem *p, int64_t *nblocks, int64_t *colptr, int64_t *rowidx, int64_t *offsets) {
+  return guarded(p, [&] { p->e->hessian_structure(nblocks, colptr, rowidx, offsets); });
+}
+gr_status gr_bal_export_csc(gr_bal_problem *p, int which, int64_t *nnz, int64_t *indptr, int64_t *indices, void *values) {
+  return guarded(p, [&] { p->e->export_csc(which, nnz, indptr, indices, values); });
+}
 gr_status gr_bal_levenberg_marquardt(gr_bal_problem *p, const gr_lm_options *opt, gr_lm_stats *stats, double *chi2_trace, double *lambda_trace) {
   if (!opt || !stats) { g_last_error = "null options/stats"; return GR_ERR_INVALID; }
   return guarded(p, [&] { p->e->lm(*opt, *stats, chi2_trace, lambda_trace); });

@@ -1,0 +1,543 @@
+// Sparse direct solve of the reduced camera system S x = b_S: nested-dissection ordering + supernodal (tile) Cholesky
+// on MFMA, scheduled by elimination-tree LEVEL.
+//
+// Role in the reference: cudssSchurSolver / EigenSchurLDLTSolver when S is sparse (solver/cudss_schur.hpp:146-234,
+// solver/eigen_schur.hpp:71-108 with Eigen's AMD ordering, src/eigen_solver.cpp:10-29) — SURVEY §8(f)-4.
+// Why: with the natural camera order a banded S (Ladybug-1723: 122 tile columns, band of ~6 tiles) is ONE dependency
+// chain of 122 x (factorise -> solve -> update) launches, 18.6 ms per LM iteration on a chip that is idle but for a
+// dozen workgroups.  Here
+//   1. the camera co-observation graph is ordered by nested dissection (recursive bisection through the middle
+//      level of a breadth-first level structure, leaves of <= LEAF cameras); every tree node is a supernode whose
+//      columns are padded to whole 128-column tiles, so independent subtrees never share a tile;
+//   2. a tile-level symbolic factorisation gives the fill and the elimination tree of the tile columns; columns of
+//      equal tree LEVEL are independent;
+//   3. the numeric phase runs level by level, three batched launches per level: every diagonal tile of the level
+//      (k_sp_potrf), every sub-diagonal tile (k_sp_gemm<0>), every target tile that a panel of the level updates,
+//      ONE workgroup per target walking its list of source panels (k_sp_gemm<1>: no two workgroups write one tile,
+//      no atomics); forward / backward substitution are one launch per level each.
+// The chain length drops from the number of tile columns to the height of the tile elimination tree (Ladybug-1723:
+// 122 -> ~35), and a level keeps tens to hundreds of workgroups busy instead of a dozen.  A graph that does not
+// dissect (Venice-like: every camera pair co-observes) comes out as ONE supernode = the dense factorisation; the
+// engine then keeps using DenseChol (chol.hpp), whose paired super-panels are tuned for that case.
+// Storage is the same padded dense row-major lower triangle as chol.hpp (only structurally non-zero tiles are ever
+// touched); the kernels reuse its diagonal-block factorisation and its MFMA tile loop.
+#pragma once
+#include "chol.hpp"
+#include <map>
+#include <numeric>
+
+namespace gr {
+
+template <typename T>
+__global__ __launch_bounds__(CH_PT) void k_sp_potrf(T *__restrict__ A, int ld, const int *__restrict__ panels, T *__restrict__ Linv, int *__restrict__ fail) {
+  extern __shared__ __align__(16) unsigned char ch_smem[];
+  const int k = panels[blockIdx.x];
+  chol_potrf_block<T>(reinterpret_cast<T *>(ch_smem), A + (size_t)k * CH_NB * ld + (size_t)k * CH_NB, ld, Linv + (size_t)k * CH_NB * CH_NB, fail, true, 0);
+}
+
+// MODE 0: L_ik = A_ik Linv_k^T for tiles[2b] = i, tiles[2b+1] = k                       (panel solve)
+// MODE 1: A_ij -= sum_{k in list(b)} L_ik L_jk^T, tiles[2b] = i, tiles[2b+1] = j, list(b) = klist[kptr[b] .. kptr[b+1])
+// Same 128x128x16 MFMA pipeline as k_chol_gemm; the K loop of MODE 1 runs over the concatenated source panels.
+// MODE 1 targets flagged (i | FUSE_BIT, i) are diagonal tiles whose LAST update this is (their column sits on the
+// next tree level): the workgroup factorises the tile on the spot from its accumulators (as k_chol_gemm<FUSE> does),
+// Linv_out = the per-panel inverse array, so the next level needs no factorisation launch of its own and the
+// 75 us diagonal-block factorisation overlaps with the other updates of this launch.
+constexpr int SP_FUSE_BIT = 1 << 30;
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, int ld, const int *__restrict__ tiles, const int *__restrict__ kptr, const int *__restrict__ klist,
+                                                 const T *__restrict__ Linv, T *__restrict__ Linv_out = nullptr, int *__restrict__ fail = nullptr) {
+  extern __shared__ __align__(16) unsigned char ch_smem[];
+  T *sm = reinterpret_cast<T *>(ch_smem);
+  using M = MfmaTile<T>;
+  typedef typename M::acc_t acc_t;
+  constexpr int KC = CH_KC, CPP = CH_NB / KC; // chunks per panel
+  const int ti_raw = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
+  const int ti = ti_raw & ~SP_FUSE_BIT;
+  const bool fuse = MODE == 1 && (ti_raw & SP_FUSE_BIT) != 0;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+  const int *kl = MODE == 1 ? klist + kptr[blockIdx.x] : nullptr;
+  const int nch = MODE == 1 ? CPP * (kptr[blockIdx.x + 1] - kptr[blockIdx.x]) : CPP;
+  const T *Prow = A + (size_t)ti * CH_NB * ld;
+  const T *Qrow = MODE == 0 ? Linv + (size_t)tj * CH_NB * CH_NB : A + (size_t)tj * CH_NB * ld;
+  const int ldq = MODE == 0 ? CH_NB : ld;
+  T *Cg = A + (size_t)ti * CH_NB * ld + (size_t)tj * CH_NB;
+  // column of chunk c in P (and in Q for MODE 1; Linv is a plain 128-column matrix)
+  auto pcol = [&](int c) { return MODE == 1 ? kl[c / CPP] * CH_NB + (c % CPP) * KC : tj * CH_NB + c * KC; };
+  auto qcol = [&](int c) { return MODE == 1 ? pcol(c) : c * KC; };
+
+  acc_t acc[4][4];
+  const int ccol = lane & 15;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (MODE == 1) acc[mi][ni][r] = Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld + wc * 64 + ni * 16 + ccol];
+        else acc[mi][ni][r] = T(0);
+      }
+  constexpr int TPR = KC / 8, RPP = 256 / TPR, NPASS = CH_NB / RPP;
+  const int lr = t / TPR, lk = (t % TPR) * 8;
+  T pp[NPASS][8], pq[NPASS][8];
+  {
+    const int pc = pcol(0), qc = qcol(0);
+#pragma unroll
+    for (int u = 0; u < NPASS; ++u) {
+      load8<T>(Prow + (size_t)(lr + u * RPP) * ld + pc + lk, pp[u]);
+      load8<T>(Qrow + (size_t)(lr + u * RPP) * ldq + qc + lk, pq[u]);
+    }
+  }
+  constexpr int BUF = 2 * KC * CH_LDP;
+  {
+    T *Ps = sm, *Qs = sm + KC * CH_LDP;
+#pragma unroll
+    for (int u = 0; u < NPASS; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { Ps[(lk + e) * CH_LDP + lr + u * RPP] = MODE == 1 ? -pp[u][e] : pp[u][e]; Qs[(lk + e) * CH_LDP + lr + u * RPP] = pq[u][e]; }
+  }
+  __syncthreads();
+  if (MODE == 1) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+v"(acc[mi][ni]));
+  }
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) {
+      const int pc = pcol(c + 1), qc = qcol(c + 1);
+#pragma unroll
+      for (int u = 0; u < NPASS; ++u) {
+        load8<T>(Prow + (size_t)(lr + u * RPP) * ld + pc + lk, pp[u]);
+        load8<T>(Qrow + (size_t)(lr + u * RPP) * ldq + qc + lk, pq[u]);
+      }
+    }
+    const T *Ps = sm + (c & 1) * BUF, *Qs = Ps + KC * CH_LDP;
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      const int krow = (kk * 4 + (lane >> 4)) * CH_LDP + ccol;
+      T a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = Ps[krow + wr * 64 + i * 16]; b[i] = Qs[krow + wc * 64 + i * 16]; }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(a[mi], b[ni], acc[mi][ni]);
+    }
+    if (c + 1 < nch) {
+      T *Pn = sm + ((c + 1) & 1) * BUF, *Qn = Pn + KC * CH_LDP;
+#pragma unroll
+      for (int u = 0; u < NPASS; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { Pn[(lk + e) * CH_LDP + lr + u * RPP] = MODE == 1 ? -pp[u][e] : pp[u][e]; Qn[(lk + e) * CH_LDP + lr + u * RPP] = pq[u][e]; }
+    }
+    __syncthreads();
+  }
+  if (MODE == 1 && fuse) { // block-uniform
+    T *L = sm; // the operand buffers are free: every wave passed the barrier that ends the K loop
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr * 64 + mi * 16 + M::row(lane, r), col = wc * 64 + ni * 16 + ccol;
+          L[row * CH_LP + col] = col <= row ? acc[mi][ni][r] : T(0);
+        }
+    chol_potrf_block<T>(L, Cg, ld, Linv_out + (size_t)ti * CH_NB * CH_NB, fail, false, 0);
+    return;
+  }
+  int ld2 = ld;
+  asm volatile("" : "+v"(ld2));
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld2 + wc * 64 + ni * 16 + ccol] = acc[mi][ni][r];
+}
+
+// permuted scatter of the upper 9x9 blocks of S (column-major blocks, block (i <= j)) into the lower triangle;
+// camcol[c] = first (padded, permuted) column of camera c
+template <typename T>
+__global__ __launch_bounds__(256) void k_sp_scatter(int64_t nnzb, const int *__restrict__ rowi, const int *__restrict__ coli, const int *__restrict__ camcol,
+                                                    const T *__restrict__ S, T *__restrict__ A, int ld) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= 81 * nnzb) return;
+  const int64_t q = e / 81;
+  const int w = (int)(e - 81 * q), c = w / 9, r = w - 9 * c; // S_q(r, c) = S(9 i + r, 9 j + c), i <= j
+  const int R = camcol[rowi[q]] + r, C = camcol[coli[q]] + c;
+  if (rowi[q] == coli[q]) { if (R >= C) A[(size_t)R * ld + C] = S[e]; } // diagonal block: its lower half
+  else if (R > C) A[(size_t)R * ld + C] = S[e];
+  else A[(size_t)C * ld + R] = S[e];
+}
+// zero the structurally non-zero lower tiles; padding columns get a unit diagonal
+template <typename T>
+__global__ __launch_bounds__(256) void k_sp_clear(T *__restrict__ A, int ld, const unsigned char *__restrict__ is_pad, const int *__restrict__ tiles) {
+  const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
+  T *Cg = A + (size_t)ti * CH_NB * ld + (size_t)tj * CH_NB;
+  for (int e = threadIdx.x; e < CH_NB * CH_NB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    Cg[(size_t)r * ld + c] = (ti == tj && r == c && is_pad[ti * CH_NB + r]) ? T(1) : T(0);
+  }
+}
+template <typename T> __global__ void k_sp_rhs(int npad, const int *__restrict__ src, const T *__restrict__ b, T *__restrict__ vb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npad) vb[i] = src[i] >= 0 ? b[src[i]] : T(0);
+}
+template <typename T> __global__ void k_sp_unpermute(int npad, const int *__restrict__ src, const T *__restrict__ vx, T *__restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npad && src[i] >= 0) x[src[i]] = vx[i];
+}
+// Substitution kernels.  A level's panels are cut into work ITEMS (panel k, a slice of <= SP_SLICE tiles of its row
+// list / column list), one workgroup per item: the long rows of the separator columns near the root (a hundred tiles)
+// are spread over many workgroups instead of one.  An item leaves its 128 partial sums in `partial`; the item that
+// arrives LAST at the panel's ticket adds them in item order (fixed order: reproducible) and finishes the panel.
+// Visibility across XCDs: write-through (agent-scope relaxed atomic) stores, drained, then a relaxed ticket; the last
+// arriver reads with agent-scope loads (cdna_hip_programming.md G16, form R1) — the same hand-off as grid_sum2.
+constexpr int SP_SLICE = 6;
+struct SpItems { const int *panel, *beg, *end, *first, *count; int base; }; // per item: panel, slice, first item / item count of its panel (absolute item ids); base = id of this launch's item 0
+template <typename T> __device__ __forceinline__ bool sp_last_arriver(T val, bool writer, T *__restrict__ partial, int item, int idx, unsigned *__restrict__ ticket, int panel, int count) {
+  __shared__ bool s_last;
+  if (writer) __hip_atomic_store(&partial[(size_t)item * CH_NB + idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tk = __hip_atomic_fetch_add(&ticket[panel], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = tk == (unsigned)count - 1;
+    if (s_last) __hip_atomic_store(&ticket[panel], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return s_last;
+}
+// forward: y_k = Linv_k (b_k - sum_{j in row(k)} L_kj y_j)
+template <typename T>
+__global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, int ld, const T *__restrict__ Linv, SpItems it, const int *__restrict__ rcols,
+                                                const T *__restrict__ b, T *__restrict__ y, T *__restrict__ partial, unsigned *__restrict__ ticket) {
+  __shared__ T bk[CH_NB];
+  const int item = blockIdx.x, k = it.panel[item], item_id = it.base + item;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  T tot[2] = {T(0), T(0)};
+  for (int e = it.beg[item]; e < it.end[item]; ++e) {
+    const int j = rcols[e];
+    const T y0 = y[j * CH_NB + lane], y1 = y[j * CH_NB + 64 + lane];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) tot[h] += rows16_dot<T>(A + (size_t)(k * CH_NB + wave * 32 + h * 16) * ld + (size_t)j * CH_NB, (size_t)ld, y0, y1, lane);
+  }
+  // lane L of (wave, h) holds the partial of row wave*32 + h*16 + (L >> 2)
+  bool last = true;
+  if (it.count[item] > 1) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if ((lane & 3) == 0) __hip_atomic_store(&partial[(size_t)item_id * CH_NB + wave * 32 + h * 16 + (lane >> 2)], tot[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = sp_last_arriver<T>(T(0), false, partial, item_id, 0, ticket, k, it.count[item]);
+    if (!last) return;
+    if (t < CH_NB) {
+      T s = T(0);
+      for (int q = it.first[item]; q < it.first[item] + it.count[item]; ++q) s += __hip_atomic_load(&partial[(size_t)q * CH_NB + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bk[t] = b[k * CH_NB + t] - s;
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if ((lane & 3) == 0) bk[wave * 32 + h * 16 + (lane >> 2)] = b[k * CH_NB + wave * 32 + h * 16 + (lane >> 2)] - tot[h];
+  }
+  __syncthreads();
+  const T b0 = bk[lane], b1 = bk[64 + lane];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r0 = wave * 32 + h * 16;
+    const T s = rows16_dot<T>(Linv + (size_t)k * CH_NB * CH_NB + r0 * CH_NB, CH_NB, b0, b1, lane);
+    if ((lane & 3) == 0) y[k * CH_NB + r0 + (lane >> 2)] = s;
+  }
+}
+// backward: x_k = Linv_k^T (y_k - sum_{i in col(k)} L_ik^T x_i)
+template <typename T>
+__global__ __launch_bounds__(256) void k_sp_bwd(const T *__restrict__ A, int ld, const T *__restrict__ Linv, SpItems it, const int *__restrict__ crows,
+                                                const T *__restrict__ y, T *__restrict__ x, T *__restrict__ partial, unsigned *__restrict__ ticket) {
+  __shared__ T v[CH_NB];
+  __shared__ T half[CH_NB];
+  const int item = blockIdx.x, k = it.panel[item], item_id = it.base + item;
+  const int t = threadIdx.x, c = t & 127, h = t >> 7;
+  T s = T(0);
+  for (int e = it.beg[item]; e < it.end[item]; ++e) {
+    const int i = crows[e];
+    const T *Lg = A + (size_t)(i * CH_NB + h * 64) * ld + (size_t)k * CH_NB + c;
+    const T *xg = x + i * CH_NB + h * 64;
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) s += Lg[(size_t)r * ld] * xg[r];
+  }
+  if (h == 1) half[c] = s;
+  __syncthreads();
+  s += half[c]; // valid for h == 0
+  if (it.count[item] > 1) {
+    if (!sp_last_arriver<T>(s, h == 0, partial, item_id, c, ticket, k, it.count[item])) return;
+    if (h == 0) {
+      s = T(0);
+      for (int q = it.first[item]; q < it.first[item] + it.count[item]; ++q) s += __hip_atomic_load(&partial[(size_t)q * CH_NB + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (h == 0) v[c] = y[k * CH_NB + c] - s;
+  __syncthreads();
+  const T *Lk = Linv + (size_t)k * CH_NB * CH_NB;
+  T s2 = T(0);
+#pragma unroll 8
+  for (int r = h * 64; r < h * 64 + 64; ++r) s2 += Lk[r * CH_NB + c] * v[r];
+  __syncthreads();
+  if (h == 1) half[c] = s2;
+  __syncthreads();
+  if (h == 0) x[k * CH_NB + c] = s2 + half[c];
+}
+
+template <typename T> struct SparseChol {
+  hipStream_t stream = nullptr;
+  int n = 0, npad = 0, nt = 0, nlevels = 0, nsuper = 0;
+  int64_t factor_tiles = 0;       // structurally non-zero lower tiles after fill
+  double flops = 0;
+  DevBuf<T> A, Linv, vb, vy, vx;
+  DevBuf<int> d_camcol, d_src, d_nz, d_fail, d_panels, d_trsm, d_upd, d_kptr, d_klist, d_rptr, d_rcols, d_cptr, d_crows;
+  DevBuf<unsigned char> d_pad;
+  DevBuf<int> d_itf[5], d_itb[5];
+  DevBuf<T> partial;
+  DevBuf<unsigned> ticket;
+  std::vector<int> lvl_fitem_off, lvl_bitem_off;
+  SpItems items(DevBuf<int> (&d)[5], int off) const { return SpItems{d[0].p + off, d[1].p + off, d[2].p + off, d[3].p + off, d[4].p + off, off}; }
+  std::vector<int> lvl_panel_off, lvl_trsm_off, lvl_upd_off; // per level offsets into d_panels / d_trsm (pairs) / d_upd (pairs)
+  std::vector<int> h_kptr;
+  int nz_tiles = 0;
+  int *h_fail = nullptr;
+  CholProfSink *sink = nullptr;
+  bool attrs_set = false;
+  static constexpr int LEAF = 56; // cameras per leaf supernode: 504 columns = 4 tiles (8 padding columns)
+  bool fuse_potrf = !(getenv("GR_SPCHOL_FUSE") && atoi(getenv("GR_SPCHOL_FUSE")) == 0); // A/B knob
+
+  SparseChol() = default;
+  SparseChol(const SparseChol &) = delete;
+  ~SparseChol() { if (h_fail) (void)hipHostFree(h_fail); }
+
+  // nested dissection of the camera graph: returns the supernodes (camera lists) in elimination order
+  static std::vector<std::vector<int>> nested_dissection(int Nc, const std::vector<std::vector<int>> &adj) {
+    std::vector<std::vector<int>> out;
+    std::vector<int> mark(Nc, -1), dist(Nc, 0);
+    int stamp = 0;
+    // bfs inside `nodes` (mark == stamp) from `root`; returns the visit order, dist[] = level
+    auto bfs = [&](int root, std::vector<int> &order) {
+      order.clear();
+      order.push_back(root); mark[root] = -2 - stamp; dist[root] = 0; // visited within this stamp
+      for (size_t h = 0; h < order.size(); ++h) {
+        const int v = order[h];
+        for (int u : adj[v]) if (mark[u] == stamp) { mark[u] = -2 - stamp; dist[u] = dist[v] + 1; order.push_back(u); }
+      }
+    };
+    struct Job { std::vector<int> nodes; bool emit_only; };
+    // explicit stack: (nodes) -> split into A, B, separator; order = nd(A), nd(B), separator
+    std::vector<Job> stack;
+    {
+      std::vector<int> all(Nc);
+      std::iota(all.begin(), all.end(), 0);
+      stack.push_back(Job{std::move(all), false});
+    }
+    while (!stack.empty()) {
+      Job job = std::move(stack.back());
+      stack.pop_back();
+      auto &nodes = job.nodes;
+      if (nodes.empty()) continue;
+      if (job.emit_only || (int)nodes.size() <= LEAF) { out.push_back(std::move(nodes)); continue; }
+      ++stamp;
+      for (int v : nodes) mark[v] = stamp;
+      std::vector<int> order, order2;
+      bfs(nodes[0], order);
+      if (order.size() < nodes.size()) { // disconnected inside `nodes`: the reached component and the rest are independent
+        std::vector<int> rest;
+        for (int v : nodes) if (mark[v] == stamp) rest.push_back(v);
+        stack.push_back(Job{std::move(rest), false});
+        stack.push_back(Job{std::move(order), false});
+        continue;
+      }
+      // pseudo-peripheral start: restart from the farthest node once
+      const int far = order.back();
+      for (int v : nodes) mark[v] = stamp;
+      bfs(far, order2);
+      const int depth = dist[order2.back()];
+      if (depth < 2) { out.push_back(std::move(nodes)); continue; } // does not dissect: one dense supernode
+      // separator = the level at which half of the nodes have been passed (kept off the two end levels)
+      std::vector<int> count(depth + 1, 0);
+      for (int v : order2) count[dist[v]]++;
+      int s = 1, acc = count[0];
+      while (s < depth - 1 && acc + count[s] < (int)nodes.size() / 2) acc += count[s++];
+      std::vector<int> Apart, Bpart, Sep;
+      for (int v : order2) (dist[v] < s ? Apart : dist[v] == s ? Sep : Bpart).push_back(v);
+      // LIFO: pushed last = processed first; wanted output order: nd(A), nd(B), Sep
+      stack.push_back(Job{std::move(Sep), true});
+      stack.push_back(Job{std::move(Bpart), false});
+      stack.push_back(Job{std::move(Apart), false});
+    }
+    // the explicit stack emits A-subtree, B-subtree, separator in that order only if the separator is emitted after
+    // BOTH subtrees are fully done, which the LIFO order above guarantees (Sep sits below A and B on the stack)
+    return out;
+  }
+
+  // Nc cameras, upper block list (rowi <= coli) of S.  Returns false when the graph does not dissect (one supernode).
+  bool set_structure(int Nc, const std::vector<int> &rowi, const std::vector<int> &coli, hipStream_t s) {
+    stream = s;
+    n = 9 * Nc;
+    std::vector<std::vector<int>> adj(Nc);
+    for (size_t q = 0; q < rowi.size(); ++q) if (rowi[q] != coli[q]) { adj[rowi[q]].push_back(coli[q]); adj[coli[q]].push_back(rowi[q]); }
+    const auto supers = nested_dissection(Nc, adj);
+    nsuper = (int)supers.size();
+    if (nsuper <= 1) return false;
+    // padded permuted columns
+    std::vector<int> camcol(Nc, 0), src;
+    std::vector<unsigned char> pad;
+    for (const auto &sn : supers) {
+      for (int c : sn) { camcol[c] = (int)src.size(); for (int k = 0; k < 9; ++k) { src.push_back(9 * c + k); pad.push_back(0); } }
+      while (src.size() % CH_NB) { src.push_back(-1); pad.push_back(1); }
+    }
+    npad = (int)src.size(); nt = npad / CH_NB;
+    // tile structure + fill + elimination tree
+    std::vector<char> tz((size_t)nt * nt, 0);
+    auto nz = [&](int i, int j) -> char & { return tz[(size_t)i * nt + j]; };
+    for (int i = 0; i < nt; ++i) nz(i, i) = 1;
+    for (size_t q = 0; q < rowi.size(); ++q) {
+      const int a0 = camcol[rowi[q]] / CH_NB, a1 = (camcol[rowi[q]] + 8) / CH_NB, b0 = camcol[coli[q]] / CH_NB, b1 = (camcol[coli[q]] + 8) / CH_NB;
+      for (int a = a0; a <= a1; ++a)
+        for (int b = b0; b <= b1; ++b) nz(std::max(a, b), std::min(a, b)) = 1;
+    }
+    std::vector<std::vector<int>> U(nt);
+    std::vector<int> level(nt, 0);
+    factor_tiles = 0; flops = 0;
+    for (int j = 0; j < nt; ++j) {
+      for (int i = j + 1; i < nt; ++i) if (nz(i, j)) U[j].push_back(i);
+      for (size_t x = 0; x < U[j].size(); ++x)
+        for (size_t y = 0; y <= x; ++y) nz(U[j][x], U[j][y]) = 1;
+      if (!U[j].empty()) level[U[j][0]] = std::max(level[U[j][0]], level[j] + 1); // parent = first sub-diagonal tile
+      factor_tiles += 1 + (int64_t)U[j].size();
+      flops += (2.0 / 3.0 + 2.0 * U[j].size() + 1.0 * U[j].size() * (U[j].size() + 1)) * CH_NB * CH_NB * CH_NB; // potrf + inverse, trsm, updates
+    }
+    // a column must also wait for every column that UPDATES it, not only its tree children: level = 1 + max over the
+    // columns k with nz(j, k) (all of them are its descendants, so this is the same number; computed explicitly)
+    for (int j = 0; j < nt; ++j)
+      for (int i : U[j]) level[i] = std::max(level[i], level[j] + 1);
+    nlevels = 1 + *std::max_element(level.begin(), level.end());
+    std::vector<std::vector<int>> by_level(nlevels);
+    for (int j = 0; j < nt; ++j) by_level[level[j]].push_back(j);
+    std::vector<int> h_panels, h_trsm, h_upd, h_klist, h_nz;
+    h_kptr.assign(1, 0);
+    lvl_panel_off.assign(1, 0); lvl_trsm_off.assign(1, 0); lvl_upd_off.assign(1, 0);
+    for (int l = 0; l < nlevels; ++l) {
+      std::map<std::pair<int, int>, std::vector<int>> targets;
+      for (int k : by_level[l]) {
+        h_panels.push_back(k);
+        for (int i : U[k]) { h_trsm.push_back(i); h_trsm.push_back(k); }
+        for (size_t x = 0; x < U[k].size(); ++x)
+          for (size_t y = 0; y <= x; ++y) targets[{U[k][x], U[k][y]}].push_back(k);
+      }
+      // the diagonal tiles of the NEXT level lead the list (their workgroups also factorise: longest, scheduled first)
+      for (int pass = 0; pass < 2; ++pass)
+        for (auto &tg : targets) {
+          const bool diag_next = fuse_potrf && tg.first.first == tg.first.second && level[tg.first.first] == l + 1;
+          if (diag_next != (pass == 0)) continue;
+          h_upd.push_back(tg.first.first | (diag_next ? SP_FUSE_BIT : 0)); h_upd.push_back(tg.first.second);
+          for (int k : tg.second) h_klist.push_back(k);
+          h_kptr.push_back((int)h_klist.size());
+        }
+      lvl_panel_off.push_back((int)h_panels.size());
+      lvl_trsm_off.push_back((int)(h_trsm.size() / 2));
+      lvl_upd_off.push_back((int)(h_upd.size() / 2));
+    }
+    // row structure (forward substitution) and column structure (backward), cut into items of <= SP_SLICE tiles
+    std::vector<int> h_rptr(nt + 1, 0), h_rcols, h_cptr(nt + 1, 0), h_crows;
+    for (int k = 0; k < nt; ++k) {
+      for (int j = 0; j < k; ++j) if (nz(k, j)) h_rcols.push_back(j);
+      h_rptr[k + 1] = (int)h_rcols.size();
+      for (int i : U[k]) h_crows.push_back(i);
+      h_cptr[k + 1] = (int)h_crows.size();
+    }
+    std::vector<int> it_f[5], it_b[5]; // panel, beg, end, first, count
+    lvl_fitem_off.assign(1, 0); lvl_bitem_off.assign(1, 0);
+    auto cut = [&](std::vector<int> (&it)[5], int k, int beg, int end) {
+      const int cnt = std::max(1, (end - beg + SP_SLICE - 1) / SP_SLICE), first = (int)it[0].size();
+      for (int q = 0; q < cnt; ++q) {
+        it[0].push_back(k); it[1].push_back(std::min(end, beg + q * SP_SLICE)); it[2].push_back(std::min(end, beg + (q + 1) * SP_SLICE));
+        it[3].push_back(first); it[4].push_back(cnt);
+      }
+    };
+    for (int l = 0; l < nlevels; ++l) {
+      for (int k : by_level[l]) { cut(it_f, k, h_rptr[k], h_rptr[k + 1]); cut(it_b, k, h_cptr[k], h_cptr[k + 1]); }
+      lvl_fitem_off.push_back((int)it_f[0].size()); lvl_bitem_off.push_back((int)it_b[0].size());
+    }
+    for (int q = 0; q < 5; ++q) { d_itf[q].upload(it_f[q], stream); d_itb[q].upload(it_b[q], stream); }
+    partial.alloc((size_t)std::max(it_f[0].size(), it_b[0].size()) * CH_NB);
+    ticket.alloc(nt); ticket.zero(stream);
+    for (int i = 0; i < nt; ++i)
+      for (int j = 0; j <= i; ++j) if (nz(i, j)) { h_nz.push_back(i); h_nz.push_back(j); }
+    nz_tiles = (int)(h_nz.size() / 2);
+    auto up = [&](DevBuf<int> &d, std::vector<int> &h) { if (h.empty()) h.push_back(0); d.upload(h, stream); };
+    up(d_panels, h_panels); up(d_trsm, h_trsm); up(d_upd, h_upd); up(d_klist, h_klist); up(d_nz, h_nz);
+    d_kptr.upload(h_kptr, stream); d_rptr.upload(h_rptr, stream); up(d_rcols, h_rcols); d_cptr.upload(h_cptr, stream); up(d_crows, h_crows);
+    d_camcol.upload(camcol, stream); d_src.upload(src, stream); d_pad.upload(pad, stream);
+    A.alloc((size_t)npad * npad); Linv.alloc((size_t)nt * CH_NB * CH_NB);
+    vb.alloc(npad); vy.alloc(npad); vx.alloc(npad);
+    d_fail.alloc(1);
+    if (!h_fail) GR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_fail), sizeof(int), hipHostMallocDefault));
+    if (!attrs_set) {
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sp_gemm<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sp_gemm<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(chol_gemm_lds(sizeof(T)), chol_potrf_lds(sizeof(T)))));
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sp_potrf<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_potrf_lds(sizeof(T))));
+      attrs_set = true;
+    }
+    GR_HIP(hipStreamSynchronize(stream));
+    return true;
+  }
+  size_t bytes() const { return (size_t)npad * npad * sizeof(T); }
+
+  struct Sc {
+    CholProfSink *s;
+    Sc(CholProfSink *s_, const char *nm, double by, double fl) : s(s_) { if (s) s->begin(nm, by, fl); }
+    ~Sc() { if (s) s->end(); }
+  };
+  // S (upper 9x9 blocks) -> permuted dense lower triangle
+  void load(int64_t nnzb, const int *rowi, const int *coli, const T *S) {
+    k_sp_clear<T><<<nz_tiles, 256, 0, stream>>>(A.p, npad, d_pad.p, d_nz.p);
+    k_sp_scatter<T><<<(unsigned)((81 * nnzb + 255) / 256), 256, 0, stream>>>(nnzb, rowi, coli, d_camcol.p, S, A.p, npad);
+  }
+  void factor() {
+    GR_HIP(hipMemsetAsync(d_fail.p, 0, sizeof(int), stream));
+    const size_t lds_g = chol_gemm_lds(sizeof(T)), lds_p = chol_potrf_lds(sizeof(T));
+    const double tb = (double)CH_NB * CH_NB * sizeof(T), tf = 2.0 * CH_NB * CH_NB * CH_NB;
+    for (int l = 0; l < nlevels; ++l) {
+      const int np_ = lvl_panel_off[l + 1] - lvl_panel_off[l], ntr = lvl_trsm_off[l + 1] - lvl_trsm_off[l], nup = lvl_upd_off[l + 1] - lvl_upd_off[l];
+      if (l == 0 || !fuse_potrf) { // deeper levels: factorised by the previous level's update launch
+        Sc sc(sink, "spchol_potrf", 3.0 * np_ * tb, np_ * tf / 3);
+        k_sp_potrf<T><<<np_, CH_PT, lds_p, stream>>>(A.p, npad, d_panels.p + lvl_panel_off[l], Linv.p, d_fail.p);
+      }
+      if (ntr) {
+        Sc sc(sink, "spchol_trsm", 3.0 * ntr * tb, ntr * tf);
+        k_sp_gemm<T, 0><<<ntr, 256, lds_g, stream>>>(A.p, npad, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], nullptr, nullptr, Linv.p);
+      }
+      if (nup) {
+        const int nk = h_kptr[lvl_upd_off[l + 1]] - h_kptr[lvl_upd_off[l]];
+        Sc sc(sink, "spchol_update", (2.0 * nup + 2.0 * nk) * tb, nk * tf);
+        k_sp_gemm<T, 1><<<nup, 256, std::max(lds_g, lds_p), stream>>>(A.p, npad, d_upd.p + 2 * (size_t)lvl_upd_off[l], d_kptr.p + lvl_upd_off[l], d_klist.p, nullptr, Linv.p, d_fail.p);
+      }
+    }
+  }
+  // b, x: device vectors of length n in the CALLER's (camera-major) order (x may alias b)
+  void solve(const T *b, T *x) {
+    Sc sc(sink, "spchol_solve", 2.0 * (double)factor_tiles * CH_NB * CH_NB * sizeof(T), 4.0 * (double)factor_tiles * CH_NB * CH_NB);
+    k_sp_rhs<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, b, vb.p);
+    for (int l = 0; l < nlevels; ++l)
+      k_sp_fwd<T><<<lvl_fitem_off[l + 1] - lvl_fitem_off[l], 256, 0, stream>>>(A.p, npad, Linv.p, items(d_itf, lvl_fitem_off[l]), d_rcols.p, vb.p, vy.p, partial.p, ticket.p);
+    for (int l = nlevels - 1; l >= 0; --l)
+      k_sp_bwd<T><<<lvl_bitem_off[l + 1] - lvl_bitem_off[l], 256, 0, stream>>>(A.p, npad, Linv.p, items(d_itb, lvl_bitem_off[l]), d_crows.p, vy.p, vx.p, partial.p, ticket.p);
+    k_sp_unpermute<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, vx.p, x);
+  }
+  bool ok() {
+    GR_HIP(hipMemcpyAsync(h_fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    GR_HIP(hipStreamSynchronize(stream));
+    return *h_fail == 0;
+  }
+};
+
+} // namespace gr

@@ -64,7 +64,10 @@ typedef enum {
   GR_GET_S = 5,        /* 81 nnzb  Schur complement blocks (upper, column-major block order)     */
   GR_GET_B_SCHUR = 6,  /* 9 Nc     b_S                              schur.hpp:901-920            */
   GR_GET_HLL_INV = 7,  /* 9 Np     (Hll + damping)^-1               schur.hpp:1067-1114          */
-  GR_GET_RESIDUALS = 8 /* 2 No     residuals, INPUT observation order ops/error.hpp:253          */
+  GR_GET_RESIDUALS = 8,/* 2 No     residuals, INPUT observation order ops/error.hpp:253          */
+  GR_GET_H = 9         /* 81 Nc + 27 No + 9 Np   the Hessian in the reference's value layout: upper block-CSC, block columns =
+                          cameras then points (caller's order), blocks sorted by row inside a column with the diagonal block
+                          last, every block column-major (hessian.hpp:257-288, :123-126); structure: gr_bal_hessian_structure */
 } gr_bal_array;
 
 typedef struct gr_bal_problem gr_bal_problem; /* opaque */
@@ -165,6 +168,15 @@ gr_status gr_bal_schur_matvec(gr_bal_problem *p, const void *x, void *y);
 gr_status gr_bal_landmark_update(gr_bal_problem *p, const void *xp, void *xl);
 /* block structure of S: colptr (Nc+1) and rowidx (nnzb) int64 host arrays; pass NULL to size */
 gr_status gr_bal_schur_structure(gr_bal_problem *p, int64_t *nnzb, int64_t *colptr, int64_t *rowidx);
+
+/* Hessian::build_structure (hessian.hpp:257-288) + csc::build_block_csc_indices (csc_utils.hpp:16-50): block-CSC of the
+ * upper Hessian: colptr (Nc + Np + 1), rowidx and value offsets (nblocks = Nc + No + Np each), int64 host arrays; NULL to size */
+gr_status gr_bal_hessian_structure(gr_bal_problem *p, int64_t *nblocks, int64_t *colptr, int64_t *rowidx, int64_t *offsets);
+/* Hessian::build_csc_structure + update_csc_values / SchurComplement::build_csc_structure + update_csc_values
+ * (hessian.hpp:310-324, schur.hpp:264-277, csc_utils.hpp:74-193): scalar CSC of the UPPER triangle of H (which = 0, n columns)
+ * or of S with the current damping (which = 1, 9 Nc columns; gr_bal_schur_update_values first).  indptr (columns + 1) and
+ * indices (nnz): int64 host arrays; values: nnz scalars of the problem's dtype (host).  Pass NULL arrays to get *nnz. */
+gr_status gr_bal_export_csc(gr_bal_problem *p, int which, int64_t *nnz, int64_t *indptr, int64_t *indices, void *values);
 
 /* copy one array (gr_bal_array) to `out` (host or device); *count receives its length */
 gr_status gr_bal_get(gr_bal_problem *p, gr_bal_array which, void *out, int64_t *count);

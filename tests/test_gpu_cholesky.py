@@ -103,3 +103,88 @@ def test_levenberg_marquardt_trace_dense_schur(oracle_mod, name, dtype, rtol):
     assert ct_g[-1] < 0.1 * ct_g[0]
     assert st["pcg_iterations"] == 0
     gpu.close()
+
+
+# ---- sparse direct path (sparse_chol.hpp): nested dissection + level-scheduled tile Cholesky -----------------------
+# (Nc, Np, No, window, seed): camera graphs that dissect (banded), in sizes where supernodes end inside / on tile edges
+SPARSE_SHAPES = [(120, 3000, 14000, 6, 41), (300, 6000, 30000, 10, 42), (513, 9000, 45000, 16, 43)]
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-9), (np.float32, 5e-3)])
+@pytest.mark.parametrize("shape", SPARSE_SHAPES, ids=lambda s: "x".join(map(str, s[:3])))
+def test_sparse_cholesky_matches_dense_and_oracle(oracle_mod, monkeypatch, shape, dtype, tol):
+    """GR_SPARSE_CHOL=1 (nested dissection, levels) and =0 (dense tile Cholesky) solve the same reduced system;
+    fp64 also against the oracle's simplicial LDL^T of S (eigen_schur.hpp:71-108)."""
+    Nc, Np, No, window, seed = shape
+    prob = synth.make_problem(Nc, Np, No, seed=seed, window=window)
+    dx = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GR_SPARSE_CHOL", mode)
+        g = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+        g.solver_update_structure(ga.SOLVER_DENSE_SCHUR)
+        g.linearize()
+        g.solver_update_values(ga.SOLVER_DENSE_SCHUR)
+        g.solver_set_damping(ga.SOLVER_DENSE_SCHUR, 1e-4)
+        dx[mode], _ = g.solver_solve(ga.SOLVER_DENSE_SCHUR)
+        again, _ = g.solver_solve(ga.SOLVER_DENSE_SCHUR)
+        # (S itself is assembled with atomics where several work items meet in one block: same solve, last-bit differences)
+        assert relerr(again, dx[mode]) < (1e-12 if dtype == np.float64 else 2e-3)  # fp32: cond(S) ~ 1e3 amplifies the last bits of S
+        g.close()
+    assert relerr(dx["1"], dx["0"]) < tol
+    if dtype == np.float64:
+        ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+        ref.linearize()
+        ref.solver_update_values(oracle_mod.SOLVER_LDLT_SCHUR)
+        ref.solver_set_damping(oracle_mod.SOLVER_LDLT_SCHUR, 1e-4)
+        dx_r, _ = ref.solver_solve(oracle_mod.SOLVER_LDLT_SCHUR)
+        assert relerr(dx["1"], dx_r) < 1e-9
+
+
+def test_sparse_cholesky_lm_trace(oracle_mod, monkeypatch):
+    monkeypatch.setenv("GR_SPARSE_CHOL", "1")
+    prob = synth.make_problem(300, 6000, 30000, seed=42, window=10)
+    g = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    ct, lt, st = g.levenberg_marquardt(solver=ga.SOLVER_DENSE_SCHUR, iterations=6)
+    g.close()
+    ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    ct_r, lt_r, st_r = ref.levenberg_marquardt(solver=oracle_mod.SOLVER_LDLT_SCHUR, iterations=6)
+    assert st["accepted"] == st_r["accepted"]
+    assert np.max(np.abs(ct - ct_r) / ct_r) < 1e-9
+
+
+# ---- Hessian / Schur exports in the reference's layouts (hessian.hpp:257-324, csc_utils.hpp:16-193) --------------------
+@pytest.mark.parametrize("name", ["schur-2x3", "mini-50"])
+def test_hessian_block_csc_and_scalar_csc_exports(oracle_mod, name):
+    prob, gpu, ref = make_pair(oracle_mod, name, np.float64)
+    gpu.solver_update_structure(ga.SOLVER_PCG_SCHUR)
+    gpu.linearize()
+    gpu.solver_update_values(ga.SOLVER_PCG_SCHUR)
+    ref.linearize()
+    ref.hessian_update()
+    values, colptr, rowidx, offsets = ref.export_hessian()
+    cp, ri, of = gpu.hessian_structure()
+    assert np.array_equal(cp, colptr) and np.array_equal(ri, rowidx) and np.array_equal(of, offsets)  # index work: bit-exact
+    assert relerr(gpu.get("H"), values) < 1e-10
+    p, i, x = ref.export_csc("H")
+    gp, gi, gx = gpu.export_csc("H")
+    assert np.array_equal(gp, p) and np.array_equal(gi, i)
+    assert relerr(gx, x) < 1e-10
+    # S with damping, as the direct solvers hand it to Eigen / cuDSS (eigen_schur.hpp:78-98)
+    mu = 1e-4
+    gpu.solver_set_damping(ga.SOLVER_PCG_SCHUR, mu)
+    gpu.schur_update_values()
+    ref.apply_damping(mu)
+    ref.schur_update()
+    p, i, x = ref.export_csc("S")
+    gp, gi, gx = gpu.export_csc("S")
+    assert np.array_equal(gp, p) and np.array_equal(gi, i)
+    assert relerr(gx, x) < 1e-9
+    # the exported CSC is the matrix the solver inverts: scipy's sparse direct solve of it reproduces the engine's step
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    Su = sp.csc_matrix((gx, gi, gp), shape=(9 * gpu.Nc, 9 * gpu.Nc))
+    Sfull = Su + sp.triu(Su, 1).T
+    xp = spla.spsolve(Sfull.tocsc(), gpu.get("b_schur"))
+    dx, _ = gpu.solver_solve(ga.SOLVER_DENSE_SCHUR)
+    assert relerr(dx[:9 * gpu.Nc], xp) < 1e-8
+    gpu.close()
