@@ -94,6 +94,21 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<int> boundary_flag;
   DevBuf<unsigned> ticket;
   DevBuf<int> cam_seg_ptr;
+  // Observation order of the per-observation kernels.  Plain: the camera-major order above.  TILED (Venice / Final
+  // shapes, build_tiled_order): (point tile, camera, point) with point tiles of equal observation count sized for an
+  // XCD's L2 and dealt round-robin to the 8 XCDs, so that the point gathers and the g3 / g9 scatters of a whole
+  // XCD fall into one L2-resident window instead of costing a 128-byte line each.  Segments = (64-observation block,
+  // camera run) pairs: blk_seg[b] = flat id of block b's first segment (the runs that start inside b follow it),
+  // seg_slot[flat id] = its slot among its camera's segments, cam_seg_ptr[c] = first slot of camera c.
+  bool tiled = false;
+  int n_ptiles = 0;
+  DevBuf<int> t_cam, t_pt, t_pos, blk_seg, seg_slot;
+  DevBuf<T> t_obs;
+  const int *o_cam() const { return tiled ? t_cam.p : cam_cm.p; }
+  const int *o_pt() const { return tiled ? t_pt.p : pt_cm.p; }
+  const int *o_pos() const { return tiled ? t_pos.p : pos_cm.p; }
+  const T *o_obs() const { return tiled ? t_obs.p : obs_cm.p; }
+  int o_ntiles() const { return tiled ? -nb_pm : nb_pm; }
   // multi-GPU: landmark shard of a larger problem (comm != null), camera rows all-reduced
   std::unique_ptr<Comm> comm;
   bool shard = false;
@@ -314,17 +329,97 @@ template <typename T> struct Engine final : EngineBase {
     }
     nch = (int)h_chunk_cam.size();
     h_chunk_beg.push_back((int)No);
-    // (wave, camera) segments of the flat camera-major kernels
-    h_cam_seg_ptr.assign(Nc + 1, 0);
-    for (int64_t c = 0; c < Nc; ++c)
-      h_cam_seg_ptr[c + 1] = h_cam_seg_ptr[c] + (h_cam_ptr[c + 1] == h_cam_ptr[c] ? 0 : ((h_cam_ptr[c + 1] - 1) >> 6) - (h_cam_ptr[c] >> 6) + 1);
-    nseg = h_cam_seg_ptr[Nc];
-    cam_seg_ptr.upload(h_cam_seg_ptr, stream);
+    build_segments(h_cam_cm, /*ptiles=*/0);
     chunk_cam.upload(h_chunk_cam, stream); chunk_beg.upload(h_chunk_beg, stream); cam_chunk_ptr.upload(h_cam_chunk_ptr, stream);
     pt_ptr.upload(h_pt_ptr, stream); cam_pm.upload(h_cam_pm, stream); pt_pm.upload(h_pt_pm, stream);
     cam_ptr.upload(h_cam_ptr, stream); pt_cm.upload(h_pt_cm, stream); pos_cm.upload(h_pos_cm, stream); cam_cm.upload(h_cam_cm, stream);
     obs_pm.upload(h_obs_pm, stream); obs_cm.upload(h_obs_cm, stream);
     GR_HIP(hipStreamSynchronize(stream));
+  }
+
+  // (64-observation block, camera) segments of an observation order given by its camera stream
+  void build_segments(const std::vector<int> &cam_of, int ptiles) {
+    const int64_t nblk = (No + 63) / 64;
+    std::vector<int> h_blk_seg(4 * (size_t)cdiv(No, TPB) + 8, 0), seg_cam; // padded: tail waves of the last tile read their entry too
+    for (int64_t b = 0; b < nblk; ++b) {
+      h_blk_seg[b] = (int)seg_cam.size();
+      const int64_t j0 = 64 * b, j1 = std::min<int64_t>(No, j0 + 64);
+      // one segment per DISTINCT camera of the block, in order of first appearance: exactly what the kernels' leader loop
+      // does (a block that crosses a point-tile boundary can hold two runs of one camera: they are one reduction)
+      const size_t first = seg_cam.size();
+      for (int64_t j = j0; j < j1; ++j) {
+        bool seen = false;
+        for (size_t q = first; q < seg_cam.size() && !seen; ++q) seen = seg_cam[q] == cam_of[j];
+        if (!seen) seg_cam.push_back(cam_of[j]);
+      }
+    }
+    nseg = (int)seg_cam.size();
+    h_cam_seg_ptr.assign(Nc + 1, 0);
+    for (int c : seg_cam) h_cam_seg_ptr[c + 1]++;
+    for (int64_t c = 0; c < Nc; ++c) h_cam_seg_ptr[c + 1] += h_cam_seg_ptr[c];
+    std::vector<int> wpos(h_cam_seg_ptr.begin(), h_cam_seg_ptr.end() - 1), h_seg_slot(std::max(nseg, 1));
+    for (int q = 0; q < nseg; ++q) h_seg_slot[q] = wpos[seg_cam[q]]++; // flat order inside a camera = ascending blocks: a fixed order
+    cam_seg_ptr.upload(h_cam_seg_ptr, stream); blk_seg.upload(h_blk_seg, stream); seg_slot.upload(h_seg_slot, stream);
+    n_ptiles = ptiles;
+  }
+  // Point-tiled observation order for graphs whose point gathers miss L2 (see the members above).  K point tiles
+  // (a multiple of 8) of equal observation count; order key (tile % 8, tile / 8, camera, point): XCD x's eighth of the
+  // list = its own tiles, one after the other.
+  void build_tiled_order(int K) {
+    std::vector<int> tile_of_pt(Np);
+    for (int64_t l = 0; l < Np; ++l) tile_of_pt[l] = (int)std::min<int64_t>(K - 1, (int64_t)h_pt_ptr[l] * K / No);
+    auto key_tile = [&](int t) { return (t % 8) * ((K + 7) / 8) + t / 8; };
+    const int KT = 8 * ((K + 7) / 8);
+    // stable counting sort of the pm order (point, camera) by (tile key, camera): points ascend inside a (tile, camera) run
+    std::vector<int64_t> cnt((size_t)KT * Nc + 1, 0);
+    for (int64_t a = 0; a < No; ++a) cnt[(size_t)key_tile(tile_of_pt[h_pt_pm[a]]) * Nc + h_cam_pm[a] + 1]++;
+    for (size_t q = 0; q + 1 < cnt.size(); ++q) cnt[q + 1] += cnt[q];
+    std::vector<int> h_cam(No), h_pt(No), h_pos(No);
+    std::vector<T> h_obs(2 * (size_t)No), obs_pm_h = obs_pm.download(stream);
+    for (int64_t a = 0; a < No; ++a) {
+      const int64_t j = cnt[(size_t)key_tile(tile_of_pt[h_pt_pm[a]]) * Nc + h_cam_pm[a]]++;
+      h_cam[j] = h_cam_pm[a]; h_pt[j] = h_pt_pm[a]; h_pos[j] = (int)a;
+      h_obs[2 * (size_t)j] = obs_pm_h[2 * (size_t)a]; h_obs[2 * (size_t)j + 1] = obs_pm_h[2 * (size_t)a + 1];
+    }
+    t_cam.upload(h_cam, stream); t_pt.upload(h_pt, stream); t_pos.upload(h_pos, stream); t_obs.upload(h_obs, stream);
+    build_segments(h_cam, K);
+    cam_partial.alloc(54 * (size_t)nseg); op_partial.alloc(9 * (size_t)nseg);
+    tiled = true;
+    GR_HIP(hipStreamSynchronize(stream));
+  }
+  void untile() {
+    if (!tiled) return;
+    tiled = false;
+    std::vector<int> h_cam_cm = cam_cm.download(stream);
+    build_segments(h_cam_cm, 0);
+    cam_partial.alloc(54 * (size_t)nseg); op_partial.alloc(9 * (size_t)nseg);
+  }
+  // decided once per problem, by timing: GR_PTILES = number of point tiles (0 = plain order) forces it
+  bool tiling_tuned = false;
+  void tune_tiling() {
+    if (tiling_tuned) return;
+    tiling_tuned = true;
+    const size_t per_point = (size_t)(6 * sizeof(T) + 3 * sizeof(T) * (double)No / (double)Np); // X + direction + this point's g3 slots
+    int K = 0;
+    if (const char *e = getenv("GR_PTILES")) K = atoi(e);
+    else {
+      if ((size_t)Np * per_point < ((size_t)24 << 20)) return; // the whole working set sits in the L2s as it is
+      // tiles small enough for an XCD's L2 (3 MB of points + scatter slots each), but not so many that a camera's run inside
+      // a tile drops below ~64 observations (a wave would straddle several cameras; measured on Final-13682: 304 tiles run
+      // the linearisation 2x slower than 32)
+      const int k_l2 = cdiv((size_t)Np * per_point, (size_t)(3u << 20)), k_run = (int)std::max<int64_t>(8, No / std::max<int64_t>(1, Nc * 64));
+      K = std::min(k_l2, k_run);
+    }
+    if (K <= 0) return;
+    K = std::max(8, (K + 7) / 8 * 8);
+    const bool forced = getenv("GR_PTILES") != nullptr;
+    const double t_plain = forced ? 0.0 : diag_time(0, 0, 5) + diag_time(1, 0, 5);
+    build_tiled_order(K);
+    if (!forced) {
+      const double t_tiled = diag_time(0, 0, 5) + diag_time(1, 0, 5);
+      if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] operator + linearise: %.1f us plain order, %.1f us with %d point tiles -> %s\n", t_plain, t_tiled, K, t_tiled < 0.95 * t_plain ? "tiled" : "plain");
+      if (!(t_tiled < 0.95 * t_plain)) untile();
+    }
   }
 
   // SchurComplement::build_structure (schur.hpp:194-225).  The reference walks
@@ -550,9 +645,9 @@ template <typename T> struct Engine final : EngineBase {
       const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
       Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)));
       if (write_hcp) {
-        if (jac32) { k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); } else { k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); }
+        if (jac32) { k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); } else { k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); }
       } else {
-        if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate); } else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate); }
+        if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate); } else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate); }
     }
       }
     {
@@ -586,7 +681,7 @@ template <typename T> struct Engine final : EngineBase {
   int chi2_async(T *res_out, const T *dx, double mu) {
     const int seq = ++seq_counter;
     Scope sc(this, "chi2", No * (2 * w() + 8) + (24.0 * Nc + 3.0 * Np) * w() + (dx ? 3.0 * n * w() : 0.0), No * 40.0);
-    k_chi2<T><<<grid_chi2, TPB, 0, stream>>>((int)No, (unsigned)n, (unsigned)pose_dim, cam_weight(), cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, comm ? nullptr : h_res, h_seq, seq, res_out);
+    k_chi2<T><<<grid_chi2, TPB, 0, stream>>>((int)No, (unsigned)n, (unsigned)pose_dim, cam_weight(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, comm ? nullptr : h_res, h_seq, seq, res_out);
     if (comm) allreduce_d(dscalars.p, 2);
     return seq;
   }
@@ -649,11 +744,12 @@ template <typename T> struct Engine final : EngineBase {
   void solver_update_structure(int solver) override {
     if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
     else if (solver == GR_SOLVER_DENSE_SCHUR) { ensure_chol(); want_hcp = true; }
-    else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) { want_hcp = false; ensure_implicit_schur(); }
+    else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) { want_hcp = false; ensure_implicit_schur(); if (!tiling_tuned) tune_tiling(); }
     else {
       want_hcp = false;
       v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
       MinvC.alloc(81 * (size_t)Nc); MinvP.alloc(9 * (size_t)Np);
+      if (!tiling_tuned) tune_tiling();
       if (!records_tuned) tune_point_records();
     }
   }
@@ -912,7 +1008,7 @@ template <typename T> struct Engine final : EngineBase {
     k_point_prepare<T><<<cdiv(Np, TPB) + 1, TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, sc, sc_cap);
     {
       Scope s0(this, "is_prepare", No * (2 * w() + 12.0) + (24.0 * Nc + 15.0 * Np) * w() + 54.0 * nseg * w(), No * 700.0);
-      if (jac32) { k_is_prepare<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); } else { k_is_prepare<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); }
+      if (jac32) { k_is_prepare<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); } else { k_is_prepare<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); }
     }
     if (comm) { // diagonal blocks of S and b_S: this shard's sums, all-reduced, then combined with the global Hcc, bc
       is_raw.alloc(90 * (size_t)Nc);
@@ -928,12 +1024,12 @@ template <typename T> struct Engine final : EngineBase {
     const int noop = run_pcg_iterations(max_iter, [&](int k) {
       {
         Scope s1(this, "is_pass1", pass_bytes, No * 290.0);
-        if (jac32) { k_is_pass1<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k); } else { k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k); }
+        if (jac32) { k_is_pass1<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k); } else { k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k); }
       }
       k_is_points<T, 0><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, zl.p, sc, k);
       {
         Scope s2(this, "is_pass2", No * (2 * w() + 12.0) + (24.0 * Nc + 6.0 * Np) * w() + 9.0 * nseg * w(), No * 290.0);
-        if (jac32) { k_is_pass2<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k); } else { k_is_pass2<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k); }
+        if (jac32) { k_is_pass2<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k); } else { k_is_pass2<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k); }
       }
       if (comm) { // one all-reduce of the 9 Nc vector per iteration; r, z, p are replicated, so no dot crosses ranks
         k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, sc.done, k);
@@ -946,7 +1042,7 @@ template <typename T> struct Engine final : EngineBase {
     note_noop({"is_pass1", "is_pass2"}, noop);
     // back-substitution x_l = Hll^-1 (b_l - Hpl^T x_p): pass 1 with q = s_c .* x_c, then the per-point solve
     k_mul<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((unsigned)pose_dim, v_q.p, scales.p, x);
-    if (jac32) { k_is_pass1<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1); } else { k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1); }
+    if (jac32) { k_is_pass1<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1); } else { k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1); }
     k_is_points<T, 1><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, x + pose_dim, sc, 0);
   }
 
@@ -955,14 +1051,14 @@ template <typename T> struct Engine final : EngineBase {
   template <int K, typename JT> void launch_operator_k(PcgState st, int k, const T *rec, const LmDev *lm, double mu) {
     const int nt = cdiv(No, (size_t)TPB * K);
     const int grid = std::max(8, std::min(nt, num_cu * 4) & ~7);
-    k_pcg_operator_k<T, K, JT><<<grid, TPB, 0, stream>>>((int)No, (int)Nc, nt, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
+    k_pcg_operator_k<T, K, JT><<<grid, TPB, 0, stream>>>((int)No, (int)Nc, tiled ? -nt : nt, o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
   }
   template <typename JT> void launch_operator_j(PcgState st, int k, const T *rec, const LmDev *lm, double mu) {
     switch (op_k) {
     case 2: launch_operator_k<2, JT>(st, k, rec, lm, mu); break;
     case 3: launch_operator_k<3, JT>(st, k, rec, lm, mu); break;
     case 4: launch_operator_k<4, JT>(st, k, rec, lm, mu); break;
-    default: k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
+    default: k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
     }
   }
   void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
@@ -1038,10 +1134,10 @@ template <typename T> struct Engine final : EngineBase {
   // Diagnostic: average device time (us) of `reps` back-to-back launches of one hot kernel
   // (which: 0 operator, 1 linearize, 2 chi2, 3 pcg_update, 4 pcg_direction, 5 linearize_finalize).
   double diag_time(int which, int variant, int reps) override {
-    const bool was_tuned = records_tuned;
-    records_tuned = true; // no recursion through solver_update_structure
+    const bool was_tuned = records_tuned, was_tl = tiling_tuned;
+    records_tuned = tiling_tuned = true; // no recursion through solver_update_structure
     solver_update_structure(GR_SOLVER_PCG);
-    records_tuned = was_tuned;
+    records_tuned = was_tuned; tiling_tuned = was_tl;
     linearize_impl(false);
     solver_set_damping(GR_SOLVER_PCG, 1e-4, false);
     ensure_ctl(4);
@@ -1057,7 +1153,7 @@ template <typename T> struct Engine final : EngineBase {
     auto launch = [&] {
       switch (which) {
       case 0:
-#define GR_OP(V) k_pcg_operator<T, V><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0, use_records ? xp.p : nullptr)
+#define GR_OP(V) k_pcg_operator<T, V><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0, use_records ? xp.p : nullptr)
 #ifdef GR_DIAG
         switch (variant) { case 1: GR_OP(1); break; case 2: GR_OP(2); break; case 4: GR_OP(4); break; case 7: GR_OP(7); break; case 8: GR_OP(8); break; case 15: GR_OP(15); break; case 16: GR_OP(16); break; case 31: GR_OP(31); break;
                            case 32: GR_OP(32); break; case 64: GR_OP(64); break; case 128: GR_OP(128); break; case 3: GR_OP(3); break; case 95: GR_OP(95); break; case 255: GR_OP(255); break; case 224: GR_OP(224); break; default: GR_OP(0); }
@@ -1067,10 +1163,10 @@ template <typename T> struct Engine final : EngineBase {
         break;
       case 1:
 #ifdef GR_DIAG
-#define GR_LIN(V) k_linearize<T, false, T, V><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p)
+#define GR_LIN(V) k_linearize<T, false, T, V><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p)
         switch (variant) { case 1: GR_LIN(1); break; case 2: GR_LIN(2); break; case 3: GR_LIN(3); break; case 4: GR_LIN(4); break; case 7: GR_LIN(7); break; case 8: GR_LIN(8); break; case 15: GR_LIN(15); break; default: GR_LIN(0); }
 #else
-        k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
+        k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
 #endif
         break;
       case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
@@ -1337,8 +1433,8 @@ template <typename T> struct Engine final : EngineBase {
       k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, k, tol, rej, (unsigned)pose_dim, rec, lm, (k == unroll - 1 && unroll < max_iter) ? 1 : 0, h_lm + 1);
     }
     k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), 1, cams.p, pts.p, cams_bak.p, pts_bak.p, x, scales.p, bu.p, 0.0, rho_partial.p, pack.p, rec, lm);
-    if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
-    else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, nb_pm, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, cam_ptr.p, cam_seg_ptr.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
+    if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
+    else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
     k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
                                                                                                     rho_partial.p, rho_blocks, nullptr, nullptr, 0, lm, pcg_iters.p, h_trace, h_trace + h_trace_cap, h_lm, h_lm + 1);
   }
@@ -1363,7 +1459,7 @@ template <typename T> struct Engine final : EngineBase {
     }
     damping_identity = opt.use_identity != 0;
     key.solver = opt.solver; key.max_iter = opt.pcg_max_iter; key.use_identity = opt.use_identity; key.jac32 = jac32 ? 1 : 0;
-    key.loss_kind = loss_kind; key.records = use_records ? 1 : 0; key.cap = ctl_cap; key.tol = opt.pcg_tol; key.rej = opt.pcg_rejection_ratio;
+    key.loss_kind = loss_kind; key.records = (use_records ? 1 : 0) | (tiled ? 4 : 0); key.cap = ctl_cap; key.tol = opt.pcg_tol; key.rej = opt.pcg_rejection_ratio;
     key.loss_delta = (double)loss_delta; key.xp = xp.p; key.pinned = h_res;
     const int mi = opt.pcg_max_iter; const double tl_ = opt.pcg_tol, rj_ = opt.pcg_rejection_ratio;
     if (opt.solver == GR_SOLVER_PCG_IDENTITY) lm_enqueue_fn = [this, mi, tl_, rj_] { lm_graph_enqueue<true>(mi, tl_, rj_); };

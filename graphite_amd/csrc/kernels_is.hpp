@@ -25,18 +25,18 @@ __device__ __forceinline__ void cm_tiles(int No, int ntiles, const int *__restri
                                          const int *__restrict__ pt_cm, const int *__restrict__ pos_cm,
                                          const T *__restrict__ obs_cm, Body &&body) {
   using V2 = typename Vec2T<T>::type;
-  int t0, t1;
-  xcd_tile_range(ntiles, t0, t1);
+  int t0, t1, tstep;
+  xcd_tile_range(ntiles, t0, t1, tstep);
   int j = t0 * TPB + threadIdx.x;
   bool valid = t0 < t1 && j < No;
   int c_n = -1, l_n = 0, a_n = 0;
   V2 o_n{};
   if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm[j]; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
-  for (int t = t0; t < t1; ++t) {
+  for (int t = t0; t < t1; t += tstep) {
     const int c = c_n, l = l_n, a = a_n;
     const V2 o = o_n;
-    const int jn = j + TPB;
-    const bool validn = (t + 1 < t1) && jn < No;
+    const int jn = j + tstep * TPB;
+    const bool validn = (t + tstep < t1) && jn < No;
     if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm[jn]; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
     body(j, valid, c, l, a, o.x, o.y);
     valid = validn;
@@ -46,13 +46,15 @@ __device__ __forceinline__ void cm_tiles(int No, int ntiles, const int *__restri
 
 // reduce NV (16 or 64) per-lane values once per distinct camera of the wave and store the first
 // NOUT of them at out[seg * NOUT + i]; build(mine, v) fills the lane's values (zero weight if !mine)
+// segf = flat id of the 64-observation block's first (run, block) segment (blk_seg[j >> 6]); seg_slot maps flat ids to
+// the camera-major slots that the consumers read
 template <typename T, int NV, int NOUT, typename Build>
-__device__ __forceinline__ void reduce_by_camera(bool valid, int c, int seg, int lane, T *__restrict__ out, Build &&build) {
+__device__ __forceinline__ void reduce_by_camera(bool valid, int c, int segf, const int *__restrict__ seg_slot, int lane, T *__restrict__ out, Build &&build) {
   unsigned long long remaining = __ballot(valid);
   while (remaining) {
     const int leader = __builtin_ctzll(remaining);
     const int cl = __shfl(c, leader, 64);
-    const int segl = __shfl(seg, leader, 64);
+    const int segl = seg_slot[segf++];
     const bool mine = valid && c == cl;
     T v[NV];
     build(mine, v);
@@ -70,20 +72,18 @@ __device__ __forceinline__ void reduce_by_camera(bool valid, int c, int seg, int
 template <typename T, typename JT = T>
 __global__ void __launch_bounds__(TPB)
 k_is_prepare(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
-             const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
-             const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
+             const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ blk_seg,
+             const int *__restrict__ seg_slot, const T *__restrict__ pts, const T *__restrict__ pack,
              int loss_kind, T loss_delta, const T *__restrict__ Mp, const T *__restrict__ vl,
              T *__restrict__ cam_partial) {
   const int lane = threadIdx.x & 63;
   cm_tiles<T>(No, ntiles, cam_cm, pt_cm, pos_cm, obs_cm, [&](int j, bool valid, int c, int l, int, T ox, T oy) {
-    int seg = 0;
     T h[27], A[27], rhs[9];
 #pragma unroll
     for (int i = 0; i < 27; ++i) { h[i] = T(0); A[i] = T(0); }
 #pragma unroll
     for (int i = 0; i < 9; ++i) rhs[i] = T(0);
     if (valid) {
-      seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
       T pk[PACK], e0, e1, Jc[18], Jp[6];
       load_pack(pack, c, pk);
       bal_linearize_j<T, JT>(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], ox, oy, e0, e1, Jc, Jp);
@@ -107,7 +107,7 @@ k_is_prepare(int No, int ntiles, const int *__restrict__ cam_cm, const int *__re
         rhs[r] = h[r] * v0 + h[r + 9] * v1 + h[r + 18] * v2;
       }
     }
-    reduce_by_camera<T, 64, 54>(valid, c, seg, lane, cam_partial, [&](bool mine, T(&acc)[64]) {
+    reduce_by_camera<T, 64, 54>(valid, c, blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)], seg_slot, lane, cam_partial, [&](bool mine, T(&acc)[64]) {
       const T z = mine ? T(1) : T(0);
       int k = 0;
 #pragma unroll
@@ -215,19 +215,17 @@ __global__ void k_is_points(int Np, int Nc, const int *__restrict__ pt_ptr, cons
 template <typename T, typename JT = T>
 __global__ void __launch_bounds__(TPB)
 k_is_pass2(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
-           const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
-           const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
+           const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ blk_seg,
+           const int *__restrict__ seg_slot, const T *__restrict__ pts, const T *__restrict__ pack,
            int loss_kind, T loss_delta, const T *__restrict__ zl, T *__restrict__ op_partial, PcgScalars sc, int k) {
   if (sc.done[k]) return;
   if (part_sum(sc.rz, sc.np, k) == 0.0) return;
   const int lane = threadIdx.x & 63;
   cm_tiles<T>(No, ntiles, cam_cm, pt_cm, pos_cm, obs_cm, [&](int j, bool valid, int c, int l, int, T ox, T oy) {
-    int seg = 0;
     T acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = T(0);
     if (valid) {
-      seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
       T pk[PACK], e0, e1, Jc[18], Jp[6];
       load_pack(pack, c, pk);
       bal_linearize_j<T, JT>(pk, pts[3 * (size_t)l], pts[3 * (size_t)l + 1], pts[3 * (size_t)l + 2], ox, oy, e0, e1, Jc, Jp);
@@ -238,7 +236,7 @@ k_is_pass2(int No, int ntiles, const int *__restrict__ cam_cm, const int *__rest
 #pragma unroll
       for (int i = 0; i < 9; ++i) acc[i] = Jc[2 * i] * v0 + Jc[2 * i + 1] * v1;
     }
-    reduce_by_camera<T, 16, 9>(valid, c, seg, lane, op_partial, [&](bool mine, T(&m)[16]) {
+    reduce_by_camera<T, 16, 9>(valid, c, blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)], seg_slot, lane, op_partial, [&](bool mine, T(&m)[16]) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) m[i] = mine ? acc[i] : T(0);
 #pragma unroll

@@ -254,11 +254,17 @@ template <typename T> __global__ void k_points_to_records(int Np, const T *__res
 // 4 MiB L2.  With gridDim.x a multiple of 8, XCD x walks the x-th eighth of the tiles, i.e. a
 // contiguous range of cameras, whose point gathers / scatters (points are ordered by first
 // camera) then stay inside that XCD's L2 instead of every L2 seeing every point.  Speed only.
-__device__ __forceinline__ void xcd_tile_range(int ntiles, int &t0, int &t1) {
+// ntiles < 0 selects the SWEEP form used with point-tiled observation orders (Engine::build_tiled_order): XCD x still
+// owns the x-th eighth of the tiles (= its point tiles, one after the other), but its workgroups take the tiles of that
+// eighth round-robin, so that at any moment the whole XCD works inside one L2-sized point tile.
+__device__ __forceinline__ void xcd_tile_range(int ntiles, int &t0, int &t1, int &tstep) {
   const int nb = gridDim.x >> 3, x = blockIdx.x & 7, bi = blockIdx.x >> 3;
-  const int x0 = (int)((long long)x * ntiles / 8), x1 = (int)((long long)(x + 1) * ntiles / 8);
+  const int nt = ntiles < 0 ? -ntiles : ntiles;
+  const int x0 = (int)((long long)x * nt / 8), x1 = (int)((long long)(x + 1) * nt / 8);
+  if (ntiles < 0) { t0 = x0 + bi; t1 = x1; tstep = nb; return; }
   t0 = x0 + (int)((long long)bi * (x1 - x0) / nb);
   t1 = x0 + (int)((long long)(bi + 1) * (x1 - x0) / nb);
+  tstep = 1;
 }
 
 // scalars of iteration k as every wave derives them (all lanes must call)
@@ -327,8 +333,8 @@ __device__ __forceinline__ bool grid_sum2(double v0, double v1, double *partial,
 template <typename T, bool WRITE_HCP, typename JT = T, int LV = 0>
 __global__ void __launch_bounds__(TPB, LIN_WAVES)
 k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
-            const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
-            const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
+            const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ blk_seg,
+            const int *__restrict__ seg_slot, const T *__restrict__ pts, const T *__restrict__ pack,
             int loss_kind, T loss_delta, T *__restrict__ g9, T *__restrict__ Hcp, T *__restrict__ cam_partial,
             double *__restrict__ chi2_partial, const LmDev *__restrict__ lm = nullptr,
             const int *__restrict__ gate = nullptr) {
@@ -337,27 +343,25 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
   __shared__ double red[4];
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
-  int t0, t1;
-  xcd_tile_range(ntiles, t0, t1);
+  int t0, t1, tstep;
+  xcd_tile_range(ntiles, t0, t1, tstep);
   double chi2 = 0.0;
   int j = t0 * TPB + threadIdx.x;
   bool valid = t0 < t1 && j < No;
   int c_n = -1, l_n = 0, a_n = 0;
   V2 o_n{};
   if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm[j]; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
-  for (int t = t0; t < t1; ++t) {
+  for (int t = t0; t < t1; t += tstep) {
     const int c = c_n, l = l_n;
     const size_t a = (size_t)a_n;
     const V2 o = o_n;
-    const int jn = j + TPB;
-    const bool validn = (t + 1 < t1) && jn < No;
+    const int jn = j + tstep * TPB;
+    const bool validn = (t + tstep < t1) && jn < No;
     if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm[jn]; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
-    int seg = 0;
     T Jc[18], e0 = 0, e1 = 0, w = 0;
 #pragma unroll
     for (int i = 0; i < 18; ++i) Jc[i] = T(0);
     if (valid) {
-      seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
       T pk[PACK], Jp[6];
       load_pack(pack, c, pk);
       const size_t lp = (LV & 4) ? (size_t)(j & 1023) : (size_t)l;
@@ -398,10 +402,11 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
     // camera-side reduction, once per distinct camera in the wave (usually one)
     unsigned long long remaining = (LV & 2) ? 0ull : __ballot(valid);
     if (LV & 2) chi2 += (double)(Jc[0] + Jc[17] + w);
+    int segf = blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)]; // flat id of the block's first (run, block) segment; the next runs follow
     while (remaining) {
       const int leader = __builtin_ctzll(remaining);
       const int cl = __shfl(c, leader, 64);
-      const int segl = __shfl(seg, leader, 64);
+      const int segl = seg_slot[segf++];
       const bool mine = valid && c == cl;
       const T wm = mine ? w : T(0);
       T acc[64];
@@ -628,8 +633,8 @@ k_chi2(int No, unsigned n, unsigned pose_dim, int cam_weight, const int *__restr
 template <typename T, int VAR = 0, typename JT = T>
 __global__ void __launch_bounds__(TPB, OP_WAVES)
 k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
-               const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
-               const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
+               const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ blk_seg,
+               const int *__restrict__ seg_slot, const T *__restrict__ pts, const T *__restrict__ pack,
                int loss_kind, T loss_delta, const T *__restrict__ ps, T *__restrict__ g3,
                T *__restrict__ op_partial, double mu, PcgState st, int k, const T *__restrict__ xp = nullptr,
                const LmDev *__restrict__ lm = nullptr) {
@@ -642,20 +647,20 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
   const size_t pose_dim = 9 * (size_t)Nc;
-  int t0, t1;
-  xcd_tile_range(ntiles, t0, t1);
+  int t0, t1, tstep;
+  xcd_tile_range(ntiles, t0, t1, tstep);
   double den = 0;
   int j = t0 * TPB + threadIdx.x;
   bool valid = t0 < t1 && j < No;
   int c_n = -1, l_n = 0, a_n = 0;
   V2 o_n{};
   if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm[j]; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
-  for (int t = t0; t < t1; ++t) {
+  for (int t = t0; t < t1; t += tstep) {
     const int c = c_n, l = l_n;
     const size_t a = (size_t)a_n;
     const V2 o = o_n;
-    const int jn = j + TPB;
-    const bool validn = (t + 1 < t1) && jn < No;
+    const int jn = j + tstep * TPB;
+    const bool validn = (t + tstep < t1) && jn < No;
     if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm[jn]; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
 #if OP_SGPR
     // Wave-uniform camera data (24-scalar pack, 9 direction scalars, segment id) are fetched per DISTINCT
@@ -673,11 +678,12 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
       pl0 = pl[0]; pl1 = pl[1]; pl2 = pl[2];
     }
     unsigned long long remaining = __ballot(valid);
+    int segf = blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)];
     while (remaining) {
       const int leader = __builtin_ctzll(remaining);
       const int cl = __builtin_amdgcn_readfirstlane(__shfl(c, leader, 64));
       const bool mine = valid && c == cl;
-      const int segl = (VAR & 64) ? (j >> 6) : cam_seg_ptr[cl] + (__builtin_amdgcn_readfirstlane(__shfl(j, leader, 64) >> 6) - (cam_ptr[cl] >> 6));
+      const int segl = (VAR & 64) ? (j >> 6) : seg_slot[segf++];
       T pk[PACK], pc[9];
       if (VAR & 64) {
 #pragma unroll
@@ -724,12 +730,10 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
       remaining &= ~__ballot(mine);
     }
 #else
-    int seg = 0;
     T acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = T(0);
     if (valid) {
-      seg = cam_seg_ptr[c] + ((j >> 6) - (cam_ptr[c] >> 6));
       T pk[PACK], pc[9];
       load_pack(pack, c, pk);
 #pragma unroll
@@ -761,10 +765,11 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     }
     if (!(VAR & 16)) {
       unsigned long long remaining = __ballot(valid);
+      int segf = blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)];
       while (remaining) {
         const int leader = __builtin_ctzll(remaining);
         const int cl = __shfl(c, leader, 64);
-        const int segl = __shfl(seg, leader, 64);
+        const int segl = seg_slot[segf++];
         const bool mine = valid && c == cl;
         T m[16];
 #pragma unroll
@@ -791,8 +796,8 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
 template <typename T, int K, typename JT = T>
 __global__ void __launch_bounds__(TPB, OP_WAVES)
 k_pcg_operator_k(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
-                 const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ cam_ptr,
-                 const int *__restrict__ cam_seg_ptr, const T *__restrict__ pts, const T *__restrict__ pack,
+                 const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ blk_seg,
+                 const int *__restrict__ seg_slot, const T *__restrict__ pts, const T *__restrict__ pack,
                  int loss_kind, T loss_delta, const T *__restrict__ ps, T *__restrict__ g3,
                  T *__restrict__ op_partial, double mu, PcgState st, int k, const T *__restrict__ xp = nullptr,
                  const LmDev *__restrict__ lm = nullptr) {
@@ -803,8 +808,8 @@ k_pcg_operator_k(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, con
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t pose_dim = 9 * (size_t)Nc;
-  int t0, t1;
-  xcd_tile_range(ntiles, t0, t1);
+  int t0, t1, tstep;
+  xcd_tile_range(ntiles, t0, t1, tstep);
   double den = 0;
   int c_n[K], l_n[K], a_n[K];
   V2 o_n[K];
@@ -817,7 +822,7 @@ k_pcg_operator_k(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, con
     }
   };
   load_indices(t0);
-  for (int t = t0; t < t1; ++t) {
+  for (int t = t0; t < t1; t += tstep) {
     int c[K];
     size_t a[K];
     V2 o[K];
@@ -836,17 +841,18 @@ k_pcg_operator_k(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, con
         pl0[u] = pl[0]; pl1[u] = pl[1]; pl2[u] = pl[2];
       }
     }
-    load_indices(t + 1);
+    load_indices(t + tstep);
 #pragma unroll
     for (int u = 0; u < K; ++u) {
       const bool valid = c[u] >= 0;
       const int jw = ((t * 4 + wave) * K + u); // index of this 64-observation run
       unsigned long long remaining = __ballot(valid);
+      int segf = blk_seg[jw < ((No + 63) >> 6) ? jw : 0];
       while (remaining) {
         const int leader = __builtin_ctzll(remaining);
         const int cl = __builtin_amdgcn_readfirstlane(__shfl(c[u], leader, 64));
         const bool mine = valid && c[u] == cl;
-        const int segl = cam_seg_ptr[cl] + (jw - (cam_ptr[cl] >> 6));
+        const int segl = seg_slot[segf++];
         T pk[PACK], pc[9];
         load_pack(pack, cl, pk);
 #pragma unroll
@@ -978,11 +984,11 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
       if (!use_identity) dg = diag[t];
       if (MODE == 0) { rn = sc * bu[t]; x[t] = T(0); }
       else {
-        int a = pt_ptr[l];
-        const int a_end = pt_ptr[l + 1];
         pv = p[t];
         const T xo = x[t], ro = r[t];
         T raw = 0;
+        int a = pt_ptr[l];
+        const int a_end = pt_ptr[l + 1];
 #if UPD_VAR != 1
         for (; a + 4 <= a_end; a += 4) { // 4 independent loads in flight, the sum stays in observation order
           const T *gp = g3 + 3 * (size_t)a + li;
