@@ -644,15 +644,12 @@ template <typename T> struct Engine final : EngineBase {
       // algorithmic bytes: every array touched once (obs, 3 index streams, points, packs, g9 out, partials, Hcp)
       const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
       Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)));
-      if (write_hcp) {
-        if (jac32) { k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); } else { k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, Hcp.p, cam_partial.p, chi2_partial.p); }
-      } else {
-        if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate); } else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate); }
+      launch_linearize_cam(write_hcp, g9.p, gate);
     }
-      }
     {
+      const int np_fin = (int)Np;
       Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
-      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
+      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)np_fin, TPB), TPB, 0, stream>>>((int)Nc, np_fin, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
                                                                                                     spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq,
                                                                                                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gate);
     }
@@ -665,6 +662,17 @@ template <typename T> struct Engine final : EngineBase {
       k_camera_scales<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, scale_system ? 1 : 0, Hcc.p, scales.p);
     }
     hcp_valid = write_hcp;
+  }
+  void launch_linearize_cam(bool hcp, T *g9p, const int *gate) {
+    if constexpr (sizeof(T) == 8) {
+      if (jac32) {
+        if (hcp) k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate);
+        else k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate);
+        return;
+      }
+    }
+    if (hcp) k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate);
+    else k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate);
   }
   bool want_hcp = false;
   void linearize() override { linearize_impl(want_hcp); }
@@ -1046,20 +1054,8 @@ template <typename T> struct Engine final : EngineBase {
     k_is_points<T, 1><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, x + pose_dim, sc, 0);
   }
 
-  // matrix-free operator launcher: K = op_k 64-observation sub-tiles per wave and trip (kernels_mf.hpp k_pcg_operator_k)
-  int op_k = getenv("GR_OP_K") ? std::max(1, std::min(4, atoi(getenv("GR_OP_K")))) : 1;
-  template <int K, typename JT> void launch_operator_k(PcgState st, int k, const T *rec, const LmDev *lm, double mu) {
-    const int nt = cdiv(No, (size_t)TPB * K);
-    const int grid = std::max(8, std::min(nt, num_cu * 4) & ~7);
-    k_pcg_operator_k<T, K, JT><<<grid, TPB, 0, stream>>>((int)No, (int)Nc, tiled ? -nt : nt, o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
-  }
   template <typename JT> void launch_operator_j(PcgState st, int k, const T *rec, const LmDev *lm, double mu) {
-    switch (op_k) {
-    case 2: launch_operator_k<2, JT>(st, k, rec, lm, mu); break;
-    case 3: launch_operator_k<3, JT>(st, k, rec, lm, mu); break;
-    case 4: launch_operator_k<4, JT>(st, k, rec, lm, mu); break;
-    default: k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
-    }
+    k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
   }
   void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
@@ -1188,6 +1184,7 @@ template <typename T> struct Engine final : EngineBase {
         else k_block_jacobi<T><<<nbc + nbp + 1, 64, 0, stream>>>(variant == 2 ? 0 : (int)Nc, variant == 1 ? 0 : (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, 1e-4, 0, MinvC.p, MinvP.p, v_diag.p, st, ctl_cap);
         break;
       }
+      case 7: linearize_impl(false, /*pack_valid=*/true); break; // the whole linearisation (all its kernels), current path
       default: throw std::invalid_argument("diag_time: unknown kernel");
       }
     };

@@ -788,105 +788,6 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
   if (threadIdx.x == 0) slot_add(st.slots(k, DEN), 0, den);
 }
 
-// The same operator with K consecutive 64-observation sub-tiles per wave and trip: the index streams of the NEXT
-// trip and the K point gathers of THIS trip are all in flight before the first Jacobian is evaluated, so a
-// block's dependent chain (indices -> gather -> math -> scatter) is paid once per K*256 observations instead
-// of once per 256 (Ladybug-1723: 2.6 trips per block at K = 1).  Same arithmetic, same (wave, camera) segments
-// (a sub-tile is still one 64-aligned run reduced by one wave), hence the same bits as k_pcg_operator.
-template <typename T, int K, typename JT = T>
-__global__ void __launch_bounds__(TPB, OP_WAVES)
-k_pcg_operator_k(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
-                 const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ blk_seg,
-                 const int *__restrict__ seg_slot, const T *__restrict__ pts, const T *__restrict__ pack,
-                 int loss_kind, T loss_delta, const T *__restrict__ ps, T *__restrict__ g3,
-                 T *__restrict__ op_partial, double mu, PcgState st, int k, const T *__restrict__ xp = nullptr,
-                 const LmDev *__restrict__ lm = nullptr) {
-  if (lm && lm->stop) return;
-  if (st.done[k]) return;
-  if (slot_sum(st.slots(k, RZP), 0) == 0.0) return;
-  __shared__ double red[4];
-  using V2 = typename Vec2T<T>::type;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t pose_dim = 9 * (size_t)Nc;
-  int t0, t1, tstep;
-  xcd_tile_range(ntiles, t0, t1, tstep);
-  double den = 0;
-  int c_n[K], l_n[K], a_n[K];
-  V2 o_n[K];
-  auto load_indices = [&](int t) {
-#pragma unroll
-    for (int u = 0; u < K; ++u) {
-      const int j = (t * 4 + wave) * (64 * K) + u * 64 + lane;
-      c_n[u] = -1; l_n[u] = 0; a_n[u] = 0; o_n[u] = V2{};
-      if (t < t1 && j < No) { c_n[u] = cam_cm[j]; l_n[u] = pt_cm[j]; a_n[u] = pos_cm[j]; o_n[u] = reinterpret_cast<const V2 *>(obs_cm)[j]; }
-    }
-  };
-  load_indices(t0);
-  for (int t = t0; t < t1; t += tstep) {
-    int c[K];
-    size_t a[K];
-    V2 o[K];
-    T X[K], Y[K], Z[K], pl0[K], pl1[K], pl2[K];
-#pragma unroll
-    for (int u = 0; u < K; ++u) {
-      c[u] = c_n[u]; a[u] = (size_t)a_n[u]; o[u] = o_n[u];
-      const size_t lp = (size_t)l_n[u];
-      if (xp) {
-        const V2 *rec = reinterpret_cast<const V2 *>(xp + 8 * lp);
-        const V2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-        X[u] = r0.x; Y[u] = r0.y; Z[u] = r1.x; pl0[u] = r1.y; pl1[u] = r2.x; pl2[u] = r2.y;
-      } else {
-        X[u] = pts[3 * lp]; Y[u] = pts[3 * lp + 1]; Z[u] = pts[3 * lp + 2];
-        const T *pl = ps + pose_dim + 3 * lp;
-        pl0[u] = pl[0]; pl1[u] = pl[1]; pl2[u] = pl[2];
-      }
-    }
-    load_indices(t + tstep);
-#pragma unroll
-    for (int u = 0; u < K; ++u) {
-      const bool valid = c[u] >= 0;
-      const int jw = ((t * 4 + wave) * K + u); // index of this 64-observation run
-      unsigned long long remaining = __ballot(valid);
-      int segf = blk_seg[jw < ((No + 63) >> 6) ? jw : 0];
-      while (remaining) {
-        const int leader = __builtin_ctzll(remaining);
-        const int cl = __builtin_amdgcn_readfirstlane(__shfl(c[u], leader, 64));
-        const bool mine = valid && c[u] == cl;
-        const int segl = seg_slot[segf++];
-        T pk[PACK], pc[9];
-        load_pack(pack, cl, pk);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) pc[i] = ps[9 * (size_t)cl + i];
-        T e0, e1, Jc[18], Jp[6];
-        bal_linearize_j<T, JT>(pk, X[u], Y[u], Z[u], o[u].x, o[u].y, e0, e1, Jc, Jp);
-        const T w = mine ? loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1) : T(0);
-        T u0 = Jp[0] * pl0[u] + Jp[2] * pl1[u] + Jp[4] * pl2[u];
-        T u1 = Jp[1] * pl0[u] + Jp[3] * pl1[u] + Jp[5] * pl2[u];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { u0 += Jc[2 * i] * pc[i]; u1 += Jc[2 * i + 1] * pc[i]; }
-        if (mine) den += (double)(w * (u0 * u0 + u1 * u1));
-        u0 *= w; u1 *= w;
-        T m[16];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) m[i] = mine ? Jc[2 * i] * u0 + Jc[2 * i + 1] * u1 : T(0);
-#pragma unroll
-        for (int i = 9; i < 16; ++i) m[i] = T(0);
-        if (mine) {
-          T *g = g3 + 3 * a[u];
-          g[0] = Jp[0] * u0 + Jp[1] * u1;
-          g[1] = Jp[2] * u0 + Jp[3] * u1;
-          g[2] = Jp[4] * u0 + Jp[5] * u1;
-        }
-        const T tot = wave_transpose_sum<T, 16>(m, lane);
-        if ((lane & 3) == 0 && (lane >> 2) < 9) op_partial[9 * (size_t)segl + (lane >> 2)] = tot;
-        remaining &= ~__ballot(mine);
-      }
-    }
-  }
-  den = block_sum_256(den, red);
-  if (threadIdx.x == 0) slot_add(st.slots(k, DEN), 0, den);
-}
-
 // x / r / z' update of the matrix-free PCG.
 // Persistent blocks walk contiguous ranges of
 //   camera tiles: 252 camera scalars (28 cameras) — fixed-order sum of the segment partials,

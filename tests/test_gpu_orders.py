@@ -1,7 +1,6 @@
 """The alternative observation orders / operator forms the engine picks by timing on large graphs, FORCED on small
 problems so that they are held to the oracle like the default path:
   GR_PTILES=K   point-tiled (tile, camera, point) order of the per-observation kernels (Engine::build_tiled_order)
-  GR_OP_K=2     two 64-observation sub-tiles per wave and trip
 Every solver, the LM traces, the sharded run."""
 import threading
 
@@ -13,12 +12,12 @@ from graphite_amd import dist as gdist, synth
 
 pytestmark = pytest.mark.gpu
 
-MODES = {"tiled8": {"GR_PTILES": "8"}, "tiled24": {"GR_PTILES": "24"}, "opk2": {"GR_OP_K": "2", "GR_PTILES": "0"}, "opk2+tiled": {"GR_OP_K": "2", "GR_PTILES": "8"}}
+MODES = {"tiled8": {"GR_PTILES": "8"}, "tiled24": {"GR_PTILES": "24"}, "plain": {"GR_PTILES": "0"}}
 SOLVERS = ["pcg", "pcg_identity", "pcg_schur_implicit", "pcg_schur", "dense_schur"]
 
 
 def setenv(monkeypatch, mode):
-    for k in ("GR_PTILES", "GR_OP_K"):
+    for k in ("GR_PTILES",):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -51,7 +50,7 @@ def test_lm_trace_matches_oracle(oracle_mod, monkeypatch, name, dtype, solver, m
         assert abs(ct[-1] - ct_r[-1]) / ct_r[-1] < 2e-3
 
 
-@pytest.mark.parametrize("mode", ["tiled8", "tiled24", "opk2+tiled"])
+@pytest.mark.parametrize("mode", ["tiled8", "tiled24"])
 def test_solver_solve_matches_oracle_pcg(oracle_mod, monkeypatch, mode):
     setenv(monkeypatch, mode)
     prob = synth.make_config("mini-50")
@@ -79,7 +78,7 @@ def test_solver_solve_matches_oracle_pcg(oracle_mod, monkeypatch, mode):
 
 
 @pytest.mark.parametrize("mode", ["tiled8", "tiled24"])
-@pytest.mark.parametrize("shape", [(3, 30, 65, 3, 3), (29, 300, 1025, 8, 9), (70, 40, 2000, 70, 10), (64, 5000, 12000, 4, 13), (700, 3000, 20000, 700, 14)],
+@pytest.mark.parametrize("shape", [(3, 30, 65, 3, 3), (29, 300, 1025, 8, 9), (70, 40, 2000, 70, 10), (64, 5000, 12000, 4, 13), (700, 3000, 20000, 700, 14), (1400, 5000, 30000, 40, 15)],
                          ids=lambda s: "x".join(map(str, s[:3])))
 def test_boundary_shapes(oracle_mod, monkeypatch, shape, mode):
     """tilings that end inside a wave, single-point tiles, more tiles than points"""

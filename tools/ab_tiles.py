@@ -14,7 +14,7 @@ for K in ks:
     g = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dt)
     f = g.lib.gr_bal_diag_time; f.restype = C.c_double
     g.solver_update_structure(ga.SOLVER_PCG)
-    t = {nm: min(f(g.h, C.c_int(w), C.c_int(0), C.c_int(20)) for _ in range(2)) for w, nm in ((0, "operator"), (1, "linearize"), (2, "chi2"))}
+    t = {nm: min(f(g.h, C.c_int(w), C.c_int(0), C.c_int(20)) for _ in range(2)) for w, nm in ((0, "operator"), (1, "k_linearize"), (7, "linearisation"), (2, "chi2"))}
     kw = dict(solver=ga.SOLVER_PCG, iterations=8)
     g.set_params(prob.cameras, prob.points); g.levenberg_marquardt(**kw)
     rates = []
