@@ -128,6 +128,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    transport = {"kind": None}
+
     def make_engine(workload, dtype):
         prob = synth.make_config(workload)
         t0 = time.perf_counter()
@@ -136,7 +138,15 @@ def main():
             part = gdist.partition_by_landmark(prob, rank, world)
             gpu = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype,
                                 device=local_rank, shard=True)
-            gdist.init_comm(gpu, rank, world)
+            # small all-reduces go peer to peer through IPC-mapped mailboxes (one hop over xGMI), RCCL carries what does
+            # not fit a slot; the mailboxes are verified at start-up and every rank drops to RCCL together if that fails.
+            # GR_COMM=rccl: RCCL for everything.
+            if os.environ.get("GR_COMM", "ipc") == "rccl":
+                gdist.init_comm(gpu, rank, world)
+                transport["kind"] = "rccl"
+            else:
+                used = gdist.init_comm_ipc(gpu, rank, world, slot_bytes=4 << 20, rccl_fallback=True)
+                transport["kind"] = "ipc-mailbox+rccl" if used else "rccl (ipc verification failed)"
         else:
             part = prob
             gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype, device=local_rank)
@@ -389,6 +399,7 @@ def main():
         "solve_seconds": round(st["solve_seconds"], 6), "loop_seconds": round(st["loop_seconds"], 6),
         "setup_seconds": round(st["setup_seconds"], 6), "create_seconds": round(create_seconds, 4),
         "setup_note": "create_seconds: gr_bal_create (orderings, upload); setup_seconds: solver structure + first linearisation inside levenberg_marquardt; both outside `value`",
+        "transport": transport["kind"],
         "collectives_per_lm_iteration": round(st.get("collectives", 0) / max(steps_run, 1), 2) if sharded else 0,
         "parity_rel": parity_rel, "parity_steps": parity_steps,
         "parity_note": "max relative difference of the timed run's chi2 trace against the CPU oracle's trace of the same solver",

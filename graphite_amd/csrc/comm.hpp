@@ -18,9 +18,11 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <algorithm>
 
 namespace gr {
 
+struct CommError : std::runtime_error { using std::runtime_error::runtime_error; };
 struct Comm {
   int rank = 0, size = 1;
   virtual ~Comm() = default;
@@ -28,6 +30,8 @@ struct Comm {
   virtual void allreduce(void *buf, size_t count, bool is_double, hipStream_t stream) = 0;
   virtual void group_start() {}
   virtual void group_end() {}
+  // a transport that can lose a message without hanging reports it here (host check after a stream synchronisation)
+  virtual bool failed() { return false; }
 };
 
 // ---- RCCL ------------------------------------------------------------------------------
@@ -86,6 +90,171 @@ struct RcclComm final : Comm {
   }
   void group_start() override { RcclApi::get().check(RcclApi::get().GroupStart(), "ncclGroupStart"); }
   void group_end() override { RcclApi::get().check(RcclApi::get().GroupEnd(), "ncclGroupEnd"); }
+};
+
+// ---- one-shot peer all-reduce over IPC-mapped mailboxes ----------------------------------------------
+// The messages of this solver are small (<= 9 Nc scalars + a few dot-product records: 64 KB on Venice-1778 fp32) and
+// there are several per LM iteration, so what a collective costs is its latency: ~16 us through RCCL even on one
+// rank.  Over xGMI every GPU can write into every other GPU's memory directly, so an all-reduce of a
+// small message is ONE hop: every rank stores its contribution into its slot of every peer's mailbox (`push`), then
+// sums the `size` slots of its own mailbox in rank order (`reduce`).  No ring, no tree; the sum has the same order on
+// every rank, so the result is bit-identical everywhere.
+//   mailbox (one per rank, hipMalloc + hipIpcGetMemHandle, opened by every peer with hipIpcOpenMemHandle):
+//     header: flags[2][size] (uint64 sequence numbers), error word;  then 2 sets x size slots of `slot_bytes`
+//   set = seq & 1: a rank can only push sequence s + 2 after it has reduced s + 1, which needed every peer's push of
+//   s + 1, issued (stream order) after that peer's reduce of s: two sets are enough.
+//   visibility: the payload is stored with system-scope (write-through) stores, drained, then the flag is stored
+//   system-scope by the block that finishes last; the reader polls the flags system-scope and fences before it loads.
+// Grouped calls (group_start .. group_end) travel as ONE message.  Messages beyond the slot size go to the fallback
+// communicator (RCCL).  Every spin is bounded (2 s) and raises the mailbox's error word instead of hanging.
+constexpr int IPC_MAX_PARTS = 8;
+constexpr size_t IPC_HEADER = 4096;
+struct IpcPart { void *ptr; unsigned long long count; unsigned long long offset; int is_double; int pad; }; // offset: bytes inside the slot
+struct IpcMsg { IpcPart part[IPC_MAX_PARTS]; int nparts; };
+
+template <typename T> __device__ __forceinline__ void ipc_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+template <typename T> __device__ __forceinline__ T ipc_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// One launch per all-reduce.  Phase 1: this rank's values -> slot `rank` of set `set` in EVERY mailbox (its own included);
+// the last block to finish raises this rank's flag in every mailbox.  Phase 2: every block waits for all ranks' flags in
+// its OWN mailbox, then buf = sum over ranks, in rank order, of the slots (identical bits on every rank).
+// The grid is at most 64 blocks, launched on a stream whose earlier kernels have finished: all blocks are resident, so
+// waiting inside the kernel cannot starve the blocks that still have to push.  Waits are bounded (2 s): a peer that died
+// or never joined turns into the error word (IpcComm::failed), not a hung GPU.
+__global__ void __launch_bounds__(256) k_ipc_allreduce(IpcMsg msg, char *const *__restrict__ boxes, int rank, int size, int set, size_t slot_bytes,
+                                                       unsigned long long seq, unsigned *__restrict__ ticket) {
+  const size_t slot_off = IPC_HEADER + ((size_t)set * size + rank) * slot_bytes;
+  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (size_t)gridDim.x * blockDim.x;
+  for (int q = 0; q < msg.nparts; ++q) {
+    const IpcPart pt = msg.part[q];
+    if (pt.is_double) {
+      const double *src = static_cast<const double *>(pt.ptr);
+      for (size_t i = gtid; i < pt.count; i += gstride) {
+        const double v = src[i];
+        for (int r = 0; r < size; ++r) ipc_store(reinterpret_cast<double *>(boxes[r] + slot_off + pt.offset) + i, v);
+      }
+    } else {
+      const float *src = static_cast<const float *>(pt.ptr);
+      for (size_t i = gtid; i < pt.count; i += gstride) {
+        const float v = src[i];
+        for (int r = 0; r < size; ++r) ipc_store(reinterpret_cast<float *>(boxes[r] + slot_off + pt.offset) + i, v);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == gridDim.x - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int r = 0; r < size; ++r)
+        ipc_store(reinterpret_cast<unsigned long long *>(boxes[r]) + (size_t)set * size + rank, seq);
+    }
+  }
+  char *box = boxes[rank];
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < size) { // thread r waits for rank r
+    const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(box) + (size_t)set * size + threadIdx.x;
+    const long long t0 = wall_clock64();
+    while (ipc_load(flag) < seq) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > 200000000ll) { // 2 s at 100 MHz
+        ipc_store(reinterpret_cast<unsigned long long *>(box) + 500, 1ull); // error word
+        s_bad = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (s_bad) return;
+  const char *slots = box + IPC_HEADER + (size_t)set * size * slot_bytes;
+  for (int q = 0; q < msg.nparts; ++q) {
+    const IpcPart pt = msg.part[q];
+    if (pt.is_double) {
+      double *dst = static_cast<double *>(pt.ptr);
+      for (size_t i = gtid; i < pt.count; i += gstride) {
+        double sum = 0;
+        for (int r = 0; r < size; ++r) sum += ipc_load(reinterpret_cast<const double *>(slots + (size_t)r * slot_bytes + pt.offset) + i);
+        dst[i] = sum;
+      }
+    } else {
+      float *dst = static_cast<float *>(pt.ptr);
+      for (size_t i = gtid; i < pt.count; i += gstride) {
+        float sum = 0;
+        for (int r = 0; r < size; ++r) sum += ipc_load(reinterpret_cast<const float *>(slots + (size_t)r * slot_bytes + pt.offset) + i);
+        dst[i] = sum;
+      }
+    }
+  }
+}
+
+struct IpcComm final : Comm {
+  std::vector<char *> boxes;   // boxes[r] = rank r's mailbox as mapped here (boxes[rank] = my own allocation)
+  std::vector<bool> opened;    // opened through hipIpcOpenMemHandle (to be closed)
+  char **d_boxes = nullptr;
+  unsigned *d_ticket = nullptr;
+  size_t slot_bytes = 0;
+  unsigned long long seq = 0;
+  std::unique_ptr<Comm> fallback; // messages larger than a slot (may be null: then they are an error)
+  bool grouping = false;
+  IpcMsg pending{};
+  size_t pending_bytes = 0;
+  hipStream_t pending_stream = nullptr;
+  int64_t n_oneshot = 0, n_fallback = 0;
+
+  static size_t mailbox_bytes(int size, size_t slot) { return IPC_HEADER + 2 * (size_t)size * slot; }
+  IpcComm(int rank_, int size_, size_t slot_bytes_, const std::vector<char *> &boxes_, const std::vector<bool> &opened_) : boxes(boxes_), opened(opened_), slot_bytes(slot_bytes_) {
+    rank = rank_; size = size_;
+    GR_HIP(hipMalloc(reinterpret_cast<void **>(&d_boxes), size * sizeof(char *)));
+    GR_HIP(hipMemcpy(d_boxes, boxes.data(), size * sizeof(char *), hipMemcpyHostToDevice));
+    GR_HIP(hipMalloc(reinterpret_cast<void **>(&d_ticket), sizeof(unsigned)));
+    GR_HIP(hipMemset(d_ticket, 0, sizeof(unsigned)));
+  }
+  ~IpcComm() override {
+    for (int r = 0; r < size; ++r) if (opened[r]) (void)hipIpcCloseMemHandle(boxes[r]);
+    if (!boxes.empty() && boxes[rank]) (void)hipFree(boxes[rank]);
+    if (d_boxes) (void)hipFree(d_boxes);
+    if (d_ticket) (void)hipFree(d_ticket);
+  }
+  void flush(hipStream_t stream) {
+    if (!pending.nparts) return;
+    ++seq;
+    const int set = (int)(seq & 1);
+    size_t total = 0;
+    for (int q = 0; q < pending.nparts; ++q) total += pending.part[q].count;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>(64, (total + 2047) / 2048));
+    k_ipc_allreduce<<<grid, 256, 0, stream>>>(pending, d_boxes, rank, size, set, slot_bytes, seq, d_ticket);
+    ++n_oneshot;
+    pending.nparts = 0; pending_bytes = 0;
+  }
+  void allreduce(void *buf, size_t count, bool is_double, hipStream_t stream) override {
+    const size_t bytes = (count * (is_double ? 8 : 4) + 15) / 16 * 16;
+    if (bytes > slot_bytes || (grouping && (pending_bytes + bytes > slot_bytes || pending.nparts == IPC_MAX_PARTS))) {
+      if (grouping) flush(stream);
+      if (bytes > slot_bytes) {
+        if (!fallback) throw std::runtime_error("IPC all-reduce: message larger than the mailbox slot and no fallback communicator");
+        fallback->allreduce(buf, count, is_double, stream);
+        ++n_fallback;
+        return;
+      }
+    }
+    IpcPart &pt = pending.part[pending.nparts++];
+    pt.ptr = buf; pt.count = count; pt.offset = pending_bytes; pt.is_double = is_double ? 1 : 0; pt.pad = 0;
+    pending_bytes += bytes;
+    pending_stream = stream;
+    if (!grouping) flush(stream);
+  }
+  void group_start() override { grouping = true; }
+  void group_end() override { grouping = false; flush(pending_stream); }
+  bool failed() override { // a bounded spin gave up (host check after a stream synchronisation)
+    unsigned long long e = 0;
+    GR_HIP(hipMemcpy(&e, boxes[rank] + 500 * sizeof(unsigned long long), sizeof(e), hipMemcpyDeviceToHost));
+    return e != 0;
+  }
 };
 
 // ---- in-process test backend -------------------------------------------------------------

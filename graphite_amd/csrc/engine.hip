@@ -64,7 +64,11 @@ struct EngineBase {
   virtual int kernel_stats(gr_kernel_stat *out, int cap) = 0;
   virtual double diag_time(int which, int variant, int reps) = 0;
   virtual void set_comm(std::unique_ptr<Comm> c) = 0;
+  virtual void allreduce_host(double *v, size_t n) = 0;
   int device = 0;
+  char *ipc_box = nullptr; // mailbox allocated by gr_bal_comm_ipc_mailbox, owned by the IpcComm once it exists
+  size_t ipc_slot = 0;
+  int ipc_world = 0;
 };
 
 template <typename T> struct Engine final : EngineBase {
@@ -115,6 +119,15 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<T> raw_c;
   int cam_weight() const { return (!comm || comm->rank == 0) ? 1 : 0; }
   void set_comm(std::unique_ptr<Comm> c) override { comm = std::move(c); raw_c.alloc(pose_dim); }
+  void allreduce_host(double *v, size_t n) override {
+    if (!comm) throw std::invalid_argument("no communicator");
+    DevBuf<double> d;
+    std::vector<double> h(v, v + n);
+    d.upload(h, stream);
+    comm->allreduce(d.p, n, true, stream);
+    h = d.download(stream);
+    std::copy(h.begin(), h.end(), v);
+  }
   int64_t coll_count = 0; // collectives issued (a group counts once): gr_lm_stats.collectives
   bool coll_in_group = false;
   void allreduce_T(T *buf, size_t count) { if (!coll_in_group) ++coll_count; comm->allreduce(buf, count, sizeof(T) == 8, stream); }
@@ -1185,9 +1198,14 @@ template <typename T> struct Engine final : EngineBase {
         break;
       }
       case 7: linearize_impl(false, /*pack_valid=*/true); break; // the whole linearisation (all its kernels), current path
+      case 8: // one all-reduce of `variant` values (0: a camera-space vector) through the communicator, every rank calls it
+        if (!comm) throw std::invalid_argument("diag_time(8): no communicator");
+        comm->allreduce(tmp.p, variant > 0 ? std::min<size_t>(variant, tmp.n) : pose_dim, sizeof(T) == 8, stream);
+        break;
       default: throw std::invalid_argument("diag_time: unknown kernel");
       }
     };
+    if (which == 8) tmp.zero(stream);
     for (int i = 0; i < 3; ++i) launch();
     GR_HIP(hipEventRecord(a, stream));
     for (int i = 0; i < reps; ++i) launch();
@@ -1683,6 +1701,7 @@ template <typename T> struct Engine final : EngineBase {
     st.ok = run ? 1 : 0;
     st.final_chi2 = (double)chi2v;
     st.collectives = coll_count - coll0;
+    if (comm && comm->failed()) throw CommError("levenberg_marquardt: an all-reduce timed out waiting for a peer (IPC mailbox transport); the result is not valid");
     if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] LM: trial step enqueued ahead of the PCG exit flag in %d iterations, not ahead in %d\n", ahead_hits, ahead_misses);
     if (getenv("GR_VERBOSE") && graph_mode)
       std::fprintf(stderr, "[graphite-mi355x] LM: %d of %d iterations replayed as graphs; handed back: %d (PCG iterations), %d (not accepted)\n", g_steps, st.iterations_run, g_stop1, g_stop2);
@@ -1823,6 +1842,7 @@ gr_status gr_dense_cholesky_solve(gr_dtype dtype, int64_t n, const void *A, int6
     return GR_OK;
   } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
   catch (const std::range_error &ex) { g_last_error = ex.what(); return GR_ERR_SOLVE_FAILED; }
+  catch (const CommError &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
 }
 gr_status gr_bal_schur_update_values(gr_bal_problem *p) { return guarded(p, [&] { p->e->schur_update_values(); }); }
@@ -1864,6 +1884,95 @@ gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int ran
     p->e->set_comm(std::unique_ptr<Comm>(new RcclComm(unique_id_128, rank, world_size)));
     return GR_OK;
   } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
+}
+gr_status gr_bal_comm_ipc_mailbox(gr_bal_problem *p, size_t slot_bytes, int world_size, void *handle_64) {
+  if (!p || !p->e || !handle_64 || world_size < 1 || world_size > 64 || slot_bytes < 1024) { g_last_error = "gr_bal_comm_ipc_mailbox: bad argument"; return GR_ERR_INVALID; }
+  try {
+    GR_HIP(hipSetDevice(p->e->device));
+    slot_bytes = (slot_bytes + 255) / 256 * 256;
+    const size_t bytes = IpcComm::mailbox_bytes(world_size, slot_bytes);
+    char *box = nullptr;
+    GR_HIP(hipMalloc(reinterpret_cast<void **>(&box), bytes));
+    GR_HIP(hipMemset(box, 0, bytes));
+    GR_HIP(hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    GR_HIP(hipIpcGetMemHandle(&h, box));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    std::memcpy(handle_64, &h, 64);
+    if (p->e->ipc_box) (void)hipFree(p->e->ipc_box);
+    p->e->ipc_box = box; p->e->ipc_slot = slot_bytes; p->e->ipc_world = world_size;
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
+}
+gr_status gr_bal_comm_init_ipc(gr_bal_problem *p, const void *handles, int rank, int world_size, const void *unique_id_128, int *used_ipc) {
+  if (!p || !p->e || !handles || rank < 0 || rank >= world_size || !p->e->ipc_box || p->e->ipc_world != world_size) { g_last_error = "gr_bal_comm_init_ipc: bad argument (call gr_bal_comm_ipc_mailbox first)"; return GR_ERR_INVALID; }
+  try {
+    GR_HIP(hipSetDevice(p->e->device));
+    // the fallback first: it is also what the ranks agree through, so nothing below may leave a rank before it has
+    // taken part in the agreement (a rank that returned early would leave its peers waiting in that all-reduce)
+    std::unique_ptr<Comm> rccl;
+    if (unique_id_128) rccl.reset(new RcclComm(unique_id_128, rank, world_size));
+    std::unique_ptr<IpcComm> ipc;
+    bool ok = true;
+    std::string why;
+    try {
+      std::vector<char *> boxes(world_size, nullptr);
+      std::vector<bool> opened(world_size, false);
+      for (int r = 0; r < world_size && ok; ++r) {
+        if (r == rank) { boxes[r] = p->e->ipc_box; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, static_cast<const char *>(handles) + 64 * (size_t)r, 64);
+        void *q = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { (void)hipGetLastError(); ok = false; why = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e); break; }
+        boxes[r] = static_cast<char *>(q); opened[r] = true;
+      }
+      if (ok) {
+        ipc.reset(new IpcComm(rank, world_size, p->e->ipc_slot, boxes, opened));
+        p->e->ipc_box = nullptr; // owned by the communicator from here on
+        // start-up verification on the real topology: known values, three sizes, both mailbox sets
+        const size_t maxn = ipc->slot_bytes / sizeof(double);
+        const double S = 0.5 * world_size * (world_size + 1);
+        for (size_t nn : {(size_t)3, std::min<size_t>(1000, maxn), maxn}) {
+          std::vector<double> h(nn);
+          for (size_t i = 0; i < nn; ++i) h[i] = (double)(rank + 1) * (double)(i % 7 + 1);
+          DevBuf<double> d;
+          d.upload(h, nullptr);
+          ipc->allreduce(d.p, nn, true, nullptr);
+          h = d.download(nullptr);
+          for (size_t i = 0; i < nn && ok; ++i) ok = h[i] == S * (double)(i % 7 + 1);
+          if (ipc->failed()) ok = false;
+          if (!ok) { why = "self-test: wrong sum or time-out"; break; }
+        }
+      } else {
+        for (int r = 0; r < world_size; ++r) if (opened[r]) (void)hipIpcCloseMemHandle(boxes[r]);
+      }
+    } catch (const std::exception &ex) { ok = false; why = ex.what(); }
+    if (rccl) { // agree: everybody uses the mailboxes, or nobody does
+      DevBuf<double> flag;
+      flag.upload(std::vector<double>{ok ? 1.0 : 0.0}, nullptr);
+      rccl->allreduce(flag.p, 1, true, nullptr);
+      ok = flag.download(nullptr)[0] == (double)world_size;
+      if (!ok) {
+        ipc.reset();
+        p->e->set_comm(std::move(rccl));
+        if (used_ipc) *used_ipc = 0;
+        return GR_OK;
+      }
+      ipc->fallback = std::move(rccl);
+    } else if (!ok) throw std::runtime_error("IPC all-reduce unavailable (" + why + ") and there is no fallback communicator");
+    p->e->set_comm(std::move(ipc));
+    if (used_ipc) *used_ipc = 1;
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
+}
+gr_status gr_bal_comm_allreduce_host(gr_bal_problem *p, double *v, size_t n) {
+  if (!p || !p->e || !v) { g_last_error = "gr_bal_comm_allreduce_host: bad argument"; return GR_ERR_INVALID; }
+  try { GR_HIP(hipSetDevice(p->e->device)); p->e->allreduce_host(v, n); return GR_OK; }
+  catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
 }
 // TEST ONLY: join `n` problems of THIS process (same GPU) into an in-process group; afterwards

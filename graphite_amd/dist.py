@@ -63,6 +63,38 @@ def init_comm(problem, rank: int, world: int):
     _lib.check(lib.gr_bal_comm_init(problem.h, buf, C.c_int(rank), C.c_int(world)))
 
 
+def init_comm_ipc(problem, rank: int, world: int, slot_bytes: int = 4 << 20, rccl_fallback: bool = True):
+    """One-shot peer all-reduce over IPC-mapped mailboxes (csrc/comm.hpp IpcComm), RCCL for messages beyond `slot_bytes`.
+    The 64-byte mailbox handles are gathered with torch.distributed (any backend).  Returns True when the mailboxes are in
+    use, False when the start-up verification failed somewhere and every rank fell back to RCCL."""
+    import torch
+    import torch.distributed as dist
+    lib = _lib.lib()
+    mine = (C.c_char * 64)()
+    _lib.check(lib.gr_bal_comm_ipc_mailbox(problem.h, C.c_size_t(slot_bytes), C.c_int(world), mine))
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.frombuffer(bytearray(mine.raw), dtype=torch.uint8).clone()
+    if on_gpu:
+        t = t.cuda()
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    raw = b"".join(bytes(g.cpu().numpy().tobytes()) for g in gathered)
+    handles = (C.c_char * (64 * world)).from_buffer_copy(raw)
+    uid = None
+    if rccl_fallback:
+        u = (C.c_char * 128)()
+        if rank == 0:
+            _lib.check(lib.gr_comm_unique_id(u))
+        tu = torch.frombuffer(bytearray(u.raw), dtype=torch.uint8).clone()
+        if on_gpu:
+            tu = tu.cuda()
+        dist.broadcast(tu, src=0)
+        uid = (C.c_char * 128).from_buffer_copy(bytes(tu.cpu().numpy().tobytes()))
+    used = C.c_int(0)
+    _lib.check(lib.gr_bal_comm_init_ipc(problem.h, handles, C.c_int(rank), C.c_int(world), uid, C.byref(used)))
+    return bool(used.value)
+
+
 def init_local_group(problems):
     """TEST ONLY: in-process group of shards on one GPU (one host thread per shard afterwards)."""
     lib = _lib.lib()

@@ -213,6 +213,17 @@ gr_status gr_bal_kernel_stats(gr_bal_problem *p, gr_kernel_stat *out, int cap, i
  * rank 0 by gr_comm_unique_id and broadcast by the caller (e.g. torch.distributed). */
 gr_status gr_comm_unique_id(void *unique_id_128);
 gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int rank, int world_size);
+/* One-shot peer all-reduce for the small messages of this solver (csrc/comm.hpp IpcComm): every rank owns a mailbox in its
+ * HBM that every peer maps (hipIpcMemHandle) and writes into directly over xGMI; an all-reduce is one hop instead of a
+ * ring.  (1) every rank calls gr_bal_comm_ipc_mailbox and gets the 64-byte handle of its mailbox; (2) the caller
+ * gathers the handles of all ranks, rank order (e.g. torch.distributed.all_gather); (3) every rank calls
+ * gr_bal_comm_init_ipc with the world_size x 64 bytes.  Messages larger than slot_bytes travel through RCCL
+ * (unique_id_128 as for gr_bal_comm_init; NULL = no fallback, such a message is then an error).  With a fallback the
+ * mailboxes are verified at start-up by all-reducing known values; if any rank sees a wrong sum or a time-out, every rank
+ * drops to RCCL alone.  *used_ipc (optional) reports the outcome. */
+gr_status gr_bal_comm_ipc_mailbox(gr_bal_problem *p, size_t slot_bytes, int world_size, void *handle_64);
+gr_status gr_bal_comm_init_ipc(gr_bal_problem *p, const void *handles_world_x_64, int rank, int world_size,
+                               const void *unique_id_128, int *used_ipc);
 /* Dense SPD solve A x = b on the MFMA Cholesky that GR_SOLVER_DENSE_SCHUR uses (the numerical role of
  * Eigen::SimplicialLDLT in src/eigen_solver.cpp:8-30 / cuDSS in solver/cudss.hpp:183-256 once S is dense).
  * A: n x n row-major, leading dimension lda, lower triangle read; A, b, x host or device pointers (x may

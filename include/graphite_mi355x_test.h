@@ -11,6 +11,9 @@ extern "C" {
 /* in-process group of `n` landmark shards on ONE GPU, one host thread per shard afterwards: exercises the
  * sharded algorithm on a 1-GPU box (the product communicator is gr_bal_comm_init, RCCL) */
 gr_status gr_bal_comm_init_local(gr_bal_problem **problems, int n);
+/* all-reduce `n` doubles (host buffer, in place) through the problem's communicator: checks a transport against a
+ * host sum (tests/test_gpu_ipc.py) */
+gr_status gr_bal_comm_allreduce_host(gr_bal_problem *p, double *host_values, size_t n);
 /* mean device time (us) of `reps` back-to-back launches of one hot kernel (tools/diag_*.py) */
 double gr_bal_diag_time(gr_bal_problem *p, int which, int variant, int reps);
 #ifdef __cplusplus

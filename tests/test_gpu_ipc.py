@@ -1,0 +1,85 @@
+"""The one-shot peer all-reduce (csrc/comm.hpp IpcComm) between REAL processes.
+
+Two fresh child processes share the one GPU of the box, map each other's mailbox through
+hipIpcMemHandle (handles exchanged over a gloo process group) and run the landmark-sharded solve
+with every all-reduce going through the mailboxes.  Checked against host sums of the same
+vectors and against the unsharded solve in this process."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import graphite_amd as ga
+from graphite_amd import dist as gdist, synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_workers(world, tmp_path, env_extra=None):
+    port = free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "ipc_worker.py"), str(r), str(world), str(port), outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    try:
+        for p in procs:
+            logs.append(p.communicate(timeout=240)[0])
+    finally:
+        for p in procs:          # exactly the children started above
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    return [json.load(open(o)) for o in outs]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ipc_allreduce_between_processes(world, tmp_path):
+    slot = 1 << 16
+    res = run_workers(world, tmp_path, {"GR_TEST_IPC_SLOT": str(slot)})
+    # raw all-reduces: every rank holds the rank-order sum of what the ranks put in, bit for bit
+    for k, n in enumerate((1, 2, 63, 64, 65, 1000, slot // 8)):
+        want = np.zeros(n)
+        for r in range(world):
+            want = want + np.random.default_rng(1000 * n + r).standard_normal(n)
+        for r in range(world):
+            assert np.array_equal(np.array(res[r]["sums"][k]), want), (n, r)
+    # a message beyond the slot without a fallback communicator is an error, not a silent truncation
+    assert all(r["oversize_rc"] != 0 for r in res)
+
+    prob = synth.make_config("mini-50")
+    ranges = gdist.point_ranges(prob.pt_idx, prob.shape[1], world)
+    for dtype, tag, solver, sname in ((np.float64, "f64", ga.SOLVER_PCG, "pcg"),
+                                      (np.float64, "f64", ga.SOLVER_PCG_SCHUR_IMPLICIT, "implicit"),
+                                      (np.float32, "f32", ga.SOLVER_PCG, "pcg")):
+        single = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+        ct, lt, st = single.levenberg_marquardt(solver=solver, iterations=8)
+        c1, p1 = single.get_params()
+        single.close()
+        key = f"{tag}_{sname}"
+        rt, at = (1e-9, 1e-7) if tag == "f64" else (2e-3, 2e-3)
+        pts = np.concatenate([np.array(res[r][key]["pts"]) for r in range(world)])
+        for r in range(world):
+            got = res[r][key]
+            n = min(len(got["chi2"]), len(ct)) if tag == "f32" else len(ct)
+            assert np.allclose(got["chi2"][:n], ct[:n], rtol=rt), (key, r, got["chi2"], ct)
+            assert got["cams"] == res[0][key]["cams"]                    # replicas identical across PROCESSES
+            assert got["collectives"] == res[0][key]["collectives"] > 0
+            if tag == "f64":
+                assert got["pcg_iterations"] == st["pcg_iterations"]
+        if tag == "f64":
+            assert np.allclose(np.array(res[0][key]["cams"]), c1, rtol=at, atol=1e-10)
+            assert np.allclose(pts, p1, rtol=at, atol=1e-10)
+        assert [len(res[r][key]["pts"]) for r in range(world)] == [b - a for a, b in ranges]
