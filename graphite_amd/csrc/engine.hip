@@ -113,6 +113,23 @@ template <typename T> struct Engine final : EngineBase {
   const int *o_pos() const { return tiled ? t_pos.p : pos_cm.p; }
   const T *o_obs() const { return tiled ? t_obs.p : obs_cm.p; }
   int o_ntiles() const { return tiled ? -nb_pm : nb_pm; }
+  // g3 (the operator's per-observation J_p^T w) in observation order, gathered by the update kernel: kernels_mf.hpp G3Gather
+  bool g3_obs_order = false;
+  // GR_G3_GATHER=0/1 forces it.  Default: with the point-tiled order only, i.e. on graphs whose g3 does not stay in the
+  // caches between the operator and the update kernel.  There the scattered 12/24-byte stores of the pm layout left L2
+  // one by one (Venice-1778 fp32, rocprofv3: 5.46 M store requests in, 4.94 M memory writes out, 242 MB for 60 MB of
+  // payload); in observation order the operator fell from 176 to 86 us inside the solve and the update kernel rose from
+  // 83 to 105 us (Final-13682 fp64: 1481 -> 786 and 472 -> 712).  Ladybug-1723 (everything cache-resident, plain order):
+  // operator 23.1 -> 20.5 us, update 20.3 -> 23.7 us, no gain, so it keeps the pm layout.
+  bool want_g3_gather() const { const char *e = getenv("GR_G3_GATHER"); return e ? atoi(e) == 1 : tiled; }
+  DevBuf<int> g3_gidx, ptile_ptr;
+  int g3_ptiles = 0;
+  const int *g3_pos() const { return g3_obs_order ? nullptr : o_pos(); }
+  G3Gather g3_gather() const { G3Gather g; if (g3_obs_order) { g.gidx = g3_gidx.p; g.ptile_ptr = ptile_ptr.p; g.n_ptiles = g3_ptiles; } return g; }
+  int update_blocks() const {
+    const int b = std::min(cdiv(pose_dim, 252) + cdiv(Np, 85), num_cu * 8);
+    return g3_obs_order ? std::max(8, (b + 7) / 8 * 8) : b;
+  }
   // multi-GPU: landmark shard of a larger problem (comm != null), camera rows all-reduced
   std::unique_ptr<Comm> comm;
   bool shard = false;
@@ -398,14 +415,34 @@ template <typename T> struct Engine final : EngineBase {
     build_segments(h_cam, K);
     cam_partial.alloc(54 * (size_t)nseg); op_partial.alloc(9 * (size_t)nseg);
     tiled = true;
+    g3_obs_order = false;
     GR_HIP(hipStreamSynchronize(stream));
   }
   void untile() {
     if (!tiled) return;
     tiled = false;
+    g3_obs_order = false;
     std::vector<int> h_cam_cm = cam_cm.download(stream);
     build_segments(h_cam_cm, 0);
     cam_partial.alloc(54 * (size_t)nseg); op_partial.alloc(9 * (size_t)nseg);
+  }
+  // g3 in observation order + XCD-matched point sweep of the update kernel (G3Gather), for the CURRENT observation order.
+  // Point tiles: the tiled order's own; in the plain order 8 ranges of equal observation count (XCD x walks the x-th eighth
+  // of the camera-major observations, and points are numbered by first camera, so its points are mostly the x-th range).
+  void build_g3_gather() {
+    std::vector<int> pos = (tiled ? t_pos : pos_cm).download(stream), gidx(No);
+    for (int64_t j = 0; j < No; ++j) gidx[pos[j]] = (int)j;
+    const int K = tiled ? n_ptiles : 8;
+    std::vector<int> pp(K + 1, (int)Np);
+    pp[0] = 0;
+    for (int64_t l = 0, t = 0; l < Np; ++l) {
+      const int tl = (int)std::min<int64_t>(K - 1, (int64_t)h_pt_ptr[l] * K / No);
+      while (t < tl) pp[++t] = (int)l;
+    }
+    g3_gidx.upload(gidx, stream); ptile_ptr.upload(pp, stream);
+    g3_ptiles = K;
+    g3_obs_order = true;
+    GR_HIP(hipStreamSynchronize(stream));
   }
   // decided once per problem, by timing: GR_PTILES = number of point tiles (0 = plain order) forces it
   bool tiling_tuned = false;
@@ -426,11 +463,11 @@ template <typename T> struct Engine final : EngineBase {
     if (K <= 0) return;
     K = std::max(8, (K + 7) / 8 * 8);
     const bool forced = getenv("GR_PTILES") != nullptr;
-    const double t_plain = forced ? 0.0 : diag_time(0, 0, 5) + diag_time(1, 0, 5);
+    const double t_plain = forced ? 0.0 : diag_time(0, 0, 5) + diag_time(1, 0, 5) + diag_time(3, 0, 5);
     build_tiled_order(K);
     if (!forced) {
-      const double t_tiled = diag_time(0, 0, 5) + diag_time(1, 0, 5);
-      if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] operator + linearise: %.1f us plain order, %.1f us with %d point tiles -> %s\n", t_plain, t_tiled, K, t_tiled < 0.95 * t_plain ? "tiled" : "plain");
+      const double t_tiled = diag_time(0, 0, 5) + diag_time(1, 0, 5) + diag_time(3, 0, 5);
+      if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] operator + linearise + update: %.1f us plain order, %.1f us with %d point tiles -> %s\n", t_plain, t_tiled, K, t_tiled < 0.95 * t_plain ? "tiled" : "plain");
       if (!(t_tiled < 0.95 * t_plain)) untile();
     }
   }
@@ -771,6 +808,7 @@ template <typename T> struct Engine final : EngineBase {
       v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
       MinvC.alloc(81 * (size_t)Nc); MinvP.alloc(9 * (size_t)Np);
       if (!tiling_tuned) tune_tiling();
+      if (want_g3_gather() && !g3_obs_order) build_g3_gather(); // rebuilt whenever the observation order has changed
       if (!records_tuned) tune_point_records();
     }
   }
@@ -1068,7 +1106,17 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   template <typename JT> void launch_operator_j(PcgState st, int k, const T *rec, const LmDev *lm, double mu) {
-    k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
+#ifdef GR_DIAG
+    { // diagnostic builds: GR_OP_VAR=1|2|3 runs an ablated operator INSIDE the solve (wrong numbers, real cache state)
+      static const int var = getenv("GR_OP_VAR") ? atoi(getenv("GR_OP_VAR")) : 0;
+#define GR_OPV(V) k_pcg_operator<T, V, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm)
+      if (var == 1) { GR_OPV(1); return; }
+      if (var == 2) { GR_OPV(2); return; }
+      if (var == 3) { GR_OPV(3); return; }
+#undef GR_OPV
+    }
+#endif
+    k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
   }
   void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
@@ -1109,10 +1157,10 @@ template <typename T> struct Engine final : EngineBase {
     h_seq[1] = 0;
     if (!started && state_fresh_cap != ctl_cap) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap); // else reset by k_block_jacobi
     state_fresh_cap = -1;
-    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, 85), num_cu * 8);
+    const int ublocks = update_blocks();
     const T *rawc = comm ? raw_c.p : nullptr;
     const int cw = cam_weight();
-    if (!started) k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
+    if (!started) k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, nullptr, g3_gather());
     if (comm) allreduce_d(st.acc, 4 * (size_t)NSW); // record 0: RZP, RR, PDZ, ZDZ
     k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, rec);
     auto enqueue = [&](int k) {
@@ -1129,7 +1177,7 @@ template <typename T> struct Engine final : EngineBase {
       }
       {
         Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
-        k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k);
+        k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
       }
       if (comm) allreduce_d(st.acc + (size_t)(k + 1) * NSLOT * NSW, 4 * (size_t)NSW);
       {
@@ -1153,16 +1201,16 @@ template <typename T> struct Engine final : EngineBase {
     ensure_point_records();
     PcgState st = pcg_state();
     const int ui = 0;
-    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, 85), num_cu * 8);
+    const int ublocks = update_blocks();
     k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
-    k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
+    k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, nullptr, g3_gather());
     k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr);
     hipEvent_t a, b;
     GR_HIP(hipEventCreate(&a)); GR_HIP(hipEventCreate(&b));
     auto launch = [&] {
       switch (which) {
       case 0:
-#define GR_OP(V) k_pcg_operator<T, V><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0, use_records ? xp.p : nullptr)
+#define GR_OP(V) k_pcg_operator<T, V><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0, use_records ? xp.p : nullptr)
 #ifdef GR_DIAG
         switch (variant) { case 1: GR_OP(1); break; case 2: GR_OP(2); break; case 4: GR_OP(4); break; case 7: GR_OP(7); break; case 8: GR_OP(8); break; case 15: GR_OP(15); break; case 16: GR_OP(16); break; case 31: GR_OP(31); break;
                            case 32: GR_OP(32); break; case 64: GR_OP(64); break; case 128: GR_OP(128); break; case 3: GR_OP(3); break; case 95: GR_OP(95); break; case 255: GR_OP(255); break; case 224: GR_OP(224); break; default: GR_OP(0); }
@@ -1181,8 +1229,9 @@ template <typename T> struct Engine final : EngineBase {
       case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
       case 3: { // variant 1: camera part only, 2: point part only, >= 8: that many blocks
         const int nc_v = variant == 2 ? 0 : (int)Nc, np_v = variant == 1 ? 0 : (int)Np;
-        const int ub = variant >= 8 ? variant : std::max(1, std::min(cdiv(9 * (size_t)nc_v, 252) + cdiv(np_v, 85), num_cu * 8));
-        k_pcg_update<T, 1, false><<<ub, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0);
+        int ub = variant >= 8 ? variant : std::max(1, std::min(cdiv(9 * (size_t)nc_v, 252) + cdiv(np_v, 85), num_cu * 8));
+        if (g3_obs_order) ub = std::max(8, (ub + 7) / 8 * 8); // the point sweep deals workgroups to XCDs by blockIdx % 8
+        k_pcg_update<T, 1, false><<<ub, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, nullptr, g3_gather());
         break;
       }
       case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr); break;
@@ -1436,14 +1485,14 @@ template <typename T> struct Engine final : EngineBase {
     T *rec = use_records ? xp.p : nullptr;
     const int nbc = cdiv(Nc, 64), nbp = cdiv(Np, 64);
     k_block_jacobi<T><<<nbc + nbp + 1, 64, 0, stream>>>((int)Nc, (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, 0.0, ui, MinvC.p, MinvP.p, v_diag.p, stt, ctl_cap, lm);
-    const int ublocks = std::min(cdiv(pose_dim, 252) + cdiv(Np, 85), num_cu * 8);
+    const int ublocks = update_blocks();
     T *x = v_dx.p;
-    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, 0.0, ui, MinvC.p, MinvP.p, stt, 0, lm);
+    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, 0.0, ui, MinvC.p, MinvP.p, stt, 0, lm, g3_gather());
     k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, -1, 0.0, 1e30, (unsigned)pose_dim, rec, lm, 0, nullptr);
     const int unroll = std::max(1, std::min(lm_unroll, max_iter));
     for (int k = 0; k < unroll; ++k) {
       launch_operator(stt, k, rec, lm, 0.0);
-      k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, 0.0, ui, MinvC.p, MinvP.p, stt, k, lm);
+      k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, 0.0, ui, MinvC.p, MinvP.p, stt, k, lm, g3_gather());
       // past the unrolled iterations the loop must have left, unless max_iter itself ends it
       k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, k, tol, rej, (unsigned)pose_dim, rec, lm, (k == unroll - 1 && unroll < max_iter) ? 1 : 0, h_lm + 1);
     }

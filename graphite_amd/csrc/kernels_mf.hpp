@@ -654,14 +654,14 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
   bool valid = t0 < t1 && j < No;
   int c_n = -1, l_n = 0, a_n = 0;
   V2 o_n{};
-  if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm[j]; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
+  if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm ? pos_cm[j] : j; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
   for (int t = t0; t < t1; t += tstep) {
     const int c = c_n, l = l_n;
     const size_t a = (size_t)a_n;
     const V2 o = o_n;
     const int jn = j + tstep * TPB;
     const bool validn = (t + tstep < t1) && jn < No;
-    if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm[jn]; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
+    if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm ? pos_cm[jn] : jn; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
 #if OP_SGPR
     // Wave-uniform camera data (24-scalar pack, 9 direction scalars, segment id) are fetched per DISTINCT
     // camera of the wave through a uniform index, i.e. with scalar loads into SGPRs: the kernel keeps its
@@ -788,6 +788,13 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
   if (threadIdx.x == 0) slot_add(st.slots(k, DEN), 0, den);
 }
 
+// g3 kept in OBSERVATION order (the operator's stores are then whole lines: a wave writes 64 consecutive 3-vectors) and
+// gathered per point by the update kernel through gidx (pm position -> observation-order position).  The update kernel
+// then walks the points as the operator walked their observations: point tile q (points [ptile_ptr[q], ptile_ptr[q+1]))
+// belongs to XCD q % 8 and that XCD's workgroups sweep it together, so the lines one XCD wrote are read back by the
+// same XCD while they are still in its L2.  gidx == nullptr: g3 in pm order, points in contiguous ranges per workgroup.
+struct G3Gather { const int *gidx = nullptr; const int *ptile_ptr = nullptr; int n_ptiles = 0; };
+
 // x / r / z' update of the matrix-free PCG.
 // Persistent blocks walk contiguous ranges of
 //   camera tiles: 252 camera scalars (28 cameras) — fixed-order sum of the segment partials,
@@ -806,7 +813,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
              const int *__restrict__ cam_seg_ptr, const T *__restrict__ raw_c, int cam_weight,
              const T *__restrict__ diag, double mu, int use_identity,
              const T *__restrict__ MinvC, const T *__restrict__ MinvP, PcgState st, int k,
-             const LmDev *__restrict__ lm = nullptr) {
+             const LmDev *__restrict__ lm = nullptr, G3Gather gg = G3Gather{}) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
   T alpha = 0;
   if (MODE == 1) {
@@ -870,11 +877,23 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
   // point tiles: 85 points = 255 scalars per tile, one thread per SCALAR so that every load and store is a
   // contiguous run over the wave (a thread per point reads 3-scalar groups 24 bytes apart: three times the
   // address-processing work for the same bytes); the 3 x 3 block-Jacobi goes through LDS like the camera part
-  const int pt0 = (int)((long long)blockIdx.x * pt_tiles / gridDim.x), pt1 = (int)((long long)(blockIdx.x + 1) * pt_tiles / gridDim.x);
   const unsigned lt = threadIdx.x / 3u, li = threadIdx.x % 3u;
-  for (int tile = pt0; tile < pt1; ++tile) {
-    const unsigned l = (unsigned)tile * 85u + lt;
-    const bool on = threadIdx.x < 255 && l < (unsigned)Np;
+  const bool sweep = gg.n_ptiles > 0; // gridDim.x is then a multiple of 8
+  const int pt0 = sweep ? 0 : (int)((long long)blockIdx.x * pt_tiles / gridDim.x), pt1 = sweep ? 0 : (int)((long long)(blockIdx.x + 1) * pt_tiles / gridDim.x);
+  int q = (int)(blockIdx.x & 7), tile = sweep ? (int)(blockIdx.x >> 3) : pt0;
+  unsigned P0 = 0, P1 = (unsigned)Np;
+  if (sweep && q < gg.n_ptiles) { P0 = (unsigned)gg.ptile_ptr[q]; P1 = (unsigned)gg.ptile_ptr[q + 1]; }
+  for (;;) {
+    if (sweep) {
+      while (q < gg.n_ptiles && P0 + 85u * (unsigned)tile >= P1) { // next point tile of this XCD
+        q += 8; tile = (int)(blockIdx.x >> 3);
+        if (q < gg.n_ptiles) { P0 = (unsigned)gg.ptile_ptr[q]; P1 = (unsigned)gg.ptile_ptr[q + 1]; }
+      }
+      if (q >= gg.n_ptiles) break;
+    } else if (tile >= pt1) break;
+    const unsigned l = P0 + (unsigned)tile * 85u + lt;
+    const bool on = threadIdx.x < 255 && l < P1;
+    tile += sweep ? (int)(gridDim.x >> 3) : 1;
     const size_t t = (size_t)pose_dim + 3 * (size_t)l + li;
     T rn = 0, pv = 0, m0 = 0, m1 = 0, m2 = 0, dg = T(1);
     if (on) {
@@ -891,12 +910,21 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         int a = pt_ptr[l];
         const int a_end = pt_ptr[l + 1];
 #if UPD_VAR != 1
+        if (gg.gidx) {
+          for (; a + 4 <= a_end; a += 4) { // same order of the sum; the slots sit where the operator's wave wrote them
+            const int j0 = gg.gidx[a], j1 = gg.gidx[a + 1], j2 = gg.gidx[a + 2], j3 = gg.gidx[a + 3];
+            const T g0 = g3[3 * (size_t)j0 + li], g1 = g3[3 * (size_t)j1 + li], g2 = g3[3 * (size_t)j2 + li], g3v = g3[3 * (size_t)j3 + li];
+            raw += g0; raw += g1; raw += g2; raw += g3v;
+          }
+          for (; a < a_end; ++a) raw += g3[3 * (size_t)gg.gidx[a] + li];
+        } else {
         for (; a + 4 <= a_end; a += 4) { // 4 independent loads in flight, the sum stays in observation order
           const T *gp = g3 + 3 * (size_t)a + li;
           const T g0 = gp[0], g1 = gp[3], g2 = gp[6], g3v = gp[9];
           raw += g0; raw += g1; raw += g2; raw += g3v;
         }
         for (; a < a_end; ++a) raw += g3[3 * (size_t)a + li];
+        }
 #else
         raw = (T)(a_end - a);
 #endif

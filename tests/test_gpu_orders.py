@@ -1,6 +1,7 @@
 """The alternative observation orders / operator forms the engine picks by timing on large graphs, FORCED on small
 problems so that they are held to the oracle like the default path:
   GR_PTILES=K   point-tiled (tile, camera, point) order of the per-observation kernels (Engine::build_tiled_order)
+  GR_G3_GATHER=1  operator output kept in observation order, gathered per point by the update kernel (G3Gather)
 Every solver, the LM traces, the sharded run."""
 import threading
 
@@ -12,12 +13,14 @@ from graphite_amd import dist as gdist, synth
 
 pytestmark = pytest.mark.gpu
 
-MODES = {"tiled8": {"GR_PTILES": "8"}, "tiled24": {"GR_PTILES": "24"}, "plain": {"GR_PTILES": "0"}}
+MODES = {"tiled8_pm": {"GR_PTILES": "8", "GR_G3_GATHER": "0"}, "tiled24_pm": {"GR_PTILES": "24", "GR_G3_GATHER": "0"},
+         "plain": {"GR_PTILES": "0"}, "plain_gather": {"GR_PTILES": "0", "GR_G3_GATHER": "1"},
+         "tiled8": {"GR_PTILES": "8"}, "tiled24": {"GR_PTILES": "24"}}  # tiled default: g3 in observation order
 SOLVERS = ["pcg", "pcg_identity", "pcg_schur_implicit", "pcg_schur", "dense_schur"]
 
 
 def setenv(monkeypatch, mode):
-    for k in ("GR_PTILES",):
+    for k in ("GR_PTILES", "GR_G3_GATHER"):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -50,7 +53,7 @@ def test_lm_trace_matches_oracle(oracle_mod, monkeypatch, name, dtype, solver, m
         assert abs(ct[-1] - ct_r[-1]) / ct_r[-1] < 2e-3
 
 
-@pytest.mark.parametrize("mode", ["tiled8", "tiled24"])
+@pytest.mark.parametrize("mode", ["tiled8", "tiled24", "plain_gather", "tiled8_pm", "tiled24_pm"])
 def test_solver_solve_matches_oracle_pcg(oracle_mod, monkeypatch, mode):
     setenv(monkeypatch, mode)
     prob = synth.make_config("mini-50")
@@ -121,3 +124,23 @@ def test_sharded_run_with_forced_orders(monkeypatch, mode):
     [e.close() for e in engines]
     assert np.allclose(out[0][0], ct, rtol=1e-9)
     assert np.array_equal(cams[0], cams[1])
+
+
+def test_g3_layouts_agree_bitwise_at_full_size(monkeypatch):
+    """Venice-1778 fp32 at full size, tiling chosen by the engine's own tuner: the PCG iterates with the operator output in
+    observation order (gathered by the update kernel, XCD-matched point sweep) equal those of the pm layout bit for bit —
+    the per-point sums run over the same values in the same order, only where they are stored differs."""
+    prob = synth.make_config("venice-1778")
+    out = {}
+    for g in ("0", "1"):
+        monkeypatch.delenv("GR_PTILES", raising=False)
+        monkeypatch.setenv("GR_G3_GATHER", g)
+        e = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float32)
+        e.solver_update_structure(ga.SOLVER_PCG)
+        e.linearize()
+        e.solver_update_values(ga.SOLVER_PCG)
+        e.solver_set_damping(ga.SOLVER_PCG, 1e-4)
+        out[g] = e.solver_solve(ga.SOLVER_PCG, max_iter=5, tol=0.0, rej=1e30)
+        e.close()
+    assert out["0"][1] == out["1"][1] == 5
+    assert np.array_equal(out["0"][0], out["1"][0])

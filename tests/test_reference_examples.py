@@ -47,18 +47,25 @@ def _need(name):
 
 @pytest.mark.gpu
 def test_reference_circle_runs():
-    out = subprocess.run([_need("circle")], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr
-    # circle.cu prints the optimised points with their radius: every free point ends on the circle of radius 4
-    before = {int(k): float(r) for k, r in re.findall(r"Adding point (\d+)=.*radius=([0-9.eE+-]+)", out.stdout)}
-    after = {int(k): float(r) for k, r in re.findall(r"Optimized point (\d+)=.*radius=([0-9.eE+-]+)", out.stdout)}
-    assert sorted(after) == [0, 1, 2, 3, 4], out.stdout[-1500:]
-    for k in (0, 1, 3):
-        # free points with an active factor end on the circle (random start, std::random_device: the LM loop may leave
-        # on "Rho is zero" a step early, levenberg_marquardt.hpp:228-231)
-        assert abs(after[k] - 4.0) < 0.05 and abs(after[k] - 4.0) <= abs(before[k] - 4.0)
-    for k in (2, 4):
-        assert abs(after[k] - before[k]) < 1e-5    # "points 2 and 4 should remain unchanged" (factor off / vertex fixed)
+    # circle.cu starts from std::random_device points: an unlucky start can leave the LM loop early on "Rho is zero"
+    # (levenberg_marquardt.hpp:228-231) before the points reach the circle, so a failed attempt is repeated with a new start
+    problems = []
+    for attempt in range(5):
+        out = subprocess.run([_need("circle")], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        # circle.cu prints the optimised points with their radius: every free point ends on the circle of radius 4
+        before = {int(k): float(r) for k, r in re.findall(r"Adding point (\d+)=.*radius=([0-9.eE+-]+)", out.stdout)}
+        after = {int(k): float(r) for k, r in re.findall(r"Optimized point (\d+)=.*radius=([0-9.eE+-]+)", out.stdout)}
+        assert sorted(after) == [0, 1, 2, 3, 4], out.stdout[-1500:]
+        # "points 2 and 4 should remain unchanged" (factor off / vertex fixed): holds for every start
+        for k in (2, 4):
+            assert abs(after[k] - before[k]) < 1e-5
+        bad = [(k, before[k], after[k]) for k in (0, 1, 3)
+               if not (abs(after[k] - 4.0) < 0.05 and abs(after[k] - 4.0) <= abs(before[k] - 4.0) + 1e-12)]
+        if not bad:
+            return
+        problems.append(bad)
+    raise AssertionError(f"free points did not reach the circle of radius 4 in 5 random starts: {problems}")
 
 
 @pytest.mark.gpu
