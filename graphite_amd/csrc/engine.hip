@@ -114,6 +114,21 @@ template <typename T> struct Engine final : EngineBase {
   const T *o_obs() const { return tiled ? t_obs.p : obs_cm.p; }
   int o_ntiles() const { return tiled ? -nb_pm : nb_pm; }
   // g3 (the operator's per-observation J_p^T w) in observation order, gathered by the update kernel: kernels_mf.hpp G3Gather
+  // Lazy PCG direction (kernels_mf.hpp PcgState): default on; GR_PCG_LAZY=0 keeps the direction kernel's vector pass.
+  // GR_PCG_LAZY=0/1 forces it.  Measured A/B on one box (LM it/s, bench line): Ladybug-49 fp32 13 230 -> 14 000,
+  // Ladybug-1723 fp64 5 060 -> 5 100, Venice-1778 fp32 1 165 -> 1 210, Final-13682 fp64 148.5 -> 139.9: the direction
+  // kernel's pass over five n-vectors goes, but the update kernel stores three more vectors (p, s.*p, s.*z') and the operator
+  // gathers two per point instead of one, so it pays where launches matter and costs where bytes do.  Default: vectors up
+  // to 16 MB.  Off in the opt-in graph-replay mode and in diagnostic builds (their kernels are the direction-kernel form).
+  bool pcg_lazy() const {
+#ifdef GR_DIAG
+    return false; // the ablation variants of tools/diag_*.py are instantiated for the direction-kernel form only
+#endif
+    if (lm_graph_enabled) return false;
+    if (const char *e = getenv("GR_PCG_LAZY")) return atoi(e) != 0;
+    return n * sizeof(T) <= ((size_t)16 << 20);
+  }
+  DevBuf<T> v_zs;
   bool g3_obs_order = false;
   // GR_G3_GATHER=0/1 forces it.  Default: with the point-tiled order only, i.e. on graphs whose g3 does not stay in the
   // caches between the operator and the update kernel.  There the scattered 12/24-byte stores of the pm layout left L2
@@ -185,6 +200,7 @@ template <typename T> struct Engine final : EngineBase {
   void tune_point_records() {
     if (records_tuned) return;
     records_tuned = true;
+    if (pcg_lazy()) { use_records = false; return; } // the lazy direction gathers ps and zs; the 8-scalar record has room for one
     if (const char *e = getenv("GR_POINT_RECORDS")) { use_records = atoi(e) != 0; return; }
     use_records = false;
     const double t_plain = diag_time(0, 0, 5);
@@ -1116,11 +1132,17 @@ template <typename T> struct Engine final : EngineBase {
 #undef GR_OPV
     }
 #endif
-    k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
+    if (st.lazy) k_pcg_operator<T, 0, JT, true><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
+    else k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
   }
   void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
     launch_operator_j<T>(st, k, rec, lm, mu);
+  }
+  template <int MODE, bool IDENTITY> void launch_update(int blocks, T *x, const T *rawc, int cw, int ui, PcgState st, int k, int nc = -1, int np = -1) {
+    const int nc_v = nc < 0 ? (int)Nc : nc, np_v = np < 0 ? (int)Np : np;
+    if (st.lazy) k_pcg_update<T, MODE, IDENTITY, true><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
+    else k_pcg_update<T, MODE, IDENTITY><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
   }
   // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
   // touched once): obs + 3 index streams, ps, packs, points, g3 out, segment partials
@@ -1129,7 +1151,7 @@ template <typename T> struct Engine final : EngineBase {
   }
   void ensure_ctl(int max_iter) {
     const int cap = max_iter + 2;
-    if (cap > ctl_cap) { ctl_cap = cap; ctl.alloc(((size_t)NSLOT * NSW + 2) * cap); ctl_i.alloc(cap); }
+    if (cap > ctl_cap) { ctl_cap = cap; ctl.alloc(((size_t)NSLOT * NSW + 4) * cap); ctl_i.alloc(cap); }
     alloc_pinned(cap);
   }
   PcgState pcg_state() {
@@ -1138,6 +1160,11 @@ template <typename T> struct Engine final : EngineBase {
     st.acc = ctl.p; st.pdp = ctl.p + blk; st.rz0 = ctl.p + blk + ctl_cap;
     st.done = ctl_i.p; st.iters = pcg_iters.p; st.hflag = h_flag; st.hiters = h_seq + 1;
     loop_left.alloc(1); st.left = loop_left.p;
+    st.beta = ctl.p + blk + 2 * (size_t)ctl_cap; st.scale = ctl.p + blk + 3 * (size_t)ctl_cap;
+    st.lazy = pcg_lazy() ? 1 : 0;
+    if (st.lazy) v_zs.alloc(n);
+    st.ps = v_ps.p; st.zs = v_zs.p;
+    st.x = nullptr; st.xb = v_xb.p; st.n = (unsigned)n; st.tol = 0.0; st.rej = 1e30; // set per solve (solve_pcg)
     return st;
   }
   // PCGSolver::solve (solver/pcg.hpp:61-232).  Scalars stay on the device; the host only
@@ -1152,6 +1179,7 @@ template <typename T> struct Engine final : EngineBase {
     ensure_point_records();
     T *rec = use_records ? xp.p : nullptr;
     PcgState st = pcg_state();
+    st.x = x; st.tol = tol; st.rej = rej;
     const int ui = damping_identity ? 1 : 0;
     for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
     h_seq[1] = 0;
@@ -1160,14 +1188,13 @@ template <typename T> struct Engine final : EngineBase {
     const int ublocks = update_blocks();
     const T *rawc = comm ? raw_c.p : nullptr;
     const int cw = cam_weight();
-    if (!started) k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, nullptr, g3_gather());
+    if (!started) launch_update<0, IDENTITY>(ublocks, x, rawc, cw, ui, st, 0);
     if (comm) allreduce_d(st.acc, 4 * (size_t)NSW); // record 0: RZP, RR, PDZ, ZDZ
-    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, rec);
-    auto enqueue = [&](int k) {
-      {
-        Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
-        launch_operator(st, k, rec, nullptr, damping);
-      }
+    auto enqueue_operator = [&](int k) {
+      Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
+      launch_operator(st, k, rec, nullptr, damping);
+    };
+    auto enqueue_update = [&](int k) {
       if (comm) { // camera rows + the p.A.p partials, summed over the landmark shards
         k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, nullptr, k);
         group_start();
@@ -1177,9 +1204,45 @@ template <typename T> struct Engine final : EngineBase {
       }
       {
         Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
-        k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
+        launch_update<1, IDENTITY>(ublocks, x, rawc, cw, ui, st, k);
       }
       if (comm) allreduce_d(st.acc + (size_t)(k + 1) * NSLOT * NSW, 4 * (size_t)NSW);
+    };
+    if (st.lazy) {
+      // LAZY form: no direction kernel.  The decision that follows update k (and the host flag of iteration k) comes from
+      // the prologue of operator k + 1, so the pair (update k, operator k + 1) is enqueued together and the host sees the
+      // flag while that operator is still running: time enough to enqueue the next pair without a prediction.
+      int enq_ops = 0;
+      bool left = false;
+      int hook_at = -1, ran = 0;
+      trial_done = false;
+      if (max_iter > 0) { enqueue_operator(0); ++enq_ops; }
+      for (int k = 0; k < max_iter; ++k) {
+        enqueue_update(k);
+        if (k + 1 < max_iter) { enqueue_operator(k + 1); ++enq_ops; }
+        else k_pcg_close<T><<<64, TPB, 0, stream>>>(st, k + 1);
+        if (trial_hook && hook_at < 0 && predicted_iters > 0 && k + 1 >= predicted_iters) {
+          trial_hook(k + 1 < max_iter ? loop_left.p : nullptr); // the iteration cap ends the loop whatever the flag says
+          hook_at = k;
+        }
+        spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
+        ran = k + 1;
+        if (h_flag[k] == 2) { left = true; break; }
+      }
+      const int active = left ? std::min((int)h_seq[1], ran) : ran; // iterations whose operator and update did work
+      if (hook_at >= 0) {
+        trial_done = (left && ran - 1 <= hook_at) || hook_at + 1 == max_iter;
+        if (!trial_done) note_noop({"linearize", "linearize_finalize"}, 1);
+      }
+      predicted_iters = std::max(active, 1);
+      note_noop({"pcg_operator"}, enq_ops - active);
+      note_noop({"pcg_update"}, ran - active);
+      return;
+    }
+    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, rec);
+    auto enqueue = [&](int k) {
+      enqueue_operator(k);
+      enqueue_update(k);
       {
         Scope s3(this, "pcg_direction", 5.0 * n * sizeof(T), 3.0 * n);
         k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej, (unsigned)pose_dim, rec);
@@ -1203,8 +1266,10 @@ template <typename T> struct Engine final : EngineBase {
     const int ui = 0;
     const int ublocks = update_blocks();
     k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
-    k_pcg_update<T, 0, false><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, nullptr, g3_gather());
-    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr);
+    st.x = v_dx.p;
+    launch_update<0, false>(ublocks, v_dx.p, nullptr, 1, ui, st, 0);
+    if (st.lazy) launch_operator(st, 0, nullptr, nullptr, damping); // publishes beta[0], scale[0], pdp[0]
+    else k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr);
     hipEvent_t a, b;
     GR_HIP(hipEventCreate(&a)); GR_HIP(hipEventCreate(&b));
     auto launch = [&] {
@@ -1231,7 +1296,7 @@ template <typename T> struct Engine final : EngineBase {
         const int nc_v = variant == 2 ? 0 : (int)Nc, np_v = variant == 1 ? 0 : (int)Np;
         int ub = variant >= 8 ? variant : std::max(1, std::min(cdiv(9 * (size_t)nc_v, 252) + cdiv(np_v, 85), num_cu * 8));
         if (g3_obs_order) ub = std::max(8, (ub + 7) / 8 * 8); // the point sweep deals workgroups to XCDs by blockIdx % 8
-        k_pcg_update<T, 1, false><<<ub, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, 0, nullptr, g3_gather());
+        launch_update<1, false>(ub, v_dx.p, nullptr, 1, ui, st, 0, nc_v, np_v);
         break;
       }
       case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr); break;

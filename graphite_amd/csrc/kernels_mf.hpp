@@ -63,6 +63,17 @@ struct PcgState {
   volatile int *hiters; // pinned host mirror of iters
   int *left;            // [1] 1 once the loop has left (set by the direction kernel, cleared by k_block_jacobi / the init kernel):
                         // the gate of the trial-step kernels that the host enqueues BEFORE it has seen the exit flag
+  // LAZY direction (lazy != 0): the direction kernel only takes the loop decision and publishes beta[k], scale[k]; the
+  // direction p_k = beta p_{k-1} + scale z'_k is formed where it is used — by the operator from the pre-scaled vectors
+  // ps = s.*p_{k-1} and zs = s.*z'_k as it gathers them, and by the update kernel, which also stores p_k, ps, zs.  One
+  // pass over five n-vectors per inner iteration less.
+  double *beta, *scale; // [cap]
+  void *ps, *zs;        // T[n]
+  int lazy;
+  // the loop decision of the lazy form is taken in the prologue of the NEXT operator launch (pcg_decide)
+  void *x, *xb;         // T[n]: solution and its backup (a rejected step restores x)
+  unsigned n;
+  double tol, rej;
   __device__ __forceinline__ double *slots(int k, int which) const { return acc + ((size_t)k * NSLOT + which) * NSW; }
 };
 
@@ -125,6 +136,7 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
           }
           const size_t t = 9 * (size_t)c + row;
           x[t] = T(0); r[t] = rv[row]; zt[t] = z;
+          if (st.lazy) static_cast<T *>(st.zs)[t] = s[row] * z;
           const T d = use_identity ? T(1) : dcl[row];
           if (cam_weight) { prr += (double)(rv[row] * rv[row]); prz += (double)(rv[row] * z); pzz += (double)(d * z * z); }
         }
@@ -160,6 +172,7 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
         for (int i = 0; i < 3; ++i) {
           const T z = identity_precond ? rv[i] : (T)A[i] * rv[0] + (T)A[i + 3] * rv[1] + (T)A[i + 6] * rv[2];
           x[t0 + i] = T(0); r[t0 + i] = rv[i]; zt[t0 + i] = z;
+          if (st.lazy) static_cast<T *>(st.zs)[t0 + i] = s[i] * z;
           const T d = use_identity ? T(1) : dcl[i];
           prr += (double)(rv[i] * rv[i]); prz += (double)(rv[i] * z); pzz += (double)(d * z * z);
         }
@@ -620,6 +633,63 @@ k_chi2(int No, unsigned n, unsigned pose_dim, int cam_weight, const int *__restr
   }
 }
 
+// Loop decision before iteration k of the LAZY form = the scalar half of k_pcg_direction(k - 1) (pcg.hpp:108-127 for
+// k = 0, :184-217 otherwise), evaluated by EVERY wave of the operator launch of iteration k from the dot-product slots
+// (same inputs, same arithmetic: all waves agree); workgroup 0 publishes it (done[k], rz0[k], pdp[k], beta[k], scale[k],
+// iteration count, the host flag of iteration k - 1 — which the host therefore sees while this launch is still running).
+// Returns false when the launch has nothing to do (loop left; a rejected step has then been reverted by all workgroups).
+template <typename T> struct PcgStep { T beta, scale; };
+template <typename T>
+__device__ __forceinline__ bool pcg_decide(const PcgState &st, int k, PcgStep<T> &stp) {
+  const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
+  stp.beta = T(0); stp.scale = T(0);
+  if (k == 0) {
+    stp.scale = (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(st.slots(0, RR), 0)));
+    const double zdz = slot_sum(st.slots(0, ZDZ), 0);
+    if (first) { st.pdp[0] = (double)stp.scale * (double)stp.scale * zdz; st.beta[0] = 0.0; st.scale[0] = (double)stp.scale; }
+    return true;
+  }
+  const int j = k - 1;
+  const double rz0 = st.rz0[j];
+  bool leave = st.done[j] != 0;
+  PcgIter it{};
+  if (!leave) { it = pcg_iter(st, j); leave = (it.rzp == 0.0); }
+  if (leave) {
+    if (first) { st.done[k] = 1; st.rz0[k] = rz0; if (st.left) *st.left = 1; st.hflag[j] = 2; __threadfence_system(); }
+    return false;
+  }
+  const PcgIter nx = pcg_iter(st, k);
+  const double pdz = slot_sum(st.slots(k, PDZ), 0), zdz = slot_sum(st.slots(k, ZDZ), 0);
+  const T rz = (T)it.rzp * (T)(double)(T)it.rscale, rz_new = (T)nx.rzp * (T)(double)(T)nx.rscale;
+  const bool reject = (fabs((double)rz_new) > st.rej * rz0) || (rz_new != rz_new);
+  const bool done_next = reject || fabs((double)rz_new) < st.tol;
+  stp.beta = rz_new / rz;
+  stp.scale = (T)(double)(T)nx.rscale;
+  if (first) {
+    st.rz0[k] = reject ? rz0 : fmin(rz0, fabs((double)rz_new));
+    st.done[k] = done_next ? 1 : 0;
+    st.pdp[k] = (double)stp.beta * (double)stp.beta * st.pdp[j] + 2.0 * (double)stp.beta * (double)stp.scale * pdz + (double)stp.scale * (double)stp.scale * zdz;
+    st.beta[k] = (double)stp.beta; st.scale[k] = (double)stp.scale;
+    st.iters[0] = k;
+    *st.hiters = k;
+    if (done_next && st.left) *st.left = 1;
+    st.hflag[j] = done_next ? 2 : 1;
+    __threadfence_system();
+  }
+  if (reject) {
+    T *x = static_cast<T *>(st.x);
+    const T *xb = static_cast<const T *>(st.xb);
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < st.n; t += gridDim.x * blockDim.x) x[t] = xb[t];
+  }
+  return !done_next;
+}
+// closes the loop after the last update of a solve that ran into its iteration cap (the decision an operator launch of
+// iteration `k` would have taken)
+template <typename T> __global__ void __launch_bounds__(TPB) k_pcg_close(PcgState st, int k) {
+  PcgStep<T> stp;
+  (void)pcg_decide<T>(st, k, stp);
+}
+
 // ===========================================================================
 // Matrix-free PCG (PCGSolver, solver/pcg.hpp:61-232)
 // ===========================================================================
@@ -630,7 +700,7 @@ k_chi2(int No, unsigned n, unsigned pose_dim, int cam_weight, const int *__restr
 //   point rows : per-observation Jp^T w                    -> g3[pm position][3]
 // VAR (diagnostic builds only, GR_DIAG): 1 no g3 scatter, 2 no point gather, 4 no ps_l gather,
 // 8 no Jacobian math, 16 no wave reduction.  VAR = 0 is the product kernel.
-template <typename T, int VAR = 0, typename JT = T>
+template <typename T, int VAR = 0, typename JT = T, bool LAZY = false>
 __global__ void __launch_bounds__(TPB, OP_WAVES)
 k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
                const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ blk_seg,
@@ -639,7 +709,11 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
                T *__restrict__ op_partial, double mu, PcgState st, int k, const T *__restrict__ xp = nullptr,
                const LmDev *__restrict__ lm = nullptr) {
   if (lm && lm->stop) return;
-  if (!(VAR & 32)) {
+  PcgStep<T> stp{T(0), T(0)};
+  if (LAZY) {
+    if (!pcg_decide<T>(st, k, stp)) return;
+    if (slot_sum(st.slots(k, RZP), 0) == 0.0) return; // rz == 0: the next launch's decision closes the loop
+  } else if (!(VAR & 32)) {
     if (st.done[k]) return;                      // direction(k-1) already told the host
     if (slot_sum(st.slots(k, RZP), 0) == 0.0) return; // rz == 0: the direction kernel of this iteration closes the loop
   }
@@ -647,6 +721,11 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
   const size_t pose_dim = 9 * (size_t)Nc;
+  // lazy direction: ps holds s.*p_{k-1}; the direction of this iteration is beta ps + scale zs (k == 0: scale zs)
+  constexpr bool lazy = LAZY;
+  const bool lazy_old = lazy && k > 0;
+  const T *zs = static_cast<const T *>(st.zs);
+  const T lz_beta = stp.beta, lz_scale = stp.scale;
   int t0, t1, tstep;
   xcd_tile_range(ntiles, t0, t1, tstep);
   double den = 0;
@@ -675,7 +754,12 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     } else {
       X = pts[3 * lp]; Y = pts[3 * lp + 1]; Z = pts[3 * lp + 2];
       const T *pl = ps + pose_dim + 3 * lp;
-      pl0 = pl[0]; pl1 = pl[1]; pl2 = pl[2];
+      if (!lazy) { pl0 = pl[0]; pl1 = pl[1]; pl2 = pl[2]; }
+      else {
+        const T *zl = zs + pose_dim + 3 * lp;
+        pl0 = lz_scale * zl[0]; pl1 = lz_scale * zl[1]; pl2 = lz_scale * zl[2];
+        if (lazy_old) { pl0 += lz_beta * pl[0]; pl1 += lz_beta * pl[1]; pl2 += lz_beta * pl[2]; }
+      }
     }
     unsigned long long remaining = __ballot(valid);
     int segf = blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)];
@@ -692,8 +776,17 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
         for (int i = 0; i < 9; ++i) pc[i] = (T)(cl - i) * T(1e-3);
       } else {
         load_pack(pack, cl, pk);
+        if (!lazy) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) pc[i] = ps[9 * (size_t)cl + i];
+          for (int i = 0; i < 9; ++i) pc[i] = ps[9 * (size_t)cl + i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) pc[i] = lz_scale * zs[9 * (size_t)cl + i];
+          if (lazy_old) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pc[i] += lz_beta * ps[9 * (size_t)cl + i];
+          }
+        }
       }
       T e0, e1, Jc[18], Jp[6];
       if (VAR & 8) {
@@ -737,8 +830,11 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
       T pk[PACK], pc[9];
       load_pack(pack, c, pk);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) pc[i] = ps[9 * (size_t)c + i];
-      const T *pl = ps + pose_dim + 3 * (size_t)((VAR & 4) ? (j & 1023) : l);
+      for (int i = 0; i < 9; ++i) pc[i] = lazy ? lz_scale * zs[9 * (size_t)c + i] + (lazy_old ? lz_beta * ps[9 * (size_t)c + i] : T(0)) : ps[9 * (size_t)c + i];
+      const T *plg = ps + pose_dim + 3 * (size_t)((VAR & 4) ? (j & 1023) : l), *zlg = zs + pose_dim + 3 * (size_t)((VAR & 4) ? (j & 1023) : l);
+      T pl[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pl[i] = lazy ? lz_scale * zlg[i] + (lazy_old ? lz_beta * plg[i] : T(0)) : plg[i];
       const size_t lp = (VAR & 2) ? (size_t)(j & 1023) : (size_t)l;
       T e0, e1, Jc[18], Jp[6];
       if (VAR & 8) {
@@ -805,7 +901,7 @@ struct G3Gather { const int *gidx = nullptr; const int *ptile_ptr = nullptr; int
 //   x_backup = x; x += alpha p; r -= alpha v2.
 // z' = Minv r; accumulates rr = r.r and rzp = r.z' (the reference applies the preconditioner to
 // r/||r||; Minv is linear so z = z'/||r|| and r.z = rzp/||r||).
-template <typename T, int MODE, bool IDENTITY>
+template <typename T, int MODE, bool IDENTITY, bool LAZY = false>
 __global__ void __launch_bounds__(TPB)
 k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ scales, T *__restrict__ x,
              T *__restrict__ xb, T *__restrict__ r, T *__restrict__ zt, const T *__restrict__ p,
@@ -826,6 +922,11 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
   __shared__ double red[4];
   __shared__ T rs[TPB];
   const unsigned pose_dim = 9u * (unsigned)Nc;
+  // lazy direction (PcgState): p_k = beta p_{k-1} + scale z'_k is formed here, stored with ps = s.*p_k; zs = s.*z'_{k+1}
+  constexpr bool lazy = LAZY;
+  const bool lazy_old = lazy && MODE == 1 && k > 0;
+  T *pw = const_cast<T *>(p), *psw = static_cast<T *>(st.ps), *zsw = static_cast<T *>(st.zs);
+  const T lz_beta = lazy_old ? (T)st.beta[k] : T(0), lz_scale = (lazy && MODE == 1) ? (T)st.scale[k] : T(0);
   const int cam_tiles = (int)((pose_dim + 251u) / 252u), pt_tiles = (Np + 84) / 85;
   double prr = 0, prz = 0, ppz = 0, pzz = 0;
   const double cw = (double)cam_weight;
@@ -834,7 +935,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
   for (int tile = ct0; tile < ct1; ++tile) {
     const unsigned t = (unsigned)tile * 252u + threadIdx.x;
     const bool on = threadIdx.x < 252 && t < pose_dim;
-    T rn = 0;
+    T rn = 0, pvk = 0;
     if (on) {
       if (MODE == 0) { rn = scales[t] * bu[t]; x[t] = T(0); }
       else {
@@ -843,7 +944,14 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         if (raw_c) raw = raw_c[t]; // multi-GPU: camera rows already summed over segments and ranks
         else
           for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) raw += op_partial[9 * (size_t)sg + i];
-        const T pv = p[t];
+        T pv;
+        if (!lazy) pv = p[t];
+        else {
+          pv = lz_scale * zt[t];
+          if (lazy_old) pv += lz_beta * p[t];
+          pw[t] = pv; psw[t] = scales[t] * pv;
+        }
+        pvk = pv;
         const T v2 = scales[t] * raw + (use_identity ? (T)mu * pv : (T)mu * diag[t] * pv);
         const T xo = x[t];
         xb[t] = xo;
@@ -866,8 +974,9 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         for (int q = 0; q < 9; ++q) s += M[row + 9 * q] * rc[q];
       }
       zt[t] = s;
+      if (lazy) zsw[t] = scales[t] * s;
       const T d = use_identity ? T(1) : diag[t];
-      const T pv = (MODE == 0) ? T(0) : p[t];
+      const T pv = pvk;
       prr += cw * (double)(rn * rn);
       prz += cw * (double)(rn * s);
       ppz += cw * (double)(d * pv * s);
@@ -904,7 +1013,12 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
       if (!use_identity) dg = diag[t];
       if (MODE == 0) { rn = sc * bu[t]; x[t] = T(0); }
       else {
-        pv = p[t];
+        if (!lazy) pv = p[t];
+        else {
+          pv = lz_scale * zt[t];
+          if (lazy_old) pv += lz_beta * p[t];
+          pw[t] = pv; psw[t] = sc * pv;
+        }
         const T xo = x[t], ro = r[t];
         T raw = 0;
         int a = pt_ptr[l];
@@ -952,6 +1066,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
 #endif
       }
       zt[t] = s;
+      if (lazy) zsw[t] = scales[t] * s;
       prr += (double)(rn * rn);
       prz += (double)(rn * s);
       ppz += (double)(dg * pv * s);

@@ -2,6 +2,7 @@
 problems so that they are held to the oracle like the default path:
   GR_PTILES=K   point-tiled (tile, camera, point) order of the per-observation kernels (Engine::build_tiled_order)
   GR_G3_GATHER=1  operator output kept in observation order, gathered per point by the update kernel (G3Gather)
+  GR_PCG_LAZY=0/1 direction kernel / lazy direction formed inside the operator and the update kernel (PcgState)
 Every solver, the LM traces, the sharded run."""
 import threading
 
@@ -15,12 +16,15 @@ pytestmark = pytest.mark.gpu
 
 MODES = {"tiled8_pm": {"GR_PTILES": "8", "GR_G3_GATHER": "0"}, "tiled24_pm": {"GR_PTILES": "24", "GR_G3_GATHER": "0"},
          "plain": {"GR_PTILES": "0"}, "plain_gather": {"GR_PTILES": "0", "GR_G3_GATHER": "1"},
-         "tiled8": {"GR_PTILES": "8"}, "tiled24": {"GR_PTILES": "24"}}  # tiled default: g3 in observation order
+         "tiled8": {"GR_PTILES": "8"}, "tiled24": {"GR_PTILES": "24"},  # tiled default: g3 in observation order
+         # small problems run the LAZY PCG direction by default (no direction kernel); the direction-kernel form is what
+         # the largest graphs use
+         "direction_kernel": {"GR_PCG_LAZY": "0"}, "tiled8_direction_kernel": {"GR_PTILES": "8", "GR_PCG_LAZY": "0"}}
 SOLVERS = ["pcg", "pcg_identity", "pcg_schur_implicit", "pcg_schur", "dense_schur"]
 
 
 def setenv(monkeypatch, mode):
-    for k in ("GR_PTILES", "GR_G3_GATHER"):
+    for k in ("GR_PTILES", "GR_G3_GATHER", "GR_PCG_LAZY"):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -53,7 +57,7 @@ def test_lm_trace_matches_oracle(oracle_mod, monkeypatch, name, dtype, solver, m
         assert abs(ct[-1] - ct_r[-1]) / ct_r[-1] < 2e-3
 
 
-@pytest.mark.parametrize("mode", ["tiled8", "tiled24", "plain_gather", "tiled8_pm", "tiled24_pm"])
+@pytest.mark.parametrize("mode", ["tiled8", "tiled24", "plain_gather", "tiled8_pm", "tiled24_pm", "direction_kernel", "tiled8_direction_kernel"])
 def test_solver_solve_matches_oracle_pcg(oracle_mod, monkeypatch, mode):
     setenv(monkeypatch, mode)
     prob = synth.make_config("mini-50")
