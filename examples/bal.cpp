@@ -1,6 +1,6 @@
 // bal.cpp — the BAL driver of the reference (examples/bal.cu:43-360) on the MI355X library.
 // Same file format, same options (--lambda --iterations --verbose --pcg_iterations --pcg_tolerance
-// --rejection_ratio --precision {FP64-FP64,FP64-FP32,FP32-FP32} --solver {pcg,pcg-schur,pcg-schur-implicit,eigen-schur,
+// --rejection_ratio --precision {FP64-FP64,FP64-FP32,FP32-FP32} --solver {pcg,pcg-schur,pcg-schur-implicit,eigen,eigen-schur,cudss,
 // cudss-schur} --identity_damping --hybrid_memory),
 // same printed summary (MSE / Half MSE).  Host-only C++17: g++ -Iinclude examples/bal.cpp
 // -Lgraphite_amd -lgraphite_mi355x -Wl,-rpath,$PWD/graphite_amd -o bal
@@ -40,7 +40,7 @@ static Args parse(int argc, char **argv) {
   }
   if (a.file.empty()) throw std::runtime_error("usage: bal <file> [--lambda 1e-4] [--iterations 50] [--verbose] [--pcg_iterations 10] "
                                                "[--pcg_tolerance 1.0] [--rejection_ratio 5.0] [--precision FP64-FP64|FP64-FP32|FP32-FP32] "
-                                               "[--solver pcg|pcg-schur|pcg-schur-implicit|eigen-schur|cudss-schur] [--identity_damping] [--hybrid_memory MB]");
+                                               "[--solver pcg|pcg-schur|pcg-schur-implicit|eigen|eigen-schur|cudss|cudss-schur] [--identity_damping] [--hybrid_memory MB]");
   return a;
 }
 
@@ -114,8 +114,15 @@ template <typename FP, typename SP = FP> void bundle_adjustment(const Args &a) {
   } else if (a.solver == "cudss-schur") {
     std::cout << "Using cuDSS Schur solver." << std::endl;
     solver_ptr = std::make_unique<cudssSchurSolver<FP>>();
-  } else throw std::runtime_error("Unsupported solver option (pcg | pcg-schur | pcg-schur-implicit | eigen-schur | cudss-schur; "
-                                  "the full-system direct solvers eigen / cudss are not provided)");
+  } else if (a.solver == "eigen") {
+    // the reference factorises the full damped H (solver/eigen.hpp:49-98); eliminating the points first and factorising S
+    // gives the same step (block Gaussian elimination of the same system), which is what the engine's direct solver does
+    std::cout << "Using Eigen LDLT solver." << std::endl;
+    solver_ptr = std::make_unique<EigenLDLTSolver<FP>>();
+  } else if (a.solver == "cudss") {
+    std::cout << "Using cuDSS solver." << std::endl;
+    solver_ptr = std::make_unique<cudssSolver<FP>>();
+  } else throw std::runtime_error("Unsupported solver option (pcg | pcg-schur | pcg-schur-implicit | eigen | eigen-schur | cudss | cudss-schur)");
 
   std::cout << "Optimizing!" << std::endl;
   StreamPool streams(8);

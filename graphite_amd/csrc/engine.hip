@@ -125,9 +125,9 @@ template <typename T> struct Engine final : EngineBase {
     return false; // the ablation variants of tools/diag_*.py are instantiated for the direction-kernel form only
 #endif
     if (lm_graph_enabled) return false;
-    if (const char *e = getenv("GR_PCG_LAZY")) return atoi(e) != 0;
-    return n * sizeof(T) <= ((size_t)16 << 20);
+    return lazy_cfg < 0 ? n * sizeof(T) <= ((size_t)16 << 20) : lazy_cfg != 0;
   }
+  int lazy_cfg = -1; // GR_PCG_LAZY, read once per solver_update_structure (no getenv inside the LM loop)
   DevBuf<T> v_zs;
   bool g3_obs_order = false;
   // GR_G3_GATHER=0/1 forces it.  Default: with the point-tiled order only, i.e. on graphs whose g3 does not stay in the
@@ -821,6 +821,7 @@ template <typename T> struct Engine final : EngineBase {
     else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) { want_hcp = false; ensure_implicit_schur(); if (!tiling_tuned) tune_tiling(); }
     else {
       want_hcp = false;
+      { const char *e = getenv("GR_PCG_LAZY"); lazy_cfg = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
       v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
       MinvC.alloc(81 * (size_t)Nc); MinvP.alloc(9 * (size_t)Np);
       if (!tiling_tuned) tune_tiling();

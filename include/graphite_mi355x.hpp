@@ -175,6 +175,17 @@ public:
   EigenSchurLDLTSolver() : CApiSolver<T, S>(GR_SOLVER_DENSE_SCHUR, 0, T(0), T(0)) {}
 };
 struct cudssSolverOptions { int64_t hybrid_memory = 0; }; // accepted, unused (solver/cudss.hpp:19-27)
+// EigenLDLTSolver (solver/eigen.hpp:49-98) / cudssSolver (solver/cudss.hpp:29-262) factorise the full damped H.  On a
+// two-type bundle-adjustment graph that is the same linear step as eliminating the points and factorising S (block
+// Gaussian elimination), so both map to the engine's direct Schur solve.
+template <typename T, typename S = T> class EigenLDLTSolver : public CApiSolver<T, S> {
+public:
+  EigenLDLTSolver() : CApiSolver<T, S>(GR_SOLVER_DENSE_SCHUR, 0, T(0), T(0)) {}
+};
+template <typename T, typename S = T> class cudssSolver : public CApiSolver<T, S> {
+public:
+  explicit cudssSolver(const cudssSolverOptions & = {}) : CApiSolver<T, S>(GR_SOLVER_DENSE_SCHUR, 0, T(0), T(0)) {}
+};
 template <typename T, typename S = T> class cudssSchurSolver : public CApiSolver<T, S> {
 public:
   explicit cudssSchurSolver(const cudssSolverOptions & = {}) : CApiSolver<T, S>(GR_SOLVER_DENSE_SCHUR, 0, T(0), T(0)) {}

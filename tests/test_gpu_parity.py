@@ -97,7 +97,8 @@ def test_solver_solve(oracle_mod, name, dtype, solver):
         dx_r, it_r = ref.solver_solve(os_, max_iter=max_iter, tol=tol, rej=1e6)
         assert it_g == it_r
         # PCG amplifies rounding differences with the iteration count
-        assert relerr(dx_g, dx_r) < tol_for(dtype, 1e-6, 5e-2)
+        # measured on MI355X: fp64 <= 5e-11 (25 identity-preconditioned iterations), fp32 <= 9e-4
+        assert relerr(dx_g, dx_r) < tol_for(dtype, 1e-9, 2e-3)
     gpu.close()
 
 
