@@ -117,15 +117,17 @@ template <typename T> struct Engine final : EngineBase {
   // Lazy PCG direction (kernels_mf.hpp PcgState): default on; GR_PCG_LAZY=0 keeps the direction kernel's vector pass.
   // GR_PCG_LAZY=0/1 forces it.  Measured A/B on one box (LM it/s, bench line): Ladybug-49 fp32 13 230 -> 14 000,
   // Ladybug-1723 fp64 5 060 -> 5 100, Venice-1778 fp32 1 165 -> 1 210, Final-13682 fp64 148.5 -> 139.9: the direction
-  // kernel's pass over five n-vectors goes, but the update kernel stores three more vectors (p, s.*p, s.*z') and the operator
-  // gathers two per point instead of one, so it pays where launches matter and costs where bytes do.  Default: vectors up
-  // to 16 MB.  Off in the opt-in graph-replay mode and in diagnostic builds (their kernels are the direction-kernel form).
+  // kernel's pass over five n-vectors goes, but the update kernel stores three more vectors (p, s.*p, s.*z'), the operator
+  // gathers two per point instead of one and every wave of it re-derives the loop decision from the dot-product slots
+  // (Ladybug-1723: operator 24.9 -> 29.7 us, update 21.3 -> 27.3 us for the 12.7 us direction launch saved).  It pays
+  // where launches dominate and is a wash or a loss where bytes do.  Default: vectors up to 1 MB (Ladybug-49-sized
+  // problems).  Off in the opt-in graph-replay mode and in diagnostic builds (their kernels are the direction-kernel form).
   bool pcg_lazy() const {
 #ifdef GR_DIAG
     return false; // the ablation variants of tools/diag_*.py are instantiated for the direction-kernel form only
 #endif
     if (lm_graph_enabled) return false;
-    return lazy_cfg < 0 ? n * sizeof(T) <= ((size_t)16 << 20) : lazy_cfg != 0;
+    return lazy_cfg < 0 ? n * sizeof(T) <= ((size_t)1 << 20) : lazy_cfg != 0;
   }
   int lazy_cfg = -1; // GR_PCG_LAZY, read once per solver_update_structure (no getenv inside the LM loop)
   DevBuf<T> v_zs;

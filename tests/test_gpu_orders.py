@@ -17,9 +17,10 @@ pytestmark = pytest.mark.gpu
 MODES = {"tiled8_pm": {"GR_PTILES": "8", "GR_G3_GATHER": "0"}, "tiled24_pm": {"GR_PTILES": "24", "GR_G3_GATHER": "0"},
          "plain": {"GR_PTILES": "0"}, "plain_gather": {"GR_PTILES": "0", "GR_G3_GATHER": "1"},
          "tiled8": {"GR_PTILES": "8"}, "tiled24": {"GR_PTILES": "24"},  # tiled default: g3 in observation order
-         # small problems run the LAZY PCG direction by default (no direction kernel); the direction-kernel form is what
-         # the largest graphs use
-         "direction_kernel": {"GR_PCG_LAZY": "0"}, "tiled8_direction_kernel": {"GR_PTILES": "8", "GR_PCG_LAZY": "0"}}
+         # problems with vectors up to 1 MB (every small test problem) run the LAZY PCG direction by default (no direction
+         # kernel); larger ones the direction-kernel form: both are forced here
+         "direction_kernel": {"GR_PCG_LAZY": "0"}, "tiled8_direction_kernel": {"GR_PTILES": "8", "GR_PCG_LAZY": "0"},
+         "lazy": {"GR_PCG_LAZY": "1"}, "tiled8_lazy": {"GR_PTILES": "8", "GR_PCG_LAZY": "1"}}
 SOLVERS = ["pcg", "pcg_identity", "pcg_schur_implicit", "pcg_schur", "dense_schur"]
 
 
@@ -57,7 +58,7 @@ def test_lm_trace_matches_oracle(oracle_mod, monkeypatch, name, dtype, solver, m
         assert abs(ct[-1] - ct_r[-1]) / ct_r[-1] < 2e-3
 
 
-@pytest.mark.parametrize("mode", ["tiled8", "tiled24", "plain_gather", "tiled8_pm", "tiled24_pm", "direction_kernel", "tiled8_direction_kernel"])
+@pytest.mark.parametrize("mode", ["tiled8", "tiled24", "plain_gather", "tiled8_pm", "tiled24_pm", "direction_kernel", "tiled8_direction_kernel", "lazy", "tiled8_lazy"])
 def test_solver_solve_matches_oracle_pcg(oracle_mod, monkeypatch, mode):
     setenv(monkeypatch, mode)
     prob = synth.make_config("mini-50")
