@@ -130,6 +130,19 @@ template <typename T> struct Engine final : EngineBase {
     return lazy_cfg < 0 ? n * sizeof(T) <= ((size_t)1 << 20) : lazy_cfg != 0;
   }
   int lazy_cfg = -1; // GR_PCG_LAZY, read once per solver_update_structure (no getenv inside the LM loop)
+  // Single-reduction PCG (kernels_mf.hpp PcgState, lazy == 2): on landmark shards by default — ONE all-reduce per inner
+  // iteration (camera rows + every dot product of the iteration) instead of two; GR_PCG_CG=0/1 forces it (1 also on a
+  // single GPU: that is how tests hold it to the oracle's solve_pcg_cg).
+  int cg_cfg = -1;
+  bool pcg_cg() const {
+#ifdef GR_DIAG
+    return false;
+#endif
+    if (lm_graph_enabled) return false;
+    return cg_cfg < 0 ? (comm && comm->size > 1) : cg_cfg != 0;
+  }
+  int pcg_mode() const { return pcg_cg() ? 2 : (pcg_lazy() ? 1 : 0); }
+  DevBuf<T> v_sv;
   DevBuf<T> v_zs;
   bool g3_obs_order = false;
   // GR_G3_GATHER=0/1 forces it.  Default: with the point-tiled order only, i.e. on graphs whose g3 does not stay in the
@@ -202,7 +215,7 @@ template <typename T> struct Engine final : EngineBase {
   void tune_point_records() {
     if (records_tuned) return;
     records_tuned = true;
-    if (pcg_lazy()) { use_records = false; return; } // the lazy direction gathers ps and zs; the 8-scalar record has room for one
+    if (pcg_mode() != 0) { use_records = false; return; } // the lazy / single-reduction forms gather zs (and ps); the 8-scalar record has room for one
     if (const char *e = getenv("GR_POINT_RECORDS")) { use_records = atoi(e) != 0; return; }
     use_records = false;
     const double t_plain = diag_time(0, 0, 5);
@@ -824,6 +837,7 @@ template <typename T> struct Engine final : EngineBase {
     else {
       want_hcp = false;
       { const char *e = getenv("GR_PCG_LAZY"); lazy_cfg = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
+      { const char *e = getenv("GR_PCG_CG"); cg_cfg = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
       v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
       MinvC.alloc(81 * (size_t)Nc); MinvP.alloc(9 * (size_t)Np);
       if (!tiling_tuned) tune_tiling();
@@ -1135,7 +1149,8 @@ template <typename T> struct Engine final : EngineBase {
 #undef GR_OPV
     }
 #endif
-    if (st.lazy) k_pcg_operator<T, 0, JT, true><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
+    if (st.lazy == 2) k_pcg_operator<T, 0, JT, 2><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
+    else if (st.lazy) k_pcg_operator<T, 0, JT, 1><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
     else k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
   }
   void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
@@ -1144,7 +1159,8 @@ template <typename T> struct Engine final : EngineBase {
   }
   template <int MODE, bool IDENTITY> void launch_update(int blocks, T *x, const T *rawc, int cw, int ui, PcgState st, int k, int nc = -1, int np = -1) {
     const int nc_v = nc < 0 ? (int)Nc : nc, np_v = np < 0 ? (int)Np : np;
-    if (st.lazy) k_pcg_update<T, MODE, IDENTITY, true><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
+    if (st.lazy == 2) k_pcg_update<T, MODE, IDENTITY, 2><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
+    else if (st.lazy) k_pcg_update<T, MODE, IDENTITY, 1><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
     else k_pcg_update<T, MODE, IDENTITY><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
   }
   // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
@@ -1164,9 +1180,10 @@ template <typename T> struct Engine final : EngineBase {
     st.done = ctl_i.p; st.iters = pcg_iters.p; st.hflag = h_flag; st.hiters = h_seq + 1;
     loop_left.alloc(1); st.left = loop_left.p;
     st.beta = ctl.p + blk + 2 * (size_t)ctl_cap; st.scale = ctl.p + blk + 3 * (size_t)ctl_cap;
-    st.lazy = pcg_lazy() ? 1 : 0;
+    st.lazy = pcg_mode();
     if (st.lazy) v_zs.alloc(n);
-    st.ps = v_ps.p; st.zs = v_zs.p;
+    if (st.lazy == 2) v_sv.alloc(n);
+    st.ps = v_ps.p; st.zs = v_zs.p; st.sv = v_sv.p;
     st.x = nullptr; st.xb = v_xb.p; st.n = (unsigned)n; st.tol = 0.0; st.rej = 1e30; // set per solve (solve_pcg)
     return st;
   }
@@ -1192,7 +1209,7 @@ template <typename T> struct Engine final : EngineBase {
     const T *rawc = comm ? raw_c.p : nullptr;
     const int cw = cam_weight();
     if (!started) launch_update<0, IDENTITY>(ublocks, x, rawc, cw, ui, st, 0);
-    if (comm) allreduce_d(st.acc, 4 * (size_t)NSW); // record 0: RZP, RR, PDZ, ZDZ
+    if (comm && st.lazy != 2) allreduce_d(st.acc, 4 * (size_t)NSW); // record 0: RZP, RR, PDZ, ZDZ (single-reduction form: rides in the first iteration's message)
     auto enqueue_operator = [&](int k) {
       Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
       launch_operator(st, k, rec, nullptr, damping);
@@ -1211,6 +1228,50 @@ template <typename T> struct Engine final : EngineBase {
       }
       if (comm) allreduce_d(st.acc + (size_t)(k + 1) * NSLOT * NSW, 4 * (size_t)NSW);
     };
+    if (st.lazy == 2) {
+      // SINGLE-REDUCTION form: operator k on z', ONE grouped all-reduce (camera rows + the five dot records of iteration
+      // k), update k, whose prologue decides about iteration k - 1 and raises its host flag.  The record-0 dots of the
+      // start ride in the first message.  Reaching the iteration cap costs one more (scalar) all-reduce + a closing launch.
+      bool left = false;
+      int hook_at = -1, ran = 0;
+      trial_done = false;
+      auto iteration = [&](int k) {
+        enqueue_operator(k);
+        if (comm) {
+          k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, nullptr, k);
+          group_start();
+          allreduce_T(raw_c.p, pose_dim);
+          allreduce_d(st.acc + (size_t)k * NSLOT * NSW, (size_t)NSLOT * NSW); // RZP, RR, PDZ, ZDZ, DEN of record k
+          group_end();
+        }
+        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
+        launch_update<1, IDENTITY>(ublocks, x, rawc, cw, ui, st, k);
+      };
+      int enq = 0;
+      if (max_iter > 0) { iteration(0); ++enq; }
+      for (int k = 0; k < max_iter; ++k) { // waits for the flag of iteration k, raised by update k + 1 (or the closing launch)
+        if (k + 1 < max_iter) { iteration(k + 1); ++enq; }
+        else {
+          if (comm) allreduce_d(st.acc + (size_t)(k + 1) * NSLOT * NSW, 4 * (size_t)NSW);
+          k_pcg_close_cg<T><<<64, TPB, 0, stream>>>(st, k + 1, damping);
+        }
+        if (trial_hook && hook_at < 0 && predicted_iters > 0 && k + 1 >= predicted_iters) {
+          trial_hook(k + 1 < max_iter ? loop_left.p : nullptr);
+          hook_at = k;
+        }
+        spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
+        ran = k + 1;
+        if (h_flag[k] == 2) { left = true; break; }
+      }
+      const int active = left ? std::min((int)h_seq[1], ran) : ran;
+      if (hook_at >= 0) {
+        trial_done = (left && ran - 1 <= hook_at) || hook_at + 1 == max_iter;
+        if (!trial_done) note_noop({"linearize", "linearize_finalize"}, 1);
+      }
+      predicted_iters = std::max(active, 1);
+      note_noop({"pcg_operator", "pcg_update"}, enq - active);
+      return;
+    }
     if (st.lazy) {
       // LAZY form: no direction kernel.  The decision that follows update k (and the host flag of iteration k) comes from
       // the prologue of operator k + 1, so the pair (update k, operator k + 1) is enqueued together and the host sees the

@@ -69,7 +69,14 @@ struct PcgState {
   // pass over five n-vectors per inner iteration less.
   double *beta, *scale; // [cap]
   void *ps, *zs;        // T[n]
-  int lazy;
+  int lazy;             // 0 direction kernel, 1 lazy direction, 2 single-reduction recurrence (below)
+  // SINGLE-REDUCTION form (lazy == 2; Chronopoulos-Gear, the variant oracle/bal_pipeline.hpp::solve_pcg_cg documents): the
+  // operator is applied to the preconditioned residual u = z'/|r| instead of the direction, s = A p follows the recurrence
+  // s_k = A u_k + beta_k s_{k-1}, and alpha_k = gamma_k / (delta_k - beta_k gamma_k / alpha_{k-1}).  All dot products of an
+  // iteration (r.z', r.r, z'.D.z' of record k and the operator's DEN of record k) are needed at ONE point, the start of
+  // update k, so landmark shards all-reduce them in one message together with the operator's camera rows.
+  // beta[k] then holds alpha_k and scale[k] holds gamma_k.
+  void *sv;             // T[n]: s = A p
   // the loop decision of the lazy form is taken in the prologue of the NEXT operator launch (pcg_decide)
   void *x, *xb;         // T[n]: solution and its backup (a rejected step restores x)
   unsigned n;
@@ -683,6 +690,58 @@ __device__ __forceinline__ bool pcg_decide(const PcgState &st, int k, PcgStep<T>
   }
   return !done_next;
 }
+// Single-reduction form: loop decision and step scalars at the start of update k, from record k of the dots (complete,
+// i.e. all-reduced, only now).  Every wave evaluates it; workgroup 0 publishes.  The decision concerns iteration k - 1
+// (solver/pcg.hpp:166-229: rejection ratio, tolerance, rz == 0) and is what the host flag of iteration k - 1 reports.
+template <typename T> struct PcgCgStep { T alpha, beta, sigma; };
+template <typename T>
+__device__ __forceinline__ bool pcg_cg_decide(const PcgState &st, int k, double mu, PcgCgStep<T> &stp) {
+  const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
+  stp.alpha = stp.beta = stp.sigma = T(0);
+  if (k > 0 && st.done[k - 1]) { if (first) { st.done[k] = 1; st.rz0[k] = st.rz0[k - 1]; } return false; }
+  const double rzp = slot_sum(st.slots(k, RZP), 0), rr = slot_sum(st.slots(k, RR), 0);
+  const T sigma = (T)(1.0 / (double)(T)sqrt((double)(T)rr));
+  const T gamma = (T)rzp * sigma;
+  bool stop = false, reject = false;
+  double rz0 = __builtin_inf();
+  if (k > 0) {
+    rz0 = st.rz0[k - 1];
+    reject = (fabs((double)gamma) > st.rej * rz0) || (gamma != gamma);
+    stop = reject || fabs((double)gamma) < st.tol;
+  }
+  if (rzp == 0.0) stop = true; // pcg.hpp:133: rz == 0 ends the loop before the iteration starts
+  if (first) {
+    st.rz0[k] = (k == 0 || reject) ? rz0 : fmin(rz0, fabs((double)gamma));
+    st.done[k] = stop ? 1 : 0;
+    if (k > 0) { st.iters[0] = k; *st.hiters = k; }
+    if (stop && st.left) *st.left = 1;
+    if (k > 0) st.hflag[k - 1] = stop ? 2 : 1;
+    else if (stop) st.hflag[0] = 2;
+    __threadfence_system();
+  }
+  if (reject) {
+    T *x = static_cast<T *>(st.x);
+    const T *xb = static_cast<const T *>(st.xb);
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < st.n; t += gridDim.x * blockDim.x) x[t] = xb[t];
+  }
+  if (stop) return false;
+  // delta = u.A.u = sigma^2 (sum rho' |J s.*z'|^2 + mu z'.D.z')
+  const double den = slot_sum(st.slots(k, DEN), 0), zdz = slot_sum(st.slots(k, ZDZ), 0);
+  const T delta = (T)((double)sigma * (double)sigma * (den + mu * zdz));
+  stp.sigma = sigma;
+  if (k == 0) { stp.beta = T(0); stp.alpha = gamma / delta; }
+  else {
+    const T gamma_prev = (T)st.scale[k - 1], alpha_prev = (T)st.beta[k - 1];
+    stp.beta = gamma / gamma_prev;
+    stp.alpha = gamma / (delta - stp.beta * gamma / alpha_prev);
+  }
+  if (first) { st.beta[k] = (double)stp.alpha; st.scale[k] = (double)gamma; }
+  return true;
+}
+template <typename T> __global__ void __launch_bounds__(TPB) k_pcg_close_cg(PcgState st, int k, double mu) {
+  PcgCgStep<T> stp;
+  (void)pcg_cg_decide<T>(st, k, mu, stp);
+}
 // closes the loop after the last update of a solve that ran into its iteration cap (the decision an operator launch of
 // iteration `k` would have taken)
 template <typename T> __global__ void __launch_bounds__(TPB) k_pcg_close(PcgState st, int k) {
@@ -700,7 +759,7 @@ template <typename T> __global__ void __launch_bounds__(TPB) k_pcg_close(PcgStat
 //   point rows : per-observation Jp^T w                    -> g3[pm position][3]
 // VAR (diagnostic builds only, GR_DIAG): 1 no g3 scatter, 2 no point gather, 4 no ps_l gather,
 // 8 no Jacobian math, 16 no wave reduction.  VAR = 0 is the product kernel.
-template <typename T, int VAR = 0, typename JT = T, bool LAZY = false>
+template <typename T, int VAR = 0, typename JT = T, int LAZY = 0>
 __global__ void __launch_bounds__(TPB, OP_WAVES)
 k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
                const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ blk_seg,
@@ -710,7 +769,10 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
                const LmDev *__restrict__ lm = nullptr) {
   if (lm && lm->stop) return;
   PcgStep<T> stp{T(0), T(0)};
-  if (LAZY) {
+  if (LAZY == 2) { // single-reduction form: A applied to the un-normalised z' (the update kernel scales); decisions are the update kernel's
+    if (k > 0 && st.done[k - 1]) return;
+    stp.scale = T(1);
+  } else if (LAZY) {
     if (!pcg_decide<T>(st, k, stp)) return;
     if (slot_sum(st.slots(k, RZP), 0) == 0.0) return; // rz == 0: the next launch's decision closes the loop
   } else if (!(VAR & 32)) {
@@ -722,8 +784,8 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
   const int lane = threadIdx.x & 63;
   const size_t pose_dim = 9 * (size_t)Nc;
   // lazy direction: ps holds s.*p_{k-1}; the direction of this iteration is beta ps + scale zs (k == 0: scale zs)
-  constexpr bool lazy = LAZY;
-  const bool lazy_old = lazy && k > 0;
+  constexpr bool lazy = LAZY != 0;
+  const bool lazy_old = LAZY == 1 && k > 0;
   const T *zs = static_cast<const T *>(st.zs);
   const T lz_beta = stp.beta, lz_scale = stp.scale;
   int t0, t1, tstep;
@@ -901,7 +963,7 @@ struct G3Gather { const int *gidx = nullptr; const int *ptile_ptr = nullptr; int
 //   x_backup = x; x += alpha p; r -= alpha v2.
 // z' = Minv r; accumulates rr = r.r and rzp = r.z' (the reference applies the preconditioner to
 // r/||r||; Minv is linear so z = z'/||r|| and r.z = rzp/||r||).
-template <typename T, int MODE, bool IDENTITY, bool LAZY = false>
+template <typename T, int MODE, bool IDENTITY, int LAZY = 0>
 __global__ void __launch_bounds__(TPB)
 k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ scales, T *__restrict__ x,
              T *__restrict__ xb, T *__restrict__ r, T *__restrict__ zt, const T *__restrict__ p,
@@ -912,7 +974,12 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
              const LmDev *__restrict__ lm = nullptr, G3Gather gg = G3Gather{}) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
   T alpha = 0;
-  if (MODE == 1) {
+  constexpr bool CG = (LAZY == 2) && MODE == 1;
+  PcgCgStep<T> cg{T(0), T(0), T(0)};
+  if (CG) {
+    if (!pcg_cg_decide<T>(st, k, mu, cg)) return;
+    alpha = cg.alpha;
+  } else if (MODE == 1) {
     if (st.done[k]) return;
     const PcgIter it = pcg_iter(st, k);
     if (it.rzp == 0.0) return;
@@ -923,10 +990,10 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
   __shared__ T rs[TPB];
   const unsigned pose_dim = 9u * (unsigned)Nc;
   // lazy direction (PcgState): p_k = beta p_{k-1} + scale z'_k is formed here, stored with ps = s.*p_k; zs = s.*z'_{k+1}
-  constexpr bool lazy = LAZY;
-  const bool lazy_old = lazy && MODE == 1 && k > 0;
-  T *pw = const_cast<T *>(p), *psw = static_cast<T *>(st.ps), *zsw = static_cast<T *>(st.zs);
-  const T lz_beta = lazy_old ? (T)st.beta[k] : T(0), lz_scale = (lazy && MODE == 1) ? (T)st.scale[k] : T(0);
+  constexpr bool lazy = LAZY != 0;
+  const bool lazy_old = lazy && MODE == 1 && k > 0; // a previous direction exists
+  T *pw = const_cast<T *>(p), *psw = static_cast<T *>(st.ps), *zsw = static_cast<T *>(st.zs), *svw = static_cast<T *>(st.sv);
+  const T lz_beta = CG ? cg.beta : (lazy_old ? (T)st.beta[k] : T(0)), lz_scale = CG ? cg.sigma : ((lazy && MODE == 1) ? (T)st.scale[k] : T(0));
   const int cam_tiles = (int)((pose_dim + 251u) / 252u), pt_tiles = (Np + 84) / 85;
   double prr = 0, prz = 0, ppz = 0, pzz = 0;
   const double cw = (double)cam_weight;
@@ -949,10 +1016,17 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         else {
           pv = lz_scale * zt[t];
           if (lazy_old) pv += lz_beta * p[t];
-          pw[t] = pv; psw[t] = scales[t] * pv;
+          pw[t] = pv; if (!CG) psw[t] = scales[t] * pv;
         }
         pvk = pv;
-        const T v2 = scales[t] * raw + (use_identity ? (T)mu * pv : (T)mu * diag[t] * pv);
+        T v2;
+        if (CG) { // raw = rows of A' z' (un-normalised): w = sigma s raw + mu d u, s_k = w + beta s_{k-1}
+          const T uo = lz_scale * zt[t];
+          v2 = lz_scale * (scales[t] * raw) + (use_identity ? (T)mu * uo : (T)mu * diag[t] * uo);
+          if (k > 0) v2 += lz_beta * svw[t];
+          svw[t] = v2;
+        } else
+        v2 = scales[t] * raw + (use_identity ? (T)mu * pv : (T)mu * diag[t] * pv);
         const T xo = x[t];
         xb[t] = xo;
         x[t] = alpha * pv + xo;
@@ -1017,7 +1091,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         else {
           pv = lz_scale * zt[t];
           if (lazy_old) pv += lz_beta * p[t];
-          pw[t] = pv; psw[t] = sc * pv;
+          pw[t] = pv; if (!CG) psw[t] = sc * pv;
         }
         const T xo = x[t], ro = r[t];
         T raw = 0;
@@ -1042,7 +1116,14 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
 #else
         raw = (T)(a_end - a);
 #endif
-        const T v2 = sc * raw + (use_identity ? (T)mu * pv : (T)mu * dg * pv);
+        T v2;
+        if (CG) {
+          const T uo = lz_scale * zt[t];
+          v2 = lz_scale * (sc * raw) + (use_identity ? (T)mu * uo : (T)mu * dg * uo);
+          if (k > 0) v2 += lz_beta * svw[t];
+          svw[t] = v2;
+        } else
+        v2 = sc * raw + (use_identity ? (T)mu * pv : (T)mu * dg * pv);
         xb[t] = xo;
         x[t] = alpha * pv + xo;
         rn = -alpha * v2 + ro;

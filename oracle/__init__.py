@@ -199,6 +199,10 @@ class BalOracle:
     def set_scale_system(self, on):
         self._call("gro_bal_set_scale_system", C.c_int(int(on)))
 
+    def set_pcg_single_reduction(self, on):
+        """documented variant (not in the reference): Chronopoulos-Gear recurrence for SOLVER_PCG / SOLVER_PCG_IDENTITY"""
+        self._call("gro_bal_set_pcg_single_reduction", C.c_int(int(on)))
+
     def set_params(self, cams, pts):
         self._call("gro_bal_set_params", _p(np.ascontiguousarray(cams, dtype=self.dt)),
                    _p(np.ascontiguousarray(pts, dtype=self.dt)))

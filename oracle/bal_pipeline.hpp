@@ -514,8 +514,65 @@ template <typename T> struct BalOracle {
         yp[c] += (Jp[6 * o + 2 * c] * v1[2 * o] + Jp[6 * o + 2 * c + 1] * v1[2 * o + 1]) * dchi2[o];
     }
   }
+  // DOCUMENTED VARIANT, not in the reference: the same preconditioned CG with the Chronopoulos-Gear single-reduction
+  // recurrence (one global reduction point per iteration instead of two), which the GPU engine runs on landmark shards
+  // (one all-reduce per inner iteration).  Same iterates as solve_pcg in exact arithmetic:
+  //   u_k = M^-1 (r_k / |r_k|), gamma_k = r_k.u_k, w_k = A u_k, delta_k = u_k.w_k,
+  //   beta_k = gamma_k / gamma_{k-1} (0 for k = 0), alpha_k = gamma_k / (delta_k - beta_k gamma_k / alpha_{k-1}),
+  //   p_k = u_k + beta_k p_{k-1}, s_k = w_k + beta_k s_{k-1} (= A p_k), x += alpha_k p_k, r -= alpha_k s_k,
+  // with the exits of solver/pcg.hpp:166-229 (rejection ratio, tolerance, rz == 0) on gamma_{k+1} unchanged.
+  bool pcg_single_reduction = false;
+  bool solve_pcg_cg(T *x, int max_iter, T tol, T rejection_ratio, bool identity_precond) {
+    std::vector<T> v1, w(n), r(b), p(n, 0), sv(n, 0), u(n), diag(n, 0), xb(n), y(n);
+    std::fill(x, x + n, T(0));
+    for (size_t o = 0; o < No; ++o) {
+      T *dc = &diag[9 * cam_idx[o]], *dp = &diag[pose_dim + 3 * pt_idx[o]];
+      for (int c = 0; c < 9; ++c)
+        dc[c] += (Jc[18 * o + 2 * c] * Jc[18 * o + 2 * c] + Jc[18 * o + 2 * c + 1] * Jc[18 * o + 2 * c + 1]) * dchi2[o];
+      for (int c = 0; c < 3; ++c)
+        dp[c] += (Jp[6 * o + 2 * c] * Jp[6 * o + 2 * c] + Jp[6 * o + 2 * c + 1] * Jp[6 * o + 2 * c + 1]) * dchi2[o];
+    }
+    for (size_t i = 0; i < n; ++i) diag[i] = std::clamp(diag[i], T(1.0e-6), T(1.0e32));
+    auto precond = [&](T *zz, const T *yy) {
+      if (identity_precond) std::copy(yy, yy + n, zz);
+      else block_jacobi_apply(zz, yy);
+    };
+    auto normalised_precond = [&]() {
+      const T scale = T(1.0 / std::sqrt(dot(n, r.data(), r.data())));
+      for (size_t i = 0; i < n; ++i) y[i] = scale * r[i];
+      precond(u.data(), y.data());
+    };
+    normalised_precond();
+    T gamma = dot(n, r.data(), u.data()), gamma_prev = 0, alpha_prev = 0;
+    T rz_0 = std::numeric_limits<T>::infinity();
+    last_pcg_iters = 0;
+    for (int k = 0; k < max_iter; ++k) {
+      if (gamma == 0) break;
+      JtJ_matvec(u.data(), w.data(), v1);
+      for (size_t i = 0; i < n; ++i) w[i] += damping_identity ? damping * u[i] : damping * diag[i] * u[i];
+      last_pcg_iters++;
+      const T delta = dot(n, u.data(), w.data());
+      const T beta = k == 0 ? T(0) : gamma / gamma_prev;
+      const T alpha = k == 0 ? gamma / delta : gamma / (delta - beta * gamma / alpha_prev);
+      for (size_t i = 0; i < n; ++i) { p[i] = u[i] + beta * p[i]; sv[i] = w[i] + beta * sv[i]; }
+      xb.assign(x, x + n);
+      for (size_t i = 0; i < n; ++i) x[i] = alpha * p[i] + x[i];
+      for (size_t i = 0; i < n; ++i) r[i] = -alpha * sv[i] + r[i];
+      normalised_precond();
+      const T gamma_new = dot(n, r.data(), u.data());
+      if (std::abs(gamma_new) > rejection_ratio * rz_0 || std::isnan(gamma_new)) {
+        std::copy(xb.begin(), xb.end(), x);
+        break;
+      }
+      rz_0 = std::min(rz_0, std::abs(gamma_new));
+      gamma_prev = gamma; alpha_prev = alpha; gamma = gamma_new;
+      if (std::abs(gamma_new) < tol) break;
+    }
+    return true;
+  }
   // PCGSolver::solve, solver/pcg.hpp:61-232.  identity_precond: IdentityPreconditioner
   bool solve_pcg(T *x, int max_iter, T tol, T rejection_ratio, bool identity_precond) {
+    if (pcg_single_reduction) return solve_pcg_cg(x, max_iter, tol, rejection_ratio, identity_precond);
     std::vector<T> v1, v2(n), r(b), p(n), z(n), diag(n, 0), xb(n), y(n);
     std::fill(x, x + n, T(0));
     for (size_t o = 0; o < No; ++o) { // pcg.hpp:93-98 diag(J^T rho' J) from the (scaled) stored J

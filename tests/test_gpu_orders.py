@@ -3,6 +3,7 @@ problems so that they are held to the oracle like the default path:
   GR_PTILES=K   point-tiled (tile, camera, point) order of the per-observation kernels (Engine::build_tiled_order)
   GR_G3_GATHER=1  operator output kept in observation order, gathered per point by the update kernel (G3Gather)
   GR_PCG_LAZY=0/1 direction kernel / lazy direction formed inside the operator and the update kernel (PcgState)
+  GR_PCG_CG=1     single-reduction (Chronopoulos-Gear) recurrence, the form landmark shards use
 Every solver, the LM traces, the sharded run."""
 import threading
 
@@ -20,12 +21,15 @@ MODES = {"tiled8_pm": {"GR_PTILES": "8", "GR_G3_GATHER": "0"}, "tiled24_pm": {"G
          # problems with vectors up to 1 MB (every small test problem) run the LAZY PCG direction by default (no direction
          # kernel); larger ones the direction-kernel form: both are forced here
          "direction_kernel": {"GR_PCG_LAZY": "0"}, "tiled8_direction_kernel": {"GR_PTILES": "8", "GR_PCG_LAZY": "0"},
-         "lazy": {"GR_PCG_LAZY": "1"}, "tiled8_lazy": {"GR_PTILES": "8", "GR_PCG_LAZY": "1"}}
+         "lazy": {"GR_PCG_LAZY": "1"}, "tiled8_lazy": {"GR_PTILES": "8", "GR_PCG_LAZY": "1"},
+         # the single-reduction recurrence the landmark shards run, forced on one GPU (equal to the reference recurrence in
+         # exact arithmetic; test_single_reduction_pcg_matches_its_oracle_variant holds it to the oracle's restatement of it)
+         "single_reduction": {"GR_PCG_CG": "1"}, "tiled8_single_reduction": {"GR_PTILES": "8", "GR_PCG_CG": "1"}}
 SOLVERS = ["pcg", "pcg_identity", "pcg_schur_implicit", "pcg_schur", "dense_schur"]
 
 
 def setenv(monkeypatch, mode):
-    for k in ("GR_PTILES", "GR_G3_GATHER", "GR_PCG_LAZY"):
+    for k in ("GR_PTILES", "GR_G3_GATHER", "GR_PCG_LAZY", "GR_PCG_CG"):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -149,3 +153,46 @@ def test_g3_layouts_agree_bitwise_at_full_size(monkeypatch):
         e.close()
     assert out["0"][1] == out["1"][1] == 5
     assert np.array_equal(out["0"][0], out["1"][0])
+
+
+@pytest.mark.parametrize("name,dtype", [("mini-50", np.float64), ("ladybug-49", np.float32)])
+@pytest.mark.parametrize("solver", ["pcg", "pcg_identity"])
+def test_single_reduction_pcg_matches_its_oracle_variant(oracle_mod, monkeypatch, name, dtype, solver):
+    """GR_PCG_CG=1 against oracle/bal_pipeline.hpp::solve_pcg_cg (the documented variant), and both against the reference
+    recurrence: solves with 4 / 10 / 25 iterations (tolerance exit, fixed count), rejection exit, LM traces."""
+    setenv(monkeypatch, "single_reduction")
+    gs = dict(pcg=ga.SOLVER_PCG, pcg_identity=ga.SOLVER_PCG_IDENTITY)[solver]
+    os_ = dict(pcg=oracle_mod.SOLVER_PCG, pcg_identity=oracle_mod.SOLVER_PCG_IDENTITY)[solver]
+    prob = synth.make_config(name)
+    f64 = np.dtype(dtype) == np.float64
+    gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+    cg = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+    cg.set_pcg_single_reduction(1)
+    std = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+    gpu.solver_update_structure(gs)
+    gpu.linearize()
+    gpu.solver_update_values(gs)
+    gpu.solver_set_damping(gs, 1e-4)
+    for o in (cg, std):
+        o.linearize()
+        o.solver_update_values(os_)
+        o.solver_set_damping(os_, 1e-4)
+    for max_iter, tol, rej in ((4, 0.0, 1e30), (10, 0.0, 1e30), (25, 1e-3, 1e30), (25, 0.0, 0.5), (1, 0.0, 1e30)):
+        dx_g, it_g = gpu.solver_solve(gs, max_iter=max_iter, tol=tol, rej=rej)
+        dx_c, it_c = cg.solver_solve(os_, max_iter=max_iter, tol=tol, rej=rej)
+        dx_s, it_s = std.solver_solve(os_, max_iter=max_iter, tol=tol, rej=rej)
+        assert it_g == it_c, (max_iter, tol, rej, it_g, it_c, it_s)
+        scale = np.abs(dx_c).max()
+        # fp32: 25 identity-preconditioned iterations amplify the rounding differences of two implementations to 4e-3
+        bar = 1e-9 if f64 else (2e-3 if it_c <= 10 else 1e-2)
+        assert np.abs(dx_g - dx_c).max() / scale < bar, (max_iter, tol, rej)
+        if it_c == it_s:   # same exit: the two recurrences give the same step up to rounding
+            assert np.abs(dx_c - dx_s).max() / scale < bar
+    ct, lt, st = gpu.levenberg_marquardt(solver=gs, iterations=6)
+    ct_c, lt_c, st_c = cg.levenberg_marquardt(solver=os_, iterations=6)
+    gpu.close()
+    if f64:
+        assert st["pcg_iterations"] == st_c["pcg_iterations"] and st["accepted"] == st_c["accepted"]
+        assert np.max(np.abs(ct - ct_c) / ct_c) < 1e-8
+    else:
+        assert np.max(np.abs(ct[:4] - ct_c[:4]) / ct_c[:4]) < 2e-3
