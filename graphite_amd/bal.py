@@ -74,6 +74,13 @@ class BalProblem:
         """np.float32 on an fp64 problem: Jacobian entries in fp32 (the reference's FP64-FP32 mode)."""
         check(self.lib.gr_bal_set_jacobian_precision(self.h, C.c_int(F64 if np.dtype(dtype) == np.float64 else F32)))
 
+    def set_fixed(self, cam_fixed=None, pt_fixed=None):
+        """VertexDescriptor::set_fixed (vertex.hpp:262): boolean masks over cameras / points (caller's order)"""
+        cf = None if cam_fixed is None else np.ascontiguousarray(np.asarray(cam_fixed) != 0, dtype=np.uint8)
+        pf = None if pt_fixed is None else np.ascontiguousarray(np.asarray(pt_fixed) != 0, dtype=np.uint8)
+        check(self.lib.gr_bal_set_fixed(self.h, None if cf is None else cf.ctypes.data_as(C.c_void_p),
+                                        None if pf is None else pf.ctypes.data_as(C.c_void_p)))
+
     def set_params(self, cameras, points):
         c = np.ascontiguousarray(cameras, dtype=self.dt)
         p = np.ascontiguousarray(points, dtype=self.dt)

@@ -41,6 +41,7 @@ struct EngineBase {
   virtual ~EngineBase() = default;
   virtual void set_loss(int kind, double delta) = 0;
   virtual void set_scale_system(bool on) = 0;
+  virtual void set_fixed(const unsigned char *cam_fixed, const unsigned char *pt_fixed) = 0;
   virtual void set_jacobian_precision(int dtype) = 0;
   virtual void set_params(const void *c, const void *p) = 0;
   virtual void get_params(void *c, void *p) = 0;
@@ -155,7 +156,12 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<int> g3_gidx, ptile_ptr;
   int g3_ptiles = 0;
   const int *g3_pos() const { return g3_obs_order ? nullptr : o_pos(); }
-  G3Gather g3_gather() const { G3Gather g; if (g3_obs_order) { g.gidx = g3_gidx.p; g.ptile_ptr = ptile_ptr.p; g.n_ptiles = g3_ptiles; } return g; }
+  G3Gather g3_gather() const {
+    G3Gather g;
+    if (g3_obs_order) { g.gidx = g3_gidx.p; g.ptile_ptr = ptile_ptr.p; g.n_ptiles = g3_ptiles; }
+    g.cam_fixed = cam_fixed_p(); g.pt_fixed = pt_fixed_p();
+    return g;
+  }
   int update_blocks() const {
     const int b = std::min(cdiv(pose_dim, 252) + cdiv(Np, 85), num_cu * 8);
     return g3_obs_order ? std::max(8, (b + 7) / 8 * 8) : b;
@@ -673,6 +679,24 @@ template <typename T> struct Engine final : EngineBase {
   // ---- Graph --------------------------------------------------------------------
   void set_loss(int kind, double delta) override { loss_kind = kind; loss_delta = (T)delta; }
   void set_scale_system(bool on) override { scale_system = on; }
+  // VertexDescriptor::set_fixed (vertex.hpp:262-264).  The reference gives a fixed vertex no Hessian column and its kernels
+  // skip the vertex's Jacobian block; here the vertex keeps its (empty) column: zero block, zero gradient, scale 1, and its
+  // rows of every operator product are dropped, so its step is exactly 0 and every other quantity is what the reduced
+  // system gives.  The explicit Schur solvers get there through zero camera-point blocks (k_linearize); the implicit-Schur
+  // PCG, which recomputes Jacobians in its own passes, refuses a problem with fixed vertices.
+  DevBuf<unsigned char> d_cam_fixed, d_pt_fixed;
+  bool has_fixed = false;
+  void set_fixed(const unsigned char *cam_fixed, const unsigned char *pt_fixed) override {
+    std::vector<unsigned char> hc(Nc, 0), hp(Np, 0);
+    bool any = false;
+    if (cam_fixed) for (int64_t c = 0; c < Nc; ++c) { hc[c] = cam_fixed[c] ? 1 : 0; any |= hc[c] != 0; }
+    if (pt_fixed) for (int64_t l = 0; l < Np; ++l) { const unsigned char f = pt_fixed[l] ? 1 : 0; hp[h_pt_old2new.empty() ? l : h_pt_old2new[l]] = f; any |= f != 0; }
+    has_fixed = any;
+    if (any) { d_cam_fixed.upload(hc, stream); d_pt_fixed.upload(hp, stream); GR_HIP(hipStreamSynchronize(stream)); }
+    hcp_valid = false;
+  }
+  const unsigned char *cam_fixed_p() const { return has_fixed ? d_cam_fixed.p : nullptr; }
+  const unsigned char *pt_fixed_p() const { return has_fixed ? d_pt_fixed.p : nullptr; }
   void set_jacobian_precision(int dtype) override {
     if (dtype == GR_F32 && sizeof(T) == 4) { jac32 = false; return; } // already fp32 throughout
     if (dtype != GR_F32 && dtype != GR_F64) throw std::invalid_argument("jacobian precision: GR_F32 or GR_F64");
@@ -732,7 +756,7 @@ template <typename T> struct Engine final : EngineBase {
       Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
       k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)np_fin, TPB), TPB, 0, stream>>>((int)Nc, np_fin, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
                                                                                                     spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq,
-                                                                                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gate);
+                                                                                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gate, cam_fixed_p(), pt_fixed_p());
     }
     if (comm) { // camera-space sums over the landmark shards
       group_start();
@@ -747,12 +771,12 @@ template <typename T> struct Engine final : EngineBase {
   void launch_linearize_cam(bool hcp, T *g9p, const int *gate) {
     if constexpr (sizeof(T) == 8) {
       if (jac32) {
-        if (hcp) k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate);
+        if (hcp) k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p());
         else k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate);
         return;
       }
     }
-    if (hcp) k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate);
+    if (hcp) k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p());
     else k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate);
   }
   bool want_hcp = false;
@@ -831,6 +855,8 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   void solver_update_structure(int solver) override {
+    if (has_fixed && solver == GR_SOLVER_PCG_SCHUR_IMPLICIT)
+      throw std::invalid_argument("fixed vertices are not supported by the implicit-Schur PCG solver (use GR_SOLVER_PCG, GR_SOLVER_PCG_SCHUR or GR_SOLVER_DENSE_SCHUR)");
     if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
     else if (solver == GR_SOLVER_DENSE_SCHUR) { ensure_chol(); want_hcp = true; }
     else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) { want_hcp = false; ensure_implicit_schur(); if (!tiling_tuned) tune_tiling(); }
@@ -1629,7 +1655,7 @@ template <typename T> struct Engine final : EngineBase {
     if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
     else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
     k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
-                                                                                                    rho_partial.p, rho_blocks, nullptr, nullptr, 0, lm, pcg_iters.p, h_trace, h_trace + h_trace_cap, h_lm, h_lm + 1);
+                                                                                                    rho_partial.p, rho_blocks, nullptr, nullptr, 0, lm, pcg_iters.p, h_trace, h_trace + h_trace_cap, h_lm, h_lm + 1, nullptr, cam_fixed_p(), pt_fixed_p());
   }
   bool lm_graph_prepare(const gr_lm_options &opt) {
     if (!lm_graph_enabled || comm || profiling || opt.early_stop || opt.stop_flag || opt.iterations < 2 || opt.pcg_max_iter < 1) return false;
@@ -1991,6 +2017,7 @@ gr_status gr_bal_destroy(gr_bal_problem *p) {
 }
 gr_status gr_bal_set_loss(gr_bal_problem *p, gr_loss kind, double delta) { return guarded(p, [&] { p->e->set_loss(kind, delta); }); }
 gr_status gr_bal_set_scale_system(gr_bal_problem *p, int enable) { return guarded(p, [&] { p->e->set_scale_system(enable != 0); }); }
+gr_status gr_bal_set_fixed(gr_bal_problem *p, const unsigned char *cam_fixed, const unsigned char *pt_fixed) { return guarded(p, [&] { p->e->set_fixed(cam_fixed, pt_fixed); }); }
 gr_status gr_bal_set_jacobian_precision(gr_bal_problem *p, gr_dtype dtype) { return guarded(p, [&] { p->e->set_jacobian_precision((int)dtype); }); }
 gr_status gr_bal_set_params(gr_bal_problem *p, const void *c, const void *q) { return guarded(p, [&] { p->e->set_params(c, q); }); }
 gr_status gr_bal_get_params(gr_bal_problem *p, void *c, void *q) { return guarded(p, [&] { p->e->get_params(c, q); }); }

@@ -357,7 +357,10 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
             const int *__restrict__ seg_slot, const T *__restrict__ pts, const T *__restrict__ pack,
             int loss_kind, T loss_delta, T *__restrict__ g9, T *__restrict__ Hcp, T *__restrict__ cam_partial,
             double *__restrict__ chi2_partial, const LmDev *__restrict__ lm = nullptr,
-            const int *__restrict__ gate = nullptr) {
+            const int *__restrict__ gate = nullptr,
+            // fixed vertices (WRITE_HCP only): the camera-point block of an observation whose camera or point is fixed is zero
+            // (the reference computes no Jacobian block for a fixed vertex, ops/linearize.hpp:24)
+            const unsigned char *__restrict__ cam_fixed = nullptr, const unsigned char *__restrict__ pt_fixed = nullptr) {
   if (lm && lm->stop) return;
   if (gate && !*gate) return;
   __shared__ double red[4];
@@ -411,11 +414,12 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
       }
       if (WRITE_HCP) {
         T *h = Hcp + 27 * a;
+        const T keep = ((cam_fixed && cam_fixed[c]) || (pt_fixed && pt_fixed[l])) ? T(0) : T(1);
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-          h[r] = Jc[2 * r] * wp0x + Jc[2 * r + 1] * wp0y;
-          h[r + 9] = Jc[2 * r] * wp1x + Jc[2 * r + 1] * wp1y;
-          h[r + 18] = Jc[2 * r] * wp2x + Jc[2 * r + 1] * wp2y;
+          h[r] = keep * (Jc[2 * r] * wp0x + Jc[2 * r + 1] * wp0y);
+          h[r + 9] = keep * (Jc[2 * r] * wp1x + Jc[2 * r + 1] * wp1y);
+          h[r + 18] = keep * (Jc[2 * r] * wp2x + Jc[2 * r + 1] * wp2y);
         }
       }
     }
@@ -468,7 +472,9 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
                      LmDev *__restrict__ lm = nullptr, const int *__restrict__ pcg_iters = nullptr,
                      volatile double *h_chi2_trace = nullptr, volatile double *h_lambda_trace = nullptr,
                      volatile int *h_steps = nullptr, volatile int *h_stop = nullptr,
-                     const int *__restrict__ gate = nullptr) {
+                     const int *__restrict__ gate = nullptr,
+                     // fixed vertices: no Jacobian block (ops/linearize.hpp:24) -> zero Hessian block, zero gradient, scale 1
+                     const unsigned char *__restrict__ cam_fixed = nullptr, const unsigned char *__restrict__ pt_fixed = nullptr) {
   if (lm && lm->stop) return;
   if (gate && !*gate) return;
   const unsigned t = blockIdx.x * TPB + threadIdx.x;
@@ -484,9 +490,11 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
     } else idx = 45 + (int)(e - 81u);
     T s = 0;
     for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) s += cam_partial[54 * (size_t)sg + idx];
+    const bool fixed = cam_fixed && cam_fixed[c];
+    if (fixed) s = T(0);
     if (e < 81u) {
       Hcc[81 * (size_t)c + e] = s;
-      if (row == col && cam_scales) scales[9 * c + row] = scale_system ? (T)(1.0 / (DBL_EPSILON + sqrt((double)s))) : T(1);
+      if (row == col && cam_scales) scales[9 * c + row] = (scale_system && !fixed) ? (T)(1.0 / (DBL_EPSILON + sqrt((double)s))) : T(1);
     } else bc[9 * c + (e - 81u)] = s;
   } else if (t >= ncam_pad && t < ncam_pad + FIN_PL * (unsigned)Np) { // point part starts on a block boundary
     // FIN_PL lanes share a point (records j, j + FIN_PL, ...): the serial chain of dependent record loads is
@@ -513,6 +521,12 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
     for (int o = 1; o < FIN_PL; o <<= 1)
 #pragma unroll
       for (int i = 0; i < 9; ++i) v[i] += __shfl_xor(v[i], o, 64);
+    const bool pfixed = pt_fixed && pt_fixed[l];
+    if (pfixed) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v[i] = T(0);
+    }
+    if (pfixed) scale_system = 0; // this thread's point only: scale 1
 #if FIN_PL == 4
     { // every lane of the group holds the sums: the 15 outputs are written 4 lanes wide (lane jl: outputs jl, jl+4, ...)
       const T out[16] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5], v[6], v[7], v[8],
@@ -951,7 +965,10 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
 // then walks the points as the operator walked their observations: point tile q (points [ptile_ptr[q], ptile_ptr[q+1]))
 // belongs to XCD q % 8 and that XCD's workgroups sweep it together, so the lines one XCD wrote are read back by the
 // same XCD while they are still in its L2.  gidx == nullptr: g3 in pm order, points in contiguous ranges per workgroup.
-struct G3Gather { const int *gidx = nullptr; const int *ptile_ptr = nullptr; int n_ptiles = 0; };
+struct G3Gather { const int *gidx = nullptr; const int *ptile_ptr = nullptr; int n_ptiles = 0;
+                  // FIXED vertices (vertex.hpp:262 set_fixed; the reference's kernels skip their Jacobian blocks, ops/linearize.hpp:24,
+                  // ops/hessian.hpp:95): their rows of every operator product are dropped here.  nullptr: none fixed.
+                  const unsigned char *cam_fixed = nullptr, *pt_fixed = nullptr; };
 
 // x / r / z' update of the matrix-free PCG.
 // Persistent blocks walk contiguous ranges of
@@ -1011,6 +1028,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         if (raw_c) raw = raw_c[t]; // multi-GPU: camera rows already summed over segments and ranks
         else
           for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) raw += op_partial[9 * (size_t)sg + i];
+        if (gg.cam_fixed && gg.cam_fixed[c]) raw = T(0);
         T pv;
         if (!lazy) pv = p[t];
         else {
@@ -1116,6 +1134,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
 #else
         raw = (T)(a_end - a);
 #endif
+        if (gg.pt_fixed && gg.pt_fixed[l]) raw = T(0);
         T v2;
         if (CG) {
           const T uo = lz_scale * zt[t];

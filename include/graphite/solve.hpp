@@ -501,7 +501,7 @@ namespace detail {
 // set_eliminate or not), one factor descriptor whose traits carry `bal_reprojection_model` — are optimised by the
 // specialised engine of libgraphite_mi355x.so (gr_bal_*: matrix-free kernels, device-resident loop) instead of
 // the generic stored-Jacobian kernels: same algorithm, same trace.  Returns false when the graph or the solver
-// is anything else (fixed or unused vertices, inactive factors, precision matrices, a solver without an engine
+// is anything else (unused vertices, inactive factors, precision matrices, a solver without an engine
 // counterpart, GRAPHITE_GENERIC_ONLY=1): the caller then runs the generic loop.
 template <typename T, typename S>
 bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, bool early_stop, bool &result) {
@@ -516,11 +516,19 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   const int kind = options->solver->engine_kind(cd->count());
   if (kind < 0) return false;
   if (!graph->initialize_optimization(options->optimization_level)) return false;
+  // fixed vertices (bit 0) go to the engine as masks (gr_bal_set_fixed); a vertex no active factor touches (bit 7) is not
+  // an engine graph
+  std::vector<unsigned char> cam_fixed(cd->count(), 0), pt_fixed(pd->count(), 0);
+  bool any_fixed = false;
   for (auto *vd : {cd, pd}) {
     const uint8_t *st = vd->get_active_state();
-    for (size_t v = 0; v < vd->count(); ++v)
-      if (!graphite::detail::is_vertex_active(st, v)) return false; // fixed, or not touched by a factor: not an engine graph
+    std::vector<unsigned char> &mask = vd == cd ? cam_fixed : pt_fixed;
+    for (size_t v = 0; v < vd->count(); ++v) {
+      if (st[v] & ~uint8_t(0x1)) return false;
+      if (st[v] & 0x1) { mask[v] = 1; any_fixed = true; }
+    }
   }
+  if (any_fixed && kind == GR_SOLVER_PCG_SCHUR_IMPLICIT) return false;
   std::vector<int32_t> ci, pi;
   std::vector<T> obs;
   int loss_kind = 0; double loss_delta = 0;
@@ -538,6 +546,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   auto fail = [&](const char *what) { std::cerr << "graphite: engine hand-over failed in " << what << ": " << gr_last_error_string() << "; using the generic kernels" << std::endl; if (prob) gr_bal_destroy(prob); return false; };
   if (gr_bal_create(&prob, dt, (int64_t)cd->count(), (int64_t)pd->count(), (int64_t)ci.size(), cams.raw(), pts.raw(), obs.data(), ci.data(), pi.data(), dev, nullptr) != GR_OK) return fail("gr_bal_create");
   if (gr_bal_set_loss(prob, loss_kind ? GR_LOSS_HUBER : GR_LOSS_DEFAULT, loss_delta) != GR_OK) return fail("gr_bal_set_loss");
+  if (any_fixed && gr_bal_set_fixed(prob, cam_fixed.data(), pt_fixed.data()) != GR_OK) return fail("gr_bal_set_fixed");
   if (gr_bal_set_scale_system(prob, graph->scales_system() ? 1 : 0) != GR_OK) return fail("gr_bal_set_scale_system");
   if (!std::is_same<T, S>::value && gr_bal_set_jacobian_precision(prob, GR_F32) != GR_OK) return fail("gr_bal_set_jacobian_precision");
   gr_lm_options o{};

@@ -199,6 +199,12 @@ class BalOracle:
     def set_scale_system(self, on):
         self._call("gro_bal_set_scale_system", C.c_int(int(on)))
 
+    def set_fixed(self, cam_fixed=None, pt_fixed=None):
+        """VertexDescriptor::set_fixed (vertex.hpp:262): boolean masks over cameras / points"""
+        cf = np.ascontiguousarray(np.zeros(self.Nc, np.uint8) if cam_fixed is None else (np.asarray(cam_fixed) != 0).astype(np.uint8))
+        pf = np.ascontiguousarray(np.zeros(self.Np, np.uint8) if pt_fixed is None else (np.asarray(pt_fixed) != 0).astype(np.uint8))
+        self._call("gro_bal_set_fixed", cf.ctypes.data_as(C.c_void_p), pf.ctypes.data_as(C.c_void_p))
+
     def set_pcg_single_reduction(self, on):
         """documented variant (not in the reference): Chronopoulos-Gear recurrence for SOLVER_PCG / SOLVER_PCG_IDENTITY"""
         self._call("gro_bal_set_pcg_single_reduction", C.c_int(int(on)))

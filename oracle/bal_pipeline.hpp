@@ -172,10 +172,24 @@ template <typename T> struct BalOracle {
     }
     return tree_sum<T>(0, No, [&](size_t o) { return chi2_vec[o]; }); // thrust::reduce, ops/chi2.hpp:61-64
   }
+  // VertexDescriptor::set_fixed (vertex.hpp:262-264): the Jacobian kernels return before writing the block of a fixed vertex
+  // (ops/linearize.hpp:24) and every consumer skips it (ops/hessian.hpp:95,135,190; the vertex has no Hessian column).
+  // Restated with the column kept and the block zero: the vertex's gradient, Hessian block and step are exactly 0.
+  std::vector<uint8_t> cam_fixed, pt_fixed;
+  void set_fixed(const uint8_t *cf, const uint8_t *pf) {
+    cam_fixed.assign(Nc, 0); pt_fixed.assign(Np, 0);
+    if (cf) for (size_t c = 0; c < Nc; ++c) cam_fixed[c] = cf[c] ? 1 : 0;
+    if (pf) for (size_t l = 0; l < Np; ++l) pt_fixed[l] = pf[l] ? 1 : 0;
+  }
   void linearize() { // graph.hpp:236-290
     for (size_t o = 0; o < No; ++o)
       bal_residual_jacobian(&cams[9 * cam_idx[o]], &pts[3 * pt_idx[o]], &obs[2 * o], &res[2 * o],
                             &Jc[18 * o], &Jp[6 * o]);
+    if (!cam_fixed.empty())
+      for (size_t o = 0; o < No; ++o) {
+        if (cam_fixed[cam_idx[o]]) std::fill(&Jc[18 * o], &Jc[18 * o] + 18, T(0));
+        if (pt_fixed[pt_idx[o]]) std::fill(&Jp[6 * o], &Jp[6 * o] + 6, T(0));
+      }
     chi2();
     if (scale_system) {
       std::fill(scales.begin(), scales.end(), T(0));

@@ -98,6 +98,7 @@ extern "C" {
     o->loss_kind = kind; o->loss_delta = delta;                                                     \
   }                                                                                                 \
   void gro_bal_set_scale_system_##SFX(void *h, int on) { static_cast<BalOracle<T> *>(h)->scale_system = on != 0; } \
+  void gro_bal_set_fixed_##SFX(void *h, const uint8_t *cf, const uint8_t *pf) { static_cast<BalOracle<T> *>(h)->set_fixed(cf, pf); } \
   void gro_bal_set_pcg_single_reduction_##SFX(void *h, int on) { static_cast<BalOracle<T> *>(h)->pcg_single_reduction = on != 0; } \
   void gro_bal_set_params_##SFX(void *h, const T *cams, const T *pts) {                             \
     auto *o = static_cast<BalOracle<T> *>(h);                                                       \

@@ -169,7 +169,7 @@ template <template <typename, typename> class Factor> static int run(int argc, c
 int main(int argc, char **argv) {
   // auto: dual-number Jacobians (stored); stored | dynamic: the Manual factor with / without Jacobian storage
   const std::string jmode = argc > 4 ? argv[4] : "auto";
-  // engine: the tagged factor (dispatched to gr_bal_*); engine-fixed: the same with one camera fixed (must fall back)
+  // engine: the tagged factor (dispatched to gr_bal_*); engine-fixed: the same with one camera fixed (handed over with a fixed-vertex mask)
   if (jmode == "engine" || jmode == "engine-fixed") return run<graphite::ReprojectionErrorEngine>(argc, argv);
   return jmode == "auto" ? run<graphite::ReprojectionError>(argc, argv) : run<graphite::ReprojectionErrorManual>(argc, argv);
 }

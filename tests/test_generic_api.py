@@ -87,8 +87,7 @@ def test_reference_known_answers_on_the_generic_kernels():
 @pytest.mark.parametrize("solver", ["pcg", "pcg-identity", "pcg-schur", "eigen-schur"])
 def test_tagged_bal_graph_runs_on_the_engine(oracle_mod, tmp_path, monkeypatch, solver):
     """A descriptor-built graph whose factor traits declare `bal_reprojection_model` is optimised by gr_bal_*
-    (the reference-style problem definition reaches the specialised kernels); anything the engine does not
-    represent (here: a fixed camera) stays on the generic kernels."""
+    (the reference-style problem definition reaches the specialised kernels), also with a fixed camera."""
     monkeypatch.setenv("GR_VERBOSE", "1")
     exe = build_all()[2]
     prob = synth.make_config("mini-50")
@@ -111,10 +110,25 @@ def test_tagged_bal_graph_runs_on_the_engine(oracle_mod, tmp_path, monkeypatch, 
     cr, _ = ref.get_params()
     cam0 = np.array([float(x) for x in [ln for ln in r.stdout.splitlines() if ln.startswith("CAM0")][0].split()[1:]])
     assert np.allclose(cam0, cr[0], rtol=1e-6, atol=1e-9)
-    if solver == "pcg":
-        fx = subprocess.run([exe, str(f), solver, "3", "engine-fixed"], capture_output=True, text=True, timeout=300)
-        assert fx.returncode == 0 and "handed to the gr_bal engine" not in fx.stderr
-        assert len(parse_trace(fx.stdout)) == 3
+    # a FIXED camera (VertexDescriptor::set_fixed) goes to the engine too, as a mask: its trace equals the oracle's with the
+    # same camera fixed AND the trace of the generic kernels (GRAPHITE_GENERIC_ONLY=1: reduced Hessian columns, stored
+    # Jacobians), an independent implementation of the reference's fixed-vertex semantics; the camera does not move
+    fx = subprocess.run([exe, str(f), solver, "6", "engine-fixed"], capture_output=True, text=True, timeout=300)
+    assert fx.returncode == 0 and "handed to the gr_bal engine" in fx.stderr
+    trf = parse_trace(fx.stdout)
+    reff = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    cf = np.zeros(prob.shape[0], bool)
+    cf[0] = True
+    reff.set_fixed(cf, None)
+    ctf, ltf, _ = reff.levenberg_marquardt(solver=os_, iterations=6)
+    assert np.allclose(trf[:, 1], ctf[1:], rtol=1e-7)
+    cam0f = np.array([float(x) for x in [ln for ln in fx.stdout.splitlines() if ln.startswith("CAM0")][0].split()[1:]])
+    assert np.array_equal(cam0f, prob.cameras[0])
+    gen = subprocess.run([exe, str(f), solver, "6", "engine-fixed"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, GRAPHITE_GENERIC_ONLY="1"))
+    assert gen.returncode == 0 and "handed to the gr_bal engine" not in gen.stderr
+    trg = parse_trace(gen.stdout)
+    assert np.allclose(trg[:, 1], trf[:, 1], rtol=1e-7)
 
 
 @pytest.mark.gpu
