@@ -212,6 +212,63 @@ public:
   T *end() const { return p_ + n_; }
 };
 
+// Storage of the library's OWN arrays (Jacobians, residuals, gradient, solver vectors, dense blocks): HBM, where the
+// reference keeps thrust::device_vector (factor.hpp:158-174, graph.hpp:40-60).  Fine-grained device memory: kernels
+// stream it at HBM speed (measured 6.7 TB/s against 0.09 TB/s for the pinned host memory of managed_vector, which every
+// access crosses PCIe for), and on these boxes it is still mapped into the host address space, so the occasional host
+// element access (a scalar, a debug read) stays legal — host WRITES are posted and fast, host READS cost about a
+// microsecond each, so bulk host access goes through to_host().  Arithmetic element types only.
+template <typename T> class hbm_vector {
+  static_assert(std::is_trivially_copyable<T>::value, "hbm_vector holds plain data");
+  T *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0, hw_ = 0; // hw_: elements ever exposed (beyond it the allocation is still zero)
+  void grow(size_t cap) {
+    if (cap <= cap_) return;
+    T *q = nullptr;
+    cap = std::max<size_t>(cap, 1);
+    GRAPHITE_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&q), cap * sizeof(T), hipDeviceMallocFinegrained));
+    if (n_) GRAPHITE_HIP(hipMemcpy(q, p_, n_ * sizeof(T), hipMemcpyDeviceToDevice));
+    GRAPHITE_HIP(hipMemset(q + n_, 0, (cap - n_) * sizeof(T))); // value-initialised tail: growing by one element costs nothing later
+    if (p_) (void)hipFree(p_);
+    p_ = q; cap_ = cap; hw_ = n_;
+  }
+public:
+  struct pointer { T *p; T *get() const { return p; } };
+  hbm_vector() = default;
+  explicit hbm_vector(size_t n) { resize(n); }
+  hbm_vector(size_t n, const T &v) { resize(n, v); }
+  hbm_vector(const hbm_vector &) = delete;
+  hbm_vector &operator=(const hbm_vector &) = delete;
+  ~hbm_vector() { if (p_) (void)hipFree(p_); }
+  void reserve(size_t cap) { grow(cap); }
+  void resize(size_t n) { // new elements are value-initialised (zero bytes)
+    if (n > cap_) grow(std::max(n, 2 * cap_));
+    if (n > n_ && n_ < hw_) GRAPHITE_HIP(hipMemset(p_ + n_, 0, (std::min(n, hw_) - n_) * sizeof(T))); // re-exposed after a shrink
+    n_ = n; hw_ = std::max(hw_, n);
+  }
+  void resize(size_t n, const T &v); // new elements = v (filled on the device)
+  void resize_uninit(size_t n) { if (n > cap_) grow(n); n_ = n; hw_ = std::max(hw_, n); }
+  void clear() { n_ = 0; }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  T &operator[](size_t i) { return p_[i]; }
+  const T &operator[](size_t i) const { return p_[i]; }
+  pointer data() const { return pointer{p_}; }
+  T *raw() const { return p_; }
+  T *begin() const { return p_; }
+  T *end() const { return p_ + n_; }
+  std::vector<T> to_host() const {
+    std::vector<T> h(n_);
+    if (n_) GRAPHITE_HIP(hipMemcpy(h.data(), p_, n_ * sizeof(T), hipMemcpyDeviceToHost));
+    return h;
+  }
+  void assign(const T *src, size_t n) { // from host (or any) memory
+    if (n > cap_) { n_ = 0; grow(n); }
+    n_ = n;
+    if (n) GRAPHITE_HIP(hipMemcpy(p_, src, n * sizeof(T), hipMemcpyDefault));
+  }
+};
+
 // ---- stream.hpp:7-24 ---------------------------------------------------------------------------
 class StreamPool {
   std::vector<hipStream_t> s_;
@@ -238,6 +295,13 @@ template <typename T> __global__ void k_fill(T *p, size_t n, T v) {
   if (i < n) p[i] = v;
 }
 template <typename T> inline void fill(T *p, size_t n, T v) { if (n) k_fill<T><<<blocks(n), TPB>>>(p, n, v); }
+} // namespace detail
+template <typename T> void hbm_vector<T>::resize(size_t n, const T &v) {
+  if (n > cap_) grow(std::max(n, 2 * cap_));
+  if (n > n_) { detail::fill(p_ + n_, n - n_, v); GRAPHITE_HIP(hipDeviceSynchronize()); }
+  n_ = n; hw_ = std::max(hw_, n);
+}
+namespace detail {
 
 // detection of the optional State / get_state / set_state of vertex traits (main.md:100-111)
 template <typename Tr, typename = void> struct state_of { using type = typename Tr::Vertex; static constexpr bool custom = false; };
@@ -264,6 +328,11 @@ public:
   virtual size_t get_local_id(size_t id) const = 0;
   virtual uint8_t *get_active_state() const = 0;
   virtual size_t *get_hessian_ids() const = 0;
+  // what kernels read: HBM copies while an optimiser loop has the vertices mirrored (begin_mirror/end_mirror), else the above
+  virtual const uint8_t *device_active_state() const = 0;
+  virtual const size_t *device_hessian_ids() const = 0;
+  virtual void begin_mirror() = 0;
+  virtual void end_mirror() = 0;
   virtual const std::vector<size_t> &local_to_global() const = 0;
   virtual void apply_update(const T *delta_x, const T *scales) = 0;
   virtual void backup_parameters() = 0;
@@ -317,6 +386,14 @@ __global__ void k_vertex_restore(typename Tr::Vertex **x, const uint8_t *state, 
   if constexpr (state_of<Tr>::custom) Tr::set_state(*x[i], bak[i]);
   else *x[i] = bak[i];
 }
+template <typename V> __global__ void k_mirror_in(V *const *user, size_t n, V *mirror, V **ptrs) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) { mirror[i] = *user[i]; ptrs[i] = mirror + i; }
+}
+template <typename V> __global__ void k_mirror_out(V *const *user, size_t n, const V *mirror) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) *user[i] = mirror[i];
+}
 } // namespace detail
 
 template <typename T, typename S, typename VTraits> class VertexDescriptor : public BaseVertexDescriptor<T, S> {
@@ -367,21 +444,58 @@ public:
   size_t get_local_id(size_t id) const override { return global_to_local_map.at(id); }
   size_t dimension() const override { return dim; }
   size_t count() const override { return x_device.size(); }
-  VertexType **vertices() const { return x_device.raw(); }
+  // Device mirror (the reference keeps user vertices in CUDA unified memory, which migrates to the GPU on first touch,
+  // vertex.hpp:65; pinned host memory does not): while an optimiser loop runs, the vertex VALUES, their active state and
+  // Hessian columns and the backup states live in HBM and every kernel reads those; end_mirror() writes the values back
+  // into the user's objects.  Outside a loop kernels dereference the user's memory directly, as before.
+  static constexpr bool can_mirror = std::is_trivially_copyable<VertexType>::value && std::is_trivially_copyable<StateType>::value;
+  struct Empty1 {};
+  std::conditional_t<can_mirror, hbm_vector<VertexType>, Empty1> mirror;
+  std::conditional_t<can_mirror, hbm_vector<StateType>, Empty1> mirror_backup;
+  hbm_vector<VertexType *> mirror_ptrs;
+  hbm_vector<uint8_t> mirror_state;
+  hbm_vector<size_t> mirror_hid;
+  bool mirrored = false;
+  void begin_mirror() override {
+    if constexpr (can_mirror) {
+      if (mirrored || !count()) return;
+      mirror.resize_uninit(count()); mirror_backup.resize_uninit(count()); mirror_ptrs.resize_uninit(count());
+      detail::k_mirror_in<VertexType><<<detail::blocks(count()), detail::TPB>>>(x_device.raw(), count(), mirror.raw(), mirror_ptrs.raw());
+      mirror_state.assign(active_state.raw(), count());
+      mirror_hid.assign(hessian_ids.raw(), count());
+      GRAPHITE_HIP(hipDeviceSynchronize());
+      mirrored = true;
+    }
+  }
+  void end_mirror() override {
+    if constexpr (can_mirror) {
+      if (!mirrored) return;
+      detail::k_mirror_out<VertexType><<<detail::blocks(count()), detail::TPB>>>(x_device.raw(), count(), mirror.raw());
+      GRAPHITE_HIP(hipDeviceSynchronize());
+      mirrored = false;
+    }
+  }
+  VertexType **vertices() const { return mirrored ? mirror_ptrs.raw() : x_device.raw(); }
+  StateType *backup_ptr() {
+    if constexpr (can_mirror) { if (mirrored) return mirror_backup.raw(); }
+    return backup_state.raw();
+  }
   uint8_t *get_active_state() const override { return active_state.raw(); }
   size_t *get_hessian_ids() const override { return hessian_ids.raw(); }
+  const uint8_t *device_active_state() const override { return mirrored ? mirror_state.raw() : active_state.raw(); }
+  const size_t *device_hessian_ids() const override { return mirrored ? mirror_hid.raw() : hessian_ids.raw(); }
   const std::vector<size_t> &local_to_global() const override { return local_to_global_map; }
   void to_device() {}
   void clear() { x_device.clear(); active_state.clear(); hessian_ids.clear(); backup_state.clear(); global_to_local_map.clear(); local_to_global_map.clear(); }
 
   void apply_update(const T *delta_x, const T *scales) override {
-    if (count()) detail::k_vertex_update<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), get_active_state(), get_hessian_ids(), count(), delta_x, scales);
+    if (count()) detail::k_vertex_update<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), device_active_state(), device_hessian_ids(), count(), delta_x, scales);
   }
   void backup_parameters() override {
-    if (count()) detail::k_vertex_backup<Traits, StateType><<<detail::blocks(count()), detail::TPB>>>(vertices(), get_active_state(), count(), backup_state.raw());
+    if (count()) detail::k_vertex_backup<Traits, StateType><<<detail::blocks(count()), detail::TPB>>>(vertices(), device_active_state(), count(), backup_ptr());
   }
   void restore_parameters() override {
-    if (count()) detail::k_vertex_restore<Traits, StateType><<<detail::blocks(count()), detail::TPB>>>(vertices(), get_active_state(), count(), backup_state.raw());
+    if (count()) detail::k_vertex_restore<Traits, StateType><<<detail::blocks(count()), detail::TPB>>>(vertices(), device_active_state(), count(), backup_ptr());
   }
   void gather_parameters(T *out) override {
     if (count()) detail::k_vertex_gather<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), count(), out);
@@ -612,15 +726,21 @@ template <typename F> __global__ void k_chi2(FactorView<F> fv) {
   fv.dchi2[f] = (typename F::Storage)fv.loss[f].loss_derivative(value);
 }
 
-template <typename T> __global__ void k_sum_active(const T *v, const size_t *active, size_t n, T *out) {
-  // small graphs: one block, fixed order per thread, tree in LDS
+// sum of v over the active factors in two stages with a fixed partition (block b sums its contiguous share, tree in LDS;
+// the partials are added in block order): the same bits every run.  partial: SUM_BLOCKS elements.
+constexpr int SUM_BLOCKS = 256;
+template <typename T> __global__ void k_sum_active(const T *v, const size_t *active, size_t n, T *partial) {
   __shared__ T red[TPB];
+  const size_t per = (n + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
   T s = 0;
-  for (size_t i = threadIdx.x; i < n; i += TPB) s += v[active[i]];
+  for (size_t i = i0 + threadIdx.x; i < i1; i += TPB) s += v[active[i]];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0) *out = red[0];
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+template <typename T> __global__ void k_sum_partials(const T *partial, int nb, T *out) {
+  if (threadIdx.x == 0) { T s = 0; for (int b = 0; b < nb; ++b) s += partial[b]; *out = s; }
 }
 
 // J_c^T P J_c' of two columns of (possibly different) slots
@@ -748,7 +868,7 @@ public:
   static constexpr size_t error_dim = E;
   static constexpr size_t get_num_vertices() { return N; }
 
-  struct JacobianStorage { managed_vector<S> data; size_t dimensions[2] = {0, 0}; };
+  struct JacobianStorage { hbm_vector<S> data; size_t dimensions[2] = {0, 0}; };
 
   std::array<BaseVertexDescriptor<T, S> *, N> vertex_descriptors{};
   std::array<void *, N> typed_descriptors{};
@@ -760,10 +880,11 @@ public:
   managed_vector<S> precision_matrices;    // E*E per factor, read row-major
   managed_vector<uint8_t> active;
   managed_vector<size_t> active_indices;
-  managed_vector<T> residuals, chi2_vec, work;
-  managed_vector<S> chi2_derivative;
+  hbm_vector<T> residuals, chi2_vec, work;
+  hbm_vector<S> chi2_derivative;
   std::array<JacobianStorage, N> jacobians;
   managed_vector<T> scalar;                // device scalar for reductions
+  hbm_vector<T> sum_partials;
   managed_vector<size_t> sparse_dst;       // [active factor][vertex pair] -> value offset in the block-sparse Hessian
   HandleManager<size_t> hm;                // factor.hpp:158-174: ids returned by add_factor are stable handles
   std::unordered_map<size_t, size_t> global_to_local_map;
@@ -784,6 +905,7 @@ public:
   // factor.hpp:373-412; precision_matrix == nullptr -> identity
   size_t add_factor(const std::array<size_t, N> &ids, const ObservationType &obs, const S *precision_matrix,
                     const ConstraintDataType &constraint_data, const LossType &loss_function) {
+    tables_mirrored = false;
     const size_t handle = hm.get(), id = internal_count(); // id: local index
     global_to_local_map.insert({handle, id});
     local_to_global_map.push_back(handle);
@@ -798,6 +920,7 @@ public:
   // local index of a factor handle; std::out_of_range for an unknown id, like the reference's .at() (factor.hpp:460)
   size_t local_id(size_t handle) const { return global_to_local_map.at(handle); }
   void remove_factor(size_t handle) { // swap with last, fix the id maps, release the handle (factor.hpp:308-371)
+    tables_mirrored = false;
     auto it = global_to_local_map.find(handle);
     if (it == global_to_local_map.end()) { std::cerr << "Factor with id " << handle << " not found." << std::endl; return; }
     const size_t id = it->second, last = internal_count() - 1;
@@ -813,7 +936,7 @@ public:
     host_ids.resize(last * N); device_ids.resize(last * N); device_obs.pop_back(); data.pop_back(); loss.pop_back(); active.pop_back();
     precision_matrices.resize(last * E * E); residuals.resize(E * last); chi2_vec.resize(last); chi2_derivative.resize(last); work.resize(E * last);
   }
-  void set_active(size_t handle, uint8_t active_value) { const size_t id = local_id(handle); active[id] = (active[id] & 0x80) | (active_value & 0x7F); } // factor.hpp:419-431
+  void set_active(size_t handle, uint8_t active_value) { tables_mirrored = false; const size_t id = local_id(handle); active[id] = (active[id] & 0x80) | (active_value & 0x7F); } // factor.hpp:419-431
   void reset_active() { for (size_t i = 0; i < active.size(); ++i) active[i] = 0; }
   // factor.hpp:626-640: false = no stored Jacobians, every product recomputes the analytic blocks (Manual
   // differentiation only; an Auto factor keeps storing, ops/linearize.hpp:109)
@@ -832,6 +955,7 @@ public:
   const ObservationType &get_observation(size_t handle) const { return device_obs[local_id(handle)]; }
   const ConstraintDataType &get_constraint_data(size_t handle) const { return data[local_id(handle)]; }
   void clear() {
+    tables_mirrored = false;
     host_ids.clear(); device_ids.clear(); device_obs.clear(); data.clear(); loss.clear(); precision_matrices.clear(); active.clear();
     active_indices.clear(); residuals.clear(); chi2_vec.clear(); chi2_derivative.clear(); work.clear();
     global_to_local_map.clear(); local_to_global_map.clear(); hm.clear();
@@ -848,16 +972,41 @@ public:
       if (detail::is_factor_active(active[f], level)) active_indices.push_back(f);
     }
     init_jacobians(std::make_index_sequence<N>{});
+    refresh_table_mirrors();
   }
   void flag_active_vertices() override {
     for (size_t i = 0; i < N; ++i)
-      if (active_count()) detail::k_flag_vertices<void><<<detail::blocks(active_count()), detail::TPB>>>(active_indices.raw(), active_count(), device_ids.raw(), N, i, vertex_descriptors[i]->get_active_state());
+      if (active_count()) detail::k_flag_vertices<void><<<detail::blocks(active_count()), detail::TPB>>>(m_active.get(active_indices, tables_mirrored), active_count(), m_ids.get(device_ids, tables_mirrored), N, i, vertex_descriptors[i]->get_active_state());
   }
 
+  // HBM copies of the per-factor tables the kernels only read (built on the host in pinned memory: ids, observations,
+  // constraint data, losses, precision matrices, the active list); refreshed by initialize(), dropped by any mutation
+  template <typename U> struct TableMirror {
+    static constexpr bool ok = std::is_trivially_copyable<U>::value && !std::is_empty<U>::value;
+    struct Nothing {};
+    std::conditional_t<ok, hbm_vector<U>, Nothing> d;
+    const U *get(const managed_vector<U> &h, bool valid) const {
+      if constexpr (ok) { if (valid && d.size() == h.size() && h.size()) return d.raw(); }
+      return h.raw();
+    }
+    void refresh(const managed_vector<U> &h) { if constexpr (ok) d.assign(h.raw(), h.size()); }
+  };
+  TableMirror<size_t> m_active, m_ids, m_sparse_dst;
+  TableMirror<ObservationType> m_obs;
+  TableMirror<ConstraintDataType> m_data;
+  TableMirror<LossType> m_loss;
+  TableMirror<S> m_pmat;
+  bool tables_mirrored = false;
+  void refresh_table_mirrors() {
+    m_active.refresh(active_indices); m_ids.refresh(device_ids); m_obs.refresh(device_obs); m_data.refresh(data);
+    m_loss.refresh(loss); m_pmat.refresh(precision_matrices);
+    tables_mirrored = true;
+  }
   detail::FactorView<FactorDescriptor> view() {
     detail::FactorView<FactorDescriptor> fv;
-    fv.active_ids = active_indices.raw(); fv.n_active = active_count(); fv.ids = device_ids.raw(); fv.obs = device_obs.raw();
-    fv.data = data.raw(); fv.loss = loss.raw(); fv.pmat = precision_matrices.raw(); fv.residuals = residuals.raw();
+    const bool mv = tables_mirrored;
+    fv.active_ids = m_active.get(active_indices, mv); fv.n_active = active_count(); fv.ids = m_ids.get(device_ids, mv); fv.obs = m_obs.get(device_obs, mv);
+    fv.data = m_data.get(data, mv); fv.loss = m_loss.get(loss, mv); fv.pmat = m_pmat.get(precision_matrices, mv); fv.residuals = residuals.raw();
     fv.chi2 = chi2_vec.raw(); fv.dchi2 = chi2_derivative.raw();
     fv.dynamic = dynamic_jacobians(); fv.scales = dynamic_scales;
     fill_view(fv, std::make_index_sequence<N>{});
@@ -877,7 +1026,10 @@ public:
   T chi2() override { // factor.hpp:551-557
     compute_chi2();
     if (!active_count()) return T(0);
-    detail::k_sum_active<T><<<1, detail::TPB>>>(chi2_vec.raw(), active_indices.raw(), active_count(), scalar.raw());
+    const int nb = (int)std::max<size_t>(1, std::min<size_t>(detail::SUM_BLOCKS, (active_count() + 4 * detail::TPB - 1) / (4 * detail::TPB)));
+    if (sum_partials.size() < (size_t)detail::SUM_BLOCKS) sum_partials.resize(detail::SUM_BLOCKS);
+    detail::k_sum_active<T><<<nb, detail::TPB>>>(chi2_vec.raw(), m_active.get(active_indices, tables_mirrored), active_count(), sum_partials.raw());
+    detail::k_sum_partials<T><<<1, 64>>>(sum_partials.raw(), nb, scalar.raw());
     detail::sync();
     return scalar[0];
   }
@@ -930,6 +1082,7 @@ public:
           sparse_dst[a * NUM_PAIRS + p] = d;
         }
     }
+    m_sparse_dst.refresh(sparse_dst);
   }
   void sparse_hessian(S *values) override {
     if constexpr (is_low_precision<S>::value) { (void)values; throw std::invalid_argument("block-sparse Hessian: 16-bit storage types are not supported (the reference refuses them too, bal.cu:181-203)"); }
@@ -970,7 +1123,7 @@ private:
   template <size_t... Is> void fill_view(detail::FactorView<FactorDescriptor> &fv, std::index_sequence<Is...>) {
     ((fv.jac[Is] = jacobians[Is].data.raw(),
       fv.verts[Is] = static_cast<typename std::tuple_element<Is, VDTuple>::type *>(typed_descriptors[Is])->vertices(),
-      fv.vstate[Is] = vertex_descriptors[Is]->get_active_state(), fv.hid[Is] = vertex_descriptors[Is]->get_hessian_ids()), ...);
+      fv.vstate[Is] = vertex_descriptors[Is]->device_active_state(), fv.hid[Is] = vertex_descriptors[Is]->device_hessian_ids()), ...);
   }
   template <size_t... Is> void jac_all(std::index_sequence<Is...> seq) {
     if (!active_count()) return;
@@ -1001,7 +1154,7 @@ private:
   template <size_t I, size_t... Ks> void sparse_row(detail::FactorView<FactorDescriptor> &fv, S *values, std::index_sequence<Ks...>) {
     // pair index of (I, K), K >= I, in the row-major upper enumeration used by sparse_setup
     ((Ks >= I ? (void)(detail::k_sparse_pair<FactorDescriptor, I, (Ks >= I ? Ks : I)><<<detail::blocks(active_count() * detail::slot_dim<FactorDescriptor, I>() * detail::slot_dim<FactorDescriptor, (Ks >= I ? Ks : I)>()), detail::TPB>>>(
-                     fv, values, sparse_dst.raw(), I * N - I * (I - 1) / 2 + (Ks - I), NUM_PAIRS))
+                     fv, values, m_sparse_dst.get(sparse_dst, tables_mirrored), I * N - I * (I - 1) / 2 + (Ks - I), NUM_PAIRS))
                : (void)0), ...);
   }
   template <size_t... Is> void sparse_all(S *values, std::index_sequence<Is...> seq) {
@@ -1037,7 +1190,7 @@ template <typename T> __global__ void k_clear_msb(uint8_t *s, size_t n) {
 template <typename T, typename S> class Graph {
   std::vector<BaseVertexDescriptor<T, S> *> vertex_descriptors;
   std::vector<BaseFactorDescriptor<T, S> *> factor_descriptors;
-  managed_vector<T> b, jacobian_scales;
+  hbm_vector<T> b, jacobian_scales;
   size_t hessian_dim = 0, pose_dim = 0, elimination_block = 0;
   std::vector<size_t> hessian_offsets; // scalar column of every block column (+ the dimension at the end), graph.hpp:40
   bool scale_jacobians_ = true;
@@ -1058,8 +1211,8 @@ public:
   size_t get_hessian_dimension() const { return hessian_dim; }
   // first column of the eliminated (set_eliminate) descriptors = dimension of the reduced system (pcg_schur.hpp:60-61)
   size_t get_pose_dimension() const { return pose_dim; }
-  managed_vector<T> &get_b() { return b; }
-  managed_vector<T> &get_jacobian_scales() { return jacobian_scales; }
+  hbm_vector<T> &get_b() { return b; }
+  hbm_vector<T> &get_jacobian_scales() { return jacobian_scales; }
   void clear() { vertex_descriptors.clear(); factor_descriptors.clear(); }
 
   // graph.hpp:92-167: active factors, which vertices they use, then one scalar column range per
@@ -1092,6 +1245,14 @@ public:
     return col > 0;
   }
   bool build_structure() { return true; }
+  // vertex values / states / Hessian columns in HBM for the duration of an optimiser loop (VertexDescriptor::begin_mirror)
+  void begin_device_mirror() { for (auto *vd : vertex_descriptors) vd->begin_mirror(); }
+  void end_device_mirror() { for (auto *vd : vertex_descriptors) vd->end_mirror(); }
+  struct DeviceMirrorScope {
+    Graph *g;
+    explicit DeviceMirrorScope(Graph *graph) : g(graph) { g->begin_device_mirror(); }
+    ~DeviceMirrorScope() { g->end_device_mirror(); }
+  };
 
   void compute_error() { for (auto *fd : factor_descriptors) fd->compute_error(); }
   T chi2() { T c = 0; for (auto *fd : factor_descriptors) c += fd->chi2(); return c; } // graph.hpp:212-225
