@@ -99,6 +99,12 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # GR_BENCH_SHARE_GPU=1 (testing only): every rank uses GPU 0, the process group is gloo and all all-reduces go through
+    # the IPC mailboxes (RCCL cannot put two ranks on one device) — exercises the N > 1 code path of this file on a
+    # 1-GPU box; the numbers it prints are not a scaling measurement
+    share_gpu = os.environ.get("GR_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # GR_BENCH_FORCE_COMM=1 (testing): run the sharded code path (process group, RCCL communicator, all-reduces)
     # even with a single rank, e.g. under `python -m torch.distributed.run --nproc-per-node 1`
@@ -108,7 +114,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import graphite_amd as ga
     from graphite_amd import synth
@@ -124,7 +133,7 @@ def main():
     def max_over_ranks(x):
         if not sharded:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -141,7 +150,10 @@ def main():
             # small all-reduces go peer to peer through IPC-mapped mailboxes (one hop over xGMI), RCCL carries what does
             # not fit a slot; the mailboxes are verified at start-up and every rank drops to RCCL together if that fails.
             # GR_COMM=rccl: RCCL for everything.
-            if os.environ.get("GR_COMM", "ipc") == "rccl":
+            if share_gpu:
+                used = gdist.init_comm_ipc(gpu, rank, world, slot_bytes=16 << 20, rccl_fallback=False)
+                transport["kind"] = "ipc-mailbox (shared GPU, test mode)"
+            elif os.environ.get("GR_COMM", "ipc") == "rccl":
                 gdist.init_comm(gpu, rank, world)
                 transport["kind"] = "rccl"
             else:

@@ -83,3 +83,23 @@ def test_ipc_allreduce_between_processes(world, tmp_path):
             assert np.allclose(np.array(res[0][key]["cams"]), c1, rtol=at, atol=1e-10)
             assert np.allclose(pts, p1, rtol=at, atol=1e-10)
         assert [len(res[r][key]["pts"]) for r in range(world)] == [b - a for a, b in ranges]
+
+
+def test_bench_two_ranks_share_the_gpu(tmp_path):
+    """bench.py's N > 1 path (torch.distributed.run, one process per rank, landmark shards, barriers, max over ranks, the
+    Venice `also` line) executed with two ranks on the one GPU of the box (GR_BENCH_SHARE_GPU=1: gloo process group, every
+    all-reduce through the IPC mailboxes).  Guards the flow the driver launches on a multi-GPU node; not a measurement."""
+    env = dict(os.environ, GR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "10",
+           "--warmup", "2", "--repeats", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 10 and line["value"] > 0 and line["scaling"] == "strong"
+    assert "landmark-sharded x2" in line["config"]["parallelism"]
+    assert line["collectives_per_lm_iteration"] > 0
+    venice = [a for a in line["also"] if "venice-1778" in a["workload"]]
+    assert venice and venice[0]["value"] > 0
