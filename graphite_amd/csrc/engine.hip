@@ -682,8 +682,8 @@ template <typename T> struct Engine final : EngineBase {
   // VertexDescriptor::set_fixed (vertex.hpp:262-264).  The reference gives a fixed vertex no Hessian column and its kernels
   // skip the vertex's Jacobian block; here the vertex keeps its (empty) column: zero block, zero gradient, scale 1, and its
   // rows of every operator product are dropped, so its step is exactly 0 and every other quantity is what the reduced
-  // system gives.  The explicit Schur solvers get there through zero camera-point blocks (k_linearize); the implicit-Schur
-  // PCG, which recomputes Jacobians in its own passes, refuses a problem with fixed vertices.
+  // system gives.  The explicit Schur solvers get there through zero camera-point blocks (k_linearize), the implicit-Schur
+  // PCG through a zero point "inverse" (k_point_prepare) and dropped camera rows (k_is_finalize, k_is_apply).
   DevBuf<unsigned char> d_cam_fixed, d_pt_fixed;
   bool has_fixed = false;
   void set_fixed(const unsigned char *cam_fixed, const unsigned char *pt_fixed) override {
@@ -855,8 +855,6 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   void solver_update_structure(int solver) override {
-    if (has_fixed && solver == GR_SOLVER_PCG_SCHUR_IMPLICIT)
-      throw std::invalid_argument("fixed vertices are not supported by the implicit-Schur PCG solver (use GR_SOLVER_PCG, GR_SOLVER_PCG_SCHUR or GR_SOLVER_DENSE_SCHUR)");
     if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
     else if (solver == GR_SOLVER_DENSE_SCHUR) { ensure_chol(); want_hcp = true; }
     else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) { want_hcp = false; ensure_implicit_schur(); if (!tiling_tuned) tune_tiling(); }
@@ -907,8 +905,8 @@ template <typename T> struct Engine final : EngineBase {
     if (!hcp_valid) linearize_impl(true);
     const int ui = damping_identity ? 1 : 0;
     const T *hcc_w = cam_weight() ? Hcc.p : nullptr; // the (global) camera blocks enter the all-reduced S once
-    if (for_solve) k_point_prepare<T><<<cdiv(Np, TPB) + 1, TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, scalars(), sc_cap);
-    else k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p);
+    if (for_solve) k_point_prepare<T><<<cdiv(Np, TPB) + 1, TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, scalars(), sc_cap, pt_fixed_p());
+    else k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, PcgScalars{}, 0, pt_fixed_p());
     if (nmulti) k_schur_multi<T, 0><<<cdiv(9 * (size_t)nmulti, TPB), TPB, 0, stream>>>(nmulti, multi_blk.p, S_rowi.p, S_coli.p, hcc_w, scales.p, damping, ui, S.p);
     {
       Scope sc(this, "schur_products", nprod * (54.0 * w() + 8) + 9.0 * Np * w() + 81.0 * nnzb * w(), nprod * 342.0);
@@ -1123,18 +1121,18 @@ template <typename T> struct Engine final : EngineBase {
     const int ui = damping_identity ? 1 : 0;
     ensure_scalars(max_iter);
     PcgScalars sc = scalars();
-    k_point_prepare<T><<<cdiv(Np, TPB) + 1, TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, sc, sc_cap);
+    k_point_prepare<T><<<cdiv(Np, TPB) + 1, TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, sc, sc_cap, pt_fixed_p());
     {
       Scope s0(this, "is_prepare", No * (2 * w() + 12.0) + (24.0 * Nc + 15.0 * Np) * w() + 54.0 * nseg * w(), No * 700.0);
       if (jac32) { k_is_prepare<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); } else { k_is_prepare<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); }
     }
     if (comm) { // diagonal blocks of S and b_S: this shard's sums, all-reduced, then combined with the global Hcc, bc
       is_raw.alloc(90 * (size_t)Nc);
-      k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p, nullptr, is_raw.p);
+      k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p, nullptr, is_raw.p, cam_fixed_p());
       allreduce_T(is_raw.p, 90 * (size_t)Nc);
-      k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p, is_raw.p, nullptr);
+      k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p, is_raw.p, nullptr, cam_fixed_p());
     } else
-      k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p);
+      k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p, nullptr, nullptr, cam_fixed_p());
     for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
     h_seq[1] = 0;
     k_schur_pcg_prepare<T, 2><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Sdiag.p, nullptr, nullptr, nullptr, nullptr, scales.p, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, v_q.p, sc);
@@ -1153,7 +1151,7 @@ template <typename T> struct Engine final : EngineBase {
         k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, sc.done, k);
         allreduce_T(raw_c.p, pose_dim);
       }
-      k_is_apply<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, Hcc.p, scales.p, v_p.p, v_q.p, damping, ui, v_Ap.p, sc, k, comm ? raw_c.p : nullptr);
+      k_is_apply<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, Hcc.p, scales.p, v_p.p, v_q.p, damping, ui, v_Ap.p, sc, k, comm ? raw_c.p : nullptr, cam_fixed_p());
       k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k);
       k_pcgs_direction<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, x, v_xb.p, v_p.p, v_z.p, v_q.p, scales.p, sc, k, tol, rej);
     });

@@ -155,7 +155,10 @@ template <typename T>
 __global__ void k_point_prepare(int Np, int Nc, const T *__restrict__ Hll, const T *__restrict__ bl,
                                 const T *__restrict__ scales, double mu, int use_identity,
                                 T *__restrict__ Hll_inv, T *__restrict__ Mp, T *__restrict__ vl,
-                                PcgScalars pcg = PcgScalars{}, int cap = 0) {
+                                PcgScalars pcg = PcgScalars{}, int cap = 0,
+                                // fixed points: eliminated with a zero "inverse", i.e. they add nothing to S and b_S, the implicit
+                                // operator skips them and their back-substituted step is 0
+                                const unsigned char *__restrict__ pt_fixed = nullptr) {
   if (pcg.rz && blockIdx.x == gridDim.x - 1) { // one extra block: reset of the PCG scalars of the solve that follows
     for (int i = threadIdx.x; i < cap * pcg.np; i += blockDim.x) { pcg.rz[i] = 0.0; pcg.den[i] = 0.0; }
     for (int i = threadIdx.x; i < cap; i += blockDim.x) { pcg.done[i] = 0; pcg.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
@@ -176,9 +179,10 @@ __global__ void k_point_prepare(int Np, int Nc, const T *__restrict__ Hll, const
       A[r + 3 * c] = (r == c) ? (double)damp_diag(v, mu, use_identity) : (double)v;
     }
   spd_inverse<3>(A);
+  const bool fixed = pt_fixed && pt_fixed[l];
   T inv[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { inv[i] = (T)A[i]; Hll_inv[9 * (size_t)l + i] = inv[i]; }
+  for (int i = 0; i < 9; ++i) { inv[i] = fixed ? T(0) : (T)A[i]; Hll_inv[9 * (size_t)l + i] = inv[i]; }
   T m[9];
 #pragma unroll
   for (int c = 0; c < 3; ++c)

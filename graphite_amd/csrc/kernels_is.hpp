@@ -127,7 +127,8 @@ template <typename T>
 __global__ void k_is_finalize(int Nc, const int *__restrict__ cam_seg_ptr, const T *__restrict__ cam_partial,
                               const T *__restrict__ Hcc, const T *__restrict__ bc, const T *__restrict__ scales,
                               double mu, int use_identity, T *__restrict__ Sdiag, T *__restrict__ b_schur,
-                              const T *__restrict__ raw_in = nullptr, T *__restrict__ raw_out = nullptr) {
+                              const T *__restrict__ raw_in = nullptr, T *__restrict__ raw_out = nullptr,
+                              const unsigned char *__restrict__ cam_fixed = nullptr) {
   // multi-GPU: stage 1 (raw_out) leaves this shard's 90 sums per camera for the all-reduce,
   // stage 2 (raw_in) combines the all-reduced sums with the (already global) Hcc, bc
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -143,6 +144,7 @@ __global__ void k_is_finalize(int Nc, const int *__restrict__ cam_seg_ptr, const
   T s = 0;
   if (raw_in) s = raw_in[t];
   else for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) s += cam_partial[54 * (size_t)sg + idx];
+  if (cam_fixed && cam_fixed[c]) s = T(0); // a fixed camera has no Jacobian block: nothing is eliminated into its (empty) row
   if (raw_out) { raw_out[t] = s; return; }
   if (e < 81u) {
     const T sr = scales[9 * c + row], sc = scales[9 * c + col];
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(TPB)
 k_is_apply(int Nc, const int *__restrict__ cam_seg_ptr, const T *__restrict__ op_partial,
            const T *__restrict__ Hcc, const T *__restrict__ scales, const T *__restrict__ p,
            const T *__restrict__ q, double mu, int use_identity, T *__restrict__ Ap, PcgScalars sc, int k,
-           const T *__restrict__ rawc = nullptr) {
+           const T *__restrict__ rawc = nullptr, const unsigned char *__restrict__ cam_fixed = nullptr) {
   if (sc.done[k]) return;
   if (part_sum(sc.rz, sc.np, k) == 0.0) return;
   __shared__ double red[4];
@@ -272,6 +274,7 @@ k_is_apply(int Nc, const int *__restrict__ cam_seg_ptr, const T *__restrict__ op
     T sub = 0;
     if (rawc) sub = rawc[t]; // multi-GPU: segment sums all-reduced over the landmark shards
     else for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) sub += op_partial[9 * (size_t)sg + r];
+    if (cam_fixed && cam_fixed[c]) sub = T(0);
     const T s = scales[t], pv = p[t];
     const T d = s * H[10 * r] * s; // scaled diagonal of Hcc (prev_diag of hessian.hpp:102-134)
     const T damp = use_identity ? (T)mu * pv : (T)(mu * clampd((double)d, 1.0e-6, 1.0e32)) * pv;

@@ -546,7 +546,6 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
       if (st[v] & 0x1) { mask[v] = 1; any_fixed = true; }
     }
   }
-  if (any_fixed && kind == GR_SOLVER_PCG_SCHUR_IMPLICIT) return false;
   std::vector<int32_t> ci, pi;
   std::vector<T> obs;
   int loss_kind = 0; double loss_delta = 0;

@@ -138,7 +138,7 @@ gr_status gr_bal_set_scale_system(gr_bal_problem *p, int enable);
 /* VertexDescriptor::set_fixed (vertex.hpp:262-264): cam_fixed[Nc] / pt_fixed[Np] (caller's vertex order), non-zero = the
  * vertex keeps its value; NULL = none of that type.  The reference gives a fixed vertex no Hessian column and skips its
  * Jacobian blocks (ops/linearize.hpp:24, ops/hessian.hpp:95); here its column stays, empty, and its step is exactly 0.
- * Supported by every solver except GR_SOLVER_PCG_SCHUR_IMPLICIT, which returns GR_ERR_INVALID on such a problem.
+ * Supported by every solver.
  * Host pointers. */
 gr_status gr_bal_set_fixed(gr_bal_problem *p, const unsigned char *cam_fixed, const unsigned char *pt_fixed);
 gr_status gr_bal_set_jacobian_precision(gr_bal_problem *p, gr_dtype dtype);

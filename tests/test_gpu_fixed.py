@@ -2,7 +2,7 @@
 Jacobian blocks of a fixed vertex, ops/linearize.hpp:24, ops/hessian.hpp:95) against the oracle's restatement:
 LM traces, inner iteration counts, the step at fixed vertices exactly zero, their parameters bit-unchanged — for every
 form of the matrix-free PCG the engine has (direction kernel, lazy direction, single-reduction recurrence, point-tiled
-order) and on landmark shards.  The solvers without fixed-vertex support must refuse such a problem."""
+order), for the Schur solvers, and on landmark shards."""
 import threading
 
 import numpy as np
@@ -29,18 +29,19 @@ def masks(prob):
 
 
 @pytest.mark.parametrize("form", list(FORMS))
-@pytest.mark.parametrize("solver", ["pcg", "pcg_identity", "pcg_schur", "dense_schur"])
+@pytest.mark.parametrize("solver", ["pcg", "pcg_identity", "pcg_schur", "pcg_schur_implicit", "dense_schur"])
 @pytest.mark.parametrize("name,dtype", [("mini-50", np.float64), ("ladybug-49", np.float32)])
 def test_lm_with_fixed_vertices_matches_oracle(oracle_mod, monkeypatch, name, dtype, solver, form):
     for k in ("GR_PCG_LAZY", "GR_PCG_CG", "GR_PTILES"):
         monkeypatch.delenv(k, raising=False)
     for k, v in FORMS[form].items():
         monkeypatch.setenv(k, v)
-    if solver in ("pcg_schur", "dense_schur") and form not in ("default", "tiled8"):
+    if solver in ("pcg_schur", "pcg_schur_implicit", "dense_schur") and form not in ("default", "tiled8"):
         pytest.skip("PCG forms concern the matrix-free solvers")
-    gs = dict(pcg=ga.SOLVER_PCG, pcg_identity=ga.SOLVER_PCG_IDENTITY, pcg_schur=ga.SOLVER_PCG_SCHUR, dense_schur=ga.SOLVER_DENSE_SCHUR)[solver]
+    gs = dict(pcg=ga.SOLVER_PCG, pcg_identity=ga.SOLVER_PCG_IDENTITY, pcg_schur=ga.SOLVER_PCG_SCHUR, pcg_schur_implicit=ga.SOLVER_PCG_SCHUR_IMPLICIT,
+              dense_schur=ga.SOLVER_DENSE_SCHUR)[solver]
     os_ = dict(pcg=oracle_mod.SOLVER_PCG, pcg_identity=oracle_mod.SOLVER_PCG_IDENTITY, pcg_schur=oracle_mod.SOLVER_PCG_SCHUR,
-               dense_schur=oracle_mod.SOLVER_LDLT_SCHUR)[solver]
+               pcg_schur_implicit=oracle_mod.SOLVER_PCG_SCHUR, dense_schur=oracle_mod.SOLVER_LDLT_SCHUR)[solver]
     prob = synth.make_config(name)
     cf, pf = masks(prob)
     gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
@@ -111,16 +112,3 @@ def test_fixed_vertices_on_landmark_shards(oracle_mod):
         assert np.allclose(out[r][0], ct_r, rtol=1e-8)
         assert np.array_equal(cams[r], cams[0])
     assert np.array_equal(cams[0][cf], prob.cameras[cf]) and np.array_equal(pts[pf], prob.points[pf])
-
-
-@pytest.mark.parametrize("solver", [ga.SOLVER_PCG_SCHUR_IMPLICIT])
-def test_solvers_without_fixed_vertex_support_refuse(solver):
-    prob = synth.make_config("mini-50")
-    cf, pf = masks(prob)
-    gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
-    gpu.set_fixed(cf, pf)
-    with pytest.raises(_lib.GraphiteError, match="fixed vertices"):
-        gpu.levenberg_marquardt(solver=solver, iterations=2)
-    gpu.set_fixed(None, None)          # cleared: the solver runs
-    gpu.levenberg_marquardt(solver=solver, iterations=2)
-    gpu.close()
