@@ -287,6 +287,20 @@ def main():
 
     # ---- CPU baseline + parity against the oracle ---------------------------------------------------------------
     cpu, parity_rel, parity_steps = None, None, 0
+    if not args.no_cpu_baseline and world > 1 and rank == 0:
+        # N > 1: no CPU timing legs (they belong to the N = 1 line), but the parity check of the sharded run's trace
+        # against the oracle of the FULL problem is kept: it is what shows that the shards solve the same problem
+        import oracle
+        osolver = {"pcg": oracle.SOLVER_PCG, "pcg-schur": oracle.SOLVER_PCG_SCHUR, "pcg-schur-implicit": oracle.SOLVER_PCG_SCHUR,
+                   "dense-schur": oracle.SOLVER_LDLT_SCHUR}[solver_name]
+        per_it = {"pcg": 0.7, "pcg-schur": 2.5, "pcg-schur-implicit": 2.5, "dense-schur": 6.0}[solver_name] * (No / 678718.0)
+        parity_steps = int(max(2, min(steps_run, 12, 10.0 / per_it)))
+        ref = oracle.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+        ct_r, _, _ = ref.levenberg_marquardt(solver=osolver, iterations=parity_steps, initial_damping=1e-4,
+                                             pcg_max_iter=args.pcg_iterations, pcg_tol=args.pcg_tol, pcg_rej=5.0)
+        m = min(len(ct_r), len(ct))
+        parity_rel = float(np.max(np.abs(np.asarray(ct[:m]) - ct_r[:m]) / np.abs(ct_r[:m])))
+        del ref
     if not args.no_cpu_baseline and world == 1:
         import oracle
         nproc = effective_cores()

@@ -1050,6 +1050,7 @@ template <typename T> struct Engine final : EngineBase {
   // dissects (the tile elimination tree is clearly shorter than the chain of tile columns), DenseChol otherwise.
   // GR_SPARSE_CHOL=0 / 1 forces the choice.
   SparseChol<T> spchol;
+  bool spchol_overlap = !(getenv("GR_SPCHOL_OVERLAP") && atoi(getenv("GR_SPCHOL_OVERLAP")) == 0); // A/B knob: forward substitution beside the factorisation
   bool use_spchol = false;
   void ensure_chol() {
     build_schur_structure();
@@ -1092,8 +1093,8 @@ template <typename T> struct Engine final : EngineBase {
     schur_update_values();
     if (use_spchol) {
       spchol.load(nnzb, S_rowi.p, S_coli.p, S.p);
-      spchol.factor();
-      spchol.solve(b_schur.p, x);
+      if (spchol_overlap) spchol.factor_solve(b_schur.p, x);
+      else { spchol.factor(); spchol.solve(b_schur.p, x); }
       broadcast_camera_step(x);
       landmark_update_dev(x, x + pose_dim);
       h_seq[1] = 0;

@@ -314,7 +314,13 @@ template <typename T> struct SparseChol {
 
   SparseChol() = default;
   SparseChol(const SparseChol &) = delete;
-  ~SparseChol() { if (h_fail) (void)hipHostFree(h_fail); }
+  ~SparseChol() {
+    if (h_fail) (void)hipHostFree(h_fail);
+    for (hipEvent_t e : lvl_done) (void)hipEventDestroy(e);
+    if (aux_done) (void)hipEventDestroy(aux_done);
+    if (rhs_ready) (void)hipEventDestroy(rhs_ready);
+    if (aux) (void)hipStreamDestroy(aux);
+  }
 
   // nested dissection of the camera graph: returns the supernodes (camera lists) in elimination order
   static std::vector<std::vector<int>> nested_dissection(int Nc, const std::vector<std::vector<int>> &adj) {
@@ -502,7 +508,8 @@ template <typename T> struct SparseChol {
     k_sp_clear<T><<<nz_tiles, 256, 0, stream>>>(A.p, npad, d_pad.p, d_nz.p);
     k_sp_scatter<T><<<(unsigned)((81 * nnzb + 255) / 256), 256, 0, stream>>>(nnzb, rowi, coli, d_camcol.p, S, A.p, npad);
   }
-  void factor() {
+  void factor() { factor_levels([](int) {}); }
+  template <typename After> void factor_levels(After &&after_level) {
     GR_HIP(hipMemsetAsync(d_fail.p, 0, sizeof(int), stream));
     const size_t lds_g = chol_gemm_lds(sizeof(T)), lds_p = chol_potrf_lds(sizeof(T));
     const double tb = (double)CH_NB * CH_NB * sizeof(T), tf = 2.0 * CH_NB * CH_NB * CH_NB;
@@ -521,7 +528,38 @@ template <typename T> struct SparseChol {
         Sc sc(sink, "spchol_update", (2.0 * nup + 2.0 * nk) * tb, nk * tf);
         k_sp_gemm<T, 1><<<nup, 256, std::max(lds_g, lds_p), stream>>>(A.p, npad, d_upd.p + 2 * (size_t)lvl_upd_off[l], d_kptr.p + lvl_upd_off[l], d_klist.p, nullptr, Linv.p, d_fail.p);
       }
+      // level l's panels (L_kk^-1, trsm'ed sub-diagonal tiles) are final here; what the update launch above still writes are
+      // tiles of LATER columns
+      after_level(l);
     }
+  }
+  // factor() with the forward substitution of `b` riding beside it: level l of L y = b only needs the panels of level l, so
+  // it is enqueued on a second stream behind level l's factor kernels and runs under level l + 1's (a level's substitution
+  // launch is 6-25 us of latency, its factor launches 110 us: hidden except for the last level).  Then back-substitution.
+  hipStream_t aux = nullptr;
+  std::vector<hipEvent_t> lvl_done;
+  hipEvent_t aux_done = nullptr, rhs_ready = nullptr;
+  void factor_solve(const T *b, T *x) {
+    if (!aux) {
+      GR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+      GR_HIP(hipEventCreateWithFlags(&aux_done, hipEventDisableTiming));
+      GR_HIP(hipEventCreateWithFlags(&rhs_ready, hipEventDisableTiming));
+    }
+    while ((int)lvl_done.size() < nlevels) { hipEvent_t e; GR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); lvl_done.push_back(e); }
+    k_sp_rhs<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, b, vb.p);
+    GR_HIP(hipEventRecord(rhs_ready, stream));
+    GR_HIP(hipStreamWaitEvent(aux, rhs_ready, 0));
+    factor_levels([&](int l) {
+      GR_HIP(hipEventRecord(lvl_done[l], stream));
+      GR_HIP(hipStreamWaitEvent(aux, lvl_done[l], 0));
+      k_sp_fwd<T><<<lvl_fitem_off[l + 1] - lvl_fitem_off[l], 256, 0, aux>>>(A.p, npad, Linv.p, items(d_itf, lvl_fitem_off[l]), d_rcols.p, vb.p, vy.p, partial.p, ticket.p);
+    });
+    GR_HIP(hipEventRecord(aux_done, aux));
+    GR_HIP(hipStreamWaitEvent(stream, aux_done, 0));
+    Sc sc(sink, "spchol_solve", 1.0 * (double)factor_tiles * CH_NB * CH_NB * sizeof(T), 2.0 * (double)factor_tiles * CH_NB * CH_NB);
+    for (int l = nlevels - 1; l >= 0; --l)
+      k_sp_bwd<T><<<lvl_bitem_off[l + 1] - lvl_bitem_off[l], 256, 0, stream>>>(A.p, npad, Linv.p, items(d_itb, lvl_bitem_off[l]), d_crows.p, vy.p, vx.p, partial.p, ticket.p);
+    k_sp_unpermute<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, vx.p, x);
   }
   // b, x: device vectors of length n in the CALLER's (camera-major) order (x may alias b)
   void solve(const T *b, T *x) {

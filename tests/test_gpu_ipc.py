@@ -101,5 +101,6 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 10 and line["value"] > 0 and line["scaling"] == "strong"
     assert "landmark-sharded x2" in line["config"]["parallelism"]
     assert line["collectives_per_lm_iteration"] > 0
+    assert line["parity_rel"] is not None and line["parity_rel"] < 1e-6     # the sharded trace against the oracle of the full problem
     venice = [a for a in line["also"] if "venice-1778" in a["workload"]]
     assert venice and venice[0]["value"] > 0

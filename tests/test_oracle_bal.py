@@ -134,3 +134,52 @@ def test_golden_fixtures(oracle_mod):
         o = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx)
         ct, _, _ = o.levenberg_marquardt(solver=solver, iterations=8)
         assert np.allclose(ct, g[key], rtol=1e-9), key
+
+
+def test_oracle_single_reduction_pcg_equals_reference_recurrence(oracle_mod):
+    """solve_pcg_cg (Chronopoulos-Gear, the documented variant the GPU engine runs on landmark shards) against solve_pcg
+    (solver/pcg.hpp:61-232): same iterates up to rounding, same iteration counts for cap, tolerance and rejection exits."""
+    from graphite_amd import synth
+    prob = synth.make_config("mini-50")
+    for dtype, bar in ((np.float64, 1e-11), (np.float32, 1e-3)):
+        out = []
+        for variant in (0, 1):
+            o = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+            o.set_pcg_single_reduction(variant)
+            o.linearize()
+            o.solver_update_values(oracle_mod.SOLVER_PCG)
+            o.solver_set_damping(oracle_mod.SOLVER_PCG, 1e-4)
+            res = [o.solver_solve(oracle_mod.SOLVER_PCG, max_iter=m, tol=t, rej=r) for m, t, r in ((10, 0.0, 1e30), (25, 1e-3, 1e30), (25, 0.0, 0.5))]
+            ct, _, st = o.levenberg_marquardt(solver=oracle_mod.SOLVER_PCG, iterations=6)
+            out.append((res, ct, st["pcg_iterations"]))
+        for (dx0, it0), (dx1, it1) in zip(out[0][0], out[1][0]):
+            assert it0 == it1
+            assert np.abs(dx0 - dx1).max() / np.abs(dx0).max() < bar
+        assert out[0][2] == out[1][2]
+        assert np.max(np.abs(out[0][1] - out[1][1]) / out[0][1]) < (1e-12 if dtype == np.float64 else 1e-4)
+
+
+def test_oracle_fixed_vertices(oracle_mod):
+    """VertexDescriptor::set_fixed (vertex.hpp:262-264) as the oracle restates it: fixed vertices do not move, their step
+    and gradient entries are exactly zero, and the Schur direct solve still equals the full-system one (tests/schur.cu's
+    relation) with vertices of both kinds fixed."""
+    from graphite_amd import synth
+    prob = synth.make_config("mini-50")
+    cf = np.zeros(prob.shape[0], bool)
+    cf[[0, 7]] = True
+    pf = np.zeros(prob.shape[1], bool)
+    pf[:10] = True
+    finals = {}
+    for solver in (oracle_mod.SOLVER_PCG, oracle_mod.SOLVER_PCG_SCHUR, oracle_mod.SOLVER_LDLT_SCHUR, oracle_mod.SOLVER_LDLT):
+        o = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx)
+        o.set_fixed(cf, pf)
+        o.linearize()
+        b = o.get("b")
+        fixed_entries = np.concatenate([np.repeat(cf, 9), np.repeat(pf, 3)])
+        assert np.all(b[fixed_entries] == 0) and np.abs(b[~fixed_entries]).max() > 0
+        ct, _, _ = o.levenberg_marquardt(solver=solver, iterations=5)
+        c, p = o.get_params()
+        assert np.array_equal(c[cf], prob.cameras[cf]) and np.array_equal(p[pf], prob.points[pf])
+        assert np.abs(c[~cf] - prob.cameras[~cf]).max() > 1e-3 and ct[-1] < 0.1 * ct[0]
+        finals[solver] = ct[-1]
+    assert abs(finals[oracle_mod.SOLVER_LDLT_SCHUR] - finals[oracle_mod.SOLVER_LDLT]) / finals[oracle_mod.SOLVER_LDLT] < 1e-9
