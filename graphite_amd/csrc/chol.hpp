@@ -55,15 +55,41 @@ template <> __device__ __forceinline__ void load8<float>(const float *p, float (
   for (int i = 0; i < 2; ++i) { const float4 t = q[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
 }
 
+// value of lane `src` (0..15) of the caller's 16-lane row, in every lane of that row: DPP row_share, a plain VALU move —
+// v_readlane goes through an SGPR and pays the VALU->SGPR->VALU wait states 480 times per 16 x 16 diagonal block.
+// `src` is a constant after unrolling (the switch folds away).
+__device__ __forceinline__ int row_share(int v, int src) {
+  switch (src & 15) {
+#define GR_RS(N) case N: return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, false);
+    GR_RS(0) GR_RS(1) GR_RS(2) GR_RS(3) GR_RS(4) GR_RS(5) GR_RS(6) GR_RS(7) GR_RS(8) GR_RS(9) GR_RS(10) GR_RS(11) GR_RS(12) GR_RS(13) GR_RS(14)
+#undef GR_RS
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 15, 0xf, 0xf, false);
+  }
+}
+// 1/sqrt(d) for the pivots: hardware estimate + Newton steps y <- y (1.5 - 0.5 d y^2) (two in fp64, one in fp32) instead
+// of the library routine (a correctly rounded sqrt followed by a division) on the serial critical path of the
+// 16 x 16 diagonal step; relative error a few ulp, absorbed by the L L^T product like any other rounding
+__device__ __forceinline__ double pivot_rsqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
+}
+__device__ __forceinline__ float pivot_rsqrt(float d) {
+  float y = __builtin_amdgcn_rsqf(d);
+  y = y * (1.5f - 0.5f * d * y * y);
+  return y;
+}
 template <typename T> __device__ __forceinline__ T lane_bcast(T v, int src);
 template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+  return __builtin_bit_cast(float, row_share(__builtin_bit_cast(int, v), src));
 }
 template <> __device__ __forceinline__ double lane_bcast<double>(double v, int src) {
   const int2 u = __builtin_bit_cast(int2, v);
   int2 r;
-  r.x = __builtin_amdgcn_readlane(u.x, src);
-  r.y = __builtin_amdgcn_readlane(u.y, src);
+  r.x = row_share(u.x, src);
+  r.y = row_share(u.y, src);
   return __builtin_bit_cast(double, r);
 }
 
@@ -101,7 +127,7 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
       for (int j = 0; j < 16; ++j) {
         T d = lane_bcast<T>(a[j], j);
         if (!(d > T(0))) { bad = true; d = T(1); }
-        rsv[j] = rsqrt(d);
+        rsv[j] = pivot_rsqrt(d);
         a[j] = cl == j ? d * rsv[j] : a[j] * rsv[j];
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) a[k] -= a[j] * lane_bcast<T>(a[j], k);
