@@ -196,7 +196,7 @@ template <typename T> __global__ void k_sp_unpermute(int npad, const int *__rest
 // arrives LAST at the panel's ticket adds them in item order (fixed order: reproducible) and finishes the panel.
 // Visibility across XCDs: write-through (agent-scope relaxed atomic) stores, drained, then a relaxed ticket; the last
 // arriver reads with agent-scope loads (cdna_hip_programming.md G16, form R1) — the same hand-off as grid_sum2.
-constexpr int SP_SLICE = 6;
+static const int SP_SLICE = getenv("GR_SPCHOL_SLICE") ? std::max(1, atoi(getenv("GR_SPCHOL_SLICE"))) : 2; // tiles per substitution item (A/B knob; 6 -> 2: 249 -> 260 LM it/s)
 struct SpItems { const int *panel, *beg, *end, *first, *count; int base; }; // per item: panel, slice, first item / item count of its panel (absolute item ids); base = id of this launch's item 0
 template <typename T> __device__ __forceinline__ bool sp_last_arriver(T val, bool writer, T *__restrict__ partial, int item, int idx, unsigned *__restrict__ ticket, int panel, int count) {
   __shared__ bool s_last;
@@ -253,6 +253,9 @@ __global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, int ld,
   }
 }
 // backward: x_k = Linv_k^T (y_k - sum_{i in col(k)} L_ik^T x_i)
+// (Measured and removed: ONE launch for all levels with an in-kernel grid barrier between them, x exchanged through
+// agent-scope atomics — 246-250 LM it/s either way on Ladybug-1723: a level's 20 us are the cold reads of its L tiles by a
+// few workgroups, not the launch boundary.  What did help is more, smaller items per panel: SP_SLICE 6 -> 2, 249 -> 260.)
 template <typename T>
 __global__ __launch_bounds__(256) void k_sp_bwd(const T *__restrict__ A, int ld, const T *__restrict__ Linv, SpItems it, const int *__restrict__ crows,
                                                 const T *__restrict__ y, T *__restrict__ x, T *__restrict__ partial, unsigned *__restrict__ ticket) {
@@ -557,9 +560,12 @@ template <typename T> struct SparseChol {
     GR_HIP(hipEventRecord(aux_done, aux));
     GR_HIP(hipStreamWaitEvent(stream, aux_done, 0));
     Sc sc(sink, "spchol_solve", 1.0 * (double)factor_tiles * CH_NB * CH_NB * sizeof(T), 2.0 * (double)factor_tiles * CH_NB * CH_NB);
+    backward();
+    k_sp_unpermute<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, vx.p, x);
+  }
+  void backward() {
     for (int l = nlevels - 1; l >= 0; --l)
       k_sp_bwd<T><<<lvl_bitem_off[l + 1] - lvl_bitem_off[l], 256, 0, stream>>>(A.p, npad, Linv.p, items(d_itb, lvl_bitem_off[l]), d_crows.p, vy.p, vx.p, partial.p, ticket.p);
-    k_sp_unpermute<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, vx.p, x);
   }
   // b, x: device vectors of length n in the CALLER's (camera-major) order (x may alias b)
   void solve(const T *b, T *x) {
@@ -567,8 +573,7 @@ template <typename T> struct SparseChol {
     k_sp_rhs<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, b, vb.p);
     for (int l = 0; l < nlevels; ++l)
       k_sp_fwd<T><<<lvl_fitem_off[l + 1] - lvl_fitem_off[l], 256, 0, stream>>>(A.p, npad, Linv.p, items(d_itf, lvl_fitem_off[l]), d_rcols.p, vb.p, vy.p, partial.p, ticket.p);
-    for (int l = nlevels - 1; l >= 0; --l)
-      k_sp_bwd<T><<<lvl_bitem_off[l + 1] - lvl_bitem_off[l], 256, 0, stream>>>(A.p, npad, Linv.p, items(d_itb, lvl_bitem_off[l]), d_crows.p, vy.p, vx.p, partial.p, ticket.p);
+    backward();
     k_sp_unpermute<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, vx.p, x);
   }
   bool ok() {
