@@ -496,6 +496,9 @@ template <typename T> struct Engine final : EngineBase {
       // the linearisation 2x slower than 32)
       const int k_l2 = cdiv((size_t)Np * per_point, (size_t)(3u << 20)), k_run = (int)std::max<int64_t>(8, No / std::max<int64_t>(1, Nc * 64));
       K = std::min(k_l2, k_run);
+      // a multiple of 8 (one share per XCD): rounded UP when the L2 asks for the tiles, DOWN when the run length caps them
+      // (Final-13682: 33 -> 40 tiles left 53-observation runs, every wave straddling two cameras; 32 keeps 66)
+      K = k_run < k_l2 ? std::max(8, K / 8 * 8) : std::max(8, (K + 7) / 8 * 8);
     }
     if (K <= 0) return;
     K = std::max(8, (K + 7) / 8 * 8);
