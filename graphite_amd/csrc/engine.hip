@@ -772,6 +772,17 @@ template <typename T> struct Engine final : EngineBase {
     hcp_valid = write_hcp;
   }
   void launch_linearize_cam(bool hcp, T *g9p, const int *gate) {
+#ifdef GR_DIAG
+    { // diagnostic builds: GR_LIN_VAR=1|2|4|8 runs an ablated lineariser INSIDE the solve (wrong numbers, real cache state)
+      static const int var = getenv("GR_LIN_VAR") ? atoi(getenv("GR_LIN_VAR")) : 0;
+#define GR_LINV(V) k_linearize<T, false, T, V><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate)
+      if (!hcp && var == 1) { GR_LINV(1); return; }
+      if (!hcp && var == 2) { GR_LINV(2); return; }
+      if (!hcp && var == 4) { GR_LINV(4); return; }
+      if (!hcp && var == 8) { GR_LINV(8); return; }
+#undef GR_LINV
+    }
+#endif
     if constexpr (sizeof(T) == 8) {
       if (jac32) {
         if (hcp) k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p());
