@@ -2111,7 +2111,9 @@ gr_status gr_bal_comm_ipc_mailbox(gr_bal_problem *p, size_t slot_bytes, int worl
     slot_bytes = (slot_bytes + 255) / 256 * 256;
     const size_t bytes = IpcComm::mailbox_bytes(world_size, slot_bytes);
     char *box = nullptr;
-    GR_HIP(hipMalloc(reinterpret_cast<void **>(&box), bytes));
+    // FINE-GRAINED device memory: peers write it over xGMI while this GPU's kernels read it; coarse-grained (plain hipMalloc)
+    // lines may sit stale in this GPU's L2s across launches, fine-grained ones are coherent at the memory side
+    GR_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&box), bytes, hipDeviceMallocFinegrained));
     GR_HIP(hipMemset(box, 0, bytes));
     GR_HIP(hipDeviceSynchronize());
     hipIpcMemHandle_t h;
