@@ -303,7 +303,11 @@ template <typename T> struct Engine final : EngineBase {
     }
     const int grid_mult = getenv("GR_GRID_MULT") ? atoi(getenv("GR_GRID_MULT")) : 4; // tuning knob (blocks per CU)
     grid_obs = std::max(8, std::min(nb_pm, num_cu * grid_mult) & ~7); // multiple of 8: one contiguous tile range per XCD
-    grid_vec = std::min(cdiv(n, TPB), num_cu * 8);   // light vector kernels
+    { // light vector kernels: GR_VEC_PER_THREAD elements per thread (every wave first re-derives the loop scalars from the
+      // dot-product slots, so one element per thread made that prologue most of the kernel)
+      const int per = getenv("GR_VEC_PER_THREAD") ? std::max(1, atoi(getenv("GR_VEC_PER_THREAD"))) : 2; // replayed back to back on Ladybug-1723: 5.3 us (1), 4.4 (2), 4.9 (4), 5.8 (8)
+      grid_vec = std::max(1, std::min(cdiv(n, (size_t)TPB * per), num_cu * 8));
+    }
     grid_chi2 = std::max(8, std::min(nb_pm, num_cu * 2) & ~7); // measured: the light chi2 pass prefers 2 long blocks per CU (16 vs 22 us at 8)
     n_chi2_blocks = std::min(cdiv(No, TPB), 1024);
     chi2_partial.alloc(std::max<size_t>(nb_pm, 2 * (size_t)cdiv(std::max<size_t>(No, n), TPB)) + 64);

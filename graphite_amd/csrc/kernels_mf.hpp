@@ -54,6 +54,9 @@ constexpr int TICKET_GROUPS = 64;
 // kernel; camera-space vectors are replicated, so their dot-product share is added by rank 0 only
 // (cam_weight).
 enum { RZP = 0, RR = 1, PDZ = 2, ZDZ = 3, DEN = 4, NSLOT = 5 };
+#ifndef GR_BJ_WAVES
+#define GR_BJ_WAVES 1
+#endif
 struct PcgState {
   double *acc;          // [cap][NSLOT][NSW]
   double *pdp, *rz0;    // [cap]
@@ -94,7 +97,7 @@ __global__ void k_pcg_state_init(PcgState st, int cap) {
 // launch of 64-thread blocks ([0, nbc) camera blocks, then point blocks); with st.acc != nullptr the last
 // block also resets the PCG loop state, so a solve starts without its own init launch.
 template <typename T>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, GR_BJ_WAVES)
 k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, const T *__restrict__ Hll,
                const T *__restrict__ scales, double mu, int use_identity, T *__restrict__ MinvC,
                T *__restrict__ MinvP, T *__restrict__ diag_clamped, PcgState st, int cap,
