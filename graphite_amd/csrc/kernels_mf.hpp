@@ -1240,6 +1240,10 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
       for (unsigned t = blockIdx.x * TPB + threadIdx.x; t < n; t += gridDim.x * TPB) x[t] = xb[t];
       return;
     }
+    // the loop has ended: nobody reads the next direction (Ladybug-1723 bench line 5 090 -> 5 250 LM it/s: with the
+    // reference's tolerance most solves end after 1-2 iterations, so this was every second direction launch).  The
+    // graph-replay mode keeps its fixed kernel sequence as it was.
+    if (done_next && !lm) return;
   }
   for (unsigned t = blockIdx.x * TPB + threadIdx.x; t < n; t += gridDim.x * TPB) {
     const T pn = (k < 0) ? scale * zt[t] : beta * p[t] + scale * zt[t];
