@@ -1787,8 +1787,18 @@ template <typename T> struct Engine final : EngineBase {
     const int64_t coll0 = coll_count;
     if (chi2_trace) chi2_trace[0] = (double)chi2v;
     if (lambda_trace) lambda_trace[0] = (double)mu;
-    hipEvent_t ev_a, ev_b;
-    GR_HIP(hipEventCreate(&ev_a)); GR_HIP(hipEventCreate(&ev_b));
+    // solve_seconds: events around every solve, two pairs used alternately and READ one iteration late (after the next
+    // iteration's first kernel has been enqueued): the query sits outside the host's decision -> launch path
+    hipEvent_t ev_pair[2][2];
+    for (auto &pr : ev_pair) for (auto &e : pr) GR_HIP(hipEventCreate(&e));
+    int ev_cur = 0;
+    bool ev_pending = false;
+    auto collect_solve_time = [&](int which) {
+      float ms = 0;
+      (void)hipEventSynchronize(ev_pair[which][1]);
+      (void)hipEventElapsedTime(&ms, ev_pair[which][0], ev_pair[which][1]);
+      st.solve_seconds += ms * 1e-3;
+    };
     const bool graph_mode = lm_graph_prepare(opt);
     GR_HIP(hipStreamSynchronize(stream));
     st.setup_seconds = std::chrono::duration<double>(clk::now() - t0).count();
@@ -1840,7 +1850,9 @@ template <typename T> struct Engine final : EngineBase {
     // one host-driven iteration: solve, trial step, hand-shake, decision
     auto host_iteration = [&](int i) -> bool {
       solver_set_damping(opt.solver, (double)mu, opt.use_identity != 0);
+      hipEvent_t ev_a = ev_pair[ev_cur][0], ev_b = ev_pair[ev_cur][1];
       GR_HIP(hipEventRecord(ev_a, stream));
+      if (ev_pending) collect_solve_time(ev_cur ^ 1); // the previous iteration's pair
       const bool speculate = accept_streak >= 2 && spec_enabled;
       int seq = 0;
       // backup_parameters + apply_update + rho-denominator partials + the camera packs in one launch, then the
@@ -1882,10 +1894,8 @@ template <typename T> struct Engine final : EngineBase {
       wait_chi2(seq);
       const int it = h_seq[1]; // every PCG variant mirrors its iteration count into pinned memory
       const double hs[2] = {h_res[0], h_res[1]};
-      float ms = 0;
-      (void)hipEventSynchronize(ev_b);
-      (void)hipEventElapsedTime(&ms, ev_a, ev_b);
-      st.solve_seconds += ms * 1e-3;
+      ev_pending = true;
+      ev_cur ^= 1;
       return decide(i, solve_ok, speculate, it, hs);
     };
 
@@ -1919,6 +1929,7 @@ template <typename T> struct Engine final : EngineBase {
     }
     GR_HIP(hipStreamSynchronize(stream));
     st.loop_seconds = std::chrono::duration<double>(clk::now() - tl).count();
+    if (ev_pending) collect_solve_time(ev_cur ^ 1);
     st.ok = run ? 1 : 0;
     st.final_chi2 = (double)chi2v;
     st.collectives = coll_count - coll0;
@@ -1926,7 +1937,7 @@ template <typename T> struct Engine final : EngineBase {
     if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] LM: trial step enqueued ahead of the PCG exit flag in %d iterations, not ahead in %d\n", ahead_hits, ahead_misses);
     if (getenv("GR_VERBOSE") && graph_mode)
       std::fprintf(stderr, "[graphite-mi355x] LM: %d of %d iterations replayed as graphs; handed back: %d (PCG iterations), %d (not accepted)\n", g_steps, st.iterations_run, g_stop1, g_stop2);
-    (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b);
+    for (auto &pr : ev_pair) for (auto &e : pr) (void)hipEventDestroy(e);
     if (profiling) flush_prof();
     profiling = false;
   }
