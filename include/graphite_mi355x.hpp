@@ -72,6 +72,9 @@ public:
   bool initialize_optimization(uint8_t /*level*/ = 0) { return true; }          // done at construction
   bool build_structure() { return true; }
   void scale_system(bool enable) { ok(gr_bal_set_scale_system(p_, enable)); }   // graph.hpp:331
+  // VertexDescriptor::set_fixed (vertex.hpp:262-264) for whole descriptors at once: byte masks over cameras / points
+  // (nullptr = none of that kind); a fixed vertex keeps its value through the optimisation
+  void set_fixed(const unsigned char *camera_fixed, const unsigned char *point_fixed) { ok(gr_bal_set_fixed(p_, camera_fixed, point_fixed)); }
   // Graph<double, float>: Jacobian entries in fp32 (bal.cu --precision FP64-FP32)
   void set_jacobian_precision_f32(bool on) { ok(gr_bal_set_jacobian_precision(p_, on ? GR_F32 : GR_F64)); }
   template <int E> void set_loss(const DefaultLoss<T, E> &) { ok(gr_bal_set_loss(p_, GR_LOSS_DEFAULT, 0.0)); }

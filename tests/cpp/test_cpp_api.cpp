@@ -87,6 +87,33 @@ template <typename T> static void lm_runs(gr_solver which) {
   CHECK(moved);
 }
 
+// VertexDescriptor::set_fixed through the mirror: the fixed camera and point keep their values, the others move
+static void fixed_vertices_stay() {
+  using T = double;
+  auto f = two_camera_three_point<T>();
+  for (size_t i = 0; i < f.obs.size(); ++i) f.obs[i] = T(3.0) * ((i % 2) ? 1 : -1);
+  BalGraph<T> graph(f.cameras, f.points, f.obs, f.ci, f.pi);
+  const unsigned char cam_fixed[2] = {1, 0}, pt_fixed[3] = {0, 0, 1};
+  graph.set_fixed(cam_fixed, pt_fixed);
+  StreamPool streams(2);
+  BlockJacobiPreconditioner<T> bp;
+  PCGSolver<T> s2(50, T(1e-12), T(1e6), &bp);
+  optimizer::LevenbergMarquardtOptions<T> opt;
+  opt.solver = &s2;
+  opt.streams = &streams;
+  opt.iterations = 10;
+  const T chi2_0 = graph.chi2();
+  gr_lm_stats st{};
+  CHECK((optimizer::levenberg_marquardt<T, T>(&graph, &opt, &st)));
+  CHECK(graph.chi2() < chi2_0);
+  std::vector<T> c, p;
+  graph.read_back(c, p);
+  bool cam0_same = true, cam1_moved = false, pt2_same = true, pt0_moved = false;
+  for (int i = 0; i < 9; ++i) { cam0_same &= c[i] == f.cameras[i]; cam1_moved |= c[9 + i] != f.cameras[9 + i]; }
+  for (int i = 0; i < 3; ++i) { pt2_same &= p[6 + i] == f.points[6 + i]; pt0_moved |= p[i] != f.points[i]; }
+  CHECK(cam0_same && pt2_same && cam1_moved && pt0_moved);
+}
+
 static void backup_and_revert() {
   using T = double;
   auto f = two_camera_three_point<T>();
@@ -118,6 +145,7 @@ int main() {
   lm_runs<double>(GR_SOLVER_PCG_SCHUR);
   lm_runs<double>(GR_SOLVER_PCG);
   lm_runs<float>(GR_SOLVER_PCG_SCHUR);
+  fixed_vertices_stay();
   backup_and_revert();
   bad_inputs_fail_loudly();
   std::printf("%s (%d failures)\n", failures ? "FAILED" : "OK", failures);
