@@ -28,13 +28,14 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     name = list(GS)[int(rng.integers(len(GS)))]
     gs, osv = GS[name]
     its = 5
-    ref = oracle.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx)
+    dt = np.float32 if rng.random() < 0.3 else np.float64
+    ref = oracle.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dt)
     if use_fixed: ref.set_fixed(cf, pf)
     ref.set_pcg_single_reduction(1 if env.get("GR_PCG_CG") == "1" else 0)
     ct_r, _, st_r = ref.levenberg_marquardt(solver=osv, iterations=its)
     world = int(rng.integers(1, 4))
     if world == 1:
-        e = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+        e = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dt)
         if use_fixed: e.set_fixed(cf, pf)
         ct, _, st = e.levenberg_marquardt(solver=gs, iterations=its)
         c, p = e.get_params(); e.close()
@@ -43,7 +44,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
             shards = [gdist.partition_by_landmark(prob, r, world) for r in range(world)]
         except ValueError:
             continue
-        es = [ga.BalProblem(s.cameras, s.points, s.obs, s.cam_idx, s.pt_idx, dtype=np.float64, shard=True) for s in shards]
+        es = [ga.BalProblem(s.cameras, s.points, s.obs, s.cam_idx, s.pt_idx, dtype=dt, shard=True) for s in shards]
         if use_fixed:
             for e, s in zip(es, shards): e.set_fixed(cf, pf[s.point_range[0]:s.point_range[1]])
         gdist.init_local_group(es)
@@ -57,12 +58,12 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
             print("TRIAL", trial, "sharded failure", errs); bad += 1; [e.close() for e in es]; continue
         ct, _, st = out[0]
         c = es[0].get_params()[0]; p = np.concatenate([e.get_params()[1] for e in es]); [e.close() for e in es]
-    m = min(len(ct), len(ct_r))
+    m = min(len(ct), len(ct_r)) if dt == np.float64 else min(len(ct), len(ct_r), 3)   # fp32: compared while both traces still move
     rel = float(np.max(np.abs(ct[:m] - ct_r[:m]) / np.abs(ct_r[:m])))
-    ok = rel < 1e-7 and len(ct) == len(ct_r)
+    ok = (rel < 1e-7 and len(ct) == len(ct_r)) if dt == np.float64 else rel < 5e-3
     if use_fixed:
-        ok = ok and np.array_equal(c[cf], prob.cameras[cf]) and np.array_equal(p[pf], prob.points[pf])
-    print(f"trial {trial}: Nc {Nc} Np {Np} No {No} solver {name} env {env} world {world} fixed {use_fixed}: rel {rel:.2e} {'ok' if ok else 'MISMATCH'}", flush=True)
+        ok = ok and np.array_equal(c[cf], prob.cameras[cf].astype(dt)) and np.array_equal(p[pf], prob.points[pf].astype(dt))
+    print(f"trial {trial}: Nc {Nc} Np {Np} No {No} solver {name} env {env} world {world} fixed {use_fixed} {np.dtype(dt).name}: rel {rel:.2e} {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
 print("failures:", bad)
 sys.exit(1 if bad else 0)
