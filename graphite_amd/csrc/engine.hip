@@ -162,6 +162,7 @@ template <typename T> struct Engine final : EngineBase {
     g.cam_fixed = cam_fixed_p(); g.pt_fixed = pt_fixed_p();
     return g;
   }
+  int is_points_blocks() const { return g3_obs_order ? std::max(8, std::min(cdiv(Np, TPB), num_cu * 8) / 8 * 8) : cdiv(Np, TPB); }
   int update_blocks() const {
     const int b = std::min(cdiv(pose_dim, 252) + cdiv(Np, 85), num_cu * 8);
     return g3_obs_order ? std::max(8, (b + 7) / 8 * 8) : b;
@@ -875,7 +876,11 @@ template <typename T> struct Engine final : EngineBase {
   void solver_update_structure(int solver) override {
     if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
     else if (solver == GR_SOLVER_DENSE_SCHUR) { ensure_chol(); want_hcp = true; }
-    else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) { want_hcp = false; ensure_implicit_schur(); if (!tiling_tuned) tune_tiling(); }
+    else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) {
+      want_hcp = false; ensure_implicit_schur();
+      if (!tiling_tuned) tune_tiling();
+      if (want_g3_gather() && !g3_obs_order) build_g3_gather(); // pass 1's output in observation order, gathered by k_is_points
+    }
     else {
       want_hcp = false;
       { const char *e = getenv("GR_PCG_LAZY"); lazy_cfg = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
@@ -1159,9 +1164,9 @@ template <typename T> struct Engine final : EngineBase {
     const int noop = run_pcg_iterations(max_iter, [&](int k) {
       {
         Scope s1(this, "is_pass1", pass_bytes, No * 290.0);
-        if (jac32) { k_is_pass1<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k); } else { k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k); }
+        if (jac32) { k_is_pass1<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k); } else { k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, k); }
       }
-      k_is_points<T, 0><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, zl.p, sc, k);
+      k_is_points<T, 0><<<is_points_blocks(), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, zl.p, sc, k, g3_gather());
       {
         Scope s2(this, "is_pass2", No * (2 * w() + 12.0) + (24.0 * Nc + 6.0 * Np) * w() + 9.0 * nseg * w(), No * 290.0);
         if (jac32) { k_is_pass2<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k); } else { k_is_pass2<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, zl.p, op_partial.p, sc, k); }
@@ -1177,8 +1182,8 @@ template <typename T> struct Engine final : EngineBase {
     note_noop({"is_pass1", "is_pass2"}, noop);
     // back-substitution x_l = Hll^-1 (b_l - Hpl^T x_p): pass 1 with q = s_c .* x_c, then the per-point solve
     k_mul<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((unsigned)pose_dim, v_q.p, scales.p, x);
-    if (jac32) { k_is_pass1<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1); } else { k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1); }
-    k_is_points<T, 1><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, x + pose_dim, sc, 0);
+    if (jac32) { k_is_pass1<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1); } else { k_is_pass1<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, v_q.p, g3.p, sc, -1); }
+    k_is_points<T, 1><<<is_points_blocks(), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, x + pose_dim, sc, 0, g3_gather());
   }
 
   template <typename JT> void launch_operator_j(PcgState st, int k, const T *rec, const LmDev *lm, double mu) {

@@ -31,13 +31,13 @@ __device__ __forceinline__ void cm_tiles(int No, int ntiles, const int *__restri
   bool valid = t0 < t1 && j < No;
   int c_n = -1, l_n = 0, a_n = 0;
   V2 o_n{};
-  if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm[j]; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
+  if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm ? pos_cm[j] : j; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; } // pos_cm == nullptr: slot = observation-order position
   for (int t = t0; t < t1; t += tstep) {
     const int c = c_n, l = l_n, a = a_n;
     const V2 o = o_n;
     const int jn = j + tstep * TPB;
     const bool validn = (t + tstep < t1) && jn < No;
-    if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm[jn]; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
+    if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm ? pos_cm[jn] : jn; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
     body(j, valid, c, l, a, o.x, o.y);
     valid = validn;
     j = jn;
@@ -189,28 +189,50 @@ k_is_pass1(int No, int ntiles, const int *__restrict__ cam_cm, const int *__rest
 // per point: y = sum of its observations' g3 (fixed order);
 //   MODE 0: zl = M' y                                   (Hll^-1 Hpl^T p in unscaled form)
 //   MODE 1: xl = Hll_inv (s_l .* (bl^u - y))            (back-substitution, schur.hpp:279-302)
+// gg.gidx != nullptr: g3 is in observation order (pass 1 then stores whole lines) and a point's slots are gathered through
+// gidx, the points walked tile by tile on the XCD that wrote the tile (kernels_mf.hpp G3Gather); gridDim.x % 8 == 0 then.
 template <typename T, int MODE>
 __global__ void k_is_points(int Np, int Nc, const int *__restrict__ pt_ptr, const T *__restrict__ g3,
                             const T *__restrict__ Mp, const T *__restrict__ Hll_inv, const T *__restrict__ bl,
-                            const T *__restrict__ scales, T *__restrict__ out, PcgScalars sc, int k) {
+                            const T *__restrict__ scales, T *__restrict__ out, PcgScalars sc, int k, G3Gather gg = G3Gather{}) {
   if (MODE == 0) {
     if (sc.done[k]) return;
     if (part_sum(sc.rz, sc.np, k) == 0.0) return;
   }
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= Np) return;
-  T y0 = 0, y1 = 0, y2 = 0;
-  for (int a = pt_ptr[l]; a < pt_ptr[l + 1]; ++a) {
-    const T *g = g3 + 3 * (size_t)a;
-    y0 += g[0]; y1 += g[1]; y2 += g[2];
-  }
-  const T *m = (MODE == 0 ? Mp : Hll_inv) + 9 * (size_t)l;
-  if (MODE == 1) {
-    const T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
-    y0 = s[0] * (bl[3 * (size_t)l] - y0); y1 = s[1] * (bl[3 * (size_t)l + 1] - y1); y2 = s[2] * (bl[3 * (size_t)l + 2] - y2);
-  }
+  auto point = [&](int l) {
+    T y0 = 0, y1 = 0, y2 = 0;
+    if (gg.gidx) {
+      for (int a = pt_ptr[l]; a < pt_ptr[l + 1]; ++a) {
+        const T *g = g3 + 3 * (size_t)gg.gidx[a];
+        y0 += g[0]; y1 += g[1]; y2 += g[2];
+      }
+    } else {
+      for (int a = pt_ptr[l]; a < pt_ptr[l + 1]; ++a) {
+        const T *g = g3 + 3 * (size_t)a;
+        y0 += g[0]; y1 += g[1]; y2 += g[2];
+      }
+    }
+    const T *m = (MODE == 0 ? Mp : Hll_inv) + 9 * (size_t)l;
+    if (MODE == 1) {
+      const T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
+      y0 = s[0] * (bl[3 * (size_t)l] - y0); y1 = s[1] * (bl[3 * (size_t)l + 1] - y1); y2 = s[2] * (bl[3 * (size_t)l + 2] - y2);
+    }
 #pragma unroll
-  for (int r = 0; r < 3; ++r) out[3 * (size_t)l + r] = m[r] * y0 + m[r + 3] * y1 + m[r + 6] * y2;
+    for (int r = 0; r < 3; ++r) out[3 * (size_t)l + r] = m[r] * y0 + m[r + 3] * y1 + m[r + 6] * y2;
+  };
+  if (gg.n_ptiles > 0) {
+    const int x = (int)(blockIdx.x & 7), bi = (int)(blockIdx.x >> 3), nb = (int)(gridDim.x >> 3);
+    for (int q = x; q < gg.n_ptiles; q += 8) {
+      const int P0 = gg.ptile_ptr[q], P1 = gg.ptile_ptr[q + 1];
+      for (int base = P0 + bi * (int)blockDim.x; base < P1; base += nb * (int)blockDim.x) {
+        const int l = base + (int)threadIdx.x;
+        if (l < P1) point(l);
+      }
+    }
+  } else {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < Np) point(l);
+  }
 }
 
 // pass 2: per (wave, camera) segment partial of  sum_obs Jc^T w Jp z_l
