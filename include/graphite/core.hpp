@@ -215,9 +215,9 @@ public:
 // Storage of the library's OWN arrays (Jacobians, residuals, gradient, solver vectors, dense blocks): HBM, where the
 // reference keeps thrust::device_vector (factor.hpp:158-174, graph.hpp:40-60).  Fine-grained device memory: kernels
 // stream it at HBM speed (measured 6.7 TB/s against 0.09 TB/s for the pinned host memory of managed_vector, which every
-// access crosses PCIe for), and on these boxes it is still mapped into the host address space, so the occasional host
-// element access (a scalar, a debug read) stays legal — host WRITES are posted and fast, host READS cost about a
-// microsecond each, so bulk host access goes through to_host().  Arithmetic element types only.
+// access crosses PCIe for).  On these boxes it is also mapped into the host address space (posted host writes are fast, a
+// host read costs about a microsecond), but the library itself never relies on that: its own host accesses are
+// hipMemcpy (to_host(), assign(), the reduction results).  Arithmetic element types only.
 template <typename T> class hbm_vector {
   static_assert(std::is_trivially_copyable<T>::value, "hbm_vector holds plain data");
   T *p_ = nullptr;
@@ -1033,7 +1033,11 @@ public:
     detail::sync();
     return scalar[0];
   }
-  T chi2(size_t handle) { detail::sync(); return chi2_vec[local_id(handle)]; }
+  T chi2(size_t handle) {
+    T v;
+    GRAPHITE_HIP(hipMemcpy(&v, chi2_vec.raw() + local_id(handle), sizeof(T), hipMemcpyDeviceToHost));
+    return v;
+  }
   void scalar_diagonal(T *diag) override { slot_all<0>(diag, nullptr, std::make_index_sequence<N>{}); }
   void scale_jacobians(const T *scales) override {
     if (dynamic_jacobians()) dynamic_scales = scales;

@@ -107,8 +107,9 @@ template <typename T, bool RHO = false> inline T dot(const T *a, const T *b, siz
   const int nb = (int)std::max<size_t>(1, std::min<size_t>(DOT_BLOCKS, (n + 4 * TPB - 1) / (4 * TPB)));
   k_dot_partial<T, RHO><<<nb, TPB>>>(a, b, n, mu, scratch + 1);
   k_dot_final<T><<<1, 64>>>(scratch + 1, nb, scratch);
-  sync();
-  return *scratch;
+  T result;
+  GRAPHITE_HIP(hipMemcpy(&result, scratch, sizeof(T), hipMemcpyDeviceToHost)); // ordered behind the kernels, no host mapping of HBM needed
+  return result;
 }
 } // namespace detail
 
