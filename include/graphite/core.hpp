@@ -251,8 +251,14 @@ public:
   void clear() { n_ = 0; }
   size_t size() const { return n_; }
   bool empty() const { return n_ == 0; }
-  T &operator[](size_t i) { return p_[i]; }
-  const T &operator[](size_t i) const { return p_[i]; }
+  // host element access as with thrust::device_vector (a copy per access: for tests and occasional scalars)
+  struct reference {
+    T *p;
+    operator T() const { T v; GRAPHITE_HIP(hipMemcpy(&v, p, sizeof(T), hipMemcpyDeviceToHost)); return v; }
+    reference &operator=(const T &v) { GRAPHITE_HIP(hipMemcpy(p, &v, sizeof(T), hipMemcpyHostToDevice)); return *this; }
+  };
+  reference operator[](size_t i) { return reference{p_ + i}; }
+  T operator[](size_t i) const { T v; GRAPHITE_HIP(hipMemcpy(&v, p_ + i, sizeof(T), hipMemcpyDeviceToHost)); return v; }
   pointer data() const { return pointer{p_}; }
   T *raw() const { return p_; }
   T *begin() const { return p_; }
