@@ -213,11 +213,10 @@ public:
 };
 
 // Storage of the library's OWN arrays (Jacobians, residuals, gradient, solver vectors, dense blocks): HBM, where the
-// reference keeps thrust::device_vector (factor.hpp:158-174, graph.hpp:40-60).  Fine-grained device memory: kernels
-// stream it at HBM speed (measured 6.7 TB/s against 0.09 TB/s for the pinned host memory of managed_vector, which every
-// access crosses PCIe for).  On these boxes it is also mapped into the host address space (posted host writes are fast, a
-// host read costs about a microsecond), but the library itself never relies on that: its own host accesses are
-// hipMemcpy (to_host(), assign(), the reduction results).  Arithmetic element types only.
+// reference keeps thrust::device_vector (factor.hpp:158-174, graph.hpp:40-60).  Kernels stream device memory at HBM
+// speed (measured 6.7 TB/s against 0.09 TB/s for the pinned host memory of managed_vector, which every access crosses
+// PCIe for).  Host access is by copy, as with thrust: operator[] returns a proxy, to_host() / assign() move whole
+// arrays.  Plain-data element types only.
 template <typename T> class hbm_vector {
   static_assert(std::is_trivially_copyable<T>::value, "hbm_vector holds plain data");
   T *p_ = nullptr;
@@ -226,7 +225,7 @@ template <typename T> class hbm_vector {
     if (cap <= cap_) return;
     T *q = nullptr;
     cap = std::max<size_t>(cap, 1);
-    GRAPHITE_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&q), cap * sizeof(T), hipDeviceMallocFinegrained));
+    GRAPHITE_HIP(hipMalloc(reinterpret_cast<void **>(&q), cap * sizeof(T)));
     if (n_) GRAPHITE_HIP(hipMemcpy(q, p_, n_ * sizeof(T), hipMemcpyDeviceToDevice));
     GRAPHITE_HIP(hipMemset(q + n_, 0, (cap - n_) * sizeof(T))); // value-initialised tail: growing by one element costs nothing later
     if (p_) (void)hipFree(p_);
