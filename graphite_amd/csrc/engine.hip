@@ -1996,6 +1996,40 @@ template <typename T> static void dense_cholesky_solve_impl(int64_t n, const voi
   GR_HIP(hipStreamSynchronize(stream));
   if (!ok) throw std::range_error("matrix is not positive definite");
 }
+// the engine's camera model on caller-supplied (camera, point, observation) triples: what the hand-written kernels compute
+// per observation (bal_device.hpp), one thread per triple
+template <typename T>
+__global__ void k_model_evaluate(int n, const T *__restrict__ cams, const T *__restrict__ pts, const T *__restrict__ obs,
+                                 T *__restrict__ res, T *__restrict__ Jc, T *__restrict__ Jp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T cam[9], pk[PACK], e0, e1, jc[18], jp[6];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) cam[k] = cams[9 * (size_t)i + k];
+  make_campack(cam, pk);
+  bal_linearize<T>(pk, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], obs[2 * (size_t)i], obs[2 * (size_t)i + 1], e0, e1, jc, jp);
+  if (res) { res[2 * (size_t)i] = e0; res[2 * (size_t)i + 1] = e1; }
+  if (Jc) {
+#pragma unroll
+    for (int k = 0; k < 18; ++k) Jc[18 * (size_t)i + k] = jc[k];
+  }
+  if (Jp) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jp[6 * (size_t)i + k] = jp[k];
+  }
+}
+template <typename T> static void model_evaluate_impl(int64_t n, const void *cams, const void *pts, const void *obs, void *res, void *Jc, void *Jp, hipStream_t stream) {
+  DevBuf<T> dc, dp, dob, dr, djc, djp;
+  dc.alloc(9 * (size_t)n); dp.alloc(3 * (size_t)n); dob.alloc(2 * (size_t)n); dr.alloc(2 * (size_t)n); djc.alloc(18 * (size_t)n); djp.alloc(6 * (size_t)n);
+  GR_HIP(hipMemcpyAsync(dc.p, cams, 9 * (size_t)n * sizeof(T), hipMemcpyDefault, stream));
+  GR_HIP(hipMemcpyAsync(dp.p, pts, 3 * (size_t)n * sizeof(T), hipMemcpyDefault, stream));
+  GR_HIP(hipMemcpyAsync(dob.p, obs, 2 * (size_t)n * sizeof(T), hipMemcpyDefault, stream));
+  k_model_evaluate<T><<<cdiv(n, 64), 64, 0, stream>>>((int)n, dc.p, dp.p, dob.p, dr.p, djc.p, djp.p);
+  if (res) GR_HIP(hipMemcpyAsync(res, dr.p, 2 * (size_t)n * sizeof(T), hipMemcpyDefault, stream));
+  if (Jc) GR_HIP(hipMemcpyAsync(Jc, djc.p, 18 * (size_t)n * sizeof(T), hipMemcpyDefault, stream));
+  if (Jp) GR_HIP(hipMemcpyAsync(Jp, djp.p, 6 * (size_t)n * sizeof(T), hipMemcpyDefault, stream));
+  GR_HIP(hipStreamSynchronize(stream));
+}
 extern "C" {
 
 const char *gr_version(void) { return "graphite-mi355x 0.1 (gfx950)"; }
@@ -2081,6 +2115,20 @@ gr_status gr_dense_cholesky_solve(gr_dtype dtype, int64_t n, const void *A, int6
   } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
   catch (const std::range_error &ex) { g_last_error = ex.what(); return GR_ERR_SOLVE_FAILED; }
   catch (const CommError &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
+}
+gr_status gr_bal_model_evaluate(gr_dtype dtype, int64_t n, const void *cameras, const void *points, const void *observations,
+                                void *residuals, void *Jc, void *Jp, int device, void *stream) {
+  if (n <= 0 || n > (1 << 24) || !cameras || !points || !observations) { g_last_error = "gr_bal_model_evaluate: bad argument"; return GR_ERR_INVALID; }
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= device || device < 0) { g_last_error = "no HIP device: the MI355X path has no CPU fallback"; return GR_ERR_NO_DEVICE; }
+  try {
+    GR_HIP(hipSetDevice(device));
+    if (dtype == GR_F64) model_evaluate_impl<double>(n, cameras, points, observations, residuals, Jc, Jp, static_cast<hipStream_t>(stream));
+    else if (dtype == GR_F32) model_evaluate_impl<float>(n, cameras, points, observations, residuals, Jc, Jp, static_cast<hipStream_t>(stream));
+    else { g_last_error = "bad dtype"; return GR_ERR_INVALID; }
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
 }
 gr_status gr_bal_schur_update_values(gr_bal_problem *p) { return guarded(p, [&] { p->e->schur_update_values(); }); }

@@ -269,7 +269,7 @@ public:
   }
   void assign(const T *src, size_t n) { // from host (or any) memory
     if (n > cap_) { n_ = 0; grow(n); }
-    n_ = n;
+    n_ = n; hw_ = std::max(hw_, n); // the assigned elements have been exposed: a later shrink + resize must zero them again
     if (n) GRAPHITE_HIP(hipMemcpy(p_, src, n * sizeof(T), hipMemcpyDefault));
   }
 };
@@ -545,6 +545,14 @@ public:
   // factors to the specialised BAL engine: local camera / point ids, 2 observation scalars per factor, loss.
   // false = not that model, or something the engine does not represent (precision matrices, mixed losses...).
   virtual bool export_bal(std::vector<int32_t> &, std::vector<int32_t> &, std::vector<T> &, int &, double &) { return false; }
+  // The evidence for that hand-over (solve.hpp compares it with gr_bal_model_evaluate): for up to max_samples active factors,
+  // evenly spread, the USER's functions evaluated on the device — Traits::parameters of both vertices (9 + 3), the
+  // observation (2), Traits::error (2), the two Jacobian blocks (Traits::jacobian<T, I>, or dual numbers for Auto
+  // factors; 18 + 6, E x d column-major) — and update_dev, the largest relative deviation of Traits::update from
+  // plain addition on the parameters.  false: not a (9, 3) -> 2 factor with a two-component observation.
+  virtual bool probe_bal(size_t /*max_samples*/, std::vector<T> & /*cam*/, std::vector<T> & /*pt*/, std::vector<T> & /*obs*/, std::vector<T> & /*res*/,
+                         std::vector<T> & /*Jc*/, std::vector<T> & /*Jp*/, double & /*update_dev*/) { return false; }
+  virtual bool declares_bal_model() const { return false; } // the optional tag: a mismatch is then reported, not silent
 };
 
 namespace detail {
@@ -573,8 +581,10 @@ template <typename F> struct FactorView {
 
 template <typename Tr, typename = void> struct has_bal_tag : std::false_type {};
 template <typename Tr> struct has_bal_tag<Tr, std::enable_if_t<Tr::bal_reprojection_model>> : std::true_type {};
-template <typename O> auto obs_component(const O &o, int i, int) -> decltype((double)o(i)) { return (double)o(i); }
-template <typename O> auto obs_component(const O &o, int i, long) -> decltype((double)o[i]) { return (double)o[i]; }
+template <typename O> __host__ __device__ auto obs_component(const O &o, int i, int) -> decltype((double)o(i)) { return (double)o(i); }
+template <typename O> __host__ __device__ auto obs_component(const O &o, int i, long) -> decltype((double)o[i]) { return (double)o[i]; }
+template <typename O, typename = void> struct obs_indexable : std::false_type {};
+template <typename O> struct obs_indexable<O, std::void_t<decltype(obs_component(std::declval<const O &>(), 0, 0))>> : std::true_type {};
 template <typename F, size_t I> using slot_traits = typename std::tuple_element<I, typename F::Traits::VertexDescriptors>::type::Traits;
 template <typename F, size_t I> using slot_vertex = typename slot_traits<F, I>::Vertex;
 template <typename F, size_t I> constexpr size_t slot_dim() { return slot_traits<F, I>::dimension; }
@@ -689,6 +699,64 @@ __global__ void k_jacobian(FactorView<F> fv, std::index_sequence<Is...> seq) {
     call_error<F, D>(v, p, fv.obs[f], fv.data[f], err, seq);
     for (size_t i = 0; i < F::E; ++i) fv.jac[I][f * F::E * d + col * F::E + i] = (Sj)err[i].dual;
   }
+}
+
+// Engine hand-over probe (BaseFactorDescriptor::probe_bal): the user's parameters / error / Jacobian blocks / update on
+// sampled factors of a (9, 3) -> 2 descriptor.  out: [ns][PROBE_W] = cam 9 | pt 3 | obs 2 | r 2 | Jc 18 | Jp 6 | update deviation 1
+constexpr size_t PROBE_W = 41;
+template <typename Tr, typename T> __device__ inline T probe_update_deviation(const typename Tr::Vertex &vtx, const T *p) {
+  using V = typename Tr::Vertex;
+  if constexpr (std::is_copy_constructible<V>::value) {
+    constexpr size_t d = Tr::dimension;
+    V copy(vtx);
+    T delta[d], q[d];
+    for (size_t k = 0; k < d; ++k) delta[k] = T(0.0009765625) * T(k + 1) * (p[k] < T(0) ? T(-1) : T(1)); // exact binary steps
+    Tr::update(copy, delta);
+    Tr::parameters(copy, q);
+    T dev = 0;
+    for (size_t k = 0; k < d; ++k) {
+      const T want = p[k] + delta[k];
+      const T e = fabs((double)(q[k] - want)) / fmax(1.0, fabs((double)want));
+      dev = e > dev || e != e ? e : dev;
+    }
+    return dev;
+  } else return std::numeric_limits<T>::infinity();
+}
+template <typename F, size_t... Is>
+__global__ void k_probe_bal(FactorView<F> fv, size_t stride, size_t ns, typename F::Scalar *out, std::index_sequence<Is...> seq) {
+  using T = typename F::Scalar;
+  const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (a >= ns) return;
+  const size_t f = fv.active_ids[a * stride];
+  auto v = gather_vertices<F, T>(fv, f, seq);
+  std::tuple<T[slot_dim<F, Is>()]...> p;
+  ((slot_traits<F, Is>::parameters(*std::get<Is>(v), (T *)std::get<Is>(p))), ...);
+  T *o = out + a * PROBE_W;
+  for (int k = 0; k < 9; ++k) o[k] = std::get<0>(p)[k];
+  for (int k = 0; k < 3; ++k) o[9 + k] = std::get<1>(p)[k];
+  o[12] = (T)obs_component(fv.obs[f], 0, 0); o[13] = (T)obs_component(fv.obs[f], 1, 0);
+  T err[2];
+  call_error<F, T>(v, p, fv.obs[f], fv.data[f], err, seq);
+  o[14] = err[0]; o[15] = err[1];
+  T *jc = o + 16, *jp = o + 34;
+  for (int k = 0; k < 24; ++k) jc[k] = T(0); // the reference zero-fills the storage before the user function writes (ops/linearize.hpp:127)
+  if constexpr (std::is_same<typename F::Traits::Differentiation, DifferentiationMode::Manual>::value) {
+    call_jacobian_t<F, 0, T>(v, fv.obs[f], fv.data[f], jc, seq);
+    call_jacobian_t<F, 1, T>(v, fv.obs[f], fv.data[f], jp, seq);
+  } else {
+    using D = Dual<T, T>;
+    for (int col = 0; col < 12; ++col) {
+      std::tuple<D[slot_dim<F, Is>()]...> pd;
+      ((slot_traits<F, Is>::parameters(*std::get<Is>(v), (D *)std::get<Is>(pd))), ...);
+      if (col < 9) std::get<0>(pd)[col].dual = T(1); else std::get<1>(pd)[col - 9].dual = T(1);
+      D e[2];
+      call_error<F, D>(v, pd, fv.obs[f], fv.data[f], e, seq);
+      jc[2 * col] = e[0].dual; jc[2 * col + 1] = e[1].dual; // jp follows jc: columns 9..11 land in the point block
+    }
+  }
+  const T d0 = probe_update_deviation<slot_traits<F, 0>, T>(*std::get<0>(v), std::get<0>(p));
+  const T d1 = probe_update_deviation<slot_traits<F, 1>, T>(*std::get<1>(v), std::get<1>(p));
+  o[40] = d0 > d1 || d0 != d0 ? d0 : d1;
 }
 
 // Jacobian block of slot I of factor f: the stored (already scaled) block, or with set_jacobian_storage(false)
@@ -1099,9 +1167,9 @@ public:
   }
 
   bool export_bal(std::vector<int32_t> &cam, std::vector<int32_t> &pt, std::vector<T> &obs, int &loss_kind, double &loss_delta) override {
-    if constexpr (detail::has_bal_tag<Traits>::value && N == 2 && E == 2) {
+    if constexpr (bal_shaped()) {
       constexpr bool plain = std::is_same<LossType, DefaultLoss<T, 2>>::value, huber = std::is_same<LossType, HuberLoss<T, 2>>::value;
-      if constexpr ((plain || huber) && detail::slot_dim<FactorDescriptor, 0>() == 9 && detail::slot_dim<FactorDescriptor, 1>() == 3) {
+      if constexpr (plain || huber) {
         const size_t nf = internal_count();
         if (!nf || active_count() != nf) return false; // the engine optimises every factor it is given
         detail::sync();
@@ -1122,6 +1190,36 @@ public:
       }
     }
     return false;
+  }
+
+  // what the engine can represent at all: two slots of dimension 9 and 3, a two-component residual and observation, no
+  // per-factor constraint data (whether the user's functions ARE the engine's model is then verified by value, probe_bal)
+  static constexpr bool bal_shaped() {
+    if constexpr (N == 2 && E == 2 && std::is_empty<ConstraintDataType>::value && detail::obs_indexable<ObservationType>::value)
+      return std::tuple_element<0, VDTuple>::type::Traits::dimension == 9 && std::tuple_element<1, VDTuple>::type::Traits::dimension == 3;
+    else return false;
+  }
+  bool declares_bal_model() const override { return detail::has_bal_tag<Traits>::value; }
+  bool probe_bal(size_t max_samples, std::vector<T> &cam, std::vector<T> &pt, std::vector<T> &obs, std::vector<T> &res, std::vector<T> &Jc, std::vector<T> &Jp, double &update_dev) override {
+    if constexpr (bal_shaped()) {
+      const size_t na = active_count();
+      if (!na || !max_samples) return false;
+      const size_t ns = std::min(na, max_samples), stride = na / ns;
+      hbm_vector<T> out(ns * detail::PROBE_W);
+      detail::k_probe_bal<FactorDescriptor><<<detail::blocks(ns), detail::TPB>>>(view(), stride, ns, out.raw(), std::make_index_sequence<N>{});
+      detail::sync();
+      const std::vector<T> h = out.to_host();
+      cam.resize(9 * ns); pt.resize(3 * ns); obs.resize(2 * ns); res.resize(2 * ns); Jc.resize(18 * ns); Jp.resize(6 * ns);
+      update_dev = 0;
+      for (size_t a = 0; a < ns; ++a) {
+        const T *o = h.data() + a * detail::PROBE_W;
+        std::copy(o, o + 9, cam.begin() + 9 * a); std::copy(o + 9, o + 12, pt.begin() + 3 * a); std::copy(o + 12, o + 14, obs.begin() + 2 * a);
+        std::copy(o + 14, o + 16, res.begin() + 2 * a); std::copy(o + 16, o + 34, Jc.begin() + 18 * a); std::copy(o + 34, o + 40, Jp.begin() + 6 * a);
+        const double d = (double)o[40];
+        if (!(d <= update_dev)) update_dev = d; // NaN sticks
+      }
+      return true;
+    } else { (void)max_samples; (void)cam; (void)pt; (void)obs; (void)res; (void)Jc; (void)Jp; (void)update_dev; return false; }
   }
 
 private:

@@ -517,11 +517,14 @@ template <typename T, typename S> T compute_rho(Graph<T, S> *graph, const T *del
 // :110-242 (EARLY = false) and :255-418 (EARLY = true: levenberg_marquardt2)
 namespace detail {
 // Bundle-adjustment graphs built with the generic descriptors — one camera descriptor (9), one point descriptor (3,
-// set_eliminate or not), one factor descriptor whose traits carry `bal_reprojection_model` — are optimised by the
+// set_eliminate or not), one factor descriptor whose error()/jacobian() ARE the engine's reprojection model (verified by
+// value on sampled factors, below; the `bal_reprojection_model` tag is optional) — are optimised by the
 // specialised engine of libgraphite_mi355x.so (gr_bal_*: matrix-free kernels, device-resident loop) instead of
 // the generic stored-Jacobian kernels: same algorithm, same trace.  Returns false when the graph or the solver
 // is anything else (unused vertices, inactive factors, precision matrices, a solver without an engine
 // counterpart, GRAPHITE_GENERIC_ONLY=1): the caller then runs the generic loop.
+// number of optimiser calls of this process that ran on the gr_bal engine (tests assert which path ran)
+inline size_t &engine_handovers() { static size_t n = 0; return n; }
 template <typename T, typename S>
 bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, bool early_stop, bool &result) {
   if (getenv("GRAPHITE_GENERIC_ONLY") && atoi(getenv("GRAPHITE_GENERIC_ONLY")) != 0) return false;
@@ -551,16 +554,55 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   std::vector<T> obs;
   int loss_kind = 0; double loss_delta = 0;
   if (!fds[0]->export_bal(ci, pi, obs, loss_kind, loss_delta)) return false;
+  int dev = 0;
+  GRAPHITE_HIP(hipGetDevice(&dev));
+  const gr_dtype dt = sizeof(T) == 8 ? GR_F64 : GR_F32;
+  // VERIFIED hand-over: the engine is specialised for one function (gr_bal_model_evaluate).  The user's own
+  // parameters() / error() / jacobian() (or dual-number Jacobian) / update() are evaluated on up to 256 of the graph's
+  // factors and must reproduce it — 1e-10 (fp64) / 1e-4 (fp32) of the block's magnitude; update() must be plain
+  // addition.  No tag is needed; a factor that carries the bal_reprojection_model tag but computes something else is
+  // reported and stays on the generic kernels.
+  {
+    std::vector<T> pc, pp, po, ur, uJc, uJp;
+    double update_dev = 0;
+    if (!fds[0]->probe_bal(256, pc, pp, po, ur, uJc, uJp, update_dev)) return false;
+    const size_t ns = pc.size() / 9;
+    std::vector<T> er(2 * ns), eJc(18 * ns), eJp(6 * ns);
+    if (gr_bal_model_evaluate(dt, (int64_t)ns, pc.data(), pp.data(), po.data(), er.data(), eJc.data(), eJp.data(), dev, nullptr) != GR_OK) {
+      std::cerr << "graphite: engine hand-over: gr_bal_model_evaluate failed: " << gr_last_error_string() << "; using the generic kernels" << std::endl;
+      return false;
+    }
+    const double tol = sizeof(T) == 8 ? 1e-10 : 1e-4;
+    double worst = 0;
+    auto block_dev = [&](const T *u, const T *e, size_t len, double floor_mag) {
+      double mag = floor_mag, d = 0;
+      for (size_t k = 0; k < len; ++k) mag = std::max(mag, std::abs((double)e[k]));
+      for (size_t k = 0; k < len; ++k) { const double x = std::abs((double)u[k] - (double)e[k]); d = (x > d || x != x) ? x : d; }
+      return d / mag;
+    };
+    for (size_t a = 0; a < ns; ++a) {
+      const double omag = std::max({1.0, std::abs((double)po[2 * a]), std::abs((double)po[2 * a + 1])});
+      for (double d : {block_dev(&ur[2 * a], &er[2 * a], 2, omag), block_dev(&uJc[18 * a], &eJc[18 * a], 18, 1e-300), block_dev(&uJp[6 * a], &eJp[6 * a], 6, 1e-300)})
+        worst = (d > worst || d != d) ? d : worst;
+    }
+    const bool model_ok = worst <= tol, update_ok = update_dev <= (sizeof(T) == 8 ? 1e-14 : 1e-6);
+    if (getenv("GR_VERBOSE"))
+      std::cerr << "[graphite] engine hand-over probe: " << ns << " factors, max deviation of error()/jacobian() from the engine's model "
+                << worst << " (bar " << tol << "), of update() from addition " << update_dev << std::endl;
+    if (!model_ok || !update_ok) {
+      if (fds[0]->declares_bal_model())
+        std::cerr << "graphite: the factor traits declare bal_reprojection_model, but " << (model_ok ? "update()" : "error()/jacobian()")
+                  << " differ from the engine's model (relative deviation " << (model_ok ? update_dev : worst) << "); using the generic kernels" << std::endl;
+      return false;
+    }
+  }
 
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
   managed_vector<T> cams(9 * cd->count()), pts(3 * pd->count());
   cd->gather_parameters(cams.raw()); pd->gather_parameters(pts.raw());
   graphite::detail::sync();
-  int dev = 0;
-  GRAPHITE_HIP(hipGetDevice(&dev));
   gr_bal_problem *prob = nullptr;
-  const gr_dtype dt = sizeof(T) == 8 ? GR_F64 : GR_F32;
   auto fail = [&](const char *what) { std::cerr << "graphite: engine hand-over failed in " << what << ": " << gr_last_error_string() << "; using the generic kernels" << std::endl; if (prob) gr_bal_destroy(prob); return false; };
   if (gr_bal_create(&prob, dt, (int64_t)cd->count(), (int64_t)pd->count(), (int64_t)ci.size(), cams.raw(), pts.raw(), obs.data(), ci.data(), pi.data(), dev, nullptr) != GR_OK) return fail("gr_bal_create");
   if (gr_bal_set_loss(prob, loss_kind ? GR_LOSS_HUBER : GR_LOSS_DEFAULT, loss_delta) != GR_OK) return fail("gr_bal_set_loss");
@@ -579,6 +621,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   if (getenv("GR_VERBOSE")) std::cerr << "[graphite] bundle-adjustment graph (" << cd->count() << " cameras, " << pd->count() << " points, " << ci.size()
                                       << " factors) handed to the gr_bal engine, gr_solver " << kind << std::endl;
   if (gr_bal_levenberg_marquardt(prob, &o, &st, chi2.data(), lambda.data()) != GR_OK) return fail("gr_bal_levenberg_marquardt");
+  ++engine_handovers();
   if (gr_bal_get_params(prob, cams.raw(), pts.raw()) != GR_OK) return fail("gr_bal_get_params");
   cd->scatter_parameters(cams.raw()); pd->scatter_parameters(pts.raw());
   graph->compute_error(); // leave the residuals of the optimised vertices behind, as the generic loop does (graph->chi2() is valid)
@@ -673,6 +716,8 @@ template <bool EARLY, typename T, typename S> bool lm_loop(Graph<T, S> *graph, L
   return run;
 }
 } // namespace detail
+// optimiser calls of this process that ran on the hand-written gr_bal engine (the others ran on the generic kernels)
+inline size_t engine_handover_count() { return detail::engine_handovers(); }
 template <typename T, typename S> bool levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {
   return detail::lm_loop<false>(graph, options);
 }

@@ -192,6 +192,16 @@ gr_status gr_bal_get(gr_bal_problem *p, gr_bal_array which, void *out, int64_t *
 gr_status gr_bal_levenberg_marquardt(gr_bal_problem *p, const gr_lm_options *options,
                                      gr_lm_stats *stats, double *chi2_trace, double *lambda_trace);
 
+/* The camera model the engine is specialised for, on caller-supplied triples: for i < n, camera i (9 scalars
+ * [angle-axis r(3), t(3), f, k1, k2]), point i (3) and observation i (2) give residual i (2), the camera block Jc
+ * (2 x 9, column-major, 18 scalars) and the point block Jp (2 x 3, column-major, 6) — the values the user traits of
+ * examples/bal.cuh:61-89 produce through bal_reprojection_error_simple (examples/reprojection_error.cuh:61-99) and
+ * bal_jacobian_simple (examples/reprojection_error.cuh:104-126, examples/projection_jacobians.cuh:2-322).  The
+ * header-only layer (include/graphite/solve.hpp) calls it to VERIFY that a user's error()/jacobian() are this model
+ * before it hands a graph to the engine.  All pointers host or device; residuals / Jc / Jp may be NULL. */
+gr_status gr_bal_model_evaluate(gr_dtype dtype, int64_t n, const void *cameras, const void *points,
+                                const void *observations, void *residuals, void *Jc, void *Jp, int device, void *stream);
+
 /* ---- measurement -----------------------------------------------------------------
  * HIP-event timing of the kernels of the last gr_bal_levenberg_marquardt call with
  * options->profile != 0.  Fills up to `cap` entries; returns the number of distinct

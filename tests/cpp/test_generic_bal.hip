@@ -99,6 +99,19 @@ template <typename T, typename S> struct ReprojectionErrorEngineTraits : Reproje
 };
 template <typename T, typename S> using ReprojectionErrorEngine = FactorDescriptor<T, S, ReprojectionErrorEngineTraits<T, S>>;
 
+// ... and a factor that CARRIES the tag but computes another function (half the radial distortion): the hand-over
+// probe must notice and leave the graph on the generic kernels
+template <typename T, typename S> struct ReprojectionErrorWrongTagTraits : ReprojectionErrorTraits<T, S> {
+  static constexpr bool bal_reprojection_model = true;
+  template <typename D> d_fn static void error(const D *camera, const D *point, const typename ReprojectionErrorTraits<T, S>::Observation &obs, D *error) {
+    D cam[9];
+    for (int k = 0; k < 9; ++k) cam[k] = camera[k];
+    cam[7] = cam[7] * D(T(0.5)); // half the radial distortion
+    reprojection<D, T>(cam, point, obs, error);
+  }
+};
+template <typename T, typename S> using ReprojectionErrorWrongTag = FactorDescriptor<T, S, ReprojectionErrorWrongTagTraits<T, S>>;
+
 } // namespace graphite
 
 template <template <typename, typename> class Factor> static int run(int argc, char **argv) {
@@ -133,7 +146,7 @@ template <template <typename, typename> class Factor> static int run(int argc, c
   graph.add_descriptor(&r_desc);
   const std::string jmode = argc > 4 ? argv[4] : "auto";
   if (jmode == "dynamic") r_desc.set_jacobian_storage(false); // factor.hpp:626-640
-  std::cout << "JACOBIANS " << (r_desc.dynamic_jacobians() ? "dynamic" : r_desc.use_autodiff() ? "auto" : "stored") << std::endl;
+  std::cout << "JACOBIANS " << (jmode == "wrong-tag" ? "wrong-tag" : r_desc.dynamic_jacobians() ? "dynamic" : r_desc.use_autodiff() ? "auto" : "stored") << std::endl;
   const DefaultLoss<FP, 2> loss;
   for (size_t i = 0; i < no; ++i) r_desc.add_factor({ci[i], nc + pi[i]}, ob[i], nullptr, Empty(), loss);
 
@@ -161,7 +174,7 @@ template <template <typename, typename> class Factor> static int run(int argc, c
   std::cout << std::setprecision(17) << "FINAL_CHI2 " << graph.chi2() << std::endl;
   std::cout << "CAM0";
   for (int k = 0; k < 9; ++k) std::cout << " " << cams[0](k);
-  std::cout << std::endl << (ok ? "OK" : "STOPPED") << std::endl;
+  std::cout << std::endl << "ENGINE_HANDOVERS " << optimizer::engine_handover_count() << std::endl << (ok ? "OK" : "STOPPED") << std::endl;
   solver.reset();
   return 0;
 }
@@ -171,5 +184,6 @@ int main(int argc, char **argv) {
   const std::string jmode = argc > 4 ? argv[4] : "auto";
   // engine: the tagged factor (dispatched to gr_bal_*); engine-fixed: the same with one camera fixed (handed over with a fixed-vertex mask)
   if (jmode == "engine" || jmode == "engine-fixed") return run<graphite::ReprojectionErrorEngine>(argc, argv);
+  if (jmode == "wrong-tag") return run<graphite::ReprojectionErrorWrongTag>(argc, argv);
   return jmode == "auto" ? run<graphite::ReprojectionError>(argc, argv) : run<graphite::ReprojectionErrorManual>(argc, argv);
 }

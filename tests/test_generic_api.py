@@ -132,6 +132,42 @@ def test_tagged_bal_graph_runs_on_the_engine(oracle_mod, tmp_path, monkeypatch, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("jacobians", ["auto", "stored"])
+def test_untagged_bal_traits_reach_the_engine(oracle_mod, tmp_path, jacobians):
+    """No tag, no source change: user traits whose error() (and jacobian(), or dual numbers) reproduce the engine's model on
+    the probe's sampled factors are handed to gr_bal_*; the trace is the oracle's."""
+    exe = build_all()[2]
+    prob = synth.make_config("mini-50")
+    f = tmp_path / "problem.txt"
+    synth.write_bal(f, prob)
+    prob = synth.read_bal(f)
+    r = subprocess.run([exe, str(f), "pcg", "8", jacobians], capture_output=True, text=True, timeout=300, env=dict(os.environ, GR_VERBOSE="1"))
+    print(r.stdout[-2000:], r.stderr[-800:])
+    assert r.returncode == 0 and "handed to the gr_bal engine" in r.stderr and "ENGINE_HANDOVERS 1" in r.stdout
+    assert "engine hand-over probe" in r.stderr
+    tr = parse_trace(r.stdout)
+    ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    ct, lt, _ = ref.levenberg_marquardt(solver=oracle_mod.SOLVER_PCG, iterations=8)
+    assert np.allclose(tr[:, 1], ct[1:], rtol=1e-7) and np.allclose(tr[:, 2], lt[1:], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_wrong_bal_tag_is_caught(tmp_path):
+    """A factor that carries `bal_reprojection_model` but computes another residual is NOT optimised as the engine's model:
+    the probe reports the mismatch and the generic kernels (which call the user's functions) run."""
+    exe = build_all()[2]
+    prob = synth.make_config("mini-50")
+    f = tmp_path / "problem.txt"
+    synth.write_bal(f, prob)
+    r = subprocess.run([exe, str(f), "pcg", "4", "wrong-tag"], capture_output=True, text=True, timeout=300, env=dict(os.environ, GR_VERBOSE="1"))
+    print(r.stdout[-2000:], r.stderr[-800:])
+    assert r.returncode == 0 and "ENGINE_HANDOVERS 0" in r.stdout
+    assert "declare bal_reprojection_model, but error()/jacobian() differ" in r.stderr and "handed to the gr_bal engine" not in r.stderr
+    tr = parse_trace(r.stdout)
+    assert tr[-1, 1] < tr[0, 0]  # the user's own function was optimised
+
+
+@pytest.mark.gpu
 def test_generic_schur_elimination_on_a_mixed_dimension_graph():
     """2-D SLAM (poses of dimension 3, eliminated landmarks of dimension 2; prior, odometry and Huber sighting
     factors): EigenSchurLDLTSolver and PCGSchurSolver reproduce the full EigenLDLTSolver optimisation."""
@@ -161,9 +197,12 @@ def test_generic_bal_matches_oracle(oracle_mod, tmp_path, solver, jacobians):
     f = tmp_path / "problem.txt"
     synth.write_bal(f, prob)
     prob = synth.read_bal(f)  # the text round trip is what the executable sees
-    r = subprocess.run([exe, str(f), solver, "8", jacobians], capture_output=True, text=True, timeout=300)
+    # GRAPHITE_GENERIC_ONLY=1: these user traits ARE the engine's model, so without it the verified hand-over would route the
+    # graph to gr_bal_* (test_untagged_bal_traits_reach_the_engine); this test is about the generic kernels
+    r = subprocess.run([exe, str(f), solver, "8", jacobians], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GRAPHITE_GENERIC_ONLY="1"))
     print(r.stdout[-3000:], r.stderr[-500:])
-    assert r.returncode == 0 and f"JACOBIANS {jacobians}" in r.stdout
+    assert r.returncode == 0 and f"JACOBIANS {jacobians}" in r.stdout and "ENGINE_HANDOVERS 0" in r.stdout
     tr = parse_trace(r.stdout)
     ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
     os_ = {"pcg": oracle_mod.SOLVER_PCG, "pcg-identity": oracle_mod.SOLVER_PCG_IDENTITY, "eigen": oracle_mod.SOLVER_LDLT,

@@ -77,8 +77,14 @@ def test_reference_bal_driver_matches_oracle(oracle_mod, tmp_path, solver, osolv
     prob = synth.make_config("mini-50")
     path = str(tmp_path / "mini50.txt")
     synth.write_bal(path, prob)
-    out = subprocess.run([exe, path, "--solver", solver, "--iterations", "6", "--verbose"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe, path, "--solver", solver, "--iterations", "6", "--verbose"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, GR_VERBOSE="1"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    # WHICH path ran: the traits of examples/bal.cuh carry no tag; the hand-over probe finds that their error() / jacobian()
+    # are the engine's model and the hand-written kernels run (the full-H direct solver has no engine counterpart yet)
+    on_engine = "handed to the gr_bal engine" in out.stderr
+    assert "engine hand-over probe" in out.stderr or solver == "eigen", out.stderr[-1500:]
+    assert on_engine == (solver != "eigen"), out.stderr[-1500:]
     mse = float(re.search(r"^MSE: ([0-9.eE+-]+)", out.stdout, re.M).group(1))
     ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx)
     ct, _, _ = ref.levenberg_marquardt(solver=getattr(oracle_mod, osolver), iterations=6)
