@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import LMOptions, LMStats, KernelStat, check
+from ._lib import LMOptions, LMStats, KernelStat, Tuning, check
 
 SOLVER_PCG_SCHUR, SOLVER_PCG, SOLVER_PCG_IDENTITY, SOLVER_PCG_SCHUR_IMPLICIT, SOLVER_DENSE_SCHUR = 0, 1, 2, 3, 4
 LOSS_DEFAULT, LOSS_HUBER = 0, 1
@@ -62,6 +62,21 @@ class BalProblem:
             self.close()
         except Exception:
             pass
+
+    def get_tuning(self):
+        t = Tuning()
+        check(self.lib.gr_bal_get_tuning(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Tuning._fields_ if k != "reserved"}
+
+    def set_tuning(self, **kw):
+        """gr_bal_set_tuning: e.g. set_tuning(point_tiles=8, pcg_lazy=0); unnamed fields keep their value"""
+        t = Tuning()
+        check(self.lib.gr_bal_get_tuning(self.h, C.byref(t)))
+        for k, v in kw.items():
+            if k not in dict(Tuning._fields_) or k == "reserved":
+                raise KeyError(k)
+            setattr(t, k, int(v))
+        check(self.lib.gr_bal_set_tuning(self.h, C.byref(t)))
 
     # --- Graph -------------------------------------------------------------------------
     def set_loss(self, kind, delta=0.0):
@@ -225,3 +240,17 @@ def dense_cholesky_solve(A, b, device=0):
     check(L.gr_dense_cholesky_solve(C.c_int(F64 if dt == np.float64 else F32), C.c_int64(n), _ptr(A), C.c_int64(lda),
                                     _ptr(b), _ptr(x), C.c_int(device), None, C.byref(sec)))
     return x, sec.value
+
+
+def model_evaluate(cameras, points, obs, dtype=np.float64, device=0):
+    """gr_bal_model_evaluate: residual (n, 2), Jc (n, 18) and Jp (n, 6) of the engine's camera model on n triples"""
+    lib = _lib.lib()
+    dt = np.dtype(dtype)
+    c = np.ascontiguousarray(cameras, dtype=dt).reshape(-1, 9)
+    p = np.ascontiguousarray(points, dtype=dt).reshape(-1, 3)
+    o = np.ascontiguousarray(obs, dtype=dt).reshape(-1, 2)
+    n = len(c)
+    r, jc, jp = np.zeros((n, 2), dt), np.zeros((n, 18), dt), np.zeros((n, 6), dt)
+    check(lib.gr_bal_model_evaluate(C.c_int(F32 if dt == np.float32 else F64), C.c_int64(n), _ptr(c), _ptr(p), _ptr(o), _ptr(r), _ptr(jc), _ptr(jp),
+                                    C.c_int(device), C.c_void_p(0)))
+    return r, jc, jp

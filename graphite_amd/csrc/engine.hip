@@ -29,6 +29,26 @@ static thread_local std::string g_last_error;
 
 static inline int cdiv(size_t a, size_t b) { return (int)((a + b - 1) / b); }
 
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+static void tuning_default(gr_bal_tuning &t) {
+  std::memset(&t, 0, sizeof(t));
+  t.point_tiles = env_int("GR_PTILES", -1);
+  t.g3_gather = env_int("GR_G3_GATHER", -1);
+  t.point_records = env_int("GR_POINT_RECORDS", -1);
+  t.pcg_lazy = env_int("GR_PCG_LAZY", -1);
+  t.pcg_single_reduction = env_int("GR_PCG_CG", -1);
+  t.sparse_cholesky = env_int("GR_SPARSE_CHOL", -1);
+  t.spchol_overlap = env_int("GR_SPCHOL_OVERLAP", 1);
+  t.lm_speculate = env_int("GR_LM_SPECULATE", 1);
+  t.lm_ahead = env_int("GR_LM_AHEAD", 1);
+  t.lm_fused = env_int("GR_LM_FUSED", 1);
+  t.grid_mult = std::max(1, env_int("GR_GRID_MULT", 4));
+  t.vec_per_thread = std::max(1, env_int("GR_VEC_PER_THREAD", 2)); // replayed back to back on Ladybug-1723: 5.3 us (1), 4.4 (2), 4.9 (4), 5.8 (8)
+  t.schur_item = env_int("GR_SCHUR_ITEM", 56);
+  t.verbose = getenv("GR_VERBOSE") ? 1 : 0;
+  t.ipc_timeout_ms = env_int("GR_IPC_TIMEOUT_MS", 30000);
+}
+
 struct KernelProf {
   std::string name;
   int64_t launches = 0, noop = 0; // noop: look-ahead launches that found the PCG loop already finished
@@ -66,6 +86,9 @@ struct EngineBase {
   virtual double diag_time(int which, int variant, int reps) = 0;
   virtual void set_comm(std::unique_ptr<Comm> c) = 0;
   virtual void allreduce_host(double *v, size_t n) = 0;
+  virtual void apply_tuning() = 0; // after `tune` changed
+  gr_bal_tuning tune;
+  EngineBase() { tuning_default(tune); }
   int device = 0;
   char *ipc_box = nullptr; // mailbox allocated by gr_bal_comm_ipc_mailbox, owned by the IpcComm once it exists
   size_t ipc_slot = 0;
@@ -122,15 +145,14 @@ template <typename T> struct Engine final : EngineBase {
   // gathers two per point instead of one and every wave of it re-derives the loop decision from the dot-product slots
   // (Ladybug-1723: operator 24.9 -> 29.7 us, update 21.3 -> 27.3 us for the 12.7 us direction launch saved).  It pays
   // where launches dominate and is a wash or a loss where bytes do.  Default: vectors up to 1 MB (Ladybug-49-sized
-  // problems).  Off in the opt-in graph-replay mode and in diagnostic builds (their kernels are the direction-kernel form).
+  // problems).  Off in diagnostic builds (their kernels are the direction-kernel form).
   bool pcg_lazy() const {
 #ifdef GR_DIAG
     return false; // the ablation variants of tools/diag_*.py are instantiated for the direction-kernel form only
 #endif
-    if (lm_graph_enabled) return false;
     return lazy_cfg < 0 ? n * sizeof(T) <= ((size_t)1 << 20) : lazy_cfg != 0;
   }
-  int lazy_cfg = -1; // GR_PCG_LAZY, read once per solver_update_structure (no getenv inside the LM loop)
+  int lazy_cfg = -1; // gr_bal_tuning.pcg_lazy, latched per solver_update_structure
   // Single-reduction PCG (kernels_mf.hpp PcgState, lazy == 2): on landmark shards by default — ONE all-reduce per inner
   // iteration (camera rows + every dot product of the iteration) instead of two; GR_PCG_CG=0/1 forces it (1 also on a
   // single GPU: that is how tests hold it to the oracle's solve_pcg_cg).
@@ -139,7 +161,6 @@ template <typename T> struct Engine final : EngineBase {
 #ifdef GR_DIAG
     return false;
 #endif
-    if (lm_graph_enabled) return false;
     return cg_cfg < 0 ? (comm && comm->size > 1) : cg_cfg != 0;
   }
   int pcg_mode() const { return pcg_cg() ? 2 : (pcg_lazy() ? 1 : 0); }
@@ -152,7 +173,7 @@ template <typename T> struct Engine final : EngineBase {
   // payload); in observation order the operator fell from 176 to 86 us inside the solve and the update kernel rose from
   // 83 to 105 us (Final-13682 fp64: 1481 -> 786 and 472 -> 712).  Ladybug-1723 (everything cache-resident, plain order):
   // operator 23.1 -> 20.5 us, update 20.3 -> 23.7 us, no gain, so it keeps the pm layout.
-  bool want_g3_gather() const { const char *e = getenv("GR_G3_GATHER"); return e ? atoi(e) == 1 : tiled; }
+  bool want_g3_gather() const { return tune.g3_gather >= 0 ? tune.g3_gather == 1 : tiled; }
   DevBuf<int> g3_gidx, ptile_ptr;
   int g3_ptiles = 0;
   const int *g3_pos() const { return g3_obs_order ? nullptr : o_pos(); }
@@ -199,10 +220,15 @@ template <typename T> struct Engine final : EngineBase {
   T *lm_x = nullptr;
   int state_clean_cap = -1;
   bool update0_done = false, update0_identity = false;
-  // pinned host mirror: [0..1] chi2 / rho doubles, then ints: seq, flags[]
+  // pinned host mirror: h_res[0..3] = trial chi2, rho denominator, new damping, accepted (the last two from k_finalize_bj);
+  // h_seq[0] = sequence number of the last published result, h_seq[1 + bank] = iteration count of the PCG loop that uses
+  // flag bank `bank`; h_flag = two banks of per-iteration exit flags.  Two banks because, on an accept streak, the first
+  // kernels of the NEXT solve are enqueued while look-ahead launches of the current one may still write their flags.
   double *h_res = nullptr;
   volatile int *h_seq = nullptr, *h_flag = nullptr;
-  int h_flag_cap = 0, seq_counter = 0;
+  int h_flag_cap = 0, seq_counter = 0, flag_bank = 0;
+  volatile int *flags() const { return h_flag + (size_t)flag_bank * h_flag_cap; }
+  volatile int *h_iters() const { return h_seq + 1 + flag_bank; }
   DevBuf<T> Hcc, Hll, Hcp, scales, bu; // bu = [bc (9Nc) ; bl (3Np)] unscaled -J^T rho' r
   struct View { T *p = nullptr; } bc, bl;
   DevBuf<double> chi2_partial, dscalars; // dscalars[0]=chi2, [1]=rho denom
@@ -223,14 +249,14 @@ template <typename T> struct Engine final : EngineBase {
     if (records_tuned) return;
     records_tuned = true;
     if (pcg_mode() != 0) { use_records = false; return; } // the lazy / single-reduction forms gather zs (and ps); the 8-scalar record has room for one
-    if (const char *e = getenv("GR_POINT_RECORDS")) { use_records = atoi(e) != 0; return; }
+    if (tune.point_records >= 0) { use_records = tune.point_records != 0; return; }
     use_records = false;
     const double t_plain = diag_time(0, 0, 5);
     use_records = true;
     const double t_rec = diag_time(0, 0, 5);
     use_records = t_rec < 0.97 * t_plain;
     xp_valid = false;
-    if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] operator %.1f us plain, %.1f us with point records -> %s\n", t_plain, t_rec, use_records ? "records" : "plain");
+    if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] operator %.1f us plain, %.1f us with point records -> %s\n", t_plain, t_rec, use_records ? "records" : "plain");
   }
   void ensure_point_records() {
     if (!use_records) return;
@@ -302,13 +328,7 @@ template <typename T> struct Engine final : EngineBase {
       GR_HIP(hipGetDeviceProperties(&prop, dev));
       num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int grid_mult = getenv("GR_GRID_MULT") ? atoi(getenv("GR_GRID_MULT")) : 4; // tuning knob (blocks per CU)
-    grid_obs = std::max(8, std::min(nb_pm, num_cu * grid_mult) & ~7); // multiple of 8: one contiguous tile range per XCD
-    { // light vector kernels: GR_VEC_PER_THREAD elements per thread (every wave first re-derives the loop scalars from the
-      // dot-product slots, so one element per thread made that prologue most of the kernel)
-      const int per = getenv("GR_VEC_PER_THREAD") ? std::max(1, atoi(getenv("GR_VEC_PER_THREAD"))) : 2; // replayed back to back on Ladybug-1723: 5.3 us (1), 4.4 (2), 4.9 (4), 5.8 (8)
-      grid_vec = std::max(1, std::min(cdiv(n, (size_t)TPB * per), num_cu * 8));
-    }
+    apply_tuning(); // grid_obs, grid_vec
     grid_chi2 = std::max(8, std::min(nb_pm, num_cu * 2) & ~7); // measured: the light chi2 pass prefers 2 long blocks per CU (16 vs 22 us at 8)
     n_chi2_blocks = std::min(cdiv(No, TPB), 1024);
     chi2_partial.alloc(std::max<size_t>(nb_pm, 2 * (size_t)cdiv(std::max<size_t>(No, n), TPB)) + 64);
@@ -324,23 +344,30 @@ template <typename T> struct Engine final : EngineBase {
     GR_HIP(hipStreamSynchronize(stream));
   }
 
+  // persistent grids and the per-problem choices that depend on the tuning; called by the constructor and by gr_bal_set_tuning
+  void apply_tuning() override {
+    grid_obs = std::max(8, std::min(nb_pm, num_cu * std::max(1, tune.grid_mult)) & ~7); // multiple of 8: one contiguous tile range per XCD
+    // light vector kernels: several elements per thread (every wave first re-derives the loop scalars from the
+    // dot-product slots, so one element per thread made that prologue most of the kernel)
+    grid_vec = std::max(1, std::min(cdiv(n, (size_t)TPB * std::max(1, tune.vec_per_thread)), num_cu * 8));
+    if (tiling_tuned) { if (tiled) untile(); tiling_tuned = false; } // timed choices are re-made by the next solver_update_structure
+    records_tuned = false;
+    if (chol_ready) { chol_ready = false; use_spchol = false; }
+    if (schur_ready && nitems) schur_ready = false;
+  }
   void alloc_pinned(int flag_cap) {
     if (h_res && flag_cap <= h_flag_cap) return;
     if (h_res) (void)hipHostFree(h_res);
     void *p = nullptr;
-    GR_HIP(hipHostMalloc(&p, 64 + sizeof(int) * (size_t)(flag_cap + 16), hipHostMallocCoherent | hipHostMallocMapped));
-    std::memset(p, 0, 64 + sizeof(int) * (size_t)(flag_cap + 16));
+    GR_HIP(hipHostMalloc(&p, 64 + sizeof(int) * 2 * (size_t)(flag_cap + 16), hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(p, 0, 64 + sizeof(int) * 2 * (size_t)(flag_cap + 16));
     h_res = static_cast<double *>(p);
-    h_seq = reinterpret_cast<volatile int *>(static_cast<char *>(p) + 16);
+    h_seq = reinterpret_cast<volatile int *>(static_cast<char *>(p) + 32);
     h_flag = reinterpret_cast<volatile int *>(static_cast<char *>(p) + 64);
-    h_flag_cap = flag_cap;
+    h_flag_cap = flag_cap + 16;
   }
   ~Engine() override {
     if (h_res) (void)hipHostFree(h_res);
-    lm_graph_release();
-    if (lmg_stream) (void)hipStreamDestroy(lmg_stream);
-    if (h_lm) (void)hipHostFree(const_cast<int *>(h_lm));
-    if (h_trace) (void)hipHostFree(const_cast<double *>(h_trace));
   }
   // spin on a pinned word written by a kernel (system-scope fence on the device side)
   template <typename Pred> void spin_until(Pred pred) {
@@ -493,7 +520,7 @@ template <typename T> struct Engine final : EngineBase {
     tiling_tuned = true;
     const size_t per_point = (size_t)(6 * sizeof(T) + 3 * sizeof(T) * (double)No / (double)Np); // X + direction + this point's g3 slots
     int K = 0;
-    if (const char *e = getenv("GR_PTILES")) K = atoi(e);
+    if (tune.point_tiles >= 0) K = tune.point_tiles;
     else {
       if ((size_t)Np * per_point < ((size_t)24 << 20)) return; // the whole working set sits in the L2s as it is
       // tiles small enough for an XCD's L2 (3 MB of points + scatter slots each), but not so many that a camera's run inside
@@ -507,12 +534,12 @@ template <typename T> struct Engine final : EngineBase {
     }
     if (K <= 0) return;
     K = std::max(8, (K + 7) / 8 * 8);
-    const bool forced = getenv("GR_PTILES") != nullptr;
+    const bool forced = tune.point_tiles >= 0;
     const double t_plain = forced ? 0.0 : diag_time(0, 0, 5) + diag_time(1, 0, 5) + diag_time(3, 0, 5);
     build_tiled_order(K);
     if (!forced) {
       const double t_tiled = diag_time(0, 0, 5) + diag_time(1, 0, 5) + diag_time(3, 0, 5);
-      if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] operator + linearise + update: %.1f us plain order, %.1f us with %d point tiles -> %s\n", t_plain, t_tiled, K, t_tiled < 0.95 * t_plain ? "tiled" : "plain");
+      if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] operator + linearise + update: %.1f us plain order, %.1f us with %d point tiles -> %s\n", t_plain, t_tiled, K, t_tiled < 0.95 * t_plain ? "tiled" : "plain");
       if (!(t_tiled < 0.95 * t_plain)) untile();
     }
   }
@@ -595,7 +622,7 @@ template <typename T> struct Engine final : EngineBase {
     // the finishing pass instead of atomics: 19 us at 56, 17 us at 7..28, but the heavier finishing pass gives it back
     // (8 765 vs 8 839 LM it/s): the kernel's floor is its chain of dependent index loads, not the atomics.
     int isz = 56;
-    if (getenv("GR_SCHUR_ITEM")) isz = std::max(7, atoi(getenv("GR_SCHUR_ITEM")) / 7 * 7);
+    if (tune.schur_item > 0) isz = std::max(7, tune.schur_item / 7 * 7);
     std::vector<int> h_item_blk, h_item_beg, h_item_end, h_item_single, h_multi;
     for (int64_t q = 0; q < nnzb; ++q) {
       const int beg = h_prod_ptr[q], end = h_prod_ptr[q + 1];
@@ -764,7 +791,7 @@ template <typename T> struct Engine final : EngineBase {
       Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
       k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)np_fin, TPB), TPB, 0, stream>>>((int)Nc, np_fin, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
                                                                                                     spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq,
-                                                                                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gate, cam_fixed_p(), pt_fixed_p());
+                                                                                                    gate, cam_fixed_p(), pt_fixed_p());
     }
     if (comm) { // camera-space sums over the landmark shards
       group_start();
@@ -776,11 +803,14 @@ template <typename T> struct Engine final : EngineBase {
     }
     hcp_valid = write_hcp;
   }
+  bool lin_reset = false; // LM loop, fused form: this k_linearize launch also clears the PCG loop state (its last workgroup)
   void launch_linearize_cam(bool hcp, T *g9p, const int *gate) {
+    const PcgState rst = lin_reset ? pcg_state() : PcgState{};
+    const int rst_cap = lin_reset ? ctl_cap : 0;
 #ifdef GR_DIAG
     { // diagnostic builds: GR_LIN_VAR=1|2|4|8 runs an ablated lineariser INSIDE the solve (wrong numbers, real cache state)
       static const int var = getenv("GR_LIN_VAR") ? atoi(getenv("GR_LIN_VAR")) : 0;
-#define GR_LINV(V) k_linearize<T, false, T, V><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate)
+#define GR_LINV(V) k_linearize<T, false, T, V><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap)
       if (!hcp && var == 1) { GR_LINV(1); return; }
       if (!hcp && var == 2) { GR_LINV(2); return; }
       if (!hcp && var == 4) { GR_LINV(4); return; }
@@ -790,13 +820,13 @@ template <typename T> struct Engine final : EngineBase {
 #endif
     if constexpr (sizeof(T) == 8) {
       if (jac32) {
-        if (hcp) k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p());
-        else k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate);
+        if (hcp) k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
+        else k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
         return;
       }
     }
-    if (hcp) k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p());
-    else k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate);
+    if (hcp) k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
+    else k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
   }
   bool want_hcp = false;
   void linearize() override { linearize_impl(want_hcp); }
@@ -869,7 +899,7 @@ template <typename T> struct Engine final : EngineBase {
     const size_t blk = (size_t)sc_cap * sc.np;
     sc.rz = sc_d.p; sc.den = sc_d.p + blk; sc.rz0 = sc_d.p + 2 * blk;
     sc.done = sc_i.p; sc.iters = sc_i.p + sc_cap;
-    sc.hflag = h_flag; sc.hiters = h_seq + 1;
+    sc.hflag = flags(); sc.hiters = h_iters();
     return sc;
   }
 
@@ -883,8 +913,8 @@ template <typename T> struct Engine final : EngineBase {
     }
     else {
       want_hcp = false;
-      { const char *e = getenv("GR_PCG_LAZY"); lazy_cfg = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
-      { const char *e = getenv("GR_PCG_CG"); cg_cfg = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
+      lazy_cfg = tune.pcg_lazy < 0 ? -1 : (tune.pcg_lazy != 0 ? 1 : 0);
+      cg_cfg = tune.pcg_single_reduction < 0 ? -1 : (tune.pcg_single_reduction != 0 ? 1 : 0);
       v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
       MinvC.alloc(81 * (size_t)Nc); MinvP.alloc(9 * (size_t)Np);
       if (!tiling_tuned) tune_tiling();
@@ -1006,27 +1036,27 @@ template <typename T> struct Engine final : EngineBase {
   std::function<void(const int *gate)> trial_hook;
   bool trial_done = false;
   DevBuf<int> loop_left;
-  template <typename Enqueue> int run_pcg_iterations(int max_iter, Enqueue &&enqueue) {
+  template <typename Enqueue> int run_pcg_iterations(int max_iter, Enqueue &&enqueue, int pre_enqueued = 0) {
     int enqueued = 0, hook_at = -1;
     bool left = false;
     trial_done = false;
-    if (max_iter > 0) { enqueue(0); ++enqueued; }
+    if (max_iter > 0) { if (!pre_enqueued) enqueue(0); ++enqueued; }
     for (int k = 0; k < max_iter; ++k) {
       if (k + 1 < max_iter && k + 1 < predicted_iters && enqueued == k + 1) { enqueue(k + 1); ++enqueued; }
       if (trial_hook && hook_at < 0 && predicted_iters > 0 && k + 1 >= predicted_iters && enqueued == k + 1) {
         trial_hook(k + 1 < max_iter ? loop_left.p : nullptr); // the iteration cap ends the loop whatever the flag says
         hook_at = k;
       }
-      spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
-      if (h_flag[k] == 2) { left = true; break; }
+      spin_until([&] { return __atomic_load_n(const_cast<const int *>(&flags()[k]), __ATOMIC_ACQUIRE) != 0; });
+      if (flags()[k] == 2) { left = true; break; }
       if (k + 1 < max_iter && enqueued == k + 1) { enqueue(k + 1); ++enqueued; }
     }
     if (hook_at >= 0) {
-      const int last = left ? std::min((int)h_seq[1], enqueued) - 1 : enqueued - 1; // last iteration that ran
+      const int last = left ? std::min((int)*h_iters(), enqueued) - 1 : enqueued - 1; // last iteration that ran
       trial_done = (left && last <= hook_at) || hook_at + 1 == max_iter;
       if (!trial_done) note_noop({"linearize", "linearize_finalize"}, 1);
     }
-    const int active = left ? std::min((int)h_seq[1], enqueued) : enqueued;
+    const int active = left ? std::min((int)*h_iters(), enqueued) : enqueued;
     predicted_iters = active;
     return enqueued - active;
   }
@@ -1041,8 +1071,8 @@ template <typename T> struct Engine final : EngineBase {
     build_schur_structure();
     ensure_scalars(max_iter);
     PcgScalars sc = scalars();
-    for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
-    h_seq[1] = 0;
+    for (int k = 0; k < max_iter + 1; ++k) flags()[k] = 0;
+    *h_iters() = 0;
     schur_update_values_impl(true);
     if (comm) k_schur_pcg_prepare<T, 1><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, S.p, S_diag.p, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, nullptr, sc);
     else k_schur_pcg_prepare<T, 0><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, S.p, S_diag.p, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, nullptr, sc);
@@ -1073,18 +1103,17 @@ template <typename T> struct Engine final : EngineBase {
   // dissects (the tile elimination tree is clearly shorter than the chain of tile columns), DenseChol otherwise.
   // GR_SPARSE_CHOL=0 / 1 forces the choice.
   SparseChol<T> spchol;
-  bool spchol_overlap = !(getenv("GR_SPCHOL_OVERLAP") && atoi(getenv("GR_SPCHOL_OVERLAP")) == 0); // A/B knob: forward substitution beside the factorisation
+  bool spchol_overlap() const { return tune.spchol_overlap != 0; } // forward substitution beside the factorisation
   bool use_spchol = false;
   void ensure_chol() {
     build_schur_structure();
     if (chol_ready) return;
     {
-      const char *e = getenv("GR_SPARSE_CHOL");
-      const int force = e ? atoi(e) : -1;
+      const int force = tune.sparse_cholesky;
       if (force != 0 && spchol.set_structure((int)Nc, h_S_rowi, h_S_coli, stream)) {
         use_spchol = force == 1 || 2 * spchol.nlevels < spchol.nt;
         if (spchol.bytes() > ((size_t)96 << 30)) use_spchol = false;
-        if (getenv("GR_VERBOSE"))
+        if (tune.verbose)
           std::fprintf(stderr, "[graphite-mi355x] sparse Cholesky: %d supernodes, %d tile columns (padded n = %d), elimination-tree height %d, %lld factor tiles -> %s\n",
                        spchol.nsuper, spchol.nt, spchol.npad, spchol.nlevels, (long long)spchol.factor_tiles, use_spchol ? "nested dissection, level-scheduled" : "dense tile Cholesky");
       }
@@ -1116,11 +1145,11 @@ template <typename T> struct Engine final : EngineBase {
     schur_update_values();
     if (use_spchol) {
       spchol.load(nnzb, S_rowi.p, S_coli.p, S.p);
-      if (spchol_overlap) spchol.factor_solve(b_schur.p, x);
+      if (spchol_overlap()) spchol.factor_solve(b_schur.p, x);
       else { spchol.factor(); spchol.solve(b_schur.p, x); }
       broadcast_camera_step(x);
       landmark_update_dev(x, x + pose_dim);
-      h_seq[1] = 0;
+      *h_iters() = 0;
       return spchol.ok();
     }
     chol.clear();
@@ -1129,7 +1158,7 @@ template <typename T> struct Engine final : EngineBase {
     chol.solve(b_schur.p, x);
     broadcast_camera_step(x);
     landmark_update_dev(x, x + pose_dim);
-    h_seq[1] = 0;
+    *h_iters() = 0;
     return chol.ok();
   }
 
@@ -1157,8 +1186,8 @@ template <typename T> struct Engine final : EngineBase {
       k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p, is_raw.p, nullptr, cam_fixed_p());
     } else
       k_is_finalize<T><<<cdiv(90 * (size_t)Nc, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, cam_partial.p, Hcc.p, bc.p, scales.p, damping, ui, Sdiag.p, b_schur.p, nullptr, nullptr, cam_fixed_p());
-    for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
-    h_seq[1] = 0;
+    for (int k = 0; k < max_iter + 1; ++k) flags()[k] = 0;
+    *h_iters() = 0;
     k_schur_pcg_prepare<T, 2><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, Sdiag.p, nullptr, nullptr, nullptr, nullptr, scales.p, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, x, v_q.p, sc);
     const double pass_bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np + 9.0 * Nc) * w() + 3.0 * No * w();
     const int noop = run_pcg_iterations(max_iter, [&](int k) {
@@ -1205,11 +1234,11 @@ template <typename T> struct Engine final : EngineBase {
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
     launch_operator_j<T>(st, k, rec, lm, mu);
   }
-  template <int MODE, bool IDENTITY> void launch_update(int blocks, T *x, const T *rawc, int cw, int ui, PcgState st, int k, int nc = -1, int np = -1) {
+  template <int MODE, bool IDENTITY> void launch_update(int blocks, T *x, const T *rawc, int cw, int ui, PcgState st, int k, int nc = -1, int np = -1, const LmDev *lm = nullptr) {
     const int nc_v = nc < 0 ? (int)Nc : nc, np_v = np < 0 ? (int)Np : np;
     if (st.lazy == 2) k_pcg_update<T, MODE, IDENTITY, 2><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
     else if (st.lazy) k_pcg_update<T, MODE, IDENTITY, 1><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
-    else k_pcg_update<T, MODE, IDENTITY><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
+    else k_pcg_update<T, MODE, IDENTITY><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather());
   }
   // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
   // touched once): obs + 3 index streams, ps, packs, points, g3 out, segment partials
@@ -1225,7 +1254,7 @@ template <typename T> struct Engine final : EngineBase {
     PcgState st;
     const size_t blk = (size_t)ctl_cap * NSLOT * NSW;
     st.acc = ctl.p; st.pdp = ctl.p + blk; st.rz0 = ctl.p + blk + ctl_cap;
-    st.done = ctl_i.p; st.iters = pcg_iters.p; st.hflag = h_flag; st.hiters = h_seq + 1;
+    st.done = ctl_i.p; st.iters = pcg_iters.p; st.hflag = flags(); st.hiters = h_iters();
     loop_left.alloc(1); st.left = loop_left.p;
     st.beta = ctl.p + blk + 2 * (size_t)ctl_cap; st.scale = ctl.p + blk + 3 * (size_t)ctl_cap;
     st.lazy = pcg_mode();
@@ -1249,8 +1278,8 @@ template <typename T> struct Engine final : EngineBase {
     PcgState st = pcg_state();
     st.x = x; st.tol = tol; st.rej = rej;
     const int ui = damping_identity ? 1 : 0;
-    for (int k = 0; k < max_iter + 1; ++k) h_flag[k] = 0;
-    h_seq[1] = 0;
+    for (int k = 0; k < max_iter + 1; ++k) flags()[k] = 0;
+    *h_iters() = 0;
     if (!started && state_fresh_cap != ctl_cap) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap); // else reset by k_block_jacobi
     state_fresh_cap = -1;
     const int ublocks = update_blocks();
@@ -1307,11 +1336,11 @@ template <typename T> struct Engine final : EngineBase {
           trial_hook(k + 1 < max_iter ? loop_left.p : nullptr);
           hook_at = k;
         }
-        spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
+        spin_until([&] { return __atomic_load_n(const_cast<const int *>(&flags()[k]), __ATOMIC_ACQUIRE) != 0; });
         ran = k + 1;
-        if (h_flag[k] == 2) { left = true; break; }
+        if (flags()[k] == 2) { left = true; break; }
       }
-      const int active = left ? std::min((int)h_seq[1], ran) : ran;
+      const int active = left ? std::min((int)*h_iters(), ran) : ran;
       if (hook_at >= 0) {
         trial_done = (left && ran - 1 <= hook_at) || hook_at + 1 == max_iter;
         if (!trial_done) note_noop({"linearize", "linearize_finalize"}, 1);
@@ -1337,11 +1366,11 @@ template <typename T> struct Engine final : EngineBase {
           trial_hook(k + 1 < max_iter ? loop_left.p : nullptr); // the iteration cap ends the loop whatever the flag says
           hook_at = k;
         }
-        spin_until([&] { return __atomic_load_n(const_cast<const int *>(&h_flag[k]), __ATOMIC_ACQUIRE) != 0; });
+        spin_until([&] { return __atomic_load_n(const_cast<const int *>(&flags()[k]), __ATOMIC_ACQUIRE) != 0; });
         ran = k + 1;
-        if (h_flag[k] == 2) { left = true; break; }
+        if (flags()[k] == 2) { left = true; break; }
       }
-      const int active = left ? std::min((int)h_seq[1], ran) : ran; // iterations whose operator and update did work
+      const int active = left ? std::min((int)*h_iters(), ran) : ran; // iterations whose operator and update did work
       if (hook_at >= 0) {
         trial_done = (left && ran - 1 <= hook_at) || hook_at + 1 == max_iter;
         if (!trial_done) note_noop({"linearize", "linearize_finalize"}, 1);
@@ -1619,154 +1648,99 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   // ---- optimizer::levenberg_marquardt (optimizer/levenberg_marquardt.hpp:110-242) -----
-  // ---- graph-replayed LM iterations ---------------------------------------------------------------
-  // One accepted LM iteration of the matrix-free PCG solvers as ONE hipGraph: block-Jacobi + PCG start,
-  // `unroll` PCG iterations, update + backup, camera packs, the (speculative) linearisation and the
-  // finalize kernel, which takes the accept decision on the device (LmDev).  The host replays the graph
-  // a few iterations ahead and only reads the traces; the first iteration that is not a plain
-  // acceptance (PCG needs more iterations, rejected step, rho == 0, non-finite value) makes every later
-  // replay a no-op and is redone by the host loop.  1.8 us per node instead of 3.1 us per stream launch
-  // and no host round trip inside the iteration.
-  struct LmGraphKey {
-    int solver = -1, max_iter = 0, use_identity = 0, jac32 = 0, loss_kind = 0, records = 0, cap = 0;
-    double tol = 0, rej = 0, loss_delta = 0;
-    const void *xp = nullptr, *pinned = nullptr; // pinned: h_res block baked into the captured PcgState
-    bool operator==(const LmGraphKey &o) const {
-      return solver == o.solver && max_iter == o.max_iter && use_identity == o.use_identity && jac32 == o.jac32 && loss_kind == o.loss_kind &&
-             records == o.records && cap == o.cap && tol == o.tol && rej == o.rej && loss_delta == o.loss_delta && xp == o.xp && pinned == o.pinned;
-    }
-  };
-  LmGraphKey lmg_key;
-  hipGraphExec_t lmg_exec = nullptr;
-  hipStream_t lmg_stream = nullptr; // capture / replay stream when the engine runs on the legacy default stream
   DevBuf<LmDev> lmdev;
-  volatile int *h_lm = nullptr;      // pinned: [0] accepted steps, [1] stop code
-  volatile double *h_trace = nullptr; // pinned: chi2[cap], lambda[cap]
-  int h_trace_cap = 0;
-  // GR_LM_GRAPH: 0 off (default), 1 hipGraph replay, 2 the same device-decided iteration enqueued ahead with plain
-  // stream launches.  Measured on Ladybug-1723 fp64 (A/B in one run): host loop 5 550-5 630 LM it/s, mode 1 4 900,
-  // mode 2 5 170-5 230: the host loop with its look-ahead predictor is kept as the product path.
-  int lm_graph_mode = getenv("GR_LM_GRAPH") ? atoi(getenv("GR_LM_GRAPH")) : 0;
-  bool lm_graph_enabled = lm_graph_mode != 0;
-  std::function<void()> lm_enqueue_fn;
-  int lm_unroll = getenv("GR_LM_UNROLL") ? atoi(getenv("GR_LM_UNROLL")) : 2;
 
-  void lm_graph_release() {
-    if (lmg_exec) { (void)hipGraphExecDestroy(lmg_exec); lmg_exec = nullptr; }
-  }
-  template <bool IDENTITY> void lm_graph_enqueue(int max_iter, double tol, double rej) {
-    // the launch sequence of one iteration, every kernel in its LmDev form (captured, never run directly)
-    const int ui = damping_identity ? 1 : 0;
-    PcgState stt = pcg_state();
-    LmDev *lm = lmdev.p;
-    T *rec = use_records ? xp.p : nullptr;
-    const int nbc = cdiv(Nc, 64), nbp = cdiv(Np, 64);
-    k_block_jacobi<T><<<nbc + nbp + 1, 64, 0, stream>>>((int)Nc, (int)Np, nbc, nbp, Hcc.p, Hll.p, scales.p, 0.0, ui, MinvC.p, MinvP.p, v_diag.p, stt, ctl_cap, lm);
-    const int ublocks = update_blocks();
-    T *x = v_dx.p;
-    k_pcg_update<T, 0, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, 0.0, ui, MinvC.p, MinvP.p, stt, 0, lm, g3_gather());
-    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, -1, 0.0, 1e30, (unsigned)pose_dim, rec, lm, 0, nullptr);
-    const int unroll = std::max(1, std::min(lm_unroll, max_iter));
-    for (int k = 0; k < unroll; ++k) {
-      launch_operator(stt, k, rec, lm, 0.0);
-      k_pcg_update<T, 1, IDENTITY><<<ublocks, TPB, 0, stream>>>((int)Nc, (int)Np, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, nullptr, 1, v_diag.p, 0.0, ui, MinvC.p, MinvP.p, stt, k, lm, g3_gather());
-      // past the unrolled iterations the loop must have left, unless max_iter itself ends it
-      k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, stt, k, tol, rej, (unsigned)pose_dim, rec, lm, (k == unroll - 1 && unroll < max_iter) ? 1 : 0, h_lm + 1);
-    }
-    k_apply_update_rho<T><<<rho_blocks, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), 1, cams.p, pts.p, cams_bak.p, pts_bak.p, x, scales.p, bu.p, 0.0, rho_partial.p, pack.p, rec, lm);
-    if (jac32) { k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
-    else { k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p, lm); }
-    k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
-                                                                                                    rho_partial.p, rho_blocks, nullptr, nullptr, 0, lm, pcg_iters.p, h_trace, h_trace + h_trace_cap, h_lm, h_lm + 1, nullptr, cam_fixed_p(), pt_fixed_p());
-  }
-  bool lm_graph_prepare(const gr_lm_options &opt) {
-    if (!lm_graph_enabled || comm || profiling || opt.early_stop || opt.stop_flag || opt.iterations < 2 || opt.pcg_max_iter < 1) return false;
-    if (opt.solver != GR_SOLVER_PCG && opt.solver != GR_SOLVER_PCG_IDENTITY) return false;
-    if (getenv("GR_LM_SPECULATE") && atoi(getenv("GR_LM_SPECULATE")) == 0) return false;
-    ensure_ctl(opt.pcg_max_iter);
-    ensure_point_records();
-    rho_blocks = cdiv(Nc, 28) + cdiv(3 * Np, TPB);
+  // ---- LM loop on the matrix-free PCG in its direction-kernel form: fused head, fused trial step ---------------------------
+  // One accepted LM iteration = k_finalize_bj (finalisation of the linearisation + block-Jacobi + PCG start + the accept
+  // decision about the PREVIOUS trial step), first direction, k x (operator, update, direction) — the direction launch that
+  // ends the PCG loop applies the trial step itself (ApplyOnExit) — and k_linearize at the trial point.  On an accept streak
+  // the head of iteration i + 1 (k_finalize_bj, first direction, first PCG iteration) is enqueued while k_linearize of
+  // iteration i is still running; the device takes the accept decision, the host only observes it (LmDev, LmDecide).
+  bool lm_fused = false;        // armed by lm() for GR_SOLVER_PCG / _IDENTITY without a communicator, PCG mode 0, max_iter >= 1
+  bool fin_pending = false;     // k_linearize ran, its finalisation is still to come (k_finalize_bj, or flush_finalize)
+  bool pcg_state_clean = false; // the PCG loop state has been cleared since the last solve (k_linearize's reset block)
+  int dir_grid() const { return std::max(grid_vec, cdiv(pose_dim, 252) + 1); }
+  ApplyOnExit<T> apply_args(int k, int max_iter) {
+    ApplyOnExit<T> ap;
+    if (!lm_fused) return ap;
+    rho_blocks = dir_grid();
     rho_partial.alloc(rho_blocks);
-    lmdev.alloc(1);
-    if (!h_lm) { void *q = nullptr; GR_HIP(hipHostMalloc(&q, 64, hipHostMallocCoherent | hipHostMallocMapped)); h_lm = static_cast<volatile int *>(q); }
-    LmGraphKey key;
-    if (opt.iterations + 2 > h_trace_cap) {
-      if (h_trace) (void)hipHostFree(const_cast<double *>(h_trace));
-      h_trace_cap = opt.iterations + 2;
-      void *q = nullptr;
-      GR_HIP(hipHostMalloc(&q, 2 * sizeof(double) * (size_t)h_trace_cap, hipHostMallocCoherent | hipHostMallocMapped));
-      h_trace = static_cast<volatile double *>(q);
-      lm_graph_release();
-    }
-    damping_identity = opt.use_identity != 0;
-    key.solver = opt.solver; key.max_iter = opt.pcg_max_iter; key.use_identity = opt.use_identity; key.jac32 = jac32 ? 1 : 0;
-    key.loss_kind = loss_kind; key.records = (use_records ? 1 : 0) | (tiled ? 4 : 0); key.cap = ctl_cap; key.tol = opt.pcg_tol; key.rej = opt.pcg_rejection_ratio;
-    key.loss_delta = (double)loss_delta; key.xp = xp.p; key.pinned = h_res;
-    const int mi = opt.pcg_max_iter; const double tl_ = opt.pcg_tol, rj_ = opt.pcg_rejection_ratio;
-    if (opt.solver == GR_SOLVER_PCG_IDENTITY) lm_enqueue_fn = [this, mi, tl_, rj_] { lm_graph_enqueue<true>(mi, tl_, rj_); };
-    else lm_enqueue_fn = [this, mi, tl_, rj_] { lm_graph_enqueue<false>(mi, tl_, rj_); };
-    if (lm_graph_mode == 2) return true; // no capture: the iteration is enqueued ahead with stream launches
-    if (lmg_exec && key == lmg_key) return true;
-    lm_graph_release();
-    if (!stream && !lmg_stream) GR_HIP(hipStreamCreate(&lmg_stream));
-    hipStream_t cap = stream ? stream : lmg_stream, saved = stream;
-    GR_HIP(hipStreamSynchronize(saved));
-    stream = cap;
-    hipGraph_t graph = nullptr;
-    GR_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-    if (opt.solver == GR_SOLVER_PCG_IDENTITY) lm_graph_enqueue<true>(opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio);
-    else lm_graph_enqueue<false>(opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio);
-    const hipError_t ce = hipStreamEndCapture(cap, &graph);
-    stream = saved;
-    if (ce != hipSuccess || !graph) { (void)hipGetLastError(); return false; }
-    const hipError_t ie = hipGraphInstantiate(&lmg_exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess) { lmg_exec = nullptr; (void)hipGetLastError(); return false; }
-    lmg_key = key;
-    return true;
+    ap.cams = cams.p; ap.pts = pts.p; ap.cams_bak = cams_bak.p; ap.pts_bak = pts_bak.p; ap.bu = bu.p;
+    ap.rho_partial = rho_partial.p; ap.pack = pack.p; ap.xp = (use_records && xp.n && xp_valid) ? xp.p : nullptr;
+    ap.cam_weight = 1; ap.at_cap = (k + 1 == max_iter) ? 1 : 0;
+    return ap;
   }
-  // replays up to `maxsteps` iterations; returns the number accepted on the device, `stop` = why it ended
-  int lm_graph_run(int maxsteps, T &mu, T &nu, T &chi2v, int &pcg_its, double *chi2_out, double *lambda_out, int &stop) {
-    hipStream_t q = (lm_graph_mode == 2) ? stream : (stream ? stream : lmg_stream);
-    LmDev init{};
-    init.mu = (double)mu; init.nu = (double)nu; init.chi2 = (double)chi2v;
-    GR_HIP(hipStreamSynchronize(stream));
-    GR_HIP(hipMemcpy(lmdev.p, &init, sizeof(LmDev), hipMemcpyHostToDevice));
-    h_lm[0] = 0; h_lm[1] = 0;
-    int launched = 0;
-    const int DEPTH = getenv("GR_LM_DEPTH") ? atoi(getenv("GR_LM_DEPTH")) : 3;
-    for (;;) {
-      const int done = __atomic_load_n(const_cast<const int *>(&h_lm[0]), __ATOMIC_ACQUIRE);
-      const int stp = __atomic_load_n(const_cast<const int *>(&h_lm[1]), __ATOMIC_ACQUIRE);
-      if (stp != 0 || done >= maxsteps) break;
-      if (launched < maxsteps && launched - done < DEPTH) {
-        if (lm_graph_mode == 2) lm_enqueue_fn(); else GR_HIP(hipGraphLaunch(lmg_exec, q));
-        ++launched;
-        continue;
-      }
-      if (launched >= maxsteps || launched - done >= DEPTH) {
-        // wait for progress (bounded: a wedged GPU must not hang the caller)
-        const auto t0 = std::chrono::steady_clock::now();
-        while (__atomic_load_n(const_cast<const int *>(&h_lm[0]), __ATOMIC_ACQUIRE) == done && __atomic_load_n(const_cast<const int *>(&h_lm[1]), __ATOMIC_ACQUIRE) == 0) {
-          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) throw std::runtime_error("graph-replayed LM iteration did not finish within 20 s");
-        }
-      }
+  void launch_direction(PcgState st, int k, double tol, double rej, T *x, T *rec, const LmDev *lm, double mu, int max_iter) {
+    Scope s3(this, "pcg_direction", 5.0 * n * sizeof(T), 3.0 * n);
+    k_pcg_direction<T><<<lm_fused ? dir_grid() : grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej, (unsigned)pose_dim, rec, lm, mu, apply_args(k, max_iter));
+  }
+  // k_linearize alone (LM loop, fused form): the finalisation follows in k_finalize_bj; its last workgroup clears the PCG loop state
+  void linearize_deferred(const int *gate) {
+    const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w();
+    Scope sc(this, "linearize", bytes, No * (250.0 + 48 + 117));
+    lin_reset = ctl_cap > 0;
+    launch_linearize_cam(false, g9.p, gate);
+    lin_reset = false;
+  }
+  // finalisation of a pending linearisation on its own (loop exit, last iteration): k_linearize_finalize
+  void flush_finalize(int spec_seq = 0) {
+    Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
+    k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
+                                                                                                       spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, spec_seq ? h_res : nullptr, h_seq, spec_seq, nullptr, cam_fixed_p(), pt_fixed_p());
+    fin_pending = false; hcp_valid = false;
+  }
+  // head of one LM iteration; dec.seq != 0: with the accept decision about the trial step just linearised (then every kernel
+  // of the head is gated on that decision and takes the damping from LmDev)
+  template <bool IDENTITY> void enqueue_head(LmDecide dec, double mu, bool use_identity, int max_iter, double tol, double rej, hipEvent_t ev_start) {
+    ensure_ctl(max_iter);
+    ensure_point_records();
+    flag_bank ^= 1; // the previous user of this bank is the solve before the last one: complete
+    for (int k = 0; k < max_iter + 1; ++k) flags()[k] = 0;
+    *h_iters() = 0;
+    damping = mu; damping_identity = use_identity;
+    T *rec = use_records ? xp.p : nullptr;
+    PcgState st = pcg_state();
+    st.x = v_dx.p; st.tol = tol; st.rej = rej;
+    if (!pcg_state_clean) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
+    pcg_state_clean = false;
+    const LmDev *lm = dec.seq ? lmdev.p : nullptr;
+    const int ui = use_identity ? 1 : 0;
+    {
+      const int nbc = cdiv(Nc, 28), nbp = std::max(1, std::min(cdiv(Np, TPB / FIN_PL), num_cu * 4));
+      Scope sc(this, "finalize_bj", 8.0 * No * w() + 54.0 * nseg * w() + (2 * 90.0 * Nc + 36.0 * Np + 27.0 * Nc) * w(), 9.0 * No + 54.0 * nseg + 900.0 * Nc + 60.0 * Np);
+      k_finalize_bj<T><<<nbc + nbp, TPB, 0, stream>>>((int)Nc, (int)Np, nbc, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bu.p, Hll.p, scales.p, mu, ui, MinvC.p, MinvP.p, v_diag.p, st,
+                                                      v_dx.p, v_r.p, v_z.p, IDENTITY ? 1 : 0, 1, dec, cam_fixed_p(), pt_fixed_p());
     }
-    GR_HIP(hipStreamSynchronize(q)); // the replays issued past a stop are no-ops
-    LmDev fin{};
-    GR_HIP(hipMemcpy(&fin, lmdev.p, sizeof(LmDev), hipMemcpyDeviceToHost));
-    const int steps = fin.step;
-    for (int sidx = 1; sidx <= steps; ++sidx) {
-      if (chi2_out) chi2_out[sidx] = h_trace[sidx];
-      if (lambda_out) lambda_out[sidx] = h_trace[h_trace_cap + sidx];
+    fin_pending = false; hcp_valid = false;
+    GR_HIP(hipEventRecord(ev_start, stream));
+    launch_direction(st, -1, 0.0, 1e30, v_dx.p, rec, lm, mu, max_iter);
+    if (max_iter > 0) {
+      { Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0); launch_operator(st, 0, rec, lm, mu); }
+      {
+        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
+        launch_update<1, IDENTITY>(update_blocks(), v_dx.p, nullptr, 1, ui, st, 0, -1, -1, lm);
+      }
+      launch_direction(st, 0, tol, rej, v_dx.p, rec, lm, mu, max_iter);
     }
-    mu = (T)fin.mu; nu = (T)fin.nu; chi2v = (T)fin.chi2;
-    pcg_its = fin.pcg_iters;
-    stop = fin.stop;
-    state_fresh_cap = -1;
-    return steps;
+  }
+  // iterations 1 ... of the solve whose head is in the stream; returns once the host has seen the loop leave
+  template <bool IDENTITY> void continue_pcg(int max_iter, double tol, double rej) {
+    T *rec = use_records ? xp.p : nullptr;
+    PcgState st = pcg_state();
+    st.x = v_dx.p; st.tol = tol; st.rej = rej;
+    const int ui = damping_identity ? 1 : 0;
+    auto enqueue = [&](int k) {
+      { Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0); launch_operator(st, k, rec, nullptr, damping); }
+      {
+        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
+        launch_update<1, IDENTITY>(update_blocks(), v_dx.p, nullptr, 1, ui, st, k);
+      }
+      launch_direction(st, k, tol, rej, v_dx.p, rec, nullptr, damping, max_iter);
+    };
+    note_noop({"pcg_operator", "pcg_update", "pcg_direction"}, run_pcg_iterations(max_iter, enqueue, /*pre_enqueued=*/1));
   }
 
+  // ---- optimizer::levenberg_marquardt (optimizer/levenberg_marquardt.hpp:110-242) -----
   void lm(const gr_lm_options &opt, gr_lm_stats &st, double *chi2_trace, double *lambda_trace) override {
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
@@ -1775,9 +1749,14 @@ template <typename T> struct Engine final : EngineBase {
     std::memset(&st, 0, sizeof(st));
     struct LmScope { // the fused PCG start (solver_set_damping) is only armed inside this loop
       Engine *e;
-      explicit LmScope(Engine *e_) : e(e_) { e->lm_x = e->v_dx.p; e->state_clean_cap = -1; e->update0_done = false; }
-      ~LmScope() { e->lm_x = nullptr; e->state_clean_cap = -1; e->update0_done = false; }
+      explicit LmScope(Engine *e_) : e(e_) { e->lm_x = e->v_dx.p; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; }
+      ~LmScope() { e->lm_x = nullptr; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; e->profiling = false; }
     } lm_scope(this);
+    struct EventPairs { // solve_seconds: events around every solve, read one iteration late, outside the decision -> launch path
+      hipEvent_t ev[3][2];
+      EventPairs() { for (auto &pr : ev) for (auto &e : pr) GR_HIP(hipEventCreate(&e)); }
+      ~EventPairs() { for (auto &pr : ev) for (auto &e : pr) (void)hipEventDestroy(e); }
+    } evp;
     T mu = (T)opt.initial_damping;
     T nu = 2;
     solver_update_structure(opt.solver);
@@ -1787,31 +1766,30 @@ template <typename T> struct Engine final : EngineBase {
     bool run = true;
     int accept_streak = 2; // consecutive accepted iterations (saturating): speculate only on a streak
     int num_bad = 0;       // levenberg_marquardt2 (:404-414): consecutive accepted iterations gaining < 0.1 %
-    const bool spec_enabled = !(getenv("GR_LM_SPECULATE") && atoi(getenv("GR_LM_SPECULATE")) == 0);
-    const bool ahead_enabled = !(getenv("GR_LM_AHEAD") && atoi(getenv("GR_LM_AHEAD")) == 0);
+    const bool spec_enabled = tune.lm_speculate != 0;
+    const bool ahead_enabled = tune.lm_ahead != 0;
     const int64_t coll0 = coll_count;
     if (chi2_trace) chi2_trace[0] = (double)chi2v;
     if (lambda_trace) lambda_trace[0] = (double)mu;
-    // solve_seconds: events around every solve, two pairs used alternately and READ one iteration late (after the next
-    // iteration's first kernel has been enqueued): the query sits outside the host's decision -> launch path
-    hipEvent_t ev_pair[2][2];
-    for (auto &pr : ev_pair) for (auto &e : pr) GR_HIP(hipEventCreate(&e));
-    int ev_cur = 0;
-    bool ev_pending = false;
+    const bool pcg_solver = opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY;
+    lm_fused = pcg_solver && !comm && pcg_mode() == 0 && opt.pcg_max_iter >= 1 && tune.lm_fused != 0;
+    if (lm_fused) { lmdev.alloc(1); ensure_ctl(opt.pcg_max_iter); pcg_state_clean = false; }
     auto collect_solve_time = [&](int which) {
       float ms = 0;
-      (void)hipEventSynchronize(ev_pair[which][1]);
-      (void)hipEventElapsedTime(&ms, ev_pair[which][0], ev_pair[which][1]);
+      (void)hipEventSynchronize(evp.ev[which][1]);
+      (void)hipEventElapsedTime(&ms, evp.ev[which][0], evp.ev[which][1]);
       st.solve_seconds += ms * 1e-3;
     };
-    const bool graph_mode = lm_graph_prepare(opt);
+    int ev_waiting = -1; // pair whose events are recorded and not yet read
     GR_HIP(hipStreamSynchronize(stream));
     st.setup_seconds = std::chrono::duration<double>(clk::now() - t0).count();
     auto tl = clk::now();
 
-    int ahead_hits = 0, ahead_misses = 0;
-    // accept / reject bookkeeping of one trial step (levenberg_marquardt.hpp:184-233); false = leave the loop
-    auto decide = [&](int i, bool solve_ok, bool speculate, int it, const double *hs) -> bool {
+    int ahead_hits = 0, ahead_misses = 0, head_hits = 0;
+    bool head_enqueued = false; // the head of the NEXT iteration is already in the stream (device-decided accept)
+    // accept / reject bookkeeping of one trial step (levenberg_marquardt.hpp:184-233); false = leave the loop.
+    // device: the decision k_finalize_bj took (and the kernels behind it follow): {new damping, accepted}
+    auto decide = [&](int i, bool solve_ok, bool speculate, int it, const double *hs, const double *device) -> bool {
       st.pcg_iterations += it;
       T new_chi2 = (T)hs[0];
       if (!solve_ok) new_chi2 = std::numeric_limits<T>::max();
@@ -1819,19 +1797,29 @@ template <typename T> struct Engine final : EngineBase {
       const T rho = (chi2v - new_chi2) / denom;
       const T initial_chi2 = chi2v;
       bool step_accepted = false;
-      if (solve_ok && std::isfinite(new_chi2) && rho > 0) {
+      const bool accept = device ? device[1] != 0.0 : (solve_ok && std::isfinite(new_chi2) && rho > 0);
+      if (accept) {
         step_accepted = true;
-        double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3);
-        alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
-        mu *= (T)alpha;
+        if (device) mu = (T)device[0]; // the same arithmetic, taken on the device
+        else {
+          double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3);
+          alpha = std::max(std::min(alpha, 2.0 / 3.0), 1.0 / 3.0);
+          mu *= (T)alpha;
+        }
         nu = 2;
-        if (!speculate) linearize_impl(want_hcp, /*pack_valid=*/true);
+        if (!speculate) {
+          if (lm_fused) { linearize_deferred(nullptr); fin_pending = true; pcg_state_clean = true; }
+          else linearize_impl(want_hcp, /*pack_valid=*/true);
+        }
         solver_update_values(opt.solver);
         st.accepted++;
         accept_streak = std::min(accept_streak + 1, 2);
       } else {
         revert();
-        if (speculate) linearize_impl(want_hcp, /*pack_valid=*/true); // restore H, b, scales of the kept point
+        if (speculate) { // restore H, b, scales of the kept point
+          if (lm_fused) { linearize_deferred(nullptr); fin_pending = true; pcg_state_clean = true; }
+          else linearize_impl(want_hcp, /*pack_valid=*/true);
+        } else if (lm_fused) pcg_state_clean = false; // the old linearisation stands, the loop state is spent
         accept_streak = 0;
         // the reference recomputes error + chi2 here (:199-201); every consumer below
         // recomputes residuals from the reverted vertices, so nothing is stale.
@@ -1855,9 +1843,10 @@ template <typename T> struct Engine final : EngineBase {
     // one host-driven iteration: solve, trial step, hand-shake, decision
     auto host_iteration = [&](int i) -> bool {
       solver_set_damping(opt.solver, (double)mu, opt.use_identity != 0);
-      hipEvent_t ev_a = ev_pair[ev_cur][0], ev_b = ev_pair[ev_cur][1];
+      const int pr = i % 3;
+      hipEvent_t ev_a = evp.ev[pr][0], ev_b = evp.ev[pr][1];
       GR_HIP(hipEventRecord(ev_a, stream));
-      if (ev_pending) collect_solve_time(ev_cur ^ 1); // the previous iteration's pair
+      if (ev_waiting >= 0) { collect_solve_time(ev_waiting); ev_waiting = -1; } // the previous iteration's pair
       const bool speculate = accept_streak >= 2 && spec_enabled;
       int seq = 0;
       // backup_parameters + apply_update + rho-denominator partials + the camera packs in one launch, then the
@@ -1866,14 +1855,13 @@ template <typename T> struct Engine final : EngineBase {
         GR_HIP(hipEventRecord(ev_b, stream));
         rho_blocks = cdiv(Nc, 28) + cdiv(3 * Np, TPB);
         rho_partial.alloc(rho_blocks);
-        const bool clear_state = ctl_cap > 0 && (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY);
+        const bool clear_state = ctl_cap > 0 && pcg_solver;
         k_apply_update_rho<T><<<rho_blocks + (clear_state ? 1 : 0), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, pack.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr,
                                                                                        nullptr, clear_state ? pcg_state() : PcgState{}, clear_state ? ctl_cap : 0, gate);
         seq = ++seq_counter;
         linearize_impl(want_hcp, /*pack_valid=*/true, seq, gate);
       };
-      const bool ahead = speculate && !comm && !profiling && ahead_enabled &&
-                         (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY);
+      const bool ahead = speculate && !comm && !profiling && ahead_enabled && pcg_solver;
       if (ahead) trial_hook = enqueue_trial;
       trial_done = false;
       const bool solve_ok = solver_solve_dev(opt.solver, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, v_dx.p);
@@ -1887,7 +1875,7 @@ template <typename T> struct Engine final : EngineBase {
       // sums are fixed-order).  After a rejection the plain chi2 pass is used.
       if (speculate) {
         if (!trial_ahead) enqueue_trial(nullptr);
-        if (ctl_cap > 0 && (opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY)) state_clean_cap = ctl_cap;
+        if (ctl_cap > 0 && pcg_solver) state_clean_cap = ctl_cap;
         if (!(use_records && xp.n && xp_valid)) xp_valid = false;
       } else {
         GR_HIP(hipEventRecord(ev_b, stream));
@@ -1897,54 +1885,90 @@ template <typename T> struct Engine final : EngineBase {
         seq = chi2_async(nullptr, v_dx.p, (double)mu);
       }
       wait_chi2(seq);
-      const int it = h_seq[1]; // every PCG variant mirrors its iteration count into pinned memory
+      const int it = *h_iters(); // every PCG variant mirrors its iteration count into pinned memory
       const double hs[2] = {h_res[0], h_res[1]};
-      ev_pending = true;
-      ev_cur ^= 1;
-      return decide(i, solve_ok, speculate, it, hs);
+      ev_waiting = pr;
+      return decide(i, solve_ok, speculate, it, hs, nullptr);
+    };
+    // the same iteration in the fused form (lm_fused)
+    auto fused_iteration = [&](int i) -> bool {
+      const int mi = opt.pcg_max_iter;
+      const bool ui = opt.use_identity != 0, ident = opt.solver == GR_SOLVER_PCG_IDENTITY;
+      const double tol = opt.pcg_tol, rej = opt.pcg_rejection_ratio;
+      last_solver = opt.solver;
+      const int pr = i % 3;
+      if (!head_enqueued) {
+        if (ident) enqueue_head<true>(LmDecide{}, (double)mu, ui, mi, tol, rej, evp.ev[pr][0]);
+        else enqueue_head<false>(LmDecide{}, (double)mu, ui, mi, tol, rej, evp.ev[pr][0]);
+      } else damping = (double)mu; // the head took it from LmDev; the iterations enqueued from here on get it as an argument
+      head_enqueued = false;
+      if (ev_waiting >= 0) { collect_solve_time(ev_waiting); ev_waiting = -1; }
+      const bool speculate = accept_streak >= 2 && spec_enabled;
+      auto enqueue_lin = [&](const int *gate) {
+        GR_HIP(hipEventRecord(evp.ev[pr][1], stream));
+        linearize_deferred(gate);
+      };
+      const bool ahead = speculate && ahead_enabled;
+      if (ahead) trial_hook = enqueue_lin;
+      trial_done = false;
+      if (ident) continue_pcg<true>(mi, tol, rej); else continue_pcg<false>(mi, tol, rej);
+      trial_hook = nullptr;
+      if (ahead) (trial_done ? ahead_hits : ahead_misses)++;
+      const int it = *h_iters(); // before the next head moves on to the other flag bank
+      if (!(use_records && xp.n && xp_valid)) xp_valid = false; // the step has been applied by the last direction launch
+      int seq = 0;
+      if (speculate) {
+        if (!(ahead && trial_done)) enqueue_lin(nullptr);
+        fin_pending = true; pcg_state_clean = true;
+        seq = ++seq_counter;
+        if (i + 1 < opt.iterations) {
+          LmDecide dec;
+          dec.seq = seq; dec.chi2_cur = (double)chi2v; dec.mu_cur = (double)mu;
+          dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_obs; dec.rho_partial = rho_partial.p; dec.n_rho = rho_blocks;
+          dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
+          if (ident) enqueue_head<true>(dec, (double)mu, ui, mi, tol, rej, evp.ev[(i + 1) % 3][0]);
+          else enqueue_head<false>(dec, (double)mu, ui, mi, tol, rej, evp.ev[(i + 1) % 3][0]);
+          head_enqueued = true;
+          ++head_hits;
+        } else flush_finalize(seq); // last iteration: only the decision is needed
+      } else {
+        GR_HIP(hipEventRecord(evp.ev[pr][1], stream));
+        seq = chi2_async(nullptr, v_dx.p, (double)mu); // the step itself was applied by the last direction launch
+      }
+      wait_chi2(seq);
+      const double hs[2] = {h_res[0], h_res[1]};
+      const double dev[2] = {h_res[2], h_res[3]};
+      ev_waiting = pr;
+      const bool go = decide(i, true, speculate, it, hs, head_enqueued ? dev : nullptr);
+      if (head_enqueued && dev[1] == 0.0) head_enqueued = false; // not accepted: the head returned at once
+      return go;
     };
 
-    int i = 0, g_steps = 0, g_stop1 = 0, g_stop2 = 0, g_runs = 0;
+    int i = 0;
     while (i < opt.iterations && run) {
-      if (graph_mode && accept_streak >= 2 && opt.iterations - i >= 2) {
-        int its = 0, stop = 0;
-        state_clean_cap = -1; update0_done = false; // the replayed iterations run their own solves on the loop state
-        const int steps = lm_graph_run(opt.iterations - i, mu, nu, chi2v, its, chi2_trace ? chi2_trace + i : nullptr, lambda_trace ? lambda_trace + i : nullptr, stop);
-        st.accepted += steps; st.iterations_run += steps; st.pcg_iterations += its;
-        i += steps;
-        g_steps += steps; (stop == 1 ? g_stop1 : stop == 2 ? g_stop2 : g_runs)++;
-        if (i >= opt.iterations) break;
-        if (stop == 2) {
-          // the device evaluated trial step i (speculative linearisation done) and did not accept it
-          double hs[2];
-          GR_HIP(hipMemcpy(hs, dscalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost));
-          int it = 0;
-          GR_HIP(hipMemcpy(&it, pcg_iters.p, sizeof(int), hipMemcpyDeviceToHost));
-          const bool go = decide(i, true, true, it, hs);
-          ++i;
-          if (!go) break;
-          continue;
-        }
-        // stop == 1: the PCG loop wants more than the unrolled iterations; nothing of step i was applied
-      }
-      const bool go = host_iteration(i);
+      const bool go = lm_fused ? fused_iteration(i) : host_iteration(i);
       ++i;
       if (!go) break;
       if (opt.stop_flag && *opt.stop_flag) break; // levenberg_marquardt.hpp:233-238: polled once per iteration
     }
+    if (head_enqueued) {
+      // the loop ends here but the head of the next iteration is already running: if its PCG loop ended inside the head,
+      // its last direction launch has applied a trial step nobody will judge — take it back
+      GR_HIP(hipStreamSynchronize(stream));
+      if (flags()[0] == 2 || opt.pcg_max_iter == 1) revert();
+      head_enqueued = false;
+    }
+    if (fin_pending) flush_finalize();
     GR_HIP(hipStreamSynchronize(stream));
     st.loop_seconds = std::chrono::duration<double>(clk::now() - tl).count();
-    if (ev_pending) collect_solve_time(ev_cur ^ 1);
+    if (ev_waiting >= 0) collect_solve_time(ev_waiting);
     st.ok = run ? 1 : 0;
     st.final_chi2 = (double)chi2v;
     st.collectives = coll_count - coll0;
     if (comm && comm->failed()) throw CommError("levenberg_marquardt: an all-reduce timed out waiting for a peer (IPC mailbox transport); the result is not valid");
-    if (getenv("GR_VERBOSE")) std::fprintf(stderr, "[graphite-mi355x] LM: trial step enqueued ahead of the PCG exit flag in %d iterations, not ahead in %d\n", ahead_hits, ahead_misses);
-    if (getenv("GR_VERBOSE") && graph_mode)
-      std::fprintf(stderr, "[graphite-mi355x] LM: %d of %d iterations replayed as graphs; handed back: %d (PCG iterations), %d (not accepted)\n", g_steps, st.iterations_run, g_stop1, g_stop2);
-    for (auto &pr : ev_pair) for (auto &e : pr) (void)hipEventDestroy(e);
+    if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] LM: %s; trial linearisation enqueued ahead of the PCG exit flag in %d iterations, not ahead in %d; next head enqueued behind the trial step in %d\n",
+                                   lm_fused ? "fused head / trial step" : "host loop", ahead_hits, ahead_misses, head_hits);
     if (profiling) flush_prof();
-    profiling = false;
   }
 };
 
@@ -2081,6 +2105,15 @@ gr_status gr_bal_destroy(gr_bal_problem *p) {
   (void)hipSetDevice(p->e->device);
   delete p;
   return GR_OK;
+}
+void gr_bal_tuning_default(gr_bal_tuning *t) { if (t) tuning_default(*t); }
+gr_status gr_bal_set_tuning(gr_bal_problem *p, const gr_bal_tuning *t) {
+  if (!t) { g_last_error = "null tuning"; return GR_ERR_INVALID; }
+  return guarded(p, [&] { p->e->tune = *t; p->e->tune.grid_mult = std::max(1, t->grid_mult); p->e->tune.vec_per_thread = std::max(1, t->vec_per_thread); p->e->apply_tuning(); });
+}
+gr_status gr_bal_get_tuning(gr_bal_problem *p, gr_bal_tuning *t) {
+  if (!t) { g_last_error = "null tuning"; return GR_ERR_INVALID; }
+  return guarded(p, [&] { *t = p->e->tune; });
 }
 gr_status gr_bal_set_loss(gr_bal_problem *p, gr_loss kind, double delta) { return guarded(p, [&] { p->e->set_loss(kind, delta); }); }
 gr_status gr_bal_set_scale_system(gr_bal_problem *p, int enable) { return guarded(p, [&] { p->e->set_scale_system(enable != 0); }); }

@@ -34,16 +34,15 @@ template <typename T> struct Vec2T;
 template <> struct Vec2T<float> { using type = float2; };
 template <> struct Vec2T<double> { using type = double2; };
 
-// Device-resident Levenberg-Marquardt state of the graph-replayed LM iteration (Engine::lm_graph): the
-// kernels of one iteration read the damping from here and return at once when `stop` is set, so the
-// host can replay the captured iteration back to back without a round trip; the finalize kernel takes
-// the accept decision (optimizer/levenberg_marquardt.hpp:184-197) and everything else is handed
-// back to the host loop.
+// Device-side hand-over of the LM accept decision.  On an accept streak the host enqueues the FIRST kernels of iteration
+// i + 1 (k_finalize_bj, first direction, first PCG iteration) while the trial linearisation of iteration i is still running,
+// i.e. before anybody knows whether step i is accepted.  k_finalize_bj takes that decision on the device
+// (optimizer/levenberg_marquardt.hpp:184-197), leaves the new damping here and sets `stop` when the step is not accepted;
+// the kernels that follow it read the damping from here and return at once when `stop` is set.  The host only OBSERVES the
+// decision (pinned memory) and runs the rejection path itself.
 struct LmDev {
-  double mu, nu, chi2;
-  int stop;      // 0 run | 1 the PCG loop needs more than the unrolled iterations | 2 the step was not accepted
-  int step;      // accepted steps completed in graph mode
-  int pcg_iters; // their inner iterations
+  double mu;
+  int stop; // 0 run | 2 the step was not accepted
   int pad;
 };
 

@@ -200,6 +200,246 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LM loop, matrix-free PCG: ONE launch between the linearisation kernel and the first PCG iteration.
+//   (1) optional: the accept decision of the trial step this linearisation evaluated (levenberg_marquardt.hpp:184-197) —
+//       every workgroup sums the chi2 / rho-denominator block partials in the same fixed order, derives rho and the new
+//       damping in T like the host loop, and returns at once when the step is not accepted; workgroup 0 publishes
+//       (chi2, denominator, new damping, accepted) to pinned host memory and to LmDev for the kernels enqueued behind it;
+//   (2) k_linearize_finalize: fixed-order sums of the (wave, camera) segment partials -> Hcc^u, bc^u, camera scales; per
+//       point the sums of its observations' records -> Hll^u, bl^u, point scales (graph.hpp:254-270);
+//   (3) k_block_jacobi: damped, scaled diagonal blocks inverted (block_jacobi.hpp:120-172), clamped diagonal;
+//   (4) the PCG start r = s .* b^u, x = 0, z' = Minv r and record 0 of the dots (pcg.hpp:108-127).
+// The blocks (2) writes and (3) re-reads never leave the registers; (2) + (3) were 16 + 18 us as two launches on
+// Ladybug-1723.  Cameras: one lane per COLUMN of a camera's 9 x 9 block (7 cameras per wave, 28 per workgroup): the
+// Gauss-Jordan inverse runs across the 9 lanes with row broadcasts instead of serially in one thread (same operations per
+// entry, same order: same bits as spd_inverse<9>).  Points: FIN_PL lanes per point as in k_linearize_finalize.
+struct LmDecide {
+  int seq = 0;                                  // != 0: decide; the value published to hres_seq
+  double chi2_cur = 0, mu_cur = 0;              // chi2 and damping of the iteration whose trial step is being judged
+  const double *chi2_partial = nullptr; int n_chi2 = 0;
+  const double *rho_partial = nullptr; int n_rho = 0;
+  volatile double *hres = nullptr;              // pinned: [0] trial chi2, [1] rho denominator, [2] new damping, [3] accepted
+  volatile int *hres_seq = nullptr;
+  LmDev *lm = nullptr;
+  double *dscal = nullptr;                      // device copy of [0], [1]
+};
+template <typename T>
+__global__ void __launch_bounds__(TPB)
+k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__ cam_seg_ptr, const T *__restrict__ cam_partial,
+              const int *__restrict__ pt_ptr, const T *__restrict__ g9, T *__restrict__ Hcc, T *__restrict__ bu,
+              T *__restrict__ Hll, T *__restrict__ scales, double mu, int use_identity, T *__restrict__ MinvC,
+              T *__restrict__ MinvP, T *__restrict__ diag_clamped, PcgState st, T *__restrict__ x, T *__restrict__ r,
+              T *__restrict__ zt, int identity_precond, int cam_weight, LmDecide dec,
+              const unsigned char *__restrict__ cam_fixed, const unsigned char *__restrict__ pt_fixed) {
+  __shared__ double red[4];
+  __shared__ double s_dec[2];
+  __shared__ double sA[4][7 * 81];
+  if (dec.seq) {
+    double cs = 0, rs = 0;
+    for (int i = threadIdx.x; i < dec.n_chi2; i += TPB) cs += dec.chi2_partial[i];
+    cs = block_sum_256(cs, red);
+    for (int i = threadIdx.x; i < dec.n_rho; i += TPB) rs += dec.rho_partial[i];
+    rs = block_sum_256(rs, red);
+    if (threadIdx.x == 0) {
+      const T chi2v = (T)dec.chi2_cur, new_chi2 = (T)cs;
+      const T denom = (T)rs + (T)1.0e-3;
+      const T rho = (chi2v - new_chi2) / denom;
+      const bool ok = isfinite((double)new_chi2) && rho > T(0);
+      double alpha = 1.0 - pow(2.0 * (double)rho - 1.0, 3.0);
+      alpha = fmax(fmin(alpha, 2.0 / 3.0), 1.0 / 3.0);
+      const T mun = (T)dec.mu_cur * (T)alpha;
+      s_dec[0] = ok ? 1.0 : 0.0; s_dec[1] = (double)mun;
+      if (blockIdx.x == 0) {
+        dec.lm->mu = (double)mun; dec.lm->stop = ok ? 0 : 2;
+        if (dec.dscal) { dec.dscal[0] = cs; dec.dscal[1] = rs; }
+        dec.hres[0] = cs; dec.hres[1] = rs; dec.hres[2] = (double)mun; dec.hres[3] = ok ? 1.0 : 0.0;
+        __threadfence_system();
+        *dec.hres_seq = dec.seq;
+      }
+    }
+    __syncthreads();
+    if (s_dec[0] == 0.0) return;
+    mu = s_dec[1];
+  }
+  const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0 && st.left) *st.left = 0; // a new loop starts
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double prr = 0, prz = 0, pzz = 0;
+  if (b < nbc) {
+    const int g = lane / 9, j = lane - 9 * g;
+    const int c = (b * 4 + wave) * 7 + g;
+    const bool on = g < 7 && c < Nc;
+    const int base = g < 7 ? 9 * g : 54; // lane 63 idles on group 6's lanes
+    T a[9], bj = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = T(0);
+    bool fixed = false;
+    if (on) {
+      int idx[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { const int lo = i < j ? i : j, hi = i < j ? j : i; idx[i] = hi * (hi + 1) / 2 + lo; }
+      for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) {
+        const T *cp = cam_partial + 54 * (size_t)sg;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] += cp[idx[i]];
+        bj += cp[45 + j];
+      }
+      fixed = cam_fixed && cam_fixed[c];
+      if (fixed) {
+        bj = T(0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] = T(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Hcc[81 * (size_t)c + i + 9 * j] = a[i];
+      bu[9 * (size_t)c + j] = bj;
+    }
+    T ajj = a[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) ajj = (i == j) ? a[i] : ajj;
+    const T sj = (on && scale_system && !fixed) ? (T)(1.0 / (DBL_EPSILON + sqrt((double)ajj))) : T(1);
+    if (on) scales[9 * (size_t)c + j] = sj;
+    // damped, scaled block: column j of A in this lane
+    double A[9];
+    T dclj = T(1);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const T si = __shfl(sj, base + i, 64);
+      const T v = si * a[i] * sj;
+      if (i == j) { A[i] = (double)damp_diag(v, mu, use_identity); dclj = (T)clampd((double)v, 1.0e-6, 1.0e32); }
+      else A[i] = (double)v;
+    }
+    if (!on) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) A[i] = (i == j) ? 1.0 : 0.0; // idle lanes invert an identity
+    }
+    if (on) diag_clamped[9 * (size_t)c + j] = dclj;
+    // in-place Gauss-Jordan without pivoting (spd_inverse), entry (r, c) in lane c: per step the pivot and the pivot
+    // column come from lane k of the group
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      double f[9];
+#pragma unroll
+      for (int rr_ = 0; rr_ < 9; ++rr_) f[rr_] = __shfl(A[rr_], base + k, 64);
+      const double piv = 1.0 / f[k];
+      A[k] = (j == k) ? piv : A[k] * piv;
+#pragma unroll
+      for (int rr_ = 0; rr_ < 9; ++rr_) {
+        if (rr_ == k) continue;
+        A[rr_] = (j == k) ? -f[rr_] * piv : A[rr_] - f[rr_] * A[k];
+      }
+    }
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) MinvC[81 * (size_t)c + i + 9 * j] = (T)A[i];
+    }
+    // z' = Minv r needs ROW j of the inverse in lane j: through LDS
+    if (g < 7) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sA[wave][81 * g + i + 9 * j] = A[i];
+    }
+    __syncthreads();
+    const T rvj = sj * bj;
+    T zj = T(0);
+    if (identity_precond) zj = rvj;
+    else {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const T rq = __shfl(rvj, base + q, 64);
+        if (g < 7) zj += (T)sA[wave][81 * g + j + 9 * q] * rq;
+      }
+    }
+    if (on) {
+      const size_t t = 9 * (size_t)c + j;
+      x[t] = T(0); r[t] = rvj; zt[t] = zj;
+      if (st.lazy) static_cast<T *>(st.zs)[t] = sj * zj;
+      const T d = use_identity ? T(1) : dclj;
+      if (cam_weight) { prr = (double)(rvj * rvj); prz = (double)(rvj * zj); pzz = (double)(d * zj * zj); }
+    }
+  } else {
+    // point tiles of TPB / FIN_PL points, dealt round-robin to the point workgroups
+    using V2 = typename Vec2T<T>::type;
+    constexpr int PPB = TPB / FIN_PL;
+    const int ntile = (Np + PPB - 1) / PPB;
+    const unsigned jl = threadIdx.x % FIN_PL;
+    for (int tile = b - nbc; tile < ntile; tile += gridDim.x - nbc) {
+      const int l = tile * PPB + (int)(threadIdx.x / FIN_PL);
+      const bool on = l < Np;
+      T v[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v[i] = T(0);
+      if (on) {
+        for (int a = pt_ptr[l] + (int)jl; a < pt_ptr[l + 1]; a += FIN_PL) {
+          const V2 *gq = reinterpret_cast<const V2 *>(g9 + 8 * (size_t)a);
+          const V2 c0 = gq[0], c1 = gq[1], c2 = gq[2], e = gq[3]; // sqrt(w) Jp columns, sqrt(w) e
+          v[0] += c0.x * c0.x + c0.y * c0.y;
+          v[1] += c0.x * c1.x + c0.y * c1.y;
+          v[2] += c0.x * c2.x + c0.y * c2.y;
+          v[3] += c1.x * c1.x + c1.y * c1.y;
+          v[4] += c1.x * c2.x + c1.y * c2.y;
+          v[5] += c2.x * c2.x + c2.y * c2.y;
+          v[6] -= c0.x * e.x + c0.y * e.y;
+          v[7] -= c1.x * e.x + c1.y * e.y;
+          v[8] -= c2.x * e.x + c2.y * e.y;
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < FIN_PL; o <<= 1)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v[i] += __shfl_xor(v[i], o, 64);
+      if (!on) continue;
+      const bool pfixed = pt_fixed && pt_fixed[l];
+      if (pfixed) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v[i] = T(0);
+      }
+      const bool sc_on = scale_system && !pfixed;
+      const T s0 = sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[0]))) : T(1);
+      const T s1 = sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1);
+      const T s2 = sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1);
+      const T H[9] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5]};
+      const T sv[3] = {s0, s1, s2};
+      double A[9];
+      T dcl[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rw = 0; rw < 3; ++rw) {
+          const T q = sv[rw] * H[rw + 3 * c] * sv[c];
+          if (rw == c) { A[rw + 3 * c] = (double)damp_diag(q, mu, use_identity); dcl[rw] = (T)clampd((double)q, 1.0e-6, 1.0e32); }
+          else A[rw + 3 * c] = (double)q;
+        }
+      spd_inverse<3>(A);
+      const T rv[3] = {s0 * v[6], s1 * v[7], s2 * v[8]};
+      T z[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) z[i] = identity_precond ? rv[i] : (T)A[i] * rv[0] + (T)A[i + 3] * rv[1] + (T)A[i + 6] * rv[2];
+      // outputs, FIN_PL lanes wide: lane jl stores entries jl, jl + FIN_PL, ... of the 3 x 3 blocks and entry jl of the 3-vectors
+      const size_t t0 = 9 * (size_t)Nc + 3 * (size_t)l;
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+        if ((unsigned)i % FIN_PL == jl) { Hll[9 * (size_t)l + i] = H[i]; MinvP[9 * (size_t)l + i] = (T)A[i]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if ((unsigned)i % FIN_PL == jl) {
+          bu[t0 + i] = v[6 + i]; scales[t0 + i] = sv[i]; diag_clamped[t0 + i] = dcl[i];
+          x[t0 + i] = T(0); r[t0 + i] = rv[i]; zt[t0 + i] = z[i];
+          if (st.lazy) static_cast<T *>(st.zs)[t0 + i] = sv[i] * z[i];
+        }
+      if (jl == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const T d = use_identity ? T(1) : dcl[i];
+          prr += (double)(rv[i] * rv[i]); prz += (double)(rv[i] * z[i]); pzz += (double)(d * z[i] * z[i]);
+        }
+      }
+    }
+  }
+  prr = wave_sum(prr); prz = wave_sum(prz); pzz = wave_sum(pzz);
+  if (lane == 0) { slot_add(st.slots(0, RR), 0, prr); slot_add(st.slots(0, RZP), 0, prz); slot_add(st.slots(0, ZDZ), 0, pzz); }
+}
+
 // Graph::backup_parameters + Graph::apply_update (graph.hpp:292-309, ops/update.hpp:11-31) over cameras and
 // points in one pass, plus this block's share of the compute_rho denominator sum dx (mu dx + b)
 // (levenberg_marquardt.hpp:34-41) while dx and the scales are in registers anyway, plus the camera packs of
@@ -363,9 +603,18 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
             const int *__restrict__ gate = nullptr,
             // fixed vertices (WRITE_HCP only): the camera-point block of an observation whose camera or point is fixed is zero
             // (the reference computes no Jacobian block for a fixed vertex, ops/linearize.hpp:24)
-            const unsigned char *__restrict__ cam_fixed = nullptr, const unsigned char *__restrict__ pt_fixed = nullptr) {
+            const unsigned char *__restrict__ cam_fixed = nullptr, const unsigned char *__restrict__ pt_fixed = nullptr,
+            // LM loop: the PCG loop state of the solve whose step this linearisation evaluates is spent (every kernel that
+            // reads it precedes this launch); the last workgroup clears it, so the next k_finalize_bj / k_block_jacobi
+            // starts the next loop itself
+            PcgState rst = PcgState{}, int rst_cap = 0) {
   if (lm && lm->stop) return;
   if (gate && !*gate) return;
+  if (rst_cap > 0 && blockIdx.x == gridDim.x - 1) {
+    for (int i = threadIdx.x; i < rst_cap * NSLOT * NS; i += TPB) rst.acc[slot_word(i)] = 0.0;
+    for (int i = threadIdx.x; i < rst_cap; i += TPB) { rst.done[i] = 0; rst.pdp[i] = 0.0; rst.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
+    if (threadIdx.x == 0) rst.iters[0] = 0;
+  }
   __shared__ double red[4];
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
@@ -472,13 +721,9 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
                      const double *__restrict__ chi2_partial, double *__restrict__ chi2_out,
                      const double *__restrict__ rho_partial = nullptr, int n_rho = 0,
                      volatile double *hres = nullptr, volatile int *hres_seq = nullptr, int seq = 0,
-                     LmDev *__restrict__ lm = nullptr, const int *__restrict__ pcg_iters = nullptr,
-                     volatile double *h_chi2_trace = nullptr, volatile double *h_lambda_trace = nullptr,
-                     volatile int *h_steps = nullptr, volatile int *h_stop = nullptr,
                      const int *__restrict__ gate = nullptr,
                      // fixed vertices: no Jacobian block (ops/linearize.hpp:24) -> zero Hessian block, zero gradient, scale 1
                      const unsigned char *__restrict__ cam_fixed = nullptr, const unsigned char *__restrict__ pt_fixed = nullptr) {
-  if (lm && lm->stop) return;
   if (gate && !*gate) return;
   const unsigned t = blockIdx.x * TPB + threadIdx.x;
   const unsigned ncam = 90u * (unsigned)Nc, ncam_pad = (ncam + TPB - 1) / TPB * TPB;
@@ -571,29 +816,7 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
     if (threadIdx.x == 0) {
       chi2_out[0] = s;
       if (rho_partial) chi2_out[1] = r;
-      if (lm) {
-        // graph mode: the accept decision of optimizer/levenberg_marquardt.hpp:184-197, in T like the host loop;
-        // anything but a plain acceptance is handed back to the host (stop = 2)
-        const T chi2v = (T)lm->chi2, new_chi2 = (T)s;
-        const T denom = (T)r + (T)1.0e-3;
-        const T rho = (chi2v - new_chi2) / denom;
-        if (isfinite((double)new_chi2) && rho > T(0)) {
-          double alpha = 1.0 - pow(2.0 * (double)rho - 1.0, 3.0);
-          alpha = fmax(fmin(alpha, 2.0 / 3.0), 1.0 / 3.0);
-          const T mu = (T)lm->mu * (T)alpha;
-          const int step = lm->step + 1;
-          lm->mu = (double)mu; lm->nu = 2.0; lm->chi2 = (double)new_chi2; lm->step = step;
-          lm->pcg_iters += pcg_iters[0];
-          h_chi2_trace[step] = (double)new_chi2;
-          h_lambda_trace[step] = (double)mu;
-          __threadfence_system();
-          *h_steps = step;
-        } else {
-          lm->stop = 2;
-          __threadfence_system();
-          *h_stop = 2;
-        }
-      } else if (hres) {
+      if (hres) {
         hres[0] = s; hres[1] = r;
         __threadfence_system();
         *hres_seq = seq;
@@ -1192,17 +1415,76 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
   }
 }
 
+// Trial step fused into the direction kernel that ENDS the PCG loop (LM loop, direction-kernel form): once every workgroup
+// has found that the loop is over (tolerance, rejection, r.z == 0, or the iteration cap: at_cap), x is final and the launch
+// turns into Graph::backup_parameters + Graph::apply_update (graph.hpp:292-309, ops/update.hpp:11-31) + this block's share of
+// the compute_rho denominator sum dx (mu dx + b) (levenberg_marquardt.hpp:34-41) + the camera packs of the moved cameras —
+// the work of k_apply_update_rho without its launch.  Workgroups [0, nct) take 28 cameras each, the others the point scalars.
+template <typename T> struct ApplyOnExit {
+  T *cams = nullptr, *pts = nullptr, *cams_bak = nullptr, *pts_bak = nullptr;
+  const T *bu = nullptr;
+  double *rho_partial = nullptr; // [gridDim.x]
+  T *pack = nullptr, *xp = nullptr;
+  int cam_weight = 1, at_cap = 0;
+};
+template <typename T>
+__device__ __forceinline__ void apply_on_exit(const ApplyOnExit<T> &ap, unsigned n, unsigned pose_dim, const T *__restrict__ dx,
+                                              const T *__restrict__ scales, double mu, T *__restrict__ x_restore) {
+  __shared__ double red[4];
+  __shared__ T cs[252];
+  double rho = 0;
+  const unsigned nct = (pose_dim + 251u) / 252u;
+  if (blockIdx.x < nct) {
+    const unsigned i = blockIdx.x * 252u + threadIdx.x;
+    if (threadIdx.x < 252 && i < pose_dim) {
+      const T d = dx[i], s = scales[i], xo = ap.cams[i];
+      if (x_restore) x_restore[i] = d;
+      ap.cams_bak[i] = xo;
+      const T xn = xo + d * s;
+      ap.cams[i] = xn;
+      cs[threadIdx.x] = xn;
+      if (ap.cam_weight) rho = (double)(d * ((T)mu * d + s * ap.bu[i]));
+    }
+    __syncthreads();
+    const unsigned c = blockIdx.x * 28u + threadIdx.x;
+    if (threadIdx.x < 28 && 9u * c < pose_dim) {
+      T cam[9], pk[PACK];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cam[k] = cs[9 * threadIdx.x + k];
+      make_campack(cam, pk);
+#pragma unroll
+      for (int k = 0; k < PACK; ++k) ap.pack[PACK * (size_t)c + k] = pk[k];
+    }
+  } else {
+    const unsigned npt = n - pose_dim, stride = (gridDim.x - nct) * TPB;
+    for (unsigned q = (blockIdx.x - nct) * TPB + threadIdx.x; q < npt; q += stride) {
+      const unsigned i = pose_dim + q;
+      const T d = dx[i], s = scales[i], xo = ap.pts[q];
+      if (x_restore) x_restore[i] = d;
+      ap.pts_bak[q] = xo;
+      const T xn = xo + d * s;
+      ap.pts[q] = xn;
+      if (ap.xp) ap.xp[8 * (size_t)(q / 3u) + q % 3u] = xn; // operator's point records
+      rho += (double)(d * ((T)mu * d + s * ap.bu[i]));
+    }
+  }
+  rho = block_sum_256(rho, red);
+  if (threadIdx.x == 0) ap.rho_partial[blockIdx.x] = rho;
+}
+
 // Direction kernel (pcg.hpp:108-127 for k = -1, :184-217 otherwise): rejection test, restore x
 // on a rejected step, else p = beta p + z'/||r||; ps = s .* p.  Thread 0 publishes the loop state
 // of iteration k+1 (device) and the host flag of iteration k;  p.D.p of the new direction follows
 // from the dots the update kernel took:  pdp' = beta^2 pdp + 2 beta sigma p.D.z' + sigma^2 z'.D.z'.
+// ap.cams != nullptr (LM loop): the launch that ends the loop applies the step (ApplyOnExit); gridDim.x must then exceed
+// the number of camera tiles.
 template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__restrict__ p,
                 T *__restrict__ ps, const T *__restrict__ zt, const T *__restrict__ scales, PcgState st,
                 int k, double tol, double rejection_ratio, unsigned pose_dim = 0, T *__restrict__ xp = nullptr,
-                LmDev *__restrict__ lm = nullptr, int last_unrolled = 0, volatile int *h_stop = nullptr) {
-  if (lm && lm->stop) return;
+                const LmDev *__restrict__ lm = nullptr, double mu = 0.0, ApplyOnExit<T> ap = ApplyOnExit<T>{}) {
+  if (lm) { if (lm->stop) return; mu = lm->mu; }
   const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
   T beta = 0, scale = 0;
   if (k < 0) {
@@ -1211,11 +1493,13 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
     if (first) st.pdp[0] = (double)scale * (double)scale * zdz;
   } else {
     const double rz0 = st.rz0[k];
-    bool leave = st.done[k] != 0;
+    const bool was_done = st.done[k] != 0; // an earlier direction launch ended the loop (and applied the step)
+    bool leave = was_done;
     PcgIter it{};
     if (!leave) { it = pcg_iter(st, k); leave = (it.rzp == 0.0); }
     if (leave) {
       if (first) { st.done[k + 1] = 1; st.rz0[k + 1] = rz0; if (st.left) *st.left = 1; st.hflag[k] = 2; __threadfence_system(); }
+      if (ap.cams && !was_done) apply_on_exit<T>(ap, n, pose_dim, x, scales, mu, nullptr); // r.z == 0: x is final
       return;
     }
     const PcgIter nx = pcg_iter(st, k + 1);
@@ -1227,23 +1511,25 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
     scale = (T)(double)(T)nx.rscale;
     if (first) {
       st.rz0[k + 1] = reject ? rz0 : fmin(rz0, fabs((double)rz_new));
-      st.done[k + 1] = done_next ? 1 : 0;
+      st.done[k + 1] = (done_next || ap.at_cap) ? 1 : 0;
       st.pdp[k + 1] = (double)beta * (double)beta * st.pdp[k] + 2.0 * (double)beta * (double)scale * pdz + (double)scale * (double)scale * zdz;
       st.iters[0] = k + 1;
       *st.hiters = k + 1;
-      if (done_next && st.left) *st.left = 1;
+      if ((done_next || ap.at_cap) && st.left) *st.left = 1;
       st.hflag[k] = done_next ? 2 : 1;
-      if (lm && last_unrolled && !done_next) { lm->stop = 1; if (h_stop) *h_stop = 1; } // graph mode: the host takes this step over
       __threadfence_system();
+    }
+    if (ap.cams && (done_next || ap.at_cap)) { // the loop ends here: the step is x (the backup on a rejected iteration)
+      apply_on_exit<T>(ap, n, pose_dim, reject ? xb : x, scales, mu, reject ? x : nullptr);
+      return;
     }
     if (reject) {
       for (unsigned t = blockIdx.x * TPB + threadIdx.x; t < n; t += gridDim.x * TPB) x[t] = xb[t];
       return;
     }
     // the loop has ended: nobody reads the next direction (Ladybug-1723 bench line 5 090 -> 5 250 LM it/s: with the
-    // reference's tolerance most solves end after 1-2 iterations, so this was every second direction launch).  The
-    // graph-replay mode keeps its fixed kernel sequence as it was.
-    if (done_next && !lm) return;
+    // reference's tolerance most solves end after 1-2 iterations, so this was every second direction launch)
+    if (done_next) return;
   }
   for (unsigned t = blockIdx.x * TPB + threadIdx.x; t < n; t += gridDim.x * TPB) {
     const T pn = (k < 0) ? scale * zt[t] : beta * p[t] + scale * zt[t];

@@ -102,6 +102,32 @@ typedef struct {
                                the LM loop by this rank; 0 without a communicator */
 } gr_lm_stats;
 
+/* Tuning of one problem handle.  The reference configures through option structs only (LevenbergMarquardtOptions,
+ * optimizer/levenberg_marquardt.hpp:52-98; cudssSolverOptions, solver/cudss.hpp:12-31) and so does this library: every
+ * choice that changes WHICH kernels run lives here (results are the same whatever is chosen: the parity suite runs the
+ * combinations).  -1 = decide per problem (the default; the timed choices are made once, at solver_update_structure).
+ * gr_bal_tuning_default fills the defaults and then applies the GR_* environment variables named below — a debugging
+ * override read ONCE, when a problem is created or gr_bal_tuning_default is called, never inside a solve. */
+typedef struct {
+  int32_t point_tiles;          /* GR_PTILES        -1 auto | 0 plain camera-major order | K point tiles (Engine::build_tiled_order) */
+  int32_t g3_gather;            /* GR_G3_GATHER     -1 auto (with point tiles) | 0 | 1: operator output in observation order         */
+  int32_t point_records;        /* GR_POINT_RECORDS -1 auto (timed) | 0 | 1: [X Y Z | s.p] records for the operator's gathers        */
+  int32_t pcg_lazy;             /* GR_PCG_LAZY      -1 auto (vectors <= 1 MB) | 0 | 1: no direction kernel                           */
+  int32_t pcg_single_reduction; /* GR_PCG_CG        -1 auto (with a communicator of > 1 rank) | 0 | 1                                */
+  int32_t sparse_cholesky;      /* GR_SPARSE_CHOL   -1 auto (when the camera graph dissects) | 0 dense tile Cholesky | 1             */
+  int32_t spchol_overlap;       /* GR_SPCHOL_OVERLAP 1: forward substitution beside the factorisation                               */
+  int32_t lm_speculate;         /* GR_LM_SPECULATE   1: trial chi2 from a speculative linearisation on accept streaks                */
+  int32_t lm_ahead;             /* GR_LM_AHEAD       1: trial linearisation enqueued ahead of the PCG exit flag                      */
+  int32_t lm_fused;             /* GR_LM_FUSED       1: fused iteration head (k_finalize_bj), trial step inside the last direction   */
+  int32_t grid_mult;            /* GR_GRID_MULT      4: workgroups per CU of the persistent per-observation kernels                 */
+  int32_t vec_per_thread;       /* GR_VEC_PER_THREAD 2: elements per thread of the light vector kernels                             */
+  int32_t schur_item;           /* GR_SCHUR_ITEM     56: products per work item of the explicit Schur reduction                     */
+  int32_t verbose;              /* GR_VERBOSE        0: report the per-problem choices on stderr                                    */
+  int32_t ipc_timeout_ms;       /* GR_IPC_TIMEOUT_MS 30000: bound of one IPC-mailbox all-reduce wait (gr_bal_comm_init_ipc)         */
+  int32_t reserved[5];
+} gr_bal_tuning;
+void gr_bal_tuning_default(gr_bal_tuning *t);
+
 const char *gr_version(void);
 const char *gr_last_error_string(void);
 /* number of visible HIP devices (0 if none); never initialises a device */
@@ -126,6 +152,10 @@ gr_status gr_bal_create_shard(gr_bal_problem **out, gr_dtype dtype, int64_t num_
                               const void *points, const void *observations, const int32_t *cam_idx,
                               const int32_t *pt_idx, int device, void *stream);
 gr_status gr_bal_destroy(gr_bal_problem *p);
+/* replace / read the tuning of a problem (created with gr_bal_tuning_default's values).  Set it before
+ * gr_bal_solver_update_structure / gr_bal_levenberg_marquardt; choices already timed are re-made. */
+gr_status gr_bal_set_tuning(gr_bal_problem *p, const gr_bal_tuning *t);
+gr_status gr_bal_get_tuning(gr_bal_problem *p, gr_bal_tuning *t);
 
 /* FactorDescriptor::add_factor loss argument (factor.hpp:373-412), one loss for all factors */
 gr_status gr_bal_set_loss(gr_bal_problem *p, gr_loss kind, double delta);

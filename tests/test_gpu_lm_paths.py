@@ -1,5 +1,6 @@
-"""The LM host loop's shortcuts do not change the optimisation: speculative trial linearisation, PCG start fused
-into the block-Jacobi kernel, trial step enqueued ahead of the PCG exit flag — each switched off through its knob,
+"""The LM host loop's shortcuts do not change the optimisation: speculative trial linearisation, the fused iteration head
+(k_finalize_bj: finalisation + block-Jacobi + PCG start + device-side accept decision) with the trial step applied by the
+last direction launch, trial linearisation enqueued ahead of the PCG exit flag — each switched off through its knob,
 the chi2 / lambda traces and the vertices must agree with the default path (same arithmetic; only the order of
 the dot-product partials may differ)."""
 import numpy as np
@@ -21,7 +22,7 @@ def run(prob, dtype, solver, iterations, **kw):
 
 @pytest.mark.parametrize("name,iterations", [("mini-50", 12), ("ladybug-49", 15)])
 @pytest.mark.parametrize("solver", [ga.SOLVER_PCG, ga.SOLVER_PCG_IDENTITY])
-@pytest.mark.parametrize("knob", ["GR_LM_AHEAD", "GR_LM_SPECULATE"])
+@pytest.mark.parametrize("knob", ["GR_LM_AHEAD", "GR_LM_SPECULATE", "GR_LM_FUSED"])
 def test_shortcuts_leave_the_trace_alone(monkeypatch, name, iterations, solver, knob):
     prob = synth.make_config(name)
     base = run(prob, np.float64, solver, iterations)
@@ -33,7 +34,7 @@ def test_shortcuts_leave_the_trace_alone(monkeypatch, name, iterations, solver, 
     assert np.allclose(base[3], off[3], rtol=1e-8, atol=1e-11) and np.allclose(base[4], off[4], rtol=1e-8, atol=1e-11)
 
 
-@pytest.mark.parametrize("knob", ["GR_LM_AHEAD", "GR_LM_SPECULATE"])
+@pytest.mark.parametrize("knob", ["GR_LM_AHEAD", "GR_LM_SPECULATE", "GR_LM_FUSED"])
 def test_rejected_steps_go_through_every_path(oracle_mod, monkeypatch, knob):
     """Noisy observations, almost no damping, PCG run to convergence: about half of the steps are rejected (speculative
     linearisations thrown away, streaks restarting).  Default path, knob-off path and the oracle agree."""

@@ -217,23 +217,31 @@ def test_against_committed_golden_fixtures():
         gpu.close()
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("name,dtype,rtol", [("mini-50", np.float64, 1e-9), ("ladybug-49", np.float64, 1e-8)])
-def test_levenberg_marquardt_graph_replay(oracle_mod, monkeypatch, name, dtype, rtol, mode):
-    """The opt-in device-decided LM iteration (GR_LM_GRAPH=1: hipGraph replay, =2: enqueued ahead): same
-    chi2 / lambda trace as the oracle, including the iterations it hands back to the host loop."""
-    monkeypatch.setenv("GR_LM_GRAPH", mode)
+def test_levenberg_marquardt_fused_iteration(oracle_mod, name, dtype, rtol, fused):
+    """gr_bal_tuning.lm_fused (default 1): iteration head in one launch with the accept decision taken on the device, trial step
+    applied by the direction launch that ends the PCG loop; 0: the host-decided loop.  Same chi2 / lambda trace as the oracle,
+    set through the tuning struct (not the environment)."""
     prob, gpu, ref = make_pair(oracle_mod, name, dtype)
+    gpu.set_tuning(lm_fused=fused, pcg_lazy=0)
+    assert gpu.get_tuning()["lm_fused"] == fused
     for solver, osolver in ((ga.SOLVER_PCG, oracle_mod.SOLVER_PCG), (ga.SOLVER_PCG_IDENTITY, oracle_mod.SOLVER_PCG_IDENTITY)):
         gpu.set_params(prob.cameras, prob.points)
         ref.set_params(prob.cameras, prob.points)
         ct_g, lt_g, st = gpu.levenberg_marquardt(solver=solver, iterations=10)
         ct_r, lt_r, st_r = ref.levenberg_marquardt(solver=osolver, iterations=10)
         assert len(ct_g) == len(ct_r)
-        assert np.allclose(ct_g, ct_r, rtol=max(rtol, 1e-6))
-        assert np.allclose(lt_g, lt_r, rtol=1e-3)
+        assert np.allclose(ct_g, ct_r, rtol=rtol)
+        assert np.allclose(lt_g, lt_r, rtol=1e-6)
         assert st["pcg_iterations"] == st_r["pcg_iterations"]
         assert st["iterations_run"] == st_r["iterations_run"] and st["accepted"] == st_r["accepted"]
+        # the state left behind is the accepted point and ITS linearisation (no half-applied trial step, no pending finalisation)
+        cg, pg = gpu.get_params()
+        cr, pr = ref.get_params()
+        assert np.allclose(cg, cr, rtol=1e-7, atol=1e-10) and np.allclose(pg, pr, rtol=1e-6, atol=1e-9)
+        chi2_now = gpu.chi2()
+        assert abs(chi2_now - ct_g[-1]) / ct_g[-1] < 1e-12
     gpu.close()
 
 

@@ -1,15 +1,15 @@
 #!/bin/bash
 # kernel timeline of the default bench (on the GPU box): per-kernel gaps inside the timed LM loop
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o t -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/timeline.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o t -- python3 bench.py --no-cpu-baseline --no-also "$@" > gpurun_out/timeline.log 2>&1
 find gpurun_out/tl -name "*kernel_trace.csv" -exec cp {} gpurun_out/timeline.csv \;
 rm -rf gpurun_out/tl
 python3 - <<'PY'
 import csv, re, collections
 rows = list(csv.DictReader(open("gpurun_out/timeline.csv")))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"^void gr::|^gr::|<.*", "", r["Kernel_Name"])[:24]) for r in rows)
-# find LM steps by k_chi2 launches; take the middle 30
-chi = [i for i, e in enumerate(ev) if e[2].startswith("k_apply_update_rho")]
+# LM steps = launches of the linearisation kernel; take the middle 30
+chi = [i for i, e in enumerate(ev) if e[2] == "k_linearize"]
 a, b = chi[len(chi)//2 - 15], chi[len(chi)//2 + 15]
 seg = ev[a:b + 1]
 wall = seg[-1][0] - seg[0][0]
