@@ -201,12 +201,13 @@ class BalProblem:
         opt = LMOptions(solver, iterations, initial_damping, int(use_identity), pcg_max_iter, pcg_tol, pcg_rej,
                         int(profile), int(early_stop))
         st = LMStats()
-        ct = np.full(iterations + 1, np.nan)
-        lt = np.full(iterations + 1, np.nan)
-        check(self.lib.gr_bal_levenberg_marquardt(self.h, C.byref(opt), C.byref(st), _ptr(ct), _ptr(lt)))
+        # trace buffers: one (iterations + 1) x 2 array per call, its address taken once (numpy's .ctypes is slow)
+        tr = np.full((2, iterations + 1), np.nan)
+        base = tr.__array_interface__["data"][0]
+        check(self.lib.gr_bal_levenberg_marquardt(self.h, C.byref(opt), C.byref(st), C.c_void_p(base), C.c_void_p(base + 8 * (iterations + 1))))
         k = st.iterations_run + 1
         stats = {f: getattr(st, f) for f, _ in LMStats._fields_}
-        return ct[:k], lt[:k], stats
+        return tr[0, :k], tr[1, :k], stats
 
     def kernel_stats(self):
         arr = (KernelStat * 64)()

@@ -161,7 +161,10 @@ template <typename T, int NV> __device__ __forceinline__ T wave_transpose_sum(T 
 // layout (SS = 1) on the 1 900-block update kernel with its 4 sums: no difference (the fire-and-forget atomics
 // of a finishing block are not what bounds these kernels), so the partials stay packed.
 constexpr int NS = 64;        // partial sums per logical scalar
-constexpr int SS = 1;         // doubles between partials
+#ifndef GR_SS
+#define GR_SS 1
+#endif
+constexpr int SS = GR_SS;     // doubles between partials
 constexpr int NSW = NS * SS;  // doubles per logical scalar
 __device__ __forceinline__ void slot_add(double *base, int k, double v) {
   atomicAdd(&base[(size_t)k * NSW + (size_t)(blockIdx.x & (NS - 1)) * SS], v);

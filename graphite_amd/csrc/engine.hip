@@ -368,6 +368,7 @@ template <typename T> struct Engine final : EngineBase {
   }
   ~Engine() override {
     if (h_res) (void)hipHostFree(h_res);
+    if (h_ts) (void)hipHostFree(h_ts);
   }
   // spin on a pinned word written by a kernel (system-scope fence on the device side)
   template <typename Pred> void spin_until(Pred pred) {
@@ -1234,10 +1235,11 @@ template <typename T> struct Engine final : EngineBase {
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
     launch_operator_j<T>(st, k, rec, lm, mu);
   }
-  template <int MODE, bool IDENTITY> void launch_update(int blocks, T *x, const T *rawc, int cw, int ui, PcgState st, int k, int nc = -1, int np = -1, const LmDev *lm = nullptr) {
+  template <int MODE, bool IDENTITY> void launch_update(int blocks, T *x, const T *rawc, int cw, int ui, PcgState st, int k, int nc = -1, int np = -1, const LmDev *lm = nullptr, bool first_lazy = false) {
     const int nc_v = nc < 0 ? (int)Nc : nc, np_v = np < 0 ? (int)Np : np;
     if (st.lazy == 2) k_pcg_update<T, MODE, IDENTITY, 2><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
     else if (st.lazy) k_pcg_update<T, MODE, IDENTITY, 1><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
+    else if (first_lazy) k_pcg_update<T, MODE, IDENTITY, 3><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather());
     else k_pcg_update<T, MODE, IDENTITY><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather());
   }
   // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
@@ -1262,6 +1264,7 @@ template <typename T> struct Engine final : EngineBase {
     if (st.lazy == 2) v_sv.alloc(n);
     st.ps = v_ps.p; st.zs = v_zs.p; st.sv = v_sv.p;
     st.x = nullptr; st.xb = v_xb.p; st.n = (unsigned)n; st.tol = 0.0; st.rej = 1e30; // set per solve (solve_pcg)
+    st.ts = (lm_fused && h_ts) ? h_ts + 2 * ts_slot : nullptr;
     return st;
   }
   // PCGSolver::solve (solver/pcg.hpp:61-232).  Scalars stay on the device; the host only
@@ -1453,6 +1456,25 @@ template <typename T> struct Engine final : EngineBase {
         break;
       }
       case 7: linearize_impl(false, /*pack_valid=*/true); break; // the whole linearisation (all its kernels), current path
+      case 9: { // k_finalize_bj: variant bit 0 cameras only, bit 1 points only, bit 2 with the decision prologue, bit 3 one point tile per workgroup
+        const int nc_v = (variant & 2) ? 0 : (int)Nc, np_v = (variant & 1) ? 0 : (int)Np;
+        const int nbc = cdiv(nc_v, 28), nbp = np_v ? ((variant & 8) ? cdiv(np_v, TPB / FIN_PL) : std::max(1, std::min(cdiv(np_v, TPB / FIN_PL), num_cu * 4))) : 0;
+        LmDecide dec;
+        if (variant & 4) {
+          ensure_lm_buffers();
+          rho_partial.alloc(dir_grid());
+          dec.seq = 1; dec.chi2_cur = 1e30; dec.mu_cur = 1e-4; dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_obs; dec.rho_partial = rho_partial.p; dec.n_rho = dir_grid();
+          dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
+        }
+#define GR_FBJ(V) k_finalize_bj<T, V><<<nbc + nbp, TPB, 0, stream>>>(nc_v, np_v, nbc, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bu.p, Hll.p, scales.p, 1e-4, 0, MinvC.p, MinvP.p, v_diag.p, st, v_dx.p, v_r.p, v_z.p, nullptr, 0, 1, dec, nullptr, nullptr)
+#ifdef GR_DIAG
+        switch (variant >> 4) { case 1: GR_FBJ(1); break; case 2: GR_FBJ(2); break; case 4: GR_FBJ(4); break; case 8: GR_FBJ(8); break; case 3: GR_FBJ(3); break; case 7: GR_FBJ(7); break; case 15: GR_FBJ(15); break; default: GR_FBJ(0); }
+#else
+        GR_FBJ(0);
+#endif
+#undef GR_FBJ
+        break;
+      }
       case 8: // one all-reduce of `variant` values (0: a camera-space vector) through the communicator, every rank calls it
         if (!comm) throw std::invalid_argument("diag_time(8): no communicator");
         comm->allreduce(tmp.p, variant > 0 ? std::min<size_t>(variant, tmp.n) : pose_dim, sizeof(T) == 8, stream);
@@ -1656,6 +1678,20 @@ template <typename T> struct Engine final : EngineBase {
   // ends the PCG loop applies the trial step itself (ApplyOnExit) — and k_linearize at the trial point.  On an accept streak
   // the head of iteration i + 1 (k_finalize_bj, first direction, first PCG iteration) is enqueued while k_linearize of
   // iteration i is still running; the device takes the accept decision, the host only observes it (LmDev, LmDecide).
+  long long *h_ts = nullptr;    // pinned: 4 (start, end) pairs of device wall-clock stamps around the PCG loops (solve_seconds without events)
+  int ts_slot = 0;
+  double wall_clock_hz = 1e8;
+  void ensure_lm_buffers() {
+    if (!h_ts) {
+      void *q = nullptr;
+      GR_HIP(hipHostMalloc(&q, 8 * sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped));
+      h_ts = static_cast<long long *>(q);
+      std::memset(h_ts, 0, 8 * sizeof(long long));
+      int khz = 0;
+      if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) wall_clock_hz = 1e3 * khz;
+    }
+    lmdev.alloc(1);
+  }
   bool lm_fused = false;        // armed by lm() for GR_SOLVER_PCG / _IDENTITY without a communicator, PCG mode 0, max_iter >= 1
   bool fin_pending = false;     // k_linearize ran, its finalisation is still to come (k_finalize_bj, or flush_finalize)
   bool pcg_state_clean = false; // the PCG loop state has been cleared since the last solve (k_linearize's reset block)
@@ -1691,9 +1727,14 @@ template <typename T> struct Engine final : EngineBase {
   }
   // head of one LM iteration; dec.seq != 0: with the accept decision about the trial step just linearised (then every kernel
   // of the head is gated on that decision and takes the damping from LmDev)
-  template <bool IDENTITY> void enqueue_head(LmDecide dec, double mu, bool use_identity, int max_iter, double tol, double rej, hipEvent_t ev_start) {
+  template <bool IDENTITY> void enqueue_head(LmDecide dec, double mu, bool use_identity, int max_iter, double tol, double rej, int time_slot) {
     ensure_ctl(max_iter);
     ensure_point_records();
+    // the first PCG iteration without its direction launch (operator and update in their lazy forms): not with point records,
+    // whose [X Y Z | s.p] sectors are what the direction launch fills
+    const bool first_lazy = max_iter > 0 && !use_records && tune.lm_fused != 2;
+    if (first_lazy) v_zs.alloc(n);
+    ts_slot = time_slot;
     flag_bank ^= 1; // the previous user of this bank is the solve before the last one: complete
     for (int k = 0; k < max_iter + 1; ++k) flags()[k] = 0;
     *h_iters() = 0;
@@ -1703,25 +1744,35 @@ template <typename T> struct Engine final : EngineBase {
     st.x = v_dx.p; st.tol = tol; st.rej = rej;
     if (!pcg_state_clean) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
     pcg_state_clean = false;
-    const LmDev *lm = dec.seq ? lmdev.p : nullptr;
+    const LmDev *lm = (dec.seq && !dec.report_only) ? lmdev.p : nullptr;
     const int ui = use_identity ? 1 : 0;
     {
       const int nbc = cdiv(Nc, 28), nbp = std::max(1, std::min(cdiv(Np, TPB / FIN_PL), num_cu * 4));
       Scope sc(this, "finalize_bj", 8.0 * No * w() + 54.0 * nseg * w() + (2 * 90.0 * Nc + 36.0 * Np + 27.0 * Nc) * w(), 9.0 * No + 54.0 * nseg + 900.0 * Nc + 60.0 * Np);
       k_finalize_bj<T><<<nbc + nbp, TPB, 0, stream>>>((int)Nc, (int)Np, nbc, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bu.p, Hll.p, scales.p, mu, ui, MinvC.p, MinvP.p, v_diag.p, st,
-                                                      v_dx.p, v_r.p, v_z.p, IDENTITY ? 1 : 0, 1, dec, cam_fixed_p(), pt_fixed_p());
+                                                      v_dx.p, v_r.p, v_z.p, first_lazy ? v_zs.p : nullptr, IDENTITY ? 1 : 0, 1, dec, cam_fixed_p(), pt_fixed_p());
     }
     fin_pending = false; hcp_valid = false;
-    GR_HIP(hipEventRecord(ev_start, stream));
-    launch_direction(st, -1, 0.0, 1e30, v_dx.p, rec, lm, mu, max_iter);
+    if (!first_lazy) launch_direction(st, -1, 0.0, 1e30, v_dx.p, rec, lm, mu, max_iter);
     if (max_iter > 0) {
-      { Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0); launch_operator(st, 0, rec, lm, mu); }
+      {
+        Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
+        if (first_lazy) launch_operator_first(st, lm, mu); // lazy form on zs: no first direction launch
+        else launch_operator(st, 0, rec, lm, mu);
+      }
       {
         Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
-        launch_update<1, IDENTITY>(update_blocks(), v_dx.p, nullptr, 1, ui, st, 0, -1, -1, lm);
+        launch_update<1, IDENTITY>(update_blocks(), v_dx.p, nullptr, 1, ui, st, 0, -1, -1, lm, first_lazy);
       }
       launch_direction(st, 0, tol, rej, v_dx.p, rec, lm, mu, max_iter);
     }
+  }
+  // operator of iteration 0 in its lazy form (direction = sigma zs, sigma derived by every wave from the dots of the PCG start)
+  void launch_operator_first(PcgState st, const LmDev *lm, double mu) {
+    if constexpr (sizeof(T) == 8) {
+      if (jac32) { k_pcg_operator<T, 0, float, 1><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm); return; }
+    }
+    k_pcg_operator<T, 0, T, 1><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm);
   }
   // iterations 1 ... of the solve whose head is in the stream; returns once the host has seen the loop leave
   template <bool IDENTITY> void continue_pcg(int max_iter, double tol, double rej) {
@@ -1760,9 +1811,31 @@ template <typename T> struct Engine final : EngineBase {
     T mu = (T)opt.initial_damping;
     T nu = 2;
     solver_update_structure(opt.solver);
-    linearize();
-    solver_update_values(opt.solver);
-    T chi2v = (T)read_scalar(0);
+    const bool pcg_solver = opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY;
+    lm_fused = pcg_solver && !comm && pcg_mode() == 0 && opt.pcg_max_iter >= 1 && tune.lm_fused != 0;
+    bool head_enqueued = false; // the head of the NEXT iteration is already in the stream (device-decided accept)
+    T chi2v = 0;
+    if (lm_fused && opt.iterations > 0) {
+      // fused form: the first linearisation is finalised by the head of iteration 0 like every other one, and that launch
+      // reports the initial chi2 (no separate finalize launch, no synchronising read before the loop)
+      ensure_lm_buffers(); ensure_ctl(opt.pcg_max_iter);
+      predicted_iters = opt.pcg_max_iter;
+      campack();
+      linearize_deferred(nullptr);
+      fin_pending = true; pcg_state_clean = true;
+      LmDecide dec;
+      dec.seq = ++seq_counter; dec.report_only = 1;
+      dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_obs; dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
+      if (opt.solver == GR_SOLVER_PCG_IDENTITY) enqueue_head<true>(dec, (double)mu, opt.use_identity != 0, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, 0);
+      else enqueue_head<false>(dec, (double)mu, opt.use_identity != 0, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, 0);
+      head_enqueued = true;
+      wait_chi2(dec.seq);
+      chi2v = (T)h_res[0];
+    } else {
+      linearize();
+      solver_update_values(opt.solver);
+      chi2v = (T)read_scalar(0);
+    }
     bool run = true;
     int accept_streak = 2; // consecutive accepted iterations (saturating): speculate only on a streak
     int num_bad = 0;       // levenberg_marquardt2 (:404-414): consecutive accepted iterations gaining < 0.1 %
@@ -1771,9 +1844,10 @@ template <typename T> struct Engine final : EngineBase {
     const int64_t coll0 = coll_count;
     if (chi2_trace) chi2_trace[0] = (double)chi2v;
     if (lambda_trace) lambda_trace[0] = (double)mu;
-    const bool pcg_solver = opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY;
-    lm_fused = pcg_solver && !comm && pcg_mode() == 0 && opt.pcg_max_iter >= 1 && tune.lm_fused != 0;
-    if (lm_fused) { lmdev.alloc(1); ensure_ctl(opt.pcg_max_iter); pcg_state_clean = false; }
+    // look-ahead predictor: nothing is known about the first solve of this call; from a fresh starting point the inner loop
+    // usually runs long, so keep one iteration of look-ahead until it has ended once (a stale count from an earlier call
+    // cost ~9 us of host round trip per inner iteration of the first solve, 90 us per call on the bench line)
+    predicted_iters = opt.pcg_max_iter;
     auto collect_solve_time = [&](int which) {
       float ms = 0;
       (void)hipEventSynchronize(evp.ev[which][1]);
@@ -1781,12 +1855,11 @@ template <typename T> struct Engine final : EngineBase {
       st.solve_seconds += ms * 1e-3;
     };
     int ev_waiting = -1; // pair whose events are recorded and not yet read
-    GR_HIP(hipStreamSynchronize(stream));
+    if (!lm_fused) GR_HIP(hipStreamSynchronize(stream)); // fused form: the loop's first kernels are already running
     st.setup_seconds = std::chrono::duration<double>(clk::now() - t0).count();
     auto tl = clk::now();
 
     int ahead_hits = 0, ahead_misses = 0, head_hits = 0;
-    bool head_enqueued = false; // the head of the NEXT iteration is already in the stream (device-decided accept)
     // accept / reject bookkeeping of one trial step (levenberg_marquardt.hpp:184-233); false = leave the loop.
     // device: the decision k_finalize_bj took (and the kernels behind it follow): {new damping, accepted}
     auto decide = [&](int i, bool solve_ok, bool speculate, int it, const double *hs, const double *device) -> bool {
@@ -1890,24 +1963,22 @@ template <typename T> struct Engine final : EngineBase {
       ev_waiting = pr;
       return decide(i, solve_ok, speculate, it, hs, nullptr);
     };
-    // the same iteration in the fused form (lm_fused)
+    // the same iteration in the fused form (lm_fused); solve time from device wall-clock stamps (an event between two launches
+    // costs a ~6 us bubble)
     auto fused_iteration = [&](int i) -> bool {
       const int mi = opt.pcg_max_iter;
       const bool ui = opt.use_identity != 0, ident = opt.solver == GR_SOLVER_PCG_IDENTITY;
       const double tol = opt.pcg_tol, rej = opt.pcg_rejection_ratio;
       last_solver = opt.solver;
-      const int pr = i % 3;
+      const int pr = i % 4;
       if (!head_enqueued) {
-        if (ident) enqueue_head<true>(LmDecide{}, (double)mu, ui, mi, tol, rej, evp.ev[pr][0]);
-        else enqueue_head<false>(LmDecide{}, (double)mu, ui, mi, tol, rej, evp.ev[pr][0]);
+        if (ident) enqueue_head<true>(LmDecide{}, (double)mu, ui, mi, tol, rej, pr);
+        else enqueue_head<false>(LmDecide{}, (double)mu, ui, mi, tol, rej, pr);
       } else damping = (double)mu; // the head took it from LmDev; the iterations enqueued from here on get it as an argument
       head_enqueued = false;
-      if (ev_waiting >= 0) { collect_solve_time(ev_waiting); ev_waiting = -1; }
+      ts_slot = pr;
       const bool speculate = accept_streak >= 2 && spec_enabled;
-      auto enqueue_lin = [&](const int *gate) {
-        GR_HIP(hipEventRecord(evp.ev[pr][1], stream));
-        linearize_deferred(gate);
-      };
+      auto enqueue_lin = [&](const int *gate) { linearize_deferred(gate); };
       const bool ahead = speculate && ahead_enabled;
       if (ahead) trial_hook = enqueue_lin;
       trial_done = false;
@@ -1926,19 +1997,16 @@ template <typename T> struct Engine final : EngineBase {
           dec.seq = seq; dec.chi2_cur = (double)chi2v; dec.mu_cur = (double)mu;
           dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_obs; dec.rho_partial = rho_partial.p; dec.n_rho = rho_blocks;
           dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
-          if (ident) enqueue_head<true>(dec, (double)mu, ui, mi, tol, rej, evp.ev[(i + 1) % 3][0]);
-          else enqueue_head<false>(dec, (double)mu, ui, mi, tol, rej, evp.ev[(i + 1) % 3][0]);
+          if (ident) enqueue_head<true>(dec, (double)mu, ui, mi, tol, rej, (i + 1) % 4);
+          else enqueue_head<false>(dec, (double)mu, ui, mi, tol, rej, (i + 1) % 4);
           head_enqueued = true;
           ++head_hits;
         } else flush_finalize(seq); // last iteration: only the decision is needed
-      } else {
-        GR_HIP(hipEventRecord(evp.ev[pr][1], stream));
-        seq = chi2_async(nullptr, v_dx.p, (double)mu); // the step itself was applied by the last direction launch
-      }
+      } else seq = chi2_async(nullptr, v_dx.p, (double)mu); // the step itself was applied by the last direction launch
       wait_chi2(seq);
+      st.solve_seconds += (double)(h_ts[2 * pr + 1] - h_ts[2 * pr]) / wall_clock_hz;
       const double hs[2] = {h_res[0], h_res[1]};
       const double dev[2] = {h_res[2], h_res[3]};
-      ev_waiting = pr;
       const bool go = decide(i, true, speculate, it, hs, head_enqueued ? dev : nullptr);
       if (head_enqueued && dev[1] == 0.0) head_enqueued = false; // not accepted: the head returned at once
       return go;

@@ -82,6 +82,7 @@ struct PcgState {
   void *sv;             // T[n]: s = A p
   // the loop decision of the lazy form is taken in the prologue of the NEXT operator launch (pcg_decide)
   void *x, *xb;         // T[n]: solution and its backup (a rejected step restores x)
+  long long *ts = nullptr; // pinned (LM loop, fused form): [0] device wall clock when the PCG loop starts, [1] when it has ended
   unsigned n;
   double tol, rej;
   __device__ __forceinline__ double *slots(int k, int which) const { return acc + ((size_t)k * NSLOT + which) * NSW; }
@@ -216,51 +217,79 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
 // entry, same order: same bits as spd_inverse<9>).  Points: FIN_PL lanes per point as in k_linearize_finalize.
 struct LmDecide {
   int seq = 0;                                  // != 0: decide; the value published to hres_seq
+  int report_only = 0;                          // with seq: only publish the chi2 sum (first linearisation of an LM call), no decision
   double chi2_cur = 0, mu_cur = 0;              // chi2 and damping of the iteration whose trial step is being judged
-  const double *chi2_partial = nullptr; int n_chi2 = 0;
-  const double *rho_partial = nullptr; int n_rho = 0;
+  const double *chi2_partial = nullptr; int n_chi2 = 0; // block partials of the trial linearisation's chi2 (k_linearize) ...
+  const double *rho_partial = nullptr; int n_rho = 0;   // ... and of the rho denominator (ApplyOnExit)
   volatile double *hres = nullptr;              // pinned: [0] trial chi2, [1] rho denominator, [2] new damping, [3] accepted
   volatile int *hres_seq = nullptr;
   LmDev *lm = nullptr;
   double *dscal = nullptr;                      // device copy of [0], [1]
 };
-template <typename T>
+template <typename T, int VAR = 0> // VAR (diagnostic timing only): 1 few output stores, 2 no inverse / scale math, 4 no record loads, 8 no dot-product atomics
 __global__ void __launch_bounds__(TPB)
 k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__ cam_seg_ptr, const T *__restrict__ cam_partial,
               const int *__restrict__ pt_ptr, const T *__restrict__ g9, T *__restrict__ Hcc, T *__restrict__ bu,
               T *__restrict__ Hll, T *__restrict__ scales, double mu, int use_identity, T *__restrict__ MinvC,
               T *__restrict__ MinvP, T *__restrict__ diag_clamped, PcgState st, T *__restrict__ x, T *__restrict__ r,
-              T *__restrict__ zt, int identity_precond, int cam_weight, LmDecide dec,
+              T *__restrict__ zt, T *__restrict__ zs /* != nullptr: s .* z' instead of x = 0 (lazy first PCG iteration) */,
+              int identity_precond, int cam_weight, LmDecide dec,
               const unsigned char *__restrict__ cam_fixed, const unsigned char *__restrict__ pt_fixed) {
-  __shared__ double red[4];
-  __shared__ double s_dec[2];
   __shared__ double sA[4][7 * 81];
+  __shared__ double red3[4][3];
   if (dec.seq) {
-    double cs = 0, rs = 0;
-    for (int i = threadIdx.x; i < dec.n_chi2; i += TPB) cs += dec.chi2_partial[i];
-    cs = block_sum_256(cs, red);
-    for (int i = threadIdx.x; i < dec.n_rho; i += TPB) rs += dec.rho_partial[i];
-    rs = block_sum_256(rs, red);
-    if (threadIdx.x == 0) {
-      const T chi2v = (T)dec.chi2_cur, new_chi2 = (T)cs;
-      const T denom = (T)rs + (T)1.0e-3;
-      const T rho = (chi2v - new_chi2) / denom;
-      const bool ok = isfinite((double)new_chi2) && rho > T(0);
-      double alpha = 1.0 - pow(2.0 * (double)rho - 1.0, 3.0);
-      alpha = fmax(fmin(alpha, 2.0 / 3.0), 1.0 / 3.0);
-      const T mun = (T)dec.mu_cur * (T)alpha;
-      s_dec[0] = ok ? 1.0 : 0.0; s_dec[1] = (double)mun;
-      if (blockIdx.x == 0) {
-        dec.lm->mu = (double)mun; dec.lm->stop = ok ? 0 : 2;
-        if (dec.dscal) { dec.dscal[0] = cs; dec.dscal[1] = rs; }
-        dec.hres[0] = cs; dec.hres[1] = rs; dec.hres[2] = (double)mun; dec.hres[3] = ok ? 1.0 : 0.0;
+    // wave 0 of every workgroup: lane L adds partials L, L + 64, ... in order (eight loads in flight at a time), then a
+    // butterfly; the two sums reach the other waves through LDS.  Same fixed order in every workgroup: same decision.
+    // (Measured alternatives: a 256-thread block reduction of each array 3-4 us per workgroup; every wave summing for itself
+    // 10-15 us; 64 group partials folded by a ticket in the producers 2.7 us of tail in k_linearize + 1.5 us in the direction launch.)
+    __shared__ double s_sum[2];
+    if (threadIdx.x < 64) {
+      const int ln = threadIdx.x;
+      double c0 = 0, r0 = 0;
+      for (int base = 0; base < dec.n_chi2; base += 512) {
+        double q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = base + 64 * u + ln; q[u] = i < dec.n_chi2 ? dec.chi2_partial[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c0 += q[u];
+      }
+      for (int base = 0; base < dec.n_rho; base += 512) {
+        double q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = base + 64 * u + ln; q[u] = i < dec.n_rho ? dec.rho_partial[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r0 += q[u];
+      }
+      c0 = wave_allsum(c0); r0 = wave_allsum(r0);
+      if (ln == 0) { s_sum[0] = c0; s_sum[1] = r0; }
+    }
+    __syncthreads();
+    const double cs = s_sum[0], rs = s_sum[1];
+    if (dec.report_only) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (dec.dscal) dec.dscal[0] = cs;
+        dec.hres[0] = cs;
         __threadfence_system();
         *dec.hres_seq = dec.seq;
       }
+    } else {
+    const T chi2v = (T)dec.chi2_cur, new_chi2 = (T)cs;
+    const T denom = (T)rs + (T)1.0e-3;
+    const T rho = (chi2v - new_chi2) / denom;
+    const bool ok = isfinite((double)new_chi2) && rho > T(0);
+    double alpha = 1.0 - pow(2.0 * (double)rho - 1.0, 3.0);
+    alpha = fmax(fmin(alpha, 2.0 / 3.0), 1.0 / 3.0);
+    const T mun = (T)dec.mu_cur * (T)alpha;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      dec.lm->mu = (double)mun; dec.lm->stop = ok ? 0 : 2;
+      if (dec.dscal) { dec.dscal[0] = cs; dec.dscal[1] = rs; }
+      dec.hres[0] = cs; dec.hres[1] = rs; dec.hres[2] = (double)mun; dec.hres[3] = ok ? 1.0 : 0.0;
+      __threadfence_system();
+      *dec.hres_seq = dec.seq;
     }
-    __syncthreads();
-    if (s_dec[0] == 0.0) return;
-    mu = s_dec[1];
+    if (!ok) return;
+    mu = (double)mun;
+    }
   }
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0 && st.left) *st.left = 0; // a new loop starts
@@ -279,7 +308,26 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
       int idx[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) { const int lo = i < j ? i : j, hi = i < j ? j : i; idx[i] = hi * (hi + 1) / 2 + lo; }
-      for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) {
+      // four segments of loads in flight, added in segment order (the sums are what k_linearize_finalize forms)
+      int sg = cam_seg_ptr[c];
+      const int sg1 = cam_seg_ptr[c + 1];
+      for (; sg + 4 <= sg1; sg += 4) {
+        T q[4][10];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const T *cp = cam_partial + 54 * (size_t)(sg + u);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) q[u][i] = cp[idx[i]];
+          q[u][9] = cp[45 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) a[i] += q[u][i];
+          bj += q[u][9];
+        }
+      }
+      for (; sg < sg1; ++sg) {
         const T *cp = cam_partial + 54 * (size_t)sg;
 #pragma unroll
         for (int i = 0; i < 9; ++i) a[i] += cp[idx[i]];
@@ -352,8 +400,8 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
     }
     if (on) {
       const size_t t = 9 * (size_t)c + j;
-      x[t] = T(0); r[t] = rvj; zt[t] = zj;
-      if (st.lazy) static_cast<T *>(st.zs)[t] = sj * zj;
+      if (zs) zs[t] = sj * zj; else x[t] = T(0);
+      r[t] = rvj; zt[t] = zj;
       const T d = use_identity ? T(1) : dclj;
       if (cam_weight) { prr = (double)(rvj * rvj); prz = (double)(rvj * zj); pzz = (double)(d * zj * zj); }
     }
@@ -369,7 +417,8 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
       T v[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) v[i] = T(0);
-      if (on) {
+      if (on && (VAR & 4)) { v[0] = v[3] = v[5] = T(2 + l % 3); v[6] = T(1); }
+      if (on && !(VAR & 4)) {
         for (int a = pt_ptr[l] + (int)jl; a < pt_ptr[l + 1]; a += FIN_PL) {
           const V2 *gq = reinterpret_cast<const V2 *>(g9 + 8 * (size_t)a);
           const V2 c0 = gq[0], c1 = gq[1], c2 = gq[2], e = gq[3]; // sqrt(w) Jp columns, sqrt(w) e
@@ -394,7 +443,7 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
 #pragma unroll
         for (int i = 0; i < 9; ++i) v[i] = T(0);
       }
-      const bool sc_on = scale_system && !pfixed;
+      const bool sc_on = scale_system && !pfixed && !(VAR & 2);
       const T s0 = sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[0]))) : T(1);
       const T s1 = sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1);
       const T s2 = sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1);
@@ -410,23 +459,29 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
           if (rw == c) { A[rw + 3 * c] = (double)damp_diag(q, mu, use_identity); dcl[rw] = (T)clampd((double)q, 1.0e-6, 1.0e32); }
           else A[rw + 3 * c] = (double)q;
         }
-      spd_inverse<3>(A);
+      if (!(VAR & 2)) spd_inverse<3>(A);
       const T rv[3] = {s0 * v[6], s1 * v[7], s2 * v[8]};
       T z[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) z[i] = identity_precond ? rv[i] : (T)A[i] * rv[0] + (T)A[i + 3] * rv[1] + (T)A[i + 6] * rv[2];
-      // outputs, FIN_PL lanes wide: lane jl stores entries jl, jl + FIN_PL, ... of the 3 x 3 blocks and entry jl of the 3-vectors
+      // 36 outputs per point, written 4 lanes wide: lane jl stores outputs jl, jl + 4, ... (9 store instructions with every lane
+      // active; one predicated store per output was 39 instructions)
+      static_assert(FIN_PL == 4, "k_finalize_bj writes its outputs four lanes wide");
       const size_t t0 = 9 * (size_t)Nc + 3 * (size_t)l;
+      const T out[36] = {H[0], H[1], H[2], H[3], H[4], H[5], H[6], H[7], H[8],
+                         (T)A[0], (T)A[1], (T)A[2], (T)A[3], (T)A[4], (T)A[5], (T)A[6], (T)A[7], (T)A[8],
+                         v[6], v[7], v[8], sv[0], sv[1], sv[2], dcl[0], dcl[1], dcl[2],
+                         zs ? sv[0] * z[0] : T(0), zs ? sv[1] * z[1] : T(0), zs ? sv[2] * z[2] : T(0), rv[0], rv[1], rv[2], z[0], z[1], z[2]};
+      T *const dst[8] = {Hll + 9 * (size_t)l, MinvP + 9 * (size_t)l, bu + t0, scales + t0, diag_clamped + t0, (zs ? zs : x) + t0, r + t0, zt + t0};
 #pragma unroll
-      for (int i = 0; i < 9; ++i)
-        if ((unsigned)i % FIN_PL == jl) { Hll[9 * (size_t)l + i] = H[i]; MinvP[9 * (size_t)l + i] = (T)A[i]; }
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        if ((unsigned)i % FIN_PL == jl) {
-          bu[t0 + i] = v[6 + i]; scales[t0 + i] = sv[i]; diag_clamped[t0 + i] = dcl[i];
-          x[t0 + i] = T(0); r[t0 + i] = rv[i]; zt[t0 + i] = z[i];
-          if (st.lazy) static_cast<T *>(st.zs)[t0 + i] = sv[i] * z[i];
-        }
+      for (int m = 0; m < ((VAR & 1) ? 3 : 9); ++m) {
+        // output e = 4 m + jl lives in array (e < 18 ? e / 9 : 2 + (e - 18) / 3) at offset (e < 18 ? e % 9 : (e - 18) % 3)
+#define GR_FBJ_PTR(e) (dst[(e) < 18 ? (e) / 9 : 2 + ((e) - 18) / 3] + ((e) < 18 ? (e) % 9 : ((e) - 18) % 3))
+        T *q = jl == 0 ? GR_FBJ_PTR(4 * m) : jl == 1 ? GR_FBJ_PTR(4 * m + 1) : jl == 2 ? GR_FBJ_PTR(4 * m + 2) : GR_FBJ_PTR(4 * m + 3);
+#undef GR_FBJ_PTR
+        const T val = jl == 0 ? out[4 * m] : jl == 1 ? out[4 * m + 1] : jl == 2 ? out[4 * m + 2] : out[4 * m + 3];
+        *q = val;
+      }
       if (jl == 0) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -436,8 +491,14 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
       }
     }
   }
+  // the three dots: one atomic each per WORKGROUP (one set per wave was 7 of the 30 us of the point part)
   prr = wave_sum(prr); prz = wave_sum(prz); pzz = wave_sum(pzz);
-  if (lane == 0) { slot_add(st.slots(0, RR), 0, prr); slot_add(st.slots(0, RZP), 0, prz); slot_add(st.slots(0, ZDZ), 0, pzz); }
+  if (lane == 0) { red3[wave][0] = prr; red3[wave][1] = prz; red3[wave][2] = pzz; }
+  __syncthreads();
+  if (threadIdx.x < 3 && !(VAR & 8)) {
+    const double v = red3[0][threadIdx.x] + red3[1][threadIdx.x] + red3[2][threadIdx.x] + red3[3][threadIdx.x];
+    slot_add(st.slots(0, threadIdx.x == 0 ? RR : threadIdx.x == 1 ? RZP : ZDZ), 0, v);
+  }
 }
 
 // Graph::backup_parameters + Graph::apply_update (graph.hpp:292-309, ops/update.hpp:11-31) over cameras and
@@ -1013,6 +1074,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     if (k > 0 && st.done[k - 1]) return;
     stp.scale = T(1);
   } else if (LAZY) {
+    if (k == 0 && st.ts && blockIdx.x == 0 && threadIdx.x == 0) st.ts[0] = wall_clock64();
     if (!pcg_decide<T>(st, k, stp)) return;
     if (slot_sum(st.slots(k, RZP), 0) == 0.0) return; // rz == 0: the next launch's decision closes the loop
   } else if (!(VAR & 32)) {
@@ -1233,7 +1295,11 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
   __shared__ T rs[TPB];
   const unsigned pose_dim = 9u * (unsigned)Nc;
   // lazy direction (PcgState): p_k = beta p_{k-1} + scale z'_k is formed here, stored with ps = s.*p_k; zs = s.*z'_{k+1}
+  // LAZY == 3: the FIRST iteration of the direction-kernel form without its first direction launch — p_0 = sigma z'_0 is formed
+  // (and stored with s .* p_0) here, the operator of iteration 0 ran in its lazy form on zs; x is known to be 0 and is not read;
+  // from the direction launch of iteration 0 on, the loop is the direction-kernel form
   constexpr bool lazy = LAZY != 0;
+  constexpr bool FIRST = LAZY == 3;
   const bool lazy_old = lazy && MODE == 1 && k > 0; // a previous direction exists
   T *pw = const_cast<T *>(p), *psw = static_cast<T *>(st.ps), *zsw = static_cast<T *>(st.zs), *svw = static_cast<T *>(st.sv);
   const T lz_beta = CG ? cg.beta : (lazy_old ? (T)st.beta[k] : T(0)), lz_scale = CG ? cg.sigma : ((lazy && MODE == 1) ? (T)st.scale[k] : T(0));
@@ -1271,7 +1337,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
           svw[t] = v2;
         } else
         v2 = scales[t] * raw + (use_identity ? (T)mu * pv : (T)mu * diag[t] * pv);
-        const T xo = x[t];
+        const T xo = FIRST ? T(0) : x[t];
         xb[t] = xo;
         x[t] = alpha * pv + xo;
         rn = -alpha * v2 + r[t];
@@ -1292,7 +1358,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         for (int q = 0; q < 9; ++q) s += M[row + 9 * q] * rc[q];
       }
       zt[t] = s;
-      if (lazy) zsw[t] = scales[t] * s;
+      if (lazy && !FIRST) zsw[t] = scales[t] * s;
       const T d = use_identity ? T(1) : diag[t];
       const T pv = pvk;
       prr += cw * (double)(rn * rn);
@@ -1337,7 +1403,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
           if (lazy_old) pv += lz_beta * p[t];
           pw[t] = pv; if (!CG) psw[t] = sc * pv;
         }
-        const T xo = x[t], ro = r[t];
+        const T xo = FIRST ? T(0) : x[t], ro = r[t];
         T raw = 0;
         int a = pt_ptr[l];
         const int a_end = pt_ptr[l + 1];
@@ -1392,7 +1458,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
 #endif
       }
       zt[t] = s;
-      if (lazy) zsw[t] = scales[t] * s;
+      if (lazy && !FIRST) zsw[t] = scales[t] * s;
       prr += (double)(rn * rn);
       prz += (double)(rn * s);
       ppz += (double)(dg * pv * s);
@@ -1426,12 +1492,14 @@ template <typename T> struct ApplyOnExit {
   double *rho_partial = nullptr; // [gridDim.x]
   T *pack = nullptr, *xp = nullptr;
   int cam_weight = 1, at_cap = 0;
+  long long *ts = nullptr;       // PcgState::ts
 };
 template <typename T>
 __device__ __forceinline__ void apply_on_exit(const ApplyOnExit<T> &ap, unsigned n, unsigned pose_dim, const T *__restrict__ dx,
                                               const T *__restrict__ scales, double mu, T *__restrict__ x_restore) {
   __shared__ double red[4];
   __shared__ T cs[252];
+  if (ap.ts && blockIdx.x == 0 && threadIdx.x == 0) ap.ts[1] = wall_clock64();
   double rho = 0;
   const unsigned nct = (pose_dim + 251u) / 252u;
   if (blockIdx.x < nct) {
@@ -1485,9 +1553,11 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
                 int k, double tol, double rejection_ratio, unsigned pose_dim = 0, T *__restrict__ xp = nullptr,
                 const LmDev *__restrict__ lm = nullptr, double mu = 0.0, ApplyOnExit<T> ap = ApplyOnExit<T>{}) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
+  ap.ts = st.ts;
   const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
   T beta = 0, scale = 0;
   if (k < 0) {
+    if (first && st.ts) st.ts[0] = wall_clock64();
     scale = (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(st.slots(0, RR), 0)));
     const double zdz = slot_sum(st.slots(0, ZDZ), 0);
     if (first) st.pdp[0] = (double)scale * (double)scale * zdz;
