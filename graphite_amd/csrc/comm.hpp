@@ -32,6 +32,7 @@ struct Comm {
   virtual void group_end() {}
   // a transport that can lose a message without hanging reports it here (host check after a stream synchronisation)
   virtual bool failed() { return false; }
+  virtual void set_timeout_ms(int) {}
 };
 
 // ---- RCCL ------------------------------------------------------------------------------
@@ -99,14 +100,18 @@ struct RcclComm final : Comm {
 // small message is ONE hop: every rank stores its contribution into its slot of every peer's mailbox (`push`), then
 // sums the `size` slots of its own mailbox in rank order (`reduce`).  No ring, no tree; the sum has the same order on
 // every rank, so the result is bit-identical everywhere.
-//   mailbox (one per rank, hipMalloc + hipIpcGetMemHandle, opened by every peer with hipIpcOpenMemHandle):
+//   mailbox (one per rank, FINE-GRAINED device memory: hipExtMallocWithFlags(hipDeviceMallocFinegrained) + hipIpcGetMemHandle,
+//   opened by every peer with hipIpcOpenMemHandle):
 //     header: flags[2][size] (uint64 sequence numbers), error word;  then 2 sets x size slots of `slot_bytes`
 //   set = seq & 1: a rank can only push sequence s + 2 after it has reduced s + 1, which needed every peer's push of
 //   s + 1, issued (stream order) after that peer's reduce of s: two sets are enough.
 //   visibility: the payload is stored with system-scope (write-through) stores, drained, then the flag is stored
 //   system-scope by the block that finishes last; the reader polls the flags system-scope and fences before it loads.
 // Grouped calls (group_start .. group_end) travel as ONE message.  Messages beyond the slot size go to the fallback
-// communicator (RCCL).  Every spin is bounded (2 s) and raises the mailbox's error word instead of hanging.
+// communicator (RCCL).  Every spin is bounded (gr_bal_tuning.ipc_timeout_ms, default 30 s: ranks may arrive seconds apart
+// after host-side set-up work) and raises the mailbox's error word instead of hanging; the host checks that word after every
+// all-reduce whose result IT consumes and before it returns from an optimisation, and a communicator that has failed once
+// refuses every later collective (CommError) — a rank that timed out holds rank-local values and must not carry on.
 constexpr int IPC_MAX_PARTS = 8;
 constexpr size_t IPC_HEADER = 4096;
 struct IpcPart { void *ptr; unsigned long long count; unsigned long long offset; int is_double; int pad; }; // offset: bytes inside the slot
@@ -119,10 +124,10 @@ template <typename T> __device__ __forceinline__ T ipc_load(const T *p) { return
 // the last block to finish raises this rank's flag in every mailbox.  Phase 2: every block waits for all ranks' flags in
 // its OWN mailbox, then buf = sum over ranks, in rank order, of the slots (identical bits on every rank).
 // The grid is at most 64 blocks, launched on a stream whose earlier kernels have finished: all blocks are resident, so
-// waiting inside the kernel cannot starve the blocks that still have to push.  Waits are bounded (2 s): a peer that died
-// or never joined turns into the error word (IpcComm::failed), not a hung GPU.
+// waiting inside the kernel cannot starve the blocks that still have to push.  Waits are bounded (timeout_ticks of the
+// 100 MHz wall clock): a peer that died or never joined turns into the error word (IpcComm::failed), not a hung GPU.
 __global__ void __launch_bounds__(256) k_ipc_allreduce(IpcMsg msg, char *const *__restrict__ boxes, int rank, int size, int set, size_t slot_bytes,
-                                                       unsigned long long seq, unsigned *__restrict__ ticket) {
+                                                       unsigned long long seq, unsigned *__restrict__ ticket, long long timeout_ticks, int *__restrict__ h_err) {
   const size_t slot_off = IPC_HEADER + ((size_t)set * size + rank) * slot_bytes;
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (size_t)gridDim.x * blockDim.x;
   for (int q = 0; q < msg.nparts; ++q) {
@@ -161,8 +166,9 @@ __global__ void __launch_bounds__(256) k_ipc_allreduce(IpcMsg msg, char *const *
     const long long t0 = wall_clock64();
     while (ipc_load(flag) < seq) {
       __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > 200000000ll) { // 2 s at 100 MHz
+      if (wall_clock64() - t0 > timeout_ticks) {
         ipc_store(reinterpret_cast<unsigned long long *>(box) + 500, 1ull); // error word
+        if (h_err) { *h_err = 1; __threadfence_system(); } // its pinned host mirror: IpcComm::failed() costs no copy
         s_bad = 1;
         break;
       }
@@ -197,6 +203,7 @@ struct IpcComm final : Comm {
   std::vector<bool> opened;    // opened through hipIpcOpenMemHandle (to be closed)
   char **d_boxes = nullptr;
   unsigned *d_ticket = nullptr;
+  int *h_err = nullptr; // pinned: raised by a kernel whose wait timed out
   size_t slot_bytes = 0;
   unsigned long long seq = 0;
   std::unique_ptr<Comm> fallback; // messages larger than a slot (may be null: then they are an error)
@@ -205,6 +212,8 @@ struct IpcComm final : Comm {
   size_t pending_bytes = 0;
   hipStream_t pending_stream = nullptr;
   int64_t n_oneshot = 0, n_fallback = 0;
+  long long timeout_ticks = 3000000000ll; // 30 s at 100 MHz (gr_bal_tuning.ipc_timeout_ms)
+  bool dead = false;                      // a wait timed out once: every later collective is refused
 
   static size_t mailbox_bytes(int size, size_t slot) { return IPC_HEADER + 2 * (size_t)size * slot; }
   IpcComm(int rank_, int size_, size_t slot_bytes_, const std::vector<char *> &boxes_, const std::vector<bool> &opened_) : boxes(boxes_), opened(opened_), slot_bytes(slot_bytes_) {
@@ -213,12 +222,15 @@ struct IpcComm final : Comm {
     GR_HIP(hipMemcpy(d_boxes, boxes.data(), size * sizeof(char *), hipMemcpyHostToDevice));
     GR_HIP(hipMalloc(reinterpret_cast<void **>(&d_ticket), sizeof(unsigned)));
     GR_HIP(hipMemset(d_ticket, 0, sizeof(unsigned)));
+    GR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_err), sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
+    *h_err = 0;
   }
   ~IpcComm() override {
     for (int r = 0; r < size; ++r) if (opened[r]) (void)hipIpcCloseMemHandle(boxes[r]);
     if (!boxes.empty() && boxes[rank]) (void)hipFree(boxes[rank]);
     if (d_boxes) (void)hipFree(d_boxes);
     if (d_ticket) (void)hipFree(d_ticket);
+    if (h_err) (void)hipHostFree(h_err);
   }
   void flush(hipStream_t stream) {
     if (!pending.nparts) return;
@@ -227,11 +239,12 @@ struct IpcComm final : Comm {
     size_t total = 0;
     for (int q = 0; q < pending.nparts; ++q) total += pending.part[q].count;
     const int grid = (int)std::max<size_t>(1, std::min<size_t>(64, (total + 2047) / 2048));
-    k_ipc_allreduce<<<grid, 256, 0, stream>>>(pending, d_boxes, rank, size, set, slot_bytes, seq, d_ticket);
+    k_ipc_allreduce<<<grid, 256, 0, stream>>>(pending, d_boxes, rank, size, set, slot_bytes, seq, d_ticket, timeout_ticks, h_err);
     ++n_oneshot;
     pending.nparts = 0; pending_bytes = 0;
   }
   void allreduce(void *buf, size_t count, bool is_double, hipStream_t stream) override {
+    if (dead) throw CommError("IPC all-reduce: an earlier all-reduce timed out waiting for a peer; this communicator is no longer usable");
     const size_t bytes = (count * (is_double ? 8 : 4) + 15) / 16 * 16;
     if (bytes > slot_bytes || (grouping && (pending_bytes + bytes > slot_bytes || pending.nparts == IPC_MAX_PARTS))) {
       if (grouping) flush(stream);
@@ -250,10 +263,10 @@ struct IpcComm final : Comm {
   }
   void group_start() override { grouping = true; }
   void group_end() override { grouping = false; flush(pending_stream); }
-  bool failed() override { // a bounded spin gave up (host check after a stream synchronisation)
-    unsigned long long e = 0;
-    GR_HIP(hipMemcpy(&e, boxes[rank] + 500 * sizeof(unsigned long long), sizeof(e), hipMemcpyDeviceToHost));
-    return e != 0;
+  void set_timeout_ms(int ms) override { timeout_ticks = (long long)std::max(1, ms) * 100000ll; }
+  bool failed() override { // a bounded spin gave up (host check after a stream synchronisation; reads pinned host memory)
+    if (__atomic_load_n(h_err, __ATOMIC_ACQUIRE) != 0) dead = true;
+    return dead;
   }
 };
 

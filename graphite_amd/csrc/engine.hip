@@ -193,7 +193,12 @@ template <typename T> struct Engine final : EngineBase {
   bool shard = false;
   DevBuf<T> raw_c;
   int cam_weight() const { return (!comm || comm->rank == 0) ? 1 : 0; }
-  void set_comm(std::unique_ptr<Comm> c) override { comm = std::move(c); raw_c.alloc(pose_dim); }
+  void set_comm(std::unique_ptr<Comm> c) override { comm = std::move(c); comm->set_timeout_ms(tune.ipc_timeout_ms); raw_c.alloc(pose_dim); }
+  // after a stream synchronisation that follows an all-reduce whose result the HOST consumes (block structure, chi2 / rho of
+  // the LM decision, stop-flag agreement): a rank whose wait timed out holds rank-local values and must not act on them
+  void check_comm(const char *where) {
+    if (comm && comm->failed()) throw CommError(std::string(where) + ": an all-reduce timed out waiting for a peer (IPC mailbox transport); the result is not valid");
+  }
   void allreduce_host(double *v, size_t n) override {
     if (!comm) throw std::invalid_argument("no communicator");
     DevBuf<double> d;
@@ -201,6 +206,7 @@ template <typename T> struct Engine final : EngineBase {
     d.upload(h, stream);
     comm->allreduce(d.p, n, true, stream);
     h = d.download(stream);
+    check_comm("allreduce_host");
     std::copy(h.begin(), h.end(), v);
   }
   int64_t coll_count = 0; // collectives issued (a group counts once): gr_lm_stats.collectives
@@ -584,6 +590,7 @@ template <typename T> struct Engine final : EngineBase {
       flags.upload(packed, stream);
       allreduce_d(flags.p, packed.size());
       packed = flags.download(stream);
+      check_comm("build_schur_structure"); // a timed-out rank would build another block list than its peers
       too_many = packed.back() != 0.0;
       packed.pop_back();
       if (too_many) throw std::invalid_argument("too many Schur products for 32-bit indices (on at least one landmark shard)");
@@ -853,6 +860,7 @@ template <typename T> struct Engine final : EngineBase {
       double hs[2];
       GR_HIP(hipMemcpyAsync(hs, dscalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
       GR_HIP(hipStreamSynchronize(stream));
+      check_comm("levenberg_marquardt"); // the accept decision of every rank hangs on these two sums
       h_res[0] = hs[0]; h_res[1] = hs[1];
       return;
     }
@@ -1119,12 +1127,12 @@ template <typename T> struct Engine final : EngineBase {
                        spchol.nsuper, spchol.nt, spchol.npad, spchol.nlevels, (long long)spchol.factor_tiles, use_spchol ? "nested dissection, level-scheduled" : "dense tile Cholesky");
       }
       if (use_spchol) {
+        spchol.allocate();
         chol_sink.reset(new CholSink(this));
         spchol.sink = chol_sink.get();
         chol_ready = true;
         return;
       }
-      spchol.A.release(); // not used: give the memory back
     }
     if (DenseChol<T>::bytes_needed((int64_t)pose_dim) > ((size_t)96 << 30))
       throw std::invalid_argument("dense reduced camera system does not fit (9 Nc padded squared > 96 GiB)");
@@ -2017,7 +2025,13 @@ template <typename T> struct Engine final : EngineBase {
       const bool go = lm_fused ? fused_iteration(i) : host_iteration(i);
       ++i;
       if (!go) break;
-      if (opt.stop_flag && *opt.stop_flag) break; // levenberg_marquardt.hpp:233-238: polled once per iteration
+      if (opt.stop_flag) { // levenberg_marquardt.hpp:233-238: polled once per iteration
+        double stop = *opt.stop_flag ? 1.0 : 0.0;
+        // landmark shards: a host flag is per process; the ranks leave together or not at all (one scalar all-reduce per
+        // iteration, only when a flag was given), otherwise one rank would enqueue collectives its peers never join
+        if (comm) allreduce_host(&stop, 1);
+        if (stop != 0.0) break;
+      }
     }
     if (head_enqueued) {
       // the loop ends here but the head of the next iteration is already running: if its PCG loop ended inside the head,
@@ -2033,7 +2047,7 @@ template <typename T> struct Engine final : EngineBase {
     st.ok = run ? 1 : 0;
     st.final_chi2 = (double)chi2v;
     st.collectives = coll_count - coll0;
-    if (comm && comm->failed()) throw CommError("levenberg_marquardt: an all-reduce timed out waiting for a peer (IPC mailbox transport); the result is not valid");
+    check_comm("levenberg_marquardt");
     if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] LM: %s; trial linearisation enqueued ahead of the PCG exit flag in %d iterations, not ahead in %d; next head enqueued behind the trial step in %d\n",
                                    lm_fused ? "fused head / trial step" : "host loop", ahead_hits, ahead_misses, head_hits);
     if (profiling) flush_prof();
@@ -2059,6 +2073,7 @@ template <typename F> static gr_status guarded(gr_bal_problem *p, F &&f) {
     f();
     return GR_OK;
   } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const CommError &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
   catch (const std::domain_error &ex) { g_last_error = ex.what(); return GR_ERR_DUPLICATE_EDGE; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
 }
@@ -2362,6 +2377,7 @@ gr_status gr_bal_comm_allreduce_host(gr_bal_problem *p, double *v, size_t n) {
   if (!p || !p->e || !v) { g_last_error = "gr_bal_comm_allreduce_host: bad argument"; return GR_ERR_INVALID; }
   try { GR_HIP(hipSetDevice(p->e->device)); p->e->allreduce_host(v, n); return GR_OK; }
   catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const CommError &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
 }
 // TEST ONLY: join `n` problems of THIS process (same GPU) into an in-process group; afterwards

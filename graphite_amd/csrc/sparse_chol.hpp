@@ -486,9 +486,7 @@ template <typename T> struct SparseChol {
     up(d_panels, h_panels); up(d_trsm, h_trsm); up(d_upd, h_upd); up(d_klist, h_klist); up(d_nz, h_nz);
     d_kptr.upload(h_kptr, stream); d_rptr.upload(h_rptr, stream); up(d_rcols, h_rcols); d_cptr.upload(h_cptr, stream); up(d_crows, h_crows);
     d_camcol.upload(camcol, stream); d_src.upload(src, stream); d_pad.upload(pad, stream);
-    A.alloc((size_t)npad * npad); Linv.alloc((size_t)nt * CH_NB * CH_NB);
-    vb.alloc(npad); vy.alloc(npad); vx.alloc(npad);
-    d_fail.alloc(1);
+    d_fail.alloc(1); // the matrix itself (bytes()) is allocated by allocate(), once the caller has decided to use this solver
     if (!h_fail) GR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_fail), sizeof(int), hipHostMallocDefault));
     if (!attrs_set) {
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sp_gemm<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
@@ -500,6 +498,11 @@ template <typename T> struct SparseChol {
     return true;
   }
   size_t bytes() const { return (size_t)npad * npad * sizeof(T); }
+  // the padded matrix, the tile inverses and the substitution vectors: only after the caller's memory guard / solver choice
+  void allocate() {
+    A.alloc((size_t)npad * npad); Linv.alloc((size_t)nt * CH_NB * CH_NB);
+    vb.alloc(npad); vy.alloc(npad); vx.alloc(npad);
+  }
 
   struct Sc {
     CholProfSink *s;

@@ -263,37 +263,6 @@ public:
   }
 };
 
-// solver/eigen.hpp:16-100 (EigenLDLTSolver): direct solve of (J^T rho' P J damped) x = b.  Here the
-// matrix is assembled densely on the device and handed to the MFMA Cholesky of libgraphite_mi355x.so.
-template <typename T, typename S> class EigenLDLTSolver : public Solver<T, S> {
-  hbm_vector<T> H, Hd;
-  T damping = 0;
-  bool damping_identity = false;
-public:
-  void update_structure(Graph<T, S> *graph, StreamPool &) override {
-    const size_t n = graph->get_hessian_dimension();
-    H.resize(n * n); Hd.resize(n * n);
-  }
-  void update_values(Graph<T, S> *graph, StreamPool &) override {
-    const size_t n = graph->get_hessian_dimension();
-    detail::fill<T>(H.raw(), n * n, T(0));
-    for (auto *fd : graph->get_factor_descriptors()) fd->dense_hessian(H.raw(), n);
-    detail::sync();
-  }
-  void set_damping_factor(Graph<T, S> *, T mu, const bool use_identity, StreamPool &) override { damping = mu; damping_identity = use_identity; }
-  bool solve(Graph<T, S> *graph, T *x, StreamPool &) override {
-    const size_t n = graph->get_hessian_dimension();
-    if (!n) return true;
-    GRAPHITE_HIP(hipMemcpy(Hd.raw(), H.raw(), n * n * sizeof(T), hipMemcpyDefault));
-    detail::k_damp_dense<T><<<detail::blocks(n), detail::TPB>>>(Hd.raw(), n, damping, damping_identity ? 1 : 0);
-    detail::sync();
-    int dev = 0;
-    GRAPHITE_HIP(hipGetDevice(&dev));
-    const gr_status st = gr_dense_cholesky_solve(sizeof(T) == 8 ? GR_F64 : GR_F32, (int64_t)n, Hd.raw(), (int64_t)n, graph->get_b().raw(), x, dev, nullptr, nullptr);
-    return st == GR_OK;
-  }
-};
-
 // ---- Schur elimination for the generic layer ------------------------------------------------------
 // H = [Hpp Hpl; Hlp Hll] is reduced over the vertices marked set_eliminate exactly as the reference does it
 // (schur.hpp:194-302): block-sparse Hessian<T,S> (upper block-CSC), SchurComplement<T,S> built from its structure
@@ -479,6 +448,76 @@ public:
     schur.compute_landmark_update(graph, streams, x + pd, x);
     detail::sync();
     return true;
+  }
+};
+
+// solver/eigen.hpp:16-100 (EigenLDLTSolver) / solver/cudss.hpp:183-256 (cudssSolver): direct solve of the FULL system
+// (J^T rho' P J damped) x = b.  A sparse direct factorisation is free to choose its elimination order, and for a graph whose
+// set_eliminate descriptors form a block-diagonal trailing part (bundle adjustment: the points; examples/bal.cu:156 marks them
+// for every --solver) the order "those vertices first" IS the Schur reduction followed by the back-substitution: the
+// block-diagonal pivots are inverted per vertex, the remaining system is S, and x_l = Hll^-1 (b_l - Hpl^T x_p).  That is what
+// runs here — the block-sparse Hessian / SchurComplement of sparse.hpp and the tile Cholesky of libgraphite_mi355x.so on S —
+// so --solver eigen | cudss works at bundle-adjustment scale with O(blocks) memory; the step equals the reference's
+// (tests/schur.cu:242-289 holds the two to 1e-8 there).  Graphs without eliminated descriptors, or with a storage type other
+// than the graph's, are assembled densely (n^2 memory: small graphs).  On the gr_bal engine: GR_SOLVER_DENSE_SCHUR.
+template <typename T, typename S> class EigenLDLTSolver : public Solver<T, S> {
+  hbm_vector<T> Hd, Hdd;
+  Hessian<T, S> H;
+  SchurComplement<T, S> schur;
+  device_vector<T> dense;
+  T damping = 0;
+  bool damping_identity = false, eliminate_first = false;
+  static constexpr bool same_type = std::is_same<T, S>::value;
+public:
+  EigenLDLTSolver() : schur(H) {}
+  int engine_kind(size_t) const override { return GR_SOLVER_DENSE_SCHUR; }
+  bool uses_elimination_order() const { return eliminate_first; }
+  void update_structure(Graph<T, S> *graph, StreamPool &streams) override {
+    const size_t n = graph->get_hessian_dimension(), pd = graph->get_pose_dimension();
+    eliminate_first = false;
+    if constexpr (same_type) {
+      if (pd > 0 && pd < n) {
+        try {
+          H.build_structure(graph, streams);
+          schur.build_structure(graph, streams); // throws when the eliminated part is not block diagonal
+          dense.resize(schur.get_pose_dimension() * schur.get_pose_dimension());
+          eliminate_first = true;
+        } catch (const std::invalid_argument &) { eliminate_first = false; }
+      }
+    }
+    if (!eliminate_first) { Hd.resize(n * n); Hdd.resize(n * n); }
+  }
+  void update_values(Graph<T, S> *graph, StreamPool &streams) override {
+    if (eliminate_first) { H.update_values(graph, streams); return; }
+    const size_t n = graph->get_hessian_dimension();
+    detail::fill<T>(Hd.raw(), n * n, T(0));
+    for (auto *fd : graph->get_factor_descriptors()) fd->dense_hessian(Hd.raw(), n);
+    detail::sync();
+  }
+  void set_damping_factor(Graph<T, S> *graph, T mu, const bool use_identity, StreamPool &streams) override {
+    damping = mu; damping_identity = use_identity;
+    if (eliminate_first) H.apply_damping(graph, mu, use_identity, streams);
+  }
+  bool solve(Graph<T, S> *graph, T *x, StreamPool &streams) override {
+    const size_t n = graph->get_hessian_dimension();
+    if (!n) return true;
+    int dev = 0;
+    GRAPHITE_HIP(hipGetDevice(&dev));
+    const gr_dtype dt = sizeof(T) == 8 ? GR_F64 : GR_F32;
+    if (eliminate_first) {
+      const size_t pd = schur.get_pose_dimension();
+      schur.update_values(graph, streams);
+      schur.to_dense(dense.raw());
+      detail::fill<T>(x, n, T(0));
+      if (gr_dense_cholesky_solve(dt, (int64_t)pd, dense.raw(), (int64_t)pd, schur.get_b_Schur().raw(), x, dev, nullptr, nullptr) != GR_OK) return false;
+      schur.compute_landmark_update(graph, streams, x + pd, x);
+      detail::sync();
+      return true;
+    }
+    GRAPHITE_HIP(hipMemcpy(Hdd.raw(), Hd.raw(), n * n * sizeof(T), hipMemcpyDefault));
+    detail::k_damp_dense<T><<<detail::blocks(n), detail::TPB>>>(Hdd.raw(), n, damping, damping_identity ? 1 : 0);
+    detail::sync();
+    return gr_dense_cholesky_solve(dt, (int64_t)n, Hdd.raw(), (int64_t)n, graph->get_b().raw(), x, dev, nullptr, nullptr) == GR_OK;
   }
 };
 

@@ -1,6 +1,7 @@
 // graphite/solver/cudss.hpp (reference path): cudssSolver<T,S> is the direct solve of the FULL damped system
 // (solver/cudss.hpp:183-256).  cuDSS does not exist on ROCm; the same role is played by the direct solver of
-// solve.hpp (EigenLDLTSolver: assembly + the MFMA Cholesky of libgraphite_mi355x.so).
+// solve.hpp (EigenLDLTSolver: eliminated vertices first = Schur reduction + back-substitution, the reduced system on the
+// MFMA tile Cholesky of libgraphite_mi355x.so; bundle-adjustment graphs go to the engine's nested-dissection sparse Cholesky).
 #pragma once
 #include "../solve.hpp"
 namespace graphite {

@@ -86,7 +86,9 @@ typedef struct {
   int32_t early_stop;       /* levenberg_marquardt2 (:255-418): also leave after 3 consecutive accepted
                                iterations that each lower chi2 by less than 0.1 % */
   const volatile unsigned char *stop_flag; /* LevenbergMarquardtOptions::stop_flag (a host `bool *`, may be NULL):
-                               polled once per LM iteration, after it, as levenberg_marquardt.hpp:233-238 does */
+                               polled once per LM iteration, after it, as levenberg_marquardt.hpp:233-238 does.  On landmark
+                               shards every rank must pass a flag or none; the ranks agree on it (one scalar all-reduce per
+                               iteration), so they leave the loop together when ANY rank has raised its flag */
 } gr_lm_options;
 
 typedef struct {

@@ -23,6 +23,32 @@ def main():
     prob = synth.make_config("mini-50")
     shard = gdist.partition_by_landmark(prob, rank, world)
     slot = int(os.environ.get("GR_TEST_IPC_SLOT", 1 << 16))
+    if os.environ.get("GR_TEST_IPC_DELAY"):
+        # one rank arrives late at its first collective (after the start-up self-test): within the wait bound (gr_bal_tuning
+        # .ipc_timeout_ms, here through GR_IPC_TIMEOUT_MS) the all-reduce simply takes that long; beyond it the waiting
+        # ranks get GR_ERR_COMM — at once also for every later collective — instead of rank-local values
+        import time
+        late, seconds = os.environ["GR_TEST_IPC_DELAY"].split(":")
+        g = ga.BalProblem(shard.cameras, shard.points, shard.obs, shard.cam_idx, shard.pt_idx, dtype=np.float64, shard=True)
+        assert gdist.init_comm_ipc(g, rank, world, slot_bytes=slot, rccl_fallback=False)
+        lib = _lib.lib()
+        dist.barrier()
+        if rank == int(late):
+            time.sleep(float(seconds))
+        v = np.full(5, float(rank + 1))
+        t0 = time.perf_counter()
+        rc1 = int(lib.gr_bal_comm_allreduce_host(g.h, v.ctypes.data_as(C.POINTER(C.c_double)), C.c_size_t(5)))
+        t1 = time.perf_counter()
+        w = np.full(3, 1.0)
+        rc2 = int(lib.gr_bal_comm_allreduce_host(g.h, w.ctypes.data_as(C.POINTER(C.c_double)), C.c_size_t(3)))
+        t2 = time.perf_counter()
+        with open(out, "w") as f:
+            json.dump({"rc1": rc1, "rc2": rc2, "v": v.tolist(), "w": w.tolist(), "t_first": t1 - t0, "t_second": t2 - t1,
+                       "timeout_ms": g.get_tuning()["ipc_timeout_ms"]}, f)
+        dist.barrier()
+        g.close()
+        dist.destroy_process_group()
+        return
     for dtype, tag in ((np.float64, "f64"), (np.float32, "f32")):
         g = ga.BalProblem(shard.cameras, shard.points, shard.obs, shard.cam_idx, shard.pt_idx, dtype=dtype, shard=True)
         used = gdist.init_comm_ipc(g, rank, world, slot_bytes=slot, rccl_fallback=False)

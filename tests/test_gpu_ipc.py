@@ -85,6 +85,25 @@ def test_ipc_allreduce_between_processes(world, tmp_path):
         assert [len(res[r][key]["pts"]) for r in range(world)] == [b - a for a, b in ranges]
 
 
+def test_late_rank_within_the_wait_bound(tmp_path):
+    """A rank that reaches its first collective 3 s after its peers (first-touch, JIT, host set-up work): with the default
+    30 s bound the all-reduce just waits for it and every rank gets the sum."""
+    res = run_workers(2, tmp_path, {"GR_TEST_IPC_DELAY": "1:3"})
+    for r in res:
+        assert r["timeout_ms"] == 30000 and r["rc1"] == 0 and r["rc2"] == 0
+        assert r["v"] == [3.0] * 5 and r["w"] == [2.0] * 3
+    assert res[0]["t_first"] > 2.0  # rank 0 really waited for the late rank
+
+
+def test_late_rank_beyond_the_wait_bound_is_an_error_not_a_wrong_sum(tmp_path):
+    """The same with the bound set to 0.5 s (gr_bal_tuning.ipc_timeout_ms): the waiting rank gets GR_ERR_COMM, and so does
+    every later collective on that communicator at once (it holds rank-local values: it must not carry on)."""
+    res = run_workers(2, tmp_path, {"GR_TEST_IPC_DELAY": "1:3", "GR_IPC_TIMEOUT_MS": "500"})
+    assert res[0]["timeout_ms"] == 500
+    assert res[0]["rc1"] == 6 and res[0]["rc2"] == 6   # GR_ERR_COMM
+    assert res[0]["t_first"] < 2.5 and res[0]["t_second"] < 0.5
+
+
 def test_bench_two_ranks_share_the_gpu(tmp_path):
     """bench.py's N > 1 path (torch.distributed.run, one process per rank, landmark shards, barriers, max over ranks, the
     Venice `also` line) executed with two ranks on the one GPU of the box (GR_BENCH_SHARE_GPU=1: gloo process group, every

@@ -81,10 +81,9 @@ def test_reference_bal_driver_matches_oracle(oracle_mod, tmp_path, solver, osolv
                          env=dict(os.environ, GR_VERBOSE="1"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     # WHICH path ran: the traits of examples/bal.cuh carry no tag; the hand-over probe finds that their error() / jacobian()
-    # are the engine's model and the hand-written kernels run (the full-H direct solver has no engine counterpart yet)
-    on_engine = "handed to the gr_bal engine" in out.stderr
-    assert "engine hand-over probe" in out.stderr or solver == "eigen", out.stderr[-1500:]
-    assert on_engine == (solver != "eigen"), out.stderr[-1500:]
+    # are the engine's model and the hand-written kernels run — also for --solver eigen (full H): eliminating the points first
+    # is the Schur reduction + back-substitution, so it runs as the engine's direct Schur solve
+    assert "engine hand-over probe" in out.stderr and "handed to the gr_bal engine" in out.stderr, out.stderr[-1500:]
     mse = float(re.search(r"^MSE: ([0-9.eE+-]+)", out.stdout, re.M).group(1))
     ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx)
     ct, _, _ = ref.levenberg_marquardt(solver=getattr(oracle_mod, osolver), iterations=6)
@@ -106,3 +105,24 @@ def test_reference_bal_driver_precisions(tmp_path, precision):
     ref = subprocess.run([exe, path, "--solver", "pcg", "--iterations", "8"], capture_output=True, text=True, timeout=600)
     mse64 = float(re.search(r"^MSE: ([0-9.eE+-]+)", ref.stdout, re.M).group(1))
     assert abs(mse - mse64) / mse64 < {"FP64-FP32": 1e-5, "FP32-FP32": 1e-3, "FP64-BF16": 1e-2}[precision]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["eigen", "cudss"])
+def test_reference_bal_full_system_direct_solver_at_ladybug1723_size(oracle_mod, tmp_path, solver):
+    """`bal.cu --solver eigen | cudss` (EigenLDLTSolver / cudssSolver: direct solve of the FULL system, solver/eigen.hpp:49-98,
+    solver/cudss.hpp:183-256) at Ladybug-1723 size, 485 013 unknowns: the points are eliminated first (= Schur reduction +
+    back-substitution), the reduced camera system goes to the nested-dissection tile Cholesky.  Two LM iterations against the
+    oracle's direct solve (its LDL^T of S: the same elimination order)."""
+    exe = _need("bal")
+    prob = synth.make_config("ladybug-1723")
+    path = str(tmp_path / "ladybug1723.txt")
+    synth.write_bal(path, prob)
+    out = subprocess.run([exe, path, "--solver", solver, "--iterations", "2", "--verbose"], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, GR_VERBOSE="1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "handed to the gr_bal engine" in out.stderr, out.stderr[-1500:]
+    mse = float(re.search(r"^MSE: ([0-9.eE+-]+)", out.stdout, re.M).group(1))
+    ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx)
+    ct, _, _ = ref.levenberg_marquardt(solver=oracle_mod.SOLVER_LDLT_SCHUR, iterations=2)
+    assert abs(mse - ct[-1] / prob.shape[2]) / (ct[-1] / prob.shape[2]) < 1e-6
