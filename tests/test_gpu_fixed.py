@@ -78,7 +78,7 @@ def test_lm_with_fixed_vertices_matches_oracle(oracle_mod, monkeypatch, name, dt
         assert st["pcg_iterations"] == st_r["pcg_iterations"] and st["accepted"] == st_r["accepted"]
         assert np.max(np.abs(ct - ct_r) / ct_r) < 1e-8
     else:
-        assert np.max(np.abs(ct[:4] - ct_r[:4]) / ct_r[:4]) < 2e-3
+        assert np.max(np.abs(ct[:4] - ct_r[:4]) / ct_r[:4]) < 1e-5
 
 
 def test_fixed_vertices_on_landmark_shards(oracle_mod):

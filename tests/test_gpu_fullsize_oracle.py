@@ -104,7 +104,7 @@ def test_venice1778_fp32_block_jacobi_pcg_lm_trace(oracle_mod, venice1778):
     (ct, lt, st), (ct_r, lt_r, st_r), (cg, pg), (cr, pr) = run_pair(
         oracle_mod, venice1778, np.float32, ga.SOLVER_PCG, oracle_mod.SOLVER_PCG, 3)
     assert st["accepted"] == st_r["accepted"]
-    assert abs(st["pcg_iterations"] - st_r["pcg_iterations"]) <= 3
+    assert abs(st["pcg_iterations"] - st_r["pcg_iterations"]) <= 1
     assert rel_trace(ct, ct_r) < 1e-4
     assert np.abs(pg - pr).max() / np.abs(pr).max() < 1e-3
 
@@ -123,18 +123,18 @@ def test_ladybug1723_mixed_precision_lm_trace(oracle_mod, ladybug1723):
 def test_final13682_fp64_block_jacobi_pcg_against_oracle(oracle_mod):
     """configs[4]'s graph at FULL size (13 682 cameras, 4.7 M points, 29 M observations) on one GPU, fp64: the largest
     configuration runs the point-tiled order (run-length-capped tile count), observation-ordered operator output and the
-    direction-kernel PCG form — two LM iterations against the oracle (≈1 min of host time), then the fp32-Jacobian variant
+    direction-kernel PCG form — four LM iterations against the oracle (≈2 min of host time), then the fp32-Jacobian variant
     of the config on the same engine."""
     prob = synth.make_config("final-13682")
     (ct, lt, st), (ct_r, lt_r, st_r), (cg, pg), (cr, pr) = run_pair(
-        oracle_mod, prob, np.float64, ga.SOLVER_PCG, oracle_mod.SOLVER_PCG, 2)
+        oracle_mod, prob, np.float64, ga.SOLVER_PCG, oracle_mod.SOLVER_PCG, 4)
     assert st["accepted"] == st_r["accepted"]
     assert st["pcg_iterations"] == st_r["pcg_iterations"]
     assert rel_trace(ct, ct_r) < 1e-8
     assert np.abs(cg - cr).max() / np.abs(cr).max() < 1e-7
     gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
     gpu.set_jacobian_precision(np.float32)
-    ct32, _, st32 = gpu.levenberg_marquardt(solver=ga.SOLVER_PCG, iterations=2)
+    ct32, _, st32 = gpu.levenberg_marquardt(solver=ga.SOLVER_PCG, iterations=4)
     gpu.close()
     assert ct32[0] == pytest.approx(ct_r[0], rel=1e-12)      # residuals in fp64
     assert rel_trace(ct32, ct_r) < 1e-4                      # fp32 Jacobians move the step at 1e-7 relative

@@ -58,8 +58,9 @@ def test_lm_trace_matches_oracle(oracle_mod, monkeypatch, name, dtype, solver, m
     else:
         # fp32 has converged after three iterations: whether a later step that moves chi2 in its last digits is accepted
         # is a rounding coin flip (the trace then repeats a value), so the traces are compared where both still move
-        assert np.max(np.abs(ct[:4] - ct_r[:4]) / ct_r[:4]) < 2e-3
-        assert abs(ct[-1] - ct_r[-1]) / ct_r[-1] < 2e-3
+        # measured (tools/fp32_parity_probe.py): <= 9e-7 over the whole trace for every solver; bar = SURVEY 8(d)'s fp32 1e-4 / 10
+        assert np.max(np.abs(ct[:4] - ct_r[:4]) / ct_r[:4]) < 1e-5
+        assert abs(ct[-1] - ct_r[-1]) / ct_r[-1] < 1e-5
 
 
 @pytest.mark.parametrize("mode", ["tiled8", "tiled24", "plain_gather", "tiled8_pm", "tiled24_pm", "direction_kernel", "tiled8_direction_kernel", "lazy", "tiled8_lazy"])
@@ -195,4 +196,4 @@ def test_single_reduction_pcg_matches_its_oracle_variant(oracle_mod, monkeypatch
         assert st["pcg_iterations"] == st_c["pcg_iterations"] and st["accepted"] == st_c["accepted"]
         assert np.max(np.abs(ct - ct_c) / ct_c) < 1e-8
     else:
-        assert np.max(np.abs(ct[:4] - ct_c[:4]) / ct_c[:4]) < 2e-3
+        assert np.max(np.abs(ct[:4] - ct_c[:4]) / ct_c[:4]) < 1e-5

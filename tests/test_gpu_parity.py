@@ -43,10 +43,11 @@ def test_linearize_and_hessian(oracle_mod, name, dtype):
     assert relerr(gpu.get("residuals"), ref.get("res")) < tol_for(dtype, 1e-12, 1e-4)
     assert relerr(gpu.get("scales"), ref.get("scales")) < tol_for(dtype, 1e-11, 1e-4)
     # b: fp32 sums of thousands of terms in a different order
-    assert relerr(gpu.get("b"), ref.get("b")) < tol_for(dtype, 1e-10, 2e-3)
-    assert relerr(gpu.get("Hcc"), ref.get("Hcc")) < tol_for(dtype, 1e-10, 2e-3)
-    assert relerr(gpu.get("Hll"), ref.get("Hll")) < tol_for(dtype, 1e-10, 1e-3)
-    assert relerr(gpu.get("Hcp"), ref.get("Hcp")) < tol_for(dtype, 1e-10, 1e-3)
+    # fp32 (measured against the fp64 oracle, tools/fp32_stage_probe.py): b 1.3e-5, Hcc 2e-7, Hll 4e-7, Hcp 5e-7 — bars 10x above
+    assert relerr(gpu.get("b"), ref.get("b")) < tol_for(dtype, 1e-10, 2e-4)
+    assert relerr(gpu.get("Hcc"), ref.get("Hcc")) < tol_for(dtype, 1e-10, 2e-5)
+    assert relerr(gpu.get("Hll"), ref.get("Hll")) < tol_for(dtype, 1e-10, 1e-5)
+    assert relerr(gpu.get("Hcp"), ref.get("Hcp")) < tol_for(dtype, 1e-10, 1e-5)
     gpu.close()
 
 
@@ -98,7 +99,12 @@ def test_solver_solve(oracle_mod, name, dtype, solver):
         assert it_g == it_r
         # PCG amplifies rounding differences with the iteration count
         # measured on MI355X: fp64 <= 5e-11 (25 identity-preconditioned iterations), fp32 <= 9e-4
-        assert relerr(dx_g, dx_r) < tol_for(dtype, 1e-9, 2e-3)
+        # fp32: the bar is the conditioning of the block-Jacobi / Schur blocks, not the assembly — tools/fp32_stage_probe.py and
+        # tools/fp32_dx_probe.py against the fp64 oracle on this problem: every assembled quantity (Hcc, Hll, Hcp, b, scales) is
+        # as close to fp64 as the fp32 oracle's or closer (Hcc 2e-7 vs 8e-7), yet after ONE inner iteration the engine's step
+        # sits 8e-4 from the fp64 step and the fp32 oracle's 3e-4 (Hll^-1 alone: 1.2e-3 vs 8e-4): two fp32 runs of the same
+        # algorithm cannot agree better than either agrees with fp64.  1e-3 for the short solve (was 2e-3), 2e-3 for 25 iterations.
+        assert relerr(dx_g, dx_r) < tol_for(dtype, 1e-9, 1e-3 if max_iter <= 4 else 2e-3)
     gpu.close()
 
 
@@ -121,7 +127,7 @@ def test_pcg_schur_matches_direct_solve(oracle_mod):
 
 @pytest.mark.parametrize("solver", ["pcg_schur", "pcg_schur_implicit", "pcg"])
 @pytest.mark.parametrize("name,dtype,rtol", [("mini-50", np.float64, 1e-9), ("ladybug-49", np.float64, 1e-8),
-                                             ("ladybug-49", np.float32, 2e-3)])
+                                             ("ladybug-49", np.float32, 1e-5)])
 def test_levenberg_marquardt_trace(oracle_mod, name, dtype, rtol, solver):
     """Whole LM loop: chi2 and lambda traces against the oracle (north star: 1e-6 relative in fp64)."""
     prob, gpu, ref = make_pair(oracle_mod, name, dtype)
