@@ -530,6 +530,7 @@ public:
   virtual void compute_Jv(T *res, const T *x) = 0;   // ops/product.hpp:195
   virtual void compute_Jtv(T *out, const T *res) = 0; // ops/product.hpp:405
   virtual T *work_residual() = 0;                 // [internal_count * E] scratch for J v
+  virtual bool compute_Jv_fresh(T * /*res*/, const T * /*x*/) { return false; } // res = J x for the active factors, written not added; false: not available
   virtual size_t error_dimension() const = 0;
   virtual void block_diagonal(size_t slot, T *blocks) = 0; // ops/hessian.hpp:171-270
   virtual size_t num_slots() const = 0;
@@ -812,8 +813,11 @@ template <typename T> __global__ void k_sum_active(const T *v, const size_t *act
   for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
-template <typename T> __global__ void k_sum_partials(const T *partial, int nb, T *out) {
-  if (threadIdx.x == 0) { T s = 0; for (int b = 0; b < nb; ++b) s += partial[b]; *out = s; }
+template <typename T> __global__ void k_sum_partials(const T *partial, int nb, T *out) { // one wave, fixed order
+  T s = 0;
+  for (int b = threadIdx.x; b < nb; b += 64) s += partial[b];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) *out = s;
 }
 
 // J_c^T P J_c' of two columns of (possibly different) slots
@@ -882,6 +886,88 @@ template <typename F, size_t I> __global__ void k_Jv(FactorView<F> fv, typename 
   T s = 0;
   for (size_t c = 0; c < d; ++c) s += (T)Jb[c * E + i] * x[fv.hid[I][v] + c];
   res[f * E + i] += s; // slots are launched one after the other on one stream: no race
+}
+
+// ---- vertex-centric accumulation: the CDNA4 form of the vertex-side sums ---------------------------------------------------
+// The reference adds every factor's contribution to its vertices with one atomicAdd per output scalar (ops/hessian.hpp:171-270,
+// 419-474, ops/linearize.hpp:240-303, ops/product.hpp:228-292): on a bundle-adjustment graph a camera's 81-entry block takes
+// 81 x (its hundreds of observations) atomics to the same addresses, and the sums come out in arrival order.  Here the
+// active factors of every slot are grouped by vertex once per initialize() (vptr / vfac, ascending factor order) and a
+// group of W lanes (a power of two <= 64 chosen from the slot's mean degree) walks ONE vertex's list: lane j takes factors
+// j, j + W, ..., keeps its partial sums in registers, a fixed butterfly over the W lanes follows, lane 0 adds the total to the
+// output.  No atomics, no zero-filled scratch, the same bits every run; a factor's stored Jacobian block is read once per
+// gather.  WHICH as in k_slot: 0 scalar diagonal, 2 b -= J^T rho' P r, 3 out += J^T (rho' P in), 4 block diagonal (one group
+// per (vertex, row)).
+template <typename F, size_t I, int WHICH>
+__global__ void k_gather(FactorView<F> fv, const size_t *__restrict__ vptr, const size_t *__restrict__ vfac, size_t nv, int W,
+                         typename F::Scalar *__restrict__ out, const typename F::Scalar *__restrict__ in) {
+  using T = typename F::Scalar;
+  constexpr size_t d = slot_dim<F, I>(), E = F::E;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t g = t / (size_t)W;
+  const int j = (int)(t % (size_t)W);
+  const size_t v = WHICH == 4 ? g / d : g, row = WHICH == 4 ? g % d : 0;
+  const bool on = v < nv && is_vertex_active(fv.vstate[I], v);
+  T acc[d];
+  for (size_t c = 0; c < d; ++c) acc[c] = T(0);
+  if (on) {
+    for (size_t k = vptr[v] + (size_t)j; k < vptr[v + 1]; k += (size_t)W) {
+      const size_t f = vfac[k];
+      typename F::Storage buf[E * d];
+      const auto *Jb = jac_block<F, I>(fv, f, buf, std::make_index_sequence<F::N>{});
+      const T w = (T)fv.dchi2[f];
+      if constexpr (WHICH == 0) {
+        for (size_t c = 0; c < d; ++c) acc[c] += jtpj(fv, f, Jb + c * E, Jb + c * E) * w;
+      } else if constexpr (WHICH == 4) {
+        for (size_t c = 0; c < d; ++c) acc[c] += jtpj(fv, f, Jb + row * E, Jb + c * E) * w;
+      } else {
+        const T *vec = WHICH == 2 ? fv.residuals + f * E : in + f * E;
+        T pr[E];
+        for (size_t i = 0; i < E; ++i) {
+          T q = 0;
+          for (size_t jj = 0; jj < E; ++jj) q += (T)fv.pmat[f * E * E + i * E + jj] * vec[jj];
+          pr[i] = q;
+        }
+        for (size_t c = 0; c < d; ++c) {
+          T q = 0;
+          for (size_t i = 0; i < E; ++i) q += (T)Jb[c * E + i] * pr[i];
+          acc[c] += q * w;
+        }
+      }
+    }
+  }
+  for (int o = 1; o < W; o <<= 1)
+    for (size_t c = 0; c < d; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+  if (!on || j != 0) return;
+  if constexpr (WHICH == 4) {
+    for (size_t c = 0; c < d; ++c) out[v * d * d + row + c * d] += acc[c];
+  } else {
+    const size_t col = fv.hid[I][v];
+    for (size_t c = 0; c < d; ++c) out[col + c] += (WHICH == 2 ? -acc[c] : acc[c]);
+  }
+}
+// res_f (+)= sum over the slots of J_s x_vs in ONE launch.  ACCUM = true is compute_Jv's public meaning (the reference adds into
+// y and leaves it alone where every vertex is fixed / unused, tests/factor.cu:597-756); ACCUM = false writes the rows, for the
+// matrix-free product of the PCG solver (no zero fill of the scratch before it)
+template <typename F, bool ACCUM, size_t... Is> __global__ void k_Jv_all(FactorView<F> fv, typename F::Scalar *res, const typename F::Scalar *x, std::index_sequence<Is...> seq) {
+  using T = typename F::Scalar;
+  constexpr size_t E = F::E;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= fv.n_active * E) return;
+  const size_t f = fv.active_ids[t / E], i = t % E;
+  T s = 0;
+  auto one = [&](auto slot) {
+    constexpr size_t I = decltype(slot)::value;
+    constexpr size_t d = slot_dim<F, I>();
+    const size_t v = fv.ids[f * F::N + I];
+    if (!is_vertex_active(fv.vstate[I], v)) return;
+    typename F::Storage buf[E * d];
+    const auto *Jb = jac_block<F, I>(fv, f, buf, seq);
+    const size_t col = fv.hid[I][v];
+    for (size_t c = 0; c < d; ++c) s += (T)Jb[c * E + i] * x[col + c];
+  };
+  (one(std::integral_constant<size_t, Is>{}), ...);
+  if (ACCUM) res[f * E + i] += s; else res[f * E + i] = s;
 }
 
 // dense H(col_a, col_b) += rho' J_a^T P J_b for every pair of slots (direct solver only)
@@ -964,6 +1050,11 @@ public:
   std::vector<size_t> local_to_global_map;
   bool store_jacobians = true;
   const T *dynamic_scales = nullptr; // column scales of the current linearisation (dynamic Jacobians only)
+  // active factors grouped by vertex, per slot (k_gather): built by initialize(); GRAPHITE_GENERIC_ATOMICS=1 (debugging
+  // override, read once per initialize) keeps the reference-style atomic kernels instead
+  std::array<hbm_vector<size_t>, N> slot_vptr, slot_vfac;
+  std::array<int, N> slot_lanes{};
+  bool gather_ready = false;
 
   template <typename... VDs> explicit FactorDescriptor(VDs *...vds) {
     static_assert(sizeof...(VDs) == N, "one vertex descriptor per slot");
@@ -1046,6 +1137,29 @@ public:
     }
     init_jacobians(std::make_index_sequence<N>{});
     refresh_table_mirrors();
+    build_vertex_lists();
+  }
+  void build_vertex_lists() {
+    gather_ready = false;
+    if (getenv("GRAPHITE_GENERIC_ATOMICS") && atoi(getenv("GRAPHITE_GENERIC_ATOMICS")) != 0) return;
+    const size_t na = active_count();
+    for (size_t i = 0; i < N; ++i) {
+      const size_t nv = vertex_descriptors[i]->count();
+      std::vector<size_t> ptr(nv + 1, 0), fac(na);
+      for (size_t a = 0; a < na; ++a) ptr[device_ids[active_indices[a] * N + i] + 1]++;
+      size_t used = 0;
+      for (size_t v = 0; v < nv; ++v) { used += ptr[v + 1] != 0; ptr[v + 1] += ptr[v]; }
+      std::vector<size_t> fill(ptr.begin(), ptr.end() - 1);
+      for (size_t a = 0; a < na; ++a) { const size_t f = active_indices[a]; fac[fill[device_ids[f * N + i]]++] = f; } // ascending factor order per vertex
+      slot_vptr[i].assign(ptr.data(), ptr.size());
+      slot_vfac[i].assign(fac.data(), fac.size());
+      // lanes per vertex: half the mean degree of the vertices in use, rounded up to a power of two, at most a wave
+      const size_t mean = used ? (na + used - 1) / used : 1;
+      int w = 1;
+      while (w < 64 && (size_t)(2 * w) <= mean) w <<= 1;
+      slot_lanes[i] = w;
+    }
+    gather_ready = true;
   }
   void flag_active_vertices() override {
     for (size_t i = 0; i < N; ++i)
@@ -1111,14 +1225,22 @@ public:
     GRAPHITE_HIP(hipMemcpy(&v, chi2_vec.raw() + local_id(handle), sizeof(T), hipMemcpyDeviceToHost));
     return v;
   }
-  void scalar_diagonal(T *diag) override { slot_all<0>(diag, nullptr, std::make_index_sequence<N>{}); }
+  void scalar_diagonal(T *diag) override { if (gather_ready) gather_all<0>(diag, nullptr, std::make_index_sequence<N>{}); else slot_all<0>(diag, nullptr, std::make_index_sequence<N>{}); }
   void scale_jacobians(const T *scales) override {
     if (dynamic_jacobians()) dynamic_scales = scales;
     else slot_all<1>(nullptr, scales, std::make_index_sequence<N>{});
   }
-  void compute_b(T *b) override { slot_all<2>(b, nullptr, std::make_index_sequence<N>{}); }
-  void compute_Jtv(T *out, const T *res) override { slot_all<3>(out, res, std::make_index_sequence<N>{}); }
-  void compute_Jv(T *res, const T *x) override { jv_all(res, x, std::make_index_sequence<N>{}); }
+  void compute_b(T *b) override { if (gather_ready) gather_all<2>(b, nullptr, std::make_index_sequence<N>{}); else slot_all<2>(b, nullptr, std::make_index_sequence<N>{}); }
+  void compute_Jtv(T *out, const T *res) override { if (gather_ready) gather_all<3>(out, res, std::make_index_sequence<N>{}); else slot_all<3>(out, res, std::make_index_sequence<N>{}); }
+  void compute_Jv(T *res, const T *x) override {
+    if (gather_ready) { if (active_count()) detail::k_Jv_all<FactorDescriptor, true><<<detail::blocks(active_count() * E), detail::TPB>>>(view(), res, x, std::make_index_sequence<N>{}); }
+    else jv_all(res, x, std::make_index_sequence<N>{});
+  }
+  bool compute_Jv_fresh(T *res, const T *x) override {
+    if (!gather_ready) return false;
+    if (active_count()) detail::k_Jv_all<FactorDescriptor, false><<<detail::blocks(active_count() * E), detail::TPB>>>(view(), res, x, std::make_index_sequence<N>{});
+    return true;
+  }
   T *work_residual() override { return work.raw(); }
   void block_diagonal(size_t slot, T *blocks) override { block_one(slot, blocks, std::make_index_sequence<N>{}); }
   void dense_hessian(T *H, size_t n) override { dense_all(H, n, std::make_index_sequence<N>{}); }
@@ -1250,9 +1372,20 @@ private:
     auto fv = view();
     ((detail::k_Jv<FactorDescriptor, Is><<<detail::blocks(active_count() * E), detail::TPB>>>(fv, res, x)), ...);
   }
+  template <int WHICH, size_t I> void gather_one(detail::FactorView<FactorDescriptor> &fv, T *out, const T *in) {
+    const size_t nv = vertex_descriptors[I]->count(), groups = nv * (WHICH == 4 ? detail::slot_dim<FactorDescriptor, I>() : 1);
+    if (!groups) return;
+    detail::k_gather<FactorDescriptor, I, WHICH><<<detail::blocks(groups * (size_t)slot_lanes[I]), detail::TPB>>>(fv, slot_vptr[I].raw(), slot_vfac[I].raw(), nv, slot_lanes[I], out, in);
+  }
+  template <int WHICH, size_t... Is> void gather_all(T *out, const T *in, std::index_sequence<Is...>) {
+    if (!active_count()) return;
+    auto fv = view();
+    ((gather_one<WHICH, Is>(fv, out, in)), ...);
+  }
   template <size_t... Is> void block_one(size_t slot, T *blocks, std::index_sequence<Is...>) {
     if (!active_count()) return;
     auto fv = view();
+    if (gather_ready) { ((slot == Is ? gather_one<4, Is>(fv, blocks, nullptr) : (void)0), ...); return; }
     ((slot == Is ? (void)(detail::k_slot<FactorDescriptor, Is, 4><<<detail::blocks(active_count() * detail::slot_dim<FactorDescriptor, Is>()), detail::TPB>>>(fv, blocks, nullptr)) : (void)0), ...);
   }
   template <size_t I, size_t... Ks> void dense_row(detail::FactorView<FactorDescriptor> &fv, T *H, size_t n, std::index_sequence<Ks...>) {
@@ -1385,8 +1518,10 @@ public:
   void hessian_matvec(T *out, const T *x) {
     detail::fill<T>(out, hessian_dim, T(0));
     for (auto *fd : factor_descriptors) {
-      detail::fill<T>(fd->work_residual(), fd->internal_count() * fd->error_dimension(), T(0));
-      fd->compute_Jv(fd->work_residual(), x);
+      if (!fd->compute_Jv_fresh(fd->work_residual(), x)) {
+        detail::fill<T>(fd->work_residual(), fd->internal_count() * fd->error_dimension(), T(0));
+        fd->compute_Jv(fd->work_residual(), x);
+      }
       fd->compute_Jtv(out, fd->work_residual());
     }
   }

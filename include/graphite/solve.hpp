@@ -41,34 +41,43 @@ template <typename T> __global__ void k_dot(const T *a, const T *b, size_t n, T 
 }
 // in-place inverse of `count` d x d blocks (column-major) after damping the diagonal
 // (block_jacobi.hpp:120-172; the reference uses cuBLAS matinvBatched = Gauss-Jordan with pivoting)
-template <typename T> __global__ void k_block_inverse(const T *blocks, T *inv, size_t count, int d, T mu, int identity, const uint8_t *state) {
-  const size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+// One thread per block, as the batched inverse of the reference, but the two d x d work matrices live in LDS ([entry][thread], so a
+// wave's accesses to one entry hit 64 banks' worth of consecutive words) instead of dynamically indexed per-thread arrays, which the
+// compiler can only keep in scratch memory: 300 camera blocks of a bundle-adjustment graph took 318 us, 60 000 3 x 3 blocks 160 us.
+// BLOCK_INV_THREADS threads per workgroup: 2 d^2 doubles each, d <= 16 -> at most 128 KB of the CU's 160 KB.
+constexpr int BLOCK_INV_THREADS = 32;
+template <typename T> __global__ void __launch_bounds__(BLOCK_INV_THREADS) k_block_inverse(const T *blocks, T *inv, size_t count, int d, T mu, int identity, const uint8_t *state) {
+  extern __shared__ double lds_inv[];
+  const int tid = threadIdx.x, nt = BLOCK_INV_THREADS;
+  const size_t v = blockIdx.x * (size_t)nt + tid;
   if (v >= count || !is_vertex_active(state, v)) return;
   const T *B = blocks + v * d * d;
   T *X = inv + v * d * d;
-  constexpr int MAXD = 16;
-  double A[MAXD * MAXD], R[MAXD * MAXD];
+  double *A = lds_inv + tid, *R = lds_inv + (size_t)d * d * nt + tid; // entry e of this thread: A[e * nt]
   for (int c = 0; c < d; ++c)
     for (int r = 0; r < d; ++r) {
       double val = (double)B[r + c * d];
       if (r == c) { const double cl = val < 1.0e-6 ? 1.0e-6 : (val > 1.0e32 ? 1.0e32 : val); val += identity ? (double)mu : (double)mu * cl; }
-      A[r + c * d] = val;
-      R[r + c * d] = r == c ? 1.0 : 0.0;
+      A[(r + c * d) * nt] = val;
+      R[(r + c * d) * nt] = r == c ? 1.0 : 0.0;
     }
   for (int k = 0; k < d; ++k) {
     int piv = k;
-    for (int r = k + 1; r < d; ++r) if (fabs(A[r + k * d]) > fabs(A[piv + k * d])) piv = r;
+    for (int r = k + 1; r < d; ++r) if (fabs(A[(r + k * d) * nt]) > fabs(A[(piv + k * d) * nt])) piv = r;
     if (piv != k)
-      for (int c = 0; c < d; ++c) { double t = A[k + c * d]; A[k + c * d] = A[piv + c * d]; A[piv + c * d] = t; t = R[k + c * d]; R[k + c * d] = R[piv + c * d]; R[piv + c * d] = t; }
-    const double ip = 1.0 / A[k + k * d];
-    for (int c = 0; c < d; ++c) { A[k + c * d] *= ip; R[k + c * d] *= ip; }
+      for (int c = 0; c < d; ++c) {
+        double t = A[(k + c * d) * nt]; A[(k + c * d) * nt] = A[(piv + c * d) * nt]; A[(piv + c * d) * nt] = t;
+        t = R[(k + c * d) * nt]; R[(k + c * d) * nt] = R[(piv + c * d) * nt]; R[(piv + c * d) * nt] = t;
+      }
+    const double ip = 1.0 / A[(k + k * d) * nt];
+    for (int c = 0; c < d; ++c) { A[(k + c * d) * nt] *= ip; R[(k + c * d) * nt] *= ip; }
     for (int r = 0; r < d; ++r) {
       if (r == k) continue;
-      const double f = A[r + k * d];
-      for (int c = 0; c < d; ++c) { A[r + c * d] -= f * A[k + c * d]; R[r + c * d] -= f * R[k + c * d]; }
+      const double f = A[(r + k * d) * nt];
+      for (int c = 0; c < d; ++c) { A[(r + c * d) * nt] -= f * A[(k + c * d) * nt]; R[(r + c * d) * nt] -= f * R[(k + c * d) * nt]; }
     }
   }
-  for (int i = 0; i < d * d; ++i) X[i] = (T)R[i];
+  for (int i = 0; i < d * d; ++i) X[i] = (T)R[i * nt];
 }
 template <typename T> __global__ void k_block_apply(const T *inv, const size_t *hid, const uint8_t *state, size_t count, int d, T *z, const T *r) {
   const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -100,8 +109,12 @@ template <typename T, bool RHO> __global__ void k_dot_partial(const T *a, const 
   for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
+// one wave: lane L adds partials L, L + 64, ... in order, then a fixed butterfly (a single thread adding 256 partials took 12 us)
 template <typename T> __global__ void k_dot_final(const T *partial, int nb, T *out) {
-  if (threadIdx.x == 0) { T s = 0; for (int b = 0; b < nb; ++b) s += partial[b]; *out = s; }
+  T s = 0;
+  for (int b = threadIdx.x; b < nb; b += 64) s += partial[b];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) *out = s;
 }
 template <typename T, bool RHO = false> inline T dot(const T *a, const T *b, size_t n, T *scratch /* DOT_SCRATCH elements */, T mu = T(0)) {
   const int nb = (int)std::max<size_t>(1, std::min<size_t>(DOT_BLOCKS, (n + 4 * TPB - 1) / (4 * TPB)));
@@ -161,9 +174,17 @@ public:
   }
   void set_damping_factor(Graph<T, S> *graph, T mu, const bool use_identity, StreamPool &) override {
     auto &vds = graph->get_vertex_descriptors();
+    static const bool lds_ok = [] { // d = 16 needs 128 KB of dynamic LDS
+      GRAPHITE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&detail::k_block_inverse<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * 16 * 16 * detail::BLOCK_INV_THREADS * (int)sizeof(double)));
+      return true;
+    }();
+    (void)lds_ok;
     for (size_t k = 0; k < vds.size(); ++k)
       if (vds[k]->count())
-        detail::k_block_inverse<T><<<detail::blocks(vds[k]->count()), detail::TPB>>>(blocks[k]->raw(), inverses[k]->raw(), vds[k]->count(), (int)vds[k]->dimension(), mu, use_identity ? 1 : 0, vds[k]->device_active_state());
+        detail::k_block_inverse<T><<<(unsigned)((vds[k]->count() + detail::BLOCK_INV_THREADS - 1) / detail::BLOCK_INV_THREADS), detail::BLOCK_INV_THREADS,
+                                     2 * vds[k]->dimension() * vds[k]->dimension() * detail::BLOCK_INV_THREADS * sizeof(double)>>>(
+            blocks[k]->raw(), inverses[k]->raw(), vds[k]->count(), (int)vds[k]->dimension(), mu, use_identity ? 1 : 0, vds[k]->device_active_state());
     detail::sync();
   }
   void apply(Graph<T, S> *graph, T *z, const T *r, StreamPool &) override {
