@@ -1749,7 +1749,7 @@ template <typename T> struct Engine final : EngineBase {
     damping = mu; damping_identity = use_identity;
     T *rec = use_records ? xp.p : nullptr;
     PcgState st = pcg_state();
-    st.x = v_dx.p; st.tol = tol; st.rej = rej;
+    st.x = v_dx.p; st.tol = tol; st.rej = rej; st.ts_op = first_lazy ? 1 : 0;
     if (!pcg_state_clean) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
     pcg_state_clean = false;
     const LmDev *lm = (dec.seq && !dec.report_only) ? lmdev.p : nullptr;
@@ -1775,12 +1775,13 @@ template <typename T> struct Engine final : EngineBase {
       launch_direction(st, 0, tol, rej, v_dx.p, rec, lm, mu, max_iter);
     }
   }
-  // operator of iteration 0 in its lazy form (direction = sigma zs, sigma derived by every wave from the dots of the PCG start)
+  // operator of iteration 0 on the UN-normalised direction s .* z' that k_finalize_bj left in zs (A is linear; the update kernel of
+  // iteration 0 applies sigma = 1 / |r|): the plain kernel, no decision prologue, no first direction launch
   void launch_operator_first(PcgState st, const LmDev *lm, double mu) {
     if constexpr (sizeof(T) == 8) {
-      if (jac32) { k_pcg_operator<T, 0, float, 1><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm); return; }
+      if (jac32) { k_pcg_operator<T, 0, float><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm); return; }
     }
-    k_pcg_operator<T, 0, T, 1><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm);
+    k_pcg_operator<T, 0, T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm);
   }
   // iterations 1 ... of the solve whose head is in the stream; returns once the host has seen the loop leave
   template <bool IDENTITY> void continue_pcg(int max_iter, double tol, double rej) {

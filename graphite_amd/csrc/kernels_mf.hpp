@@ -83,6 +83,7 @@ struct PcgState {
   // the loop decision of the lazy form is taken in the prologue of the NEXT operator launch (pcg_decide)
   void *x, *xb;         // T[n]: solution and its backup (a rejected step restores x)
   long long *ts = nullptr; // pinned (LM loop, fused form): [0] device wall clock when the PCG loop starts, [1] when it has ended
+  int ts_op = 0;           // the loop starts with the operator of iteration 0 (no first direction launch): it takes stamp [0]
   unsigned n;
   double tol, rej;
   __device__ __forceinline__ double *slots(int k, int which) const { return acc + ((size_t)k * NSLOT + which) * NSW; }
@@ -1078,6 +1079,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     if (!pcg_decide<T>(st, k, stp)) return;
     if (slot_sum(st.slots(k, RZP), 0) == 0.0) return; // rz == 0: the next launch's decision closes the loop
   } else if (!(VAR & 32)) {
+    if (k == 0 && st.ts_op && st.ts && blockIdx.x == 0 && threadIdx.x == 0) st.ts[0] = wall_clock64();
     if (st.done[k]) return;                      // direction(k-1) already told the host
     if (slot_sum(st.slots(k, RZP), 0) == 0.0) return; // rz == 0: the direction kernel of this iteration closes the loop
   }
@@ -1278,7 +1280,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
              const T *__restrict__ MinvC, const T *__restrict__ MinvP, PcgState st, int k,
              const LmDev *__restrict__ lm = nullptr, G3Gather gg = G3Gather{}) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
-  T alpha = 0;
+  T alpha = 0, first_sigma = 0;
   constexpr bool CG = (LAZY == 2) && MODE == 1;
   PcgCgStep<T> cg{T(0), T(0), T(0)};
   if (CG) {
@@ -1289,20 +1291,29 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
     const PcgIter it = pcg_iter(st, k);
     if (it.rzp == 0.0) return;
     // T-precision scalars, as the reference keeps them in T on the host;  p.A.p = den + mu p.D.p
+    if (LAZY == 3) {
+      // first iteration without a direction launch: the operator ran on the UN-normalised direction s .* z' (it is linear:
+      // A (sigma z') = sigma A z'), sigma = 1 / |r| is applied here: p.A.p = sigma^2 (den~ + mu z'.D.z')
+      first_sigma = (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(st.slots(0, RR), 0)));
+      const double pdp0 = (double)first_sigma * (double)first_sigma * slot_sum(st.slots(0, ZDZ), 0);
+      if (blockIdx.x == 0 && threadIdx.x == 0) { st.pdp[0] = pdp0; st.beta[0] = 0.0; st.scale[0] = (double)first_sigma; }
+      alpha = (T)it.rz / (T)((double)first_sigma * (double)first_sigma * slot_sum(st.slots(k, DEN), 0) + mu * pdp0);
+    } else
     alpha = (T)it.rz / (T)(slot_sum(st.slots(k, DEN), 0) + mu * st.pdp[k]);
   }
   __shared__ double red[4];
   __shared__ T rs[TPB];
   const unsigned pose_dim = 9u * (unsigned)Nc;
   // lazy direction (PcgState): p_k = beta p_{k-1} + scale z'_k is formed here, stored with ps = s.*p_k; zs = s.*z'_{k+1}
-  // LAZY == 3: the FIRST iteration of the direction-kernel form without its first direction launch — p_0 = sigma z'_0 is formed
-  // (and stored with s .* p_0) here, the operator of iteration 0 ran in its lazy form on zs; x is known to be 0 and is not read;
-  // from the direction launch of iteration 0 on, the loop is the direction-kernel form
+  // LAZY == 3: the FIRST iteration of the direction-kernel form without its first direction launch — the operator of iteration 0
+  // ran (in its plain form) on the un-normalised s .* z'_0 that k_finalize_bj left in zs; sigma = 1 / |r_0| is applied here, where
+  // p_0 = sigma z'_0 is formed and stored; x is known to be 0 and is not read; from the direction launch of iteration 0 on, the
+  // loop is the direction-kernel form
   constexpr bool lazy = LAZY != 0;
   constexpr bool FIRST = LAZY == 3;
   const bool lazy_old = lazy && MODE == 1 && k > 0; // a previous direction exists
   T *pw = const_cast<T *>(p), *psw = static_cast<T *>(st.ps), *zsw = static_cast<T *>(st.zs), *svw = static_cast<T *>(st.sv);
-  const T lz_beta = CG ? cg.beta : (lazy_old ? (T)st.beta[k] : T(0)), lz_scale = CG ? cg.sigma : ((lazy && MODE == 1) ? (T)st.scale[k] : T(0));
+  const T lz_beta = CG ? cg.beta : (lazy_old ? (T)st.beta[k] : T(0)), lz_scale = CG ? cg.sigma : FIRST ? first_sigma : ((lazy && MODE == 1) ? (T)st.scale[k] : T(0));
   const int cam_tiles = (int)((pose_dim + 251u) / 252u), pt_tiles = (Np + 84) / 85;
   double prr = 0, prz = 0, ppz = 0, pzz = 0;
   const double cw = (double)cam_weight;
@@ -1326,7 +1337,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         else {
           pv = lz_scale * zt[t];
           if (lazy_old) pv += lz_beta * p[t];
-          pw[t] = pv; if (!CG) psw[t] = scales[t] * pv;
+          pw[t] = pv; if (!CG && !FIRST) psw[t] = scales[t] * pv;
         }
         pvk = pv;
         T v2;
@@ -1335,7 +1346,8 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
           v2 = lz_scale * (scales[t] * raw) + (use_identity ? (T)mu * uo : (T)mu * diag[t] * uo);
           if (k > 0) v2 += lz_beta * svw[t];
           svw[t] = v2;
-        } else
+        } else if (FIRST) v2 = lz_scale * (scales[t] * raw) + (use_identity ? (T)mu * pv : (T)mu * diag[t] * pv);
+        else
         v2 = scales[t] * raw + (use_identity ? (T)mu * pv : (T)mu * diag[t] * pv);
         const T xo = FIRST ? T(0) : x[t];
         xb[t] = xo;
@@ -1401,7 +1413,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         else {
           pv = lz_scale * zt[t];
           if (lazy_old) pv += lz_beta * p[t];
-          pw[t] = pv; if (!CG) psw[t] = sc * pv;
+          pw[t] = pv; if (!CG && !FIRST) psw[t] = sc * pv;
         }
         const T xo = FIRST ? T(0) : x[t], ro = r[t];
         T raw = 0;
@@ -1433,7 +1445,8 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
           v2 = lz_scale * (sc * raw) + (use_identity ? (T)mu * uo : (T)mu * dg * uo);
           if (k > 0) v2 += lz_beta * svw[t];
           svw[t] = v2;
-        } else
+        } else if (FIRST) v2 = lz_scale * (sc * raw) + (use_identity ? (T)mu * pv : (T)mu * dg * pv);
+        else
         v2 = sc * raw + (use_identity ? (T)mu * pv : (T)mu * dg * pv);
         xb[t] = xo;
         x[t] = alpha * pv + xo;
