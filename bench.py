@@ -206,9 +206,14 @@ def main():
     # one more identical pass with HIP events around every hot kernel (kept out of `value`): the roofline leg
     gpu.set_params(part.cameras, part.points)
     barrier()
-    gpu.levenberg_marquardt(iterations=args.steps, profile=True, **lm_kw)
+    _, _, st_prof = gpu.levenberg_marquardt(iterations=args.steps, profile=True, **lm_kw)
     barrier()
     ks = gpu.kernel_stats()
+    if main_run["st"]["solve_seconds"] <= 0:
+        # host-driven LM forms (Schur solvers, landmark shards) time the solve with HIP events only when profiling is on (an
+        # event between two launches is a ~6 us bubble): solve_seconds then comes from this profiled pass, not from `value`'s
+        main_run["st"]["solve_seconds"] = st_prof["solve_seconds"]
+        main_run["st"]["solve_seconds_from"] = "profiled pass"
 
     n = 9 * Nc + 3 * Np
     w = np.dtype(dtype).itemsize

@@ -1926,15 +1926,19 @@ template <typename T> struct Engine final : EngineBase {
     auto host_iteration = [&](int i) -> bool {
       solver_set_damping(opt.solver, (double)mu, opt.use_identity != 0);
       const int pr = i % 3;
+      // solve_seconds of the host-driven form comes from HIP events, and an event between two launches costs a ~6 us bubble
+      // (k_finalize_bj -> first direction: 6.1 us, last direction -> k_linearize: 6.6 us in the kernel trace): they are only
+      // recorded when the caller asked for timing (options->profile); the fused form stamps the device wall clock instead
       hipEvent_t ev_a = evp.ev[pr][0], ev_b = evp.ev[pr][1];
-      GR_HIP(hipEventRecord(ev_a, stream));
+      const bool time_solve = profiling;
+      if (time_solve) GR_HIP(hipEventRecord(ev_a, stream));
       if (ev_waiting >= 0) { collect_solve_time(ev_waiting); ev_waiting = -1; } // the previous iteration's pair
       const bool speculate = accept_streak >= 2 && spec_enabled;
       int seq = 0;
       // backup_parameters + apply_update + rho-denominator partials + the camera packs in one launch, then the
       // speculative linearisation; `gate` != nullptr: enqueued ahead of the PCG exit flag (run_pcg_iterations)
       auto enqueue_trial = [&](const int *gate) {
-        GR_HIP(hipEventRecord(ev_b, stream));
+        if (time_solve) GR_HIP(hipEventRecord(ev_b, stream));
         rho_blocks = cdiv(Nc, 28) + cdiv(3 * Np, TPB);
         rho_partial.alloc(rho_blocks);
         const bool clear_state = ctl_cap > 0 && pcg_solver;
@@ -1960,7 +1964,7 @@ template <typename T> struct Engine final : EngineBase {
         if (ctl_cap > 0 && pcg_solver) state_clean_cap = ctl_cap;
         if (!(use_records && xp.n && xp_valid)) xp_valid = false;
       } else {
-        GR_HIP(hipEventRecord(ev_b, stream));
+        if (time_solve) GR_HIP(hipEventRecord(ev_b, stream));
         apply_update_dev(v_dx.p, /*with_backup=*/true);
         // trial chi2 + compute_rho denominator (:20-47) in one kernel; its last block mirrors the two
         // sums into pinned host memory, so the host polls one word instead of memcpy + stream sync
@@ -1969,7 +1973,7 @@ template <typename T> struct Engine final : EngineBase {
       wait_chi2(seq);
       const int it = *h_iters(); // every PCG variant mirrors its iteration count into pinned memory
       const double hs[2] = {h_res[0], h_res[1]};
-      ev_waiting = pr;
+      if (time_solve) ev_waiting = pr;
       return decide(i, solve_ok, speculate, it, hs, nullptr);
     };
     // the same iteration in the fused form (lm_fused); solve time from device wall-clock stamps (an event between two launches

@@ -98,7 +98,10 @@ typedef struct {
   int32_t ok;               /* return value of levenberg_marquardt() */
   double setup_seconds;     /* update_structure + first linearize + update_values */
   double loop_seconds;      /* the LM for-loop (host wall clock, stream synchronised) */
-  double solve_seconds;     /* device time inside solver->solve (HIP events)          */
+  double solve_seconds;     /* device time inside solver->solve.  Matrix-free PCG in its fused form (single GPU):
+                               device wall-clock stamps, always filled.  Every other solver / landmark shards: HIP
+                               events around the solve, recorded only with options->profile != 0 (an event between
+                               two launches costs a ~6 us bubble), 0 otherwise */
   double final_chi2;
   int64_t collectives;      /* landmark-sharded runs: collective operations (grouped calls count once) issued inside
                                the LM loop by this rank; 0 without a communicator */
