@@ -42,7 +42,7 @@ static void tuning_default(gr_bal_tuning &t) {
   t.lm_speculate = env_int("GR_LM_SPECULATE", 1);
   t.lm_ahead = env_int("GR_LM_AHEAD", 1);
   t.lm_fused = env_int("GR_LM_FUSED", 1);
-  t.grid_mult = std::max(1, env_int("GR_GRID_MULT", 4));
+  t.grid_mult = std::max(0, env_int("GR_GRID_MULT", 0));
   t.vec_per_thread = std::max(1, env_int("GR_VEC_PER_THREAD", 2)); // replayed back to back on Ladybug-1723: 5.3 us (1), 4.4 (2), 4.9 (4), 5.8 (8)
   t.schur_item = env_int("GR_SCHUR_ITEM", 56);
   t.verbose = getenv("GR_VERBOSE") ? 1 : 0;
@@ -110,6 +110,7 @@ template <typename T> struct Engine final : EngineBase {
   std::vector<int> h_pt_new2old, h_pt_old2new; // internal point order: sorted by first observing camera
   int nch = 0, nb_pm = 0, nseg = 0;
   int num_cu = 256, grid_obs = 0, grid_vec = 0, grid_chi2 = 0; // persistent grids
+  int grid_lin = 0, grid_op = 0; // k_linearize / k_pcg_operator: exactly the workgroups that are resident at once (apply_tuning)
   // Schur structure (lazy)
   bool schur_ready = false;
   int64_t nnzb = 0, nprod = 0;
@@ -352,7 +353,19 @@ template <typename T> struct Engine final : EngineBase {
 
   // persistent grids and the per-problem choices that depend on the tuning; called by the constructor and by gr_bal_set_tuning
   void apply_tuning() override {
-    grid_obs = std::max(8, std::min(nb_pm, num_cu * std::max(1, tune.grid_mult)) & ~7); // multiple of 8: one contiguous tile range per XCD
+    grid_obs = std::max(8, std::min(nb_pm, num_cu * (tune.grid_mult > 0 ? tune.grid_mult : 4)) & ~7); // multiple of 8: one contiguous tile range per XCD
+    // The two heaviest persistent kernels get EXACTLY the workgroups that fit at once (occupancy query), unless grid_mult forces
+    // a count: k_linearize is built for 3 workgroups per CU, and 4 per CU (the old common grid) left a quarter of them waiting
+    // for a free slot — Ladybug-1723 fp64: 38.4 -> 33.8 us (grid x 1 41.5, x 2 36.8, x 3 33.8, x 4 38.4); operator 21.5 -> 20.9
+    auto resident = [&](const void *fn, int dflt, int cap) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = dflt; }
+      const int mult = tune.grid_mult > 0 ? tune.grid_mult : std::min(nb, cap);
+      return std::max(8, std::min(nb_pm, num_cu * mult) & ~7);
+    };
+    grid_lin = resident(reinterpret_cast<const void *>(&k_linearize<T, false>), LIN_WAVES, 8);
+    // the operator prefers 3 (fp64) / 4 (fp32) workgroups per CU even where more would fit (Venice-1778 fp32: 83.6 us at 4, 89.7 at its occupancy)
+    grid_op = resident(reinterpret_cast<const void *>(&k_pcg_operator<T, 0, T>), 3, sizeof(T) == 8 ? 3 : 4);
     // light vector kernels: several elements per thread (every wave first re-derives the loop scalars from the
     // dot-product slots, so one element per thread made that prologue most of the kernel)
     grid_vec = std::max(1, std::min(cdiv(n, (size_t)TPB * std::max(1, tune.vec_per_thread)), num_cu * 8));
@@ -797,7 +810,7 @@ template <typename T> struct Engine final : EngineBase {
     {
       const int np_fin = (int)Np;
       Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
-      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)np_fin, TPB), TPB, 0, stream>>>((int)Nc, np_fin, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
+      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)np_fin, TPB), TPB, 0, stream>>>((int)Nc, np_fin, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
                                                                                                     spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq,
                                                                                                     gate, cam_fixed_p(), pt_fixed_p());
     }
@@ -818,7 +831,7 @@ template <typename T> struct Engine final : EngineBase {
 #ifdef GR_DIAG
     { // diagnostic builds: GR_LIN_VAR=1|2|4|8 runs an ablated lineariser INSIDE the solve (wrong numbers, real cache state)
       static const int var = getenv("GR_LIN_VAR") ? atoi(getenv("GR_LIN_VAR")) : 0;
-#define GR_LINV(V) k_linearize<T, false, T, V><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap)
+#define GR_LINV(V) k_linearize<T, false, T, V><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap)
       if (!hcp && var == 1) { GR_LINV(1); return; }
       if (!hcp && var == 2) { GR_LINV(2); return; }
       if (!hcp && var == 4) { GR_LINV(4); return; }
@@ -828,13 +841,13 @@ template <typename T> struct Engine final : EngineBase {
 #endif
     if constexpr (sizeof(T) == 8) {
       if (jac32) {
-        if (hcp) k_linearize<T, true, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
-        else k_linearize<T, false, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
+        if (hcp) k_linearize<T, true, float><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
+        else k_linearize<T, false, float><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
         return;
       }
     }
-    if (hcp) k_linearize<T, true><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
-    else k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
+    if (hcp) k_linearize<T, true><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
+    else k_linearize<T, false><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
   }
   bool want_hcp = false;
   void linearize() override { linearize_impl(want_hcp); }
@@ -1037,7 +1050,7 @@ template <typename T> struct Engine final : EngineBase {
   // to continue: no bubble); past that the host first waits for the flag, so a loop that leaves where the last
   // one did costs neither a bubble nor no-op launches.  Returns the number of enqueued iterations that ran as
   // no-ops (the loop had already left).
-  int predicted_iters = 0;
+  int predicted_iters = 0, last_active = 0;
   // LM host loop, speculative trial step: at the iteration where the loop is PREDICTED to leave, the trial-step
   // kernels (backup/update/rho, linearise, finalize) are enqueued before the exit flag has been seen, gated on the
   // device by PcgState::left.  Right prediction: the round trip between the last direction kernel and the
@@ -1066,7 +1079,10 @@ template <typename T> struct Engine final : EngineBase {
       if (!trial_done) note_noop({"linearize", "linearize_finalize"}, 1);
     }
     const int active = left ? std::min((int)*h_iters(), enqueued) : enqueued;
-    predicted_iters = active;
+    // next solve's inner iteration count: the last one, extrapolated when the count is falling (10 -> 8 -> 2 -> 1 on the
+    // bench line: "same as last time" enqueued one iteration too many in each of those solves, three no-op launches of 4.7 us)
+    predicted_iters = std::max(1, active + std::min(0, active - last_active));
+    last_active = active;
     return enqueued - active;
   }
   void note_noop(std::initializer_list<const char *> names, int count) {
@@ -1228,16 +1244,16 @@ template <typename T> struct Engine final : EngineBase {
 #ifdef GR_DIAG
     { // diagnostic builds: GR_OP_VAR=1|2|3 runs an ablated operator INSIDE the solve (wrong numbers, real cache state)
       static const int var = getenv("GR_OP_VAR") ? atoi(getenv("GR_OP_VAR")) : 0;
-#define GR_OPV(V) k_pcg_operator<T, V, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm)
+#define GR_OPV(V) k_pcg_operator<T, V, JT><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm)
       if (var == 1) { GR_OPV(1); return; }
       if (var == 2) { GR_OPV(2); return; }
       if (var == 3) { GR_OPV(3); return; }
 #undef GR_OPV
     }
 #endif
-    if (st.lazy == 2) k_pcg_operator<T, 0, JT, 2><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
-    else if (st.lazy) k_pcg_operator<T, 0, JT, 1><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
-    else k_pcg_operator<T, 0, JT><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
+    if (st.lazy == 2) k_pcg_operator<T, 0, JT, 2><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
+    else if (st.lazy) k_pcg_operator<T, 0, JT, 1><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
+    else k_pcg_operator<T, 0, JT><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
   }
   void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
@@ -1427,7 +1443,7 @@ template <typename T> struct Engine final : EngineBase {
     auto launch = [&] {
       switch (which) {
       case 0:
-#define GR_OP(V) k_pcg_operator<T, V><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0, use_records ? xp.p : nullptr)
+#define GR_OP(V) k_pcg_operator<T, V><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0, use_records ? xp.p : nullptr)
 #ifdef GR_DIAG
         switch (variant) { case 1: GR_OP(1); break; case 2: GR_OP(2); break; case 4: GR_OP(4); break; case 7: GR_OP(7); break; case 8: GR_OP(8); break; case 15: GR_OP(15); break; case 16: GR_OP(16); break; case 31: GR_OP(31); break;
                            case 32: GR_OP(32); break; case 64: GR_OP(64); break; case 128: GR_OP(128); break; case 3: GR_OP(3); break; case 95: GR_OP(95); break; case 255: GR_OP(255); break; case 224: GR_OP(224); break; default: GR_OP(0); }
@@ -1437,10 +1453,10 @@ template <typename T> struct Engine final : EngineBase {
         break;
       case 1:
 #ifdef GR_DIAG
-#define GR_LIN(V) k_linearize<T, false, T, V><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p)
+#define GR_LIN(V) k_linearize<T, false, T, V><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p)
         switch (variant) { case 1: GR_LIN(1); break; case 2: GR_LIN(2); break; case 3: GR_LIN(3); break; case 4: GR_LIN(4); break; case 7: GR_LIN(7); break; case 8: GR_LIN(8); break; case 15: GR_LIN(15); break; default: GR_LIN(0); }
 #else
-        k_linearize<T, false><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
+        k_linearize<T, false><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p);
 #endif
         break;
       case 2: chi2_async(nullptr, variant ? v_dx.p : nullptr, 1e-4); break;
@@ -1454,7 +1470,7 @@ template <typename T> struct Engine final : EngineBase {
       case 4: k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr); break;
       case 5: { // variant 1: camera part (+ chi2 block) only, 2: point part only (the blocks of the other part return at once)
         const int nc_v = variant == 2 ? 0 : (int)Nc, np_v = variant == 1 ? 0 : (int)Np;
-        k_linearize_finalize<T><<<cdiv(90 * (size_t)nc_v, TPB) + cdiv(FIN_PL * (size_t)np_v, TPB), TPB, 0, stream>>>(nc_v, np_v, 1, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, variant == 2 ? nullptr : dscalars.p);
+        k_linearize_finalize<T><<<cdiv(90 * (size_t)nc_v, TPB) + cdiv(FIN_PL * (size_t)np_v, TPB), TPB, 0, stream>>>(nc_v, np_v, 1, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, variant == 2 ? nullptr : dscalars.p);
         break;
       }
       case 6: { // block-Jacobi inverses: variant 1 cameras only, 2 points only, 3 with the fused PCG start
@@ -1471,7 +1487,7 @@ template <typename T> struct Engine final : EngineBase {
         if (variant & 4) {
           ensure_lm_buffers();
           rho_partial.alloc(dir_grid());
-          dec.seq = 1; dec.chi2_cur = 1e30; dec.mu_cur = 1e-4; dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_obs; dec.rho_partial = rho_partial.p; dec.n_rho = dir_grid();
+          dec.seq = 1; dec.chi2_cur = 1e30; dec.mu_cur = 1e-4; dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_lin; dec.rho_partial = rho_partial.p; dec.n_rho = dir_grid();
           dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
         }
 #define GR_FBJ(V) k_finalize_bj<T, V><<<nbc + nbp, TPB, 0, stream>>>(nc_v, np_v, nbc, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bu.p, Hll.p, scales.p, 1e-4, 0, MinvC.p, MinvP.p, v_diag.p, st, v_dx.p, v_r.p, v_z.p, nullptr, 0, 1, dec, nullptr, nullptr)
@@ -1729,7 +1745,7 @@ template <typename T> struct Engine final : EngineBase {
   // finalisation of a pending linearisation on its own (loop exit, last iteration): k_linearize_finalize
   void flush_finalize(int spec_seq = 0) {
     Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
-    k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_obs, chi2_partial.p, dscalars.p,
+    k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
                                                                                                        spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, spec_seq ? h_res : nullptr, h_seq, spec_seq, nullptr, cam_fixed_p(), pt_fixed_p());
     fin_pending = false; hcp_valid = false;
   }
@@ -1779,9 +1795,9 @@ template <typename T> struct Engine final : EngineBase {
   // iteration 0 applies sigma = 1 / |r|): the plain kernel, no decision prologue, no first direction launch
   void launch_operator_first(PcgState st, const LmDev *lm, double mu) {
     if constexpr (sizeof(T) == 8) {
-      if (jac32) { k_pcg_operator<T, 0, float><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm); return; }
+      if (jac32) { k_pcg_operator<T, 0, float><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm); return; }
     }
-    k_pcg_operator<T, 0, T><<<grid_obs, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm);
+    k_pcg_operator<T, 0, T><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm);
   }
   // iterations 1 ... of the solve whose head is in the stream; returns once the host has seen the loop leave
   template <bool IDENTITY> void continue_pcg(int max_iter, double tol, double rej) {
@@ -1828,13 +1844,13 @@ template <typename T> struct Engine final : EngineBase {
       // fused form: the first linearisation is finalised by the head of iteration 0 like every other one, and that launch
       // reports the initial chi2 (no separate finalize launch, no synchronising read before the loop)
       ensure_lm_buffers(); ensure_ctl(opt.pcg_max_iter);
-      predicted_iters = opt.pcg_max_iter;
+      predicted_iters = opt.pcg_max_iter; last_active = opt.pcg_max_iter;
       campack();
       linearize_deferred(nullptr);
       fin_pending = true; pcg_state_clean = true;
       LmDecide dec;
       dec.seq = ++seq_counter; dec.report_only = 1;
-      dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_obs; dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
+      dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_lin; dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
       if (opt.solver == GR_SOLVER_PCG_IDENTITY) enqueue_head<true>(dec, (double)mu, opt.use_identity != 0, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, 0);
       else enqueue_head<false>(dec, (double)mu, opt.use_identity != 0, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, 0);
       head_enqueued = true;
@@ -1856,7 +1872,7 @@ template <typename T> struct Engine final : EngineBase {
     // look-ahead predictor: nothing is known about the first solve of this call; from a fresh starting point the inner loop
     // usually runs long, so keep one iteration of look-ahead until it has ended once (a stale count from an earlier call
     // cost ~9 us of host round trip per inner iteration of the first solve, 90 us per call on the bench line)
-    predicted_iters = opt.pcg_max_iter;
+    predicted_iters = opt.pcg_max_iter; last_active = opt.pcg_max_iter;
     auto collect_solve_time = [&](int which) {
       float ms = 0;
       (void)hipEventSynchronize(evp.ev[which][1]);
@@ -2008,7 +2024,7 @@ template <typename T> struct Engine final : EngineBase {
         if (i + 1 < opt.iterations) {
           LmDecide dec;
           dec.seq = seq; dec.chi2_cur = (double)chi2v; dec.mu_cur = (double)mu;
-          dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_obs; dec.rho_partial = rho_partial.p; dec.n_rho = rho_blocks;
+          dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_lin; dec.rho_partial = rho_partial.p; dec.n_rho = rho_blocks;
           dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
           if (ident) enqueue_head<true>(dec, (double)mu, ui, mi, tol, rej, (i + 1) % 4);
           else enqueue_head<false>(dec, (double)mu, ui, mi, tol, rej, (i + 1) % 4);
@@ -2197,7 +2213,7 @@ gr_status gr_bal_destroy(gr_bal_problem *p) {
 void gr_bal_tuning_default(gr_bal_tuning *t) { if (t) tuning_default(*t); }
 gr_status gr_bal_set_tuning(gr_bal_problem *p, const gr_bal_tuning *t) {
   if (!t) { g_last_error = "null tuning"; return GR_ERR_INVALID; }
-  return guarded(p, [&] { p->e->tune = *t; p->e->tune.grid_mult = std::max(1, t->grid_mult); p->e->tune.vec_per_thread = std::max(1, t->vec_per_thread); p->e->apply_tuning(); });
+  return guarded(p, [&] { p->e->tune = *t; p->e->tune.grid_mult = std::max(0, t->grid_mult); p->e->tune.vec_per_thread = std::max(1, t->vec_per_thread); p->e->apply_tuning(); });
 }
 gr_status gr_bal_get_tuning(gr_bal_problem *p, gr_bal_tuning *t) {
   if (!t) { g_last_error = "null tuning"; return GR_ERR_INVALID; }

@@ -124,7 +124,8 @@ typedef struct {
   int32_t lm_speculate;         /* GR_LM_SPECULATE   1: trial chi2 from a speculative linearisation on accept streaks                */
   int32_t lm_ahead;             /* GR_LM_AHEAD       1: trial linearisation enqueued ahead of the PCG exit flag                      */
   int32_t lm_fused;             /* GR_LM_FUSED       1: fused iteration head (k_finalize_bj), trial step inside the last direction   */
-  int32_t grid_mult;            /* GR_GRID_MULT      4: workgroups per CU of the persistent per-observation kernels                 */
+  int32_t grid_mult;            /* GR_GRID_MULT      0: workgroups per CU of the persistent per-observation kernels; 0 = as many as
+                                                       are resident at once (occupancy query per kernel)                             */
   int32_t vec_per_thread;       /* GR_VEC_PER_THREAD 2: elements per thread of the light vector kernels                             */
   int32_t schur_item;           /* GR_SCHUR_ITEM     56: products per work item of the explicit Schur reduction                     */
   int32_t verbose;              /* GR_VERBOSE        0: report the per-problem choices on stderr                                    */
