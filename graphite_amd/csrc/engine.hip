@@ -151,7 +151,9 @@ template <typename T> struct Engine final : EngineBase {
 #ifdef GR_DIAG
     return false; // the ablation variants of tools/diag_*.py are instantiated for the direction-kernel form only
 #endif
-    return lazy_cfg < 0 ? n * sizeof(T) <= ((size_t)1 << 20) : lazy_cfg != 0;
+    // round 3: off by default at every size — the fused LM iteration (direction-kernel form, k_finalize_bj) beats the lazy host
+    // loop also where launches dominate (Ladybug-49 fp32 PCG: 15 590 lazy host loop -> 17 520 LM it/s fused; fp64 14 400 -> 15 170)
+    return lazy_cfg < 0 ? false : lazy_cfg != 0;
   }
   int lazy_cfg = -1; // gr_bal_tuning.pcg_lazy, latched per solver_update_structure
   // Single-reduction PCG (kernels_mf.hpp PcgState, lazy == 2): on landmark shards by default — ONE all-reduce per inner

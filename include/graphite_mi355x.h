@@ -117,7 +117,7 @@ typedef struct {
   int32_t point_tiles;          /* GR_PTILES        -1 auto | 0 plain camera-major order | K point tiles (Engine::build_tiled_order) */
   int32_t g3_gather;            /* GR_G3_GATHER     -1 auto (with point tiles) | 0 | 1: operator output in observation order         */
   int32_t point_records;        /* GR_POINT_RECORDS -1 auto (timed) | 0 | 1: [X Y Z | s.p] records for the operator's gathers        */
-  int32_t pcg_lazy;             /* GR_PCG_LAZY      -1 auto (vectors <= 1 MB) | 0 | 1: no direction kernel                           */
+  int32_t pcg_lazy;             /* GR_PCG_LAZY      -1 auto (= 0 since round 3) | 0 | 1: no direction kernel (host-driven LM loop)   */
   int32_t pcg_single_reduction; /* GR_PCG_CG        -1 auto (with a communicator of > 1 rank) | 0 | 1                                */
   int32_t sparse_cholesky;      /* GR_SPARSE_CHOL   -1 auto (when the camera graph dissects) | 0 dense tile Cholesky | 1             */
   int32_t spchol_overlap;       /* GR_SPCHOL_OVERLAP 1: forward substitution beside the factorisation                               */

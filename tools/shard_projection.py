@@ -64,7 +64,7 @@ def main():
     for r in range(args.world):
         part = gdist.partition_by_landmark(prob, r, args.world)
         g = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype, shard=True)
-        gdist.init_comm_ipc(g, 0, 1, slot_bytes=4 << 20, rccl_fallback=False)
+        gdist.init_comm_ipc(g, 0, 1, slot_bytes=max(4 << 20, 2 * 90 * Nc * 8), rccl_fallback=False)  # one slot holds the largest grouped message (Hcc + bc + chi2)
         tr, st = run(g, part)
         if lat1 is None:
             f = g.lib.gr_bal_diag_time; f.restype = C.c_double
