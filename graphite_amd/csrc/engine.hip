@@ -1466,6 +1466,7 @@ template <typename T> struct Engine final : EngineBase {
         const int nc_v = variant == 2 ? 0 : (int)Nc, np_v = variant == 1 ? 0 : (int)Np;
         int ub = variant >= 8 ? variant : std::max(1, std::min(cdiv(9 * (size_t)nc_v, 252) + cdiv(np_v, 85), num_cu * 8));
         if (g3_obs_order) ub = std::max(8, (ub + 7) / 8 * 8); // the point sweep deals workgroups to XCDs by blockIdx % 8
+        if (variant == 100) { ub = update_blocks(); launch_update<1, false>(ub, v_dx.p, nullptr, 1, ui, st, 0, (int)Nc, (int)Np, nullptr, /*first_lazy=*/true); break; } // the first-iteration form (LAZY = 3)
         launch_update<1, false>(ub, v_dx.p, nullptr, 1, ui, st, 0, nc_v, np_v);
         break;
       }
@@ -1718,6 +1719,7 @@ template <typename T> struct Engine final : EngineBase {
     }
     lmdev.alloc(1);
   }
+  DevBuf<double> fbj_part;      // PcgState::part0
   bool lm_fused = false;        // armed by lm() for GR_SOLVER_PCG / _IDENTITY without a communicator, PCG mode 0, max_iter >= 1
   bool fin_pending = false;     // k_linearize ran, its finalisation is still to come (k_finalize_bj, or flush_finalize)
   bool pcg_state_clean = false; // the PCG loop state has been cleared since the last solve (k_linearize's reset block)
@@ -1768,12 +1770,14 @@ template <typename T> struct Engine final : EngineBase {
     T *rec = use_records ? xp.p : nullptr;
     PcgState st = pcg_state();
     st.x = v_dx.p; st.tol = tol; st.rej = rej; st.ts_op = first_lazy ? 1 : 0;
+    const int fbj_nbc = cdiv(Nc, 28), fbj_nbp = std::max(1, std::min(cdiv(Np, TPB / FIN_PL), num_cu * 4));
+    if (first_lazy) { fbj_part.alloc(3 * (size_t)(fbj_nbc + fbj_nbp)); st.part0 = fbj_part.p; st.n_part0 = fbj_nbc + fbj_nbp; }
     if (!pcg_state_clean) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
     pcg_state_clean = false;
     const LmDev *lm = (dec.seq && !dec.report_only) ? lmdev.p : nullptr;
     const int ui = use_identity ? 1 : 0;
     {
-      const int nbc = cdiv(Nc, 28), nbp = std::max(1, std::min(cdiv(Np, TPB / FIN_PL), num_cu * 4));
+      const int nbc = fbj_nbc, nbp = fbj_nbp;
       Scope sc(this, "finalize_bj", 8.0 * No * w() + 54.0 * nseg * w() + (2 * 90.0 * Nc + 36.0 * Np + 27.0 * Nc) * w(), 9.0 * No + 54.0 * nseg + 900.0 * Nc + 60.0 * Np);
       k_finalize_bj<T><<<nbc + nbp, TPB, 0, stream>>>((int)Nc, (int)Np, nbc, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bu.p, Hll.p, scales.p, mu, ui, MinvC.p, MinvP.p, v_diag.p, st,
                                                       v_dx.p, v_r.p, v_z.p, first_lazy ? v_zs.p : nullptr, IDENTITY ? 1 : 0, 1, dec, cam_fixed_p(), pt_fixed_p());

@@ -84,6 +84,12 @@ struct PcgState {
   void *x, *xb;         // T[n]: solution and its backup (a rejected step restores x)
   long long *ts = nullptr; // pinned (LM loop, fused form): [0] device wall clock when the PCG loop starts, [1] when it has ended
   int ts_op = 0;           // the loop starts with the operator of iteration 0 (no first direction launch): it takes stamp [0]
+  // ... and in that form k_finalize_bj leaves the three dots of the PCG start (r.r, r.z', z'.D.z') as one partial per workgroup
+  // here ([3][n_part0]) instead of adding them to the slots with atomics at its very end (5 us of tail: 3 x 1 086 atomics that
+  // all workgroups issue at the same moment); the LAST workgroup of the operator launch of iteration 0 — which does not need
+  // them — adds them in workgroup order into slot 0 while the others already work: off the critical path, and reproducible
+  double *part0 = nullptr;
+  int n_part0 = 0;
   unsigned n;
   double tol, rej;
   __device__ __forceinline__ double *slots(int k, int which) const { return acc + ((size_t)k * NSLOT + which) * NSW; }
@@ -498,7 +504,8 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
   __syncthreads();
   if (threadIdx.x < 3 && !(VAR & 8)) {
     const double v = red3[0][threadIdx.x] + red3[1][threadIdx.x] + red3[2][threadIdx.x] + red3[3][threadIdx.x];
-    slot_add(st.slots(0, threadIdx.x == 0 ? RR : threadIdx.x == 1 ? RZP : ZDZ), 0, v);
+    if (zs && st.part0) st.part0[(size_t)threadIdx.x * st.n_part0 + blockIdx.x] = v; // threadIdx 0: r.r, 1: r.z', 2: z'.D.z'
+    else slot_add(st.slots(0, threadIdx.x == 0 ? RR : threadIdx.x == 1 ? RZP : ZDZ), 0, v);
   }
 }
 
@@ -1081,9 +1088,22 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
   } else if (!(VAR & 32)) {
     if (k == 0 && st.ts_op && st.ts && blockIdx.x == 0 && threadIdx.x == 0) st.ts[0] = wall_clock64();
     if (st.done[k]) return;                      // direction(k-1) already told the host
-    if (slot_sum(st.slots(k, RZP), 0) == 0.0) return; // rz == 0: the direction kernel of this iteration closes the loop
+    // rz == 0: the direction kernel of this iteration closes the loop.  (Iteration 0 of the first-lazy form: the dots are
+    // still per-workgroup partials — summed below — and a zero r.z' only makes the update kernel return.)
+    if (!(k == 0 && st.ts_op && st.part0) && slot_sum(st.slots(k, RZP), 0) == 0.0) return;
   }
   __shared__ double red[4];
+  if (LAZY == 0 && k == 0 && st.ts_op && st.part0 && blockIdx.x == gridDim.x - 1) {
+    // PcgState::part0: the PCG start's dots, one partial per workgroup of k_finalize_bj, summed here in workgroup order
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double v = 0;
+      for (int i = threadIdx.x; i < st.n_part0; i += TPB) v += st.part0[(size_t)q * st.n_part0 + i];
+      v = block_sum_256(v, red);
+      if (threadIdx.x == 0) st.slots(0, q == 0 ? RR : q == 1 ? RZP : ZDZ)[0] = v;
+    }
+    __syncthreads();
+  }
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
   const size_t pose_dim = 9 * (size_t)Nc;
@@ -1288,18 +1308,23 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
     alpha = cg.alpha;
   } else if (MODE == 1) {
     if (st.done[k]) return;
-    const PcgIter it = pcg_iter(st, k);
+    // the dot products of this iteration in one go (slot_sums): r.z', r.r, den (and z'.D.z' for the first iteration)
+    const double *const sl[4] = {st.slots(k, RZP), st.slots(k, RR), st.slots(k, DEN), st.slots(k, ZDZ)};
+    double sv[4];
+    slot_sums<4>(sl, sv);
+    PcgIter it;
+    it.rzp = sv[0]; it.rscale = 1.0 / sqrt(sv[1]); it.rz = it.rzp * it.rscale;
     if (it.rzp == 0.0) return;
     // T-precision scalars, as the reference keeps them in T on the host;  p.A.p = den + mu p.D.p
     if (LAZY == 3) {
       // first iteration without a direction launch: the operator ran on the UN-normalised direction s .* z' (it is linear:
       // A (sigma z') = sigma A z'), sigma = 1 / |r| is applied here: p.A.p = sigma^2 (den~ + mu z'.D.z')
-      first_sigma = (T)(1.0 / (double)(T)sqrt((double)(T)slot_sum(st.slots(0, RR), 0)));
-      const double pdp0 = (double)first_sigma * (double)first_sigma * slot_sum(st.slots(0, ZDZ), 0);
+      first_sigma = (T)(1.0 / (double)(T)sqrt((double)(T)sv[1]));
+      const double pdp0 = (double)first_sigma * (double)first_sigma * sv[3];
       if (blockIdx.x == 0 && threadIdx.x == 0) { st.pdp[0] = pdp0; st.beta[0] = 0.0; st.scale[0] = (double)first_sigma; }
-      alpha = (T)it.rz / (T)((double)first_sigma * (double)first_sigma * slot_sum(st.slots(k, DEN), 0) + mu * pdp0);
+      alpha = (T)it.rz / (T)((double)first_sigma * (double)first_sigma * sv[2] + mu * pdp0);
     } else
-    alpha = (T)it.rz / (T)(slot_sum(st.slots(k, DEN), 0) + mu * st.pdp[k]);
+    alpha = (T)it.rz / (T)(sv[2] + mu * st.pdp[k]);
   }
   __shared__ double red[4];
   __shared__ T rs[TPB];
@@ -1578,15 +1603,20 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
     const double rz0 = st.rz0[k];
     const bool was_done = st.done[k] != 0; // an earlier direction launch ended the loop (and applied the step)
     bool leave = was_done;
+    // every dot product this launch may need, in one go (slot_sums): records k and k + 1
+    const double *const sl[6] = {st.slots(k, RZP), st.slots(k, RR), st.slots(k + 1, RZP), st.slots(k + 1, RR), st.slots(k + 1, PDZ), st.slots(k + 1, ZDZ)};
+    double sv[6];
+    slot_sums<6>(sl, sv);
     PcgIter it{};
-    if (!leave) { it = pcg_iter(st, k); leave = (it.rzp == 0.0); }
+    if (!leave) { it.rzp = sv[0]; it.rscale = 1.0 / sqrt(sv[1]); it.rz = it.rzp * it.rscale; leave = (it.rzp == 0.0); }
     if (leave) {
       if (first) { st.done[k + 1] = 1; st.rz0[k + 1] = rz0; if (st.left) *st.left = 1; st.hflag[k] = 2; __threadfence_system(); }
       if (ap.cams && !was_done) apply_on_exit<T>(ap, n, pose_dim, x, scales, mu, nullptr); // r.z == 0: x is final
       return;
     }
-    const PcgIter nx = pcg_iter(st, k + 1);
-    const double pdz = slot_sum(st.slots(k + 1, PDZ), 0), zdz = slot_sum(st.slots(k + 1, ZDZ), 0);
+    PcgIter nx;
+    nx.rzp = sv[2]; nx.rscale = 1.0 / sqrt(sv[3]); nx.rz = nx.rzp * nx.rscale;
+    const double pdz = sv[4], zdz = sv[5];
     const T rz = (T)it.rzp * (T)(double)(T)it.rscale, rz_new = (T)nx.rzp * (T)(double)(T)nx.rscale;
     const bool reject = (fabs((double)rz_new) > rejection_ratio * rz0) || (rz_new != rz_new);
     const bool done_next = reject || fabs((double)rz_new) < tol;
