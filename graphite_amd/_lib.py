@@ -30,7 +30,7 @@ EXPORTS = [
     "gr_dense_cholesky_solve", "gr_bal_model_evaluate", "gr_bal_tuning_default", "gr_bal_set_tuning", "gr_bal_get_tuning",
 ]
 # include/graphite_mi355x_test.h (test / diagnostic entry points, not part of the drop-in boundary)
-TEST_EXPORTS = ["gr_bal_comm_init_local", "gr_bal_diag_time", "gr_bal_comm_allreduce_host"]
+TEST_EXPORTS = ["gr_bal_comm_init_local", "gr_bal_diag_time", "gr_bal_comm_allreduce_host", "gr_test_lane_xor"]
 
 
 class GraphiteError(RuntimeError):

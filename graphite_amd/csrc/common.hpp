@@ -59,12 +59,65 @@ template <typename T> struct DevBuf {
   }
 };
 
-// ---- wave64 / block reductions -----------------------------------------------
-template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v; // valid in lane 0
+// ---- cross-lane exchange without LDS ------------------------------------------------------------------------------------
+// lane i <- lane i ^ OFFSET for OFFSET = 1, 2, 4, 8 as DPP moves (plain VALU instructions): quad_perm for 1 and 2, row_ror:8 for
+// 8, two bank-masked row rotations for 4.  hipcc lowers __shfl_xor to ds_bpermute_b32 whatever the pattern — an LDS-crossbar
+// instruction with ~100 cycles of latency on the dependent chains of the butterflies below (the kernels had 43-294 of them and
+// not one DPP move).  OFFSET 16 / 32 keep the bpermute here; the transpose reductions use v_permlane16/32_swap for those.
+template <int CTRL, int BANK> __device__ __forceinline__ unsigned dpp_mov(unsigned old, unsigned src) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, BANK, false);
 }
+template <int OFFSET> __device__ __forceinline__ unsigned lane_xor_u32(unsigned v) {
+  static_assert(OFFSET == 1 || OFFSET == 2 || OFFSET == 4 || OFFSET == 8, "DPP forms exist for 1, 2, 4, 8");
+  if constexpr (OFFSET == 1) return dpp_mov<0xB1, 0xf>(v, v);      // quad_perm [1, 0, 3, 2]
+  else if constexpr (OFFSET == 2) return dpp_mov<0x4E, 0xf>(v, v); // quad_perm [2, 3, 0, 1]
+  else if constexpr (OFFSET == 8) return dpp_mov<0x128, 0xf>(v, v); // row_ror:8
+  else { // row_ror:n: lane i of a 16-lane row reads lane (i - n) mod 16.  Lanes 4-7, 12-15 (banks 1, 3) take i - 4, the others i + 4 = i - 12
+    const unsigned t = dpp_mov<0x124, 0xA>(v, v);
+    return dpp_mov<0x12C, 0x5>(t, v);
+  }
+}
+template <int OFFSET> __device__ __forceinline__ float lane_xor(float v) { return __builtin_bit_cast(float, lane_xor_u32<OFFSET>(__builtin_bit_cast(unsigned, v))); }
+template <int OFFSET> __device__ __forceinline__ int lane_xor(int v) { return (int)lane_xor_u32<OFFSET>((unsigned)v); }
+template <int OFFSET> __device__ __forceinline__ double lane_xor(double v) {
+  uint2 u = __builtin_bit_cast(uint2, v);
+  u.x = lane_xor_u32<OFFSET>(u.x); u.y = lane_xor_u32<OFFSET>(u.y);
+  return __builtin_bit_cast(double, u);
+}
+// v + (v of lane ^ OFFSET) for the six butterfly steps of a wave
+template <typename T> __device__ __forceinline__ T butterfly_low(T v) { // offsets 8, 4, 2, 1: DPP
+  v += lane_xor<8>(v); v += lane_xor<4>(v); v += lane_xor<2>(v); v += lane_xor<1>(v);
+  return v;
+}
+
+// gfx950 half / row exchanges: v_permlane32_swap swaps lanes 32-63 of `a` with lanes 0-31 of `b`, v_permlane16_swap the odd
+// 16-lane rows of `a` with the even rows of `b`.  After the swap every lane holds (its own value, its partner's) in (a, b) or
+// (b, a); with a == b == v that is the xor-32 / xor-16 butterfly step, again without LDS.
+template <int OFFSET> __device__ __forceinline__ void lane_swap(unsigned &a, unsigned &b) {
+  if constexpr (OFFSET == 32) { const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r[0]; b = r[1]; }
+  else { const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r[0]; b = r[1]; }
+}
+template <int OFFSET> __device__ __forceinline__ float swap_add(float a, float b) {
+  unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+  lane_swap<OFFSET>(ua, ub);
+  return __builtin_bit_cast(float, ua) + __builtin_bit_cast(float, ub);
+}
+template <int OFFSET> __device__ __forceinline__ double swap_add(double a, double b) {
+  uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  lane_swap<OFFSET>(ua.x, ub.x);
+  lane_swap<OFFSET>(ua.y, ub.y);
+  return __builtin_bit_cast(double, ua) + __builtin_bit_cast(double, ub);
+}
+
+// ---- wave64 / block reductions -----------------------------------------------
+// butterfly sum: every lane gets the wave total.  All six steps without LDS: permlane swaps for 32 / 16, DPP for 8 / 4 / 2 / 1;
+// the partners and the order of the steps are those of the __shfl_xor butterfly, so the bits are too.
+template <typename T> __device__ __forceinline__ T wave_allsum(T v) {
+  v = swap_add<32>(v, v);
+  v = swap_add<16>(v, v);
+  return butterfly_low(v);
+}
+template <typename T> __device__ __forceinline__ T wave_sum(T v) { return wave_allsum(v); } // (valid in every lane)
 
 // Sum over a 256-thread block; result valid in thread 0.  smem: >= 4 T.
 template <typename T> __device__ __forceinline__ T block_sum_256(T v, T *smem) {
@@ -74,13 +127,6 @@ template <typename T> __device__ __forceinline__ T block_sum_256(T v, T *smem) {
   if (lane == 0) smem[wave] = v;
   __syncthreads();
   if (threadIdx.x == 0) v = smem[0] + smem[1] + smem[2] + smem[3];
-  return v;
-}
-
-// butterfly sum: every lane gets the wave total
-template <typename T> __device__ __forceinline__ T wave_allsum(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
@@ -105,26 +151,6 @@ template <typename T, int NV> __device__ __forceinline__ void seg_scan(T (&v)[NV
 // other half to its partner (lane ^ offset).  On return lane L holds the wave total of
 // value index (NV == 64 ? L : L >> 2).  Template recursion keeps every array index a
 // compile-time constant (the array must stay in VGPRs).
-// gfx950 half / row exchanges: v_permlane32_swap swaps lanes 32-63 of `a` with lanes 0-31 of `b`,
-// v_permlane16_swap the odd 16-lane rows of `a` with the even rows of `b`.  After the swap every lane
-// holds (its kept value, its partner's copy of the same value) in (a, b) or (b, a): the transpose step is
-// the swap plus one add, without the two selects and the crossbar shuffle of the generic form.
-template <int OFFSET> __device__ __forceinline__ void lane_swap(unsigned &a, unsigned &b) {
-  if constexpr (OFFSET == 32) { const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r[0]; b = r[1]; }
-  else { const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r[0]; b = r[1]; }
-}
-template <int OFFSET> __device__ __forceinline__ float swap_add(float a, float b) {
-  unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
-  lane_swap<OFFSET>(ua, ub);
-  return __builtin_bit_cast(float, ua) + __builtin_bit_cast(float, ub);
-}
-template <int OFFSET> __device__ __forceinline__ double swap_add(double a, double b) {
-  uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
-  lane_swap<OFFSET>(ua.x, ub.x);
-  lane_swap<OFFSET>(ua.y, ub.y);
-  return __builtin_bit_cast(double, ua) + __builtin_bit_cast(double, ub);
-}
-
 template <typename T, int NV, int HALF, int OFFSET> struct TransposeStep {
   static __device__ __forceinline__ void run(T (&v)[NV], int lane) {
     if constexpr (OFFSET == 32 || OFFSET == 16) {
@@ -136,7 +162,7 @@ template <typename T, int NV, int HALF, int OFFSET> struct TransposeStep {
       for (int i = 0; i < HALF; ++i) {
         const T keep = hi ? v[i + HALF] : v[i];
         const T send = hi ? v[i] : v[i + HALF];
-        v[i] = keep + __shfl_xor(send, OFFSET, 64);
+        v[i] = keep + lane_xor<OFFSET>(send);
       }
     }
     TransposeStep<T, NV, HALF / 2, OFFSET / 2>::run(v, lane);
@@ -149,7 +175,7 @@ template <typename T, int NV> __device__ __forceinline__ T wave_transpose_sum(T 
   static_assert(NV == 64 || NV == 16, "NV must be 16 or 64");
   TransposeStep<T, NV, NV / 2, 32>::run(v, lane);
   T r = v[0];
-  if (NV == 16) { r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64); }
+  if (NV == 16) { r += lane_xor<2>(r); r += lane_xor<1>(r); }
   return r;
 }
 
@@ -181,12 +207,7 @@ template <int N> __device__ __forceinline__ void slot_sums(const double *const (
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] = base[i][(size_t)(threadIdx.x & 63) * SS];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += __shfl_xor(v[i], o, 64);
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) out[i] = v[i];
+  for (int i = 0; i < N; ++i) out[i] = wave_allsum(v[i]);
 }
 // index of partial i (0 <= i < count * NS) of an array of logical scalars, for the loops that clear them
 __device__ __forceinline__ size_t slot_word(int i) { return (size_t)(i / NS) * NSW + (size_t)(i % NS) * SS; }

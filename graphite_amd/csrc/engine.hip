@@ -2407,6 +2407,32 @@ gr_status gr_bal_comm_allreduce_host(gr_bal_problem *p, double *v, size_t n) {
   catch (const CommError &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
 }
+// TEST ONLY: the DPP lane exchanges of common.hpp (lane_xor<1 | 2 | 4 | 8>) against __shfl_xor on every lane, 32- and 64-bit;
+// *mismatches = number of (offset, lane, width) triples that differ
+__global__ void k_test_lane_xor(int *bad) {
+  const int lane = threadIdx.x & 63;
+  const unsigned u = 0x9E3779B9u * (unsigned)(lane + 1);
+  const double d = 1.0 + lane * 0.125 + (double)u * 1e-12;
+  int n = 0;
+  n += lane_xor_u32<1>(u) != (unsigned)__shfl_xor((int)u, 1, 64); n += lane_xor_u32<2>(u) != (unsigned)__shfl_xor((int)u, 2, 64);
+  n += lane_xor_u32<4>(u) != (unsigned)__shfl_xor((int)u, 4, 64); n += lane_xor_u32<8>(u) != (unsigned)__shfl_xor((int)u, 8, 64);
+  n += lane_xor<1>(d) != __shfl_xor(d, 1, 64); n += lane_xor<2>(d) != __shfl_xor(d, 2, 64);
+  n += lane_xor<4>(d) != __shfl_xor(d, 4, 64); n += lane_xor<8>(d) != __shfl_xor(d, 8, 64);
+  double s = d;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  n += wave_allsum(d) != s;
+  if (n) atomicAdd(bad, n);
+}
+gr_status gr_test_lane_xor(int device, int *mismatches) {
+  if (!mismatches) { g_last_error = "gr_test_lane_xor: bad argument"; return GR_ERR_INVALID; }
+  try {
+    GR_HIP(hipSetDevice(device));
+    DevBuf<int> bad; bad.alloc(1); bad.zero(nullptr);
+    k_test_lane_xor<<<4, 256>>>(bad.p);
+    *mismatches = bad.download(nullptr)[0];
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+}
 // TEST ONLY: join `n` problems of THIS process (same GPU) into an in-process group; afterwards
 // every collective call (linearize, solve, levenberg_marquardt ...) must be made concurrently,
 // one host thread per problem.  Exercises the sharded algorithm on a 1-GPU box.

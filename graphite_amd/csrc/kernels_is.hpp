@@ -53,7 +53,7 @@ __device__ __forceinline__ void reduce_by_camera(bool valid, int c, int segf, co
   unsigned long long remaining = __ballot(valid);
   while (remaining) {
     const int leader = __builtin_ctzll(remaining);
-    const int cl = __shfl(c, leader, 64);
+    const int cl = __builtin_amdgcn_readlane(c, leader); // leader is wave-uniform (from a ballot): v_readlane, not ds_bpermute
     const int segl = seg_slot[segf++];
     const bool mine = valid && c == cl;
     T v[NV];

@@ -441,9 +441,7 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
         }
       }
 #pragma unroll
-      for (int o = 1; o < FIN_PL; o <<= 1)
-#pragma unroll
-        for (int i = 0; i < 9; ++i) v[i] += __shfl_xor(v[i], o, 64);
+      for (int i = 0; i < 9; ++i) { v[i] += lane_xor<1>(v[i]); v[i] += lane_xor<2>(v[i]); } // DPP quad_perm, not ds_bpermute
       if (!on) continue;
       const bool pfixed = pt_fixed && pt_fixed[l];
       if (pfixed) {
@@ -750,7 +748,7 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
     int segf = blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)]; // flat id of the block's first (run, block) segment; the next runs follow
     while (remaining) {
       const int leader = __builtin_ctzll(remaining);
-      const int cl = __shfl(c, leader, 64);
+      const int cl = __builtin_amdgcn_readlane(c, leader); // leader is wave-uniform (from a ballot): v_readlane, not ds_bpermute
       const int segl = seg_slot[segf++];
       const bool mine = valid && c == cl;
       const T wm = mine ? w : T(0);
@@ -834,10 +832,9 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
       v[7] -= c1.x * e.x + c1.y * e.y;
       v[8] -= c2.x * e.x + c2.y * e.y;
     }
+    static_assert(FIN_PL == 4, "quad butterfly");
 #pragma unroll
-    for (int o = 1; o < FIN_PL; o <<= 1)
-#pragma unroll
-      for (int i = 0; i < 9; ++i) v[i] += __shfl_xor(v[i], o, 64);
+    for (int i = 0; i < 9; ++i) { v[i] += lane_xor<1>(v[i]); v[i] += lane_xor<2>(v[i]); } // DPP quad_perm, not ds_bpermute
     const bool pfixed = pt_fixed && pt_fixed[l];
     if (pfixed) {
 #pragma unroll
@@ -1151,7 +1148,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     int segf = blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)];
     while (remaining) {
       const int leader = __builtin_ctzll(remaining);
-      const int cl = __builtin_amdgcn_readfirstlane(__shfl(c, leader, 64));
+      const int cl = __builtin_amdgcn_readlane(c, leader); // leader is wave-uniform (from a ballot): v_readlane, not ds_bpermute
       const bool mine = valid && c == cl;
       const int segl = (VAR & 64) ? (j >> 6) : seg_slot[segf++];
       T pk[PACK], pc[9];
@@ -1250,7 +1247,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
       int segf = blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)];
       while (remaining) {
         const int leader = __builtin_ctzll(remaining);
-        const int cl = __shfl(c, leader, 64);
+        const int cl = __builtin_amdgcn_readlane(c, leader); // leader is wave-uniform (from a ballot): v_readlane, not ds_bpermute
         const int segl = seg_slot[segf++];
         const bool mine = valid && c == cl;
         T m[16];

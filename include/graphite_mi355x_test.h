@@ -16,6 +16,8 @@ gr_status gr_bal_comm_init_local(gr_bal_problem **problems, int n);
 gr_status gr_bal_comm_allreduce_host(gr_bal_problem *p, double *host_values, size_t n);
 /* mean device time (us) of `reps` back-to-back launches of one hot kernel (tools/diag_*.py) */
 double gr_bal_diag_time(gr_bal_problem *p, int which, int variant, int reps);
+/* the DPP lane exchanges of csrc/common.hpp against __shfl_xor on every lane; *mismatches must come back 0 */
+gr_status gr_test_lane_xor(int device, int *mismatches);
 #ifdef __cplusplus
 }
 #endif

@@ -269,3 +269,12 @@ def test_levenberg_marquardt2_early_termination(oracle_mod, solver):
     assert st_full["iterations_run"] > st["iterations_run"]
     assert np.allclose(ct_full[:len(ct_g)], ct_g, rtol=1e-9)
     gpu.close()
+
+
+def test_dpp_lane_exchanges_equal_shfl_xor():
+    """common.hpp lane_xor<1|2|4|8> (DPP quad_perm / row_ror moves) and the wave sums built on them against __shfl_xor, every lane"""
+    import ctypes as C
+    from graphite_amd import _lib
+    bad = C.c_int(-1)
+    _lib.check(_lib.lib().gr_test_lane_xor(C.c_int(0), C.byref(bad)))
+    assert bad.value == 0
