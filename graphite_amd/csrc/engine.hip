@@ -10,6 +10,7 @@
 // The C ABI at the bottom (include/graphite_mi355x.h) is the drop-in boundary.
 #include "../../include/graphite_mi355x_test.h"
 #include "comm.hpp"
+#include <hip/hip_ext.h>
 #include <functional>
 #include "kernels_is.hpp"
 #include "chol.hpp"
@@ -690,21 +691,34 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   // ---- profiling ------------------------------------------------------------------
+  // A scope's two events ride ON the first launch() inside it (hipExtLaunchKernelGGL start / stop events: the
+  // dispatch packet's own begin / end stamps, what rocprofv3 reports) — no marker packets between kernels, which
+  // cost a ~4-6 us bubble each.  Scopes whose body goes through no launch() fall back to recording around it.
+  hipEvent_t ext_a = nullptr, ext_b = nullptr;
   struct Scope {
-    Engine *e; KernelProf *kp = nullptr; hipEvent_t a{}, b{};
-    Scope(Engine *e_, const char *name, double bytes, double flops) : e(e_) {
+    Engine *e; KernelProf *kp = nullptr; hipEvent_t a{}, b{}; bool ext;
+    Scope(Engine *e_, const char *name, double bytes, double flops, bool ext_ = false) : e(e_), ext(ext_) {
       if (!e->profiling) return;
       kp = &e->prof[name];
       kp->name = name; kp->bytes += bytes; kp->flops += flops; kp->scoped++;
       (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-      (void)hipEventRecord(a, e->stream);
+      if (ext) { e->ext_a = a; e->ext_b = b; }
+      else (void)hipEventRecord(a, e->stream);
     }
     ~Scope() {
       if (!kp) return;
-      (void)hipEventRecord(b, e->stream);
+      if (ext && e->ext_a == a) { e->ext_a = e->ext_b = nullptr; (void)hipEventRecord(a, e->stream); ext = false; } // nothing launched
+      if (!ext) (void)hipEventRecord(b, e->stream);
       kp->pending.emplace_back(a, b);
     }
   };
+  template <typename K, typename... A> void launch(K kernel, size_t grid, A... args) {
+    if (ext_a) {
+      hipEvent_t a = ext_a, b = ext_b;
+      ext_a = ext_b = nullptr;
+      hipExtLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(TPB), 0, stream, a, b, 0, args...);
+    } else hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(TPB), 0, stream, args...);
+  }
   void flush_prof() {
     for (auto &it : prof) {
       for (auto &ev : it.second.pending) {
@@ -806,13 +820,13 @@ template <typename T> struct Engine final : EngineBase {
     {
       // algorithmic bytes: every array touched once (obs, 3 index streams, points, packs, g9 out, partials, Hcp)
       const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
-      Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)));
+      Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)), true);
       launch_linearize_cam(write_hcp, g9.p, gate);
     }
     {
       const int np_fin = (int)Np;
-      Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
-      k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)np_fin, TPB), TPB, 0, stream>>>((int)Nc, np_fin, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
+      Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg, true);
+      launch(k_linearize_finalize<T>, cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)np_fin, TPB), (int)Nc, np_fin, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
                                                                                                     spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq,
                                                                                                     gate, cam_fixed_p(), pt_fixed_p());
     }
@@ -833,7 +847,7 @@ template <typename T> struct Engine final : EngineBase {
 #ifdef GR_DIAG
     { // diagnostic builds: GR_LIN_VAR=1|2|4|8 runs an ablated lineariser INSIDE the solve (wrong numbers, real cache state)
       static const int var = getenv("GR_LIN_VAR") ? atoi(getenv("GR_LIN_VAR")) : 0;
-#define GR_LINV(V) k_linearize<T, false, T, V><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap)
+#define GR_LINV(V) launch(k_linearize<T, false, T, V>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap)
       if (!hcp && var == 1) { GR_LINV(1); return; }
       if (!hcp && var == 2) { GR_LINV(2); return; }
       if (!hcp && var == 4) { GR_LINV(4); return; }
@@ -843,13 +857,13 @@ template <typename T> struct Engine final : EngineBase {
 #endif
     if constexpr (sizeof(T) == 8) {
       if (jac32) {
-        if (hcp) k_linearize<T, true, float><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
-        else k_linearize<T, false, float><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
+        if (hcp) launch(k_linearize<T, true, float>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
+        else launch(k_linearize<T, false, float>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
         return;
       }
     }
-    if (hcp) k_linearize<T, true><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
-    else k_linearize<T, false><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
+    if (hcp) launch(k_linearize<T, true>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
+    else launch(k_linearize<T, false>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
   }
   bool want_hcp = false;
   void linearize() override { linearize_impl(want_hcp); }
@@ -1246,16 +1260,16 @@ template <typename T> struct Engine final : EngineBase {
 #ifdef GR_DIAG
     { // diagnostic builds: GR_OP_VAR=1|2|3 runs an ablated operator INSIDE the solve (wrong numbers, real cache state)
       static const int var = getenv("GR_OP_VAR") ? atoi(getenv("GR_OP_VAR")) : 0;
-#define GR_OPV(V) k_pcg_operator<T, V, JT><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm)
+#define GR_OPV(V) launch(k_pcg_operator<T, V, JT>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm)
       if (var == 1) { GR_OPV(1); return; }
       if (var == 2) { GR_OPV(2); return; }
       if (var == 3) { GR_OPV(3); return; }
 #undef GR_OPV
     }
 #endif
-    if (st.lazy == 2) k_pcg_operator<T, 0, JT, 2><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
-    else if (st.lazy) k_pcg_operator<T, 0, JT, 1><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
-    else k_pcg_operator<T, 0, JT><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
+    if (st.lazy == 2) launch(k_pcg_operator<T, 0, JT, 2>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
+    else if (st.lazy) launch(k_pcg_operator<T, 0, JT, 1>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
+    else launch(k_pcg_operator<T, 0, JT>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
   }
   void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
@@ -1263,10 +1277,10 @@ template <typename T> struct Engine final : EngineBase {
   }
   template <int MODE, bool IDENTITY> void launch_update(int blocks, T *x, const T *rawc, int cw, int ui, PcgState st, int k, int nc = -1, int np = -1, const LmDev *lm = nullptr, bool first_lazy = false) {
     const int nc_v = nc < 0 ? (int)Nc : nc, np_v = np < 0 ? (int)Np : np;
-    if (st.lazy == 2) k_pcg_update<T, MODE, IDENTITY, 2><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
-    else if (st.lazy) k_pcg_update<T, MODE, IDENTITY, 1><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
-    else if (first_lazy) k_pcg_update<T, MODE, IDENTITY, 3><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather());
-    else k_pcg_update<T, MODE, IDENTITY><<<blocks, TPB, 0, stream>>>(nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather());
+    if (st.lazy == 2) launch(k_pcg_update<T, MODE, IDENTITY, 2>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
+    else if (st.lazy) launch(k_pcg_update<T, MODE, IDENTITY, 1>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
+    else if (first_lazy) launch(k_pcg_update<T, MODE, IDENTITY, 3>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather());
+    else launch(k_pcg_update<T, MODE, IDENTITY>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather());
   }
   // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
   // touched once): obs + 3 index streams, ps, packs, points, g3 out, segment partials
@@ -1317,7 +1331,7 @@ template <typename T> struct Engine final : EngineBase {
     if (!started) launch_update<0, IDENTITY>(ublocks, x, rawc, cw, ui, st, 0);
     if (comm && st.lazy != 2) allreduce_d(st.acc, 4 * (size_t)NSW); // record 0: RZP, RR, PDZ, ZDZ (single-reduction form: rides in the first iteration's message)
     auto enqueue_operator = [&](int k) {
-      Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
+      Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0, true);
       launch_operator(st, k, rec, nullptr, damping);
     };
     auto enqueue_update = [&](int k) {
@@ -1329,7 +1343,7 @@ template <typename T> struct Engine final : EngineBase {
         group_end();
       }
       {
-        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
+        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np), true);
         launch_update<1, IDENTITY>(ublocks, x, rawc, cw, ui, st, k);
       }
       if (comm) allreduce_d(st.acc + (size_t)(k + 1) * NSLOT * NSW, 4 * (size_t)NSW);
@@ -1350,7 +1364,7 @@ template <typename T> struct Engine final : EngineBase {
           allreduce_d(st.acc + (size_t)k * NSLOT * NSW, (size_t)NSLOT * NSW); // RZP, RR, PDZ, ZDZ, DEN of record k
           group_end();
         }
-        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
+        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np), true);
         launch_update<1, IDENTITY>(ublocks, x, rawc, cw, ui, st, k);
       };
       int enq = 0;
@@ -1409,13 +1423,13 @@ template <typename T> struct Engine final : EngineBase {
       note_noop({"pcg_update"}, ran - active);
       return;
     }
-    k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, rec);
+    launch(k_pcg_direction<T>, grid_vec, (unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, rec, nullptr, 0.0, ApplyOnExit<T>{});
     auto enqueue = [&](int k) {
       enqueue_operator(k);
       enqueue_update(k);
       {
-        Scope s3(this, "pcg_direction", 5.0 * n * sizeof(T), 3.0 * n);
-        k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej, (unsigned)pose_dim, rec);
+        Scope s3(this, "pcg_direction", 5.0 * n * sizeof(T), 3.0 * n, true);
+        launch(k_pcg_direction<T>, grid_vec, (unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej, (unsigned)pose_dim, rec, nullptr, 0.0, ApplyOnExit<T>{});
       }
     };
     note_noop({"pcg_operator", "pcg_update", "pcg_direction"}, run_pcg_iterations(max_iter, enqueue));
@@ -1442,7 +1456,7 @@ template <typename T> struct Engine final : EngineBase {
     else k_pcg_direction<T><<<grid_vec, TPB, 0, stream>>>((unsigned)n, v_dx.p, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, -1, 0.0, 1e30, (unsigned)pose_dim, use_records ? xp.p : nullptr);
     hipEvent_t a, b;
     GR_HIP(hipEventCreate(&a)); GR_HIP(hipEventCreate(&b));
-    auto launch = [&] {
+    auto one_launch = [&] {
       switch (which) {
       case 0:
 #define GR_OP(V) k_pcg_operator<T, V><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, damping, st, 0, use_records ? xp.p : nullptr)
@@ -1510,9 +1524,9 @@ template <typename T> struct Engine final : EngineBase {
       }
     };
     if (which == 8) tmp.zero(stream);
-    for (int i = 0; i < 3; ++i) launch();
+    for (int i = 0; i < 3; ++i) one_launch();
     GR_HIP(hipEventRecord(a, stream));
-    for (int i = 0; i < reps; ++i) launch();
+    for (int i = 0; i < reps; ++i) one_launch();
     GR_HIP(hipEventRecord(b, stream));
     GR_HIP(hipEventSynchronize(b));
     float ms = 0;
@@ -1735,21 +1749,21 @@ template <typename T> struct Engine final : EngineBase {
     return ap;
   }
   void launch_direction(PcgState st, int k, double tol, double rej, T *x, T *rec, const LmDev *lm, double mu, int max_iter) {
-    Scope s3(this, "pcg_direction", 5.0 * n * sizeof(T), 3.0 * n);
-    k_pcg_direction<T><<<lm_fused ? dir_grid() : grid_vec, TPB, 0, stream>>>((unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej, (unsigned)pose_dim, rec, lm, mu, apply_args(k, max_iter));
+    Scope s3(this, "pcg_direction", 5.0 * n * sizeof(T), 3.0 * n, true);
+    launch(k_pcg_direction<T>, lm_fused ? dir_grid() : grid_vec, (unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej, (unsigned)pose_dim, rec, lm, mu, apply_args(k, max_iter));
   }
   // k_linearize alone (LM loop, fused form): the finalisation follows in k_finalize_bj; its last workgroup clears the PCG loop state
   void linearize_deferred(const int *gate) {
     const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w();
-    Scope sc(this, "linearize", bytes, No * (250.0 + 48 + 117));
+    Scope sc(this, "linearize", bytes, No * (250.0 + 48 + 117), true);
     lin_reset = ctl_cap > 0;
     launch_linearize_cam(false, g9.p, gate);
     lin_reset = false;
   }
   // finalisation of a pending linearisation on its own (loop exit, last iteration): k_linearize_finalize
   void flush_finalize(int spec_seq = 0) {
-    Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg);
-    k_linearize_finalize<T><<<cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), TPB, 0, stream>>>((int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
+    Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg, true);
+    launch(k_linearize_finalize<T>, cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), (int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
                                                                                                        spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, spec_seq ? h_res : nullptr, h_seq, spec_seq, nullptr, cam_fixed_p(), pt_fixed_p());
     fin_pending = false; hcp_valid = false;
   }
@@ -1778,20 +1792,20 @@ template <typename T> struct Engine final : EngineBase {
     const int ui = use_identity ? 1 : 0;
     {
       const int nbc = fbj_nbc, nbp = fbj_nbp;
-      Scope sc(this, "finalize_bj", 8.0 * No * w() + 54.0 * nseg * w() + (2 * 90.0 * Nc + 36.0 * Np + 27.0 * Nc) * w(), 9.0 * No + 54.0 * nseg + 900.0 * Nc + 60.0 * Np);
-      k_finalize_bj<T><<<nbc + nbp, TPB, 0, stream>>>((int)Nc, (int)Np, nbc, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bu.p, Hll.p, scales.p, mu, ui, MinvC.p, MinvP.p, v_diag.p, st,
+      Scope sc(this, "finalize_bj", 8.0 * No * w() + 54.0 * nseg * w() + (2 * 90.0 * Nc + 36.0 * Np + 27.0 * Nc) * w(), 9.0 * No + 54.0 * nseg + 900.0 * Nc + 60.0 * Np, true);
+      launch(k_finalize_bj<T>, nbc + nbp, (int)Nc, (int)Np, nbc, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bu.p, Hll.p, scales.p, mu, ui, MinvC.p, MinvP.p, v_diag.p, st,
                                                       v_dx.p, v_r.p, v_z.p, first_lazy ? v_zs.p : nullptr, IDENTITY ? 1 : 0, 1, dec, cam_fixed_p(), pt_fixed_p());
     }
     fin_pending = false; hcp_valid = false;
     if (!first_lazy) launch_direction(st, -1, 0.0, 1e30, v_dx.p, rec, lm, mu, max_iter);
     if (max_iter > 0) {
       {
-        Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0);
+        Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0, true);
         if (first_lazy) launch_operator_first(st, lm, mu); // lazy form on zs: no first direction launch
         else launch_operator(st, 0, rec, lm, mu);
       }
       {
-        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
+        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np), true);
         launch_update<1, IDENTITY>(update_blocks(), v_dx.p, nullptr, 1, ui, st, 0, -1, -1, lm, first_lazy);
       }
       launch_direction(st, 0, tol, rej, v_dx.p, rec, lm, mu, max_iter);
@@ -1801,9 +1815,9 @@ template <typename T> struct Engine final : EngineBase {
   // iteration 0 applies sigma = 1 / |r|): the plain kernel, no decision prologue, no first direction launch
   void launch_operator_first(PcgState st, const LmDev *lm, double mu) {
     if constexpr (sizeof(T) == 8) {
-      if (jac32) { k_pcg_operator<T, 0, float><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm); return; }
+      if (jac32) { launch(k_pcg_operator<T, 0, float>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm); return; }
     }
-    k_pcg_operator<T, 0, T><<<grid_op, TPB, 0, stream>>>((int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm);
+    launch(k_pcg_operator<T, 0, T>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm);
   }
   // iterations 1 ... of the solve whose head is in the stream; returns once the host has seen the loop leave
   template <bool IDENTITY> void continue_pcg(int max_iter, double tol, double rej) {
@@ -1812,9 +1826,9 @@ template <typename T> struct Engine final : EngineBase {
     st.x = v_dx.p; st.tol = tol; st.rej = rej;
     const int ui = damping_identity ? 1 : 0;
     auto enqueue = [&](int k) {
-      { Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0); launch_operator(st, k, rec, nullptr, damping); }
+      { Scope s1(this, "pcg_operator", operator_bytes(), No * 340.0, true); launch_operator(st, k, rec, nullptr, damping); }
       {
-        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np));
+        Scope s2(this, "pcg_update", 9.0 * n * sizeof(T) + (81.0 * Nc + 9.0 * Np) * sizeof(T) + 9.0 * nseg * sizeof(T) + 3.0 * No * sizeof(T), 16.0 * n + 2.0 * (81.0 * Nc + 9.0 * Np), true);
         launch_update<1, IDENTITY>(update_blocks(), v_dx.p, nullptr, 1, ui, st, k);
       }
       launch_direction(st, k, tol, rej, v_dx.p, rec, nullptr, damping, max_iter);
