@@ -27,9 +27,6 @@ namespace gr {
 #ifndef OP_WAVES
 #define OP_WAVES 4
 #endif
-#ifndef OP_SGPR
-#define OP_SGPR 1
-#endif
 #ifndef FIN_PL
 #ifndef UPD_VAR
 #define UPD_VAR 0 // diagnostic builds only: ablations of the update kernel's point part
@@ -1124,7 +1121,6 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     const int jn = j + tstep * TPB;
     const bool validn = (t + tstep < t1) && jn < No;
     if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm ? pos_cm[jn] : jn; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
-#if OP_SGPR
     // Wave-uniform camera data (24-scalar pack, 9 direction scalars, segment id) are fetched per DISTINCT
     // camera of the wave through a uniform index, i.e. with scalar loads into SGPRs: the kernel keeps its
     // VGPRs for the per-observation state and more waves fit per SIMD.  Almost every wave has one camera.
@@ -1205,60 +1201,6 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
       }
       remaining &= ~__ballot(mine);
     }
-#else
-    T acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = T(0);
-    if (valid) {
-      T pk[PACK], pc[9];
-      load_pack(pack, c, pk);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) pc[i] = lazy ? lz_scale * zs[9 * (size_t)c + i] + (lazy_old ? lz_beta * ps[9 * (size_t)c + i] : T(0)) : ps[9 * (size_t)c + i];
-      const T *plg = ps + pose_dim + 3 * (size_t)((VAR & 4) ? (j & 1023) : l), *zlg = zs + pose_dim + 3 * (size_t)((VAR & 4) ? (j & 1023) : l);
-      T pl[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) pl[i] = lazy ? lz_scale * zlg[i] + (lazy_old ? lz_beta * plg[i] : T(0)) : plg[i];
-      const size_t lp = (VAR & 2) ? (size_t)(j & 1023) : (size_t)l;
-      T e0, e1, Jc[18], Jp[6];
-      if (VAR & 8) {
-        e0 = o.x; e1 = o.y;
-#pragma unroll
-        for (int i = 0; i < 18; ++i) Jc[i] = pts[3 * lp + (i % 3)] + pk[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Jp[i] = pts[3 * lp + (i % 3)] - pk[i];
-      } else
-        bal_linearize_j<T, JT>(pk, pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2], o.x, o.y, e0, e1, Jc, Jp);
-      const T w = loss_drho(loss_kind, loss_delta, e0 * e0 + e1 * e1);
-      T u0 = Jp[0] * pl[0] + Jp[2] * pl[1] + Jp[4] * pl[2];
-      T u1 = Jp[1] * pl[0] + Jp[3] * pl[1] + Jp[5] * pl[2];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { u0 += Jc[2 * i] * pc[i]; u1 += Jc[2 * i + 1] * pc[i]; }
-      den += (double)(w * (u0 * u0 + u1 * u1));
-      u0 *= w; u1 *= w;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) acc[i] = Jc[2 * i] * u0 + Jc[2 * i + 1] * u1;
-      T *g = g3 + 3 * ((VAR & 1) ? (size_t)j : a);
-      g[0] = Jp[0] * u0 + Jp[1] * u1;
-      g[1] = Jp[2] * u0 + Jp[3] * u1;
-      g[2] = Jp[4] * u0 + Jp[5] * u1;
-    }
-    if (!(VAR & 16)) {
-      unsigned long long remaining = __ballot(valid);
-      int segf = blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)];
-      while (remaining) {
-        const int leader = __builtin_ctzll(remaining);
-        const int cl = __builtin_amdgcn_readlane(c, leader); // leader is wave-uniform (from a ballot): v_readlane, not ds_bpermute
-        const int segl = seg_slot[segf++];
-        const bool mine = valid && c == cl;
-        T m[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) m[i] = mine ? acc[i] : T(0);
-        const T tot = wave_transpose_sum<T, 16>(m, lane);
-        if ((lane & 3) == 0 && (lane >> 2) < 9) op_partial[9 * (size_t)segl + (lane >> 2)] = tot;
-        remaining &= ~__ballot(mine);
-      }
-    }
-#endif
     valid = validn;
     j = jn;
   }
