@@ -538,8 +538,12 @@ public:
   virtual void dense_hessian(T *H, size_t n) = 0; // upper + lower, for the direct solver
   // block-sparse Hessian (sparse.hpp, hessian.hpp:45-330): upper block coordinates touched by the active factors
   // (scalar_to_block: Hessian column -> block column), where each (factor, vertex pair) block lives, accumulation
-  virtual void block_pairs(std::vector<BlockCoordinates> &coords, const std::vector<size_t> &scalar_to_block) = 0;
-  virtual void sparse_setup(const std::function<size_t(size_t, size_t)> &value_offset_of, const std::vector<size_t> &scalar_to_block) = 0;
+  // The symbolic phase runs on the device (the reference walks an unordered_map on the host, hessian.hpp:257-288): every
+  // descriptor writes one 64-bit key (col << 32 | row, ~0 = no block) per active factor and vertex pair i < k, the Hessian
+  // sorts / uniques them, and each descriptor then finds its blocks by binary search in the sorted key list.
+  virtual size_t block_key_count() = 0;                                                       // active factors x N (N - 1) / 2
+  virtual void emit_block_keys(uint64_t *keys, const size_t *scalar_to_block) = 0;            // device pointers
+  virtual void sparse_setup(const uint64_t *keys, size_t num_keys, const size_t *value_offsets, const size_t *scalar_to_block) = 0;
   virtual void sparse_hessian(S *values) = 0;
   // A factor descriptor whose traits declare `static constexpr bool bal_reprojection_model = true` (camera 9 =
   // [angle-axis, t, f, k1, k2], point 3, pixel residual of examples/reprojection_error.cuh) can hand its active
@@ -1006,6 +1010,52 @@ template <typename F, size_t I, size_t K> __global__ void k_sparse_pair(FactorVi
   atomicAdd(&values[off + idx], (typename F::Storage)val);
 }
 
+hd_fn inline uint64_t pack_block_key(size_t row, size_t col) { return ((uint64_t)col << 32) | (uint64_t)row; }
+// position of `key` in the sorted unique key list (it is there by construction)
+__device__ inline size_t find_block_key(const uint64_t *keys, size_t n, uint64_t key) {
+  size_t lo = 0, hi = n;
+  while (lo < hi) { const size_t mid = (lo + hi) / 2; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+// block column of every slot of factor f (npos: that vertex has no column — fixed / unused)
+template <typename F> __device__ inline void slot_blocks(const FactorView<F> &fv, size_t f, const size_t *s2b, size_t (&blk)[F::N]) {
+  for (size_t i = 0; i < F::N; ++i) {
+    const size_t v = fv.ids[f * F::N + i];
+    blk[i] = is_vertex_active(fv.vstate[i], v) ? s2b[fv.hid[i][v]] : ~size_t(0);
+  }
+}
+template <typename F> __global__ void k_block_keys(FactorView<F> fv, const size_t *s2b, uint64_t *keys) {
+  const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (a >= fv.n_active) return;
+  size_t blk[F::N];
+  slot_blocks<F>(fv, fv.active_ids[a], s2b, blk);
+  size_t p = a * (F::N * (F::N - 1) / 2);
+  for (size_t i = 0; i < F::N; ++i)
+    for (size_t k = i + 1; k < F::N; ++k, ++p) {
+      const bool none = blk[i] == ~size_t(0) || blk[k] == ~size_t(0) || blk[i] == blk[k];
+      keys[p] = none ? ~uint64_t(0) : pack_block_key(blk[i] < blk[k] ? blk[i] : blk[k], blk[i] < blk[k] ? blk[k] : blk[i]);
+    }
+}
+// per active factor and vertex pair i <= k (row-major upper enumeration): value offset of its block, top bit set when the
+// block's rows belong to slot k (the transpose is stored); npos when the pair has no block
+template <typename F> __global__ void k_sparse_dst(FactorView<F> fv, const size_t *s2b, const uint64_t *keys, size_t nkeys, const size_t *offsets, size_t *dst) {
+  const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (a >= fv.n_active) return;
+  size_t blk[F::N];
+  slot_blocks<F>(fv, fv.active_ids[a], s2b, blk);
+  size_t p = a * (F::N * (F::N + 1) / 2);
+  for (size_t i = 0; i < F::N; ++i)
+    for (size_t k = i; k < F::N; ++k, ++p) {
+      size_t d = ~size_t(0);
+      if (blk[i] != ~size_t(0) && blk[k] != ~size_t(0) && (i == k || blk[i] != blk[k])) {
+        const bool swap = blk[k] < blk[i];
+        d = offsets[find_block_key(keys, nkeys, pack_block_key(swap ? blk[k] : blk[i], swap ? blk[i] : blk[k]))];
+        if (swap) d |= size_t(1) << 63;
+      }
+      dst[p] = d;
+    }
+}
+
 template <typename VD> __global__ void k_flag_vertices(const size_t *active_ids, size_t n_active, const size_t *ids, size_t N, size_t I, uint8_t *state) {
   const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (a >= n_active) return;
@@ -1044,7 +1094,7 @@ public:
   std::array<JacobianStorage, N> jacobians;
   managed_vector<T> scalar;                // device scalar for reductions
   hbm_vector<T> sum_partials;
-  managed_vector<size_t> sparse_dst;       // [active factor][vertex pair] -> value offset in the block-sparse Hessian
+  hbm_vector<size_t> d_sparse_dst;         // [active factor][vertex pair] -> value offset in the block-sparse Hessian (written by k_sparse_dst)
   HandleManager<size_t> hm;                // factor.hpp:158-174: ids returned by add_factor are stable handles
   std::unordered_map<size_t, size_t> global_to_local_map;
   std::vector<size_t> local_to_global_map;
@@ -1178,7 +1228,7 @@ public:
     }
     void refresh(const managed_vector<U> &h) { if constexpr (ok) d.assign(h.raw(), h.size()); }
   };
-  TableMirror<size_t> m_active, m_ids, m_sparse_dst;
+  TableMirror<size_t> m_active, m_ids;
   TableMirror<ObservationType> m_obs;
   TableMirror<ConstraintDataType> m_data;
   TableMirror<LossType> m_loss;
@@ -1246,42 +1296,13 @@ public:
   void dense_hessian(T *H, size_t n) override { dense_all(H, n, std::make_index_sequence<N>{}); }
   // ---- block-sparse Hessian (sparse.hpp) ------------------------------------------------------
   static constexpr size_t NUM_PAIRS = N * (N + 1) / 2;
-  // block column of slot i of local factor f, or npos when that vertex has no column (fixed / unused)
-  size_t slot_block(size_t f, size_t i, const std::vector<size_t> &s2b) const {
-    const size_t v = device_ids[f * N + i];
-    if (!detail::is_vertex_active(vertex_descriptors[i]->get_active_state(), v)) return ~size_t(0);
-    return s2b[vertex_descriptors[i]->get_hessian_ids()[v]];
+  size_t block_key_count() override { return active_count() * (N * (N - 1) / 2); }
+  void emit_block_keys(uint64_t *keys, const size_t *s2b) override {
+    if (N > 1 && active_count()) detail::k_block_keys<FactorDescriptor><<<detail::blocks(active_count()), detail::TPB>>>(view(), s2b, keys);
   }
-  void block_pairs(std::vector<BlockCoordinates> &coords, const std::vector<size_t> &s2b) override {
-    detail::sync();
-    for (size_t a = 0; a < active_count(); ++a) {
-      const size_t f = active_indices[a];
-      for (size_t i = 0; i < N; ++i)
-        for (size_t k = i + 1; k < N; ++k) {
-          const size_t bi = slot_block(f, i, s2b), bk = slot_block(f, k, s2b);
-          if (bi == ~size_t(0) || bk == ~size_t(0) || bi == bk) continue;
-          coords.push_back(BlockCoordinates{std::min(bi, bk), std::max(bi, bk)});
-        }
-    }
-  }
-  void sparse_setup(const std::function<size_t(size_t, size_t)> &value_offset_of, const std::vector<size_t> &s2b) override {
-    detail::sync();
-    sparse_dst.resize(active_count() * NUM_PAIRS);
-    for (size_t a = 0; a < active_count(); ++a) {
-      const size_t f = active_indices[a];
-      size_t p = 0;
-      for (size_t i = 0; i < N; ++i)
-        for (size_t k = i; k < N; ++k, ++p) {
-          const size_t bi = slot_block(f, i, s2b), bk = slot_block(f, k, s2b);
-          size_t d = ~size_t(0);
-          if (bi != ~size_t(0) && bk != ~size_t(0) && (i == k || bi != bk)) {
-            d = value_offset_of(std::min(bi, bk), std::max(bi, bk));
-            if (bk < bi) d |= size_t(1) << 63; // the block's rows belong to slot k: store the transpose
-          }
-          sparse_dst[a * NUM_PAIRS + p] = d;
-        }
-    }
-    m_sparse_dst.refresh(sparse_dst);
+  void sparse_setup(const uint64_t *keys, size_t num_keys, const size_t *value_offsets, const size_t *s2b) override {
+    d_sparse_dst.resize_uninit(active_count() * NUM_PAIRS);
+    if (active_count()) detail::k_sparse_dst<FactorDescriptor><<<detail::blocks(active_count()), detail::TPB>>>(view(), s2b, keys, num_keys, value_offsets, d_sparse_dst.raw());
   }
   void sparse_hessian(S *values) override {
     if constexpr (is_low_precision<S>::value) { (void)values; throw std::invalid_argument("block-sparse Hessian: 16-bit storage types are not supported (the reference refuses them too, bal.cu:181-203)"); }
@@ -1394,7 +1415,7 @@ private:
   template <size_t I, size_t... Ks> void sparse_row(detail::FactorView<FactorDescriptor> &fv, S *values, std::index_sequence<Ks...>) {
     // pair index of (I, K), K >= I, in the row-major upper enumeration used by sparse_setup
     ((Ks >= I ? (void)(detail::k_sparse_pair<FactorDescriptor, I, (Ks >= I ? Ks : I)><<<detail::blocks(active_count() * detail::slot_dim<FactorDescriptor, I>() * detail::slot_dim<FactorDescriptor, (Ks >= I ? Ks : I)>()), detail::TPB>>>(
-                     fv, values, m_sparse_dst.get(sparse_dst, tables_mirrored), I * N - I * (I - 1) / 2 + (Ks - I), NUM_PAIRS))
+                     fv, values, d_sparse_dst.raw(), I * N - I * (I - 1) / 2 + (Ks - I), NUM_PAIRS))
                : (void)0), ...);
   }
   template <size_t... Is> void sparse_all(S *values, std::index_sequence<Is...> seq) {

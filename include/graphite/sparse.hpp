@@ -10,14 +10,16 @@
 //                                                   landmark back-substitution (:279-302), S x (:347-393), CSC export
 // exercised the way tests/schur.cu:113-240 drives them.  What differs is how they are built: the reference walks hash
 // maps of block coordinates on the host and fills per-dimension MulOp pointer tables (schur.hpp:484-585); here the
-// structure is a sorted coordinate list, the products are plain index records and one generic kernel handles every
-// (dim_a, dim_b, dim_c) combination.  Correctness-first like the rest of the generic layer (one thread per output
-// scalar, atomics where several factors / products meet in one block); bundle-adjustment graphs that carry the
-// bal_reprojection_model tag are optimised by the gr_bal engine instead (solve.hpp).
+// structure is a sorted list of 64-bit block keys (col << 32 | row) BUILT ON THE DEVICE — every factor / landmark column
+// emits its keys, a radix sort + unique (hipCUB) orders them column-major, exclusive scans give the value offsets and
+// the operation lists, and every consumer finds its block by binary search — the products are plain index records and
+// one generic kernel handles every (dim_a, dim_b, dim_c) combination.  The host keeps copies of the block-CSC arrays
+// for the accessors only.  Correctness-first like the rest of the generic layer (one thread per output scalar, atomics
+// where several factors / products meet in one block); bundle-adjustment graphs whose traits are the BAL model are
+// optimised by the gr_bal engine instead (solve.hpp).
 #pragma once
 #include "core.hpp"
-#include <functional>
-#include <unordered_map>
+#include <hipcub/hipcub.hpp>
 
 namespace graphite {
 
@@ -70,7 +72,73 @@ public:
 };
 
 namespace detail {
-inline uint64_t block_key(size_t row, size_t col) { return ((uint64_t)col << 32) | (uint64_t)row; }
+inline uint64_t block_key(size_t row, size_t col) { return pack_block_key(row, col); }
+
+// ---- device symbolic phase: sorted unique keys, scans, lookups -------------------------------------------------------
+struct ScratchBytes {
+  void *p = nullptr; size_t cap = 0;
+  ~ScratchBytes() { if (p) (void)hipFree(p); }
+  void *get(size_t n) { if (n > cap) { if (p) (void)hipFree(p); GRAPHITE_HIP(hipMalloc(&p, n)); cap = n; } return p; }
+};
+// keys <- its sorted distinct valid (!= ~0) entries; returns how many
+inline size_t sort_unique_keys(device_vector<uint64_t> &keys) {
+  const size_t n = keys.size();
+  if (!n) return 0;
+  if (n > (size_t)std::numeric_limits<int>::max()) throw std::invalid_argument("block-sparse structure: more than 2^31 block keys");
+  device_vector<uint64_t> tmp(n);
+  device_vector<int> count(1);
+  ScratchBytes scratch;
+  size_t bytes = 0;
+  GRAPHITE_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, keys.raw(), tmp.raw(), (int)n));
+  GRAPHITE_HIP(hipcub::DeviceRadixSort::SortKeys(scratch.get(bytes), bytes, keys.raw(), tmp.raw(), (int)n));
+  GRAPHITE_HIP(hipcub::DeviceSelect::Unique(nullptr, bytes, tmp.raw(), keys.raw(), count.raw(), (int)n));
+  GRAPHITE_HIP(hipcub::DeviceSelect::Unique(scratch.get(bytes), bytes, tmp.raw(), keys.raw(), count.raw(), (int)n));
+  size_t m = (size_t)count[0];
+  if (m && keys[m - 1] == ~uint64_t(0)) --m; // the "no block" marker sorts last
+  keys.resize(m);
+  return m;
+}
+// out[i] = sum of in[0..i), out[n] = total (n + 1 entries); returns the total
+inline size_t exclusive_scan(const device_vector<size_t> &in, device_vector<size_t> &out) {
+  const size_t n = in.size();
+  out.resize(n + 1);
+  if (!n) { out.zero(); return 0; }
+  ScratchBytes scratch;
+  size_t bytes = 0;
+  GRAPHITE_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in.raw(), out.raw(), (int)n));
+  GRAPHITE_HIP(hipcub::DeviceScan::ExclusiveSum(scratch.get(bytes), bytes, in.raw(), out.raw(), (int)n));
+  const size_t total = out[n - 1] + in[n - 1];
+  GRAPHITE_HIP(hipMemcpy(out.raw() + n, &total, sizeof(size_t), hipMemcpyHostToDevice));
+  return total;
+}
+__global__ void k_scalar_to_block(size_t nb, const size_t *soff, size_t *s2b) {
+  const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  for (size_t c = soff[b]; c < soff[b + 1]; ++c) s2b[c] = b;
+}
+__global__ void k_diag_keys(size_t nb, uint64_t *keys) {
+  const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (b < nb) keys[b] = pack_block_key(b, b);
+}
+// sorted keys -> row index, block column and value count of every block
+__global__ void k_unpack_keys(size_t n, const uint64_t *keys, const size_t *soff, size_t *rowi, size_t *bcol, size_t *count) {
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const size_t r = (size_t)(keys[q] & 0xffffffffu), c = (size_t)(keys[q] >> 32);
+  rowi[q] = r;
+  if (bcol) bcol[q] = c;
+  count[q] = (soff[r + 1] - soff[r]) * (soff[c + 1] - soff[c]);
+}
+// colp[b] = first key of block column >= b (b = 0 .. nb)
+__global__ void k_col_pointers(size_t nb, const uint64_t *keys, size_t n, size_t *colp) {
+  const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (b <= nb) colp[b] = find_block_key(keys, n, (uint64_t)b << 32);
+}
+inline bool host_find_key(const std::vector<uint64_t> &keys, uint64_t key, size_t &pos) {
+  const auto it = std::lower_bound(keys.begin(), keys.end(), key);
+  pos = (size_t)(it - keys.begin());
+  return it != keys.end() && *it == key;
+}
 
 // number of stored scalars of scalar column `col` (rows <= col), csc_utils.hpp:87-113
 template <typename I> __global__ void k_csc_count(size_t dim, const size_t *s2b, const size_t *colp, const size_t *rowi, const size_t *soff, I *count) {
@@ -143,9 +211,10 @@ template <typename T, typename S, int MODE> __global__ void k_hessian_diag(size_
 // Hessian (hessian.hpp:45-330)
 // =================================================================================================
 template <typename T, typename S> class Hessian {
-  std::unordered_map<uint64_t, size_t> block_indices; // (row, col) -> value offset
+  std::vector<uint64_t> h_keys; // sorted (col, row) keys of the blocks: the host-side lookup
   std::vector<size_t> h_col_pointers, h_row_indices, h_offsets, h_scalar_offsets;
-  device_vector<size_t> d_col_pointers, d_row_indices, d_offsets, d_hessian_offsets, scalar_to_block_map;
+  device_vector<uint64_t> d_keys;
+  device_vector<size_t> d_col_pointers, d_row_indices, d_block_col, d_offsets, d_hessian_offsets, scalar_to_block_map;
   device_vector<S> d_hessian, d_prev_diag;
 public:
   Hessian() = default;
@@ -155,42 +224,50 @@ public:
   const device_vector<S> &get_values() const { return d_hessian; }
   S *get_values_ptr() { return d_hessian.raw(); }
   const S *get_values_ptr() const { return d_hessian.raw(); }
-  // host copies of the block-CSC (what SchurComplement::build_structure walks)
+  // host copies of the block-CSC (accessors, tests)
   const std::vector<size_t> &host_col_pointers() const { return h_col_pointers; }
   const std::vector<size_t> &host_row_indices() const { return h_row_indices; }
   const std::vector<size_t> &host_value_offsets() const { return h_offsets; }
   const std::vector<size_t> &host_scalar_offsets() const { return h_scalar_offsets; }
-  bool has_block(size_t row, size_t col) const { return block_indices.count(detail::block_key(row, col)) != 0; }
-  size_t block_offset(size_t row, size_t col) const { return block_indices.at(detail::block_key(row, col)); }
+  // ... and what SchurComplement::build_structure reads on the device
+  const device_vector<size_t> &device_scalar_offsets() const { return d_hessian_offsets; }
+  const device_vector<size_t> &device_block_columns() const { return d_block_col; }
+  const device_vector<uint64_t> &device_block_keys() const { return d_keys; }
+  bool has_block(size_t row, size_t col) const { size_t q; return detail::host_find_key(h_keys, detail::block_key(row, col), q); }
+  size_t block_offset(size_t row, size_t col) const {
+    size_t q;
+    if (!detail::host_find_key(h_keys, detail::block_key(row, col), q)) throw std::out_of_range("Hessian: no such block");
+    return h_offsets[q];
+  }
 
   void build_structure(Graph<T, S> *graph, StreamPool &) {
+    using namespace detail;
     h_scalar_offsets = graph->get_offset_vector();
     const size_t nb = graph->get_num_block_columns(), dim = graph->get_hessian_dimension();
-    std::vector<size_t> s2b(dim);
-    for (size_t b = 0; b < nb; ++b)
-      for (size_t c = h_scalar_offsets[b]; c < h_scalar_offsets[b + 1]; ++c) s2b[c] = b;
-    // unique upper block coordinates: every active vertex's diagonal block + one block per vertex pair of a factor
-    std::vector<BlockCoordinates> coords;
-    for (size_t b = 0; b < nb; ++b) coords.push_back(BlockCoordinates{b, b});
-    for (auto *fd : graph->get_factor_descriptors()) fd->block_pairs(coords, s2b);
-    std::sort(coords.begin(), coords.end(), [](const BlockCoordinates &a, const BlockCoordinates &b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
-    coords.erase(std::unique(coords.begin(), coords.end()), coords.end());
-    block_indices.clear();
-    h_col_pointers.assign(nb + 1, 0); h_row_indices.clear(); h_offsets.clear();
-    size_t nvalues = 0;
-    for (const auto &c : coords) {
-      block_indices[detail::block_key(c.row, c.col)] = nvalues;
-      h_col_pointers[c.col + 1]++;
-      h_row_indices.push_back(c.row); h_offsets.push_back(nvalues);
-      nvalues += graph->get_variable_dimension(c.row) * graph->get_variable_dimension(c.col);
-    }
-    for (size_t b = 0; b < nb; ++b) h_col_pointers[b + 1] += h_col_pointers[b];
+    if (nb >= (size_t(1) << 32)) throw std::invalid_argument("Hessian: more than 2^32 block columns");
+    d_hessian_offsets = h_scalar_offsets;
+    scalar_to_block_map.resize(dim);
+    if (nb) k_scalar_to_block<<<blocks(nb), TPB>>>(nb, d_hessian_offsets.raw(), scalar_to_block_map.raw());
+    // keys of the upper blocks: every active vertex's diagonal block + one per vertex pair of an active factor
+    size_t nkeys = nb;
+    for (auto *fd : graph->get_factor_descriptors()) nkeys += fd->block_key_count();
+    d_keys.resize(nkeys);
+    if (nb) k_diag_keys<<<blocks(nb), TPB>>>(nb, d_keys.raw());
+    size_t at = nb;
+    for (auto *fd : graph->get_factor_descriptors()) { fd->emit_block_keys(d_keys.raw() + at, scalar_to_block_map.raw()); at += fd->block_key_count(); }
+    const size_t nblk = sort_unique_keys(d_keys); // column-major, row inside a column (the diagonal block last: upper triangle)
+    device_vector<size_t> counts(nblk);
+    d_row_indices.resize(nblk); d_block_col.resize(nblk);
+    if (nblk) k_unpack_keys<<<blocks(nblk), TPB>>>(nblk, d_keys.raw(), d_hessian_offsets.raw(), d_row_indices.raw(), d_block_col.raw(), counts.raw());
+    const size_t nvalues = exclusive_scan(counts, d_offsets);
+    d_offsets.resize(nblk);
+    d_col_pointers.resize(nb + 1);
+    k_col_pointers<<<blocks(nb + 1), TPB>>>(nb, d_keys.raw(), nblk, d_col_pointers.raw());
     d_hessian.resize(nvalues); d_prev_diag.resize(dim);
-    d_col_pointers = h_col_pointers; d_row_indices = h_row_indices; d_offsets = h_offsets;
-    d_hessian_offsets = h_scalar_offsets; scalar_to_block_map = s2b;
     // per factor and vertex pair: where its block lives (the role of setup_hessian_computation, hessian.hpp:178-208)
-    const auto lookup = [this](size_t row, size_t col) { return block_indices.at(detail::block_key(row, col)); };
-    for (auto *fd : graph->get_factor_descriptors()) fd->sparse_setup(lookup, s2b);
+    for (auto *fd : graph->get_factor_descriptors()) fd->sparse_setup(d_keys.raw(), nblk, d_offsets.raw(), scalar_to_block_map.raw());
+    sync();
+    h_keys = d_keys.to_host(); h_col_pointers = d_col_pointers.to_host(); h_row_indices = d_row_indices.to_host(); h_offsets = d_offsets.to_host();
   }
   void update_values(Graph<T, S> *graph, StreamPool &) { // hessian.hpp:290-307
     d_hessian.zero();
@@ -328,13 +405,78 @@ template <typename T, typename S> __global__ void k_blocks_to_dense(size_t nblk,
     D[(soff[bc] + c) * ld + soff[br] + r] = v;
   }
 }
+
+// ---- symbolic phase of S on the device (schur.hpp:397-585 walks hash maps on the host) ----------------------------------
+// View of H's block-CSC: colp / rowi / bcol / boff per block, soff = scalar start of every block column, L = first
+// eliminated (landmark) column.  The blocks of a landmark column l are its pose rows (ascending) and, last, Hll.
+struct HView { const size_t *colp, *rowi, *bcol, *boff, *soff; size_t L, nb, pose_dim; };
+hd_fn inline size_t hv_dim(const HView &h, size_t b) { return h.soff[b + 1] - h.soff[b]; }
+// per landmark column: number of (a <= bq) pose-row pairs; flags: 1 = an eliminated vertex shares a factor with another, 2 = dimension > 16
+__global__ void k_schur_pair_counts(HView h, size_t *pairs, size_t *inv_size, int *flags) {
+  const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x, l = h.L + j;
+  if (l >= h.nb) return;
+  const size_t k0 = h.colp[l], k1 = h.colp[l + 1] - 1, k = k1 - k0, dl = hv_dim(h, l);
+  if (k && h.rowi[k1 - 1] >= h.L) atomicOr(flags, 1); // rows ascend: the last pose row is the largest
+  if (dl > 16) atomicOr(flags, 2);
+  pairs[j] = k * (k + 1) / 2;
+  inv_size[j] = dl * dl;
+}
+// one thread per Hpl block q (pose row a of landmark column l): its Hpl record, and the products (a, bq >= a) it starts —
+// S key, product record (dst filled in by k_schur_mul_dst once S is known) and thread count
+__global__ void k_schur_emit(HView h, size_t nhpl, const size_t *pair_start, const size_t *inv_off, SchurHplOp *hpl, uint64_t *keys, SchurMulOp *mul, size_t *mul_count) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= nhpl) return;
+  // Hpl blocks and Hll blocks interleave in H's list: block q = colp[L] + t + (landmark columns before it); find the column by bisection
+  size_t lo = h.L, hi = h.nb; // largest l with colp[l] - (l - L) <= colp[L] + t
+  const size_t base = h.colp[h.L];
+  while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (h.colp[mid] - (mid - h.L) <= base + t) lo = mid; else hi = mid; }
+  const size_t l = lo, q = base + t + (l - h.L), k0 = h.colp[l], k1 = h.colp[l + 1] - 1, a = q - k0, k = k1 - k0, dl = hv_dim(h, l);
+  const size_t ra = h.rowi[q], da = hv_dim(h, ra), io = inv_off[l - h.L];
+  hpl[t] = SchurHplOp{h.boff[q], io, h.soff[ra], h.soff[l] - h.pose_dim, (uint32_t)da, (uint32_t)dl};
+  size_t p = pair_start[l - h.L] + a * k - (a * (a - 1)) / 2;
+  for (size_t bq = q; bq < k1; ++bq, ++p) {
+    const size_t rb = h.rowi[bq], db = hv_dim(h, rb);
+    keys[p] = pack_block_key(ra, rb);
+    mul[p] = SchurMulOp{0, h.boff[q], h.boff[bq], io, (uint32_t)da, (uint32_t)db, (uint32_t)dl, 0};
+    mul_count[p] = da * db;
+  }
+}
+__global__ void k_schur_mul_dst(size_t n, const uint64_t *pair_keys, const uint64_t *skeys, size_t ns, const size_t *soffs, SchurMulOp *mul) {
+  const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p < n) mul[p].dst = soffs[find_block_key(skeys, ns, pair_keys[p])];
+}
+__global__ void k_schur_copy_ops(size_t n, const uint64_t *hkeys, const size_t *hboff, HView h, const uint64_t *skeys, size_t ns, const size_t *soffs, SchurCopyOp *ops) {
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  ops[q] = SchurCopyOp{hboff[q], soffs[find_block_key(skeys, ns, hkeys[q])], hv_dim(h, h.rowi[q]) * hv_dim(h, h.bcol[q])};
+}
+__global__ void k_schur_inv_ops(HView h, const size_t *inv_off, SchurInvOp *ops, size_t *lrow) {
+  const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x, l = h.L + j;
+  if (l >= h.nb) return;
+  ops[j] = SchurInvOp{h.boff[h.colp[l + 1] - 1], inv_off[j], (uint32_t)hv_dim(h, l), 0};
+  lrow[j] = h.soff[l] - h.pose_dim;
+}
+// S x: one record per upper block and one for its transpose below the diagonal (schur.hpp:307-345); COUNT: records per block
+template <bool COUNT> __global__ void k_schur_vec_ops(size_t ns, const size_t *rowi, const size_t *bcol, const size_t *boff, const size_t *soff, const size_t *first, size_t *count, SchurVecOp *ops) {
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= ns) return;
+  const size_t r = rowi[q], c = bcol[q];
+  if (COUNT) { count[q] = r == c ? 1 : 2; return; }
+  const uint32_t dr = (uint32_t)(soff[r + 1] - soff[r]), dc = (uint32_t)(soff[c + 1] - soff[c]);
+  ops[first[q]] = SchurVecOp{boff[q], soff[c], soff[r], dr, dc, 0, 0};
+  if (r != c) ops[first[q] + 1] = SchurVecOp{boff[q], soff[r], soff[c], dr, dc, 1, 0};
+}
+__global__ void k_schur_diag_offsets(size_t L, const size_t *colp, const size_t *boff, size_t *diag) {
+  const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (b < L) diag[b] = colp[b + 1] > colp[b] ? boff[colp[b + 1] - 1] : 0; // upper triangle: the diagonal block closes its column
+}
 } // namespace detail
 
 template <typename T, typename S> class SchurComplement {
   Hessian<T, S> &H;
   // structure of S: upper pose blocks, column-major sorted, blocks column-major (same layout as H)
-  std::unordered_map<uint64_t, size_t> block_indices;
-  std::vector<size_t> h_col_pointers, h_row_indices, h_offsets, h_block_col, h_pose_offsets, h_diag_offsets;
+  std::vector<size_t> h_col_pointers, h_row_indices, h_pose_offsets, h_diag_offsets;
+  device_vector<uint64_t> d_keys;
   device_vector<size_t> d_col_pointers, d_row_indices, d_offsets, d_block_col, d_schur_offsets, scalar_to_block_map, d_mul_first, d_inv_lrow;
   device_vector<S> d_schur, d_hll_inv;
   device_vector<T> b_Schur, l_workspace, l_rhs;
@@ -343,7 +485,7 @@ template <typename T, typename S> class SchurComplement {
   device_vector<detail::SchurCopyOp> d_copy_ops;
   device_vector<detail::SchurInvOp> d_inv_ops;
   device_vector<detail::SchurVecOp> d_vec_ops;
-  size_t landmark_col_start = 0, num_block_columns = 0, pose_dim = 0, landmark_dim = 0, mul_threads = 0;
+  size_t landmark_col_start = 0, num_block_columns = 0, pose_dim = 0, landmark_dim = 0, mul_threads = 0, num_blocks = 0;
 public:
   explicit SchurComplement(Hessian<T, S> &H_) : H(H_) {}
   size_t get_pose_dimension() const { return pose_dim; }
@@ -361,78 +503,61 @@ public:
     using namespace detail;
     num_block_columns = graph->get_num_block_columns();
     landmark_col_start = graph->get_elimination_block_column();
+    const size_t L = landmark_col_start, nb = num_block_columns, nl = nb - L;
     const auto &soff = H.host_scalar_offsets();
-    pose_dim = soff[landmark_col_start];
-    landmark_dim = soff[num_block_columns] - pose_dim;
-    const auto &hcp = H.host_col_pointers();
-    const auto &hri = H.host_row_indices();
-    const auto &hof = H.host_value_offsets();
-    auto dim = [&](size_t b) { return soff[b + 1] - soff[b]; };
+    pose_dim = soff[L];
+    landmark_dim = soff[nb] - pose_dim;
+    const HView hv{H.get_block_col_pointers().raw(), H.get_block_row_indices().raw(), H.device_block_columns().raw(), H.get_block_value_offsets().raw(),
+                   H.device_scalar_offsets().raw(), L, nb, pose_dim};
+    const size_t n_hpp = H.host_col_pointers()[L];                                    // blocks of the pose columns
+    const size_t n_hpl = H.host_col_pointers()[nb] - n_hpp - nl;                      // landmark columns minus their Hll blocks
     // symbolic S: Hpp pattern U {(i, j): i <= j both meet a landmark} (schur.hpp:397-476)
-    std::vector<BlockCoordinates> coords;
-    for (size_t col = 0; col < landmark_col_start; ++col)
-      for (size_t k = hcp[col]; k < hcp[col + 1]; ++k) coords.push_back(BlockCoordinates{hri[k], col});
-    for (size_t l = landmark_col_start; l < num_block_columns; ++l) {
-      const size_t k0 = hcp[l], k1 = hcp[l + 1] - 1; // the last block of the column is Hll
-      for (size_t a = k0; a < k1; ++a) {
-        if (hri[a] >= landmark_col_start) throw std::invalid_argument("SchurComplement: eliminated vertices share a factor (Hll must be block diagonal)");
-        for (size_t bq = a; bq < k1; ++bq) coords.push_back(BlockCoordinates{hri[a], hri[bq]});
-      }
-    }
-    std::sort(coords.begin(), coords.end(), [](const BlockCoordinates &a, const BlockCoordinates &b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
-    coords.erase(std::unique(coords.begin(), coords.end()), coords.end());
-    block_indices.clear();
-    h_col_pointers.assign(landmark_col_start + 1, 0); h_row_indices.clear(); h_offsets.clear(); h_block_col.clear();
-    h_diag_offsets.assign(landmark_col_start, 0);
-    size_t nvalues = 0;
-    for (const auto &c : coords) {
-      block_indices[block_key(c.row, c.col)] = nvalues;
-      if (c.row == c.col) h_diag_offsets[c.col] = nvalues;
-      h_col_pointers[c.col + 1]++;
-      h_row_indices.push_back(c.row); h_offsets.push_back(nvalues); h_block_col.push_back(c.col);
-      nvalues += dim(c.row) * dim(c.col);
-    }
-    for (size_t b = 0; b < landmark_col_start; ++b) h_col_pointers[b + 1] += h_col_pointers[b];
-    h_pose_offsets.assign(soff.begin(), soff.begin() + landmark_col_start + 1);
-    std::vector<size_t> s2b(pose_dim);
-    for (size_t b = 0; b < landmark_col_start; ++b)
-      for (size_t c = soff[b]; c < soff[b + 1]; ++c) s2b[c] = b;
+    device_vector<size_t> pairs(nl), pair_start, inv_size(nl), inv_off;
+    device_vector<int> flags(1);
+    flags.zero();
+    if (nl) k_schur_pair_counts<<<blocks(nl), TPB>>>(hv, pairs.raw(), inv_size.raw(), flags.raw());
+    const size_t npairs = exclusive_scan(pairs, pair_start), inv_values = exclusive_scan(inv_size, inv_off);
+    const int bad = flags[0];
+    if (bad & 1) throw std::invalid_argument("SchurComplement: eliminated vertices share a factor (Hll must be block diagonal)");
+    if (bad & 2) throw std::invalid_argument("SchurComplement: eliminated vertex dimension > 16");
+    d_keys.resize(n_hpp + npairs);
+    if (n_hpp) GRAPHITE_HIP(hipMemcpy(d_keys.raw(), H.device_block_keys().raw(), n_hpp * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+    device_vector<uint64_t> pair_keys(npairs);
+    device_vector<size_t> mul_count(npairs);
+    d_hpl_ops.resize(n_hpl); d_mul_ops.resize(npairs);
+    if (n_hpl) k_schur_emit<<<blocks(n_hpl), TPB>>>(hv, n_hpl, pair_start.raw(), inv_off.raw(), d_hpl_ops.raw(), pair_keys.raw(), d_mul_ops.raw(), mul_count.raw());
+    if (npairs) GRAPHITE_HIP(hipMemcpy(d_keys.raw() + n_hpp, pair_keys.raw(), npairs * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+    num_blocks = sort_unique_keys(d_keys);
+    d_schur_offsets.resize(L + 1);
+    if (L + 1) GRAPHITE_HIP(hipMemcpy(d_schur_offsets.raw(), H.device_scalar_offsets().raw(), (L + 1) * sizeof(size_t), hipMemcpyDeviceToDevice));
+    device_vector<size_t> counts(num_blocks);
+    d_row_indices.resize(num_blocks); d_block_col.resize(num_blocks);
+    if (num_blocks) k_unpack_keys<<<blocks(num_blocks), TPB>>>(num_blocks, d_keys.raw(), d_schur_offsets.raw(), d_row_indices.raw(), d_block_col.raw(), counts.raw());
+    const size_t nvalues = exclusive_scan(counts, d_offsets);
+    d_offsets.resize(num_blocks);
+    d_col_pointers.resize(L + 1);
+    k_col_pointers<<<blocks(L + 1), TPB>>>(L, d_keys.raw(), num_blocks, d_col_pointers.raw());
+    scalar_to_block_map.resize(pose_dim);
+    if (L) k_scalar_to_block<<<blocks(L), TPB>>>(L, d_schur_offsets.raw(), scalar_to_block_map.raw());
     d_schur.resize(nvalues);
-    d_col_pointers = h_col_pointers; d_row_indices = h_row_indices; d_offsets = h_offsets; d_block_col = h_block_col;
-    d_schur_offsets = h_pose_offsets; scalar_to_block_map = s2b;
     // operation lists
-    std::vector<SchurCopyOp> copy_ops;
-    std::vector<SchurInvOp> inv_ops;
-    std::vector<SchurMulOp> mul_ops;
-    std::vector<SchurHplOp> hpl_ops;
-    std::vector<SchurVecOp> vec_ops;
-    std::vector<size_t> mul_first, inv_lrow;
-    for (size_t col = 0; col < landmark_col_start; ++col) // Hpp copy (:587)
-      for (size_t k = hcp[col]; k < hcp[col + 1]; ++k) copy_ops.push_back(SchurCopyOp{hof[k], block_indices.at(block_key(hri[k], col)), dim(hri[k]) * dim(col)});
-    size_t inv_values = 0;
-    mul_threads = 0;
-    for (size_t l = landmark_col_start; l < num_block_columns; ++l) {
-      const size_t k0 = hcp[l], k1 = hcp[l + 1] - 1, dl = dim(l);
-      if (dl > 16) throw std::invalid_argument("SchurComplement: eliminated vertex dimension > 16");
-      inv_ops.push_back(SchurInvOp{hof[k1], inv_values, (uint32_t)dl, 0});
-      inv_lrow.push_back(soff[l] - pose_dim);
-      for (size_t a = k0; a < k1; ++a) {
-        hpl_ops.push_back(SchurHplOp{hof[a], inv_values, soff[hri[a]], soff[l] - pose_dim, (uint32_t)dim(hri[a]), (uint32_t)dl});
-        for (size_t bq = a; bq < k1; ++bq) {
-          mul_first.push_back(mul_threads);
-          mul_ops.push_back(SchurMulOp{block_indices.at(block_key(hri[a], hri[bq])), hof[a], hof[bq], inv_values, (uint32_t)dim(hri[a]), (uint32_t)dim(hri[bq]), (uint32_t)dl, 0});
-          mul_threads += dim(hri[a]) * dim(hri[bq]);
-        }
-      }
-      inv_values += dl * dl;
-    }
-    for (size_t q = 0; q < h_row_indices.size(); ++q) { // S x: upper blocks, and their transposes below the diagonal (:307-345)
-      const size_t r = h_row_indices[q], c = h_block_col[q];
-      vec_ops.push_back(SchurVecOp{h_offsets[q], soff[c], soff[r], (uint32_t)dim(r), (uint32_t)dim(c), 0, 0});
-      if (r != c) vec_ops.push_back(SchurVecOp{h_offsets[q], soff[r], soff[c], (uint32_t)dim(r), (uint32_t)dim(c), 1, 0});
-    }
+    d_copy_ops.resize(n_hpp);
+    if (n_hpp) k_schur_copy_ops<<<blocks(n_hpp), TPB>>>(n_hpp, H.device_block_keys().raw(), H.get_block_value_offsets().raw(), hv, d_keys.raw(), num_blocks, d_offsets.raw(), d_copy_ops.raw()); // Hpp copy (:587)
+    d_inv_ops.resize(nl); d_inv_lrow.resize(nl);
+    if (nl) k_schur_inv_ops<<<blocks(nl), TPB>>>(hv, inv_off.raw(), d_inv_ops.raw(), d_inv_lrow.raw());
+    if (npairs) k_schur_mul_dst<<<blocks(npairs), TPB>>>(npairs, pair_keys.raw(), d_keys.raw(), num_blocks, d_offsets.raw(), d_mul_ops.raw());
+    mul_threads = exclusive_scan(mul_count, d_mul_first);
+    d_mul_first.resize(npairs);
+    device_vector<size_t> vec_count(num_blocks), vec_first;
+    if (num_blocks) k_schur_vec_ops<true><<<blocks(num_blocks), TPB>>>(num_blocks, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), nullptr, vec_count.raw(), nullptr);
+    d_vec_ops.resize(exclusive_scan(vec_count, vec_first));
+    if (num_blocks) k_schur_vec_ops<false><<<blocks(num_blocks), TPB>>>(num_blocks, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), vec_first.raw(), nullptr, d_vec_ops.raw());
+    device_vector<size_t> diag(L);
+    if (L) k_schur_diag_offsets<<<blocks(L), TPB>>>(L, d_col_pointers.raw(), d_offsets.raw(), diag.raw());
+    sync();
+    h_col_pointers = d_col_pointers.to_host(); h_row_indices = d_row_indices.to_host(); h_diag_offsets = diag.to_host();
+    h_pose_offsets.assign(soff.begin(), soff.begin() + L + 1);
     d_hll_inv.resize(inv_values);
-    d_copy_ops = copy_ops; d_inv_ops = inv_ops; d_mul_ops = mul_ops; d_hpl_ops = hpl_ops; d_vec_ops = vec_ops; d_mul_first = mul_first; d_inv_lrow = inv_lrow;
     b_Schur.resize(pose_dim); l_workspace.resize(landmark_dim); l_rhs.resize(landmark_dim);
   }
 
@@ -478,7 +603,7 @@ public:
   void to_dense(T *D) {
     using namespace detail;
     fill<T>(D, pose_dim * pose_dim, T(0));
-    if (h_row_indices.size()) k_blocks_to_dense<T, S><<<(unsigned)h_row_indices.size(), 64>>>(h_row_indices.size(), d_block_col.raw(), d_row_indices.raw(), d_offsets.raw(), d_schur_offsets.raw(), d_schur.raw(), D, pose_dim);
+    if (num_blocks) k_blocks_to_dense<T, S><<<(unsigned)num_blocks, 64>>>(num_blocks, d_block_col.raw(), d_row_indices.raw(), d_offsets.raw(), d_schur_offsets.raw(), d_schur.raw(), D, pose_dim);
     sync();
   }
 };
