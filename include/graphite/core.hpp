@@ -1038,11 +1038,15 @@ template <typename F> __global__ void k_block_keys(FactorView<F> fv, const size_
 }
 // per active factor and vertex pair i <= k (row-major upper enumeration): value offset of its block, top bit set when the
 // block's rows belong to slot k (the transpose is stored); npos when the pair has no block
-template <typename F> __global__ void k_sparse_dst(FactorView<F> fv, const size_t *s2b, const uint64_t *keys, size_t nkeys, const size_t *offsets, size_t *dst) {
+// ... and, per slot and vertex, the value offset of the vertex's DIAGONAL block (vdiag: every factor of a vertex writes the same
+// number), for the gathered diagonal accumulation (k_diag_store)
+template <size_t N> struct VertexDiag { size_t *p[N]; };
+template <typename F> __global__ void k_sparse_dst(FactorView<F> fv, const size_t *s2b, const uint64_t *keys, size_t nkeys, const size_t *offsets, size_t *dst, VertexDiag<F::N> vdiag) {
   const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (a >= fv.n_active) return;
   size_t blk[F::N];
-  slot_blocks<F>(fv, fv.active_ids[a], s2b, blk);
+  const size_t f = fv.active_ids[a];
+  slot_blocks<F>(fv, f, s2b, blk);
   size_t p = a * (F::N * (F::N + 1) / 2);
   for (size_t i = 0; i < F::N; ++i)
     for (size_t k = i; k < F::N; ++k, ++p) {
@@ -1051,9 +1055,17 @@ template <typename F> __global__ void k_sparse_dst(FactorView<F> fv, const size_
         const bool swap = blk[k] < blk[i];
         d = offsets[find_block_key(keys, nkeys, pack_block_key(swap ? blk[k] : blk[i], swap ? blk[i] : blk[k]))];
         if (swap) d |= size_t(1) << 63;
+        if (i == k) vdiag.p[i][fv.ids[f * F::N + i]] = d;
       }
       dst[p] = d;
     }
+}
+// values[diagonal block of vertex v] += the gathered d x d block of v (k_gather<.., 4>: column-major, one writer per entry)
+template <typename T, typename S> __global__ void k_diag_store(size_t nv, size_t dd, const T *blocks, const size_t *vdiag, S *values) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= nv * dd) return;
+  const size_t off = vdiag[t / dd];
+  if (off != ~size_t(0)) values[off + t % dd] += (S)blocks[t];
 }
 
 template <typename VD> __global__ void k_flag_vertices(const size_t *active_ids, size_t n_active, const size_t *ids, size_t N, size_t I, uint8_t *state) {
@@ -1095,6 +1107,8 @@ public:
   managed_vector<T> scalar;                // device scalar for reductions
   hbm_vector<T> sum_partials;
   hbm_vector<size_t> d_sparse_dst;         // [active factor][vertex pair] -> value offset in the block-sparse Hessian (written by k_sparse_dst)
+  std::array<hbm_vector<size_t>, N> slot_vdiag; // [slot][vertex] -> value offset of the vertex's diagonal block (npos: none)
+  hbm_vector<T> diag_blocks;               // gathered diagonal blocks of one slot
   HandleManager<size_t> hm;                // factor.hpp:158-174: ids returned by add_factor are stable handles
   std::unordered_map<size_t, size_t> global_to_local_map;
   std::vector<size_t> local_to_global_map;
@@ -1302,7 +1316,14 @@ public:
   }
   void sparse_setup(const uint64_t *keys, size_t num_keys, const size_t *value_offsets, const size_t *s2b) override {
     d_sparse_dst.resize_uninit(active_count() * NUM_PAIRS);
-    if (active_count()) detail::k_sparse_dst<FactorDescriptor><<<detail::blocks(active_count()), detail::TPB>>>(view(), s2b, keys, num_keys, value_offsets, d_sparse_dst.raw());
+    detail::VertexDiag<N> vd;
+    for (size_t i = 0; i < N; ++i) {
+      const size_t nv = vertex_descriptors[i]->count();
+      slot_vdiag[i].resize_uninit(nv);
+      if (nv) GRAPHITE_HIP(hipMemset(slot_vdiag[i].raw(), 0xff, nv * sizeof(size_t))); // npos: no diagonal block through this slot
+      vd.p[i] = slot_vdiag[i].raw();
+    }
+    if (active_count()) detail::k_sparse_dst<FactorDescriptor><<<detail::blocks(active_count()), detail::TPB>>>(view(), s2b, keys, num_keys, value_offsets, d_sparse_dst.raw(), vd);
   }
   void sparse_hessian(S *values) override {
     if constexpr (is_low_precision<S>::value) { (void)values; throw std::invalid_argument("block-sparse Hessian: 16-bit storage types are not supported (the reference refuses them too, bal.cu:181-203)"); }
@@ -1412,11 +1433,26 @@ private:
   template <size_t I, size_t... Ks> void dense_row(detail::FactorView<FactorDescriptor> &fv, T *H, size_t n, std::index_sequence<Ks...>) {
     ((detail::k_dense_pair<FactorDescriptor, I, Ks><<<detail::blocks(active_count() * detail::slot_dim<FactorDescriptor, I>() * detail::slot_dim<FactorDescriptor, Ks>()), detail::TPB>>>(fv, H, n)), ...);
   }
+  template <size_t I, size_t K> void sparse_pair(detail::FactorView<FactorDescriptor> &fv, S *values) {
+    if constexpr (K >= I) {
+      constexpr size_t di = detail::slot_dim<FactorDescriptor, I>(), dk = detail::slot_dim<FactorDescriptor, K>();
+      if (K == I && gather_ready) {
+        // a vertex's diagonal block collects one term per factor of the vertex: gathered per vertex (no atomics: a camera's
+        // 81 entries would take 81 x its observations of them), then added to where the block lives
+        const size_t nv = vertex_descriptors[I]->count();
+        if (!nv) return;
+        diag_blocks.resize_uninit(nv * di * di);
+        GRAPHITE_HIP(hipMemsetAsync(diag_blocks.raw(), 0, nv * di * di * sizeof(T), 0));
+        gather_one<4, I>(fv, diag_blocks.raw(), nullptr);
+        detail::k_diag_store<T, S><<<detail::blocks(nv * di * di), detail::TPB>>>(nv, di * di, diag_blocks.raw(), slot_vdiag[I].raw(), values);
+        return;
+      }
+      // pair index of (I, K) in the row-major upper enumeration used by sparse_setup
+      detail::k_sparse_pair<FactorDescriptor, I, K><<<detail::blocks(active_count() * di * dk), detail::TPB>>>(fv, values, d_sparse_dst.raw(), I * N - I * (I - 1) / 2 + (K - I), NUM_PAIRS);
+    }
+  }
   template <size_t I, size_t... Ks> void sparse_row(detail::FactorView<FactorDescriptor> &fv, S *values, std::index_sequence<Ks...>) {
-    // pair index of (I, K), K >= I, in the row-major upper enumeration used by sparse_setup
-    ((Ks >= I ? (void)(detail::k_sparse_pair<FactorDescriptor, I, (Ks >= I ? Ks : I)><<<detail::blocks(active_count() * detail::slot_dim<FactorDescriptor, I>() * detail::slot_dim<FactorDescriptor, (Ks >= I ? Ks : I)>()), detail::TPB>>>(
-                     fv, values, d_sparse_dst.raw(), I * N - I * (I - 1) / 2 + (Ks - I), NUM_PAIRS))
-               : (void)0), ...);
+    ((sparse_pair<I, Ks>(fv, values)), ...);
   }
   template <size_t... Is> void sparse_all(S *values, std::index_sequence<Is...> seq) {
     if (!active_count()) return;

@@ -327,22 +327,72 @@ template <typename S> __global__ void k_schur_invert(const SchurInvOp *ops, size
   }
   for (int i = 0; i < d * d; ++i) inv[ops[op].inv + i] = (S)R[i];
 }
-// one thread per (product, output scalar): value = sum_k L(row,k) sum_j M(k,j) R(col,j)   (ops/schur.hpp:155-188)
-template <typename S> __global__ void k_schur_mul(const SchurMulOp *ops, const size_t *first_thread, size_t nops, size_t nthreads, const S *H, const S *inv, S *Sv) {
-  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (t >= nthreads) return;
-  size_t lo = 0, hi = nops; // op = last with first_thread[op] <= t
-  while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (first_thread[mid] <= t) lo = mid; else hi = mid; }
-  const SchurMulOp o = ops[lo];
-  const size_t e = t - first_thread[lo], row = e % o.da, col = e / o.da;
-  const S *L = H + o.left, *R = H + o.right, *M = inv + o.mid;
-  S value = 0;
-  for (uint32_t k = 0; k < o.dl; ++k) {
-    S mrt = 0;
-    for (uint32_t j = 0; j < o.dl; ++j) mrt += M[k + o.dl * j] * R[col + o.db * j];
-    value += L[row + o.da * k] * mrt;
+// S_dst -= sum over the products of that destination block of L M R^T (ops/schur.hpp:155-188 adds every product with one
+// atomicAdd per output scalar).  The products are sorted by destination at build_structure (stable: landmark order) and cut
+// into CHUNKS of <= SCHUR_MUL_CHUNK products of one destination; one workgroup per chunk: its threads form
+// blockDim / (da db) slices, slice s takes products s, s + slices, ... with one thread per output scalar
+// (value = sum_k L(row,k) sum_j M(k,j) R(col,j)), the slices are added through LDS in slice order.  A destination with a
+// single chunk (almost all off-diagonal blocks) is finished there; the others (a camera's diagonal block collects one
+// product per observation) leave one partial block per chunk and k_schur_mul_join adds them in chunk order — no atomics,
+// no per-thread search, the same bits every run, and no workgroup walks more than SCHUR_MUL_CHUNK products.
+constexpr int SCHUR_MUL_THREADS = 256, SCHUR_MUL_CHUNK = 64;
+struct SchurChunks { const unsigned *blk; const size_t *first_chunk; const size_t *first_product; double *partial; size_t stride; };
+template <typename S> __global__ void __launch_bounds__(SCHUR_MUL_THREADS)
+k_schur_mul(const SchurMulOp *ops, SchurChunks ch, const size_t *rowi, const size_t *bcol, const size_t *boff, const size_t *soff, const S *H, const S *inv, S *Sv) {
+  __shared__ double part[SCHUR_MUL_THREADS];
+  const size_t j = blockIdx.x, q = ch.blk[j], i = j - ch.first_chunk[q], nchunk = ch.first_chunk[q + 1] - ch.first_chunk[q];
+  const size_t p0 = ch.first_product[q] + i * SCHUR_MUL_CHUNK, pe = ch.first_product[q + 1], p1 = p0 + SCHUR_MUL_CHUNK < pe ? p0 + SCHUR_MUL_CHUNK : pe;
+  const size_t r = rowi[q], c = bcol[q];
+  const uint32_t da = (uint32_t)(soff[r + 1] - soff[r]), db = (uint32_t)(soff[c + 1] - soff[c]), nout = da * db;
+  // more outputs than threads (two pose blocks beyond 16 x 16): round trips
+  for (uint32_t e0 = 0; e0 < nout; e0 += SCHUR_MUL_THREADS) {
+    const uint32_t span = nout - e0 < SCHUR_MUL_THREADS ? nout - e0 : SCHUR_MUL_THREADS;
+    const uint32_t slices = SCHUR_MUL_THREADS / span, s = threadIdx.x / span, e = e0 + threadIdx.x % span;
+    double acc = 0;
+    if (s < slices) {
+      const uint32_t row = e % da, col = e / da;
+#pragma unroll 4
+      for (size_t p = p0 + s; p < p1; p += slices) {
+        const SchurMulOp o = ops[p];
+        const S *L = H + o.left, *R = H + o.right, *M = inv + o.mid;
+        S value = 0;
+        for (uint32_t k = 0; k < o.dl; ++k) {
+          S mrt = 0;
+          for (uint32_t jj = 0; jj < o.dl; ++jj) mrt += M[k + o.dl * jj] * R[col + db * jj];
+          value += L[row + da * k] * mrt;
+        }
+        acc += (double)value;
+      }
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (s == 0) {
+      double tot = 0;
+      for (uint32_t k = 0; k < slices; ++k) tot += part[k * span + threadIdx.x];
+      if (nchunk == 1) Sv[boff[q] + e] -= (S)tot;
+      else ch.partial[j * ch.stride + e] = tot;
+    }
+    __syncthreads();
   }
-  atomicAdd(&Sv[o.dst + row + o.da * col], -value);
+}
+template <typename S> __global__ void k_schur_mul_join(size_t nblk, SchurChunks ch, const size_t *rowi, const size_t *bcol, const size_t *boff, const size_t *soff, S *Sv) {
+  const size_t q = blockIdx.x, c0 = ch.first_chunk[q], c1 = ch.first_chunk[q + 1];
+  if (c1 - c0 < 2) return;
+  const size_t r = rowi[q], c = bcol[q], nout = (soff[r + 1] - soff[r]) * (soff[c + 1] - soff[c]);
+  for (size_t e = threadIdx.x; e < nout; e += blockDim.x) {
+    double tot = 0;
+    for (size_t j = c0; j < c1; ++j) tot += ch.partial[j * ch.stride + e];
+    Sv[boff[q] + e] -= (S)tot;
+  }
+}
+__global__ void k_schur_chunk_count(size_t nblk, const size_t *first_product, size_t *count) {
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q < nblk) count[q] = (first_product[q + 1] - first_product[q] + SCHUR_MUL_CHUNK - 1) / SCHUR_MUL_CHUNK;
+}
+__global__ void k_schur_chunk_fill(size_t nblk, const size_t *first_chunk, unsigned *blk) {
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= nblk) return;
+  for (size_t j = first_chunk[q]; j < first_chunk[q + 1]; ++j) blk[j] = (unsigned)q;
 }
 // w_l = Hll^-1 v_l for every landmark block (v = b_l, or b_l - Hpl^T x_p)
 template <typename T, typename S> __global__ void k_schur_apply_inverse(const SchurInvOp *ops, size_t nops, const size_t *lrow, const S *inv, const T *v, T *w) {
@@ -422,8 +472,8 @@ __global__ void k_schur_pair_counts(HView h, size_t *pairs, size_t *inv_size, in
   inv_size[j] = dl * dl;
 }
 // one thread per Hpl block q (pose row a of landmark column l): its Hpl record, and the products (a, bq >= a) it starts —
-// S key, product record (dst filled in by k_schur_mul_dst once S is known) and thread count
-__global__ void k_schur_emit(HView h, size_t nhpl, const size_t *pair_start, const size_t *inv_off, SchurHplOp *hpl, uint64_t *keys, SchurMulOp *mul, size_t *mul_count) {
+// S key and product record (dst filled in by k_schur_mul_dst once S is known)
+__global__ void k_schur_emit(HView h, size_t nhpl, const size_t *pair_start, const size_t *inv_off, SchurHplOp *hpl, uint64_t *keys, SchurMulOp *mul) {
   const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (t >= nhpl) return;
   // Hpl blocks and Hll blocks interleave in H's list: block q = colp[L] + t + (landmark columns before it); find the column by bisection
@@ -438,12 +488,26 @@ __global__ void k_schur_emit(HView h, size_t nhpl, const size_t *pair_start, con
     const size_t rb = h.rowi[bq], db = hv_dim(h, rb);
     keys[p] = pack_block_key(ra, rb);
     mul[p] = SchurMulOp{0, h.boff[q], h.boff[bq], io, (uint32_t)da, (uint32_t)db, (uint32_t)dl, 0};
-    mul_count[p] = da * db;
   }
 }
-__global__ void k_schur_mul_dst(size_t n, const uint64_t *pair_keys, const uint64_t *skeys, size_t ns, const size_t *soffs, SchurMulOp *mul) {
+__global__ void k_schur_mul_dst(size_t n, const uint64_t *pair_keys, const uint64_t *skeys, size_t ns, const size_t *soffs, SchurMulOp *mul, unsigned *blk, unsigned *perm) {
   const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (p < n) mul[p].dst = soffs[find_block_key(skeys, ns, pair_keys[p])];
+  if (p >= n) return;
+  const size_t q = find_block_key(skeys, ns, pair_keys[p]);
+  mul[p].dst = soffs[q];
+  blk[p] = (unsigned)q; perm[p] = (unsigned)p;
+}
+__global__ void k_schur_permute(size_t n, const SchurMulOp *in, const unsigned *perm, SchurMulOp *out) {
+  const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p < n) out[p] = in[perm[p]];
+}
+// first[q] = first sorted product whose block index is >= q (q = 0 .. nblk)
+__global__ void k_first_of_block(size_t nblk, const unsigned *blk_sorted, size_t n, size_t *first) {
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q > nblk) return;
+  size_t lo = 0, hi = n;
+  while (lo < hi) { const size_t mid = (lo + hi) / 2; if (blk_sorted[mid] < q) lo = mid + 1; else hi = mid; }
+  first[q] = lo;
 }
 __global__ void k_schur_copy_ops(size_t n, const uint64_t *hkeys, const size_t *hboff, HView h, const uint64_t *skeys, size_t ns, const size_t *soffs, SchurCopyOp *ops) {
   const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -485,7 +549,11 @@ template <typename T, typename S> class SchurComplement {
   device_vector<detail::SchurCopyOp> d_copy_ops;
   device_vector<detail::SchurInvOp> d_inv_ops;
   device_vector<detail::SchurVecOp> d_vec_ops;
-  size_t landmark_col_start = 0, num_block_columns = 0, pose_dim = 0, landmark_dim = 0, mul_threads = 0, num_blocks = 0;
+  device_vector<unsigned> d_chunk_blk;   // destination block of every product chunk
+  device_vector<size_t> d_chunk_first;   // first chunk of every S block (+ end)
+  device_vector<double> d_mul_partial;   // [chunk][chunk_stride]: partial blocks of the destinations with several chunks
+  size_t num_chunks = 0, chunk_stride = 0;
+  size_t landmark_col_start = 0, num_block_columns = 0, pose_dim = 0, landmark_dim = 0, num_blocks = 0;
 public:
   explicit SchurComplement(Hessian<T, S> &H_) : H(H_) {}
   size_t get_pose_dimension() const { return pose_dim; }
@@ -505,6 +573,7 @@ public:
     landmark_col_start = graph->get_elimination_block_column();
     const size_t L = landmark_col_start, nb = num_block_columns, nl = nb - L;
     const auto &soff = H.host_scalar_offsets();
+    const auto dim_of = [&](size_t b) { return soff[b + 1] - soff[b]; };
     pose_dim = soff[L];
     landmark_dim = soff[nb] - pose_dim;
     const HView hv{H.get_block_col_pointers().raw(), H.get_block_row_indices().raw(), H.device_block_columns().raw(), H.get_block_value_offsets().raw(),
@@ -523,9 +592,8 @@ public:
     d_keys.resize(n_hpp + npairs);
     if (n_hpp) GRAPHITE_HIP(hipMemcpy(d_keys.raw(), H.device_block_keys().raw(), n_hpp * sizeof(uint64_t), hipMemcpyDeviceToDevice));
     device_vector<uint64_t> pair_keys(npairs);
-    device_vector<size_t> mul_count(npairs);
     d_hpl_ops.resize(n_hpl); d_mul_ops.resize(npairs);
-    if (n_hpl) k_schur_emit<<<blocks(n_hpl), TPB>>>(hv, n_hpl, pair_start.raw(), inv_off.raw(), d_hpl_ops.raw(), pair_keys.raw(), d_mul_ops.raw(), mul_count.raw());
+    if (n_hpl) k_schur_emit<<<blocks(n_hpl), TPB>>>(hv, n_hpl, pair_start.raw(), inv_off.raw(), d_hpl_ops.raw(), pair_keys.raw(), d_mul_ops.raw());
     if (npairs) GRAPHITE_HIP(hipMemcpy(d_keys.raw() + n_hpp, pair_keys.raw(), npairs * sizeof(uint64_t), hipMemcpyDeviceToDevice));
     num_blocks = sort_unique_keys(d_keys);
     d_schur_offsets.resize(L + 1);
@@ -545,9 +613,32 @@ public:
     if (n_hpp) k_schur_copy_ops<<<blocks(n_hpp), TPB>>>(n_hpp, H.device_block_keys().raw(), H.get_block_value_offsets().raw(), hv, d_keys.raw(), num_blocks, d_offsets.raw(), d_copy_ops.raw()); // Hpp copy (:587)
     d_inv_ops.resize(nl); d_inv_lrow.resize(nl);
     if (nl) k_schur_inv_ops<<<blocks(nl), TPB>>>(hv, inv_off.raw(), d_inv_ops.raw(), d_inv_lrow.raw());
-    if (npairs) k_schur_mul_dst<<<blocks(npairs), TPB>>>(npairs, pair_keys.raw(), d_keys.raw(), num_blocks, d_offsets.raw(), d_mul_ops.raw());
-    mul_threads = exclusive_scan(mul_count, d_mul_first);
-    d_mul_first.resize(npairs);
+    // products grouped by destination block (stable sort on the block index: landmark order inside a block), d_mul_first[q] = first product of S block q
+    {
+      device_vector<unsigned> blk(npairs), blk_sorted(npairs), perm(npairs), perm_sorted(npairs);
+      device_vector<SchurMulOp> unsorted(npairs);
+      if (npairs) {
+        k_schur_mul_dst<<<blocks(npairs), TPB>>>(npairs, pair_keys.raw(), d_keys.raw(), num_blocks, d_offsets.raw(), d_mul_ops.raw(), blk.raw(), perm.raw());
+        ScratchBytes scratch;
+        size_t bytes = 0;
+        GRAPHITE_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, blk.raw(), blk_sorted.raw(), perm.raw(), perm_sorted.raw(), (int)npairs));
+        GRAPHITE_HIP(hipcub::DeviceRadixSort::SortPairs(scratch.get(bytes), bytes, blk.raw(), blk_sorted.raw(), perm.raw(), perm_sorted.raw(), (int)npairs));
+        GRAPHITE_HIP(hipMemcpy(unsorted.raw(), d_mul_ops.raw(), npairs * sizeof(SchurMulOp), hipMemcpyDeviceToDevice));
+        k_schur_permute<<<blocks(npairs), TPB>>>(npairs, unsorted.raw(), perm_sorted.raw(), d_mul_ops.raw());
+      }
+      d_mul_first.resize(num_blocks + 1);
+      k_first_of_block<<<blocks(num_blocks + 1), TPB>>>(num_blocks, blk_sorted.raw(), npairs, d_mul_first.raw());
+      // chunks of <= SCHUR_MUL_CHUNK products of one destination: the workgroups of k_schur_mul
+      device_vector<size_t> nchunk(num_blocks);
+      if (num_blocks) k_schur_chunk_count<<<blocks(num_blocks), TPB>>>(num_blocks, d_mul_first.raw(), nchunk.raw());
+      num_chunks = exclusive_scan(nchunk, d_chunk_first);
+      d_chunk_blk.resize(num_chunks);
+      if (num_blocks) k_schur_chunk_fill<<<blocks(num_blocks), TPB>>>(num_blocks, d_chunk_first.raw(), d_chunk_blk.raw());
+      chunk_stride = 0;
+      for (size_t b = 0; b < L; ++b) chunk_stride = std::max(chunk_stride, dim_of(b));
+      chunk_stride *= chunk_stride; // the largest S block
+      d_mul_partial.resize(num_chunks * chunk_stride);
+    }
     device_vector<size_t> vec_count(num_blocks), vec_first;
     if (num_blocks) k_schur_vec_ops<true><<<blocks(num_blocks), TPB>>>(num_blocks, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), nullptr, vec_count.raw(), nullptr);
     d_vec_ops.resize(exclusive_scan(vec_count, vec_first));
@@ -566,7 +657,11 @@ public:
     d_schur.zero();
     if (d_copy_ops.size()) k_schur_copy<S><<<(unsigned)d_copy_ops.size(), 64>>>(d_copy_ops.raw(), d_copy_ops.size(), H.get_values_ptr(), d_schur.raw());
     if (d_inv_ops.size()) k_schur_invert<S><<<blocks(d_inv_ops.size()), TPB>>>(d_inv_ops.raw(), d_inv_ops.size(), H.get_values_ptr(), d_hll_inv.raw());
-    if (mul_threads) k_schur_mul<S><<<blocks(mul_threads), TPB>>>(d_mul_ops.raw(), d_mul_first.raw(), d_mul_ops.size(), mul_threads, H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw());
+    if (num_chunks) {
+      const SchurChunks ch{d_chunk_blk.raw(), d_chunk_first.raw(), d_mul_first.raw(), d_mul_partial.raw(), chunk_stride};
+      k_schur_mul<S><<<(unsigned)num_chunks, SCHUR_MUL_THREADS>>>(d_mul_ops.raw(), ch, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw());
+      k_schur_mul_join<S><<<(unsigned)num_blocks, 128>>>(num_blocks, ch, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), d_schur.raw());
+    }
     // b_S = b_p - Hpl Hll^-1 b_l (:901-920)
     const T *b = graph->get_b().raw();
     GRAPHITE_HIP(hipMemcpy(b_Schur.raw(), b, pose_dim * sizeof(T), hipMemcpyDefault));
