@@ -837,6 +837,7 @@ template <typename T> struct Engine final : EngineBase {
       allreduce_d(dscalars.p, spec_seq ? 2 : 1);
       group_end();
       k_camera_scales<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, scale_system ? 1 : 0, Hcc.p, scales.p);
+      if (spec_seq) publish_scalars(2, spec_seq);
     }
     hcp_valid = write_hcp;
   }
@@ -881,19 +882,14 @@ template <typename T> struct Engine final : EngineBase {
     const int seq = ++seq_counter;
     Scope sc(this, "chi2", No * (2 * w() + 8) + (24.0 * Nc + 3.0 * Np) * w() + (dx ? 3.0 * n * w() : 0.0), No * 40.0);
     k_chi2<T><<<grid_chi2, TPB, 0, stream>>>((int)No, (unsigned)n, (unsigned)pose_dim, cam_weight(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, comm ? nullptr : h_res, h_seq, seq, res_out);
-    if (comm) allreduce_d(dscalars.p, 2);
+    if (comm) { allreduce_d(dscalars.p, 2); publish_scalars(2, seq); }
     return seq;
   }
+  // landmark shards: the sums over ranks live in device memory; one tiny launch mirrors them to the pinned words the host polls
+  void publish_scalars(int count, int seq) { k_publish_scalars<<<1, 1, 0, stream>>>(dscalars.p, count, h_res, h_seq, seq); }
   void wait_chi2(int seq) {
-    if (comm) { // the sums over ranks live in device memory
-      double hs[2];
-      GR_HIP(hipMemcpyAsync(hs, dscalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
-      GR_HIP(hipStreamSynchronize(stream));
-      check_comm("levenberg_marquardt"); // the accept decision of every rank hangs on these two sums
-      h_res[0] = hs[0]; h_res[1] = hs[1];
-      return;
-    }
     spin_until([&] { return __atomic_load_n(const_cast<const int *>(h_seq), __ATOMIC_ACQUIRE) == seq; });
+    if (comm) check_comm("levenberg_marquardt"); // the accept decision of every rank hangs on these sums
   }
   double read_scalar(int idx) {
     double v = 0;

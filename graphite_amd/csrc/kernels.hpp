@@ -568,4 +568,13 @@ k_pcgs_direction(int Nc, T *__restrict__ x, const T *__restrict__ xb, T *__restr
   }
 }
 
+// Landmark shards: the two LM scalars (trial chi2, rho denominator) have just been summed over the ranks in device memory;
+// mirror them into pinned host memory and raise the sequence word the host polls (same hand-over as the single-GPU kernels'
+// own publication: no device-to-host copy, no stream synchronisation on the accept path)
+__global__ void k_publish_scalars(const double *__restrict__ d, int count, volatile double *hres, volatile int *hres_seq, int seq) {
+  for (int i = 0; i < count; ++i) hres[i] = d[i];
+  __threadfence_system();
+  *hres_seq = seq;
+  __threadfence_system();
+}
 } // namespace gr
