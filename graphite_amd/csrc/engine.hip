@@ -815,14 +815,18 @@ template <typename T> struct Engine final : EngineBase {
   // rho-denominator partials and publishes (chi2, denominator, spec_seq) to pinned host memory
   DevBuf<double> rho_partial;
   int rho_blocks = 0;
-  void linearize_impl(bool write_hcp, bool pack_valid = false, int spec_seq = 0, const int *gate = nullptr) {
+  // part: 1 = the k_linearize launch only, 2 = its finalisation (+ the collectives of landmark shards) only, 3 = both.  The LM
+  // loop of landmark shards enqueues part 1 AHEAD of the PCG exit flag (gated on the device, no collective inside: a rank whose
+  // gate was still closed repeats it later on its own) and part 2 once the flag has been seen.
+  void linearize_impl(bool write_hcp, bool pack_valid = false, int spec_seq = 0, const int *gate = nullptr, int part = 3) {
     if (!pack_valid) campack();
-    {
+    if (part & 1) {
       // algorithmic bytes: every array touched once (obs, 3 index streams, points, packs, g9 out, partials, Hcp)
       const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
       Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)), true);
       launch_linearize_cam(write_hcp, g9.p, gate);
     }
+    if (!(part & 2)) return;
     {
       const int np_fin = (int)Np;
       Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg, true);
@@ -1069,6 +1073,7 @@ template <typename T> struct Engine final : EngineBase {
   // trial step disappears; wrong: three kernels return at once and the trial step is enqueued again later.
   std::function<void(const int *gate)> trial_hook;
   bool trial_done = false;
+  int trial_part = 3; // linearize_impl's `part` for the trial enqueued by the LM loop
   DevBuf<int> loop_left;
   template <typename Enqueue> int run_pcg_iterations(int max_iter, Enqueue &&enqueue, int pre_enqueued = 0) {
     int enqueued = 0, hook_at = -1;
@@ -1977,10 +1982,12 @@ template <typename T> struct Engine final : EngineBase {
         k_apply_update_rho<T><<<rho_blocks + (clear_state ? 1 : 0), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, pack.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr,
                                                                                        nullptr, clear_state ? pcg_state() : PcgState{}, clear_state ? ctl_cap : 0, gate);
         seq = ++seq_counter;
-        linearize_impl(want_hcp, /*pack_valid=*/true, seq, gate);
+        linearize_impl(want_hcp, /*pack_valid=*/true, seq, gate, trial_part);
       };
-      const bool ahead = speculate && !comm && !profiling && ahead_enabled && pcg_solver;
-      if (ahead) trial_hook = enqueue_trial;
+      // landmark shards: only the collective-free front of the trial (step + k_linearize) goes ahead of the exit flag
+      auto enqueue_trial_front = [&](const int *gate) { trial_part = 1; enqueue_trial(gate); trial_part = 3; };
+      const bool ahead = speculate && !profiling && ahead_enabled && pcg_solver;
+      if (ahead) { if (comm) trial_hook = enqueue_trial_front; else trial_hook = enqueue_trial; }
       trial_done = false;
       const bool solve_ok = solver_solve_dev(opt.solver, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, v_dx.p);
       trial_hook = nullptr;
@@ -1993,6 +2000,7 @@ template <typename T> struct Engine final : EngineBase {
       // sums are fixed-order).  After a rejection the plain chi2 pass is used.
       if (speculate) {
         if (!trial_ahead) enqueue_trial(nullptr);
+        else if (comm) linearize_impl(want_hcp, /*pack_valid=*/true, seq, nullptr, 2); // the loop has left: finalisation + the sums over ranks
         if (ctl_cap > 0 && pcg_solver) state_clean_cap = ctl_cap;
         if (!(use_records && xp.n && xp_valid)) xp_valid = false;
       } else {
