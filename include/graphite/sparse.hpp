@@ -335,26 +335,45 @@ template <typename S> __global__ void k_schur_invert(const SchurInvOp *ops, size
 // single chunk (almost all off-diagonal blocks) is finished there; the others (a camera's diagonal block collects one
 // product per observation) leave one partial block per chunk and k_schur_mul_join adds them in chunk order — no atomics,
 // no per-thread search, the same bits every run, and no workgroup walks more than SCHUR_MUL_CHUNK products.
-constexpr int SCHUR_MUL_THREADS = 256, SCHUR_MUL_CHUNK = 64;
+constexpr int SCHUR_MUL_THREADS = 256, SCHUR_MUL_CHUNK = 64, SCHUR_MUL_STAGE = 1024;
 struct SchurChunks { const unsigned *blk; const size_t *first_chunk; const size_t *first_product; double *partial; size_t stride; };
+// max_dl: largest eliminated-vertex dimension of the graph (sizes the LDS share of a slice).  Every product's three blocks
+// (L: da x dl, R: db x dl, M: dl x dl — contiguous in H / the inverse array) are staged through LDS by the slice that
+// owns the product, one coalesced load per value, instead of every output thread fetching its 2 dl + dl^2 operands itself.
 template <typename S> __global__ void __launch_bounds__(SCHUR_MUL_THREADS)
-k_schur_mul(const SchurMulOp *ops, SchurChunks ch, const size_t *rowi, const size_t *bcol, const size_t *boff, const size_t *soff, const S *H, const S *inv, S *Sv) {
+k_schur_mul(const SchurMulOp *ops, SchurChunks ch, const size_t *rowi, const size_t *bcol, const size_t *boff, const size_t *soff, const S *H, const S *inv, S *Sv, uint32_t max_dl) {
   __shared__ double part[SCHUR_MUL_THREADS];
+  __shared__ S stage[SCHUR_MUL_STAGE];
   const size_t j = blockIdx.x, q = ch.blk[j], i = j - ch.first_chunk[q], nchunk = ch.first_chunk[q + 1] - ch.first_chunk[q];
   const size_t p0 = ch.first_product[q] + i * SCHUR_MUL_CHUNK, pe = ch.first_product[q + 1], p1 = p0 + SCHUR_MUL_CHUNK < pe ? p0 + SCHUR_MUL_CHUNK : pe;
   const size_t r = rowi[q], c = bcol[q];
   const uint32_t da = (uint32_t)(soff[r + 1] - soff[r]), db = (uint32_t)(soff[c + 1] - soff[c]), nout = da * db;
+  const uint32_t cap = max_dl * (da + db + max_dl); // staged values of one product, at most
   // more outputs than threads (two pose blocks beyond 16 x 16): round trips
   for (uint32_t e0 = 0; e0 < nout; e0 += SCHUR_MUL_THREADS) {
     const uint32_t span = nout - e0 < SCHUR_MUL_THREADS ? nout - e0 : SCHUR_MUL_THREADS;
-    const uint32_t slices = SCHUR_MUL_THREADS / span, s = threadIdx.x / span, e = e0 + threadIdx.x % span;
+    uint32_t slices = SCHUR_MUL_THREADS / span;
+    const bool staged = cap <= SCHUR_MUL_STAGE;
+    if (staged && slices * cap > SCHUR_MUL_STAGE) slices = SCHUR_MUL_STAGE / cap;
+    const uint32_t s = threadIdx.x / span, el = threadIdx.x % span, e = e0 + el, row = e % da, col = e / da;
+    const uint32_t nit = (uint32_t)((p1 - p0 + slices - 1) / slices);
     double acc = 0;
-    if (s < slices) {
-      const uint32_t row = e % da, col = e / da;
-#pragma unroll 4
-      for (size_t p = p0 + s; p < p1; p += slices) {
-        const SchurMulOp o = ops[p];
-        const S *L = H + o.left, *R = H + o.right, *M = inv + o.mid;
+    for (uint32_t it = 0; it < nit; ++it) { // block-uniform trip count: the barriers are reached by every thread
+      const size_t p = p0 + (size_t)it * slices + s;
+      const bool mine = s < slices && p < p1;
+      SchurMulOp o{};
+      if (mine) o = ops[p];
+      const S *L = H + o.left, *R = H + o.right, *M = inv + o.mid;
+      if (staged) {
+        S *st = stage + s * cap;
+        if (mine) {
+          const uint32_t nl = da * o.dl, nr = db * o.dl, cnt = nl + nr + o.dl * o.dl;
+          for (uint32_t v = el; v < cnt; v += span) st[v] = v < nl ? L[v] : v < nl + nr ? R[v - nl] : M[v - nl - nr];
+          L = st; R = st + nl; M = st + nl + nr;
+        }
+        __syncthreads();
+      }
+      if (mine) {
         S value = 0;
         for (uint32_t k = 0; k < o.dl; ++k) {
           S mrt = 0;
@@ -363,6 +382,7 @@ k_schur_mul(const SchurMulOp *ops, SchurChunks ch, const size_t *rowi, const siz
         }
         acc += (double)value;
       }
+      if (staged) __syncthreads();
     }
     part[threadIdx.x] = acc;
     __syncthreads();
@@ -552,7 +572,7 @@ template <typename T, typename S> class SchurComplement {
   device_vector<unsigned> d_chunk_blk;   // destination block of every product chunk
   device_vector<size_t> d_chunk_first;   // first chunk of every S block (+ end)
   device_vector<double> d_mul_partial;   // [chunk][chunk_stride]: partial blocks of the destinations with several chunks
-  size_t num_chunks = 0, chunk_stride = 0;
+  size_t num_chunks = 0, chunk_stride = 0, max_landmark_dim = 1;
   size_t landmark_col_start = 0, num_block_columns = 0, pose_dim = 0, landmark_dim = 0, num_blocks = 0;
 public:
   explicit SchurComplement(Hessian<T, S> &H_) : H(H_) {}
@@ -637,6 +657,8 @@ public:
       chunk_stride = 0;
       for (size_t b = 0; b < L; ++b) chunk_stride = std::max(chunk_stride, dim_of(b));
       chunk_stride *= chunk_stride; // the largest S block
+      max_landmark_dim = 1;
+      for (size_t b = L; b < nb; ++b) max_landmark_dim = std::max(max_landmark_dim, dim_of(b));
       d_mul_partial.resize(num_chunks * chunk_stride);
     }
     device_vector<size_t> vec_count(num_blocks), vec_first;
@@ -659,7 +681,7 @@ public:
     if (d_inv_ops.size()) k_schur_invert<S><<<blocks(d_inv_ops.size()), TPB>>>(d_inv_ops.raw(), d_inv_ops.size(), H.get_values_ptr(), d_hll_inv.raw());
     if (num_chunks) {
       const SchurChunks ch{d_chunk_blk.raw(), d_chunk_first.raw(), d_mul_first.raw(), d_mul_partial.raw(), chunk_stride};
-      k_schur_mul<S><<<(unsigned)num_chunks, SCHUR_MUL_THREADS>>>(d_mul_ops.raw(), ch, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw());
+      k_schur_mul<S><<<(unsigned)num_chunks, SCHUR_MUL_THREADS>>>(d_mul_ops.raw(), ch, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw(), (uint32_t)max_landmark_dim);
       k_schur_mul_join<S><<<(unsigned)num_blocks, 128>>>(num_blocks, ch, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), d_schur.raw());
     }
     // b_S = b_p - Hpl Hll^-1 b_l (:901-920)
