@@ -101,6 +101,7 @@ inline size_t sort_unique_keys(device_vector<uint64_t> &keys) {
 // out[i] = sum of in[0..i), out[n] = total (n + 1 entries); returns the total
 inline size_t exclusive_scan(const device_vector<size_t> &in, device_vector<size_t> &out) {
   const size_t n = in.size();
+  if (n > (size_t)std::numeric_limits<int>::max()) throw std::invalid_argument("block-sparse structure: more than 2^31 entries in a scan");
   out.resize(n + 1);
   if (!n) { out.zero(); return 0; }
   ScratchBytes scratch;
