@@ -239,9 +239,16 @@ k_schur_products(int nitems, const int *__restrict__ item_blk, const int *__rest
 #pragma unroll
   for (int r = 0; r < 9; ++r) acc[r] = T(0);
   if (g < 7) {
-    for (int q = item_beg[item] + g; q < item_end[item]; q += 7) {
-      const int a = prod_a[q], b = prod_b[q];
-      const T *m = Mp + 9 * (size_t)pt_pm[a];
+    // the index chain of the NEXT product of this group (product list -> pm position -> point) is fetched while the current
+    // one is being multiplied: one memory round trip per round instead of three dependent ones
+    const int q_end = item_end[item];
+    int q = item_beg[item] + g;
+    int a_n = 0, b_n = 0, pm_n = 0;
+    if (q < q_end) { a_n = prod_a[q]; b_n = prod_b[q]; pm_n = pt_pm[a_n]; }
+    for (; q < q_end; q += 7) {
+      const int a = a_n, b = b_n;
+      const T *m = Mp + 9 * (size_t)pm_n;
+      if (q + 7 < q_end) { a_n = prod_a[q + 7]; b_n = prod_b[q + 7]; pm_n = pt_pm[a_n]; }
       const T *hb = Hcp + 27 * (size_t)b + c;
       const T hb0 = hb[0], hb1 = hb[9], hb2 = hb[18];
       const T u0 = m[0] * hb0 + m[3] * hb1 + m[6] * hb2;
