@@ -221,8 +221,11 @@ __device__ __forceinline__ void schur_epilogue(int i, int j, int c, const T *acc
   }
 }
 
+#ifndef SCHUR_WAVES
+#define SCHUR_WAVES 4
+#endif
 template <typename T>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB, SCHUR_WAVES)
 k_schur_products(int nitems, const int *__restrict__ item_blk, const int *__restrict__ item_beg,
                  const int *__restrict__ item_end, const int *__restrict__ item_single,
                  const int *__restrict__ prod_a, const int *__restrict__ prod_b,

@@ -18,7 +18,7 @@ for f in glob.glob(os.path.join(out, "*", "*counter_collection.csv")) + glob.glo
         agg[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(os.path.join(out, "summary.txt"), "w") as fh:
     for k, d in sorted(agg.items()):
-        if not any(x in k for x in ("k_linearize", "k_pcg", "k_block", "k_apply")): continue
+        if not any(x in k for x in ("k_linearize", "k_pcg", "k_block", "k_apply", "k_schur", "k_finalize", "k_bschur", "k_backsub")): continue
         line = k.ljust(62) + " ".join(f"{c}={sum(v)/len(v):.3g}" for c, v in sorted(d.items()))
         print(line); fh.write(line + "\n")
 PY
