@@ -241,25 +241,39 @@ k_schur_products(int nitems, const int *__restrict__ item_blk, const int *__rest
   T acc[9];
 #pragma unroll
   for (int r = 0; r < 9; ++r) acc[r] = T(0);
+  // Operands through LDS.  Every lane of a group needs the SAME 27 scalars of Ha and 9 of M (plus its own column of Hb): fetched
+  // redundantly they are 39 live fp64 registers per lane and every round of 7 products waits one full memory latency for them at
+  // 3 waves per SIMD (352-369 us on Ladybug-1723).  Here the 9 lanes of a group fetch the 36 shared scalars ONCE (4 per lane, the
+  // NEXT round's while the current one is multiplied), park them in the group's LDS strip and read them back as broadcasts.  LDS
+  // operations of one wave execute in issue order, so a strip needs no barrier between its writes, its reads and the next
+  // round's writes.
+  __shared__ T strip[4][7][40]; // [wave][group][27 Ha | 9 M | pad]
   if (g < 7) {
-    // the index chain of the NEXT product of this group (product list -> pm position -> point) is fetched while the current
-    // one is being multiplied: one memory round trip per round instead of three dependent ones
+    T *sg = strip[threadIdx.x >> 6][g];
     const int q_end = item_end[item];
     int q = item_beg[item] + g;
     int a_n = 0, b_n = 0, pm_n = 0;
-    if (q < q_end) { a_n = prod_a[q]; b_n = prod_b[q]; pm_n = pt_pm[a_n]; }
+    T h_n[3], hb_n[3], m_n = T(0);
+    auto fetch = [&](int qq) { // indices (dependent chain) and, from them, this lane's share of the operands of product qq
+      a_n = prod_a[qq]; b_n = prod_b[qq]; pm_n = pt_pm[a_n];
+      const T *ha = Hcp + 27 * (size_t)a_n + c, *hb = Hcp + 27 * (size_t)b_n + c;
+      h_n[0] = ha[0]; h_n[1] = ha[9]; h_n[2] = ha[18];
+      hb_n[0] = hb[0]; hb_n[1] = hb[9]; hb_n[2] = hb[18];
+      m_n = Mp[9 * (size_t)pm_n + c];
+    };
+    if (q < q_end) fetch(q);
     for (; q < q_end; q += 7) {
-      const int a = a_n, b = b_n;
-      const T *m = Mp + 9 * (size_t)pm_n;
-      if (q + 7 < q_end) { a_n = prod_a[q + 7]; b_n = prod_b[q + 7]; pm_n = pt_pm[a_n]; }
-      const T *hb = Hcp + 27 * (size_t)b + c;
-      const T hb0 = hb[0], hb1 = hb[9], hb2 = hb[18];
-      const T u0 = m[0] * hb0 + m[3] * hb1 + m[6] * hb2;
-      const T u1 = m[1] * hb0 + m[4] * hb1 + m[7] * hb2;
-      const T u2 = m[2] * hb0 + m[5] * hb1 + m[8] * hb2;
-      const T *ha = Hcp + 27 * (size_t)a;
+      sg[c] = h_n[0]; sg[c + 9] = h_n[1]; sg[c + 18] = h_n[2]; sg[27 + c] = m_n;
+      const T hb0 = hb_n[0], hb1 = hb_n[1], hb2 = hb_n[2];
+      if (q + 7 < q_end) fetch(q + 7);
+      T mv[9];
 #pragma unroll
-      for (int r = 0; r < 9; ++r) acc[r] += ha[r] * u0 + ha[r + 9] * u1 + ha[r + 18] * u2;
+      for (int i = 0; i < 9; ++i) mv[i] = sg[27 + i];
+      const T u0 = mv[0] * hb0 + mv[3] * hb1 + mv[6] * hb2;
+      const T u1 = mv[1] * hb0 + mv[4] * hb1 + mv[7] * hb2;
+      const T u2 = mv[2] * hb0 + mv[5] * hb1 + mv[8] * hb2;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) acc[r] += sg[r] * u0 + sg[r + 9] * u1 + sg[r + 18] * u2;
     }
   }
   // combine the 7 groups: lanes 0..8 collect
