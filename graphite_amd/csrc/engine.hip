@@ -111,6 +111,8 @@ template <typename T> struct Engine final : EngineBase {
   std::vector<int> h_pt_new2old, h_pt_old2new; // internal point order: sorted by first observing camera
   int nch = 0, nb_pm = 0, nseg = 0;
   int num_cu = 256, grid_obs = 0, grid_vec = 0, grid_chi2 = 0; // persistent grids
+  int fbj_per_cu = 4;            // k_finalize_bj: workgroups resident per CU (occupancy query)
+  int grid_isp = 0;              // k_is_prepare: resident workgroups
   int grid_lin = 0, grid_op = 0; // k_linearize / k_pcg_operator: exactly the workgroups that are resident at once (apply_tuning)
   // Schur structure (lazy)
   bool schur_ready = false;
@@ -367,6 +369,13 @@ template <typename T> struct Engine final : EngineBase {
       return std::max(8, std::min(nb_pm, num_cu * mult) & ~7);
     };
     grid_lin = resident(reinterpret_cast<const void *>(&k_linearize<T, false>), LIN_WAVES, 8);
+    // implicit Schur complement: k_is_prepare needs 242 VGPRs (2 workgroups per CU) and was launched on the common 4-per-CU grid
+    grid_isp = resident(reinterpret_cast<const void *>(&k_is_prepare<T, T>), 2, 4);
+    {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_finalize_bj<T>), TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 3; }
+      fbj_per_cu = env_int("GR_FBJ_PER_CU", 0) > 0 ? env_int("GR_FBJ_PER_CU", 0) : std::min(nb, 8);
+    }
     // the operator prefers 3 (fp64) / 4 (fp32) workgroups per CU even where more would fit (Venice-1778 fp32: 83.6 us at 4, 89.7 at its occupancy)
     grid_op = resident(reinterpret_cast<const void *>(&k_pcg_operator<T, 0, T>), 3, sizeof(T) == 8 ? 3 : 4);
     // light vector kernels: several elements per thread (every wave first re-derives the loop scalars from the
@@ -1785,7 +1794,12 @@ template <typename T> struct Engine final : EngineBase {
     T *rec = use_records ? xp.p : nullptr;
     PcgState st = pcg_state();
     st.x = v_dx.p; st.tol = tol; st.rej = rej; st.ts_op = first_lazy ? 1 : 0;
-    const int fbj_nbc = cdiv(Nc, 28), fbj_nbp = std::max(1, std::min(cdiv(Np, TPB / FIN_PL), num_cu * 4));
+    // The point workgroups are persistent.  Few camera workgroups (Ladybug-1723: 62 of 1 024 slots): the whole grid is resident at
+    // once — a point workgroup that has to wait for a camera workgroup's slot finishes a camera part + a full point share late
+    // (30.9 vs 26.4 us).  Many (Final-13682: 489): they are short-lived, and leaving their slots to them alone starves the point
+    // part (1 024 vs 840 us), so the point workgroups fill every slot and start as the camera workgroups retire.
+    const int fbj_nbc = cdiv(Nc, 28), fbj_slots = num_cu * fbj_per_cu;
+    const int fbj_nbp = std::max(1, std::min(cdiv(Np, TPB / FIN_PL), 4 * fbj_nbc < fbj_slots ? fbj_slots - fbj_nbc : fbj_slots));
     if (first_lazy) { fbj_part.alloc(3 * (size_t)(fbj_nbc + fbj_nbp)); st.part0 = fbj_part.p; st.n_part0 = fbj_nbc + fbj_nbp; }
     if (!pcg_state_clean) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
     pcg_state_clean = false;

@@ -230,8 +230,11 @@ struct LmDecide {
   LmDev *lm = nullptr;
   double *dscal = nullptr;                      // device copy of [0], [1]
 };
+#ifndef FBJ_WAVES
+#define FBJ_WAVES 4 // waves per SIMD the kernel is compiled for (130 VGPRs uncapped: 3 workgroups per CU of a grid sized for 4)
+#endif
 template <typename T, int VAR = 0> // VAR (diagnostic timing only): 1 few output stores, 2 no inverse / scale math, 4 no record loads, 8 no dot-product atomics
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB, FBJ_WAVES)
 k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__ cam_seg_ptr, const T *__restrict__ cam_partial,
               const int *__restrict__ pt_ptr, const T *__restrict__ g9, T *__restrict__ Hcc, T *__restrict__ bu,
               T *__restrict__ Hll, T *__restrict__ scales, double mu, int use_identity, T *__restrict__ MinvC,
