@@ -1068,6 +1068,34 @@ template <typename T, typename S> __global__ void k_diag_store(size_t nv, size_t
   if (off != ~size_t(0)) values[off + t % dd] += (S)blocks[t];
 }
 
+// ---- small dense inverses, one thread per block ------------------------------------------------------------------------------
+// The two d x d work matrices of a thread live in LDS laid out [entry][thread] (a wave's accesses to one entry are consecutive
+// words) instead of dynamically indexed per-thread arrays, which the compiler can only keep in scratch memory (4 KB per thread
+// for d <= 16: the 1 723 camera blocks of a bundle-adjustment S took 320 us that way).  BLOCK_INV_THREADS threads per
+// workgroup: 2 d^2 doubles each, d <= 16 -> at most 128 KB of the CU's 160 KB.
+constexpr int BLOCK_INV_THREADS = 32;
+inline size_t block_inverse_lds_bytes(size_t d) { return 2 * d * d * BLOCK_INV_THREADS * sizeof(double); }
+// Gauss-Jordan with partial pivoting (the reference: cuBLAS matinvBatched): A (column-major, destroyed), R = A^-1; entry e of
+// this thread is A[e * nt]
+__device__ inline void lds_gauss_jordan(double *A, double *R, int d, int nt) {
+  for (int k = 0; k < d; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < d; ++r) if (fabs(A[(r + k * d) * nt]) > fabs(A[(piv + k * d) * nt])) piv = r;
+    if (piv != k)
+      for (int c = 0; c < d; ++c) {
+        double t = A[(k + c * d) * nt]; A[(k + c * d) * nt] = A[(piv + c * d) * nt]; A[(piv + c * d) * nt] = t;
+        t = R[(k + c * d) * nt]; R[(k + c * d) * nt] = R[(piv + c * d) * nt]; R[(piv + c * d) * nt] = t;
+      }
+    const double ip = 1.0 / A[(k + k * d) * nt];
+    for (int c = 0; c < d; ++c) { A[(k + c * d) * nt] *= ip; R[(k + c * d) * nt] *= ip; }
+    for (int r = 0; r < d; ++r) {
+      if (r == k) continue;
+      const double f = A[(r + k * d) * nt];
+      for (int c = 0; c < d; ++c) { A[(r + c * d) * nt] -= f * A[(k + c * d) * nt]; R[(r + c * d) * nt] -= f * R[(k + c * d) * nt]; }
+    }
+  }
+}
+
 template <typename VD> __global__ void k_flag_vertices(const size_t *active_ids, size_t n_active, const size_t *ids, size_t N, size_t I, uint8_t *state) {
   const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (a >= n_active) return;

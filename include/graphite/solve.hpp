@@ -41,11 +41,7 @@ template <typename T> __global__ void k_dot(const T *a, const T *b, size_t n, T 
 }
 // in-place inverse of `count` d x d blocks (column-major) after damping the diagonal
 // (block_jacobi.hpp:120-172; the reference uses cuBLAS matinvBatched = Gauss-Jordan with pivoting)
-// One thread per block, as the batched inverse of the reference, but the two d x d work matrices live in LDS ([entry][thread], so a
-// wave's accesses to one entry hit 64 banks' worth of consecutive words) instead of dynamically indexed per-thread arrays, which the
-// compiler can only keep in scratch memory: 300 camera blocks of a bundle-adjustment graph took 318 us, 60 000 3 x 3 blocks 160 us.
-// BLOCK_INV_THREADS threads per workgroup: 2 d^2 doubles each, d <= 16 -> at most 128 KB of the CU's 160 KB.
-constexpr int BLOCK_INV_THREADS = 32;
+// One thread per block, as the batched inverse of the reference; work matrices in LDS (core.hpp: lds_gauss_jordan).
 template <typename T> __global__ void __launch_bounds__(BLOCK_INV_THREADS) k_block_inverse(const T *blocks, T *inv, size_t count, int d, T mu, int identity, const uint8_t *state) {
   extern __shared__ double lds_inv[];
   const int tid = threadIdx.x, nt = BLOCK_INV_THREADS;
@@ -61,22 +57,7 @@ template <typename T> __global__ void __launch_bounds__(BLOCK_INV_THREADS) k_blo
       A[(r + c * d) * nt] = val;
       R[(r + c * d) * nt] = r == c ? 1.0 : 0.0;
     }
-  for (int k = 0; k < d; ++k) {
-    int piv = k;
-    for (int r = k + 1; r < d; ++r) if (fabs(A[(r + k * d) * nt]) > fabs(A[(piv + k * d) * nt])) piv = r;
-    if (piv != k)
-      for (int c = 0; c < d; ++c) {
-        double t = A[(k + c * d) * nt]; A[(k + c * d) * nt] = A[(piv + c * d) * nt]; A[(piv + c * d) * nt] = t;
-        t = R[(k + c * d) * nt]; R[(k + c * d) * nt] = R[(piv + c * d) * nt]; R[(piv + c * d) * nt] = t;
-      }
-    const double ip = 1.0 / A[(k + k * d) * nt];
-    for (int c = 0; c < d; ++c) { A[(k + c * d) * nt] *= ip; R[(k + c * d) * nt] *= ip; }
-    for (int r = 0; r < d; ++r) {
-      if (r == k) continue;
-      const double f = A[(r + k * d) * nt];
-      for (int c = 0; c < d; ++c) { A[(r + c * d) * nt] -= f * A[(k + c * d) * nt]; R[(r + c * d) * nt] -= f * R[(k + c * d) * nt]; }
-    }
-  }
+  lds_gauss_jordan(A, R, d, nt);
   for (int i = 0; i < d * d; ++i) X[i] = (T)R[i * nt];
 }
 template <typename T> __global__ void k_block_apply(const T *inv, const size_t *hid, const uint8_t *state, size_t count, int d, T *z, const T *r) {
@@ -291,28 +272,18 @@ public:
 // vertices must not share a factor (Hll block diagonal), as in the reference.
 namespace detail {
 // d x d diagonal blocks of the sparse S, one per pose block (block_jacobi_schur.hpp:114-150): copy + invert
-template <typename T, typename S> __global__ void k_schur_diag_inverse(size_t nblocks, const size_t *diag_off, const size_t *soff, const S *Sv, T *inv, const size_t *inv_off) {
-  const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+template <typename T, typename S> __global__ void __launch_bounds__(BLOCK_INV_THREADS)
+k_schur_diag_inverse(size_t nblocks, const size_t *diag_off, const size_t *soff, const S *Sv, T *inv, const size_t *inv_off, int max_d) {
+  extern __shared__ double lds_inv[];
+  const int tid = threadIdx.x, nt = BLOCK_INV_THREADS;
+  const size_t b = blockIdx.x * (size_t)nt + tid;
   if (b >= nblocks) return;
-  constexpr int MAXD = 16;
   const int d = (int)(soff[b + 1] - soff[b]);
-  double A[MAXD * MAXD], R[MAXD * MAXD];
+  double *A = lds_inv + tid, *R = lds_inv + (size_t)max_d * max_d * nt + tid;
   const S *B = Sv + diag_off[b];
-  for (int i = 0; i < d * d; ++i) { A[i] = (double)B[i]; R[i] = (i % d == i / d) ? 1.0 : 0.0; }
-  for (int k = 0; k < d; ++k) {
-    int piv = k;
-    for (int r = k + 1; r < d; ++r) if (fabs(A[r + k * d]) > fabs(A[piv + k * d])) piv = r;
-    if (piv != k)
-      for (int c = 0; c < d; ++c) { double t = A[k + c * d]; A[k + c * d] = A[piv + c * d]; A[piv + c * d] = t; t = R[k + c * d]; R[k + c * d] = R[piv + c * d]; R[piv + c * d] = t; }
-    const double ip = 1.0 / A[k + k * d];
-    for (int c = 0; c < d; ++c) { A[k + c * d] *= ip; R[k + c * d] *= ip; }
-    for (int r = 0; r < d; ++r) {
-      if (r == k) continue;
-      const double f = A[r + k * d];
-      for (int c = 0; c < d; ++c) { A[r + c * d] -= f * A[k + c * d]; R[r + c * d] -= f * R[k + c * d]; }
-    }
-  }
-  for (int i = 0; i < d * d; ++i) inv[inv_off[b] + i] = (T)R[i];
+  for (int i = 0; i < d * d; ++i) { A[i * nt] = (double)B[i]; R[i * nt] = (i % d == i / d) ? 1.0 : 0.0; }
+  lds_gauss_jordan(A, R, d, nt);
+  for (int i = 0; i < d * d; ++i) inv[inv_off[b] + i] = (T)R[i * nt];
 }
 template <typename T> __global__ void k_schur_diag_apply(size_t pose_dim, const size_t *s2b_start, const size_t *soff, const T *inv, const size_t *inv_off, const size_t *s2b, T *z, const T *r) {
   const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -338,7 +309,7 @@ public:
 template <typename T, typename S> class BlockJacobiSchurPreconditioner : public SchurPreconditioner<T, S> {
   device_vector<T> inverses;
   device_vector<size_t> d_diag_off, d_soff, d_inv_off, d_s2b;
-  size_t nblocks = 0, pose_dim = 0;
+  size_t nblocks = 0, pose_dim = 0, max_dim = 1;
 public:
   bool is_block_jacobi() const override { return true; }
   void update_structure(Graph<T, S> *, SchurComplement<T, S> *schur, StreamPool &) override {
@@ -350,6 +321,7 @@ public:
       const size_t d = soff[b + 1] - soff[b];
       if (d > 16) throw std::invalid_argument("BlockJacobiSchurPreconditioner: vertex dimension > 16");
       inv_off[b] = total; total += d * d;
+      max_dim = std::max(max_dim, d);
       for (size_t c = soff[b]; c < soff[b + 1]; ++c) s2b[c] = b;
     }
     inverses.resize(total);
@@ -357,7 +329,14 @@ public:
   }
   // S already carries the damping (it is reduced from the damped H), so the blocks are inverted as they are
   void update_values(Graph<T, S> *, SchurComplement<T, S> *schur, StreamPool &) override {
-    if (nblocks) detail::k_schur_diag_inverse<T, S><<<detail::blocks(nblocks), detail::TPB>>>(nblocks, d_diag_off.raw(), d_soff.raw(), schur->get_values_ptr(), inverses.raw(), d_inv_off.raw());
+    if (!nblocks) return;
+    static const bool lds_ok = [] { // d = 16 needs 128 KB of dynamic LDS
+      GRAPHITE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&detail::k_schur_diag_inverse<T, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)detail::block_inverse_lds_bytes(16)));
+      return true;
+    }();
+    (void)lds_ok;
+    detail::k_schur_diag_inverse<T, S><<<(unsigned)((nblocks + detail::BLOCK_INV_THREADS - 1) / detail::BLOCK_INV_THREADS), detail::BLOCK_INV_THREADS, detail::block_inverse_lds_bytes(max_dim)>>>(
+        nblocks, d_diag_off.raw(), d_soff.raw(), schur->get_values_ptr(), inverses.raw(), d_inv_off.raw(), (int)max_dim);
   }
   void set_damping_factor(Graph<T, S> *, SchurComplement<T, S> *, T, const bool, StreamPool &) override {}
   void apply(Graph<T, S> *, SchurComplement<T, S> *, T *z, const T *r, StreamPool &) override {

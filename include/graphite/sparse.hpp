@@ -305,28 +305,17 @@ template <typename S> __global__ void k_schur_copy(const SchurCopyOp *ops, size_
   if (op >= nops) return;
   for (size_t i = threadIdx.x; i < ops[op].count; i += blockDim.x) Sv[ops[op].dst + i] = H[ops[op].src + i];
 }
-template <typename S> __global__ void k_schur_invert(const SchurInvOp *ops, size_t nops, const S *H, S *inv) {
-  const size_t op = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+template <typename S> __global__ void __launch_bounds__(BLOCK_INV_THREADS) k_schur_invert(const SchurInvOp *ops, size_t nops, const S *H, S *inv, int max_d) {
+  extern __shared__ double lds_inv[]; // [entry][thread] work matrices (core.hpp: lds_gauss_jordan), the role of cublas<t>matinvBatched (:1101)
+  const int tid = threadIdx.x, nt = BLOCK_INV_THREADS;
+  const size_t op = blockIdx.x * (size_t)nt + tid;
   if (op >= nops) return;
-  constexpr int MAXD = 16;
   const int d = (int)ops[op].d;
-  double A[MAXD * MAXD], R[MAXD * MAXD];
+  double *A = lds_inv + tid, *R = lds_inv + (size_t)max_d * max_d * nt + tid;
   const S *B = H + ops[op].blk;
-  for (int i = 0; i < d * d; ++i) { A[i] = (double)B[i]; R[i] = (i % d == i / d) ? 1.0 : 0.0; }
-  for (int k = 0; k < d; ++k) { // Gauss-Jordan with partial pivoting: the role of cublas<t>matinvBatched (:1101)
-    int piv = k;
-    for (int r = k + 1; r < d; ++r) if (fabs(A[r + k * d]) > fabs(A[piv + k * d])) piv = r;
-    if (piv != k)
-      for (int c = 0; c < d; ++c) { double t = A[k + c * d]; A[k + c * d] = A[piv + c * d]; A[piv + c * d] = t; t = R[k + c * d]; R[k + c * d] = R[piv + c * d]; R[piv + c * d] = t; }
-    const double ip = 1.0 / A[k + k * d];
-    for (int c = 0; c < d; ++c) { A[k + c * d] *= ip; R[k + c * d] *= ip; }
-    for (int r = 0; r < d; ++r) {
-      if (r == k) continue;
-      const double f = A[r + k * d];
-      for (int c = 0; c < d; ++c) { A[r + c * d] -= f * A[k + c * d]; R[r + c * d] -= f * R[k + c * d]; }
-    }
-  }
-  for (int i = 0; i < d * d; ++i) inv[ops[op].inv + i] = (S)R[i];
+  for (int i = 0; i < d * d; ++i) { A[i * nt] = (double)B[i]; R[i * nt] = (i % d == i / d) ? 1.0 : 0.0; }
+  lds_gauss_jordan(A, R, d, nt);
+  for (int i = 0; i < d * d; ++i) inv[ops[op].inv + i] = (S)R[i * nt];
 }
 // S_dst -= sum over the products of that destination block of L M R^T (ops/schur.hpp:155-188 adds every product with one
 // atomicAdd per output scalar).  The products are sorted by destination at build_structure (stable: landmark order) and cut
@@ -679,7 +668,15 @@ public:
     using namespace detail;
     d_schur.zero();
     if (d_copy_ops.size()) k_schur_copy<S><<<(unsigned)d_copy_ops.size(), 64>>>(d_copy_ops.raw(), d_copy_ops.size(), H.get_values_ptr(), d_schur.raw());
-    if (d_inv_ops.size()) k_schur_invert<S><<<blocks(d_inv_ops.size()), TPB>>>(d_inv_ops.raw(), d_inv_ops.size(), H.get_values_ptr(), d_hll_inv.raw());
+    if (d_inv_ops.size()) {
+      static const bool lds_ok = [] { // d = 16 needs 128 KB of dynamic LDS
+        GRAPHITE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_schur_invert<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_inverse_lds_bytes(16)));
+        return true;
+      }();
+      (void)lds_ok;
+      k_schur_invert<S><<<(unsigned)((d_inv_ops.size() + BLOCK_INV_THREADS - 1) / BLOCK_INV_THREADS), BLOCK_INV_THREADS, block_inverse_lds_bytes(max_landmark_dim)>>>(
+          d_inv_ops.raw(), d_inv_ops.size(), H.get_values_ptr(), d_hll_inv.raw(), (int)max_landmark_dim);
+    }
     if (num_chunks) {
       const SchurChunks ch{d_chunk_blk.raw(), d_chunk_first.raw(), d_mul_first.raw(), d_mul_partial.raw(), chunk_stride};
       k_schur_mul<S><<<(unsigned)num_chunks, SCHUR_MUL_THREADS>>>(d_mul_ops.raw(), ch, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw(), (uint32_t)max_landmark_dim);
