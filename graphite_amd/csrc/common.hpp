@@ -84,6 +84,13 @@ template <int OFFSET> __device__ __forceinline__ double lane_xor(double v) {
   u.x = lane_xor_u32<OFFSET>(u.x); u.y = lane_xor_u32<OFFSET>(u.y);
   return __builtin_bit_cast(double, u);
 }
+// Orders the LDS accesses of ONE wave whose lanes exchange data through LDS without a workgroup barrier: the hardware runs a
+// wave's LDS instructions in issue order, but without this the compiler may move a lane's reads above another lane's writes.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // v + (v of lane ^ OFFSET) for the six butterfly steps of a wave
 template <typename T> __device__ __forceinline__ T butterfly_low(T v) { // offsets 8, 4, 2, 1: DPP
   v += lane_xor<8>(v); v += lane_xor<4>(v); v += lane_xor<2>(v); v += lane_xor<1>(v);

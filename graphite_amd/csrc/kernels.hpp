@@ -244,9 +244,9 @@ k_schur_products(int nitems, const int *__restrict__ item_blk, const int *__rest
   // Operands through LDS.  Every lane of a group needs the SAME 27 scalars of Ha and 9 of M (plus its own column of Hb): fetched
   // redundantly they are 39 live fp64 registers per lane and every round of 7 products waits one full memory latency for them at
   // 3 waves per SIMD (352-369 us on Ladybug-1723).  Here the 9 lanes of a group fetch the 36 shared scalars ONCE (4 per lane, the
-  // NEXT round's while the current one is multiplied), park them in the group's LDS strip and read them back as broadcasts.  LDS
-  // operations of one wave execute in issue order, so a strip needs no barrier between its writes, its reads and the next
-  // round's writes.
+  // NEXT round's while the current one is multiplied), park them in the group's LDS strip and read them back as broadcasts.  One
+  // wave owns a strip: a wave-level fence (wave_lds_fence) orders its writes, its reads and the next round's writes — no
+  // workgroup barrier.
   __shared__ T strip[4][7][40]; // [wave][group][27 Ha | 9 M | pad]
   if (g < 7) {
     T *sg = strip[threadIdx.x >> 6][g];
@@ -266,6 +266,7 @@ k_schur_products(int nitems, const int *__restrict__ item_blk, const int *__rest
       sg[c] = h_n[0]; sg[c + 9] = h_n[1]; sg[c + 18] = h_n[2]; sg[27 + c] = m_n;
       const T hb0 = hb_n[0], hb1 = hb_n[1], hb2 = hb_n[2];
       if (q + 7 < q_end) fetch(q + 7);
+      wave_lds_fence(); // the strip is written and read by different lanes of this wave
       T mv[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) mv[i] = sg[27 + i];
@@ -274,6 +275,7 @@ k_schur_products(int nitems, const int *__restrict__ item_blk, const int *__rest
       const T u2 = mv[2] * hb0 + mv[5] * hb1 + mv[8] * hb2;
 #pragma unroll
       for (int r = 0; r < 9; ++r) acc[r] += sg[r] * u0 + sg[r + 9] * u1 + sg[r + 18] * u2;
+      wave_lds_fence(); // ... and rewritten by the next round
     }
   }
   // combine the 7 groups: lanes 0..8 collect

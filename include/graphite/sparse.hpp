@@ -385,6 +385,85 @@ k_schur_mul(const SchurMulOp *ops, SchurChunks ch, const size_t *rowi, const siz
     __syncthreads();
   }
 }
+// The same reduction for graphs whose pose blocks all have dimension D and whose eliminated vertices all have dimension DL
+// (bundle adjustment 9 / 3, SE(3) poses with 3-d landmarks 6 / 3, planar SLAM 3 / 2): compile-time dimensions, ONE WAVE per
+// chunk, one lane per output COLUMN and G = 64 / D products side by side.  Lane (g, c) keeps column c of product group g's sum
+// in D registers; the operands the D lanes of a group share (L: D x DL, M: DL x DL) are fetched once per group, the next
+// round's while the current one is multiplied, and read back from the group's LDS strip as broadcasts (one wave: a wave-level fence,
+// no workgroup barrier); R's column belongs to the lane.  The groups are then added in group order.  This is
+// the engine's k_schur_products (graphite_amd/csrc/kernels.hpp) on the generic layer's operation records.
+// Orders the LDS accesses of ONE wave whose lanes exchange data through LDS without a workgroup barrier: the hardware runs a
+// wave's LDS instructions in issue order, but without this the compiler may move a lane's reads above another lane's writes
+// (seen: garbage in the 3 / 2 instantiation below).
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <typename S, int D, int DL> __global__ void __launch_bounds__(64)
+k_schur_mul_fixed(const SchurMulOp *ops, SchurChunks ch, const size_t *boff, const S *H, const S *inv, S *Sv) {
+  constexpr int G = 64 / D, NL = D * DL, NS = NL + DL * DL, PER = (NS + D - 1) / D; // shared scalars per product, per lane
+  __shared__ S strip[G][NS + 1];
+  const size_t j = blockIdx.x, q = ch.blk[j], i = j - ch.first_chunk[q], nchunk = ch.first_chunk[q + 1] - ch.first_chunk[q];
+  const size_t p0 = ch.first_product[q] + i * SCHUR_MUL_CHUNK, pe = ch.first_product[q + 1], p1 = p0 + SCHUR_MUL_CHUNK < pe ? p0 + SCHUR_MUL_CHUNK : pe;
+  const int lane = threadIdx.x, g = lane / D, c = lane % D;
+  double acc[D]; // products in S, their sum in double (as the any-dimension kernel)
+#pragma unroll
+  for (int r = 0; r < D; ++r) acc[r] = 0.0;
+  if (g < G) {
+    S *sg = strip[g];
+    S sh_n[PER], rc_n[DL];
+    auto fetch = [&](size_t p) {
+      const SchurMulOp o = ops[p];
+      const S *L = H + o.left, *R = H + o.right, *M = inv + o.mid;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) { const int e = c + D * u; sh_n[u] = e < NL ? L[e] : (e < NS ? M[e - NL] : S(0)); }
+#pragma unroll
+      for (int jj = 0; jj < DL; ++jj) rc_n[jj] = R[c + D * jj];
+    };
+    size_t p = p0 + g;
+    if (p < p1) fetch(p);
+    for (; p < p1; p += G) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) { const int e = c + D * u; if (e < NS) sg[e] = sh_n[u]; }
+      S rc[DL];
+#pragma unroll
+      for (int jj = 0; jj < DL; ++jj) rc[jj] = rc_n[jj];
+      if (p + G < p1) fetch(p + G);
+      wave_lds_fence(); // the strip is written and read by different lanes of this wave
+      S u_k[DL]; // (M R^T)(k, c)
+#pragma unroll
+      for (int k = 0; k < DL; ++k) {
+        S t = S(0);
+#pragma unroll
+        for (int jj = 0; jj < DL; ++jj) t += sg[NL + k + DL * jj] * rc[jj];
+        u_k[k] = t;
+      }
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        S t = S(0);
+#pragma unroll
+        for (int k = 0; k < DL; ++k) t += sg[r + D * k] * u_k[k];
+        acc[r] += (double)t;
+      }
+      wave_lds_fence(); // ... and rewritten by the next round
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < D; ++r) { // groups added in group order into lanes 0 .. D - 1
+    double tot = acc[r];
+#pragma unroll
+    for (int gg = 1; gg < G; ++gg) tot += __shfl(acc[r], gg * D + c, 64);
+    acc[r] = tot;
+  }
+  if (lane < D) {
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      if (nchunk == 1) Sv[boff[q] + r + D * c] -= (S)acc[r];
+      else ch.partial[j * ch.stride + r + D * c] = acc[r];
+    }
+  }
+}
 template <typename S> __global__ void k_schur_mul_join(size_t nblk, SchurChunks ch, const size_t *rowi, const size_t *bcol, const size_t *boff, const size_t *soff, S *Sv) {
   const size_t q = blockIdx.x, c0 = ch.first_chunk[q], c1 = ch.first_chunk[q + 1];
   if (c1 - c0 < 2) return;
@@ -563,6 +642,7 @@ template <typename T, typename S> class SchurComplement {
   device_vector<size_t> d_chunk_first;   // first chunk of every S block (+ end)
   device_vector<double> d_mul_partial;   // [chunk][chunk_stride]: partial blocks of the destinations with several chunks
   size_t num_chunks = 0, chunk_stride = 0, max_landmark_dim = 1;
+  size_t uniform_pose_dim = 0, uniform_landmark_dim = 0; // the dimension every pose / eliminated block shares, 0 = mixed
   size_t landmark_col_start = 0, num_block_columns = 0, pose_dim = 0, landmark_dim = 0, num_blocks = 0;
 public:
   explicit SchurComplement(Hessian<T, S> &H_) : H(H_) {}
@@ -649,6 +729,10 @@ public:
       chunk_stride *= chunk_stride; // the largest S block
       max_landmark_dim = 1;
       for (size_t b = L; b < nb; ++b) max_landmark_dim = std::max(max_landmark_dim, dim_of(b));
+      uniform_pose_dim = L ? dim_of(0) : 0; uniform_landmark_dim = nb > L ? dim_of(L) : 0;
+      for (size_t b = 0; b < L; ++b) if (dim_of(b) != uniform_pose_dim) uniform_pose_dim = 0;
+      for (size_t b = L; b < nb; ++b) if (dim_of(b) != uniform_landmark_dim) uniform_landmark_dim = 0;
+      if (getenv("GRAPHITE_SCHUR_MUL_GENERIC") && atoi(getenv("GRAPHITE_SCHUR_MUL_GENERIC")) != 0) uniform_pose_dim = 0; // A/B: the any-dimension kernel
       d_mul_partial.resize(num_chunks * chunk_stride);
     }
     device_vector<size_t> vec_count(num_blocks), vec_first;
@@ -679,7 +763,13 @@ public:
     }
     if (num_chunks) {
       const SchurChunks ch{d_chunk_blk.raw(), d_chunk_first.raw(), d_mul_first.raw(), d_mul_partial.raw(), chunk_stride};
-      k_schur_mul<S><<<(unsigned)num_chunks, SCHUR_MUL_THREADS>>>(d_mul_ops.raw(), ch, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw(), (uint32_t)max_landmark_dim);
+      // uniform dimensions with a compiled fast form: 9 / 3 (bundle adjustment), 6 / 3 (SE(3) + 3-d landmarks), 3 / 2 (planar SLAM)
+      const unsigned nc = (unsigned)num_chunks;
+      if (uniform_pose_dim == 9 && uniform_landmark_dim == 3) k_schur_mul_fixed<S, 9, 3><<<nc, 64>>>(d_mul_ops.raw(), ch, d_offsets.raw(), H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw());
+      else if (uniform_pose_dim == 6 && uniform_landmark_dim == 3) k_schur_mul_fixed<S, 6, 3><<<nc, 64>>>(d_mul_ops.raw(), ch, d_offsets.raw(), H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw());
+      else if (uniform_pose_dim == 3 && uniform_landmark_dim == 2) k_schur_mul_fixed<S, 3, 2><<<nc, 64>>>(d_mul_ops.raw(), ch, d_offsets.raw(), H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw());
+      else
+      k_schur_mul<S><<<nc, SCHUR_MUL_THREADS>>>(d_mul_ops.raw(), ch, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), H.get_values_ptr(), d_hll_inv.raw(), d_schur.raw(), (uint32_t)max_landmark_dim);
       k_schur_mul_join<S><<<(unsigned)num_blocks, 128>>>(num_blocks, ch, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), d_schur.raw());
     }
     // b_S = b_p - Hpl Hll^-1 b_l (:901-920)
