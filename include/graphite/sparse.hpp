@@ -496,24 +496,117 @@ template <typename T, typename S> __global__ void k_schur_apply_inverse(const Sc
     w[r0 + r] = s;
   }
 }
-// MODE 0: out_p[prow..] -= Hpl w_l  (b_S, schur.hpp:901-920);  MODE 1: out_l[lrow..] -= Hpl^T x_p  (back-substitution, :279-302)
-template <typename T, typename S, int MODE> __global__ void k_schur_hpl(const SchurHplOp *ops, size_t nops, const S *H, const T *in, T *out) {
-  const size_t op = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (op >= nops) return;
-  const SchurHplOp o = ops[op];
-  const S *A = H + o.blk; // da x dl, column-major
-  if (MODE == 0) {
-    for (uint32_t r = 0; r < o.da; ++r) {
-      T s = 0;
-      for (uint32_t c = 0; c < o.dl; ++c) s += (T)A[r + o.da * c] * in[o.lrow + c];
-      atomicAdd(&out[o.prow + r], -s);
+// out_p[prow..] -= Hpl w_l (b_S, schur.hpp:901-920) and out_l[lrow..] -= Hpl^T x_p (back-substitution, :279-302).  The reference
+// adds every block's product with atomics; here every output row has ONE writer and a fixed order of summation:
+//   landmarks: the Hpl blocks of an eliminated vertex are consecutive records -> one thread per vertex walks them;
+//   poses    : the records are sorted by pose block at build_structure (pose_idx, pose_first) -> one wave per pose block, lanes
+//              stride over its records (a camera meets hundreds of points), then a butterfly.
+// D, DL != 0: every pose block D x D and every eliminated vertex of dimension DL (loops unrolled at compile time); 0: run-time dimensions <= 16
+template <typename T, typename S, int D = 0, int DL = 0> __global__ void k_schur_hpl_landmarks(size_t nl, const size_t *lm_first, const SchurHplOp *ops, const S *H, const T *xp, T *out_l) {
+  const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (j >= nl) return;
+  if constexpr (D != 0) {
+    T s[DL];
+#pragma unroll
+    for (int c = 0; c < DL; ++c) s[c] = T(0);
+    const size_t t0 = lm_first[j], t1 = lm_first[j + 1];
+    if (t0 == t1) return;
+    for (size_t t = t0; t < t1; ++t) {
+      const SchurHplOp o = ops[t];
+      const S *A = H + o.blk;
+      T x[D];
+#pragma unroll
+      for (int r = 0; r < D; ++r) x[r] = xp[o.prow + r];
+#pragma unroll
+      for (int c = 0; c < DL; ++c) {
+        T q = 0;
+#pragma unroll
+        for (int r = 0; r < D; ++r) q += (T)A[r + D * c] * x[r];
+        s[c] += q;
+      }
     }
-  } else {
-    for (uint32_t c = 0; c < o.dl; ++c) {
-      T s = 0;
-      for (uint32_t r = 0; r < o.da; ++r) s += (T)A[r + o.da * c] * in[o.prow + r];
-      atomicAdd(&out[o.lrow + c], -s);
+    const size_t lrow = ops[t0].lrow;
+#pragma unroll
+    for (int c = 0; c < DL; ++c) out_l[lrow + c] -= s[c];
+    return;
+  }
+  constexpr int MAXD = 16;
+  T s[MAXD];
+#pragma unroll
+  for (int c = 0; c < MAXD; ++c) s[c] = T(0);
+  uint32_t dl = 0;
+  size_t lrow = 0;
+  for (size_t t = lm_first[j]; t < lm_first[j + 1]; ++t) {
+    const SchurHplOp o = ops[t];
+    const S *A = H + o.blk; // da x dl, column-major
+    dl = o.dl; lrow = o.lrow;
+#pragma unroll
+    for (int c = 0; c < MAXD; ++c)
+      if ((uint32_t)c < o.dl) {
+        T q = 0;
+        for (uint32_t r = 0; r < o.da; ++r) q += (T)A[r + o.da * c] * xp[o.prow + r];
+        s[c] += q;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < MAXD; ++c)
+    if ((uint32_t)c < dl) out_l[lrow + c] -= s[c];
+}
+template <typename T, typename S, int D = 0, int DL = 0> __global__ void __launch_bounds__(64)
+k_schur_hpl_poses(const size_t *pose_first, const unsigned *pose_idx, const SchurHplOp *ops, const S *H, const T *wl, T *out_p) {
+  const size_t b = blockIdx.x, t0 = pose_first[b], t1 = pose_first[b + 1];
+  if (t0 == t1) return;
+  if constexpr (D != 0) {
+    T s[D];
+#pragma unroll
+    for (int r = 0; r < D; ++r) s[r] = T(0);
+    for (size_t t = t0 + threadIdx.x; t < t1; t += 64) {
+      const SchurHplOp o = ops[pose_idx[t]];
+      const S *A = H + o.blk;
+      T w[DL];
+#pragma unroll
+      for (int c = 0; c < DL; ++c) w[c] = wl[o.lrow + c];
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        T q = 0;
+#pragma unroll
+        for (int c = 0; c < DL; ++c) q += (T)A[r + D * c] * w[c];
+        s[r] += q;
+      }
     }
+    const size_t prow = ops[pose_idx[t0]].prow;
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      T v = s[r];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (threadIdx.x == 0) out_p[prow + r] -= v;
+    }
+    return;
+  }
+  constexpr int MAXD = 16;
+  T s[MAXD];
+#pragma unroll
+  for (int r = 0; r < MAXD; ++r) s[r] = T(0);
+  uint32_t da = 0;
+  size_t prow = 0;
+  for (size_t t = t0 + threadIdx.x; t < t1; t += 64) {
+    const SchurHplOp o = ops[pose_idx[t]];
+    const S *A = H + o.blk;
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+      if ((uint32_t)r < o.da) {
+        T q = 0;
+        for (uint32_t c = 0; c < o.dl; ++c) q += (T)A[r + o.da * c] * wl[o.lrow + c];
+        s[r] += q;
+      }
+  }
+  { const SchurHplOp o = ops[pose_idx[t0]]; da = o.da; prow = o.prow; } // the same for every record of the block
+#pragma unroll
+  for (int r = 0; r < MAXD; ++r) {
+    if ((uint32_t)r >= da) break; // block-uniform
+    T v = s[r];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (threadIdx.x == 0) out_p[prow + r] -= v;
   }
 }
 template <typename T, typename S> __global__ void k_schur_vec(const SchurVecOp *ops, size_t nops, const S *Sv, const T *x, T *y) {
@@ -562,7 +655,7 @@ __global__ void k_schur_pair_counts(HView h, size_t *pairs, size_t *inv_size, in
 }
 // one thread per Hpl block q (pose row a of landmark column l): its Hpl record, and the products (a, bq >= a) it starts —
 // S key and product record (dst filled in by k_schur_mul_dst once S is known)
-__global__ void k_schur_emit(HView h, size_t nhpl, const size_t *pair_start, const size_t *inv_off, SchurHplOp *hpl, uint64_t *keys, SchurMulOp *mul) {
+__global__ void k_schur_emit(HView h, size_t nhpl, const size_t *pair_start, const size_t *inv_off, SchurHplOp *hpl, uint64_t *keys, SchurMulOp *mul, unsigned *hpl_pose) {
   const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (t >= nhpl) return;
   // Hpl blocks and Hll blocks interleave in H's list: block q = colp[L] + t + (landmark columns before it); find the column by bisection
@@ -572,6 +665,7 @@ __global__ void k_schur_emit(HView h, size_t nhpl, const size_t *pair_start, con
   const size_t l = lo, q = base + t + (l - h.L), k0 = h.colp[l], k1 = h.colp[l + 1] - 1, a = q - k0, k = k1 - k0, dl = hv_dim(h, l);
   const size_t ra = h.rowi[q], da = hv_dim(h, ra), io = inv_off[l - h.L];
   hpl[t] = SchurHplOp{h.boff[q], io, h.soff[ra], h.soff[l] - h.pose_dim, (uint32_t)da, (uint32_t)dl};
+  hpl_pose[t] = (unsigned)ra;
   size_t p = pair_start[l - h.L] + a * k - (a * (a - 1)) / 2;
   for (size_t bq = q; bq < k1; ++bq, ++p) {
     const size_t rb = h.rowi[bq], db = hv_dim(h, rb);
@@ -589,6 +683,15 @@ __global__ void k_schur_mul_dst(size_t n, const uint64_t *pair_keys, const uint6
 __global__ void k_schur_permute(size_t n, const SchurMulOp *in, const unsigned *perm, SchurMulOp *out) {
   const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (p < n) out[p] = in[perm[p]];
+}
+__global__ void k_iota(size_t n, unsigned *v) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (unsigned)i;
+}
+// first Hpl record of eliminated vertex j (records are emitted column by column, the Hll block of every column skipped)
+__global__ void k_hpl_landmark_first(HView h, size_t nl, size_t *first) {
+  const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (j <= nl) first[j] = h.colp[h.L + j] - h.colp[h.L] - j;
 }
 // first[q] = first sorted product whose block index is >= q (q = 0 .. nblk)
 __global__ void k_first_of_block(size_t nblk, const unsigned *blk_sorted, size_t n, size_t *first) {
@@ -638,6 +741,8 @@ template <typename T, typename S> class SchurComplement {
   device_vector<detail::SchurCopyOp> d_copy_ops;
   device_vector<detail::SchurInvOp> d_inv_ops;
   device_vector<detail::SchurVecOp> d_vec_ops;
+  device_vector<size_t> d_hpl_lm_first, d_hpl_pose_first; // first Hpl record of every eliminated vertex / (sorted) of every pose block (+ end)
+  device_vector<unsigned> d_hpl_pose_idx;                 // Hpl records sorted by pose block
   device_vector<unsigned> d_chunk_blk;   // destination block of every product chunk
   device_vector<size_t> d_chunk_first;   // first chunk of every S block (+ end)
   device_vector<double> d_mul_partial;   // [chunk][chunk_stride]: partial blocks of the destinations with several chunks
@@ -683,7 +788,23 @@ public:
     if (n_hpp) GRAPHITE_HIP(hipMemcpy(d_keys.raw(), H.device_block_keys().raw(), n_hpp * sizeof(uint64_t), hipMemcpyDeviceToDevice));
     device_vector<uint64_t> pair_keys(npairs);
     d_hpl_ops.resize(n_hpl); d_mul_ops.resize(npairs);
-    if (n_hpl) k_schur_emit<<<blocks(n_hpl), TPB>>>(hv, n_hpl, pair_start.raw(), inv_off.raw(), d_hpl_ops.raw(), pair_keys.raw(), d_mul_ops.raw());
+    device_vector<unsigned> hpl_pose(n_hpl);
+    if (n_hpl) k_schur_emit<<<blocks(n_hpl), TPB>>>(hv, n_hpl, pair_start.raw(), inv_off.raw(), d_hpl_ops.raw(), pair_keys.raw(), d_mul_ops.raw(), hpl_pose.raw());
+    { // Hpl records by eliminated vertex (consecutive as emitted) and by pose block (stable sort): the two walks of k_schur_hpl_*
+      d_hpl_lm_first.resize(nl + 1);
+      k_hpl_landmark_first<<<blocks(nl + 1), TPB>>>(hv, nl, d_hpl_lm_first.raw());
+      device_vector<unsigned> idx(n_hpl), pose_sorted(n_hpl);
+      d_hpl_pose_idx.resize(n_hpl);
+      if (n_hpl) {
+        k_iota<<<blocks(n_hpl), TPB>>>(n_hpl, idx.raw());
+        ScratchBytes scratch;
+        size_t bytes = 0;
+        GRAPHITE_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, hpl_pose.raw(), pose_sorted.raw(), idx.raw(), d_hpl_pose_idx.raw(), (int)n_hpl));
+        GRAPHITE_HIP(hipcub::DeviceRadixSort::SortPairs(scratch.get(bytes), bytes, hpl_pose.raw(), pose_sorted.raw(), idx.raw(), d_hpl_pose_idx.raw(), (int)n_hpl));
+      }
+      d_hpl_pose_first.resize(L + 1);
+      k_first_of_block<<<blocks(L + 1), TPB>>>(L, pose_sorted.raw(), n_hpl, d_hpl_pose_first.raw());
+    }
     if (npairs) GRAPHITE_HIP(hipMemcpy(d_keys.raw() + n_hpp, pair_keys.raw(), npairs * sizeof(uint64_t), hipMemcpyDeviceToDevice));
     num_blocks = sort_unique_keys(d_keys);
     d_schur_offsets.resize(L + 1);
@@ -777,7 +898,15 @@ public:
     GRAPHITE_HIP(hipMemcpy(b_Schur.raw(), b, pose_dim * sizeof(T), hipMemcpyDefault));
     if (d_inv_ops.size()) {
       k_schur_apply_inverse<T, S><<<blocks(d_inv_ops.size()), TPB>>>(d_inv_ops.raw(), d_inv_ops.size(), d_inv_lrow.raw(), d_hll_inv.raw(), b + pose_dim, l_workspace.raw());
-      if (d_hpl_ops.size()) k_schur_hpl<T, S, 0><<<blocks(d_hpl_ops.size()), TPB>>>(d_hpl_ops.raw(), d_hpl_ops.size(), H.get_values_ptr(), l_workspace.raw(), b_Schur.raw());
+      if (d_hpl_ops.size()) {
+        const unsigned np = (unsigned)landmark_col_start;
+#define GRAPHITE_HPL_POSES(D, DL) k_schur_hpl_poses<T, S, D, DL><<<np, 64>>>(d_hpl_pose_first.raw(), d_hpl_pose_idx.raw(), d_hpl_ops.raw(), H.get_values_ptr(), l_workspace.raw(), b_Schur.raw())
+        if (uniform_pose_dim == 9 && uniform_landmark_dim == 3) GRAPHITE_HPL_POSES(9, 3);
+        else if (uniform_pose_dim == 6 && uniform_landmark_dim == 3) GRAPHITE_HPL_POSES(6, 3);
+        else if (uniform_pose_dim == 3 && uniform_landmark_dim == 2) GRAPHITE_HPL_POSES(3, 2);
+        else GRAPHITE_HPL_POSES(0, 0);
+#undef GRAPHITE_HPL_POSES
+      }
     }
     sync();
   }
@@ -793,7 +922,14 @@ public:
     if (landmark_col_start >= num_block_columns) return;
     const T *b = graph->get_b().raw();
     GRAPHITE_HIP(hipMemcpy(l_rhs.raw(), b + pose_dim, landmark_dim * sizeof(T), hipMemcpyDefault));
-    if (d_hpl_ops.size()) k_schur_hpl<T, S, 1><<<blocks(d_hpl_ops.size()), TPB>>>(d_hpl_ops.raw(), d_hpl_ops.size(), H.get_values_ptr(), xp, l_rhs.raw());
+    if (d_hpl_ops.size()) {
+#define GRAPHITE_HPL_LM(D, DL) k_schur_hpl_landmarks<T, S, D, DL><<<blocks(d_inv_ops.size()), TPB>>>(d_inv_ops.size(), d_hpl_lm_first.raw(), d_hpl_ops.raw(), H.get_values_ptr(), xp, l_rhs.raw())
+      if (uniform_pose_dim == 9 && uniform_landmark_dim == 3) GRAPHITE_HPL_LM(9, 3);
+      else if (uniform_pose_dim == 6 && uniform_landmark_dim == 3) GRAPHITE_HPL_LM(6, 3);
+      else if (uniform_pose_dim == 3 && uniform_landmark_dim == 2) GRAPHITE_HPL_LM(3, 2);
+      else GRAPHITE_HPL_LM(0, 0);
+#undef GRAPHITE_HPL_LM
+    }
     k_schur_apply_inverse<T, S><<<blocks(d_inv_ops.size()), TPB>>>(d_inv_ops.raw(), d_inv_ops.size(), d_inv_lrow.raw(), d_hll_inv.raw(), l_rhs.raw(), xl);
     sync();
   }
