@@ -609,15 +609,50 @@ k_schur_hpl_poses(const size_t *pose_first, const unsigned *pose_idx, const Schu
     if (threadIdx.x == 0) out_p[prow + r] -= v;
   }
 }
-template <typename T, typename S> __global__ void k_schur_vec(const SchurVecOp *ops, size_t nops, const S *Sv, const T *x, T *y) {
-  const size_t op = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (op >= nops) return;
-  const SchurVecOp o = ops[op];
-  const S *A = Sv + o.blk; // rows x cols, column-major
-  if (!o.transposed) {
-    for (uint32_t r = 0; r < o.rows; ++r) { T s = 0; for (uint32_t c = 0; c < o.cols; ++c) s += (T)A[r + o.rows * c] * x[o.xoff + c]; atomicAdd(&y[o.yoff + r], s); }
-  } else {
-    for (uint32_t c = 0; c < o.cols; ++c) { T s = 0; for (uint32_t r = 0; r < o.rows; ++r) s += (T)A[r + o.rows * c] * x[o.xoff + r]; atomicAdd(&y[o.yoff + c], s); }
+// y = S x (schur.hpp:347-393 adds one atomic per block row).  The block records (upper blocks and their transposes) are sorted by
+// OUTPUT block row at build_structure: one wave per block row, lanes stride over its records, butterfly, one plain store per
+// row.  D != 0: every pose block D x D (compile-time loops); 0: run-time dimensions <= 16.
+template <typename T, typename S, int D = 0> __global__ void __launch_bounds__(64)
+k_schur_vec(const size_t *row_first, const unsigned *row_idx, const SchurVecOp *ops, const S *Sv, const T *x, T *y) {
+  const size_t b = blockIdx.x, t0 = row_first[b], t1 = row_first[b + 1];
+  if (t0 == t1) return;
+  constexpr int MAXD = D != 0 ? D : 16;
+  T s[MAXD];
+#pragma unroll
+  for (int r = 0; r < MAXD; ++r) s[r] = T(0);
+  for (size_t t = t0 + threadIdx.x; t < t1; t += 64) {
+    const SchurVecOp o = ops[row_idx[t]];
+    const S *A = Sv + o.blk; // rows x cols, column-major
+    if constexpr (D != 0) {
+      T xv[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) xv[c] = x[o.xoff + c];
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        T q = 0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) q += (T)(o.transposed ? A[c + D * r] : A[r + D * c]) * xv[c];
+        s[r] += q;
+      }
+    } else {
+      const uint32_t nout = o.transposed ? o.cols : o.rows, nin = o.transposed ? o.rows : o.cols;
+#pragma unroll
+      for (int r = 0; r < MAXD; ++r)
+        if ((uint32_t)r < nout) {
+          T q = 0;
+          for (uint32_t c = 0; c < nin; ++c) q += (T)(o.transposed ? A[c + o.rows * r] : A[r + o.rows * c]) * x[o.xoff + c];
+          s[r] += q;
+        }
+    }
+  }
+  const SchurVecOp o0 = ops[row_idx[t0]];
+  const uint32_t nout = D != 0 ? (uint32_t)D : (o0.transposed ? o0.cols : o0.rows);
+#pragma unroll
+  for (int r = 0; r < MAXD; ++r) {
+    if ((uint32_t)r >= nout) break; // block-uniform
+    T v = s[r];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (threadIdx.x == 0) y[o0.yoff + r] = v;
   }
 }
 template <typename T> __global__ void k_sub(T *out, const T *a, const T *b, size_t n) {
@@ -713,14 +748,15 @@ __global__ void k_schur_inv_ops(HView h, const size_t *inv_off, SchurInvOp *ops,
   lrow[j] = h.soff[l] - h.pose_dim;
 }
 // S x: one record per upper block and one for its transpose below the diagonal (schur.hpp:307-345); COUNT: records per block
-template <bool COUNT> __global__ void k_schur_vec_ops(size_t ns, const size_t *rowi, const size_t *bcol, const size_t *boff, const size_t *soff, const size_t *first, size_t *count, SchurVecOp *ops) {
+template <bool COUNT> __global__ void k_schur_vec_ops(size_t ns, const size_t *rowi, const size_t *bcol, const size_t *boff, const size_t *soff, const size_t *first, size_t *count, SchurVecOp *ops, unsigned *out_blk) {
   const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (q >= ns) return;
   const size_t r = rowi[q], c = bcol[q];
   if (COUNT) { count[q] = r == c ? 1 : 2; return; }
   const uint32_t dr = (uint32_t)(soff[r + 1] - soff[r]), dc = (uint32_t)(soff[c + 1] - soff[c]);
   ops[first[q]] = SchurVecOp{boff[q], soff[c], soff[r], dr, dc, 0, 0};
-  if (r != c) ops[first[q] + 1] = SchurVecOp{boff[q], soff[r], soff[c], dr, dc, 1, 0};
+  out_blk[first[q]] = (unsigned)r;
+  if (r != c) { ops[first[q] + 1] = SchurVecOp{boff[q], soff[r], soff[c], dr, dc, 1, 0}; out_blk[first[q] + 1] = (unsigned)c; }
 }
 __global__ void k_schur_diag_offsets(size_t L, const size_t *colp, const size_t *boff, size_t *diag) {
   const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -741,6 +777,8 @@ template <typename T, typename S> class SchurComplement {
   device_vector<detail::SchurCopyOp> d_copy_ops;
   device_vector<detail::SchurInvOp> d_inv_ops;
   device_vector<detail::SchurVecOp> d_vec_ops;
+  device_vector<size_t> d_vec_first;   // S x: first (sorted) block record of every output block row (+ end)
+  device_vector<unsigned> d_vec_idx;   // ... and the records sorted by output block row
   device_vector<size_t> d_hpl_lm_first, d_hpl_pose_first; // first Hpl record of every eliminated vertex / (sorted) of every pose block (+ end)
   device_vector<unsigned> d_hpl_pose_idx;                 // Hpl records sorted by pose block
   device_vector<unsigned> d_chunk_blk;   // destination block of every product chunk
@@ -857,9 +895,23 @@ public:
       d_mul_partial.resize(num_chunks * chunk_stride);
     }
     device_vector<size_t> vec_count(num_blocks), vec_first;
-    if (num_blocks) k_schur_vec_ops<true><<<blocks(num_blocks), TPB>>>(num_blocks, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), nullptr, vec_count.raw(), nullptr);
-    d_vec_ops.resize(exclusive_scan(vec_count, vec_first));
-    if (num_blocks) k_schur_vec_ops<false><<<blocks(num_blocks), TPB>>>(num_blocks, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), vec_first.raw(), nullptr, d_vec_ops.raw());
+    if (num_blocks) k_schur_vec_ops<true><<<blocks(num_blocks), TPB>>>(num_blocks, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), nullptr, vec_count.raw(), nullptr, nullptr);
+    const size_t nvec = exclusive_scan(vec_count, vec_first);
+    d_vec_ops.resize(nvec);
+    {
+      device_vector<unsigned> out_blk(nvec), out_sorted(nvec), idx(nvec);
+      if (num_blocks) k_schur_vec_ops<false><<<blocks(num_blocks), TPB>>>(num_blocks, d_row_indices.raw(), d_block_col.raw(), d_offsets.raw(), d_schur_offsets.raw(), vec_first.raw(), nullptr, d_vec_ops.raw(), out_blk.raw());
+      d_vec_idx.resize(nvec);
+      if (nvec) { // records by output block row (stable: column order inside a row)
+        k_iota<<<blocks(nvec), TPB>>>(nvec, idx.raw());
+        ScratchBytes scratch;
+        size_t bytes = 0;
+        GRAPHITE_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, out_blk.raw(), out_sorted.raw(), idx.raw(), d_vec_idx.raw(), (int)nvec));
+        GRAPHITE_HIP(hipcub::DeviceRadixSort::SortPairs(scratch.get(bytes), bytes, out_blk.raw(), out_sorted.raw(), idx.raw(), d_vec_idx.raw(), (int)nvec));
+      }
+      d_vec_first.resize(L + 1);
+      k_first_of_block<<<blocks(L + 1), TPB>>>(L, out_sorted.raw(), nvec, d_vec_first.raw());
+    }
     device_vector<size_t> diag(L);
     if (L) k_schur_diag_offsets<<<blocks(L), TPB>>>(L, d_col_pointers.raw(), d_offsets.raw(), diag.raw());
     sync();
@@ -936,8 +988,16 @@ public:
   // vec_out = S vec_in (schur.hpp:347-393)
   void execute_schur_vector_multiply(Graph<T, S> *, StreamPool &, T *vec_out, const T *vec_in) {
     using namespace detail;
-    fill<T>(vec_out, pose_dim, T(0));
-    if (d_vec_ops.size()) k_schur_vec<T, S><<<blocks(d_vec_ops.size()), TPB>>>(d_vec_ops.raw(), d_vec_ops.size(), d_schur.raw(), vec_in, vec_out);
+    fill<T>(vec_out, pose_dim, T(0)); // a block row without records keeps 0
+    if (d_vec_ops.size()) {
+      const unsigned np = (unsigned)landmark_col_start;
+#define GRAPHITE_SVEC(D) k_schur_vec<T, S, D><<<np, 64>>>(d_vec_first.raw(), d_vec_idx.raw(), d_vec_ops.raw(), d_schur.raw(), vec_in, vec_out)
+      if (uniform_pose_dim == 9) GRAPHITE_SVEC(9);
+      else if (uniform_pose_dim == 6) GRAPHITE_SVEC(6);
+      else if (uniform_pose_dim == 3) GRAPHITE_SVEC(3);
+      else GRAPHITE_SVEC(0);
+#undef GRAPHITE_SVEC
+    }
     sync();
   }
   // dense row-major image of S (both triangles), leading dimension pose_dim: input of the direct reduced solve
