@@ -902,6 +902,7 @@ template <typename F, size_t I> __global__ void k_Jv(FactorView<F> fv, typename 
 // output.  No atomics, no zero-filled scratch, the same bits every run; a factor's stored Jacobian block is read once per
 // gather.  WHICH as in k_slot: 0 scalar diagonal, 2 b -= J^T rho' P r, 3 out += J^T (rho' P in), 4 block diagonal (one group
 // per (vertex, row)).
+constexpr size_t GATHER_ROWS = 3;
 template <typename F, size_t I, int WHICH>
 __global__ void k_gather(FactorView<F> fv, const size_t *__restrict__ vptr, const size_t *__restrict__ vfac, size_t nv, int W,
                          typename F::Scalar *__restrict__ out, const typename F::Scalar *__restrict__ in) {
@@ -910,10 +911,13 @@ __global__ void k_gather(FactorView<F> fv, const size_t *__restrict__ vptr, cons
   const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   const size_t g = t / (size_t)W;
   const int j = (int)(t % (size_t)W);
-  const size_t v = WHICH == 4 ? g / d : g, row = WHICH == 4 ? g % d : 0;
+  // block diagonal: a group takes GATHER_ROWS rows of its vertex's d x d block, so a factor's Jacobian block is read
+  // ceil(d / GATHER_ROWS) times instead of d times
+  constexpr size_t RB = WHICH == 4 ? (d < GATHER_ROWS ? d : GATHER_ROWS) : 1, NRB = (d + RB - 1) / RB, NACC = WHICH == 4 ? RB * d : d;
+  const size_t v = WHICH == 4 ? g / NRB : g, row0 = WHICH == 4 ? (g % NRB) * RB : 0;
   const bool on = v < nv && is_vertex_active(fv.vstate[I], v);
-  T acc[d];
-  for (size_t c = 0; c < d; ++c) acc[c] = T(0);
+  T acc[NACC];
+  for (size_t c = 0; c < NACC; ++c) acc[c] = T(0);
   if (on) {
     for (size_t k = vptr[v] + (size_t)j; k < vptr[v + 1]; k += (size_t)W) {
       const size_t f = vfac[k];
@@ -923,7 +927,9 @@ __global__ void k_gather(FactorView<F> fv, const size_t *__restrict__ vptr, cons
       if constexpr (WHICH == 0) {
         for (size_t c = 0; c < d; ++c) acc[c] += jtpj(fv, f, Jb + c * E, Jb + c * E) * w;
       } else if constexpr (WHICH == 4) {
-        for (size_t c = 0; c < d; ++c) acc[c] += jtpj(fv, f, Jb + row * E, Jb + c * E) * w;
+        for (size_t rr = 0; rr < RB; ++rr)
+          if (row0 + rr < d)
+            for (size_t c = 0; c < d; ++c) acc[rr * d + c] += jtpj(fv, f, Jb + (row0 + rr) * E, Jb + c * E) * w;
       } else {
         const T *vec = WHICH == 2 ? fv.residuals + f * E : in + f * E;
         T pr[E];
@@ -941,10 +947,12 @@ __global__ void k_gather(FactorView<F> fv, const size_t *__restrict__ vptr, cons
     }
   }
   for (int o = 1; o < W; o <<= 1)
-    for (size_t c = 0; c < d; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+    for (size_t c = 0; c < NACC; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
   if (!on || j != 0) return;
   if constexpr (WHICH == 4) {
-    for (size_t c = 0; c < d; ++c) out[v * d * d + row + c * d] += acc[c];
+    for (size_t rr = 0; rr < RB; ++rr)
+      if (row0 + rr < d)
+        for (size_t c = 0; c < d; ++c) out[v * d * d + (row0 + rr) + c * d] += acc[rr * d + c];
   } else {
     const size_t col = fv.hid[I][v];
     for (size_t c = 0; c < d; ++c) out[col + c] += (WHICH == 2 ? -acc[c] : acc[c]);
@@ -1443,7 +1451,8 @@ private:
     ((detail::k_Jv<FactorDescriptor, Is><<<detail::blocks(active_count() * E), detail::TPB>>>(fv, res, x)), ...);
   }
   template <int WHICH, size_t I> void gather_one(detail::FactorView<FactorDescriptor> &fv, T *out, const T *in) {
-    const size_t nv = vertex_descriptors[I]->count(), groups = nv * (WHICH == 4 ? detail::slot_dim<FactorDescriptor, I>() : 1);
+    constexpr size_t dI = detail::slot_dim<FactorDescriptor, I>(), rbI = dI < detail::GATHER_ROWS ? dI : detail::GATHER_ROWS;
+    const size_t nv = vertex_descriptors[I]->count(), groups = nv * (WHICH == 4 ? (dI + rbI - 1) / rbI : 1);
     if (!groups) return;
     detail::k_gather<FactorDescriptor, I, WHICH><<<detail::blocks(groups * (size_t)slot_lanes[I]), detail::TPB>>>(fv, slot_vptr[I].raw(), slot_vfac[I].raw(), nv, slot_lanes[I], out, in);
   }
