@@ -112,7 +112,6 @@ template <typename T> struct Engine final : EngineBase {
   int nch = 0, nb_pm = 0, nseg = 0;
   int num_cu = 256, grid_obs = 0, grid_vec = 0, grid_chi2 = 0; // persistent grids
   int fbj_per_cu = 4;            // k_finalize_bj: workgroups resident per CU (occupancy query)
-  int grid_isp = 0;              // k_is_prepare: resident workgroups
   int grid_lin = 0, grid_op = 0; // k_linearize / k_pcg_operator: exactly the workgroups that are resident at once (apply_tuning)
   // Schur structure (lazy)
   bool schur_ready = false;
@@ -369,8 +368,6 @@ template <typename T> struct Engine final : EngineBase {
       return std::max(8, std::min(nb_pm, num_cu * mult) & ~7);
     };
     grid_lin = resident(reinterpret_cast<const void *>(&k_linearize<T, false>), LIN_WAVES, 8);
-    // implicit Schur complement: k_is_prepare needs 242 VGPRs (2 workgroups per CU) and was launched on the common 4-per-CU grid
-    grid_isp = resident(reinterpret_cast<const void *>(&k_is_prepare<T, T>), 2, 4);
     {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_finalize_bj<T>), TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 3; }
