@@ -518,7 +518,9 @@ public:
   virtual ~BaseFactorDescriptor() = default;
   virtual size_t internal_count() const = 0;
   virtual size_t active_count() const = 0;
-  virtual void initialize(uint8_t level) = 0;     // active list, local ids, vertex use flags
+  // active list, local ids, vertex use flags; `light`: without what only the generic kernels need (Jacobian storage, the
+  // per-vertex factor lists of the gathers) — the probe / export of the engine hand-over (solve.hpp) runs on a light one
+  virtual void initialize(uint8_t level, bool light = false) = 0;
   virtual void flag_active_vertices() = 0;
   virtual void compute_error() = 0;
   virtual void compute_jacobians() = 0;
@@ -1229,14 +1231,16 @@ public:
   size_t error_dimension() const override { return E; }
   BaseVertexDescriptor<T, S> *slot_descriptor(size_t s) const override { return vertex_descriptors[s]; }
 
-  void initialize(uint8_t level) override {
+  void initialize(uint8_t level, bool light = false) override {
     active_indices.clear();
     for (size_t f = 0; f < internal_count(); ++f) {
       for (size_t i = 0; i < N; ++i) device_ids[f * N + i] = vertex_descriptors[i]->get_local_id(host_ids[f * N + i]);
       if (detail::is_factor_active(active[f], level)) active_indices.push_back(f);
     }
-    init_jacobians(std::make_index_sequence<N>{});
     refresh_table_mirrors();
+    gather_ready = false; jacobians_sized = false;
+    if (light) return;
+    init_jacobians(std::make_index_sequence<N>{});
     build_vertex_lists();
   }
   void build_vertex_lists() {
@@ -1305,6 +1309,7 @@ public:
   }
   void compute_jacobians() override {
     dynamic_scales = nullptr; // a new linearisation: the scalar diagonal is taken from unscaled blocks
+    if (!jacobians_sized) init_jacobians(std::make_index_sequence<N>{});
     if (!dynamic_jacobians()) jac_all(std::make_index_sequence<N>{});
   }
   void compute_chi2() override {
@@ -1423,7 +1428,9 @@ public:
   }
 
 private:
+  bool jacobians_sized = false; // a light initialize() leaves the storage to the first compute_jacobians()
   template <size_t... Is> void init_jacobians(std::index_sequence<Is...>) {
+    jacobians_sized = true;
     ((jacobians[Is].dimensions[0] = E, jacobians[Is].dimensions[1] = detail::slot_dim<FactorDescriptor, Is>(),
       jacobians[Is].data.resize(dynamic_jacobians() ? 0 : E * detail::slot_dim<FactorDescriptor, Is>() * internal_count())), ...);
   }
@@ -1551,10 +1558,10 @@ public:
 
   // graph.hpp:92-167: active factors, which vertices they use, then one scalar column range per
   // active vertex, descriptors in the order they were added, vertices by ascending global id
-  bool initialize_optimization(uint8_t level = 0) {
+  bool initialize_optimization(uint8_t level = 0, bool light = false) {
     for (auto *vd : vertex_descriptors)
       if (vd->count()) detail::k_clear_msb<T><<<detail::blocks(vd->count()), detail::TPB>>>(vd->get_active_state(), vd->count());
-    for (auto *fd : factor_descriptors) fd->initialize(level);
+    for (auto *fd : factor_descriptors) fd->initialize(level, light);
     for (auto *fd : factor_descriptors) fd->flag_active_vertices();
     for (auto *vd : vertex_descriptors)
       if (vd->count()) detail::k_xor_msb<T><<<detail::blocks(vd->count()), detail::TPB>>>(vd->get_active_state(), vd->count());

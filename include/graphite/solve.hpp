@@ -576,7 +576,19 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   if (!((vds[0] == cd && vds[1] == pd) || (vds[0] == pd && vds[1] == cd))) return false;
   const int kind = options->solver->engine_kind(cd->count());
   if (kind < 0) return false;
-  if (!graph->initialize_optimization(options->optimization_level)) return false;
+  const bool timing = getenv("GR_VERBOSE") != nullptr;
+  const auto tt0 = std::chrono::steady_clock::now();
+  auto lap = [&, last = tt0](const char *what) mutable {
+    if (!timing) return;
+    graphite::detail::sync();
+    const auto now = std::chrono::steady_clock::now();
+    std::cerr << "[graphite] hand-over: " << what << " " << std::chrono::duration<double, std::milli>(now - last).count() << " ms" << std::endl;
+    last = now;
+  };
+  // light: local ids, active list, vertex states and Hessian columns — what the checks, the probe and the export below read;
+  // the Jacobian storage and gather lists of the generic kernels are only built when the graph stays with them (lm_loop)
+  if (!graph->initialize_optimization(options->optimization_level, /*light=*/true)) return false;
+  lap("initialize_optimization (light)");
   // fixed vertices (bit 0) go to the engine as masks (gr_bal_set_fixed); a vertex no active factor touches (bit 7) is not
   // an engine graph
   std::vector<unsigned char> cam_fixed(cd->count(), 0), pt_fixed(pd->count(), 0);
@@ -593,6 +605,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   std::vector<T> obs;
   int loss_kind = 0; double loss_delta = 0;
   if (!fds[0]->export_bal(ci, pi, obs, loss_kind, loss_delta)) return false;
+  lap("fixed masks + export_bal");
   int dev = 0;
   GRAPHITE_HIP(hipGetDevice(&dev));
   const gr_dtype dt = sizeof(T) == 8 ? GR_F64 : GR_F32;
@@ -636,11 +649,13 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
     }
   }
 
+  lap("probe");
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
   managed_vector<T> cams(9 * cd->count()), pts(3 * pd->count());
   cd->gather_parameters(cams.raw()); pd->gather_parameters(pts.raw());
   graphite::detail::sync();
+  lap("gather_parameters");
   gr_bal_problem *prob = nullptr;
   auto fail = [&](const char *what) { std::cerr << "graphite: engine hand-over failed in " << what << ": " << gr_last_error_string() << "; using the generic kernels" << std::endl; if (prob) gr_bal_destroy(prob); return false; };
   if (gr_bal_create(&prob, dt, (int64_t)cd->count(), (int64_t)pd->count(), (int64_t)ci.size(), cams.raw(), pts.raw(), obs.data(), ci.data(), pi.data(), dev, nullptr) != GR_OK) return fail("gr_bal_create");
@@ -648,6 +663,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   if (any_fixed && gr_bal_set_fixed(prob, cam_fixed.data(), pt_fixed.data()) != GR_OK) return fail("gr_bal_set_fixed");
   if (gr_bal_set_scale_system(prob, graph->scales_system() ? 1 : 0) != GR_OK) return fail("gr_bal_set_scale_system");
   if (!std::is_same<T, S>::value && gr_bal_set_jacobian_precision(prob, GR_F32) != GR_OK) return fail("gr_bal_set_jacobian_precision");
+  lap("gr_bal_create + settings");
   gr_lm_options o{};
   o.solver = kind; o.iterations = (int32_t)options->iterations; o.initial_damping = options->initial_damping;
   o.use_identity = options->use_identity ? 1 : 0; o.early_stop = early_stop ? 1 : 0;
@@ -661,11 +677,15 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
                                       << " factors) handed to the gr_bal engine, gr_solver " << kind << std::endl;
   if (gr_bal_levenberg_marquardt(prob, &o, &st, chi2.data(), lambda.data()) != GR_OK) return fail("gr_bal_levenberg_marquardt");
   ++engine_handovers();
+  lap("gr_bal_levenberg_marquardt");
   if (gr_bal_get_params(prob, cams.raw(), pts.raw()) != GR_OK) return fail("gr_bal_get_params");
   cd->scatter_parameters(cams.raw()); pd->scatter_parameters(pts.raw());
+  lap("get_params + scatter_parameters");
   graph->compute_error(); // leave the residuals of the optimised vertices behind, as the generic loop does (graph->chi2() is valid)
   graphite::detail::sync();
+  lap("compute_error");
   gr_bal_destroy(prob);
+  lap("gr_bal_destroy");
   if (options->verbose) {
     const double total = std::chrono::duration<double>(clk::now() - t0).count();
     const double per_it = st.iterations_run ? st.loop_seconds / st.iterations_run : 0.0, setup = total - st.loop_seconds;
