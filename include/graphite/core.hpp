@@ -414,9 +414,28 @@ public:
   managed_vector<StateType> backup_state;
   std::unordered_map<size_t, size_t> global_to_local_map;
   std::vector<size_t> local_to_global_map;
+  // get_local_id is called once per factor slot by every initialize_optimization (1.36 M times on Ladybug-1723: ~40 ms of
+  // hash look-ups).  Ids that span a range of at most a few times their number (the usual 0 .. n - 1 or offset blocks) get a
+  // plain table [id - base] -> local id, rebuilt lazily after any change of the vertex set.
+  mutable std::vector<uint32_t> dense_local;
+  mutable size_t dense_base = 0;
+  mutable bool dense_dirty = true, dense_usable = false;
+  void build_dense_ids() const {
+    dense_dirty = false; dense_usable = false; dense_local.clear();
+    const size_t n = local_to_global_map.size();
+    if (!n || n >= 0xffffffffu) return;
+    size_t lo = local_to_global_map[0], hi = lo;
+    for (size_t g : local_to_global_map) { lo = std::min(lo, g); hi = std::max(hi, g); }
+    if (hi - lo >= 4 * n + 1024) return; // sparse ids: stay with the hash map
+    dense_base = lo;
+    dense_local.assign(hi - lo + 1, 0xffffffffu);
+    for (size_t l = 0; l < n; ++l) dense_local[local_to_global_map[l] - lo] = (uint32_t)l;
+    dense_usable = true;
+  }
 
   void reserve(size_t n) { x_device.reserve(n); active_state.reserve(n); hessian_ids.reserve(n); backup_state.reserve(n); local_to_global_map.reserve(n); }
   void add_vertex(size_t id, VertexType *vertex, bool fixed = false) { // vertex.hpp:241-256
+    dense_dirty = true;
     global_to_local_map[id] = x_device.size();
     local_to_global_map.push_back(id);
     x_device.push_back(vertex);
@@ -427,6 +446,7 @@ public:
   void remove_vertex(size_t id) { // swap with last, vertex.hpp:185-215
     auto it = global_to_local_map.find(id);
     if (it == global_to_local_map.end()) { std::cerr << "Vertex with id " << id << " not found." << std::endl; return; }
+    dense_dirty = true;
     const size_t l = it->second, last = x_device.size() - 1;
     x_device[l] = x_device[last]; active_state[l] = active_state[last]; hessian_ids[l] = hessian_ids[last];
     const size_t moved = local_to_global_map[last];
@@ -446,7 +466,14 @@ public:
   bool is_active(size_t id) const override { return detail::is_vertex_active(active_state.raw(), global_to_local_map.at(id)); }
   bool exists(size_t id) const override { return global_to_local_map.count(id) > 0; }
   VertexType *get_vertex(size_t id) { return x_device[global_to_local_map.at(id)]; }
-  size_t get_local_id(size_t id) const override { return global_to_local_map.at(id); }
+  size_t get_local_id(size_t id) const override {
+    if (dense_dirty) build_dense_ids();
+    if (dense_usable) {
+      const size_t k = id - dense_base; // wraps for id < base: caught by the range test
+      if (k < dense_local.size() && dense_local[k] != 0xffffffffu) return dense_local[k];
+    }
+    return global_to_local_map.at(id); // throws for an unknown id, as before
+  }
   size_t dimension() const override { return dim; }
   size_t count() const override { return x_device.size(); }
   // Device mirror (the reference keeps user vertices in CUDA unified memory, which migrates to the GPU on first touch,
@@ -491,7 +518,7 @@ public:
   const size_t *device_hessian_ids() const override { return mirrored ? mirror_hid.raw() : hessian_ids.raw(); }
   const std::vector<size_t> &local_to_global() const override { return local_to_global_map; }
   void to_device() {}
-  void clear() { x_device.clear(); active_state.clear(); hessian_ids.clear(); backup_state.clear(); global_to_local_map.clear(); local_to_global_map.clear(); }
+  void clear() { x_device.clear(); active_state.clear(); hessian_ids.clear(); backup_state.clear(); global_to_local_map.clear(); local_to_global_map.clear(); dense_dirty = true; }
 
   void apply_update(const T *delta_x, const T *scales) override {
     if (count()) detail::k_vertex_update<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), device_active_state(), device_hessian_ids(), count(), delta_x, scales);
@@ -1572,12 +1599,20 @@ public:
       if (pass == 1) { pose_dim = col; elimination_block = hessian_offsets.size(); }
       for (auto *vd : vertex_descriptors) {
         if ((int)vd->eliminate != pass) continue;
-        std::vector<std::pair<size_t, size_t>> order;
+        // columns in ascending GLOBAL id; vertices added in id order (the usual case) need no sort
         const auto &l2g = vd->local_to_global();
-        for (size_t l = 0; l < vd->count(); ++l) order.emplace_back(l2g[l], l);
-        std::sort(order.begin(), order.end());
-        for (auto &e : order)
-          if (detail::is_vertex_active(vd->get_active_state(), e.second)) { vd->get_hessian_ids()[e.second] = col; hessian_offsets.push_back(col); col += vd->dimension(); }
+        const uint8_t *state = vd->get_active_state();
+        auto *hid = &vd->get_hessian_ids()[0];
+        const size_t nvd = vd->count(), dimv = vd->dimension();
+        auto place = [&](size_t l) { if (detail::is_vertex_active(state, l)) { hid[l] = col; hessian_offsets.push_back(col); col += dimv; } };
+        if (std::is_sorted(l2g.begin(), l2g.begin() + nvd)) { for (size_t l = 0; l < nvd; ++l) place(l); }
+        else {
+          std::vector<std::pair<size_t, size_t>> order;
+          order.reserve(nvd);
+          for (size_t l = 0; l < nvd; ++l) order.emplace_back(l2g[l], l);
+          std::sort(order.begin(), order.end());
+          for (auto &e : order) place(e.second);
+        }
       }
     }
     hessian_offsets.push_back(col);
