@@ -1194,6 +1194,7 @@ public:
   void reserve(size_t n) {
     host_ids.reserve(N * n); device_ids.reserve(N * n); device_obs.reserve(n); data.reserve(n); loss.reserve(n);
     precision_matrices.reserve(E * E * n); active.reserve(n); residuals.reserve(E * n); chi2_vec.reserve(n); chi2_derivative.reserve(n);
+    work.reserve(E * n); global_to_local_map.reserve(n); local_to_global_map.reserve(n);
   }
   // factor.hpp:373-412; precision_matrix == nullptr -> identity
   size_t add_factor(const std::array<size_t, N> &ids, const ObservationType &obs, const S *precision_matrix,
