@@ -433,7 +433,7 @@ public:
     dense_usable = true;
   }
 
-  void reserve(size_t n) { x_device.reserve(n); active_state.reserve(n); hessian_ids.reserve(n); backup_state.reserve(n); local_to_global_map.reserve(n); }
+  void reserve(size_t n) { x_device.reserve(n); active_state.reserve(n); hessian_ids.reserve(n); backup_state.reserve(n); local_to_global_map.reserve(n); global_to_local_map.reserve(n); }
   void add_vertex(size_t id, VertexType *vertex, bool fixed = false) { // vertex.hpp:241-256
     dense_dirty = true;
     global_to_local_map[id] = x_device.size();
