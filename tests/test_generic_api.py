@@ -38,7 +38,8 @@ def hipcc(src, out, *flags):
 def build_all():
     # the clients are independent translation units (tens of seconds each: the whole header-only layer): built side by side
     from concurrent.futures import ThreadPoolExecutor
-    names = ["test_generic_radius", "test_generic_bal", "test_generic_known_answers", "test_generic_schur_mixed", "test_sparse_schur"]
+    names = ["test_generic_radius", "test_generic_bal", "test_generic_known_answers", "test_generic_schur_mixed", "test_sparse_schur",
+             "test_generic_schur_dims"]
     lib = os.path.join(ROOT, "graphite_amd", "libgraphite_mi355x.so")
     if not os.path.exists(lib):
         import __graft_entry__ as g
@@ -46,7 +47,7 @@ def build_all():
     with ThreadPoolExecutor(max_workers=4) as pool:
         exe = list(pool.map(lambda n: hipcc(os.path.join(ROOT, "tests", "cpp", n + ".hip"), os.path.join(BUILD, n)), names))
     radius = exe[0]
-    return (radius, radius, exe[1], exe[2], exe[3], exe[4])
+    return (radius, radius, exe[1], exe[2], exe[3], exe[4], exe[5])
 
 
 def test_generic_layer_compiles_for_gfx950():
@@ -291,3 +292,21 @@ def test_sparse_schur_on_a_graph_beyond_dense_reach():
     per_factor = float(line[line.index("per_factor") + 1])
     assert per_factor < 2.5 * 0.02 ** 2     # chi2 per factor at the noise level (2 residuals of sigma 0.02 each)
     assert float(line[line.index("max_pose_error") + 1]) < 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["pcg-schur", "eigen-schur"])
+def test_fixed_dimension_schur_kernels_equal_the_any_dimension_ones(solver):
+    """sparse.hpp's compile-time forms (k_schur_mul_fixed / k_schur_hpl_* / k_schur_vec <6, 3>) on a graph of 6-d poses and 3-d
+    eliminated landmarks: same LM result as the any-dimension kernels (GRAPHITE_SCHUR_MUL_GENERIC=1) to rounding."""
+    exe = build_all()[6]
+    outs = []
+    for generic in ("0", "1"):
+        r = subprocess.run([exe, solver], capture_output=True, text=True, timeout=300, env=dict(os.environ, GRAPHITE_SCHUR_MUL_GENERIC=generic))
+        assert r.returncode == 0, r.stderr[-1000:]
+        outs.append([float(x) for ln in r.stdout.splitlines() if ln.split()[0] in ("CHI2", "POSE", "LM") for x in ln.split()[1:]])
+    print(outs[0][:4], outs[1][:4])
+    assert len(outs[0]) == len(outs[1]) > 10
+    assert np.allclose(outs[0], outs[1], rtol=1e-9, atol=1e-11)
+    assert outs[0][0] < 10.0  # the optimisation converged (chi2 of the noisy observations)
+
