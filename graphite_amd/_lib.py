@@ -28,6 +28,7 @@ EXPORTS = [
     "gr_bal_landmark_update", "gr_bal_schur_structure", "gr_bal_get", "gr_bal_hessian_structure", "gr_bal_export_csc",
     "gr_bal_levenberg_marquardt", "gr_bal_kernel_stats", "gr_comm_unique_id", "gr_bal_comm_init", "gr_bal_comm_ipc_mailbox", "gr_bal_comm_init_ipc", "gr_bal_set_fixed",
     "gr_dense_cholesky_solve", "gr_bal_model_evaluate", "gr_bal_tuning_default", "gr_bal_set_tuning", "gr_bal_get_tuning",
+    "gr_bal_direct_solver_info",
 ]
 # include/graphite_mi355x_test.h (test / diagnostic entry points, not part of the drop-in boundary)
 TEST_EXPORTS = ["gr_bal_comm_init_local", "gr_bal_diag_time", "gr_bal_comm_allreduce_host", "gr_test_lane_xor"]
@@ -57,6 +58,12 @@ class Tuning(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("point_tiles", "g3_gather", "point_records", "pcg_lazy", "pcg_single_reduction", "sparse_cholesky",
                                          "spchol_overlap", "lm_speculate", "lm_ahead", "lm_fused", "grid_mult", "vec_per_thread", "schur_item",
                                          "verbose", "ipc_timeout_ms")] + [("reserved", C.c_int32 * 5)]
+
+
+class DirectSolverInfo(C.Structure):
+    """gr_direct_solver_info (include/graphite_mi355x.h)"""
+    _fields_ = [("sparse", C.c_int32), ("tile_columns", C.c_int32), ("levels", C.c_int32), ("supernodes", C.c_int32),
+                ("padded_n", C.c_int64), ("factor_tiles", C.c_int64), ("factor_bytes", C.c_int64), ("dense_bytes", C.c_int64)]
 
 
 class KernelStat(C.Structure):

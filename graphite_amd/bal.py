@@ -209,6 +209,13 @@ class BalProblem:
         stats = {f: getattr(st, f) for f, _ in LMStats._fields_}
         return tr[0, :k], tr[1, :k], stats
 
+    def direct_solver_info(self):
+        """gr_bal_direct_solver_info: what solver_update_structure(SOLVER_DENSE_SCHUR) set up (tile-sparse or dense factor)."""
+        from ._lib import DirectSolverInfo
+        info = DirectSolverInfo()
+        check(self.lib.gr_bal_direct_solver_info(self.h, C.byref(info)))
+        return {f: getattr(info, f) for f, _ in DirectSolverInfo._fields_}
+
     def kernel_stats(self):
         arr = (KernelStat * 64)()
         n = C.c_int()

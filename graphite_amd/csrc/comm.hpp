@@ -128,6 +128,9 @@ template <typename T> __device__ __forceinline__ T ipc_load(const T *p) { return
 // 100 MHz wall clock): a peer that died or never joined turns into the error word (IpcComm::failed), not a hung GPU.
 __global__ void __launch_bounds__(256) k_ipc_allreduce(IpcMsg msg, char *const *__restrict__ boxes, int rank, int size, int set, size_t slot_bytes,
                                                        unsigned long long seq, unsigned *__restrict__ ticket, long long timeout_ticks, int *__restrict__ h_err) {
+  // a communicator on which an earlier all-reduce timed out holds rank-local values: every collective already enqueued
+  // behind the failed one returns at once (only the FIRST failure pays the wait bound; the host sees h_err / failed())
+  if (h_err && __hip_atomic_load(h_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
   const size_t slot_off = IPC_HEADER + ((size_t)set * size + rank) * slot_bytes;
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (size_t)gridDim.x * blockDim.x;
   for (int q = 0; q < msg.nparts; ++q) {

@@ -84,6 +84,7 @@ struct EngineBase {
   virtual void export_csc(int which, int64_t *nnz, int64_t *indptr, int64_t *indices, void *values) = 0;
   virtual void lm(const gr_lm_options &opt, gr_lm_stats &st, double *chi2_trace, double *lambda_trace) = 0;
   virtual int kernel_stats(gr_kernel_stat *out, int cap) = 0;
+  virtual void direct_solver_info(gr_direct_solver_info &o) = 0;
   virtual double diag_time(int which, int variant, int reps) = 0;
   virtual void set_comm(std::unique_ptr<Comm> c) = 0;
   virtual void allreduce_host(double *v, size_t n) = 0;
@@ -387,6 +388,7 @@ template <typename T> struct Engine final : EngineBase {
     records_tuned = false;
     if (chol_ready) { chol_ready = false; use_spchol = false; }
     if (schur_ready && nitems) schur_ready = false;
+    if (comm) comm->set_timeout_ms(tune.ipc_timeout_ms);
   }
   void alloc_pinned(int flag_cap) {
     if (h_res && flag_cap <= h_flag_cap) return;
@@ -408,6 +410,9 @@ template <typename T> struct Engine final : EngineBase {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned it = 0;; ++it) {
       if (pred()) return;
+      // on landmark shards a flag that does not come may be a peer that does not: surface the transport's failure as CommError
+      // (and stop enqueueing collectives behind it) as soon as its error word is up, not after the generic 20 s
+      if (comm && (it & 0x3FF) == 0x3FF) check_comm("PCG loop");
       if ((it & 0xFFFF) == 0xFFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
         GR_HIP(hipStreamSynchronize(stream)); // surfaces a kernel fault instead of hanging
         if (pred()) return;
@@ -1173,12 +1178,21 @@ template <typename T> struct Engine final : EngineBase {
     if (chol_ready) return;
     {
       const int force = tune.sparse_cholesky;
+      // what either form may take: 3/4 of the free HBM (the factor is the largest single allocation of the direct solvers)
+      size_t mem_free = 0, mem_total = 0;
+      GR_HIP(hipMemGetInfo(&mem_free, &mem_total));
+      const size_t budget = mem_free / 4 * 3;
+      const bool dense_fits = DenseChol<T>::bytes_needed((int64_t)pose_dim) <= budget;
       if (force != 0 && spchol.set_structure((int)Nc, h_S_rowi, h_S_coli, stream)) {
-        use_spchol = force == 1 || 2 * spchol.nlevels < spchol.nt;
-        if (spchol.bytes() > ((size_t)96 << 30)) use_spchol = false;
+        // tile-sparse storage: chosen when the elimination tree is clearly shorter than the chain of tile columns, and whenever the
+        // padded dense triangle would not fit but the factor's own tiles do (memory follows nnz(L))
+        use_spchol = force == 1 || 2 * spchol.nlevels < spchol.nt || !dense_fits;
+        if (spchol.bytes() > budget) use_spchol = false;
         if (tune.verbose)
-          std::fprintf(stderr, "[graphite-mi355x] sparse Cholesky: %d supernodes, %d tile columns (padded n = %d), elimination-tree height %d, %lld factor tiles -> %s\n",
-                       spchol.nsuper, spchol.nt, spchol.npad, spchol.nlevels, (long long)spchol.factor_tiles, use_spchol ? "nested dissection, level-scheduled" : "dense tile Cholesky");
+          std::fprintf(stderr, "[graphite-mi355x] sparse Cholesky: %d supernodes, %d tile columns (padded n = %d), elimination-tree height %d, %lld factor tiles "
+                               "= %.3f GB (dense triangle: %.3f GB) -> %s\n",
+                       spchol.nsuper, spchol.nt, spchol.npad, spchol.nlevels, (long long)spchol.factor_tiles, spchol.bytes() / 1e9, spchol.dense_bytes() / 1e9,
+                       use_spchol ? "nested dissection, level-scheduled, tile-sparse storage" : "dense tile Cholesky");
       }
       if (use_spchol) {
         spchol.allocate();
@@ -1187,9 +1201,9 @@ template <typename T> struct Engine final : EngineBase {
         chol_ready = true;
         return;
       }
+      if (!dense_fits)
+        throw std::invalid_argument("direct solve of the reduced camera system: neither the tile-sparse factor nor the padded dense triangle fits in the free HBM");
     }
-    if (DenseChol<T>::bytes_needed((int64_t)pose_dim) > ((size_t)96 << 30))
-      throw std::invalid_argument("dense reduced camera system does not fit (9 Nc padded squared > 96 GiB)");
     const int nt = (int)((pose_dim + CH_NB - 1) / CH_NB);
     std::vector<char> tz((size_t)nt * nt, 0);
     for (int64_t q = 0; q < nnzb; ++q) {
@@ -1202,6 +1216,18 @@ template <typename T> struct Engine final : EngineBase {
     chol_sink.reset(new CholSink(this));
     chol.sink = chol_sink.get();
     chol_ready = true;
+  }
+  void direct_solver_info(gr_direct_solver_info &o) override {
+    if (!chol_ready) throw std::logic_error("gr_bal_direct_solver_info: call gr_bal_solver_update_structure(GR_SOLVER_DENSE_SCHUR) first");
+    std::memset(&o, 0, sizeof(o));
+    if (use_spchol) {
+      o.sparse = 1; o.tile_columns = spchol.nt; o.levels = spchol.nlevels; o.supernodes = spchol.nsuper; o.padded_n = spchol.npad;
+      o.factor_tiles = spchol.nz_tiles; o.factor_bytes = (int64_t)spchol.bytes(); o.dense_bytes = (int64_t)spchol.dense_bytes();
+    } else {
+      o.sparse = 0; o.tile_columns = chol.nt; o.levels = chol.nt; o.supernodes = 1; o.padded_n = chol.npad;
+      o.factor_tiles = chol.nz_tiles; o.dense_bytes = (int64_t)chol.npad * chol.npad * (int64_t)sizeof(T);
+      o.factor_bytes = o.dense_bytes + (int64_t)chol.nt * CH_NB * CH_NB * (int64_t)sizeof(T);
+    }
   }
   bool solve_dense_schur(T *x) {
     ensure_chol();
@@ -2336,6 +2362,10 @@ gr_status gr_bal_levenberg_marquardt(gr_bal_problem *p, const gr_lm_options *opt
 gr_status gr_bal_kernel_stats(gr_bal_problem *p, gr_kernel_stat *out, int cap, int *n) {
   return guarded(p, [&] { const int k = p->e->kernel_stats(out, cap); if (n) *n = k; });
 }
+gr_status gr_bal_direct_solver_info(gr_bal_problem *p, gr_direct_solver_info *info) {
+  if (!info) { g_last_error = "gr_bal_direct_solver_info: bad argument"; return GR_ERR_INVALID; }
+  return guarded(p, [&] { p->e->direct_solver_info(*info); });
+}
 // diagnostic (not part of the drop-in surface): mean device time in us of one hot kernel
 double gr_bal_diag_time(gr_bal_problem *p, int which, int variant, int reps) {
   double us = -1;
@@ -2407,6 +2437,9 @@ gr_status gr_bal_comm_init_ipc(gr_bal_problem *p, const void *handles, int rank,
       if (ok) {
         ipc.reset(new IpcComm(rank, world_size, p->e->ipc_slot, boxes, opened));
         p->e->ipc_box = nullptr; // owned by the communicator from here on
+        // the caller's wait bound also governs the start-up self-test, with a floor of 5 s: this is the one collective at
+        // which ranks arrive after unequal host-side set-up work (code-object loading, first launches)
+        ipc->set_timeout_ms(std::max(5000, p->e->tune.ipc_timeout_ms));
         // start-up verification on the real topology: known values, three sizes, both mailbox sets
         const size_t maxn = ipc->slot_bytes / sizeof(double);
         const double S = 0.5 * world_size * (world_size + 1);

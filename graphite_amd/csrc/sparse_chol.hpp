@@ -19,8 +19,12 @@
 // 122 -> ~35), and a level keeps tens to hundreds of workgroups busy instead of a dozen.  A graph that does not
 // dissect (Venice-like: every camera pair co-observes) comes out as ONE supernode = the dense factorisation; the
 // engine then keeps using DenseChol (chol.hpp), whose paired super-panels are tuned for that case.
-// Storage is the same padded dense row-major lower triangle as chol.hpp (only structurally non-zero tiles are ever
-// touched); the kernels reuse its diagonal-block factorisation and its MFMA tile loop.
+// Storage is TILE-SPARSE (round 4): only the structurally non-zero lower tiles of the factor (fill included) exist, each a
+// contiguous row-major 128 x 128 image (ld = 128) at A + slot * 128 * 128; bytes() = nz_tiles * 128^2 * sizeof(T), i.e.
+// memory follows nnz(L) as cuDSS / SimplicialLDLT do (solver/cudss_schur.hpp:146-219, solver/eigen_schur.hpp:71-108) — a
+// 13 000-camera banded S is ~1 GB instead of a 121 GB dense array.  Every launch list carries tile SLOTS, not (row, column)
+// coordinates; the scatter of S finds its tile through a dense nt x nt slot map (4 bytes per tile position).
+// The kernels reuse chol.hpp's diagonal-block factorisation and its MFMA tile loop.
 #pragma once
 #include "chol.hpp"
 #include <map>
@@ -28,15 +32,17 @@
 
 namespace gr {
 
+constexpr size_t SP_TT = (size_t)CH_NB * CH_NB; // scalars per tile
 template <typename T>
-__global__ __launch_bounds__(CH_PT) void k_sp_potrf(T *__restrict__ A, int ld, const int *__restrict__ panels, T *__restrict__ Linv, int *__restrict__ fail) {
+__global__ __launch_bounds__(CH_PT) void k_sp_potrf(T *__restrict__ A, const int *__restrict__ panels, const int *__restrict__ dslot, T *__restrict__ Linv, int *__restrict__ fail) {
   extern __shared__ __align__(16) unsigned char ch_smem[];
   const int k = panels[blockIdx.x];
-  chol_potrf_block<T>(reinterpret_cast<T *>(ch_smem), A + (size_t)k * CH_NB * ld + (size_t)k * CH_NB, ld, Linv + (size_t)k * CH_NB * CH_NB, fail, true, 0);
+  chol_potrf_block<T>(reinterpret_cast<T *>(ch_smem), A + (size_t)dslot[k] * SP_TT, CH_NB, Linv + (size_t)k * CH_NB * CH_NB, fail, true, 0);
 }
 
-// MODE 0: L_ik = A_ik Linv_k^T for tiles[2b] = i, tiles[2b+1] = k                       (panel solve)
-// MODE 1: A_ij -= sum_{k in list(b)} L_ik L_jk^T, tiles[2b] = i, tiles[2b+1] = j, list(b) = klist[kptr[b] .. kptr[b+1])
+// MODE 0: L_ik = A_ik Linv_k^T for tiles[2b] = slot(i, k), tiles[2b+1] = k                       (panel solve, in place)
+// MODE 1: A_ij -= sum_{k in list(b)} L_ik L_jk^T, tiles[2b] = slot(i, j) [| FUSE bit], tiles[2b+1] = i,
+//         list(b) = klist[2 q], klist[2 q + 1] = slot(i, k), slot(j, k) for q in kptr[b] .. kptr[b+1])
 // Same 128x128x16 MFMA pipeline as k_chol_gemm; the K loop of MODE 1 runs over the concatenated source panels.
 // MODE 1 targets flagged (i | FUSE_BIT, i) are diagonal tiles whose LAST update this is (their column sits on the
 // next tree level): the workgroup factorises the tile on the spot from its accumulators (as k_chol_gemm<FUSE> does),
@@ -44,26 +50,26 @@ __global__ __launch_bounds__(CH_PT) void k_sp_potrf(T *__restrict__ A, int ld, c
 // 75 us diagonal-block factorisation overlaps with the other updates of this launch.
 constexpr int SP_FUSE_BIT = 1 << 30;
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, int ld, const int *__restrict__ tiles, const int *__restrict__ kptr, const int *__restrict__ klist,
+__global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, const int *__restrict__ tiles, const int *__restrict__ kptr, const int *__restrict__ klist,
                                                  const T *__restrict__ Linv, T *__restrict__ Linv_out = nullptr, int *__restrict__ fail = nullptr) {
   extern __shared__ __align__(16) unsigned char ch_smem[];
   T *sm = reinterpret_cast<T *>(ch_smem);
   using M = MfmaTile<T>;
   typedef typename M::acc_t acc_t;
   constexpr int KC = CH_KC, CPP = CH_NB / KC; // chunks per panel
-  const int ti_raw = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
-  const int ti = ti_raw & ~SP_FUSE_BIT;
-  const bool fuse = MODE == 1 && (ti_raw & SP_FUSE_BIT) != 0;
+  constexpr int ld = CH_NB;
+  const int cs_raw = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1]; // MODE 0: tj = panel k; MODE 1: tj = tile row / column of a diagonal target
+  const int cslot = cs_raw & ~SP_FUSE_BIT;
+  const bool fuse = MODE == 1 && (cs_raw & SP_FUSE_BIT) != 0;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-  const int *kl = MODE == 1 ? klist + kptr[blockIdx.x] : nullptr;
+  const int *kl = MODE == 1 ? klist + 2 * (size_t)kptr[blockIdx.x] : nullptr;
   const int nch = MODE == 1 ? CPP * (kptr[blockIdx.x + 1] - kptr[blockIdx.x]) : CPP;
-  const T *Prow = A + (size_t)ti * CH_NB * ld;
-  const T *Qrow = MODE == 0 ? Linv + (size_t)tj * CH_NB * CH_NB : A + (size_t)tj * CH_NB * ld;
-  const int ldq = MODE == 0 ? CH_NB : ld;
-  T *Cg = A + (size_t)ti * CH_NB * ld + (size_t)tj * CH_NB;
-  // column of chunk c in P (and in Q for MODE 1; Linv is a plain 128-column matrix)
-  auto pcol = [&](int c) { return MODE == 1 ? kl[c / CPP] * CH_NB + (c % CPP) * KC : tj * CH_NB + c * KC; };
-  auto qcol = [&](int c) { return MODE == 1 ? pcol(c) : c * KC; };
+  T *Cg = A + (size_t)cslot * SP_TT;
+  const T *Q0 = MODE == 0 ? Linv + (size_t)tj * SP_TT : nullptr;
+  // chunk c of the K loop: rows of P / Q start at ptile(c) / qtile(c), its KC columns at kcol(c)
+  auto ptile = [&](int c) -> const T * { return MODE == 1 ? A + (size_t)kl[2 * (c / CPP)] * SP_TT : Cg; };
+  auto qtile = [&](int c) -> const T * { return MODE == 1 ? A + (size_t)kl[2 * (c / CPP) + 1] * SP_TT : Q0; };
+  auto kcol = [&](int c) { return (c % CPP) * KC; };
 
   acc_t acc[4][4];
   const int ccol = lane & 15;
@@ -80,11 +86,11 @@ __global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, int ld, cons
   const int lr = t / TPR, lk = (t % TPR) * 8;
   T pp[NPASS][8], pq[NPASS][8];
   {
-    const int pc = pcol(0), qc = qcol(0);
+    const T *P = ptile(0) + lk, *Q = qtile(0) + lk;
 #pragma unroll
     for (int u = 0; u < NPASS; ++u) {
-      load8<T>(Prow + (size_t)(lr + u * RPP) * ld + pc + lk, pp[u]);
-      load8<T>(Qrow + (size_t)(lr + u * RPP) * ldq + qc + lk, pq[u]);
+      load8<T>(P + (size_t)(lr + u * RPP) * ld, pp[u]);
+      load8<T>(Q + (size_t)(lr + u * RPP) * ld, pq[u]);
     }
   }
   constexpr int BUF = 2 * KC * CH_LDP;
@@ -105,11 +111,11 @@ __global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, int ld, cons
 #pragma unroll 1
   for (int c = 0; c < nch; ++c) {
     if (c + 1 < nch) {
-      const int pc = pcol(c + 1), qc = qcol(c + 1);
+      const T *P = ptile(c + 1) + kcol(c + 1) + lk, *Q = qtile(c + 1) + kcol(c + 1) + lk;
 #pragma unroll
       for (int u = 0; u < NPASS; ++u) {
-        load8<T>(Prow + (size_t)(lr + u * RPP) * ld + pc + lk, pp[u]);
-        load8<T>(Qrow + (size_t)(lr + u * RPP) * ldq + qc + lk, pq[u]);
+        load8<T>(P + (size_t)(lr + u * RPP) * ld, pp[u]);
+        load8<T>(Q + (size_t)(lr + u * RPP) * ld, pq[u]);
       }
     }
     const T *Ps = sm + (c & 1) * BUF, *Qs = Ps + KC * CH_LDP;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, int ld, cons
           const int row = wr * 64 + mi * 16 + M::row(lane, r), col = wc * 64 + ni * 16 + ccol;
           L[row * CH_LP + col] = col <= row ? acc[mi][ni][r] : T(0);
         }
-    chol_potrf_block<T>(L, Cg, ld, Linv_out + (size_t)ti * CH_NB * CH_NB, fail, false, 0);
+    chol_potrf_block<T>(L, Cg, ld, Linv_out + (size_t)tj * SP_TT, fail, false, 0);
     return;
   }
   int ld2 = ld;
@@ -162,24 +168,24 @@ __global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, int ld, cons
 // camcol[c] = first (padded, permuted) column of camera c
 template <typename T>
 __global__ __launch_bounds__(256) void k_sp_scatter(int64_t nnzb, const int *__restrict__ rowi, const int *__restrict__ coli, const int *__restrict__ camcol,
-                                                    const T *__restrict__ S, T *__restrict__ A, int ld) {
+                                                    const T *__restrict__ S, T *__restrict__ A, const int *__restrict__ tmap, int nt) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= 81 * nnzb) return;
   const int64_t q = e / 81;
   const int w = (int)(e - 81 * q), c = w / 9, r = w - 9 * c; // S_q(r, c) = S(9 i + r, 9 j + c), i <= j
-  const int R = camcol[rowi[q]] + r, C = camcol[coli[q]] + c;
-  if (rowi[q] == coli[q]) { if (R >= C) A[(size_t)R * ld + C] = S[e]; } // diagonal block: its lower half
-  else if (R > C) A[(size_t)R * ld + C] = S[e];
-  else A[(size_t)C * ld + R] = S[e];
+  int R = camcol[rowi[q]] + r, C = camcol[coli[q]] + c;
+  if (rowi[q] == coli[q]) { if (R < C) return; } // diagonal block: its lower half
+  else if (R < C) { const int x = R; R = C; C = x; }
+  A[(size_t)tmap[(size_t)(R >> 7) * nt + (C >> 7)] * SP_TT + (size_t)(R & 127) * CH_NB + (C & 127)] = S[e];
 }
 // zero the structurally non-zero lower tiles; padding columns get a unit diagonal
 template <typename T>
-__global__ __launch_bounds__(256) void k_sp_clear(T *__restrict__ A, int ld, const unsigned char *__restrict__ is_pad, const int *__restrict__ tiles) {
-  const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
-  T *Cg = A + (size_t)ti * CH_NB * ld + (size_t)tj * CH_NB;
+__global__ __launch_bounds__(256) void k_sp_clear(T *__restrict__ A, const unsigned char *__restrict__ is_pad, const int *__restrict__ tiles) {
+  const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1]; // slot = blockIdx.x: the tiles are stored in this list's order
+  T *Cg = A + (size_t)blockIdx.x * SP_TT;
   for (int e = threadIdx.x; e < CH_NB * CH_NB; e += 256) {
     const int r = e >> 7, c = e & 127;
-    Cg[(size_t)r * ld + c] = (ti == tj && r == c && is_pad[ti * CH_NB + r]) ? T(1) : T(0);
+    Cg[e] = (ti == tj && r == c && is_pad[ti * CH_NB + r]) ? T(1) : T(0);
   }
 }
 template <typename T> __global__ void k_sp_rhs(int npad, const int *__restrict__ src, const T *__restrict__ b, T *__restrict__ vb) {
@@ -213,7 +219,7 @@ template <typename T> __device__ __forceinline__ bool sp_last_arriver(T val, boo
 }
 // forward: y_k = Linv_k (b_k - sum_{j in row(k)} L_kj y_j)
 template <typename T>
-__global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, int ld, const T *__restrict__ Linv, SpItems it, const int *__restrict__ rcols,
+__global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, const T *__restrict__ Linv, SpItems it, const int *__restrict__ rcols, const int *__restrict__ rslot,
                                                 const T *__restrict__ b, T *__restrict__ y, T *__restrict__ partial, unsigned *__restrict__ ticket) {
   __shared__ T bk[CH_NB];
   const int item = blockIdx.x, k = it.panel[item], item_id = it.base + item;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, int ld,
     const int j = rcols[e];
     const T y0 = y[j * CH_NB + lane], y1 = y[j * CH_NB + 64 + lane];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) tot[h] += rows16_dot<T>(A + (size_t)(k * CH_NB + wave * 32 + h * 16) * ld + (size_t)j * CH_NB, (size_t)ld, y0, y1, lane);
+    for (int h = 0; h < 2; ++h) tot[h] += rows16_dot<T>(A + (size_t)rslot[e] * SP_TT + (size_t)(wave * 32 + h * 16) * CH_NB, (size_t)CH_NB, y0, y1, lane);
   }
   // lane L of (wave, h) holds the partial of row wave*32 + h*16 + (L >> 2)
   bool last = true;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, int ld,
 // agent-scope atomics — 246-250 LM it/s either way on Ladybug-1723: a level's 20 us are the cold reads of its L tiles by a
 // few workgroups, not the launch boundary.  What did help is more, smaller items per panel: SP_SLICE 6 -> 2, 249 -> 260.)
 template <typename T>
-__global__ __launch_bounds__(256) void k_sp_bwd(const T *__restrict__ A, int ld, const T *__restrict__ Linv, SpItems it, const int *__restrict__ crows,
+__global__ __launch_bounds__(256) void k_sp_bwd(const T *__restrict__ A, const T *__restrict__ Linv, SpItems it, const int *__restrict__ crows, const int *__restrict__ cslot,
                                                 const T *__restrict__ y, T *__restrict__ x, T *__restrict__ partial, unsigned *__restrict__ ticket) {
   __shared__ T v[CH_NB];
   __shared__ T half[CH_NB];
@@ -266,10 +272,10 @@ __global__ __launch_bounds__(256) void k_sp_bwd(const T *__restrict__ A, int ld,
   T s = T(0);
   for (int e = it.beg[item]; e < it.end[item]; ++e) {
     const int i = crows[e];
-    const T *Lg = A + (size_t)(i * CH_NB + h * 64) * ld + (size_t)k * CH_NB + c;
+    const T *Lg = A + (size_t)cslot[e] * SP_TT + (size_t)(h * 64) * CH_NB + c;
     const T *xg = x + i * CH_NB + h * 64;
 #pragma unroll 8
-    for (int r = 0; r < 64; ++r) s += Lg[(size_t)r * ld] * xg[r];
+    for (int r = 0; r < 64; ++r) s += Lg[(size_t)r * CH_NB] * xg[r];
   }
   if (h == 1) half[c] = s;
   __syncthreads();
@@ -300,6 +306,7 @@ template <typename T> struct SparseChol {
   double flops = 0;
   DevBuf<T> A, Linv, vb, vy, vx;
   DevBuf<int> d_camcol, d_src, d_nz, d_fail, d_panels, d_trsm, d_upd, d_kptr, d_klist, d_rptr, d_rcols, d_cptr, d_crows;
+  DevBuf<int> d_tmap, d_dslot, d_rslot, d_cslot; // tile-sparse storage: (i, j) -> slot map, diagonal slots, slots beside d_rcols / d_crows
   DevBuf<unsigned char> d_pad;
   DevBuf<int> d_itf[5], d_itb[5];
   DevBuf<T> partial;
@@ -431,36 +438,44 @@ template <typename T> struct SparseChol {
     nlevels = 1 + *std::max_element(level.begin(), level.end());
     std::vector<std::vector<int>> by_level(nlevels);
     for (int j = 0; j < nt; ++j) by_level[level[j]].push_back(j);
-    std::vector<int> h_panels, h_trsm, h_upd, h_klist, h_nz;
+    // tile slots: the structurally non-zero lower tiles in row-major order of (i, j); everything below addresses tiles by slot
+    std::vector<int> h_nz, tmap((size_t)nt * nt, -1), dslot(nt, 0);
+    for (int i = 0; i < nt; ++i)
+      for (int j = 0; j <= i; ++j) if (nz(i, j)) { tmap[(size_t)i * nt + j] = (int)(h_nz.size() / 2); h_nz.push_back(i); h_nz.push_back(j); }
+    nz_tiles = (int)(h_nz.size() / 2);
+    auto slot = [&](int i, int j) { return tmap[(size_t)i * nt + j]; };
+    for (int k = 0; k < nt; ++k) dslot[k] = slot(k, k);
+    std::vector<int> h_panels, h_trsm, h_upd, h_klist;
     h_kptr.assign(1, 0);
     lvl_panel_off.assign(1, 0); lvl_trsm_off.assign(1, 0); lvl_upd_off.assign(1, 0);
     for (int l = 0; l < nlevels; ++l) {
       std::map<std::pair<int, int>, std::vector<int>> targets;
       for (int k : by_level[l]) {
         h_panels.push_back(k);
-        for (int i : U[k]) { h_trsm.push_back(i); h_trsm.push_back(k); }
+        for (int i : U[k]) { h_trsm.push_back(slot(i, k)); h_trsm.push_back(k); }
         for (size_t x = 0; x < U[k].size(); ++x)
           for (size_t y = 0; y <= x; ++y) targets[{U[k][x], U[k][y]}].push_back(k);
       }
       // the diagonal tiles of the NEXT level lead the list (their workgroups also factorise: longest, scheduled first)
       for (int pass = 0; pass < 2; ++pass)
         for (auto &tg : targets) {
-          const bool diag_next = fuse_potrf && tg.first.first == tg.first.second && level[tg.first.first] == l + 1;
+          const int ti = tg.first.first, tj = tg.first.second;
+          const bool diag_next = fuse_potrf && ti == tj && level[ti] == l + 1;
           if (diag_next != (pass == 0)) continue;
-          h_upd.push_back(tg.first.first | (diag_next ? SP_FUSE_BIT : 0)); h_upd.push_back(tg.first.second);
-          for (int k : tg.second) h_klist.push_back(k);
-          h_kptr.push_back((int)h_klist.size());
+          h_upd.push_back(slot(ti, tj) | (diag_next ? SP_FUSE_BIT : 0)); h_upd.push_back(ti);
+          for (int k : tg.second) { h_klist.push_back(slot(ti, k)); h_klist.push_back(slot(tj, k)); }
+          h_kptr.push_back((int)(h_klist.size() / 2));
         }
       lvl_panel_off.push_back((int)h_panels.size());
       lvl_trsm_off.push_back((int)(h_trsm.size() / 2));
       lvl_upd_off.push_back((int)(h_upd.size() / 2));
     }
     // row structure (forward substitution) and column structure (backward), cut into items of <= SP_SLICE tiles
-    std::vector<int> h_rptr(nt + 1, 0), h_rcols, h_cptr(nt + 1, 0), h_crows;
+    std::vector<int> h_rptr(nt + 1, 0), h_rcols, h_rslot, h_cptr(nt + 1, 0), h_crows, h_cslot;
     for (int k = 0; k < nt; ++k) {
-      for (int j = 0; j < k; ++j) if (nz(k, j)) h_rcols.push_back(j);
+      for (int j = 0; j < k; ++j) if (nz(k, j)) { h_rcols.push_back(j); h_rslot.push_back(slot(k, j)); }
       h_rptr[k + 1] = (int)h_rcols.size();
-      for (int i : U[k]) h_crows.push_back(i);
+      for (int i : U[k]) { h_crows.push_back(i); h_cslot.push_back(slot(i, k)); }
       h_cptr[k + 1] = (int)h_crows.size();
     }
     std::vector<int> it_f[5], it_b[5]; // panel, beg, end, first, count
@@ -479,12 +494,10 @@ template <typename T> struct SparseChol {
     for (int q = 0; q < 5; ++q) { d_itf[q].upload(it_f[q], stream); d_itb[q].upload(it_b[q], stream); }
     partial.alloc((size_t)std::max(it_f[0].size(), it_b[0].size()) * CH_NB);
     ticket.alloc(nt); ticket.zero(stream);
-    for (int i = 0; i < nt; ++i)
-      for (int j = 0; j <= i; ++j) if (nz(i, j)) { h_nz.push_back(i); h_nz.push_back(j); }
-    nz_tiles = (int)(h_nz.size() / 2);
     auto up = [&](DevBuf<int> &d, std::vector<int> &h) { if (h.empty()) h.push_back(0); d.upload(h, stream); };
     up(d_panels, h_panels); up(d_trsm, h_trsm); up(d_upd, h_upd); up(d_klist, h_klist); up(d_nz, h_nz);
     d_kptr.upload(h_kptr, stream); d_rptr.upload(h_rptr, stream); up(d_rcols, h_rcols); d_cptr.upload(h_cptr, stream); up(d_crows, h_crows);
+    up(d_rslot, h_rslot); up(d_cslot, h_cslot); d_tmap.upload(tmap, stream); d_dslot.upload(dslot, stream);
     d_camcol.upload(camcol, stream); d_src.upload(src, stream); d_pad.upload(pad, stream);
     d_fail.alloc(1); // the matrix itself (bytes()) is allocated by allocate(), once the caller has decided to use this solver
     if (!h_fail) GR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_fail), sizeof(int), hipHostMallocDefault));
@@ -497,10 +510,12 @@ template <typename T> struct SparseChol {
     GR_HIP(hipStreamSynchronize(stream));
     return true;
   }
-  size_t bytes() const { return (size_t)npad * npad * sizeof(T); }
-  // the padded matrix, the tile inverses and the substitution vectors: only after the caller's memory guard / solver choice
+  // the factor's tiles (fill included) and the per-panel inverses of the diagonal tiles: memory follows nnz(L)
+  size_t bytes() const { return ((size_t)nz_tiles + (size_t)nt) * SP_TT * sizeof(T); }
+  size_t dense_bytes() const { return (size_t)npad * npad * sizeof(T); } // what the padded dense array of rounds 2-3 took
+  // the tiles, the tile inverses and the substitution vectors: only after the caller's memory guard / solver choice
   void allocate() {
-    A.alloc((size_t)npad * npad); Linv.alloc((size_t)nt * CH_NB * CH_NB);
+    A.alloc((size_t)nz_tiles * SP_TT); Linv.alloc((size_t)nt * SP_TT);
     vb.alloc(npad); vy.alloc(npad); vx.alloc(npad);
   }
 
@@ -511,8 +526,8 @@ template <typename T> struct SparseChol {
   };
   // S (upper 9x9 blocks) -> permuted dense lower triangle
   void load(int64_t nnzb, const int *rowi, const int *coli, const T *S) {
-    k_sp_clear<T><<<nz_tiles, 256, 0, stream>>>(A.p, npad, d_pad.p, d_nz.p);
-    k_sp_scatter<T><<<(unsigned)((81 * nnzb + 255) / 256), 256, 0, stream>>>(nnzb, rowi, coli, d_camcol.p, S, A.p, npad);
+    k_sp_clear<T><<<nz_tiles, 256, 0, stream>>>(A.p, d_pad.p, d_nz.p);
+    k_sp_scatter<T><<<(unsigned)((81 * nnzb + 255) / 256), 256, 0, stream>>>(nnzb, rowi, coli, d_camcol.p, S, A.p, d_tmap.p, nt);
   }
   void factor() { factor_levels([](int) {}); }
   template <typename After> void factor_levels(After &&after_level) {
@@ -523,16 +538,16 @@ template <typename T> struct SparseChol {
       const int np_ = lvl_panel_off[l + 1] - lvl_panel_off[l], ntr = lvl_trsm_off[l + 1] - lvl_trsm_off[l], nup = lvl_upd_off[l + 1] - lvl_upd_off[l];
       if (l == 0 || !fuse_potrf) { // deeper levels: factorised by the previous level's update launch
         Sc sc(sink, "spchol_potrf", 3.0 * np_ * tb, np_ * tf / 3);
-        k_sp_potrf<T><<<np_, CH_PT, lds_p, stream>>>(A.p, npad, d_panels.p + lvl_panel_off[l], Linv.p, d_fail.p);
+        k_sp_potrf<T><<<np_, CH_PT, lds_p, stream>>>(A.p, d_panels.p + lvl_panel_off[l], d_dslot.p, Linv.p, d_fail.p);
       }
       if (ntr) {
         Sc sc(sink, "spchol_trsm", 3.0 * ntr * tb, ntr * tf);
-        k_sp_gemm<T, 0><<<ntr, 256, lds_g, stream>>>(A.p, npad, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], nullptr, nullptr, Linv.p);
+        k_sp_gemm<T, 0><<<ntr, 256, lds_g, stream>>>(A.p, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], nullptr, nullptr, Linv.p);
       }
       if (nup) {
         const int nk = h_kptr[lvl_upd_off[l + 1]] - h_kptr[lvl_upd_off[l]];
         Sc sc(sink, "spchol_update", (2.0 * nup + 2.0 * nk) * tb, nk * tf);
-        k_sp_gemm<T, 1><<<nup, 256, std::max(lds_g, lds_p), stream>>>(A.p, npad, d_upd.p + 2 * (size_t)lvl_upd_off[l], d_kptr.p + lvl_upd_off[l], d_klist.p, nullptr, Linv.p, d_fail.p);
+        k_sp_gemm<T, 1><<<nup, 256, std::max(lds_g, lds_p), stream>>>(A.p, d_upd.p + 2 * (size_t)lvl_upd_off[l], d_kptr.p + lvl_upd_off[l], d_klist.p, nullptr, Linv.p, d_fail.p);
       }
       // level l's panels (L_kk^-1, trsm'ed sub-diagonal tiles) are final here; what the update launch above still writes are
       // tiles of LATER columns
@@ -558,7 +573,7 @@ template <typename T> struct SparseChol {
     factor_levels([&](int l) {
       GR_HIP(hipEventRecord(lvl_done[l], stream));
       GR_HIP(hipStreamWaitEvent(aux, lvl_done[l], 0));
-      k_sp_fwd<T><<<lvl_fitem_off[l + 1] - lvl_fitem_off[l], 256, 0, aux>>>(A.p, npad, Linv.p, items(d_itf, lvl_fitem_off[l]), d_rcols.p, vb.p, vy.p, partial.p, ticket.p);
+      k_sp_fwd<T><<<lvl_fitem_off[l + 1] - lvl_fitem_off[l], 256, 0, aux>>>(A.p, Linv.p, items(d_itf, lvl_fitem_off[l]), d_rcols.p, d_rslot.p, vb.p, vy.p, partial.p, ticket.p);
     });
     GR_HIP(hipEventRecord(aux_done, aux));
     GR_HIP(hipStreamWaitEvent(stream, aux_done, 0));
@@ -568,14 +583,14 @@ template <typename T> struct SparseChol {
   }
   void backward() {
     for (int l = nlevels - 1; l >= 0; --l)
-      k_sp_bwd<T><<<lvl_bitem_off[l + 1] - lvl_bitem_off[l], 256, 0, stream>>>(A.p, npad, Linv.p, items(d_itb, lvl_bitem_off[l]), d_crows.p, vy.p, vx.p, partial.p, ticket.p);
+      k_sp_bwd<T><<<lvl_bitem_off[l + 1] - lvl_bitem_off[l], 256, 0, stream>>>(A.p, Linv.p, items(d_itb, lvl_bitem_off[l]), d_crows.p, d_cslot.p, vy.p, vx.p, partial.p, ticket.p);
   }
   // b, x: device vectors of length n in the CALLER's (camera-major) order (x may alias b)
   void solve(const T *b, T *x) {
     Sc sc(sink, "spchol_solve", 2.0 * (double)factor_tiles * CH_NB * CH_NB * sizeof(T), 4.0 * (double)factor_tiles * CH_NB * CH_NB);
     k_sp_rhs<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, b, vb.p);
     for (int l = 0; l < nlevels; ++l)
-      k_sp_fwd<T><<<lvl_fitem_off[l + 1] - lvl_fitem_off[l], 256, 0, stream>>>(A.p, npad, Linv.p, items(d_itf, lvl_fitem_off[l]), d_rcols.p, vb.p, vy.p, partial.p, ticket.p);
+      k_sp_fwd<T><<<lvl_fitem_off[l + 1] - lvl_fitem_off[l], 256, 0, stream>>>(A.p, Linv.p, items(d_itf, lvl_fitem_off[l]), d_rcols.p, d_rslot.p, vb.p, vy.p, partial.p, ticket.p);
     backward();
     k_sp_unpermute<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, vx.p, x);
   }

@@ -346,7 +346,10 @@ public:
   virtual void gather_parameters(T *out) = 0;
   virtual void scatter_parameters(const T *in) = 0;
   bool eliminate = false; // set_eliminate (vertex.hpp:98): kept for API parity, the PCG path ignores it
-  void set_eliminate(bool e) { eliminate = e; }
+  void set_eliminate(bool e) { eliminate = e; ++structure_epoch; }
+  // bumped by every call that changes the vertex set, a vertex's address or its fixed flag: what a cached engine problem
+  // (solve.hpp, EngineCache) is keyed on, next to the factor descriptor's epoch and content fingerprint
+  size_t structure_epoch = 0;
 };
 
 namespace detail {
@@ -435,7 +438,7 @@ public:
 
   void reserve(size_t n) { x_device.reserve(n); active_state.reserve(n); hessian_ids.reserve(n); backup_state.reserve(n); local_to_global_map.reserve(n); global_to_local_map.reserve(n); }
   void add_vertex(size_t id, VertexType *vertex, bool fixed = false) { // vertex.hpp:241-256
-    dense_dirty = true;
+    dense_dirty = true; ++this->structure_epoch;
     global_to_local_map[id] = x_device.size();
     local_to_global_map.push_back(id);
     x_device.push_back(vertex);
@@ -446,7 +449,7 @@ public:
   void remove_vertex(size_t id) { // swap with last, vertex.hpp:185-215
     auto it = global_to_local_map.find(id);
     if (it == global_to_local_map.end()) { std::cerr << "Vertex with id " << id << " not found." << std::endl; return; }
-    dense_dirty = true;
+    dense_dirty = true; ++this->structure_epoch;
     const size_t l = it->second, last = x_device.size() - 1;
     x_device[l] = x_device[last]; active_state[l] = active_state[last]; hessian_ids[l] = hessian_ids[last];
     const size_t moved = local_to_global_map[last];
@@ -458,9 +461,9 @@ public:
   void replace_vertex(size_t id, VertexType *vertex) {
     auto it = global_to_local_map.find(id);
     if (it == global_to_local_map.end()) { std::cerr << "Vertex with id " << id << " not found." << std::endl; return; }
-    x_device[it->second] = vertex;
+    x_device[it->second] = vertex; ++this->structure_epoch;
   }
-  void set_fixed(size_t id, bool fixed) { active_state[global_to_local_map.at(id)] = static_cast<uint8_t>(fixed); }
+  void set_fixed(size_t id, bool fixed) { active_state[global_to_local_map.at(id)] = static_cast<uint8_t>(fixed); ++this->structure_epoch; }
   void set_hessian_column(size_t id, size_t column, size_t /*block*/) { hessian_ids[global_to_local_map.at(id)] = column; } // vertex.hpp:288-296
   bool is_fixed(size_t id) const override { return (active_state[global_to_local_map.at(id)] & 0x1) > 0; }
   bool is_active(size_t id) const override { return detail::is_vertex_active(active_state.raw(), global_to_local_map.at(id)); }
@@ -518,7 +521,7 @@ public:
   const size_t *device_hessian_ids() const override { return mirrored ? mirror_hid.raw() : hessian_ids.raw(); }
   const std::vector<size_t> &local_to_global() const override { return local_to_global_map; }
   void to_device() {}
-  void clear() { x_device.clear(); active_state.clear(); hessian_ids.clear(); backup_state.clear(); global_to_local_map.clear(); local_to_global_map.clear(); dense_dirty = true; }
+  void clear() { x_device.clear(); active_state.clear(); hessian_ids.clear(); backup_state.clear(); global_to_local_map.clear(); local_to_global_map.clear(); dense_dirty = true; ++this->structure_epoch; }
 
   void apply_update(const T *delta_x, const T *scales) override {
     if (count()) detail::k_vertex_update<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), device_active_state(), device_hessian_ids(), count(), delta_x, scales);
@@ -1112,6 +1115,13 @@ template <typename T, typename S> __global__ void k_diag_store(size_t nv, size_t
 // workgroup: 2 d^2 doubles each, d <= 16 -> at most 128 KB of the CU's 160 KB.
 constexpr int BLOCK_INV_THREADS = 32;
 inline size_t block_inverse_lds_bytes(size_t d) { return 2 * d * d * BLOCK_INV_THREADS * sizeof(double); }
+// d >= 12 needs more than the default 64 KB of dynamic LDS.  The attribute is per DEVICE, so it is set before every launch (it
+// costs a table write), not once per process; launch_check() after the <<<>>> turns a refused launch into an exception instead
+// of stale inverses.
+inline void allow_block_inverse_lds(const void *kernel) {
+  GRAPHITE_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_inverse_lds_bytes(16)));
+}
+inline void launch_check() { GRAPHITE_HIP(hipGetLastError()); }
 // Gauss-Jordan with partial pivoting (the reference: cuBLAS matinvBatched): A (column-major, destroyed), R = A^-1; entry e of
 // this thread is A[e * nt]
 __device__ inline void lds_gauss_jordan(double *A, double *R, int d, int nt) {

@@ -155,17 +155,13 @@ public:
   }
   void set_damping_factor(Graph<T, S> *graph, T mu, const bool use_identity, StreamPool &) override {
     auto &vds = graph->get_vertex_descriptors();
-    static const bool lds_ok = [] { // d = 16 needs 128 KB of dynamic LDS
-      GRAPHITE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&detail::k_block_inverse<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * 16 * 16 * detail::BLOCK_INV_THREADS * (int)sizeof(double)));
-      return true;
-    }();
-    (void)lds_ok;
+    detail::allow_block_inverse_lds(reinterpret_cast<const void *>(&detail::k_block_inverse<T>));
     for (size_t k = 0; k < vds.size(); ++k)
       if (vds[k]->count())
         detail::k_block_inverse<T><<<(unsigned)((vds[k]->count() + detail::BLOCK_INV_THREADS - 1) / detail::BLOCK_INV_THREADS), detail::BLOCK_INV_THREADS,
                                      2 * vds[k]->dimension() * vds[k]->dimension() * detail::BLOCK_INV_THREADS * sizeof(double)>>>(
             blocks[k]->raw(), inverses[k]->raw(), vds[k]->count(), (int)vds[k]->dimension(), mu, use_identity ? 1 : 0, vds[k]->device_active_state());
+    detail::launch_check();
     detail::sync();
   }
   void apply(Graph<T, S> *graph, T *z, const T *r, StreamPool &) override {
@@ -330,13 +326,10 @@ public:
   // S already carries the damping (it is reduced from the damped H), so the blocks are inverted as they are
   void update_values(Graph<T, S> *, SchurComplement<T, S> *schur, StreamPool &) override {
     if (!nblocks) return;
-    static const bool lds_ok = [] { // d = 16 needs 128 KB of dynamic LDS
-      GRAPHITE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&detail::k_schur_diag_inverse<T, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)detail::block_inverse_lds_bytes(16)));
-      return true;
-    }();
-    (void)lds_ok;
+    detail::allow_block_inverse_lds(reinterpret_cast<const void *>(&detail::k_schur_diag_inverse<T, S>));
     detail::k_schur_diag_inverse<T, S><<<(unsigned)((nblocks + detail::BLOCK_INV_THREADS - 1) / detail::BLOCK_INV_THREADS), detail::BLOCK_INV_THREADS, detail::block_inverse_lds_bytes(max_dim)>>>(
         nblocks, d_diag_off.raw(), d_soff.raw(), schur->get_values_ptr(), inverses.raw(), d_inv_off.raw(), (int)max_dim);
+    detail::launch_check();
   }
   void set_damping_factor(Graph<T, S> *, SchurComplement<T, S> *, T, const bool, StreamPool &) override {}
   void apply(Graph<T, S> *, SchurComplement<T, S> *, T *z, const T *r, StreamPool &) override {

@@ -926,13 +926,10 @@ public:
     d_schur.zero();
     if (d_copy_ops.size()) k_schur_copy<S><<<(unsigned)d_copy_ops.size(), 64>>>(d_copy_ops.raw(), d_copy_ops.size(), H.get_values_ptr(), d_schur.raw());
     if (d_inv_ops.size()) {
-      static const bool lds_ok = [] { // d = 16 needs 128 KB of dynamic LDS
-        GRAPHITE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_schur_invert<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_inverse_lds_bytes(16)));
-        return true;
-      }();
-      (void)lds_ok;
+      allow_block_inverse_lds(reinterpret_cast<const void *>(&k_schur_invert<S>));
       k_schur_invert<S><<<(unsigned)((d_inv_ops.size() + BLOCK_INV_THREADS - 1) / BLOCK_INV_THREADS), BLOCK_INV_THREADS, block_inverse_lds_bytes(max_landmark_dim)>>>(
           d_inv_ops.raw(), d_inv_ops.size(), H.get_values_ptr(), d_hll_inv.raw(), (int)max_landmark_dim);
+      launch_check();
     }
     if (num_chunks) {
       const SchurChunks ch{d_chunk_blk.raw(), d_chunk_first.raw(), d_mul_first.raw(), d_mul_partial.raw(), chunk_stride};

@@ -220,6 +220,22 @@ gr_status gr_bal_hessian_structure(gr_bal_problem *p, int64_t *nblocks, int64_t 
  * indices (nnz): int64 host arrays; values: nnz scalars of the problem's dtype (host).  Pass NULL arrays to get *nnz. */
 gr_status gr_bal_export_csc(gr_bal_problem *p, int which, int64_t *nnz, int64_t *indptr, int64_t *indices, void *values);
 
+/* What the direct solver of the reduced camera system set up (valid after gr_bal_solver_update_structure(GR_SOLVER_DENSE_SCHUR)):
+ * the counterpart of the analysis phase's report of cudssSchurSolver (solver/cudss_schur.hpp:146-170: CUDSS_PHASE_ANALYSIS) /
+ * SimplicialLDLT::analyzePattern (src/eigen_solver.cpp:10-19).  factor_bytes follows the structurally non-zero 128 x 128
+ * tiles of L (fill included) in the nested-dissection form; the padded dense triangle is only taken when S does not dissect. */
+typedef struct {
+  int32_t sparse;        /* 1: nested dissection + level-scheduled tile Cholesky on tile-sparse storage; 0: dense tile Cholesky */
+  int32_t tile_columns;  /* 128-column panels after padding                                                                   */
+  int32_t levels;        /* height of the tile elimination tree = length of the launch chain (dense: tile_columns)            */
+  int32_t supernodes;    /* nodes of the dissection tree (dense: 1)                                                           */
+  int64_t padded_n;      /* 128 * tile_columns                                                                                */
+  int64_t factor_tiles;  /* structurally non-zero lower tiles of L                                                            */
+  int64_t factor_bytes;  /* device memory of the factor and the per-panel inverses                                            */
+  int64_t dense_bytes;   /* padded_n^2 scalars: what a dense array would take                                                 */
+} gr_direct_solver_info;
+gr_status gr_bal_direct_solver_info(gr_bal_problem *p, gr_direct_solver_info *info);
+
 /* copy one array (gr_bal_array) to `out` (host or device); *count receives its length */
 gr_status gr_bal_get(gr_bal_problem *p, gr_bal_array which, void *out, int64_t *count);
 

@@ -104,14 +104,28 @@ def test_late_rank_beyond_the_wait_bound_is_an_error_not_a_wrong_sum(tmp_path):
     assert res[0]["t_first"] < 2.5 and res[0]["t_second"] < 0.5
 
 
+def test_bench_under_torchrun_two_ranks_share_the_gpu():
+    """The driver's own N > 1 command (python -m torch.distributed.run ... bench.py --gpus 2): the ranks it starts must not
+    start ranks of their own."""
+    env = dict(os.environ, GR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--repeats", "1", "--no-also"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
 def test_bench_two_ranks_share_the_gpu(tmp_path):
     """bench.py's N > 1 path (torch.distributed.run, one process per rank, landmark shards, barriers, max over ranks, the
     Venice `also` line) executed with two ranks on the one GPU of the box (GR_BENCH_SHARE_GPU=1: gloo process group, every
     all-reduce through the IPC mailboxes).  Guards the flow the driver launches on a multi-GPU node; not a measurement."""
     env = dict(os.environ, GR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "10",
-           "--warmup", "2", "--repeats", "2"]
+    env.pop("WORLD_SIZE", None)
+    # started PLAINLY, as the driver starts its N = 1 line: bench.py itself launches its ranks (torch.distributed.run as a child
+    # process, before anything touches the GPU) and returns their exit code
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--repeats", "2"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

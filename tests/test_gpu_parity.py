@@ -108,6 +108,36 @@ def test_solver_solve(oracle_mod, name, dtype, solver):
     gpu.close()
 
 
+@pytest.mark.parametrize("solver", ["pcg_schur", "pcg"])
+def test_fp32_step_is_as_close_to_fp64_as_the_fp32_oracle(oracle_mod, solver):
+    """The fp32 step pinned from both sides: two fp32 runs of one algorithm that sum in different orders
+    cannot agree better than either agrees with fp64 (block conditioning: Hll^-1 alone is 1e-3 from its fp64 value), so the
+    engine's fp32 step is held (a) to the FP64 oracle at 1e-3 and (b) to the fp32 ORACLE's own distance from fp64: at most
+    5 x that distance (measured 0.4-3.6 x: 8.7e-4 against the fp32 oracle's 2.4e-4 for pcg_schur; tools/fp32_dx_probe.py) — fp32 hand-written kernels that lost digits the plain
+    fp32 restatement keeps would fail (b) long before (a)."""
+    prob = synth.make_config("mini-50")
+    gs = dict(pcg_schur=ga.SOLVER_PCG_SCHUR, pcg=ga.SOLVER_PCG)[solver]
+    os_ = dict(pcg_schur=oracle_mod.SOLVER_PCG_SCHUR, pcg=oracle_mod.SOLVER_PCG)[solver]
+    gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float32)
+    gpu.solver_update_structure(gs)
+    gpu.linearize()
+    gpu.solver_update_values(gs)
+    gpu.solver_set_damping(gs, 1e-4)
+    dx_g, it_g = gpu.solver_solve(gs, max_iter=4, tol=0.0, rej=1e6)
+    dx = {}
+    for dt in (np.float32, np.float64):
+        ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dt)
+        ref.linearize()
+        ref.solver_update_values(os_)
+        ref.solver_set_damping(os_, 1e-4)
+        dx[dt], it_r = ref.solver_solve(os_, max_iter=4, tol=0.0, rej=1e6)
+        assert it_r == it_g
+    e_gpu, e_ref = relerr(dx_g, dx[np.float64]), relerr(dx[np.float32], dx[np.float64])
+    assert e_gpu < 1e-3, (e_gpu, e_ref)
+    assert e_gpu < 5.0 * e_ref + 1e-5, (e_gpu, e_ref)
+    gpu.close()
+
+
 def test_pcg_schur_matches_direct_solve(oracle_mod):
     """tests/schur.cu:340-389: PCG-Schur (512 it, tol 1e-14, rejection 1e6) vs the direct Schur
     LDLT solve, mu = 1e-4, |delta| < 5e-4 on the 2x3 fixture."""
