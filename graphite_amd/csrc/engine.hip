@@ -90,6 +90,7 @@ struct EngineBase {
   virtual void allreduce_host(double *v, size_t n) = 0;
   virtual void apply_tuning() = 0; // after `tune` changed
   gr_bal_tuning tune;
+  std::vector<double> lm_iter_seconds; // last lm(): host time from the start of the loop at which iteration i's decision was observed
   EngineBase() { tuning_default(tune); }
   int device = 0;
   char *ipc_box = nullptr; // mailbox allocated by gr_bal_comm_ipc_mailbox, owned by the IpcComm once it exists
@@ -1958,6 +1959,7 @@ template <typename T> struct Engine final : EngineBase {
     auto tl = clk::now();
 
     int ahead_hits = 0, ahead_misses = 0, head_hits = 0;
+    lm_iter_seconds.clear();
     // accept / reject bookkeeping of one trial step (levenberg_marquardt.hpp:184-233); false = leave the loop.
     // device: the decision k_finalize_bj took (and the kernels behind it follow): {new damping, accepted}
     auto decide = [&](int i, bool solve_ok, bool speculate, int it, const double *hs, const double *device) -> bool {
@@ -2000,6 +2002,7 @@ template <typename T> struct Engine final : EngineBase {
       }
       chi2v = new_chi2;
       st.iterations_run++;
+      lm_iter_seconds.push_back(std::chrono::duration<double>(clk::now() - tl).count());
       if (chi2_trace) chi2_trace[i + 1] = (double)chi2v;
       if (lambda_trace) lambda_trace[i + 1] = (double)mu;
       if (!std::isfinite(mu)) run = false;
@@ -2361,6 +2364,13 @@ gr_status gr_bal_levenberg_marquardt(gr_bal_problem *p, const gr_lm_options *opt
 }
 gr_status gr_bal_kernel_stats(gr_bal_problem *p, gr_kernel_stat *out, int cap, int *n) {
   return guarded(p, [&] { const int k = p->e->kernel_stats(out, cap); if (n) *n = k; });
+}
+gr_status gr_bal_lm_iteration_seconds(gr_bal_problem *p, double *seconds, int cap, int *n) {
+  return guarded(p, [&] {
+    const auto &v = p->e->lm_iter_seconds;
+    if (n) *n = (int)v.size();
+    for (int i = 0; seconds && i < cap && i < (int)v.size(); ++i) seconds[i] = v[i] - (i ? v[i - 1] : 0.0);
+  });
 }
 gr_status gr_bal_direct_solver_info(gr_bal_problem *p, gr_direct_solver_info *info) {
   if (!info) { g_last_error = "gr_bal_direct_solver_info: bad argument"; return GR_ERR_INVALID; }

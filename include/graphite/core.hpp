@@ -290,6 +290,24 @@ namespace detail {
 constexpr int TPB = 256;
 inline int blocks(size_t n) { return (int)((n + TPB - 1) / TPB); }
 inline void sync() { GRAPHITE_HIP(hipDeviceSynchronize()); }
+// order-sensitive 64-bit digest of a byte range (four independent multiply-add lanes over 8-byte words, then the tail):
+// EngineCache's guard against writes to a descriptor's public arrays that no API call announced
+inline uint64_t digest(uint64_t seed, const void *data, size_t bytes) {
+  const unsigned char *p = static_cast<const unsigned char *>(data);
+  uint64_t a = seed, b = seed ^ 0xC2B2AE3D27D4EB4Full, c = seed + 0x165667B19E3779F9ull, d = ~seed;
+  size_t i = 0;
+  for (; i + 32 <= bytes; i += 32) {
+    uint64_t w[4];
+    std::memcpy(w, p + i, 32);
+    a = a * 0x9E3779B97F4A7C15ull + w[0]; b = b * 0xC2B2AE3D27D4EB4Full + w[1];
+    c = c * 0x165667B19E3779F9ull + w[2]; d = d * 0x27D4EB2F165667C5ull + w[3];
+  }
+  uint64_t t = 0;
+  for (; i < bytes; ++i) t = t * 131 + p[i];
+  uint64_t h = a ^ (b << 1 | b >> 63) ^ (c << 7 | c >> 57) ^ (d << 13 | d >> 51) ^ (t * 0x9E3779B97F4A7C15ull) ^ (uint64_t)bytes;
+  h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+  return h;
+}
 
 // active.hpp:11-21
 hd_fn inline bool is_factor_active(uint8_t v, uint8_t level) { return (v & 0x7F) <= level && (v & 0x80) == 0; }
@@ -350,6 +368,8 @@ public:
   // bumped by every call that changes the vertex set, a vertex's address or its fixed flag: what a cached engine problem
   // (solve.hpp, EngineCache) is keyed on, next to the factor descriptor's epoch and content fingerprint
   size_t structure_epoch = 0;
+  // digest of the vertex addresses and state bytes (public arrays, writable without an API call)
+  virtual uint64_t content_fingerprint() const { return 0; }
 };
 
 namespace detail {
@@ -532,6 +552,11 @@ public:
   void restore_parameters() override {
     if (count()) detail::k_vertex_restore<Traits, StateType><<<detail::blocks(count()), detail::TPB>>>(vertices(), device_active_state(), count(), backup_ptr());
   }
+  uint64_t content_fingerprint() const override {
+    uint64_t h = detail::digest(0x51ED270B9F3C8A11ull ^ (uint64_t)count(), x_device.raw(), x_device.size() * sizeof(VertexType *));
+    h = detail::digest(h, active_state.raw(), active_state.size());
+    return detail::digest(h, local_to_global_map.data(), local_to_global_map.size() * sizeof(size_t));
+  }
   void gather_parameters(T *out) override {
     if (count()) detail::k_vertex_gather<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), count(), out);
   }
@@ -581,14 +606,28 @@ public:
   // [angle-axis, t, f, k1, k2], point 3, pixel residual of examples/reprojection_error.cuh) can hand its active
   // factors to the specialised BAL engine: local camera / point ids, 2 observation scalars per factor, loss.
   // false = not that model, or something the engine does not represent (precision matrices, mixed losses...).
+  // Only the ACTIVE factors are exported (active_indices, factor.hpp:419-465 / active.hpp:18-21): a deactivated outlier or a
+  // level mask is an index list at export, not a reason to leave the engine.
   virtual bool export_bal(std::vector<int32_t> &, std::vector<int32_t> &, std::vector<T> &, int &, double &) { return false; }
+  // bumped by every call that changes the factor set or a factor's level (add / remove / set_active / clear)
+  size_t structure_epoch = 0;
+  // 64-bit digest of everything an engine problem is built from and that is reachable WITHOUT such a call (the reference
+  // exposes these arrays as public members, tests/factor.cu:154,177,318,796): vertex ids, observations, activity bytes,
+  // precision matrices, losses.  One pass over pinned host memory, ~2 ms for 680 k factors.
+  virtual uint64_t content_fingerprint() const { return 0; }
   // The evidence for that hand-over (solve.hpp compares it with gr_bal_model_evaluate): for up to max_samples active factors,
   // evenly spread, the USER's functions evaluated on the device — Traits::parameters of both vertices (9 + 3), the
   // observation (2), Traits::error (2), the two Jacobian blocks (Traits::jacobian<T, I>, or dual numbers for Auto
   // factors; 18 + 6, E x d column-major) — and update_dev, the largest relative deviation of Traits::update from
   // plain addition on the parameters.  false: not a (9, 3) -> 2 factor with a two-component observation.
+  // Behind the sampled factors come SYNTHETIC triples that steer the user's functions into the branches a sample of a
+  // well-conditioned graph never visits (copies of a sampled factor's vertices moved there through the user's own update(),
+  // which the same probe verifies to be plain addition): rotation vector exactly 0 (the theta == 0 branch,
+  // projection_jacobians.cuh:175-212: identity rotation, ZERO rotation block), the point on the other side of the camera
+  // (P_z of the other sign), a large radial term (k1 r^2, k2 r^4 of order one), a quarter-turn rotation (theta > 0.5: closed
+  // forms instead of series).  *num_synthetic (optional) receives how many of the returned triples are synthetic.
   virtual bool probe_bal(size_t /*max_samples*/, std::vector<T> & /*cam*/, std::vector<T> & /*pt*/, std::vector<T> & /*obs*/, std::vector<T> & /*res*/,
-                         std::vector<T> & /*Jc*/, std::vector<T> & /*Jp*/, double & /*update_dev*/) { return false; }
+                         std::vector<T> & /*Jc*/, std::vector<T> & /*Jp*/, double & /*update_dev*/, size_t * /*num_synthetic*/ = nullptr) { return false; }
   virtual bool declares_bal_model() const { return false; } // the optional tag: a mismatch is then reported, not silent
 };
 
@@ -759,16 +798,11 @@ template <typename Tr, typename T> __device__ inline T probe_update_deviation(co
     return dev;
   } else return std::numeric_limits<T>::infinity();
 }
-template <typename F, size_t... Is>
-__global__ void k_probe_bal(FactorView<F> fv, size_t stride, size_t ns, typename F::Scalar *out, std::index_sequence<Is...> seq) {
+template <typename F, typename VT, size_t... Is>
+__device__ inline void probe_evaluate(const FactorView<F> &fv, size_t f, VT &v, typename F::Scalar *o, std::index_sequence<Is...> seq) {
   using T = typename F::Scalar;
-  const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (a >= ns) return;
-  const size_t f = fv.active_ids[a * stride];
-  auto v = gather_vertices<F, T>(fv, f, seq);
   std::tuple<T[slot_dim<F, Is>()]...> p;
   ((slot_traits<F, Is>::parameters(*std::get<Is>(v), (T *)std::get<Is>(p))), ...);
-  T *o = out + a * PROBE_W;
   for (int k = 0; k < 9; ++k) o[k] = std::get<0>(p)[k];
   for (int k = 0; k < 3; ++k) o[9 + k] = std::get<1>(p)[k];
   o[12] = (T)obs_component(fv.obs[f], 0, 0); o[13] = (T)obs_component(fv.obs[f], 1, 0);
@@ -794,6 +828,54 @@ __global__ void k_probe_bal(FactorView<F> fv, size_t stride, size_t ns, typename
   const T d0 = probe_update_deviation<slot_traits<F, 0>, T>(*std::get<0>(v), std::get<0>(p));
   const T d1 = probe_update_deviation<slot_traits<F, 1>, T>(*std::get<1>(v), std::get<1>(p));
   o[40] = d0 > d1 || d0 != d0 ? d0 : d1;
+}
+// variant 0: the factor as it is; 1: r = 0; 2: t_z -> t_z - 2 P_z' with P_z' ~ the camera-frame depth (the point lands on the
+// other side of the camera); 3: k1 = 5, k2 = 20 and the point pulled off the optical axis (radial terms of order one);
+// 4: r = (1.1, -0.7, 0.9) (theta = 1.6: closed forms).  Variants > 0 move COPIES of the vertices with the user's update().
+constexpr int PROBE_VARIANTS = 5;
+template <typename Tr, typename T> __device__ inline void probe_move(typename Tr::Vertex &vtx, const T *target) {
+  constexpr size_t d = Tr::dimension;
+  T p[d], delta[d];
+  Tr::parameters(vtx, p);
+  for (size_t k = 0; k < d; ++k) delta[k] = target[k] - p[k];
+  Tr::update(vtx, delta);
+}
+template <typename F, size_t... Is>
+__global__ void k_probe_bal(FactorView<F> fv, size_t stride, size_t ns, size_t nsyn, typename F::Scalar *out, std::index_sequence<Is...> seq) {
+  using T = typename F::Scalar;
+  using V0 = typename slot_traits<F, 0>::Vertex;
+  using V1 = typename slot_traits<F, 1>::Vertex;
+  const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (a >= ns + nsyn) return;
+  const int variant = a < ns ? 0 : 1 + (int)((a - ns) % (PROBE_VARIANTS - 1));
+  const size_t src = a < ns ? a : ((a - ns) / (PROBE_VARIANTS - 1)) % ns;
+  const size_t f = fv.active_ids[src * stride];
+  auto v = gather_vertices<F, T>(fv, f, seq);
+  T *o = out + a * PROBE_W;
+  if constexpr (std::is_copy_constructible<V0>::value && std::is_copy_constructible<V1>::value) {
+    V0 cam_copy(*std::get<0>(v));
+    V1 pt_copy(*std::get<1>(v));
+    if (variant > 0) {
+      T c[9], x[3];
+      slot_traits<F, 0>::parameters(cam_copy, c);
+      slot_traits<F, 1>::parameters(pt_copy, x);
+      if (variant == 1) { c[0] = c[1] = c[2] = T(0); }
+      else if (variant == 4) { c[0] = T(1.1); c[1] = T(-0.7); c[2] = T(0.9); }
+      else if (variant == 2) {
+        // depth along the optical axis with the small-angle rotation R ~ I + [r]x: enough to flip its sign
+        const T pz = x[2] + c[0] * x[1] - c[1] * x[0] + c[5];
+        c[5] -= T(2) * pz + (pz < T(0) ? T(-1) : T(1));
+      } else { c[7] = T(5); c[8] = T(20); x[0] += T(1.5); x[1] -= T(1.25); }
+      probe_move<slot_traits<F, 0>, T>(cam_copy, c);
+      probe_move<slot_traits<F, 1>, T>(pt_copy, x);
+      std::get<0>(v) = &cam_copy;
+      std::get<1>(v) = &pt_copy;
+    }
+    probe_evaluate<F>(fv, f, v, o, seq);
+  } else {
+    if (variant > 0) { for (size_t k = 0; k < PROBE_W; ++k) o[k] = T(0); o[40] = std::numeric_limits<T>::infinity(); return; }
+    probe_evaluate<F>(fv, f, v, o, seq);
+  }
 }
 
 // Jacobian block of slot I of factor f: the stored (already scaled) block, or with set_jacobian_storage(false)
@@ -1209,7 +1291,7 @@ public:
   // factor.hpp:373-412; precision_matrix == nullptr -> identity
   size_t add_factor(const std::array<size_t, N> &ids, const ObservationType &obs, const S *precision_matrix,
                     const ConstraintDataType &constraint_data, const LossType &loss_function) {
-    tables_mirrored = false;
+    tables_mirrored = false; ++this->structure_epoch;
     const size_t handle = hm.get(), id = internal_count(); // id: local index
     global_to_local_map.insert({handle, id});
     local_to_global_map.push_back(handle);
@@ -1224,7 +1306,7 @@ public:
   // local index of a factor handle; std::out_of_range for an unknown id, like the reference's .at() (factor.hpp:460)
   size_t local_id(size_t handle) const { return global_to_local_map.at(handle); }
   void remove_factor(size_t handle) { // swap with last, fix the id maps, release the handle (factor.hpp:308-371)
-    tables_mirrored = false;
+    tables_mirrored = false; ++this->structure_epoch;
     auto it = global_to_local_map.find(handle);
     if (it == global_to_local_map.end()) { std::cerr << "Factor with id " << handle << " not found." << std::endl; return; }
     const size_t id = it->second, last = internal_count() - 1;
@@ -1240,8 +1322,8 @@ public:
     host_ids.resize(last * N); device_ids.resize(last * N); device_obs.pop_back(); data.pop_back(); loss.pop_back(); active.pop_back();
     precision_matrices.resize(last * E * E); residuals.resize(E * last); chi2_vec.resize(last); chi2_derivative.resize(last); work.resize(E * last);
   }
-  void set_active(size_t handle, uint8_t active_value) { tables_mirrored = false; const size_t id = local_id(handle); active[id] = (active[id] & 0x80) | (active_value & 0x7F); } // factor.hpp:419-431
-  void reset_active() { for (size_t i = 0; i < active.size(); ++i) active[i] = 0; }
+  void set_active(size_t handle, uint8_t active_value) { tables_mirrored = false; ++this->structure_epoch; const size_t id = local_id(handle); active[id] = (active[id] & 0x80) | (active_value & 0x7F); } // factor.hpp:419-431
+  void reset_active() { ++this->structure_epoch; for (size_t i = 0; i < active.size(); ++i) active[i] = 0; }
   // factor.hpp:626-640: false = no stored Jacobians, every product recomputes the analytic blocks (Manual
   // differentiation only; an Auto factor keeps storing, ops/linearize.hpp:109)
   void set_jacobian_storage(bool on) { store_jacobians = on; }
@@ -1259,7 +1341,7 @@ public:
   const ObservationType &get_observation(size_t handle) const { return device_obs[local_id(handle)]; }
   const ConstraintDataType &get_constraint_data(size_t handle) const { return data[local_id(handle)]; }
   void clear() {
-    tables_mirrored = false;
+    tables_mirrored = false; ++this->structure_epoch;
     host_ids.clear(); device_ids.clear(); device_obs.clear(); data.clear(); loss.clear(); precision_matrices.clear(); active.clear();
     active_indices.clear(); residuals.clear(); chi2_vec.clear(); chi2_derivative.clear(); work.clear();
     global_to_local_map.clear(); local_to_global_map.clear(); hm.clear();
@@ -1413,26 +1495,37 @@ public:
     if constexpr (bal_shaped()) {
       constexpr bool plain = std::is_same<LossType, DefaultLoss<T, 2>>::value, huber = std::is_same<LossType, HuberLoss<T, 2>>::value;
       if constexpr (plain || huber) {
-        const size_t nf = internal_count();
-        if (!nf || active_count() != nf) return false; // the engine optimises every factor it is given
+        const size_t na = active_count();
+        if (!na) return false;
         detail::sync();
         loss_kind = huber ? 1 : 0; loss_delta = 0;
-        cam.resize(nf); pt.resize(nf); obs.resize(2 * nf);
-        for (size_t f = 0; f < nf; ++f) {
+        cam.resize(na); pt.resize(na); obs.resize(2 * na);
+        for (size_t a = 0; a < na; ++a) { // the ACTIVE factors, in active_indices order (factor.hpp:433-465)
+          const size_t f = active_indices[a];
           for (size_t i = 0; i < 2; ++i)
             for (size_t j = 0; j < 2; ++j)
               if (precision_matrices[f * 4 + i * 2 + j] != (i == j ? S(1) : S(0))) return false;
           if constexpr (huber) {
-            if (f == 0) loss_delta = (double)loss[0].delta;
+            if (a == 0) loss_delta = (double)loss[f].delta;
             else if ((double)loss[f].delta != loss_delta) return false;
           }
-          cam[f] = (int32_t)device_ids[2 * f]; pt[f] = (int32_t)device_ids[2 * f + 1];
-          obs[2 * f] = (T)detail::obs_component(device_obs[f], 0, 0); obs[2 * f + 1] = (T)detail::obs_component(device_obs[f], 1, 0);
+          cam[a] = (int32_t)device_ids[2 * f]; pt[a] = (int32_t)device_ids[2 * f + 1];
+          obs[2 * a] = (T)detail::obs_component(device_obs[f], 0, 0); obs[2 * a + 1] = (T)detail::obs_component(device_obs[f], 1, 0);
         }
         return true;
       }
     }
     return false;
+  }
+  uint64_t content_fingerprint() const override {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)internal_count();
+    h = detail::digest(h, host_ids.data(), host_ids.size() * sizeof(size_t));
+    if constexpr (std::is_trivially_copyable<ObservationType>::value) h = detail::digest(h, device_obs.raw(), device_obs.size() * sizeof(ObservationType));
+    h = detail::digest(h, active.raw(), active.size());
+    h = detail::digest(h, precision_matrices.raw(), precision_matrices.size() * sizeof(S));
+    if constexpr (std::is_trivially_copyable<LossType>::value && !std::is_empty<LossType>::value && !std::is_polymorphic<LossType>::value)
+      h = detail::digest(h, loss.raw(), loss.size() * sizeof(LossType));
+    return h;
   }
 
   // what the engine can represent at all: two slots of dimension 9 and 3, a two-component residual and observation, no
@@ -1443,18 +1536,22 @@ public:
     else return false;
   }
   bool declares_bal_model() const override { return detail::has_bal_tag<Traits>::value; }
-  bool probe_bal(size_t max_samples, std::vector<T> &cam, std::vector<T> &pt, std::vector<T> &obs, std::vector<T> &res, std::vector<T> &Jc, std::vector<T> &Jp, double &update_dev) override {
+  bool probe_bal(size_t max_samples, std::vector<T> &cam, std::vector<T> &pt, std::vector<T> &obs, std::vector<T> &res, std::vector<T> &Jc, std::vector<T> &Jp, double &update_dev,
+                 size_t *num_synthetic = nullptr) override {
     if constexpr (bal_shaped()) {
       const size_t na = active_count();
       if (!na || !max_samples) return false;
       const size_t ns = std::min(na, max_samples), stride = na / ns;
-      hbm_vector<T> out(ns * detail::PROBE_W);
-      detail::k_probe_bal<FactorDescriptor><<<detail::blocks(ns), detail::TPB>>>(view(), stride, ns, out.raw(), std::make_index_sequence<N>{});
+      const size_t nsyn = (detail::PROBE_VARIANTS - 1) * std::min<size_t>(ns, 8); // every branch-steering variant on up to 8 of the sampled factors
+      const size_t nt = ns + nsyn;
+      if (num_synthetic) *num_synthetic = nsyn;
+      hbm_vector<T> out(nt * detail::PROBE_W);
+      detail::k_probe_bal<FactorDescriptor><<<detail::blocks(nt), detail::TPB>>>(view(), stride, ns, nsyn, out.raw(), std::make_index_sequence<N>{});
       detail::sync();
       const std::vector<T> h = out.to_host();
-      cam.resize(9 * ns); pt.resize(3 * ns); obs.resize(2 * ns); res.resize(2 * ns); Jc.resize(18 * ns); Jp.resize(6 * ns);
+      cam.resize(9 * nt); pt.resize(3 * nt); obs.resize(2 * nt); res.resize(2 * nt); Jc.resize(18 * nt); Jp.resize(6 * nt);
       update_dev = 0;
-      for (size_t a = 0; a < ns; ++a) {
+      for (size_t a = 0; a < nt; ++a) {
         const T *o = h.data() + a * detail::PROBE_W;
         std::copy(o, o + 9, cam.begin() + 9 * a); std::copy(o + 9, o + 12, pt.begin() + 3 * a); std::copy(o + 12, o + 14, obs.begin() + 2 * a);
         std::copy(o + 14, o + 16, res.begin() + 2 * a); std::copy(o + 16, o + 34, Jc.begin() + 18 * a); std::copy(o + 34, o + 40, Jp.begin() + 6 * a);
@@ -1462,7 +1559,7 @@ public:
         if (!(d <= update_dev)) update_dev = d; // NaN sticks
       }
       return true;
-    } else { (void)max_samples; (void)cam; (void)pt; (void)obs; (void)res; (void)Jc; (void)Jp; (void)update_dev; return false; }
+    } else { (void)max_samples; (void)cam; (void)pt; (void)obs; (void)res; (void)Jc; (void)Jp; (void)update_dev; (void)num_synthetic; return false; }
   }
 
 private:
@@ -1592,11 +1689,19 @@ public:
   size_t get_pose_dimension() const { return pose_dim; }
   hbm_vector<T> &get_b() { return b; }
   hbm_vector<T> &get_jacobian_scales() { return jacobian_scales; }
-  void clear() { vertex_descriptors.clear(); factor_descriptors.clear(); }
+  void clear() { vertex_descriptors.clear(); factor_descriptors.clear(); engine_cache.reset(); }
+  // The engine problem (gr_bal_problem + staging buffers) that optimizer::levenberg_marquardt built for this graph, kept
+  // between optimiser calls (solve.hpp, EngineCache; type-erased here, destroyed with the graph or by clear()): the SLAM-style
+  // caller that optimises a slowly changing graph again and again (README.md:27) pays orderings, allocations and uploads
+  // once per STRUCTURE, not once per call.
+  std::shared_ptr<void> engine_cache;
+  uint8_t last_init_level = 0;
+  bool last_init_light = false;
 
   // graph.hpp:92-167: active factors, which vertices they use, then one scalar column range per
   // active vertex, descriptors in the order they were added, vertices by ascending global id
   bool initialize_optimization(uint8_t level = 0, bool light = false) {
+    last_init_level = level; last_init_light = light;
     for (auto *vd : vertex_descriptors)
       if (vd->count()) detail::k_clear_msb<T><<<detail::blocks(vd->count()), detail::TPB>>>(vd->get_active_state(), vd->count());
     for (auto *fd : factor_descriptors) fd->initialize(level, light);

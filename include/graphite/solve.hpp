@@ -557,6 +557,32 @@ namespace detail {
 // counterpart, GRAPHITE_GENERIC_ONLY=1): the caller then runs the generic loop.
 // number of optimiser calls of this process that ran on the gr_bal engine (tests assert which path ran)
 inline size_t &engine_handovers() { static size_t n = 0; return n; }
+// ... and how many of them found their engine problem already built (EngineCache hit: parameters uploaded, nothing else)
+inline size_t &engine_cache_hits() { static size_t n = 0; return n; }
+// host seconds the last hand-over spent outside gr_bal_levenberg_marquardt (checks, export, probe, create / cache look-up,
+// parameter transfer both ways, residual refresh)
+inline double &engine_last_setup_seconds() { static double s = 0; return s; }
+
+// The engine problem of one graph, kept on the Graph between optimiser calls (Graph::engine_cache).  Valid while the three
+// descriptors are the same objects, none of their structure epochs moved (add / remove / replace / set_fixed / set_active
+// / set_eliminate / clear all bump one), the optimisation level is the same and the digests of their public arrays (vertex
+// addresses and state bytes; factor ids, observations, activity, precision matrices, losses) are unchanged.
+template <typename T> struct EngineCache {
+  gr_bal_problem *prob = nullptr;
+  const void *cd = nullptr, *pd = nullptr, *fd = nullptr;
+  size_t epoch_c = 0, epoch_p = 0, epoch_f = 0;
+  uint64_t digest_c = 0, digest_p = 0, digest_f = 0;
+  uint8_t level = 0;
+  int device = 0;
+  size_t n_factors = 0;
+  // vertices no active factor touches are not part of the engine problem: used[k] = local vertex id of engine vertex k
+  // (empty = every vertex is used, identity)
+  std::vector<uint32_t> cam_used, pt_used;
+  managed_vector<T> cams, pts;      // all vertices of the descriptors, local order (gather / scatter staging)
+  std::vector<T> ecams, epts;       // the engine's subset when it is not the identity
+  ~EngineCache() { if (prob) gr_bal_destroy(prob); }
+};
+
 template <typename T, typename S>
 bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, bool early_stop, bool &result) {
   if (getenv("GRAPHITE_GENERIC_ONLY") && atoi(getenv("GRAPHITE_GENERIC_ONLY")) != 0) return false;
@@ -569,94 +595,163 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   if (!((vds[0] == cd && vds[1] == pd) || (vds[0] == pd && vds[1] == cd))) return false;
   const int kind = options->solver->engine_kind(cd->count());
   if (kind < 0) return false;
+  using clk = std::chrono::steady_clock;
   const bool timing = getenv("GR_VERBOSE") != nullptr;
-  const auto tt0 = std::chrono::steady_clock::now();
+  const auto tt0 = clk::now();
   auto lap = [&, last = tt0](const char *what) mutable {
     if (!timing) return;
     graphite::detail::sync();
-    const auto now = std::chrono::steady_clock::now();
+    const auto now = clk::now();
     std::cerr << "[graphite] hand-over: " << what << " " << std::chrono::duration<double, std::milli>(now - last).count() << " ms" << std::endl;
     last = now;
   };
-  // light: local ids, active list, vertex states and Hessian columns — what the checks, the probe and the export below read;
-  // the Jacobian storage and gather lists of the generic kernels are only built when the graph stays with them (lm_loop)
-  if (!graph->initialize_optimization(options->optimization_level, /*light=*/true)) return false;
-  lap("initialize_optimization (light)");
-  // fixed vertices (bit 0) go to the engine as masks (gr_bal_set_fixed); a vertex no active factor touches (bit 7) is not
-  // an engine graph
-  std::vector<unsigned char> cam_fixed(cd->count(), 0), pt_fixed(pd->count(), 0);
-  bool any_fixed = false;
-  for (auto *vd : {cd, pd}) {
-    const uint8_t *st = vd->get_active_state();
-    std::vector<unsigned char> &mask = vd == cd ? cam_fixed : pt_fixed;
-    for (size_t v = 0; v < vd->count(); ++v) {
-      if (st[v] & ~uint8_t(0x1)) return false;
-      if (st[v] & 0x1) { mask[v] = 1; any_fixed = true; }
-    }
-  }
-  std::vector<int32_t> ci, pi;
-  std::vector<T> obs;
-  int loss_kind = 0; double loss_delta = 0;
-  if (!fds[0]->export_bal(ci, pi, obs, loss_kind, loss_delta)) return false;
-  lap("fixed masks + export_bal");
   int dev = 0;
   GRAPHITE_HIP(hipGetDevice(&dev));
   const gr_dtype dt = sizeof(T) == 8 ? GR_F64 : GR_F32;
-  // VERIFIED hand-over: the engine is specialised for one function (gr_bal_model_evaluate).  The user's own
-  // parameters() / error() / jacobian() (or dual-number Jacobian) / update() are evaluated on up to 256 of the graph's
-  // factors and must reproduce it — 1e-10 (fp64) / 1e-4 (fp32) of the block's magnitude; update() must be plain
-  // addition.  No tag is needed; a factor that carries the bal_reprojection_model tag but computes something else is
-  // reported and stays on the generic kernels.
-  {
-    std::vector<T> pc, pp, po, ur, uJc, uJp;
-    double update_dev = 0;
-    if (!fds[0]->probe_bal(256, pc, pp, po, ur, uJc, uJp, update_dev)) return false;
-    const size_t ns = pc.size() / 9;
-    std::vector<T> er(2 * ns), eJc(18 * ns), eJp(6 * ns);
-    if (gr_bal_model_evaluate(dt, (int64_t)ns, pc.data(), pp.data(), po.data(), er.data(), eJc.data(), eJp.data(), dev, nullptr) != GR_OK) {
-      std::cerr << "graphite: engine hand-over: gr_bal_model_evaluate failed: " << gr_last_error_string() << "; using the generic kernels" << std::endl;
-      return false;
-    }
-    const double tol = sizeof(T) == 8 ? 1e-10 : 1e-4;
-    double worst = 0;
-    auto block_dev = [&](const T *u, const T *e, size_t len, double floor_mag) {
-      double mag = floor_mag, d = 0;
-      for (size_t k = 0; k < len; ++k) mag = std::max(mag, std::abs((double)e[k]));
-      for (size_t k = 0; k < len; ++k) { const double x = std::abs((double)u[k] - (double)e[k]); d = (x > d || x != x) ? x : d; }
-      return d / mag;
-    };
-    for (size_t a = 0; a < ns; ++a) {
-      const double omag = std::max({1.0, std::abs((double)po[2 * a]), std::abs((double)po[2 * a + 1])});
-      for (double d : {block_dev(&ur[2 * a], &er[2 * a], 2, omag), block_dev(&uJc[18 * a], &eJc[18 * a], 18, 1e-300), block_dev(&uJp[6 * a], &eJp[6 * a], 6, 1e-300)})
-        worst = (d > worst || d != d) ? d : worst;
-    }
-    const bool model_ok = worst <= tol, update_ok = update_dev <= (sizeof(T) == 8 ? 1e-14 : 1e-6);
-    if (getenv("GR_VERBOSE"))
-      std::cerr << "[graphite] engine hand-over probe: " << ns << " factors, max deviation of error()/jacobian() from the engine's model "
-                << worst << " (bar " << tol << "), of update() from addition " << update_dev << std::endl;
-    if (!model_ok || !update_ok) {
-      if (fds[0]->declares_bal_model())
-        std::cerr << "graphite: the factor traits declare bal_reprojection_model, but " << (model_ok ? "update()" : "error()/jacobian()")
-                  << " differ from the engine's model (relative deviation " << (model_ok ? update_dev : worst) << "); using the generic kernels" << std::endl;
-      return false;
-    }
-  }
 
-  lap("probe");
-  using clk = std::chrono::steady_clock;
-  const auto t0 = clk::now();
-  managed_vector<T> cams(9 * cd->count()), pts(3 * pd->count());
-  cd->gather_parameters(cams.raw()); pd->gather_parameters(pts.raw());
-  graphite::detail::sync();
-  lap("gather_parameters");
-  gr_bal_problem *prob = nullptr;
-  auto fail = [&](const char *what) { std::cerr << "graphite: engine hand-over failed in " << what << ": " << gr_last_error_string() << "; using the generic kernels" << std::endl; if (prob) gr_bal_destroy(prob); return false; };
-  if (gr_bal_create(&prob, dt, (int64_t)cd->count(), (int64_t)pd->count(), (int64_t)ci.size(), cams.raw(), pts.raw(), obs.data(), ci.data(), pi.data(), dev, nullptr) != GR_OK) return fail("gr_bal_create");
-  if (gr_bal_set_loss(prob, loss_kind ? GR_LOSS_HUBER : GR_LOSS_DEFAULT, loss_delta) != GR_OK) return fail("gr_bal_set_loss");
-  if (any_fixed && gr_bal_set_fixed(prob, cam_fixed.data(), pt_fixed.data()) != GR_OK) return fail("gr_bal_set_fixed");
+  // ---- the cached engine problem of this graph, if the graph is still the one it was built from -----------------------
+  using Cache = EngineCache<T>;
+  std::shared_ptr<Cache> cache = std::static_pointer_cast<Cache>(graph->engine_cache);
+  const uint64_t dg_c = cd->content_fingerprint(), dg_p = pd->content_fingerprint(), dg_f = fds[0]->content_fingerprint();
+  bool hit = cache && cache->prob && cache->cd == cd && cache->pd == pd && cache->fd == fds[0] && cache->epoch_c == cd->structure_epoch &&
+             cache->epoch_p == pd->structure_epoch && cache->epoch_f == fds[0]->structure_epoch && cache->level == options->optimization_level &&
+             cache->device == dev && cache->digest_c == dg_c && cache->digest_p == dg_p && cache->digest_f == dg_f &&
+             graph->last_init_level == options->optimization_level;
+  lap(hit ? "cache look-up (epochs + digests): HIT" : "cache look-up (epochs + digests): miss");
+  auto fail = [&](const char *what) {
+    std::cerr << "graphite: engine hand-over failed in " << what << ": " << gr_last_error_string() << "; using the generic kernels" << std::endl;
+    graph->engine_cache.reset();
+    return false;
+  };
+  if (!hit) {
+    graph->engine_cache.reset();
+    cache.reset();
+    // light: local ids, active list, vertex states and Hessian columns — what the checks, the probe and the export below read;
+    // the Jacobian storage and gather lists of the generic kernels are only built when the graph stays with them (lm_loop)
+    if (!graph->initialize_optimization(options->optimization_level, /*light=*/true)) return false;
+    lap("initialize_optimization (light)");
+    // fixed vertices (bit 0) go to the engine as masks (gr_bal_set_fixed); a vertex no active factor touches (bit 7: outlier
+    // rejection or a level mask took its factors away, active.hpp:18-21) is simply not part of the engine problem
+    auto fresh = std::make_shared<Cache>();
+    std::vector<unsigned char> cam_fixed, pt_fixed;
+    bool any_fixed = false;
+    std::vector<int32_t> cam_new(cd->count(), -1), pt_new(pd->count(), -1);
+    for (auto *vd : {cd, pd}) {
+      const uint8_t *st = vd->get_active_state();
+      std::vector<unsigned char> &mask = vd == cd ? cam_fixed : pt_fixed;
+      std::vector<uint32_t> &used = vd == cd ? fresh->cam_used : fresh->pt_used;
+      std::vector<int32_t> &renum = vd == cd ? cam_new : pt_new;
+      for (size_t v = 0; v < vd->count(); ++v) {
+        if (st[v] & ~uint8_t(0x81)) return false; // a state this layer does not know
+        if (st[v] & 0x80) continue;
+        renum[v] = (int32_t)used.size();
+        used.push_back((uint32_t)v);
+        mask.push_back(st[v] & 0x1);
+        any_fixed = any_fixed || (st[v] & 0x1);
+      }
+      if (used.empty()) return false;
+      if (used.size() == vd->count()) used.clear(); // identity
+    }
+    std::vector<int32_t> ci, pi;
+    std::vector<T> obs;
+    int loss_kind = 0; double loss_delta = 0;
+    if (!fds[0]->export_bal(ci, pi, obs, loss_kind, loss_delta)) return false; // the ACTIVE factors
+    if (!fresh->cam_used.empty() || !fresh->pt_used.empty())
+      for (size_t f = 0; f < ci.size(); ++f) { ci[f] = cam_new[ci[f]]; pi[f] = pt_new[pi[f]]; }
+    lap("fixed masks + export_bal");
+    // VERIFIED hand-over: the engine is specialised for one function (gr_bal_model_evaluate).  The user's own
+    // parameters() / error() / jacobian() (or dual-number Jacobian) / update() are evaluated on up to 256 of the graph's
+    // factors AND on synthetic triples that reach the branches a sample does not (theta == 0, the point behind / in front of
+    // the camera, a large radial term, a large rotation) and must reproduce it — 1e-10 (fp64) / 1e-4 (fp32) of the block's
+    // magnitude; update() must be plain addition.  No tag is needed; a factor that carries the bal_reprojection_model tag
+    // but computes something else is reported and stays on the generic kernels.  Verified once per cached problem: the
+    // functions are properties of the traits TYPE.
+    {
+      std::vector<T> pc, pp, po, ur, uJc, uJp;
+      double update_dev = 0;
+      size_t nsyn = 0;
+      if (!fds[0]->probe_bal(256, pc, pp, po, ur, uJc, uJp, update_dev, &nsyn)) return false;
+      const size_t ns = pc.size() / 9;
+      std::vector<T> er(2 * ns), eJc(18 * ns), eJp(6 * ns);
+      if (gr_bal_model_evaluate(dt, (int64_t)ns, pc.data(), pp.data(), po.data(), er.data(), eJc.data(), eJp.data(), dev, nullptr) != GR_OK) {
+        std::cerr << "graphite: engine hand-over: gr_bal_model_evaluate failed: " << gr_last_error_string() << "; using the generic kernels" << std::endl;
+        return false;
+      }
+      const double tol = sizeof(T) == 8 ? 1e-10 : 1e-4;
+      double worst = 0, worst_syn = 0;
+      auto block_dev = [&](const T *u, const T *e, size_t len, double floor_mag) {
+        double mag = floor_mag, d = 0;
+        for (size_t k = 0; k < len; ++k) mag = std::max(mag, std::abs((double)e[k]));
+        for (size_t k = 0; k < len; ++k) { const double x = std::abs((double)u[k] - (double)e[k]); d = (x > d || x != x) ? x : d; }
+        return d / mag;
+      };
+      for (size_t a = 0; a < ns; ++a) {
+        const double omag = std::max({1.0, std::abs((double)po[2 * a]), std::abs((double)po[2 * a + 1])});
+        double &w = a + nsyn < ns ? worst : worst_syn;
+        for (double d : {block_dev(&ur[2 * a], &er[2 * a], 2, omag), block_dev(&uJc[18 * a], &eJc[18 * a], 18, 1e-300), block_dev(&uJp[6 * a], &eJp[6 * a], 6, 1e-300)})
+          w = (d > w || d != d) ? d : w;
+      }
+      const bool model_ok = worst <= tol && worst_syn <= tol, update_ok = update_dev <= (sizeof(T) == 8 ? 1e-14 : 1e-6);
+      if (getenv("GR_VERBOSE"))
+        std::cerr << "[graphite] engine hand-over probe: " << ns - nsyn << " factors + " << nsyn << " synthetic branch triples, max deviation of error()/jacobian() from the engine's model "
+                  << worst << " / " << worst_syn << " (bar " << tol << "), of update() from addition " << update_dev << std::endl;
+      if (!model_ok || !update_ok) {
+        if (fds[0]->declares_bal_model())
+          std::cerr << "graphite: the factor traits declare bal_reprojection_model, but " << (model_ok ? "update()" : "error()/jacobian()")
+                    << " differ from the engine's model (relative deviation " << (model_ok ? update_dev : std::max(worst, worst_syn))
+                    << (worst <= tol && !(worst_syn <= tol) ? ", on the synthetic branch triples only" : "") << "); using the generic kernels" << std::endl;
+        return false;
+      }
+    }
+    lap("probe");
+    fresh->cams.resize(9 * cd->count()); fresh->pts.resize(3 * pd->count());
+    cd->gather_parameters(fresh->cams.raw()); pd->gather_parameters(fresh->pts.raw());
+    graphite::detail::sync();
+    const size_t nc = fresh->cam_used.empty() ? cd->count() : fresh->cam_used.size(), np = fresh->pt_used.empty() ? pd->count() : fresh->pt_used.size();
+    const T *c_src = fresh->cams.raw(), *p_src = fresh->pts.raw();
+    if (!fresh->cam_used.empty()) {
+      fresh->ecams.resize(9 * nc);
+      for (size_t k = 0; k < nc; ++k) std::copy(c_src + 9 * (size_t)fresh->cam_used[k], c_src + 9 * (size_t)fresh->cam_used[k] + 9, fresh->ecams.begin() + 9 * k);
+      c_src = fresh->ecams.data();
+    }
+    if (!fresh->pt_used.empty()) {
+      fresh->epts.resize(3 * np);
+      for (size_t k = 0; k < np; ++k) std::copy(p_src + 3 * (size_t)fresh->pt_used[k], p_src + 3 * (size_t)fresh->pt_used[k] + 3, fresh->epts.begin() + 3 * k);
+      p_src = fresh->epts.data();
+    }
+    lap("gather_parameters");
+    auto bad = [&](const char *what) { std::cerr << "graphite: engine hand-over failed in " << what << ": " << gr_last_error_string() << "; using the generic kernels" << std::endl; return false; };
+    if (gr_bal_create(&fresh->prob, dt, (int64_t)nc, (int64_t)np, (int64_t)ci.size(), c_src, p_src, obs.data(), ci.data(), pi.data(), dev, nullptr) != GR_OK) return bad("gr_bal_create");
+    if (gr_bal_set_loss(fresh->prob, loss_kind ? GR_LOSS_HUBER : GR_LOSS_DEFAULT, loss_delta) != GR_OK) return bad("gr_bal_set_loss");
+    if (any_fixed && gr_bal_set_fixed(fresh->prob, cam_fixed.data(), pt_fixed.data()) != GR_OK) return bad("gr_bal_set_fixed");
+    fresh->cd = cd; fresh->pd = pd; fresh->fd = fds[0];
+    fresh->epoch_c = cd->structure_epoch; fresh->epoch_p = pd->structure_epoch; fresh->epoch_f = fds[0]->structure_epoch;
+    // initialize_optimization rewrote the bit-7 state bytes: the digests are taken of what the NEXT call will see
+    fresh->digest_c = cd->content_fingerprint(); fresh->digest_p = pd->content_fingerprint(); fresh->digest_f = fds[0]->content_fingerprint();
+    fresh->level = options->optimization_level; fresh->device = dev; fresh->n_factors = ci.size();
+    cache = fresh;
+    graph->engine_cache = cache;
+    lap("gr_bal_create + settings");
+  } else {
+    // unchanged structure: only the vertex VALUES travel
+    cd->gather_parameters(cache->cams.raw()); pd->gather_parameters(cache->pts.raw());
+    graphite::detail::sync();
+    const T *c_src = cache->cams.raw(), *p_src = cache->pts.raw();
+    if (!cache->cam_used.empty()) {
+      for (size_t k = 0; k < cache->cam_used.size(); ++k) std::copy(c_src + 9 * (size_t)cache->cam_used[k], c_src + 9 * (size_t)cache->cam_used[k] + 9, cache->ecams.begin() + 9 * k);
+      c_src = cache->ecams.data();
+    }
+    if (!cache->pt_used.empty()) {
+      for (size_t k = 0; k < cache->pt_used.size(); ++k) std::copy(p_src + 3 * (size_t)cache->pt_used[k], p_src + 3 * (size_t)cache->pt_used[k] + 3, cache->epts.begin() + 3 * k);
+      p_src = cache->epts.data();
+    }
+    if (gr_bal_set_params(cache->prob, c_src, p_src) != GR_OK) return fail("gr_bal_set_params");
+    ++engine_cache_hits();
+    lap("gather_parameters + gr_bal_set_params");
+  }
+  gr_bal_problem *prob = cache->prob;
   if (gr_bal_set_scale_system(prob, graph->scales_system() ? 1 : 0) != GR_OK) return fail("gr_bal_set_scale_system");
-  if (!std::is_same<T, S>::value && gr_bal_set_jacobian_precision(prob, GR_F32) != GR_OK) return fail("gr_bal_set_jacobian_precision");
-  lap("gr_bal_create + settings");
+  if (gr_bal_set_jacobian_precision(prob, std::is_same<T, S>::value ? dt : GR_F32) != GR_OK) return fail("gr_bal_set_jacobian_precision");
   gr_lm_options o{};
   o.solver = kind; o.iterations = (int32_t)options->iterations; o.initial_damping = options->initial_damping;
   o.use_identity = options->use_identity ? 1 : 0; o.early_stop = early_stop ? 1 : 0;
@@ -666,29 +761,43 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   o.pcg_max_iter = m; o.pcg_tol = tl; o.pcg_rejection_ratio = rj;
   gr_lm_stats st{};
   std::vector<double> chi2(options->iterations + 1), lambda(options->iterations + 1);
-  if (getenv("GR_VERBOSE")) std::cerr << "[graphite] bundle-adjustment graph (" << cd->count() << " cameras, " << pd->count() << " points, " << ci.size()
-                                      << " factors) handed to the gr_bal engine, gr_solver " << kind << std::endl;
+  if (getenv("GR_VERBOSE")) std::cerr << "[graphite] bundle-adjustment graph (" << cd->count() << " cameras, " << pd->count() << " points, " << cache->n_factors
+                                      << " active factors) handed to the gr_bal engine, gr_solver " << kind << (hit ? " (cached problem)" : "") << std::endl;
+  const auto t_lm0 = clk::now();
   if (gr_bal_levenberg_marquardt(prob, &o, &st, chi2.data(), lambda.data()) != GR_OK) return fail("gr_bal_levenberg_marquardt");
+  const double lm_seconds = std::chrono::duration<double>(clk::now() - t_lm0).count();
   ++engine_handovers();
   lap("gr_bal_levenberg_marquardt");
-  if (gr_bal_get_params(prob, cams.raw(), pts.raw()) != GR_OK) return fail("gr_bal_get_params");
-  cd->scatter_parameters(cams.raw()); pd->scatter_parameters(pts.raw());
+  {
+    T *c_dst = cache->cam_used.empty() ? cache->cams.raw() : cache->ecams.data(), *p_dst = cache->pt_used.empty() ? cache->pts.raw() : cache->epts.data();
+    if (gr_bal_get_params(prob, c_dst, p_dst) != GR_OK) return fail("gr_bal_get_params");
+    // vertices outside the engine problem keep the values gathered above
+    for (size_t k = 0; k < cache->cam_used.size(); ++k) std::copy(cache->ecams.begin() + 9 * k, cache->ecams.begin() + 9 * k + 9, cache->cams.raw() + 9 * (size_t)cache->cam_used[k]);
+    for (size_t k = 0; k < cache->pt_used.size(); ++k) std::copy(cache->epts.begin() + 3 * k, cache->epts.begin() + 3 * k + 3, cache->pts.raw() + 3 * (size_t)cache->pt_used[k]);
+  }
+  cd->scatter_parameters(cache->cams.raw()); pd->scatter_parameters(cache->pts.raw());
   lap("get_params + scatter_parameters");
   graph->compute_error(); // leave the residuals of the optimised vertices behind, as the generic loop does (graph->chi2() is valid)
   graphite::detail::sync();
   lap("compute_error");
-  gr_bal_destroy(prob);
-  lap("gr_bal_destroy");
+  const double total = std::chrono::duration<double>(clk::now() - tt0).count();
+  engine_last_setup_seconds() = total - lm_seconds;
   if (options->verbose) {
-    const double total = std::chrono::duration<double>(clk::now() - t0).count();
-    const double per_it = st.iterations_run ? st.loop_seconds / st.iterations_run : 0.0, setup = total - st.loop_seconds;
+    // the reference's table (levenberg_marquardt.hpp:216-221): every row carries ITS iteration's time; what the hand-over
+    // cost before the loop is in the first row's total, as the reference's set-up is
+    std::vector<double> it_s(std::max(1, st.iterations_run), 0.0);
+    int nit = 0;
+    (void)gr_bal_lm_iteration_seconds(prob, it_s.data(), (int)it_s.size(), &nit);
+    double run = total - st.loop_seconds;
     const int prec = early_stop ? 4 : 12, w0 = early_stop ? 10 : 18, w = early_stop ? 16 : 24;
     std::cout << std::setprecision(12) << std::setw(18) << "Iteration" << std::setw(24) << "Initial Chi2" << std::setw(24)
               << "Current Chi2" << std::setw(24) << "Lambda" << std::setw(24) << "Time" << std::setw(24) << "Total Time" << std::endl;
     std::cout << std::string(138, '-') << std::endl;
-    for (int i = 0; i < st.iterations_run; ++i)
+    for (int i = 0; i < st.iterations_run; ++i) {
+      run += it_s[i];
       std::cout << std::setprecision(prec) << std::setw(w0) << i << std::setw(w) << chi2[i] << std::setw(w) << chi2[i + 1] << std::setw(w)
-                << lambda[i + 1] << std::setw(w) << per_it << std::setw(w) << setup + per_it * (i + 1) << std::endl;
+                << lambda[i + 1] << std::setw(w) << it_s[i] << std::setw(w) << run << std::endl;
+    }
   }
   result = st.ok != 0;
   return true;
@@ -770,6 +879,10 @@ template <bool EARLY, typename T, typename S> bool lm_loop(Graph<T, S> *graph, L
 } // namespace detail
 // optimiser calls of this process that ran on the hand-written gr_bal engine (the others ran on the generic kernels)
 inline size_t engine_handover_count() { return detail::engine_handovers(); }
+// ... of which: calls that found the graph's engine problem cached (structure unchanged since the previous call)
+inline size_t engine_cache_hit_count() { return detail::engine_cache_hits(); }
+// host seconds the last hand-over spent around gr_bal_levenberg_marquardt (checks, export, probe, create or cache look-up, transfers)
+inline double engine_last_setup_seconds() { return detail::engine_last_setup_seconds(); }
 template <typename T, typename S> bool levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {
   return detail::lm_loop<false>(graph, options);
 }

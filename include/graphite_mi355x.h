@@ -244,6 +244,12 @@ gr_status gr_bal_get(gr_bal_problem *p, gr_bal_array which, void *out, int64_t *
 gr_status gr_bal_levenberg_marquardt(gr_bal_problem *p, const gr_lm_options *options,
                                      gr_lm_stats *stats, double *chi2_trace, double *lambda_trace);
 
+/* Per-iteration wall time of the LAST gr_bal_levenberg_marquardt call: seconds[i] = host time between observing the
+ * decisions of iterations i - 1 and i (the first from the start of the loop) — the "Time" column of the reference's
+ * verbose table (optimizer/levenberg_marquardt.hpp:216-221).  In the fused form the host only observes decisions the
+ * device has taken, so these are completion times, not enqueue times.  *n = iterations run; up to cap entries are written. */
+gr_status gr_bal_lm_iteration_seconds(gr_bal_problem *p, double *seconds, int cap, int *n);
+
 /* The camera model the engine is specialised for, on caller-supplied triples: for i < n, camera i (9 scalars
  * [angle-axis r(3), t(3), f, k1, k2]), point i (3) and observation i (2) give residual i (2), the camera block Jc
  * (2 x 9, column-major, 18 scalars) and the point block Jp (2 x 3, column-major, 6) — the values the user traits of

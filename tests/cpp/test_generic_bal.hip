@@ -112,6 +112,20 @@ template <typename T, typename S> struct ReprojectionErrorWrongTagTraits : Repro
 };
 template <typename T, typename S> using ReprojectionErrorWrongTag = FactorDescriptor<T, S, ReprojectionErrorWrongTagTraits<T, S>>;
 
+// ... and a tagged factor that IS the model everywhere except at theta == 0 exactly, where the reference's Jacobian has a
+// zero rotation block (projection_jacobians.cuh:175-212) and this one does not: no sampled factor of a real graph sits at
+// theta == 0, only the probe's synthetic triples see the difference
+template <typename T, typename S> struct ReprojectionErrorTheta0Traits : ReprojectionErrorManualTraits<T, S> {
+  static constexpr bool bal_reprojection_model = true;
+  template <typename Sj, size_t I>
+  d_fn static void jacobian(const Camera<T> &cam, const Point3<T> &pt, const Pixel<T> &obs, Sj *jac) {
+    ReprojectionErrorManualTraits<T, S>::template jacobian<Sj, I>(cam, pt, obs, jac);
+    if (I == 0 && cam(0) == T(0) && cam(1) == T(0) && cam(2) == T(0))
+      for (int k = 0; k < 6; ++k) jac[k] = jac[6 + k]; // "rotation derivative" = translation derivative, at theta == 0 only
+  }
+};
+template <typename T, typename S> using ReprojectionErrorTheta0 = FactorDescriptor<T, S, ReprojectionErrorTheta0Traits<T, S>>;
+
 } // namespace graphite
 
 template <template <typename, typename> class Factor> static int run(int argc, char **argv) {
@@ -131,6 +145,10 @@ template <template <typename, typename> class Factor> static int run(int argc, c
   for (size_t c = 0; c < nc; ++c) for (int k = 0; k < 9; ++k) file >> cams[c](k);
   for (size_t p = 0; p < np; ++p) for (int k = 0; k < 3; ++k) file >> pts[p](k);
   if (!file) { std::cerr << "bad BAL file" << std::endl; return 2; }
+  std::vector<Camera<FP>> cams0(nc);
+  std::vector<Point3<FP>> pts0(np);
+  for (size_t c = 0; c < nc; ++c) cams0[c] = cams[c];
+  for (size_t p = 0; p < np; ++p) pts0[p] = pts[p];
 
   Graph<FP, SP> graph;
   CameraDescriptor<FP, SP> cam_desc;
@@ -146,11 +164,17 @@ template <template <typename, typename> class Factor> static int run(int argc, c
   graph.add_descriptor(&r_desc);
   const std::string jmode = argc > 4 ? argv[4] : "auto";
   if (jmode == "dynamic") r_desc.set_jacobian_storage(false); // factor.hpp:626-640
-  std::cout << "JACOBIANS " << (jmode == "wrong-tag" ? "wrong-tag" : r_desc.dynamic_jacobians() ? "dynamic" : r_desc.use_autodiff() ? "auto" : "stored") << std::endl;
+  std::cout << "JACOBIANS " << (jmode == "wrong-tag" || jmode == "theta0" ? jmode : r_desc.dynamic_jacobians() ? "dynamic" : r_desc.use_autodiff() ? "auto" : "stored") << std::endl;
   const DefaultLoss<FP, 2> loss;
-  for (size_t i = 0; i < no; ++i) r_desc.add_factor({ci[i], nc + pi[i]}, ob[i], nullptr, Empty(), loss);
+  std::vector<size_t> handles(no);
+  for (size_t i = 0; i < no; ++i) handles[i] = r_desc.add_factor({ci[i], nc + pi[i]}, ob[i], nullptr, Empty(), loss);
 
   if (jmode == "engine-fixed") cam_desc.set_fixed(0, true);
+  // engine-inactive: every 97th observation is rejected as an outlier (FactorDescriptor::set_active, factor.hpp:419-431:
+  // level 1 > the optimisation level 0) and the LAST point loses all its observations (an unused vertex, active.hpp:18-21)
+  if (jmode == "engine-inactive") {
+    for (size_t i = 0; i < no; ++i) if (i % 97 == 5 || pi[i] == np - 1) r_desc.set_active(handles[i], 1);
+  }
   const std::string kind = argv[2];
   BlockJacobiPreconditioner<FP, SP> bj;
   IdentityPreconditioner<FP, SP> id;
@@ -170,7 +194,31 @@ template <template <typename, typename> class Factor> static int run(int argc, c
   options.iterations = std::stoul(argv[3]);
   options.verbose = true; // the table is the chi2 / lambda trace the test parses
   options.streams = &streams;
-  const bool ok = optimizer::levenberg_marquardt<FP, SP>(&graph, &options);
+  bool ok = optimizer::levenberg_marquardt<FP, SP>(&graph, &options);
+  if (jmode == "engine-twice") {
+    // the SLAM pattern (README.md:27): the optimiser is called again on the same structure.  The second call must find the
+    // engine problem cached on the graph and only move parameters; a THIRD call after one more factor went inactive rebuilds it.
+    const double first_setup = optimizer::engine_last_setup_seconds();
+    const FP chi2_first = graph.chi2();
+    const Camera<FP> cam0_first = cams[0];
+    for (size_t c = 0; c < nc; ++c) cams[c] = cams0[c];
+    for (size_t p = 0; p < np; ++p) pts[p] = pts0[p];
+    options.verbose = false;
+    ok = optimizer::levenberg_marquardt<FP, SP>(&graph, &options) && ok;
+    bool same = graph.chi2() == chi2_first;
+    for (int k = 0; k < 9; ++k) same = same && cams[0](k) == cam0_first(k);
+    std::cout << "SECOND_CALL_SAME_RESULT " << (same ? 1 : 0) << std::endl
+              << "SETUP_MS " << first_setup * 1e3 << " " << optimizer::engine_last_setup_seconds() * 1e3 << std::endl
+              << "CACHE_HITS " << optimizer::engine_cache_hit_count() << std::endl;
+    r_desc.set_active(handles[0], 1);
+    ok = optimizer::levenberg_marquardt<FP, SP>(&graph, &options) && ok;
+    std::cout << "CACHE_HITS_AFTER_SET_ACTIVE " << optimizer::engine_cache_hit_count() << std::endl;
+    // ... and a write to a PUBLIC array that no API call announced (the reference's tests read and write these members
+    // directly, tests/factor.cu:154,177): the content digest notices
+    r_desc.device_obs[1](0) += FP(0.25);
+    ok = optimizer::levenberg_marquardt<FP, SP>(&graph, &options) && ok;
+    std::cout << "CACHE_HITS_AFTER_DIRECT_WRITE " << optimizer::engine_cache_hit_count() << std::endl;
+  }
   std::cout << std::setprecision(17) << "FINAL_CHI2 " << graph.chi2() << std::endl;
   std::cout << "CAM0";
   for (int k = 0; k < 9; ++k) std::cout << " " << cams[0](k);
@@ -183,7 +231,10 @@ int main(int argc, char **argv) {
   // auto: dual-number Jacobians (stored); stored | dynamic: the Manual factor with / without Jacobian storage
   const std::string jmode = argc > 4 ? argv[4] : "auto";
   // engine: the tagged factor (dispatched to gr_bal_*); engine-fixed: the same with one camera fixed (handed over with a fixed-vertex mask)
-  if (jmode == "engine" || jmode == "engine-fixed") return run<graphite::ReprojectionErrorEngine>(argc, argv);
+  // engine-twice: the optimiser called repeatedly on one graph (cached engine problem); engine-inactive: deactivated factors and
+  // an unused vertex still reach the engine; theta0: a tagged factor that leaves the model only at theta == 0 is refused
+  if (jmode == "engine" || jmode == "engine-fixed" || jmode == "engine-twice" || jmode == "engine-inactive") return run<graphite::ReprojectionErrorEngine>(argc, argv);
+  if (jmode == "theta0") return run<graphite::ReprojectionErrorTheta0>(argc, argv);
   if (jmode == "wrong-tag") return run<graphite::ReprojectionErrorWrongTag>(argc, argv);
   return jmode == "auto" ? run<graphite::ReprojectionError>(argc, argv) : run<graphite::ReprojectionErrorManual>(argc, argv);
 }
