@@ -19,7 +19,7 @@ STATUS_NAMES = {0: "GR_OK", 1: "GR_ERR_INVALID", 2: "GR_ERR_HIP", 3: "GR_ERR_NO_
 
 # every symbol include/graphite_mi355x.h declares
 EXPORTS = [
-    "gr_version", "gr_last_error_string", "gr_device_count",
+    "gr_version", "gr_last_error_string", "gr_device_count", "gr_warm_up",
     "gr_bal_create", "gr_bal_create_shard", "gr_bal_destroy", "gr_bal_set_loss", "gr_bal_set_scale_system", "gr_bal_set_jacobian_precision",
     "gr_bal_set_params", "gr_bal_get_params", "gr_bal_linearize", "gr_bal_chi2",
     "gr_bal_backup_parameters", "gr_bal_revert_parameters", "gr_bal_apply_update",

@@ -1,10 +1,14 @@
 // Shared host/device helpers of libgraphite_mi355x.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <exception>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace gr {
@@ -20,6 +24,46 @@ struct HipError : std::runtime_error {
       throw ::gr::HipError(std::string(#expr) + " -> " + hipGetErrorString(_e) + " @" + __FILE__ + \
                            ":" + std::to_string(__LINE__));                                        \
   } while (0)
+
+// host loops over the observation list (set-up phases) on a few threads: fn(begin, end, chunk) over `nt` contiguous chunks;
+// an exception of any chunk is rethrown in the caller
+inline int host_threads() { return (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())); }
+template <typename F> inline void par_chunks(size_t n, int nt, F &&fn) {
+  if (nt <= 1 || n < (size_t)(1 << 14)) { fn((size_t)0, n, 0); return; }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err(nt);
+  const size_t per = (n + nt - 1) / nt;
+  for (int k = 0; k < nt; ++k)
+    th.emplace_back([&, k] {
+      try { fn(std::min(n, (size_t)k * per), std::min(n, (size_t)(k + 1) * per), k); } catch (...) { err[k] = std::current_exception(); }
+    });
+  for (auto &t : th) t.join();
+  for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
+// Host -> device uploads of the set-up phase go through a pinned staging ring (one per host thread, 64 MB, allocated on
+// first use or by gr_warm_up): a hipMemcpyAsync from PAGEABLE memory is staged by the runtime at ~2 GB/s and blocks the next
+// synchronising call for as long (measured: 20 ms for the 40 MB of index arrays of Ladybug-1723 inside gr_bal_create);
+// from pinned memory the same bytes take 2 ms and the call returns at once.  Arrays larger than half the ring take the
+// runtime's own path.  The ring wraps behind a device synchronisation.
+struct UploadRing {
+  static constexpr size_t CAP = (size_t)64 << 20;
+  char *base = nullptr;
+  size_t used = 0;
+  ~UploadRing() { if (base) (void)hipHostFree(base); }
+  void ensure() { if (!base) GR_HIP(hipHostMalloc(reinterpret_cast<void **>(&base), CAP, hipHostMallocDefault)); }
+  void upload(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    if (bytes > CAP / 2) { GR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s)); return; }
+    ensure();
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (used + need > CAP) { GR_HIP(hipDeviceSynchronize()); used = 0; }
+    std::memcpy(base + used, src, bytes);
+    GR_HIP(hipMemcpyAsync(dst, base + used, bytes, hipMemcpyHostToDevice, s));
+    used += need;
+  }
+  static UploadRing &get() { static thread_local UploadRing r; return r; }
+};
 
 // Device buffer owned by the engine (plain hipMalloc; sized for 288 GB HBM, so
 // nothing is pooled or re-used across stages: every stage keeps its arrays
@@ -44,7 +88,7 @@ template <typename T> struct DevBuf {
   }
   void upload(const std::vector<T> &h, hipStream_t s) {
     alloc(h.size());
-    if (!h.empty()) GR_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    if (!h.empty()) UploadRing::get().upload(p, h.data(), h.size() * sizeof(T), s);
   }
   void zero(hipStream_t s) {
     if (n) GR_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));

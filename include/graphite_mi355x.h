@@ -138,6 +138,10 @@ const char *gr_version(void);
 const char *gr_last_error_string(void);
 /* number of visible HIP devices (0 if none); never initialises a device */
 int gr_device_count(void);
+/* Loads this library's code object on `device` (one empty kernel launch, synchronised): the one-time cost of the first
+ * kernel launch of a process, taken where the caller wants it (graph construction) instead of inside the first
+ * gr_bal_model_evaluate / gr_bal_create of an optimiser call.  Idempotent. */
+gr_status gr_warm_up(int device);
 
 /* ---- problem handle ------------------------------------------------------------
  * Replaces the construction done by examples/bal.cu:55-141 (descriptors,
