@@ -50,14 +50,14 @@ class LMOptions(C.Structure):
 class LMStats(C.Structure):
     _fields_ = [("iterations_run", C.c_int32), ("accepted", C.c_int32), ("pcg_iterations", C.c_int32),
                 ("ok", C.c_int32), ("setup_seconds", C.c_double), ("loop_seconds", C.c_double),
-                ("solve_seconds", C.c_double), ("final_chi2", C.c_double), ("collectives", C.c_int64)]
+                ("solve_seconds", C.c_double), ("final_chi2", C.c_double), ("collectives", C.c_int64), ("kernel_launches", C.c_int64)]
 
 
 class Tuning(C.Structure):
     """gr_bal_tuning (include/graphite_mi355x.h)"""
     _fields_ = [(k, C.c_int32) for k in ("point_tiles", "g3_gather", "point_records", "pcg_lazy", "pcg_single_reduction", "sparse_cholesky",
                                          "spchol_overlap", "lm_speculate", "lm_ahead", "lm_fused", "grid_mult", "vec_per_thread", "schur_item",
-                                         "verbose", "ipc_timeout_ms")] + [("reserved", C.c_int32 * 5)]
+                                         "verbose", "ipc_timeout_ms", "shard_fused", "shard_virtual_ranks")] + [("reserved", C.c_int32 * 3)]
 
 
 class DirectSolverInfo(C.Structure):

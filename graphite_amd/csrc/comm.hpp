@@ -114,6 +114,34 @@ struct RcclComm final : Comm {
 // refuses every later collective (CommError) — a rank that timed out holds rank-local values and must not carry on.
 constexpr int IPC_MAX_PARTS = 8;
 constexpr size_t IPC_HEADER = 4096;
+// FUSED channel (round 4): the per-inner-iteration message of the single-reduction PCG on landmark shards does not go through
+// a kernel of its own.  The OPERATOR's finishing workgroups push this rank's camera rows and dot-product records straight
+// into every peer's mailbox, and the UPDATE kernel's prologue waits for the flags and sums the slots in rank order: the
+// all-reduce is the seam between two kernels that exist anyway (4 launches per inner iteration -> 2).  It has its own flags
+// (header offset IPC_FUSED_FLAGS) and its own 2 x size slots behind the collective channel's, and its sequence number lives on
+// the DEVICE (it advances only when a launch really pushes: launches that find the PCG loop finished return at once on every
+// rank alike), so the two channels never disturb each other's double buffering.
+constexpr size_t IPC_FUSED_FLAGS = 1024; // flags[2][size] of the fused channel (the collective channel's start at 0; size <= 64)
+struct IpcFused {
+  char *const *boxes = nullptr;       // device array [size] of mailbox base pointers as mapped on this rank; nullptr = not fused
+  int rank = 0, size = 0;
+  size_t slot_bytes = 0;
+  unsigned long long *seq = nullptr;  // device: fused messages pushed so far by this rank (identical on all ranks between launches)
+  unsigned *counter = nullptr;        // device: [0] completion count of the pushing launch
+  long long timeout_ticks = 0;
+  int *h_err = nullptr;
+  // PROJECTION ONLY (tools/shard_projection.py, gr_bal_tuning.shard_virtual_ranks = V on a ONE-rank communicator): the rank
+  // plays all V ranks of a V-rank message on its own mailbox — it stores its rows into slot 0 and zeros into slots 1 .. V - 1,
+  // raises all V flags, and the consumer sums V slots: the stores, loads and waits of a V-rank message, without the xGMI hops
+  int virt = 0;
+  __device__ __forceinline__ int push_box(int r) const { return virt ? 0 : r; }
+  __device__ __forceinline__ int push_slot(int r) const { return virt ? r : rank; }
+  template <typename U> __device__ __forceinline__ U push_value(int r, U v) const { return (virt && r) ? U(0) : v; }
+  __device__ __forceinline__ char *slot(int box, int set, int r) const { return boxes[box] + IPC_HEADER + ((size_t)(2 + set) * size + r) * slot_bytes; }
+  __device__ __forceinline__ unsigned long long *flag(int box, int set, int r) const {
+    return reinterpret_cast<unsigned long long *>(boxes[box] + IPC_FUSED_FLAGS) + (size_t)set * size + r;
+  }
+};
 struct IpcPart { void *ptr; unsigned long long count; unsigned long long offset; int is_double; int pad; }; // offset: bytes inside the slot
 struct IpcMsg { IpcPart part[IPC_MAX_PARTS]; int nparts; };
 
@@ -218,7 +246,25 @@ struct IpcComm final : Comm {
   long long timeout_ticks = 3000000000ll; // 30 s at 100 MHz (gr_bal_tuning.ipc_timeout_ms)
   bool dead = false;                      // a wait timed out once: every later collective is refused
 
-  static size_t mailbox_bytes(int size, size_t slot) { return IPC_HEADER + 2 * (size_t)size * slot; }
+  static size_t mailbox_bytes(int size, size_t slot) { return IPC_HEADER + 4 * (size_t)size * slot; } // 2 sets x size slots per channel
+  // the fused channel's view of this communicator (kernels_mf.hpp: k_pcg_operator<..., FUSE>, k_pcg_update)
+  unsigned long long *d_seq2 = nullptr;
+  unsigned *d_counter2 = nullptr;
+  int virtual_ranks = 0;   // projection only (IpcFused::virt)
+  size_t box_bytes = 0;    // size of this rank's mailbox allocation
+  IpcFused fused() {
+    if (!d_seq2) {
+      GR_HIP(hipMalloc(reinterpret_cast<void **>(&d_seq2), sizeof(unsigned long long)));
+      GR_HIP(hipMemset(d_seq2, 0, sizeof(unsigned long long)));
+      GR_HIP(hipMalloc(reinterpret_cast<void **>(&d_counter2), 4 * sizeof(unsigned)));
+      GR_HIP(hipMemset(d_counter2, 0, 4 * sizeof(unsigned)));
+    }
+    IpcFused f;
+    f.boxes = d_boxes; f.rank = rank; f.size = size; f.slot_bytes = slot_bytes; f.seq = d_seq2; f.counter = d_counter2;
+    f.timeout_ticks = timeout_ticks; f.h_err = h_err;
+    if (size == 1 && virtual_ranks > 1 && 4 * (size_t)virtual_ranks * slot_bytes + IPC_HEADER <= box_bytes) { f.size = virtual_ranks; f.virt = 1; }
+    return f;
+  }
   IpcComm(int rank_, int size_, size_t slot_bytes_, const std::vector<char *> &boxes_, const std::vector<bool> &opened_) : boxes(boxes_), opened(opened_), slot_bytes(slot_bytes_) {
     rank = rank_; size = size_;
     GR_HIP(hipMalloc(reinterpret_cast<void **>(&d_boxes), size * sizeof(char *)));
@@ -233,6 +279,8 @@ struct IpcComm final : Comm {
     if (!boxes.empty() && boxes[rank]) (void)hipFree(boxes[rank]);
     if (d_boxes) (void)hipFree(d_boxes);
     if (d_ticket) (void)hipFree(d_ticket);
+    if (d_seq2) (void)hipFree(d_seq2);
+    if (d_counter2) (void)hipFree(d_counter2);
     if (h_err) (void)hipHostFree(h_err);
   }
   void flush(hipStream_t stream) {

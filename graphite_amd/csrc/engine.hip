@@ -48,6 +48,7 @@ static void tuning_default(gr_bal_tuning &t) {
   t.schur_item = env_int("GR_SCHUR_ITEM", 56);
   t.verbose = getenv("GR_VERBOSE") ? 1 : 0;
   t.ipc_timeout_ms = env_int("GR_IPC_TIMEOUT_MS", 30000);
+  t.shard_fused = env_int("GR_SHARD_FUSED", -1);
 }
 
 // GR_VERBOSE: host laps of the set-up phases (gr_bal_create is what a drop-in user waits for before the first iteration)
@@ -231,9 +232,10 @@ template <typename T> struct Engine final : EngineBase {
   }
   int64_t coll_count = 0; // collectives issued (a group counts once): gr_lm_stats.collectives
   bool coll_in_group = false;
-  void allreduce_T(T *buf, size_t count) { if (!coll_in_group) ++coll_count; comm->allreduce(buf, count, sizeof(T) == 8, stream); }
-  void allreduce_d(double *buf, size_t count) { if (!coll_in_group) ++coll_count; comm->allreduce(buf, count, true, stream); }
-  void group_start() { ++coll_count; coll_in_group = true; comm->group_start(); }
+  void allreduce_T(T *buf, size_t count) { if (!coll_in_group) { ++coll_count; ++comm_launches; } comm->allreduce(buf, count, sizeof(T) == 8, stream); }
+  void allreduce_d(double *buf, size_t count) { if (!coll_in_group) { ++coll_count; ++comm_launches; } comm->allreduce(buf, count, true, stream); }
+  int64_t comm_launches = 0; // kernels the communicator launched for them (one per message on the mailbox transport)
+  void group_start() { ++coll_count; ++comm_launches; coll_in_group = true; comm->group_start(); }
   void group_end() { comm->group_end(); coll_in_group = false; }
   // matrix-free PCG control
   DevBuf<double> ctl; // PCG slot accumulators + loop state
@@ -797,7 +799,9 @@ template <typename T> struct Engine final : EngineBase {
       kp->pending.emplace_back(a, b);
     }
   };
+  int64_t launch_count = 0; // kernels of the per-iteration paths (launch()) + the sharded form's k_cam_rows / mailbox kernels
   template <typename K, typename... A> void launch(K kernel, size_t grid, A... args) {
+    ++launch_count;
     if (ext_a) {
       hipEvent_t a = ext_a, b = ext_b;
       ext_a = ext_b = nullptr;
@@ -1363,20 +1367,63 @@ template <typename T> struct Engine final : EngineBase {
     k_is_points<T, 1><<<is_points_blocks(), TPB, 0, stream>>>((int)Np, (int)Nc, pt_ptr.p, g3.p, Mp.p, Hll_inv.p, bl.p, scales.p, x + pose_dim, sc, 0, g3_gather());
   }
 
+  // ---- landmark shards: the inner iteration's message fused into the operator / update launches (kernels_mf.hpp ShardPush,
+  // comm.hpp IpcFused).  Needs the IPC mailbox transport, the single-reduction PCG form, the plain camera-major order (a
+  // workgroup's observations are one contiguous camera range) and a message that fits a mailbox slot.
+  DevBuf<int> sp_cam_wg, sp_empty;
+  DevBuf<unsigned> sp_cam_cnt;
+  int sp_grid = -1, sp_nempty = 0;
+  int64_t fused_messages = 0; // pushed by operator launches (host count of the enqueued ones)
+  size_t shard_dots_off() const { return (9 * (size_t)Nc * sizeof(T) + 15) / 16 * 16; }
+  IpcComm *ipc_comm() const { return dynamic_cast<IpcComm *>(comm.get()); }
+  bool shard_fused() const {
+    IpcComm *ic = ipc_comm();
+    if (!ic || tune.shard_fused == 0 || (ic->size < 2 && tune.shard_fused != 1) || tiled || pcg_mode() != 2) return false;
+    return shard_dots_off() + NSLOT * sizeof(double) <= ic->slot_bytes;
+  }
+  ShardPush shard_push() {
+    if (sp_grid != grid_op) { // per camera: how many workgroups of the operator grid hold observations of it (xcd_tile_range, plain form)
+      std::vector<int> wg(Nc, 0), empty;
+      const std::vector<int> h_cam = cam_cm.download(stream);
+      const int nb = grid_op >> 3, nt = nb_pm;
+      for (int b = 0; b < grid_op; ++b) {
+        const int x = b & 7, bi = b >> 3;
+        const int x0 = (int)((long long)x * nt / 8), x1 = (int)((long long)(x + 1) * nt / 8);
+        const int t0 = x0 + (int)((long long)bi * (x1 - x0) / nb), t1 = x0 + (int)((long long)(bi + 1) * (x1 - x0) / nb);
+        const long long j0 = (long long)t0 * TPB, j1 = std::min<long long>((long long)t1 * TPB, (long long)No);
+        if (t0 >= t1 || j0 >= j1) continue;
+        for (int c = h_cam[j0]; c <= h_cam[j1 - 1]; ++c) if (h_cam_ptr[c + 1] > h_cam_ptr[c]) wg[c]++;
+      }
+      for (int64_t c = 0; c < Nc; ++c) if (h_cam_ptr[c + 1] == h_cam_ptr[c]) empty.push_back((int)c);
+      sp_nempty = (int)empty.size();
+      if (empty.empty()) empty.push_back(0);
+      sp_cam_wg.upload(wg, stream); sp_empty.upload(empty, stream);
+      sp_cam_cnt.alloc(Nc); sp_cam_cnt.zero(stream);
+      GR_HIP(hipStreamSynchronize(stream));
+      sp_grid = grid_op;
+    }
+    ShardPush sp;
+    ipc_comm()->virtual_ranks = tune.shard_virtual_ranks;
+    sp.fz = ipc_comm()->fused();
+    sp.cam_seg_ptr = cam_seg_ptr.p; sp.cam_wg = sp_cam_wg.p; sp.cam_cnt = sp_cam_cnt.p; sp.empty = sp_empty.p; sp.n_empty = sp_nempty;
+    sp.dots_off = shard_dots_off();
+    return sp;
+  }
   template <typename JT> void launch_operator_j(PcgState st, int k, const T *rec, const LmDev *lm, double mu) {
 #ifdef GR_DIAG
     { // diagnostic builds: GR_OP_VAR=1|2|3 runs an ablated operator INSIDE the solve (wrong numbers, real cache state)
       static const int var = getenv("GR_OP_VAR") ? atoi(getenv("GR_OP_VAR")) : 0;
-#define GR_OPV(V) launch(k_pcg_operator<T, V, JT>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm)
+#define GR_OPV(V) launch(k_pcg_operator<T, V, JT>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm, ShardPush{})
       if (var == 1) { GR_OPV(1); return; }
       if (var == 2) { GR_OPV(2); return; }
       if (var == 3) { GR_OPV(3); return; }
 #undef GR_OPV
     }
 #endif
-    if (st.lazy == 2) launch(k_pcg_operator<T, 0, JT, 2>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
-    else if (st.lazy) launch(k_pcg_operator<T, 0, JT, 1>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm);
-    else launch(k_pcg_operator<T, 0, JT>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm);
+    if (st.lazy == 2 && shard_fused()) launch(k_pcg_operator<T, 0, JT, 2, true>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm, shard_push());
+    else if (st.lazy == 2) launch(k_pcg_operator<T, 0, JT, 2>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm, ShardPush{});
+    else if (st.lazy) launch(k_pcg_operator<T, 0, JT, 1>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm, ShardPush{});
+    else launch(k_pcg_operator<T, 0, JT>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm, ShardPush{});
   }
   void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
@@ -1384,10 +1431,14 @@ template <typename T> struct Engine final : EngineBase {
   }
   template <int MODE, bool IDENTITY> void launch_update(int blocks, T *x, const T *rawc, int cw, int ui, PcgState st, int k, int nc = -1, int np = -1, const LmDev *lm = nullptr, bool first_lazy = false) {
     const int nc_v = nc < 0 ? (int)Nc : nc, np_v = np < 0 ? (int)Np : np;
-    if (st.lazy == 2) launch(k_pcg_update<T, MODE, IDENTITY, 2>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
-    else if (st.lazy) launch(k_pcg_update<T, MODE, IDENTITY, 1>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather());
-    else if (first_lazy) launch(k_pcg_update<T, MODE, IDENTITY, 3>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather());
-    else launch(k_pcg_update<T, MODE, IDENTITY>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather());
+    if (st.lazy == 2) {
+      const bool fz_on = MODE == 1 && shard_fused();
+      launch(k_pcg_update<T, MODE, IDENTITY, 2>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather(),
+             fz_on ? (ipc_comm()->virtual_ranks = tune.shard_virtual_ranks, ipc_comm()->fused()) : IpcFused{}, (unsigned long long)shard_dots_off());
+    }
+    else if (st.lazy) launch(k_pcg_update<T, MODE, IDENTITY, 1>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather(), IpcFused{}, 0ull);
+    else if (first_lazy) launch(k_pcg_update<T, MODE, IDENTITY, 3>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather(), IpcFused{}, 0ull);
+    else launch(k_pcg_update<T, MODE, IDENTITY>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather(), IpcFused{}, 0ull);
   }
   // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
   // touched once): obs + 3 index streams, ps, packs, points, g3 out, segment partials
@@ -1462,10 +1513,13 @@ template <typename T> struct Engine final : EngineBase {
       bool left = false;
       int hook_at = -1, ran = 0;
       trial_done = false;
+      const bool fz_on = comm && shard_fused();
       auto iteration = [&](int k) {
         enqueue_operator(k);
-        if (comm) {
+        if (fz_on) { ++coll_count; ++fused_messages; } // the operator launch pushed the message, the update launch awaits it: no kernel in between
+        else if (comm) {
           k_cam_rows<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_seg_ptr.p, op_partial.p, raw_c.p, nullptr, k);
+          ++launch_count;
           group_start();
           allreduce_T(raw_c.p, pose_dim);
           allreduce_d(st.acc + (size_t)k * NSLOT * NSW, (size_t)NSLOT * NSW); // RZP, RR, PDZ, ZDZ, DEN of record k
@@ -1928,9 +1982,9 @@ template <typename T> struct Engine final : EngineBase {
   // iteration 0 applies sigma = 1 / |r|): the plain kernel, no decision prologue, no first direction launch
   void launch_operator_first(PcgState st, const LmDev *lm, double mu) {
     if constexpr (sizeof(T) == 8) {
-      if (jac32) { launch(k_pcg_operator<T, 0, float>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm); return; }
+      if (jac32) { launch(k_pcg_operator<T, 0, float>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm, ShardPush{}); return; }
     }
-    launch(k_pcg_operator<T, 0, T>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm);
+    launch(k_pcg_operator<T, 0, T>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm, ShardPush{});
   }
   // iterations 1 ... of the solve whose head is in the stream; returns once the host has seen the loop leave
   template <bool IDENTITY> void continue_pcg(int max_iter, double tol, double rej) {
@@ -1999,7 +2053,7 @@ template <typename T> struct Engine final : EngineBase {
     int num_bad = 0;       // levenberg_marquardt2 (:404-414): consecutive accepted iterations gaining < 0.1 %
     const bool spec_enabled = tune.lm_speculate != 0;
     const bool ahead_enabled = tune.lm_ahead != 0;
-    const int64_t coll0 = coll_count;
+    const int64_t coll0 = coll_count, launch0 = launch_count + comm_launches;
     if (chi2_trace) chi2_trace[0] = (double)chi2v;
     if (lambda_trace) lambda_trace[0] = (double)mu;
     // look-ahead predictor: nothing is known about the first solve of this call; from a fresh starting point the inner loop
@@ -2206,6 +2260,7 @@ template <typename T> struct Engine final : EngineBase {
     st.ok = run ? 1 : 0;
     st.final_chi2 = (double)chi2v;
     st.collectives = coll_count - coll0;
+    st.kernel_launches = launch_count + comm_launches - launch0;
     check_comm("levenberg_marquardt");
     if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] LM: %s; trial linearisation enqueued ahead of the PCG exit flag in %d iterations, not ahead in %d; next head enqueued behind the trial step in %d\n",
                                    lm_fused ? "fused head / trial step" : "host loop", ahead_hits, ahead_misses, head_hits);
@@ -2536,6 +2591,7 @@ gr_status gr_bal_comm_init_ipc(gr_bal_problem *p, const void *handles, int rank,
       }
       if (ok) {
         ipc.reset(new IpcComm(rank, world_size, p->e->ipc_slot, boxes, opened));
+        ipc->box_bytes = IpcComm::mailbox_bytes(world_size, p->e->ipc_slot);
         p->e->ipc_box = nullptr; // owned by the communicator from here on
         // the caller's wait bound also governs the start-up self-test, with a floor of 5 s: this is the one collective at
         // which ranks arrive after unequal host-side set-up work (code-object loading, first launches)

@@ -19,6 +19,7 @@
 // host can stop enqueueing iterations as soon as the loop has left (pinned flag).
 #pragma once
 #include "kernels.hpp"
+#include "comm.hpp"
 
 namespace gr {
 #ifndef LIN_WAVES
@@ -1000,12 +1001,11 @@ __device__ __forceinline__ bool pcg_decide(const PcgState &st, int k, PcgStep<T>
 // i.e. all-reduced, only now).  Every wave evaluates it; workgroup 0 publishes.  The decision concerns iteration k - 1
 // (solver/pcg.hpp:166-229: rejection ratio, tolerance, rz == 0) and is what the host flag of iteration k - 1 reports.
 template <typename T> struct PcgCgStep { T alpha, beta, sigma; };
+// dots[RZP], dots[RR], dots[ZDZ], dots[DEN]: record k of the dot products, complete (summed over the ranks)
 template <typename T>
-__device__ __forceinline__ bool pcg_cg_decide(const PcgState &st, int k, double mu, PcgCgStep<T> &stp) {
+__device__ __forceinline__ bool pcg_cg_decide_v(const PcgState &st, int k, double mu, PcgCgStep<T> &stp, const double (&dots)[NSLOT]) {
   const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
-  stp.alpha = stp.beta = stp.sigma = T(0);
-  if (k > 0 && st.done[k - 1]) { if (first) { st.done[k] = 1; st.rz0[k] = st.rz0[k - 1]; } return false; }
-  const double rzp = slot_sum(st.slots(k, RZP), 0), rr = slot_sum(st.slots(k, RR), 0);
+  const double rzp = dots[RZP], rr = dots[RR];
   const T sigma = (T)(1.0 / (double)(T)sqrt((double)(T)rr));
   const T gamma = (T)rzp * sigma;
   bool stop = false, reject = false;
@@ -1032,7 +1032,7 @@ __device__ __forceinline__ bool pcg_cg_decide(const PcgState &st, int k, double 
   }
   if (stop) return false;
   // delta = u.A.u = sigma^2 (sum rho' |J s.*z'|^2 + mu z'.D.z')
-  const double den = slot_sum(st.slots(k, DEN), 0), zdz = slot_sum(st.slots(k, ZDZ), 0);
+  const double den = dots[DEN], zdz = dots[ZDZ];
   const T delta = (T)((double)sigma * (double)sigma * (den + mu * zdz));
   stp.sigma = sigma;
   if (k == 0) { stp.beta = T(0); stp.alpha = gamma / delta; }
@@ -1042,6 +1042,54 @@ __device__ __forceinline__ bool pcg_cg_decide(const PcgState &st, int k, double 
     stp.alpha = gamma / (delta - stp.beta * gamma / alpha_prev);
   }
   if (first) { st.beta[k] = (double)stp.alpha; st.scale[k] = (double)gamma; }
+  return true;
+}
+// the loop had already ended before iteration k: nothing to decide (every rank sees the same done[k - 1])
+__device__ __forceinline__ bool pcg_cg_already_done(const PcgState &st, int k) {
+  if (!(k > 0 && st.done[k - 1])) return false;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st.done[k] = 1; st.rz0[k] = st.rz0[k - 1]; }
+  return true;
+}
+template <typename T>
+__device__ __forceinline__ bool pcg_cg_decide(const PcgState &st, int k, double mu, PcgCgStep<T> &stp) {
+  stp.alpha = stp.beta = stp.sigma = T(0);
+  if (pcg_cg_already_done(st, k)) return false;
+  double dots[NSLOT];
+  dots[RZP] = slot_sum(st.slots(k, RZP), 0); dots[RR] = slot_sum(st.slots(k, RR), 0); dots[PDZ] = 0.0;
+  dots[ZDZ] = slot_sum(st.slots(k, ZDZ), 0); dots[DEN] = slot_sum(st.slots(k, DEN), 0);
+  return pcg_cg_decide_v<T>(st, k, mu, stp, dots);
+}
+// Landmark shards, fused message: wait (bounded) until every rank's message `seq` is in THIS rank's mailbox, then the dot
+// records summed over the ranks in rank order.  All threads of the workgroup call; false = a peer did not arrive in time
+// (error word raised, the caller returns).  Thread r waits for rank r.
+__device__ __forceinline__ bool shard_wait_dots(const IpcFused &fz, unsigned long long dots_off, int &set, double (&dots)[NSLOT]) {
+  __shared__ int s_bad;
+  const unsigned long long seq = __hip_atomic_load(fz.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  set = (int)(seq & 1ull);
+  if (threadIdx.x == 0) s_bad = (fz.h_err && __hip_atomic_load(fz.h_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1 : 0;
+  __syncthreads();
+  if (!s_bad && (int)threadIdx.x < fz.size) {
+    const unsigned long long *flag = fz.flag(fz.rank, set, threadIdx.x);
+    const long long t0 = wall_clock64();
+    while (ipc_load(flag) < seq) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > fz.timeout_ticks) {
+        ipc_store(reinterpret_cast<unsigned long long *>(fz.boxes[fz.rank]) + 500, 1ull); // the mailbox's error word (comm.hpp)
+        if (fz.h_err) { *fz.h_err = 1; __threadfence_system(); }
+        s_bad = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (s_bad) return false;
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) {
+    double v = 0;
+    for (int r = 0; r < fz.size; ++r) v += ipc_load(reinterpret_cast<const double *>(fz.slot(fz.rank, set, r) + dots_off) + q);
+    dots[q] = v;
+  }
   return true;
 }
 template <typename T> __global__ void __launch_bounds__(TPB) k_pcg_close_cg(PcgState st, int k, double mu) {
@@ -1065,14 +1113,108 @@ template <typename T> __global__ void __launch_bounds__(TPB) k_pcg_close(PcgStat
 //   point rows : per-observation Jp^T w                    -> g3[pm position][3]
 // VAR (diagnostic builds only, GR_DIAG): 1 no g3 scatter, 2 no point gather, 4 no ps_l gather,
 // 8 no Jacobian math, 16 no wave reduction.  VAR = 0 is the product kernel.
-template <typename T, int VAR = 0, typename JT = T, int LAZY = 0>
+// Landmark shards, fused message (comm.hpp IpcFused): what the operator launch needs to finish the camera rows of this rank and
+// push them, with the dot-product records of the iteration, into every peer's mailbox.
+struct ShardPush {
+  IpcFused fz;
+  const int *cam_seg_ptr = nullptr; // [Nc + 1] segments of camera c
+  const int *cam_wg = nullptr;      // [Nc] workgroups of THIS grid whose tile range holds observations of camera c (0: none on this shard)
+  unsigned *cam_cnt = nullptr;      // [Nc] workgroups that have finished camera c so far (returns to 0)
+  const int *empty = nullptr;       // cameras without observations on this shard: workgroup 0 pushes their zero rows
+  int n_empty = 0;
+  unsigned long long dots_off = 0;  // byte offset of the NSLOT dot sums inside a slot (behind the 9 Nc camera rows)
+};
+// sum of the NS partials of one dot-product record, read past this XCD's L2 (the partials were added by atomics of other XCDs)
+__device__ __forceinline__ double slot_sum_agent(const double *base) { // whole wave must call
+  return wave_allsum(__hip_atomic_load(&base[(size_t)(threadIdx.x & 63) * SS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// The tail of a FUSE operator launch, called by every workgroup (all threads) once its own tiles are done and its DEN partial
+// is in the slots.  [c_lo, c_hi]: cameras of the workgroup's observation range (c_lo > c_hi: none).
+//  1. per camera of the range an arrival counter; the workgroup that arrives LAST at a camera sums that camera's segment
+//     partials in segment order (fixed: reproducible) and stores the 9 sums into slot `rank` of EVERY mailbox (system scope);
+//  2. a launch-wide counter over cameras finished + workgroups finished; whoever completes it sums the rank's NSLOT dot-product
+//     records, pushes them too, and raises this rank's flag in every mailbox with the new sequence number.
+// Visibility inside the GPU: the segment partials are written through (agent-scope stores) and drained before the arrival
+// counters are touched; across GPUs: system-scope stores, drained, system fence, then the counter / the flags.
+template <typename T>
+__device__ __forceinline__ void shard_push_tail(const ShardPush &sp, const PcgState &st, int k, int Nc, int c_lo, int c_hi, const T *__restrict__ op_partial) {
+  const IpcFused &fz = sp.fz;
+  __shared__ int s_list[TPB];
+  __shared__ int s_n;
+  __shared__ unsigned s_last;
+  const unsigned long long seq = __hip_atomic_load(fz.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull; // this launch's message
+  const int set = (int)(seq & 1ull);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads(); // every segment partial (and the DEN atomic) of this workgroup has left the CU
+  int pushed = 0;
+  for (int base = c_lo; base <= c_hi; base += TPB) {
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int c = base + (int)threadIdx.x;
+    if (c <= c_hi) {
+      const int want = sp.cam_wg[c];
+      if (want > 0) {
+        const unsigned old = __hip_atomic_fetch_add(&sp.cam_cnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)old == want - 1) {
+          __hip_atomic_store(&sp.cam_cnt[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_list[atomicAdd(&s_n, 1)] = c;
+        }
+      }
+    }
+    __syncthreads();
+    const int nfin = s_n;
+    for (int e = threadIdx.x; e < 9 * nfin; e += TPB) {
+      const int cc = s_list[e / 9], i = e % 9;
+      T row = T(0);
+      for (int sg = sp.cam_seg_ptr[cc]; sg < sp.cam_seg_ptr[cc + 1]; ++sg)
+        row += __hip_atomic_load(&op_partial[9 * (size_t)sg + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int r = 0; r < fz.size; ++r) ipc_store(reinterpret_cast<T *>(fz.slot(fz.push_box(r), set, fz.push_slot(r))) + 9 * (size_t)cc + i, fz.push_value(r, row));
+    }
+    pushed += nfin;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) { // the cameras this shard never sees: zero rows (the slot is reused every other message)
+    for (int e = threadIdx.x; e < 9 * sp.n_empty; e += TPB)
+      for (int r = 0; r < fz.size; ++r) ipc_store(reinterpret_cast<T *>(fz.slot(fz.push_box(r), set, fz.push_slot(r))) + 9 * (size_t)sp.empty[e / 9] + e % 9, T(0));
+    pushed += sp.n_empty;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    const unsigned add = (unsigned)pushed + 1u, target = (unsigned)Nc + gridDim.x;
+    const unsigned old = __hip_atomic_fetch_add(fz.counter, add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (old + add == target) ? 1u : 0u;
+    if (s_last) __hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // every camera row of this rank is in every mailbox and every workgroup's DEN partial is in the slots
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) {
+      const double v = slot_sum_agent(st.slots(k, q));
+      if (threadIdx.x == 0)
+        for (int r = 0; r < fz.size; ++r) ipc_store(reinterpret_cast<double *>(fz.slot(fz.push_box(r), set, fz.push_slot(r)) + sp.dots_off) + q, fz.push_value(r, v));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(fz.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int r = 0; r < fz.size; ++r) ipc_store(fz.flag(fz.push_box(r), set, fz.push_slot(r)), seq);
+  }
+}
+
+template <typename T, int VAR = 0, typename JT = T, int LAZY = 0, bool FUSE = false>
 __global__ void __launch_bounds__(TPB, OP_WAVES)
 k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
                const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ blk_seg,
                const int *__restrict__ seg_slot, const T *__restrict__ pts, const T *__restrict__ pack,
                int loss_kind, T loss_delta, const T *__restrict__ ps, T *__restrict__ g3,
                T *__restrict__ op_partial, double mu, PcgState st, int k, const T *__restrict__ xp = nullptr,
-               const LmDev *__restrict__ lm = nullptr) {
+               const LmDev *__restrict__ lm = nullptr, ShardPush sp = ShardPush{}) {
   if (lm && lm->stop) return;
   PcgStep<T> stp{T(0), T(0)};
   if (LAZY == 2) { // single-reduction form: A applied to the un-normalised z' (the update kernel scales); decisions are the update kernel's
@@ -1200,7 +1342,10 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
       if (VAR & 16) { den += (double)(m[0] + m[8]); }
       else {
       const T tot = wave_transpose_sum<T, 16>(m, lane);
-      if ((lane & 3) == 0 && (lane >> 2) < 9) op_partial[9 * (size_t)segl + (lane >> 2)] = tot;
+      if ((lane & 3) == 0 && (lane >> 2) < 9) {
+        if (FUSE) __hip_atomic_store(&op_partial[9 * (size_t)segl + (lane >> 2)], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // read by another XCD's workgroup (shard_push_tail)
+        else op_partial[9 * (size_t)segl + (lane >> 2)] = tot;
+      }
       }
       remaining &= ~__ballot(mine);
     }
@@ -1210,6 +1355,14 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
   if (VAR & 128) { if (den == 1.2345) st.pdp[0] = den; return; }
   den = block_sum_256(den, red);
   if (threadIdx.x == 0) slot_add(st.slots(k, DEN), 0, den);
+  if (FUSE) {
+    // plain camera-major order (the fused form is not used with point tiles): the workgroup's observations are one contiguous
+    // range, its cameras the range between the first and the last one's
+    int c_lo = 0, c_hi = -1;
+    const long long j_first = (long long)t0 * TPB, j_end = (long long)t1 * TPB < (long long)No ? (long long)t1 * TPB : (long long)No;
+    if (t0 < t1 && j_first < j_end) { c_lo = cam_cm[j_first]; c_hi = cam_cm[j_end - 1]; }
+    shard_push_tail<T>(sp, st, k, Nc, c_lo, c_hi, op_partial);
+  }
 }
 
 // g3 kept in OBSERVATION order (the operator's stores are then whole lines: a wave writes 64 consecutive 3-vectors) and
@@ -1240,13 +1393,20 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
              const int *__restrict__ cam_seg_ptr, const T *__restrict__ raw_c, int cam_weight,
              const T *__restrict__ diag, double mu, int use_identity,
              const T *__restrict__ MinvC, const T *__restrict__ MinvP, PcgState st, int k,
-             const LmDev *__restrict__ lm = nullptr, G3Gather gg = G3Gather{}) {
+             const LmDev *__restrict__ lm = nullptr, G3Gather gg = G3Gather{}, IpcFused fz = IpcFused{}, unsigned long long dots_off = 0) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
   T alpha = 0, first_sigma = 0;
   constexpr bool CG = (LAZY == 2) && MODE == 1;
   PcgCgStep<T> cg{T(0), T(0), T(0)};
+  int fz_set = 0;
+  const bool fused = CG && fz.boxes != nullptr; // landmark shards: the iteration's message is in the mailbox, pushed by the operator launch
   if (CG) {
-    if (!pcg_cg_decide<T>(st, k, mu, cg)) return;
+    if (fused) {
+      if (pcg_cg_already_done(st, k)) return; // nothing was pushed for this iteration, on any rank
+      double dots[NSLOT];
+      if (!shard_wait_dots(fz, dots_off, fz_set, dots)) return;
+      if (!pcg_cg_decide_v<T>(st, k, mu, cg, dots)) return;
+    } else if (!pcg_cg_decide<T>(st, k, mu, cg)) return;
     alpha = cg.alpha;
   } else if (MODE == 1) {
     if (st.done[k]) return;
@@ -1295,7 +1455,9 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
       else {
         const unsigned c = t / 9u, i = t % 9u;
         T raw = 0;
-        if (raw_c) raw = raw_c[t]; // multi-GPU: camera rows already summed over segments and ranks
+        if (fused) { // the ranks' camera rows, summed here in rank order (the same bits on every rank)
+          for (int rk = 0; rk < fz.size; ++rk) raw += ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, fz_set, rk)) + t);
+        } else if (raw_c) raw = raw_c[t]; // multi-GPU: camera rows already summed over segments and ranks
         else
           for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) raw += op_partial[9 * (size_t)sg + i];
         if (gg.cam_fixed && gg.cam_fixed[c]) raw = T(0);

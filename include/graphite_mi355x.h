@@ -103,8 +103,11 @@ typedef struct {
                                events around the solve, recorded only with options->profile != 0 (an event between
                                two launches costs a ~6 us bubble), 0 otherwise */
   double final_chi2;
-  int64_t collectives;      /* landmark-sharded runs: collective operations (grouped calls count once) issued inside
-                               the LM loop by this rank; 0 without a communicator */
+  int64_t collectives;      /* landmark-sharded runs: collective operations (grouped calls count once; a message fused
+                               into the operator / update launches counts once too) issued inside the LM loop by this
+                               rank; 0 without a communicator */
+  int64_t kernel_launches;  /* kernels launched inside the LM loop by the matrix-free PCG paths, the communicator's own
+                               (one per mailbox message) included: what the sharded iteration costs in launch floors */
 } gr_lm_stats;
 
 /* Tuning of one problem handle.  The reference configures through option structs only (LevenbergMarquardtOptions,
@@ -130,7 +133,13 @@ typedef struct {
   int32_t schur_item;           /* GR_SCHUR_ITEM     56: products per work item of the explicit Schur reduction                     */
   int32_t verbose;              /* GR_VERBOSE        0: report the per-problem choices on stderr                                    */
   int32_t ipc_timeout_ms;       /* GR_IPC_TIMEOUT_MS 30000: bound of one IPC-mailbox all-reduce wait (gr_bal_comm_init_ipc)         */
-  int32_t reserved[5];
+  int32_t shard_fused;          /* GR_SHARD_FUSED   -1 auto (IPC mailboxes, single-reduction PCG, plain observation order) | 0 | 1:
+                                   the per-inner-iteration message is pushed by the operator launch and awaited by the update
+                                   launch (2 launches per inner iteration instead of 4).  0 keeps a kernel of its own for the
+                                   all-reduce — needed when several ranks SHARE one GPU and their grids do not fit side by side */
+  int32_t shard_virtual_ranks;  /* PROJECTION ONLY (tools/shard_projection.py): on a ONE-rank mailbox communicator the fused message is
+                                   pushed / awaited / summed as if V ranks took part (V slots of the own mailbox)                    */
+  int32_t reserved[3];
 } gr_bal_tuning;
 void gr_bal_tuning_default(gr_bal_tuning *t);
 

@@ -65,14 +65,19 @@ def main():
             v = np.zeros(slot // 8 + 1)
             rc = lib.gr_bal_comm_allreduce_host(g.h, v.ctypes.data_as(C.POINTER(C.c_double)), C.c_size_t(v.size))
             res["oversize_rc"] = int(rc)
-        for solver, sname in ((ga.SOLVER_PCG, "pcg"), (ga.SOLVER_PCG_SCHUR_IMPLICIT, "implicit")):
+        # "pcg": the default on landmark shards = the inner iteration's message FUSED into the operator / update launches
+        # (gr_bal_tuning.shard_fused, 2 launches per inner iteration); "pcg_unfused": the same solve with a kernel of its own
+        # for the all-reduce (4 launches per inner iteration)
+        for solver, sname in ((ga.SOLVER_PCG, "pcg"), (ga.SOLVER_PCG, "pcg_unfused"), (ga.SOLVER_PCG_SCHUR_IMPLICIT, "implicit")):
             if tag == "f32" and sname != "pcg":
                 continue
+            g.set_tuning(shard_fused=0 if sname == "pcg_unfused" else -1)
             g.set_params(shard.cameras, shard.points)
             ct, lt, st = g.levenberg_marquardt(solver=solver, iterations=8)
             cams, pts = g.get_params()
             res[f"{tag}_{sname}"] = {"chi2": [float(x) for x in ct], "lambda": [float(x) for x in lt],
                                      "pcg_iterations": int(st["pcg_iterations"]), "collectives": int(st["collectives"]),
+                                     "kernel_launches": int(st["kernel_launches"]),
                                      "cams": np.asarray(cams, np.float64).tolist(), "pts": np.asarray(pts, np.float64).tolist()}
         dist.barrier()
         g.close()

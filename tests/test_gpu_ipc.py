@@ -62,6 +62,7 @@ def test_ipc_allreduce_between_processes(world, tmp_path):
     prob = synth.make_config("mini-50")
     ranges = gdist.point_ranges(prob.pt_idx, prob.shape[1], world)
     for dtype, tag, solver, sname in ((np.float64, "f64", ga.SOLVER_PCG, "pcg"),
+                                      (np.float64, "f64", ga.SOLVER_PCG, "pcg_unfused"),
                                       (np.float64, "f64", ga.SOLVER_PCG_SCHUR_IMPLICIT, "implicit"),
                                       (np.float32, "f32", ga.SOLVER_PCG, "pcg")):
         single = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
@@ -83,6 +84,16 @@ def test_ipc_allreduce_between_processes(world, tmp_path):
             assert np.allclose(np.array(res[0][key]["cams"]), c1, rtol=at, atol=1e-10)
             assert np.allclose(pts, p1, rtol=at, atol=1e-10)
         assert [len(res[r][key]["pts"]) for r in range(world)] == [b - a for a, b in ranges]
+    # the fused form runs the SAME iteration (equal inner iteration counts, the same number of messages:
+    # a fused message counts as one collective) with TWO launches per inner iteration less — operator + update instead of
+    # operator + camera-row kernel + mailbox kernel + update (every enqueued iteration, look-ahead launches included)
+    for r in range(world):
+        fu, un = res[r]["f64_pcg"], res[r]["f64_pcg_unfused"]
+        assert fu["pcg_iterations"] == un["pcg_iterations"] > 0
+        assert fu["collectives"] == un["collectives"]
+        saved = un["kernel_launches"] - fu["kernel_launches"]
+        assert saved > 0 and saved % 2 == 0 and saved // 2 >= fu["pcg_iterations"], (un["kernel_launches"], fu["kernel_launches"], fu["pcg_iterations"])
+        assert np.allclose(fu["chi2"], un["chi2"], rtol=1e-10)
 
 
 def test_late_rank_within_the_wait_bound(tmp_path):
