@@ -169,9 +169,6 @@ def main():
             # GR_COMM=rccl: RCCL for everything.
             if share_gpu:
                 used = gdist.init_comm_ipc(gpu, rank, world, slot_bytes=16 << 20, rccl_fallback=False)
-                # ranks that SHARE one GPU: a kernel of one rank that waits inside for its peer's message can keep that peer's
-                # kernels off the CUs (full-size grids do not fit side by side), so the all-reduce keeps a kernel of its own here
-                gpu.set_tuning(shard_fused=0)
                 transport["kind"] = "ipc-mailbox (shared GPU, test mode)"
             elif os.environ.get("GR_COMM", "ipc") == "rccl":
                 gdist.init_comm(gpu, rank, world)

@@ -1379,7 +1379,8 @@ template <typename T> struct Engine final : EngineBase {
   bool shard_fused() const {
     IpcComm *ic = ipc_comm();
     if (!ic || tune.shard_fused == 0 || (ic->size < 2 && tune.shard_fused != 1) || tiled || pcg_mode() != 2) return false;
-    return shard_dots_off() + NSLOT * sizeof(double) <= ic->slot_bytes;
+    ic->virtual_ranks = tune.shard_virtual_ranks;
+    return shard_dots_off() + NSLOT * sizeof(double) <= ic->fused_slot_bytes();
   }
   ShardPush shard_push() {
     if (sp_grid != grid_op) { // per camera: how many workgroups of the operator grid hold observations of it (xcd_tile_range, plain form)
@@ -2591,7 +2592,6 @@ gr_status gr_bal_comm_init_ipc(gr_bal_problem *p, const void *handles, int rank,
       }
       if (ok) {
         ipc.reset(new IpcComm(rank, world_size, p->e->ipc_slot, boxes, opened));
-        ipc->box_bytes = IpcComm::mailbox_bytes(world_size, p->e->ipc_slot);
         p->e->ipc_box = nullptr; // owned by the communicator from here on
         // the caller's wait bound also governs the start-up self-test, with a floor of 5 s: this is the one collective at
         // which ranks arrive after unequal host-side set-up work (code-object loading, first launches)

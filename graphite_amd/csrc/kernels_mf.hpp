@@ -1059,39 +1059,6 @@ __device__ __forceinline__ bool pcg_cg_decide(const PcgState &st, int k, double 
   dots[ZDZ] = slot_sum(st.slots(k, ZDZ), 0); dots[DEN] = slot_sum(st.slots(k, DEN), 0);
   return pcg_cg_decide_v<T>(st, k, mu, stp, dots);
 }
-// Landmark shards, fused message: wait (bounded) until every rank's message `seq` is in THIS rank's mailbox, then the dot
-// records summed over the ranks in rank order.  All threads of the workgroup call; false = a peer did not arrive in time
-// (error word raised, the caller returns).  Thread r waits for rank r.
-__device__ __forceinline__ bool shard_wait_dots(const IpcFused &fz, unsigned long long dots_off, int &set, double (&dots)[NSLOT]) {
-  __shared__ int s_bad;
-  const unsigned long long seq = __hip_atomic_load(fz.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  set = (int)(seq & 1ull);
-  if (threadIdx.x == 0) s_bad = (fz.h_err && __hip_atomic_load(fz.h_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1 : 0;
-  __syncthreads();
-  if (!s_bad && (int)threadIdx.x < fz.size) {
-    const unsigned long long *flag = fz.flag(fz.rank, set, threadIdx.x);
-    const long long t0 = wall_clock64();
-    while (ipc_load(flag) < seq) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > fz.timeout_ticks) {
-        ipc_store(reinterpret_cast<unsigned long long *>(fz.boxes[fz.rank]) + 500, 1ull); // the mailbox's error word (comm.hpp)
-        if (fz.h_err) { *fz.h_err = 1; __threadfence_system(); }
-        s_bad = 1;
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  if (s_bad) return false;
-#pragma unroll
-  for (int q = 0; q < NSLOT; ++q) {
-    double v = 0;
-    for (int r = 0; r < fz.size; ++r) v += ipc_load(reinterpret_cast<const double *>(fz.slot(fz.rank, set, r) + dots_off) + q);
-    dots[q] = v;
-  }
-  return true;
-}
 template <typename T> __global__ void __launch_bounds__(TPB) k_pcg_close_cg(PcgState st, int k, double mu) {
   PcgCgStep<T> stp;
   (void)pcg_cg_decide<T>(st, k, mu, stp);
@@ -1135,17 +1102,20 @@ __device__ __forceinline__ double slot_sum_agent(const double *base) { // whole 
 //  2. a launch-wide counter over cameras finished + workgroups finished; whoever completes it sums the rank's NSLOT dot-product
 //     records, pushes them too, and raises this rank's flag in every mailbox with the new sequence number.
 // Visibility inside the GPU: the segment partials are written through (agent-scope stores) and drained before the arrival
-// counters are touched; across GPUs: system-scope stores, drained, system fence, then the counter / the flags.
+// counters are touched (relaxed tickets, cdna_hip_programming.md G16 form R1); across GPUs: write-through system-scope stores,
+// drained by every thread, relaxed launch-wide counter, and ONE system fence in the workgroup that raises the flags.
 template <typename T>
 __device__ __forceinline__ void shard_push_tail(const ShardPush &sp, const PcgState &st, int k, int Nc, int c_lo, int c_hi, const T *__restrict__ op_partial) {
   const IpcFused &fz = sp.fz;
   __shared__ int s_list[TPB];
   __shared__ int s_n;
   __shared__ unsigned s_last;
-  const unsigned long long seq = __hip_atomic_load(fz.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull; // this launch's message
-  const int set = (int)(seq & 1ull);
+  __shared__ unsigned long long s_seq;
+  if (threadIdx.x == 0) s_seq = __hip_atomic_load(fz.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull; // this launch's message
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads(); // every segment partial (and the DEN atomic) of this workgroup has left the CU
+  const unsigned long long seq = s_seq;
+  const int set = (int)(seq & 1ull);
   int pushed = 0;
   for (int base = c_lo; base <= c_hi; base += TPB) {
     if (threadIdx.x == 0) s_n = 0;
@@ -1181,29 +1151,71 @@ __device__ __forceinline__ void shard_push_tail(const ShardPush &sp, const PcgSt
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence_system();
+    // no fence here: the rows went out as write-through system-scope stores and every thread drained its own (vmcnt) before the
+    // barrier above; a release fence per WORKGROUP would write this kernel's dirty g3 lines back 768 times (measured: 200 us)
     const unsigned add = (unsigned)pushed + 1u, target = (unsigned)Nc + gridDim.x;
-    const unsigned old = __hip_atomic_fetch_add(fz.counter, add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add(fz.counter, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (old + add == target) ? 1u : 0u;
     if (s_last) __hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (!s_last) return;
-  // every camera row of this rank is in every mailbox and every workgroup's DEN partial is in the slots
-  if (threadIdx.x < 64) {
-#pragma unroll
-    for (int q = 0; q < NSLOT; ++q) {
-      const double v = slot_sum_agent(st.slots(k, q));
-      if (threadIdx.x == 0)
-        for (int r = 0; r < fz.size; ++r) ipc_store(reinterpret_cast<double *>(fz.slot(fz.push_box(r), set, fz.push_slot(r)) + sp.dots_off) + q, fz.push_value(r, v));
-    }
+  // every camera row of this rank is in every mailbox and every workgroup's DEN partial is in the slots.  From here on ONE
+  // workgroup runs alone: everything below is spread over its threads so that no lane walks a chain of uncached round trips
+  __shared__ double s_d[NSLOT];
+  __shared__ double s_g[NSLOT * 64];
+  for (int q = (int)(threadIdx.x >> 6); q < NSLOT; q += TPB / 64) { // one wave per record
+    const double v = slot_sum_agent(st.slots(k, q));
+    if ((threadIdx.x & 63) == 0) s_d[q] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NSLOT * fz.size; e += TPB) {
+    const int q = e / fz.size, r = e % fz.size;
+    ipc_store(reinterpret_cast<double *>(fz.slot(fz.push_box(r), set, fz.push_slot(r)) + sp.dots_off) + q, fz.push_value(r, s_d[q]));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence_system();
     __hip_atomic_store(fz.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int r = 0; r < fz.size; ++r) ipc_store(fz.flag(fz.push_box(r), set, fz.push_slot(r)), seq);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < fz.size) ipc_store(fz.flag(fz.push_box(threadIdx.x), set, fz.push_slot(threadIdx.x)), seq);
+  // 3. the same workgroup — ONE, at the very end of the launch, while nothing else of this rank runs — waits (bounded) for every
+  //    rank's message and leaves the dot records summed over the ranks (rank order) in record k of the slots: slot 0 the sum, the
+  //    others zero, so that the update launch reads them exactly as it reads all-reduced slots.  (Waiting in the update launch
+  //    instead cost 42 us: its 1 500 workgroups each paid three uncached round trips to the mailbox.)  The camera rows are summed
+  //    over the ranks by the update launch's camera workgroups, straight from the mailbox.
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < fz.size) {
+    const unsigned long long *flag = fz.flag(fz.rank, set, threadIdx.x);
+    const long long t0 = wall_clock64();
+    while (ipc_load(flag) < seq) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > fz.timeout_ticks) {
+        ipc_store(reinterpret_cast<unsigned long long *>(fz.boxes[fz.rank]) + 500, 1ull); // the mailbox's error word (comm.hpp)
+        if (fz.h_err) { *fz.h_err = 1; __threadfence_system(); }
+        s_bad = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  for (int e = threadIdx.x; e < NSLOT * fz.size; e += TPB) // one load per thread, summed below in rank order
+    s_g[e] = ipc_load(reinterpret_cast<const double *>(fz.slot(fz.rank, set, e % fz.size) + sp.dots_off) + e / fz.size);
+  __syncthreads();
+  for (int e = threadIdx.x; e < NSLOT * NS; e += TPB) {
+    const int q = e / NS, sl = e % NS;
+    double v = 0.0;
+    if (sl == 0) {
+      // a peer that never arrived: NaN dots end this rank's PCG loop by the rejection test; the host finds the error word
+      if (s_bad) v = __builtin_nan("");
+      else for (int r = 0; r < fz.size; ++r) v += s_g[q * fz.size + r];
+    }
+    st.slots(k, q)[(size_t)sl * SS] = v;
   }
 }
 
@@ -1398,15 +1410,12 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
   T alpha = 0, first_sigma = 0;
   constexpr bool CG = (LAZY == 2) && MODE == 1;
   PcgCgStep<T> cg{T(0), T(0), T(0)};
-  int fz_set = 0;
-  const bool fused = CG && fz.boxes != nullptr; // landmark shards: the iteration's message is in the mailbox, pushed by the operator launch
+  // landmark shards, fused message: the operator launch has pushed this rank's camera rows, waited for every peer's and left the
+  // dot records summed over the ranks in the slots; the camera rows are summed here, by the camera workgroups, from the mailbox
+  const bool fused = CG && fz.boxes != nullptr;
+  (void)dots_off;
   if (CG) {
-    if (fused) {
-      if (pcg_cg_already_done(st, k)) return; // nothing was pushed for this iteration, on any rank
-      double dots[NSLOT];
-      if (!shard_wait_dots(fz, dots_off, fz_set, dots)) return;
-      if (!pcg_cg_decide_v<T>(st, k, mu, cg, dots)) return;
-    } else if (!pcg_cg_decide<T>(st, k, mu, cg)) return;
+    if (!pcg_cg_decide<T>(st, k, mu, cg)) return;
     alpha = cg.alpha;
   } else if (MODE == 1) {
     if (st.done[k]) return;
@@ -1446,6 +1455,13 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
   const double cw = (double)cam_weight;
   // persistent: every block walks a contiguous range of camera tiles, then of point tiles
   const int ct0 = (int)((long long)blockIdx.x * cam_tiles / gridDim.x), ct1 = (int)((long long)(blockIdx.x + 1) * cam_tiles / gridDim.x);
+  int fz_set = 0;
+  if (fused && ct0 < ct1) { // block-uniform: the message the operator launch of this iteration pushed
+    __shared__ int s_set;
+    if (threadIdx.x == 0) s_set = (int)(__hip_atomic_load(fz.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1ull);
+    __syncthreads();
+    fz_set = s_set;
+  }
   for (int tile = ct0; tile < ct1; ++tile) {
     const unsigned t = (unsigned)tile * 252u + threadIdx.x;
     const bool on = threadIdx.x < 252 && t < pose_dim;

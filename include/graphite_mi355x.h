@@ -134,9 +134,10 @@ typedef struct {
   int32_t verbose;              /* GR_VERBOSE        0: report the per-problem choices on stderr                                    */
   int32_t ipc_timeout_ms;       /* GR_IPC_TIMEOUT_MS 30000: bound of one IPC-mailbox all-reduce wait (gr_bal_comm_init_ipc)         */
   int32_t shard_fused;          /* GR_SHARD_FUSED   -1 auto (IPC mailboxes, single-reduction PCG, plain observation order) | 0 | 1:
-                                   the per-inner-iteration message is pushed by the operator launch and awaited by the update
-                                   launch (2 launches per inner iteration instead of 4).  0 keeps a kernel of its own for the
-                                   all-reduce — needed when several ranks SHARE one GPU and their grids do not fit side by side */
+                                   the per-inner-iteration message is pushed by the operator launch's finishing workgroups, its
+                                   last workgroup waits for the peers' messages, the update launch sums the camera rows from the
+                                   mailbox (2 launches per inner iteration instead of 4).  0 keeps a kernel of its own for the
+                                   all-reduce                                                                                    */
   int32_t shard_virtual_ranks;  /* PROJECTION ONLY (tools/shard_projection.py): on a ONE-rank mailbox communicator the fused message is
                                    pushed / awaited / summed as if V ranks took part (V slots of the own mailbox)                    */
   int32_t reserved[3];

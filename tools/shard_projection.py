@@ -13,10 +13,13 @@ the unsharded run, so that all nine runs do the same algorithmic work per LM ite
                                                       L8 = assumed latency of the 8-rank one-shot mailbox all-reduce
     projected speed-up = T1 / projected T8
 
-L8 cannot be measured on a 1-GPU box: the figure used is the measured two-process latency on one GPU (tools/ipc_latency.py,
-profiles/r02_v3_ipc_allreduce_latency_2_processes_one_gpu.txt: 11.9 us for 121 KB) scaled by message size, i.e. the
-mechanism's floor WITHOUT an xGMI hop — the projection is an upper bound on the scaling.  What it does show is the part that
-cannot shrink: the replicated camera-space work, launch floors and collectives that max_r T_r still contains.
+Round 4: (i) the inner iteration's message is FUSED into the operator / update launches (gr_bal_tuning.shard_fused) and each
+shard run plays all `world` ranks of that message on its own mailbox (gr_bal_tuning.shard_virtual_ranks: `world` stores per
+pushed value, `world` flags, `world` slots summed per consumed value), so T_r CONTAINS the N-rank cost of the fused messages;
+(ii) the collectives that still have a kernel of their own (the linearisation group, the closing scalars) are priced with
+L8 MEASURED between `world` processes sharing this GPU (--l8-us from tools/ipc_latency.py <world>; the assumed 1-rank-like
+figure of round 3 is gone).  What remains outside the measurement is the xGMI hop itself (~2 us per message on MI300-class
+parts): --hop-us adds it per message, fused ones included.  Still a projection — no run here crosses an xGMI link.
 """
 import argparse, ctypes as C, json, os, sys, time
 import numpy as np
@@ -30,7 +33,11 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--pcg-iterations", type=int, default=10)
-    ap.add_argument("--l8-us", type=float, default=None, help="assumed 8-rank all-reduce latency in us (default: scaled from the 2-process figure)")
+    ap.add_argument("--l8-us", type=float, default=None, help="MEASURED latency (us) of the mailbox all-reduce of a camera vector between `world` processes on this GPU (tools/ipc_latency.py <world>)")
+    ap.add_argument("--l8-large-us", type=float, default=None, help="the same for the linearisation group (Hcc + bc + chi2: 90 Nc scalars), one per LM iteration")
+    ap.add_argument("--l8-small-us", type=float, default=None, help="the same for a message of a few scalars (the closing dots of a solve that ran into its cap)")
+    ap.add_argument("--hop-us", type=float, default=2.0, help="xGMI hop added to every message (fused ones included): not measurable on one GPU")
+    ap.add_argument("--unfused", action="store_true", help="round-3 form: a kernel of its own for every all-reduce")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
@@ -65,26 +72,47 @@ def main():
         part = gdist.partition_by_landmark(prob, r, args.world)
         g = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype, shard=True)
         gdist.init_comm_ipc(g, 0, 1, slot_bytes=max(4 << 20, 2 * 90 * Nc * 8), rccl_fallback=False)  # one slot holds the largest grouped message (Hcc + bc + chi2)
+        if args.unfused:
+            g.set_tuning(shard_fused=0)
+        else:
+            g.set_tuning(shard_fused=1, shard_virtual_ranks=args.world, pcg_single_reduction=1)
         tr, st = run(g, part)
         if lat1 is None:
             f = g.lib.gr_bal_diag_time; f.restype = C.c_double
             lat1 = f(g.h, C.c_int(8), C.c_int(0), C.c_int(200))  # us per 1-rank all-reduce of a camera-space vector
+            lat1_large = f(g.h, C.c_int(8), C.c_int(90 * Nc), C.c_int(200))
+            lat1_small = f(g.h, C.c_int(8), C.c_int(8), C.c_int(200))
         shards.append({"rank": r, "points": int(part.shape[1]), "observations": int(part.shape[2]), "seconds_per_lm_iteration": tr,
-                       "collectives_per_lm_iteration": st["collectives"] / max(st["iterations_run"], 1), "pcg_iterations": st["pcg_iterations"]})
+                       "collectives_per_lm_iteration": st["collectives"] / max(st["iterations_run"], 1), "pcg_iterations": st["pcg_iterations"],
+                       "kernel_launches_per_lm_iteration": st["kernel_launches"] / max(st["iterations_run"], 1)})
         g.close()
     w = np.dtype(dtype).itemsize
     msg_kb = 9 * Nc * w / 1024.0
-    l8 = args.l8_us if args.l8_us is not None else 4.3 + (11.9 - 4.3) * min(1.0, msg_kb / 121.0)
+    if args.l8_us is None:
+        raise SystemExit("--l8-us: pass the latency measured by `python tools/ipc_latency.py %d` for a camera-space vector" % args.world)
+    l8 = args.l8_us
     c = max(s["collectives_per_lm_iteration"] for s in shards)
+    inner = max(s["pcg_iterations"] for s in shards) / float(args.steps)   # fused messages per LM iteration (one per inner iteration)
+    c_kernel = c if args.unfused else max(0.0, c - inner)                   # collectives that still have a kernel of their own
     tmax = max(s["seconds_per_lm_iteration"] for s in shards)
-    t8 = tmax + c * (l8 - lat1) * 1e-6
+    if args.unfused or args.l8_large_us is None or args.l8_small_us is None:
+        t8 = tmax + c_kernel * (l8 - lat1) * 1e-6 + c * args.hop_us * 1e-6
+        priced = "every kernel collective at the camera-vector latency"
+    else:
+        # fused form: what keeps a kernel of its own is ONE large message per LM iteration (the linearisation group) and small ones
+        t8 = tmax + (args.l8_large_us - lat1_large) * 1e-6 + max(0.0, c_kernel - 1.0) * (args.l8_small_us - lat1_small) * 1e-6 + c * args.hop_us * 1e-6
+        priced = "1 linearisation group at L8_large, %.2f small messages at L8_small per LM iteration" % max(0.0, c_kernel - 1.0)
     res = {"kind": "PROJECTION from one GPU (tools/shard_projection.py), not a multi-GPU measurement",
            "workload": f"{args.workload} {args.dtype}, block-Jacobi PCG, {args.pcg_iterations} fixed inner iterations, {args.world} landmark shards",
            "T1_seconds_per_lm_iteration": t1, "T1_lm_iterations_per_sec": 1.0 / t1, "shards": shards,
            "max_shard_seconds_per_lm_iteration": tmax, "collectives_per_lm_iteration": c,
-           "L1_us_one_rank_allreduce_camera_vector": lat1, "L8_us_assumed": l8, "camera_vector_kb": msg_kb,
+           "form": "unfused (kernel per all-reduce)" if args.unfused else "inner-iteration message fused into operator / update, %d virtual ranks inside every shard run" % args.world,
+           "collectives_with_a_kernel_of_their_own_per_lm_iteration": c_kernel, "fused_messages_per_lm_iteration": 0.0 if args.unfused else inner,
+           "L1_us_one_rank_allreduce_camera_vector": lat1, "L8_us_measured_between_%d_processes_on_one_gpu" % args.world: l8,
+           "xgmi_hop_us_assumed_per_message": args.hop_us, "camera_vector_kb": msg_kb, "kernel_collectives_priced_as": priced,
+           "L1_us_large_small": [lat1_large, lat1_small], "L8_us_large_small_measured": [args.l8_large_us, args.l8_small_us],
            "projected_T8_seconds_per_lm_iteration": t8, "projected_lm_iterations_per_sec": 1.0 / t8, "projected_speedup": t1 / t8,
-           "speedup_if_collectives_were_free": t1 / (tmax - c * lat1 * 1e-6),
+           "speedup_if_collectives_were_free": t1 / (tmax - c_kernel * lat1 * 1e-6),
            "ideal": args.world}
     print(json.dumps(res, indent=1))
     if args.out:
