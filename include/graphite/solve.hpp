@@ -105,6 +105,155 @@ template <typename T, bool RHO = false> inline T dot(const T *a, const T *b, siz
   GRAPHITE_HIP(hipMemcpy(&result, scratch, sizeof(T), hipMemcpyDeviceToHost)); // ordered behind the kernels, no host mapping of HBM needed
   return result;
 }
+
+// ---- device-resident PCG control (solver/pcg.hpp:61-232, solver/pcg_schur.hpp:79-168) ---------------------------------------
+// The reference's loops read three dot products per inner iteration back to the host (and so did rounds 1-3 here: three
+// synchronising copies, ~25 us each, plus a D2D copy that blocks).  Here the scalars never leave the GPU: every dot product is
+// a set of per-workgroup partials in fixed order, the kernels that need alpha / beta / the loop decision re-derive them from
+// the partials and a small control record, and the host only watches one pinned word per iteration to know when to stop
+// enqueueing (with one iteration of look-ahead while the previous solve ran that long).  Same iterates, same stopping and
+// rejection rules; the preconditioner is applied to r and the 1 / ||r|| of pcg.hpp:118,190 is folded into the scalars (it is
+// linear).
+template <typename T> struct PcgCtl { T rz, rz0, beta, rinv; int done, iters, reject, pad; };
+template <typename T> __device__ inline T sum_partials(const T *partial, int nb, T *lds /* [TPB] */) { // every thread gets the sum, fixed order
+  T s = 0;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partial[b];
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) lds[threadIdx.x] += lds[threadIdx.x + o]; __syncthreads(); }
+  const T tot = lds[0];
+  __syncthreads();
+  return tot;
+}
+// partial[b] = sum over block b's range of a[i] * b[i]; DAMP: first v2 += mu (diag | 1) p (ops/vector.hpp:25-41), then p . v2
+template <typename T, bool DAMP> __global__ void k_pcg_dot(const PcgCtl<T> *ctl, T *a, const T *b, const T *diag, T mu, int identity, size_t n, T *partial) {
+  __shared__ T red[TPB];
+  if (ctl->done) return;
+  const size_t per = (n + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+  T s = 0;
+  for (size_t i = i0 + threadIdx.x; i < i1; i += TPB) {
+    T av = a[i];
+    if (DAMP) { av += identity ? mu * b[i] : mu * diag[i] * b[i]; a[i] = av; }
+    s += av * b[i];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// start of a solve: rz = r . z (z = Minv r, times 1 / ||r|| with NORM), p = z; hflag[*] cleared by the host
+template <typename T, bool NORM> __global__ void k_pcg_start(PcgCtl<T> *ctl, const T *part_rz, const T *part_rr, int nb, volatile int *hflag0) {
+  __shared__ T lds[TPB];
+  const T rzp = sum_partials(part_rz, nb, lds);
+  T rinv = T(1);
+  if (NORM) rinv = (T)(1.0 / std::sqrt((double)sum_partials(part_rr, nb, lds)));
+  if (threadIdx.x == 0) {
+    ctl->rz = rzp * rinv; ctl->rz0 = std::numeric_limits<T>::infinity(); ctl->beta = T(0); ctl->rinv = rinv;
+    ctl->done = (rzp * rinv == T(0)) ? 1 : 0; ctl->iters = 0; ctl->reject = 0;
+    if (ctl->done) { *hflag0 = 2; __threadfence_system(); } // pcg.hpp:133: rz == 0 ends the loop before it starts
+  }
+}
+// x_backup = x; x += alpha p; r -= alpha v2 with alpha = rz / (p . v2) re-derived by every workgroup; partial r . r
+template <typename T> __global__ void k_pcg_xr(const PcgCtl<T> *ctl, const T *part_pap, int nb, T *x, T *xb, T *r, const T *p, const T *v2, size_t n, T *part_rr, int nb_out) {
+  __shared__ T lds[TPB];
+  if (ctl->done) return;
+  const T denom = sum_partials(part_pap, nb, lds);
+  if (denom == T(0) || denom != denom) return; // pcg_schur.hpp:122: the decision kernel closes the loop
+  const T alpha = ctl->rz / denom;
+  const size_t per = (n + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+  T s = 0;
+  for (size_t i = i0 + threadIdx.x; i < i1; i += TPB) {
+    const T xo = x[i];
+    xb[i] = xo;
+    x[i] = alpha * p[i] + xo;
+    const T rn = -alpha * v2[i] + r[i];
+    r[i] = rn;
+    s += rn * rn;
+  }
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) lds[threadIdx.x] += lds[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0 && (int)blockIdx.x < nb_out) part_rr[blockIdx.x] = lds[0];
+}
+// the loop decision after iteration k (pcg.hpp:196-229): rejection, tolerance, beta; one workgroup; the host sees hflag[k]
+template <typename T, bool NORM> __global__ void k_pcg_decide(PcgCtl<T> *ctl, const T *part_pap, const T *part_rz, const T *part_rr, int nb, T tol, T rej, int k, volatile int *hflag) {
+  __shared__ T lds[TPB];
+  if (ctl->done) { if (threadIdx.x == 0) { hflag[k] = 2; __threadfence_system(); } return; }
+  const T denom = sum_partials(part_pap, nb, lds);
+  const T rzp = sum_partials(part_rz, nb, lds);
+  T rinv = T(1);
+  if (NORM) rinv = (T)(1.0 / std::sqrt((double)sum_partials(part_rr, nb, lds)));
+  if (threadIdx.x != 0) return;
+  int flag = 1;
+  if (denom == T(0) || denom != denom) { ctl->done = 1; flag = 2; }
+  else {
+    const T rz_new = rzp * rinv;
+    ctl->iters = k + 1;
+    const T arz = rz_new < T(0) ? -rz_new : rz_new;
+    if (arz > rej * ctl->rz0 || rz_new != rz_new) { ctl->done = 1; ctl->reject = 1; flag = 2; }
+    else {
+      ctl->rz0 = ctl->rz0 < arz ? ctl->rz0 : arz;
+      ctl->beta = rz_new / ctl->rz;
+      ctl->rz = rz_new;
+      ctl->rinv = rinv;
+      if (arz < tol) { ctl->done = 1; flag = 2; }
+      else if (rz_new == T(0)) { ctl->done = 1; flag = 2; } // the next trip would leave at pcg.hpp:133
+    }
+  }
+  hflag[k] = flag;
+  __threadfence_system();
+}
+// p = z / ||r|| + beta p (first: p = z / ||r||); a rejected step restores x from its backup (pcg.hpp:203-207)
+template <typename T> __global__ void k_pcg_dir(PcgCtl<T> *ctl, T *p, const T *z, T *x, const T *xb, size_t n, int first) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (ctl->reject) { if (i < n) x[i] = xb[i]; return; } // stays set for the launches enqueued ahead: they restore the same values again
+  if (ctl->done || i >= n) return;
+  p[i] = first ? z[i] * ctl->rinv : z[i] * ctl->rinv + ctl->beta * p[i];
+}
+template <typename T> struct DevicePcg {
+  hbm_vector<PcgCtl<T>> ctl;
+  hbm_vector<T> part_pap, part_rz, part_rr;
+  volatile int *hflag = nullptr;
+  size_t cap = 0;
+  int predicted = 1 << 30;
+  DevicePcg() { ctl.resize(1); part_pap.resize(DOT_BLOCKS); part_rz.resize(DOT_BLOCKS); part_rr.resize(DOT_BLOCKS); }
+  DevicePcg(const DevicePcg &) = delete;
+  ~DevicePcg() { if (hflag) (void)hipHostFree(const_cast<int *>(hflag)); }
+  static int nblocks(size_t n) { return (int)std::max<size_t>(1, std::min<size_t>(DOT_BLOCKS, (n + 4 * TPB - 1) / (4 * TPB))); }
+  void begin(size_t max_iter) {
+    if (max_iter + 1 > cap) {
+      if (hflag) (void)hipHostFree(const_cast<int *>(hflag));
+      void *q = nullptr;
+      GRAPHITE_HIP(hipHostMalloc(&q, (max_iter + 1) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+      hflag = static_cast<volatile int *>(q);
+      cap = max_iter + 1;
+    }
+    for (size_t k = 0; k <= max_iter; ++k) hflag[k] = 0;
+  }
+  // runs the loop: enqueue(k) puts iteration k's kernels into the (null) stream; returns the number of iterations executed
+  template <typename Enqueue> size_t run(size_t max_iter, Enqueue &&enqueue) {
+    size_t enq = 0, ran = 0;
+    if (max_iter > 0 && hflag[0] == 0) { enqueue(0); enq = 1; }
+    for (size_t k = 0; k < max_iter; ++k) {
+      if (k + 1 < max_iter && (int)(k + 1) < predicted && enq == k + 1) { enqueue(k + 1); ++enq; } // look-ahead
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned it = 0; __atomic_load_n(const_cast<const int *>(&hflag[k]), __ATOMIC_ACQUIRE) == 0; ++it)
+        if ((it & 0xFFFF) == 0xFFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
+          GRAPHITE_HIP(hipDeviceSynchronize()); // surfaces a kernel fault instead of hanging
+          if (hflag[k] == 0) throw std::runtime_error("PCG: timeout waiting for the device's loop decision");
+        }
+      ran = k + 1;
+      if (hflag[k] == 2) break;
+      if (k + 1 < max_iter && enq == k + 1) { enqueue(k + 1); ++enq; }
+    }
+    sync();
+    PcgCtl<T> h;
+    GRAPHITE_HIP(hipMemcpy(&h, ctl.raw(), sizeof(h), hipMemcpyDeviceToHost));
+    predicted = std::max(1, h.iters);
+    (void)ran;
+    return (size_t)h.iters;
+  }
+};
 } // namespace detail
 
 // ---- preconditioner/preconditioner.hpp:8-20 ------------------------------------------------------
@@ -125,7 +274,7 @@ public:
   void update_values(Graph<T, S> *, StreamPool &) override {}
   void set_damping_factor(Graph<T, S> *, T, const bool, StreamPool &) override {}
   void apply(Graph<T, S> *graph, T *z, const T *r, StreamPool &) override {
-    GRAPHITE_HIP(hipMemcpy(z, r, graph->get_hessian_dimension() * sizeof(T), hipMemcpyDefault));
+    GRAPHITE_HIP(hipMemcpyAsync(z, r, graph->get_hessian_dimension() * sizeof(T), hipMemcpyDeviceToDevice, nullptr));
   }
 };
 
@@ -193,6 +342,7 @@ template <typename T, typename S> class PCGSolver : public Solver<T, S> {
   T tol, rejection_ratio;
   Preconditioner<T, S> *preconditioner;
   hbm_vector<T> r, p, z, v2, diag, y, xb, scratch;
+  detail::DevicePcg<T> dev;
   T damping = 0;
   bool damping_identity = false;
   size_t iterations_ = 0;
@@ -222,41 +372,27 @@ public:
     using namespace detail;
     const size_t n = graph->get_hessian_dimension();
     if (!n) return true;
-    const int nb = blocks(n);
+    const int nb = blocks(n), nd = DevicePcg<T>::nblocks(n);
+    PcgCtl<T> *c = dev.ctl.raw();
+    dev.begin(max_iter);
     fill<T>(x, n, T(0));
-    GRAPHITE_HIP(hipMemcpy(r.raw(), graph->get_b().raw(), n * sizeof(T), hipMemcpyDefault));
-    T rnorm = std::sqrt(dot(r.raw(), r.raw(), n, scratch.raw()));
-    k_scale_copy<T><<<nb, TPB>>>(y.raw(), (T)(1.0 / rnorm), r.raw(), n);
-    preconditioner->apply(graph, z.raw(), y.raw(), streams);
-    sync();
-    GRAPHITE_HIP(hipMemcpy(p.raw(), z.raw(), n * sizeof(T), hipMemcpyDefault));
-    T rz = dot(r.raw(), z.raw(), n, scratch.raw());
-    T rz_0 = std::numeric_limits<T>::infinity();
-    iterations_ = 0;
-    for (size_t k = 0; k < max_iter; ++k) {
-      if (rz == 0) break;
+    GRAPHITE_HIP(hipMemcpyAsync(r.raw(), graph->get_b().raw(), n * sizeof(T), hipMemcpyDeviceToDevice, nullptr));
+    // z' = Minv r; rz = r . z' / ||r||; p = z' / ||r||  (pcg.hpp:114-131 with the normalisation folded into the scalars)
+    fill<int>(&c->done, 1, 0); // the dot kernels look at it
+    k_pcg_dot<T, false><<<nd, TPB>>>(c, r.raw(), r.raw(), nullptr, T(0), 0, n, dev.part_rr.raw());
+    preconditioner->apply(graph, z.raw(), r.raw(), streams);
+    k_pcg_dot<T, false><<<nd, TPB>>>(c, r.raw(), z.raw(), nullptr, T(0), 0, n, dev.part_rz.raw());
+    k_pcg_start<T, true><<<1, TPB>>>(c, dev.part_rz.raw(), dev.part_rr.raw(), nd, dev.hflag);
+    k_pcg_dir<T><<<nb, TPB>>>(c, p.raw(), z.raw(), x, xb.raw(), n, 1);
+    iterations_ = dev.run(max_iter, [&](size_t k) {
       graph->hessian_matvec(v2.raw(), p.raw());
-      k_damp<T><<<nb, TPB>>>(v2.raw(), p.raw(), diag.raw(), damping, damping_identity ? 1 : 0, n);
-      ++iterations_;
-      const T alpha = rz / dot(p.raw(), v2.raw(), n, scratch.raw());
-      GRAPHITE_HIP(hipMemcpy(xb.raw(), x, n * sizeof(T), hipMemcpyDefault));
-      k_axpy<T><<<nb, TPB>>>(x, alpha, p.raw(), n);
-      k_axpy<T><<<nb, TPB>>>(r.raw(), -alpha, v2.raw(), n);
-      rnorm = std::sqrt(dot(r.raw(), r.raw(), n, scratch.raw()));
-      k_scale_copy<T><<<nb, TPB>>>(y.raw(), (T)(1.0 / rnorm), r.raw(), n);
-      preconditioner->apply(graph, z.raw(), y.raw(), streams);
-      const T rz_new = dot(r.raw(), z.raw(), n, scratch.raw());
-      if (std::abs(rz_new) > rejection_ratio * rz_0 || std::isnan(rz_new)) {
-        GRAPHITE_HIP(hipMemcpy(x, xb.raw(), n * sizeof(T), hipMemcpyDefault));
-        break;
-      }
-      rz_0 = std::min(rz_0, std::abs(rz_new));
-      const T beta = rz_new / rz;
-      rz = rz_new;
-      k_xpby<T><<<nb, TPB>>>(p.raw(), z.raw(), beta, n);
-      if (std::abs(rz_new) < tol) break;
-    }
-    sync();
+      k_pcg_dot<T, true><<<nd, TPB>>>(c, v2.raw(), p.raw(), diag.raw(), damping, damping_identity ? 1 : 0, n, dev.part_pap.raw());
+      k_pcg_xr<T><<<nd, TPB>>>(c, dev.part_pap.raw(), nd, x, xb.raw(), r.raw(), p.raw(), v2.raw(), n, dev.part_rr.raw(), nd);
+      preconditioner->apply(graph, z.raw(), r.raw(), streams);
+      k_pcg_dot<T, false><<<nd, TPB>>>(c, r.raw(), z.raw(), nullptr, T(0), 0, n, dev.part_rz.raw());
+      k_pcg_decide<T, true><<<1, TPB>>>(c, dev.part_pap.raw(), dev.part_rz.raw(), dev.part_rr.raw(), nd, tol, rejection_ratio, (int)k, dev.hflag);
+      k_pcg_dir<T><<<nb, TPB>>>(c, p.raw(), z.raw(), x, xb.raw(), n, 0);
+    });
     return true;
   }
 };
@@ -343,6 +479,7 @@ template <typename T, typename S> class PCGSchurSolver : public Solver<T, S> {
   SchurComplement<T, S> schur;
   SchurPreconditioner<T, S> *preconditioner;
   hbm_vector<T> r, p, z, Ap, xb, scratch;
+  detail::DevicePcg<T> dev;
   size_t max_iter, iterations_ = 0;
   T tol, rejection_ratio;
 public:
@@ -374,37 +511,25 @@ public:
     if (!n) return true;
     schur.update_values(graph, streams); // S depends on the damping: reduced here, as pcg_schur.hpp:84 does
     preconditioner->update_values(graph, &schur, streams);
-    const int nb = blocks(pd);
+    const int nb = blocks(pd), nd = DevicePcg<T>::nblocks(pd);
+    PcgCtl<T> *c = dev.ctl.raw();
+    dev.begin(max_iter);
     fill<T>(x, n, T(0));
-    GRAPHITE_HIP(hipMemcpy(r.raw(), schur.get_b_Schur().raw(), pd * sizeof(T), hipMemcpyDefault));
+    GRAPHITE_HIP(hipMemcpyAsync(r.raw(), schur.get_b_Schur().raw(), pd * sizeof(T), hipMemcpyDeviceToDevice, nullptr));
+    fill<int>(&c->done, 1, 0);
     preconditioner->apply(graph, &schur, z.raw(), r.raw(), streams);
-    sync();
-    GRAPHITE_HIP(hipMemcpy(p.raw(), z.raw(), pd * sizeof(T), hipMemcpyDefault));
-    T rz = dot(r.raw(), z.raw(), pd, scratch.raw());
-    T rz_0 = std::numeric_limits<T>::infinity();
-    iterations_ = 0;
-    for (size_t k = 0; k < max_iter; ++k) {
-      if (rz == 0) break;
+    k_pcg_dot<T, false><<<nd, TPB>>>(c, r.raw(), z.raw(), nullptr, T(0), 0, pd, dev.part_rz.raw());
+    k_pcg_start<T, false><<<1, TPB>>>(c, dev.part_rz.raw(), nullptr, nd, dev.hflag);
+    k_pcg_dir<T><<<nb, TPB>>>(c, p.raw(), z.raw(), x, xb.raw(), pd, 1);
+    iterations_ = dev.run(max_iter, [&](size_t k) {
       schur.execute_schur_vector_multiply(graph, streams, Ap.raw(), p.raw());
-      const T denom = dot(p.raw(), Ap.raw(), pd, scratch.raw());
-      if (denom == 0 || std::isnan(denom)) break;
-      ++iterations_;
-      const T alpha = rz / denom;
-      GRAPHITE_HIP(hipMemcpy(xb.raw(), x, pd * sizeof(T), hipMemcpyDefault));
-      k_axpy<T><<<nb, TPB>>>(x, alpha, p.raw(), pd);
-      k_axpy<T><<<nb, TPB>>>(r.raw(), -alpha, Ap.raw(), pd);
+      k_pcg_dot<T, false><<<nd, TPB>>>(c, Ap.raw(), p.raw(), nullptr, T(0), 0, pd, dev.part_pap.raw());
+      k_pcg_xr<T><<<nd, TPB>>>(c, dev.part_pap.raw(), nd, x, xb.raw(), r.raw(), p.raw(), Ap.raw(), pd, dev.part_rr.raw(), nd);
       preconditioner->apply(graph, &schur, z.raw(), r.raw(), streams);
-      const T rz_new = dot(r.raw(), z.raw(), pd, scratch.raw());
-      if (std::abs(rz_new) > rejection_ratio * rz_0 || std::isnan(rz_new)) {
-        GRAPHITE_HIP(hipMemcpy(x, xb.raw(), pd * sizeof(T), hipMemcpyDefault));
-        break;
-      }
-      rz_0 = std::min(rz_0, std::abs(rz_new));
-      const T beta = rz_new / rz;
-      rz = rz_new;
-      k_xpby<T><<<nb, TPB>>>(p.raw(), z.raw(), beta, pd);
-      if (std::abs(rz_new) < tol) break;
-    }
+      k_pcg_dot<T, false><<<nd, TPB>>>(c, r.raw(), z.raw(), nullptr, T(0), 0, pd, dev.part_rz.raw());
+      k_pcg_decide<T, false><<<1, TPB>>>(c, dev.part_pap.raw(), dev.part_rz.raw(), nullptr, nd, tol, rejection_ratio, (int)k, dev.hflag);
+      k_pcg_dir<T><<<nb, TPB>>>(c, p.raw(), z.raw(), x, xb.raw(), pd, 0);
+    });
     schur.compute_landmark_update(graph, streams, x + pd, x);
     sync();
     return true;
