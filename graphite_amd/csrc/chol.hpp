@@ -493,11 +493,11 @@ template <typename T> struct DenseChol {
   int *h_fail = nullptr;
   CholProfSink *sink = nullptr;
   bool attrs_set = false;
-  bool fuse_potrf = !(getenv("GR_CHOL_FUSE") && atoi(getenv("GR_CHOL_FUSE")) == 0); // A/B knob
+  bool fuse_potrf = true; // gr_bal_tuning.chol_fuse (the next diagonal tile factorised inside the trailing update: 43.5 -> 39.4 ms on n = 15 507)
   // PIN = 1 keeps the C tile in VGPRs until the loop (one workgroup per CU in fp64): measured 7 % faster in
   // fp64 and on par in fp32 against the AGPR-pinned, two-workgroup variant (A/B in one run, n = 15507)
-  int pin_variant = getenv("GR_CHOL_PIN") ? atoi(getenv("GR_CHOL_PIN")) : 1;
-  int potrf_skip = getenv("GR_CHOL_POTRF_SKIP") ? atoi(getenv("GR_CHOL_POTRF_SKIP")) : 0; // timing ablation only
+  int pin_variant = 1;    // gr_bal_tuning.chol_pin
+  int potrf_skip = 0;     // timing ablation of chol_potrf_block's phases (tools/potrf_bench.hip sets it; never set by the product)
 
   DenseChol() = default;
   DenseChol(const DenseChol &) = delete;

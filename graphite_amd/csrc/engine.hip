@@ -49,6 +49,10 @@ static void tuning_default(gr_bal_tuning &t) {
   t.verbose = getenv("GR_VERBOSE") ? 1 : 0;
   t.ipc_timeout_ms = env_int("GR_IPC_TIMEOUT_MS", 30000);
   t.shard_fused = env_int("GR_SHARD_FUSED", -1);
+  t.chol_fuse = env_int("GR_CHOL_FUSE", 1);
+  t.chol_pin = env_int("GR_CHOL_PIN", 1);
+  t.spchol_fuse = env_int("GR_SPCHOL_FUSE", 1);
+  t.spchol_slice = std::max(1, env_int("GR_SPCHOL_SLICE", 2));
 }
 
 // GR_VERBOSE: host laps of the set-up phases (gr_bal_create is what a drop-in user waits for before the first iteration)
@@ -1241,6 +1245,8 @@ template <typename T> struct Engine final : EngineBase {
     if (chol_ready) return;
     {
       const int force = tune.sparse_cholesky;
+      spchol.fuse_potrf = tune.spchol_fuse != 0; spchol.slice = std::max(1, tune.spchol_slice);
+      chol.fuse_potrf = tune.chol_fuse != 0; chol.pin_variant = tune.chol_pin;
       // what either form may take: 3/4 of the free HBM (the factor is the largest single allocation of the direct solvers)
       size_t mem_free = 0, mem_total = 0;
       GR_HIP(hipMemGetInfo(&mem_free, &mem_total));

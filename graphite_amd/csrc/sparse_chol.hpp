@@ -196,13 +196,13 @@ template <typename T> __global__ void k_sp_unpermute(int npad, const int *__rest
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < npad && src[i] >= 0) x[src[i]] = vx[i];
 }
-// Substitution kernels.  A level's panels are cut into work ITEMS (panel k, a slice of <= SP_SLICE tiles of its row
+// Substitution kernels.  A level's panels are cut into work ITEMS (panel k, a slice of <= slice tiles of its row
 // list / column list), one workgroup per item: the long rows of the separator columns near the root (a hundred tiles)
 // are spread over many workgroups instead of one.  An item leaves its 128 partial sums in `partial`; the item that
 // arrives LAST at the panel's ticket adds them in item order (fixed order: reproducible) and finishes the panel.
 // Visibility across XCDs: write-through (agent-scope relaxed atomic) stores, drained, then a relaxed ticket; the last
 // arriver reads with agent-scope loads (cdna_hip_programming.md G16, form R1) — the same hand-off as grid_sum2.
-static const int SP_SLICE = getenv("GR_SPCHOL_SLICE") ? std::max(1, atoi(getenv("GR_SPCHOL_SLICE"))) : 2; // tiles per substitution item (A/B knob; 6 -> 2: 249 -> 260 LM it/s)
+// tiles per substitution item: SparseChol::slice (gr_bal_tuning.spchol_slice; 6 -> 2: 249 -> 260 LM it/s on Ladybug-1723)
 struct SpItems { const int *panel, *beg, *end, *first, *count; int base; }; // per item: panel, slice, first item / item count of its panel (absolute item ids); base = id of this launch's item 0
 template <typename T> __device__ __forceinline__ bool sp_last_arriver(T val, bool writer, T *__restrict__ partial, int item, int idx, unsigned *__restrict__ ticket, int panel, int count) {
   __shared__ bool s_last;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, const T
 // backward: x_k = Linv_k^T (y_k - sum_{i in col(k)} L_ik^T x_i)
 // (Measured and removed: ONE launch for all levels with an in-kernel grid barrier between them, x exchanged through
 // agent-scope atomics — 246-250 LM it/s either way on Ladybug-1723: a level's 20 us are the cold reads of its L tiles by a
-// few workgroups, not the launch boundary.  What did help is more, smaller items per panel: SP_SLICE 6 -> 2, 249 -> 260.)
+// few workgroups, not the launch boundary.  What did help is more, smaller items per panel: slice 6 -> 2, 249 -> 260.)
 template <typename T>
 __global__ __launch_bounds__(256) void k_sp_bwd(const T *__restrict__ A, const T *__restrict__ Linv, SpItems it, const int *__restrict__ crows, const int *__restrict__ cslot,
                                                 const T *__restrict__ y, T *__restrict__ x, T *__restrict__ partial, unsigned *__restrict__ ticket) {
@@ -320,7 +320,8 @@ template <typename T> struct SparseChol {
   CholProfSink *sink = nullptr;
   bool attrs_set = false;
   static constexpr int LEAF = 56; // cameras per leaf supernode: 504 columns = 4 tiles (8 padding columns)
-  bool fuse_potrf = !(getenv("GR_SPCHOL_FUSE") && atoi(getenv("GR_SPCHOL_FUSE")) == 0); // A/B knob
+  bool fuse_potrf = true; // gr_bal_tuning.spchol_fuse: the next level's diagonal tiles factorised inside this level's update launch
+  int slice = 2;          // gr_bal_tuning.spchol_slice: tiles per substitution work item
 
   SparseChol() = default;
   SparseChol(const SparseChol &) = delete;
@@ -470,7 +471,7 @@ template <typename T> struct SparseChol {
       lvl_trsm_off.push_back((int)(h_trsm.size() / 2));
       lvl_upd_off.push_back((int)(h_upd.size() / 2));
     }
-    // row structure (forward substitution) and column structure (backward), cut into items of <= SP_SLICE tiles
+    // row structure (forward substitution) and column structure (backward), cut into items of <= slice tiles
     std::vector<int> h_rptr(nt + 1, 0), h_rcols, h_rslot, h_cptr(nt + 1, 0), h_crows, h_cslot;
     for (int k = 0; k < nt; ++k) {
       for (int j = 0; j < k; ++j) if (nz(k, j)) { h_rcols.push_back(j); h_rslot.push_back(slot(k, j)); }
@@ -481,9 +482,9 @@ template <typename T> struct SparseChol {
     std::vector<int> it_f[5], it_b[5]; // panel, beg, end, first, count
     lvl_fitem_off.assign(1, 0); lvl_bitem_off.assign(1, 0);
     auto cut = [&](std::vector<int> (&it)[5], int k, int beg, int end) {
-      const int cnt = std::max(1, (end - beg + SP_SLICE - 1) / SP_SLICE), first = (int)it[0].size();
+      const int cnt = std::max(1, (end - beg + slice - 1) / slice), first = (int)it[0].size();
       for (int q = 0; q < cnt; ++q) {
-        it[0].push_back(k); it[1].push_back(std::min(end, beg + q * SP_SLICE)); it[2].push_back(std::min(end, beg + (q + 1) * SP_SLICE));
+        it[0].push_back(k); it[1].push_back(std::min(end, beg + q * slice)); it[2].push_back(std::min(end, beg + (q + 1) * slice));
         it[3].push_back(first); it[4].push_back(cnt);
       }
     };

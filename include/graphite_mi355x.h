@@ -140,7 +140,11 @@ typedef struct {
                                    all-reduce                                                                                    */
   int32_t shard_virtual_ranks;  /* PROJECTION ONLY (tools/shard_projection.py): on a ONE-rank mailbox communicator the fused message is
                                    pushed / awaited / summed as if V ranks took part (V slots of the own mailbox)                    */
-  int32_t reserved[3];
+  int32_t chol_fuse;            /* GR_CHOL_FUSE      1: dense tile Cholesky factorises the next diagonal tile inside the trailing update   */
+  int32_t chol_pin;             /* GR_CHOL_PIN       1: its C tile parked in VGPRs (one workgroup per CU in fp64)                          */
+  int32_t spchol_fuse;          /* GR_SPCHOL_FUSE    1: the same fusion in the nested-dissection form                                      */
+  int32_t spchol_slice;         /* GR_SPCHOL_SLICE   2: tiles per work item of its triangular solves                                       */
+  int32_t reserved[4];
 } gr_bal_tuning;
 void gr_bal_tuning_default(gr_bal_tuning *t);
 
