@@ -97,8 +97,8 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
 // 16x16 diagonal sub-blocks are sequential (one wave, rows in registers, readlane broadcasts) and
 // everything else (sub-panel solve, trailing update, blocked inverse) is 16x16x4 MFMA on LDS data.
 // X^T lives in the unused strictly-upper part of the same LDS image; the diagonal of X in xd[].
-// Writes L back into A (lower part) and X as a full 128x128 row-major matrix (zeros above the
-// diagonal) for the panel GEMM and the solves.  A pivot that is not > 0 raises *fail and is
+// Writes the lower triangle of X into `Linv` (a 128x128 row-major matrix whose strictly upper part stays zero from its
+// allocation) for the panel GEMM and the solves; L_kk itself is not stored: nothing reads it again.  A pivot that is not > 0 raises *fail and is
 // replaced by 1 so that the rest stays finite.
 // `L` is the LDS image [128][129] (+128 for the diagonal of X); with `load` it is filled from the global
 // tile first, otherwise the caller has already put the lower triangle (zeros above) there.
@@ -115,6 +115,32 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
       L[r * CH_LP + c] = c <= r ? Ag[(size_t)r * ld + c] : T(0);
     }
   __syncthreads();
+  // blocked inverse, block (i, j), j < i: X_ij = -X_ii sum_{k=j}^{i-1} L_ik X_kj.  Row i needs the diagonal step i (X_ii), the
+  // sub-panel solves of the steps before it (L_ik) and the rows of X above it: it is computed by waves 1 .. 3 WHILE wave 0 runs
+  // the serial diagonal step i + 1 (they used to idle through the eight 3.25 us steps, and the inverse then cost 12 us of its own)
+  auto inverse_block = [&](int i, int j) {
+    acc_t tacc = {T(0), T(0), T(0), T(0)};
+    for (int k = j; k < i; ++k) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int kr = 4 * kk + g;
+        const T av = L[(16 * i + cl) * CH_LP + 16 * k + kr];
+        T bv;
+        if (k == j) bv = kr > cl ? L[(16 * j + cl) * CH_LP + 16 * j + kr] : (kr == cl ? xd[16 * j + cl] : T(0));
+        else bv = L[(16 * j + cl) * CH_LP + 16 * k + kr];
+        tacc = M::mma(av, bv, tacc);
+      }
+    }
+    acc_t xacc = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int kr = M::row(lane, kk); // the row of T this lane holds in register kk is the k it feeds
+      const T av = cl > kr ? L[(16 * i + kr) * CH_LP + 16 * i + cl] : (cl == kr ? xd[16 * i + cl] : T(0));
+      xacc = M::mma(av, tacc[kk], xacc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) L[(16 * j + cl) * CH_LP + 16 * i + M::row(lane, r)] = -xacc[r];
+  };
   for (int s = 0; s < NB16; ++s) {
     const int o = 16 * s;
     if (wave == 0 && !(skip & 1)) {
@@ -148,6 +174,9 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
         xd[o + cl] = x[cl];
       }
       if (bad && lane == 0) *fail = 1;
+    }
+    else if (wave != 0 && s >= 2 && !(skip & 4)) {
+      for (int j = wave - 1; j < s - 1; j += NW - 1) inverse_block(s - 1, j); // row s - 1: complete since the barrier that ended step s - 1
     }
     __syncthreads();
     // sub-panel solve: L_is = A_is X_ss^T for the 16-row blocks below
@@ -183,50 +212,33 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
     }
     __syncthreads();
   }
-  // blocked inverse: X_ij = -X_ii sum_{k=j}^{i-1} L_ik X_kj, block row by block row
-  for (int i = 1; i < NB16 && !(skip & 4); ++i) {
-    for (int j = wave; j < i; j += NW) {
-      acc_t tacc = {T(0), T(0), T(0), T(0)};
-      for (int k = j; k < i; ++k) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int kr = 4 * kk + g;
-          const T av = L[(16 * i + cl) * CH_LP + 16 * k + kr];
-          T bv;
-          if (k == j) bv = kr > cl ? L[(16 * j + cl) * CH_LP + 16 * j + kr] : (kr == cl ? xd[16 * j + cl] : T(0));
-          else bv = L[(16 * j + cl) * CH_LP + 16 * k + kr];
-          tacc = M::mma(av, bv, tacc);
-        }
-      }
-      acc_t xacc = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int kr = M::row(lane, kk); // the row of T this lane holds in register kk is the k it feeds
-        const T av = cl > kr ? L[(16 * i + kr) * CH_LP + 16 * i + cl] : (cl == kr ? xd[16 * i + cl] : T(0));
-        xacc = M::mma(av, tacc[kk], xacc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) L[(16 * j + cl) * CH_LP + 16 * i + M::row(lane, r)] = -xacc[r];
-    }
+  // the last row of the inverse has nothing left to hide behind
+  if (!(skip & 4)) {
+    for (int j = wave; j < NB16 - 1; j += NW) inverse_block(NB16 - 1, j);
     __syncthreads();
   }
   if (skip & 8) return;
-  // write-back, 8 elements per thread and pass with all LDS reads ahead of the stores (one element per pass: 64 dependent
-  // LDS-read -> store round trips, 8.7 us of the 59 us this block costs inside k_sp_gemm)
-  constexpr int WB = 8;
-  for (int e0 = t; e0 < CH_NB * CH_NB; e0 += CH_PT * WB) {
-    T lv[WB], xv[WB];
+  // Write-back: ONLY the lower triangle of X = L^-1 (8 256 of the 32 768 scalars the block used to store).  L_kk itself is read
+  // by nobody once the panel is solved with X (the panel GEMM and both triangular solves use X), and the strictly upper part of
+  // X is zero: the buffer is zeroed when it is allocated and never written above the diagonal.  One wave per row, 8 rows in
+  // flight per wave, all LDS reads ahead of the stores.
+  (void)Ag; (void)ld;
+  constexpr int RB = 8;
+  for (int r0 = wave; r0 < CH_NB; r0 += NW * RB) {
 #pragma unroll
-    for (int u = 0; u < WB; ++u) {
-      const int e = e0 + u * CH_PT, r = e >> 7, cc = e & 127;
-      lv[u] = L[r * CH_LP + cc];
-      xv[u] = cc < r ? L[cc * CH_LP + r] : (cc == r ? xd[r] : T(0));
-    }
+    for (int half = 0; half < 2; ++half) {
+      T xv[RB];
+      const int cc = 64 * half + lane;
 #pragma unroll
-    for (int u = 0; u < WB; ++u) {
-      const int e = e0 + u * CH_PT, r = e >> 7, cc = e & 127;
-      if (cc <= r) Ag[(size_t)r * ld + cc] = lv[u];
-      Linv[e] = xv[u];
+      for (int u = 0; u < RB; ++u) {
+        const int r = r0 + u * NW;
+        xv[u] = (r < CH_NB && cc < r) ? L[cc * CH_LP + r] : ((r < CH_NB && cc == r) ? xd[r] : T(0));
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int r = r0 + u * NW;
+        if (r < CH_NB && cc <= r) Linv[r * CH_NB + cc] = xv[u];
+      }
     }
   }
 }
@@ -572,6 +584,7 @@ template <typename T> struct DenseChol {
     if (h_pairs.empty()) { h_pairs.push_back(0); h_pairs.push_back(0); }
     d_rows.upload(h_rows, stream); d_pairs.upload(h_pairs, stream); d_nz.upload(h_nz, stream);
     A.alloc((size_t)npad * npad); Linv.alloc((size_t)nt * CH_NB * CH_NB);
+    Linv.zero(stream); // chol_potrf_block writes the lower triangle of every inverse only
     vb.alloc(npad); vy.alloc(npad); vx.alloc(npad); partial.alloc((size_t)std::max(max_rows, 1) * CH_NB);
     d_fail.alloc(1);
     if (!h_fail) GR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_fail), sizeof(int), hipHostMallocDefault));

@@ -164,6 +164,71 @@ __global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, const int *_
         Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld2 + wc * 64 + ni * 16 + ccol] = acc[mi][ni][r];
 }
 
+
+// Panel solve, ROW-SPLIT: L_ik = A_ik Linv_k^T with one workgroup per 32-row slab of the tile (tiles[2 (b / 4)] = slot(i, k),
+// tiles[2 (b / 4) + 1] = k, slab b % 4), in place: a slab only reads its own rows of A_ik.  The upper levels of the tree hold a
+// handful of tiles, and one workgroup per 128 x 128 x 128 product is 26 us of a chain that runs 21 times per factorisation
+// (14 us of MFMA on ONE CU + launch + cold loads); four slabs on four CUs divide the MFMA work and read Linv_k (128 KB) once
+// each from L2.  Wave w computes columns [32 w, 32 w + 32) of the slab: 2 x 2 MFMA tiles, K in chunks of 16 through LDS.
+constexpr int SP_SLAB = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void k_sp_trsm_rows(T *__restrict__ A, const int *__restrict__ tiles, const T *__restrict__ Linv) {
+  using M = MfmaTile<T>;
+  typedef typename M::acc_t acc_t;
+  constexpr int KC = CH_KC, NCH = CH_NB / KC, PP = SP_SLAB + 4; // LDS pitch of the [k][row] slab image
+  __shared__ T Ps[2][KC * PP];
+  __shared__ T Qs[2][KC * CH_LDP];
+  const int tile = blockIdx.x >> 2, slab = blockIdx.x & 3;
+  T *Cg = A + (size_t)tiles[2 * tile] * SP_TT + (size_t)slab * SP_SLAB * CH_NB;
+  const T *Qg = Linv + (size_t)tiles[2 * tile + 1] * SP_TT;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, ccol = lane & 15;
+  // loaders: Q chunk = 128 rows x 16 k: thread -> (row t / 2, 8 k's); P chunk = 32 rows x 16 k: thread -> (row t / 8, 2 k's)
+  const int qr = t >> 1, qk = (t & 1) * 8, pr = t >> 3, pk = (t & 7) * 2;
+  T q8[8], p2[2];
+  auto fetch = [&](int c) {
+    load8<T>(Qg + (size_t)qr * CH_NB + c * KC + qk, q8);
+    p2[0] = Cg[(size_t)pr * CH_NB + c * KC + pk]; p2[1] = Cg[(size_t)pr * CH_NB + c * KC + pk + 1];
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Qs[buf][(qk + e) * CH_LDP + qr] = q8[e];
+    Ps[buf][pk * PP + pr] = p2[0]; Ps[buf][(pk + 1) * PP + pr] = p2[1];
+  };
+  acc_t acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = acc_t{T(0), T(0), T(0), T(0)};
+  fetch(0);
+  stage(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) fetch(c + 1);
+    const T *P = Ps[c & 1], *Q = Qs[c & 1];
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      const int k = kk * 4 + (lane >> 4);
+      T a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { a[i] = P[k * PP + i * 16 + ccol]; b[i] = Q[k * CH_LDP + wave * 32 + i * 16 + ccol]; }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = M::mma(a[mi], b[ni], acc[mi][ni]);
+    }
+    if (c + 1 < NCH) stage((c + 1) & 1);
+    __syncthreads();
+  }
+  // every read of the slab's rows happened before the last barrier: the in-place store is safe
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cg[(size_t)(mi * 16 + M::row(lane, r)) * CH_NB + wave * 32 + ni * 16 + ccol] = acc[mi][ni][r];
+}
+
 // permuted scatter of the upper 9x9 blocks of S (column-major blocks, block (i <= j)) into the lower triangle;
 // camcol[c] = first (padded, permuted) column of camera c
 template <typename T>
@@ -322,6 +387,7 @@ template <typename T> struct SparseChol {
   static constexpr int LEAF = 56; // cameras per leaf supernode: 504 columns = 4 tiles (8 padding columns)
   bool fuse_potrf = true; // gr_bal_tuning.spchol_fuse: the next level's diagonal tiles factorised inside this level's update launch
   int slice = 2;          // gr_bal_tuning.spchol_slice: tiles per substitution work item
+  bool row_split_trsm = true; // panel solves by 32-row slabs (k_sp_trsm_rows)
 
   SparseChol() = default;
   SparseChol(const SparseChol &) = delete;
@@ -517,6 +583,7 @@ template <typename T> struct SparseChol {
   // the tiles, the tile inverses and the substitution vectors: only after the caller's memory guard / solver choice
   void allocate() {
     A.alloc((size_t)nz_tiles * SP_TT); Linv.alloc((size_t)nt * SP_TT);
+    Linv.zero(stream); // chol_potrf_block writes the lower triangle of every inverse only
     vb.alloc(npad); vy.alloc(npad); vx.alloc(npad);
   }
 
@@ -543,7 +610,8 @@ template <typename T> struct SparseChol {
       }
       if (ntr) {
         Sc sc(sink, "spchol_trsm", 3.0 * ntr * tb, ntr * tf);
-        k_sp_gemm<T, 0><<<ntr, 256, lds_g, stream>>>(A.p, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], nullptr, nullptr, Linv.p);
+        if (row_split_trsm) k_sp_trsm_rows<T><<<4 * ntr, 256, 0, stream>>>(A.p, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], Linv.p);
+        else k_sp_gemm<T, 0><<<ntr, 256, lds_g, stream>>>(A.p, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], nullptr, nullptr, Linv.p);
       }
       if (nup) {
         const int nk = h_kptr[lvl_upd_off[l + 1]] - h_kptr[lvl_upd_off[l]];
