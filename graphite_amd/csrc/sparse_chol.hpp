@@ -49,23 +49,20 @@ __global__ __launch_bounds__(CH_PT) void k_sp_potrf(T *__restrict__ A, const int
 // Linv_out = the per-panel inverse array, so the next level needs no factorisation launch of its own and the
 // 75 us diagonal-block factorisation overlaps with the other updates of this launch.
 constexpr int SP_FUSE_BIT = 1 << 30;
+// One tile product on the 128x128x16 MFMA pipeline of k_chol_gemm.
+//   MODE 0: C = C Linv^T in place (Q0 = Linv_k)                                        [kept for A/B: the level kernels use k_sp_trsm_rows]
+//   MODE 1: C -= sum over the nk (slotP, slotQ) pairs of kl of P Q^T; `fuse`: C is a diagonal tile whose LAST update this is —
+//           its lower triangle goes from the accumulators straight into the LDS image and is factorised on the spot
+//           (chol_potrf_block), Linv_out = where its inverse goes; nothing is stored to C then.
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, const int *__restrict__ tiles, const int *__restrict__ kptr, const int *__restrict__ klist,
-                                                 const T *__restrict__ Linv, T *__restrict__ Linv_out = nullptr, int *__restrict__ fail = nullptr) {
-  extern __shared__ __align__(16) unsigned char ch_smem[];
-  T *sm = reinterpret_cast<T *>(ch_smem);
+__device__ __forceinline__ void sp_tile_product(T *__restrict__ sm, T *__restrict__ A, T *__restrict__ Cg, const int *__restrict__ kl, int nk,
+                                                const T *__restrict__ Q0, bool fuse, T *__restrict__ Linv_out, int *__restrict__ fail) {
   using M = MfmaTile<T>;
   typedef typename M::acc_t acc_t;
   constexpr int KC = CH_KC, CPP = CH_NB / KC; // chunks per panel
   constexpr int ld = CH_NB;
-  const int cs_raw = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1]; // MODE 0: tj = panel k; MODE 1: tj = tile row / column of a diagonal target
-  const int cslot = cs_raw & ~SP_FUSE_BIT;
-  const bool fuse = MODE == 1 && (cs_raw & SP_FUSE_BIT) != 0;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-  const int *kl = MODE == 1 ? klist + 2 * (size_t)kptr[blockIdx.x] : nullptr;
-  const int nch = MODE == 1 ? CPP * (kptr[blockIdx.x + 1] - kptr[blockIdx.x]) : CPP;
-  T *Cg = A + (size_t)cslot * SP_TT;
-  const T *Q0 = MODE == 0 ? Linv + (size_t)tj * SP_TT : nullptr;
+  const int nch = MODE == 1 ? CPP * nk : CPP;
   // chunk c of the K loop: rows of P / Q start at ptile(c) / qtile(c), its KC columns at kcol(c)
   auto ptile = [&](int c) -> const T * { return MODE == 1 ? A + (size_t)kl[2 * (c / CPP)] * SP_TT : Cg; };
   auto qtile = [&](int c) -> const T * { return MODE == 1 ? A + (size_t)kl[2 * (c / CPP) + 1] * SP_TT : Q0; };
@@ -150,7 +147,7 @@ __global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, const int *_
           const int row = wr * 64 + mi * 16 + M::row(lane, r), col = wc * 64 + ni * 16 + ccol;
           L[row * CH_LP + col] = col <= row ? acc[mi][ni][r] : T(0);
         }
-    chol_potrf_block<T>(L, Cg, ld, Linv_out + (size_t)tj * SP_TT, fail, false, 0);
+    chol_potrf_block<T>(L, Cg, ld, Linv_out, fail, false, 0);
     return;
   }
   int ld2 = ld;
@@ -163,40 +160,56 @@ __global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, const int *_
       for (int r = 0; r < 4; ++r)
         Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld2 + wc * 64 + ni * 16 + ccol] = acc[mi][ni][r];
 }
+// the level-scheduled launches:
+// MODE 0: L_ik = A_ik Linv_k^T for tiles[2b] = slot(i, k), tiles[2b+1] = k                       (panel solve, in place)
+// MODE 1: A_ij -= sum_{k in list(b)} L_ik L_jk^T, tiles[2b] = slot(i, j) [| FUSE bit], tiles[2b+1] = i,
+//         list(b) = klist[2 q], klist[2 q + 1] = slot(i, k), slot(j, k) for q in kptr[b] .. kptr[b+1])
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, const int *__restrict__ tiles, const int *__restrict__ kptr, const int *__restrict__ klist,
+                                                 const T *__restrict__ Linv, T *__restrict__ Linv_out = nullptr, int *__restrict__ fail = nullptr) {
+  extern __shared__ __align__(16) unsigned char ch_smem[];
+  const int cs_raw = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1]; // MODE 0: tj = panel k; MODE 1: tj = tile row / column of a diagonal target
+  const bool fuse = MODE == 1 && (cs_raw & SP_FUSE_BIT) != 0;
+  sp_tile_product<T, MODE>(reinterpret_cast<T *>(ch_smem), A, A + (size_t)(cs_raw & ~SP_FUSE_BIT) * SP_TT,
+                           MODE == 1 ? klist + 2 * (size_t)kptr[blockIdx.x] : nullptr, MODE == 1 ? kptr[blockIdx.x + 1] - kptr[blockIdx.x] : 0,
+                           MODE == 0 ? Linv + (size_t)tj * SP_TT : nullptr, fuse, fuse ? Linv_out + (size_t)tj * SP_TT : nullptr, fail);
+}
 
-
-// Panel solve, ROW-SPLIT: L_ik = A_ik Linv_k^T with one workgroup per 32-row slab of the tile (tiles[2 (b / 4)] = slot(i, k),
-// tiles[2 (b / 4) + 1] = k, slab b % 4), in place: a slab only reads its own rows of A_ik.  The upper levels of the tree hold a
+// Panel solve, ROW-SPLIT: L_ik = A_ik Linv_k^T with one workgroup per SP_SLAB-row slab of the tile (tiles[2 t] = slot(i, k),
+// tiles[2 t + 1] = k for tile t = b / slabs-per-tile, slab b % slabs-per-tile), in place: a slab only reads its own rows of A_ik.  The upper levels of the tree hold a
 // handful of tiles, and one workgroup per 128 x 128 x 128 product is 26 us of a chain that runs 21 times per factorisation
 // (14 us of MFMA on ONE CU + launch + cold loads); four slabs on four CUs divide the MFMA work and read Linv_k (128 KB) once
 // each from L2.  Wave w computes columns [32 w, 32 w + 32) of the slab: 2 x 2 MFMA tiles, K in chunks of 16 through LDS.
-constexpr int SP_SLAB = 32;
+constexpr int SP_SLAB = 32; // rows per slab (panel-solve launch on Ladybug-1723: 25.9 us unsplit, 15.4 us with 32-row slabs, 15.6 us with 16-row slabs)
+constexpr size_t sp_trsm_lds(size_t w) { return (size_t)2 * CH_KC * (SP_SLAB + 4 + CH_LDP) * w; }
+// Cg: the slab's first row inside its tile; Qg: Linv_k; sm: sp_trsm_lds bytes of LDS
 template <typename T>
-__global__ __launch_bounds__(256) void k_sp_trsm_rows(T *__restrict__ A, const int *__restrict__ tiles, const T *__restrict__ Linv) {
+__device__ __forceinline__ void sp_trsm_slab(T *__restrict__ sm, T *__restrict__ Cg, const T *__restrict__ Qg) {
   using M = MfmaTile<T>;
   typedef typename M::acc_t acc_t;
-  constexpr int KC = CH_KC, NCH = CH_NB / KC, PP = SP_SLAB + 4; // LDS pitch of the [k][row] slab image
-  __shared__ T Ps[2][KC * PP];
-  __shared__ T Qs[2][KC * CH_LDP];
-  const int tile = blockIdx.x >> 2, slab = blockIdx.x & 3;
-  T *Cg = A + (size_t)tiles[2 * tile] * SP_TT + (size_t)slab * SP_SLAB * CH_NB;
-  const T *Qg = Linv + (size_t)tiles[2 * tile + 1] * SP_TT;
+  constexpr int KC = CH_KC, NCH = CH_NB / KC, PP = SP_SLAB + 4, MI = SP_SLAB / 16; // LDS pitch of the [k][row] slab image; MFMA row tiles
+  constexpr int PE = SP_SLAB * KC / 256;                                            // slab scalars per thread and chunk (2 or 1)
+  static_assert(SP_SLAB == 16 || SP_SLAB == 32, "slab of 16 or 32 rows");
+  T (*Ps)[KC * PP] = reinterpret_cast<T (*)[KC * PP]>(sm);
+  T (*Qs)[KC * CH_LDP] = reinterpret_cast<T (*)[KC * CH_LDP]>(sm + 2 * KC * PP);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, ccol = lane & 15;
-  // loaders: Q chunk = 128 rows x 16 k: thread -> (row t / 2, 8 k's); P chunk = 32 rows x 16 k: thread -> (row t / 8, 2 k's)
-  const int qr = t >> 1, qk = (t & 1) * 8, pr = t >> 3, pk = (t & 7) * 2;
-  T q8[8], p2[2];
+  // loaders: Q chunk = 128 rows x 16 k: thread -> (row t / 2, 8 k's); P chunk = SLAB rows x 16 k: thread -> (row, PE consecutive k's)
+  const int qr = t >> 1, qk = (t & 1) * 8, pr = t / (KC / PE), pk = (t % (KC / PE)) * PE;
+  T q8[8], p2[PE];
   auto fetch = [&](int c) {
     load8<T>(Qg + (size_t)qr * CH_NB + c * KC + qk, q8);
-    p2[0] = Cg[(size_t)pr * CH_NB + c * KC + pk]; p2[1] = Cg[(size_t)pr * CH_NB + c * KC + pk + 1];
+#pragma unroll
+    for (int e = 0; e < PE; ++e) p2[e] = Cg[(size_t)pr * CH_NB + c * KC + pk + e];
   };
   auto stage = [&](int buf) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) Qs[buf][(qk + e) * CH_LDP + qr] = q8[e];
-    Ps[buf][pk * PP + pr] = p2[0]; Ps[buf][(pk + 1) * PP + pr] = p2[1];
-  };
-  acc_t acc[2][2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+    for (int e = 0; e < PE; ++e) Ps[buf][(pk + e) * PP + pr] = p2[e];
+  };
+  acc_t acc[MI][2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = acc_t{T(0), T(0), T(0), T(0)};
   fetch(0);
@@ -209,11 +222,13 @@ __global__ __launch_bounds__(256) void k_sp_trsm_rows(T *__restrict__ A, const i
 #pragma unroll
     for (int kk = 0; kk < KC / 4; ++kk) {
       const int k = kk * 4 + (lane >> 4);
-      T a[2], b[2];
+      T a[MI], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { a[i] = P[k * PP + i * 16 + ccol]; b[i] = Q[k * CH_LDP + wave * 32 + i * 16 + ccol]; }
+      for (int i = 0; i < MI; ++i) a[i] = P[k * PP + i * 16 + ccol];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int i = 0; i < 2; ++i) b[i] = Q[k * CH_LDP + wave * 32 + i * 16 + ccol];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = M::mma(a[mi], b[ni], acc[mi][ni]);
     }
@@ -222,12 +237,25 @@ __global__ __launch_bounds__(256) void k_sp_trsm_rows(T *__restrict__ A, const i
   }
   // every read of the slab's rows happened before the last barrier: the in-place store is safe
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cg[(size_t)(mi * 16 + M::row(lane, r)) * CH_NB + wave * 32 + ni * 16 + ccol] = acc[mi][ni][r];
 }
+template <typename T>
+__global__ __launch_bounds__(256) void k_sp_trsm_rows(T *__restrict__ A, const int *__restrict__ tiles, const T *__restrict__ Linv) {
+  extern __shared__ __align__(16) unsigned char ch_smem[];
+  constexpr int SPT = CH_NB / SP_SLAB; // slabs per tile
+  const int tile = blockIdx.x / SPT, slab = blockIdx.x % SPT;
+  sp_trsm_slab<T>(reinterpret_cast<T *>(ch_smem), A + (size_t)tiles[2 * tile] * SP_TT + (size_t)slab * SP_SLAB * CH_NB, Linv + (size_t)tiles[2 * tile + 1] * SP_TT);
+}
+
+// (Round 4, measured and removed: the whole factorisation as ONE dependency-driven launch — every panel-solve slab, target update
+// and diagonal factorisation an item of a level-ordered queue, persistent workgroups waiting on per-tile counters with agent-scope
+// release / acquire fences.  2.51 ms per factorisation on Ladybug-1723 against 2.45 ms for the level launches: the launch floors
+// and event bubbles it removes (~0.45 ms) come back as fence + poll latency on the same chain, whose length is set by the compute
+// of its links — panel solve 10 us, diagonal update + 128 x 128 factorisation 67 us, 21 times.)
 
 // permuted scatter of the upper 9x9 blocks of S (column-major blocks, block (i <= j)) into the lower triangle;
 // camcol[c] = first (padded, permuted) column of camera c
@@ -610,7 +638,7 @@ template <typename T> struct SparseChol {
       }
       if (ntr) {
         Sc sc(sink, "spchol_trsm", 3.0 * ntr * tb, ntr * tf);
-        if (row_split_trsm) k_sp_trsm_rows<T><<<4 * ntr, 256, 0, stream>>>(A.p, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], Linv.p);
+        if (row_split_trsm) k_sp_trsm_rows<T><<<(CH_NB / SP_SLAB) * ntr, 256, sp_trsm_lds(sizeof(T)), stream>>>(A.p, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], Linv.p);
         else k_sp_gemm<T, 0><<<ntr, 256, lds_g, stream>>>(A.p, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], nullptr, nullptr, Linv.p);
       }
       if (nup) {
