@@ -711,7 +711,13 @@ template <typename T> struct EngineCache {
 template <typename T, typename S>
 bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, bool early_stop, bool &result) {
   if (getenv("GRAPHITE_GENERIC_ONLY") && atoi(getenv("GRAPHITE_GENERIC_ONLY")) != 0) return false;
-  if (!(std::is_same<T, S>::value || (std::is_same<T, double>::value && std::is_same<S, float>::value))) return false;
+  if (!(std::is_same<T, S>::value || (std::is_same<T, double>::value && std::is_same<S, float>::value))) {
+    // Graph<T, bf16 / half>: the engine keeps no Jacobians (it recomputes them from the camera pack), so there is nothing to hold
+    // in a 16-bit storage type; such graphs run on the generic kernels, which DO store S-typed Jacobians (types.hpp:8-43)
+    if (getenv("GR_VERBOSE")) std::cerr << "[graphite] Jacobian storage type of " << sizeof(S) << " bytes under a " << sizeof(T)
+                                        << "-byte graph: not an engine configuration (no stored Jacobians there); using the generic kernels" << std::endl;
+    return false;
+  }
   auto &vds = graph->get_vertex_descriptors();
   auto &fds = graph->get_factor_descriptors();
   if (vds.size() != 2 || fds.size() != 1 || fds[0]->num_slots() != 2) return false;
