@@ -1049,7 +1049,17 @@ template <typename F, size_t I> __global__ void k_Jv(FactorView<F> fv, typename 
 // gather.  WHICH as in k_slot: 0 scalar diagonal, 2 b -= J^T rho' P r, 3 out += J^T (rho' P in), 4 block diagonal (one group
 // per (vertex, row)).
 constexpr size_t GATHER_ROWS = 3;
-template <typename F, size_t I, int WHICH>
+constexpr size_t GATHER_SYM_MAX_DIM = 9; // 45 accumulators
+// every E x E precision matrix symmetric?  (information matrices are; the single-pass block diagonal of k_gather relies on it and
+// the three-pass form is kept for descriptors where some matrix is not)
+template <typename S> __global__ void k_pmat_asymmetric(const S *pmat, size_t nf, size_t E, int *flag) {
+  const size_t f = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  for (size_t i = 0; i < E; ++i)
+    for (size_t j = i + 1; j < E; ++j)
+      if (!((double)pmat[f * E * E + i * E + j] == (double)pmat[f * E * E + j * E + i])) *flag = 1;
+}
+template <typename F, size_t I, int WHICH, bool SYM = false>
 __global__ void k_gather(FactorView<F> fv, const size_t *__restrict__ vptr, const size_t *__restrict__ vfac, size_t nv, int W,
                          typename F::Scalar *__restrict__ out, const typename F::Scalar *__restrict__ in) {
   using T = typename F::Scalar;
@@ -1058,8 +1068,11 @@ __global__ void k_gather(FactorView<F> fv, const size_t *__restrict__ vptr, cons
   const size_t g = t / (size_t)W;
   const int j = (int)(t % (size_t)W);
   // block diagonal: a group takes GATHER_ROWS rows of its vertex's d x d block, so a factor's Jacobian block is read
-  // ceil(d / GATHER_ROWS) times instead of d times
-  constexpr size_t RB = WHICH == 4 ? (d < GATHER_ROWS ? d : GATHER_ROWS) : 1, NRB = (d + RB - 1) / RB, NACC = WHICH == 4 ? RB * d : d;
+  // ceil(d / GATHER_ROWS) times instead of d times — or, SYM (every precision matrix symmetric, checked at initialize(); d <= 9):
+  // the whole lower triangle in ONE pass, d (d + 1) / 2 accumulators, the block read once (Ladybug-1723 camera blocks: the three
+  // passes moved 294 MB of stored Jacobians for 98 MB of data)
+  constexpr size_t RB = WHICH == 4 ? (SYM ? d : (d < GATHER_ROWS ? d : GATHER_ROWS)) : 1, NRB = (d + RB - 1) / RB,
+                   NACC = WHICH == 4 ? (SYM ? d * (d + 1) / 2 : RB * d) : d;
   const size_t v = WHICH == 4 ? g / NRB : g, row0 = WHICH == 4 ? (g % NRB) * RB : 0;
   const bool on = v < nv && is_vertex_active(fv.vstate[I], v);
   T acc[NACC];
@@ -1072,6 +1085,9 @@ __global__ void k_gather(FactorView<F> fv, const size_t *__restrict__ vptr, cons
       const T w = (T)fv.dchi2[f];
       if constexpr (WHICH == 0) {
         for (size_t c = 0; c < d; ++c) acc[c] += jtpj(fv, f, Jb + c * E, Jb + c * E) * w;
+      } else if constexpr (WHICH == 4 && SYM) {
+        for (size_t r = 0; r < d; ++r)
+          for (size_t c = 0; c <= r; ++c) acc[r * (r + 1) / 2 + c] += jtpj(fv, f, Jb + r * E, Jb + c * E) * w;
       } else if constexpr (WHICH == 4) {
         for (size_t rr = 0; rr < RB; ++rr)
           if (row0 + rr < d)
@@ -1092,10 +1108,27 @@ __global__ void k_gather(FactorView<F> fv, const size_t *__restrict__ vptr, cons
       }
     }
   }
-  for (int o = 1; o < W; o <<= 1)
+  for (int o = 1; o < W && o < 64; o <<= 1)
     for (size_t c = 0; c < NACC; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+  if (W > 64) {
+    // a whole WORKGROUP per vertex (W = TPB = 256, high-degree vertices: a camera of a bundle-adjustment graph sees hundreds of
+    // factors, and one wave per camera left most of the chip idle): the four waves' sums meet in LDS and are added in wave order
+    __shared__ T red[TPB / 64][NACC];
+    if ((threadIdx.x & 63) == 0)
+      for (size_t c = 0; c < NACC; ++c) red[threadIdx.x >> 6][c] = acc[c];
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (size_t c = 0; c < NACC; ++c) { T s = red[0][c]; for (int wv = 1; wv < TPB / 64; ++wv) s += red[wv][c]; acc[c] = s; }
+  }
   if (!on || j != 0) return;
-  if constexpr (WHICH == 4) {
+  if constexpr (WHICH == 4 && SYM) {
+    for (size_t r = 0; r < d; ++r)
+      for (size_t c = 0; c <= r; ++c) {
+        const T a = acc[r * (r + 1) / 2 + c];
+        out[v * d * d + r + c * d] += a;
+        if (c != r) out[v * d * d + c + r * d] += a;
+      }
+  } else if constexpr (WHICH == 4) {
     for (size_t rr = 0; rr < RB; ++rr)
       if (row0 + rr < d)
         for (size_t c = 0; c < d; ++c) out[v * d * d + (row0 + rr) + c * d] += acc[rr * d + c];
@@ -1401,7 +1434,11 @@ public:
     if (light) return;
     init_jacobians(std::make_index_sequence<N>{});
     build_vertex_lists();
+    // (read by gather_one after the synchronisation that ends Graph::initialize_optimization)
+    pmat_flag.resize(1); pmat_flag[0] = 0;
+    if (nf) detail::k_pmat_asymmetric<S><<<detail::blocks(nf), detail::TPB>>>(m_pmat.get(precision_matrices, tables_mirrored), nf, E, pmat_flag.raw());
   }
+  managed_vector<int> pmat_flag; // [0] != 0: some precision matrix is not symmetric
   void build_vertex_lists() {
     gather_ready = false;
     if (getenv("GRAPHITE_GENERIC_ATOMICS") && atoi(getenv("GRAPHITE_GENERIC_ATOMICS")) != 0) return;
@@ -1416,10 +1453,12 @@ public:
       for (size_t a = 0; a < na; ++a) { const size_t f = active_indices[a]; fac[fill[device_ids[f * N + i]]++] = f; } // ascending factor order per vertex
       slot_vptr[i].assign(ptr.data(), ptr.size());
       slot_vfac[i].assign(fac.data(), fac.size());
-      // lanes per vertex: half the mean degree of the vertices in use, rounded up to a power of two, at most a wave
+      // lanes per vertex: half the mean degree of the vertices in use, rounded up to a power of two, at most a wave — or a
+      // whole workgroup (k_gather: W = 256) from a mean degree of 768 on (300 cameras x 1 000 factors: 1.01 -> 0.98 ms per LM iteration; at 394 factors per camera it lost: 145 -> 204 us for the camera blocks)
       const size_t mean = used ? (na + used - 1) / used : 1;
       int w = 1;
       while (w < 64 && (size_t)(2 * w) <= mean) w <<= 1;
+      if (mean >= 768) w = detail::TPB;
       slot_lanes[i] = w;
     }
     gather_ready = true;
@@ -1639,8 +1678,15 @@ private:
   }
   template <int WHICH, size_t I> void gather_one(detail::FactorView<FactorDescriptor> &fv, T *out, const T *in) {
     constexpr size_t dI = detail::slot_dim<FactorDescriptor, I>(), rbI = dI < detail::GATHER_ROWS ? dI : detail::GATHER_ROWS;
-    const size_t nv = vertex_descriptors[I]->count(), groups = nv * (WHICH == 4 ? (dI + rbI - 1) / rbI : 1);
-    if (!groups) return;
+    const size_t nv = vertex_descriptors[I]->count();
+    if (!nv) return;
+    if constexpr (WHICH == 4 && dI <= detail::GATHER_SYM_MAX_DIM) {
+      if (pmat_flag.size() && pmat_flag[0] == 0) { // symmetric precision matrices (checked by initialize()): one pass, the block read once
+        detail::k_gather<FactorDescriptor, I, WHICH, true><<<detail::blocks(nv * (size_t)slot_lanes[I]), detail::TPB>>>(fv, slot_vptr[I].raw(), slot_vfac[I].raw(), nv, slot_lanes[I], out, in);
+        return;
+      }
+    }
+    const size_t groups = nv * (WHICH == 4 ? (dI + rbI - 1) / rbI : 1);
     detail::k_gather<FactorDescriptor, I, WHICH><<<detail::blocks(groups * (size_t)slot_lanes[I]), detail::TPB>>>(fv, slot_vptr[I].raw(), slot_vfac[I].raw(), nv, slot_lanes[I], out, in);
   }
   template <int WHICH, size_t... Is> void gather_all(T *out, const T *in, std::index_sequence<Is...>) {
