@@ -50,7 +50,7 @@ class LMOptions(C.Structure):
 class LMStats(C.Structure):
     _fields_ = [("iterations_run", C.c_int32), ("accepted", C.c_int32), ("pcg_iterations", C.c_int32),
                 ("ok", C.c_int32), ("setup_seconds", C.c_double), ("loop_seconds", C.c_double),
-                ("solve_seconds", C.c_double), ("final_chi2", C.c_double), ("collectives", C.c_int64), ("kernel_launches", C.c_int64)]
+                ("solve_seconds", C.c_double), ("final_chi2", C.c_double), ("collectives", C.c_int64), ("kernel_launches", C.c_int64), ("fused_messages", C.c_int64)]
 
 
 class Tuning(C.Structure):

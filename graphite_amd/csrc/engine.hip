@@ -923,9 +923,18 @@ template <typename T> struct Engine final : EngineBase {
     {
       const int np_fin = (int)Np;
       Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg, true);
+      const bool fz_lin = comm && shard_fused_lin();
+      IpcFused fz{};
+      if (fz_lin) { ipc_comm()->virtual_ranks = tune.shard_virtual_ranks; fz = ipc_comm()->fused(); }
       launch(k_linearize_finalize<T>, cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)np_fin, TPB), (int)Nc, np_fin, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
-                                                                                                    spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && !comm) ? h_res : nullptr, h_seq, spec_seq,
-                                                                                                    gate, cam_fixed_p(), pt_fixed_p());
+                                                                                                    spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && (!comm || fz_lin)) ? h_res : nullptr, h_seq, spec_seq,
+                                                                                                    gate, cam_fixed_p(), pt_fixed_p(), fz, (unsigned long long)shard_lin_scal_off());
+      if (fz_lin) { // the camera-space sums over the landmark shards travelled with the finalize launch: no all-reduce kernel, no publish kernel
+        ++coll_count; ++fused_messages;
+        launch(k_shard_cam_sums<T>, cdiv(90 * (size_t)Nc, TPB), (int)Nc, scale_system ? 1 : 0, fz, Hcc.p, bc.p, scales.p, cam_fixed_p());
+        hcp_valid = write_hcp;
+        return;
+      }
     }
     if (comm) { // camera-space sums over the landmark shards
       group_start();
@@ -934,7 +943,8 @@ template <typename T> struct Engine final : EngineBase {
       allreduce_d(dscalars.p, spec_seq ? 2 : 1);
       group_end();
       k_camera_scales<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, scale_system ? 1 : 0, Hcc.p, scales.p);
-      if (spec_seq) publish_scalars(2, spec_seq);
+      ++launch_count;
+      if (spec_seq) { publish_scalars(2, spec_seq); ++launch_count; }
     }
     hcp_valid = write_hcp;
   }
@@ -1387,6 +1397,14 @@ template <typename T> struct Engine final : EngineBase {
     if (!ic || tune.shard_fused == 0 || (ic->size < 2 && tune.shard_fused != 1) || tiled || pcg_mode() != 2) return false;
     ic->virtual_ranks = tune.shard_virtual_ranks;
     return shard_dots_off() + NSLOT * sizeof(double) <= ic->fused_slot_bytes();
+  }
+  // ... and the linearisation's camera-space sums [Hcc 81 Nc | bc 9 Nc | chi2, rho denominator] pushed by k_linearize_finalize
+  size_t shard_lin_scal_off() const { return (90 * (size_t)Nc * sizeof(T) + 15) / 16 * 16; }
+  bool shard_fused_lin() const {
+    IpcComm *ic = ipc_comm();
+    if (!ic || tune.shard_fused == 0 || (ic->size < 2 && tune.shard_fused != 1)) return false;
+    ic->virtual_ranks = tune.shard_virtual_ranks;
+    return shard_lin_scal_off() + 2 * sizeof(double) <= ic->fused_slot_bytes();
   }
   ShardPush shard_push() {
     if (sp_grid != grid_op) { // per camera: how many workgroups of the operator grid hold observations of it (xcd_tile_range, plain form)
@@ -1933,7 +1951,7 @@ template <typename T> struct Engine final : EngineBase {
   void flush_finalize(int spec_seq = 0) {
     Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg, true);
     launch(k_linearize_finalize<T>, cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), (int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
-                                                                                                       spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, spec_seq ? h_res : nullptr, h_seq, spec_seq, nullptr, cam_fixed_p(), pt_fixed_p());
+                                                                                                       spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, spec_seq ? h_res : nullptr, h_seq, spec_seq, nullptr, cam_fixed_p(), pt_fixed_p(), IpcFused{}, 0ull);
     fin_pending = false; hcp_valid = false;
   }
   // head of one LM iteration; dec.seq != 0: with the accept decision about the trial step just linearised (then every kernel
@@ -2060,7 +2078,7 @@ template <typename T> struct Engine final : EngineBase {
     int num_bad = 0;       // levenberg_marquardt2 (:404-414): consecutive accepted iterations gaining < 0.1 %
     const bool spec_enabled = tune.lm_speculate != 0;
     const bool ahead_enabled = tune.lm_ahead != 0;
-    const int64_t coll0 = coll_count, launch0 = launch_count + comm_launches;
+    const int64_t coll0 = coll_count, launch0 = launch_count + comm_launches, fused0 = fused_messages;
     if (chi2_trace) chi2_trace[0] = (double)chi2v;
     if (lambda_trace) lambda_trace[0] = (double)mu;
     // look-ahead predictor: nothing is known about the first solve of this call; from a fresh starting point the inner loop
@@ -2268,6 +2286,7 @@ template <typename T> struct Engine final : EngineBase {
     st.final_chi2 = (double)chi2v;
     st.collectives = coll_count - coll0;
     st.kernel_launches = launch_count + comm_launches - launch0;
+    st.fused_messages = fused_messages - fused0;
     check_comm("levenberg_marquardt");
     if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] LM: %s; trial linearisation enqueued ahead of the PCG exit flag in %d iterations, not ahead in %d; next head enqueued behind the trial step in %d\n",
                                    lm_fused ? "fused head / trial step" : "host loop", ahead_hits, ahead_misses, head_hits);

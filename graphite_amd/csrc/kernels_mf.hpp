@@ -791,10 +791,22 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
                      volatile double *hres = nullptr, volatile int *hres_seq = nullptr, int seq = 0,
                      const int *__restrict__ gate = nullptr,
                      // fixed vertices: no Jacobian block (ops/linearize.hpp:24) -> zero Hessian block, zero gradient, scale 1
-                     const unsigned char *__restrict__ cam_fixed = nullptr, const unsigned char *__restrict__ pt_fixed = nullptr) {
+                     const unsigned char *__restrict__ cam_fixed = nullptr, const unsigned char *__restrict__ pt_fixed = nullptr,
+                     // landmark shards, fused message (comm.hpp IpcFused; fz.boxes == nullptr: off): every camera thread also stores its
+                     // LOCAL sum (entry 90 c + e of the message) into every peer's mailbox, the launch's last workgroup adds the
+                     // scalars (chi2, rho denominator) at scal_off, raises the flags, waits for the peers and leaves the scalars
+                     // summed over the ranks in chi2_out / hres; k_shard_cam_sums then sums the camera entries over the ranks
+                     IpcFused fz = IpcFused{}, unsigned long long scal_off = 0) {
   if (gate && !*gate) return;
   const unsigned t = blockIdx.x * TPB + threadIdx.x;
   const unsigned ncam = 90u * (unsigned)Nc, ncam_pad = (ncam + TPB - 1) / TPB * TPB;
+  __shared__ unsigned long long s_seq;
+  int fz_set = 0;
+  if (fz.boxes) {
+    if (threadIdx.x == 0) s_seq = __hip_atomic_load(fz.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+    __syncthreads();
+    fz_set = (int)(s_seq & 1ull);
+  }
   if (t < ncam) {
     const unsigned c = t / 90u, e = t % 90u;
     int idx;
@@ -812,6 +824,8 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
       Hcc[81 * (size_t)c + e] = s;
       if (row == col && cam_scales) scales[9 * c + row] = (scale_system && !fixed) ? (T)(1.0 / (DBL_EPSILON + sqrt((double)s))) : T(1);
     } else bc[9 * c + (e - 81u)] = s;
+    if (fz.boxes)
+      for (int r = 0; r < fz.size; ++r) ipc_store(reinterpret_cast<T *>(fz.slot(fz.push_box(r), fz_set, fz.push_slot(r))) + t, fz.push_value(r, s));
   } else if (t >= ncam_pad && t < ncam_pad + FIN_PL * (unsigned)Np) { // point part starts on a block boundary
     // FIN_PL lanes share a point (records j, j + FIN_PL, ...): the serial chain of dependent record loads is
     // ~deg / FIN_PL long; then a butterfly over the FIN_PL lanes (fixed order)
@@ -881,6 +895,10 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
     for (int k = threadIdx.x; k < n_rho; k += TPB) r += rho_partial[k];
     r = block_sum_256(r, red);
     if (threadIdx.x == 0) {
+      if (fz.boxes) { // read by the launch's last workgroup, possibly on another XCD: written through
+        __hip_atomic_store(&chi2_out[0], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&chi2_out[1], rho_partial ? r : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
       chi2_out[0] = s;
       if (rho_partial) chi2_out[1] = r;
       if (hres) {
@@ -888,8 +906,86 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
         __threadfence_system();
         *hres_seq = seq;
       }
+      }
     }
   }
+  if (!fz.boxes) return;
+  // ---- fused message: completion count over the workgroups, then ONE workgroup finishes the message (as shard_push_tail does)
+  __shared__ unsigned s_last;
+  __shared__ int s_bad;
+  __shared__ double s_g[2 * 64];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(fz.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old + 1u == gridDim.x ? 1u : 0u;
+    if (s_last) __hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_bad = 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const unsigned long long mseq = s_seq;
+  if ((int)threadIdx.x < 2 * fz.size) {
+    const int q = threadIdx.x / fz.size, r = threadIdx.x % fz.size;
+    const double v = __hip_atomic_load(&chi2_out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ipc_store(reinterpret_cast<double *>(fz.slot(fz.push_box(r), fz_set, fz.push_slot(r)) + scal_off) + q, fz.push_value(r, v));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(fz.seq, mseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < fz.size) ipc_store(fz.flag(fz.push_box(threadIdx.x), fz_set, fz.push_slot(threadIdx.x)), mseq);
+  if ((int)threadIdx.x < fz.size) {
+    const unsigned long long *flag = fz.flag(fz.rank, fz_set, threadIdx.x);
+    const long long t0 = wall_clock64();
+    while (ipc_load(flag) < mseq) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > fz.timeout_ticks) {
+        ipc_store(reinterpret_cast<unsigned long long *>(fz.boxes[fz.rank]) + 500, 1ull);
+        if (fz.h_err) { *fz.h_err = 1; __threadfence_system(); }
+        s_bad = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if ((int)threadIdx.x < 2 * fz.size)
+    s_g[threadIdx.x] = ipc_load(reinterpret_cast<const double *>(fz.slot(fz.rank, fz_set, threadIdx.x % fz.size) + scal_off) + threadIdx.x / fz.size);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double c2 = 0, rh = 0;
+    for (int r = 0; r < fz.size; ++r) { c2 += s_g[r]; rh += s_g[fz.size + r]; }
+    if (s_bad) c2 = rh = __builtin_nan(""); // a peer never arrived: the host finds the error word before it uses these
+    chi2_out[0] = c2; chi2_out[1] = rh;
+    if (hres) {
+      hres[0] = c2; hres[1] = rh;
+      __threadfence_system();
+      *hres_seq = seq;
+    }
+  }
+}
+
+// Landmark shards, fused linearisation message: Hcc, bc and the camera column scales from the ranks' entries in the mailbox,
+// summed in rank order (the same bits on every rank); entry 90 c + e as k_linearize_finalize's camera threads index them
+template <typename T>
+__global__ void __launch_bounds__(TPB) k_shard_cam_sums(int Nc, int scale_system, IpcFused fz, T *__restrict__ Hcc, T *__restrict__ bc, T *__restrict__ scales,
+                                                        const unsigned char *__restrict__ cam_fixed) {
+  __shared__ int s_set;
+  if (threadIdx.x == 0) s_set = (int)(__hip_atomic_load(fz.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1ull);
+  __syncthreads();
+  const unsigned t = blockIdx.x * TPB + threadIdx.x;
+  if (t >= 90u * (unsigned)Nc) return;
+  T s = T(0);
+  for (int r = 0; r < fz.size; ++r) s += ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, s_set, r)) + t);
+  const unsigned c = t / 90u, e = t % 90u;
+  if (e < 81u) {
+    Hcc[81 * (size_t)c + e] = s;
+    if (e % 10u == 0u) scales[9 * c + e / 10u] = (scale_system && !(cam_fixed && cam_fixed[c])) ? (T)(1.0 / (DBL_EPSILON + sqrt((double)s))) : T(1);
+  } else bc[9 * c + (e - 81u)] = s;
 }
 
 

@@ -108,6 +108,8 @@ typedef struct {
                                rank; 0 without a communicator */
   int64_t kernel_launches;  /* kernels launched inside the LM loop by the matrix-free PCG paths, the communicator's own
                                (one per mailbox message) included: what the sharded iteration costs in launch floors */
+  int64_t fused_messages;   /* of `collectives`: messages that travelled inside the producing / consuming launches
+                               (gr_bal_tuning.shard_fused) instead of through an all-reduce kernel of their own */
 } gr_lm_stats;
 
 /* Tuning of one problem handle.  The reference configures through option structs only (LevenbergMarquardtOptions,

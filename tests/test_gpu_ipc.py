@@ -91,8 +91,10 @@ def test_ipc_allreduce_between_processes(world, tmp_path):
         fu, un = res[r]["f64_pcg"], res[r]["f64_pcg_unfused"]
         assert fu["pcg_iterations"] == un["pcg_iterations"] > 0
         assert fu["collectives"] == un["collectives"]
+        # (the linearisation's camera-space sums are fused too: finalize + one summing launch instead of finalize + mailbox kernel +
+        # camera scales [+ publish])
         saved = un["kernel_launches"] - fu["kernel_launches"]
-        assert saved > 0 and saved % 2 == 0 and saved // 2 >= fu["pcg_iterations"], (un["kernel_launches"], fu["kernel_launches"], fu["pcg_iterations"])
+        assert saved >= 2 * fu["pcg_iterations"] + 8, (un["kernel_launches"], fu["kernel_launches"], fu["pcg_iterations"])
         assert np.allclose(fu["chi2"], un["chi2"], rtol=1e-10)
 
 

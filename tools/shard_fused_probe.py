@@ -17,7 +17,7 @@ kw = dict(solver=ga.SOLVER_PCG, initial_damping=1e-4, pcg_max_iter=10, pcg_tol=0
 for name, tune in (("unfused", dict(shard_fused=0)), ("unfused, single-reduction form", dict(shard_fused=0, pcg_single_reduction=1)), ("fused x1", dict(shard_fused=1, shard_virtual_ranks=0, pcg_single_reduction=1)),
                    (f"fused x{world} virtual", dict(shard_fused=1, shard_virtual_ranks=world, pcg_single_reduction=1))):
     g = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=np.float32, shard=True)
-    gdist.init_comm_ipc(g, 0, 1, slot_bytes=4 << 20, rccl_fallback=False)
+    gdist.init_comm_ipc(g, 0, 1, slot_bytes=max(4 << 20, world * (90 * prob.shape[0] * 8 + 4096)), rccl_fallback=False)  # the virtual ranks cut a slot into `world` pieces
     g.set_tuning(**tune)
     g.levenberg_marquardt(iterations=3, **kw)
     g.set_params(part.cameras, part.points)

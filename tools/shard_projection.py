@@ -71,7 +71,7 @@ def main():
     for r in range(args.world):
         part = gdist.partition_by_landmark(prob, r, args.world)
         g = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype, shard=True)
-        gdist.init_comm_ipc(g, 0, 1, slot_bytes=max(4 << 20, 2 * 90 * Nc * 8), rccl_fallback=False)  # one slot holds the largest grouped message (Hcc + bc + chi2)
+        gdist.init_comm_ipc(g, 0, 1, slot_bytes=max(4 << 20, args.world * (90 * Nc * 8 + 4096)), rccl_fallback=False)  # one slot holds the largest grouped message (Hcc + bc + chi2)
         if args.unfused:
             g.set_tuning(shard_fused=0)
         else:
@@ -84,7 +84,8 @@ def main():
             lat1_small = f(g.h, C.c_int(8), C.c_int(8), C.c_int(200))
         shards.append({"rank": r, "points": int(part.shape[1]), "observations": int(part.shape[2]), "seconds_per_lm_iteration": tr,
                        "collectives_per_lm_iteration": st["collectives"] / max(st["iterations_run"], 1), "pcg_iterations": st["pcg_iterations"],
-                       "kernel_launches_per_lm_iteration": st["kernel_launches"] / max(st["iterations_run"], 1)})
+                       "kernel_launches_per_lm_iteration": st["kernel_launches"] / max(st["iterations_run"], 1),
+                       "fused_messages_per_lm_iteration": st["fused_messages"] / max(st["iterations_run"], 1)})
         g.close()
     w = np.dtype(dtype).itemsize
     msg_kb = 9 * Nc * w / 1024.0
@@ -92,16 +93,16 @@ def main():
         raise SystemExit("--l8-us: pass the latency measured by `python tools/ipc_latency.py %d` for a camera-space vector" % args.world)
     l8 = args.l8_us
     c = max(s["collectives_per_lm_iteration"] for s in shards)
-    inner = max(s["pcg_iterations"] for s in shards) / float(args.steps)   # fused messages per LM iteration (one per inner iteration)
+    inner = max(s["fused_messages_per_lm_iteration"] for s in shards)      # messages that travel inside launches (inner iterations + the linearisation)
     c_kernel = c if args.unfused else max(0.0, c - inner)                   # collectives that still have a kernel of their own
     tmax = max(s["seconds_per_lm_iteration"] for s in shards)
     if args.unfused or args.l8_large_us is None or args.l8_small_us is None:
         t8 = tmax + c_kernel * (l8 - lat1) * 1e-6 + c * args.hop_us * 1e-6
         priced = "every kernel collective at the camera-vector latency"
     else:
-        # fused form: what keeps a kernel of its own is ONE large message per LM iteration (the linearisation group) and small ones
-        t8 = tmax + (args.l8_large_us - lat1_large) * 1e-6 + max(0.0, c_kernel - 1.0) * (args.l8_small_us - lat1_small) * 1e-6 + c * args.hop_us * 1e-6
-        priced = "1 linearisation group at L8_large, %.2f small messages at L8_small per LM iteration" % max(0.0, c_kernel - 1.0)
+        # fused form: what keeps a kernel of its own are messages of a few scalars (the closing dots of a solve that ran into its cap)
+        t8 = tmax + c_kernel * (args.l8_small_us - lat1_small) * 1e-6 + c * args.hop_us * 1e-6
+        priced = "%.2f small messages at L8_small per LM iteration (inner iterations and the linearisation group are fused)" % c_kernel
     res = {"kind": "PROJECTION from one GPU (tools/shard_projection.py), not a multi-GPU measurement",
            "workload": f"{args.workload} {args.dtype}, block-Jacobi PCG, {args.pcg_iterations} fixed inner iterations, {args.world} landmark shards",
            "T1_seconds_per_lm_iteration": t1, "T1_lm_iterations_per_sec": 1.0 / t1, "shards": shards,
