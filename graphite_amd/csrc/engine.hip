@@ -1061,6 +1061,7 @@ template <typename T> struct Engine final : EngineBase {
       if (!tiling_tuned) tune_tiling();
       if (want_g3_gather() && !g3_obs_order) build_g3_gather(); // rebuilt whenever the observation order has changed
       if (!records_tuned) tune_point_records();
+      if (comm && !diag_running) agree_on_fusion(); // collective: every rank of a sharded problem calls solver_update_structure
     }
   }
   // H.update_values / preconditioner->update_values: the blocks are produced by
@@ -1392,12 +1393,24 @@ template <typename T> struct Engine final : EngineBase {
   int64_t fused_messages = 0; // pushed by operator launches (host count of the enqueued ones)
   size_t shard_dots_off() const { return (9 * (size_t)Nc * sizeof(T) + 15) / 16 * 16; }
   IpcComm *ipc_comm() const { return dynamic_cast<IpcComm *>(comm.get()); }
-  bool shard_fused() const {
+  // The observation order is a per-rank, TIMED choice (tune_tiling): whether the inner iteration's message can be fused is
+  // therefore AGREED between the ranks (solver_update_structure: one host all-reduce of this rank's answer) — a rank that pushed
+  // from its operator launch while a peer waited in a mailbox kernel would hang both.
+  bool shard_fused_local() const {
     IpcComm *ic = ipc_comm();
-    if (!ic || tune.shard_fused == 0 || (ic->size < 2 && tune.shard_fused != 1) || tiled || pcg_mode() != 2) return false;
+    if (!ic || tune.shard_fused == 0 || (ic->size < 2 && tune.shard_fused != 1) || tiled) return false;
     ic->virtual_ranks = tune.shard_virtual_ranks;
     return shard_dots_off() + NSLOT * sizeof(double) <= ic->fused_slot_bytes();
   }
+  bool fused_agreed = false;
+  void agree_on_fusion() {
+    fused_agreed = false;
+    if (!ipc_comm()) return;
+    double mine = shard_fused_local() ? 1.0 : 0.0;
+    if (comm->size > 1) allreduce_host(&mine, 1);
+    fused_agreed = mine == (double)comm->size;
+  }
+  bool shard_fused() const { return fused_agreed && !tiled && pcg_mode() == 2; }
   // ... and the linearisation's camera-space sums [Hcc 81 Nc | bc 9 Nc | chi2, rho denominator] pushed by k_linearize_finalize
   size_t shard_lin_scal_off() const { return (90 * (size_t)Nc * sizeof(T) + 15) / 16 * 16; }
   bool shard_fused_lin() const {
@@ -1623,10 +1636,13 @@ template <typename T> struct Engine final : EngineBase {
 
   // Diagnostic: average device time (us) of `reps` back-to-back launches of one hot kernel
   // (which: 0 operator, 1 linearize, 2 chi2, 3 pcg_update, 4 pcg_direction, 5 linearize_finalize).
+  bool diag_running = false; // diag_time is per-rank (the timed tuning choices): nothing collective may happen inside it
   double diag_time(int which, int variant, int reps) override {
     const bool was_tuned = records_tuned, was_tl = tiling_tuned;
     records_tuned = tiling_tuned = true; // no recursion through solver_update_structure
+    diag_running = true;
     solver_update_structure(GR_SOLVER_PCG);
+    diag_running = false;
     records_tuned = was_tuned; tiling_tuned = was_tl;
     linearize_impl(false);
     solver_set_damping(GR_SOLVER_PCG, 1e-4, false);
