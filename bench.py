@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--parity-only", action="store_true", help="cpu_baseline: only the sequential same-algorithm oracle leg (the parity gate), no further CPU timing legs")
     ap.add_argument("--cpu-baseline-iters", type=int, default=2)  # direct-solve legs: ~6 s (Schur) / ~12 s (full H) per iteration
     ap.add_argument("--dump-kernels", default=None, help="write per-kernel HIP-event table to this JSON file")
+    ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
+                    help="auto (N = 1): measure roofline.traffic live — two child passes of this workload under `rocprofv3 --pmc` "
+                         "(FETCH_SIZE, WRITE_SIZE) after the timed region; off: the committed profiles/pmc_traffic.json is looked up")
     return ap.parse_args()
 
 
@@ -99,6 +102,44 @@ def self_launch(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     return subprocess.run(cmd).returncode
+
+
+def measure_pmc_traffic(args, solver_name, dtype_name, kernel):
+    """roofline.traffic measured BY THIS RUN: two short child passes of the same workload under rocprofv3 (one counter per pass, as
+    MI355X_MICROARCH.md prescribes: FETCH_SIZE counts 64 B per 128-B request on gfx950, WRITE_SIZE is KB of 64-B writes), median over
+    the dominant kernel's launches.  Children, never an exec; any failure returns None and the committed table is looked up instead."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    med = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="gr_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", args.workload, "--solver", solver_name, "--dtype", dtype_name, "--pcg-iterations", str(args.pcg_iterations),
+                   "--pcg-tol", str(args.pcg_tol), "--no-cpu-baseline", "--no-also", "--repeats", "1", "--steps", "10", "--warmup", "2", "--pmc-traffic", "off"]
+            r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and ("k_" + kernel) in row["Kernel_Name"].split("(")[0]:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            med[counter] = statistics.median(vals)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return {"hbm_bytes": 2 * med["FETCH_SIZE"] * 1024 + med["WRITE_SIZE"] * 1024, "FETCH_SIZE_KB": med["FETCH_SIZE"], "WRITE_SIZE_KB": med["WRITE_SIZE"]}
 
 
 def main():
@@ -398,7 +439,17 @@ def main():
 
     # PMC traffic of the dominant kernel, measured offline with the same command under
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) and committed under profiles/
-    if roofline:
+    live = None
+    if roofline and world == 1 and args.pmc_traffic == "auto" and roofline["bound"] == "hbm":
+        live = measure_pmc_traffic(args, solver_name, dtype_name, roofline["kernel"])
+    if roofline and live:
+        roofline["traffic"] = live["hbm_bytes"]
+        roofline["traffic_source"] = ("measured by this run: two child passes of the same workload under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; "
+                                      "10 LM iterations each), median over the kernel's launches")
+        roofline["traffic_detail"] = live
+        roofline["traffic_over_algorithmic"] = round(live["hbm_bytes"] / roofline["algorithmic_bytes_per_launch"], 3)
+        roofline["traffic_note"] = "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)"
+    elif roofline:
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             key = f"{args.workload} {dtype_name} {solver_name}"
