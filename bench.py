@@ -117,6 +117,8 @@ def measure_pmc_traffic(args, solver_name, dtype_name, kernel):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None  # this process is itself being profiled: no profiler inside a profiler
     med = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="gr_pmc_", dir="/tmp")
