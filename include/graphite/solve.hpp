@@ -908,8 +908,14 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   }
   cd->scatter_parameters(cache->cams.raw()); pd->scatter_parameters(cache->pts.raw());
   lap("get_params + scatter_parameters");
-  graph->compute_error(); // leave the residuals of the optimised vertices behind, as the generic loop does (graph->chi2() is valid)
-  graphite::detail::sync();
+  {
+    // leave the residuals of the optimised vertices behind, as the generic loop does (graph->chi2() is valid).  Through the HBM
+    // mirror of the vertex values: dereferencing the user's (pinned host) vertices per factor is 65 MB of PCIe reads on
+    // Ladybug-1723 (1.7 ms); mirrored in and out they are 4 MB each way
+    typename Graph<T, S>::DeviceMirrorScope mirror_scope(graph);
+    graph->compute_error();
+    graphite::detail::sync();
+  }
   lap("compute_error");
   const double total = std::chrono::duration<double>(clk::now() - tt0).count();
   engine_last_setup_seconds() = total - lm_seconds;
