@@ -102,15 +102,17 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
 // replaced by 1 so that the rest stays finite.
 // `L` is the LDS image [128][129] (+128 for the diagonal of X); with `load` it is filled from the global
 // tile first, otherwise the caller has already put the lower triangle (zeros above) there.
-template <typename T>
+// NT: threads of the calling workgroup (256, or 512 in the nested-dissection update launch: the sub-panel solves, trailing updates
+// and inverse rows spread over twice the waves; the serial diagonal steps stay one wave's)
+template <typename T, int NT = CH_PT>
 __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restrict__ Ag, int ld, T *__restrict__ Linv, int *__restrict__ fail, bool load, int skip) {
   using M = MfmaTile<T>;
   typedef typename M::acc_t acc_t;
   T *xd = L + CH_NB * CH_LP; // diag of X
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, cl = lane & 15, g = lane >> 4;
-  constexpr int NW = CH_PT / 64, NB16 = CH_NB / 16;
+  constexpr int NW = NT / 64, NB16 = CH_NB / 16;
   if (load)
-    for (int e = t; e < CH_NB * CH_NB; e += CH_PT) {
+    for (int e = t; e < CH_NB * CH_NB; e += NT) {
       const int r = e >> 7, c = e & 127;
       L[r * CH_LP + c] = c <= r ? Ag[(size_t)r * ld + c] : T(0);
     }

@@ -175,6 +175,10 @@ __global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, const int *_
                            MODE == 0 ? Linv + (size_t)tj * SP_TT : nullptr, fuse, fuse ? Linv_out + (size_t)tj * SP_TT : nullptr, fail);
 }
 
+// (Round 4, measured and removed: the update launch with 512-thread workgroups — eight waves of 32 x 64 outputs, the sub-panel /
+// trailing / inverse phases of the fused factorisation on twice the waves.  In fp64 the kernel is then limited to 256 registers per
+// lane (two waves per SIMD) and spills 291 VGPRs: 94 -> 248 us per launch.  The 256-thread form keeps its 256 VGPRs + 240 AGPRs.)
+
 // Panel solve, ROW-SPLIT: L_ik = A_ik Linv_k^T with one workgroup per SP_SLAB-row slab of the tile (tiles[2 t] = slot(i, k),
 // tiles[2 t + 1] = k for tile t = b / slabs-per-tile, slab b % slabs-per-tile), in place: a slab only reads its own rows of A_ik.  The upper levels of the tree hold a
 // handful of tiles, and one workgroup per 128 x 128 x 128 product is 26 us of a chain that runs 21 times per factorisation
