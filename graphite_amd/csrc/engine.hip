@@ -1458,10 +1458,16 @@ template <typename T> struct Engine final : EngineBase {
 #undef GR_OPV
     }
 #endif
-    if (st.lazy == 2 && shard_fused()) launch(k_pcg_operator<T, 0, JT, 2, true>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm, shard_push());
-    else if (st.lazy == 2) launch(k_pcg_operator<T, 0, JT, 2>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm, ShardPush{});
-    else if (st.lazy) launch(k_pcg_operator<T, 0, JT, 1>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, nullptr, lm, ShardPush{});
-    else launch(k_pcg_operator<T, 0, JT>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, rec, lm, ShardPush{});
+    // operator forms: (LAZY, FUSE, REC) by the PCG form / shard message / record layout
+#define GR_OP_ARGS(REC_P, SP) grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, REC_P, lm, SP
+#define GR_OP_FORM(LZ, FU, RC, REC_P, SP) launch(k_pcg_operator<T, 0, JT, LZ, FU, RC>, GR_OP_ARGS(REC_P, SP))
+    if (st.lazy == 2 && shard_fused()) GR_OP_FORM(2, true, false, nullptr, shard_push());
+    else if (st.lazy == 2) GR_OP_FORM(2, false, false, nullptr, ShardPush{});
+    else if (st.lazy) GR_OP_FORM(1, false, false, nullptr, ShardPush{});
+    else if (rec) GR_OP_FORM(0, false, true, rec, ShardPush{});
+    else GR_OP_FORM(0, false, false, nullptr, ShardPush{});
+#undef GR_OP_FORM
+#undef GR_OP_ARGS
   }
   void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
@@ -1975,9 +1981,10 @@ template <typename T> struct Engine final : EngineBase {
   template <bool IDENTITY> void enqueue_head(LmDecide dec, double mu, bool use_identity, int max_iter, double tol, double rej, int time_slot) {
     ensure_ctl(max_iter);
     ensure_point_records();
-    // the first PCG iteration without its direction launch (operator and update in their lazy forms): not with point records,
-    // whose [X Y Z | s.p] sectors are what the direction launch fills
-    const bool first_lazy = max_iter > 0 && !use_records && tune.lm_fused != 2;
+    // the first PCG iteration without its direction launch (operator and update in their lazy forms).  With point records too: the
+    // record layout is a compile-time form of the operator, iteration 0 runs the plain form on zs / pts and the direction launch that
+    // ends it fills the [X Y Z | s.p] sectors for iteration 1
+    const bool first_lazy = max_iter > 0 && tune.lm_fused != 2;
     if (first_lazy) v_zs.alloc(n);
     ts_slot = time_slot;
     flag_bank ^= 1; // the previous user of this bank is the solve before the last one: complete
@@ -2022,10 +2029,12 @@ template <typename T> struct Engine final : EngineBase {
   // operator of iteration 0 on the UN-normalised direction s .* z' that k_finalize_bj left in zs (A is linear; the update kernel of
   // iteration 0 applies sigma = 1 / |r|): the plain kernel, no decision prologue, no first direction launch
   void launch_operator_first(PcgState st, const LmDev *lm, double mu) {
+#define GR_OP_FIRST(JT_) launch(k_pcg_operator<T, 0, JT_>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm, ShardPush{})
     if constexpr (sizeof(T) == 8) {
-      if (jac32) { launch(k_pcg_operator<T, 0, float>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm, ShardPush{}); return; }
+      if (jac32) { GR_OP_FIRST(float); return; }
     }
-    launch(k_pcg_operator<T, 0, T>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_zs.p, g3.p, op_partial.p, mu, st, 0, nullptr, lm, ShardPush{});
+    GR_OP_FIRST(T);
+#undef GR_OP_FIRST
   }
   // iterations 1 ... of the solve whose head is in the stream; returns once the host has seen the loop leave
   template <bool IDENTITY> void continue_pcg(int max_iter, double tol, double rej) {

@@ -661,6 +661,9 @@ __device__ __forceinline__ bool grid_sum2(double v0, double v1, double *partial,
 // current one, so the per-block fixed costs (launch, tail, chi2 partial) are amortised and the
 // index -> gather dependency is off the critical path.
 // LV (diagnostic builds only, GR_DIAG): 1 no point-record write, 2 no camera reduction, 4 no point gather, 8 no Jacobian math
+// (Round 4, measured and removed: the camera pack through a wave-uniform index (scalar loads, as in k_pcg_operator) with the Jacobian
+// evaluated inside the per-camera loop: Ladybug-1723 27.8 -> 27.5 us, Final-13682 1 608 -> 1 565 us, Venice-1778 fp32 154 -> 163 us —
+// a vector load whose lanes share one address is cheap, and the fp32 kernel took 13 more VGPRs.)
 template <typename T, bool WRITE_HCP, typename JT = T, int LV = 0>
 __global__ void __launch_bounds__(TPB, LIN_WAVES)
 k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
@@ -1315,7 +1318,12 @@ __device__ __forceinline__ void shard_push_tail(const ShardPush &sp, const PcgSt
   }
 }
 
-template <typename T, int VAR = 0, typename JT = T, int LAZY = 0, bool FUSE = false>
+// REC: xp records (compile time: three 16-byte loads per lane; a run-time test makes hipcc merge both layouts into five).
+// (Round 4, measured and removed — a MULTI form for orders whose waves mostly hold two cameras (point-tiled Final-13682: 66-observation
+// runs; landmark shards): Jacobian and products once per lane from per-lane camera data, only the 9-value reduction per distinct
+// camera.  Final-13682 774 -> 932 us, Venice-1778 83.5 -> 90.4 us: the 21 extra vector loads per lane cost more than the second
+// evaluation from SGPRs.)
+template <typename T, int VAR = 0, typename JT = T, int LAZY = 0, bool FUSE = false, bool REC = false>
 __global__ void __launch_bounds__(TPB, OP_WAVES)
 k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const int *__restrict__ pt_cm,
                const int *__restrict__ pos_cm, const T *__restrict__ obs_cm, const int *__restrict__ blk_seg,
@@ -1362,37 +1370,11 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
   int t0, t1, tstep;
   xcd_tile_range(ntiles, t0, t1, tstep);
   double den = 0;
-  int j = t0 * TPB + threadIdx.x;
-  bool valid = t0 < t1 && j < No;
-  int c_n = -1, l_n = 0, a_n = 0;
-  V2 o_n{};
-  if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm ? pos_cm[j] : j; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
-  for (int t = t0; t < t1; t += tstep) {
-    const int c = c_n, l = l_n;
-    const size_t a = (size_t)a_n;
-    const V2 o = o_n;
-    const int jn = j + tstep * TPB;
-    const bool validn = (t + tstep < t1) && jn < No;
-    if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm ? pos_cm[jn] : jn; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
-    // Wave-uniform camera data (24-scalar pack, 9 direction scalars, segment id) are fetched per DISTINCT
-    // camera of the wave through a uniform index, i.e. with scalar loads into SGPRs: the kernel keeps its
-    // VGPRs for the per-observation state and more waves fit per SIMD.  Almost every wave has one camera.
-    const size_t lp = (VAR & 2) ? (size_t)(j & 1023) : (size_t)(valid ? l : 0);
-    T X, Y, Z, pl0, pl1, pl2;
-    if (xp) { // one aligned record: [X Y Z ps_x ps_y ps_z . .]
-      const V2 *rec = reinterpret_cast<const V2 *>(xp + 8 * lp);
-      const V2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-      X = r0.x; Y = r0.y; Z = r1.x; pl0 = r1.y; pl1 = r2.x; pl2 = r2.y;
-    } else {
-      X = pts[3 * lp]; Y = pts[3 * lp + 1]; Z = pts[3 * lp + 2];
-      const T *pl = ps + pose_dim + 3 * lp;
-      if (!lazy) { pl0 = pl[0]; pl1 = pl[1]; pl2 = pl[2]; }
-      else {
-        const T *zl = zs + pose_dim + 3 * lp;
-        pl0 = lz_scale * zl[0]; pl1 = lz_scale * zl[1]; pl2 = lz_scale * zl[2];
-        if (lazy_old) { pl0 += lz_beta * pl[0]; pl1 += lz_beta * pl[1]; pl2 += lz_beta * pl[2]; }
-      }
-    }
+  // One 64-observation tile of a wave, given its index streams and its gathered point record: wave-uniform camera data (24-scalar
+  // pack, 9 direction scalars, segment id) are fetched per DISTINCT camera of the wave through a uniform index, i.e. with scalar
+  // loads into SGPRs: the kernel keeps its VGPRs for the per-observation state.  Almost every wave has one camera.
+  auto tile_body = [&](const int j, const bool valid, const int c, const size_t a, const V2 o,
+                       const T X, const T Y, const T Z, const T pl0, const T pl1, const T pl2) __attribute__((always_inline)) {
     unsigned long long remaining = __ballot(valid);
     int segf = blk_seg[__builtin_amdgcn_readfirstlane(j >> 6)];
     while (remaining) {
@@ -1456,6 +1438,50 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
       }
       }
       remaining &= ~__ballot(mine);
+    }
+  };
+  // (Round 4, measured and removed: index streams two tiles and the point gather one tile ahead of the arithmetic — +19 VGPRs, exact
+  // vmcnt waits, no spill: Ladybug-1723 19.55 -> 19.47 us with records, 19.85 -> 20.4 us without; Final-13682 723 -> 715 / 868 -> 919 us.
+  // The kernel is bound by the NUMBER of divergent memory instructions (64 lines each), not by the latency of the chain:
+  // the record layout as a compile-time parameter — three 16-byte loads instead of the five hipcc emits for the run-time test —
+  // gave 782 -> 723 us on Final-13682.)
+  struct Gat { T X, Y, Z, p0, p1, p2; };
+  auto gather_plain = [&](const size_t lp) __attribute__((always_inline)) {
+    Gat g;
+    if constexpr (REC) { // one aligned record: [X Y Z ps_x ps_y ps_z . .]
+      const V2 *rec = reinterpret_cast<const V2 *>(xp + 8 * lp);
+      const V2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+      g.X = r0.x; g.Y = r0.y; g.Z = r1.x; g.p0 = r1.y; g.p1 = r2.x; g.p2 = r2.y;
+    } else {
+      g.X = pts[3 * lp]; g.Y = pts[3 * lp + 1]; g.Z = pts[3 * lp + 2];
+      const T *pl = ps + pose_dim + 3 * lp;
+      g.p0 = pl[0]; g.p1 = pl[1]; g.p2 = pl[2];
+    }
+    return g;
+  };
+  int j = t0 * TPB + threadIdx.x;
+  bool valid = t0 < t1 && j < No;
+  int c_n = -1, l_n = 0, a_n = 0;
+  V2 o_n{};
+  if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm ? pos_cm[j] : j; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
+  for (int t = t0; t < t1; t += tstep) {
+    const int c = c_n, l = l_n;
+    const size_t a = (size_t)a_n;
+    const V2 o = o_n;
+    const int jn = j + tstep * TPB;
+    const bool validn = (t + tstep < t1) && jn < No;
+    if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm ? pos_cm[jn] : jn; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
+    const size_t lp = (VAR & 2) ? (size_t)(j & 1023) : (size_t)(valid ? l : 0);
+    if constexpr (!lazy) {
+      const Gat g = gather_plain(lp);
+      tile_body(j, valid, c, a, o, g.X, g.Y, g.Z, g.p0, g.p1, g.p2);
+    } else { // lazy direction: formed from zs (and the previous ps) while it is gathered
+      const T X = pts[3 * lp], Y = pts[3 * lp + 1], Z = pts[3 * lp + 2];
+      const T *pl = ps + pose_dim + 3 * lp;
+      const T *zl = zs + pose_dim + 3 * lp;
+      T pl0 = lz_scale * zl[0], pl1 = lz_scale * zl[1], pl2 = lz_scale * zl[2];
+      if (lazy_old) { pl0 += lz_beta * pl[0]; pl1 += lz_beta * pl[1]; pl2 += lz_beta * pl[2]; }
+      tile_body(j, valid, c, a, o, X, Y, Z, pl0, pl1, pl2);
     }
     valid = validn;
     j = jn;

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--l8-large-us", type=float, default=None, help="the same for the linearisation group (Hcc + bc + chi2: 90 Nc scalars), one per LM iteration")
     ap.add_argument("--l8-small-us", type=float, default=None, help="the same for a message of a few scalars (the closing dots of a solve that ran into its cap)")
     ap.add_argument("--hop-us", type=float, default=2.0, help="xGMI hop added to every message (fused ones included): not measurable on one GPU")
+    ap.add_argument("--link-gbs", type=float, default=153.0, help="xGMI link bandwidth (GB/s): every message also pays bytes / link (the peers are reached over their own links in parallel)")
     ap.add_argument("--unfused", action="store_true", help="round-3 form: a kernel of its own for every all-reduce")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -96,12 +97,14 @@ def main():
     inner = max(s["fused_messages_per_lm_iteration"] for s in shards)      # messages that travel inside launches (inner iterations + the linearisation)
     c_kernel = c if args.unfused else max(0.0, c - inner)                   # collectives that still have a kernel of their own
     tmax = max(s["seconds_per_lm_iteration"] for s in shards)
+    # bytes on the wire: the inner-iteration messages carry a camera vector, the linearisation group (one per LM iteration) 90 Nc scalars
+    wire = (max(0.0, c - 1.0) * 9 * Nc * w + 90 * Nc * w) / (args.link_gbs * 1e9)
     if args.unfused or args.l8_large_us is None or args.l8_small_us is None:
-        t8 = tmax + c_kernel * (l8 - lat1) * 1e-6 + c * args.hop_us * 1e-6
+        t8 = tmax + c_kernel * (l8 - lat1) * 1e-6 + c * args.hop_us * 1e-6 + wire
         priced = "every kernel collective at the camera-vector latency"
     else:
         # fused form: what keeps a kernel of its own are messages of a few scalars (the closing dots of a solve that ran into its cap)
-        t8 = tmax + c_kernel * (args.l8_small_us - lat1_small) * 1e-6 + c * args.hop_us * 1e-6
+        t8 = tmax + c_kernel * (args.l8_small_us - lat1_small) * 1e-6 + c * args.hop_us * 1e-6 + wire
         priced = "%.2f small messages at L8_small per LM iteration (inner iterations and the linearisation group are fused)" % c_kernel
     res = {"kind": "PROJECTION from one GPU (tools/shard_projection.py), not a multi-GPU measurement",
            "workload": f"{args.workload} {args.dtype}, block-Jacobi PCG, {args.pcg_iterations} fixed inner iterations, {args.world} landmark shards",
@@ -110,7 +113,7 @@ def main():
            "form": "unfused (kernel per all-reduce)" if args.unfused else "inner-iteration message fused into operator / update, %d virtual ranks inside every shard run" % args.world,
            "collectives_with_a_kernel_of_their_own_per_lm_iteration": c_kernel, "fused_messages_per_lm_iteration": 0.0 if args.unfused else inner,
            "L1_us_one_rank_allreduce_camera_vector": lat1, "L8_us_measured_between_%d_processes_on_one_gpu" % args.world: l8,
-           "xgmi_hop_us_assumed_per_message": args.hop_us, "camera_vector_kb": msg_kb, "kernel_collectives_priced_as": priced,
+           "xgmi_hop_us_assumed_per_message": args.hop_us, "xgmi_link_gbs_assumed": args.link_gbs, "wire_seconds_per_lm_iteration": wire, "camera_vector_kb": msg_kb, "kernel_collectives_priced_as": priced,
            "L1_us_large_small": [lat1_large, lat1_small], "L8_us_large_small_measured": [args.l8_large_us, args.l8_small_us],
            "projected_T8_seconds_per_lm_iteration": t8, "projected_lm_iterations_per_sec": 1.0 / t8, "projected_speedup": t1 / t8,
            "speedup_if_collectives_were_free": t1 / (tmax - c_kernel * lat1 * 1e-6),
