@@ -204,7 +204,7 @@ def main():
         t0 = time.perf_counter()
         if sharded:
             from graphite_amd import dist as gdist
-            part = gdist.partition_by_landmark(prob, rank, world)
+            part = gdist.partition_by_landmark(prob, rank, world, point_weight=gdist.point_weight_for(dtype))  # points by first camera, cut by observations + weighted points
             gpu = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype,
                                 device=local_rank, shard=True)
             # small all-reduces go peer to peer through IPC-mapped mailboxes (one hop over xGMI), RCCL carries what does

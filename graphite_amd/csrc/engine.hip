@@ -198,7 +198,8 @@ template <typename T> struct Engine final : EngineBase {
   // payload); in observation order the operator fell from 176 to 86 us inside the solve and the update kernel rose from
   // 83 to 105 us (Final-13682 fp64: 1481 -> 786 and 472 -> 712).  Ladybug-1723 (everything cache-resident, plain order):
   // operator 23.1 -> 20.5 us, update 20.3 -> 23.7 us, no gain, so it keeps the pm layout.
-  bool want_g3_gather() const { return tune.g3_gather >= 0 ? tune.g3_gather == 1 : tiled; }
+  bool want_g3_gather() const { return tune.g3_gather >= 0 ? tune.g3_gather == 1 : (tiled || g3_plain_pays); }
+  bool g3_plain_pays = false; // plain order, working set beyond the L2s: decided by timing operator + update both ways (tune_tiling)
   DevBuf<int> g3_gidx, ptile_ptr;
   int g3_ptiles = 0;
   const int *g3_pos() const { return g3_obs_order ? nullptr : o_pos(); }
@@ -280,7 +281,7 @@ template <typename T> struct Engine final : EngineBase {
   void tune_point_records() {
     if (records_tuned) return;
     records_tuned = true;
-    if (pcg_mode() != 0) { use_records = false; return; } // the lazy / single-reduction forms gather zs (and ps); the 8-scalar record has room for one
+    if (pcg_mode() == 1) { use_records = false; return; } // the lazy form gathers zs AND ps; the 8-scalar record has room for one (single-reduction form: zs only)
     if (tune.point_records >= 0) { use_records = tune.point_records != 0; return; }
     use_records = false;
     const double t_plain = diag_time(0, 0, 5);
@@ -632,6 +633,14 @@ template <typename T> struct Engine final : EngineBase {
   void tune_tiling() {
     if (tiling_tuned) return;
     tiling_tuned = true;
+    tune_tiling_order();
+    const size_t per_point = (size_t)(6 * sizeof(T) + 3 * sizeof(T) * (double)No / (double)Np);
+    if ((size_t)Np * per_point >= ((size_t)24 << 20)) tune_g3_order();
+  }
+  void tune_tiling_order() {
+    // landmark shards that can fuse the inner iteration's message keep the plain order: the fused form needs it (one rank that tiled
+    // would un-fuse every rank), and a shard cut by camera locality (dist.py) has the camera runs of the unsharded problem
+    if (comm && ipc_comm() && tune.shard_fused != 0 && tune.point_tiles < 0) return;
     const size_t per_point = (size_t)(6 * sizeof(T) + 3 * sizeof(T) * (double)No / (double)Np); // X + direction + this point's g3 slots
     int K = 0;
     if (tune.point_tiles >= 0) K = tune.point_tiles;
@@ -656,6 +665,19 @@ template <typename T> struct Engine final : EngineBase {
       if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] operator + linearise + update: %.1f us plain order, %.1f us with %d point tiles -> %s\n", t_plain, t_tiled, K, t_tiled < 0.95 * t_plain ? "tiled" : "plain");
       if (!(t_tiled < 0.95 * t_plain)) untile();
     }
+  }
+  // Plain camera-major order on a graph whose g3 does not stay in the L2s (a landmark shard of Final-13682: 87 MB): the operator's
+  // scattered 24-byte stores against whole lines + a gather in the update launch, timed both ways (one shard of Final-13682, fp64,
+  // records: operator 137 -> 92 us, update 45 -> 72 us).  Rank-local: the sums keep their order, results do not depend on it.
+  void tune_g3_order() {
+    g3_plain_pays = false;
+    if (tiled || tune.g3_gather >= 0) return;
+    const double t_pm = diag_time(0, 0, 5) + diag_time(3, 0, 5);
+    build_g3_gather();
+    const double t_obs = diag_time(0, 0, 5) + diag_time(3, 0, 5);
+    g3_plain_pays = t_obs < 0.95 * t_pm;
+    if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] operator + update: %.1f us with g3 in point-major order, %.1f us in observation order + gather -> %s\n", t_pm, t_obs, g3_plain_pays ? "observation order" : "point-major");
+    if (!g3_plain_pays) g3_obs_order = false;
   }
 
   // SchurComplement::build_structure (schur.hpp:194-225).  The reference walks
@@ -923,7 +945,7 @@ template <typename T> struct Engine final : EngineBase {
     {
       const int np_fin = (int)Np;
       Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg, true);
-      const bool fz_lin = comm && shard_fused_lin();
+      const bool fz_lin = comm && !diag_running && shard_fused_lin();
       IpcFused fz{};
       if (fz_lin) { ipc_comm()->virtual_ranks = tune.shard_virtual_ranks; fz = ipc_comm()->fused(); }
       launch(k_linearize_finalize<T>, cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)np_fin, TPB), (int)Nc, np_fin, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
@@ -936,7 +958,7 @@ template <typename T> struct Engine final : EngineBase {
         return;
       }
     }
-    if (comm) { // camera-space sums over the landmark shards
+    if (comm && !diag_running) { // camera-space sums over the landmark shards; not inside a rank-local timing run (diag_time)
       group_start();
       allreduce_T(Hcc.p, 81 * (size_t)Nc);
       allreduce_T(bc.p, pose_dim);
@@ -1076,7 +1098,7 @@ template <typename T> struct Engine final : EngineBase {
       // variant only needs the clamped diagonal (pcg.hpp:93-103)
       // one launch: camera inverses, point inverses and (when the loop state exists) its reset
       PcgState st{};
-      if (ctl_cap > 0) st = pcg_state();
+      if (ctl_cap > 0) { ensure_point_records(); st = pcg_state(); } // records first: the fused PCG start below writes their zs half (single-reduction form)
       const int nbc = cdiv(Nc, 64), nbp = cdiv(Np, 64);
       const bool fuse = lm_x && ctl_cap > 0 && state_clean_cap == ctl_cap;
       if (fuse) {
@@ -1461,8 +1483,8 @@ template <typename T> struct Engine final : EngineBase {
     // operator forms: (LAZY, FUSE, REC) by the PCG form / shard message / record layout
 #define GR_OP_ARGS(REC_P, SP) grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, v_ps.p, g3.p, op_partial.p, mu, st, k, REC_P, lm, SP
 #define GR_OP_FORM(LZ, FU, RC, REC_P, SP) launch(k_pcg_operator<T, 0, JT, LZ, FU, RC>, GR_OP_ARGS(REC_P, SP))
-    if (st.lazy == 2 && shard_fused()) GR_OP_FORM(2, true, false, nullptr, shard_push());
-    else if (st.lazy == 2) GR_OP_FORM(2, false, false, nullptr, ShardPush{});
+    if (st.lazy == 2 && shard_fused()) { if (rec) GR_OP_FORM(2, true, true, rec, shard_push()); else GR_OP_FORM(2, true, false, nullptr, shard_push()); }
+    else if (st.lazy == 2) { if (rec) GR_OP_FORM(2, false, true, rec, ShardPush{}); else GR_OP_FORM(2, false, false, nullptr, ShardPush{}); }
     else if (st.lazy) GR_OP_FORM(1, false, false, nullptr, ShardPush{});
     else if (rec) GR_OP_FORM(0, false, true, rec, ShardPush{});
     else GR_OP_FORM(0, false, false, nullptr, ShardPush{});
@@ -1505,6 +1527,7 @@ template <typename T> struct Engine final : EngineBase {
     if (st.lazy) v_zs.alloc(n);
     if (st.lazy == 2) v_sv.alloc(n);
     st.ps = v_ps.p; st.zs = v_zs.p; st.sv = v_sv.p;
+    st.zrec = (st.lazy == 2 && use_records && xp.n == 8 * (size_t)Np) ? xp.p : nullptr;
     st.x = nullptr; st.xb = v_xb.p; st.n = (unsigned)n; st.tol = 0.0; st.rej = 1e30; // set per solve (solve_pcg)
     st.ts = (lm_fused && h_ts) ? h_ts + 2 * ts_slot : nullptr;
     return st;
@@ -1646,9 +1669,10 @@ template <typename T> struct Engine final : EngineBase {
   double diag_time(int which, int variant, int reps) override {
     const bool was_tuned = records_tuned, was_tl = tiling_tuned;
     records_tuned = tiling_tuned = true; // no recursion through solver_update_structure
-    diag_running = true;
+    // nothing collective in here: the timed choices are per rank, and ranks call this a different number of times (a rank that
+    // stays in the plain order also times the g3 layouts) — the linearisation below keeps its camera-space sums rank-local
+    struct Running { bool &f; explicit Running(bool &f_) : f(f_) { f = true; } ~Running() { f = false; } } running(diag_running);
     solver_update_structure(GR_SOLVER_PCG);
-    diag_running = false;
     records_tuned = was_tuned; tiling_tuned = was_tl;
     linearize_impl(false);
     solver_set_damping(GR_SOLVER_PCG, 1e-4, false);

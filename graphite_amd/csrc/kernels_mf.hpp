@@ -70,6 +70,7 @@ struct PcgState {
   // pass over five n-vectors per inner iteration less.
   double *beta, *scale; // [cap]
   void *ps, *zs;        // T[n]
+  void *zrec = nullptr; // single-reduction form with point records: [X Y Z | zs_x zs_y zs_z . .] per point, the zs half written by whoever writes zs
   int lazy;             // 0 direction kernel, 1 lazy direction, 2 single-reduction recurrence (below)
   // SINGLE-REDUCTION form (lazy == 2; Chronopoulos-Gear, the variant oracle/bal_pipeline.hpp::solve_pcg_cg documents): the
   // operator is applied to the preconditioned residual u = z'/|r| instead of the direction, s = A p follows the recurrence
@@ -189,6 +190,7 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
           const T z = identity_precond ? rv[i] : (T)A[i] * rv[0] + (T)A[i + 3] * rv[1] + (T)A[i + 6] * rv[2];
           x[t0 + i] = T(0); r[t0 + i] = rv[i]; zt[t0 + i] = z;
           if (st.lazy) static_cast<T *>(st.zs)[t0 + i] = s[i] * z;
+          if (st.zrec) static_cast<T *>(st.zrec)[8 * (size_t)l + 3 + i] = s[i] * z;
           const T d = use_identity ? T(1) : dcl[i];
           prr += (double)(rv[i] * rv[i]); prz += (double)(rv[i] * z); pzz += (double)(d * z * z);
         }
@@ -1242,10 +1244,13 @@ __device__ __forceinline__ void shard_push_tail(const ShardPush &sp, const PcgSt
     pushed += nfin;
     __syncthreads();
   }
-  if (blockIdx.x == 0) { // the cameras this shard never sees: zero rows (the slot is reused every other message)
-    for (int e = threadIdx.x; e < 9 * sp.n_empty; e += TPB)
+  { // the cameras this shard never sees: zero rows (the slot is reused every other message), an equal share per workgroup — with
+    // points cut by camera locality (dist.py) 7/8 of the cameras of a shard are such, and one workgroup pushing all of them was
+    // the longest part of the launch (Final-13682: 12 000 cameras x 9 rows x 8 peers)
+    const int e0 = (int)((long long)sp.n_empty * blockIdx.x / gridDim.x), e1 = (int)((long long)sp.n_empty * (blockIdx.x + 1) / gridDim.x);
+    for (int e = 9 * e0 + (int)threadIdx.x; e < 9 * e1; e += TPB)
       for (int r = 0; r < fz.size; ++r) ipc_store(reinterpret_cast<T *>(fz.slot(fz.push_box(r), set, fz.push_slot(r))) + 9 * (size_t)sp.empty[e / 9] + e % 9, T(0));
-    pushed += sp.n_empty;
+    pushed += e1 - e0;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1475,6 +1480,9 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     if constexpr (!lazy) {
       const Gat g = gather_plain(lp);
       tile_body(j, valid, c, a, o, g.X, g.Y, g.Z, g.p0, g.p1, g.p2);
+    } else if constexpr (LAZY == 2 && REC) { // single-reduction form on records: [X Y Z | zs] (the un-normalised s .* z'; lz_scale = 1)
+      const Gat g = gather_plain(lp);
+      tile_body(j, valid, c, a, o, g.X, g.Y, g.Z, lz_scale * g.p0, lz_scale * g.p1, lz_scale * g.p2);
     } else { // lazy direction: formed from zs (and the previous ps) while it is gathered
       const T X = pts[3 * lp], Y = pts[3 * lp + 1], Z = pts[3 * lp + 2];
       const T *pl = ps + pose_dim + 3 * lp;
@@ -1738,7 +1746,11 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
 #endif
       }
       zt[t] = s;
-      if (lazy && !FIRST) zsw[t] = scales[t] * s;
+      if (lazy && !FIRST) {
+        const T zv = scales[t] * s;
+        zsw[t] = zv;
+        if (LAZY == 2 && st.zrec) static_cast<T *>(st.zrec)[8 * (size_t)l + 3 + li] = zv; // the operator's [X Y Z | zs] record
+      }
       prr += (double)(rn * rn);
       prz += (double)(rn * s);
       ppz += (double)(dg * pv * s);

@@ -1,6 +1,6 @@
 """Landmark sharding of a BAL problem over the GPUs of one node.
 
-One process per GPU.  Points are cut into `world` contiguous ranges balanced by observation
+One process per GPU.  Points — ordered by first observing camera — are cut into `world` contiguous ranges balanced by observation
 count; a rank owns its points and ALL their observations; cameras are replicated.  Only
 camera-space sums cross ranks (RCCL all-reduce inside libgraphite_mi355x.so)."""
 from __future__ import annotations
@@ -13,9 +13,18 @@ from . import _lib
 from .synth import BalProblem as HostProblem
 
 
-def point_ranges(pt_idx, num_points, world):
-    """Contiguous point ranges with (nearly) equal observation counts: list of (p0, p1)."""
-    deg = np.bincount(pt_idx, minlength=num_points).astype(np.int64)
+POINT_WEIGHT = 4.0  # one point costs a rank about as much as four observations (the point-space vector work of an inner iteration;
+#                     measured on the 8 shards of Final-13682 fp64: 2.2 ns per point, 0.48 ns per observation and LM iteration);
+#                     fp32 (Venice-1778, 8 shards: 1.5 left the point-heavy last shard 15 % behind, 4.0 the observation-heavy first one 5 %): 3.0
+
+
+def point_weight_for(dtype):
+    return POINT_WEIGHT if np.dtype(dtype) == np.float64 else 3.0
+
+
+def point_ranges(pt_idx, num_points, world, point_weight=POINT_WEIGHT):
+    """Contiguous point ranges of (nearly) equal cost = observations + point_weight x points: list of (p0, p1)."""
+    deg = np.bincount(pt_idx, minlength=num_points).astype(np.float64) + float(point_weight)
     cum = np.concatenate([[0], np.cumsum(deg)])
     total = cum[-1]
     cuts = [0]
@@ -26,23 +35,59 @@ def point_ranges(pt_idx, num_points, world):
     return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
 
 
-def partition_by_landmark(prob: HostProblem, rank: int, world: int) -> HostProblem:
-    """The shard of `prob` owned by `rank`: all cameras, points [p0, p1) renumbered from 0 and
-    exactly their observations (original relative order kept)."""
+def locality_order(cam_idx, pt_idx, num_points):
+    """Points ordered by their FIRST observing camera (ties: original id).  Cut into contiguous ranges of this order, a shard's
+    observations fall on the cameras of one band instead of on all of them: the camera runs of its camera-major order keep the
+    length they have in the unsharded problem (a wave = one camera), and only the band's camera rows are non-zero in its messages."""
+    first = np.full(num_points, np.iinfo(np.int64).max, np.int64)
+    np.minimum.at(first, pt_idx, cam_idx.astype(np.int64))
+    return np.argsort(first, kind="stable")
+
+
+def partition_by_landmark(prob: HostProblem, rank: int, world: int, locality: bool = True, point_weight: float = POINT_WEIGHT) -> HostProblem:
+    """The shard of `prob` owned by `rank`: all cameras, `world` contiguous ranges of the points — in locality_order (default) or in
+    the caller's numbering — renumbered from 0, and exactly their observations (original relative order kept).
+    shard.point_ids: the original ids of the shard's points, in the shard's numbering; shard.obs_index: its observations."""
     Nc, Np, No = prob.shape
-    ranges = point_ranges(prob.pt_idx, Np, world)
+    cache = getattr(prob, "_shard_cache", None)
+    if cache is None or cache[0] != (world, locality, point_weight):
+        if locality:
+            order = locality_order(prob.cam_idx, prob.pt_idx, Np)
+            new_of_old = np.empty(Np, np.int64)
+            new_of_old[order] = np.arange(Np)
+            pt_new = new_of_old[prob.pt_idx]
+        else:
+            order = np.arange(Np)
+            pt_new = prob.pt_idx.astype(np.int64)
+        cache = ((world, locality, point_weight), order, pt_new, point_ranges(pt_new, Np, world, point_weight))
+        try:
+            prob._shard_cache = cache  # the ranks of one process (tests, projections) cut the same problem `world` times
+        except AttributeError:
+            pass
+    _, order, pt_new, ranges = cache
     # validated for EVERY rank on every rank: all of them raise, or none does (a rank that raised alone would
     # leave its peers waiting in init_comm's broadcast)
     empty = [r for r, (a, b) in enumerate(ranges) if b <= a]
     if empty:
         raise ValueError(f"ranks {empty} of {world} would own no points ({Np} points)")
     p0, p1 = ranges[rank]
-    sel = np.nonzero((prob.pt_idx >= p0) & (prob.pt_idx < p1))[0]
-    shard = HostProblem(prob.cameras, prob.points[p0:p1].copy(), prob.obs[sel].copy(),
-                        prob.cam_idx[sel].copy(), (prob.pt_idx[sel] - p0).astype(np.int32), f"{prob.name}[{rank}/{world}]")
-    shard.point_range = (p0, p1)
+    sel = np.nonzero((pt_new >= p0) & (pt_new < p1))[0]
+    ids = order[p0:p1]
+    shard = HostProblem(prob.cameras, prob.points[ids].copy(), prob.obs[sel].copy(),
+                        prob.cam_idx[sel].copy(), (pt_new[sel] - p0).astype(np.int32), f"{prob.name}[{rank}/{world}]")
+    shard.point_ids = ids
+    shard.point_range = (p0, p1) if not locality else None
     shard.obs_index = sel
     return shard
+
+
+def assemble_points(shards, pts_per_shard):
+    """The ranks' point blocks (each in its shard's numbering) put back into the caller's numbering: (Np, 3)."""
+    ids = np.concatenate([np.asarray(s.point_ids) for s in shards])
+    cat = np.concatenate([np.asarray(p).reshape(-1, 3) for p in pts_per_shard])
+    out = np.empty_like(cat)
+    out[ids] = cat
+    return out
 
 
 def init_comm(problem, rank: int, world: int):

@@ -23,8 +23,8 @@ def test_point_ranges_partition_everything():
         assert sum(s.shape[2] for s in shards) == No and sum(s.shape[1] for s in shards) == Np
         seen = np.concatenate([s.obs_index for s in shards])
         assert np.array_equal(np.sort(seen), np.arange(No))           # every observation exactly once
-        counts = [s.shape[2] for s in shards]
-        assert max(counts) - min(counts) <= max(2 * np.bincount(prob.pt_idx).max(), 0.2 * No / world)
+        counts = [s.shape[2] + gdist.POINT_WEIGHT * s.shape[1] for s in shards]  # the balanced quantity: observations + POINT_WEIGHT x points
+        assert max(counts) - min(counts) <= max(2 * (np.bincount(prob.pt_idx).max() + gdist.POINT_WEIGHT), 0.2 * (No + gdist.POINT_WEIGHT * Np) / world)
         for s in shards:
             assert s.pt_idx.min() == 0 and s.pt_idx.max() == s.shape[1] - 1
             assert np.array_equal(s.cameras, prob.cameras)
@@ -52,8 +52,7 @@ def _worker(rank, world, port, q):
     # camera rows of the operator: y_c = sum_obs Jc^T (Jc p_c + Jp p_l)
     rng = np.random.default_rng(0)
     p_full = rng.normal(size=9 * Nc + 3 * prob.shape[1])
-    p0, p1 = s.point_range
-    p_loc = np.concatenate([p_full[:9 * Nc], p_full[9 * Nc + 3 * p0:9 * Nc + 3 * p1]])
+    p_loc = np.concatenate([p_full[:9 * Nc], p_full[9 * Nc:].reshape(-1, 3)[s.point_ids].ravel()])
     Jc = o.get("Jc").reshape(-1, 9, 2)
     Jp = o.get("Jp").reshape(-1, 3, 2)
     u = np.einsum("fde,fd->fe", Jc, p_loc[:9 * Nc].reshape(Nc, 9)[s.cam_idx]) + \

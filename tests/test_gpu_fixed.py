@@ -91,7 +91,7 @@ def test_fixed_vertices_on_landmark_shards(oracle_mod):
     shards = [gdist.partition_by_landmark(prob, r, world) for r in range(world)]
     engines = [ga.BalProblem(s.cameras, s.points, s.obs, s.cam_idx, s.pt_idx, dtype=np.float64, shard=True) for s in shards]
     for e, s in zip(engines, shards):
-        e.set_fixed(cf, pf[s.point_range[0]:s.point_range[1]])
+        e.set_fixed(cf, pf[s.point_ids])
     gdist.init_local_group(engines)
     out, err = [None] * world, []
 
@@ -106,7 +106,7 @@ def test_fixed_vertices_on_landmark_shards(oracle_mod):
     [t.join(timeout=120) for t in th]
     assert not err, err
     cams = [e.get_params()[0] for e in engines]
-    pts = np.concatenate([e.get_params()[1] for e in engines])
+    pts = gdist.assemble_points(shards, [e.get_params()[1] for e in engines])
     [e.close() for e in engines]
     for r in range(world):
         assert np.allclose(out[r][0], ct_r, rtol=1e-8)

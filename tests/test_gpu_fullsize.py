@@ -153,7 +153,7 @@ def test_sharded_4way_reproduces_single_gpu_ladybug1723(ladybug1723):
         assert np.allclose(out[r][0], ct, rtol=1e-9)
         assert out[r][2]["pcg_iterations"] == st["pcg_iterations"]
     cams = [e.get_params()[0] for e in eng]
-    pts = np.concatenate([e.get_params()[1] for e in eng])
+    pts = gdist.assemble_points(shards, [e.get_params()[1] for e in eng])
     assert all(np.array_equal(c, cams[0]) for c in cams)
     assert np.allclose(cams[0], c1, rtol=1e-7, atol=1e-10) and np.allclose(pts, p1, rtol=1e-7, atol=1e-10)
     [e.close() for e in eng]

@@ -60,7 +60,7 @@ def test_ipc_allreduce_between_processes(world, tmp_path):
     assert all(r["oversize_rc"] != 0 for r in res)
 
     prob = synth.make_config("mini-50")
-    ranges = gdist.point_ranges(prob.pt_idx, prob.shape[1], world)
+    shards = [gdist.partition_by_landmark(prob, r, world) for r in range(world)]  # the cut every worker makes (tests/ipc_worker.py)
     for dtype, tag, solver, sname in ((np.float64, "f64", ga.SOLVER_PCG, "pcg"),
                                       (np.float64, "f64", ga.SOLVER_PCG, "pcg_unfused"),
                                       (np.float64, "f64", ga.SOLVER_PCG_SCHUR_IMPLICIT, "implicit"),
@@ -71,7 +71,7 @@ def test_ipc_allreduce_between_processes(world, tmp_path):
         single.close()
         key = f"{tag}_{sname}"
         rt, at = (1e-9, 1e-7) if tag == "f64" else (1e-5, 2e-3)
-        pts = np.concatenate([np.array(res[r][key]["pts"]) for r in range(world)])
+        pts = gdist.assemble_points(shards, [np.array(res[r][key]["pts"]) for r in range(world)])
         for r in range(world):
             got = res[r][key]
             n = min(len(got["chi2"]), len(ct)) if tag == "f32" else len(ct)
@@ -83,7 +83,7 @@ def test_ipc_allreduce_between_processes(world, tmp_path):
         if tag == "f64":
             assert np.allclose(np.array(res[0][key]["cams"]), c1, rtol=at, atol=1e-10)
             assert np.allclose(pts, p1, rtol=at, atol=1e-10)
-        assert [len(res[r][key]["pts"]) for r in range(world)] == [b - a for a, b in ranges]
+        assert [len(res[r][key]["pts"]) for r in range(world)] == [s.shape[1] for s in shards]
     # the fused form runs the SAME iteration (equal inner iteration counts, the same number of messages:
     # a fused message counts as one collective) with TWO launches per inner iteration less — operator + update instead of
     # operator + camera-row kernel + mailbox kernel + update (every enqueued iteration, look-ahead launches included)

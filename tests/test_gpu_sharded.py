@@ -34,7 +34,7 @@ def run_sharded(prob, world, dtype, iterations, solver):
     assert not err, err
     assert all(o is not None for o in out), "a shard thread hung"
     cams = [e.get_params()[0] for e in engines]
-    pts = np.concatenate([e.get_params()[1] for e in engines])
+    pts = gdist.assemble_points(shards, [e.get_params()[1] for e in engines])
     [e.close() for e in engines]
     return out, cams, pts
 

@@ -10,11 +10,11 @@ world = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 prob = synth.make_config(name)
 part = gdist.partition_by_landmark(prob, 0, world)
 print(name, "shard 0 of", world, ":", part.shape, flush=True)
-for tiles in (0, 8, 16, 32):
+for tiles, g3g in ((0, 0), (0, 1), (8, 0), (8, 1), (16, 0)):
     for rec in (0, 1):
         g = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dt)
-        g.set_tuning(pcg_lazy=0, point_records=rec, point_tiles=tiles)
+        g.set_tuning(pcg_lazy=0, point_records=rec, point_tiles=tiles, g3_gather=g3g)
         g.solver_update_structure(ga.SOLVER_PCG)
         f = g.lib.gr_bal_diag_time; f.restype = C.c_double
-        print("point tiles %2d records %d: operator %.1f us  linearise %.1f us  update %.1f us" % (tiles, rec, f(g.h, 0, 0, 20), f(g.h, 1, 0, 20), f(g.h, 3, 0, 20)), flush=True)
+        print("point tiles %2d g3 in observation order %d records %d: operator %.1f us  linearise %.1f us  update %.1f us" % (tiles, g3g, rec, f(g.h, 0, 0, 20), f(g.h, 1, 0, 20), f(g.h, 3, 0, 20)), flush=True)
         g.close()

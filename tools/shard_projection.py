@@ -70,7 +70,7 @@ def main():
     shards = []
     lat1 = None
     for r in range(args.world):
-        part = gdist.partition_by_landmark(prob, r, args.world)
+        part = gdist.partition_by_landmark(prob, r, args.world, point_weight=gdist.point_weight_for(dtype))
         g = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype, shard=True)
         gdist.init_comm_ipc(g, 0, 1, slot_bytes=max(4 << 20, args.world * (90 * Nc * 8 + 4096)), rccl_fallback=False)  # one slot holds the largest grouped message (Hcc + bc + chi2)
         if args.unfused:

@@ -46,7 +46,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
             continue
         es = [ga.BalProblem(s.cameras, s.points, s.obs, s.cam_idx, s.pt_idx, dtype=dt, shard=True) for s in shards]
         if use_fixed:
-            for e, s in zip(es, shards): e.set_fixed(cf, pf[s.point_range[0]:s.point_range[1]])
+            for e, s in zip(es, shards): e.set_fixed(cf, pf[s.point_ids])
         gdist.init_local_group(es)
         out = [None] * world; errs = []
         def work(r):
