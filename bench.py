@@ -300,21 +300,39 @@ def main():
                  "us_per_pcg_iteration": round(r0["st"]["solve_seconds"] / max(r0["st"]["pcg_iterations"], 1) * 1e6, 2),
                  "chi2_final": float(r0["ct"][-1])}
 
-    venice = None
-    if sharded and args.workload != "venice-1778" and not args.no_also:
-        # the configuration the north star's 8-GPU target is quoted on (BASELINE.json configs[3]): Venice-1778 fp32
+    venice, final_mixed = None, None
+    default_line = args.workload == "ladybug-1723" and args.solver is None and args.dtype is None and not args.no_also
+    if (sharded and args.workload != "venice-1778" and not args.no_also) or (not sharded and default_line):
+        # the configuration the north star's 8-GPU target is quoted on (BASELINE.json configs[3]): Venice-1778 fp32 — on every N,
+        # the N = 1 line included, so that its strong scaling can be read off the lines of one SCALE run
         gpu.close()
         vprob, vpart, vgpu, _ = make_engine("venice-1778", np.float32)
         vkw = dict(solver=ga.SOLVER_PCG, initial_damping=1e-4, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0)
         rv = summarise(timed_runs(vgpu, vpart, args.steps, 3, min(args.repeats, 5), vkw))
         vNc, vNp, vNo = vprob.shape
-        venice = {"workload": f"BAL venice-1778 shape ({vNc} cameras, {vNp} points, {vNo} observations), pcg, f32, landmark-sharded x{world}",
+        par = f"landmark-sharded x{world}" if sharded else "single GPU"
+        venice = {"workload": f"BAL venice-1778 shape ({vNc} cameras, {vNp} points, {vNo} observations), pcg, f32, {par}",
                   "value": round(rv["value"], 2), "value_min": round(rv["value_min"], 2), "value_max": round(rv["value_max"], 2),
                   "unit": "LM iterations/s", "steps_run": rv["steps_run"], "accepted_steps": rv["st"]["accepted"],
                   "pcg_iterations": rv["st"]["pcg_iterations"], "ms_per_step": round(rv["dt"] / max(rv["steps_run"], 1) * 1e3, 4),
                   "collectives_per_lm_iteration": round(rv["st"]["collectives"] / max(rv["steps_run"], 1), 2),
                   "chi2_initial": float(rv["ct"][0]), "chi2_final": float(rv["ct"][-1])}
         vgpu.close()
+        del vprob, vpart
+        if (sharded and world >= 4) or os.environ.get("GR_BENCH_FINAL") == "1":
+            # BASELINE.json configs[4]: Final-13682, fp32 Jacobian entries + fp64 PCG (the reference's FP64-FP32 mode), 3 LM iterations
+            fprob, fpart, fgpu, _ = make_engine("final-13682", np.float64)
+            fgpu.set_jacobian_precision(np.float32)
+            rf = summarise(timed_runs(fgpu, fpart, 3, 1, 3, vkw))
+            fNc, fNp, fNo = fprob.shape
+            final_mixed = {"workload": f"BAL final-13682 shape ({fNc} cameras, {fNp} points, {fNo} observations), pcg, fp32 Jacobians + fp64 PCG, {par}",
+                           "value": round(rf["value"], 2), "value_min": round(rf["value_min"], 2), "value_max": round(rf["value_max"], 2),
+                           "unit": "LM iterations/s", "steps_run": rf["steps_run"], "accepted_steps": rf["st"]["accepted"],
+                           "pcg_iterations": rf["st"]["pcg_iterations"], "ms_per_step": round(rf["dt"] / max(rf["steps_run"], 1) * 1e3, 4),
+                           "collectives_per_lm_iteration": round(rf["st"]["collectives"] / max(rf["steps_run"], 1), 2),
+                           "chi2_initial": float(rf["ct"][0]), "chi2_final": float(rf["ct"][-1])}
+            fgpu.close()
+            del fprob, fpart
 
     if rank != 0:
         if sharded:
@@ -483,6 +501,8 @@ def main():
         also.append(fixed)
     if venice:
         also.append(venice)
+    if final_mixed:
+        also.append(final_mixed)
     if world == 1 and args.workload == "ladybug-1723" and args.solver is None and args.dtype is None and not args.no_also:
         # BASELINE.json configs[1] next to the default configs[2]: Ladybug-49 fp32, Schur + PCG
         p49 = synth.make_config("ladybug-49")
