@@ -1701,14 +1701,27 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
             const T g0 = g3[3 * (size_t)j0 + li], g1 = g3[3 * (size_t)j1 + li], g2 = g3[3 * (size_t)j2 + li], g3v = g3[3 * (size_t)j3 + li];
             raw += g0; raw += g1; raw += g2; raw += g3v;
           }
-          for (; a < a_end; ++a) raw += g3[3 * (size_t)gg.gidx[a] + li];
+          if (a < a_end) { // 1-3 left: ONE batch with clamped indices (a serial loop is a dependent index -> value round trip per element)
+            const int n = a_end - a, last = a_end - 1;
+            const int j0 = gg.gidx[a], j1 = gg.gidx[a + 1 < last ? a + 1 : last], j2 = gg.gidx[a + 2 < last ? a + 2 : last];
+            const T g0 = g3[3 * (size_t)j0 + li], g1 = g3[3 * (size_t)j1 + li], g2 = g3[3 * (size_t)j2 + li];
+            raw += g0;
+            if (n > 1) raw += g1;
+            if (n > 2) raw += g2;
+          }
         } else {
         for (; a + 4 <= a_end; a += 4) { // 4 independent loads in flight, the sum stays in observation order
           const T *gp = g3 + 3 * (size_t)a + li;
           const T g0 = gp[0], g1 = gp[3], g2 = gp[6], g3v = gp[9];
           raw += g0; raw += g1; raw += g2; raw += g3v;
         }
-        for (; a < a_end; ++a) raw += g3[3 * (size_t)a + li];
+        if (a < a_end) { // 1-3 left: one batch, clamped
+          const int n = a_end - a, last = a_end - 1;
+          const T g0 = g3[3 * (size_t)a + li], g1 = g3[3 * (size_t)(a + 1 < last ? a + 1 : last) + li], g2 = g3[3 * (size_t)(a + 2 < last ? a + 2 : last) + li];
+          raw += g0;
+          if (n > 1) raw += g1;
+          if (n > 2) raw += g2;
+        }
         }
 #else
         raw = (T)(a_end - a);
