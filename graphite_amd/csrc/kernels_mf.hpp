@@ -822,7 +822,19 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
       idx = (int)(cc * (cc + 1) / 2 + r);
     } else idx = 45 + (int)(e - 81u);
     T s = 0;
-    for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) s += cam_partial[54 * (size_t)sg + idx];
+    { // four loads in flight (the last batch clamped), added in segment order
+      int sg = cam_seg_ptr[c];
+      const int sg1 = cam_seg_ptr[c + 1], last = sg1 - 1;
+      for (; sg < sg1; sg += 4) {
+        const int n = sg1 - sg;
+        const T q0 = cam_partial[54 * (size_t)sg + idx], q1 = cam_partial[54 * (size_t)(sg + 1 < last ? sg + 1 : last) + idx],
+                q2 = cam_partial[54 * (size_t)(sg + 2 < last ? sg + 2 : last) + idx], q3 = cam_partial[54 * (size_t)(sg + 3 < last ? sg + 3 : last) + idx];
+        s += q0;
+        if (n > 1) s += q1;
+        if (n > 2) s += q2;
+        if (n > 3) s += q3;
+      }
+    }
     const bool fixed = cam_fixed && cam_fixed[c];
     if (fixed) s = T(0);
     if (e < 81u) {
@@ -985,7 +997,13 @@ __global__ void __launch_bounds__(TPB) k_shard_cam_sums(int Nc, int scale_system
   const unsigned t = blockIdx.x * TPB + threadIdx.x;
   if (t >= 90u * (unsigned)Nc) return;
   T s = T(0);
-  for (int r = 0; r < fz.size; ++r) s += ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, s_set, r)) + t);
+  for (int r0 = 0; r0 < fz.size; r0 += 8) { // eight uncached loads in flight, added in rank order
+    T q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, s_set, r0 + u < fz.size ? r0 + u : fz.size - 1)) + t);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (r0 + u < fz.size) s += q[u];
+  }
   const unsigned c = t / 90u, e = t % 90u;
   if (e < 81u) {
     Hcc[81 * (size_t)c + e] = s;
@@ -1237,8 +1255,21 @@ __device__ __forceinline__ void shard_push_tail(const ShardPush &sp, const PcgSt
     for (int e = threadIdx.x; e < 9 * nfin; e += TPB) {
       const int cc = s_list[e / 9], i = e % 9;
       T row = T(0);
-      for (int sg = sp.cam_seg_ptr[cc]; sg < sp.cam_seg_ptr[cc + 1]; ++sg)
-        row += __hip_atomic_load(&op_partial[9 * (size_t)sg + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      { // uncached loads (another XCD's workgroup wrote them): four in flight, the last batch clamped, added in segment order
+        int sg = sp.cam_seg_ptr[cc];
+        const int sg1 = sp.cam_seg_ptr[cc + 1], last = sg1 - 1;
+        for (; sg < sg1; sg += 4) {
+          const int n = sg1 - sg;
+          const T q0 = __hip_atomic_load(&op_partial[9 * (size_t)sg + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                  q1 = __hip_atomic_load(&op_partial[9 * (size_t)(sg + 1 < last ? sg + 1 : last) + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                  q2 = __hip_atomic_load(&op_partial[9 * (size_t)(sg + 2 < last ? sg + 2 : last) + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                  q3 = __hip_atomic_load(&op_partial[9 * (size_t)(sg + 3 < last ? sg + 3 : last) + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          row += q0;
+          if (n > 1) row += q1;
+          if (n > 2) row += q2;
+          if (n > 3) row += q3;
+        }
+      }
       for (int r = 0; r < fz.size; ++r) ipc_store(reinterpret_cast<T *>(fz.slot(fz.push_box(r), set, fz.push_slot(r))) + 9 * (size_t)cc + i, fz.push_value(r, row));
     }
     pushed += nfin;
@@ -1602,10 +1633,30 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         const unsigned c = t / 9u, i = t % 9u;
         T raw = 0;
         if (fused) { // the ranks' camera rows, summed here in rank order (the same bits on every rank)
-          for (int rk = 0; rk < fz.size; ++rk) raw += ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, fz_set, rk)) + t);
+          for (int r0 = 0; r0 < fz.size; r0 += 8) { // eight uncached loads in flight instead of a chain of them; added in rank order
+            T q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, fz_set, r0 + u < fz.size ? r0 + u : fz.size - 1)) + t);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (r0 + u < fz.size) raw += q[u];
+          }
         } else if (raw_c) raw = raw_c[t]; // multi-GPU: camera rows already summed over segments and ranks
         else
-          for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) raw += op_partial[9 * (size_t)sg + i];
+        {
+          // the workgroups that hold a camera tile start their point share after it: the segment sums are on the launch's critical
+          // path — four loads in flight (the last batch clamped), added in segment order
+          int sg = cam_seg_ptr[c];
+          const int sg1 = cam_seg_ptr[c + 1], last = sg1 - 1;
+          for (; sg < sg1; sg += 4) {
+            const int n = sg1 - sg;
+            const T q0 = op_partial[9 * (size_t)sg + i], q1 = op_partial[9 * (size_t)(sg + 1 < last ? sg + 1 : last) + i],
+                    q2 = op_partial[9 * (size_t)(sg + 2 < last ? sg + 2 : last) + i], q3 = op_partial[9 * (size_t)(sg + 3 < last ? sg + 3 : last) + i];
+            raw += q0;
+            if (n > 1) raw += q1;
+            if (n > 2) raw += q2;
+            if (n > 3) raw += q3;
+          }
+        }
         if (gg.cam_fixed && gg.cam_fixed[c]) raw = T(0);
         T pv;
         if (!lazy) pv = p[t];
@@ -1929,7 +1980,17 @@ __global__ void k_cam_rows(int Nc, const int *__restrict__ cam_seg_ptr, const T 
   if (t >= 9u * (unsigned)Nc) return;
   const unsigned c = t / 9u, i = t % 9u;
   T raw = 0;
-  for (int sg = cam_seg_ptr[c]; sg < cam_seg_ptr[c + 1]; ++sg) raw += op_partial[9 * (size_t)sg + i];
+  int sg = cam_seg_ptr[c];
+  const int sg1 = cam_seg_ptr[c + 1], last = sg1 - 1;
+  for (; sg < sg1; sg += 4) { // four loads in flight (the last batch clamped), added in segment order
+    const int n = sg1 - sg;
+    const T q0 = op_partial[9 * (size_t)sg + i], q1 = op_partial[9 * (size_t)(sg + 1 < last ? sg + 1 : last) + i],
+            q2 = op_partial[9 * (size_t)(sg + 2 < last ? sg + 2 : last) + i], q3 = op_partial[9 * (size_t)(sg + 3 < last ? sg + 3 : last) + i];
+    raw += q0;
+    if (n > 1) raw += q1;
+    if (n > 2) raw += q2;
+    if (n > 3) raw += q3;
+  }
   raw_c[t] = raw;
 }
 
