@@ -54,13 +54,18 @@ struct UploadRing {
   void ensure() { if (!base) GR_HIP(hipHostMalloc(reinterpret_cast<void **>(&base), CAP, hipHostMallocDefault)); }
   void upload(void *dst, const void *src, size_t bytes, hipStream_t s) {
     if (!bytes) return;
-    if (bytes > CAP / 2) { GR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s)); return; }
     ensure();
-    const size_t need = (bytes + 255) & ~(size_t)255;
-    if (used + need > CAP) { GR_HIP(hipDeviceSynchronize()); used = 0; }
-    std::memcpy(base + used, src, bytes);
-    GR_HIP(hipMemcpyAsync(dst, base + used, bytes, hipMemcpyHostToDevice, s));
-    used += need;
+    // larger than half the ring: in half-ring pieces (a pageable hipMemcpyAsync of Final-13682's 107 MB of points ran at ~5 GB/s and
+    // finished INSIDE the next call that synchronised: 15-23 ms of "set-up" in a 3-iteration LM call), then waited for here
+    const bool large = bytes > CAP / 2;
+    for (size_t off = 0; off < bytes;) {
+      const size_t chunk = std::min(bytes - off, CAP / 2), need = (chunk + 255) & ~(size_t)255;
+      if (used + need > CAP) { GR_HIP(hipDeviceSynchronize()); used = 0; }
+      std::memcpy(base + used, static_cast<const char *>(src) + off, chunk);
+      GR_HIP(hipMemcpyAsync(static_cast<char *>(dst) + off, base + used, chunk, hipMemcpyHostToDevice, s));
+      used += need; off += chunk;
+    }
+    if (large) GR_HIP(hipStreamSynchronize(s));
   }
   static UploadRing &get() { static thread_local UploadRing r; return r; }
 };
