@@ -26,7 +26,7 @@ EXPORTS = [
     "gr_bal_solver_update_structure", "gr_bal_solver_update_values", "gr_bal_solver_set_damping",
     "gr_bal_solver_solve", "gr_bal_schur_update_values", "gr_bal_schur_matvec",
     "gr_bal_landmark_update", "gr_bal_schur_structure", "gr_bal_get", "gr_bal_hessian_structure", "gr_bal_export_csc",
-    "gr_bal_levenberg_marquardt", "gr_bal_kernel_stats", "gr_comm_unique_id", "gr_bal_comm_init", "gr_bal_comm_ipc_mailbox", "gr_bal_comm_init_ipc", "gr_bal_set_fixed",
+    "gr_bal_levenberg_marquardt", "gr_bal_kernel_stats", "gr_comm_unique_id", "gr_bal_comm_init", "gr_bal_comm_ipc_mailbox", "gr_bal_comm_set_contributors", "gr_bal_comm_init_ipc", "gr_bal_set_fixed",
     "gr_dense_cholesky_solve", "gr_bal_model_evaluate", "gr_bal_tuning_default", "gr_bal_set_tuning", "gr_bal_get_tuning",
     "gr_bal_direct_solver_info", "gr_bal_lm_iteration_seconds",
 ]

@@ -134,6 +134,11 @@ struct IpcFused {
   // plays all V ranks of a V-rank message on its own mailbox — it stores its rows into slot 0 and zeros into slots 1 .. V - 1,
   // raises all V flags, and the consumer sums V slots: the stores, loads and waits of a V-rank message, without the xGMI hops
   int virt = 0;
+  // [Nc] bit r: rank r holds observations of camera c (nullptr: not known, every rank pushes every row).  Shards cut by camera
+  // locality see about 1 / size of the cameras: a rank pushes only the rows of its own cameras and a consumer sums, in rank order,
+  // only the slots of a camera's contributors — the same bits as the full sum (the skipped terms were +0.0), 1 / size of the bytes
+  const unsigned *contrib = nullptr;
+  __device__ __forceinline__ unsigned contributors(unsigned c) const { return contrib ? contrib[c] : ~0u; }
   __device__ __forceinline__ int push_box(int r) const { return virt ? 0 : r; }
   __device__ __forceinline__ int push_slot(int r) const { return virt ? r : rank; }
   template <typename U> __device__ __forceinline__ U push_value(int r, U v) const { return (virt && r) ? U(0) : v; }

@@ -105,6 +105,7 @@ struct EngineBase {
   virtual void direct_solver_info(gr_direct_solver_info &o) = 0;
   virtual double diag_time(int which, int variant, int reps) = 0;
   virtual void set_comm(std::unique_ptr<Comm> c) = 0;
+  virtual void set_contributors(const unsigned *mask, int64_t count) = 0;
   virtual void allreduce_host(double *v, size_t n) = 0;
   virtual void apply_tuning() = 0; // after `tune` changed
   gr_bal_tuning tune;
@@ -947,7 +948,7 @@ template <typename T> struct Engine final : EngineBase {
       Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg, true);
       const bool fz_lin = comm && !diag_running && shard_fused_lin();
       IpcFused fz{};
-      if (fz_lin) { ipc_comm()->virtual_ranks = tune.shard_virtual_ranks; fz = ipc_comm()->fused(); }
+      if (fz_lin) fz = fused_fz();
       launch(k_linearize_finalize<T>, cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)np_fin, TPB), (int)Nc, np_fin, scale_system ? 1 : 0, comm ? 0 : 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
                                                                                                     spec_seq ? rho_partial.p : nullptr, spec_seq ? rho_blocks : 0, (spec_seq && (!comm || fz_lin)) ? h_res : nullptr, h_seq, spec_seq,
                                                                                                     gate, cam_fixed_p(), pt_fixed_p(), fz, (unsigned long long)shard_lin_scal_off());
@@ -1425,12 +1426,38 @@ template <typename T> struct Engine final : EngineBase {
     return shard_dots_off() + NSLOT * sizeof(double) <= ic->fused_slot_bytes();
   }
   bool fused_agreed = false;
+  // which ranks hold observations of which camera (IpcFused::contrib): bit r of entry c.  Agreed with the fusion itself (one host
+  // all-reduce of 2^rank per held camera: exact in a double up to 32 ranks); gr_bal_comm_set_contributors overrides it (projection
+  // runs, where one rank plays all: tools/shard_projection.py hands in the masks of the real partition)
+  DevBuf<unsigned> d_contrib;
+  bool contrib_forced = false;
   void agree_on_fusion() {
     fused_agreed = false;
     if (!ipc_comm()) return;
     double mine = shard_fused_local() ? 1.0 : 0.0;
     if (comm->size > 1) allreduce_host(&mine, 1);
     fused_agreed = mine == (double)comm->size;
+    if (contrib_forced) return;
+    d_contrib.release();
+    if (comm->size > 32) return; // no masks: every rank pushes every row
+    std::vector<double> m(Nc);
+    for (int64_t c = 0; c < Nc; ++c) m[c] = h_cam_ptr[c + 1] > h_cam_ptr[c] ? (double)(1u << comm->rank) : 0.0;
+    if (comm->size > 1) allreduce_host(m.data(), m.size());
+    std::vector<unsigned> u(Nc);
+    for (int64_t c = 0; c < Nc; ++c) u[c] = (unsigned)m[c];
+    d_contrib.upload(u, stream);
+  }
+  void set_contributors(const unsigned *mask, int64_t count) override {
+    if (count != Nc) throw std::invalid_argument("contributor masks: one entry per camera");
+    std::vector<unsigned> u(mask, mask + count);
+    d_contrib.upload(u, stream);
+    contrib_forced = true;
+  }
+  IpcFused fused_fz() {
+    ipc_comm()->virtual_ranks = tune.shard_virtual_ranks;
+    IpcFused f = ipc_comm()->fused();
+    f.contrib = d_contrib.n == (size_t)Nc ? d_contrib.p : nullptr;
+    return f;
   }
   bool shard_fused() const { return fused_agreed && !tiled && pcg_mode() == 2; }
   // ... and the linearisation's camera-space sums [Hcc 81 Nc | bc 9 Nc | chi2, rho denominator] pushed by k_linearize_finalize
@@ -1463,8 +1490,7 @@ template <typename T> struct Engine final : EngineBase {
       sp_grid = grid_op;
     }
     ShardPush sp;
-    ipc_comm()->virtual_ranks = tune.shard_virtual_ranks;
-    sp.fz = ipc_comm()->fused();
+    sp.fz = fused_fz();
     sp.cam_seg_ptr = cam_seg_ptr.p; sp.cam_wg = sp_cam_wg.p; sp.cam_cnt = sp_cam_cnt.p; sp.empty = sp_empty.p; sp.n_empty = sp_nempty;
     sp.dots_off = shard_dots_off();
     return sp;
@@ -1500,7 +1526,7 @@ template <typename T> struct Engine final : EngineBase {
     if (st.lazy == 2) {
       const bool fz_on = MODE == 1 && shard_fused();
       launch(k_pcg_update<T, MODE, IDENTITY, 2>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather(),
-             fz_on ? (ipc_comm()->virtual_ranks = tune.shard_virtual_ranks, ipc_comm()->fused()) : IpcFused{}, (unsigned long long)shard_dots_off());
+             fz_on ? fused_fz() : IpcFused{}, (unsigned long long)shard_dots_off());
     }
     else if (st.lazy) launch(k_pcg_update<T, MODE, IDENTITY, 1>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather(), IpcFused{}, 0ull);
     else if (first_lazy) launch(k_pcg_update<T, MODE, IDENTITY, 3>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather(), IpcFused{}, 0ull);
@@ -2618,6 +2644,15 @@ gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int ran
     return GR_OK;
   } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
+}
+gr_status gr_bal_comm_set_contributors(gr_bal_problem *p, const uint32_t *mask, int64_t count) {
+  if (!p || !p->e || !mask) { g_last_error = "gr_bal_comm_set_contributors: bad argument"; return GR_ERR_INVALID; }
+  try {
+    GR_HIP(hipSetDevice(p->e->device));
+    p->e->set_contributors(mask, count);
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
 }
 gr_status gr_bal_comm_ipc_mailbox(gr_bal_problem *p, size_t slot_bytes, int world_size, void *handle_64) {
   if (!p || !p->e || !handle_64 || world_size < 1 || world_size > 64 || slot_bytes < 1024) { g_last_error = "gr_bal_comm_ipc_mailbox: bad argument"; return GR_ERR_INVALID; }

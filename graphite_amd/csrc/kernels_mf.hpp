@@ -841,7 +841,7 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
       Hcc[81 * (size_t)c + e] = s;
       if (row == col && cam_scales) scales[9 * c + row] = (scale_system && !fixed) ? (T)(1.0 / (DBL_EPSILON + sqrt((double)s))) : T(1);
     } else bc[9 * c + (e - 81u)] = s;
-    if (fz.boxes)
+    if (fz.boxes && (!fz.contrib || cam_seg_ptr[c + 1] > cam_seg_ptr[c])) // with contributor masks: only the cameras this rank holds
       for (int r = 0; r < fz.size; ++r) ipc_store(reinterpret_cast<T *>(fz.slot(fz.push_box(r), fz_set, fz.push_slot(r))) + t, fz.push_value(r, s));
   } else if (t >= ncam_pad && t < ncam_pad + FIN_PL * (unsigned)Np) { // point part starts on a block boundary
     // FIN_PL lanes share a point (records j, j + FIN_PL, ...): the serial chain of dependent record loads is
@@ -997,12 +997,13 @@ __global__ void __launch_bounds__(TPB) k_shard_cam_sums(int Nc, int scale_system
   const unsigned t = blockIdx.x * TPB + threadIdx.x;
   if (t >= 90u * (unsigned)Nc) return;
   T s = T(0);
+  const unsigned who = fz.contributors(t / 90u);
   for (int r0 = 0; r0 < fz.size; r0 += 8) { // eight uncached loads in flight, added in rank order
     T q[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) q[u] = ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, s_set, r0 + u < fz.size ? r0 + u : fz.size - 1)) + t);
+    for (int u = 0; u < 8; ++u) q[u] = (r0 + u < fz.size && ((who >> (r0 + u)) & 1u)) ? ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, s_set, r0 + u)) + t) : T(0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) if (r0 + u < fz.size) s += q[u];
+    for (int u = 0; u < 8; ++u) if (r0 + u < fz.size && ((who >> (r0 + u)) & 1u)) s += q[u];
   }
   const unsigned c = t / 90u, e = t % 90u;
   if (e < 81u) {
@@ -1279,6 +1280,7 @@ __device__ __forceinline__ void shard_push_tail(const ShardPush &sp, const PcgSt
     // points cut by camera locality (dist.py) 7/8 of the cameras of a shard are such, and one workgroup pushing all of them was
     // the longest part of the launch (Final-13682: 12 000 cameras x 9 rows x 8 peers)
     const int e0 = (int)((long long)sp.n_empty * blockIdx.x / gridDim.x), e1 = (int)((long long)sp.n_empty * (blockIdx.x + 1) / gridDim.x);
+    if (!fz.contrib) // with contributor masks nobody reads this rank's slot for a camera it does not hold
     for (int e = 9 * e0 + (int)threadIdx.x; e < 9 * e1; e += TPB)
       for (int r = 0; r < fz.size; ++r) ipc_store(reinterpret_cast<T *>(fz.slot(fz.push_box(r), set, fz.push_slot(r))) + 9 * (size_t)sp.empty[e / 9] + e % 9, T(0));
     pushed += e1 - e0;
@@ -1633,12 +1635,13 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         const unsigned c = t / 9u, i = t % 9u;
         T raw = 0;
         if (fused) { // the ranks' camera rows, summed here in rank order (the same bits on every rank)
+          const unsigned who = fz.contributors(c);
           for (int r0 = 0; r0 < fz.size; r0 += 8) { // eight uncached loads in flight instead of a chain of them; added in rank order
             T q[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) q[u] = ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, fz_set, r0 + u < fz.size ? r0 + u : fz.size - 1)) + t);
+            for (int u = 0; u < 8; ++u) q[u] = (r0 + u < fz.size && ((who >> (r0 + u)) & 1u)) ? ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, fz_set, r0 + u)) + t) : T(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (r0 + u < fz.size) raw += q[u];
+            for (int u = 0; u < 8; ++u) if (r0 + u < fz.size && ((who >> (r0 + u)) & 1u)) raw += q[u];
           }
         } else if (raw_c) raw = raw_c[t]; // multi-GPU: camera rows already summed over segments and ranks
         else

@@ -81,6 +81,30 @@ def partition_by_landmark(prob: HostProblem, rank: int, world: int, locality: bo
     return shard
 
 
+def contributor_masks(prob: HostProblem, world: int, locality: bool = True, point_weight: float = POINT_WEIGHT):
+    """(world, Nc) booleans: rank r holds observations of camera c under partition_by_landmark's cut (what the ranks of a real
+    run agree on at gr_bal_solver_update_structure; tools/shard_projection.py hands them to its one-rank runs)."""
+    Nc, Np, No = prob.shape
+    partition_by_landmark(prob, 0, world, locality, point_weight)  # fills the cache
+    _, order, pt_new, ranges = prob._shard_cache
+    cuts = np.array([a for a, _ in ranges] + [ranges[-1][1]])
+    rank_of_obs = np.searchsorted(cuts, pt_new, side="right") - 1
+    cnt = np.bincount(rank_of_obs * Nc + prob.cam_idx.astype(np.int64), minlength=world * Nc)
+    return cnt.reshape(world, Nc) > 0
+
+
+def set_contributors(problem, has, own_rank: int):
+    """gr_bal_comm_set_contributors for a ONE-rank run that plays rank `own_rank` of `has` (contributor_masks): bit 0 = this shard,
+    bits 1.. = the other ranks in rank order (the virtual ranks' slots)."""
+    world = has.shape[0]
+    others = [q for q in range(world) if q != own_rank]
+    mask = has[own_rank].astype(np.uint32)
+    for b, q in enumerate(others):
+        mask |= has[q].astype(np.uint32) << np.uint32(b + 1)
+    mask = np.ascontiguousarray(mask, np.uint32)
+    _lib.check(_lib.lib().gr_bal_comm_set_contributors(problem.h, mask.ctypes.data_as(C.c_void_p), C.c_int64(len(mask))))
+
+
 def assemble_points(shards, pts_per_shard):
     """The ranks' point blocks (each in its shard's numbering) put back into the caller's numbering: (Np, 3)."""
     ids = np.concatenate([np.asarray(s.point_ids) for s in shards])

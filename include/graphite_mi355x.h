@@ -318,6 +318,11 @@ gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int ran
 gr_status gr_bal_comm_ipc_mailbox(gr_bal_problem *p, size_t slot_bytes, int world_size, void *handle_64);
 gr_status gr_bal_comm_init_ipc(gr_bal_problem *p, const void *handles_world_x_64, int rank, int world_size,
                                const void *unique_id_128, int *used_ipc);
+/* Which ranks hold observations of which camera: mask[c] bit r (world_size <= 32).  The mailbox transport agrees on these masks itself
+ * (gr_bal_solver_update_structure: one host all-reduce) — a rank then pushes only the camera rows it holds and sums only the
+ * contributors' slots.  This call overrides them; it exists for tools/shard_projection.py, where ONE rank plays all the ranks of a
+ * message (gr_bal_tuning.shard_virtual_ranks) and must be told the masks of the real partition.  count = number of cameras. */
+gr_status gr_bal_comm_set_contributors(gr_bal_problem *p, const uint32_t *mask, int64_t count);
 /* Dense SPD solve A x = b on the MFMA Cholesky that GR_SOLVER_DENSE_SCHUR uses (the numerical role of
  * Eigen::SimplicialLDLT in src/eigen_solver.cpp:8-30 / cuDSS in solver/cudss.hpp:183-256 once S is dense).
  * A: n x n row-major, leading dimension lda, lower triangle read; A, b, x host or device pointers (x may

@@ -26,7 +26,9 @@ for name, tune in (("WHOLE problem, one GPU, no communicator", None),) + forms:
         src = part
         g = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dt, shard=True)
         gdist.init_comm_ipc(g, 0, 1, slot_bytes=max(4 << 20, world * (90 * prob.shape[0] * 8 + 4096)), rccl_fallback=False)  # the virtual ranks cut a slot into `world` pieces
-    if tune: g.set_tuning(**tune)
+    if tune:
+        if tune.get("shard_virtual_ranks"): gdist.set_contributors(g, gdist.contributor_masks(prob, world), 0)
+        g.set_tuning(**tune)
     g.levenberg_marquardt(iterations=3, **kw)
     g.set_params(src.cameras, src.points)
     ct, lt, st = g.levenberg_marquardt(iterations=10, **kw)

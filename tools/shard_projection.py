@@ -69,10 +69,13 @@ def main():
     g.close()
     shards = []
     lat1 = None
+    has = gdist.contributor_masks(prob, args.world, point_weight=gdist.point_weight_for(dtype))
+    print("contributors per camera: mean %.2f of %d ranks" % (has.sum(0).mean(), args.world), file=sys.stderr)
     for r in range(args.world):
         part = gdist.partition_by_landmark(prob, r, args.world, point_weight=gdist.point_weight_for(dtype))
         g = ga.BalProblem(part.cameras, part.points, part.obs, part.cam_idx, part.pt_idx, dtype=dtype, shard=True)
         gdist.init_comm_ipc(g, 0, 1, slot_bytes=max(4 << 20, args.world * (90 * Nc * 8 + 4096)), rccl_fallback=False)  # one slot holds the largest grouped message (Hcc + bc + chi2)
+        gdist.set_contributors(g, has, r)  # the masks the ranks of a real run agree on; here one rank plays them all
         if args.unfused:
             g.set_tuning(shard_fused=0)
         else:
@@ -98,7 +101,9 @@ def main():
     c_kernel = c if args.unfused else max(0.0, c - inner)                   # collectives that still have a kernel of their own
     tmax = max(s["seconds_per_lm_iteration"] for s in shards)
     # bytes on the wire: the inner-iteration messages carry a camera vector, the linearisation group (one per LM iteration) 90 Nc scalars
-    wire = (max(0.0, c - 1.0) * 9 * Nc * w + 90 * Nc * w) / (args.link_gbs * 1e9)
+    # a rank pushes only the rows of the cameras it holds (contributor masks): the busiest rank's count sets the wire time
+    held = float(Nc) if args.unfused else float(has.sum(1).max())
+    wire = (max(0.0, c - 1.0) * 9 * held * w + 90 * held * w) / (args.link_gbs * 1e9)
     if args.unfused or args.l8_large_us is None or args.l8_small_us is None:
         t8 = tmax + c_kernel * (l8 - lat1) * 1e-6 + c * args.hop_us * 1e-6 + wire
         priced = "every kernel collective at the camera-vector latency"
@@ -113,7 +118,7 @@ def main():
            "form": "unfused (kernel per all-reduce)" if args.unfused else "inner-iteration message fused into operator / update, %d virtual ranks inside every shard run" % args.world,
            "collectives_with_a_kernel_of_their_own_per_lm_iteration": c_kernel, "fused_messages_per_lm_iteration": 0.0 if args.unfused else inner,
            "L1_us_one_rank_allreduce_camera_vector": lat1, "L8_us_measured_between_%d_processes_on_one_gpu" % args.world: l8,
-           "xgmi_hop_us_assumed_per_message": args.hop_us, "xgmi_link_gbs_assumed": args.link_gbs, "wire_seconds_per_lm_iteration": wire, "camera_vector_kb": msg_kb, "kernel_collectives_priced_as": priced,
+           "xgmi_hop_us_assumed_per_message": args.hop_us, "xgmi_link_gbs_assumed": args.link_gbs, "wire_seconds_per_lm_iteration": wire, "cameras_held_by_the_busiest_rank": held, "contributors_per_camera_mean": float(has.sum(0).mean()), "camera_vector_kb": msg_kb, "kernel_collectives_priced_as": priced,
            "L1_us_large_small": [lat1_large, lat1_small], "L8_us_large_small_measured": [args.l8_large_us, args.l8_small_us],
            "projected_T8_seconds_per_lm_iteration": t8, "projected_lm_iterations_per_sec": 1.0 / t8, "projected_speedup": t1 / t8,
            "speedup_if_collectives_were_free": t1 / (tmax - c_kernel * lat1 * 1e-6),
