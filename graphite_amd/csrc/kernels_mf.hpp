@@ -1225,13 +1225,13 @@ __device__ __forceinline__ double slot_sum_agent(const double *base) { // whole 
 // counters are touched (relaxed tickets, cdna_hip_programming.md G16 form R1); across GPUs: write-through system-scope stores,
 // drained by every thread, relaxed launch-wide counter, and ONE system fence in the workgroup that raises the flags.
 template <typename T>
-__device__ __forceinline__ void shard_push_tail(const ShardPush &sp, const PcgState &st, int k, int Nc, int c_lo, int c_hi, const T *__restrict__ op_partial) {
+__device__ __forceinline__ void shard_push_tail(const ShardPush &sp, const PcgState &st, int k, int Nc, int c_lo, int c_hi, const T *__restrict__ op_partial, unsigned long long seq_before) {
   const IpcFused &fz = sp.fz;
   __shared__ int s_list[TPB];
   __shared__ int s_n;
   __shared__ unsigned s_last;
   __shared__ unsigned long long s_seq;
-  if (threadIdx.x == 0) s_seq = __hip_atomic_load(fz.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull; // this launch's message
+  if (threadIdx.x == 0) s_seq = seq_before + 1ull; // this launch's message (the count was loaded by thread 0 at the START of the launch: an uncached round trip off the tail)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads(); // every segment partial (and the DEN atomic) of this workgroup has left the CU
   const unsigned long long seq = s_seq;
@@ -1386,6 +1386,8 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     if (!(k == 0 && st.ts_op && st.part0) && slot_sum(st.slots(k, RZP), 0) == 0.0) return;
   }
   __shared__ double red[4];
+  unsigned long long fuse_seq = 0; // FUSE: messages pushed so far (only this launch's last workgroup changes it, after every workgroup has read it)
+  if (FUSE && threadIdx.x == 0) fuse_seq = __hip_atomic_load(sp.fz.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (LAZY == 0 && k == 0 && st.ts_op && st.part0 && blockIdx.x == gridDim.x - 1) {
     // PcgState::part0: the PCG start's dots, one partial per workgroup of k_finalize_bj, summed here in workgroup order
 #pragma unroll
@@ -1536,7 +1538,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     int c_lo = 0, c_hi = -1;
     const long long j_first = (long long)t0 * TPB, j_end = (long long)t1 * TPB < (long long)No ? (long long)t1 * TPB : (long long)No;
     if (t0 < t1 && j_first < j_end) { c_lo = cam_cm[j_first]; c_hi = cam_cm[j_end - 1]; }
-    shard_push_tail<T>(sp, st, k, Nc, c_lo, c_hi, op_partial);
+    shard_push_tail<T>(sp, st, k, Nc, c_lo, c_hi, op_partial, fuse_seq);
   }
 }
 
