@@ -1472,13 +1472,13 @@ template <typename T> struct Engine final : EngineBase {
     if (sp_grid != grid_op) { // per camera: how many workgroups of the operator grid hold observations of it (xcd_tile_range, plain form)
       std::vector<int> wg(Nc, 0), empty;
       const std::vector<int> h_cam = cam_cm.download(stream);
-      const int nb = grid_op >> 3, nt = nb_pm;
+      const int nb = grid_op >> 3, nblk = (int)((No + 63) >> 6); // as xcd_obs_range (kernels_mf.hpp), plain form: ranges of 64-observation blocks
       for (int b = 0; b < grid_op; ++b) {
         const int x = b & 7, bi = b >> 3;
-        const int x0 = (int)((long long)x * nt / 8), x1 = (int)((long long)(x + 1) * nt / 8);
-        const int t0 = x0 + (int)((long long)bi * (x1 - x0) / nb), t1 = x0 + (int)((long long)(bi + 1) * (x1 - x0) / nb);
-        const long long j0 = (long long)t0 * TPB, j1 = std::min<long long>((long long)t1 * TPB, (long long)No);
-        if (t0 >= t1 || j0 >= j1) continue;
+        const int x0 = (int)((long long)x * nblk / 8), x1 = (int)((long long)(x + 1) * nblk / 8);
+        const int b0 = x0 + (int)((long long)bi * (x1 - x0) / nb), b1 = x0 + (int)((long long)(bi + 1) * (x1 - x0) / nb);
+        const long long j0 = (long long)b0 << 6, j1 = std::min<long long>((long long)b1 << 6, (long long)No);
+        if (j0 >= j1) continue;
         for (int c = h_cam[j0]; c <= h_cam[j1 - 1]; ++c) if (h_cam_ptr[c + 1] > h_cam_ptr[c]) wg[c]++;
       }
       for (int64_t c = 0; c < Nc; ++c) if (h_cam_ptr[c + 1] == h_cam_ptr[c]) empty.push_back((int)c);

@@ -600,6 +600,32 @@ __device__ __forceinline__ void xcd_tile_range(int ntiles, int &t0, int &t1, int
   tstep = 1;
 }
 
+// The same partition as an observation range [j0, jlim) walked in steps of jstride, niter workgroup tiles.  Plain form (ntiles >= 0):
+// the ranges are cut at 64-observation WAVE blocks, not at 256-observation workgroup tiles — Ladybug-1723 has 3.45 tiles per
+// workgroup, i.e. 3 or 4, and a CU that drew three 4-tile workgroups carried 48 wave blocks against an average of 41.4 (the kernels
+// are bound per CU by their memory instructions); cut by wave blocks every workgroup has 13 or 14.  Its last tile is then partly
+// empty (whole waves idle: ranges start and end on 64-observation boundaries, so the (wave, camera) segments are unchanged).
+__device__ __forceinline__ void xcd_obs_range(int ntiles, int No, int &j0, int &jstride, int &niter, int &jlim) {
+  const int nb = gridDim.x >> 3, x = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  if (ntiles < 0) {
+    const int nt = -ntiles;
+    const int x0 = (int)((long long)x * nt / 8), x1 = (int)((long long)(x + 1) * nt / 8), t0 = x0 + bi;
+    j0 = t0 * TPB; jstride = nb * TPB;
+    niter = t0 < x1 ? (x1 - t0 + nb - 1) / nb : 0;
+    const long long lim = (long long)x1 * TPB;
+    jlim = lim < (long long)No ? (int)lim : No;
+    return;
+  }
+  const int nblk = (No + 63) >> 6;
+  const int x0 = (int)((long long)x * nblk / 8), x1 = (int)((long long)(x + 1) * nblk / 8);
+  const int b0 = x0 + (int)((long long)bi * (x1 - x0) / nb), b1 = x0 + (int)((long long)(bi + 1) * (x1 - x0) / nb);
+  j0 = b0 << 6;
+  const long long lim = (long long)b1 << 6;
+  jlim = lim < (long long)No ? (int)lim : No;
+  jstride = TPB;
+  niter = jlim > j0 ? (jlim - j0 + TPB - 1) / TPB : 0;
+}
+
 // scalars of iteration k as every wave derives them (all lanes must call)
 struct PcgIter { double rzp, rscale, rz; };
 __device__ __forceinline__ PcgIter pcg_iter(const PcgState &st, int k) {
@@ -691,20 +717,20 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
   __shared__ double red[4];
   using V2 = typename Vec2T<T>::type;
   const int lane = threadIdx.x & 63;
-  int t0, t1, tstep;
-  xcd_tile_range(ntiles, t0, t1, tstep);
+  int j0, jstride, niter, jlim;
+  xcd_obs_range(ntiles, No, j0, jstride, niter, jlim);
   double chi2 = 0.0;
-  int j = t0 * TPB + threadIdx.x;
-  bool valid = t0 < t1 && j < No;
+  int j = j0 + threadIdx.x;
+  bool valid = niter > 0 && j < jlim;
   int c_n = -1, l_n = 0, a_n = 0;
   V2 o_n{};
   if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm[j]; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
-  for (int t = t0; t < t1; t += tstep) {
+  for (int it = 0; it < niter; ++it) {
     const int c = c_n, l = l_n;
     const size_t a = (size_t)a_n;
     const V2 o = o_n;
-    const int jn = j + tstep * TPB;
-    const bool validn = (t + tstep < t1) && jn < No;
+    const int jn = j + jstride;
+    const bool validn = (it + 1 < niter) && jn < jlim;
     if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm[jn]; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
     T Jc[18], e0 = 0, e1 = 0, w = 0;
 #pragma unroll
@@ -1407,8 +1433,8 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
   const bool lazy_old = LAZY == 1 && k > 0;
   const T *zs = static_cast<const T *>(st.zs);
   const T lz_beta = stp.beta, lz_scale = stp.scale;
-  int t0, t1, tstep;
-  xcd_tile_range(ntiles, t0, t1, tstep);
+  int j0, jstride, niter, jlim;
+  xcd_obs_range(ntiles, No, j0, jstride, niter, jlim);
   double den = 0;
   // One 64-observation tile of a wave, given its index streams and its gathered point record: wave-uniform camera data (24-scalar
   // pack, 9 direction scalars, segment id) are fetched per DISTINCT camera of the wave through a uniform index, i.e. with scalar
@@ -1499,17 +1525,17 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     }
     return g;
   };
-  int j = t0 * TPB + threadIdx.x;
-  bool valid = t0 < t1 && j < No;
+  int j = j0 + threadIdx.x;
+  bool valid = niter > 0 && j < jlim;
   int c_n = -1, l_n = 0, a_n = 0;
   V2 o_n{};
   if (valid) { c_n = cam_cm[j]; l_n = pt_cm[j]; a_n = pos_cm ? pos_cm[j] : j; o_n = reinterpret_cast<const V2 *>(obs_cm)[j]; }
-  for (int t = t0; t < t1; t += tstep) {
+  for (int it = 0; it < niter; ++it) {
     const int c = c_n, l = l_n;
     const size_t a = (size_t)a_n;
     const V2 o = o_n;
-    const int jn = j + tstep * TPB;
-    const bool validn = (t + tstep < t1) && jn < No;
+    const int jn = j + jstride;
+    const bool validn = (it + 1 < niter) && jn < jlim;
     if (validn) { c_n = cam_cm[jn]; l_n = pt_cm[jn]; a_n = pos_cm ? pos_cm[jn] : jn; o_n = reinterpret_cast<const V2 *>(obs_cm)[jn]; }
     const size_t lp = (VAR & 2) ? (size_t)(j & 1023) : (size_t)(valid ? l : 0);
     if constexpr (!lazy) {
@@ -1536,8 +1562,7 @@ k_pcg_operator(int No, int Nc, int ntiles, const int *__restrict__ cam_cm, const
     // plain camera-major order (the fused form is not used with point tiles): the workgroup's observations are one contiguous
     // range, its cameras the range between the first and the last one's
     int c_lo = 0, c_hi = -1;
-    const long long j_first = (long long)t0 * TPB, j_end = (long long)t1 * TPB < (long long)No ? (long long)t1 * TPB : (long long)No;
-    if (t0 < t1 && j_first < j_end) { c_lo = cam_cm[j_first]; c_hi = cam_cm[j_end - 1]; }
+    if (niter > 0 && j0 < jlim) { c_lo = cam_cm[j0]; c_hi = cam_cm[jlim - 1]; }
     shard_push_tail<T>(sp, st, k, Nc, c_lo, c_hi, op_partial, fuse_seq);
   }
 }
