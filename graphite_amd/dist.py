@@ -97,6 +97,8 @@ def set_contributors(problem, has, own_rank: int):
     """gr_bal_comm_set_contributors for a ONE-rank run that plays rank `own_rank` of `has` (contributor_masks): bit 0 = this shard,
     bits 1.. = the other ranks in rank order (the virtual ranks' slots)."""
     world = has.shape[0]
+    if world > 32:
+        return  # the masks are 32-bit; beyond that every rank pushes every row (as the engine itself decides)
     others = [q for q in range(world) if q != own_rank]
     mask = has[own_rank].astype(np.uint32)
     for b, q in enumerate(others):

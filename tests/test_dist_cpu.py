@@ -30,6 +30,27 @@ def test_point_ranges_partition_everything():
             assert np.array_equal(s.cameras, prob.cameras)
 
 
+def test_locality_cut_masks_and_reassembly():
+    """Points cut by first observing camera: the shards' contributor masks are what contributor_masks computes, a camera is held by
+    fewer ranks than under the caller's numbering, and assemble_points puts the ranks' point blocks back in the caller's order."""
+    from graphite_amd import dist as gdist, synth
+    prob = synth.make_config("ladybug-49")
+    Nc, Np, No = prob.shape
+    world = 4
+    shards = [gdist.partition_by_landmark(prob, r, world) for r in range(world)]
+    has = gdist.contributor_masks(prob, world)
+    for r, s in enumerate(shards):
+        assert np.array_equal(np.bincount(s.cam_idx, minlength=Nc) > 0, has[r])
+        assert np.array_equal(s.points, prob.points[s.point_ids])
+        first = np.full(s.shape[1], Nc, np.int64)
+        np.minimum.at(first, s.pt_idx, s.cam_idx.astype(np.int64))
+        assert np.all(np.diff(first) >= 0)                             # inside a shard the points are still ordered by first camera
+    assert np.array_equal(gdist.assemble_points(shards, [s.points for s in shards]), prob.points)
+    prob2 = synth.make_config("ladybug-49")
+    has_plain = np.stack([np.bincount(gdist.partition_by_landmark(prob2, r, world, locality=False).cam_idx, minlength=Nc) > 0 for r in range(world)])
+    assert has.sum() < has_plain.sum()                                  # fewer (rank, camera) pairs: shorter messages, longer camera runs
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch
