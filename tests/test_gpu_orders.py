@@ -24,12 +24,17 @@ MODES = {"tiled8_pm": {"GR_PTILES": "8", "GR_G3_GATHER": "0"}, "tiled24_pm": {"G
          "lazy": {"GR_PCG_LAZY": "1"}, "tiled8_lazy": {"GR_PTILES": "8", "GR_PCG_LAZY": "1"},
          # the single-reduction recurrence the landmark shards run, forced on one GPU (equal to the reference recurrence in
          # exact arithmetic; test_single_reduction_pcg_matches_its_oracle_variant holds it to the oracle's restatement of it)
-         "single_reduction": {"GR_PCG_CG": "1"}, "tiled8_single_reduction": {"GR_PTILES": "8", "GR_PCG_CG": "1"}}
+         "single_reduction": {"GR_PCG_CG": "1"}, "tiled8_single_reduction": {"GR_PTILES": "8", "GR_PCG_CG": "1"},
+         # [X Y Z | s.p] point records (a compile-time form of the operator; picked by timing on Final-13682 / Venice-1778), with the
+         # first PCG iteration still saving its direction launch, and the [X Y Z | zs] records of the single-reduction form the shards run
+         "records": {"GR_POINT_RECORDS": "1", "GR_PCG_LAZY": "0"}, "records_gather": {"GR_POINT_RECORDS": "1", "GR_PCG_LAZY": "0", "GR_PTILES": "0", "GR_G3_GATHER": "1"},
+         "single_reduction_records": {"GR_PCG_CG": "1", "GR_POINT_RECORDS": "1"},
+         "single_reduction_records_gather": {"GR_PCG_CG": "1", "GR_POINT_RECORDS": "1", "GR_PTILES": "0", "GR_G3_GATHER": "1"}}
 SOLVERS = ["pcg", "pcg_identity", "pcg_schur_implicit", "pcg_schur", "dense_schur"]
 
 
 def setenv(monkeypatch, mode):
-    for k in ("GR_PTILES", "GR_G3_GATHER", "GR_PCG_LAZY", "GR_PCG_CG"):
+    for k in ("GR_PTILES", "GR_G3_GATHER", "GR_PCG_LAZY", "GR_PCG_CG", "GR_POINT_RECORDS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
