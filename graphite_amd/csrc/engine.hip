@@ -1521,16 +1521,31 @@ template <typename T> struct Engine final : EngineBase {
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
     launch_operator_j<T>(st, k, rec, lm, mu);
   }
+  // k_pcg_update is persistent: a grid beyond what is resident at once runs its excess workgroups as a second, nearly empty round
+  // (the single-reduction form takes 73 VGPRs in fp64 = 6 workgroups per CU, the first-iteration form 68 = 7, against the 8 the
+  // common grid assumes: 512 of a Final-13682 shard's 2 048 workgroups waited for a slot).  Capped per kernel variant, once.
+  template <int MODE, bool IDENTITY, int LZ> int update_grid(int blocks) {
+    static thread_local int per_cu = 0; // one per instantiation (= kernel variant); the same for every problem of the process
+    if (per_cu == 0) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pcg_update<T, MODE, IDENTITY, LZ>), TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 4; }
+      per_cu = std::min(nb, 8);
+    }
+    int b = std::min(blocks, num_cu * per_cu);
+    if (g3_obs_order) b = std::max(8, b / 8 * 8); // the point sweep deals workgroups to XCDs by blockIdx % 8
+    return std::max(1, b);
+  }
   template <int MODE, bool IDENTITY> void launch_update(int blocks, T *x, const T *rawc, int cw, int ui, PcgState st, int k, int nc = -1, int np = -1, const LmDev *lm = nullptr, bool first_lazy = false) {
     const int nc_v = nc < 0 ? (int)Nc : nc, np_v = np < 0 ? (int)Np : np;
+#define GR_UPD(LZ, LM_P, FZ, OFF) launch(k_pcg_update<T, MODE, IDENTITY, LZ>, update_grid<MODE, IDENTITY, LZ>(blocks), nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, LM_P, g3_gather(), FZ, OFF)
     if (st.lazy == 2) {
       const bool fz_on = MODE == 1 && shard_fused();
-      launch(k_pcg_update<T, MODE, IDENTITY, 2>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather(),
-             fz_on ? fused_fz() : IpcFused{}, (unsigned long long)shard_dots_off());
+      GR_UPD(2, nullptr, fz_on ? fused_fz() : IpcFused{}, (unsigned long long)shard_dots_off());
     }
-    else if (st.lazy) launch(k_pcg_update<T, MODE, IDENTITY, 1>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, nullptr, g3_gather(), IpcFused{}, 0ull);
-    else if (first_lazy) launch(k_pcg_update<T, MODE, IDENTITY, 3>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather(), IpcFused{}, 0ull);
-    else launch(k_pcg_update<T, MODE, IDENTITY>, blocks, nc_v, np_v, bu.p, scales.p, x, v_xb.p, v_r.p, v_z.p, v_p.p, g3.p, pt_ptr.p, op_partial.p, cam_seg_ptr.p, rawc, cw, v_diag.p, damping, ui, MinvC.p, MinvP.p, st, k, lm, g3_gather(), IpcFused{}, 0ull);
+    else if (st.lazy) GR_UPD(1, nullptr, IpcFused{}, 0ull);
+    else if (first_lazy) GR_UPD(3, lm, IpcFused{}, 0ull);
+    else GR_UPD(0, lm, IpcFused{}, 0ull);
+#undef GR_UPD
   }
   // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
   // touched once): obs + 3 index streams, ps, packs, points, g3 out, segment partials
