@@ -422,7 +422,13 @@ template <typename T> struct Engine final : EngineBase {
     grid_op = resident(reinterpret_cast<const void *>(&k_pcg_operator<T, 0, T>), 3, sizeof(T) == 8 ? 3 : 4);
     // light vector kernels: several elements per thread (every wave first re-derives the loop scalars from the
     // dot-product slots, so one element per thread made that prologue most of the kernel)
-    grid_vec = std::max(1, std::min(cdiv(n, (size_t)TPB * std::max(1, tune.vec_per_thread)), num_cu * 8));
+    {
+      // grid-stride kernels: no more workgroups than are resident at once (k_pcg_direction takes 69 VGPRs in fp64 = 7 per CU; the 8
+      // assumed before left Final-13682's 2 048-workgroup launches with a second, nearly empty round)
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pcg_direction<T>), TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 4; }
+      grid_vec = std::max(1, std::min(cdiv(n, (size_t)TPB * std::max(1, tune.vec_per_thread)), num_cu * std::min(nb, 8)));
+    }
     if (tiling_tuned) { if (tiled) untile(); tiling_tuned = false; } // timed choices are re-made by the next solver_update_structure
     records_tuned = false;
     if (chol_ready) { chol_ready = false; use_spchol = false; }
@@ -1361,6 +1367,17 @@ template <typename T> struct Engine final : EngineBase {
     Sdiag.alloc(81 * (size_t)Nc); MinvS.alloc(81 * (size_t)Nc); b_schur.alloc(pose_dim); v_q.alloc(pose_dim);
     v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_Ap.alloc(n); v_xb.alloc(n);
   }
+  // k_is_prepare takes 242 VGPRs in fp64 (two workgroups per CU): on the common grid of four per CU half of its persistent
+  // workgroups waited for a slot
+  int grid_is_prepare() {
+    static thread_local int per_cu = 0;
+    if (per_cu == 0) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_is_prepare<T>), TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 2; }
+      per_cu = std::min(nb, 4);
+    }
+    return std::max(8, std::min(grid_obs, num_cu * per_cu) & ~7);
+  }
   void solve_pcg_schur_implicit(int max_iter, double tol, double rej, T *x) {
     ensure_implicit_schur();
     const int ui = damping_identity ? 1 : 0;
@@ -1369,7 +1386,7 @@ template <typename T> struct Engine final : EngineBase {
     k_point_prepare<T><<<cdiv(Np, TPB) + 1, TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, sc, sc_cap, pt_fixed_p());
     {
       Scope s0(this, "is_prepare", No * (2 * w() + 12.0) + (24.0 * Nc + 15.0 * Np) * w() + 54.0 * nseg * w(), No * 700.0);
-      if (jac32) { k_is_prepare<T, float><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); } else { k_is_prepare<T><<<grid_obs, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); }
+      if (jac32) { k_is_prepare<T, float><<<grid_is_prepare(), TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); } else { k_is_prepare<T><<<grid_is_prepare(), TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, Mp.p, vl.p, cam_partial.p); }
     }
     if (comm) { // diagonal blocks of S and b_S: this shard's sums, all-reduced, then combined with the global Hcc, bc
       is_raw.alloc(90 * (size_t)Nc);
