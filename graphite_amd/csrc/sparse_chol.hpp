@@ -316,10 +316,9 @@ template <typename T> __device__ __forceinline__ bool sp_last_arriver(T val, boo
 }
 // forward: y_k = Linv_k (b_k - sum_{j in row(k)} L_kj y_j)
 template <typename T>
-__global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, const T *__restrict__ Linv, SpItems it, const int *__restrict__ rcols, const int *__restrict__ rslot,
-                                                const T *__restrict__ b, T *__restrict__ y, T *__restrict__ partial, unsigned *__restrict__ ticket) {
-  __shared__ T bk[CH_NB];
-  const int item = blockIdx.x, k = it.panel[item], item_id = it.base + item;
+__device__ __forceinline__ void sp_fwd_item(T *__restrict__ bk /* LDS, CH_NB scalars */, const int item, const T *A, const T *Linv, const SpItems &it, const int *__restrict__ rcols,
+                                            const int *__restrict__ rslot, const T *__restrict__ b, T *y, T *__restrict__ partial, unsigned *__restrict__ ticket) {
+  const int k = it.panel[item], item_id = it.base + item;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   T tot[2] = {T(0), T(0)};
   for (int e = it.beg[item]; e < it.end[item]; ++e) {
@@ -354,6 +353,30 @@ __global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, const T
     const T s = rows16_dot<T>(Linv + (size_t)k * CH_NB * CH_NB + r0 * CH_NB, CH_NB, b0, b1, lane);
     if ((lane & 3) == 0) y[k * CH_NB + r0 + (lane >> 2)] = s;
   }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, const T *__restrict__ Linv, SpItems it, const int *__restrict__ rcols, const int *__restrict__ rslot,
+                                                const T *__restrict__ b, T *__restrict__ y, T *__restrict__ partial, unsigned *__restrict__ ticket) {
+  __shared__ T bk[CH_NB];
+  sp_fwd_item<T>(bk, (int)blockIdx.x, A, Linv, it, rcols, rslot, b, y, partial, ticket);
+}
+// Level l's update launch WITH level l's forward-substitution items as its last workgroups (both need the panels of level l and
+// nothing of each other: the update writes tiles of later columns, the substitution reads tiles of earlier ones).  The substitution
+// used to ride on a second stream behind an event per level: each event record was a bubble on the factorisation's stream — in the
+// kernel trace 10 us between panel solve and update, 16 us between update and the next panel solve, on each of 26 levels.
+template <typename T>
+__global__ __launch_bounds__(256) void k_sp_update_fwd(T *A, const int *__restrict__ tiles, const int *__restrict__ kptr, const int *__restrict__ klist,
+                                                       T *Linv, int *__restrict__ fail, int nup, SpItems it, const int *__restrict__ rcols,
+                                                       const int *__restrict__ rslot, const T *__restrict__ b, T *y, T *__restrict__ partial, unsigned *__restrict__ ticket) {
+  extern __shared__ __align__(16) unsigned char ch_smem[];
+  if ((int)blockIdx.x >= nup) {
+    sp_fwd_item<T>(reinterpret_cast<T *>(ch_smem), (int)blockIdx.x - nup, A, Linv, it, rcols, rslot, b, y, partial, ticket);
+    return;
+  }
+  const int cs_raw = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
+  const bool fuse = (cs_raw & SP_FUSE_BIT) != 0;
+  sp_tile_product<T, 1>(reinterpret_cast<T *>(ch_smem), A, A + (size_t)(cs_raw & ~SP_FUSE_BIT) * SP_TT, klist + 2 * (size_t)kptr[blockIdx.x],
+                        kptr[blockIdx.x + 1] - kptr[blockIdx.x], nullptr, fuse, fuse ? Linv + (size_t)tj * SP_TT : nullptr, fail);
 }
 // backward: x_k = Linv_k^T (y_k - sum_{i in col(k)} L_ik^T x_i)
 // (Measured and removed: ONE launch for all levels with an in-kernel grid barrier between them, x exchanged through
@@ -604,6 +627,7 @@ template <typename T> struct SparseChol {
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sp_gemm<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_gemm_lds(sizeof(T))));
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sp_gemm<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(chol_gemm_lds(sizeof(T)), chol_potrf_lds(sizeof(T)))));
       GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sp_potrf<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_potrf_lds(sizeof(T))));
+      GR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sp_update_fwd<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(chol_gemm_lds(sizeof(T)), chol_potrf_lds(sizeof(T)))));
       attrs_set = true;
     }
     GR_HIP(hipStreamSynchronize(stream));
@@ -630,7 +654,7 @@ template <typename T> struct SparseChol {
     k_sp_scatter<T><<<(unsigned)((81 * nnzb + 255) / 256), 256, 0, stream>>>(nnzb, rowi, coli, d_camcol.p, S, A.p, d_tmap.p, nt);
   }
   void factor() { factor_levels([](int) {}); }
-  template <typename After> void factor_levels(After &&after_level) {
+  template <typename After> void factor_levels(After &&after_level, bool ride_fwd = false) {
     GR_HIP(hipMemsetAsync(d_fail.p, 0, sizeof(int), stream));
     const size_t lds_g = chol_gemm_lds(sizeof(T)), lds_p = chol_potrf_lds(sizeof(T));
     const double tb = (double)CH_NB * CH_NB * sizeof(T), tf = 2.0 * CH_NB * CH_NB * CH_NB;
@@ -645,11 +669,14 @@ template <typename T> struct SparseChol {
         if (row_split_trsm) k_sp_trsm_rows<T><<<(CH_NB / SP_SLAB) * ntr, 256, sp_trsm_lds(sizeof(T)), stream>>>(A.p, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], Linv.p);
         else k_sp_gemm<T, 0><<<ntr, 256, lds_g, stream>>>(A.p, d_trsm.p + 2 * (size_t)lvl_trsm_off[l], nullptr, nullptr, Linv.p);
       }
+      const int nf = ride_fwd ? lvl_fitem_off[l + 1] - lvl_fitem_off[l] : 0;
       if (nup) {
         const int nk = h_kptr[lvl_upd_off[l + 1]] - h_kptr[lvl_upd_off[l]];
         Sc sc(sink, "spchol_update", (2.0 * nup + 2.0 * nk) * tb, nk * tf);
-        k_sp_gemm<T, 1><<<nup, 256, std::max(lds_g, lds_p), stream>>>(A.p, d_upd.p + 2 * (size_t)lvl_upd_off[l], d_kptr.p + lvl_upd_off[l], d_klist.p, nullptr, Linv.p, d_fail.p);
-      }
+        if (nf) k_sp_update_fwd<T><<<nup + nf, 256, std::max(lds_g, lds_p), stream>>>(A.p, d_upd.p + 2 * (size_t)lvl_upd_off[l], d_kptr.p + lvl_upd_off[l], d_klist.p, Linv.p, d_fail.p, nup,
+                                                                                     items(d_itf, lvl_fitem_off[l]), d_rcols.p, d_rslot.p, vb.p, vy.p, partial.p, ticket.p);
+        else k_sp_gemm<T, 1><<<nup, 256, std::max(lds_g, lds_p), stream>>>(A.p, d_upd.p + 2 * (size_t)lvl_upd_off[l], d_kptr.p + lvl_upd_off[l], d_klist.p, nullptr, Linv.p, d_fail.p);
+      } else if (nf) k_sp_fwd<T><<<nf, 256, 0, stream>>>(A.p, Linv.p, items(d_itf, lvl_fitem_off[l]), d_rcols.p, d_rslot.p, vb.p, vy.p, partial.p, ticket.p);
       // level l's panels (L_kk^-1, trsm'ed sub-diagonal tiles) are final here; what the update launch above still writes are
       // tiles of LATER columns
       after_level(l);
@@ -661,7 +688,16 @@ template <typename T> struct SparseChol {
   hipStream_t aux = nullptr;
   std::vector<hipEvent_t> lvl_done;
   hipEvent_t aux_done = nullptr, rhs_ready = nullptr;
+  int overlap_form = 1; // 1: level l's forward substitution rides in level l's update launch; 2: on a second stream behind an event per level (round 3)
   void factor_solve(const T *b, T *x) {
+    if (overlap_form != 2) {
+      k_sp_rhs<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, b, vb.p);
+      factor_levels([](int) {}, true);
+      Sc sc(sink, "spchol_solve", 1.0 * (double)factor_tiles * CH_NB * CH_NB * sizeof(T), 2.0 * (double)factor_tiles * CH_NB * CH_NB);
+      backward();
+      k_sp_unpermute<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, vx.p, x);
+      return;
+    }
     if (!aux) {
       GR_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
       GR_HIP(hipEventCreateWithFlags(&aux_done, hipEventDisableTiming));

@@ -125,7 +125,7 @@ typedef struct {
   int32_t pcg_lazy;             /* GR_PCG_LAZY      -1 auto (= 0 since round 3) | 0 | 1: no direction kernel (host-driven LM loop)   */
   int32_t pcg_single_reduction; /* GR_PCG_CG        -1 auto (with a communicator of > 1 rank) | 0 | 1                                */
   int32_t sparse_cholesky;      /* GR_SPARSE_CHOL   -1 auto (when the camera graph dissects) | 0 dense tile Cholesky | 1             */
-  int32_t spchol_overlap;       /* GR_SPCHOL_OVERLAP 1: forward substitution beside the factorisation                               */
+  int32_t spchol_overlap;       /* GR_SPCHOL_OVERLAP 1: a level's forward substitution rides in its update launch | 2: second stream | 0: after */
   int32_t lm_speculate;         /* GR_LM_SPECULATE   1: trial chi2 from a speculative linearisation on accept streaks                */
   int32_t lm_ahead;             /* GR_LM_AHEAD       1: trial linearisation enqueued ahead of the PCG exit flag                      */
   int32_t lm_fused;             /* GR_LM_FUSED       1: fused iteration head (k_finalize_bj), trial step inside the last direction   */
