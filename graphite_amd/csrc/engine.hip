@@ -52,7 +52,7 @@ static void tuning_default(gr_bal_tuning &t) {
   t.chol_fuse = env_int("GR_CHOL_FUSE", 1);
   t.chol_pin = env_int("GR_CHOL_PIN", 1);
   t.spchol_fuse = env_int("GR_SPCHOL_FUSE", 1);
-  t.spchol_slice = std::max(1, env_int("GR_SPCHOL_SLICE", 2));
+  t.spchol_slice = std::max(1, env_int("GR_SPCHOL_SLICE", 1)); // tiles per substitution item (Ladybug-1723 direct Schur: 1 -> 322.5, 2 -> 319.5, 3 -> 314.5, 4 -> 310 LM it/s)
 }
 
 // GR_VERBOSE: host laps of the set-up phases (gr_bal_create is what a drop-in user waits for before the first iteration)

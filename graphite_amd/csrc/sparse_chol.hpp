@@ -299,7 +299,7 @@ template <typename T> __global__ void k_sp_unpermute(int npad, const int *__rest
 // arrives LAST at the panel's ticket adds them in item order (fixed order: reproducible) and finishes the panel.
 // Visibility across XCDs: write-through (agent-scope relaxed atomic) stores, drained, then a relaxed ticket; the last
 // arriver reads with agent-scope loads (cdna_hip_programming.md G16, form R1) — the same hand-off as grid_sum2.
-// tiles per substitution item: SparseChol::slice (gr_bal_tuning.spchol_slice; 6 -> 2: 249 -> 260 LM it/s on Ladybug-1723)
+// tiles per substitution item: SparseChol::slice (gr_bal_tuning.spchol_slice; 6 -> 2: 249 -> 260 LM it/s on Ladybug-1723; 2 -> 1: 319.5 -> 322.5)
 struct SpItems { const int *panel, *beg, *end, *first, *count; int base; }; // per item: panel, slice, first item / item count of its panel (absolute item ids); base = id of this launch's item 0
 template <typename T> __device__ __forceinline__ bool sp_last_arriver(T val, bool writer, T *__restrict__ partial, int item, int idx, unsigned *__restrict__ ticket, int panel, int count) {
   __shared__ bool s_last;
@@ -441,7 +441,7 @@ template <typename T> struct SparseChol {
   bool attrs_set = false;
   static constexpr int LEAF = 56; // cameras per leaf supernode: 504 columns = 4 tiles (8 padding columns)
   bool fuse_potrf = true; // gr_bal_tuning.spchol_fuse: the next level's diagonal tiles factorised inside this level's update launch
-  int slice = 2;          // gr_bal_tuning.spchol_slice: tiles per substitution work item
+  int slice = 1;          // gr_bal_tuning.spchol_slice: tiles per substitution work item
   bool row_split_trsm = true; // panel solves by 32-row slabs (k_sp_trsm_rows)
 
   SparseChol() = default;

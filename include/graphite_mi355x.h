@@ -145,7 +145,7 @@ typedef struct {
   int32_t chol_fuse;            /* GR_CHOL_FUSE      1: dense tile Cholesky factorises the next diagonal tile inside the trailing update   */
   int32_t chol_pin;             /* GR_CHOL_PIN       1: its C tile parked in VGPRs (one workgroup per CU in fp64)                          */
   int32_t spchol_fuse;          /* GR_SPCHOL_FUSE    1: the same fusion in the nested-dissection form                                      */
-  int32_t spchol_slice;         /* GR_SPCHOL_SLICE   2: tiles per work item of its triangular solves                                       */
+  int32_t spchol_slice;         /* GR_SPCHOL_SLICE   1: tiles per work item of its triangular solves                                       */
   int32_t reserved[4];
 } gr_bal_tuning;
 void gr_bal_tuning_default(gr_bal_tuning *t);
