@@ -140,6 +140,26 @@ def test_sparse_cholesky_matches_dense_and_oracle(oracle_mod, monkeypatch, shape
         assert relerr(dx["1"], dx_r) < 1e-9
 
 
+@pytest.mark.parametrize("slice_", ["1", "3"])
+def test_sparse_cholesky_substitution_forms_agree(monkeypatch, slice_):
+    """The forward substitution inside the update launches (GR_SPCHOL_OVERLAP=1, default), on a second stream (2) and after the
+    factorisation (0), with one and several tiles per substitution item: the same step to the last bits (fixed-order sums)."""
+    prob = synth.make_problem(300, 6000, 30000, seed=42, window=10)
+    monkeypatch.setenv("GR_SPARSE_CHOL", "1")
+    monkeypatch.setenv("GR_SPCHOL_SLICE", slice_)
+    dx = {}
+    for form in ("1", "2", "0"):
+        monkeypatch.setenv("GR_SPCHOL_OVERLAP", form)
+        g = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+        g.solver_update_structure(ga.SOLVER_DENSE_SCHUR)
+        g.linearize()
+        g.solver_update_values(ga.SOLVER_DENSE_SCHUR)
+        g.solver_set_damping(ga.SOLVER_DENSE_SCHUR, 1e-4)
+        dx[form], _ = g.solver_solve(ga.SOLVER_DENSE_SCHUR)
+        g.close()
+    assert relerr(dx["1"], dx["2"]) < 1e-12 and relerr(dx["1"], dx["0"]) < 1e-12
+
+
 def test_sparse_cholesky_lm_trace(oracle_mod, monkeypatch):
     monkeypatch.setenv("GR_SPARSE_CHOL", "1")
     prob = synth.make_problem(300, 6000, 30000, seed=42, window=10)
