@@ -337,11 +337,23 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
           bj += q[u][9];
         }
       }
-      for (; sg < sg1; ++sg) {
-        const T *cp = cam_partial + 54 * (size_t)sg;
+      if (sg < sg1) { // 1-3 segments left: one batch with clamped indices instead of a dependent round trip per segment
+        const int nleft = sg1 - sg, last = sg1 - 1;
+        T q[3][10];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) a[i] += cp[idx[i]];
-        bj += cp[45 + j];
+        for (int u = 0; u < 3; ++u) {
+          const T *cp = cam_partial + 54 * (size_t)(sg + u < last ? sg + u : last);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) q[u][i] = cp[idx[i]];
+          q[u][9] = cp[45 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          if (u < nleft) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a[i] += q[u][i];
+            bj += q[u][9];
+          }
       }
       fixed = cam_fixed && cam_fixed[c];
       if (fixed) {
