@@ -143,44 +143,64 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) L[(16 * j + cl) * CH_LP + 16 * i + M::row(lane, r)] = -xacc[r];
   };
+  // 16x16 Cholesky + inverse of diagonal block s by ONE wave: lane r (mod 16) owns row r of the block, then column r of X
+  auto diag_step = [&](int s) {
+    const int o = 16 * s;
+    T a[16], x[16], rsv[16];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = k <= cl ? L[(o + cl) * CH_LP + o + k] : T(0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      T d = lane_bcast<T>(a[j], j);
+      if (!(d > T(0))) { bad = true; d = T(1); }
+      rsv[j] = pivot_rsqrt(d);
+      a[j] = cl == j ? d * rsv[j] : a[j] * rsv[j];
+#pragma unroll
+      for (int k = j + 1; k < 16; ++k) a[k] -= a[j] * lane_bcast<T>(a[j], k);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      T sum = T(0);
+#pragma unroll
+      for (int k = 0; k < m; ++k) sum += lane_bcast<T>(a[k], m) * x[k];
+      x[m] = ((m == cl ? T(1) : T(0)) - sum) * rsv[m];
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k <= cl) L[(o + cl) * CH_LP + o + k] = a[k];
+        if (k > cl) L[(o + cl) * CH_LP + o + k] = x[k];
+      }
+      xd[o + cl] = x[cl];
+    }
+    if (bad && lane == 0) *fail = 1;
+  };
+  // trailing update of ONE 16x16 tile (ti >= tk > s) by the sub-panel column of step s: A_ik -= L_is L_ks^T
+  auto trailing_tile = [&](int s, int q) {
+    const int o = 16 * s;
+    int bi = 0, rem = q;
+    while (rem > bi) { rem -= bi + 1; ++bi; } // q -> (bi, bk) in the lower triangle; q = 0 is the next diagonal block
+    const int ti = s + 1 + bi, tk = s + 1 + rem;
+    acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = L[(16 * ti + M::row(lane, r)) * CH_LP + 16 * tk + cl];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 4 * kk + g;
+      acc = M::mma(-L[(16 * ti + cl) * CH_LP + o + k], L[(16 * tk + cl) * CH_LP + o + k], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) L[(16 * ti + M::row(lane, r)) * CH_LP + 16 * tk + cl] = acc[r];
+  };
+  // LOOK-AHEAD: after the sub-panel solve of step s, wave 0 updates the next diagonal block alone and walks straight into its
+  // serial 16 x 16 step, while the other waves finish the trailing update of step s and row s of the blocked inverse — the diagonal
+  // steps (2 us each, one wave) used to wait for the whole trailing update, and the trailing update for them.  Two workgroup
+  // barriers per step instead of three; every tile is still updated once per step by one wave: same bits.
+  if (wave == 0 && !(skip & 1)) diag_step(0);
+  __syncthreads();
   for (int s = 0; s < NB16; ++s) {
     const int o = 16 * s;
-    if (wave == 0 && !(skip & 1)) {
-      // 16x16 Cholesky + inverse: lane r (mod 16) owns row r of the block, then column r of X
-      T a[16], x[16], rsv[16];
-      bool bad = false;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = k <= cl ? L[(o + cl) * CH_LP + o + k] : T(0);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        T d = lane_bcast<T>(a[j], j);
-        if (!(d > T(0))) { bad = true; d = T(1); }
-        rsv[j] = pivot_rsqrt(d);
-        a[j] = cl == j ? d * rsv[j] : a[j] * rsv[j];
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) a[k] -= a[j] * lane_bcast<T>(a[j], k);
-      }
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        T sum = T(0);
-#pragma unroll
-        for (int k = 0; k < m; ++k) sum += lane_bcast<T>(a[k], m) * x[k];
-        x[m] = ((m == cl ? T(1) : T(0)) - sum) * rsv[m];
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          if (k <= cl) L[(o + cl) * CH_LP + o + k] = a[k];
-          if (k > cl) L[(o + cl) * CH_LP + o + k] = x[k];
-        }
-        xd[o + cl] = x[cl];
-      }
-      if (bad && lane == 0) *fail = 1;
-    }
-    else if (wave != 0 && s >= 2 && !(skip & 4)) {
-      for (int j = wave - 1; j < s - 1; j += NW - 1) inverse_block(s - 1, j); // row s - 1: complete since the barrier that ended step s - 1
-    }
-    __syncthreads();
     // sub-panel solve: L_is = A_is X_ss^T for the 16-row blocks below
     for (int bi = s + 1 + wave; bi < NB16 && !(skip & 2); bi += NW) {
       acc_t acc = {T(0), T(0), T(0), T(0)};
@@ -195,28 +215,15 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
       for (int r = 0; r < 4; ++r) L[(16 * bi + M::row(lane, r)) * CH_LP + o + cl] = acc[r];
     }
     __syncthreads();
-    // trailing update of the 16x16 tiles (bi >= bk > s): A_ik -= L_is L_ks^T
     const int m = NB16 - 1 - s, ntile = m * (m + 1) / 2;
-    for (int q = wave; q < ntile && !(skip & 2); q += NW) {
-      int bi = 0, rem = q;
-      while (rem > bi) { rem -= bi + 1; ++bi; } // q -> (bi, bk) in the lower triangle
-      const int ti = s + 1 + bi, tk = s + 1 + rem;
-      acc_t acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = L[(16 * ti + M::row(lane, r)) * CH_LP + 16 * tk + cl];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int k = 4 * kk + g;
-        acc = M::mma(-L[(16 * ti + cl) * CH_LP + o + k], L[(16 * tk + cl) * CH_LP + o + k], acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) L[(16 * ti + M::row(lane, r)) * CH_LP + 16 * tk + cl] = acc[r];
+    if (wave == 0) {
+      if (ntile > 0 && !(skip & 2)) trailing_tile(s, 0);
+      if (s + 1 < NB16 && !(skip & 1)) diag_step(s + 1); // only this wave touches block (s + 1, s + 1) until the barrier below
+    } else {
+      for (int q = wave; q < ntile && !(skip & 2); q += NW - 1) trailing_tile(s, q);
+      // row s of the inverse: X_ss, the sub-panel solves of the steps before s and the rows of X above it are complete
+      if (!(skip & 4)) for (int j = wave - 1; j < s; j += NW - 1) inverse_block(s, j);
     }
-    __syncthreads();
-  }
-  // the last row of the inverse has nothing left to hide behind
-  if (!(skip & 4)) {
-    for (int j = wave; j < NB16 - 1; j += NW) inverse_block(NB16 - 1, j);
     __syncthreads();
   }
   if (skip & 8) return;
