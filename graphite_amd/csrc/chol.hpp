@@ -85,12 +85,17 @@ template <typename T> __device__ __forceinline__ T lane_bcast(T v, int src);
 template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) {
   return __builtin_bit_cast(float, row_share(__builtin_bit_cast(int, v), src));
 }
+// fp64: ONE 64-bit DPP move (v_mov_b64_dpp row_newbcast, gfx90a+) instead of two 32-bit ones — 240 broadcasts per 16 x 16 diagonal step
+__device__ __forceinline__ long long row_share64(long long v, int src) {
+  switch (src & 15) {
+#define GR_RS(N) case N: return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xf, 0xf, false);
+    GR_RS(0) GR_RS(1) GR_RS(2) GR_RS(3) GR_RS(4) GR_RS(5) GR_RS(6) GR_RS(7) GR_RS(8) GR_RS(9) GR_RS(10) GR_RS(11) GR_RS(12) GR_RS(13) GR_RS(14)
+#undef GR_RS
+    default: return __builtin_amdgcn_update_dpp(v, v, 0x150 + 15, 0xf, 0xf, false);
+  }
+}
 template <> __device__ __forceinline__ double lane_bcast<double>(double v, int src) {
-  const int2 u = __builtin_bit_cast(int2, v);
-  int2 r;
-  r.x = row_share(u.x, src);
-  r.y = row_share(u.y, src);
-  return __builtin_bit_cast(double, r);
+  return __builtin_bit_cast(double, row_share64(__builtin_bit_cast(long long, v), src));
 }
 
 // Diagonal block: L = chol(A_kk) and X = L^-1, entirely in LDS, blocked by 16 so that only the eight
@@ -193,6 +198,20 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) L[(16 * ti + M::row(lane, r)) * CH_LP + 16 * tk + cl] = acc[r];
   };
+  // Write-back of rows [rb, rb + 16) of X = L^-1, lower triangle only, by the waves wv0 .. NW - 1 (8 256 of the 32 768 scalars the
+  // block used to store; L_kk itself is read by nobody once the panel is solved with X, and the strictly upper part of X is zero:
+  // the buffer is zeroed when it is allocated and never written above the diagonal).  Row block s - 1 goes out in window s, under
+  // wave 0's diagonal step: the write-back used to be a 6.6 us tail of the factorisation (tools/potrf_bench.hip).
+  auto store_rows = [&](int rb, int wv0) {
+    if (wave < wv0) return;
+    for (int r = rb + (wave - wv0); r < rb + 16; r += NW - wv0) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int cc = 64 * half + lane;
+        if (cc <= r) Linv[r * CH_NB + cc] = cc < r ? L[cc * CH_LP + r] : xd[r];
+      }
+    }
+  };
   // LOOK-AHEAD: after the sub-panel solve of step s, wave 0 updates the next diagonal block alone and walks straight into its
   // serial 16 x 16 step, while the other waves finish the trailing update of step s and row s of the blocked inverse — the diagonal
   // steps (2 us each, one wave) used to wait for the whole trailing update, and the trailing update for them.  Two workgroup
@@ -223,33 +242,12 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
       for (int q = wave; q < ntile && !(skip & 2); q += NW - 1) trailing_tile(s, q);
       // row s of the inverse: X_ss, the sub-panel solves of the steps before s and the rows of X above it are complete
       if (!(skip & 4)) for (int j = wave - 1; j < s; j += NW - 1) inverse_block(s, j);
+      if (s >= 1 && !(skip & 8)) store_rows(16 * (s - 1), 1); // complete since the barrier that ended window s - 1
     }
     __syncthreads();
   }
-  if (skip & 8) return;
-  // Write-back: ONLY the lower triangle of X = L^-1 (8 256 of the 32 768 scalars the block used to store).  L_kk itself is read
-  // by nobody once the panel is solved with X (the panel GEMM and both triangular solves use X), and the strictly upper part of
-  // X is zero: the buffer is zeroed when it is allocated and never written above the diagonal.  One wave per row, 8 rows in
-  // flight per wave, all LDS reads ahead of the stores.
+  if (!(skip & 8)) store_rows(16 * (NB16 - 1), 0);
   (void)Ag; (void)ld;
-  constexpr int RB = 8;
-  for (int r0 = wave; r0 < CH_NB; r0 += NW * RB) {
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      T xv[RB];
-      const int cc = 64 * half + lane;
-#pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        const int r = r0 + u * NW;
-        xv[u] = (r < CH_NB && cc < r) ? L[cc * CH_LP + r] : ((r < CH_NB && cc == r) ? xd[r] : T(0));
-      }
-#pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        const int r = r0 + u * NW;
-        if (r < CH_NB && cc <= r) Linv[r * CH_NB + cc] = xv[u];
-      }
-    }
-  }
 }
 template <typename T>
 __global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld, int k0, T *__restrict__ Linv, int *__restrict__ fail, int skip = 0) {
