@@ -149,6 +149,7 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
     for (int r = 0; r < 4; ++r) L[(16 * j + cl) * CH_LP + 16 * i + M::row(lane, r)] = -xacc[r];
   };
   // 16x16 Cholesky + inverse of diagonal block s by ONE wave: lane r (mod 16) owns row r of the block, then column r of X
+  __shared__ int s_next;
   auto diag_step = [&](int s) {
     const int o = 16 * s;
     T a[16], x[16], rsv[16];
@@ -220,6 +221,7 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
   __syncthreads();
   for (int s = 0; s < NB16; ++s) {
     const int o = 16 * s;
+    if (t == 0) s_next = 0; // every wave left the previous window's dealing loop before the barrier that ended it
     // sub-panel solve: L_is = A_is X_ss^T for the 16-row blocks below
     for (int bi = s + 1 + wave; bi < NB16 && !(skip & 2); bi += NW) {
       acc_t acc = {T(0), T(0), T(0), T(0)};
@@ -240,10 +242,19 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
       if (s + 1 < NB16 && !(skip & 1)) diag_step(s + 1); // only this wave touches block (s + 1, s + 1) until the barrier below
     } else {
       for (int q = wave; q < ntile && !(skip & 2); q += NW - 1) trailing_tile(s, q);
-      // row s of the inverse: X_ss, the sub-panel solves of the steps before s and the rows of X above it are complete
-      if (!(skip & 4)) for (int j = wave - 1; j < s; j += NW - 1) inverse_block(s, j);
       if (s >= 1 && !(skip & 8)) store_rows(16 * (s - 1), 1); // complete since the barrier that ended window s - 1
     }
+    // row s of the inverse: X_ss, the sub-panel solves of the steps before s and the rows of X above it are complete.  Its s blocks
+    // are dealt from a counter to whichever wave is free — in the late windows the row (O(s^2) MFMA steps) outweighs the 16 x 16
+    // diagonal step, and wave 0 joins once that is done
+    if (!(skip & 4))
+      for (;;) {
+        int j = 0;
+        if (lane == 0) j = atomicAdd(&s_next, 1);
+        j = __builtin_amdgcn_readfirstlane(j);
+        if (j >= s) break;
+        inverse_block(s, j);
+      }
     __syncthreads();
   }
   if (!(skip & 8)) store_rows(16 * (NB16 - 1), 0);
