@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, const int *_
 // (14 us of MFMA on ONE CU + launch + cold loads); four slabs on four CUs divide the MFMA work and read Linv_k (128 KB) once
 // each from L2.  Wave w computes columns [32 w, 32 w + 32) of the slab: 2 x 2 MFMA tiles, K in chunks of 16 through LDS.
 constexpr int SP_SLAB = 32; // rows per slab (panel-solve launch on Ladybug-1723: 25.9 us unsplit, 15.4 us with 32-row slabs, 15.6 us with 16-row slabs;
-                            // K chunks of 32 with the chunks above a wave's columns skipped — X is lower triangular —: 15.0 -> 17.0 us)
+                            // K chunks of 32 with the chunks above a wave's columns skipped — X is lower triangular —: 15.0 -> 17.0 us; all operands requested up
+                            // front, the chunk loop fed from registers: 15.4 us — the launch is not waiting for its loads)
 constexpr size_t sp_trsm_lds(size_t w) { return (size_t)2 * CH_KC * (SP_SLAB + 4 + CH_LDP) * w; }
 // Cg: the slab's first row inside its tile; Qg: Linv_k; sm: sp_trsm_lds bytes of LDS
 template <typename T>
