@@ -9,12 +9,14 @@
 //   optimizer::levenberg_marquardt                                             (optimizer/levenberg_marquardt.hpp)
 // The C ABI at the bottom (include/graphite_mi355x.h) is the drop-in boundary.
 #include "../../include/graphite_mi355x_test.h"
+#include "../../include/graphite_mi355x_model.h"
 #include "comm.hpp"
 #include <hip/hip_ext.h>
 #include <functional>
 #include "kernels_is.hpp"
 #include "chol.hpp"
 #include "sparse_chol.hpp"
+#include "kernels_model.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -108,6 +110,7 @@ struct EngineBase {
   virtual void set_contributors(const unsigned *mask, int64_t count) = 0;
   virtual void allreduce_host(double *v, size_t n) = 0;
   virtual void apply_tuning() = 0; // after `tune` changed
+  virtual void orders(int32_t *obs_order, int32_t *landmark_order) = 0;
   gr_bal_tuning tune;
   std::vector<double> lm_iter_seconds; // last lm(): host time from the start of the loop at which iteration i's decision was observed
   EngineBase() { tuning_default(tune); }
@@ -125,6 +128,18 @@ template <typename T> struct Engine final : EngineBase {
   T loss_delta = 0;
   bool scale_system = true;
   bool jac32 = false; // Jacobian entries evaluated in fp32 and promoted (Graph<double, float>); T = double only
+  // USER-TRAITS engine (graphite_mi355x_model.h): the kernels that call the user's error / jacobian / update live in the user's
+  // translation unit and are reached through this table; nullptr = the built-in BAL camera model (bal_device.hpp)
+  const gr_model_ops *model = nullptr;
+  DevBuf<char> jst;          // stored weighted Jacobian, GR_MODEL_JSTREAMS streams of jst_stride scalars of the storage type
+  int64_t jst_stride = 0;
+  hipEvent_t hook_b = nullptr; // profiling: the stop event of a scope whose body is a user-side launcher
+  void hook_begin() { ++launch_count; if (ext_a) { (void)hipEventRecord(ext_a, stream); hook_b = ext_b; ext_a = ext_b = nullptr; } }
+  void hook_end(int err, const char *what) {
+    if (hook_b) { (void)hipEventRecord(hook_b, stream); hook_b = nullptr; }
+    if (err != 0) throw HipError(std::string("user-traits kernel launcher `") + what + "` failed: " + hipGetErrorString((hipError_t)err));
+  }
+  void no_model(const char *what) const { if (model) throw std::invalid_argument(std::string(what) + ": not available on a user-traits problem (gr_bal_create_model)"); }
 
   // host structure
   std::vector<int> h_pt_ptr, h_cam_pm, h_pt_pm, h_cam_ptr, h_pt_cm, h_pos_cm, h_pm_of_orig;
@@ -189,7 +204,7 @@ template <typename T> struct Engine final : EngineBase {
 #endif
     return cg_cfg < 0 ? (comm && comm->size > 1) : cg_cfg != 0;
   }
-  int pcg_mode() const { return pcg_cg() ? 2 : (pcg_lazy() ? 1 : 0); }
+  int pcg_mode() const { return model ? 0 : (pcg_cg() ? 2 : (pcg_lazy() ? 1 : 0)); }
   DevBuf<T> v_sv;
   DevBuf<T> v_zs;
   bool g3_obs_order = false;
@@ -282,6 +297,7 @@ template <typename T> struct Engine final : EngineBase {
   void tune_point_records() {
     if (records_tuned) return;
     records_tuned = true;
+    if (model) { use_records = false; return; } // landmark parameters are the user's vertex objects, not [X Y Z] records
     if (pcg_mode() == 1) { use_records = false; return; } // the lazy form gathers zs AND ps; the 8-scalar record has room for one (single-reduction form: zs only)
     if (tune.point_records >= 0) { use_records = tune.point_records != 0; return; }
     use_records = false;
@@ -315,15 +331,16 @@ template <typename T> struct Engine final : EngineBase {
   std::map<std::string, KernelProf> prof;
 
   Engine(int64_t nc, int64_t np, int64_t no, const void *c, const void *p, const void *o,
-         const int32_t *ci, const int32_t *pi, int dev, hipStream_t s, bool shard_ = false) {
+         const int32_t *ci, const int32_t *pi, int dev, hipStream_t s, bool shard_ = false, const gr_model_ops *model_ = nullptr) {
     device = dev;
     shard = shard_;
     stream = s;
+    model = model_;
     Nc = nc; Np = np; No = no;
     pose_dim = 9 * (size_t)Nc;
     n = pose_dim + 3 * (size_t)Np;
     Laps lap(tune.verbose != 0, "gr_bal_create");
-    std::vector<T> hc(9 * Nc), hp(3 * Np), ho(2 * No);
+    std::vector<T> hc(9 * Nc), hp(3 * Np), ho(model ? 0 : 2 * No); // user-traits problems: vertex values and observations stay on the user side
     std::vector<int32_t> hci(No), hpi(No);
     // inputs may be host or device pointers; plain host memory (the usual case) is copied by the CPU, not through the runtime
     auto copy_in = [](void *dst, const void *src, size_t bytes) {
@@ -333,9 +350,11 @@ template <typename T> struct Engine final : EngineBase {
       if (e != hipSuccess || at.type == hipMemoryTypeHost || at.type == hipMemoryTypeUnregistered) std::memcpy(dst, src, bytes);
       else GR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
     };
-    copy_in(hc.data(), c, hc.size() * sizeof(T));
-    copy_in(hp.data(), p, hp.size() * sizeof(T));
-    copy_in(ho.data(), o, ho.size() * sizeof(T));
+    if (!model) {
+      copy_in(hc.data(), c, hc.size() * sizeof(T));
+      copy_in(hp.data(), p, hp.size() * sizeof(T));
+      copy_in(ho.data(), o, ho.size() * sizeof(T));
+    }
     copy_in(hci.data(), ci, No * sizeof(int32_t));
     copy_in(hpi.data(), pi, No * sizeof(int32_t));
     // Internal point order = sorted by the first (lowest) camera that observes the point, so that
@@ -413,6 +432,10 @@ template <typename T> struct Engine final : EngineBase {
       return std::max(8, std::min(nb_pm, num_cu * mult) & ~7);
     };
     grid_lin = resident(reinterpret_cast<const void *>(&k_linearize<T, false>), LIN_WAVES, 8);
+    if (model) { // the user-side lineariser's own residency (gr_model_ops.lin_wg_per_cu, from its occupancy query)
+      const int mult = tune.grid_mult > 0 ? tune.grid_mult : std::max(1, std::min(model->lin_wg_per_cu > 0 ? model->lin_wg_per_cu : 3, 8));
+      grid_lin = std::max(8, std::min(nb_pm, num_cu * mult) & ~7);
+    }
     {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_finalize_bj<T>), TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 3; }
@@ -420,6 +443,17 @@ template <typename T> struct Engine final : EngineBase {
     }
     // the operator prefers 3 (fp64) / 4 (fp32) workgroups per CU even where more would fit (Venice-1778 fp32: 83.6 us at 4, 89.7 at its occupancy)
     grid_op = resident(reinterpret_cast<const void *>(&k_pcg_operator<T, 0, T>), 3, sizeof(T) == 8 ? 3 : 4);
+    if (model) {
+      int mult = tune.grid_mult;
+      if (mult <= 0) {
+        if (model->store_jacobians) {
+          int nb = 0;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_pcg_operator_stored<T, T, 9>), TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 4; }
+          mult = std::min(nb, 8);
+        } else mult = std::max(1, std::min(model->op_wg_per_cu > 0 ? model->op_wg_per_cu : 3, 8));
+      }
+      grid_op = std::max(8, std::min(nb_pm, num_cu * mult) & ~7);
+    }
     // light vector kernels: several elements per thread (every wave first re-derives the loop scalars from the
     // dot-product slots, so one element per thread made that prologue most of the kernel)
     {
@@ -496,7 +530,8 @@ template <typename T> struct Engine final : EngineBase {
     }
     lap("point-major counting sort + per-point camera order");
     h_cam_pm.resize(No); h_pt_pm.resize(No); h_pm_of_orig.resize(No);
-    std::vector<T> h_obs_pm(2 * No);
+    const bool with_obs = !ho.empty();
+    std::vector<T> h_obs_pm(with_obs ? 2 * No : 0);
     // per-thread camera histograms of the pm order: the camera-major order below is a stable counting sort by camera whose
     // chunks scatter side by side, each from its own offsets
     std::vector<std::vector<int>> hist(nth, std::vector<int>(Nc + 1, 0));
@@ -505,7 +540,7 @@ template <typename T> struct Engine final : EngineBase {
       for (size_t a = a0; a < a1; ++a) {
         const int o = pm_obs[a];
         h_cam_pm[a] = ci[o]; h_pt_pm[a] = pi[o]; h_pm_of_orig[o] = (int)a;
-        h_obs_pm[2 * a] = ho[2 * (size_t)o]; h_obs_pm[2 * a + 1] = ho[2 * (size_t)o + 1];
+        if (with_obs) { h_obs_pm[2 * a] = ho[2 * (size_t)o]; h_obs_pm[2 * a + 1] = ho[2 * (size_t)o + 1]; }
         hk[ci[o]]++;
       }
     });
@@ -530,13 +565,13 @@ template <typename T> struct Engine final : EngineBase {
     }
     h_pos_cm.resize(No); h_pt_cm.resize(No);
     std::vector<int> h_cam_cm(No);
-    std::vector<T> h_obs_cm(2 * No);
+    std::vector<T> h_obs_cm(with_obs ? 2 * No : 0);
     par_chunks((size_t)No, nth, [&](size_t a0, size_t a1, int k) {
       std::vector<int> &wc = hist[k];
       for (size_t a = a0; a < a1; ++a) {
         const int j = wc[h_cam_pm[a]]++;
         h_pos_cm[j] = (int)a; h_pt_cm[j] = h_pt_pm[a]; h_cam_cm[j] = h_cam_pm[a];
-        h_obs_cm[2 * (size_t)j] = h_obs_pm[2 * a]; h_obs_cm[2 * (size_t)j + 1] = h_obs_pm[2 * a + 1];
+        if (with_obs) { h_obs_cm[2 * (size_t)j] = h_obs_pm[2 * a]; h_obs_cm[2 * (size_t)j + 1] = h_obs_pm[2 * a + 1]; }
       }
     });
     // camera-major chunks: <= CHUNK consecutive observations of one camera per wave
@@ -640,6 +675,7 @@ template <typename T> struct Engine final : EngineBase {
   void tune_tiling() {
     if (tiling_tuned) return;
     tiling_tuned = true;
+    if (model) return; // user-traits problems keep the plain camera-major order (their per-observation streams are laid out in it once)
     tune_tiling_order();
     const size_t per_point = (size_t)(6 * sizeof(T) + 3 * sizeof(T) * (double)No / (double)Np);
     if ((size_t)Np * per_point >= ((size_t)24 << 20)) tune_g3_order();
@@ -871,7 +907,16 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   // ---- Graph --------------------------------------------------------------------
-  void set_loss(int kind, double delta) override { loss_kind = kind; loss_delta = (T)delta; }
+  // gr_bal_model_orders: input index of the observation at camera-major position j; caller's index of engine landmark q
+  void orders(int32_t *obs_order, int32_t *landmark_order) override {
+    if (obs_order) {
+      std::vector<int> orig_of_pm(No);
+      for (int64_t o = 0; o < No; ++o) orig_of_pm[h_pm_of_orig[o]] = (int)o;
+      for (int64_t j = 0; j < No; ++j) obs_order[j] = orig_of_pm[h_pos_cm[j]];
+    }
+    if (landmark_order) for (int64_t q = 0; q < Np; ++q) landmark_order[q] = h_pt_new2old[q];
+  }
+  void set_loss(int kind, double delta) override { no_model("gr_bal_set_loss"); loss_kind = kind; loss_delta = (T)delta; }
   void set_scale_system(bool on) override { scale_system = on; }
   // VertexDescriptor::set_fixed (vertex.hpp:262-264).  The reference gives a fixed vertex no Hessian column and its kernels
   // skip the vertex's Jacobian block; here the vertex keeps its (empty) column: zero block, zero gradient, scale 1, and its
@@ -892,6 +937,7 @@ template <typename T> struct Engine final : EngineBase {
   const unsigned char *cam_fixed_p() const { return has_fixed ? d_cam_fixed.p : nullptr; }
   const unsigned char *pt_fixed_p() const { return has_fixed ? d_pt_fixed.p : nullptr; }
   void set_jacobian_precision(int dtype) override {
+    no_model("gr_bal_set_jacobian_precision");
     if (dtype == GR_F32 && sizeof(T) == 4) { jac32 = false; return; } // already fp32 throughout
     if (dtype != GR_F32 && dtype != GR_F64) throw std::invalid_argument("jacobian precision: GR_F32 or GR_F64");
     if (dtype == GR_F64 && sizeof(T) == 4) throw std::invalid_argument("an fp32 problem cannot evaluate fp64 Jacobians");
@@ -916,17 +962,20 @@ template <typename T> struct Engine final : EngineBase {
     GR_HIP(hipMemcpy(user_dst, b.data(), b.size() * sizeof(T), hipMemcpyDefault));
   }
   void set_params(const void *c, const void *p) override {
+    no_model("gr_bal_set_params");
     GR_HIP(hipMemcpyAsync(cams.p, c, cams.n * sizeof(T), hipMemcpyDefault, stream));
     points_in(p, pts.p, 3);
     xp_valid = false;
   }
   void get_params(void *c, void *p) override {
+    no_model("gr_bal_get_params");
     GR_HIP(hipMemcpyAsync(c, cams.p, cams.n * sizeof(T), hipMemcpyDefault, stream));
     points_out(pts.p, p, 3);
   }
   double w() const { return (double)sizeof(T); }
 
   void campack(const T *dx = nullptr, T *bak = nullptr) {
+    if (model) return; // no pack: the user-side kernels read the user's vertex objects
     k_campack<T><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, cams.p, pack.p, dx, scales.p, bak);
   }
 
@@ -979,6 +1028,23 @@ template <typename T> struct Engine final : EngineBase {
   }
   bool lin_reset = false; // LM loop, fused form: this k_linearize launch also clears the PCG loop state (its last workgroup)
   void launch_linearize_cam(bool hcp, T *g9p, const int *gate) {
+    if (model) {
+      if (model->store_jacobians && !jst.p) {
+        const size_t sw = model->storage_dtype == GR_F64 ? 8 : 4;
+        jst_stride = ((int64_t)No + 63) / 64 * 64;
+        jst.alloc((size_t)GR_MODEL_JSTREAMS * (size_t)jst_stride * sw);
+        GR_HIP(hipMemsetAsync(jst.p, 0, jst.n, stream)); // the streams of zero-padded rows / columns are never written
+      }
+      gr_model_lin_args a{};
+      a.No = (int)No; a.ntiles = o_ntiles(); a.grid = grid_lin;
+      a.cam = o_cam(); a.pt = o_pt(); a.pos = o_pos(); a.blk_seg = blk_seg.p; a.seg_slot = seg_slot.p;
+      a.g9 = g9p; a.Hcp = hcp ? Hcp.p : nullptr; a.cam_partial = cam_partial.p; a.chi2_partial = chi2_partial.p;
+      a.jst = model->store_jacobians ? jst.p : nullptr; a.jst_stride = jst_stride;
+      a.lm = nullptr; a.gate = gate; a.cam_fixed = hcp ? cam_fixed_p() : nullptr; a.pt_fixed = hcp ? pt_fixed_p() : nullptr; a.stream = stream;
+      hook_begin();
+      hook_end(model->linearize(model->ctx, &a), "linearize");
+      return;
+    }
     const PcgState rst = lin_reset ? pcg_state() : PcgState{};
     const int rst_cap = lin_reset ? ctl_cap : 0;
 #ifdef GR_DIAG
@@ -1016,6 +1082,17 @@ template <typename T> struct Engine final : EngineBase {
   // block mirrors both into pinned host memory and then publishes `seq`.
   int chi2_async(T *res_out, const T *dx, double mu) {
     const int seq = ++seq_counter;
+    if (model) {
+      Scope sc(this, "chi2", No * 12.0 + (dx ? 3.0 * n * w() : 0.0), No * 40.0);
+      gr_model_chi2_args a{};
+      a.No = (int)No; a.grid = grid_chi2; a.cam = o_cam(); a.pt = o_pt(); a.pos = o_pos(); a.chi2_partial = chi2_partial.p; a.res_out = res_out; a.stream = stream;
+      hook_begin();
+      hook_end(model->chi2(model->ctx, &a), "chi2");
+      const int nb = std::max(1, std::min(cdiv(n, (size_t)TPB * 4), 256));
+      k_chi2_finish<T><<<nb, TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cam_weight(), chi2_partial.p, grid_chi2, dx, bu.p, scales.p, mu, grid_partial.p, ticket.p, dscalars.p, comm ? nullptr : h_res, h_seq, seq);
+      if (comm) { allreduce_d(dscalars.p, 2); publish_scalars(2, seq); }
+      return seq;
+    }
     Scope sc(this, "chi2", No * (2 * w() + 8) + (24.0 * Nc + 3.0 * Np) * w() + (dx ? 3.0 * n * w() : 0.0), No * 40.0);
     k_chi2<T><<<grid_chi2, TPB, 0, stream>>>((int)No, (unsigned)n, (unsigned)pose_dim, cam_weight(), o_cam(), o_pt(), o_pos(), o_obs(), pts.p, pack.p, loss_kind, loss_delta, dx, bu.p, scales.p, mu, chi2_partial.p, ticket.p, dscalars.p, comm ? nullptr : h_res, h_seq, seq, res_out);
     if (comm) { allreduce_d(dscalars.p, 2); publish_scalars(2, seq); }
@@ -1034,17 +1111,28 @@ template <typename T> struct Engine final : EngineBase {
     return v;
   }
 
+  // user-traits problems: Graph::backup_parameters + apply_update through the user's Traits::update (gr_model_ops.step)
+  void model_step(const T *dx, bool with_backup, double mu, double *rho_part, const LmDev *lm, const int *gate) {
+    gr_model_step_args a{};
+    a.dx = dx; a.scales = scales.p; a.bu = bu.p; a.mu = mu; a.with_backup = with_backup ? 1 : 0; a.cam_weight = cam_weight();
+    a.rho_partial = rho_part; a.lm = lm; a.gate = gate; a.cam_fixed = cam_fixed_p(); a.pt_fixed = pt_fixed_p(); a.stream = stream;
+    hook_begin();
+    hook_end(model->step(model->ctx, &a), "step");
+  }
   void backup() override { // graph.hpp:302-309
+    if (model) { hook_begin(); hook_end(model->backup(model->ctx, stream), "backup"); return; }
     GR_HIP(hipMemcpyAsync(cams_bak.p, cams.p, cams.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
     GR_HIP(hipMemcpyAsync(pts_bak.p, pts.p, pts.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
   }
   void revert() override { // graph.hpp:311-318
+    if (model) { hook_begin(); hook_end(model->revert(model->ctx, stream), "revert"); return; }
     GR_HIP(hipMemcpyAsync(cams.p, cams_bak.p, cams.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
     GR_HIP(hipMemcpyAsync(pts.p, pts_bak.p, pts.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
     xp_valid = false;
     campack(); // the matrix-free operator recomputes J from the pack: keep it in step with the vertices
   }
   void apply_update_dev(const T *dx, bool with_backup = false) { // graph.hpp:292-300, ops/update.hpp:11-31
+    if (model) { model_step(dx, with_backup, 0.0, nullptr, nullptr, nullptr); return; }
     campack(dx, with_backup ? cams_bak.p : nullptr); // cameras: x += dx .* s fused with backup + pack rebuild
     k_apply_update<T><<<cdiv(3 * Np, TPB), TPB, 0, stream>>>((unsigned)(3 * Np), pts.p, dx + pose_dim, scales.p + pose_dim, with_backup ? pts_bak.p : nullptr);
     xp_valid = false;
@@ -1077,6 +1165,7 @@ template <typename T> struct Engine final : EngineBase {
     if (solver == GR_SOLVER_PCG_SCHUR) { build_schur_structure(); want_hcp = true; }
     else if (solver == GR_SOLVER_DENSE_SCHUR) { ensure_chol(); want_hcp = true; }
     else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) {
+      no_model("GR_SOLVER_PCG_SCHUR_IMPLICIT (its kernels recompute the built-in model's Jacobian; use GR_SOLVER_PCG_SCHUR)");
       want_hcp = false; ensure_implicit_schur();
       if (!tiling_tuned) tune_tiling();
       if (want_g3_gather() && !g3_obs_order) build_g3_gather(); // pass 1's output in observation order, gathered by k_is_points
@@ -1534,7 +1623,32 @@ template <typename T> struct Engine final : EngineBase {
 #undef GR_OP_FORM
 #undef GR_OP_ARGS
   }
+  // user-traits problems: the library's operator on the stored weighted Jacobian, or the user-side one that recomputes the blocks
+  template <typename SJ> void launch_operator_stored(PcgState st, int k, const LmDev *lm) {
+    const SJ *j = reinterpret_cast<const SJ *>(jst.p);
+#define GR_OPS(DC) launch(k_pcg_operator_stored<T, SJ, DC>, grid_op, (int)No, (int)Nc, o_ntiles(), o_cam(), o_pt(), g3_pos(), blk_seg.p, seg_slot.p, j, (long long)jst_stride, v_ps.p, g3.p, op_partial.p, st, k, lm)
+    const int dc = model->pose_dim;
+    if (dc <= 6) GR_OPS(6); else if (dc == 7) GR_OPS(7); else GR_OPS(9);
+#undef GR_OPS
+  }
+  void launch_operator_model(PcgState st, int k, const LmDev *lm) {
+    if (st.lazy) throw std::invalid_argument("user-traits problems run the direction-kernel form of the PCG");
+    if (model->store_jacobians) {
+      if (!jst.p) throw std::invalid_argument("stored-Jacobian operator before the first linearisation");
+      if constexpr (sizeof(T) == 8) { if (model->storage_dtype == GR_F32) { launch_operator_stored<float>(st, k, lm); return; } }
+      launch_operator_stored<T>(st, k, lm);
+      return;
+    }
+    if (!model->op) throw std::invalid_argument("gr_model_ops.op is NULL and store_jacobians is 0");
+    gr_model_op_args a{};
+    a.No = (int)No; a.Nc = (int)Nc; a.ntiles = o_ntiles(); a.grid = grid_op; a.cam = o_cam(); a.pt = o_pt(); a.pos = g3_pos();
+    a.blk_seg = blk_seg.p; a.seg_slot = seg_slot.p; a.ps = v_ps.p; a.g3 = g3.p; a.op_partial = op_partial.p;
+    a.den_slots = st.slots(k, DEN); a.done = st.done + k; a.lm = lm; a.stream = stream;
+    hook_begin();
+    hook_end(model->op(model->ctx, &a), "op");
+  }
   void launch_operator(PcgState st, int k, const T *rec, const LmDev *lm = nullptr, double mu = 0.0) {
+    if (model) { launch_operator_model(st, k, lm); return; }
     if constexpr (sizeof(T) == 8) { if (jac32) { launch_operator_j<float>(st, k, rec, lm, mu); return; } }
     launch_operator_j<T>(st, k, rec, lm, mu);
   }
@@ -1567,6 +1681,8 @@ template <typename T> struct Engine final : EngineBase {
   // bytes one matrix-free operator launch has to move at minimum (J recomputed, every array
   // touched once): obs + 3 index streams, ps, packs, points, g3 out, segment partials
   double operator_bytes() const {
+    if (model && model->store_jacobians) // the stored weighted Jacobian + 3 index streams, ps, g3 out, segment partials
+      return No * ((2.0 * std::max(6, (int)model->pose_dim == 7 ? 7 : ((int)model->pose_dim <= 6 ? 6 : 9)) + 6.0) * (model->storage_dtype == GR_F64 ? 8.0 : 4.0) + 12.0) + n * (double)sizeof(T) + 3.0 * No * sizeof(T) + 9.0 * nseg * sizeof(T);
     return No * (2.0 * sizeof(T) + 12.0) + (n + 24.0 * Nc + 3.0 * Np) * sizeof(T) + 3.0 * No * sizeof(T) + 9.0 * nseg * sizeof(T);
   }
   void ensure_ctl(int max_iter) {
@@ -1758,6 +1874,7 @@ template <typename T> struct Engine final : EngineBase {
 #endif
         break;
       case 1:
+        if (model) { launch_linearize_cam(false, g9.p, nullptr); break; }
 #ifdef GR_DIAG
 #define GR_LIN(V) k_linearize<T, false, T, V><<<grid_lin, TPB, 0, stream>>>((int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9.p, nullptr, cam_partial.p, chi2_partial.p)
         switch (variant) { case 1: GR_LIN(1); break; case 2: GR_LIN(2); break; case 3: GR_LIN(3); break; case 4: GR_LIN(4); break; case 7: GR_LIN(7); break; case 8: GR_LIN(8); break; case 15: GR_LIN(15); break; default: GR_LIN(0); }
@@ -2156,7 +2273,9 @@ template <typename T> struct Engine final : EngineBase {
     T nu = 2;
     solver_update_structure(opt.solver);
     const bool pcg_solver = opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY;
-    lm_fused = pcg_solver && !comm && pcg_mode() == 0 && opt.pcg_max_iter >= 1 && tune.lm_fused != 0;
+    // user-traits problems take the host-driven form: the trial step goes through the user's Traits::update (gr_model_ops.step),
+    // which the library's loop-ending direction launch cannot call
+    lm_fused = pcg_solver && !comm && !model && pcg_mode() == 0 && opt.pcg_max_iter >= 1 && tune.lm_fused != 0;
     bool head_enqueued = false; // the head of the NEXT iteration is already in the stream (device-decided accept)
     T chi2v = 0;
     if (lm_fused && opt.iterations > 0) {
@@ -2276,9 +2395,13 @@ template <typename T> struct Engine final : EngineBase {
       // speculative linearisation; `gate` != nullptr: enqueued ahead of the PCG exit flag (run_pcg_iterations)
       auto enqueue_trial = [&](const int *gate) {
         if (time_solve) GR_HIP(hipEventRecord(ev_b, stream));
-        rho_blocks = cdiv(Nc, 28) + cdiv(3 * Np, TPB);
+        rho_blocks = model ? model->step_blocks : cdiv(Nc, 28) + cdiv(3 * Np, TPB);
         rho_partial.alloc(rho_blocks);
         const bool clear_state = ctl_cap > 0 && pcg_solver;
+        if (model) {
+          model_step(v_dx.p, /*with_backup=*/true, (double)mu, rho_partial.p, nullptr, gate);
+          if (clear_state) { k_pcg_state_init<<<1, TPB, 0, stream>>>(pcg_state(), ctl_cap, gate); ++launch_count; }
+        } else
         k_apply_update_rho<T><<<rho_blocks + (clear_state ? 1 : 0), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, pack.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr,
                                                                                        nullptr, clear_state ? pcg_state() : PcgState{}, clear_state ? ctl_cap : 0, gate);
         seq = ++seq_counter;
@@ -2527,8 +2650,14 @@ gr_status gr_warm_up(int device) {
 
 static gr_status create_impl(gr_bal_problem **out, gr_dtype dtype, int64_t nc, int64_t np, int64_t no,
                              const void *cameras, const void *points, const void *observations,
-                             const int32_t *cam_idx, const int32_t *pt_idx, int device, void *stream, bool shard) {
-  if (!out || nc <= 0 || np <= 0 || no <= 0 || !cameras || !points || !observations || !cam_idx || !pt_idx ||
+                             const int32_t *cam_idx, const int32_t *pt_idx, int device, void *stream, bool shard, const gr_model_ops *model = nullptr) {
+  if (model && (model->pose_dim < 1 || model->pose_dim > 9 || model->landmark_dim < 1 || model->landmark_dim > 3 || model->error_dim < 1 || model->error_dim > 2 ||
+                !model->linearize || !model->chi2 || !model->step || !model->backup || !model->revert || (!model->store_jacobians && !model->op) || model->step_blocks < 1 ||
+                (model->storage_dtype != GR_F32 && model->storage_dtype != GR_F64) || (model->storage_dtype == GR_F64 && dtype == GR_F32))) {
+    g_last_error = "gr_bal_create_model: the launcher table does not describe a (<= 9, <= 3) -> <= 2 model";
+    return GR_ERR_INVALID;
+  }
+  if (!out || nc <= 0 || np <= 0 || no <= 0 || (!model && (!cameras || !points || !observations)) || !cam_idx || !pt_idx ||
       no >= (int64_t)std::numeric_limits<int>::max() / 27) {
     g_last_error = "gr_bal_create: bad argument";
     return GR_ERR_INVALID;
@@ -2542,14 +2671,22 @@ static gr_status create_impl(gr_bal_problem **out, gr_dtype dtype, int64_t nc, i
     GR_HIP(hipSetDevice(device));
     auto *p = new gr_bal_problem();
     p->dtype = dtype;
-    if (dtype == GR_F32) p->e.reset(new Engine<float>(nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, (hipStream_t)stream, shard));
-    else if (dtype == GR_F64) p->e.reset(new Engine<double>(nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, (hipStream_t)stream, shard));
+    if (dtype == GR_F32) p->e.reset(new Engine<float>(nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, (hipStream_t)stream, shard, model));
+    else if (dtype == GR_F64) p->e.reset(new Engine<double>(nc, np, no, cameras, points, observations, cam_idx, pt_idx, device, (hipStream_t)stream, shard, model));
     else { delete p; g_last_error = "bad dtype"; return GR_ERR_INVALID; }
     *out = p;
     return GR_OK;
   } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
   catch (const std::domain_error &ex) { g_last_error = ex.what(); return GR_ERR_DUPLICATE_EDGE; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
+}
+gr_status gr_bal_create_model(gr_bal_problem **out, gr_dtype dtype, int64_t nc, int64_t np, int64_t no, const int32_t *pose_idx, const int32_t *landmark_idx,
+                              const gr_model_ops *ops, int device, void *stream) {
+  if (!ops) { g_last_error = "gr_bal_create_model: ops is NULL"; return GR_ERR_INVALID; }
+  return create_impl(out, dtype, nc, np, no, nullptr, nullptr, nullptr, pose_idx, landmark_idx, device, stream, false, ops);
+}
+gr_status gr_bal_model_orders(gr_bal_problem *p, int32_t *obs_order, int32_t *landmark_order) {
+  return guarded(p, [&] { p->e->orders(obs_order, landmark_order); });
 }
 gr_status gr_bal_create(gr_bal_problem **out, gr_dtype dtype, int64_t nc, int64_t np, int64_t no,
                         const void *cameras, const void *points, const void *observations,

@@ -27,24 +27,7 @@
 
 namespace gr {
 
-constexpr int TPB = 256;
 constexpr int CHUNK = 128; // observations of one camera handled by one wave (2 per lane)
-
-template <typename T> struct Vec2T;
-template <> struct Vec2T<float> { using type = float2; };
-template <> struct Vec2T<double> { using type = double2; };
-
-// Device-side hand-over of the LM accept decision.  On an accept streak the host enqueues the FIRST kernels of iteration
-// i + 1 (k_finalize_bj, first direction, first PCG iteration) while the trial linearisation of iteration i is still running,
-// i.e. before anybody knows whether step i is accepted.  k_finalize_bj takes that decision on the device
-// (optimizer/levenberg_marquardt.hpp:184-197), leaves the new damping here and sets `stop` when the step is not accepted;
-// the kernels that follow it read the damping from here and return at once when `stop` is set.  The host only OBSERVES the
-// decision (pinned memory) and runs the rejection path itself.
-struct LmDev {
-  double mu;
-  int stop; // 0 run | 2 the step was not accepted
-  int pad;
-};
 
 template <typename T> __device__ __forceinline__ void load_pack(const T *__restrict__ pack, int c, T *pk) {
   const T *src = pack + PACK * (size_t)c;

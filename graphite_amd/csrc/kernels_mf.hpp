@@ -94,10 +94,13 @@ struct PcgState {
   __device__ __forceinline__ double *slots(int k, int which) const { return acc + ((size_t)k * NSLOT + which) * NSW; }
 };
 
-__global__ void k_pcg_state_init(PcgState st, int cap) {
+// gate != nullptr (user-traits problems, the trial step's "loop state is spent" reset): enqueued ahead of the PCG exit flag — nothing
+// to do while the loop has not left; the gate word itself (st.left) is then left alone, the kernels behind this one test it too
+__global__ void k_pcg_state_init(PcgState st, int cap, const int *__restrict__ gate = nullptr) {
+  if (gate && !*gate) return;
   for (int i = threadIdx.x; i < cap * NSLOT * NS; i += blockDim.x) st.acc[slot_word(i)] = 0.0;
   for (int i = threadIdx.x; i < cap; i += blockDim.x) { st.done[i] = 0; st.pdp[i] = 0.0; st.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
-  if (threadIdx.x == 0) { st.iters[0] = 0; if (st.left) *st.left = 0; }
+  if (threadIdx.x == 0) { st.iters[0] = 0; if (st.left && !gate) *st.left = 0; }
 }
 
 // BlockJacobiPreconditioner::set_damping_factor (block_jacobi.hpp:120-172) for cameras AND points in one
@@ -610,32 +613,6 @@ __device__ __forceinline__ void xcd_tile_range(int ntiles, int &t0, int &t1, int
   t0 = x0 + (int)((long long)bi * (x1 - x0) / nb);
   t1 = x0 + (int)((long long)(bi + 1) * (x1 - x0) / nb);
   tstep = 1;
-}
-
-// The same partition as an observation range [j0, jlim) walked in steps of jstride, niter workgroup tiles.  Plain form (ntiles >= 0):
-// the ranges are cut at 64-observation WAVE blocks, not at 256-observation workgroup tiles — Ladybug-1723 has 3.45 tiles per
-// workgroup, i.e. 3 or 4, and a CU that drew three 4-tile workgroups carried 48 wave blocks against an average of 41.4 (the kernels
-// are bound per CU by their memory instructions); cut by wave blocks every workgroup has 13 or 14.  Its last tile is then partly
-// empty (whole waves idle: ranges start and end on 64-observation boundaries, so the (wave, camera) segments are unchanged).
-__device__ __forceinline__ void xcd_obs_range(int ntiles, int No, int &j0, int &jstride, int &niter, int &jlim) {
-  const int nb = gridDim.x >> 3, x = blockIdx.x & 7, bi = blockIdx.x >> 3;
-  if (ntiles < 0) {
-    const int nt = -ntiles;
-    const int x0 = (int)((long long)x * nt / 8), x1 = (int)((long long)(x + 1) * nt / 8), t0 = x0 + bi;
-    j0 = t0 * TPB; jstride = nb * TPB;
-    niter = t0 < x1 ? (x1 - t0 + nb - 1) / nb : 0;
-    const long long lim = (long long)x1 * TPB;
-    jlim = lim < (long long)No ? (int)lim : No;
-    return;
-  }
-  const int nblk = (No + 63) >> 6;
-  const int x0 = (int)((long long)x * nblk / 8), x1 = (int)((long long)(x + 1) * nblk / 8);
-  const int b0 = x0 + (int)((long long)bi * (x1 - x0) / nb), b1 = x0 + (int)((long long)(bi + 1) * (x1 - x0) / nb);
-  j0 = b0 << 6;
-  const long long lim = (long long)b1 << 6;
-  jlim = lim < (long long)No ? (int)lim : No;
-  jstride = TPB;
-  niter = jlim > j0 ? (jlim - j0 + TPB - 1) / TPB : 0;
 }
 
 // scalars of iteration k as every wave derives them (all lanes must call)

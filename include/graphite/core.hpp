@@ -600,9 +600,14 @@ public:
 // =================================================================================================
 // FactorDescriptor (factor.hpp:120-830)
 // =================================================================================================
+namespace detail { class EngineModelBase; } // engine_model.hpp
 template <typename T, typename S> class BaseFactorDescriptor {
 public:
   virtual ~BaseFactorDescriptor() = default;
+  // The engine's per-observation kernels instantiated on THIS descriptor's traits (engine_model.hpp), for the active factors:
+  // local pose / landmark ids per active factor (active_indices order) in cam / pt.  nullptr: not a (<= 9, <= 3) -> <= 2 binary
+  // factor of plain-data types, or a precision matrix that is not symmetric positive semi-definite.
+  virtual std::shared_ptr<detail::EngineModelBase> make_engine_model(std::vector<int32_t> & /*cam*/, std::vector<int32_t> & /*pt*/, size_t /*num_poses*/, size_t /*num_landmarks*/) { return nullptr; }
   virtual size_t internal_count() const = 0;
   virtual size_t active_count() const = 0;
   // active list, local ids, vertex use flags; `light`: without what only the generic kernels need (Jacobian storage, the
@@ -1391,7 +1396,7 @@ public:
   void reset_active() { ++this->structure_epoch; for (size_t i = 0; i < active.size(); ++i) active[i] = 0; }
   // factor.hpp:626-640: false = no stored Jacobians, every product recomputes the analytic blocks (Manual
   // differentiation only; an Auto factor keeps storing, ops/linearize.hpp:109)
-  void set_jacobian_storage(bool on) { store_jacobians = on; }
+  void set_jacobian_storage(bool on) { if (store_jacobians != on) ++this->structure_epoch; store_jacobians = on; }
   bool dynamic_jacobians() const { return !store_jacobians && supports_dynamic_jacobians(); }
   size_t add_factor(const std::array<size_t, N> &ids, const ObservationType &obs) { return add_factor(ids, obs, nullptr, ConstraintDataType(), LossType()); }
   static constexpr bool use_autodiff() { return std::is_same<typename Traits::Differentiation, DifferentiationMode::Auto>::value; }
@@ -1607,6 +1612,7 @@ public:
     if constexpr (std::is_trivially_copyable<ObservationType>::value) h = detail::digest(h, device_obs.raw(), device_obs.size() * sizeof(ObservationType));
     h = detail::digest(h, active.raw(), active.size());
     h = detail::digest(h, precision_matrices.raw(), precision_matrices.size() * sizeof(S));
+    if constexpr (std::is_trivially_copyable<ConstraintDataType>::value && !std::is_empty<ConstraintDataType>::value) h = detail::digest(h, data.raw(), data.size() * sizeof(ConstraintDataType));
     if constexpr (std::is_trivially_copyable<LossType>::value && !std::is_empty<LossType>::value && !std::is_polymorphic<LossType>::value)
       h = detail::digest(h, loss.raw(), loss.size() * sizeof(LossType));
     return h;
@@ -1620,6 +1626,7 @@ public:
     else return false;
   }
   bool declares_bal_model() const override { return detail::has_bal_tag<Traits>::value; }
+  std::shared_ptr<detail::EngineModelBase> make_engine_model(std::vector<int32_t> &cam, std::vector<int32_t> &pt, size_t num_poses, size_t num_landmarks) override; // engine_model.hpp
   bool probe_bal(size_t max_samples, std::vector<T> &cam, std::vector<T> &pt, std::vector<T> &obs, std::vector<T> &res, std::vector<T> &Jc, std::vector<T> &Jp, double &update_dev,
                  size_t *num_synthetic = nullptr) override {
     if constexpr (bal_shaped()) {
@@ -1887,3 +1894,5 @@ public:
 };
 
 } // namespace graphite
+
+#include "engine_model.hpp" // the engine's kernels on user traits: needs everything above

@@ -684,6 +684,8 @@ namespace detail {
 inline size_t &engine_handovers() { static size_t n = 0; return n; }
 // ... and how many of them found their engine problem already built (EngineCache hit: parameters uploaded, nothing else)
 inline size_t &engine_cache_hits() { static size_t n = 0; return n; }
+// ... and how many ran the engine's kernels instantiated on the user's traits (engine_model.hpp) rather than the built-in model
+inline size_t &engine_model_handovers() { static size_t n = 0; return n; }
 // host seconds the last hand-over spent outside gr_bal_levenberg_marquardt (checks, export, probe, create / cache look-up,
 // parameter transfer both ways, residual refresh)
 inline double &engine_last_setup_seconds() { static double s = 0; return s; }
@@ -705,7 +707,10 @@ template <typename T> struct EngineCache {
   std::vector<uint32_t> cam_used, pt_used;
   managed_vector<T> cams, pts;      // all vertices of the descriptors, local order (gather / scatter staging)
   std::vector<T> ecams, epts;       // the engine's subset when it is not the identity
-  ~EngineCache() { if (prob) gr_bal_destroy(prob); }
+  // USER-TRAITS engine (engine_model.hpp): the kernels instantiated on the user's traits + their engine-order vertex copies and
+  // factor streams; null = the library's built-in camera model was verified and runs (the parameter arrays above travel)
+  std::shared_ptr<graphite::detail::EngineModelBase> model;
+  ~EngineCache() { if (prob) gr_bal_destroy(prob); } // before `model`: the problem calls into it
 };
 
 template <typename T, typename S>
@@ -722,7 +727,10 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   auto &fds = graph->get_factor_descriptors();
   if (vds.size() != 2 || fds.size() != 1 || fds[0]->num_slots() != 2) return false;
   auto *cd = fds[0]->slot_descriptor(0), *pd = fds[0]->slot_descriptor(1);
-  if (cd == pd || cd->dimension() != 9 || pd->dimension() != 3 || cd->eliminate) return false;
+  if (cd == pd || cd->dimension() > 9 || pd->dimension() > 3 || fds[0]->error_dimension() > 2 || cd->eliminate) return false;
+  const bool bal_dims = cd->dimension() == 9 && pd->dimension() == 3 && fds[0]->error_dimension() == 2;
+  // GRAPHITE_ENGINE=model: run even a graph whose traits ARE the built-in model on the kernels instantiated from them (tests, A/B)
+  const bool force_model = getenv("GRAPHITE_ENGINE") && std::string(getenv("GRAPHITE_ENGINE")) == "model";
   if (!((vds[0] == cd && vds[1] == pd) || (vds[0] == pd && vds[1] == cd))) return false;
   const int kind = options->solver->engine_kind(cd->count());
   if (kind < 0) return false;
@@ -786,6 +794,11 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
     std::vector<int32_t> ci, pi;
     std::vector<T> obs;
     int loss_kind = 0; double loss_delta = 0;
+    const size_t nc = fresh->cam_used.empty() ? cd->count() : fresh->cam_used.size(), np = fresh->pt_used.empty() ? pd->count() : fresh->pt_used.size();
+    auto bad = [&](const char *what) { std::cerr << "graphite: engine hand-over failed in " << what << ": " << gr_last_error_string() << "; using the generic kernels" << std::endl; return false; };
+    // the library's built-in camera model, when the user's traits are verified to BE it (by value, below)
+    auto try_builtin = [&]() -> bool {
+    if (!bal_dims || force_model) return false;
     if (!fds[0]->export_bal(ci, pi, obs, loss_kind, loss_delta)) return false; // the ACTIVE factors
     if (!fresh->cam_used.empty() || !fresh->pt_used.empty())
       for (size_t f = 0; f < ci.size(); ++f) { ci[f] = cam_new[ci[f]]; pi[f] = pt_new[pi[f]]; }
@@ -838,7 +851,6 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
     fresh->cams.resize(9 * cd->count()); fresh->pts.resize(3 * pd->count());
     cd->gather_parameters(fresh->cams.raw()); pd->gather_parameters(fresh->pts.raw());
     graphite::detail::sync();
-    const size_t nc = fresh->cam_used.empty() ? cd->count() : fresh->cam_used.size(), np = fresh->pt_used.empty() ? pd->count() : fresh->pt_used.size();
     const T *c_src = fresh->cams.raw(), *p_src = fresh->pts.raw();
     if (!fresh->cam_used.empty()) {
       fresh->ecams.resize(9 * nc);
@@ -851,9 +863,31 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
       p_src = fresh->epts.data();
     }
     lap("gather_parameters");
-    auto bad = [&](const char *what) { std::cerr << "graphite: engine hand-over failed in " << what << ": " << gr_last_error_string() << "; using the generic kernels" << std::endl; return false; };
     if (gr_bal_create(&fresh->prob, dt, (int64_t)nc, (int64_t)np, (int64_t)ci.size(), c_src, p_src, obs.data(), ci.data(), pi.data(), dev, nullptr) != GR_OK) return bad("gr_bal_create");
     if (gr_bal_set_loss(fresh->prob, loss_kind ? GR_LOSS_HUBER : GR_LOSS_DEFAULT, loss_delta) != GR_OK) return bad("gr_bal_set_loss");
+    return true;
+    };
+    // ... otherwise the engine's kernels instantiated on the user's traits (engine_model.hpp): per-factor precision matrices and
+    // losses, constraint data, any (<= 9, <= 3) -> <= 2 error / jacobian / update
+    auto try_model = [&]() -> bool {
+      if (fresh->prob) { gr_bal_destroy(fresh->prob); fresh->prob = nullptr; }
+      if (kind == GR_SOLVER_PCG_SCHUR_IMPLICIT) return false; // beyond the explicit form's camera count: generic kernels
+      ci.clear(); pi.clear();
+      fresh->model = fds[0]->make_engine_model(ci, pi, nc, np);
+      if (!fresh->model) return false;
+      if (!fresh->cam_used.empty() || !fresh->pt_used.empty())
+        for (size_t f = 0; f < ci.size(); ++f) { ci[f] = cam_new[ci[f]]; pi[f] = pt_new[pi[f]]; }
+      if (gr_bal_create_model(&fresh->prob, dt, (int64_t)nc, (int64_t)np, (int64_t)ci.size(), ci.data(), pi.data(), fresh->model->ops(), dev, nullptr) != GR_OK) return bad("gr_bal_create_model");
+      std::vector<int32_t> obs_order(ci.size()), lm_order(np);
+      if (gr_bal_model_orders(fresh->prob, obs_order.data(), lm_order.data()) != GR_OK) return bad("gr_bal_model_orders");
+      fresh->model->bind(fresh->cam_used, fresh->pt_used, obs_order, lm_order);
+      lap("user-traits engine: export + gr_bal_create_model + factor streams");
+      return true;
+    };
+    if (!try_builtin()) {
+      fresh->model.reset();
+      if (!try_model()) { fresh->model.reset(); return false; }
+    }
     if (any_fixed && gr_bal_set_fixed(fresh->prob, cam_fixed.data(), pt_fixed.data()) != GR_OK) return bad("gr_bal_set_fixed");
     fresh->cd = cd; fresh->pd = pd; fresh->fd = fds[0];
     fresh->epoch_c = cd->structure_epoch; fresh->epoch_p = pd->structure_epoch; fresh->epoch_f = fds[0]->structure_epoch;
@@ -862,7 +896,12 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
     fresh->level = options->optimization_level; fresh->device = dev; fresh->n_factors = ci.size();
     cache = fresh;
     graph->engine_cache = cache;
+    if (cache->model) cache->model->upload_vertices();
     lap("gr_bal_create + settings");
+  } else if (cache->model) {
+    cache->model->upload_vertices(); // unchanged structure: only the vertex VALUES travel
+    ++engine_cache_hits();
+    lap("user-traits engine: vertex upload");
   } else {
     // unchanged structure: only the vertex VALUES travel
     cd->gather_parameters(cache->cams.raw()); pd->gather_parameters(cache->pts.raw());
@@ -882,7 +921,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   }
   gr_bal_problem *prob = cache->prob;
   if (gr_bal_set_scale_system(prob, graph->scales_system() ? 1 : 0) != GR_OK) return fail("gr_bal_set_scale_system");
-  if (gr_bal_set_jacobian_precision(prob, std::is_same<T, S>::value ? dt : GR_F32) != GR_OK) return fail("gr_bal_set_jacobian_precision");
+  if (!cache->model && gr_bal_set_jacobian_precision(prob, std::is_same<T, S>::value ? dt : GR_F32) != GR_OK) return fail("gr_bal_set_jacobian_precision");
   gr_lm_options o{};
   o.solver = kind; o.iterations = (int32_t)options->iterations; o.initial_damping = options->initial_damping;
   o.use_identity = options->use_identity ? 1 : 0; o.early_stop = early_stop ? 1 : 0;
@@ -893,20 +932,23 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   gr_lm_stats st{};
   std::vector<double> chi2(options->iterations + 1), lambda(options->iterations + 1);
   if (getenv("GR_VERBOSE")) std::cerr << "[graphite] bundle-adjustment graph (" << cd->count() << " cameras, " << pd->count() << " points, " << cache->n_factors
-                                      << " active factors) handed to the gr_bal engine, gr_solver " << kind << (hit ? " (cached problem)" : "") << std::endl;
+                                      << " active factors) handed to the gr_bal engine" << (cache->model ? " (kernels instantiated on the user's traits)" : " (built-in camera model)")
+                                      << ", gr_solver " << kind << (hit ? " (cached problem)" : "") << std::endl;
+  if (cache->model) ++engine_model_handovers();
   const auto t_lm0 = clk::now();
   if (gr_bal_levenberg_marquardt(prob, &o, &st, chi2.data(), lambda.data()) != GR_OK) return fail("gr_bal_levenberg_marquardt");
   const double lm_seconds = std::chrono::duration<double>(clk::now() - t_lm0).count();
   ++engine_handovers();
   lap("gr_bal_levenberg_marquardt");
-  {
+  if (cache->model) cache->model->download_vertices();
+  else {
     T *c_dst = cache->cam_used.empty() ? cache->cams.raw() : cache->ecams.data(), *p_dst = cache->pt_used.empty() ? cache->pts.raw() : cache->epts.data();
     if (gr_bal_get_params(prob, c_dst, p_dst) != GR_OK) return fail("gr_bal_get_params");
     // vertices outside the engine problem keep the values gathered above
     for (size_t k = 0; k < cache->cam_used.size(); ++k) std::copy(cache->ecams.begin() + 9 * k, cache->ecams.begin() + 9 * k + 9, cache->cams.raw() + 9 * (size_t)cache->cam_used[k]);
     for (size_t k = 0; k < cache->pt_used.size(); ++k) std::copy(cache->epts.begin() + 3 * k, cache->epts.begin() + 3 * k + 3, cache->pts.raw() + 3 * (size_t)cache->pt_used[k]);
   }
-  cd->scatter_parameters(cache->cams.raw()); pd->scatter_parameters(cache->pts.raw());
+  if (!cache->model) { cd->scatter_parameters(cache->cams.raw()); pd->scatter_parameters(cache->pts.raw()); }
   lap("get_params + scatter_parameters");
   {
     // leave the residuals of the optimised vertices behind, as the generic loop does (graph->chi2() is valid).  Through the HBM
@@ -1018,6 +1060,8 @@ template <bool EARLY, typename T, typename S> bool lm_loop(Graph<T, S> *graph, L
 inline size_t engine_handover_count() { return detail::engine_handovers(); }
 // ... of which: calls that found the graph's engine problem cached (structure unchanged since the previous call)
 inline size_t engine_cache_hit_count() { return detail::engine_cache_hits(); }
+// ... of which: calls whose per-observation kernels were instantiated on the user's traits (user-traits engine)
+inline size_t engine_model_handover_count() { return detail::engine_model_handovers(); }
 // host seconds the last hand-over spent around gr_bal_levenberg_marquardt (checks, export, probe, create or cache look-up, transfers)
 inline double engine_last_setup_seconds() { return detail::engine_last_setup_seconds(); }
 template <typename T, typename S> bool levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {

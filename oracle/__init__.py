@@ -19,6 +19,7 @@ _lib = None
 
 SOLVER_PCG_SCHUR, SOLVER_PCG, SOLVER_PCG_IDENTITY, SOLVER_LDLT, SOLVER_LDLT_SCHUR = range(5)
 LOSS_DEFAULT, LOSS_HUBER = 0, 1
+MODEL_BAL, MODEL_K3, MODEL_PINHOLE = 0, 1, 2
 
 
 def build(force: bool = False) -> str:
@@ -198,6 +199,19 @@ class BalOracle:
 
     def set_scale_system(self, on):
         self._call("gro_bal_set_scale_system", C.c_int(int(on)))
+
+    def set_factor_tables(self, pmat=None, loss_kinds=None, loss_deltas=None, fdata=None):
+        """Per-factor precision matrices (No, 4) row-major, loss kinds / deltas (No,), constraint data (No, 4)
+        (factor.hpp:158-174, :373-412); None = identity / the loss of set_loss / none."""
+        pm = None if pmat is None else np.ascontiguousarray(pmat, dtype=self.dt).reshape(-1)
+        lk = None if loss_kinds is None else np.ascontiguousarray(loss_kinds, dtype=np.int32)
+        ld = None if loss_kinds is None else np.ascontiguousarray(loss_deltas, dtype=self.dt)
+        fd = None if fdata is None else np.ascontiguousarray(fdata, dtype=self.dt).reshape(-1)
+        self._call("gro_bal_set_factor_tables", _p(pm), _p(lk), _p(ld), _p(fd))
+
+    def set_model(self, kind):
+        """0 the BAL camera (analytic Jacobian), 1 BAL + k3 r^6 (data[:, 0]), 2 pinhole (6, 3) -> 2 (oracle/user_models.hpp)"""
+        self._call("gro_bal_set_model", C.c_int(int(kind)))
 
     def set_fixed(self, cam_fixed=None, pt_fixed=None):
         """VertexDescriptor::set_fixed (vertex.hpp:262): boolean masks over cameras / points"""

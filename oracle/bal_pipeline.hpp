@@ -24,6 +24,7 @@
 // Venice-1778 is off by 0.4 %, which no tree reduction is.
 #pragma once
 #include "bal_model.hpp"
+#include "user_models.hpp"
 #include "generic_ops.hpp"
 #include "sparse_ldlt.hpp"
 #include <algorithm>
@@ -160,15 +161,43 @@ template <typename T> struct BalOracle {
   size_t nnzb_S() const { return S_row.size(); }
 
   // ---- linearisation -----------------------------------------------------
-  void compute_error() { // graph.hpp:212-217
-    for (size_t o = 0; o < No; ++o)
-      bal_residual(&cams[9 * cam_idx[o]], &pts[3 * pt_idx[o]], &obs[2 * o], &res[2 * o]);
+  // Per-factor precision matrices (factor.hpp:158-174 precision_matrices, read row-major, ops/linearize.hpp:283), per-factor
+  // losses (factor.hpp:373-412: every factor carries its own loss object) and per-factor constraint data; empty = identity /
+  // the one loss of set_loss / none.  model_kind selects the factor function (user_models.hpp): 0 the BAL camera of
+  // examples/reprojection_error.cuh with its analytic Jacobian, > 0 a test model differentiated by dual numbers.
+  std::vector<T> pmat, fdata;          // [No][4] each
+  std::vector<int> loss_kinds;         // [No]
+  std::vector<T> loss_deltas;          // [No]
+  int model_kind = MODEL_BAL;
+  // a^T (rho' P) b as ops/hessian.hpp's jtpj + the dchi2 factor evaluate it; P = I keeps the closed form used before
+  T wdot(size_t o, T a0, T a1, T b0, T b1) const {
+    if (pmat.empty()) return (a0 * b0 + a1 * b1) * dchi2[o];
+    const T *P = &pmat[4 * o];
+    return ((P[0] * b0 + P[1] * b1) * a0 + (P[2] * b0 + P[3] * b1) * a1) * dchi2[o];
   }
-  T chi2() { // graph.hpp:219-225, factor.hpp:551-557, ops/chi2.hpp:34-44 (P = I)
+  void wvec(size_t o, T r0, T r1, T &x0, T &x1) const { // rho' P r  (ops/linearize.hpp:283-290)
+    if (pmat.empty()) { x0 = dchi2[o] * r0; x1 = dchi2[o] * r1; return; }
+    const T *P = &pmat[4 * o];
+    x0 = dchi2[o] * (P[0] * r0 + P[1] * r1); x1 = dchi2[o] * (P[2] * r0 + P[3] * r1);
+  }
+  void compute_error() { // graph.hpp:212-217
     for (size_t o = 0; o < No; ++o) {
-      const T raw = res[2 * o] * res[2 * o] + res[2 * o + 1] * res[2 * o + 1];
-      chi2_vec[o] = loss_value(loss_kind, loss_delta, raw);
-      dchi2[o] = loss_derivative(loss_kind, loss_delta, raw);
+      if (model_kind == MODEL_BAL) bal_residual(&cams[9 * cam_idx[o]], &pts[3 * pt_idx[o]], &obs[2 * o], &res[2 * o]);
+      else user_model_residual<T>(model_kind, &cams[9 * cam_idx[o]], &pts[3 * pt_idx[o]], &obs[2 * o], fdata.empty() ? nullptr : &fdata[4 * o], &res[2 * o]);
+    }
+  }
+  T chi2() { // graph.hpp:219-225, factor.hpp:551-557, ops/chi2.hpp:34-44
+    for (size_t o = 0; o < No; ++o) {
+      T raw;
+      if (pmat.empty()) raw = res[2 * o] * res[2 * o] + res[2 * o + 1] * res[2 * o + 1];
+      else { // value += (sum_j P_ij r_j) r_i, ops/chi2.hpp:20-30
+        const T *P = &pmat[4 * o];
+        raw = (P[0] * res[2 * o] + P[1] * res[2 * o + 1]) * res[2 * o] + (P[2] * res[2 * o] + P[3] * res[2 * o + 1]) * res[2 * o + 1];
+      }
+      const int lk = loss_kinds.empty() ? loss_kind : loss_kinds[o];
+      const T ld = loss_deltas.empty() ? loss_delta : loss_deltas[o];
+      chi2_vec[o] = loss_value(lk, ld, raw);
+      dchi2[o] = loss_derivative(lk, ld, raw);
     }
     return tree_sum<T>(0, No, [&](size_t o) { return chi2_vec[o]; }); // thrust::reduce, ops/chi2.hpp:61-64
   }
@@ -182,9 +211,10 @@ template <typename T> struct BalOracle {
     if (pf) for (size_t l = 0; l < Np; ++l) pt_fixed[l] = pf[l] ? 1 : 0;
   }
   void linearize() { // graph.hpp:236-290
-    for (size_t o = 0; o < No; ++o)
-      bal_residual_jacobian(&cams[9 * cam_idx[o]], &pts[3 * pt_idx[o]], &obs[2 * o], &res[2 * o],
-                            &Jc[18 * o], &Jp[6 * o]);
+    for (size_t o = 0; o < No; ++o) {
+      if (model_kind == MODEL_BAL) bal_residual_jacobian(&cams[9 * cam_idx[o]], &pts[3 * pt_idx[o]], &obs[2 * o], &res[2 * o], &Jc[18 * o], &Jp[6 * o]);
+      else user_model_residual_jacobian<T>(model_kind, &cams[9 * cam_idx[o]], &pts[3 * pt_idx[o]], &obs[2 * o], fdata.empty() ? nullptr : &fdata[4 * o], &res[2 * o], &Jc[18 * o], &Jp[6 * o]);
+    }
     if (!cam_fixed.empty())
       for (size_t o = 0; o < No; ++o) {
         if (cam_fixed[cam_idx[o]]) std::fill(&Jc[18 * o], &Jc[18 * o] + 18, T(0));
@@ -196,9 +226,9 @@ template <typename T> struct BalOracle {
       for (size_t o = 0; o < No; ++o) { // ops/hessian.hpp:419-474 (P = I)
         T *dc = &scales[9 * cam_idx[o]], *dp = &scales[pose_dim + 3 * pt_idx[o]];
         for (int c = 0; c < 9; ++c)
-          dc[c] += (Jc[18 * o + 2 * c] * Jc[18 * o + 2 * c] + Jc[18 * o + 2 * c + 1] * Jc[18 * o + 2 * c + 1]) * dchi2[o];
+          dc[c] += wdot(o, Jc[18 * o + 2 * c], Jc[18 * o + 2 * c + 1], Jc[18 * o + 2 * c], Jc[18 * o + 2 * c + 1]);
         for (int c = 0; c < 3; ++c)
-          dp[c] += (Jp[6 * o + 2 * c] * Jp[6 * o + 2 * c] + Jp[6 * o + 2 * c + 1] * Jp[6 * o + 2 * c + 1]) * dchi2[o];
+          dp[c] += wdot(o, Jp[6 * o + 2 * c], Jp[6 * o + 2 * c + 1], Jp[6 * o + 2 * c], Jp[6 * o + 2 * c + 1]);
       }
       for (size_t i = 0; i < n; ++i) { // graph.hpp:262-270
         const double denom = std::numeric_limits<double>::epsilon() + std::sqrt(static_cast<double>(scales[i]));
@@ -214,7 +244,8 @@ template <typename T> struct BalOracle {
     }
     std::fill(b.begin(), b.end(), T(0));
     for (size_t o = 0; o < No; ++o) { // ops/linearize.hpp:240-303
-      const T x0 = dchi2[o] * res[2 * o], x1 = dchi2[o] * res[2 * o + 1];
+      T x0, x1;
+      wvec(o, res[2 * o], res[2 * o + 1], x0, x1); // rho' P r
       T *bc = &b[9 * cam_idx[o]], *bp = &b[pose_dim + 3 * pt_idx[o]];
       for (int c = 0; c < 9; ++c) bc[c] -= Jc[18 * o + 2 * c] * x0 + Jc[18 * o + 2 * c + 1] * x1;
       for (int c = 0; c < 3; ++c) bp[c] -= Jp[6 * o + 2 * c] * x0 + Jp[6 * o + 2 * c + 1] * x1;
@@ -228,17 +259,16 @@ template <typename T> struct BalOracle {
     std::fill(Hll.begin(), Hll.end(), T(0));
     for (size_t o = 0; o < No; ++o) {
       const T *jc = &Jc[18 * o], *jp = &Jp[6 * o];
-      const T w = dchi2[o];
       T *hcc = &Hcc[81 * cam_idx[o]], *hcp = &Hcp[27 * o], *hll = &Hll[9 * pt_idx[o]];
       for (int col = 0; col < 9; ++col)
         for (int row = 0; row < 9; ++row)
-          hcc[row + 9 * col] += (jc[2 * row] * jc[2 * col] + jc[2 * row + 1] * jc[2 * col + 1]) * w;
+          hcc[row + 9 * col] += wdot(o, jc[2 * row], jc[2 * row + 1], jc[2 * col], jc[2 * col + 1]);
       for (int col = 0; col < 3; ++col)
         for (int row = 0; row < 9; ++row)
-          hcp[row + 9 * col] += (jc[2 * row] * jp[2 * col] + jc[2 * row + 1] * jp[2 * col + 1]) * w;
+          hcp[row + 9 * col] += wdot(o, jc[2 * row], jc[2 * row + 1], jp[2 * col], jp[2 * col + 1]);
       for (int col = 0; col < 3; ++col)
         for (int row = 0; row < 3; ++row)
-          hll[row + 3 * col] += (jp[2 * row] * jp[2 * col] + jp[2 * row + 1] * jp[2 * col + 1]) * w;
+          hll[row + 3 * col] += wdot(o, jp[2 * row], jp[2 * row + 1], jp[2 * col], jp[2 * col + 1]);
     }
     for (size_t c = 0; c < Nc; ++c) // backup_diagonal, hessian.hpp:102-134
       for (int i = 0; i < 9; ++i) prev_diag[9 * c + i] = Hcc[81 * c + 10 * i];
@@ -460,14 +490,13 @@ template <typename T> struct BalOracle {
     bj_blocks.assign(81 * Nc + 9 * Np, 0);
     for (size_t o = 0; o < No; ++o) {
       const T *jc = &Jc[18 * o], *jp = &Jp[6 * o];
-      const T w = dchi2[o];
       T *hc = &bj_blocks[81 * cam_idx[o]], *hl = &bj_blocks[81 * Nc + 9 * pt_idx[o]];
       for (int col = 0; col < 9; ++col)
         for (int row = 0; row < 9; ++row)
-          hc[row + 9 * col] += (jc[2 * row] * jc[2 * col] + jc[2 * row + 1] * jc[2 * col + 1]) * w;
+          hc[row + 9 * col] += wdot(o, jc[2 * row], jc[2 * row + 1], jc[2 * col], jc[2 * col + 1]);
       for (int col = 0; col < 3; ++col)
         for (int row = 0; row < 3; ++row)
-          hl[row + 3 * col] += (jp[2 * row] * jp[2 * col] + jp[2 * row + 1] * jp[2 * col + 1]) * w;
+          hl[row + 3 * col] += wdot(o, jp[2 * row], jp[2 * row + 1], jp[2 * col], jp[2 * col + 1]);
     }
     bj_scalar.assign(n, 0);
     for (size_t c = 0; c < Nc; ++c) for (int i = 0; i < 9; ++i) bj_scalar[9 * c + i] = bj_blocks[81 * c + 10 * i];
@@ -523,9 +552,9 @@ template <typename T> struct BalOracle {
     for (size_t o = 0; o < No; ++o) {
       T *yc = &v2[9 * cam_idx[o]], *yp = &v2[pose_dim + 3 * pt_idx[o]];
       for (int c = 0; c < 9; ++c)
-        yc[c] += (Jc[18 * o + 2 * c] * v1[2 * o] + Jc[18 * o + 2 * c + 1] * v1[2 * o + 1]) * dchi2[o];
+        yc[c] += wdot(o, Jc[18 * o + 2 * c], Jc[18 * o + 2 * c + 1], v1[2 * o], v1[2 * o + 1]);
       for (int c = 0; c < 3; ++c)
-        yp[c] += (Jp[6 * o + 2 * c] * v1[2 * o] + Jp[6 * o + 2 * c + 1] * v1[2 * o + 1]) * dchi2[o];
+        yp[c] += wdot(o, Jp[6 * o + 2 * c], Jp[6 * o + 2 * c + 1], v1[2 * o], v1[2 * o + 1]);
     }
   }
   // DOCUMENTED VARIANT, not in the reference: the same preconditioned CG with the Chronopoulos-Gear single-reduction
@@ -542,9 +571,9 @@ template <typename T> struct BalOracle {
     for (size_t o = 0; o < No; ++o) {
       T *dc = &diag[9 * cam_idx[o]], *dp = &diag[pose_dim + 3 * pt_idx[o]];
       for (int c = 0; c < 9; ++c)
-        dc[c] += (Jc[18 * o + 2 * c] * Jc[18 * o + 2 * c] + Jc[18 * o + 2 * c + 1] * Jc[18 * o + 2 * c + 1]) * dchi2[o];
+        dc[c] += wdot(o, Jc[18 * o + 2 * c], Jc[18 * o + 2 * c + 1], Jc[18 * o + 2 * c], Jc[18 * o + 2 * c + 1]);
       for (int c = 0; c < 3; ++c)
-        dp[c] += (Jp[6 * o + 2 * c] * Jp[6 * o + 2 * c] + Jp[6 * o + 2 * c + 1] * Jp[6 * o + 2 * c + 1]) * dchi2[o];
+        dp[c] += wdot(o, Jp[6 * o + 2 * c], Jp[6 * o + 2 * c + 1], Jp[6 * o + 2 * c], Jp[6 * o + 2 * c + 1]);
     }
     for (size_t i = 0; i < n; ++i) diag[i] = std::clamp(diag[i], T(1.0e-6), T(1.0e32));
     auto precond = [&](T *zz, const T *yy) {
@@ -592,9 +621,9 @@ template <typename T> struct BalOracle {
     for (size_t o = 0; o < No; ++o) { // pcg.hpp:93-98 diag(J^T rho' J) from the (scaled) stored J
       T *dc = &diag[9 * cam_idx[o]], *dp = &diag[pose_dim + 3 * pt_idx[o]];
       for (int c = 0; c < 9; ++c)
-        dc[c] += (Jc[18 * o + 2 * c] * Jc[18 * o + 2 * c] + Jc[18 * o + 2 * c + 1] * Jc[18 * o + 2 * c + 1]) * dchi2[o];
+        dc[c] += wdot(o, Jc[18 * o + 2 * c], Jc[18 * o + 2 * c + 1], Jc[18 * o + 2 * c], Jc[18 * o + 2 * c + 1]);
       for (int c = 0; c < 3; ++c)
-        dp[c] += (Jp[6 * o + 2 * c] * Jp[6 * o + 2 * c] + Jp[6 * o + 2 * c + 1] * Jp[6 * o + 2 * c + 1]) * dchi2[o];
+        dp[c] += wdot(o, Jp[6 * o + 2 * c], Jp[6 * o + 2 * c + 1], Jp[6 * o + 2 * c], Jp[6 * o + 2 * c + 1]);
     }
     for (size_t i = 0; i < n; ++i) diag[i] = std::clamp(diag[i], T(1.0e-6), T(1.0e32));
     auto precond = [&](T *zz, const T *yy) {

@@ -97,6 +97,15 @@ extern "C" {
     auto *o = static_cast<BalOracle<T> *>(h);                                                       \
     o->loss_kind = kind; o->loss_delta = delta;                                                     \
   }                                                                                                 \
+  /* per-factor precision matrices [No][4] row-major, loss kinds / deltas [No], constraint data [No][4]; NULL = none */ \
+  void gro_bal_set_factor_tables_##SFX(void *h, const T *pmat, const int *loss_kinds, const T *loss_deltas, const T *fdata) { \
+    auto *o = static_cast<BalOracle<T> *>(h);                                                       \
+    o->pmat.clear(); o->loss_kinds.clear(); o->loss_deltas.clear(); o->fdata.clear();               \
+    if (pmat) o->pmat.assign(pmat, pmat + 4 * o->No);                                               \
+    if (loss_kinds) { o->loss_kinds.assign(loss_kinds, loss_kinds + o->No); o->loss_deltas.assign(loss_deltas, loss_deltas + o->No); } \
+    if (fdata) o->fdata.assign(fdata, fdata + 4 * o->No);                                           \
+  }                                                                                                 \
+  void gro_bal_set_model_##SFX(void *h, int kind) { static_cast<BalOracle<T> *>(h)->model_kind = kind; } \
   void gro_bal_set_scale_system_##SFX(void *h, int on) { static_cast<BalOracle<T> *>(h)->scale_system = on != 0; } \
   void gro_bal_set_fixed_##SFX(void *h, const uint8_t *cf, const uint8_t *pf) { static_cast<BalOracle<T> *>(h)->set_fixed(cf, pf); } \
   void gro_bal_set_pcg_single_reduction_##SFX(void *h, int on) { static_cast<BalOracle<T> *>(h)->pcg_single_reduction = on != 0; } \

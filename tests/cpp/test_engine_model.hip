@@ -1,0 +1,241 @@
+// The engine's kernels instantiated on USER traits (include/graphite/engine_model.hpp): graphs that are NOT the library's
+// built-in camera model — or that carry per-factor precision matrices / losses / constraint data — optimised by
+// levenberg_marquardt on the gr_bal engine.  tests/test_engine_model.py compares the printed chi2 traces with the CPU oracle
+// and with the generic kernels (GRAPHITE_GENERIC_ONLY=1) and checks which path ran.
+//   usage: test_engine_model <bal file> <pcg|pcg-identity|pcg-schur|eigen-schur> <iterations> <bal|weighted|k3|pinhole> [stored|dynamic] [fp64|fp32|mixed]
+//   bal      : the reprojection factor of docs/markdown/main.md:230-262 (Manual Jacobian), identity precision, DefaultLoss
+//   weighted : the same factor, every factor with its own 2 x 2 information matrix and its own Huber delta (factor.hpp:373-412)
+//   k3       : a sixth-order radial term whose coefficient is per-factor constraint data (Traits::Data), dual-number Jacobian
+//   pinhole  : 6-dof pose [angle-axis, t] x 3-d point -> pixel, intrinsics in the constraint data
+#include <fstream>
+#include <graphite/optimizer/levenberg_marquardt.hpp>
+#include <graphite/preconditioner/block_jacobi.hpp>
+#include <graphite/preconditioner/identity.hpp>
+#include <graphite/preconditioner/block_jacobi_schur.hpp>
+#include <graphite/solver/eigen_schur.hpp>
+#include <graphite/solver/pcg.hpp>
+#include <graphite/solver/pcg_schur.hpp>
+#include <iostream>
+#include <memory>
+#include <string>
+
+namespace graphite {
+
+template <typename T, int N> struct Vec {
+  T v[N];
+  hd_fn T operator()(int i) const { return v[i]; }
+  hd_fn T &operator()(int i) { return v[i]; }
+};
+template <typename T> using Pixel = Vec<T, 2>;
+
+template <typename T, int N> struct VecTraits {
+  static constexpr size_t dimension = N;
+  using Vertex = Vec<T, N>;
+  template <typename P> d_fn static void parameters(const Vertex &x, P *p) { for (int i = 0; i < N; ++i) p[i] = P(x(i)); }
+  d_fn static void update(Vertex &x, const T *d) { for (int i = 0; i < N; ++i) x(i) += d[i]; }
+};
+template <typename T, typename S, int N> using VecDescriptor = VertexDescriptor<T, S, VecTraits<T, N>>;
+
+// P = R(r) X + t, angle-axis rotation as a Rodrigues matrix; theta == 0 -> identity
+template <typename D, typename T> d_fn void transform(const D *pose, const D *pt, D *P) {
+  const D rx = pose[0], ry = pose[1], rz = pose[2];
+  const D theta2 = rx * rx + ry * ry + rz * rz;
+  if (theta2 > D(T(0))) {
+    const D theta = sqrt(theta2);
+    const D ax = rx / theta, ay = ry / theta, az = rz / theta;
+    const D s = sin(theta), c = cos(theta), k = D(T(1)) - c;
+    const D R[9] = {k * ax * ax + c,      k * ax * ay - s * az, k * ax * az + s * ay,
+                    k * ax * ay + s * az, k * ay * ay + c,      k * ay * az - s * ax,
+                    k * ax * az - s * ay, k * ay * az + s * ax, k * az * az + c};
+    for (int i = 0; i < 3; ++i) P[i] = R[3 * i] * pt[0] + R[3 * i + 1] * pt[1] + R[3 * i + 2] * pt[2] + pose[3 + i];
+  } else {
+    for (int i = 0; i < 3; ++i) P[i] = pt[i] + pose[3 + i];
+  }
+}
+// Snavely camera with an optional sixth-order radial term
+template <typename D, typename T> d_fn void reprojection(const D *cam, const D *pt, const Pixel<T> &obs, T k3, D *err) {
+  D P[3];
+  transform<D, T>(cam, pt, P);
+  const D px = -P[0] / P[2], py = -P[1] / P[2];
+  const D r2 = px * px + py * py;
+  const D d = D(T(1)) + cam[7] * r2 + cam[8] * r2 * r2 + D(k3) * r2 * r2 * r2;
+  err[0] = cam[6] * d * px - D(obs(0));
+  err[1] = cam[6] * d * py - D(obs(1));
+}
+
+// ---- bal / weighted: Manual Jacobian (by dual numbers inside the user function), HuberLoss per factor ----------------------
+template <typename T, typename S, typename LossT> struct ReprojectionTraits {
+  static constexpr size_t dimension = 2;
+  using VertexDescriptors = std::tuple<VecDescriptor<T, S, 9>, VecDescriptor<T, S, 3>>;
+  using Observation = Pixel<T>;
+  using Data = Empty;
+  using Loss = LossT;
+  using Differentiation = DifferentiationMode::Manual;
+  template <typename D> d_fn static void error(const D *camera, const D *point, const Observation &obs, D *error) {
+    reprojection<D, T>(camera, point, obs, T(0), error);
+  }
+  template <typename Sj, size_t I>
+  d_fn static void jacobian(const Vec<T, 9> &cam, const Vec<T, 3> &pt, const Pixel<T> &obs, Sj *jac) {
+    using D = Dual<T, T>;
+    constexpr int d = I == 0 ? 9 : 3;
+    for (int c = 0; c < d; ++c) {
+      D cp[9], pp[3], err[2];
+      for (int k = 0; k < 9; ++k) cp[k] = D(cam(k));
+      for (int k = 0; k < 3; ++k) pp[k] = D(pt(k));
+      (I == 0 ? cp[c] : pp[c]).dual = T(1);
+      reprojection<D, T>(cp, pp, obs, T(0), err);
+      jac[2 * c] = (Sj)err[0].dual;
+      jac[2 * c + 1] = (Sj)err[1].dual;
+    }
+  }
+};
+template <typename T, typename S> using BalFactor = FactorDescriptor<T, S, ReprojectionTraits<T, S, DefaultLoss<T, 2>>>;
+template <typename T, typename S> using WeightedFactor = FactorDescriptor<T, S, ReprojectionTraits<T, S, HuberLoss<T, 2>>>;
+
+// ---- k3: constraint data + automatic differentiation ------------------------------------------------------------------------
+template <typename T> struct Radial6 { T k3; };
+template <typename T, typename S> struct K3Traits {
+  static constexpr size_t dimension = 2;
+  using VertexDescriptors = std::tuple<VecDescriptor<T, S, 9>, VecDescriptor<T, S, 3>>;
+  using Observation = Pixel<T>;
+  using Data = Radial6<T>;
+  using Loss = DefaultLoss<T, 2>;
+  using Differentiation = DifferentiationMode::Auto;
+  template <typename D> d_fn static void error(const D *camera, const D *point, const Observation &obs, const Data &data, D *error) {
+    reprojection<D, T>(camera, point, obs, data.k3, error);
+  }
+};
+template <typename T, typename S> using K3Factor = FactorDescriptor<T, S, K3Traits<T, S>>;
+
+// ---- pinhole: (6, 3) -> 2 ---------------------------------------------------------------------------------------------------
+template <typename T> struct Intrinsics { T fx, fy, cx, cy; };
+template <typename T, typename S> struct PinholeTraits {
+  static constexpr size_t dimension = 2;
+  using VertexDescriptors = std::tuple<VecDescriptor<T, S, 6>, VecDescriptor<T, S, 3>>;
+  using Observation = Pixel<T>;
+  using Data = Intrinsics<T>;
+  using Loss = HuberLoss<T, 2>;
+  using Differentiation = DifferentiationMode::Auto;
+  template <typename D> d_fn static void error(const D *pose, const D *point, const Observation &obs, const Data &k, D *error) {
+    D P[3];
+    transform<D, T>(pose, point, P);
+    error[0] = D(k.fx) * (P[0] / P[2]) + D(k.cx) - D(obs(0));
+    error[1] = D(k.fy) * (P[1] / P[2]) + D(k.cy) - D(obs(1));
+  }
+};
+template <typename T, typename S> using PinholeFactor = FactorDescriptor<T, S, PinholeTraits<T, S>>;
+
+} // namespace graphite
+
+// per-factor weights, the same closed forms tests/test_engine_model.py evaluates
+static void information(size_t f, double (&P)[4]) {
+  const double a = 0.5 + (double)(f % 7) / 4.0, c = 0.75 + (double)(f % 5) / 8.0;
+  const double b = 0.25 * ((double)(f % 3) - 1.0) * std::sqrt(a * c);
+  P[0] = a; P[1] = b; P[2] = b; P[3] = c;
+}
+static double huber_delta(size_t f) { return 1.0 + (double)(f % 4); }
+static double k3_of(size_t f) { return 0.01 * ((double)(f % 5) - 2.0); }
+
+template <typename FP, typename SP, template <typename, typename> class Factor, int DC>
+static int run(int argc, char **argv, const std::string &mode) {
+  using namespace graphite;
+  (void)hipSetDevice(0);
+  std::ifstream file(argv[1]);
+  size_t nc = 0, np = 0, no = 0;
+  file >> nc >> np >> no;
+  std::vector<size_t> ci(no), pi(no);
+  std::vector<Pixel<FP>> ob(no);
+  for (size_t i = 0; i < no; ++i) { double u, v; file >> ci[i] >> pi[i] >> u >> v; ob[i](0) = (FP)u; ob[i](1) = (FP)v; }
+  managed_vector<Vec<FP, DC>> cams(nc);
+  managed_vector<Vec<FP, 3>> pts(np);
+  std::vector<double> focal(nc);
+  for (size_t c = 0; c < nc; ++c)
+    for (int k = 0; k < 9; ++k) { double x; file >> x; if (k < DC) cams[c](k) = (FP)x; if (k == 6) focal[c] = x; }
+  for (size_t p = 0; p < np; ++p) for (int k = 0; k < 3; ++k) { double x; file >> x; pts[p](k) = (FP)x; }
+  if (!file) { std::cerr << "bad BAL file" << std::endl; return 2; }
+
+  Graph<FP, SP> graph;
+  VecDescriptor<FP, SP, DC> cam_desc;
+  VecDescriptor<FP, SP, 3> pt_desc;
+  cam_desc.reserve(nc); pt_desc.reserve(np);
+  graph.add_descriptor(&cam_desc);
+  graph.add_descriptor(&pt_desc);
+  for (size_t c = 0; c < nc; ++c) cam_desc.add_vertex(c, &cams[c]);
+  for (size_t p = 0; p < np; ++p) pt_desc.add_vertex(nc + p, &pts[p]);
+  pt_desc.set_eliminate(true);
+  Factor<FP, SP> r_desc(&cam_desc, &pt_desc);
+  r_desc.reserve(no);
+  graph.add_descriptor(&r_desc);
+  const std::string jmode = argc > 5 ? argv[5] : "stored";
+  if (jmode == "dynamic") r_desc.set_jacobian_storage(false);
+  using Loss = typename Factor<FP, SP>::LossType;
+  using Data = typename Factor<FP, SP>::ConstraintDataType;
+  for (size_t i = 0; i < no; ++i) {
+    SP P[4] = {SP(1), SP(0), SP(0), SP(1)};
+    Loss loss{};
+    Data data{};
+    if (mode == "weighted") { double Pd[4]; information(i, Pd); for (int k = 0; k < 4; ++k) P[k] = (SP)Pd[k]; }
+    if constexpr (std::is_same<Loss, HuberLoss<FP, 2>>::value) loss = Loss((FP)huber_delta(i));
+    if constexpr (std::is_same<Data, Radial6<FP>>::value) data.k3 = (FP)k3_of(i);
+    if constexpr (std::is_same<Data, Intrinsics<FP>>::value) {
+      // the BAL observation is -f d p: as a pinhole pixel with the camera looking down -z it is f p' with p' = (X / Z, Y / Z) = -p
+      data.fx = (FP)focal[ci[i]]; data.fy = (FP)focal[ci[i]]; data.cx = FP(0); data.cy = FP(0);
+    }
+    r_desc.add_factor({ci[i], nc + pi[i]}, ob[i], mode == "weighted" ? P : nullptr, data, loss);
+  }
+  const std::string kind = argv[2];
+  BlockJacobiPreconditioner<FP, SP> bj;
+  IdentityPreconditioner<FP, SP> id;
+  BlockJacobiSchurPreconditioner<FP, SP> bjs;
+  std::unique_ptr<Solver<FP, SP>> solver;
+  if (kind == "pcg") solver.reset(new PCGSolver<FP, SP>(10, 1.0, 5.0, &bj));
+  else if (kind == "pcg-identity") solver.reset(new PCGSolver<FP, SP>(10, 1.0, 5.0, &id));
+  else if (kind == "pcg-schur") solver.reset(new PCGSchurSolver<FP, SP>(10, 1.0, 5.0, &bjs));
+  else if (kind == "eigen-schur") solver.reset(new EigenSchurLDLTSolver<FP, SP>());
+  else return 2;
+  StreamPool streams(2);
+  optimizer::LevenbergMarquardtOptions<FP, SP> options;
+  options.solver = solver.get();
+  options.initial_damping = 1e-4;
+  options.iterations = std::stoul(argv[3]);
+  options.verbose = true;
+  options.streams = &streams;
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool ok = optimizer::levenberg_marquardt<FP, SP>(&graph, &options);
+  const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::cout << std::setprecision(17) << "FINAL_CHI2 " << graph.chi2() << std::endl;
+  std::cout << "CAM0";
+  for (int k = 0; k < DC; ++k) std::cout << " " << cams[0](k);
+  std::cout << std::endl << "PT0 " << pts[0](0) << " " << pts[0](1) << " " << pts[0](2) << std::endl;
+  std::cout << "ENGINE_HANDOVERS " << optimizer::engine_handover_count() << std::endl
+            << "ENGINE_MODEL_HANDOVERS " << optimizer::engine_model_handover_count() << std::endl
+            << "TOTAL_SECONDS " << total << " SETUP_SECONDS " << optimizer::engine_last_setup_seconds() << std::endl
+            << (ok ? "OK" : "STOPPED") << std::endl;
+  if (argc > 7 && std::string(argv[7]) == "twice") { // second call on the unchanged structure: cached problem, loop time only
+    options.verbose = false;
+    const auto t1 = std::chrono::steady_clock::now();
+    (void)optimizer::levenberg_marquardt<FP, SP>(&graph, &options);
+    const double second = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    std::cout << "SECOND_CALL_SECONDS " << second << " SETUP_SECONDS " << optimizer::engine_last_setup_seconds() << " CACHE_HITS " << optimizer::engine_cache_hit_count() << std::endl;
+  }
+  solver.reset();
+  return 0;
+}
+
+template <typename FP, typename SP> static int dispatch(int argc, char **argv, const std::string &mode) {
+  if (mode == "bal") return run<FP, SP, graphite::BalFactor, 9>(argc, argv, mode);
+  if (mode == "weighted") return run<FP, SP, graphite::WeightedFactor, 9>(argc, argv, mode);
+  if (mode == "k3") return run<FP, SP, graphite::K3Factor, 9>(argc, argv, mode);
+  if (mode == "pinhole") return run<FP, SP, graphite::PinholeFactor, 6>(argc, argv, mode);
+  return 2;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 5) { std::cerr << "usage: test_engine_model <file> <solver> <iterations> <bal|weighted|k3|pinhole> [stored|dynamic] [fp64|fp32|mixed] [twice]" << std::endl; return 2; }
+  const std::string mode = argv[4], prec = argc > 6 ? argv[6] : "fp64";
+  // fp32 / mixed precision: the weighted BAL factor only (every instantiation is a set of kernels to compile)
+  if (prec == "fp32" && mode == "weighted") return run<float, float, graphite::WeightedFactor, 9>(argc, argv, mode);
+  if (prec == "mixed" && mode == "weighted") return run<double, float, graphite::WeightedFactor, 9>(argc, argv, mode);
+  if (prec != "fp64") return 2;
+  return dispatch<double, double>(argc, argv, mode);
+}

@@ -1,0 +1,177 @@
+"""The engine's kernels instantiated on USER traits (include/graphite/engine_model.hpp, include/graphite_mi355x_model.h):
+graphs that are not the library's built-in camera model, or that carry per-factor information matrices / losses / constraint
+data, must (i) stay on the gr_bal engine, (ii) reproduce the CPU oracle's LM trace (oracle/bal_pipeline.hpp with the
+per-factor tables and oracle/user_models.hpp) and (iii) reproduce the generic kernels' trace (GRAPHITE_GENERIC_ONLY=1).
+
+Reference behaviour being matched: every hot kernel is instantiated on the user's traits (ops/linearize.hpp:10-138,
+ops/error.hpp:253-323, ops/product.hpp:103,292) with a precision matrix and a loss object per factor (factor.hpp:158-174,
+ops/chi2.hpp:34-44, ops/linearize.hpp:283)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from graphite_amd import synth
+from tests.test_generic_api import build_all, parse_trace
+
+ORACLE_SOLVER = {"pcg": "SOLVER_PCG", "pcg-identity": "SOLVER_PCG_IDENTITY", "pcg-schur": "SOLVER_PCG_SCHUR", "eigen-schur": "SOLVER_LDLT_SCHUR"}
+
+
+def information(no):
+    f = np.arange(no)
+    a = 0.5 + (f % 7) / 4.0
+    c = 0.75 + (f % 5) / 8.0
+    b = 0.25 * ((f % 3) - 1.0) * np.sqrt(a * c)
+    return np.stack([a, b, b, c], axis=1)
+
+
+def huber_delta(no):
+    return 1.0 + (np.arange(no) % 4).astype(np.float64)
+
+
+def k3_of(no):
+    return 0.01 * ((np.arange(no) % 5) - 2.0)
+
+
+def pinhole_problem(prob, seed=11):
+    """observations of the (6, 3) -> 2 pinhole factor of tests/cpp/test_engine_model.hip: u = f X / Z, v = f Y / Z with
+    P = R(r) X + t, + 0.5 px noise; a few gross outliers for the per-factor Huber losses to act on"""
+    rng = np.random.default_rng(seed)
+    cams, pts = prob.cameras.copy(), prob.points.copy()
+    R = synth._rodrigues(cams[:, :3])
+    P = np.einsum("oij,oj->oi", R[prob.cam_idx], pts[prob.pt_idx]) + cams[prob.cam_idx, 3:6]
+    obs = cams[prob.cam_idx, 6:7] * P[:, :2] / P[:, 2:3]
+    obs += rng.normal(0.0, 0.5, obs.shape)
+    obs[::53] += rng.normal(0.0, 25.0, obs[::53].shape)
+    pts += rng.normal(0.0, 0.01, pts.shape)
+    cams[:, :6] += rng.normal(0.0, 0.001, (cams.shape[0], 6))
+    return synth.BalProblem(cams, pts, obs, prob.cam_idx, prob.pt_idx, name="pinhole")
+
+
+def make_file(tmp_path, mode):
+    prob = synth.make_config("mini-50")
+    if mode == "pinhole":
+        prob = pinhole_problem(prob)
+    f = tmp_path / f"problem-{mode}.txt"
+    synth.write_bal(f, prob)
+    return f, synth.read_bal(f)  # the text round trip is what the executable sees
+
+
+def oracle_trace(oracle_mod, prob, mode, solver, iterations, dtype=np.float64):
+    no = len(prob.cam_idx)
+    ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+    if mode == "weighted":
+        ref.set_factor_tables(pmat=information(no), loss_kinds=np.full(no, oracle_mod.LOSS_HUBER), loss_deltas=huber_delta(no))
+    elif mode == "k3":
+        data = np.zeros((no, 4)); data[:, 0] = k3_of(no)
+        ref.set_model(oracle_mod.MODEL_K3); ref.set_factor_tables(fdata=data)
+    elif mode == "pinhole":
+        data = np.zeros((no, 4)); data[:, 0] = data[:, 1] = prob.cameras[prob.cam_idx, 6]
+        ref.set_model(oracle_mod.MODEL_PINHOLE)
+        ref.set_factor_tables(loss_kinds=np.full(no, oracle_mod.LOSS_HUBER), loss_deltas=huber_delta(no), fdata=data)
+    return ref.levenberg_marquardt(solver=getattr(oracle_mod, ORACLE_SOLVER[solver]), iterations=iterations)
+
+
+def run_exe(f, solver, iterations, mode, jac="stored", prec="fp64", env=None, extra=()):
+    exe = build_all()[7]
+    e = dict(os.environ)
+    e.pop("GRAPHITE_GENERIC_ONLY", None); e.pop("GRAPHITE_ENGINE", None)
+    e.update(env or {})
+    r = subprocess.run([exe, str(f), solver, str(iterations), mode, jac, prec, *extra], capture_output=True, text=True, timeout=300, env=e)
+    print(r.stdout[-2500:], r.stderr[-800:])
+    assert r.returncode == 0
+    return r.stdout
+
+
+def fields(out):
+    d = {}
+    for ln in out.splitlines():
+        p = ln.split()
+        if p and p[0].isupper() and len(p) >= 2:
+            d[p[0]] = p[1:]
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["pcg", "pcg-identity", "pcg-schur", "eigen-schur"])
+@pytest.mark.parametrize("mode", ["bal", "weighted", "k3", "pinhole"])
+def test_user_traits_run_on_the_engine_and_match_the_oracle(oracle_mod, tmp_path, mode, solver):
+    f, prob = make_file(tmp_path, mode)
+    its = 8
+    # "bal": traits that ARE the built-in model; GRAPHITE_ENGINE=model keeps them on the kernels instantiated from the traits
+    out = run_exe(f, solver, its, mode, env={"GRAPHITE_ENGINE": "model"} if mode == "bal" else None)
+    d = fields(out)
+    assert d["ENGINE_HANDOVERS"] == ["1"] and d["ENGINE_MODEL_HANDOVERS"] == ["1"]  # one optimiser call, on the engine, user-traits kernels
+    tr = parse_trace(out)
+    ct, lt, _ = oracle_trace(oracle_mod, prob, mode, solver, its)
+    assert len(tr) == len(ct) - 1
+    bar = 1e-8
+    assert np.allclose(tr[:, 0], ct[:-1], rtol=bar) and np.allclose(tr[:, 1], ct[1:], rtol=bar)
+    assert np.allclose(tr[:, 2], lt[1:], rtol=1e-5)
+    assert abs(float(d["FINAL_CHI2"][0]) - ct[-1]) / ct[-1] < bar
+    # ... and the generic kernels (core.hpp) on the same binary and file
+    gen = run_exe(f, solver, its, mode, env={"GRAPHITE_GENERIC_ONLY": "1"})
+    assert fields(gen)["ENGINE_HANDOVERS"] == ["0"]
+    tg = parse_trace(gen)
+    assert np.allclose(tr[:, 1], tg[:, 1], rtol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bal", "weighted"])
+def test_recomputed_jacobians_give_the_stored_iterates(oracle_mod, tmp_path, mode):
+    """FactorDescriptor::set_jacobian_storage(false) (factor.hpp:626-640): the operator calls the user's jacobian<> per
+    observation (k_em_operator) instead of reading the stored weighted blocks (k_pcg_operator_stored)"""
+    f, prob = make_file(tmp_path, mode)
+    env = {"GRAPHITE_ENGINE": "model"} if mode == "bal" else None
+    a = parse_trace(run_exe(f, "pcg", 6, mode, jac="stored", env=env))
+    out = run_exe(f, "pcg", 6, mode, jac="dynamic", env=env)
+    assert fields(out)["ENGINE_MODEL_HANDOVERS"] == ["1"]
+    b = parse_trace(out)
+    assert np.allclose(a[:, 1], b[:, 1], rtol=1e-11)
+    ct, _, _ = oracle_trace(oracle_mod, prob, mode, "pcg", 6)
+    assert np.allclose(b[:, 1], ct[1:], rtol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,bar", [("fp32", 2e-4), ("mixed", 1e-5)])
+def test_user_traits_engine_in_fp32_and_mixed_precision(oracle_mod, tmp_path, prec, bar):
+    """Graph<float, float> and Graph<double, float> (examples/bal.cu:338-345): fp32 throughout / fp64 with the weighted
+    Jacobian stored in fp32; held to the fp64 oracle at the stated bars"""
+    f, prob = make_file(tmp_path, "weighted")
+    out = run_exe(f, "pcg", 6, "weighted", prec=prec)
+    assert fields(out)["ENGINE_MODEL_HANDOVERS"] == ["1"]
+    tr = parse_trace(out)
+    ct, _, _ = oracle_trace(oracle_mod, prob, "weighted", "pcg", 6)
+    assert np.allclose(tr[:, 1], ct[1:], rtol=bar)
+
+
+@pytest.mark.gpu
+def test_second_call_finds_the_user_traits_problem_cached(tmp_path):
+    f, _ = make_file(tmp_path, "weighted")
+    out = run_exe(f, "pcg", 4, "weighted", extra=("twice",))
+    d = fields(out)
+    assert d["ENGINE_MODEL_HANDOVERS"] == ["1"]  # printed before the second call
+    assert "CACHE_HITS 1" in out
+
+
+def test_oracle_dual_number_model_equals_the_analytic_bal_model(oracle_mod):
+    """k3 = 0 in oracle/user_models.hpp's dual-number model is the BAL camera: its LM trace must equal the analytic
+    restatement's (oracle/bal_model.hpp) — an independent pin of that Jacobian — and identity information matrices / one
+    Huber delta passed as per-factor tables must equal the global settings"""
+    prob = synth.make_config("mini-50")
+    no = len(prob.cam_idx)
+    a = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    a.set_loss(oracle_mod.LOSS_HUBER, 2.0)
+    ca, _, _ = a.levenberg_marquardt(solver=oracle_mod.SOLVER_PCG, iterations=5)
+    b = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    b.set_model(oracle_mod.MODEL_K3)
+    eye = np.tile(np.array([1.0, 0.0, 0.0, 1.0]), (no, 1))
+    b.set_factor_tables(pmat=eye, loss_kinds=np.full(no, oracle_mod.LOSS_HUBER), loss_deltas=np.full(no, 2.0), fdata=np.zeros((no, 4)))
+    cb, _, _ = b.levenberg_marquardt(solver=oracle_mod.SOLVER_PCG, iterations=5)
+    assert np.allclose(ca, cb, rtol=1e-12)
+    # a non-trivial information matrix changes the problem (the tables are live)
+    c = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    c.set_factor_tables(pmat=information(no))
+    cc, _, _ = c.levenberg_marquardt(solver=oracle_mod.SOLVER_PCG, iterations=2)
+    assert abs(cc[0] - ca[0]) / ca[0] > 1e-3

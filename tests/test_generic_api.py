@@ -29,7 +29,10 @@ def hipcc(src, out, *flags):
         g.build()
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "graphite", "core.hpp")),
                                                               os.path.getmtime(os.path.join(ROOT, "include", "graphite", "solve.hpp")),
-                                                              os.path.getmtime(os.path.join(ROOT, "include", "graphite", "sparse.hpp"))):
+                                                              os.path.getmtime(os.path.join(ROOT, "include", "graphite", "sparse.hpp")),
+                                                              os.path.getmtime(os.path.join(ROOT, "include", "graphite", "engine_model.hpp")),
+                                                              os.path.getmtime(os.path.join(ROOT, "include", "graphite_mi355x_device.hpp")),
+                                                              os.path.getmtime(os.path.join(ROOT, "include", "graphite_mi355x_model.h"))):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O2", *flags, f"-I{ROOT}/include", src,
                                f"-L{lib}", "-lgraphite_mi355x", f"-Wl,-rpath,{lib}", "-o", out])
     return out
@@ -39,7 +42,7 @@ def build_all():
     # the clients are independent translation units (tens of seconds each: the whole header-only layer): built side by side
     from concurrent.futures import ThreadPoolExecutor
     names = ["test_generic_radius", "test_generic_bal", "test_generic_known_answers", "test_generic_schur_mixed", "test_sparse_schur",
-             "test_generic_schur_dims"]
+             "test_generic_schur_dims", "test_engine_model"]
     lib = os.path.join(ROOT, "graphite_amd", "libgraphite_mi355x.so")
     if not os.path.exists(lib):
         import __graft_entry__ as g
@@ -47,7 +50,7 @@ def build_all():
     with ThreadPoolExecutor(max_workers=4) as pool:
         exe = list(pool.map(lambda n: hipcc(os.path.join(ROOT, "tests", "cpp", n + ".hip"), os.path.join(BUILD, n)), names))
     radius = exe[0]
-    return (radius, radius, exe[1], exe[2], exe[3], exe[4], exe[5])
+    return (radius, radius, exe[1], exe[2], exe[3], exe[4], exe[5], exe[6])
 
 
 def test_generic_layer_compiles_for_gfx950():
