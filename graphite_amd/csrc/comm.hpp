@@ -139,6 +139,9 @@ struct IpcFused {
   // only the slots of a camera's contributors — the same bits as the full sum (the skipped terms were +0.0), 1 / size of the bytes
   const unsigned *contrib = nullptr;
   __device__ __forceinline__ unsigned contributors(unsigned c) const { return contrib ? contrib[c] : ~0u; }
+  // bit r of a contributor mask; masks are 32 bits wide (gr_bal_comm_set_contributors: world_size <= 32): ranks beyond them only
+  // exist without masks (who == ~0u), where every rank contributes — never a shift by >= 32
+  static __device__ __forceinline__ bool rank_in(unsigned who, int r) { return r >= 32 || ((who >> r) & 1u); }
   __device__ __forceinline__ int push_box(int r) const { return virt ? 0 : r; }
   __device__ __forceinline__ int push_slot(int r) const { return virt ? r : rank; }
   template <typename U> __device__ __forceinline__ U push_value(int r, U v) const { return (virt && r) ? U(0) : v; }

@@ -17,6 +17,7 @@
 #include "chol.hpp"
 #include "sparse_chol.hpp"
 #include "kernels_model.hpp"
+#include "kernels_sf.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -54,6 +55,7 @@ static void tuning_default(gr_bal_tuning &t) {
   t.chol_fuse = env_int("GR_CHOL_FUSE", 1);
   t.chol_pin = env_int("GR_CHOL_PIN", 1);
   t.spchol_fuse = env_int("GR_SPCHOL_FUSE", 1);
+  t.schur_fused = env_int("GR_SCHUR_FUSED", -1);
   t.spchol_slice = std::max(1, env_int("GR_SPCHOL_SLICE", 1)); // tiles per substitution item (Ladybug-1723 direct Schur: 1 -> 322.5, 2 -> 319.5, 3 -> 314.5, 4 -> 310 LM it/s)
 }
 
@@ -284,6 +286,9 @@ template <typename T> struct Engine final : EngineBase {
   // Schur
   DevBuf<int> prod_a, prod_b, S_rowi, S_coli, S_diag, row_ptr, row_blk, row_col;
   DevBuf<int> item_blk, item_beg, item_end, item_single, multi_blk;
+  DevBuf<int> item_multi, multi_first, multi_n; // k_schur_reduce (kernels_sf.hpp)
+  DevBuf<unsigned> multi_cnt;
+  DevBuf<T> slab;
   int nitems = 0, nmulti = 0;
   DevBuf<T> S, b_schur, Hll_inv, Mp, vl, MinvS;
   // PCG work vectors
@@ -429,7 +434,10 @@ template <typename T> struct Engine final : EngineBase {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, TPB, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = dflt; }
       const int mult = tune.grid_mult > 0 ? tune.grid_mult : std::min(nb, cap);
-      return std::max(8, std::min(nb_pm, num_cu * mult) & ~7);
+      // fewer tiles than resident slots: one tile per workgroup, rounded UP to the XCD count (rounded down, 8 workgroups of a
+      // 125-tile problem walked two tiles each: a second dependent load chain in a kernel that is nothing but such a chain)
+      if (nb_pm <= num_cu * mult) return std::max(8, (nb_pm + 7) & ~7);
+      return std::max(8, (num_cu * mult) & ~7);
     };
     grid_lin = resident(reinterpret_cast<const void *>(&k_linearize<T, false>), LIN_WAVES, 8);
     if (model) { // the user-side lineariser's own residency (gr_model_ops.lin_wg_per_cu, from its occupancy query)
@@ -464,6 +472,7 @@ template <typename T> struct Engine final : EngineBase {
       grid_vec = std::max(1, std::min(cdiv(n, (size_t)TPB * std::max(1, tune.vec_per_thread)), num_cu * std::min(nb, 8)));
     }
     if (tiling_tuned) { if (tiled) untile(); tiling_tuned = false; } // timed choices are re-made by the next solver_update_structure
+    fused_agreed = false; // ... before the ranks agree on the fused message again (agree_on_fusion, collective): the timing runs must not fuse
     records_tuned = false;
     if (chol_ready) { chol_ready = false; use_spchol = false; }
     if (schur_ready && nitems) schur_ready = false;
@@ -672,6 +681,7 @@ template <typename T> struct Engine final : EngineBase {
   }
   // decided once per problem, by timing: GR_PTILES = number of point tiles (0 = plain order) forces it
   bool tiling_tuned = false;
+  bool tiling_for_pcg = false; // the solver being set up is the matrix-free PCG (solver_update_structure)
   void tune_tiling() {
     if (tiling_tuned) return;
     tiling_tuned = true;
@@ -683,7 +693,9 @@ template <typename T> struct Engine final : EngineBase {
   void tune_tiling_order() {
     // landmark shards that can fuse the inner iteration's message keep the plain order: the fused form needs it (one rank that tiled
     // would un-fuse every rank), and a shard cut by camera locality (dist.py) has the camera runs of the unsharded problem
-    if (comm && ipc_comm() && tune.shard_fused != 0 && tune.point_tiles < 0) return;
+    // (only for the solver that can fuse: the matrix-free PCG in its single-reduction form with a message that fits the slot;
+    // the implicit-Schur PCG and the two-reduction form keep the timed choice)
+    if (comm && ipc_comm() && tune.point_tiles < 0 && tiling_for_pcg && pcg_cg() && shard_fused_local()) return;
     const size_t per_point = (size_t)(6 * sizeof(T) + 3 * sizeof(T) * (double)No / (double)Np); // X + direction + this point's g3 slots
     int K = 0;
     if (tune.point_tiles >= 0) K = tune.point_tiles;
@@ -816,6 +828,18 @@ template <typename T> struct Engine final : EngineBase {
       } while (b0 < end);
     }
     nitems = (int)h_item_blk.size(); nmulti = (int)h_multi.size();
+    { // k_schur_reduce: the items of a multi-item block are consecutive; its last arriver adds their slabs in item order
+      std::vector<int> h_item_multi(nitems, -1), h_multi_first(std::max(nmulti, 1), 0), h_multi_n(std::max(nmulti, 1), 0);
+      int m = -1;
+      for (int it = 0; it < nitems; ++it) {
+        if (h_item_single[it]) continue;
+        if (m < 0 || h_multi[m] != h_item_blk[it]) { ++m; h_multi_first[m] = it; }
+        h_item_multi[it] = m; h_multi_n[m]++;
+      }
+      item_multi.upload(h_item_multi, stream); multi_first.upload(h_multi_first, stream); multi_n.upload(h_multi_n, stream);
+      multi_cnt.alloc(std::max(nmulti, 1)); multi_cnt.zero(stream);
+      slab.alloc(81 * (size_t)std::max(nitems, 1));
+    }
     // row lists for y = S x: upper blocks of row i, then lower blocks as transposes (~blk)
     std::vector<int> h_row_ptr(Nc + 1, 0);
     for (int64_t q = 0; q < nnzb; ++q) {
@@ -1126,10 +1150,9 @@ template <typename T> struct Engine final : EngineBase {
   }
   void revert() override { // graph.hpp:311-318
     if (model) { hook_begin(); hook_end(model->revert(model->ctx, stream), "revert"); return; }
-    GR_HIP(hipMemcpyAsync(cams.p, cams_bak.p, cams.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
-    GR_HIP(hipMemcpyAsync(pts.p, pts_bak.p, pts.n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    // one launch: vertices <- backups and the camera packs (the matrix-free operator recomputes J from the pack: kept in step)
+    k_revert_pack<T><<<cdiv(Nc, 28) + cdiv(3 * (size_t)Np, TPB), TPB, 0, stream>>>((unsigned)pose_dim, (unsigned)(3 * Np), cdiv(Nc, 28), cams.p, pts.p, cams_bak.p, pts_bak.p, pack.p);
     xp_valid = false;
-    campack(); // the matrix-free operator recomputes J from the pack: keep it in step with the vertices
   }
   void apply_update_dev(const T *dx, bool with_backup = false) { // graph.hpp:292-300, ops/update.hpp:11-31
     if (model) { model_step(dx, with_backup, 0.0, nullptr, nullptr, nullptr); return; }
@@ -1167,7 +1190,7 @@ template <typename T> struct Engine final : EngineBase {
     else if (solver == GR_SOLVER_PCG_SCHUR_IMPLICIT) {
       no_model("GR_SOLVER_PCG_SCHUR_IMPLICIT (its kernels recompute the built-in model's Jacobian; use GR_SOLVER_PCG_SCHUR)");
       want_hcp = false; ensure_implicit_schur();
-      if (!tiling_tuned) tune_tiling();
+      tiling_for_pcg = false; if (!tiling_tuned) tune_tiling();
       if (want_g3_gather() && !g3_obs_order) build_g3_gather(); // pass 1's output in observation order, gathered by k_is_points
     }
     else {
@@ -1176,7 +1199,7 @@ template <typename T> struct Engine final : EngineBase {
       cg_cfg = tune.pcg_single_reduction < 0 ? -1 : (tune.pcg_single_reduction != 0 ? 1 : 0);
       v_r.alloc(n); v_p.alloc(n); v_z.alloc(n); v_xb.alloc(n); v_ps.alloc(n); v_diag.alloc(n);
       MinvC.alloc(81 * (size_t)Nc); MinvP.alloc(9 * (size_t)Np);
-      if (!tiling_tuned) tune_tiling();
+      tiling_for_pcg = true; if (!tiling_tuned) tune_tiling();
       if (want_g3_gather() && !g3_obs_order) build_g3_gather(); // rebuilt whenever the observation order has changed
       if (!records_tuned) tune_point_records();
       if (comm && !diag_running) agree_on_fusion(); // collective: every rank of a sharded problem calls solver_update_structure
@@ -1220,6 +1243,8 @@ template <typename T> struct Engine final : EngineBase {
     const T *hcc_w = cam_weight() ? Hcc.p : nullptr; // the (global) camera blocks enter the all-reduced S once
     if (for_solve) k_point_prepare<T><<<cdiv(Np, TPB) + 1, TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, scalars(), sc_cap, pt_fixed_p());
     else k_point_prepare<T><<<cdiv(Np, TPB), TPB, 0, stream>>>((int)Np, (int)Nc, Hll.p, bl.p, scales.p, damping, ui, Hll_inv.p, Mp.p, vl.p, PcgScalars{}, 0, pt_fixed_p());
+    if (tune.schur_fused != 0) launch_schur_reduce(hcc_w, damping, ui, nullptr); // S (multi-item blocks by their last arriver) + the b_S chunk partials
+    else {
     if (nmulti) k_schur_multi<T, 0><<<cdiv(9 * (size_t)nmulti, TPB), TPB, 0, stream>>>(nmulti, multi_blk.p, S_rowi.p, S_coli.p, hcc_w, scales.p, damping, ui, S.p);
     {
       Scope sc(this, "schur_products", nprod * (54.0 * w() + 8) + 9.0 * Np * w() + 81.0 * nnzb * w(), nprod * 342.0);
@@ -1229,6 +1254,7 @@ template <typename T> struct Engine final : EngineBase {
     {
       Scope sc(this, "b_schur", No * (27.0 * w() + 8) + 3.0 * Np * w(), No * 54.0);
       k_bschur_partial<T><<<cdiv(nch, 4), TPB, 0, stream>>>(nch, chunk_beg.p, pt_cm.p, pos_cm.p, Hcp.p, vl.p, part9.p);
+    }
     }
     if (!for_solve || comm) k_bschur_finalize<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p, cam_weight());
     if (comm) {
@@ -1240,6 +1266,12 @@ template <typename T> struct Engine final : EngineBase {
       allreduce_T(b_schur.p, (size_t)pose_dim);
       group_end();
     }
+  }
+  void launch_schur_reduce(const T *hcc_w, double mu, int ui, const LmDev *lm) {
+    Scope sc(this, "schur_products", nprod * (54.0 * w() + 8) + 9.0 * Np * w() + 81.0 * nnzb * w() + No * (27.0 * w() + 8) + 3.0 * Np * w(), nprod * 342.0 + No * 54.0, true);
+    const int nwg_items = cdiv(nitems, 4);
+    launch(k_schur_reduce<T>, nwg_items + cdiv(nch, 4), nitems, nwg_items, item_blk.p, item_beg.p, item_end.p, item_multi.p, multi_first.p, multi_n.p, multi_cnt.p, slab.p,
+           prod_a.p, prod_b.p, S_rowi.p, S_coli.p, pt_pm.p, Hcp.p, Mp.p, hcc_w, scales.p, mu, ui, S.p, nch, chunk_beg.p, pt_cm.p, pos_cm.p, vl.p, part9.p, lm);
   }
   // replicated reduced solves: rank 0's camera step is the one every rank applies (the per-rank copies agree
   // only up to the order of the atomic dot-product partials, which must not leak into the replicated cameras)
@@ -1565,7 +1597,9 @@ template <typename T> struct Engine final : EngineBase {
     f.contrib = d_contrib.n == (size_t)Nc ? d_contrib.p : nullptr;
     return f;
   }
-  bool shard_fused() const { return fused_agreed && !tiled && pcg_mode() == 2; }
+  // never inside a rank-local timing run (diag_time): a fused launch pushes a mailbox message and waits for the peers', and the ranks
+  // time different numbers of launches (the g3 layouts are only timed by ranks above a size threshold)
+  bool shard_fused() const { return fused_agreed && !diag_running && tune.shard_fused != 0 && !tiled && pcg_mode() == 2; }
   // ... and the linearisation's camera-space sums [Hcc 81 Nc | bc 9 Nc | chi2, rho denominator] pushed by k_linearize_finalize
   size_t shard_lin_scal_off() const { return (90 * (size_t)Nc * sizeof(T) + 15) / 16 * 16; }
   bool shard_fused_lin() const {
@@ -2118,6 +2152,87 @@ template <typename T> struct Engine final : EngineBase {
     if (nnz) *nnz = count;
   }
 
+  // ---- device-decided LM iteration of PCGSchurSolver on small reduced systems (kernels_sf.hpp) ------------------------------------
+  DevBuf<unsigned> coop_bar;
+  DevBuf<double> coop_part;
+  DevBuf<int> coop_iters;
+  volatile int *h_coop_fail = nullptr; // pinned, sticky
+  bool sf_active = false;              // armed by lm()
+  bool schur_fused_ok(int max_iter) const { return !comm && !model && max_iter >= 1 && tune.schur_fused != 0 && tune.lm_fused != 0; }
+  // the whole PCG on S in one cooperative launch: one wave per camera row, all of them resident at once
+  bool schur_coop() const { return Nc <= 2 * (int64_t)num_cu; }
+  void ensure_coop(int max_iter) {
+    coop_bar.alloc(1); coop_iters.alloc(1);
+    coop_part.alloc((3 * (size_t)max_iter + 4) * (size_t)Nc);
+    if (!h_coop_fail) {
+      void *q = nullptr;
+      GR_HIP(hipHostMalloc(&q, 64, hipHostMallocCoherent | hipHostMallocMapped));
+      std::memset(q, 0, 64);
+      h_coop_fail = static_cast<volatile int *>(q);
+    }
+    alloc_pinned(max_iter + 2);
+  }
+  // finalisation (+ accept decision of the pending trial step), S and b_S partials, the whole PCG on S, back-substitution + trial step
+  void enqueue_schur_head(LmDecide dec, double mu, bool use_identity, int max_iter, double tol, double rej, int time_slot) {
+    ts_slot = time_slot;
+    flag_bank ^= 1;
+    *h_iters() = 0;
+    damping = mu; damping_identity = use_identity;
+    const LmDev *lm = (dec.seq && !dec.report_only) ? lmdev.p : nullptr;
+    const int ui = use_identity ? 1 : 0;
+    CoopState cs{};
+    cs.barrier = coop_bar.p; cs.part = coop_part.p; cs.iters = coop_iters.p; cs.hiters = h_iters(); cs.fail = h_coop_fail; cs.ts = h_ts ? h_ts + 2 * ts_slot : nullptr;
+    const int nbc = cdiv(Nc, 28), nbp = std::max(1, std::min(cdiv(Np, TPB / FIN_PL), num_cu * 4));
+    const bool coop = schur_coop();
+    if (!coop) { ensure_scalars(max_iter); for (int k = 0; k < max_iter + 1; ++k) flags()[k] = 0; }
+    {
+      Scope sc(this, "finalize_schur", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 36.0 * Np) * w(), 9.0 * No + 54.0 * nseg + 120.0 * Np, true);
+      launch(k_finalize_schur<T>, nbc + nbp + (coop ? 0 : 1), (int)Nc, (int)Np, nbc, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bu.p, Hll.p, scales.p, mu, ui,
+             Hll_inv.p, Mp.p, vl.p, dec, cam_fixed_p(), pt_fixed_p(), cs, coop ? PcgScalars{} : scalars(), coop ? 0 : sc_cap);
+    }
+    launch_schur_reduce(Hcc.p, mu, ui, lm);
+    if (!coop) {
+      // large reduced system: the per-iteration PCG kernels, each gated on the decision; the host follows the exit flags as before.
+      // solve_seconds: HIP events only with options->profile (an event between two launches is a bubble)
+      PcgScalars sc = scalars();
+      k_schur_pcg_prepare<T, 0><<<cdiv(Nc, 64), 64, 0, stream>>>((int)Nc, S.p, S_diag.p, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p, MinvS.p, v_r.p, v_z.p, v_p.p, v_dx.p, nullptr, sc, lm);
+      ++launch_count;
+      const int noop = run_pcg_iterations(max_iter, [&](int k) {
+        { Scope s1(this, "schur_matvec", (2.0 * nnzb - Nc) * 81.0 * w(), (2.0 * nnzb - Nc) * 162.0);
+          k_schur_matvec<T><<<cdiv(Nc, 4), TPB, 0, stream>>>((int)Nc, row_ptr.p, row_blk.p, row_col.p, S.p, v_p.p, v_Ap.p, sc, k, lm); }
+        k_pcgs_update<T><<<cdiv(pose_dim, 252), TPB, 0, stream>>>((int)Nc, v_dx.p, v_xb.p, v_r.p, v_z.p, v_p.p, v_Ap.p, MinvS.p, sc, k, lm);
+        k_pcgs_direction<T><<<cdiv(pose_dim, TPB), TPB, 0, stream>>>((int)Nc, v_dx.p, v_xb.p, v_p.p, v_z.p, nullptr, nullptr, sc, k, tol, rej, lm);
+        launch_count += 3;
+      });
+      note_noop({"schur_matvec"}, noop);
+    } else
+    {
+      Scope sc(this, "schur_pcg_coop", (2.0 * nnzb - Nc) * 81.0 * w(), (2.0 * nnzb - Nc) * 162.0, true);
+      ++launch_count;
+      hipEvent_t ea = ext_a, eb = ext_b;
+      ext_a = ext_b = nullptr;
+      if (ea) hipExtLaunchKernelGGL(k_schur_pcg_coop<T>, dim3((unsigned)Nc), dim3(64), 0, stream, ea, eb, 0, (int)Nc, row_ptr.p, row_blk.p, row_col.p, S.p, S_diag.p, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p,
+                                    v_p.p, v_dx.p, max_iter, tol, rej, cs, lm);
+      else hipLaunchKernelGGL(k_schur_pcg_coop<T>, dim3((unsigned)Nc), dim3(64), 0, stream, (int)Nc, row_ptr.p, row_blk.p, row_col.p, S.p, S_diag.p, cam_chunk_ptr.p, part9.p, bc.p, scales.p, b_schur.p,
+                              v_p.p, v_dx.p, max_iter, tol, rej, cs, lm);
+    }
+    {
+      const int nct = cdiv(pose_dim, 252);
+      rho_blocks = nct + nbp;
+      rho_partial.alloc(rho_blocks);
+      Scope sc(this, "backsub_apply", No * (27.0 * w() + 4) + (9.0 * Np + 3.0 * n + 24.0 * Nc) * w(), No * 54.0, true);
+      launch(k_backsub_apply<T>, rho_blocks, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, cams.p, pts.p, cams_bak.p, pts_bak.p, pack.p, mu, rho_partial.p, lm);
+    }
+    xp_valid = false;
+  }
+  // the trial linearisation of the Schur solvers: k_linearize with the camera-point blocks, finalised by the next head
+  void linearize_hcp_deferred() {
+    const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + 27.0 * No * w();
+    Scope sc(this, "linearize_hcp", bytes, No * (250.0 + 48 + 117 + 81.0), true);
+    launch_linearize_cam(true, g9.p, nullptr);
+    hcp_valid = true;
+  }
+
   // ---- optimizer::levenberg_marquardt (optimizer/levenberg_marquardt.hpp:110-242) -----
   DevBuf<LmDev> lmdev;
 
@@ -2261,8 +2376,8 @@ template <typename T> struct Engine final : EngineBase {
     std::memset(&st, 0, sizeof(st));
     struct LmScope { // the fused PCG start (solver_set_damping) is only armed inside this loop
       Engine *e;
-      explicit LmScope(Engine *e_) : e(e_) { e->lm_x = e->v_dx.p; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; }
-      ~LmScope() { e->lm_x = nullptr; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; e->profiling = false; }
+      explicit LmScope(Engine *e_) : e(e_) { e->lm_x = e->v_dx.p; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; e->sf_active = false; }
+      ~LmScope() { e->lm_x = nullptr; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; e->sf_active = false; e->profiling = false; }
     } lm_scope(this);
     struct EventPairs { // solve_seconds: events around every solve, read one iteration late, outside the decision -> launch path
       hipEvent_t ev[3][2];
@@ -2276,8 +2391,25 @@ template <typename T> struct Engine final : EngineBase {
     // user-traits problems take the host-driven form: the trial step goes through the user's Traits::update (gr_model_ops.step),
     // which the library's loop-ending direction launch cannot call
     lm_fused = pcg_solver && !comm && !model && pcg_mode() == 0 && opt.pcg_max_iter >= 1 && tune.lm_fused != 0;
+    // (larger reduced systems keep the host-driven loop: measured on Ladybug-1723, 1 723 cameras, the merged finalisation and
+    // back-substitution launches are no faster than their parts there — 1 716 vs 1 737 LM it/s — the shared S / b_S launch is what pays)
+    sf_active = opt.solver == GR_SOLVER_PCG_SCHUR && schur_fused_ok(opt.pcg_max_iter) && schur_coop() && opt.iterations > 0;
     bool head_enqueued = false; // the head of the NEXT iteration is already in the stream (device-decided accept)
     T chi2v = 0;
+    if (sf_active) {
+      // Schur solver, small reduced system: the first linearisation is finalised by the head of iteration 0 like every other one,
+      // and that launch reports the initial chi2
+      ensure_lm_buffers(); ensure_coop(opt.pcg_max_iter); ensure_scalars(opt.pcg_max_iter); // (pinned words are sized before the first head uses them)
+      campack();
+      linearize_hcp_deferred();
+      LmDecide dec;
+      dec.seq = ++seq_counter; dec.report_only = 1;
+      dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_lin; dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
+      enqueue_schur_head(dec, (double)mu, opt.use_identity != 0, opt.pcg_max_iter, opt.pcg_tol, opt.pcg_rejection_ratio, 0);
+      head_enqueued = true;
+      wait_chi2(dec.seq);
+      chi2v = (T)h_res[0];
+    } else
     if (lm_fused && opt.iterations > 0) {
       // fused form: the first linearisation is finalised by the head of iteration 0 like every other one, and that launch
       // reports the initial chi2 (no separate finalize launch, no synchronising read before the loop)
@@ -2318,7 +2450,7 @@ template <typename T> struct Engine final : EngineBase {
       st.solve_seconds += ms * 1e-3;
     };
     int ev_waiting = -1; // pair whose events are recorded and not yet read
-    if (!lm_fused) GR_HIP(hipStreamSynchronize(stream)); // fused form: the loop's first kernels are already running
+    if (!lm_fused && !sf_active) GR_HIP(hipStreamSynchronize(stream)); // fused forms: the loop's first kernels are already running
     st.setup_seconds = std::chrono::duration<double>(clk::now() - t0).count();
     auto tl = clk::now();
 
@@ -2355,6 +2487,7 @@ template <typename T> struct Engine final : EngineBase {
         revert();
         if (speculate) { // restore H, b, scales of the kept point
           if (lm_fused) { linearize_deferred(nullptr); fin_pending = true; pcg_state_clean = true; }
+          else if (sf_active) linearize_hcp_deferred(); // finalised by the next head
           else linearize_impl(want_hcp, /*pack_valid=*/true);
         } else if (lm_fused) pcg_state_clean = false; // the old linearisation stands, the loop state is spent
         accept_streak = 0;
@@ -2488,9 +2621,45 @@ template <typename T> struct Engine final : EngineBase {
       return go;
     };
 
+    // PCGSchurSolver on a small reduced system (kernels_sf.hpp): every trial step is judged by the finalisation launch of the NEXT
+    // iteration's head, which the host enqueues (with the rest of that head) right behind the trial linearisation
+    auto schur_fused_iteration = [&](int i) -> bool {
+      const int mi = opt.pcg_max_iter;
+      const bool ui = opt.use_identity != 0;
+      last_solver = opt.solver;
+      const int pr = i % 4;
+      if (!head_enqueued) enqueue_schur_head(LmDecide{}, (double)mu, ui, mi, opt.pcg_tol, opt.pcg_rejection_ratio, pr);
+      else damping = (double)mu;
+      head_enqueued = false;
+      const volatile int *iters_word = h_iters(); // this head's bank (the next head moves on to the other one)
+      linearize_hcp_deferred(); // at the trial point the head's last launch has stepped to
+      const int seq = ++seq_counter;
+      if (i + 1 < opt.iterations) {
+        LmDecide dec;
+        dec.seq = seq; dec.chi2_cur = (double)chi2v; dec.mu_cur = (double)mu;
+        dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_lin; dec.rho_partial = rho_partial.p; dec.n_rho = rho_blocks;
+        dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
+        enqueue_schur_head(dec, (double)mu, ui, mi, opt.pcg_tol, opt.pcg_rejection_ratio, (i + 1) % 4);
+        head_enqueued = true;
+      } else { // last iteration: only the decision is needed
+        Scope sc(this, "linearize_finalize", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 15.0 * Np) * w(), 9.0 * No + 54.0 * nseg, true);
+        launch(k_linearize_finalize<T>, cdiv(90 * (size_t)Nc, TPB) + cdiv(FIN_PL * (size_t)Np, TPB), (int)Nc, (int)Np, scale_system ? 1 : 0, 1, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bc.p, Hll.p, bl.p, scales.p, grid_lin, chi2_partial.p, dscalars.p,
+               rho_partial.p, rho_blocks, h_res, h_seq, seq, nullptr, cam_fixed_p(), pt_fixed_p(), IpcFused{}, 0ull);
+      }
+      wait_chi2(seq);
+      if (*h_coop_fail) throw HipError("cooperative PCG on S: a grid barrier timed out (workgroups not co-resident); set gr_bal_tuning.schur_fused = 0");
+      const int it = *iters_word;
+      if (schur_coop()) st.solve_seconds += (double)(h_ts[2 * pr + 1] - h_ts[2 * pr]) / wall_clock_hz; // device stamps around the cooperative PCG
+      const double hs[2] = {h_res[0], h_res[1]};
+      const double dev[2] = {h_res[2], h_res[3]};
+      const bool go = decide(i, true, /*speculate=*/true, it, hs, head_enqueued ? dev : nullptr);
+      if (head_enqueued && dev[1] == 0.0) head_enqueued = false; // not accepted: the head returned at once
+      return go;
+    };
+
     int i = 0;
     while (i < opt.iterations && run) {
-      const bool go = lm_fused ? fused_iteration(i) : host_iteration(i);
+      const bool go = sf_active ? schur_fused_iteration(i) : lm_fused ? fused_iteration(i) : host_iteration(i);
       ++i;
       if (!go) break;
       if (opt.stop_flag) { // levenberg_marquardt.hpp:233-238: polled once per iteration
@@ -2505,7 +2674,7 @@ template <typename T> struct Engine final : EngineBase {
       // the loop ends here but the head of the next iteration is already running: if its PCG loop ended inside the head,
       // its last direction launch has applied a trial step nobody will judge — take it back
       GR_HIP(hipStreamSynchronize(stream));
-      if (flags()[0] == 2 || opt.pcg_max_iter == 1) revert();
+      if (sf_active || flags()[0] == 2 || opt.pcg_max_iter == 1) revert(); // (Schur form: an accepted head always ends with its trial step)
       head_enqueued = false;
     }
     if (fin_pending) flush_finalize();
@@ -2609,7 +2778,7 @@ template <typename T> static void model_evaluate_impl(int64_t n, const void *cam
 }
 extern "C" {
 
-const char *gr_version(void) { return "graphite-mi355x 0.1 (gfx950)"; }
+const char *gr_version(void) { return "graphite-mi355x 0.2 (gfx950)"; } // 0.2: sizeof(gr_bal_tuning) = 100, sizeof(gr_lm_stats) = 80 (both grew in round 4), gr_model_ops
 const char *gr_last_error_string(void) { return g_last_error.c_str(); }
 int gr_device_count(void) {
   int nd = 0;

@@ -406,7 +406,8 @@ template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_schur_matvec(int Nc, const int *__restrict__ row_ptr, const int *__restrict__ row_blk,
                const int *__restrict__ row_col, const T *__restrict__ S, const T *__restrict__ x,
-               T *__restrict__ y, PcgScalars sc, int k) {
+               T *__restrict__ y, PcgScalars sc, int k, const LmDev *__restrict__ lm = nullptr) {
+  if (lm && lm->stop) return; // device-decided LM loop (kernels_sf.hpp): the trial step this head belongs to was not accepted
   if (k >= 0) {
     if (sc.done[k]) return;
     if (part_sum(sc.rz, sc.np, k) == 0.0) return;
@@ -459,7 +460,8 @@ __global__ void __launch_bounds__(64)
 k_schur_pcg_prepare(int Nc, const T *__restrict__ Ssrc, const int *__restrict__ diag_blk,
                     const int *__restrict__ cam_chunk_ptr, const T *__restrict__ partial9, const T *__restrict__ bc,
                     const T *__restrict__ scales, T *__restrict__ b_schur, T *__restrict__ Minv, T *__restrict__ r,
-                    T *__restrict__ z, T *__restrict__ p, T *__restrict__ x, T *__restrict__ q, PcgScalars sc) {
+                    T *__restrict__ z, T *__restrict__ p, T *__restrict__ x, T *__restrict__ q, PcgScalars sc, const LmDev *__restrict__ lm = nullptr) {
+  if (lm && lm->stop) return;
   const int c = blockIdx.x * 64 + threadIdx.x;
   double part = 0;
   if (c < Nc) {
@@ -503,7 +505,8 @@ template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_pcgs_update(int Nc, T *__restrict__ x, T *__restrict__ xb, T *__restrict__ r, T *__restrict__ z,
               const T *__restrict__ p, const T *__restrict__ Ap, const T *__restrict__ Minv,
-              PcgScalars sc, int k) {
+              PcgScalars sc, int k, const LmDev *__restrict__ lm = nullptr) {
+  if (lm && lm->stop) return;
   if (sc.done[k]) return;
   const double rz = part_sum(sc.rz, sc.np, k);
   if (rz == 0.0) return;
@@ -544,11 +547,12 @@ template <typename T>
 __global__ void __launch_bounds__(TPB)
 k_pcgs_direction(int Nc, T *__restrict__ x, const T *__restrict__ xb, T *__restrict__ p,
                  const T *__restrict__ z, T *__restrict__ q, const T *__restrict__ scales, PcgScalars sc,
-                 int k, double tol, double rejection_ratio) {
+                 int k, double tol, double rejection_ratio, const LmDev *__restrict__ lm = nullptr) {
   const unsigned t = blockIdx.x * TPB + threadIdx.x;
   const bool first = (t == 0);
   const double rz0 = sc.rz0[k];
   auto publish = [&](int flag) { if (sc.hflag) { sc.hflag[k] = flag; __threadfence_system(); } };
+  if (lm && lm->stop) { if (first) publish(2); return; } // the host's loop over the exit flags still ends
   if (sc.done[k]) { if (first) { sc.done[k + 1] = 1; sc.rz0[k + 1] = rz0; publish(2); } return; }
   const double rz = part_sum(sc.rz, sc.np, k);
   const double den = part_sum(sc.den, sc.np, k);
@@ -575,6 +579,13 @@ k_pcgs_direction(int Nc, T *__restrict__ x, const T *__restrict__ xb, T *__restr
     if (sc.hiters) *sc.hiters = k + 1;
     publish(dn ? 2 : 1);
   }
+}
+
+// reset of the Schur-PCG scalars (the extra block of k_point_prepare in the host-driven form)
+__global__ void k_pcgs_reset(PcgScalars pcg, int cap) {
+  for (int i = threadIdx.x; i < cap * pcg.np; i += blockDim.x) { pcg.rz[i] = 0.0; pcg.den[i] = 0.0; }
+  for (int i = threadIdx.x; i < cap; i += blockDim.x) { pcg.done[i] = 0; pcg.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
+  if (threadIdx.x == 0) pcg.iters[0] = 0;
 }
 
 // Landmark shards: the two LM scalars (trial chi2, rho denominator) have just been summed over the ranks in device memory;

@@ -588,6 +588,32 @@ k_apply_update_rho(unsigned n, unsigned pose_dim, int nbc, int cam_weight, T *__
   if (threadIdx.x == 0) rho_partial[blockIdx.x] = rho;
 }
 
+// Graph::revert_parameters (graph.hpp:311-318) + the camera packs of the restored cameras, one launch: workgroups [0, nbc) restore
+// 28 cameras each (252 scalars, then their packs), the others one point scalar per thread
+template <typename T>
+__global__ void __launch_bounds__(TPB)
+k_revert_pack(unsigned pose_dim, unsigned npt, int nbc, T *__restrict__ cams, T *__restrict__ pts, const T *__restrict__ cams_bak,
+              const T *__restrict__ pts_bak, T *__restrict__ pack) {
+  if ((int)blockIdx.x < nbc) {
+    __shared__ T cs[252];
+    const unsigned i = blockIdx.x * 252u + threadIdx.x;
+    if (threadIdx.x < 252 && i < pose_dim) { const T v = cams_bak[i]; cams[i] = v; cs[threadIdx.x] = v; }
+    __syncthreads();
+    const unsigned c = blockIdx.x * 28u + threadIdx.x;
+    if (threadIdx.x < 28 && 9u * c < pose_dim) {
+      T cam[9], pk[PACK];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cam[k] = cs[9 * threadIdx.x + k];
+      make_campack(cam, pk);
+#pragma unroll
+      for (int k = 0; k < PACK; ++k) pack[PACK * (size_t)c + k] = pk[k];
+    }
+  } else {
+    const unsigned q = (blockIdx.x - nbc) * TPB + threadIdx.x;
+    if (q < npt) pts[q] = pts_bak[q];
+  }
+}
+
 // Point records of the matrix-free operator: [X Y Z | ps_x ps_y ps_z | pad pad] per point, one aligned
 // 64-byte (fp64) / 32-byte (fp32) sector.  The operator's two per-observation gathers (point, scaled
 // direction) become ONE sector; on Venice/Final-shaped graphs, where every such gather is a cache-line
@@ -970,7 +996,9 @@ k_linearize_finalize(int Nc, int Np, int scale_system, int cam_scales, const int
   }
   __syncthreads();
   if ((int)threadIdx.x < fz.size) ipc_store(fz.flag(fz.push_box(threadIdx.x), fz_set, fz.push_slot(threadIdx.x)), mseq);
-  if ((int)threadIdx.x < fz.size) {
+  if (threadIdx.x == 0 && ipc_load(reinterpret_cast<const unsigned long long *>(fz.boxes[fz.rank]) + 500) != 0ull) s_bad = 1; // an earlier message timed out: no second wait
+  __syncthreads();
+  if ((int)threadIdx.x < fz.size && !s_bad) {
     const unsigned long long *flag = fz.flag(fz.rank, fz_set, threadIdx.x);
     const long long t0 = wall_clock64();
     while (ipc_load(flag) < mseq) {
@@ -1016,9 +1044,9 @@ __global__ void __launch_bounds__(TPB) k_shard_cam_sums(int Nc, int scale_system
   for (int r0 = 0; r0 < fz.size; r0 += 8) { // eight uncached loads in flight, added in rank order
     T q[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) q[u] = (r0 + u < fz.size && ((who >> (r0 + u)) & 1u)) ? ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, s_set, r0 + u)) + t) : T(0);
+    for (int u = 0; u < 8; ++u) q[u] = (r0 + u < fz.size && IpcFused::rank_in(who, r0 + u)) ? ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, s_set, r0 + u)) + t) : T(0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) if (r0 + u < fz.size && ((who >> (r0 + u)) & 1u)) s += q[u];
+    for (int u = 0; u < 8; ++u) if (r0 + u < fz.size && IpcFused::rank_in(who, r0 + u)) s += q[u];
   }
   const unsigned c = t / 90u, e = t % 90u;
   if (e < 81u) {
@@ -1339,9 +1367,11 @@ __device__ __forceinline__ void shard_push_tail(const ShardPush &sp, const PcgSt
   //    instead cost 42 us: its 1 500 workgroups each paid three uncached round trips to the mailbox.)  The camera rows are summed
   //    over the ranks by the update launch's camera workgroups, straight from the mailbox.
   __shared__ int s_bad;
-  if (threadIdx.x == 0) s_bad = 0;
+  // a communicator on which an earlier message timed out (the mailbox's error word, comm.hpp k_ipc_allreduce): no second wait —
+  // only the FIRST failure pays the bound, every fused launch enqueued behind it finishes at once with NaN dots
+  if (threadIdx.x == 0) s_bad = ipc_load(reinterpret_cast<const unsigned long long *>(fz.boxes[fz.rank]) + 500) != 0ull ? 1 : 0;
   __syncthreads();
-  if ((int)threadIdx.x < fz.size) {
+  if ((int)threadIdx.x < fz.size && !s_bad) {
     const unsigned long long *flag = fz.flag(fz.rank, set, threadIdx.x);
     const long long t0 = wall_clock64();
     while (ipc_load(flag) < seq) {
@@ -1655,9 +1685,9 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
           for (int r0 = 0; r0 < fz.size; r0 += 8) { // eight uncached loads in flight instead of a chain of them; added in rank order
             T q[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) q[u] = (r0 + u < fz.size && ((who >> (r0 + u)) & 1u)) ? ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, fz_set, r0 + u)) + t) : T(0);
+            for (int u = 0; u < 8; ++u) q[u] = (r0 + u < fz.size && IpcFused::rank_in(who, r0 + u)) ? ipc_load(reinterpret_cast<const T *>(fz.slot(fz.rank, fz_set, r0 + u)) + t) : T(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (r0 + u < fz.size && ((who >> (r0 + u)) & 1u)) raw += q[u];
+            for (int u = 0; u < 8; ++u) if (r0 + u < fz.size && IpcFused::rank_in(who, r0 + u)) raw += q[u];
           }
         } else if (raw_c) raw = raw_c[t]; // multi-GPU: camera rows already summed over segments and ranks
         else

@@ -1,0 +1,608 @@
+// Device-decided LM iteration for PCGSchurSolver on graphs whose reduced camera system is SMALL (Ladybug-49: 49 cameras,
+// S = 441 x 441) — gfx950.  solver/pcg_schur.hpp:79-168 + optimizer/levenberg_marquardt.hpp:110-242.
+//
+// The host-driven form of this solver runs ~18 launches of 2.5-20 us and two host decisions per LM iteration; on such graphs
+// every kernel is a latency chain, so the iteration costs what its launches and round trips cost.  Here it is FIVE launches and
+// the host only observes:
+//   k_linearize<WRITE_HCP>      (kernels_mf.hpp)  residuals, Jacobian blocks, Hcp, segment / point partials, chi2 partials
+//   k_finalize_schur                               accept decision of the PREVIOUS trial step (LmDecide, as k_finalize_bj), segment
+//                                                  sums -> Hcc, bc, camera scales; point sums -> Hll, bl, point scales, damped
+//                                                  inverse, M' = D Hll^-1 D, v = M' bl  (k_linearize_finalize + k_point_prepare)
+//   k_schur_reduce                                 S^u products per destination block, multi-item blocks finished by their LAST
+//                                                  ARRIVER in item order (no atomics on values, no zero / fix-up launches), and
+//                                                  the b_S chunk partials in the same launch (k_schur_multi x 2 + k_schur_products
+//                                                  + k_bschur_partial)
+//   k_schur_pcg_coop                               b_S, block-Jacobi inverses and ALL inner iterations of the PCG on S: one wave
+//                                                  per camera row, three grid barriers per iteration (k_schur_pcg_prepare +
+//                                                  (k_schur_matvec, k_pcgs_update, k_pcgs_direction) x iterations + the host's
+//                                                  exit-flag round trips)
+//   k_backsub_apply                                x_l = Hll^-1 (b_l - Hpl^T x_p), then the trial step: backup, update, camera packs,
+//                                                  rho-denominator partials (k_backsub + k_backsub_fixup + k_apply_update_rho)
+#pragma once
+#include "kernels_mf.hpp"
+
+namespace gr {
+
+// accept decision of the trial step the pending linearisation evaluated — the prologue of k_finalize_bj (kernels_mf.hpp), same
+// sums in the same order; returns false when the launch has nothing more to do (step not accepted)
+__device__ __forceinline__ bool lm_decide_prologue(const LmDecide &dec, double &mu, double *s_sum /* __shared__ [2] */) {
+  if (!dec.seq) return true;
+  if (threadIdx.x < 64) {
+    const int ln = threadIdx.x;
+    double c0 = 0, r0 = 0;
+    for (int base = 0; base < dec.n_chi2; base += 512) {
+      double q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = base + 64 * u + ln; q[u] = i < dec.n_chi2 ? dec.chi2_partial[i] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c0 += q[u];
+    }
+    for (int base = 0; base < dec.n_rho; base += 512) {
+      double q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = base + 64 * u + ln; q[u] = i < dec.n_rho ? dec.rho_partial[i] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r0 += q[u];
+    }
+    c0 = wave_allsum(c0); r0 = wave_allsum(r0);
+    if (ln == 0) { s_sum[0] = c0; s_sum[1] = r0; }
+  }
+  __syncthreads();
+  const double cs = s_sum[0], rs = s_sum[1];
+  if (dec.report_only) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (dec.dscal) dec.dscal[0] = cs;
+      dec.hres[0] = cs;
+      __threadfence_system();
+      *dec.hres_seq = dec.seq;
+    }
+    return true;
+  }
+  // levenberg_marquardt.hpp:184-197, scalars in the graph precision like the host loop: the caller passes chi2 / mu already rounded
+  return true;
+}
+
+// LmDecide's arithmetic in T (optimizer/levenberg_marquardt.hpp:20-47,184-197): ok = accepted; mun = the damping that follows
+template <typename T> __device__ __forceinline__ bool lm_accept(const LmDecide &dec, double cs, double rs, double &mun) {
+  const T chi2v = (T)dec.chi2_cur, new_chi2 = (T)cs;
+  const T denom = (T)rs + (T)1.0e-3;
+  const T rho = (chi2v - new_chi2) / denom;
+  const bool ok = isfinite((double)new_chi2) && rho > T(0);
+  double alpha = 1.0 - pow(2.0 * (double)rho - 1.0, 3.0);
+  alpha = fmax(fmin(alpha, 2.0 / 3.0), 1.0 / 3.0);
+  mun = (double)((T)dec.mu_cur * (T)alpha);
+  return ok;
+}
+
+struct CoopState {           // k_schur_pcg_coop's cross-workgroup state (device memory)
+  unsigned *barrier;         // [1] arrivals, cleared by k_finalize_schur
+  double *part;              // [(cap) * 3][Nc] per-row partials: phase 0 r.z (start / new), 1 p.Sp
+  int *iters;                // [1] inner iterations run
+  volatile int *hiters;      // pinned mirror
+  volatile int *fail;        // pinned host word, sticky: != 0 once a grid barrier has timed out (workgroups not co-resident)
+  long long *ts;             // pinned [2] wall-clock stamps around the loop (solve_seconds), may be null
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(TPB)
+k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restrict__ cam_seg_ptr, const T *__restrict__ cam_partial,
+                 const int *__restrict__ pt_ptr, const T *__restrict__ g9, T *__restrict__ Hcc, T *__restrict__ bu, T *__restrict__ Hll,
+                 T *__restrict__ scales, double mu, int use_identity, T *__restrict__ Hll_inv, T *__restrict__ Mp, T *__restrict__ vl,
+                 LmDecide dec, const unsigned char *__restrict__ cam_fixed, const unsigned char *__restrict__ pt_fixed, CoopState cs,
+                 PcgScalars pcg = PcgScalars{}, int pcg_cap = 0 /* > 0: the last workgroup resets the scalars of the per-iteration PCG kernels */) {
+  __shared__ double s_sum[2];
+  if (dec.seq) {
+    (void)lm_decide_prologue(dec, mu, s_sum);
+    if (!dec.report_only) {
+      double mun;
+      const bool ok = lm_accept<T>(dec, s_sum[0], s_sum[1], mun);
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        dec.lm->mu = mun; dec.lm->stop = ok ? 0 : 2;
+        if (dec.dscal) { dec.dscal[0] = s_sum[0]; dec.dscal[1] = s_sum[1]; }
+        dec.hres[0] = s_sum[0]; dec.hres[1] = s_sum[1]; dec.hres[2] = mun; dec.hres[3] = ok ? 1.0 : 0.0;
+        __threadfence_system();
+        *dec.hres_seq = dec.seq;
+      }
+      if (!ok) return;
+      mu = mun;
+    }
+  }
+  const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0 && cs.barrier) *cs.barrier = 0u;
+  if (pcg_cap > 0 && b == (int)gridDim.x - 1) { // an extra workgroup
+    for (int i = threadIdx.x; i < pcg_cap * pcg.np; i += TPB) { pcg.rz[i] = 0.0; pcg.den[i] = 0.0; }
+    for (int i = threadIdx.x; i < pcg_cap; i += TPB) { pcg.done[i] = 0; pcg.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }
+    if (threadIdx.x == 0) pcg.iters[0] = 0;
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (b < nbc) {
+    // cameras: lane j of a 9-lane group sums column j of the camera's 45 + 9 segment partials (as k_finalize_bj)
+    const int g = lane / 9, j = lane - 9 * g;
+    const int c = (b * 4 + wave) * 7 + g;
+    const bool on = g < 7 && c < Nc;
+    if (!on) return;
+    T a[9], bj = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = T(0);
+    int idx[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const int lo = i < j ? i : j, hi = i < j ? j : i; idx[i] = hi * (hi + 1) / 2 + lo; }
+    int sg = cam_seg_ptr[c];
+    const int sg1 = cam_seg_ptr[c + 1];
+    for (; sg + 4 <= sg1; sg += 4) {
+      T q[4][10];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const T *cp = cam_partial + 54 * (size_t)(sg + u);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) q[u][i] = cp[idx[i]];
+        q[u][9] = cp[45 + j];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] += q[u][i];
+        bj += q[u][9];
+      }
+    }
+    if (sg < sg1) {
+      const int nleft = sg1 - sg, last = sg1 - 1;
+      T q[3][10];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const T *cp = cam_partial + 54 * (size_t)(sg + u < last ? sg + u : last);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) q[u][i] = cp[idx[i]];
+        q[u][9] = cp[45 + j];
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (u < nleft) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) a[i] += q[u][i];
+          bj += q[u][9];
+        }
+    }
+    const bool fixed = cam_fixed && cam_fixed[c];
+    if (fixed) {
+      bj = T(0);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) a[i] = T(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Hcc[81 * (size_t)c + i + 9 * j] = a[i];
+    bu[9 * (size_t)c + j] = bj;
+    T ajj = a[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) ajj = (i == j) ? a[i] : ajj;
+    scales[9 * (size_t)c + j] = (scale_system && !fixed) ? (T)(1.0 / (DBL_EPSILON + sqrt((double)ajj))) : T(1);
+    return;
+  }
+  // points: FIN_PL lanes per point sum its observations' records (fixed order), then k_point_prepare's arithmetic
+  using V2 = typename Vec2T<T>::type;
+  constexpr int PPB = TPB / FIN_PL;
+  const int ntile = (Np + PPB - 1) / PPB;
+  const unsigned jl = threadIdx.x % FIN_PL;
+  const int npw = (int)gridDim.x - nbc - (pcg_cap > 0 ? 1 : 0); // point workgroups
+  for (int tile = b - nbc; tile < ntile; tile += npw) {
+    const int l = tile * PPB + (int)(threadIdx.x / FIN_PL);
+    const bool on = l < Np;
+    T v[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = T(0);
+    if (on) {
+      for (int a = pt_ptr[l] + (int)jl; a < pt_ptr[l + 1]; a += FIN_PL) {
+        const V2 *gq = reinterpret_cast<const V2 *>(g9 + 8 * (size_t)a);
+        const V2 c0 = gq[0], c1 = gq[1], c2 = gq[2], e = gq[3];
+        v[0] += c0.x * c0.x + c0.y * c0.y;
+        v[1] += c0.x * c1.x + c0.y * c1.y;
+        v[2] += c0.x * c2.x + c0.y * c2.y;
+        v[3] += c1.x * c1.x + c1.y * c1.y;
+        v[4] += c1.x * c2.x + c1.y * c2.y;
+        v[5] += c2.x * c2.x + c2.y * c2.y;
+        v[6] -= c0.x * e.x + c0.y * e.y;
+        v[7] -= c1.x * e.x + c1.y * e.y;
+        v[8] -= c2.x * e.x + c2.y * e.y;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { v[i] += lane_xor<1>(v[i]); v[i] += lane_xor<2>(v[i]); }
+    if (!on || jl != 0) continue;
+    const bool pfixed = pt_fixed && pt_fixed[l];
+    if (pfixed) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v[i] = T(0);
+    }
+    const bool sc_on = scale_system && !pfixed;
+    const T sc[3] = {sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[0]))) : T(1), sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1),
+                     sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1)};
+    const T H[9] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5]};
+    double A[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const T q = sc[r] * H[r + 3 * c] * sc[c];
+        A[r + 3 * c] = (r == c) ? (double)damp_diag(q, mu, use_identity) : (double)q;
+      }
+    spd_inverse<3>(A);
+    const size_t t0 = 9 * (size_t)Nc + 3 * (size_t)l;
+    T inv[9], m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { inv[i] = pfixed ? T(0) : (T)A[i]; Hll[9 * (size_t)l + i] = H[i]; Hll_inv[9 * (size_t)l + i] = inv[i]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { m[r + 3 * c] = sc[r] * inv[r + 3 * c] * sc[c]; Mp[9 * (size_t)l + r + 3 * c] = m[r + 3 * c]; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      bu[t0 + r] = v[6 + r]; scales[t0 + r] = sc[r];
+      vl[3 * (size_t)l + r] = m[r] * v[6] + m[r + 3] * v[7] + m[r + 6] * v[8];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// S^u products + b_S chunk partials in one launch.  Workgroups [0, nwg_items): 4 work items each (k_schur_products' arithmetic and
+// LDS strips); multi-item blocks: every item leaves its 81 partial sums in slab[item] (written through), arrives at the block's
+// counter, and the LAST arriver adds the slabs in item order and applies the epilogue — fixed order, no float atomics, no zeroing.
+// Workgroups [nwg_items, ...): k_bschur_partial's chunks.
+template <typename T>
+__global__ void __launch_bounds__(TPB, SCHUR_WAVES)
+k_schur_reduce(int nitems, int nwg_items, const int *__restrict__ item_blk, const int *__restrict__ item_beg,
+               const int *__restrict__ item_end, const int *__restrict__ item_multi /* -1: the block's only item, else its multi-block index */,
+               const int *__restrict__ multi_first, const int *__restrict__ multi_n, unsigned *__restrict__ multi_cnt, T *__restrict__ slab,
+               const int *__restrict__ prod_a, const int *__restrict__ prod_b, const int *__restrict__ S_rowi, const int *__restrict__ S_coli,
+               const int *__restrict__ pt_pm, const T *__restrict__ Hcp, const T *__restrict__ Mp, const T *__restrict__ Hcc,
+               const T *__restrict__ scales, double mu, int use_identity, T *__restrict__ S,
+               int nch, const int *__restrict__ chunk_beg, const int *__restrict__ pt_cm, const int *__restrict__ pos_cm, const T *__restrict__ vl,
+               T *__restrict__ partial9, const LmDev *__restrict__ lm) {
+  if (lm) { if (lm->stop) return; mu = lm->mu; }
+  const int lane = threadIdx.x & 63;
+  if ((int)blockIdx.x >= nwg_items) { // ---- b_S partials: one wave per camera chunk
+    const int ch = ((int)blockIdx.x - nwg_items) * 4 + (threadIdx.x >> 6);
+    if (ch >= nch) return;
+    T acc[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) acc[r] = T(0);
+    for (int j = chunk_beg[ch] + lane; j < chunk_beg[ch + 1]; j += 64) {
+      const T *v = vl + 3 * (size_t)pt_cm[j];
+      const T v0 = v[0], v1 = v[1], v2 = v[2];
+      const T *h = Hcp + 27 * (size_t)pos_cm[j];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) acc[r] += h[r] * v0 + h[r + 9] * v1 + h[r + 18] * v2;
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const T s = wave_sum(acc[r]);
+      if (lane == 0) partial9[9 * (size_t)ch + r] = s;
+    }
+    return;
+  }
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= nitems) return;
+  const int g = lane / 9, c = lane % 9;
+  const int blk = item_blk[item];
+  T acc[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) acc[r] = T(0);
+  __shared__ T strip[4][7][40];
+  if (g < 7) {
+    T *sg = strip[threadIdx.x >> 6][g];
+    const int q_end = item_end[item];
+    int q = item_beg[item] + g;
+    int a_n = 0, b_n = 0, pm_n = 0;
+    T h_n[3], hb_n[3], m_n = T(0);
+    auto fetch = [&](int qq) {
+      a_n = prod_a[qq]; b_n = prod_b[qq]; pm_n = pt_pm[a_n];
+      const T *ha = Hcp + 27 * (size_t)a_n + c, *hb = Hcp + 27 * (size_t)b_n + c;
+      h_n[0] = ha[0]; h_n[1] = ha[9]; h_n[2] = ha[18];
+      hb_n[0] = hb[0]; hb_n[1] = hb[9]; hb_n[2] = hb[18];
+      m_n = Mp[9 * (size_t)pm_n + c];
+    };
+    if (q < q_end) fetch(q);
+    for (; q < q_end; q += 7) {
+      sg[c] = h_n[0]; sg[c + 9] = h_n[1]; sg[c + 18] = h_n[2]; sg[27 + c] = m_n;
+      const T hb0 = hb_n[0], hb1 = hb_n[1], hb2 = hb_n[2];
+      if (q + 7 < q_end) fetch(q + 7);
+      wave_lds_fence();
+      T mv[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) mv[i] = sg[27 + i];
+      const T u0 = mv[0] * hb0 + mv[3] * hb1 + mv[6] * hb2;
+      const T u1 = mv[1] * hb0 + mv[4] * hb1 + mv[7] * hb2;
+      const T u2 = mv[2] * hb0 + mv[5] * hb1 + mv[8] * hb2;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) acc[r] += sg[r] * u0 + sg[r + 9] * u1 + sg[r + 18] * u2;
+      wave_lds_fence();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    T tot = acc[r];
+#pragma unroll
+    for (int gg = 1; gg < 7; ++gg) tot += __shfl(acc[r], gg * 9 + c, 64);
+    acc[r] = tot;
+  }
+  const int m = item_multi[item];
+  if (m < 0) {
+    if (lane < 9) schur_epilogue<T>(S_rowi[blk], S_coli[blk], c, acc, Hcc, scales, mu, use_identity, S + 81 * (size_t)blk + 9 * c);
+    return;
+  }
+  // multi-item block: slab out (written through), arrive; the last arriver finishes the block
+  if (lane < 9) {
+    T *out = slab + 81 * (size_t)item + 9 * c;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) __hip_atomic_store(&out[r], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int last = 0;
+  if (lane == 0) {
+    const unsigned n = (unsigned)multi_n[m];
+    const unsigned old = __hip_atomic_fetch_add(&multi_cnt[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == n) { last = 1; __hip_atomic_store(&multi_cnt[m], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  if (lane < 9) {
+    T tot[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) tot[r] = T(0);
+    const int i0 = multi_first[m], n = multi_n[m];
+    for (int it = 0; it < n; it += 2) { // two slabs in flight, added in item order
+      const T *s0 = slab + 81 * (size_t)(i0 + it) + 9 * c, *s1 = slab + 81 * (size_t)(i0 + (it + 1 < n ? it + 1 : it)) + 9 * c;
+      T q0[9], q1[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) { q0[r] = __hip_atomic_load(&s0[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); q1[r] = __hip_atomic_load(&s1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#pragma unroll
+      for (int r = 0; r < 9; ++r) { tot[r] += q0[r]; if (it + 1 < n) tot[r] += q1[r]; }
+    }
+    schur_epilogue<T>(S_rowi[blk], S_coli[blk], c, tot, Hcc, scales, mu, use_identity, S + 81 * (size_t)blk + 9 * c);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// grid barrier of the cooperative PCG: monotonic counter, every workgroup one wave.  Everything that crosses workgroups is
+// written through (agent-scope stores) and drained before the arrival (cdna_hip_programming.md G16, form R1) and read back with
+// agent-scope loads.  Bounded: a launch whose workgroups are not all resident would wait for ever otherwise.
+__device__ __forceinline__ bool coop_barrier(unsigned *counter, unsigned target, volatile int *fail) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int ok = 1;
+  if ((threadIdx.x & 63) == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > 200000000ll) { // 2 s of the 100 MHz clock: the launch's workgroups are not all resident
+        *fail = 1; // pinned host word (sticky): the host raises an error instead of using this solve
+        __threadfence_system();
+        ok = 0;
+        break;
+      }
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(ok) != 0;
+}
+// sum of the Nc per-row partials of one phase, the same order in every workgroup (whole wave must call)
+__device__ __forceinline__ double coop_sum(const double *part, int Nc) {
+  double s = 0;
+  for (int i = threadIdx.x & 63; i < Nc; i += 64) s += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return wave_allsum(s);
+}
+
+// PCGSchurSolver::solve (solver/pcg_schur.hpp:79-168) + BlockJacobiSchurPreconditioner (block_jacobi_schur.hpp:114-178), all of
+// it in ONE launch: grid = Nc workgroups of one wave, workgroup i owns block row i of S.  Lanes 0..8 hold the row's x, r, z, p,
+// x_backup entries in registers for the whole loop; p and the dot-product partials cross workgroups through device memory.
+// The arithmetic per entry is that of k_schur_pcg_prepare / k_schur_matvec / k_pcgs_update / k_pcgs_direction; the dot products
+// are summed per row first, then over the rows in row order.
+template <typename T>
+__global__ void __launch_bounds__(64)
+k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict__ row_blk, const int *__restrict__ row_col,
+                 const T *__restrict__ S, const int *__restrict__ diag_blk, const int *__restrict__ cam_chunk_ptr,
+                 const T *__restrict__ partial9, const T *__restrict__ bc, const T *__restrict__ scales, T *__restrict__ b_schur,
+                 T *__restrict__ p_glob, T *__restrict__ x_out, int max_iter, double tol, double rejection_ratio, CoopState cs,
+                 const LmDev *__restrict__ lm) {
+  if (lm && lm->stop) return;
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int g = lane / 9, r = lane % 9;
+  const bool own = lane < 9;
+  unsigned phase = 0;
+  if (i == 0 && lane == 0 && cs.ts) cs.ts[0] = wall_clock64();
+  // ---- b_S row, block-Jacobi inverse of the diagonal block (Gauss-Jordan across the 9 lanes, as k_finalize_bj), start of the loop
+  T b = T(0);
+  if (own) {
+    for (int ch = cam_chunk_ptr[i]; ch < cam_chunk_ptr[i + 1]; ++ch) b += partial9[9 * (size_t)ch + r];
+    b = scales[9 * (size_t)i + r] * (bc[9 * (size_t)i + r] - b);
+    b_schur[9 * (size_t)i + r] = b;
+  }
+  double A[9]; // column r of the diagonal block in lane r
+  {
+    const T *B = S + 81 * (size_t)diag_blk[i];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) A[q] = own ? (double)B[q + 9 * r] : (q == r % 9 ? 1.0 : 0.0);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      double f[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) f[q] = __shfl(A[q], k, 64);
+      const double piv = 1.0 / f[k];
+      if (own) {
+        A[k] = (r == k) ? piv : A[k] * piv;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          if (q == k) continue;
+          A[q] = (r == k) ? -f[q] * piv : A[q] - f[q] * A[k];
+        }
+      }
+    }
+  }
+  // z = Minv r needs ROW r of the inverse in lane r (the inverse of a symmetric block is symmetric only up to rounding; the row
+  // keeps the bits of spd_inverse<9> / k_schur_pcg_prepare): transposed across the lanes once, Mrow[q] = Minv[r][q] = entry r of lane q's column
+  T Mrow[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    double mrq = 0.0;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { const double t = __shfl(A[e], q, 64); mrq = (e == r) ? t : mrq; }
+    Mrow[q] = (T)mrq;
+  }
+  auto apply_minv = [&](T v) -> T {
+    T s = T(0);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s += Mrow[q] * __shfl(v, q, 64);
+    return s;
+  };
+  T xr = T(0), rr = b, zr = apply_minv(b), pr = zr, xbr = T(0);
+  double *part = cs.part;
+  {
+    const double d = wave_allsum(own ? (double)(rr * zr) : 0.0);
+    if (lane == 0) __hip_atomic_store(&part[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (own) __hip_atomic_store(&p_glob[9 * (size_t)i + r], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!coop_barrier(cs.barrier, ++phase * (unsigned)Nc, cs.fail)) return;
+  double rz = coop_sum(part, Nc);
+  double rz0 = __builtin_inf();
+  int k = 0, iters = 0;
+  for (; k < max_iter; ++k) {
+    if (rz == 0.0) break;
+    // y_i = (S p)_i : 7 groups of 9 lanes stride over the row's block list (k_schur_matvec)
+    T acc = T(0);
+    if (g < 7) {
+      for (int e = row_ptr[i] + g; e < row_ptr[i + 1]; e += 7) {
+        const int blk = row_blk[e], j = row_col[e];
+        const bool transposed = blk < 0;
+        const T *Ab = S + 81 * (size_t)(transposed ? ~blk : blk);
+        T xj[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) xj[c] = __hip_atomic_load(&p_glob[9 * (size_t)j + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!transposed) {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) acc += Ab[r + 9 * c] * xj[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) acc += Ab[c + 9 * r] * xj[c];
+        }
+      }
+    }
+    T y = acc;
+#pragma unroll
+    for (int gg = 1; gg < 7; ++gg) y += __shfl(acc, gg * 9 + r, 64);
+    double *pden = part + (size_t)(3 * k + 1) * Nc, *prz = part + (size_t)(3 * k + 3) * Nc;
+    {
+      const double d = wave_allsum(own ? (double)(y * pr) : 0.0);
+      if (lane == 0) __hip_atomic_store(&pden[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!coop_barrier(cs.barrier, ++phase * (unsigned)Nc, cs.fail)) return;
+    const double den = coop_sum(pden, Nc);
+    if (den == 0.0 || den != den) break;
+    ++iters;
+    const T alpha = (T)rz / (T)den;
+    xbr = xr;
+    xr = alpha * pr + xr;
+    rr = -alpha * y + rr;
+    zr = apply_minv(rr);
+    {
+      const double d = wave_allsum(own ? (double)(rr * zr) : 0.0);
+      if (lane == 0) __hip_atomic_store(&prz[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!coop_barrier(cs.barrier, ++phase * (unsigned)Nc, cs.fail)) return;
+    const T rz_new = (T)coop_sum(prz, Nc);
+    const bool reject = (fabs((double)rz_new) > rejection_ratio * rz0) || (rz_new != rz_new);
+    if (reject) { xr = xbr; break; }
+    const T beta = rz_new / (T)rz;
+    pr = beta * pr + zr;
+    rz0 = fmin(rz0, fabs((double)rz_new));
+    rz = (double)rz_new; // pcg_schur.hpp keeps rz in T
+    if (fabs((double)rz_new) < tol) { ++k; break; }
+    if (own) __hip_atomic_store(&p_glob[9 * (size_t)i + r], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!coop_barrier(cs.barrier, ++phase * (unsigned)Nc, cs.fail)) return;
+  }
+  if (own) x_out[9 * (size_t)i + r] = xr;
+  if (i == 0 && lane == 0) {
+    *cs.iters = iters;
+    if (cs.hiters) *cs.hiters = iters;
+    if (cs.ts) cs.ts[1] = wall_clock64();
+    __threadfence_system();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// SchurComplement::compute_landmark_update (schur.hpp:279-302) + the trial step (graph.hpp:292-309, ops/update.hpp:11-31) +
+// compute_rho's denominator partials (levenberg_marquardt.hpp:34-41) + the camera packs: workgroups [0, nct) take 28 cameras each,
+// the others points, FIN_PL lanes per point over its observations (point-major order: a point's Hcp blocks are contiguous).
+template <typename T>
+__global__ void __launch_bounds__(TPB)
+k_backsub_apply(int Nc, int Np, int nct, const int *__restrict__ pt_ptr, const int *__restrict__ cam_pm, const T *__restrict__ Hcp,
+                const T *__restrict__ Hll_inv, const T *__restrict__ bu, const T *__restrict__ scales, T *__restrict__ x /* [9 Nc + 3 Np]: xp in, xl out */,
+                T *__restrict__ cams, T *__restrict__ pts, T *__restrict__ cams_bak, T *__restrict__ pts_bak, T *__restrict__ pack,
+                double mu, double *__restrict__ rho_partial, const LmDev *__restrict__ lm) {
+  if (lm) { if (lm->stop) return; mu = lm->mu; }
+  __shared__ double red[4];
+  __shared__ T cs[252];
+  const unsigned pose_dim = 9u * (unsigned)Nc;
+  double rho = 0;
+  if ((int)blockIdx.x < nct) {
+    const unsigned i = blockIdx.x * 252u + threadIdx.x;
+    if (threadIdx.x < 252 && i < pose_dim) {
+      const T d = x[i], s = scales[i], xo = cams[i];
+      cams_bak[i] = xo;
+      const T xn = xo + d * s;
+      cams[i] = xn;
+      cs[threadIdx.x] = xn;
+      rho = (double)(d * ((T)mu * d + s * bu[i]));
+    }
+    __syncthreads();
+    const unsigned c = blockIdx.x * 28u + threadIdx.x;
+    if (threadIdx.x < 28 && 9u * c < pose_dim) {
+      T cam[9], pk[PACK];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cam[k] = cs[9 * threadIdx.x + k];
+      make_campack(cam, pk);
+#pragma unroll
+      for (int k = 0; k < PACK; ++k) pack[PACK * (size_t)c + k] = pk[k];
+    }
+  } else {
+    constexpr int PPB = TPB / FIN_PL;
+    const int ntile = (Np + PPB - 1) / PPB;
+    const unsigned jl = threadIdx.x % FIN_PL;
+    for (int tile = (int)blockIdx.x - nct; tile < ntile; tile += (int)gridDim.x - nct) {
+      const int l = tile * PPB + (int)(threadIdx.x / FIN_PL);
+      const bool on = l < Np;
+      T v[3] = {T(0), T(0), T(0)};
+      if (on) {
+        for (int a = pt_ptr[l] + (int)jl; a < pt_ptr[l + 1]; a += FIN_PL) {
+          const int c = cam_pm[a];
+          const T *h = Hcp + 27 * (size_t)a;
+#pragma unroll
+          for (int r = 0; r < 9; ++r) {
+            const T xs = scales[9 * (size_t)c + r] * x[9 * (size_t)c + r];
+            v[0] += h[r] * xs; v[1] += h[r + 9] * xs; v[2] += h[r + 18] * xs;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { v[q] += lane_xor<1>(v[q]); v[q] += lane_xor<2>(v[q]); }
+      if (!on || jl != 0) continue;
+      const size_t t0 = (size_t)pose_dim + 3 * (size_t)l;
+      const T s0 = scales[t0], s1 = scales[t0 + 1], s2 = scales[t0 + 2];
+      const T r0 = s0 * (bu[t0] - v[0]), r1 = s1 * (bu[t0 + 1] - v[1]), r2 = s2 * (bu[t0 + 2] - v[2]);
+      const T *inv = Hll_inv + 9 * (size_t)l;
+      const T sv[3] = {s0, s1, s2};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const T d = inv[q] * r0 + inv[q + 3] * r1 + inv[q + 6] * r2;
+        x[t0 + q] = d;
+        const T xo = pts[3 * (size_t)l + q];
+        pts_bak[3 * (size_t)l + q] = xo;
+        pts[3 * (size_t)l + q] = xo + d * sv[q];
+        rho += (double)(d * ((T)mu * d + sv[q] * bu[t0 + q]));
+      }
+    }
+  }
+  rho = block_sum_256(rho, red);
+  if (threadIdx.x == 0) rho_partial[blockIdx.x] = rho;
+}
+
+} // namespace gr

@@ -146,10 +146,17 @@ typedef struct {
   int32_t chol_pin;             /* GR_CHOL_PIN       1: its C tile parked in VGPRs (one workgroup per CU in fp64)                          */
   int32_t spchol_fuse;          /* GR_SPCHOL_FUSE    1: the same fusion in the nested-dissection form                                      */
   int32_t spchol_slice;         /* GR_SPCHOL_SLICE   1: tiles per work item of its triangular solves                                       */
-  int32_t reserved[4];
+  int32_t schur_fused;          /* GR_SCHUR_FUSED   -1 auto | 0 | 1: GR_SOLVER_PCG_SCHUR — S and the b_S partials in ONE launch whose multi-item
+                                   blocks are finished by their last arriver (no float atomics), and, where the reduced system is small
+                                   (cameras <= 2 x CUs), the device-decided LM iteration of kernels_sf.hpp: five launches, the whole PCG
+                                   on S inside one of them.  0: the round-4 kernels and the host-driven loop                              */
+  int32_t reserved[3];
 } gr_bal_tuning;
 void gr_bal_tuning_default(gr_bal_tuning *t);
 
+/* "graphite-mi355x <major.minor> (gfx950)".  ABI note: 0.2 = the layouts below (sizeof(gr_bal_tuning) == 100, sizeof(gr_lm_stats) == 80);
+ * a caller built against an earlier header (80 / 64 bytes) must be rebuilt — the library writes the whole struct.  New tuning fields
+ * from here on take `reserved` slots so that the size stays at 100. */
 const char *gr_version(void);
 const char *gr_last_error_string(void);
 /* number of visible HIP devices (0 if none); never initialises a device */

@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+for f in 0 1; do
+  echo "GR_SCHUR_FUSED=$f"
+  GR_SCHUR_FUSED=$f timeout 300 python bench.py --workload ladybug-1723 --solver pcg-schur --no-cpu-baseline --no-also --pmc-traffic off --repeats 3 --steps 10 2>&1 | tail -1 | python -c "
+import json,sys
+l=json.loads(sys.stdin.readline()); print(l['value'], l['value_min'], l['value_max'], l['ms_per_step'], l['pcg_iterations'], l['chi2_final'], l['accepted_steps']); print({k:(v['avg_us'],v['active_launches']) for k,v in l['roofline']['kernels'].items()})"
+done
