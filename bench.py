@@ -104,10 +104,9 @@ def self_launch(n):
     return subprocess.run(cmd).returncode
 
 
-def measure_pmc_traffic(args, solver_name, dtype_name, kernel):
-    """roofline.traffic measured BY THIS RUN: two short child passes of the same workload under rocprofv3 (one counter per pass, as
-    MI355X_MICROARCH.md prescribes: FETCH_SIZE counts 64 B per 128-B request on gfx950, WRITE_SIZE is KB of 64-B writes), median over
-    the dominant kernel's launches.  Children, never an exec; any failure returns None and the committed table is looked up instead."""
+def pmc_pass(args, solver_name, dtype_name, kernel, counters):
+    """one short child pass of the same workload under `rocprofv3 --pmc <counters>` (a child, never an exec): median of every counter
+    over the dominant kernel's launches, or None"""
     import csv
     import glob
     import shutil
@@ -119,29 +118,63 @@ def measure_pmc_traffic(args, solver_name, dtype_name, kernel):
         return None
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None  # this process is itself being profiled: no profiler inside a profiler
+    out = tempfile.mkdtemp(prefix="gr_pmc_", dir="/tmp")
+    try:
+        cmd = [prof, "--pmc", *counters, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+               "--workload", args.workload, "--solver", solver_name, "--dtype", dtype_name, "--pcg-iterations", str(args.pcg_iterations),
+               "--pcg-tol", str(args.pcg_tol), "--no-cpu-baseline", "--no-also", "--repeats", "1", "--steps", "10", "--warmup", "2", "--pmc-traffic", "off"]
+        r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", capture_output=True, text=True, timeout=240)
+        if r.returncode != 0:
+            return None
+        vals = {}
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if ("k_" + kernel) in row["Kernel_Name"].split("(")[0]:
+                    vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        if not vals:
+            return None
+        return {k: statistics.median(v) for k, v in vals.items()}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def measure_pmc_traffic(args, solver_name, dtype_name, kernel):
+    """roofline.traffic measured BY THIS RUN: two short child passes of the same workload under rocprofv3 (one counter per pass, as
+    MI355X_MICROARCH.md prescribes: FETCH_SIZE counts 64 B per 128-B request on gfx950, WRITE_SIZE is KB of 64-B writes), median over
+    the dominant kernel's launches.  Any failure returns None and the committed table is looked up instead."""
     med = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        out = tempfile.mkdtemp(prefix="gr_pmc_", dir="/tmp")
-        try:
-            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--workload", args.workload, "--solver", solver_name, "--dtype", dtype_name, "--pcg-iterations", str(args.pcg_iterations),
-                   "--pcg-tol", str(args.pcg_tol), "--no-cpu-baseline", "--no-also", "--repeats", "1", "--steps", "10", "--warmup", "2", "--pmc-traffic", "off"]
-            r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", capture_output=True, text=True, timeout=240)
-            if r.returncode != 0:
-                return None
-            vals = []
-            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if row["Counter_Name"] == counter and ("k_" + kernel) in row["Kernel_Name"].split("(")[0]:
-                        vals.append(float(row["Counter_Value"]))
-            if not vals:
-                return None
-            med[counter] = statistics.median(vals)
-        except Exception:
+        m = pmc_pass(args, solver_name, dtype_name, kernel, [counter])
+        if not m or counter not in m:
             return None
-        finally:
-            shutil.rmtree(out, ignore_errors=True)
+        med[counter] = m[counter]
     return {"hbm_bytes": 2 * med["FETCH_SIZE"] * 1024 + med["WRITE_SIZE"] * 1024, "FETCH_SIZE_KB": med["FETCH_SIZE"], "WRITE_SIZE_KB": med["WRITE_SIZE"]}
+
+
+def measure_sq(args, solver_name, dtype_name, kernel):
+    """what the dominant kernel's waves do with their time: one child pass with the SQ activity counters
+    (MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, disjoint) and one each for rocprofv3's derived
+    VALUBusy / OccupancyPercent (gfx94x formulas on gfx950)"""
+    raw = pmc_pass(args, solver_name, dtype_name, kernel, ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                                                            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"])
+    if not raw or not raw.get("SQ_WAVE_CYCLES"):
+        return None
+    wc = raw["SQ_WAVE_CYCLES"]
+    out = {"mem_wait": round(raw.get("SQ_WAIT_ANY", 0.0) / wc, 4), "issue_stall": round(raw.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
+           "issuing": round(raw.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 4),
+           "valu_share_of_issued": round(raw.get("SQ_ACTIVE_INST_VALU", 0.0) / max(raw.get("SQ_ACTIVE_INST_ANY", 0.0), 1.0), 4),
+           "waves_per_launch": raw.get("SQ_WAVES"),
+           "definitions": "fractions of the kernel's wave-cycles (SQ_WAVE_CYCLES): mem_wait = SQ_WAIT_ANY (waves parked on s_waitcnt / barrier), "
+                          "issue_stall = SQ_WAIT_INST_ANY, issuing = SQ_ACTIVE_INST_ANY; valu_share_of_issued = SQ_ACTIVE_INST_VALU / SQ_ACTIVE_INST_ANY",
+           "raw": {k: raw[k] for k in sorted(raw)}}
+    for name, key in (("VALUBusy", "valu_busy"), ("OccupancyPercent", "occupancy_percent")):
+        d = pmc_pass(args, solver_name, dtype_name, kernel, [name])
+        out[key] = None if not d or name not in d else round(d[name], 3)
+    if out.get("occupancy_percent") is not None:
+        out["waves_per_simd"] = round(out["occupancy_percent"] / 100.0 * 8.0, 2)  # 8 wave slots per SIMD
+    return out
 
 
 def main():
@@ -240,6 +273,189 @@ def main():
             runs.append((dt, ct, lt, st))
         return runs
 
+    def config_cached(workload):
+        """synth.make_config through a /tmp cache keyed by the workload name (= shape + seed): the 29 M observations of
+        final-13682 take about a minute to synthesise"""
+        path = f"/tmp/graphite_synth_{workload}_v1.npz"
+        if workload in ("venice-1778", "final-13682") and os.path.exists(path):
+            try:
+                z = np.load(path)
+                return synth.BalProblem(z["cameras"], z["points"], z["obs"], z["cam_idx"], z["pt_idx"], workload)
+            except Exception:
+                pass
+        prob = synth.make_config(workload)
+        if workload in ("venice-1778", "final-13682") and rank == 0:
+            try:
+                np.savez(path + ".tmp.npz", cameras=prob.cameras, points=prob.points, obs=prob.obs, cam_idx=prob.cam_idx, pt_idx=prob.pt_idx)
+                os.replace(path + ".tmp.npz", path)
+            except Exception:
+                pass
+        return prob
+
+    def roofline_of(ks, itemsize):
+        """dominant kernel of a profiled pass: algorithmic bytes (or flops) per launch / its mean ACTIVE launch"""
+        if not ks:
+            return None
+        name, k = max(ks.items(), key=lambda kv: kv[1]["total_ms"])
+        active = max(k.get("active_launches", k["launches"]), 1)
+        avg_s = k["total_ms"] * 1e-3 / active
+        achieved = k["bytes_per_launch"] / avg_s / 1e9
+        bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
+        if name in MFMA_KERNELS:
+            bound, unit = "mfma", "TFLOP/s"
+            peak = 78.6 if itemsize == 8 else 157.3
+            achieved = k["flops_per_launch"] / avg_s / 1e12
+        return {"bound": bound, "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),
+                "traffic": None, "avg_launch_us": round(avg_s * 1e6, 3), "launches": k["launches"], "active_launches": active,
+                "algorithmic_bytes_per_launch": k["bytes_per_launch"], "flops_per_launch": k["flops_per_launch"]}
+
+    def cache_residency(working_set_bytes):
+        """where the working set of one LM iteration lives — 32 MiB of L2 (8 x 4 MiB, not coherent across XCDs) and
+        the 256 MiB Infinity Cache, whose hits rocprofv3's FETCH_SIZE counts like HBM fetches (MI355X_MICROARCH.md)"""
+        l2, ic = 32 * 2 ** 20, 256 * 2 ** 20
+        where = "L2" if working_set_bytes <= l2 else ("Infinity Cache" if working_set_bytes <= ic else "HBM")
+        return {"working_set_bytes": int(working_set_bytes), "l2_bytes": l2, "infinity_cache_bytes": ic,
+                "working_set_over_l2": round(working_set_bytes / l2, 3), "working_set_over_infinity_cache": round(working_set_bytes / ic, 3),
+                "served_from": where,
+                "note": "arrays one LM iteration touches (observations, index streams, per-observation records, vectors, blocks); "
+                        + ("they fit the Infinity Cache: `traffic` is then mostly cache-served, and `frac` of the 8 TB/s HBM peak is a "
+                           "lower bound on how close the kernel is to what actually feeds it" if where != "HBM" else
+                           "beyond the Infinity Cache: `traffic` is HBM traffic")}
+
+    def working_set(nc, npts, nobs, itemsize, nseg_est=None):
+        nn = 9 * nc + 3 * npts
+        nseg_est = nseg_est or (nobs / 64 + nc)
+        return nobs * (2 * itemsize + 12) + nobs * 11 * itemsize + 63 * nseg_est * itemsize + 12 * nn * itemsize + (24 * nc + 2 * (81 * nc + 9 * npts)) * itemsize
+
+    def also_entry(workload, dt, solver_key, label, steps, warmup, repeats, jac32=False, parity_iters=0):
+        """one more BASELINE config on this box: value + parity_rel of the timed trace against the oracle + its dominant kernel's roofline"""
+        aprob = config_cached(workload)
+        t0 = time.perf_counter()
+        if sharded:
+            from graphite_amd import dist as gdist
+            apart = gdist.partition_by_landmark(aprob, rank, world, point_weight=gdist.point_weight_for(dt))
+            agpu = ga.BalProblem(apart.cameras, apart.points, apart.obs, apart.cam_idx, apart.pt_idx, dtype=dt, device=local_rank, shard=True)
+            if share_gpu:
+                gdist.init_comm_ipc(agpu, rank, world, slot_bytes=16 << 20, rccl_fallback=False)
+            elif os.environ.get("GR_COMM", "ipc") == "rccl":
+                gdist.init_comm(agpu, rank, world)
+            else:
+                gdist.init_comm_ipc(agpu, rank, world, slot_bytes=4 << 20, rccl_fallback=True)
+        else:
+            apart = aprob
+            agpu = ga.BalProblem(aprob.cameras, aprob.points, aprob.obs, aprob.cam_idx, aprob.pt_idx, dtype=dt, device=local_rank)
+        if jac32:
+            agpu.set_jacobian_precision(np.float32)
+        akw = dict(solver=SOLVERS[solver_key], initial_damping=1e-4, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0)
+        ra = summarise(timed_runs(agpu, apart, steps, warmup, repeats, akw))
+        agpu.set_params(apart.cameras, apart.points)
+        barrier()
+        agpu.levenberg_marquardt(iterations=steps, profile=True, **akw)
+        barrier()
+        aks = agpu.kernel_stats()
+        agpu.close()
+        aNc, aNp, aNo = aprob.shape
+        isz = np.dtype(dt).itemsize
+        par = f"landmark-sharded x{world}" if sharded else "single GPU"
+        e = {"workload": f"BAL {workload} shape ({aNc} cameras, {aNp} points, {aNo} observations), {label}, {par}",
+             "value": round(ra["value"], 2), "value_min": round(ra["value_min"], 2), "value_max": round(ra["value_max"], 2),
+             "unit": "LM iterations/s", "steps_run": ra["steps_run"], "accepted_steps": ra["st"]["accepted"],
+             "pcg_iterations": ra["st"]["pcg_iterations"], "ms_per_step": round(ra["dt"] / max(ra["steps_run"], 1) * 1e3, 4),
+             "collectives_per_lm_iteration": round(ra["st"].get("collectives", 0) / max(ra["steps_run"], 1), 2),
+             "chi2_initial": float(ra["ct"][0]), "chi2_final": float(ra["ct"][-1]), "parity_rel": None, "roofline": roofline_of(aks, isz)}
+        if e["roofline"]:
+            e["roofline"]["cache_residency"] = cache_residency(working_set(aNc, aNp, aNo, isz))
+        if parity_iters > 0 and rank == 0 and not args.no_cpu_baseline:
+            import oracle
+            osolver = {"pcg": oracle.SOLVER_PCG, "pcg-schur": oracle.SOLVER_PCG_SCHUR, "pcg-schur-implicit": oracle.SOLVER_PCG_SCHUR,
+                       "dense-schur": oracle.SOLVER_LDLT_SCHUR}[solver_key]
+            m = min(parity_iters, ra["steps_run"])
+            # the oracle runs in the graph precision; the fp32-Jacobian mode is compared with the fp64 oracle (its bar is fp32's)
+            ref = oracle.BalOracle(aprob.cameras, aprob.points, aprob.obs, aprob.cam_idx, aprob.pt_idx, dtype=dt)
+            ct_r, _, _ = ref.levenberg_marquardt(solver=osolver, iterations=m, initial_damping=1e-4, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0)
+            k = min(len(ct_r), len(ra["ct"]))
+            e["parity_rel"] = float(np.max(np.abs(np.asarray(ra["ct"][:k]) - ct_r[:k]) / np.abs(ct_r[:k])))
+            e["parity_steps"] = k - 1
+            e["parity_bar"] = PARITY_BAR["f32" if (isz == 4 or jac32) else "f64"]
+            del ref
+        del aprob, apart
+        return e
+
+    def user_traits_entry(steps):
+        """The engine's kernels instantiated on USER traits (include/graphite/engine_model.hpp): the Ladybug-1723 shape as a graph of
+        the generic C++ API whose factors carry per-factor information matrices and per-factor Huber deltas — not the built-in camera
+        model — through tests/cpp/test_engine_model.hip (a hipcc-compiled client; its binary travels in build/).  value = LM iterations
+        / seconds inside the engine's loop of a second call on the cached problem; roofline from a GR_PROFILE_KERNELS pass; parity
+        against the oracle with the same per-factor tables."""
+        import subprocess
+        exe = os.path.join(ROOT, "build", "test_engine_model")
+        src = os.path.join(ROOT, "tests", "cpp", "test_engine_model.hip")
+        if not os.path.exists(exe):
+            hipcc = "/opt/rocm/bin/hipcc"
+            if not os.path.exists(hipcc):
+                return None
+            os.makedirs(os.path.dirname(exe), exist_ok=True)
+            lib = os.path.join(ROOT, "graphite_amd")
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O2", f"-I{ROOT}/include", src, f"-L{lib}", "-lgraphite_mi355x", f"-Wl,-rpath,{lib}", "-o", exe],
+                               capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                return None
+        uprob = synth.make_config("ladybug-1723")
+        path = "/tmp/graphite_bench_ladybug1723.txt"
+        synth.write_bal(path, uprob)
+        uprob = synth.read_bal(path)  # the text round trip is what the client sees
+        env = dict(os.environ, GRAPHITE_ENGINE="model")
+        env.pop("GRAPHITE_GENERIC_ONLY", None)
+        cmd = [exe, path, "pcg", str(steps), "weighted", "stored", "fp64", "twice"]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            rp = subprocess.run(cmd[:-1], env=dict(env, GR_PROFILE_KERNELS="1"), capture_output=True, text=True, timeout=600)
+        except Exception:
+            return None
+        if r.returncode != 0 or rp.returncode != 0 or "ENGINE_MODEL_HANDOVERS 1" not in r.stdout:
+            return None
+        trace, second, uks = [], None, {}
+        for ln in r.stdout.splitlines():
+            f = ln.split()
+            if len(f) == 6 and f[0].isdigit():
+                trace.append((float(f[1]), float(f[2])))
+            if ln.startswith("SECOND_CALL_SECONDS"):
+                second = dict(zip(f[0::2], f[1::2]))
+        for ln in rp.stdout.splitlines():
+            f = ln.split()
+            if f and f[0] == "KERNEL":
+                uks[f[1]] = dict(launches=int(f[3]), active_launches=int(f[5]), total_ms=float(f[7]), bytes_per_launch=float(f[9]), flops_per_launch=float(f[11]))
+        if not trace or not second:
+            return None
+        loop_s, its = float(second["LOOP_SECONDS"]), int(second["ITERATIONS"])
+        uNc, uNp, uNo = uprob.shape
+        e = {"workload": f"user-traits engine: BAL ladybug-1723 shape ({uNc} cameras, {uNp} points, {uNo} observations) as a generic-API graph with per-factor "
+                         "2 x 2 information matrices and per-factor Huber deltas (engine_model.hpp kernels on the user's traits, stored weighted Jacobian), pcg, f64, single GPU",
+             "value": round(its / loop_s, 2), "unit": "LM iterations/s", "steps_run": its, "ms_per_step": round(loop_s / max(its, 1) * 1e3, 4),
+             "value_note": "second optimiser call on the cached engine problem: LM iterations / seconds inside the engine's loop",
+             "hand_over_seconds_second_call": float(second["SETUP_SECONDS"]), "chi2_initial": trace[0][0], "chi2_final": trace[-1][1],
+             "parity_rel": None, "roofline": roofline_of(uks, 8)}
+        if e["roofline"]:
+            e["roofline"]["kernels"] = {nm: {"avg_us": round(v["total_ms"] * 1e3 / max(v["active_launches"], 1), 2), "active_launches": v["active_launches"]} for nm, v in uks.items()}
+            e["roofline"]["cache_residency"] = cache_residency(working_set(uNc, uNp, uNo, 8) + uNo * 24 * 8)
+        if not args.no_cpu_baseline:
+            import oracle
+            f = np.arange(uNo)
+            a_ = 0.5 + (f % 7) / 4.0
+            c_ = 0.75 + (f % 5) / 8.0
+            b_ = 0.25 * ((f % 3) - 1.0) * np.sqrt(a_ * c_)
+            ref = oracle.BalOracle(uprob.cameras, uprob.points, uprob.obs, uprob.cam_idx, uprob.pt_idx, dtype=np.float64)
+            ref.set_factor_tables(pmat=np.stack([a_, b_, b_, c_], axis=1), loss_kinds=np.full(uNo, oracle.LOSS_HUBER), loss_deltas=1.0 + (f % 4).astype(np.float64))
+            m = min(6, len(trace))
+            ct_r, _, _ = ref.levenberg_marquardt(solver=oracle.SOLVER_PCG, iterations=m, initial_damping=1e-4, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0)
+            got = np.array([trace[0][0]] + [t[1] for t in trace[:m]])
+            k = min(len(ct_r), len(got))
+            e["parity_rel"] = float(np.max(np.abs(got[:k] - ct_r[:k]) / np.abs(ct_r[:k])))
+            e["parity_steps"] = k - 1
+            e["parity_bar"] = PARITY_BAR["f64"]
+            del ref
+        return e
+
     def summarise(runs):
         dts = [r[0] for r in runs]
         m = median_index(dts)
@@ -306,35 +522,18 @@ def main():
         # the configuration the north star's 8-GPU target is quoted on (BASELINE.json configs[3]): Venice-1778 fp32 — on every N,
         # the N = 1 line included, so that its strong scaling can be read off the lines of one SCALE run
         gpu.close()
-        vprob, vpart, vgpu, _ = make_engine("venice-1778", np.float32)
-        vkw = dict(solver=ga.SOLVER_PCG, initial_damping=1e-4, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0)
-        rv = summarise(timed_runs(vgpu, vpart, args.steps, 3, min(args.repeats, 5), vkw))
-        vNc, vNp, vNo = vprob.shape
-        par = f"landmark-sharded x{world}" if sharded else "single GPU"
-        venice = {"workload": f"BAL venice-1778 shape ({vNc} cameras, {vNp} points, {vNo} observations), pcg, f32, {par}",
-                  "value": round(rv["value"], 2), "value_min": round(rv["value_min"], 2), "value_max": round(rv["value_max"], 2),
-                  "unit": "LM iterations/s", "steps_run": rv["steps_run"], "accepted_steps": rv["st"]["accepted"],
-                  "pcg_iterations": rv["st"]["pcg_iterations"], "ms_per_step": round(rv["dt"] / max(rv["steps_run"], 1) * 1e3, 4),
-                  "collectives_per_lm_iteration": round(rv["st"]["collectives"] / max(rv["steps_run"], 1), 2),
-                  "chi2_initial": float(rv["ct"][0]), "chi2_final": float(rv["ct"][-1])}
-        vgpu.close()
-        del vprob, vpart
-        if os.environ.get("GR_BENCH_FINAL") == "1":
-            # BASELINE.json configs[4]: Final-13682, fp32 Jacobian entries + fp64 PCG (the reference's FP64-FP32 mode), 3 LM iterations.
-            # Opt-in (GR_BENCH_FINAL=1, any N): every rank synthesises the 29 M observations (~1 minute), which the default line,
-            # bound to finish within minutes on every N, does not spend
-            fprob, fpart, fgpu, _ = make_engine("final-13682", np.float64)
-            fgpu.set_jacobian_precision(np.float32)
-            rf = summarise(timed_runs(fgpu, fpart, 3, 1, 3, vkw))
-            fNc, fNp, fNo = fprob.shape
-            final_mixed = {"workload": f"BAL final-13682 shape ({fNc} cameras, {fNp} points, {fNo} observations), pcg, fp32 Jacobians + fp64 PCG, {par}",
-                           "value": round(rf["value"], 2), "value_min": round(rf["value_min"], 2), "value_max": round(rf["value_max"], 2),
-                           "unit": "LM iterations/s", "steps_run": rf["steps_run"], "accepted_steps": rf["st"]["accepted"],
-                           "pcg_iterations": rf["st"]["pcg_iterations"], "ms_per_step": round(rf["dt"] / max(rf["steps_run"], 1) * 1e3, 4),
-                           "collectives_per_lm_iteration": round(rf["st"]["collectives"] / max(rf["steps_run"], 1), 2),
-                           "chi2_initial": float(rf["ct"][0]), "chi2_final": float(rf["ct"][-1])}
-            fgpu.close()
-            del fprob, fpart
+        venice = also_entry("venice-1778", np.float32, "pcg", "pcg, f32", args.steps, 3, min(args.repeats, 5), parity_iters=3 if world == 1 else 0)
+        # BASELINE.json configs[4]: Final-13682, fp32 Jacobian entries + fp64 PCG (the reference's FP64-FP32 mode), 3 LM iterations.
+        # Default at N = 1 when the box has the memory for it (the oracle's parity leg keeps ~12 GB of host arrays) and
+        # GR_BENCH_FINAL != 0; N > 1: opt-in (GR_BENCH_FINAL=1) — every rank would synthesise / load the 29 M observations
+        want_final = os.environ.get("GR_BENCH_FINAL")
+        host_gb = 0.0
+        try:
+            host_gb = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
+        except Exception:
+            pass
+        if want_final == "1" or (want_final is None and world == 1 and host_gb >= 48 and torch.cuda.mem_get_info()[0] >= 40 * 2 ** 30):
+            final_mixed = also_entry("final-13682", np.float64, "pcg", "pcg, fp32 Jacobians + fp64 PCG", 3, 1, 3, jac32=True, parity_iters=2 if world == 1 else 0)
 
     if rank != 0:
         if sharded:
@@ -342,32 +541,14 @@ def main():
         return
 
     steps_run = main_run["steps_run"]
-    dominant = max(ks.items(), key=lambda kv: kv[1]["total_ms"]) if ks else None
-    roofline = None
-    if dominant:
-        name, k = dominant
-        # look-ahead launches that found the PCG loop finished return at once and move nothing: their
-        # (small) time is charged to the active launches, their bytes are not counted
-        active = max(k.get("active_launches", k["launches"]), 1)
-        avg_s = k["total_ms"] * 1e-3 / active
-        achieved = k["bytes_per_launch"] / avg_s / 1e9
-        bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
-        if name in MFMA_KERNELS:
-            # the reduced-camera Cholesky (dense tiles or the nested-dissection sparse form) is the one MFMA-bound stage: v_mfma_f64_16x16x4_f64 /
-            # v_mfma_f32_16x16x4_f32 run at the vector rate (MI355X_MICROARCH.md: 157.3 TF fp32, 78.6 TF fp64)
-            bound, unit = "mfma", "TFLOP/s"
-            peak = 78.6 if w == 8 else 157.3
-            achieved = k["flops_per_launch"] / avg_s / 1e12
-        roofline = {"bound": bound, "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-                    "unit": unit, "frac": round(achieved / peak, 5), "traffic": None,
-                    "avg_launch_us": round(avg_s * 1e6, 3), "launches": k["launches"], "active_launches": active,
-                    "algorithmic_bytes_per_launch": k["bytes_per_launch"],
-                    "flops_per_launch": k["flops_per_launch"],
-                    "achieved_gflops": round(k["flops_per_launch"] / avg_s / 1e9, 1),
-                    "kernels": {nm: {"avg_us": round(v["total_ms"] * 1e3 / max(v.get("active_launches", v["launches"]), 1), 2),
-                                     "active_launches": v.get("active_launches", v["launches"]),
-                                     "frac_of_hbm_peak": round(v["bytes_per_launch"] / (v["total_ms"] * 1e-3 / max(v.get("active_launches", v["launches"]), 1)) / 1e9 / HBM_PEAK_GBS, 4) if v["total_ms"] > 0 else None}
-                                for nm, v in ks.items()}}
+    roofline = roofline_of(ks, w)
+    if roofline:
+        roofline["achieved_gflops"] = round(roofline["flops_per_launch"] / (roofline["avg_launch_us"] * 1e-6) / 1e9, 1)
+        roofline["kernels"] = {nm: {"avg_us": round(v["total_ms"] * 1e3 / max(v.get("active_launches", v["launches"]), 1), 2),
+                                    "active_launches": v.get("active_launches", v["launches"]),
+                                    "frac_of_hbm_peak": round(v["bytes_per_launch"] / (v["total_ms"] * 1e-3 / max(v.get("active_launches", v["launches"]), 1)) / 1e9 / HBM_PEAK_GBS, 4) if v["total_ms"] > 0 else None}
+                               for nm, v in ks.items()}
+        roofline["cache_residency"] = cache_residency(working_set(Nc, Np, No, w))
     pcg_gflops = pcg_gflops_of(st)
 
     # ---- CPU baseline + parity against the oracle ---------------------------------------------------------------
@@ -471,6 +652,20 @@ def main():
         roofline["traffic_detail"] = live
         roofline["traffic_over_algorithmic"] = round(live["hbm_bytes"] / roofline["algorithmic_bytes_per_launch"], 3)
         roofline["traffic_note"] = "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)"
+        # the x2 is calibrated for wide coalesced streams only; profiles/r05_fetch_size_calibration.json (tools/fetch_calib.hip: 8 M records
+        # read once each from a 4 GiB table) shows the counter tallies 64 B per REQUEST: a 64-byte gather is counted in full, a 192-byte
+        # record as 128, a 16 B-per-lane stream at half.  Bounds, and an estimate that only doubles the coalesced share:
+        F, Wr = live["FETCH_SIZE_KB"] * 1024.0, live["WRITE_SIZE_KB"] * 1024.0
+        coalesced = float(No) * (2 * w + 12)  # observation + index streams of the per-observation kernels: read as whole 128-B requests
+        if roofline["kernel"] in ("pcg_update", "pcg_direction"):
+            coalesced = roofline["algorithmic_bytes_per_launch"] * 0.6  # vector kernels: reads are streams
+        est = F + min(F, 0.5 * coalesced) + Wr
+        roofline["traffic_calibrated"] = {"lower": F + Wr, "upper": 2 * F + Wr, "estimate": est,
+                                          "estimate_over_algorithmic": round(est / roofline["algorithmic_bytes_per_launch"], 3),
+                                          "estimate_GBs": round(est / (roofline["avg_launch_us"] * 1e-6) / 1e9, 1),
+                                          "note": "lower: every request 64 B; upper: every request 128 B (the guide's x2); estimate: the kernel's coalesced "
+                                                  "streams (observations + indices) doubled, its gathers counted as they are",
+                                          "calibration": "profiles/r05_fetch_size_calibration.json"}
     elif roofline:
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -482,21 +677,34 @@ def main():
                 roofline["traffic_note"] = tr.get("note")
         except Exception:
             pass
-        # the reference ALGORITHM streams stored Jacobians: SURVEY §8(d) bytes per matrix-free PCG iteration
-        if solver_name == "pcg":
-            ref_bytes = No * (24 * w + 8) + 14 * n * w + (81 * Nc + 9 * Np) * w
-            roofline["reference_algorithm_bytes_per_pcg_iteration"] = ref_bytes
-            roofline["reference_algorithm_time_at_peak_us"] = round(ref_bytes / HBM_PEAK_GBS / 1e3, 2)
-            # second roofline entry, in the survey's own unit: ONE WHOLE matrix-free PCG iteration (operator + update + direction)
-            # against SURVEY 8(d)'s bytes for it (the reference algorithm with stored Jacobians read once), timed on the
-            # fixed-iteration `also` run where every solve runs all its inner iterations
-            if fixed and fixed.get("us_per_pcg_iteration"):
-                ach = ref_bytes / (fixed["us_per_pcg_iteration"] * 1e-6) / 1e9
-                roofline["reference_equivalent_pcg_iteration"] = {
-                    "reference_equivalent_GBs": round(ach, 2), "reference_equivalent_frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 5),
-                    "us_per_iteration": fixed["us_per_pcg_iteration"], "reference_algorithm_bytes_per_iteration": ref_bytes,
-                    "note": "NOT a measured bandwidth: SURVEY 8(d) bytes of the reference algorithm's PCG iteration (stored Jacobians) / "
-                            "measured device time per iteration of this implementation, which recomputes J and moves fewer bytes"}
+    if roofline and world == 1 and args.pmc_traffic == "auto":
+        sq = measure_sq(args, solver_name, dtype_name, roofline["kernel"])
+        if sq:
+            roofline["sq"] = sq
+            roofline["valu_busy"] = sq.get("valu_busy")
+            roofline["mem_wait"] = sq["mem_wait"]
+            roofline["waves_per_simd"] = sq.get("waves_per_simd")
+            # `bound` keeps the contract's vocabulary (which roof the fraction is taken of); `limiter` says what the counters show
+            if roofline["bound"] == "hbm":
+                ic = roofline.get("cache_residency", {}).get("served_from")
+                roofline["limiter"] = ("memory latency at low occupancy" if sq["mem_wait"] >= 0.45 else "instruction issue" if sq["issuing"] + sq["issue_stall"] >= 0.6 else "mixed") + \
+                    f": waves parked on memory {sq['mem_wait']:.0%} of their cycles, issue stalls {sq['issue_stall']:.0%}, issuing {sq['issuing']:.0%} " \
+                    f"({sq['valu_share_of_issued']:.0%} of it VALU); working set served from {ic}"
+    # the reference ALGORITHM streams stored Jacobians: SURVEY §8(d) bytes per matrix-free PCG iteration
+    if roofline and solver_name == "pcg":
+        ref_bytes = No * (24 * w + 8) + 14 * n * w + (81 * Nc + 9 * Np) * w
+        roofline["reference_algorithm_bytes_per_pcg_iteration"] = ref_bytes
+        roofline["reference_algorithm_time_at_peak_us"] = round(ref_bytes / HBM_PEAK_GBS / 1e3, 2)
+        # second roofline entry, in the survey's own unit: ONE WHOLE matrix-free PCG iteration (operator + update + direction)
+        # against SURVEY 8(d)'s bytes for it (the reference algorithm with stored Jacobians read once), timed on the
+        # fixed-iteration `also` run where every solve runs all its inner iterations
+        if fixed and fixed.get("us_per_pcg_iteration"):
+            ach = ref_bytes / (fixed["us_per_pcg_iteration"] * 1e-6) / 1e9
+            roofline["reference_equivalent_pcg_iteration"] = {
+                "reference_equivalent_GBs": round(ach, 2), "reference_equivalent_frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 5),
+                "us_per_iteration": fixed["us_per_pcg_iteration"], "reference_algorithm_bytes_per_iteration": ref_bytes,
+                "note": "NOT a measured bandwidth: SURVEY 8(d) bytes of the reference algorithm's PCG iteration (stored Jacobians) / "
+                        "measured device time per iteration of this implementation, which recomputes J and moves fewer bytes"}
 
     also = []
     if fixed:
@@ -507,16 +715,10 @@ def main():
         also.append(final_mixed)
     if world == 1 and args.workload == "ladybug-1723" and args.solver is None and args.dtype is None and not args.no_also:
         # BASELINE.json configs[1] next to the default configs[2]: Ladybug-49 fp32, Schur + PCG
-        p49 = synth.make_config("ladybug-49")
-        g49 = ga.BalProblem(p49.cameras, p49.points, p49.obs, p49.cam_idx, p49.pt_idx, dtype=np.float32, device=local_rank)
-        kw49 = dict(solver=ga.SOLVER_PCG_SCHUR, initial_damping=1e-4, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0)
-        r49 = summarise(timed_runs(g49, p49, args.steps, 3, min(args.repeats, 5), kw49))
-        also.append({"workload": "BAL ladybug-49 shape (49 cameras, 7776 points, 31843 observations), pcg-schur, f32",
-                     "value": round(r49["value"], 2), "value_min": round(r49["value_min"], 2), "value_max": round(r49["value_max"], 2),
-                     "unit": "LM iterations/s", "steps_run": r49["steps_run"],
-                     "ms_per_step": round(r49["dt"] / max(r49["steps_run"], 1) * 1e3, 4), "chi2_initial": float(r49["ct"][0]),
-                     "chi2_final": float(r49["ct"][-1])})
-        g49.close()
+        also.append(also_entry("ladybug-49", np.float32, "pcg-schur", "pcg-schur, f32", args.steps, 3, min(args.repeats, 5), parity_iters=6))
+        ut = user_traits_entry(args.steps)
+        if ut:
+            also.append(ut)
 
     line = {
         "metric": "lm_iterations_per_sec", "value": round(main_run["value"], 4), "unit": "LM iterations/s",
@@ -547,6 +749,10 @@ def main():
     print(json.dumps(line))
     if sharded:
         dist.destroy_process_group()
+    for e in also:
+        if e.get("parity_rel") is not None and not (e["parity_rel"] < e.get("parity_bar", 1e-4)):
+            sys.stderr.write(f"bench.py: PARITY FAILURE in `also` entry {e['workload'][:60]}...: {e['parity_rel']:.3e} (bar {e.get('parity_bar')})\n")
+            sys.exit(3)
     if parity_rel is not None and not (parity_rel < PARITY_BAR[dtype_name]):
         sys.stderr.write(f"bench.py: PARITY FAILURE: chi2 trace differs from the oracle by {parity_rel:.3e} (bar {PARITY_BAR[dtype_name]:g})\n")
         sys.exit(3)

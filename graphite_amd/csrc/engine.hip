@@ -1017,7 +1017,8 @@ template <typename T> struct Engine final : EngineBase {
     if (!pack_valid) campack();
     if (part & 1) {
       // algorithmic bytes: every array touched once (obs, 3 index streams, points, packs, g9 out, partials, Hcp)
-      const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
+      double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
+      if (model && model->store_jacobians) bytes += No * (2.0 * model->pose_dim + 2.0 * model->landmark_dim) * (model->storage_dtype == GR_F64 ? 8.0 : 4.0); // the stored weighted Jacobian
       Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)), true);
       launch_linearize_cam(write_hcp, g9.p, gate);
     }

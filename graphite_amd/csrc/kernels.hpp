@@ -150,29 +150,35 @@ __global__ void k_point_prepare(int Np, int Nc, const T *__restrict__ Hll, const
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= Np) return;
   const T *s = scales + 9 * (size_t)Nc + 3 * (size_t)l;
-  const T sc[3] = {s[0], s[1], s[2]};
   const T *H = Hll + 9 * (size_t)l;
+  // the whole chain scale -> scaled damped block -> inverse -> M' -> v in double from the stored sums (scale_hat): the inversion
+  // amplifies entry errors by the block's condition number (1e3-1e4 for weakly observed points), so in fp32 the block it sees must
+  // not carry roundings of its own; only the outputs are rounded to T
+  const double sc[3] = {scale_hat(s[0], H[0]), scale_hat(s[1], H[4]), scale_hat(s[2], H[8])};
   double A[9];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const T v = sc[r] * H[r + 3 * c] * sc[c]; // scaled block in T, as the reference forms it
-      A[r + 3 * c] = (r == c) ? (double)damp_diag(v, mu, use_identity) : (double)v;
+      const double v = sc[r] * (double)H[r + 3 * c] * sc[c];
+      A[r + 3 * c] = (r == c) ? (use_identity ? v + mu : v + mu * clampd(v, 1.0e-6, 1.0e32)) : v;
     }
   spd_inverse<3>(A);
   const bool fixed = pt_fixed && pt_fixed[l];
-  T inv[9];
+  if (fixed) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { inv[i] = fixed ? T(0) : (T)A[i]; Hll_inv[9 * (size_t)l + i] = inv[i]; }
-  T m[9];
+    for (int i = 0; i < 9; ++i) A[i] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Hll_inv[9 * (size_t)l + i] = (T)A[i];
+  double m[9];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int r = 0; r < 3; ++r) { m[r + 3 * c] = sc[r] * inv[r + 3 * c] * sc[c]; Mp[9 * (size_t)l + r + 3 * c] = m[r + 3 * c]; }
-  const T b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
+    for (int r = 0; r < 3; ++r) { m[r + 3 * c] = sc[r] * A[r + 3 * c] * sc[c]; Mp[9 * (size_t)l + r + 3 * c] = (T)m[r + 3 * c]; }
+  const double b0 = (double)bl[3 * (size_t)l], b1 = (double)bl[3 * (size_t)l + 1], b2 = (double)bl[3 * (size_t)l + 2];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) vl[3 * (size_t)l + r] = m[r] * b0 + m[r + 3] * b1 + m[r + 6] * b2;
+  for (int r = 0; r < 3; ++r) vl[3 * (size_t)l + r] = (T)(m[r] * b0 + m[r + 3] * b1 + m[r + 6] * b2);
 }
 
 // S^u accumulation: sum_l Hcp_il M'_l Hcp_jl^T for every upper block (i,j).

@@ -128,16 +128,19 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
       T dcl[9];
       const T *B = Hcc + 81 * (size_t)c;
       const T *s = scales + 9 * (size_t)c;
+      double sh[9]; // the scaled, damped block is formed in double from the stored sums (scale_hat): its inverse sees no fp32 rounding of its own
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sh[i] = scale_hat(s[i], B[10 * i]);
 #pragma unroll
       for (int col = 0; col < 9; ++col)
 #pragma unroll
         for (int rw = 0; rw < 9; ++rw) {
-          const T v = s[rw] * B[rw + 9 * col] * s[col];
+          const double v = sh[rw] * (double)B[rw + 9 * col] * sh[col];
           if (rw == col) {
-            A[rw + 9 * col] = (double)damp_diag(v, mu, use_identity);
-            dcl[rw] = (T)clampd((double)v, 1.0e-6, 1.0e32);
+            A[rw + 9 * col] = use_identity ? v + mu : v + mu * clampd(v, 1.0e-6, 1.0e32);
+            dcl[rw] = (T)clampd(v, 1.0e-6, 1.0e32);
             diag_clamped[9 * (size_t)c + rw] = dcl[rw];
-          } else A[rw + 9 * col] = (double)v;
+          } else A[rw + 9 * col] = v;
         }
       spd_inverse<9>(A);
 #pragma unroll
@@ -170,16 +173,17 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
       const T *H = Hll + 9 * (size_t)l;
       double A[9];
       T dcl[3];
+      const double sh[3] = {scale_hat(s[0], H[0]), scale_hat(s[1], H[4]), scale_hat(s[2], H[8])};
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int rw = 0; rw < 3; ++rw) {
-          const T v = s[rw] * H[rw + 3 * c] * s[c];
+          const double v = sh[rw] * (double)H[rw + 3 * c] * sh[c];
           if (rw == c) {
-            A[rw + 3 * c] = (double)damp_diag(v, mu, use_identity);
-            dcl[rw] = (T)clampd((double)v, 1.0e-6, 1.0e32);
+            A[rw + 3 * c] = use_identity ? v + mu : v + mu * clampd(v, 1.0e-6, 1.0e32);
+            dcl[rw] = (T)clampd(v, 1.0e-6, 1.0e32);
             diag_clamped[t0 + rw] = dcl[rw];
-          } else A[rw + 3 * c] = (double)v;
+          } else A[rw + 3 * c] = v;
         }
       spd_inverse<3>(A);
 #pragma unroll
@@ -439,23 +443,28 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
     for (int tile = b - nbc; tile < ntile; tile += gridDim.x - nbc) {
       const int l = tile * PPB + (int)(threadIdx.x / FIN_PL);
       const bool on = l < Np;
-      T v[9];
+      // The sums of a point's records, its scales, the scaled damped block, the inverse and z' = Minv r are taken in DOUBLE whatever
+      // T is (for T = double nothing changes): the 3 x 3 block of a weakly observed point has a condition number of 1e3-1e4, and in
+      // fp32 every rounding of the block's entries came back that much larger in the inverse (fp32 step 2.8 x further from the fp64
+      // step than a plain fp32 restatement's, all of it in the point part; tools/fp32_first_iteration_probe.py).  Only outputs are rounded.
+      double v[9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) v[i] = T(0);
-      if (on && (VAR & 4)) { v[0] = v[3] = v[5] = T(2 + l % 3); v[6] = T(1); }
+      for (int i = 0; i < 9; ++i) v[i] = 0.0;
+      if (on && (VAR & 4)) { v[0] = v[3] = v[5] = (double)(2 + l % 3); v[6] = 1.0; }
       if (on && !(VAR & 4)) {
         for (int a = pt_ptr[l] + (int)jl; a < pt_ptr[l + 1]; a += FIN_PL) {
           const V2 *gq = reinterpret_cast<const V2 *>(g9 + 8 * (size_t)a);
-          const V2 c0 = gq[0], c1 = gq[1], c2 = gq[2], e = gq[3]; // sqrt(w) Jp columns, sqrt(w) e
-          v[0] += c0.x * c0.x + c0.y * c0.y;
-          v[1] += c0.x * c1.x + c0.y * c1.y;
-          v[2] += c0.x * c2.x + c0.y * c2.y;
-          v[3] += c1.x * c1.x + c1.y * c1.y;
-          v[4] += c1.x * c2.x + c1.y * c2.y;
-          v[5] += c2.x * c2.x + c2.y * c2.y;
-          v[6] -= c0.x * e.x + c0.y * e.y;
-          v[7] -= c1.x * e.x + c1.y * e.y;
-          v[8] -= c2.x * e.x + c2.y * e.y;
+          const V2 q0 = gq[0], q1 = gq[1], q2 = gq[2], qe = gq[3]; // sqrt(w) Jp columns, sqrt(w) e
+          const double c0x = q0.x, c0y = q0.y, c1x = q1.x, c1y = q1.y, c2x = q2.x, c2y = q2.y, ex = qe.x, ey = qe.y;
+          v[0] += c0x * c0x + c0y * c0y;
+          v[1] += c0x * c1x + c0y * c1y;
+          v[2] += c0x * c2x + c0y * c2y;
+          v[3] += c1x * c1x + c1y * c1y;
+          v[4] += c1x * c2x + c1y * c2y;
+          v[5] += c2x * c2x + c2y * c2y;
+          v[6] -= c0x * ex + c0y * ey;
+          v[7] -= c1x * ex + c1y * ey;
+          v[8] -= c2x * ex + c2y * ey;
         }
       }
 #pragma unroll
@@ -464,36 +473,36 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
       const bool pfixed = pt_fixed && pt_fixed[l];
       if (pfixed) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) v[i] = T(0);
+        for (int i = 0; i < 9; ++i) v[i] = 0.0;
       }
       const bool sc_on = scale_system && !pfixed && !(VAR & 2);
-      const T s0 = sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[0]))) : T(1);
-      const T s1 = sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1);
-      const T s2 = sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1);
-      const T H[9] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5]};
-      const T sv[3] = {s0, s1, s2};
+      const double sd[3] = {sc_on ? 1.0 / (DBL_EPSILON + sqrt(v[0])) : 1.0, sc_on ? 1.0 / (DBL_EPSILON + sqrt(v[3])) : 1.0, sc_on ? 1.0 / (DBL_EPSILON + sqrt(v[5])) : 1.0};
+      const double Hd[9] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5]};
+      const T H[9] = {(T)v[0], (T)v[1], (T)v[2], (T)v[1], (T)v[3], (T)v[4], (T)v[2], (T)v[4], (T)v[5]};
+      const T sv[3] = {(T)sd[0], (T)sd[1], (T)sd[2]};
       double A[9];
       T dcl[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int rw = 0; rw < 3; ++rw) {
-          const T q = sv[rw] * H[rw + 3 * c] * sv[c];
-          if (rw == c) { A[rw + 3 * c] = (double)damp_diag(q, mu, use_identity); dcl[rw] = (T)clampd((double)q, 1.0e-6, 1.0e32); }
-          else A[rw + 3 * c] = (double)q;
+          const double q = sd[rw] * Hd[rw + 3 * c] * sd[c];
+          if (rw == c) { A[rw + 3 * c] = use_identity ? q + mu : q + mu * clampd(q, 1.0e-6, 1.0e32); dcl[rw] = (T)clampd(q, 1.0e-6, 1.0e32); }
+          else A[rw + 3 * c] = q;
         }
       if (!(VAR & 2)) spd_inverse<3>(A);
-      const T rv[3] = {s0 * v[6], s1 * v[7], s2 * v[8]};
+      const double rvd[3] = {sd[0] * v[6], sd[1] * v[7], sd[2] * v[8]};
+      const T rv[3] = {(T)rvd[0], (T)rvd[1], (T)rvd[2]};
       T z[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) z[i] = identity_precond ? rv[i] : (T)A[i] * rv[0] + (T)A[i + 3] * rv[1] + (T)A[i + 6] * rv[2];
+      for (int i = 0; i < 3; ++i) z[i] = identity_precond ? rv[i] : (T)(A[i] * rvd[0] + A[i + 3] * rvd[1] + A[i + 6] * rvd[2]);
       // 36 outputs per point, written 4 lanes wide: lane jl stores outputs jl, jl + 4, ... (9 store instructions with every lane
       // active; one predicated store per output was 39 instructions)
       static_assert(FIN_PL == 4, "k_finalize_bj writes its outputs four lanes wide");
       const size_t t0 = 9 * (size_t)Nc + 3 * (size_t)l;
       const T out[36] = {H[0], H[1], H[2], H[3], H[4], H[5], H[6], H[7], H[8],
                          (T)A[0], (T)A[1], (T)A[2], (T)A[3], (T)A[4], (T)A[5], (T)A[6], (T)A[7], (T)A[8],
-                         v[6], v[7], v[8], sv[0], sv[1], sv[2], dcl[0], dcl[1], dcl[2],
+                         (T)v[6], (T)v[7], (T)v[8], sv[0], sv[1], sv[2], dcl[0], dcl[1], dcl[2],
                          zs ? sv[0] * z[0] : T(0), zs ? sv[1] * z[1] : T(0), zs ? sv[2] * z[2] : T(0), rv[0], rv[1], rv[2], z[0], z[1], z[2]};
       T *const dst[8] = {Hll + 9 * (size_t)l, MinvP + 9 * (size_t)l, bu + t0, scales + t0, diag_clamped + t0, (zs ? zs : x) + t0, r + t0, zt + t0};
 #pragma unroll
@@ -1791,7 +1800,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
           pw[t] = pv; if (!CG && !FIRST) psw[t] = sc * pv;
         }
         const T xo = FIRST ? T(0) : x[t], ro = r[t];
-        T raw = 0;
+        double raw = 0; // summed in double whatever T is (a point's rows cancel; T = double: unchanged)
         int a = pt_ptr[l];
         const int a_end = pt_ptr[l + 1];
 #if UPD_VAR != 1
@@ -1824,18 +1833,19 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         }
         }
 #else
-        raw = (T)(a_end - a);
+        raw = (double)(a_end - a);
 #endif
-        if (gg.pt_fixed && gg.pt_fixed[l]) raw = T(0);
+        if (gg.pt_fixed && gg.pt_fixed[l]) raw = 0.0;
+        const T rawt = (T)raw;
         T v2;
         if (CG) {
           const T uo = lz_scale * zt[t];
-          v2 = lz_scale * (sc * raw) + (use_identity ? (T)mu * uo : (T)mu * dg * uo);
+          v2 = lz_scale * (sc * rawt) + (use_identity ? (T)mu * uo : (T)mu * dg * uo);
           if (k > 0) v2 += lz_beta * svw[t];
           svw[t] = v2;
-        } else if (FIRST) v2 = lz_scale * (sc * raw) + (use_identity ? (T)mu * pv : (T)mu * dg * pv);
+        } else if (FIRST) v2 = lz_scale * (sc * rawt) + (use_identity ? (T)mu * pv : (T)mu * dg * pv);
         else
-        v2 = sc * raw + (use_identity ? (T)mu * pv : (T)mu * dg * pv);
+        v2 = sc * rawt + (use_identity ? (T)mu * pv : (T)mu * dg * pv);
         xb[t] = xo;
         x[t] = alpha * pv + xo;
         rn = -alpha * v2 + ro;
@@ -1853,7 +1863,7 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
       else {
 #if UPD_VAR != 3
         const T *rc = rs + 3 * lt;
-        s = m0 * rc[0] + m1 * rc[1] + m2 * rc[2];
+        s = (T)((double)m0 * (double)rc[0] + (double)m1 * (double)rc[1] + (double)m2 * (double)rc[2]);
 #else
         s = m0 * rn + m1 * rn + m2 * rn;
 #endif

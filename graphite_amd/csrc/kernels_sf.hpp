@@ -189,22 +189,23 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
   for (int tile = b - nbc; tile < ntile; tile += npw) {
     const int l = tile * PPB + (int)(threadIdx.x / FIN_PL);
     const bool on = l < Np;
-    T v[9];
+    double v[9]; // sums, scales, block, inverse, M', v in double whatever T is (see k_finalize_bj): only the outputs are rounded
 #pragma unroll
-    for (int i = 0; i < 9; ++i) v[i] = T(0);
+    for (int i = 0; i < 9; ++i) v[i] = 0.0;
     if (on) {
       for (int a = pt_ptr[l] + (int)jl; a < pt_ptr[l + 1]; a += FIN_PL) {
         const V2 *gq = reinterpret_cast<const V2 *>(g9 + 8 * (size_t)a);
-        const V2 c0 = gq[0], c1 = gq[1], c2 = gq[2], e = gq[3];
-        v[0] += c0.x * c0.x + c0.y * c0.y;
-        v[1] += c0.x * c1.x + c0.y * c1.y;
-        v[2] += c0.x * c2.x + c0.y * c2.y;
-        v[3] += c1.x * c1.x + c1.y * c1.y;
-        v[4] += c1.x * c2.x + c1.y * c2.y;
-        v[5] += c2.x * c2.x + c2.y * c2.y;
-        v[6] -= c0.x * e.x + c0.y * e.y;
-        v[7] -= c1.x * e.x + c1.y * e.y;
-        v[8] -= c2.x * e.x + c2.y * e.y;
+        const V2 q0 = gq[0], q1 = gq[1], q2 = gq[2], qe = gq[3];
+        const double c0x = q0.x, c0y = q0.y, c1x = q1.x, c1y = q1.y, c2x = q2.x, c2y = q2.y, ex = qe.x, ey = qe.y;
+        v[0] += c0x * c0x + c0y * c0y;
+        v[1] += c0x * c1x + c0y * c1y;
+        v[2] += c0x * c2x + c0y * c2y;
+        v[3] += c1x * c1x + c1y * c1y;
+        v[4] += c1x * c2x + c1y * c2y;
+        v[5] += c2x * c2x + c2y * c2y;
+        v[6] -= c0x * ex + c0y * ey;
+        v[7] -= c1x * ex + c1y * ey;
+        v[8] -= c2x * ex + c2y * ey;
       }
     }
 #pragma unroll
@@ -213,33 +214,32 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
     const bool pfixed = pt_fixed && pt_fixed[l];
     if (pfixed) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) v[i] = T(0);
+      for (int i = 0; i < 9; ++i) v[i] = 0.0;
     }
     const bool sc_on = scale_system && !pfixed;
-    const T sc[3] = {sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[0]))) : T(1), sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[3]))) : T(1),
-                     sc_on ? (T)(1.0 / (DBL_EPSILON + sqrt((double)v[5]))) : T(1)};
-    const T H[9] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5]};
+    const double sc[3] = {sc_on ? 1.0 / (DBL_EPSILON + sqrt(v[0])) : 1.0, sc_on ? 1.0 / (DBL_EPSILON + sqrt(v[3])) : 1.0, sc_on ? 1.0 / (DBL_EPSILON + sqrt(v[5])) : 1.0};
+    const double H[9] = {v[0], v[1], v[2], v[1], v[3], v[4], v[2], v[4], v[5]};
     double A[9];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const T q = sc[r] * H[r + 3 * c] * sc[c];
-        A[r + 3 * c] = (r == c) ? (double)damp_diag(q, mu, use_identity) : (double)q;
+        const double q = sc[r] * H[r + 3 * c] * sc[c];
+        A[r + 3 * c] = (r == c) ? (use_identity ? q + mu : q + mu * clampd(q, 1.0e-6, 1.0e32)) : q;
       }
     spd_inverse<3>(A);
     const size_t t0 = 9 * (size_t)Nc + 3 * (size_t)l;
-    T inv[9], m[9];
+    double m[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { inv[i] = pfixed ? T(0) : (T)A[i]; Hll[9 * (size_t)l + i] = H[i]; Hll_inv[9 * (size_t)l + i] = inv[i]; }
+    for (int i = 0; i < 9; ++i) { if (pfixed) A[i] = 0.0; Hll[9 * (size_t)l + i] = (T)H[i]; Hll_inv[9 * (size_t)l + i] = (T)A[i]; }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) { m[r + 3 * c] = sc[r] * inv[r + 3 * c] * sc[c]; Mp[9 * (size_t)l + r + 3 * c] = m[r + 3 * c]; }
+      for (int r = 0; r < 3; ++r) { m[r + 3 * c] = sc[r] * A[r + 3 * c] * sc[c]; Mp[9 * (size_t)l + r + 3 * c] = (T)m[r + 3 * c]; }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      bu[t0 + r] = v[6 + r]; scales[t0 + r] = sc[r];
-      vl[3 * (size_t)l + r] = m[r] * v[6] + m[r + 3] * v[7] + m[r + 6] * v[8];
+      bu[t0 + r] = (T)v[6 + r]; scales[t0 + r] = (T)sc[r];
+      vl[3 * (size_t)l + r] = (T)(m[r] * v[6] + m[r + 3] * v[7] + m[r + 6] * v[8]);
     }
   }
 }

@@ -689,6 +689,9 @@ inline size_t &engine_model_handovers() { static size_t n = 0; return n; }
 // host seconds the last hand-over spent outside gr_bal_levenberg_marquardt (checks, export, probe, create / cache look-up,
 // parameter transfer both ways, residual refresh)
 inline double &engine_last_setup_seconds() { static double s = 0; return s; }
+// ... and inside the engine's LM loop (gr_lm_stats.loop_seconds) / its iteration count
+inline double &engine_last_loop_seconds() { static double s = 0; return s; }
+inline int &engine_last_iterations() { static int n = 0; return n; }
 
 // The engine problem of one graph, kept on the Graph between optimiser calls (Graph::engine_cache).  Valid while the three
 // descriptors are the same objects, none of their structure epochs moved (add / remove / replace / set_fixed / set_active
@@ -843,7 +846,8 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
         if (fds[0]->declares_bal_model())
           std::cerr << "graphite: the factor traits declare bal_reprojection_model, but " << (model_ok ? "update()" : "error()/jacobian()")
                     << " differ from the engine's model (relative deviation " << (model_ok ? update_dev : std::max(worst, worst_syn))
-                    << (worst <= tol && !(worst_syn <= tol) ? ", on the synthetic branch triples only" : "") << "); using the generic kernels" << std::endl;
+                    << (worst <= tol && !(worst_syn <= tol) ? ", on the synthetic branch triples only" : "")
+                    << "); not the library's built-in camera model: the engine's kernels are instantiated on these traits instead (engine_model.hpp)" << std::endl;
         return false;
       }
     }
@@ -929,6 +933,9 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   int m; double tl, rj;
   options->solver->engine_pcg_parameters(m, tl, rj);
   o.pcg_max_iter = m; o.pcg_tol = tl; o.pcg_rejection_ratio = rj;
+  // GR_PROFILE_KERNELS=1 (measurement: bench.py's user-traits entry, tools/): per-kernel dispatch times of this call, printed below
+  const bool profile_kernels = getenv("GR_PROFILE_KERNELS") && atoi(getenv("GR_PROFILE_KERNELS")) != 0;
+  o.profile = profile_kernels ? 1 : 0;
   gr_lm_stats st{};
   std::vector<double> chi2(options->iterations + 1), lambda(options->iterations + 1);
   if (getenv("GR_VERBOSE")) std::cerr << "[graphite] bundle-adjustment graph (" << cd->count() << " cameras, " << pd->count() << " points, " << cache->n_factors
@@ -939,6 +946,16 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   if (gr_bal_levenberg_marquardt(prob, &o, &st, chi2.data(), lambda.data()) != GR_OK) return fail("gr_bal_levenberg_marquardt");
   const double lm_seconds = std::chrono::duration<double>(clk::now() - t_lm0).count();
   ++engine_handovers();
+  engine_last_loop_seconds() = st.loop_seconds; engine_last_iterations() = st.iterations_run;
+  if (profile_kernels) {
+    gr_kernel_stat ks[64];
+    int nk = 0;
+    if (gr_bal_kernel_stats(prob, ks, 64, &nk) == GR_OK)
+      for (int k = 0; k < std::min(nk, 64); ++k)
+        std::cout << "KERNEL " << ks[k].name << " launches " << ks[k].launches << " active " << ks[k].active_launches << " total_ms " << std::setprecision(9) << ks[k].total_ms
+                  << " bytes_per_launch " << ks[k].bytes_per_launch << " flops_per_launch " << ks[k].flops_per_launch << std::endl;
+    std::cout << "LM_LOOP_SECONDS " << st.loop_seconds << " ITERATIONS " << st.iterations_run << " PCG_ITERATIONS " << st.pcg_iterations << std::endl;
+  }
   lap("gr_bal_levenberg_marquardt");
   if (cache->model) cache->model->download_vertices();
   else {
@@ -1064,6 +1081,9 @@ inline size_t engine_cache_hit_count() { return detail::engine_cache_hits(); }
 inline size_t engine_model_handover_count() { return detail::engine_model_handovers(); }
 // host seconds the last hand-over spent around gr_bal_levenberg_marquardt (checks, export, probe, create or cache look-up, transfers)
 inline double engine_last_setup_seconds() { return detail::engine_last_setup_seconds(); }
+// seconds inside the engine's LM loop of the last hand-over, and the LM iterations it ran
+inline double engine_last_loop_seconds() { return detail::engine_last_loop_seconds(); }
+inline int engine_last_iterations() { return detail::engine_last_iterations(); }
 template <typename T, typename S> bool levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options) {
   return detail::lm_loop<false>(graph, options);
 }

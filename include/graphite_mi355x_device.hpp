@@ -197,6 +197,17 @@ template <typename T> __device__ __forceinline__ T damp_diag(T d, double mu, int
   return (T)((double)d + mu * clampd((double)d, 1.0e-6, 1.0e32));
 }
 
+// Column scale of a vertex entry in double, for the small per-vertex algebra (block inverses): graph.hpp:262-270 computes
+// 1 / (eps + sqrt(diag)) in double even when T = float; the stored scale s is that value rounded to T.  Where s IS that value
+// (scale_system on, vertex not fixed) the unrounded one is returned, so that the scaled block has an exactly unit diagonal and the
+// inversion — which amplifies entry errors by the block's condition number, 1e3-1e4 for weakly observed points — does not see the
+// fp32 rounding of the scale; otherwise (scaling off: 1, fixed vertex: 1) the stored value.
+template <typename T> __device__ __forceinline__ double scale_hat(T s, T hii) {
+  const double sh = 1.0 / (2.220446049250313e-16 + sqrt((double)hii));
+  const double sd = (double)s;
+  return fabs(sd - sh) <= 1e-6 * sh ? sh : sd;
+}
+
 // In-register inverse of a symmetric positive definite N x N block (column-major
 // in/out), Gauss-Jordan without pivoting, fully unrolled so that the block
 // stays in VGPRs.  The role of cublas<t>matinvBatched (schur.hpp:1101,

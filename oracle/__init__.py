@@ -209,6 +209,10 @@ class BalOracle:
         fd = None if fdata is None else np.ascontiguousarray(fdata, dtype=self.dt).reshape(-1)
         self._call("gro_bal_set_factor_tables", _p(pm), _p(lk), _p(ld), _p(fd))
 
+    def set_jacobian_storage(self, mode):
+        """Graph<T, S>'s Jacobian storage type S: 0 = T, 1 = bfloat16 (round to nearest even), 2 = float (types.hpp:8-43)"""
+        self._call("gro_bal_set_jacobian_storage", C.c_int({"T": 0, "bf16": 1, "f32": 2}.get(mode, mode)))
+
     def set_model(self, kind):
         """0 the BAL camera (analytic Jacobian), 1 BAL + k3 r^6 (data[:, 0]), 2 pinhole (6, 3) -> 2 (oracle/user_models.hpp)"""
         self._call("gro_bal_set_model", C.c_int(int(kind)))

@@ -169,6 +169,27 @@ template <typename T> struct BalOracle {
   std::vector<int> loss_kinds;         // [No]
   std::vector<T> loss_deltas;          // [No]
   int model_kind = MODEL_BAL;
+  // Jacobian STORAGE type S of Graph<T, S> (types.hpp:8-43, examples/bal.cu:338-345): 0 = T; 1 = bfloat16, 2 = float — every stored
+  // entry is rounded to S when the Jacobian kernel writes it (ops/linearize.hpp:43-79: the block is evaluated in T, stored as S) and
+  // again when scale_jacobians rewrites it (ops/linearize.hpp:142-180: J <- S(T(J) * scale)); everything downstream reads T(S)
+  int jac_storage = 0;
+  static T round_storage(T v, int mode) {
+    if (mode == 0) return v;
+    const float f = (float)v;
+    if (mode == 2) return (T)f;
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) u = (u | 0x400000u) & 0xffff0000u; // NaN stays NaN
+    else u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;                 // round to nearest even (cuda_bf16.h __float2bfloat16_rn)
+    float g;
+    std::memcpy(&g, &u, 4);
+    return (T)g;
+  }
+  void round_jacobians() {
+    if (!jac_storage) return;
+    for (auto &v : Jc) v = round_storage(v, jac_storage);
+    for (auto &v : Jp) v = round_storage(v, jac_storage);
+  }
   // a^T (rho' P) b as ops/hessian.hpp's jtpj + the dchi2 factor evaluate it; P = I keeps the closed form used before
   T wdot(size_t o, T a0, T a1, T b0, T b1) const {
     if (pmat.empty()) return (a0 * b0 + a1 * b1) * dchi2[o];
@@ -220,6 +241,7 @@ template <typename T> struct BalOracle {
         if (cam_fixed[cam_idx[o]]) std::fill(&Jc[18 * o], &Jc[18 * o] + 18, T(0));
         if (pt_fixed[pt_idx[o]]) std::fill(&Jp[6 * o], &Jp[6 * o] + 6, T(0));
       }
+    round_jacobians(); // stored as S
     chi2();
     if (scale_system) {
       std::fill(scales.begin(), scales.end(), T(0));
@@ -239,6 +261,7 @@ template <typename T> struct BalOracle {
         for (int c = 0; c < 9; ++c) { Jc[18 * o + 2 * c] *= sc[c]; Jc[18 * o + 2 * c + 1] *= sc[c]; }
         for (int c = 0; c < 3; ++c) { Jp[6 * o + 2 * c] *= sp[c]; Jp[6 * o + 2 * c + 1] *= sp[c]; }
       }
+      round_jacobians(); // rewritten as S
     } else {
       std::fill(scales.begin(), scales.end(), T(1));
     }

@@ -106,6 +106,7 @@ extern "C" {
     if (fdata) o->fdata.assign(fdata, fdata + 4 * o->No);                                           \
   }                                                                                                 \
   void gro_bal_set_model_##SFX(void *h, int kind) { static_cast<BalOracle<T> *>(h)->model_kind = kind; } \
+  void gro_bal_set_jacobian_storage_##SFX(void *h, int mode) { static_cast<BalOracle<T> *>(h)->jac_storage = mode; } \
   void gro_bal_set_scale_system_##SFX(void *h, int on) { static_cast<BalOracle<T> *>(h)->scale_system = on != 0; } \
   void gro_bal_set_fixed_##SFX(void *h, const uint8_t *cf, const uint8_t *pf) { static_cast<BalOracle<T> *>(h)->set_fixed(cf, pf); } \
   void gro_bal_set_pcg_single_reduction_##SFX(void *h, int on) { static_cast<BalOracle<T> *>(h)->pcg_single_reduction = on != 0; } \

@@ -209,14 +209,16 @@ static int run(int argc, char **argv, const std::string &mode) {
   std::cout << std::endl << "PT0 " << pts[0](0) << " " << pts[0](1) << " " << pts[0](2) << std::endl;
   std::cout << "ENGINE_HANDOVERS " << optimizer::engine_handover_count() << std::endl
             << "ENGINE_MODEL_HANDOVERS " << optimizer::engine_model_handover_count() << std::endl
-            << "TOTAL_SECONDS " << total << " SETUP_SECONDS " << optimizer::engine_last_setup_seconds() << std::endl
+            << "TOTAL_SECONDS " << total << " SETUP_SECONDS " << optimizer::engine_last_setup_seconds() << " LOOP_SECONDS " << optimizer::engine_last_loop_seconds()
+            << " ITERATIONS " << optimizer::engine_last_iterations() << std::endl
             << (ok ? "OK" : "STOPPED") << std::endl;
   if (argc > 7 && std::string(argv[7]) == "twice") { // second call on the unchanged structure: cached problem, loop time only
     options.verbose = false;
     const auto t1 = std::chrono::steady_clock::now();
     (void)optimizer::levenberg_marquardt<FP, SP>(&graph, &options);
     const double second = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-    std::cout << "SECOND_CALL_SECONDS " << second << " SETUP_SECONDS " << optimizer::engine_last_setup_seconds() << " CACHE_HITS " << optimizer::engine_cache_hit_count() << std::endl;
+    std::cout << "SECOND_CALL_SECONDS " << second << " SETUP_SECONDS " << optimizer::engine_last_setup_seconds() << " CACHE_HITS " << optimizer::engine_cache_hit_count()
+              << " LOOP_SECONDS " << optimizer::engine_last_loop_seconds() << " ITERATIONS " << optimizer::engine_last_iterations() << std::endl;
   }
   solver.reset();
   return 0;

@@ -222,7 +222,8 @@ template <template <typename, typename> class Factor> static int run(int argc, c
   std::cout << std::setprecision(17) << "FINAL_CHI2 " << graph.chi2() << std::endl;
   std::cout << "CAM0";
   for (int k = 0; k < 9; ++k) std::cout << " " << cams[0](k);
-  std::cout << std::endl << "ENGINE_HANDOVERS " << optimizer::engine_handover_count() << std::endl << (ok ? "OK" : "STOPPED") << std::endl;
+  std::cout << std::endl << "ENGINE_HANDOVERS " << optimizer::engine_handover_count() << std::endl
+            << "ENGINE_MODEL_HANDOVERS " << optimizer::engine_model_handover_count() << std::endl << (ok ? "OK" : "STOPPED") << std::endl;
   solver.reset();
   return 0;
 }

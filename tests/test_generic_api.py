@@ -163,18 +163,23 @@ def test_untagged_bal_traits_reach_the_engine(oracle_mod, tmp_path, jacobians):
 
 @pytest.mark.gpu
 def test_wrong_bal_tag_is_caught(tmp_path):
-    """A factor that carries `bal_reprojection_model` but computes another residual is NOT optimised as the engine's model:
-    the probe reports the mismatch and the generic kernels (which call the user's functions) run."""
+    """A factor that carries `bal_reprojection_model` but computes another residual is NOT optimised as the library's built-in
+    model: the probe reports the mismatch, and the engine's kernels are instantiated on the user's own functions instead
+    (engine_model.hpp) — the iterates are those of the generic kernels, which call the same functions."""
     exe = build_all()[2]
     prob = synth.make_config("mini-50")
     f = tmp_path / "problem.txt"
     synth.write_bal(f, prob)
     r = subprocess.run([exe, str(f), "pcg", "4", "wrong-tag"], capture_output=True, text=True, timeout=300, env=dict(os.environ, GR_VERBOSE="1"))
     print(r.stdout[-2000:], r.stderr[-800:])
-    assert r.returncode == 0 and "ENGINE_HANDOVERS 0" in r.stdout
-    assert "declare bal_reprojection_model, but error()/jacobian() differ" in r.stderr and "handed to the gr_bal engine" not in r.stderr
+    assert r.returncode == 0 and "ENGINE_HANDOVERS 1" in r.stdout and "ENGINE_MODEL_HANDOVERS 1" in r.stdout
+    assert "declare bal_reprojection_model, but error()/jacobian() differ" in r.stderr and "(built-in camera model)" not in r.stderr
+    assert "kernels instantiated on the user's traits" in r.stderr
     tr = parse_trace(r.stdout)
     assert tr[-1, 1] < tr[0, 0]  # the user's own function was optimised
+    g = subprocess.run([exe, str(f), "pcg", "4", "wrong-tag"], capture_output=True, text=True, timeout=300, env=dict(os.environ, GRAPHITE_GENERIC_ONLY="1"))
+    assert g.returncode == 0 and "ENGINE_HANDOVERS 0" in g.stdout
+    assert np.allclose(tr[:, 1], parse_trace(g.stdout)[:, 1], rtol=1e-9)
 
 
 @pytest.mark.gpu
@@ -235,14 +240,15 @@ def test_inactive_factors_and_unused_vertices_stay_on_the_engine(oracle_mod, tmp
 def test_traits_that_leave_the_model_only_at_theta_zero_are_refused(tmp_path):
     """a 256-factor sample of a real graph never visits the theta == 0 branch (projection_jacobians.cuh:175-212:
     zero rotation block).  The probe's synthetic triples do: a tagged factor that is the model everywhere else is reported and
-    stays on the generic kernels."""
+    does not run as the built-in model (the engine's kernels are instantiated on its own functions)."""
     exe = build_all()[2]
     prob = synth.make_config("mini-50")
     f = tmp_path / "problem.txt"
     synth.write_bal(f, prob)
     r = subprocess.run([exe, str(f), "pcg", "4", "theta0"], capture_output=True, text=True, timeout=300, env=dict(os.environ, GR_VERBOSE="1"))
     print(r.stdout[-2000:], r.stderr[-1500:])
-    assert r.returncode == 0 and "ENGINE_HANDOVERS 0" in r.stdout and "handed to the gr_bal engine" not in r.stderr
+    # not the built-in model (the probe's synthetic triples see it): the engine runs the user's own functions instead
+    assert r.returncode == 0 and "ENGINE_MODEL_HANDOVERS 1" in r.stdout and "(built-in camera model)" not in r.stderr
     assert "on the synthetic branch triples only" in r.stderr
     tr = parse_trace(r.stdout)
     assert tr[-1, 1] < tr[0, 0]

@@ -105,7 +105,7 @@ def test_venice1778_fp32_block_jacobi_pcg_lm_trace(oracle_mod, venice1778):
         oracle_mod, venice1778, np.float32, ga.SOLVER_PCG, oracle_mod.SOLVER_PCG, 3)
     assert st["accepted"] == st_r["accepted"]
     assert abs(st["pcg_iterations"] - st_r["pcg_iterations"]) <= 1
-    assert rel_trace(ct, ct_r) < 1e-4
+    assert rel_trace(ct, ct_r) < 2e-5  # round 5: was 1e-4
     assert np.abs(pg - pr).max() / np.abs(pr).max() < 1e-3
 
 

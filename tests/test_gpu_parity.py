@@ -69,9 +69,15 @@ def test_schur_complement(oracle_mod, name, dtype):
     cp_r, ri_r = ref.schur_structure()
     assert np.array_equal(cp_g, cp_r) and np.array_equal(ri_g, ri_r)  # index work: bit-exact
     t = tol_for(dtype, 1e-12 if name == "schur-2x3" else 1e-9, 5e-3)
-    assert relerr(gpu.get("Hll_inv"), ref.get("Hll_inv")) < t
-    assert relerr(gpu.get("S"), ref.get("S")) < t
-    assert relerr(gpu.get("b_schur"), ref.get("b_schur")) < t
+    # fp32 (round 5: the per-point chain scale -> block -> inverse -> M' runs in double from the stored sums): S and b_S at 1e-4
+    # (measured 1.9e-5 / 4.2e-5 against the fp64 oracle, where the fp32 oracle itself sits at 1.1e-5 / 4.1e-5).  Hll^-1 is the
+    # inverse of 3 x 3 blocks with condition numbers of 1e3-1e4: the fp32 ORACLE is 8.3e-4 from the fp64 one, the engine 6.6e-4
+    # (tools/fp32_stage_probe.py), so two fp32 computations cannot be asked to agree below ~2e-3
+    t_s = tol_for(dtype, 1e-12 if name == "schur-2x3" else 1e-9, 1e-4)
+    t_inv = tol_for(dtype, 1e-12 if name == "schur-2x3" else 1e-9, 2e-3)
+    assert relerr(gpu.get("Hll_inv"), ref.get("Hll_inv")) < t_inv
+    assert relerr(gpu.get("S"), ref.get("S")) < t_s
+    assert relerr(gpu.get("b_schur"), ref.get("b_schur")) < t_s
     xp = (0.01 * np.arange(1, 9 * gpu.Nc + 1)).astype(dtype)  # tests/schur.cu:211-214
     assert relerr(gpu.landmark_update(xp), ref.landmark_update(xp)) < t
     assert relerr(gpu.schur_matvec(xp), ref.schur_matvec(xp)) < t
@@ -104,7 +110,8 @@ def test_solver_solve(oracle_mod, name, dtype, solver):
         # as close to fp64 as the fp32 oracle's or closer (Hcc 2e-7 vs 8e-7), yet after ONE inner iteration the engine's step
         # sits 8e-4 from the fp64 step and the fp32 oracle's 3e-4 (Hll^-1 alone: 1.2e-3 vs 8e-4): two fp32 runs of the same
         # algorithm cannot agree better than either agrees with fp64.  1e-3 for the short solve (was 2e-3), 2e-3 for 25 iterations.
-        assert relerr(dx_g, dx_r) < tol_for(dtype, 1e-9, 1e-3 if max_iter <= 4 else 2e-3)
+        # round 5 (per-point block algebra and sums in double): 7e-4 for the short solve (measured <= 5.4e-4), 2e-3 for 25 iterations
+        assert relerr(dx_g, dx_r) < tol_for(dtype, 1e-9, 7e-4 if max_iter <= 4 else 2e-3)
     gpu.close()
 
 
@@ -112,9 +119,13 @@ def test_solver_solve(oracle_mod, name, dtype, solver):
 def test_fp32_step_is_as_close_to_fp64_as_the_fp32_oracle(oracle_mod, solver):
     """The fp32 step pinned from both sides: two fp32 runs of one algorithm that sum in different orders
     cannot agree better than either agrees with fp64 (block conditioning: Hll^-1 alone is 1e-3 from its fp64 value), so the
-    engine's fp32 step is held (a) to the FP64 oracle at 1e-3 and (b) to the fp32 ORACLE's own distance from fp64: at most
-    8 x that distance (measured: pcg_schur 8.7e-4 against the fp32 oracle's 2.4e-4, pcg 5.9e-4 against 1.1e-4) — fp32 hand-written kernels that lost digits the plain
-    fp32 restatement keeps would fail (b) long before (a)."""
+    engine's fp32 step is held (a) to the FP64 oracle at 5e-4 and (b) to the fp32 ORACLE's own distance from fp64: at most
+    2 x that distance for the Schur PCG (measured 3.7e-4 against the fp32 oracle's 2.4e-4 = 1.5 x; round 4: 3.6 x) and 3.5 x for the
+    matrix-free PCG (3.0e-4 against 1.05e-4 = 2.8 x; round 4: 5.6 x).  Found with tools/fp32_first_iteration_probe.py: all of the
+    loss sat in the POINT part of the step — the 3 x 3 point blocks (condition 1e3-1e4) were scaled, damped and inverted from
+    entries that had been rounded to fp32 three times; the chain now runs in double from the stored sums (scale_hat, k_finalize_bj,
+    k_point_prepare) and the per-point sums of the update kernel are taken in double.  After ONE iteration the engine is 1.4 x
+    the fp32 oracle's distance; what is left after four is the fp32 operator itself (J recomputed per product)."""
     prob = synth.make_config("mini-50")
     gs = dict(pcg_schur=ga.SOLVER_PCG_SCHUR, pcg=ga.SOLVER_PCG)[solver]
     os_ = dict(pcg_schur=oracle_mod.SOLVER_PCG_SCHUR, pcg=oracle_mod.SOLVER_PCG)[solver]
@@ -133,8 +144,8 @@ def test_fp32_step_is_as_close_to_fp64_as_the_fp32_oracle(oracle_mod, solver):
         dx[dt], it_r = ref.solver_solve(os_, max_iter=4, tol=0.0, rej=1e6)
         assert it_r == it_g
     e_gpu, e_ref = relerr(dx_g, dx[np.float64]), relerr(dx[np.float32], dx[np.float64])
-    assert e_gpu < 1e-3, (e_gpu, e_ref)
-    assert e_gpu < 8.0 * e_ref + 1e-5, (e_gpu, e_ref)
+    assert e_gpu < 5e-4, (e_gpu, e_ref)
+    assert e_gpu < (2.0 if solver == "pcg_schur" else 3.5) * e_ref + 1e-5, (e_gpu, e_ref)
     gpu.close()
 
 

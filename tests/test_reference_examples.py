@@ -91,6 +91,37 @@ def test_reference_bal_driver_matches_oracle(oracle_mod, tmp_path, solver, osolv
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision,storage,bar", [("FP64-BF16", "bf16", 1e-6), ("FP64-FP32", "f32", 1e-8)])
+def test_reference_bal_driver_low_precision_storage_matches_the_oracle(oracle_mod, tmp_path, precision, storage, bar):
+    """Graph<double, __nv_bfloat16> / Graph<double, float> (types.hpp:8-43, examples/bal.cu:338-345) against an ORACLE that stores its
+    Jacobians the same way (oracle/bal_pipeline.hpp jac_storage: every entry rounded to S when written and again when
+    scale_jacobians rewrites it, round to nearest even): the LM chi2 trace of the reference's unmodified bal.cu on the generic
+    kernels, not a comparison of the product with itself.  FP64-BF16 stays on the generic kernels (the engine stores fp32 / fp64)."""
+    exe = _need("bal")
+    prob = synth.make_config("mini-50")
+    path = str(tmp_path / "mini50.txt")
+    synth.write_bal(path, prob)
+    prob = synth.read_bal(path)
+    its = 8
+    env = dict(os.environ, GRAPHITE_GENERIC_ONLY="1")  # FP64-FP32 would otherwise be handed to the engine: this test is about the generic kernels' S storage
+    out = subprocess.run([exe, path, "--solver", "pcg", "--iterations", str(its), "--precision", precision, "--verbose"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rows = [ln.split() for ln in out.stdout.splitlines()]
+    rows = [r for r in rows if len(r) == 6 and r[0].isdigit()]
+    got = np.array([float(rows[0][1])] + [float(r[2]) for r in rows])
+    ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    ref.set_jacobian_storage(storage)
+    ct, _, _ = ref.levenberg_marquardt(solver=oracle_mod.SOLVER_PCG, iterations=its)
+    assert len(got) == len(ct)
+    assert np.allclose(got, ct, rtol=bar), np.abs(got - ct) / ct
+    # ... and the storage type is live: the same run with fp64 storage differs from the bf16 trace by far more than the bar
+    if storage == "bf16":
+        ref64 = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+        c64, _, _ = ref64.levenberg_marquardt(solver=oracle_mod.SOLVER_PCG, iterations=its)
+        assert abs(c64[-1] - ct[-1]) / ct[-1] > 10 * bar
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["FP64-FP32", "FP32-FP32", "FP64-BF16"])
 def test_reference_bal_driver_precisions(tmp_path, precision):
     """--precision pairs of bal.cu:338-345 (graph T, Jacobian storage S), PCG: converges to the fp64 optimum within
