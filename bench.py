@@ -484,6 +484,28 @@ def main():
     _, _, st_prof = gpu.levenberg_marquardt(iterations=args.steps, profile=True, **lm_kw)
     barrier()
     ks = gpu.kernel_stats()
+    # ---- audit record of a sharded run: what every rank's communicator really is after the start-up self-test,
+    # and per-phase times as the MAX over ranks per phase (a sharded iteration costs the slowest rank of each phase, not of the sum)
+    shard_audit = None
+    if sharded:
+        ci = gpu.comm_info()
+        lin_names = ("linearize", "linearize_hcp", "linearize_finalize", "finalize_bj", "chi2")
+        phase = {"linearise_ms": sum(v["total_ms"] for k, v in ks.items() if k in lin_names),
+                 "inner_iterations_ms": sum(v["total_ms"] for k, v in ks.items() if k not in lin_names)}
+        infos = [None] * world
+        dist.all_gather_object(infos, {"rank": rank, "device": ci["device"], "transport": ci["transport_name"], "rccl_ranks": ci["rccl_ranks"],
+                                       "mailboxes_opened": ci["mailboxes_opened"], "fused_agreed": ci["fused_agreed"],
+                                       "oneshot_messages": ci["oneshot_messages"], "fallback_messages": ci["fallback_messages"], **phase,
+                                       "observations": int(len(part.cam_idx)), "points": int(len(part.points))})
+        shard_audit = {"ranks_seen": {"process_group": world, "rccl_comm_count": [i["rccl_ranks"] for i in infos],
+                                      "mailboxes_opened_per_rank": [i["mailboxes_opened"] for i in infos]},
+                       "devices": [i["device"] for i in infos], "transport_per_rank": [i["transport"] for i in infos],
+                       "fused_inner_iteration_message": [i["fused_agreed"] for i in infos],
+                       "oneshot_messages_per_rank": [i["oneshot_messages"] for i in infos], "fallback_messages_per_rank": [i["fallback_messages"] for i in infos],
+                       "per_phase_max_over_ranks_ms": {"linearise": max(i["linearise_ms"] for i in infos), "inner_iterations": max(i["inner_iterations_ms"] for i in infos),
+                                                        "note": f"device time of the phase's kernels over the profiled pass of {args.steps} LM iterations, slowest rank PER PHASE"},
+                       "per_rank_ms": [{"rank": i["rank"], "linearise": round(i["linearise_ms"], 3), "inner_iterations": round(i["inner_iterations_ms"], 3),
+                                        "observations": i["observations"], "points": i["points"]} for i in infos]}
     if main_run["st"]["solve_seconds"] <= 0:
         # host-driven LM forms (Schur solvers, landmark shards) time the solve with HIP events only when profiling is on (an
         # event between two launches is a ~6 us bubble): solve_seconds then comes from this profiled pass, not from `value`'s
@@ -737,7 +759,7 @@ def main():
         "solve_seconds": round(st["solve_seconds"], 6), "loop_seconds": round(st["loop_seconds"], 6),
         "setup_seconds": round(st["setup_seconds"], 6), "create_seconds": round(create_seconds, 4),
         "setup_note": "create_seconds: gr_bal_create (orderings, upload); setup_seconds: solver structure + first linearisation inside levenberg_marquardt; both outside `value`",
-        "transport": transport["kind"],
+        "transport": transport["kind"], "shard_audit": shard_audit,
         "collectives_per_lm_iteration": round(st.get("collectives", 0) / max(steps_run, 1), 2) if sharded else 0,
         "parity_rel": parity_rel, "parity_steps": parity_steps,
         "parity_note": "max relative difference of the timed run's chi2 trace against the CPU oracle's trace of the same solver",

@@ -28,7 +28,8 @@ EXPORTS = [
     "gr_bal_landmark_update", "gr_bal_schur_structure", "gr_bal_get", "gr_bal_hessian_structure", "gr_bal_export_csc",
     "gr_bal_levenberg_marquardt", "gr_bal_kernel_stats", "gr_comm_unique_id", "gr_bal_comm_init", "gr_bal_comm_ipc_mailbox", "gr_bal_comm_set_contributors", "gr_bal_comm_init_ipc", "gr_bal_set_fixed",
     "gr_dense_cholesky_solve", "gr_bal_model_evaluate", "gr_bal_tuning_default", "gr_bal_set_tuning", "gr_bal_get_tuning",
-    "gr_bal_direct_solver_info", "gr_bal_lm_iteration_seconds",
+    "gr_bal_direct_solver_info", "gr_bal_lm_iteration_seconds", "gr_bal_comm_info",
+    "gr_bal_create_model", "gr_bal_model_orders",  # include/graphite_mi355x_model.h: the engine on user traits
 ]
 # include/graphite_mi355x_test.h (test / diagnostic entry points, not part of the drop-in boundary)
 TEST_EXPORTS = ["gr_bal_comm_init_local", "gr_bal_diag_time", "gr_bal_comm_allreduce_host", "gr_test_lane_xor"]
@@ -38,6 +39,12 @@ class GraphiteError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"{STATUS_NAMES.get(status, status)}: {msg}")
         self.status = status
+
+
+class CommInfo(C.Structure):
+    """gr_comm_info (include/graphite_mi355x.h)"""
+    _fields_ = [(k, C.c_int32) for k in ("rank", "size", "transport", "rccl_ranks", "mailboxes_opened", "device", "fused_agreed", "reserved")] + \
+               [("oneshot_messages", C.c_int64), ("fallback_messages", C.c_int64)]
 
 
 class LMOptions(C.Structure):

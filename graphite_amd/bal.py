@@ -216,6 +216,14 @@ class BalProblem:
         check(self.lib.gr_bal_direct_solver_info(self.h, C.byref(info)))
         return {f: getattr(info, f) for f, _ in DirectSolverInfo._fields_}
 
+    def comm_info(self):
+        """gr_bal_comm_info: the communicator this problem uses after the start-up self-test (audit record of a sharded run)"""
+        info = _lib.CommInfo()
+        check(self.lib.gr_bal_comm_info(self.h, C.byref(info)))
+        d = {k: getattr(info, k) for k, _ in _lib.CommInfo._fields_ if k != "reserved"}
+        d["transport_name"] = {0: "none", 1: "rccl", 2: "ipc-mailbox", 3: "in-process test group"}.get(d["transport"], "?")
+        return d
+
     def kernel_stats(self):
         arr = (KernelStat * 64)()
         n = C.c_int()

@@ -33,6 +33,11 @@ struct Comm {
   // a transport that can lose a message without hanging reports it here (host check after a stream synchronisation)
   virtual bool failed() { return false; }
   virtual void set_timeout_ms(int) {}
+  // what a SCALE record is audited with (gr_bal_comm_info): 1 RCCL, 2 IPC mailboxes, 3 in-process test group
+  virtual int transport() const { return 0; }
+  virtual int rccl_ranks() { return 0; }          // ncclCommCount of the RCCL communicator in use (0: none)
+  virtual int mailboxes_opened() const { return 0; } // peer mailboxes mapped through hipIpcOpenMemHandle
+  virtual void message_counts(int64_t &oneshot, int64_t &fallback_) const { oneshot = 0; fallback_ = 0; }
 };
 
 // ---- RCCL ------------------------------------------------------------------------------
@@ -43,6 +48,7 @@ struct RcclApi {
   int (*CommInitRank)(void **, int, UID, int) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
+  int (*CommCount)(void *, int *) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
@@ -59,6 +65,7 @@ struct RcclApi {
       api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
       api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
       api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+      api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
       api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.lib, "ncclGroupStart"));
       api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.lib, "ncclGroupEnd"));
       api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
@@ -91,6 +98,13 @@ struct RcclComm final : Comm {
   }
   void group_start() override { RcclApi::get().check(RcclApi::get().GroupStart(), "ncclGroupStart"); }
   void group_end() override { RcclApi::get().check(RcclApi::get().GroupEnd(), "ncclGroupEnd"); }
+  int transport() const override { return 1; }
+  int rccl_ranks() override {
+    int n = 0;
+    RcclApi &api = RcclApi::get();
+    if (!api.CommCount || api.CommCount(comm, &n) != 0) return -1;
+    return n;
+  }
 };
 
 // ---- one-shot peer all-reduce over IPC-mapped mailboxes ----------------------------------------------
@@ -335,6 +349,10 @@ struct IpcComm final : Comm {
     if (__atomic_load_n(h_err, __ATOMIC_ACQUIRE) != 0) dead = true;
     return dead;
   }
+  int transport() const override { return 2; }
+  int rccl_ranks() override { return fallback ? fallback->rccl_ranks() : 0; }
+  int mailboxes_opened() const override { int n = 0; for (int r = 0; r < size; ++r) n += opened[r] ? 1 : 0; return n; }
+  void message_counts(int64_t &oneshot, int64_t &fallback_) const override { oneshot = n_oneshot; fallback_ = n_fallback; }
 };
 
 // ---- in-process test backend -------------------------------------------------------------
@@ -371,6 +389,7 @@ struct LocalGroup {
 struct LocalComm final : Comm {
   std::shared_ptr<LocalGroup> g;
   LocalComm(std::shared_ptr<LocalGroup> grp, int rank_) : g(std::move(grp)) { rank = rank_; size = g->size; }
+  int transport() const override { return 3; }
   void allreduce(void *buf, size_t count, bool is_double, hipStream_t stream) override {
     GR_HIP(hipStreamSynchronize(stream)); // my producers are done
     {

@@ -113,6 +113,7 @@ struct EngineBase {
   virtual void allreduce_host(double *v, size_t n) = 0;
   virtual void apply_tuning() = 0; // after `tune` changed
   virtual void orders(int32_t *obs_order, int32_t *landmark_order) = 0;
+  virtual void comm_info(gr_comm_info &o) = 0;
   gr_bal_tuning tune;
   std::vector<double> lm_iter_seconds; // last lm(): host time from the start of the loop at which iteration i's decision was observed
   EngineBase() { tuning_default(tune); }
@@ -931,6 +932,14 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   // ---- Graph --------------------------------------------------------------------
+  void comm_info(gr_comm_info &o) override {
+    std::memset(&o, 0, sizeof(o));
+    o.device = device;
+    if (!comm) return;
+    o.rank = comm->rank; o.size = comm->size; o.transport = comm->transport(); o.rccl_ranks = comm->rccl_ranks();
+    o.mailboxes_opened = comm->mailboxes_opened(); o.fused_agreed = fused_agreed ? 1 : 0;
+    comm->message_counts(o.oneshot_messages, o.fallback_messages);
+  }
   // gr_bal_model_orders: input index of the observation at camera-major position j; caller's index of engine landmark q
   void orders(int32_t *obs_order, int32_t *landmark_order) override {
     if (obs_order) {
@@ -2983,6 +2992,10 @@ gr_status gr_bal_comm_init(gr_bal_problem *p, const void *unique_id_128, int ran
     return GR_OK;
   } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
+}
+gr_status gr_bal_comm_info(gr_bal_problem *p, gr_comm_info *info) {
+  if (!info) { g_last_error = "gr_bal_comm_info: null info"; return GR_ERR_INVALID; }
+  return guarded(p, [&] { p->e->comm_info(*info); });
 }
 gr_status gr_bal_comm_set_contributors(gr_bal_problem *p, const uint32_t *mask, int64_t count) {
   if (!p || !p->e || !mask) { g_last_error = "gr_bal_comm_set_contributors: bad argument"; return GR_ERR_INVALID; }

@@ -330,6 +330,21 @@ gr_status gr_bal_comm_init_ipc(gr_bal_problem *p, const void *handles_world_x_64
  * contributors' slots.  This call overrides them; it exists for tools/shard_projection.py, where ONE rank plays all the ranks of a
  * message (gr_bal_tuning.shard_virtual_ranks) and must be told the masks of the real partition.  count = number of cameras. */
 gr_status gr_bal_comm_set_contributors(gr_bal_problem *p, const uint32_t *mask, int64_t count);
+/* What the first real multi-GPU run is audited with: which communicator this problem ended up with AFTER the start-up self-test
+ * of gr_bal_comm_init_ipc (a failed mailbox verification drops every rank to RCCL), how many ranks RCCL itself sees
+ * (ncclCommCount), how many peer mailboxes were mapped, and whether the ranks agreed on the fused inner-iteration message. */
+typedef struct {
+  int32_t rank, size;         /* of the communicator in use; size 0 = none                                                     */
+  int32_t transport;          /* 0 none | 1 RCCL | 2 IPC mailboxes (RCCL behind them for large messages when rccl_ranks > 0) | 3 in-process test group */
+  int32_t rccl_ranks;         /* ncclCommCount of the RCCL communicator (0: none, -1: the call failed)                         */
+  int32_t mailboxes_opened;   /* peer mailboxes mapped through hipIpcOpenMemHandle: size - 1 when every peer is reachable      */
+  int32_t device;             /* HIP ordinal of this rank                                                                      */
+  int32_t fused_agreed;       /* the ranks agreed on the fused inner-iteration message (gr_bal_tuning.shard_fused)             */
+  int32_t reserved;
+  int64_t oneshot_messages;   /* mailbox all-reduces since the communicator was created                                        */
+  int64_t fallback_messages;  /* ... of the collectives, those that went through the fallback (messages beyond a slot)         */
+} gr_comm_info;
+gr_status gr_bal_comm_info(gr_bal_problem *p, gr_comm_info *info);
 /* Dense SPD solve A x = b on the MFMA Cholesky that GR_SOLVER_DENSE_SCHUR uses (the numerical role of
  * Eigen::SimplicialLDLT in src/eigen_solver.cpp:8-30 / cuDSS in solver/cudss.hpp:183-256 once S is dense).
  * A: n x n row-major, leading dimension lda, lower triangle read; A, b, x host or device pointers (x may

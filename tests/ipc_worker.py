@@ -79,6 +79,16 @@ def main():
                                      "pcg_iterations": int(st["pcg_iterations"]), "collectives": int(st["collectives"]),
                                      "kernel_launches": int(st["kernel_launches"]),
                                      "cams": np.asarray(cams, np.float64).tolist(), "pts": np.asarray(pts, np.float64).tolist()}
+        if tag == "f64":
+            # set_tuning between two sharded LM calls, with the ranks on DIFFERENT sides of a timed choice — rank 0 re-times
+            # the point-record layout (two runs of eight operator launches inside solver_update_structure), the others have it forced
+            # and time nothing.  Timing launches must be rank-local (never the fused message); the solve that follows must fuse again
+            # and reproduce the first call.
+            g.set_tuning(shard_fused=-1, point_records=(-1 if rank == 0 else 0))
+            g.set_params(shard.cameras, shard.points)
+            ct, lt, st = g.levenberg_marquardt(solver=ga.SOLVER_PCG, iterations=8)
+            res["f64_pcg_retuned"] = {"chi2": [float(x) for x in ct], "pcg_iterations": int(st["pcg_iterations"]), "collectives": int(st["collectives"]),
+                                      "fused_messages": int(st["fused_messages"]), "comm": g.comm_info()}
         dist.barrier()
         g.close()
     with open(out, "w") as f:

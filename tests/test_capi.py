@@ -13,9 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    text = open(os.path.join(ROOT, "include", "graphite_mi355x.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(gr_[a-z0-9_]+)\s*\(", text)))
+    # the drop-in boundary: graphite_mi355x.h + its extension for user-traits problems, graphite_mi355x_model.h
+    syms = set()
+    for h in ("graphite_mi355x.h", "graphite_mi355x_model.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"^\s*(?:gr_status|const char \*|int|void)\s*(gr_[a-z0-9_]+)\s*\(", text, flags=re.M))
+    return sorted(syms)
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -41,10 +45,11 @@ def test_header_is_plain_c(tmp_path):
 
 def test_struct_layouts_match_ctypes(tmp_path):
     src = tmp_path / "s.c"
-    src.write_text('#include <stdio.h>\n#include "graphite_mi355x.h"\nint main(void){printf("%zu %zu %zu\\n", sizeof(gr_lm_options), sizeof(gr_lm_stats), sizeof(gr_kernel_stat));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "graphite_mi355x_model.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(gr_lm_options), sizeof(gr_lm_stats), sizeof(gr_kernel_stat), sizeof(gr_bal_tuning), sizeof(gr_comm_info));return 0;}\n')
     assert os.system(f"gcc -I{ROOT}/include {src} -o {tmp_path}/s") == 0
     sizes = [int(x) for x in os.popen(f"{tmp_path}/s").read().split()]
-    assert sizes == [C.sizeof(_lib.LMOptions), C.sizeof(_lib.LMStats), C.sizeof(_lib.KernelStat)]
+    assert sizes == [C.sizeof(_lib.LMOptions), C.sizeof(_lib.LMStats), C.sizeof(_lib.KernelStat), C.sizeof(_lib.Tuning), C.sizeof(_lib.CommInfo)]
+    assert sizes[3] == 100  # gr_version 0.2: new tuning fields take `reserved` slots
 
 
 def test_no_cpu_fallback():

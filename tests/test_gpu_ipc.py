@@ -96,6 +96,14 @@ def test_ipc_allreduce_between_processes(world, tmp_path):
         saved = un["kernel_launches"] - fu["kernel_launches"]
         assert saved >= 2 * fu["pcg_iterations"] + 8, (un["kernel_launches"], fu["kernel_launches"], fu["pcg_iterations"])
         assert np.allclose(fu["chi2"], un["chi2"], rtol=1e-10)
+        # a set_tuning between two sharded LM calls that makes only SOME ranks re-time a choice — the timing
+        # launches stay rank-local, the ranks agree on the fused message again, and the solve is the first call's
+        rt_ = res[r]["f64_pcg_retuned"]
+        assert rt_["pcg_iterations"] == fu["pcg_iterations"] and rt_["collectives"] == fu["collectives"] and rt_["fused_messages"] > 0
+        assert np.allclose(rt_["chi2"], fu["chi2"], rtol=1e-10)
+        # gr_bal_comm_info: what a SCALE record is audited with
+        assert rt_["comm"]["size"] == world and rt_["comm"]["transport_name"] == "ipc-mailbox" and rt_["comm"]["mailboxes_opened"] == world - 1
+        assert rt_["comm"]["fused_agreed"] == 1 and rt_["comm"]["oneshot_messages"] > 0
 
 
 def test_late_rank_within_the_wait_bound(tmp_path):
