@@ -150,6 +150,25 @@ def test_user_traits_engine_in_fp32_and_mixed_precision(oracle_mod, tmp_path, pr
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["pcg", "pcg-schur"])
+@pytest.mark.parametrize("mode", ["weighted", "pinhole"])
+def test_fixed_vertices_inactive_factors_and_unused_vertices_stay_on_the_user_traits_engine(tmp_path, mode, solver):
+    """set_fixed / set_active / a landmark that lost all its factors (vertex.hpp:262-264, factor.hpp:419-431, active.hpp:18-21): the
+    engine problem holds the ACTIVE factors and the USED vertices only — the user-traits kernels' streams and vertex copies follow
+    that compaction and the engine's landmark order; the iterates are those of the generic kernels on the same graph"""
+    f, _ = make_file(tmp_path, mode)
+    out = run_exe(f, solver, 6, mode, extra=("masked",))
+    d = fields(out)
+    assert d["ENGINE_HANDOVERS"] == ["1"] and d["ENGINE_MODEL_HANDOVERS"] == ["1"]
+    gen = run_exe(f, solver, 6, mode, env={"GRAPHITE_GENERIC_ONLY": "1"}, extra=("masked",))
+    assert fields(gen)["ENGINE_HANDOVERS"] == ["0"]
+    tr, tg = parse_trace(out), parse_trace(gen)
+    assert len(tr) == len(tg) and np.allclose(tr[:, 1], tg[:, 1], rtol=1e-9)
+    assert np.allclose([float(x) for x in d["CAM0"]], [float(x) for x in fields(gen)["CAM0"]], rtol=0, atol=0)  # the fixed pose did not move
+    assert np.allclose([float(x) for x in d["PT0"]], [float(x) for x in fields(gen)["PT0"]], rtol=1e-7)
+
+
+@pytest.mark.gpu
 def test_second_call_finds_the_user_traits_problem_cached(tmp_path):
     f, _ = make_file(tmp_path, "weighted")
     out = run_exe(f, "pcg", 4, "weighted", extra=("twice",))
