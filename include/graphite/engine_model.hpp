@@ -332,15 +332,20 @@ __global__ void __launch_bounds__(256) k_em_step(gr_model_step_args a, slot_vert
   __shared__ double red[4];
   const T *dx = static_cast<const T *>(a.dx), *sc = static_cast<const T *>(a.scales), *bu = static_cast<const T *>(a.bu);
   double rho = 0;
+  // (a fixed vertex keeps its value: no update — but its state IS saved, the revert restores every vertex)
   if ((int)blockIdx.x < nbc) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < Nc && !(a.cam_fixed && a.cam_fixed[i]))
-      rho = em_step_one<slot_traits<F, 0>, T, 9>(camv[i], cam_bak + i, a.with_backup != 0, dx + 9 * (size_t)i, sc + 9 * (size_t)i, bu + 9 * (size_t)i, a.mu, a.cam_weight != 0);
+    if (i < Nc) {
+      if (a.cam_fixed && a.cam_fixed[i]) { if (a.with_backup) { if constexpr (state_of<slot_traits<F, 0>>::custom) cam_bak[i] = slot_traits<F, 0>::get_state(camv[i]); else cam_bak[i] = camv[i]; } }
+      else rho = em_step_one<slot_traits<F, 0>, T, 9>(camv[i], cam_bak + i, a.with_backup != 0, dx + 9 * (size_t)i, sc + 9 * (size_t)i, bu + 9 * (size_t)i, a.mu, a.cam_weight != 0);
+    }
   } else {
     const int i = (blockIdx.x - nbc) * 256 + threadIdx.x;
     const size_t o = 9 * (size_t)Nc + 3 * (size_t)i;
-    if (i < Np && !(a.pt_fixed && a.pt_fixed[i]))
-      rho = em_step_one<slot_traits<F, 1>, T, 3>(ptv[i], pt_bak + i, a.with_backup != 0, dx + o, sc + o, bu + o, a.mu, true);
+    if (i < Np) {
+      if (a.pt_fixed && a.pt_fixed[i]) { if (a.with_backup) { if constexpr (state_of<slot_traits<F, 1>>::custom) pt_bak[i] = slot_traits<F, 1>::get_state(ptv[i]); else pt_bak[i] = ptv[i]; } }
+      else rho = em_step_one<slot_traits<F, 1>, T, 3>(ptv[i], pt_bak + i, a.with_backup != 0, dx + o, sc + o, bu + o, a.mu, true);
+    }
   }
   rho = gr::block_sum_256(rho, red);
   if (threadIdx.x == 0 && a.rho_partial) a.rho_partial[blockIdx.x] = rho;

@@ -125,7 +125,96 @@ template <typename T, typename S> struct PinholeTraits {
 };
 template <typename T, typename S> using PinholeFactor = FactorDescriptor<T, S, PinholeTraits<T, S>>;
 
+// ---- slam2d: (3, 2) -> 2 range-bearing and (3, 2) -> 1 range-only sightings of 2-D landmarks from SE(2) poses -------------------
+// (the zero-padded layout at its smallest: pose block 3 of 9, landmark block 2 of 3, error 1 of 2)
+template <typename T, typename S, int EDIM> struct SightingTraits {
+  static constexpr size_t dimension = EDIM;
+  using VertexDescriptors = std::tuple<VecDescriptor<T, S, 3>, VecDescriptor<T, S, 2>>;
+  using Observation = Vec<T, EDIM>;
+  using Data = Empty;
+  using Loss = HuberLoss<T, EDIM>;
+  using Differentiation = DifferentiationMode::Auto;
+  template <typename D> d_fn static void error(const D *pose, const D *lm, const Observation &obs, D *error) {
+    const D dx = lm[0] - pose[0], dy = lm[1] - pose[1];
+    error[0] = sqrt(dx * dx + dy * dy) - D(obs(0));
+    if constexpr (EDIM == 2) error[1] = atan2(dy, dx) - pose[2] - D(obs(1));
+  }
+};
+template <typename T, typename S> using RangeBearingFactor = FactorDescriptor<T, S, SightingTraits<T, S, 2>>;
+template <typename T, typename S> using RangeFactor = FactorDescriptor<T, S, SightingTraits<T, S, 1>>;
+
 } // namespace graphite
+
+// 2-D SLAM toy: poses on a circle, landmarks in a square, every pose sights the landmarks within reach; pose 0 is fixed (gauge)
+template <typename FP, typename SP, template <typename, typename> class Factor, int EDIM>
+static int run_slam2d(int argc, char **argv) {
+  using namespace graphite;
+  (void)hipSetDevice(0);
+  const size_t NP = 60, NL = 400;
+  uint64_t state = 0x2545F4914F6CDD1Dull;
+  auto uni = [&]() { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return (double)(state >> 11) / 9007199254740992.0; };
+  std::vector<std::array<double, 3>> pose_true(NP);
+  std::vector<std::array<double, 2>> lm_true(NL);
+  for (size_t i = 0; i < NP; ++i) { const double a = 2.0 * M_PI * i / NP; pose_true[i] = {10.0 * std::cos(a), 10.0 * std::sin(a), a + M_PI / 2 - 2.0 * M_PI * (a + M_PI / 2 > M_PI ? 1 : 0)}; }
+  for (size_t l = 0; l < NL; ++l) lm_true[l] = {24.0 * uni() - 12.0, 24.0 * uni() - 12.0};
+  managed_vector<Vec<FP, 3>> poses(NP);
+  managed_vector<Vec<FP, 2>> lms(NL);
+  for (size_t i = 0; i < NP; ++i) for (int k = 0; k < 3; ++k) poses[i](k) = (FP)(pose_true[i][k] + (i == 0 ? 0.0 : 0.05 * (uni() - 0.5)));
+  for (size_t l = 0; l < NL; ++l) for (int k = 0; k < 2; ++k) lms[l](k) = (FP)(lm_true[l][k] + 0.2 * (uni() - 0.5));
+  Graph<FP, SP> graph;
+  VecDescriptor<FP, SP, 3> pose_desc;
+  VecDescriptor<FP, SP, 2> lm_desc;
+  pose_desc.reserve(NP); lm_desc.reserve(NL);
+  graph.add_descriptor(&pose_desc);
+  graph.add_descriptor(&lm_desc);
+  for (size_t i = 0; i < NP; ++i) pose_desc.add_vertex(i, &poses[i], i == 0);
+  for (size_t l = 0; l < NL; ++l) lm_desc.add_vertex(NP + l, &lms[l]);
+  lm_desc.set_eliminate(true);
+  Factor<FP, SP> f_desc(&pose_desc, &lm_desc);
+  graph.add_descriptor(&f_desc);
+  size_t nf = 0;
+  for (size_t i = 0; i < NP; ++i)
+    for (size_t l = 0; l < NL; ++l) {
+      const double dx = lm_true[l][0] - pose_true[i][0], dy = lm_true[l][1] - pose_true[i][1], r = std::sqrt(dx * dx + dy * dy);
+      if (r > 7.0 || r < 0.5) continue;
+      Vec<FP, EDIM> ob;
+      ob(0) = (FP)(r + 0.02 * (uni() - 0.5));
+      if constexpr (EDIM == 2) {
+        // (the error function does not wrap angles: only sightings whose global bearing and whose bearing relative to the pose both stay
+        // well inside (-pi, pi) are kept, so that no estimate near the truth crosses the branch cut of atan2)
+        const double g = std::atan2(dy, dx), b = g - pose_true[i][2];
+        if (std::abs(g) > 2.6 || std::abs(b) > 2.6) continue;
+        ob(1) = (FP)(b + 0.005 * (uni() - 0.5));
+      }
+      SP P[EDIM * EDIM];
+      for (int a = 0; a < EDIM; ++a) for (int c = 0; c < EDIM; ++c) P[a * EDIM + c] = a == c ? (a == 0 ? SP(4) : SP(100)) : SP(0); // information: range 0.5, bearing 0.1
+      f_desc.add_factor({i, NP + l}, ob, P, Empty(), typename Factor<FP, SP>::LossType((FP)(3.0 + (nf % 3))));
+      ++nf;
+    }
+  const std::string kind = argv[2];
+  BlockJacobiPreconditioner<FP, SP> bj;
+  BlockJacobiSchurPreconditioner<FP, SP> bjs;
+  std::unique_ptr<Solver<FP, SP>> solver;
+  if (kind == "pcg") solver.reset(new PCGSolver<FP, SP>(10, 1e-6, 5.0, &bj));
+  else if (kind == "pcg-schur") solver.reset(new PCGSchurSolver<FP, SP>(10, 1e-6, 5.0, &bjs));
+  else if (kind == "eigen-schur") solver.reset(new EigenSchurLDLTSolver<FP, SP>());
+  else return 2;
+  StreamPool streams(2);
+  optimizer::LevenbergMarquardtOptions<FP, SP> options;
+  options.solver = solver.get();
+  options.initial_damping = 1e-4;
+  options.iterations = std::stoul(argv[3]);
+  options.verbose = true;
+  options.streams = &streams;
+  const bool ok = optimizer::levenberg_marquardt<FP, SP>(&graph, &options);
+  std::cout << std::setprecision(17) << "FINAL_CHI2 " << graph.chi2() << std::endl << "FACTORS " << nf << std::endl;
+  std::cout << "CAM0 " << poses[0](0) << " " << poses[0](1) << " " << poses[0](2) << std::endl << "PT0 " << lms[0](0) << " " << lms[0](1) << " 0" << std::endl;
+  std::cout << "POSE1 " << poses[1](0) << " " << poses[1](1) << " " << poses[1](2) << std::endl;
+  std::cout << "ENGINE_HANDOVERS " << optimizer::engine_handover_count() << std::endl
+            << "ENGINE_MODEL_HANDOVERS " << optimizer::engine_model_handover_count() << std::endl << (ok ? "OK" : "STOPPED") << std::endl;
+  solver.reset();
+  return 0;
+}
 
 // per-factor weights, the same closed forms tests/test_engine_model.py evaluates
 static void information(size_t f, double (&P)[4]) {
@@ -243,6 +332,8 @@ template <typename FP, typename SP> static int dispatch(int argc, char **argv, c
 int main(int argc, char **argv) {
   if (argc < 5) { std::cerr << "usage: test_engine_model <file> <solver> <iterations> <bal|weighted|k3|pinhole> [stored|dynamic] [fp64|fp32|mixed] [twice]" << std::endl; return 2; }
   const std::string mode = argv[4], prec = argc > 6 ? argv[6] : "fp64";
+  if (mode == "slam2d") return run_slam2d<double, double, graphite::RangeBearingFactor, 2>(argc, argv);
+  if (mode == "slam2d-range") return run_slam2d<double, double, graphite::RangeFactor, 1>(argc, argv);
   // fp32 / mixed precision: the weighted BAL factor only (every instantiation is a set of kernels to compile)
   if (prec == "fp32" && mode == "weighted") return run<float, float, graphite::WeightedFactor, 9>(argc, argv, mode);
   if (prec == "mixed" && mode == "weighted") return run<double, float, graphite::WeightedFactor, 9>(argc, argv, mode);

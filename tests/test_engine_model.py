@@ -169,6 +169,25 @@ def test_fixed_vertices_inactive_factors_and_unused_vertices_stay_on_the_user_tr
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["pcg", "pcg-schur", "eigen-schur"])
+@pytest.mark.parametrize("mode", ["slam2d", "slam2d-range"])
+def test_smallest_blocks_of_the_zero_padded_layout(tmp_path, mode, solver):
+    """(3, 2) -> 2 range-bearing and (3, 2) -> 1 range-only sightings in 2-D SLAM (60 SE(2) poses, 400 landmarks, pose 0 fixed, per-factor
+    information and Huber deltas, dual-number Jacobians): pose block 3 of 9, landmark block 2 of 3, error 1 of 2 in the engine's
+    zero-padded layout — the iterates are those of the generic any-dimension kernels"""
+    out = run_exe("-", solver, 8, mode)
+    d = fields(out)
+    assert d["ENGINE_HANDOVERS"] == ["1"] and d["ENGINE_MODEL_HANDOVERS"] == ["1"] and int(d["FACTORS"][0]) > 1000
+    gen = run_exe("-", solver, 8, mode, env={"GRAPHITE_GENERIC_ONLY": "1"})
+    assert fields(gen)["ENGINE_HANDOVERS"] == ["0"]
+    tr, tg = parse_trace(out), parse_trace(gen)
+    assert len(tr) == len(tg) and tr[-1, 1] < 0.05 * tr[0, 0]
+    assert np.allclose(tr[:, 1], tg[:, 1], rtol=1e-9) and np.allclose(tr[:, 2], tg[:, 2], rtol=1e-6)
+    for key in ("CAM0", "POSE1", "PT0"):
+        assert np.allclose([float(x) for x in d[key]], [float(x) for x in fields(gen)[key]], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.gpu
 def test_second_call_finds_the_user_traits_problem_cached(tmp_path):
     f, _ = make_file(tmp_path, "weighted")
     out = run_exe(f, "pcg", 4, "weighted", extra=("twice",))
