@@ -33,6 +33,43 @@ public:
   virtual void download_vertices() = 0; // and back
 };
 
+// K directional derivatives carried at once as the dual part of Dual<T, Tangent<T, K>>: the user's error function is evaluated
+// ceil((pose_dim + landmark_dim) / K) times instead of once per column (ops/linearize.hpp:43-79 seeds one column per evaluation;
+// every component below goes through the same operations in the same order as that column's own evaluation would).
+// GRAPHITE_ENGINE_TANGENT_WIDTH = 1 keeps the one-column form (for error functions that name Dual<T, T> explicitly).
+#ifndef GRAPHITE_ENGINE_TANGENT_WIDTH
+#define GRAPHITE_ENGINE_TANGENT_WIDTH 4
+#endif
+template <typename T, int K> struct Tangent {
+  T v[K];
+  hd_fn Tangent() {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = T(0);
+  }
+  hd_fn Tangent(T s) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = s;
+  }
+#define GRAPHITE_TANGENT_OP(expr) Tangent r; _Pragma("unroll") for (int k = 0; k < K; ++k) r.v[k] = expr; return r;
+  hd_fn friend Tangent operator+(const Tangent &a, const Tangent &b) { GRAPHITE_TANGENT_OP(a.v[k] + b.v[k]) }
+  hd_fn friend Tangent operator-(const Tangent &a, const Tangent &b) { GRAPHITE_TANGENT_OP(a.v[k] - b.v[k]) }
+  hd_fn friend Tangent operator-(const Tangent &a) { GRAPHITE_TANGENT_OP(-a.v[k]) }
+  hd_fn friend Tangent operator*(T s, const Tangent &a) { GRAPHITE_TANGENT_OP(s * a.v[k]) }
+  hd_fn friend Tangent operator*(const Tangent &a, T s) { GRAPHITE_TANGENT_OP(a.v[k] * s) }
+  hd_fn friend Tangent operator/(const Tangent &a, T s) { GRAPHITE_TANGENT_OP(a.v[k] / s) }
+#undef GRAPHITE_TANGENT_OP
+};
+} // namespace detail
+} // namespace graphite
+namespace std { // Dual::operator/ returns numeric_limits<D>::infinity() as the dual part of a division by zero (core.hpp)
+template <typename T, int K> struct numeric_limits<graphite::detail::Tangent<T, K>> {
+  static constexpr bool is_specialized = true;
+  hd_fn static graphite::detail::Tangent<T, K> infinity() { return graphite::detail::Tangent<T, K>(numeric_limits<T>::infinity()); }
+};
+} // namespace std
+namespace graphite {
+namespace detail {
+
 template <typename F> struct ModelView {
   using V0 = slot_vertex<F, 0>;
   using V1 = slot_vertex<F, 1>;
@@ -99,6 +136,32 @@ __device__ __forceinline__ typename F::Scalar em_evaluate(const ModelView<F> &mv
     if constexpr (std::is_same<typename F::Traits::Differentiation, DifferentiationMode::Manual>::value) {
       call_jacobian_t<F, 0, T>(v, mv.obs[j], mv.data[j], jc, seq);
       call_jacobian_t<F, 1, T>(v, mv.obs[j], mv.data[j], jp, seq);
+    } else if constexpr (GRAPHITE_ENGINE_TANGENT_WIDTH > 1) { // dual numbers, K columns per evaluation (Tangent above)
+      constexpr int K = GRAPHITE_ENGINE_TANGENT_WIDTH, NPASS = (DC + DL + K - 1) / K;
+      using D = Dual<T, Tangent<T, K>>;
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) {
+        std::tuple<D[DC], D[DL]> pd;
+        slot_traits<F, 0>::parameters(*std::get<0>(v), (D *)std::get<0>(pd));
+        slot_traits<F, 1>::parameters(*std::get<1>(v), (D *)std::get<1>(pd));
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int col = pass * K + k; // a constant after unrolling
+          if (col < DC) std::get<0>(pd)[col < DC ? col : 0].dual.v[k] = T(1);
+          else if (col < DC + DL) std::get<1>(pd)[col < DC + DL ? col - DC : 0].dual.v[k] = T(1);
+        }
+        D ed[E];
+        call_error<F, D>(v, pd, mv.obs[j], mv.data[j], ed, seq);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int col = pass * K + k;
+#pragma unroll
+          for (int i = 0; i < E; ++i) {
+            if (col < DC) jc[(col < DC ? col : 0) * E + i] = ed[i].dual.v[k];
+            else if (col < DC + DL) jp[(col < DC + DL ? col - DC : 0) * E + i] = ed[i].dual.v[k];
+          }
+        }
+      }
     } else { // dual numbers, one column at a time (ops/linearize.hpp:43-79 with Dual<T>)
       using D = Dual<T, T>;
 #pragma unroll 1

@@ -4,7 +4,7 @@
 // and with the generic kernels (GRAPHITE_GENERIC_ONLY=1) and checks which path ran.
 //   usage: test_engine_model <bal file> <pcg|pcg-identity|pcg-schur|eigen-schur> <iterations> <bal|weighted|k3|pinhole> [stored|dynamic] [fp64|fp32|mixed]
 //   bal      : the reprojection factor of docs/markdown/main.md:230-262 (Manual Jacobian), identity precision, DefaultLoss
-//   weighted : the same factor, every factor with its own 2 x 2 information matrix and its own Huber delta (factor.hpp:373-412)
+//   weighted : the same factor with a closed-form Jacobian, every factor with its own 2 x 2 information matrix and its own Huber delta (factor.hpp:373-412)
 //   k3       : a sixth-order radial term whose coefficient is per-factor constraint data (Traits::Data), dual-number Jacobian
 //   pinhole  : 6-dof pose [angle-axis, t] x 3-d point -> pixel, intrinsics in the constraint data
 #include <fstream>
@@ -63,8 +63,51 @@ template <typename D, typename T> d_fn void reprojection(const D *cam, const D *
   err[1] = cam[6] * d * py - D(obs(1));
 }
 
-// ---- bal / weighted: Manual Jacobian (by dual numbers inside the user function), HuberLoss per factor ----------------------
-template <typename T, typename S, typename LossT> struct ReprojectionTraits {
+// closed-form derivative of `reprojection` (k3 = 0) with respect to slot I (0: camera, 9 columns; 1: point, 3 columns), column-major 2 x d:
+// err = f d p - obs, p = -(P0, P1) / P2, P = R(w) X + t.  With M = d err / d P (2 x 3) and N = M R:
+//   d err / d X = N,  d err / d t = M,  d err / d w: row = ((u . w) w + (R u - u) x w) / theta^2 with u = X x n  (n = the row of N; theta = 0: u)
+//   — the derivative of a rotated vector with respect to its rotation vector, d (R X) / d w = -R [X]x (w w^T + (R^T - I) [w]x) / theta^2 —
+//   d err / d f = d p,  d err / d k1 = f r^2 p,  d err / d k2 = f r^4 p
+template <typename T, typename Sj, size_t I> d_fn void reprojection_jacobian(const Vec<T, 9> &cam, const Vec<T, 3> &pt, Sj *jac) {
+  const T wx = cam(0), wy = cam(1), wz = cam(2), X0 = pt(0), X1 = pt(1), X2 = pt(2);
+  const T theta2 = wx * wx + wy * wy + wz * wz;
+  T R[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+  if (theta2 > T(0)) {
+    const T theta = sqrt(theta2), ax = wx / theta, ay = wy / theta, az = wz / theta;
+    const T s = sin(theta), c = cos(theta), k = T(1) - c;
+    R[0] = k * ax * ax + c;      R[1] = k * ax * ay - s * az; R[2] = k * ax * az + s * ay;
+    R[3] = k * ax * ay + s * az; R[4] = k * ay * ay + c;      R[5] = k * ay * az - s * ax;
+    R[6] = k * ax * az - s * ay; R[7] = k * ay * az + s * ax; R[8] = k * az * az + c;
+  }
+  const T P0 = R[0] * X0 + R[1] * X1 + R[2] * X2 + cam(3), P1 = R[3] * X0 + R[4] * X1 + R[5] * X2 + cam(4), P2 = R[6] * X0 + R[7] * X1 + R[8] * X2 + cam(5);
+  const T iz = T(1) / P2, px = -P0 * iz, py = -P1 * iz, r2 = px * px + py * py;
+  const T f = cam(6), k1 = cam(7), k2 = cam(8), d = T(1) + k1 * r2 + k2 * r2 * r2, g = T(2) * (k1 + T(2) * k2 * r2);
+  // A = d err / d p = f (d I + g p p^T);  d p / d P = [[-iz, 0, -px iz], [0, -iz, -py iz]]
+  const T a00 = f * (d + g * px * px), a01 = f * g * px * py, a11 = f * (d + g * py * py);
+  const T M[2][3] = {{-a00 * iz, -a01 * iz, -(a00 * px + a01 * py) * iz}, {-a01 * iz, -a11 * iz, -(a01 * px + a11 * py) * iz}};
+  for (int r = 0; r < 2; ++r) {
+    const T n0 = M[r][0] * R[0] + M[r][1] * R[3] + M[r][2] * R[6], n1 = M[r][0] * R[1] + M[r][1] * R[4] + M[r][2] * R[7], n2 = M[r][0] * R[2] + M[r][1] * R[5] + M[r][2] * R[8];
+    if constexpr (I == 1) { jac[r] = (Sj)n0; jac[2 + r] = (Sj)n1; jac[4 + r] = (Sj)n2; }
+    else {
+      const T u0 = X1 * n2 - X2 * n1, u1 = X2 * n0 - X0 * n2, u2 = X0 * n1 - X1 * n0;
+      T j0 = u0, j1 = u1, j2 = u2;
+      if (theta2 > T(0)) {
+        const T v0 = R[0] * u0 + R[1] * u1 + R[2] * u2 - u0, v1 = R[3] * u0 + R[4] * u1 + R[5] * u2 - u1, v2 = R[6] * u0 + R[7] * u1 + R[8] * u2 - u2;
+        const T uw = u0 * wx + u1 * wy + u2 * wz, it2 = T(1) / theta2;
+        j0 = (uw * wx + (v1 * wz - v2 * wy)) * it2; j1 = (uw * wy + (v2 * wx - v0 * wz)) * it2; j2 = (uw * wz + (v0 * wy - v1 * wx)) * it2;
+      }
+      const T pr = r == 0 ? px : py;
+      jac[r] = (Sj)j0; jac[2 + r] = (Sj)j1; jac[4 + r] = (Sj)j2;
+      jac[6 + r] = (Sj)M[r][0]; jac[8 + r] = (Sj)M[r][1]; jac[10 + r] = (Sj)M[r][2];
+      jac[12 + r] = (Sj)(d * pr); jac[14 + r] = (Sj)(f * r2 * pr); jac[16 + r] = (Sj)(f * r2 * r2 * pr);
+    }
+  }
+}
+
+// ---- bal / weighted: Manual Jacobian, HuberLoss per factor --------------------------------------------------------------------
+// ANALYTIC false: the Jacobian by dual numbers INSIDE the user function (arbitrary user code on the Manual path); true: the closed form above,
+// as a user with a generated Jacobian supplies it (examples/bal.cu)
+template <typename T, typename S, typename LossT, bool ANALYTIC> struct ReprojectionTraits {
   static constexpr size_t dimension = 2;
   using VertexDescriptors = std::tuple<VecDescriptor<T, S, 9>, VecDescriptor<T, S, 3>>;
   using Observation = Pixel<T>;
@@ -76,21 +119,24 @@ template <typename T, typename S, typename LossT> struct ReprojectionTraits {
   }
   template <typename Sj, size_t I>
   d_fn static void jacobian(const Vec<T, 9> &cam, const Vec<T, 3> &pt, const Pixel<T> &obs, Sj *jac) {
-    using D = Dual<T, T>;
-    constexpr int d = I == 0 ? 9 : 3;
-    for (int c = 0; c < d; ++c) {
-      D cp[9], pp[3], err[2];
-      for (int k = 0; k < 9; ++k) cp[k] = D(cam(k));
-      for (int k = 0; k < 3; ++k) pp[k] = D(pt(k));
-      (I == 0 ? cp[c] : pp[c]).dual = T(1);
-      reprojection<D, T>(cp, pp, obs, T(0), err);
-      jac[2 * c] = (Sj)err[0].dual;
-      jac[2 * c + 1] = (Sj)err[1].dual;
+    if constexpr (ANALYTIC) { reprojection_jacobian<T, Sj, I>(cam, pt, jac); (void)obs; }
+    else {
+      using D = Dual<T, T>;
+      constexpr int d = I == 0 ? 9 : 3;
+      for (int c = 0; c < d; ++c) {
+        D cp[9], pp[3], err[2];
+        for (int k = 0; k < 9; ++k) cp[k] = D(cam(k));
+        for (int k = 0; k < 3; ++k) pp[k] = D(pt(k));
+        (I == 0 ? cp[c] : pp[c]).dual = T(1);
+        reprojection<D, T>(cp, pp, obs, T(0), err);
+        jac[2 * c] = (Sj)err[0].dual;
+        jac[2 * c + 1] = (Sj)err[1].dual;
+      }
     }
   }
 };
-template <typename T, typename S> using BalFactor = FactorDescriptor<T, S, ReprojectionTraits<T, S, DefaultLoss<T, 2>>>;
-template <typename T, typename S> using WeightedFactor = FactorDescriptor<T, S, ReprojectionTraits<T, S, HuberLoss<T, 2>>>;
+template <typename T, typename S> using BalFactor = FactorDescriptor<T, S, ReprojectionTraits<T, S, DefaultLoss<T, 2>, false>>;
+template <typename T, typename S> using WeightedFactor = FactorDescriptor<T, S, ReprojectionTraits<T, S, HuberLoss<T, 2>, true>>;
 
 // ---- k3: constraint data + automatic differentiation ------------------------------------------------------------------------
 template <typename T> struct Radial6 { T k3; };
