@@ -435,6 +435,18 @@ def main():
              "value_note": "second optimiser call on the cached engine problem: LM iterations / seconds inside the engine's loop",
              "hand_over_seconds_second_call": float(second["SETUP_SECONDS"]), "chi2_initial": trace[0][0], "chi2_final": trace[-1][1],
              "parity_rel": None, "roofline": roofline_of(uks, 8)}
+        # the same graph with set_jacobian_storage(false): blocks recomputed through the user's jacobian<> in every operator launch
+        # (ops/product.hpp:103,292); which of the two is faster depends on the model's cost and the inner iteration count
+        try:
+            rd = subprocess.run([exe, path, "pcg", str(steps), "weighted", "dynamic", "fp64", "twice"], env=env, capture_output=True, text=True, timeout=600)
+            for ln in rd.stdout.splitlines():
+                if ln.startswith("SECOND_CALL_SECONDS") and rd.returncode == 0:
+                    f = ln.split()
+                    sd = dict(zip(f[0::2], f[1::2]))
+                    e["recomputed_jacobian"] = {"value": round(int(sd["ITERATIONS"]) / float(sd["LOOP_SECONDS"]), 2), "unit": "LM iterations/s",
+                                                "ms_per_step": round(float(sd["LOOP_SECONDS"]) / max(int(sd["ITERATIONS"]), 1) * 1e3, 4)}
+        except Exception:
+            pass
         if e["roofline"]:
             e["roofline"]["kernels"] = {nm: {"avg_us": round(v["total_ms"] * 1e3 / max(v["active_launches"], 1), 2), "active_launches": v["active_launches"]} for nm, v in uks.items()}
             e["roofline"]["cache_residency"] = cache_residency(working_set(uNc, uNp, uNo, 8) + uNo * 24 * 8)

@@ -2274,6 +2274,8 @@ template <typename T> struct Engine final : EngineBase {
   ApplyOnExit<T> apply_args(int k, int max_iter) {
     ApplyOnExit<T> ap;
     if (!lm_fused) return ap;
+    ap.at_cap = (k + 1 == max_iter) ? 1 : 0;
+    if (model) return ap; // the loop-ending launch only closes the loop; the step is gr_model_ops.step's (fused_iteration)
     rho_blocks = dir_grid();
     rho_partial.alloc(rho_blocks);
     ap.cams = cams.p; ap.pts = pts.p; ap.cams_bak = cams_bak.p; ap.pts_bak = pts_bak.p; ap.bu = bu.p;
@@ -2308,7 +2310,7 @@ template <typename T> struct Engine final : EngineBase {
     // the first PCG iteration without its direction launch (operator and update in their lazy forms).  With point records too: the
     // record layout is a compile-time form of the operator, iteration 0 runs the plain form on zs / pts and the direction launch that
     // ends it fills the [X Y Z | s.p] sectors for iteration 1
-    const bool first_lazy = max_iter > 0 && tune.lm_fused != 2;
+    const bool first_lazy = max_iter > 0 && tune.lm_fused != 2 && !model; // (the lazy first operator is a form of the built-in kernel)
     if (first_lazy) v_zs.alloc(n);
     ts_slot = time_slot;
     flag_bank ^= 1; // the previous user of this bank is the solve before the last one: complete
@@ -2398,9 +2400,9 @@ template <typename T> struct Engine final : EngineBase {
     T nu = 2;
     solver_update_structure(opt.solver);
     const bool pcg_solver = opt.solver == GR_SOLVER_PCG || opt.solver == GR_SOLVER_PCG_IDENTITY;
-    // user-traits problems take the host-driven form: the trial step goes through the user's Traits::update (gr_model_ops.step),
-    // which the library's loop-ending direction launch cannot call
-    lm_fused = pcg_solver && !comm && !model && pcg_mode() == 0 && opt.pcg_max_iter >= 1 && tune.lm_fused != 0;
+    // (user-traits problems too: their trial step goes through the user's Traits::update — gr_model_ops.step, a launch of its own behind the
+    // loop-ending direction launch, gated on the loop's exit word like the trial linearisation — and their heads run the direction-kernel form)
+    lm_fused = pcg_solver && !comm && pcg_mode() == 0 && opt.pcg_max_iter >= 1 && tune.lm_fused != 0;
     // (larger reduced systems keep the host-driven loop: measured on Ladybug-1723, 1 723 cameras, the merged finalisation and
     // back-substitution launches are no faster than their parts there — 1 716 vs 1 737 LM it/s — the shared S / b_S launch is what pays)
     sf_active = opt.solver == GR_SOLVER_PCG_SCHUR && schur_fused_ok(opt.pcg_max_iter) && schur_coop() && opt.iterations > 0;
@@ -2427,7 +2429,7 @@ template <typename T> struct Engine final : EngineBase {
       predicted_iters = opt.pcg_max_iter; last_active = opt.pcg_max_iter;
       campack();
       linearize_deferred(nullptr);
-      fin_pending = true; pcg_state_clean = true;
+      fin_pending = true; pcg_state_clean = !model; // (the built-in k_linearize clears the loop state in its last workgroup)
       LmDecide dec;
       dec.seq = ++seq_counter; dec.report_only = 1;
       dec.chi2_partial = chi2_partial.p; dec.n_chi2 = grid_lin; dec.hres = h_res; dec.hres_seq = h_seq; dec.lm = lmdev.p; dec.dscal = dscalars.p;
@@ -2487,7 +2489,7 @@ template <typename T> struct Engine final : EngineBase {
         }
         nu = 2;
         if (!speculate) {
-          if (lm_fused) { linearize_deferred(nullptr); fin_pending = true; pcg_state_clean = true; }
+          if (lm_fused) { linearize_deferred(nullptr); fin_pending = true; pcg_state_clean = !model; }
           else linearize_impl(want_hcp, /*pack_valid=*/true);
         }
         solver_update_values(opt.solver);
@@ -2496,7 +2498,7 @@ template <typename T> struct Engine final : EngineBase {
       } else {
         revert();
         if (speculate) { // restore H, b, scales of the kept point
-          if (lm_fused) { linearize_deferred(nullptr); fin_pending = true; pcg_state_clean = true; }
+          if (lm_fused) { linearize_deferred(nullptr); fin_pending = true; pcg_state_clean = !model; }
           else if (sf_active) linearize_hcp_deferred(); // finalised by the next head
           else linearize_impl(want_hcp, /*pack_valid=*/true);
         } else if (lm_fused) pcg_state_clean = false; // the old linearisation stands, the loop state is spent
@@ -2597,7 +2599,14 @@ template <typename T> struct Engine final : EngineBase {
       head_enqueued = false;
       ts_slot = pr;
       const bool speculate = accept_streak >= 2 && spec_enabled;
-      auto enqueue_lin = [&](const int *gate) { linearize_deferred(gate); };
+      auto enqueue_lin = [&](const int *gate) {
+        if (model) { // backup + Traits::update + the rho-denominator partials, then the trial linearisation: both wait for the loop's exit word
+          rho_blocks = model->step_blocks;
+          rho_partial.alloc(rho_blocks);
+          model_step(v_dx.p, /*with_backup=*/true, (double)mu, rho_partial.p, nullptr, gate);
+        }
+        linearize_deferred(gate);
+      };
       const bool ahead = speculate && ahead_enabled;
       if (ahead) trial_hook = enqueue_lin;
       trial_done = false;
@@ -2609,7 +2618,7 @@ template <typename T> struct Engine final : EngineBase {
       int seq = 0;
       if (speculate) {
         if (!(ahead && trial_done)) enqueue_lin(nullptr);
-        fin_pending = true; pcg_state_clean = true;
+        fin_pending = true; pcg_state_clean = !model;
         seq = ++seq_counter;
         if (i + 1 < opt.iterations) {
           LmDecide dec;
@@ -2621,7 +2630,10 @@ template <typename T> struct Engine final : EngineBase {
           head_enqueued = true;
           ++head_hits;
         } else flush_finalize(seq); // last iteration: only the decision is needed
-      } else seq = chi2_async(nullptr, v_dx.p, (double)mu); // the step itself was applied by the last direction launch
+      } else {
+        if (model) apply_update_dev(v_dx.p, /*with_backup=*/true);
+        seq = chi2_async(nullptr, v_dx.p, (double)mu); // (built-in model: the step itself was applied by the last direction launch)
+      }
       wait_chi2(seq);
       st.solve_seconds += (double)(h_ts[2 * pr + 1] - h_ts[2 * pr]) / wall_clock_hz;
       const double hs[2] = {h_res[0], h_res[1]};
@@ -2684,7 +2696,8 @@ template <typename T> struct Engine final : EngineBase {
       // the loop ends here but the head of the next iteration is already running: if its PCG loop ended inside the head,
       // its last direction launch has applied a trial step nobody will judge — take it back
       GR_HIP(hipStreamSynchronize(stream));
-      if (sf_active || flags()[0] == 2 || opt.pcg_max_iter == 1) revert(); // (Schur form: an accepted head always ends with its trial step)
+      // (Schur form: an accepted head always ends with its trial step; user-traits problems: the head applies none)
+      if (!model && (sf_active || flags()[0] == 2 || opt.pcg_max_iter == 1)) revert();
       head_enqueued = false;
     }
     if (fin_pending) flush_finalize();

@@ -1987,7 +1987,7 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
     PcgIter it{};
     if (!leave) { it.rzp = sv[0]; it.rscale = 1.0 / sqrt(sv[1]); it.rz = it.rzp * it.rscale; leave = (it.rzp == 0.0); }
     if (leave) {
-      if (first) { st.done[k + 1] = 1; st.rz0[k + 1] = rz0; if (st.left) *st.left = 1; st.hflag[k] = 2; __threadfence_system(); }
+      if (first) { st.done[k + 1] = 1; st.rz0[k + 1] = rz0; if (st.left) *st.left = 1; if (!ap.cams && st.ts && !was_done) st.ts[1] = wall_clock64(); st.hflag[k] = 2; __threadfence_system(); }
       if (ap.cams && !was_done) apply_on_exit<T>(ap, n, pose_dim, x, scales, mu, nullptr); // r.z == 0: x is final
       return;
     }
@@ -2006,6 +2006,7 @@ k_pcg_direction(unsigned n, T *__restrict__ x, const T *__restrict__ xb, T *__re
       st.iters[0] = k + 1;
       *st.hiters = k + 1;
       if ((done_next || ap.at_cap) && st.left) *st.left = 1;
+      if ((done_next || ap.at_cap) && !ap.cams && st.ts) st.ts[1] = wall_clock64(); // (with ApplyOnExit the stamp is apply_on_exit's)
       st.hflag[k] = done_next ? 2 : 1;
       __threadfence_system();
     }
