@@ -149,6 +149,40 @@ def test_fp32_step_is_as_close_to_fp64_as_the_fp32_oracle(oracle_mod, solver):
     gpu.close()
 
 
+@pytest.mark.parametrize("name", ["mini-50", "ladybug-49"])
+def test_fp32_pcg_step_distance_per_inner_iteration(oracle_mod, name):
+    """The same comparison in the 2-norm and for every inner-iteration count 1 .. 6 (tools/fp32_iter_probe.py prints the table): the
+    single-sample maximum-norm ratio above is set by the worst entry of one step; over the whole step the engine's fp32 matrix-free PCG
+    is 0.98-1.59 x the fp32 oracle's distance from fp64 on mini-50 and 0.65-0.94 x on Ladybug-49 (closer than the restatement: tree sums
+    instead of sequential ones) — held at 2 x for every count, the bar VERDICT r4 asked for."""
+    prob = synth.make_config(name)
+    def dist(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float32)
+    gpu.solver_update_structure(ga.SOLVER_PCG)
+    refs = {}
+    for dt in (np.float32, np.float64):
+        refs[dt] = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dt)
+    worst = 0.0
+    for k in range(1, 7):
+        gpu.linearize()
+        gpu.solver_update_values(ga.SOLVER_PCG)
+        gpu.solver_set_damping(ga.SOLVER_PCG, 1e-4)
+        dx_g, _ = gpu.solver_solve(ga.SOLVER_PCG, max_iter=k, tol=0.0, rej=1e6)
+        dx = {}
+        for dt, ref in refs.items():
+            ref.linearize()
+            ref.solver_update_values(oracle_mod.SOLVER_PCG)
+            ref.solver_set_damping(oracle_mod.SOLVER_PCG, 1e-4)
+            dx[dt], _ = ref.solver_solve(oracle_mod.SOLVER_PCG, max_iter=k, tol=0.0, rej=1e6)
+        e_gpu, e_ref = dist(dx_g, dx[np.float64]), dist(dx[np.float32], dx[np.float64])
+        worst = max(worst, e_gpu / e_ref)
+        assert e_gpu < 2.0 * e_ref, (k, e_gpu, e_ref)
+        assert e_gpu < 2e-4, (k, e_gpu)
+    gpu.close()
+
+
 def test_pcg_schur_matches_direct_solve(oracle_mod):
     """tests/schur.cu:340-389: PCG-Schur (512 it, tol 1e-14, rejection 1e6) vs the direct Schur
     LDLT solve, mu = 1e-4, |delta| < 5e-4 on the 2x3 fixture."""
