@@ -116,11 +116,24 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
   T *xd = L + CH_NB * CH_LP; // diag of X
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, cl = lane & 15, g = lane >> 4;
   constexpr int NW = NT / 64, NB16 = CH_NB / 16;
-  if (load)
-    for (int e = t; e < CH_NB * CH_NB; e += NT) {
-      const int r = e >> 7, c = e & 127;
-      L[r * CH_LP + c] = c <= r ? Ag[(size_t)r * ld + c] : T(0);
+  if (load) { // eight contiguous scalars per request, every request of a thread in flight before the first LDS store (scalar loads: 14 us of the 57)
+    constexpr int NCH = CH_NB * CH_NB / 8 / NT, BATCH = NCH < 4 ? NCH : 4; // (four requests of a thread in flight: 64 fp64 registers)
+#pragma unroll 1
+    for (int q0 = 0; q0 < NCH; q0 += BATCH) {
+      T v[BATCH][8];
+#pragma unroll
+      for (int q = 0; q < BATCH; ++q) {
+        const int e = t + (q0 + q) * NT, r = e >> 4, c0 = (e & 15) * 8;
+        if (c0 <= r) load8<T>(Ag + (size_t)r * ld + c0, v[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < BATCH; ++q) {
+        const int e = t + (q0 + q) * NT, r = e >> 4, c0 = (e & 15) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) L[r * CH_LP + c0 + i] = (c0 <= r && c0 + i <= r) ? v[q][i] : T(0);
+      }
     }
+  }
   __syncthreads();
   // blocked inverse, block (i, j), j < i: X_ij = -X_ii sum_{k=j}^{i-1} L_ik X_kj.  Row i needs the diagonal step i (X_ii), the
   // sub-panel solves of the steps before it (L_ik) and the rows of X above it: it is computed by waves 1 .. 3 WHILE wave 0 runs
@@ -149,7 +162,6 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
     for (int r = 0; r < 4; ++r) L[(16 * j + cl) * CH_LP + 16 * i + M::row(lane, r)] = -xacc[r];
   };
   // 16x16 Cholesky + inverse of diagonal block s by ONE wave: lane r (mod 16) owns row r of the block, then column r of X
-  __shared__ int s_next;
   auto diag_step = [&](int s) {
     const int o = 16 * s;
     T a[16], x[16], rsv[16];
@@ -165,12 +177,20 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
 #pragma unroll
       for (int k = j + 1; k < 16; ++k) a[k] -= a[j] * lane_bcast<T>(a[j], k);
     }
+    // X = L^-1, lane cl holds column cl: x[m] = (delta_m,cl - sum_{k<m} L[m][k] x[k]) / L[m][m], by COLUMNS of L — once x[k] is final its
+    // multiples leave all later entries at once (15 - k independent multiply-adds; the row form summed each row in a serial chain).  Same
+    // products, same order of additions per entry: same bits.  The broadcasts depend on a[] only; left alone all 120 are issued up front
+    // (240 fp64 registers: fine in a 256-thread workgroup, 170 spilled to scratch in a 512-thread one) — there they are tied to the
+    // previous column's result, one column of look-ahead.
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      T sum = T(0);
+    for (int m = 0; m < 16; ++m) x[m] = (m == cl) ? T(1) : T(0);
 #pragma unroll
-      for (int k = 0; k < m; ++k) sum += lane_bcast<T>(a[k], m) * x[k];
-      x[m] = ((m == cl ? T(1) : T(0)) - sum) * rsv[m];
+    for (int k = 0; k < 16; ++k) {
+      x[k] = x[k] * rsv[k];
+      T ak = a[k];
+      if (NT > 256 && k > 0) asm volatile("" : "+v"(ak) : "v"(x[k - 1]));
+#pragma unroll
+      for (int m = k + 1; m < 16; ++m) x[m] -= lane_bcast<T>(ak, m) * x[k];
     }
     if (lane < 16) {
 #pragma unroll
@@ -213,34 +233,52 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
       }
     }
   };
-  // LOOK-AHEAD: after the sub-panel solve of step s, wave 0 updates the next diagonal block alone and walks straight into its
-  // serial 16 x 16 step, while the other waves finish the trailing update of step s and row s of the blocked inverse — the diagonal
-  // steps (2 us each, one wave) used to wait for the whole trailing update, and the trailing update for them.  Two workgroup
-  // barriers per step instead of three; every tile is still updated once per step by one wave: same bits.
+  // sub-panel solve of ONE 16-row block below diagonal block s: L_bi,s = A_bi,s X_ss^T
+  auto subpanel_block = [&](int s, int bi) {
+    const int o = 16 * s;
+    acc_t acc = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 4 * kk + g;
+      const T av = L[(16 * bi + cl) * CH_LP + o + k];
+      const T bv = cl > k ? L[(o + k) * CH_LP + o + cl] : (cl == k ? xd[o + cl] : T(0));
+      acc = M::mma(av, bv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) L[(16 * bi + M::row(lane, r)) * CH_LP + o + cl] = acc[r];
+  };
+  // WAVE 0 OWNS THE CRITICAL CHAIN (round 5).  The next diagonal step needs, of step s, only the sub-panel block right below the
+  // diagonal and the trailing update of the next diagonal block — both 16 x 16 MFMA products on data only wave 0 touches in this window.
+  // So wave 0 runs  sub-panel (s + 1, s) -> trailing (s + 1, s + 1) -> diagonal step s + 1  without meeting a workgroup barrier, while
+  // waves 1 .. solve the rest of the sub-panel, meet each other (and wave 0's sub-panel block) at an LDS counter, update the rest of the
+  // trailing matrix, write back inverse rows and take the blocks of row s of the inverse; ONE workgroup barrier per window instead of two.
+  // The window used to cost max over the waves of (sub-panel share) + barrier + max(wave 0: update + diagonal step, others: trailing share +
+  // inverse) = 4.3 us; wave 0's chain alone is 2.6 us.  Every tile is still computed once, by the same instruction sequence: same bits.
+  __shared__ int s_arrive[2], s_deal[2]; // window s uses element s & 1; the other one is cleared for window s + 1 meanwhile
+  if (t < 2) { s_arrive[t] = 0; s_deal[t] = 0; }
   if (wave == 0 && !(skip & 1)) diag_step(0);
   __syncthreads();
   for (int s = 0; s < NB16; ++s) {
-    const int o = 16 * s;
-    if (t == 0) s_next = 0; // every wave left the previous window's dealing loop before the barrier that ended it
-    // sub-panel solve: L_is = A_is X_ss^T for the 16-row blocks below
-    for (int bi = s + 1 + wave; bi < NB16 && !(skip & 2); bi += NW) {
-      acc_t acc = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int k = 4 * kk + g;
-        const T av = L[(16 * bi + cl) * CH_LP + o + k];
-        const T bv = cl > k ? L[(o + k) * CH_LP + o + cl] : (cl == k ? xd[o + cl] : T(0));
-        acc = M::mma(av, bv, acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) L[(16 * bi + M::row(lane, r)) * CH_LP + o + cl] = acc[r];
-    }
-    __syncthreads();
+    const int par = s & 1;
+    if (t == 64) { s_arrive[par ^ 1] = 0; s_deal[par ^ 1] = 0; } // next window's counters: their last use ended before the barrier that opened this window
     const int m = NB16 - 1 - s, ntile = m * (m + 1) / 2;
     if (wave == 0) {
-      if (ntile > 0 && !(skip & 2)) trailing_tile(s, 0);
-      if (s + 1 < NB16 && !(skip & 1)) diag_step(s + 1); // only this wave touches block (s + 1, s + 1) until the barrier below
+      if (s + 1 < NB16) {
+        if (!(skip & 2)) subpanel_block(s, s + 1);
+        wave_lds_fence();
+        if (lane == 0) atomicAdd(&s_arrive[par], 1); // (LDS runs a wave's instructions in order: the block is written when the count is)
+        if (!(skip & 2)) trailing_tile(s, 0);
+        wave_lds_fence();
+        if (!(skip & 1)) diag_step(s + 1); // only this wave touches block (s + 1, s + 1) until the barrier below
+      }
     } else {
+      for (int bi = s + 2 + (wave - 1); bi < NB16 && !(skip & 2); bi += NW - 1) subpanel_block(s, bi);
+      if (s + 1 < NB16) {
+        wave_lds_fence();
+        if (lane == 0) atomicAdd(&s_arrive[par], 1);
+        while (__hip_atomic_load(&s_arrive[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NW) __builtin_amdgcn_s_sleep(1);
+        wave_lds_fence();
+      }
       for (int q = wave; q < ntile && !(skip & 2); q += NW - 1) trailing_tile(s, q);
       if (s >= 1 && !(skip & 8)) store_rows(16 * (s - 1), 1); // complete since the barrier that ended window s - 1
     }
@@ -250,7 +288,7 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
     if (!(skip & 4))
       for (;;) {
         int j = 0;
-        if (lane == 0) j = atomicAdd(&s_next, 1);
+        if (lane == 0) j = atomicAdd(&s_deal[par], 1);
         j = __builtin_amdgcn_readfirstlane(j);
         if (j >= s) break;
         inverse_block(s, j);
@@ -260,10 +298,10 @@ __device__ __forceinline__ void chol_potrf_block(T *__restrict__ L, T *__restric
   if (!(skip & 8)) store_rows(16 * (NB16 - 1), 0);
   (void)Ag; (void)ld;
 }
-template <typename T>
-__global__ __launch_bounds__(CH_PT) void k_chol_potrf(T *__restrict__ A, int ld, int k0, T *__restrict__ Linv, int *__restrict__ fail, int skip = 0) {
+template <typename T, int NT = CH_PT>
+__global__ __launch_bounds__(NT) void k_chol_potrf(T *__restrict__ A, int ld, int k0, T *__restrict__ Linv, int *__restrict__ fail, int skip = 0) {
   extern __shared__ __align__(16) unsigned char ch_smem[];
-  chol_potrf_block<T>(reinterpret_cast<T *>(ch_smem), A + (size_t)k0 * ld + k0, ld, Linv, fail, true, skip);
+  chol_potrf_block<T, NT>(reinterpret_cast<T *>(ch_smem), A + (size_t)k0 * ld + k0, ld, Linv, fail, true, skip);
 }
 
 constexpr size_t chol_potrf_lds(size_t w) { return (CH_NB * CH_LP + CH_NB) * w; }

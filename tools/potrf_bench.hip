@@ -7,7 +7,7 @@
 #include "common.hpp"
 #include "chol.hpp"
 using namespace gr;
-template <typename T> void run(const char *name) {
+template <typename T, int NT> void run(const char *name) {
   const int n = CH_NB;
   std::vector<T> h((size_t)n * n);
   std::mt19937 rng(1);
@@ -18,21 +18,21 @@ template <typename T> void run(const char *name) {
   T *A, *A0, *Linv; int *fail;
   hipMalloc(&A, sizeof(T) * n * n); hipMalloc(&A0, sizeof(T) * n * n); hipMalloc(&Linv, sizeof(T) * n * n); hipMalloc(&fail, 4);
   hipMemcpy(A0, h.data(), sizeof(T) * n * n, hipMemcpyHostToDevice);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_potrf<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_potrf_lds(sizeof(T)));
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_potrf<T, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_potrf_lds(sizeof(T)));
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int skip : {0, 1, 2, 4, 8, 3, 7, 15}) {
+  for (int skip : {0, 1, 14, 13, 11, 15}) {
     float tot = 0;
     const int reps = 50;
     for (int r = 0; r < reps + 3; ++r) {
       hipMemcpyAsync(A, A0, sizeof(T) * n * n, hipMemcpyDeviceToDevice, 0);
       hipEventRecord(a, 0);
-      k_chol_potrf<T><<<1, CH_PT, chol_potrf_lds(sizeof(T)), 0>>>(A, n, 0, Linv, fail, skip);
+      k_chol_potrf<T, NT><<<1, NT, chol_potrf_lds(sizeof(T)), 0>>>(A, n, 0, Linv, fail, skip);
       hipEventRecord(b, 0);
       hipEventSynchronize(b);
       float ms; hipEventElapsedTime(&ms, a, b);
       if (r >= 3) tot += ms;
     }
-    std::printf("%s skip=%2d (1 diag16, 2 solve+update, 4 inverse, 8 store): %.1f us\n", name, skip, tot * 1e3 / reps);
+    std::printf("%s NT=%d skip=%2d (1 diag16, 2 solve+update, 4 inverse, 8 store): %.1f us\n", name, NT, skip, tot * 1e3 / reps);
   }
 }
-int main() { run<double>("f64"); run<float>("f32"); return 0; }
+int main() { run<double, 256>("f64"); run<double, 512>("f64"); run<double, 1024>("f64"); run<float, 256>("f32"); run<float, 512>("f32"); return 0; }
