@@ -1146,10 +1146,19 @@ template <typename T> struct Engine final : EngineBase {
   }
 
   // user-traits problems: Graph::backup_parameters + apply_update through the user's Traits::update (gr_model_ops.step)
-  void model_step(const T *dx, bool with_backup, double mu, double *rho_part, const LmDev *lm, const int *gate) {
+  // clear_state: the PCG loop state is reset inside the step launch (what k_pcg_state_init does in its gated form: the slots, done, pdp,
+  // rz0 = {inf, 0 ...}, the iteration count; the exit word `left` stays — it IS the gate)
+  void model_step(const T *dx, bool with_backup, double mu, double *rho_part, const LmDev *lm, const int *gate, bool clear_state = false) {
     gr_model_step_args a{};
     a.dx = dx; a.scales = scales.p; a.bu = bu.p; a.mu = mu; a.with_backup = with_backup ? 1 : 0; a.cam_weight = cam_weight();
     a.rho_partial = rho_part; a.lm = lm; a.gate = gate; a.cam_fixed = cam_fixed_p(); a.pt_fixed = pt_fixed_p(); a.stream = stream;
+    if (clear_state && ctl_cap > 0) {
+      const PcgState st = pcg_state();
+      a.clear_ptr[0] = ctl.p; a.clear_bytes[0] = (int64_t)(ctl.n * sizeof(double));
+      a.clear_ptr[1] = ctl_i.p; a.clear_bytes[1] = (int64_t)(ctl_i.n * sizeof(int));
+      a.clear_ptr[2] = st.iters; a.clear_bytes[2] = (int64_t)sizeof(int);
+      a.inf_word = st.rz0;
+    }
     hook_begin();
     hook_end(model->step(model->ctx, &a), "step");
   }
@@ -2543,10 +2552,8 @@ template <typename T> struct Engine final : EngineBase {
         rho_blocks = model ? model->step_blocks : cdiv(Nc, 28) + cdiv(3 * Np, TPB);
         rho_partial.alloc(rho_blocks);
         const bool clear_state = ctl_cap > 0 && pcg_solver;
-        if (model) {
-          model_step(v_dx.p, /*with_backup=*/true, (double)mu, rho_partial.p, nullptr, gate);
-          if (clear_state) { k_pcg_state_init<<<1, TPB, 0, stream>>>(pcg_state(), ctl_cap, gate); ++launch_count; }
-        } else
+        if (model) model_step(v_dx.p, /*with_backup=*/true, (double)mu, rho_partial.p, nullptr, gate, clear_state);
+        else
         k_apply_update_rho<T><<<rho_blocks + (clear_state ? 1 : 0), TPB, 0, stream>>>((unsigned)n, (unsigned)pose_dim, cdiv(Nc, 28), cam_weight(), cams.p, pts.p, cams_bak.p, pts_bak.p, v_dx.p, scales.p, bu.p, (double)mu, rho_partial.p, pack.p, (use_records && xp.n && xp_valid) ? xp.p : nullptr,
                                                                                        nullptr, clear_state ? pcg_state() : PcgState{}, clear_state ? ctl_cap : 0, gate);
         seq = ++seq_counter;
@@ -2603,7 +2610,7 @@ template <typename T> struct Engine final : EngineBase {
         if (model) { // backup + Traits::update + the rho-denominator partials, then the trial linearisation: both wait for the loop's exit word
           rho_blocks = model->step_blocks;
           rho_partial.alloc(rho_blocks);
-          model_step(v_dx.p, /*with_backup=*/true, (double)mu, rho_partial.p, nullptr, gate);
+          model_step(v_dx.p, /*with_backup=*/true, (double)mu, rho_partial.p, nullptr, gate, /*clear_state=*/true);
         }
         linearize_deferred(gate);
       };
@@ -2618,7 +2625,7 @@ template <typename T> struct Engine final : EngineBase {
       int seq = 0;
       if (speculate) {
         if (!(ahead && trial_done)) enqueue_lin(nullptr);
-        fin_pending = true; pcg_state_clean = !model;
+        fin_pending = true; pcg_state_clean = true; // (built-in model: k_linearize's last workgroup; user traits: the step launch)
         seq = ++seq_counter;
         if (i + 1 < opt.iterations) {
           LmDecide dec;

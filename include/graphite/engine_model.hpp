@@ -394,6 +394,17 @@ __global__ void __launch_bounds__(256) k_em_step(gr_model_step_args a, slot_vert
   if (a.gate && !*a.gate) return;
   __shared__ double red[4];
   const T *dx = static_cast<const T *>(a.dx), *sc = static_cast<const T *>(a.scales), *bu = static_cast<const T *>(a.bu);
+#ifndef GR_NO_CLEAR
+  { // the library's loop-state reset (gr_model_step_args::clear_ptr): a few thousand words, spread over the launch
+    const uint32_t *const inf_hi = a.inf_word ? reinterpret_cast<const uint32_t *>(a.inf_word) + 1 : nullptr;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      uint32_t *const base = static_cast<uint32_t *>(a.clear_ptr[q]);
+      const long long nw = a.clear_bytes[q] / 4;
+      for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < nw; w += (long long)gridDim.x * 256) base[w] = (base + w == inf_hi) ? 0x7FF00000u : 0u;
+    }
+  }
+#endif
   double rho = 0;
   // (a fixed vertex keeps its value: no update — but its state IS saved, the revert restores every vertex)
   if ((int)blockIdx.x < nbc) {

@@ -91,6 +91,12 @@ typedef struct {
   const int32_t *gate;
   const unsigned char *cam_fixed, *pt_fixed;
   void *stream;
+  /* the library's inner-loop state reset riding in this launch (it used to be a launch of its own behind the step): zero the ranges
+     clear_ptr[i] .. + clear_bytes[i] (multiples of 4 bytes; 0 = none), except that the double at inf_word (inside one of them, or NULL)
+     becomes +infinity.  Under the same gate as the step itself. */
+  void *clear_ptr[3];
+  int64_t clear_bytes[3];
+  double *inf_word;
 } gr_model_step_args;
 
 typedef struct gr_model_ops {
