@@ -2177,7 +2177,7 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<int> coop_iters;
   volatile int *h_coop_fail = nullptr; // pinned, sticky
   bool sf_active = false;              // armed by lm()
-  bool schur_fused_ok(int max_iter) const { return !comm && !model && max_iter >= 1 && tune.schur_fused != 0 && tune.lm_fused != 0; }
+  bool schur_fused_ok(int max_iter) const { return !comm && max_iter >= 1 && tune.schur_fused != 0 && tune.lm_fused != 0; }
   // the whole PCG on S in one cooperative launch: one wave per camera row, all of them resident at once
   bool schur_coop() const { return Nc <= 2 * (int64_t)num_cu; }
   void ensure_coop(int max_iter) {
@@ -2237,11 +2237,14 @@ template <typename T> struct Engine final : EngineBase {
     }
     {
       const int nct = cdiv(pose_dim, 252);
-      rho_blocks = nct + nbp;
+      rho_blocks = model ? model->step_blocks : nct + nbp;
       rho_partial.alloc(rho_blocks);
       Scope sc(this, "backsub_apply", No * (27.0 * w() + 4) + (9.0 * Np + 3.0 * n + 24.0 * Nc) * w(), No * 54.0, true);
-      launch(k_backsub_apply<T>, rho_blocks, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, cams.p, pts.p, cams_bak.p, pts_bak.p, pack.p, mu, rho_partial.p, lm);
+      if (model) launch(k_backsub_apply<T, false>, nct + nbp, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, nullptr, nullptr, nullptr, nullptr, nullptr, mu, nullptr, lm);
+      else launch(k_backsub_apply<T>, rho_blocks, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, cams.p, pts.p, cams_bak.p, pts_bak.p, pack.p, mu, rho_partial.p, lm);
     }
+    // user-traits problems: the trial step through Traits::update, under the same decision (the damping of its rho partials from LmDev)
+    if (model) model_step(v_dx.p, /*with_backup=*/true, mu, rho_partial.p, lm, nullptr);
     xp_valid = false;
   }
   // the trial linearisation of the Schur solvers: k_linearize with the camera-point blocks, finalised by the next head
@@ -2703,8 +2706,8 @@ template <typename T> struct Engine final : EngineBase {
       // the loop ends here but the head of the next iteration is already running: if its PCG loop ended inside the head,
       // its last direction launch has applied a trial step nobody will judge — take it back
       GR_HIP(hipStreamSynchronize(stream));
-      // (Schur form: an accepted head always ends with its trial step; user-traits problems: the head applies none)
-      if (!model && (sf_active || flags()[0] == 2 || opt.pcg_max_iter == 1)) revert();
+      // (Schur form: an accepted head always ends with its trial step; matrix-free form on user traits: the head applies none)
+      if (sf_active || (!model && (flags()[0] == 2 || opt.pcg_max_iter == 1))) revert();
       head_enqueued = false;
     }
     if (fin_pending) flush_finalize();
@@ -2718,7 +2721,7 @@ template <typename T> struct Engine final : EngineBase {
     st.fused_messages = fused_messages - fused0;
     check_comm("levenberg_marquardt");
     if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] LM: %s; trial linearisation enqueued ahead of the PCG exit flag in %d iterations, not ahead in %d; next head enqueued behind the trial step in %d\n",
-                                   lm_fused ? "fused head / trial step" : "host loop", ahead_hits, ahead_misses, head_hits);
+                                   sf_active ? "Schur solver, device-decided head (finalisation, S, cooperative PCG, back-substitution, trial step)" : lm_fused ? "fused head / trial step" : "host loop", ahead_hits, ahead_misses, head_hits);
     if (profiling) flush_prof();
   }
 };

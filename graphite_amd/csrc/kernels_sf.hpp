@@ -532,7 +532,9 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
 // SchurComplement::compute_landmark_update (schur.hpp:279-302) + the trial step (graph.hpp:292-309, ops/update.hpp:11-31) +
 // compute_rho's denominator partials (levenberg_marquardt.hpp:34-41) + the camera packs: workgroups [0, nct) take 28 cameras each,
 // the others points, FIN_PL lanes per point over its observations (point-major order: a point's Hcp blocks are contiguous).
-template <typename T>
+// APPLY = false (user-traits problems): the landmark part of the step only — the trial step is the user's Traits::update
+// (gr_model_ops.step, the launch behind this one)
+template <typename T, bool APPLY = true>
 __global__ void __launch_bounds__(TPB)
 k_backsub_apply(int Nc, int Np, int nct, const int *__restrict__ pt_ptr, const int *__restrict__ cam_pm, const T *__restrict__ Hcp,
                 const T *__restrict__ Hll_inv, const T *__restrict__ bu, const T *__restrict__ scales, T *__restrict__ x /* [9 Nc + 3 Np]: xp in, xl out */,
@@ -544,6 +546,7 @@ k_backsub_apply(int Nc, int Np, int nct, const int *__restrict__ pt_ptr, const i
   const unsigned pose_dim = 9u * (unsigned)Nc;
   double rho = 0;
   if ((int)blockIdx.x < nct) {
+    if (!APPLY) return;
     const unsigned i = blockIdx.x * 252u + threadIdx.x;
     if (threadIdx.x < 252 && i < pose_dim) {
       const T d = x[i], s = scales[i], xo = cams[i];
@@ -594,6 +597,7 @@ k_backsub_apply(int Nc, int Np, int nct, const int *__restrict__ pt_ptr, const i
       for (int q = 0; q < 3; ++q) {
         const T d = inv[q] * r0 + inv[q + 3] * r1 + inv[q + 6] * r2;
         x[t0 + q] = d;
+        if (!APPLY) continue;
         const T xo = pts[3 * (size_t)l + q];
         pts_bak[3 * (size_t)l + q] = xo;
         pts[3 * (size_t)l + q] = xo + d * sv[q];
@@ -601,6 +605,7 @@ k_backsub_apply(int Nc, int Np, int nct, const int *__restrict__ pt_ptr, const i
       }
     }
   }
+  if (!APPLY) return;
   rho = block_sum_256(rho, red);
   if (threadIdx.x == 0) rho_partial[blockIdx.x] = rho;
 }

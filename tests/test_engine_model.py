@@ -121,6 +121,32 @@ def test_user_traits_run_on_the_engine_and_match_the_oracle(oracle_mod, tmp_path
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver,form", [("pcg", "fused head / trial step"), ("pcg-schur", "Schur solver, device-decided head")])
+@pytest.mark.parametrize("mode", ["weighted", "pinhole"])
+def test_user_traits_take_the_device_decided_loops(tmp_path, mode, solver, form):
+    """The LM loops whose accept decision is taken on the device (optimizer/levenberg_marquardt.hpp:184-233 as the prologue of the next
+    iteration's first launch) also run on user traits: the trial step is gr_model_ops.step — Traits::update under the device's gate /
+    decision — behind the loop-ending launch (matrix-free PCG) or behind the back-substitution (Schur PCG on a small reduced system).
+    Asserted: that form ran (the library's own report), and the host-driven form of the same loop gives the same chi2 trace — the
+    pinhole graph rejects steps on the way, so reverts and re-linearisations are compared too."""
+    f, _ = make_file(tmp_path, mode)
+    exe = build_all()[7]
+    def run(env):
+        e = dict(os.environ); e.pop("GRAPHITE_GENERIC_ONLY", None); e.pop("GRAPHITE_ENGINE", None)
+        e.update(env)
+        r = subprocess.run([exe, str(f), solver, "10", mode, "stored", "fp64"], capture_output=True, text=True, timeout=300, env=e)
+        assert r.returncode == 0, r.stderr[-800:]
+        return r
+    dev = run({"GR_VERBOSE": "1"})
+    assert form in dev.stderr, dev.stderr[-600:]
+    assert fields(dev.stdout)["ENGINE_MODEL_HANDOVERS"] == ["1"]
+    host = run({"GR_VERBOSE": "1", "GR_LM_FUSED": "0", "GR_SCHUR_FUSED": "0"})
+    assert "host loop" in host.stderr
+    a, b = parse_trace(dev.stdout), parse_trace(host.stdout)
+    assert len(a) == len(b) and np.allclose(a[:, 1], b[:, 1], rtol=1e-10) and np.allclose(a[:, 2], b[:, 2], rtol=1e-8)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["bal", "weighted"])
 def test_recomputed_jacobians_give_the_stored_iterates(oracle_mod, tmp_path, mode):
     """FactorDescriptor::set_jacobian_storage(false) (factor.hpp:626-640): the operator calls the user's jacobian<> per
