@@ -285,7 +285,7 @@ template <typename T> struct Engine final : EngineBase {
   struct View { T *p = nullptr; } bc, bl;
   DevBuf<double> chi2_partial, dscalars; // dscalars[0]=chi2, [1]=rho denom
   // Schur
-  DevBuf<int> prod_a, prod_b, S_rowi, S_coli, S_diag, row_ptr, row_blk, row_col;
+  DevBuf<int> prod_a, prod_b, prod_pm, S_rowi, S_coli, S_diag, row_ptr, row_blk, row_col;
   DevBuf<int> item_blk, item_beg, item_end, item_single, multi_blk;
   DevBuf<int> item_multi, multi_first, multi_n; // k_schur_reduce (kernels_sf.hpp)
   DevBuf<unsigned> multi_cnt;
@@ -801,12 +801,12 @@ template <typename T> struct Engine final : EngineBase {
       for (int a = h_pt_ptr[l]; a < h_pt_ptr[l + 1]; ++a)
         for (int b = a; b < h_pt_ptr[l + 1]; ++b) h_prod_ptr[map[(size_t)h_cam_pm[b] * Nc + h_cam_pm[a]] + 1]++;
     for (int64_t q = 0; q < nnzb; ++q) h_prod_ptr[q + 1] += h_prod_ptr[q];
-    std::vector<int> h_prod_a(nprod), h_prod_b(nprod), w(h_prod_ptr.begin(), h_prod_ptr.end() - 1);
+    std::vector<int> h_prod_a(nprod), h_prod_b(nprod), h_prod_pm(nprod), w(h_prod_ptr.begin(), h_prod_ptr.end() - 1);
     for (int64_t l = 0; l < Np; ++l)
       for (int a = h_pt_ptr[l]; a < h_pt_ptr[l + 1]; ++a)
         for (int b = a; b < h_pt_ptr[l + 1]; ++b) {
           const int q = w[map[(size_t)h_cam_pm[b] * Nc + h_cam_pm[a]]]++;
-          h_prod_a[q] = a; h_prod_b[q] = b;
+          h_prod_a[q] = a; h_prod_b[q] = b; h_prod_pm[q] = (int)l;
         }
     // work items: <= `isz` products of one block per wave (7 lane groups, so a multiple of 7).  Measured on
     // Ladybug-49 (82 K products over 1 225 blocks): 7 / 14 / 28 / 56 / 84 / 112 / 168 / 336 products per item ->
@@ -857,7 +857,7 @@ template <typename T> struct Engine final : EngineBase {
     }
     item_blk.upload(h_item_blk, stream); item_beg.upload(h_item_beg, stream); item_end.upload(h_item_end, stream);
     item_single.upload(h_item_single, stream); multi_blk.upload(h_multi, stream);
-    prod_a.upload(h_prod_a, stream); prod_b.upload(h_prod_b, stream);
+    prod_a.upload(h_prod_a, stream); prod_b.upload(h_prod_b, stream); prod_pm.upload(h_prod_pm, stream);
     S_rowi.upload(h_S_rowi, stream); S_coli.upload(h_S_coli, stream); S_diag.upload(h_S_diag, stream);
     row_ptr.upload(h_row_ptr, stream); row_blk.upload(h_row_blk, stream); row_col.upload(h_row_col, stream);
     S.alloc(81 * (size_t)nnzb); b_schur.alloc(pose_dim);
@@ -1290,7 +1290,7 @@ template <typename T> struct Engine final : EngineBase {
     Scope sc(this, "schur_products", nprod * (54.0 * w() + 8) + 9.0 * Np * w() + 81.0 * nnzb * w() + No * (27.0 * w() + 8) + 3.0 * Np * w(), nprod * 342.0 + No * 54.0, true);
     const int nwg_items = cdiv(nitems, 4);
     launch(k_schur_reduce<T>, nwg_items + cdiv(nch, 4), nitems, nwg_items, item_blk.p, item_beg.p, item_end.p, item_multi.p, multi_first.p, multi_n.p, multi_cnt.p, slab.p,
-           prod_a.p, prod_b.p, S_rowi.p, S_coli.p, pt_pm.p, Hcp.p, Mp.p, hcc_w, scales.p, mu, ui, S.p, nch, chunk_beg.p, pt_cm.p, pos_cm.p, vl.p, part9.p, lm);
+           prod_a.p, prod_b.p, S_rowi.p, S_coli.p, prod_pm.p, Hcp.p, Mp.p, hcc_w, scales.p, mu, ui, S.p, nch, chunk_beg.p, pt_cm.p, pos_cm.p, vl.p, part9.p, lm);
   }
   // replicated reduced solves: rank 0's camera step is the one every rank applies (the per-rank copies agree
   // only up to the order of the atomic dot-product partials, which must not leak into the replicated cameras)
