@@ -33,11 +33,13 @@
 namespace gr {
 
 constexpr size_t SP_TT = (size_t)CH_NB * CH_NB; // scalars per tile
+constexpr int SP_PT = 512; // threads of the stand-alone diagonal-tile factorisation: eight waves share the trailing updates / inverse rows
+                           // beside wave 0's chain (tools/potrf_bench.hip: others' share 28 -> 21 us; the chain itself is 26 us either way)
 template <typename T>
-__global__ __launch_bounds__(CH_PT) void k_sp_potrf(T *__restrict__ A, const int *__restrict__ panels, const int *__restrict__ dslot, T *__restrict__ Linv, int *__restrict__ fail) {
+__global__ __launch_bounds__(SP_PT) void k_sp_potrf(T *__restrict__ A, const int *__restrict__ panels, const int *__restrict__ dslot, T *__restrict__ Linv, int *__restrict__ fail) {
   extern __shared__ __align__(16) unsigned char ch_smem[];
   const int k = panels[blockIdx.x];
-  chol_potrf_block<T>(reinterpret_cast<T *>(ch_smem), A + (size_t)dslot[k] * SP_TT, CH_NB, Linv + (size_t)k * CH_NB * CH_NB, fail, true, 0);
+  chol_potrf_block<T, SP_PT>(reinterpret_cast<T *>(ch_smem), A + (size_t)dslot[k] * SP_TT, CH_NB, Linv + (size_t)k * CH_NB * CH_NB, fail, true, 0);
 }
 
 // MODE 0: L_ik = A_ik Linv_k^T for tiles[2b] = slot(i, k), tiles[2b+1] = k                       (panel solve, in place)
@@ -664,7 +666,7 @@ template <typename T> struct SparseChol {
       const int np_ = lvl_panel_off[l + 1] - lvl_panel_off[l], ntr = lvl_trsm_off[l + 1] - lvl_trsm_off[l], nup = lvl_upd_off[l + 1] - lvl_upd_off[l];
       if (l == 0 || !fuse_potrf) { // deeper levels: factorised by the previous level's update launch
         Sc sc(sink, "spchol_potrf", 3.0 * np_ * tb, np_ * tf / 3);
-        k_sp_potrf<T><<<np_, CH_PT, lds_p, stream>>>(A.p, d_panels.p + lvl_panel_off[l], d_dslot.p, Linv.p, d_fail.p);
+        k_sp_potrf<T><<<np_, SP_PT, lds_p, stream>>>(A.p, d_panels.p + lvl_panel_off[l], d_dslot.p, Linv.p, d_fail.p);
       }
       if (ntr) {
         Sc sc(sink, "spchol_trsm", 3.0 * ntr * tb, ntr * tf);
