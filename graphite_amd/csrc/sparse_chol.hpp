@@ -162,15 +162,141 @@ __device__ __forceinline__ void sp_tile_product(T *__restrict__ sm, T *__restric
       for (int r = 0; r < 4; ++r)
         Cg[(size_t)(wr * 64 + mi * 16 + M::row(lane, r)) * ld2 + wc * 64 + ni * 16 + ccol] = acc[mi][ni][r];
 }
+// QUADRANT form of the update of a diagonal tile whose LAST update this is (round 5).  The upper levels of the tree
+// are one tile column each: their update launch is as long as the ONE workgroup that accumulates the next diagonal tile (K = 128:
+// 14 us of MFMA on one CU at the peak, 24 us measured with its loads) and then factorises it (34 us).  Here that tile's lower three
+// 64 x 64 quadrants go to three workgroups — two helpers that update quadrants (1, 0) and (1, 1) in place (written through) and arrive
+// at the tile's counter, and the factorising workgroup, which takes quadrant (0, 0) straight into its LDS image, waits for the counter,
+// fetches the other two quadrants and factorises.  Each workgroup: 2 x 2 waves of 32 x 32 outputs, K in chunks of 16 through LDS.
+// The helpers precede their factorising workgroup in the launch (lower block index: dispatched no later), and wait for nothing.
+constexpr int SP_QUAD_BIT = 1 << 29;   // tiles[2 b] flag: a quadrant entry; with SP_FUSE_BIT: quadrant (0, 0) + the factorisation
+constexpr int SP_QUAD_SHIFT = 27;      // bits 27-28: 1 = quadrant (1, 0), 2 = quadrant (1, 1)
+constexpr int SP_SLOT_MASK = (1 << SP_QUAD_SHIFT) - 1;
+constexpr int SP_QP = 64 + 4;          // LDS pitch of the [k][row] quadrant operand images
+constexpr size_t sp_quad_lds(size_t w) { return (size_t)2 * 2 * CH_KC * SP_QP * w; }
+// acc (out): C[qi * 64 + wr * 32 + mi * 16 + row(lane, r)][qj * 64 + wc * 32 + ni * 16 + (lane & 15)] after C -= sum_k P_k Q_k^T
+template <typename T>
+__device__ __forceinline__ void sp_quad_product(T *__restrict__ sm, const T *__restrict__ A, const T *__restrict__ Cg, const int *__restrict__ kl, int nk, int qi, int qj,
+                                                typename MfmaTile<T>::acc_t (&acc)[2][2]) {
+  using M = MfmaTile<T>;
+  constexpr int KC = CH_KC, CPP = CH_NB / KC, ld = CH_NB;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1, ccol = lane & 15;
+  const int nch = CPP * nk;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mi][ni][r] = Cg[(size_t)(qi * 64 + wr * 32 + mi * 16 + M::row(lane, r)) * ld + qj * 64 + wc * 32 + ni * 16 + ccol];
+  // loaders: threads 0..127 fetch P (64 rows x 16 k: row t / 2, eight k's), threads 128..255 fetch Q
+  const bool isq = t >= 128;
+  const int lr = (t & 127) >> 1, lk = (t & 1) * 8;
+  auto src = [&](int c) -> const T * {
+    const int slot = kl[2 * (c / CPP) + (isq ? 1 : 0)];
+    return A + (size_t)slot * SP_TT + (size_t)((isq ? qj : qi) * 64 + lr) * ld + (c % CPP) * KC + lk;
+  };
+  T v[8];
+  auto stage = [&](int buf) {
+    T *dst = sm + (size_t)buf * 2 * KC * SP_QP + (isq ? KC * SP_QP : 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[(lk + e) * SP_QP + lr] = isq ? v[e] : -v[e];
+  };
+  load8<T>(src(0), v);
+  stage(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) load8<T>(src(c + 1), v);
+    const T *Ps = sm + (size_t)(c & 1) * 2 * KC * SP_QP, *Qs = Ps + KC * SP_QP;
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      const int krow = (kk * 4 + (lane >> 4)) * SP_QP + ccol;
+      T a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { a[i] = Ps[krow + wr * 32 + i * 16]; b[i] = Qs[krow + wc * 32 + i * 16]; }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = M::mma(a[mi], b[ni], acc[mi][ni]);
+    }
+    if (c + 1 < nch) stage((c + 1) & 1);
+    __syncthreads();
+  }
+}
+// one quadrant entry of an update launch (see above).  qcnt: one arrival counter per tile column, zero between uses.
+template <typename T>
+__device__ __forceinline__ void sp_quad_entry(T *__restrict__ sm, T *__restrict__ A, int cs_raw, int tj, const int *__restrict__ kl, int nk,
+                                              T *__restrict__ Linv, unsigned *__restrict__ qcnt, int *__restrict__ fail) {
+  using M = MfmaTile<T>;
+  typename M::acc_t acc[2][2];
+  T *Cg = A + (size_t)(cs_raw & SP_SLOT_MASK) * SP_TT;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1, ccol = lane & 15;
+  const bool fuse = (cs_raw & SP_FUSE_BIT) != 0;
+  const int q = (cs_raw >> SP_QUAD_SHIFT) & 3, qi = fuse ? 0 : 1, qj = fuse ? 0 : q - 1;
+  sp_quad_product<T>(sm, A, Cg, kl, nk, qi, qj, acc);
+  if (!fuse) { // helper: the quadrant in place, written through; then the arrival
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __hip_atomic_store(&Cg[(size_t)(qi * 64 + wr * 32 + mi * 16 + M::row(lane, r)) * CH_NB + qj * 64 + wc * 32 + ni * 16 + ccol], acc[mi][ni][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_fetch_add(&qcnt[tj], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // factorising workgroup: quadrant (0, 0) from the accumulators, (0, 1) zero, (1, 0) and (1, 1) from the helpers
+  T *L = sm; // (every wave is past the barrier that ends the K loop: the operand images are free)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * 32 + mi * 16 + M::row(lane, r), col = wc * 32 + ni * 16 + ccol;
+        L[row * CH_LP + col] = col <= row ? acc[mi][ni][r] : T(0);
+      }
+  for (int e = t; e < 64 * 64; e += 256) L[(e >> 6) * CH_LP + 64 + (e & 63)] = T(0);
+  if (t == 0) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(&qcnt[tj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > 200000000ll) { *fail = 1; break; } // 2 s: the helpers never ran (reported as a failed factorisation)
+    }
+    __hip_atomic_store(&qcnt[tj], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int base = 0; base < 64 * 128; base += 256 * 8) { // eight requests of a thread in flight (one at a time: 32 round trips to L2)
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = base + u * 256 + t, row = 64 + (e >> 7), col = e & 127;
+      v[u] = col <= row ? __hip_atomic_load(&Cg[(size_t)row * CH_NB + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = base + u * 256 + t, row = 64 + (e >> 7), col = e & 127;
+      L[row * CH_LP + col] = v[u];
+    }
+  }
+  chol_potrf_block<T>(L, Cg, CH_NB, Linv + (size_t)tj * SP_TT, fail, false, 0);
+}
 // the level-scheduled launches:
 // MODE 0: L_ik = A_ik Linv_k^T for tiles[2b] = slot(i, k), tiles[2b+1] = k                       (panel solve, in place)
 // MODE 1: A_ij -= sum_{k in list(b)} L_ik L_jk^T, tiles[2b] = slot(i, j) [| FUSE bit], tiles[2b+1] = i,
 //         list(b) = klist[2 q], klist[2 q + 1] = slot(i, k), slot(j, k) for q in kptr[b] .. kptr[b+1])
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_sp_gemm(T *__restrict__ A, const int *__restrict__ tiles, const int *__restrict__ kptr, const int *__restrict__ klist,
-                                                 const T *__restrict__ Linv, T *__restrict__ Linv_out = nullptr, int *__restrict__ fail = nullptr) {
+                                                 const T *__restrict__ Linv, T *__restrict__ Linv_out = nullptr, int *__restrict__ fail = nullptr, unsigned *__restrict__ qcnt = nullptr) {
   extern __shared__ __align__(16) unsigned char ch_smem[];
   const int cs_raw = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1]; // MODE 0: tj = panel k; MODE 1: tj = tile row / column of a diagonal target
+  if (MODE == 1 && (cs_raw & SP_QUAD_BIT)) {
+    sp_quad_entry<T>(reinterpret_cast<T *>(ch_smem), A, cs_raw, tj, klist + 2 * (size_t)kptr[blockIdx.x], kptr[blockIdx.x + 1] - kptr[blockIdx.x], Linv_out, qcnt, fail);
+    return;
+  }
   const bool fuse = MODE == 1 && (cs_raw & SP_FUSE_BIT) != 0;
   sp_tile_product<T, MODE>(reinterpret_cast<T *>(ch_smem), A, A + (size_t)(cs_raw & ~SP_FUSE_BIT) * SP_TT,
                            MODE == 1 ? klist + 2 * (size_t)kptr[blockIdx.x] : nullptr, MODE == 1 ? kptr[blockIdx.x + 1] - kptr[blockIdx.x] : 0,
@@ -371,13 +497,18 @@ __global__ __launch_bounds__(256) void k_sp_fwd(const T *__restrict__ A, const T
 template <typename T>
 __global__ __launch_bounds__(256) void k_sp_update_fwd(T *A, const int *__restrict__ tiles, const int *__restrict__ kptr, const int *__restrict__ klist,
                                                        T *Linv, int *__restrict__ fail, int nup, SpItems it, const int *__restrict__ rcols,
-                                                       const int *__restrict__ rslot, const T *__restrict__ b, T *y, T *__restrict__ partial, unsigned *__restrict__ ticket) {
+                                                       const int *__restrict__ rslot, const T *__restrict__ b, T *y, T *__restrict__ partial, unsigned *__restrict__ ticket,
+                                                       unsigned *__restrict__ qcnt) {
   extern __shared__ __align__(16) unsigned char ch_smem[];
   if ((int)blockIdx.x >= nup) {
     sp_fwd_item<T>(reinterpret_cast<T *>(ch_smem), (int)blockIdx.x - nup, A, Linv, it, rcols, rslot, b, y, partial, ticket);
     return;
   }
   const int cs_raw = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
+  if (cs_raw & SP_QUAD_BIT) {
+    sp_quad_entry<T>(reinterpret_cast<T *>(ch_smem), A, cs_raw, tj, klist + 2 * (size_t)kptr[blockIdx.x], kptr[blockIdx.x + 1] - kptr[blockIdx.x], Linv, qcnt, fail);
+    return;
+  }
   const bool fuse = (cs_raw & SP_FUSE_BIT) != 0;
   sp_tile_product<T, 1>(reinterpret_cast<T *>(ch_smem), A, A + (size_t)(cs_raw & ~SP_FUSE_BIT) * SP_TT, klist + 2 * (size_t)kptr[blockIdx.x],
                         kptr[blockIdx.x + 1] - kptr[blockIdx.x], nullptr, fuse, fuse ? Linv + (size_t)tj * SP_TT : nullptr, fail);
@@ -445,6 +576,10 @@ template <typename T> struct SparseChol {
   bool attrs_set = false;
   static constexpr int LEAF = 56; // cameras per leaf supernode: 504 columns = 4 tiles (8 padding columns)
   bool fuse_potrf = true; // gr_bal_tuning.spchol_fuse: the next level's diagonal tiles factorised inside this level's update launch
+  bool fuse_quads = true; // ... and that tile's update spread over three workgroups by quadrant (spchol_fuse = 2; 1: one workgroup)
+  int quad_max_targets = 1 << 30; // levels with more update targets would keep the one-workgroup form (measured: 64 / 128 / 256 / all -> 364 / 366 / 368 / 367 LM it/s: all)
+  DevBuf<unsigned> d_qcnt; // [nt] arrivals of the quadrant helpers, zero between uses
+  std::vector<double> lvl_upd_tiles; // tile products per level's update launch (a quadrant entry counts a quarter per source)
   int slice = 1;          // gr_bal_tuning.spchol_slice: tiles per substitution work item
   bool row_split_trsm = true; // panel solves by 32-row slabs (k_sp_trsm_rows)
 
@@ -573,9 +708,10 @@ template <typename T> struct SparseChol {
     for (int k = 0; k < nt; ++k) dslot[k] = slot(k, k);
     std::vector<int> h_panels, h_trsm, h_upd, h_klist;
     h_kptr.assign(1, 0);
-    lvl_panel_off.assign(1, 0); lvl_trsm_off.assign(1, 0); lvl_upd_off.assign(1, 0);
+    lvl_panel_off.assign(1, 0); lvl_trsm_off.assign(1, 0); lvl_upd_off.assign(1, 0); lvl_upd_tiles.clear();
     for (int l = 0; l < nlevels; ++l) {
       std::map<std::pair<int, int>, std::vector<int>> targets;
+      double tiles_l = 0;
       for (int k : by_level[l]) {
         h_panels.push_back(k);
         for (int i : U[k]) { h_trsm.push_back(slot(i, k)); h_trsm.push_back(k); }
@@ -588,13 +724,25 @@ template <typename T> struct SparseChol {
           const int ti = tg.first.first, tj = tg.first.second;
           const bool diag_next = fuse_potrf && ti == tj && level[ti] == l + 1;
           if (diag_next != (pass == 0)) continue;
-          h_upd.push_back(slot(ti, tj) | (diag_next ? SP_FUSE_BIT : 0)); h_upd.push_back(ti);
-          for (int k : tg.second) { h_klist.push_back(slot(ti, k)); h_klist.push_back(slot(tj, k)); }
-          h_kptr.push_back((int)(h_klist.size() / 2));
+          auto entry = [&](int head) {
+            h_upd.push_back(head); h_upd.push_back(ti);
+            for (int k : tg.second) { h_klist.push_back(slot(ti, k)); h_klist.push_back(slot(tj, k)); }
+            h_kptr.push_back((int)(h_klist.size() / 2));
+          };
+          if (diag_next && fuse_quads && (int)targets.size() <= quad_max_targets) { // helpers first: a lower block index is dispatched no later than its factorising workgroup
+            entry(slot(ti, tj) | SP_QUAD_BIT | (1 << SP_QUAD_SHIFT));
+            entry(slot(ti, tj) | SP_QUAD_BIT | (2 << SP_QUAD_SHIFT));
+            entry(slot(ti, tj) | SP_QUAD_BIT | SP_FUSE_BIT);
+            tiles_l += 0.75 * tg.second.size();
+          } else {
+            entry(slot(ti, tj) | (diag_next ? SP_FUSE_BIT : 0));
+            tiles_l += 1.0 * tg.second.size();
+          }
         }
       lvl_panel_off.push_back((int)h_panels.size());
       lvl_trsm_off.push_back((int)(h_trsm.size() / 2));
       lvl_upd_off.push_back((int)(h_upd.size() / 2));
+      lvl_upd_tiles.push_back(tiles_l);
     }
     // row structure (forward substitution) and column structure (backward), cut into items of <= slice tiles
     std::vector<int> h_rptr(nt + 1, 0), h_rcols, h_rslot, h_cptr(nt + 1, 0), h_crows, h_cslot;
@@ -625,6 +773,7 @@ template <typename T> struct SparseChol {
     d_kptr.upload(h_kptr, stream); d_rptr.upload(h_rptr, stream); up(d_rcols, h_rcols); d_cptr.upload(h_cptr, stream); up(d_crows, h_crows);
     up(d_rslot, h_rslot); up(d_cslot, h_cslot); d_tmap.upload(tmap, stream); d_dslot.upload(dslot, stream);
     d_camcol.upload(camcol, stream); d_src.upload(src, stream); d_pad.upload(pad, stream);
+    d_qcnt.alloc(nt); d_qcnt.zero(stream);
     d_fail.alloc(1); // the matrix itself (bytes()) is allocated by allocate(), once the caller has decided to use this solver
     if (!h_fail) GR_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_fail), sizeof(int), hipHostMallocDefault));
     if (!attrs_set) {
@@ -675,11 +824,11 @@ template <typename T> struct SparseChol {
       }
       const int nf = ride_fwd ? lvl_fitem_off[l + 1] - lvl_fitem_off[l] : 0;
       if (nup) {
-        const int nk = h_kptr[lvl_upd_off[l + 1]] - h_kptr[lvl_upd_off[l]];
+        const double nk = lvl_upd_tiles[l];
         Sc sc(sink, "spchol_update", (2.0 * nup + 2.0 * nk) * tb, nk * tf);
         if (nf) k_sp_update_fwd<T><<<nup + nf, 256, std::max(lds_g, lds_p), stream>>>(A.p, d_upd.p + 2 * (size_t)lvl_upd_off[l], d_kptr.p + lvl_upd_off[l], d_klist.p, Linv.p, d_fail.p, nup,
-                                                                                     items(d_itf, lvl_fitem_off[l]), d_rcols.p, d_rslot.p, vb.p, vy.p, partial.p, ticket.p);
-        else k_sp_gemm<T, 1><<<nup, 256, std::max(lds_g, lds_p), stream>>>(A.p, d_upd.p + 2 * (size_t)lvl_upd_off[l], d_kptr.p + lvl_upd_off[l], d_klist.p, nullptr, Linv.p, d_fail.p);
+                                                                                     items(d_itf, lvl_fitem_off[l]), d_rcols.p, d_rslot.p, vb.p, vy.p, partial.p, ticket.p, d_qcnt.p);
+        else k_sp_gemm<T, 1><<<nup, 256, std::max(lds_g, lds_p), stream>>>(A.p, d_upd.p + 2 * (size_t)lvl_upd_off[l], d_kptr.p + lvl_upd_off[l], d_klist.p, nullptr, Linv.p, d_fail.p, d_qcnt.p);
       } else if (nf) k_sp_fwd<T><<<nf, 256, 0, stream>>>(A.p, Linv.p, items(d_itf, lvl_fitem_off[l]), d_rcols.p, d_rslot.p, vb.p, vy.p, partial.p, ticket.p);
       // level l's panels (L_kk^-1, trsm'ed sub-diagonal tiles) are final here; what the update launch above still writes are
       // tiles of LATER columns

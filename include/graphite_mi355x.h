@@ -144,7 +144,7 @@ typedef struct {
                                    pushed / awaited / summed as if V ranks took part (V slots of the own mailbox)                    */
   int32_t chol_fuse;            /* GR_CHOL_FUSE      1: dense tile Cholesky factorises the next diagonal tile inside the trailing update   */
   int32_t chol_pin;             /* GR_CHOL_PIN       1: its C tile parked in VGPRs (one workgroup per CU in fp64)                          */
-  int32_t spchol_fuse;          /* GR_SPCHOL_FUSE    1: the same fusion in the nested-dissection form                                      */
+  int32_t spchol_fuse;          /* GR_SPCHOL_FUSE    1: the same fusion in the nested-dissection form; 2 (default): that tile's update by quadrants on three workgroups */
   int32_t spchol_slice;         /* GR_SPCHOL_SLICE   1: tiles per work item of its triangular solves                                       */
   int32_t schur_fused;          /* GR_SCHUR_FUSED   -1 auto | 0 | 1: GR_SOLVER_PCG_SCHUR — S and the b_S partials in ONE launch whose multi-item
                                    blocks are finished by their last arriver (no float atomics), and, where the reduced system is small
