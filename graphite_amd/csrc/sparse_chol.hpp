@@ -170,8 +170,9 @@ __device__ __forceinline__ void sp_tile_product(T *__restrict__ sm, T *__restric
 // fetches the other two quadrants and factorises.  Each workgroup: 2 x 2 waves of 32 x 32 outputs, K in chunks of 16 through LDS.
 // The helpers precede their factorising workgroup in the launch (lower block index: dispatched no later), and wait for nothing.
 constexpr int SP_QUAD_BIT = 1 << 29;   // tiles[2 b] flag: a quadrant entry; with SP_FUSE_BIT: quadrant (0, 0) + the factorisation
-constexpr int SP_QUAD_SHIFT = 27;      // bits 27-28: 1 = quadrant (1, 0), 2 = quadrant (1, 1)
-constexpr int SP_SLOT_MASK = (1 << SP_QUAD_SHIFT) - 1;
+constexpr int SP_QUAD_SHIFT = 27;      // bits 27-28: the quadrant, 2 * (row half) + (column half)
+constexpr int SP_QHELP_BIT = 1 << 26;  // the quadrant is written through and its workgroup arrives at the tile's counter (helper of a factorising workgroup)
+constexpr int SP_SLOT_MASK = SP_QHELP_BIT - 1;
 constexpr int SP_QP = 64 + 4;          // LDS pitch of the [k][row] quadrant operand images
 constexpr size_t sp_quad_lds(size_t w) { return (size_t)2 * 2 * CH_KC * SP_QP * w; }
 // acc (out): C[qi * 64 + wr * 32 + mi * 16 + row(lane, r)][qj * 64 + wc * 32 + ni * 16 + (lane & 15)] after C -= sum_k P_k Q_k^T
@@ -231,9 +232,18 @@ __device__ __forceinline__ void sp_quad_entry(T *__restrict__ sm, T *__restrict_
   typename M::acc_t acc[2][2];
   T *Cg = A + (size_t)(cs_raw & SP_SLOT_MASK) * SP_TT;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1, ccol = lane & 15;
-  const bool fuse = (cs_raw & SP_FUSE_BIT) != 0;
-  const int q = (cs_raw >> SP_QUAD_SHIFT) & 3, qi = fuse ? 0 : 1, qj = fuse ? 0 : q - 1;
+  const bool fuse = (cs_raw & SP_FUSE_BIT) != 0, help = (cs_raw & SP_QHELP_BIT) != 0;
+  const int q = (cs_raw >> SP_QUAD_SHIFT) & 3, qi = q >> 1, qj = q & 1;
   sp_quad_product<T>(sm, A, Cg, kl, nk, qi, qj, acc);
+  if (!fuse && !help) { // a quadrant of an ordinary target: plain stores (the launch boundary publishes them)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cg[(size_t)(qi * 64 + wr * 32 + mi * 16 + M::row(lane, r)) * CH_NB + qj * 64 + wc * 32 + ni * 16 + ccol] = acc[mi][ni][r];
+    return;
+  }
   if (!fuse) { // helper: the quadrant in place, written through; then the arrival
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -730,11 +740,13 @@ template <typename T> struct SparseChol {
             h_kptr.push_back((int)(h_klist.size() / 2));
           };
           if (diag_next && fuse_quads && (int)targets.size() <= quad_max_targets) { // helpers first: a lower block index is dispatched no later than its factorising workgroup
-            entry(slot(ti, tj) | SP_QUAD_BIT | (1 << SP_QUAD_SHIFT));
-            entry(slot(ti, tj) | SP_QUAD_BIT | (2 << SP_QUAD_SHIFT));
+            entry(slot(ti, tj) | SP_QUAD_BIT | SP_QHELP_BIT | (2 << SP_QUAD_SHIFT));
+            entry(slot(ti, tj) | SP_QUAD_BIT | SP_QHELP_BIT | (3 << SP_QUAD_SHIFT));
             entry(slot(ti, tj) | SP_QUAD_BIT | SP_FUSE_BIT);
             tiles_l += 0.75 * tg.second.size();
           } else {
+            // (measured, not kept: EVERY target by quadrants — four small workgroups instead of one 128 x 128 one: 352 vs 362 LM it/s.  The
+            // launch's LDS size is the factorising workgroups' 132 KB for every workgroup, so the small ones do not share a CU either.)
             entry(slot(ti, tj) | (diag_next ? SP_FUSE_BIT : 0));
             tiles_l += 1.0 * tg.second.size();
           }
