@@ -1425,7 +1425,7 @@ template <typename T> struct Engine final : EngineBase {
     if (chol_ready) return;
     {
       const int force = tune.sparse_cholesky;
-      spchol.fuse_potrf = tune.spchol_fuse != 0; spchol.fuse_quads = tune.spchol_fuse >= 2; spchol.slice = std::max(1, tune.spchol_slice); spchol.overlap_form = tune.spchol_overlap == 2 ? 2 : 1;
+      spchol.fuse_potrf = tune.spchol_fuse != 0; spchol.fuse_quads = tune.spchol_fuse >= 2; spchol.bwd_chain = !(getenv("GR_SPCHOL_BWD_CHAIN") && atoi(getenv("GR_SPCHOL_BWD_CHAIN")) == 0); spchol.slice = std::max(1, tune.spchol_slice); spchol.overlap_form = tune.spchol_overlap == 2 ? 2 : 1;
       chol.fuse_potrf = tune.chol_fuse != 0; chol.pin_variant = tune.chol_pin;
       // what either form may take: 3/4 of the free HBM (the factor is the largest single allocation of the direct solvers)
       size_t mem_free = 0, mem_total = 0;

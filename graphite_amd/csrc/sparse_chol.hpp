@@ -564,6 +564,81 @@ __global__ __launch_bounds__(256) void k_sp_bwd(const T *__restrict__ A, const T
   if (h == 0) x[k * CH_NB + c] = s2 + half[c];
 }
 
+// Backward substitution as ONE dependency-driven launch (round 5).  The level-by-level form is 21 launches of 10-12 us on Ladybug-1723 —
+// each a chain launch floor -> cold read of the level's L tiles -> partial sums -> ticket -> read of Linv_k -> x_k — for a handful of
+// workgroups per level: 240 us of a 2.7 ms LM iteration.  Here every work item is a workgroup of one launch, in the level order the
+// launches had (top of the tree first: a workgroup only ever waits for workgroups with a LOWER block index, which are resident or done):
+//   item (panel k, tile (i, k)) : fetches its 128 x 128 tile into REGISTERS at once (64 scalars per thread), only then waits for x_i
+//                                 (ready[i] == seq), forms L_ik^T x_i, leaves its 128 partial sums (written through) and arrives at cnt[k];
+//   finisher (panel k)          : fetches Linv_k into registers, waits for the panel's items, adds their partial sums in item order,
+//                                 x_k = Linv_k^T (y_k - sum), written through, then ready[k] = seq.
+// What crosses workgroups is written through and drained before the arrival / the ready word and read back with agent-scope loads
+// (cdna_hip_programming.md G16, form R1).  The tiles of the factor are final before the launch: plain loads.  Same products, same order of
+// additions as k_sp_bwd: same bits.
+struct SpChain { const int *kind_panel, *row, *slot, *idx; const int *pfirst, *pcount; }; // per entry: (finisher ? ~k : k), tile row i, tile slot, item index in its panel; per panel: first partial row, items
+template <typename T>
+__global__ __launch_bounds__(256) void k_sp_bwd_chain(const T *__restrict__ A, const T *__restrict__ Linv, SpChain ch, const T *__restrict__ y, T *x, T *partial,
+                                                      unsigned *cnt, unsigned *ready, unsigned seq, int *__restrict__ fail) {
+  __shared__ T xs[CH_NB];
+  __shared__ T half[CH_NB];
+  const int e = blockIdx.x, kp = ch.kind_panel[e];
+  const bool finisher = kp < 0;
+  const int k = finisher ? ~kp : kp;
+  const int t = threadIdx.x, c = t & 127, h = t >> 7;
+  auto wait_for = [&](unsigned *word, unsigned want, bool at_least) {
+    if (t == 0) {
+      const long long t0 = wall_clock64();
+      for (;;) {
+        const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (at_least ? v >= want : v == want) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 200000000ll) { *fail = 1; break; } // 2 s: an earlier workgroup never ran (reported as a failed factorisation)
+      }
+    }
+    __syncthreads();
+  };
+  T Lr[64];
+  const T *Lg = (finisher ? Linv + (size_t)k * SP_TT : A + (size_t)ch.slot[e] * SP_TT) + (size_t)(h * 64) * CH_NB + c;
+#pragma unroll
+  for (int r = 0; r < 64; ++r) Lr[r] = Lg[(size_t)r * CH_NB];
+  if (!finisher) {
+    const int i = ch.row[e];
+    wait_for(&ready[i], seq, false);
+    if (t < CH_NB) xs[t] = __hip_atomic_load(&x[i * CH_NB + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    T s = T(0);
+#pragma unroll
+    for (int r = 0; r < 64; ++r) s += Lr[r] * xs[h * 64 + r];
+    if (h == 1) half[c] = s;
+    __syncthreads();
+    if (h == 0) __hip_atomic_store(&partial[(size_t)(ch.pfirst[k] + ch.idx[e]) * CH_NB + c], s + half[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_fetch_add(&cnt[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int n = ch.pcount[k];
+  if (n > 0) {
+    wait_for(&cnt[k], (unsigned)n, true);
+    if (t == 0) __hip_atomic_store(&cnt[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (t < CH_NB) {
+    T s = T(0);
+    for (int q = 0; q < n; ++q) s += __hip_atomic_load(&partial[(size_t)(ch.pfirst[k] + q) * CH_NB + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xs[t] = y[k * CH_NB + t] - s;
+  }
+  __syncthreads();
+  T s2 = T(0);
+#pragma unroll
+  for (int r = 0; r < 64; ++r) s2 += Lr[r] * xs[h * 64 + r];
+  if (h == 1) half[c] = s2;
+  __syncthreads();
+  if (h == 0) __hip_atomic_store(&x[k * CH_NB + c], s2 + half[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(&ready[k], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename T> struct SparseChol {
   hipStream_t stream = nullptr;
   int n = 0, npad = 0, nt = 0, nlevels = 0, nsuper = 0;
@@ -588,6 +663,12 @@ template <typename T> struct SparseChol {
   bool fuse_potrf = true; // gr_bal_tuning.spchol_fuse: the next level's diagonal tiles factorised inside this level's update launch
   bool fuse_quads = true; // ... and that tile's update spread over three workgroups by quadrant (spchol_fuse = 2; 1: one workgroup)
   int quad_max_targets = 1 << 30; // levels with more update targets would keep the one-workgroup form (measured: 64 / 128 / 256 / all -> 364 / 366 / 368 / 367 LM it/s: all)
+  // backward substitution as one dependency-driven launch (k_sp_bwd_chain; gr_bal_tuning.spchol_overlap = 3 keeps the level launches)
+  DevBuf<int> d_ch[6];
+  DevBuf<unsigned> d_bcnt, d_ready;
+  int chain_entries = 0;
+  unsigned chain_seq = 0;
+  bool bwd_chain = true;
   DevBuf<unsigned> d_qcnt; // [nt] arrivals of the quadrant helpers, zero between uses
   std::vector<double> lvl_upd_tiles; // tile products per level's update launch (a quadrant entry counts a quarter per source)
   int slice = 1;          // gr_bal_tuning.spchol_slice: tiles per substitution work item
@@ -778,7 +859,24 @@ template <typename T> struct SparseChol {
       lvl_fitem_off.push_back((int)it_f[0].size()); lvl_bitem_off.push_back((int)it_b[0].size());
     }
     for (int q = 0; q < 5; ++q) { d_itf[q].upload(it_f[q], stream); d_itb[q].upload(it_b[q], stream); }
-    partial.alloc((size_t)std::max(it_f[0].size(), it_b[0].size()) * CH_NB);
+    { // entries of k_sp_bwd_chain: top level first; a panel's items (one tile each), then its finisher
+      std::vector<int> ch[6]; // kind_panel, row, slot, idx | pfirst, pcount (per panel)
+      ch[4].assign(nt, 0); ch[5].assign(nt, 0);
+      int prow = 0;
+      for (int l = nlevels - 1; l >= 0; --l)
+        for (int k : by_level[l]) {
+          const int nk_ = h_cptr[k + 1] - h_cptr[k];
+          ch[4][k] = prow; ch[5][k] = nk_;
+          for (int q = 0; q < nk_; ++q) { ch[0].push_back(k); ch[1].push_back(h_crows[h_cptr[k] + q]); ch[2].push_back(h_cslot[h_cptr[k] + q]); ch[3].push_back(q); }
+          ch[0].push_back(~k); ch[1].push_back(0); ch[2].push_back(0); ch[3].push_back(0);
+          prow += nk_;
+        }
+      chain_entries = (int)ch[0].size();
+      for (int q = 0; q < 6; ++q) d_ch[q].upload(ch[q], stream);
+      d_bcnt.alloc(nt); d_bcnt.zero(stream); d_ready.alloc(nt); d_ready.zero(stream);
+      chain_seq = 0;
+    }
+    partial.alloc((size_t)std::max({it_f[0].size(), it_b[0].size(), h_crows.size()}) * CH_NB);
     ticket.alloc(nt); ticket.zero(stream);
     auto up = [&](DevBuf<int> &d, std::vector<int> &h) { if (h.empty()) h.push_back(0); d.upload(h, stream); };
     up(d_panels, h_panels); up(d_trsm, h_trsm); up(d_upd, h_upd); up(d_klist, h_klist); up(d_nz, h_nz);
@@ -884,6 +982,11 @@ template <typename T> struct SparseChol {
     k_sp_unpermute<T><<<(npad + 255) / 256, 256, 0, stream>>>(npad, d_src.p, vx.p, x);
   }
   void backward() {
+    if (bwd_chain) {
+      ++chain_seq;
+      k_sp_bwd_chain<T><<<chain_entries, 256, 0, stream>>>(A.p, Linv.p, SpChain{d_ch[0].p, d_ch[1].p, d_ch[2].p, d_ch[3].p, d_ch[4].p, d_ch[5].p}, vy.p, vx.p, partial.p, d_bcnt.p, d_ready.p, chain_seq, d_fail.p);
+      return;
+    }
     for (int l = nlevels - 1; l >= 0; --l)
       k_sp_bwd<T><<<lvl_bitem_off[l + 1] - lvl_bitem_off[l], 256, 0, stream>>>(A.p, Linv.p, items(d_itb, lvl_bitem_off[l]), d_crows.p, d_cslot.p, vy.p, vx.p, partial.p, ticket.p);
   }
