@@ -395,6 +395,9 @@ __global__ __launch_bounds__(256) void k_sp_trsm_rows(T *__restrict__ A, const i
   sp_trsm_slab<T>(reinterpret_cast<T *>(ch_smem), A + (size_t)tiles[2 * tile] * SP_TT + (size_t)slab * SP_SLAB * CH_NB, Linv + (size_t)tiles[2 * tile + 1] * SP_TT);
 }
 
+// (Round 5, measured and removed: the level's panel-solve slabs as the FIRST workgroups of its update launch — written through, a counter
+// per tile, update workgroups waiting for their source tiles' four slabs: upper-level launch 61.3 us against 8.8 + 50.4 us and one launch
+// boundary; 371 vs 375 LM it/s.  The slab's write-through stores, the poll and the cold first read of the sources cost what the launch did.)
 // (Round 4, measured and removed: the whole factorisation as ONE dependency-driven launch — every panel-solve slab, target update
 // and diagonal factorisation an item of a level-ordered queue, persistent workgroups waiting on per-tile counters with agent-scope
 // release / acquire fences.  2.51 ms per factorisation on Ladybug-1723 against 2.45 ms for the level launches: the launch floors
