@@ -1022,12 +1022,16 @@ template <typename T> struct Engine final : EngineBase {
   // part: 1 = the k_linearize launch only, 2 = its finalisation (+ the collectives of landmark shards) only, 3 = both.  The LM
   // loop of landmark shards enqueues part 1 AHEAD of the PCG exit flag (gated on the device, no collective inside: a rank whose
   // gate was still closed repeats it later on its own) and part 2 once the flag has been seen.
+  // user-traits problems with a stored Jacobian: the lineariser also writes the weighted blocks (2 x (pose + landmark) scalars per observation)
+  double model_jac_bytes() const {
+    return (model && model->store_jacobians) ? No * (2.0 * model->pose_dim + 2.0 * model->landmark_dim) * (model->storage_dtype == GR_F64 ? 8.0 : 4.0) : 0.0;
+  }
   void linearize_impl(bool write_hcp, bool pack_valid = false, int spec_seq = 0, const int *gate = nullptr, int part = 3) {
     if (!pack_valid) campack();
     if (part & 1) {
       // algorithmic bytes: every array touched once (obs, 3 index streams, points, packs, g9 out, partials, Hcp)
       double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + (write_hcp ? 27.0 * No * w() : 0.0);
-      if (model && model->store_jacobians) bytes += No * (2.0 * model->pose_dim + 2.0 * model->landmark_dim) * (model->storage_dtype == GR_F64 ? 8.0 : 4.0); // the stored weighted Jacobian
+      bytes += model_jac_bytes();
       Scope sc(this, write_hcp ? "linearize_hcp" : "linearize", bytes, No * (250.0 + 48 + 117 + (write_hcp ? 81.0 : 0.0)), true);
       launch_linearize_cam(write_hcp, g9.p, gate);
     }
@@ -2249,7 +2253,7 @@ template <typename T> struct Engine final : EngineBase {
   }
   // the trial linearisation of the Schur solvers: k_linearize with the camera-point blocks, finalised by the next head
   void linearize_hcp_deferred() {
-    const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + 27.0 * No * w();
+    const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + 27.0 * No * w() + model_jac_bytes();
     Scope sc(this, "linearize_hcp", bytes, No * (250.0 + 48 + 117 + 81.0), true);
     launch_linearize_cam(true, g9.p, nullptr);
     hcp_valid = true;
@@ -2301,7 +2305,7 @@ template <typename T> struct Engine final : EngineBase {
   }
   // k_linearize alone (LM loop, fused form): the finalisation follows in k_finalize_bj; its last workgroup clears the PCG loop state
   void linearize_deferred(const int *gate) {
-    const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w();
+    const double bytes = No * (2 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 8.0 * No * w() + 54.0 * nseg * w() + model_jac_bytes();
     Scope sc(this, "linearize", bytes, No * (250.0 + 48 + 117), true);
     lin_reset = ctl_cap > 0;
     launch_linearize_cam(false, g9.p, gate);
