@@ -160,6 +160,38 @@ def test_sparse_cholesky_substitution_forms_agree(monkeypatch, slice_):
     assert relerr(dx["1"], dx["2"]) < 1e-12 and relerr(dx["1"], dx["0"]) < 1e-12
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sparse_cholesky_round5_forms_agree(monkeypatch, dtype):
+    """Round 5: the fused diagonal tile's update by quadrants on three workgroups (GR_SPCHOL_FUSE=2, default) against the one-workgroup
+    form (1) and the un-fused factorisation launches (0) — every output element still accumulates its K products in the same order —,
+    and the backward substitution as one dependency-driven launch (GR_SPCHOL_BWD_CHAIN unset) against the level launches (0): the same
+    products summed in the same order."""
+    prob = synth.make_problem(300, 6000, 30000, seed=42, window=10)
+    monkeypatch.setenv("GR_SPARSE_CHOL", "1")
+    dx = {}
+    for fuse, chain in (("2", None), ("1", None), ("0", None), ("2", "0")):
+        monkeypatch.setenv("GR_SPCHOL_FUSE", fuse)
+        if chain is None:
+            monkeypatch.delenv("GR_SPCHOL_BWD_CHAIN", raising=False)
+        else:
+            monkeypatch.setenv("GR_SPCHOL_BWD_CHAIN", chain)
+        g = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype)
+        g.solver_update_structure(ga.SOLVER_DENSE_SCHUR)
+        g.linearize()
+        g.solver_update_values(ga.SOLVER_DENSE_SCHUR)
+        g.solver_set_damping(ga.SOLVER_DENSE_SCHUR, 1e-4)
+        first, _ = g.solver_solve(ga.SOLVER_DENSE_SCHUR)
+        again, _ = g.solver_solve(ga.SOLVER_DENSE_SCHUR)   # the counters / ready words are left as the next solve needs them
+        assert np.array_equal(first, again) or relerr(again, first) < (1e-12 if dtype == np.float64 else 2e-3)
+        dx[(fuse, chain)] = first
+        g.close()
+    base = dx[("2", None)]
+    # held to the last bits of fp64 (fp32: to the conditioning of S, as the older form tests above)
+    tol = 1e-12 if dtype == np.float64 else 2e-3
+    for key, v in dx.items():
+        assert relerr(v, base) < tol, key
+
+
 def test_sparse_cholesky_lm_trace(oracle_mod, monkeypatch):
     monkeypatch.setenv("GR_SPARSE_CHOL", "1")
     prob = synth.make_problem(300, 6000, 30000, seed=42, window=10)
