@@ -1088,7 +1088,7 @@ template <typename T> struct Engine final : EngineBase {
 #ifdef GR_DIAG
     { // diagnostic builds: GR_LIN_VAR=1|2|4|8 runs an ablated lineariser INSIDE the solve (wrong numbers, real cache state)
       static const int var = getenv("GR_LIN_VAR") ? atoi(getenv("GR_LIN_VAR")) : 0;
-#define GR_LINV(V) launch(k_linearize<T, false, T, V>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap)
+#define GR_LINV(V) launch(k_linearize<T, false, T, V>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap, nullptr, nullptr)
       if (!hcp && var == 1) { GR_LINV(1); return; }
       if (!hcp && var == 2) { GR_LINV(2); return; }
       if (!hcp && var == 4) { GR_LINV(4); return; }
@@ -1098,13 +1098,13 @@ template <typename T> struct Engine final : EngineBase {
 #endif
     if constexpr (sizeof(T) == 8) {
       if (jac32) {
-        if (hcp) launch(k_linearize<T, true, float>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
-        else launch(k_linearize<T, false, float>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
+        if (hcp) launch(k_linearize<T, true, float>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap, sf_cont ? Hcp1.p : nullptr, sf_cont ? lmdev.p : nullptr);
+        else launch(k_linearize<T, false, float>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap, nullptr, nullptr);
         return;
       }
     }
-    if (hcp) launch(k_linearize<T, true>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap);
-    else launch(k_linearize<T, false>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap);
+    if (hcp) launch(k_linearize<T, true>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, Hcp.p, cam_partial.p, chi2_partial.p, nullptr, gate, cam_fixed_p(), pt_fixed_p(), rst, rst_cap, sf_cont ? Hcp1.p : nullptr, sf_cont ? lmdev.p : nullptr);
+    else launch(k_linearize<T, false>, grid_lin, (int)No, o_ntiles(), o_cam(), o_pt(), o_pos(), o_obs(), blk_seg.p, seg_slot.p, pts.p, pack.p, loss_kind, loss_delta, g9p, nullptr, cam_partial.p, chi2_partial.p, nullptr, gate, nullptr, nullptr, rst, rst_cap, nullptr, nullptr);
   }
   bool want_hcp = false;
   void linearize() override { linearize_impl(want_hcp); }
@@ -1294,7 +1294,7 @@ template <typename T> struct Engine final : EngineBase {
     Scope sc(this, "schur_products", nprod * (54.0 * w() + 8) + 9.0 * Np * w() + 81.0 * nnzb * w() + No * (27.0 * w() + 8) + 3.0 * Np * w(), nprod * 342.0 + No * 54.0, true);
     const int nwg_items = cdiv(nitems, 4);
     launch(k_schur_reduce<T>, nwg_items + cdiv(nch, 4), nitems, nwg_items, item_blk.p, item_beg.p, item_end.p, item_multi.p, multi_first.p, multi_n.p, multi_cnt.p, slab.p,
-           prod_a.p, prod_b.p, S_rowi.p, S_coli.p, prod_pm.p, Hcp.p, Mp.p, hcc_w, scales.p, mu, ui, S.p, nch, chunk_beg.p, pt_cm.p, pos_cm.p, vl.p, part9.p, lm);
+           prod_a.p, prod_b.p, S_rowi.p, S_coli.p, prod_pm.p, Hcp.p, Mp.p, hcc_w, scales.p, mu, ui, S.p, nch, chunk_beg.p, pt_cm.p, pos_cm.p, vl.p, part9.p, lm, sf_cont ? Hcp1.p : nullptr, sf_cont ? lmdev.p : nullptr);
   }
   // replicated reduced solves: rank 0's camera step is the one every rank applies (the per-rank copies agree
   // only up to the order of the atomic dot-product partials, which must not leak into the replicated cameras)
@@ -2181,6 +2181,11 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<int> coop_iters;
   volatile int *h_coop_fail = nullptr; // pinned, sticky
   bool sf_active = false;              // armed by lm()
+  // ... and in that form (built-in model, gr_bal_tuning.schur_fused = 2 / auto) a rejected step does not stop the head: RejectCont (kernels_sf.hpp)
+  bool sf_cont = false;
+  double sf_nu = 2.0;                  // the factor the NEXT rejection multiplies the damping with (the host's nu)
+  DevBuf<T> Hcp1;                      // second buffer of camera-point blocks (LmDev::hsel)
+  DevBuf<double> sf_vsum;              // per-point sums of the current linearisation
   bool schur_fused_ok(int max_iter) const { return !comm && max_iter >= 1 && tune.schur_fused != 0 && tune.lm_fused != 0; }
   // the whole PCG on S in one cooperative launch: one wave per camera row, all of them resident at once
   bool schur_coop() const { return Nc <= 2 * (int64_t)num_cu; }
@@ -2210,8 +2215,10 @@ template <typename T> struct Engine final : EngineBase {
     if (!coop) { ensure_scalars(max_iter); for (int k = 0; k < max_iter + 1; ++k) flags()[k] = 0; }
     {
       Scope sc(this, "finalize_schur", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 36.0 * Np) * w(), 9.0 * No + 54.0 * nseg + 120.0 * Np, true);
+      RejectCont<T> rc{};
+      if (sf_cont) { rc.cams = cams.p; rc.pts = pts.p; rc.cams_bak = cams_bak.p; rc.pts_bak = pts_bak.p; rc.pack = pack.p; rc.vsum = sf_vsum.p; rc.lm = lmdev.p; rc.nu_cur = sf_nu; }
       launch(k_finalize_schur<T>, nbc + nbp + (coop ? 0 : 1), (int)Nc, (int)Np, nbc, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bu.p, Hll.p, scales.p, mu, ui,
-             Hll_inv.p, Mp.p, vl.p, dec, cam_fixed_p(), pt_fixed_p(), cs, coop ? PcgScalars{} : scalars(), coop ? 0 : sc_cap);
+             Hll_inv.p, Mp.p, vl.p, dec, cam_fixed_p(), pt_fixed_p(), cs, coop ? PcgScalars{} : scalars(), coop ? 0 : sc_cap, rc);
     }
     launch_schur_reduce(Hcc.p, mu, ui, lm);
     if (!coop) {
@@ -2244,8 +2251,8 @@ template <typename T> struct Engine final : EngineBase {
       rho_blocks = model ? model->step_blocks : nct + nbp;
       rho_partial.alloc(rho_blocks);
       Scope sc(this, "backsub_apply", No * (27.0 * w() + 4) + (9.0 * Np + 3.0 * n + 24.0 * Nc) * w(), No * 54.0, true);
-      if (model) launch(k_backsub_apply<T, false>, nct + nbp, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, nullptr, nullptr, nullptr, nullptr, nullptr, mu, nullptr, lm);
-      else launch(k_backsub_apply<T>, rho_blocks, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, cams.p, pts.p, cams_bak.p, pts_bak.p, pack.p, mu, rho_partial.p, lm);
+      if (model) launch(k_backsub_apply<T, false>, nct + nbp, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, nullptr, nullptr, nullptr, nullptr, nullptr, mu, nullptr, lm, nullptr, nullptr);
+      else launch(k_backsub_apply<T>, rho_blocks, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, cams.p, pts.p, cams_bak.p, pts_bak.p, pack.p, mu, rho_partial.p, lm, sf_cont ? Hcp1.p : nullptr, sf_cont ? lmdev.p : nullptr);
     }
     // user-traits problems: the trial step through Traits::update, under the same decision (the damping of its rho partials from LmDev)
     if (model) model_step(v_dx.p, /*with_backup=*/true, mu, rho_partial.p, lm, nullptr);
@@ -2404,8 +2411,8 @@ template <typename T> struct Engine final : EngineBase {
     std::memset(&st, 0, sizeof(st));
     struct LmScope { // the fused PCG start (solver_set_damping) is only armed inside this loop
       Engine *e;
-      explicit LmScope(Engine *e_) : e(e_) { e->lm_x = e->v_dx.p; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; e->sf_active = false; }
-      ~LmScope() { e->lm_x = nullptr; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; e->sf_active = false; e->profiling = false; }
+      explicit LmScope(Engine *e_) : e(e_) { e->lm_x = e->v_dx.p; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; e->sf_active = false; e->sf_cont = false; }
+      ~LmScope() { e->lm_x = nullptr; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; e->sf_active = false; e->sf_cont = false; e->profiling = false; }
     } lm_scope(this);
     struct EventPairs { // solve_seconds: events around every solve, read one iteration late, outside the decision -> launch path
       hipEvent_t ev[3][2];
@@ -2424,10 +2431,17 @@ template <typename T> struct Engine final : EngineBase {
     sf_active = opt.solver == GR_SOLVER_PCG_SCHUR && schur_fused_ok(opt.pcg_max_iter) && schur_coop() && opt.iterations > 0;
     bool head_enqueued = false; // the head of the NEXT iteration is already in the stream (device-decided accept)
     T chi2v = 0;
+    sf_cont = sf_active && !model && tune.schur_fused != 1; // (1: the head stops on a rejected step and the host runs the rejection)
     if (sf_active) {
       // Schur solver, small reduced system: the first linearisation is finalised by the head of iteration 0 like every other one,
       // and that launch reports the initial chi2
       ensure_lm_buffers(); ensure_coop(opt.pcg_max_iter); ensure_scalars(opt.pcg_max_iter); // (pinned words are sized before the first head uses them)
+      if (sf_cont) {
+        Hcp1.alloc(27 * (size_t)No); sf_vsum.alloc(9 * (size_t)Np);
+        const LmDev init{(double)mu, 0, 1}; // hsel = 1: the first linearisation writes buffer 0, the first head flips to it
+        GR_HIP(hipMemcpyAsync(lmdev.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
+        sf_nu = (double)nu;
+      }
       campack();
       linearize_hcp_deferred();
       LmDecide dec;
@@ -2504,6 +2518,7 @@ template <typename T> struct Engine final : EngineBase {
           mu *= (T)alpha;
         }
         nu = 2;
+        sf_nu = 2.0;
         if (!speculate) {
           if (lm_fused) { linearize_deferred(nullptr); fin_pending = true; pcg_state_clean = !model; }
           else linearize_impl(want_hcp, /*pack_valid=*/true);
@@ -2511,6 +2526,12 @@ template <typename T> struct Engine final : EngineBase {
         solver_update_values(opt.solver);
         st.accepted++;
         accept_streak = std::min(accept_streak + 1, 2);
+      } else if (device && sf_cont) {
+        // the head went on from the kept point by itself (RejectCont): vertices taken back, damping raised, blocks in the other buffer
+        accept_streak = 0;
+        mu = (T)device[0];
+        nu *= 2;
+        new_chi2 = chi2v;
       } else {
         revert();
         if (speculate) { // restore H, b, scales of the kept point
@@ -2689,7 +2710,8 @@ template <typename T> struct Engine final : EngineBase {
       const double hs[2] = {h_res[0], h_res[1]};
       const double dev[2] = {h_res[2], h_res[3]};
       const bool go = decide(i, true, /*speculate=*/true, it, hs, head_enqueued ? dev : nullptr);
-      if (head_enqueued && dev[1] == 0.0) head_enqueued = false; // not accepted: the head returned at once
+      if (head_enqueued && dev[1] == 0.0 && !sf_cont) head_enqueued = false; // not accepted: the head returned at once (RejectCont: it went on)
+      sf_nu = (double)nu;
       return go;
     };
 
@@ -2715,6 +2737,7 @@ template <typename T> struct Engine final : EngineBase {
       head_enqueued = false;
     }
     if (fin_pending) flush_finalize();
+    if (sf_cont) hcp_valid = false; // (the current point's blocks may sit in the second buffer: whoever needs them next re-linearises)
     GR_HIP(hipStreamSynchronize(stream));
     st.loop_seconds = std::chrono::duration<double>(clk::now() - tl).count();
     if (ev_waiting >= 0) collect_solve_time(ev_waiting);

@@ -730,9 +730,13 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
             // LM loop: the PCG loop state of the solve whose step this linearisation evaluates is spent (every kernel that
             // reads it precedes this launch); the last workgroup clears it, so the next k_finalize_bj / k_block_jacobi
             // starts the next loop itself
-            PcgState rst = PcgState{}, int rst_cap = 0) {
+            PcgState rst = PcgState{}, int rst_cap = 0,
+            // Schur solvers whose rejected steps do not stop the head (kernels_sf.hpp): the blocks go to the buffer that does NOT hold the
+            // current point's (hs->hsel: 0 = Hcp, 1 = Hcp_alt), which a rejected step still needs
+            T *__restrict__ Hcp_alt = nullptr, const LmDev *__restrict__ hs = nullptr) {
   if (lm && lm->stop) return;
   if (gate && !*gate) return;
+  if (WRITE_HCP && hs && hs->hsel == 0) Hcp = Hcp_alt;
   if (rst_cap > 0 && blockIdx.x == gridDim.x - 1) {
     for (int i = threadIdx.x; i < rst_cap * NSLOT * NS; i += TPB) rst.acc[slot_word(i)] = 0.0;
     for (int i = threadIdx.x; i < rst_cap; i += TPB) { rst.done[i] = 0; rst.pdp[i] = 0.0; rst.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }

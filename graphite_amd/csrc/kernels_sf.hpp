@@ -83,6 +83,20 @@ struct CoopState {           // k_schur_pcg_coop's cross-workgroup state (device
   long long *ts;             // pinned [2] wall-clock stamps around the loop (solve_seconds), may be null
 };
 
+// A REJECTED STEP DOES NOT STOP THE HEAD (round 5, built-in model).  What a rejection needs of the current point is still in memory — Hcc,
+// bc, the scales and the per-point sums are only ever written by this kernel — except the camera-point blocks, which the trial
+// linearisation overwrites: those get a second buffer (LmDev::hsel).  So on "not accepted" this launch takes the vertices back
+// (k_revert_pack's work), keeps the sums, recomputes what depends on the damping (Hll^-1, M', v) from the stored per-point sums with
+// mu * nu, and the rest of the head runs as the first head of the next LM iteration: no four no-op launches, no host round trip, no
+// revert launch, no re-linearisation (Ladybug-49: ~50 us per rejected step, every fourth step of the bench line).
+template <typename T> struct RejectCont {
+  T *cams = nullptr, *pts = nullptr;             // != nullptr: this form is on
+  const T *cams_bak = nullptr, *pts_bak = nullptr;
+  T *pack = nullptr;
+  double *vsum = nullptr;                        // [Np][9] per-point sums of the current linearisation, as summed (double)
+  LmDev *lm = nullptr;                           // hsel lives here (also for heads that take no decision)
+  double nu_cur = 2.0;                           // the damping factor a rejection applies (levenberg_marquardt.hpp:206-207)
+};
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(TPB)
@@ -90,24 +104,31 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
                  const int *__restrict__ pt_ptr, const T *__restrict__ g9, T *__restrict__ Hcc, T *__restrict__ bu, T *__restrict__ Hll,
                  T *__restrict__ scales, double mu, int use_identity, T *__restrict__ Hll_inv, T *__restrict__ Mp, T *__restrict__ vl,
                  LmDecide dec, const unsigned char *__restrict__ cam_fixed, const unsigned char *__restrict__ pt_fixed, CoopState cs,
-                 PcgScalars pcg = PcgScalars{}, int pcg_cap = 0 /* > 0: the last workgroup resets the scalars of the per-iteration PCG kernels */) {
+                 PcgScalars pcg = PcgScalars{}, int pcg_cap = 0 /* > 0: the last workgroup resets the scalars of the per-iteration PCG kernels */,
+                 RejectCont<T> rc = RejectCont<T>{}) {
   __shared__ double s_sum[2];
+  bool cont = false; // the step was not accepted and this head goes on from the current point
   if (dec.seq) {
     (void)lm_decide_prologue(dec, mu, s_sum);
     if (!dec.report_only) {
       double mun;
       const bool ok = lm_accept<T>(dec, s_sum[0], s_sum[1], mun);
+      cont = !ok && rc.cams != nullptr;
+      if (cont) mun = (double)((T)dec.mu_cur * (T)rc.nu_cur);
       if (blockIdx.x == 0 && threadIdx.x == 0) {
-        dec.lm->mu = mun; dec.lm->stop = ok ? 0 : 2;
+        dec.lm->mu = mun; dec.lm->stop = (ok || cont) ? 0 : 2;
         if (dec.dscal) { dec.dscal[0] = s_sum[0]; dec.dscal[1] = s_sum[1]; }
         dec.hres[0] = s_sum[0]; dec.hres[1] = s_sum[1]; dec.hres[2] = mun; dec.hres[3] = ok ? 1.0 : 0.0;
         __threadfence_system();
         *dec.hres_seq = dec.seq;
       }
-      if (!ok) return;
+      if (!ok && !cont) return;
       mu = mun;
     }
   }
+  // this launch takes a NEW linearisation over unless it continues from the current point: the other block buffer becomes the current one
+  // (nothing in this kernel reads the blocks or hsel)
+  if (rc.lm && !cont && blockIdx.x == 0 && threadIdx.x == 0) rc.lm->hsel ^= 1;
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0 && cs.barrier) *cs.barrier = 0u;
   if (pcg_cap > 0 && b == (int)gridDim.x - 1) { // an extra workgroup
@@ -123,6 +144,20 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
     const int c = (b * 4 + wave) * 7 + g;
     const bool on = g < 7 && c < Nc;
     if (!on) return;
+    if (cont) { // the camera's sums stand; its parameters and pack go back to the backup
+      const T v = rc.cams_bak[9 * (size_t)c + j];
+      rc.cams[9 * (size_t)c + j] = v;
+      T cam[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) cam[i] = __shfl(v, 9 * g + i, 64);
+      if (j == 0) {
+        T pk[PACK];
+        make_campack(cam, pk);
+#pragma unroll
+        for (int k = 0; k < PACK; ++k) rc.pack[PACK * (size_t)c + k] = pk[k];
+      }
+      return;
+    }
     T a[9], bj = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) a[i] = T(0);
@@ -192,7 +227,7 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
     double v[9]; // sums, scales, block, inverse, M', v in double whatever T is (see k_finalize_bj): only the outputs are rounded
 #pragma unroll
     for (int i = 0; i < 9; ++i) v[i] = 0.0;
-    if (on) {
+    if (on && !cont) {
       for (int a = pt_ptr[l] + (int)jl; a < pt_ptr[l + 1]; a += FIN_PL) {
         const V2 *gq = reinterpret_cast<const V2 *>(g9 + 8 * (size_t)a);
         const V2 q0 = gq[0], q1 = gq[1], q2 = gq[2], qe = gq[3];
@@ -211,6 +246,15 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
 #pragma unroll
     for (int i = 0; i < 9; ++i) { v[i] += lane_xor<1>(v[i]); v[i] += lane_xor<2>(v[i]); }
     if (!on || jl != 0) continue;
+    if (cont) { // the sums as they were taken, the point back at its backup
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v[i] = rc.vsum[9 * (size_t)l + i];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) rc.pts[3 * (size_t)l + q] = rc.pts_bak[3 * (size_t)l + q];
+    } else if (rc.vsum) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) rc.vsum[9 * (size_t)l + i] = v[i];
+    }
     const bool pfixed = pt_fixed && pt_fixed[l];
     if (pfixed) {
 #pragma unroll
@@ -258,8 +302,9 @@ k_schur_reduce(int nitems, int nwg_items, const int *__restrict__ item_blk, cons
                const int *__restrict__ prod_pm /* landmark of each product */, const T *__restrict__ Hcp, const T *__restrict__ Mp, const T *__restrict__ Hcc,
                const T *__restrict__ scales, double mu, int use_identity, T *__restrict__ S,
                int nch, const int *__restrict__ chunk_beg, const int *__restrict__ pt_cm, const int *__restrict__ pos_cm, const T *__restrict__ vl,
-               T *__restrict__ partial9, const LmDev *__restrict__ lm) {
+               T *__restrict__ partial9, const LmDev *__restrict__ lm, const T *__restrict__ Hcp_alt = nullptr, const LmDev *__restrict__ hs = nullptr) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
+  if (hs && hs->hsel) Hcp = Hcp_alt; // (RejectCont: the buffer that holds the current point's blocks)
   const int lane = threadIdx.x & 63;
   if ((int)blockIdx.x >= nwg_items) { // ---- b_S partials: one wave per camera chunk
     const int ch = ((int)blockIdx.x - nwg_items) * 4 + (threadIdx.x >> 6);
@@ -544,8 +589,9 @@ __global__ void __launch_bounds__(TPB)
 k_backsub_apply(int Nc, int Np, int nct, const int *__restrict__ pt_ptr, const int *__restrict__ cam_pm, const T *__restrict__ Hcp,
                 const T *__restrict__ Hll_inv, const T *__restrict__ bu, const T *__restrict__ scales, T *__restrict__ x /* [9 Nc + 3 Np]: xp in, xl out */,
                 T *__restrict__ cams, T *__restrict__ pts, T *__restrict__ cams_bak, T *__restrict__ pts_bak, T *__restrict__ pack,
-                double mu, double *__restrict__ rho_partial, const LmDev *__restrict__ lm) {
+                double mu, double *__restrict__ rho_partial, const LmDev *__restrict__ lm, const T *__restrict__ Hcp_alt = nullptr, const LmDev *__restrict__ hs = nullptr) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
+  if (hs && hs->hsel) Hcp = Hcp_alt;
   __shared__ double red[4];
   __shared__ T cs[252];
   const unsigned pose_dim = 9u * (unsigned)Nc;

@@ -149,7 +149,10 @@ typedef struct {
   int32_t schur_fused;          /* GR_SCHUR_FUSED   -1 auto | 0 | 1: GR_SOLVER_PCG_SCHUR — S and the b_S partials in ONE launch whose multi-item
                                    blocks are finished by their last arriver (no float atomics), and, where the reduced system is small
                                    (cameras <= 2 x CUs), the device-decided LM iteration of kernels_sf.hpp: five launches, the whole PCG
-                                   on S inside one of them.  0: the round-4 kernels and the host-driven loop                              */
+                                   on S inside one of them — and (auto / 2, built-in model) a rejected step does not stop that head: the
+                                   finalisation takes the vertices back, keeps its sums, raises the damping and the head goes on as the
+                                   next iteration's (second buffer of camera-point blocks).  1: the head stops on a rejected step and the
+                                   host runs the rejection.  0: the round-4 kernels and the host-driven loop                              */
   int32_t reserved[3];
 } gr_bal_tuning;
 void gr_bal_tuning_default(gr_bal_tuning *t);

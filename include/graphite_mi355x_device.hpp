@@ -24,7 +24,8 @@ template <> struct Vec2T<double> { using type = double2; };
 struct LmDev {
   double mu;
   int stop; // 0 run | 2 the step was not accepted
-  int pad;
+  int hsel; // Schur solvers with two camera-point block buffers: the one that holds the CURRENT point's blocks (the trial linearisation
+            // writes the other one; the finalisation that takes a new linearisation over flips it, a rejected step leaves it)
 };
 
 // ---- cross-lane exchange without LDS ------------------------------------------------------------------------------------
