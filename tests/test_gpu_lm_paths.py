@@ -49,3 +49,44 @@ def test_rejected_steps_go_through_every_path(oracle_mod, monkeypatch, knob):
     assert np.allclose(base[0], off[0], rtol=1e-8) and np.allclose(base[0], ct_r, rtol=1e-6)
     assert base[2]["accepted"] == off[2]["accepted"] == st_r["accepted"]
     assert base[2]["accepted"] < base[2]["iterations_run"], "the scenario is meant to contain rejected steps"
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_schur_head_that_goes_on_after_a_rejected_step(oracle_mod, monkeypatch, dtype):
+    """PCGSchurSolver on a small reduced system (device-decided head, kernels_sf.hpp): by default a rejected step does not stop the head —
+    the finalisation launch takes the vertices back, keeps its sums, raises the damping and the head runs on (second buffer of camera-point
+    blocks, per-point sums kept in double).  Against GR_SCHUR_FUSED=1 (the head stops, the host reverts and re-linearises) and
+    GR_SCHUR_FUSED=0 (host-driven loop), and against the oracle.
+    Scenario 1 — noisy observations, almost no damping, PCG run to convergence: the first seven steps are rejected in a row, about half of all.
+    fp64: the same chi2 / damping traces and final vertices to the last bit as the stopping form.  fp32: the reduced system is close to
+    singular here and turns one ulp of an input into 1e-4 of the step — the three forms differ from each other by that much (the stopping
+    form re-linearises with camera packs rebuilt by another kernel, the form that goes on keeps the original linearisation): held at 2e-3,
+    with equal accept counts.
+    Scenario 2 — Ladybug-49 with the bench line's options (9 of 20 steps rejected): fp32 traces equal at 1e-6."""
+    prob = synth.make_problem(8, 200, 1600, seed=1, noise_px=30.0)
+    kw = dict(initial_damping=1e-12, pcg_max_iter=30, pcg_tol=1e-30, pcg_rej=1e30)
+    res = {}
+    for mode in ("2", "1", "0"):
+        monkeypatch.setenv("GR_SCHUR_FUSED", mode)
+        res[mode] = run(prob, dtype, ga.SOLVER_PCG_SCHUR, 25, **kw)
+    a, b, c = res["2"], res["1"], res["0"]
+    assert a[2]["accepted"] < a[2]["iterations_run"], "the scenario is meant to contain rejected steps"
+    assert a[2]["accepted"] == b[2]["accepted"] == c[2]["accepted"]
+    if dtype == np.float64:
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])  # chi2 and damping traces: bit for bit
+        assert a[2]["pcg_iterations"] == b[2]["pcg_iterations"]
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])  # final cameras and points
+        assert np.allclose(a[0], c[0], rtol=1e-8)
+        ref = oracle_mod.BalOracle(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+        ct_r, lt_r, st_r = ref.levenberg_marquardt(solver=oracle_mod.SOLVER_PCG_SCHUR, iterations=25, **kw)
+        assert len(a[0]) == len(ct_r) and np.allclose(a[0], ct_r, rtol=1e-6) and a[2]["accepted"] == st_r["accepted"]
+    else:
+        assert np.allclose(a[0], b[0], rtol=2e-3) and np.allclose(a[0], c[0], rtol=2e-3) and np.allclose(a[1], b[1], rtol=2e-2)
+        l49 = synth.make_config("ladybug-49")
+        kw49 = dict(initial_damping=1e-4, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0)
+        r = {}
+        for mode in ("2", "1"):
+            monkeypatch.setenv("GR_SCHUR_FUSED", mode)
+            r[mode] = run(l49, np.float32, ga.SOLVER_PCG_SCHUR, 20, **kw49)
+        assert r["2"][2]["accepted"] < r["2"][2]["iterations_run"]
+        assert r["2"][2]["accepted"] == r["1"][2]["accepted"] and np.allclose(r["2"][0], r["1"][0], rtol=1e-6)
