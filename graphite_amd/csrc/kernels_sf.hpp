@@ -467,6 +467,29 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
     b = scales[9 * (size_t)i + r] * (bc[9 * (size_t)i + r] - b);
     b_schur[9 * (size_t)i + r] = b;
   }
+  // The row's blocks do not change over the inner iterations, and the matvec used to be a chain per round — block index -> block ->
+  // its 9 entries, 7 rounds of it per iteration on a 49-block row (Ladybug-49: ~7 us of an 18 us launch that runs ONE inner iteration on
+  // average).  The first CR rounds of every lane group are fetched ONCE, here, into registers (entry (r, c) of the block as the product
+  // uses it); the loads fly under the 9 x 9 inversion below.  An iteration then only fetches p.  Same products in the same order.
+  constexpr int CR = 7;
+  T cS[CR][9];
+  int ccol[CR];
+  const int row_beg = row_ptr[i], row_end = row_ptr[i + 1];
+#pragma unroll
+  for (int q = 0; q < CR; ++q) {
+    const int e = row_beg + g + 7 * q;
+    ccol[q] = -1;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) cS[q][c] = T(0);
+    if (g < 7 && e < row_end) {
+      const int blk = row_blk[e];
+      ccol[q] = row_col[e];
+      const bool transposed = blk < 0;
+      const T *Ab = S + 81 * (size_t)(transposed ? ~blk : blk);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) cS[q][c] = transposed ? Ab[c + 9 * r] : Ab[r + 9 * c];
+    }
+  }
   double A[9]; // column r of the diagonal block in lane r
   {
     const T *B = S + 81 * (size_t)diag_blk[i];
@@ -520,7 +543,18 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
     // y_i = (S p)_i : 7 groups of 9 lanes stride over the row's block list (k_schur_matvec)
     T acc = T(0);
     if (g < 7) {
-      for (int e = row_ptr[i] + g; e < row_ptr[i + 1]; e += 7) {
+      T xq[CR][9];
+#pragma unroll
+      for (int q = 0; q < CR; ++q)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) xq[q][c] = ccol[q] >= 0 ? __hip_atomic_load(&p_glob[9 * (size_t)ccol[q] + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
+#pragma unroll
+      for (int q = 0; q < CR; ++q)
+        if (ccol[q] >= 0) {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) acc += cS[q][c] * xq[q][c];
+        }
+      for (int e = row_beg + g + 7 * CR; e < row_end; e += 7) { // rows of more than 49 blocks: the rest as before
         const int blk = row_blk[e], j = row_col[e];
         const bool transposed = blk < 0;
         const T *Ab = S + 81 * (size_t)(transposed ? ~blk : blk);

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for it in 112 224 448; do
+for it in 14 28 42 56 84; do
   echo "GR_SCHUR_ITEM=$it"
   GR_SCHUR_ITEM=$it python bench.py --workload ladybug-49 --no-cpu-baseline --no-also --pmc-traffic off --repeats 5 2>/dev/null | python -c "
 import json,sys
