@@ -55,6 +55,7 @@ static void tuning_default(gr_bal_tuning &t) {
   t.chol_fuse = env_int("GR_CHOL_FUSE", 1);
   t.chol_pin = env_int("GR_CHOL_PIN", 1);
   t.spchol_fuse = env_int("GR_SPCHOL_FUSE", 2);
+  t.spchol_bwd_chain = env_int("GR_SPCHOL_BWD_CHAIN", 1);
   t.schur_fused = env_int("GR_SCHUR_FUSED", -1);
   t.spchol_slice = std::max(1, env_int("GR_SPCHOL_SLICE", 1)); // tiles per substitution item (Ladybug-1723 direct Schur: 1 -> 322.5, 2 -> 319.5, 3 -> 314.5, 4 -> 310 LM it/s)
 }
@@ -1429,7 +1430,7 @@ template <typename T> struct Engine final : EngineBase {
     if (chol_ready) return;
     {
       const int force = tune.sparse_cholesky;
-      spchol.fuse_potrf = tune.spchol_fuse != 0; spchol.fuse_quads = tune.spchol_fuse >= 2; spchol.bwd_chain = !(getenv("GR_SPCHOL_BWD_CHAIN") && atoi(getenv("GR_SPCHOL_BWD_CHAIN")) == 0); spchol.slice = std::max(1, tune.spchol_slice); spchol.overlap_form = tune.spchol_overlap == 2 ? 2 : 1;
+      spchol.fuse_potrf = tune.spchol_fuse != 0; spchol.fuse_quads = tune.spchol_fuse >= 2; spchol.bwd_chain = tune.spchol_bwd_chain != 0; spchol.slice = std::max(1, tune.spchol_slice); spchol.overlap_form = tune.spchol_overlap == 2 ? 2 : 1;
       chol.fuse_potrf = tune.chol_fuse != 0; chol.pin_variant = tune.chol_pin;
       // what either form may take: 3/4 of the free HBM (the factor is the largest single allocation of the direct solvers)
       size_t mem_free = 0, mem_total = 0;

@@ -153,7 +153,9 @@ typedef struct {
                                    finalisation takes the vertices back, keeps its sums, raises the damping and the head goes on as the
                                    next iteration's (second buffer of camera-point blocks).  1: the head stops on a rejected step and the
                                    host runs the rejection.  0: the round-4 kernels and the host-driven loop                              */
-  int32_t reserved[3];
+  int32_t spchol_bwd_chain;     /* GR_SPCHOL_BWD_CHAIN 1: the backward substitution of the nested-dissection Cholesky as ONE dependency-driven
+                                   launch (items fetch their tile into registers before waiting for x_i); 0: one launch per level       */
+  int32_t reserved[2];
 } gr_bal_tuning;
 void gr_bal_tuning_default(gr_bal_tuning *t);
 
