@@ -45,24 +45,54 @@ template <typename F> inline void par_chunks(size_t n, int nt, F &&fn) {
 // first use or by gr_warm_up): a hipMemcpyAsync from PAGEABLE memory is staged by the runtime at ~2 GB/s and blocks the next
 // synchronising call for as long (measured: 20 ms for the 40 MB of index arrays of Ladybug-1723 inside gr_bal_create);
 // from pinned memory the same bytes take 2 ms and the call returns at once.  Arrays larger than half the ring take the
-// runtime's own path.  The ring wraps behind a device synchronisation.
+// runtime's own path.  A half of the ring is reused once the copies that read it have finished (an event per copy).
 struct UploadRing {
-  static constexpr size_t CAP = (size_t)64 << 20;
+  static constexpr size_t CAP = (size_t)64 << 20, HALF = CAP / 2;
   char *base = nullptr;
   size_t used = 0;
-  ~UploadRing() { if (base) (void)hipHostFree(base); }
+  // A half of the ring is written again only when every copy that read it has finished: one event per copy, recorded on the copy's
+  // own stream (the wrap used to synchronise the CURRENT device only — a thread that drives engines on two devices or
+  // streams could overwrite staging memory with a copy to the other one still in flight).  Events belong to the device they were
+  // created on: the pools are per device.
+  struct Pending { hipEvent_t ev; int dev; };
+  std::vector<Pending> inflight[2];
+  std::vector<Pending> spare;
+  ~UploadRing() {
+    for (auto &h : inflight) for (auto &p : h) (void)hipEventDestroy(p.ev);
+    for (auto &p : spare) (void)hipEventDestroy(p.ev);
+    if (base) (void)hipHostFree(base);
+  }
   void ensure() { if (!base) GR_HIP(hipHostMalloc(reinterpret_cast<void **>(&base), CAP, hipHostMallocDefault)); }
+  void drain(int half) {
+    for (auto &p : inflight[half]) { GR_HIP(hipEventSynchronize(p.ev)); spare.push_back(p); }
+    inflight[half].clear();
+  }
+  void mark(int half, hipStream_t s) {
+    int dev = 0;
+    GR_HIP(hipGetDevice(&dev));
+    Pending p{nullptr, dev};
+    for (size_t i = 0; i < spare.size(); ++i)
+      if (spare[i].dev == dev) { p = spare[i]; spare[i] = spare.back(); spare.pop_back(); break; }
+    if (!p.ev) GR_HIP(hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
+    GR_HIP(hipEventRecord(p.ev, s));
+    inflight[half].push_back(p);
+  }
   void upload(void *dst, const void *src, size_t bytes, hipStream_t s) {
     if (!bytes) return;
     ensure();
     // larger than half the ring: in half-ring pieces (a pageable hipMemcpyAsync of Final-13682's 107 MB of points ran at ~5 GB/s and
     // finished INSIDE the next call that synchronised: 15-23 ms of "set-up" in a 3-iteration LM call), then waited for here
-    const bool large = bytes > CAP / 2;
+    const bool large = bytes > HALF;
     for (size_t off = 0; off < bytes;) {
-      const size_t chunk = std::min(bytes - off, CAP / 2), need = (chunk + 255) & ~(size_t)255;
-      if (used + need > CAP) { GR_HIP(hipDeviceSynchronize()); used = 0; }
+      const size_t chunk = std::min(bytes - off, HALF), need = (chunk + 255) & ~(size_t)255;
+      // a piece never straddles the two halves: it starts the next half (or wraps) instead
+      if (used < HALF && used + need > HALF) used = HALF;
+      if (used + need > CAP) used = 0;
+      const int half = used < HALF ? 0 : 1;
+      if (used == 0 || used == HALF) drain(half); // entering a half: every copy that read it has finished
       std::memcpy(base + used, static_cast<const char *>(src) + off, chunk);
       GR_HIP(hipMemcpyAsync(static_cast<char *>(dst) + off, base + used, chunk, hipMemcpyHostToDevice, s));
+      mark(half, s);
       used += need; off += chunk;
     }
     if (large) GR_HIP(hipStreamSynchronize(s));
