@@ -753,6 +753,10 @@ def main():
         ut = user_traits_entry(args.steps)
         if ut:
             also.append(ut)
+        # the default workload under the two other inner solvers of the path, so that their numbers are the driver's too:
+        # explicit Schur complement + PCG on S, and the direct solve of S (nested-dissection tile Cholesky on MFMA)
+        also.append(also_entry("ladybug-1723", np.float64, "pcg-schur", "pcg-schur, f64", args.steps, 3, min(args.repeats, 3), parity_iters=2))
+        also.append(also_entry("ladybug-1723", np.float64, "dense-schur", "dense-schur (direct solve of S), f64", args.steps, 3, min(args.repeats, 3), parity_iters=2))
 
     line = {
         "metric": "lm_iterations_per_sec", "value": round(main_run["value"], 4), "unit": "LM iterations/s",
