@@ -1080,6 +1080,7 @@ template <typename T> struct Engine final : EngineBase {
       a.g9 = g9p; a.Hcp = hcp ? Hcp.p : nullptr; a.cam_partial = cam_partial.p; a.chi2_partial = chi2_partial.p;
       a.jst = model->store_jacobians ? jst.p : nullptr; a.jst_stride = jst_stride;
       a.lm = nullptr; a.gate = gate; a.cam_fixed = hcp ? cam_fixed_p() : nullptr; a.pt_fixed = hcp ? pt_fixed_p() : nullptr; a.stream = stream;
+      if (hcp && sf_cont) { a.Hcp_alt = Hcp1.p; a.hsel = lmdev.p; }
       hook_begin();
       hook_end(model->linearize(model->ctx, &a), "linearize");
       return;
@@ -2217,7 +2218,11 @@ template <typename T> struct Engine final : EngineBase {
     {
       Scope sc(this, "finalize_schur", 8.0 * No * w() + 54.0 * nseg * w() + (90.0 * Nc + 36.0 * Np) * w(), 9.0 * No + 54.0 * nseg + 120.0 * Np, true);
       RejectCont<T> rc{};
-      if (sf_cont) { rc.cams = cams.p; rc.pts = pts.p; rc.cams_bak = cams_bak.p; rc.pts_bak = pts_bak.p; rc.pack = pack.p; rc.vsum = sf_vsum.p; rc.lm = lmdev.p; rc.nu_cur = sf_nu; }
+      if (sf_cont) {
+        if (model) rc.model_cont = 1; // (the user's vertices: restored by gr_model_ops.step, LmDev::hsel bit 1)
+        else { rc.cams = cams.p; rc.pts = pts.p; rc.cams_bak = cams_bak.p; rc.pts_bak = pts_bak.p; rc.pack = pack.p; }
+        rc.vsum = sf_vsum.p; rc.lm = lmdev.p; rc.nu_cur = sf_nu;
+      }
       launch(k_finalize_schur<T>, nbc + nbp + (coop ? 0 : 1), (int)Nc, (int)Np, nbc, scale_system ? 1 : 0, cam_seg_ptr.p, cam_partial.p, pt_ptr.p, g9.p, Hcc.p, bu.p, Hll.p, scales.p, mu, ui,
              Hll_inv.p, Mp.p, vl.p, dec, cam_fixed_p(), pt_fixed_p(), cs, coop ? PcgScalars{} : scalars(), coop ? 0 : sc_cap, rc);
     }
@@ -2252,7 +2257,7 @@ template <typename T> struct Engine final : EngineBase {
       rho_blocks = model ? model->step_blocks : nct + nbp;
       rho_partial.alloc(rho_blocks);
       Scope sc(this, "backsub_apply", No * (27.0 * w() + 4) + (9.0 * Np + 3.0 * n + 24.0 * Nc) * w(), No * 54.0, true);
-      if (model) launch(k_backsub_apply<T, false>, nct + nbp, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, nullptr, nullptr, nullptr, nullptr, nullptr, mu, nullptr, lm, nullptr, nullptr);
+      if (model) launch(k_backsub_apply<T, false>, nct + nbp, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, nullptr, nullptr, nullptr, nullptr, nullptr, mu, nullptr, lm, sf_cont ? Hcp1.p : nullptr, sf_cont ? lmdev.p : nullptr);
       else launch(k_backsub_apply<T>, rho_blocks, (int)Nc, (int)Np, nct, pt_ptr.p, cam_pm.p, Hcp.p, Hll_inv.p, bu.p, scales.p, v_dx.p, cams.p, pts.p, cams_bak.p, pts_bak.p, pack.p, mu, rho_partial.p, lm, sf_cont ? Hcp1.p : nullptr, sf_cont ? lmdev.p : nullptr);
     }
     // user-traits problems: the trial step through Traits::update, under the same decision (the damping of its rho partials from LmDev)
@@ -2432,7 +2437,7 @@ template <typename T> struct Engine final : EngineBase {
     sf_active = opt.solver == GR_SOLVER_PCG_SCHUR && schur_fused_ok(opt.pcg_max_iter) && schur_coop() && opt.iterations > 0;
     bool head_enqueued = false; // the head of the NEXT iteration is already in the stream (device-decided accept)
     T chi2v = 0;
-    sf_cont = sf_active && !model && tune.schur_fused != 1; // (1: the head stops on a rejected step and the host runs the rejection)
+    sf_cont = sf_active && tune.schur_fused != 1; // (1: the head stops on a rejected step and the host runs the rejection)
     if (sf_active) {
       // Schur solver, small reduced system: the first linearisation is finalised by the head of iteration 0 like every other one,
       // and that launch reports the initial chi2

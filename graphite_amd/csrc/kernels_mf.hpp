@@ -736,7 +736,7 @@ k_linearize(int No, int ntiles, const int *__restrict__ cam_cm, const int *__res
             T *__restrict__ Hcp_alt = nullptr, const LmDev *__restrict__ hs = nullptr) {
   if (lm && lm->stop) return;
   if (gate && !*gate) return;
-  if (WRITE_HCP && hs && hs->hsel == 0) Hcp = Hcp_alt;
+  if (WRITE_HCP && hs && (hs->hsel & 1) == 0) Hcp = Hcp_alt;
   if (rst_cap > 0 && blockIdx.x == gridDim.x - 1) {
     for (int i = threadIdx.x; i < rst_cap * NSLOT * NS; i += TPB) rst.acc[slot_word(i)] = 0.0;
     for (int i = threadIdx.x; i < rst_cap; i += TPB) { rst.done[i] = 0; rst.pdp[i] = 0.0; rst.rz0[i] = (i == 0) ? __builtin_inf() : 0.0; }

@@ -90,7 +90,9 @@ struct CoopState {           // k_schur_pcg_coop's cross-workgroup state (device
 // mu * nu, and the rest of the head runs as the first head of the next LM iteration: no four no-op launches, no host round trip, no
 // revert launch, no re-linearisation (Ladybug-49: ~50 us per rejected step, every fourth step of the bench line).
 template <typename T> struct RejectCont {
-  T *cams = nullptr, *pts = nullptr;             // != nullptr: this form is on
+  T *cams = nullptr, *pts = nullptr;             // != nullptr: this form is on, and the vertices are the library's (taken back here)
+  int model_cont = 0;                            // user-traits problems: this form is on; the vertices are the user's — LmDev::hsel bit 1 tells
+                                                 // the step launch behind this head (gr_model_ops.step) to restore its backup first
   const T *cams_bak = nullptr, *pts_bak = nullptr;
   T *pack = nullptr;
   double *vsum = nullptr;                        // [Np][9] per-point sums of the current linearisation, as summed (double)
@@ -113,7 +115,7 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
     if (!dec.report_only) {
       double mun;
       const bool ok = lm_accept<T>(dec, s_sum[0], s_sum[1], mun);
-      cont = !ok && rc.cams != nullptr;
+      cont = !ok && (rc.cams != nullptr || rc.model_cont);
       if (cont) mun = (double)((T)dec.mu_cur * (T)rc.nu_cur);
       if (blockIdx.x == 0 && threadIdx.x == 0) {
         dec.lm->mu = mun; dec.lm->stop = (ok || cont) ? 0 : 2;
@@ -128,7 +130,7 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
   }
   // this launch takes a NEW linearisation over unless it continues from the current point: the other block buffer becomes the current one
   // (nothing in this kernel reads the blocks or hsel)
-  if (rc.lm && !cont && blockIdx.x == 0 && threadIdx.x == 0) rc.lm->hsel ^= 1;
+  if (rc.lm && blockIdx.x == 0 && threadIdx.x == 0) rc.lm->hsel = cont ? (rc.lm->hsel | (rc.model_cont ? 2 : 0)) : ((rc.lm->hsel ^ 1) & 1);
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0 && cs.barrier) *cs.barrier = 0u;
   if (pcg_cap > 0 && b == (int)gridDim.x - 1) { // an extra workgroup
@@ -144,6 +146,7 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
     const int c = (b * 4 + wave) * 7 + g;
     const bool on = g < 7 && c < Nc;
     if (!on) return;
+    if (cont && !rc.cams) return; // (user-traits problems: the sums stand, the vertices are the step launch's business)
     if (cont) { // the camera's sums stand; its parameters and pack go back to the backup
       const T v = rc.cams_bak[9 * (size_t)c + j];
       rc.cams[9 * (size_t)c + j] = v;
@@ -249,8 +252,10 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
     if (cont) { // the sums as they were taken, the point back at its backup
 #pragma unroll
       for (int i = 0; i < 9; ++i) v[i] = rc.vsum[9 * (size_t)l + i];
+      if (rc.pts) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) rc.pts[3 * (size_t)l + q] = rc.pts_bak[3 * (size_t)l + q];
+        for (int q = 0; q < 3; ++q) rc.pts[3 * (size_t)l + q] = rc.pts_bak[3 * (size_t)l + q];
+      }
     } else if (rc.vsum) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) rc.vsum[9 * (size_t)l + i] = v[i];
@@ -304,7 +309,7 @@ k_schur_reduce(int nitems, int nwg_items, const int *__restrict__ item_blk, cons
                int nch, const int *__restrict__ chunk_beg, const int *__restrict__ pt_cm, const int *__restrict__ pos_cm, const T *__restrict__ vl,
                T *__restrict__ partial9, const LmDev *__restrict__ lm, const T *__restrict__ Hcp_alt = nullptr, const LmDev *__restrict__ hs = nullptr) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
-  if (hs && hs->hsel) Hcp = Hcp_alt; // (RejectCont: the buffer that holds the current point's blocks)
+  if (hs && (hs->hsel & 1)) Hcp = Hcp_alt; // (RejectCont: the buffer that holds the current point's blocks)
   const int lane = threadIdx.x & 63;
   if ((int)blockIdx.x >= nwg_items) { // ---- b_S partials: one wave per camera chunk
     const int ch = ((int)blockIdx.x - nwg_items) * 4 + (threadIdx.x >> 6);
@@ -625,7 +630,7 @@ k_backsub_apply(int Nc, int Np, int nct, const int *__restrict__ pt_ptr, const i
                 T *__restrict__ cams, T *__restrict__ pts, T *__restrict__ cams_bak, T *__restrict__ pts_bak, T *__restrict__ pack,
                 double mu, double *__restrict__ rho_partial, const LmDev *__restrict__ lm, const T *__restrict__ Hcp_alt = nullptr, const LmDev *__restrict__ hs = nullptr) {
   if (lm) { if (lm->stop) return; mu = lm->mu; }
-  if (hs && hs->hsel) Hcp = Hcp_alt;
+  if (hs && (hs->hsel & 1)) Hcp = Hcp_alt;
   __shared__ double red[4];
   __shared__ T cs[252];
   const unsigned pose_dim = 9u * (unsigned)Nc;

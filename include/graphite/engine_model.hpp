@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(256) k_em_linearize(gr_model_lin_args a, Model
   const int lane = threadIdx.x & 63;
   int j0, jstride, niter, jlim;
   gr::xcd_obs_range(a.ntiles, a.No, j0, jstride, niter, jlim);
-  T *const g9 = static_cast<T *>(a.g9), *const Hcp = static_cast<T *>(a.Hcp), *const cam_partial = static_cast<T *>(a.cam_partial);
+  T *const g9 = static_cast<T *>(a.g9), *const cam_partial = static_cast<T *>(a.cam_partial);
+  T *const Hcp = static_cast<T *>((WRITE_HCP && a.hsel && (static_cast<const gr::LmDev *>(a.hsel)->hsel & 1) == 0) ? a.Hcp_alt : a.Hcp);
   double chi2 = 0.0;
   int j = j0 + threadIdx.x;
   bool valid = niter > 0 && j < jlim;
@@ -372,9 +373,10 @@ template <typename F> __global__ void __launch_bounds__(256) k_em_operator(gr_mo
 // Workgroups [0, nbc): one thread per pose; the others: one thread per landmark.  PAD = the engine's block width (9 / 3).
 template <typename Tr, typename T, int PAD>
 __device__ __forceinline__ double em_step_one(typename Tr::Vertex &vtx, typename state_of<Tr>::type *bak, bool with_backup,
-                                              const T *dx, const T *scales, const T *bu, double mu, bool count) {
+                                              const T *dx, const T *scales, const T *bu, double mu, bool count, bool restore_first = false) {
   constexpr int D = (int)Tr::dimension;
-  if (with_backup) { if constexpr (state_of<Tr>::custom) *bak = Tr::get_state(vtx); else *bak = vtx; }
+  if (restore_first) { if constexpr (state_of<Tr>::custom) Tr::set_state(vtx, *bak); else vtx = *bak; } // (a rejected trial point: back to the kept one; its backup stands)
+  else if (with_backup) { if constexpr (state_of<Tr>::custom) *bak = Tr::get_state(vtx); else *bak = vtx; }
   T d[D];
   double rho = 0;
 #pragma unroll
@@ -393,6 +395,7 @@ __global__ void __launch_bounds__(256) k_em_step(gr_model_step_args a, slot_vert
   if (a.lm && static_cast<const gr::LmDev *>(a.lm)->stop) return;
   if (a.gate && !*a.gate) return;
   if (a.lm) a.mu = static_cast<const gr::LmDev *>(a.lm)->mu; // device-decided loop: the damping the decision left
+  const bool restore_first = a.lm && (static_cast<const gr::LmDev *>(a.lm)->hsel & 2) != 0;
   __shared__ double red[4];
   const T *dx = static_cast<const T *>(a.dx), *sc = static_cast<const T *>(a.scales), *bu = static_cast<const T *>(a.bu);
 #ifndef GR_NO_CLEAR
@@ -411,15 +414,15 @@ __global__ void __launch_bounds__(256) k_em_step(gr_model_step_args a, slot_vert
   if ((int)blockIdx.x < nbc) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < Nc) {
-      if (a.cam_fixed && a.cam_fixed[i]) { if (a.with_backup) { if constexpr (state_of<slot_traits<F, 0>>::custom) cam_bak[i] = slot_traits<F, 0>::get_state(camv[i]); else cam_bak[i] = camv[i]; } }
-      else rho = em_step_one<slot_traits<F, 0>, T, 9>(camv[i], cam_bak + i, a.with_backup != 0, dx + 9 * (size_t)i, sc + 9 * (size_t)i, bu + 9 * (size_t)i, a.mu, a.cam_weight != 0);
+      if (a.cam_fixed && a.cam_fixed[i]) { if (a.with_backup && !restore_first) { if constexpr (state_of<slot_traits<F, 0>>::custom) cam_bak[i] = slot_traits<F, 0>::get_state(camv[i]); else cam_bak[i] = camv[i]; } }
+      else rho = em_step_one<slot_traits<F, 0>, T, 9>(camv[i], cam_bak + i, a.with_backup != 0, dx + 9 * (size_t)i, sc + 9 * (size_t)i, bu + 9 * (size_t)i, a.mu, a.cam_weight != 0, restore_first);
     }
   } else {
     const int i = (blockIdx.x - nbc) * 256 + threadIdx.x;
     const size_t o = 9 * (size_t)Nc + 3 * (size_t)i;
     if (i < Np) {
-      if (a.pt_fixed && a.pt_fixed[i]) { if (a.with_backup) { if constexpr (state_of<slot_traits<F, 1>>::custom) pt_bak[i] = slot_traits<F, 1>::get_state(ptv[i]); else pt_bak[i] = ptv[i]; } }
-      else rho = em_step_one<slot_traits<F, 1>, T, 3>(ptv[i], pt_bak + i, a.with_backup != 0, dx + o, sc + o, bu + o, a.mu, true);
+      if (a.pt_fixed && a.pt_fixed[i]) { if (a.with_backup && !restore_first) { if constexpr (state_of<slot_traits<F, 1>>::custom) pt_bak[i] = slot_traits<F, 1>::get_state(ptv[i]); else pt_bak[i] = ptv[i]; } }
+      else rho = em_step_one<slot_traits<F, 1>, T, 3>(ptv[i], pt_bak + i, a.with_backup != 0, dx + o, sc + o, bu + o, a.mu, true, restore_first);
     }
   }
   rho = gr::block_sum_256(rho, red);

@@ -24,8 +24,9 @@ template <> struct Vec2T<double> { using type = double2; };
 struct LmDev {
   double mu;
   int stop; // 0 run | 2 the step was not accepted
-  int hsel; // Schur solvers with two camera-point block buffers: the one that holds the CURRENT point's blocks (the trial linearisation
-            // writes the other one; the finalisation that takes a new linearisation over flips it, a rejected step leaves it)
+  int hsel; // Schur solvers with two camera-point block buffers — bit 0: the one that holds the CURRENT point's blocks (the trial
+            // linearisation writes the other one; the finalisation that takes a new linearisation over flips it, a rejected step leaves
+            // it); bit 1 (user-traits problems): the vertices still sit at a rejected trial point — the next step restores its backup first
 };
 
 // ---- cross-lane exchange without LDS ------------------------------------------------------------------------------------

@@ -52,6 +52,10 @@ typedef struct {
   const int32_t *gate;                    /* NULL or a device word: return at once when *gate == 0                        */
   const unsigned char *cam_fixed, *pt_fixed; /* NULL or per-vertex flags: Hcp of a fixed vertex's observation is zero     */
   void *stream;
+  /* device-decided Schur loop whose rejected steps do not stop the head: two buffers of camera-point blocks; hsel (an LmDev *, bit 0 of its
+     hsel field = the buffer that holds the CURRENT point's blocks: 0 = Hcp, 1 = Hcp_alt) — the lineariser writes the OTHER one.  NULL: Hcp. */
+  void *Hcp_alt;
+  const void *hsel;
 } gr_model_lin_args;
 
 /* Graph::compute_error + chi2 (graph.hpp:212-225) at the current vertex values */
@@ -97,6 +101,8 @@ typedef struct {
   void *clear_ptr[3];
   int64_t clear_bytes[3];
   double *inf_word;
+  /* `lm` != NULL and bit 1 of its hsel field set: the vertices still sit at a rejected trial point — restore every vertex from its
+     backup first (and leave the backup alone), then apply this step */
 } gr_model_step_args;
 
 typedef struct gr_model_ops {
