@@ -401,19 +401,29 @@ k_schur_reduce(int nitems, int nwg_items, const int *__restrict__ item_blk, cons
   }
   last = __builtin_amdgcn_readfirstlane(last);
   if (!last) return;
-  if (lane < 9) {
+  {
+    // the slabs in item order, SEVEN in flight — one per lane group, nine registers per lane — and added in item order through
+    // shuffles: the heaviest blocks (a camera's own: one product per observation, a dozen items on Ladybug-49) used to cost their last
+    // arriver six dependent round trips at two slabs each, the tail of the launch.  (Eight slabs in nine lanes' registers: 72 more
+    // VGPRs, Ladybug-1723's launch 266 -> 317 us.)
     T tot[9];
 #pragma unroll
     for (int r = 0; r < 9; ++r) tot[r] = T(0);
     const int i0 = multi_first[m], n = multi_n[m];
-    for (int it = 0; it < n; it += 2) { // two slabs in flight, added in item order
-      const T *s0 = slab + 81 * (size_t)(i0 + it) + 9 * c, *s1 = slab + 81 * (size_t)(i0 + (it + 1 < n ? it + 1 : it)) + 9 * c;
-      T q0[9], q1[9];
+    for (int it = 0; it < n; it += 7) {
+      T q[9];
+      const int idx = it + (g < 7 ? g : 0);
+      const T *su = slab + 81 * (size_t)(i0 + (idx < n ? idx : n - 1)) + 9 * c;
 #pragma unroll
-      for (int r = 0; r < 9; ++r) { q0[r] = __hip_atomic_load(&s0[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); q1[r] = __hip_atomic_load(&s1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      for (int r = 0; r < 9; ++r) q[r] = __hip_atomic_load(&su[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-      for (int r = 0; r < 9; ++r) { tot[r] += q0[r]; if (it + 1 < n) tot[r] += q1[r]; }
+      for (int u = 0; u < 7; ++u)
+        if (it + u < n) {
+#pragma unroll
+          for (int r = 0; r < 9; ++r) tot[r] += __shfl(q[r], 9 * u + c, 64);
+        }
     }
+    if (lane < 9)
     schur_epilogue<T>(S_rowi[blk], S_coli[blk], c, tot, Hcc, scales, mu, use_identity, S + 81 * (size_t)blk + 9 * c);
   }
 }
