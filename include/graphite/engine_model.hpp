@@ -36,9 +36,12 @@ public:
 // K directional derivatives carried at once as the dual part of Dual<T, Tangent<T, K>>: the user's error function is evaluated
 // ceil((pose_dim + landmark_dim) / K) times instead of once per column (ops/linearize.hpp:43-79 seeds one column per evaluation;
 // every component below goes through the same operations in the same order as that column's own evaluation would).
-// GRAPHITE_ENGINE_TANGENT_WIDTH = 1 keeps the one-column form (for error functions that name Dual<T, T> explicitly).
+// GRAPHITE_ENGINE_TANGENT_WIDTH: 0 (default) = ALL columns in one evaluation (K = pose_dim + landmark_dim <= 12; measured on the
+// Ladybug-1723 shape, fp64, no spills at 180-190 VGPRs: k3 factor 99 / 89 / 80 us per linearisation at K = 4 / 6 / 12, pinhole 89 / 81 / 72);
+// a smaller K for an error function whose temporaries do not fit; 1 keeps the one-column form (for error functions that name
+// Dual<T, T> explicitly).
 #ifndef GRAPHITE_ENGINE_TANGENT_WIDTH
-#define GRAPHITE_ENGINE_TANGENT_WIDTH 4
+#define GRAPHITE_ENGINE_TANGENT_WIDTH 0
 #endif
 template <typename T, int K> struct Tangent {
   T v[K];
@@ -136,8 +139,8 @@ __device__ __forceinline__ typename F::Scalar em_evaluate(const ModelView<F> &mv
     if constexpr (std::is_same<typename F::Traits::Differentiation, DifferentiationMode::Manual>::value) {
       call_jacobian_t<F, 0, T>(v, mv.obs[j], mv.data[j], jc, seq);
       call_jacobian_t<F, 1, T>(v, mv.obs[j], mv.data[j], jp, seq);
-    } else if constexpr (GRAPHITE_ENGINE_TANGENT_WIDTH > 1) { // dual numbers, K columns per evaluation (Tangent above)
-      constexpr int K = GRAPHITE_ENGINE_TANGENT_WIDTH, NPASS = (DC + DL + K - 1) / K;
+    } else if constexpr (GRAPHITE_ENGINE_TANGENT_WIDTH != 1) { // dual numbers, K columns per evaluation (Tangent above)
+      constexpr int K = GRAPHITE_ENGINE_TANGENT_WIDTH > 1 ? GRAPHITE_ENGINE_TANGENT_WIDTH : DC + DL, NPASS = (DC + DL + K - 1) / K;
       using D = Dual<T, Tangent<T, K>>;
 #pragma unroll
       for (int pass = 0; pass < NPASS; ++pass) {
