@@ -18,6 +18,7 @@
 #include "sparse_chol.hpp"
 #include "kernels_model.hpp"
 #include "kernels_sf.hpp"
+#include "kernels_rp.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -57,6 +58,7 @@ static void tuning_default(gr_bal_tuning &t) {
   t.spchol_fuse = env_int("GR_SPCHOL_FUSE", 2);
   t.spchol_bwd_chain = env_int("GR_SPCHOL_BWD_CHAIN", 1);
   t.schur_fused = env_int("GR_SCHUR_FUSED", -1);
+  t.pcg_resident = env_int("GR_PCG_RESIDENT", -1);
   t.spchol_slice = std::max(1, env_int("GR_SPCHOL_SLICE", 1)); // tiles per substitution item (Ladybug-1723 direct Schur: 1 -> 322.5, 2 -> 319.5, 3 -> 314.5, 4 -> 310 LM it/s)
 }
 
@@ -476,6 +478,7 @@ template <typename T> struct Engine final : EngineBase {
     if (tiling_tuned) { if (tiled) untile(); tiling_tuned = false; } // timed choices are re-made by the next solver_update_structure
     fused_agreed = false; // ... before the ranks agree on the fused message again (agree_on_fusion, collective): the timing runs must not fuse
     records_tuned = false;
+    rp_fit = -1;
     if (chol_ready) { chol_ready = false; use_spchol = false; }
     if (schur_ready && nitems) schur_ready = false;
     if (comm) comm->set_timeout_ms(tune.ipc_timeout_ms);
@@ -972,6 +975,7 @@ template <typename T> struct Engine final : EngineBase {
   const unsigned char *pt_fixed_p() const { return has_fixed ? d_pt_fixed.p : nullptr; }
   void set_jacobian_precision(int dtype) override {
     no_model("gr_bal_set_jacobian_precision");
+    rp_fit = -1;
     if (dtype == GR_F32 && sizeof(T) == 4) { jac32 = false; return; } // already fp32 throughout
     if (dtype != GR_F32 && dtype != GR_F64) throw std::invalid_argument("jacobian precision: GR_F32 or GR_F64");
     if (dtype == GR_F64 && sizeof(T) == 4) throw std::invalid_argument("an fp32 problem cannot evaluate fp64 Jacobians");
@@ -2312,6 +2316,86 @@ template <typename T> struct Engine final : EngineBase {
     ap.cam_weight = 1; ap.at_cap = (k + 1 == max_iter) ? 1 : 0;
     return ap;
   }
+  // ---- resident PCG (kernels_rp.hpp): the whole inner solve + the trial step as ONE launch, one 512-thread workgroup per CU ----
+  DevBuf<T> rp_rec6, rp_crec, rp_g4;
+  DevBuf<unsigned> rp_bar;
+  DevBuf<long long> rp_dbg; // GR_RP_DEBUG=1: phase stamps of the last resident launch (gr_test_rp_stamps)
+  volatile int *h_rp_fail = nullptr; // pinned: a grid barrier of the resident launch timed out (workgroups not co-resident)
+  bool lm_resident = false;          // armed by lm()
+  bool rp_disabled = false;          // a barrier timed out once on this handle: the multi-launch form from then on
+  int rp_fit = -1;                   // -1 not decided, 0 / 1 (structure, tuning and device dependent: re-decided by apply_tuning)
+  int rp_grid() const { return num_cu & ~7; }
+  bool resident_fits() {
+    if (rp_fit >= 0) return rp_fit != 0;
+    rp_fit = 0;
+    if (model || comm || tiled || jac32 || tune.lm_fused == 2 || tune.lm_fused == 0) return false;
+    const int G = rp_grid();
+    if (G < 8 || No <= 0 || 4 * No >= (int64_t)1 << 29 || 6 * Np >= (int64_t)1 << 28) return false; // 32-bit byte offsets of the buffer accesses
+    // the kernel's own partition, evaluated for every workgroup
+    const int nblk = (int)((No + 63) >> 6), nb = G >> 3;
+    const int cam_tiles = cdiv(pose_dim, 9 * RP_CT), ntile = cam_tiles + cdiv(Np, RP_PT);
+    for (int b = 0; b < G; ++b) {
+      const int x = b & 7, bi = b >> 3;
+      const int x0 = (int)((long long)x * nblk / 8), x1 = (int)((long long)(x + 1) * nblk / 8);
+      const int b0 = x0 + (int)((long long)bi * (x1 - x0) / nb), b1 = x0 + (int)((long long)(bi + 1) * (x1 - x0) / nb);
+      if ((long long)(b1 - b0) * 64 > (long long)RP_RO * RTPB) return false;
+      const int ut0 = (int)((long long)b * ntile / G), ut1 = (int)((long long)(b + 1) * ntile / G);
+      if (ut1 - ut0 > RP_RV) return false;
+    }
+    // one workgroup per CU must be resident: LDS image + the occupancy query
+    const void *fn = reinterpret_cast<const void *>(&k_pcg_resident<T, T>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RpLds<T>::bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    int nbk = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, fn, RTPB, RpLds<T>::bytes) != hipSuccess || nbk < 1) { (void)hipGetLastError(); return false; }
+    if (!h_rp_fail) {
+      void *q = nullptr;
+      GR_HIP(hipHostMalloc(&q, 64, hipHostMallocCoherent | hipHostMallocMapped));
+      std::memset(q, 0, 64);
+      h_rp_fail = static_cast<volatile int *>(q);
+    }
+    rp_rec6.alloc(6 * (size_t)Np); rp_crec.alloc(18 * (size_t)Nc); rp_g4.alloc(4 * (size_t)No); rp_bar.alloc(RP_BAR_WORDS);
+    GR_HIP(hipMemsetAsync(rp_bar.p, 0, sizeof(unsigned) * RP_BAR_WORDS, stream));
+    rp_fit = 1;
+    if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] resident PCG: %d workgroups x %d threads, %zu bytes of LDS each\n", G, RTPB, (size_t)RpLds<T>::bytes);
+    return true;
+  }
+  // auto = OFF: measured on Ladybug-1723 fp64 the resident launch is 0.85-0.91 x the three launches it replaces (profiles/r06_v1_resident_pcg_*:
+  // the grid barriers cost 2-3 us each, but the operator phase is issue / latency bound at the same per-SIMD rate with two waves per SIMD
+  // where the stand-alone kernel has three, and the owners' registers spill); kept as a tested form behind gr_bal_tuning.pcg_resident = 1
+  bool resident_wanted() { return tune.pcg_resident > 0 && !rp_disabled && resident_fits(); }
+  // algorithmic bytes of one resident launch: what it reads once (the lane's streams, packs, points, the finalisation's vectors and
+  // inverses) and leaves (dx, the stepped vertices, their backups, the packs) + per inner iteration the exchange arrays touched once
+  // each way
+  double resident_fixed_bytes() const { return No * (2.0 * w() + 12.0) + (24.0 * Nc + 3.0 * Np) * w() + 5.0 * n * w() + (81.0 * Nc + 9.0 * Np) * w() + 5.0 * n * w() + 24.0 * Nc * w(); }
+  double resident_iter_bytes() const { return 2.0 * (6.0 * Np + 18.0 * Nc) * w() + 2.0 * 3.0 * No * w() + 2.0 * 9.0 * nseg * w() + (24.0 * Nc + 81.0 * Nc + 9.0 * Np + 2.0 * n) * w(); }
+  void launch_resident(PcgState st, const LmDev *lm, double mu, bool use_identity, bool identity_precond, int max_iter, double tol, double rej) {
+    RpParams<T> P{};
+    P.No = (int)No; P.Nc = (int)Nc; P.Np = (int)Np;
+    P.loss_kind = loss_kind; P.loss_delta = loss_delta;
+    P.cam_fixed = cam_fixed_p(); P.pt_fixed = pt_fixed_p();
+    P.rec6 = rp_rec6.p; P.crec = rp_crec.p; P.g4 = rp_g4.p; P.op_partial = op_partial.p;
+    P.max_iter = max_iter; P.use_identity = use_identity ? 1 : 0; P.identity_precond = identity_precond ? 1 : 0;
+    P.tol = tol; P.rej = rej; P.mu = mu;
+    P.st = st; P.bar = rp_bar.p; P.fail = h_rp_fail; P.dx = v_dx.p; P.lm = lm;
+    P.var = env_int("GR_RP_VAR", 0);
+    if (env_int("GR_RP_DEBUG", 0)) { rp_dbg.alloc(64 * (size_t)rp_grid()); P.dbg = rp_dbg.p; }
+    rho_blocks = rp_grid();
+    rho_partial.alloc(rho_blocks);
+    ApplyOnExit<T> ap;
+    ap.cams = cams.p; ap.pts = pts.p; ap.cams_bak = cams_bak.p; ap.pts_bak = pts_bak.p; ap.bu = bu.p;
+    ap.rho_partial = rho_partial.p; ap.pack = pack.p; ap.xp = (use_records && xp.n && xp_valid) ? xp.p : nullptr;
+    ap.cam_weight = 1;
+    P.ap = ap;
+    Scope sc(this, "pcg_resident", resident_fixed_bytes(), 0.0, true);
+    ++launch_count;
+    hipEvent_t ea = ext_a, eb = ext_b;
+    ext_a = ext_b = nullptr;
+#define GR_RP_ARGS P, cam_cm.p, pt_cm.p, pos_cm.p, obs_cm.p, blk_seg.p, seg_slot.p, pt_ptr.p, cam_seg_ptr.p, pts.p, pack.p, scales.p, v_diag.p, MinvC.p, MinvP.p, v_r.p, v_z.p, v_zs.p
+    if (ea) hipExtLaunchKernelGGL((k_pcg_resident<T, T>), dim3((unsigned)rp_grid()), dim3(RTPB), (unsigned)RpLds<T>::bytes, stream, ea, eb, 0, GR_RP_ARGS);
+    else hipLaunchKernelGGL((k_pcg_resident<T, T>), dim3((unsigned)rp_grid()), dim3(RTPB), (unsigned)RpLds<T>::bytes, stream, GR_RP_ARGS);
+#undef GR_RP_ARGS
+    GR_HIP(hipGetLastError());
+  }
   void launch_direction(PcgState st, int k, double tol, double rej, T *x, T *rec, const LmDev *lm, double mu, int max_iter) {
     Scope s3(this, "pcg_direction", 5.0 * n * sizeof(T), 3.0 * n, true);
     launch(k_pcg_direction<T>, lm_fused ? dir_grid() : grid_vec, (unsigned)n, x, v_xb.p, v_p.p, v_ps.p, v_z.p, scales.p, st, k, tol, rej, (unsigned)pose_dim, rec, lm, mu, apply_args(k, max_iter));
@@ -2356,6 +2440,8 @@ template <typename T> struct Engine final : EngineBase {
     const int fbj_nbc = cdiv(Nc, 28), fbj_slots = num_cu * fbj_per_cu;
     const int fbj_nbp = std::max(1, std::min(cdiv(Np, TPB / FIN_PL), 4 * fbj_nbc < fbj_slots ? fbj_slots - fbj_nbc : fbj_slots));
     if (first_lazy) { fbj_part.alloc(3 * (size_t)(fbj_nbc + fbj_nbp)); st.part0 = fbj_part.p; st.n_part0 = fbj_nbc + fbj_nbp; }
+    const bool resident = lm_resident && first_lazy;
+    if (resident) { st.bar = rp_bar.p; st.bar_words = RP_BAR_WORDS; } // cleared by k_finalize_bj's first workgroup
     if (!pcg_state_clean) k_pcg_state_init<<<1, TPB, 0, stream>>>(st, ctl_cap);
     pcg_state_clean = false;
     const LmDev *lm = (dec.seq && !dec.report_only) ? lmdev.p : nullptr;
@@ -2367,6 +2453,10 @@ template <typename T> struct Engine final : EngineBase {
                                                       v_dx.p, v_r.p, v_z.p, first_lazy ? v_zs.p : nullptr, IDENTITY ? 1 : 0, 1, dec, cam_fixed_p(), pt_fixed_p());
     }
     fin_pending = false; hcp_valid = false;
+    if (resident) { // every inner iteration and the trial step: one launch
+      launch_resident(st, lm, mu, use_identity, IDENTITY, max_iter, tol, rej);
+      return;
+    }
     if (!first_lazy) launch_direction(st, -1, 0.0, 1e30, v_dx.p, rec, lm, mu, max_iter);
     if (max_iter > 0) {
       {
@@ -2417,8 +2507,8 @@ template <typename T> struct Engine final : EngineBase {
     std::memset(&st, 0, sizeof(st));
     struct LmScope { // the fused PCG start (solver_set_damping) is only armed inside this loop
       Engine *e;
-      explicit LmScope(Engine *e_) : e(e_) { e->lm_x = e->v_dx.p; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; e->sf_active = false; e->sf_cont = false; }
-      ~LmScope() { e->lm_x = nullptr; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->fin_pending = false; e->sf_active = false; e->sf_cont = false; e->profiling = false; }
+      explicit LmScope(Engine *e_) : e(e_) { e->lm_x = e->v_dx.p; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->lm_resident = false; e->fin_pending = false; e->sf_active = false; e->sf_cont = false; }
+      ~LmScope() { e->lm_x = nullptr; e->state_clean_cap = -1; e->update0_done = false; e->lm_fused = false; e->lm_resident = false; e->fin_pending = false; e->sf_active = false; e->sf_cont = false; e->profiling = false; }
     } lm_scope(this);
     struct EventPairs { // solve_seconds: events around every solve, read one iteration late, outside the decision -> launch path
       hipEvent_t ev[3][2];
@@ -2432,6 +2522,7 @@ template <typename T> struct Engine final : EngineBase {
     // (user-traits problems too: their trial step goes through the user's Traits::update — gr_model_ops.step, a launch of its own behind the
     // loop-ending direction launch, gated on the loop's exit word like the trial linearisation — and their heads run the direction-kernel form)
     lm_fused = pcg_solver && !comm && pcg_mode() == 0 && opt.pcg_max_iter >= 1 && tune.lm_fused != 0;
+    lm_resident = lm_fused && opt.iterations > 0 && resident_wanted();
     // (larger reduced systems keep the host-driven loop: measured on Ladybug-1723, 1 723 cameras, the merged finalisation and
     // back-substitution launches are no faster than their parts there — 1 716 vs 1 737 LM it/s — the shared S / b_S launch is what pays)
     sf_active = opt.solver == GR_SOLVER_PCG_SCHUR && schur_fused_ok(opt.pcg_max_iter) && schur_coop() && opt.iterations > 0;
@@ -2651,10 +2742,13 @@ template <typename T> struct Engine final : EngineBase {
       const bool ahead = speculate && ahead_enabled;
       if (ahead) trial_hook = enqueue_lin;
       trial_done = false;
-      if (ident) continue_pcg<true>(mi, tol, rej); else continue_pcg<false>(mi, tol, rej);
+      volatile int *const hit = h_iters(); // (the next head moves on to the other flag bank)
+      if (lm_resident) { // the whole solve and the step are one launch, already in the stream: the trial linearisation simply follows it
+        if (ahead) { enqueue_lin(nullptr); trial_done = true; }
+      } else if (ident) continue_pcg<true>(mi, tol, rej); else continue_pcg<false>(mi, tol, rej);
       trial_hook = nullptr;
       if (ahead) (trial_done ? ahead_hits : ahead_misses)++;
-      const int it = *h_iters(); // before the next head moves on to the other flag bank
+      int it = lm_resident ? 0 : *hit; // (resident: known once the launch has run — read after wait_chi2)
       if (!(use_records && xp.n && xp_valid)) xp_valid = false; // the step has been applied by the last direction launch
       int seq = 0;
       if (speculate) {
@@ -2676,6 +2770,15 @@ template <typename T> struct Engine final : EngineBase {
         seq = chi2_async(nullptr, v_dx.p, (double)mu); // (built-in model: the step itself was applied by the last direction launch)
       }
       wait_chi2(seq);
+      if (lm_resident) {
+        if (*h_rp_fail) { // not every workgroup was resident: this handle goes back to the multi-launch form; this call cannot be continued
+          *h_rp_fail = 0; rp_disabled = true;
+          GR_HIP(hipMemsetAsync(rp_bar.p, 0, sizeof(unsigned) * RP_BAR_WORDS, stream));
+          throw HipError("resident PCG: a grid barrier timed out (workgroups not co-resident); the handle now uses the multi-launch form (gr_bal_tuning.pcg_resident = 0)");
+        }
+        it = *hit;
+        if (profiling) { auto pf = prof.find("pcg_resident"); if (pf != prof.end()) pf->second.bytes += it * resident_iter_bytes(); }
+      }
       st.solve_seconds += (double)(h_ts[2 * pr + 1] - h_ts[2 * pr]) / wall_clock_hz;
       const double hs[2] = {h_res[0], h_res[1]};
       const double dev[2] = {h_res[2], h_res[3]};
@@ -2746,6 +2849,20 @@ template <typename T> struct Engine final : EngineBase {
     if (sf_cont) hcp_valid = false; // (the current point's blocks may sit in the second buffer: whoever needs them next re-linearises)
     GR_HIP(hipStreamSynchronize(stream));
     st.loop_seconds = std::chrono::duration<double>(clk::now() - tl).count();
+    if (lm_resident && rp_dbg.n && env_int("GR_RP_DEBUG", 0)) { // phase stamps of the LAST resident launch, over the workgroups (100 MHz clock)
+      GR_HIP(hipStreamSynchronize(stream));
+      const std::vector<long long> h = rp_dbg.download(stream);
+      const int G = rp_grid();
+      long long t0 = h[0];
+      for (int b = 0; b < G; ++b) t0 = std::min(t0, h[(size_t)b * 64]);
+      const int ns = (int)h[63];
+      std::fprintf(stderr, "[rp-debug] %d stamps; per stamp: min / mean / max over %d workgroups, us since the first workgroup started\n", ns, G);
+      for (int i = 0; i < ns && i < 63; ++i) {
+        long long lo = h[i], hi = h[i]; double sum = 0;
+        for (int b = 0; b < G; ++b) { const long long v = h[(size_t)b * 64 + i]; lo = std::min(lo, v); hi = std::max(hi, v); sum += (double)v; }
+        std::fprintf(stderr, "[rp-debug]   %2d  %7.2f %7.2f %7.2f\n", i, (lo - t0) * 0.01, (sum / G - t0) * 0.01, (hi - t0) * 0.01);
+      }
+    }
     if (ev_waiting >= 0) collect_solve_time(ev_waiting);
     st.ok = run ? 1 : 0;
     st.final_chi2 = (double)chi2v;

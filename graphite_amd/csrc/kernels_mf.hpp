@@ -89,6 +89,9 @@ struct PcgState {
   // them — adds them in workgroup order into slot 0 while the others already work: off the critical path, and reproducible
   double *part0 = nullptr;
   int n_part0 = 0;
+  // resident PCG (kernels_rp.hpp): the words of its grid barrier, cleared by the launch in front of it (k_finalize_bj's first workgroup)
+  unsigned *bar = nullptr;
+  int bar_words = 0;
   unsigned n;
   double tol, rej;
   __device__ __forceinline__ double *slots(int k, int which) const { return acc + ((size_t)k * NSLOT + which) * NSW; }
@@ -120,6 +123,7 @@ k_block_jacobi(int Nc, int Np, int nbc, int nbp, const T *__restrict__ Hcc, cons
   if (lm) { if (lm->stop) return; mu = lm->mu; }
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0 && st.left) *st.left = 0; // a new loop starts
+  if (b == 0 && st.bar) for (int i = threadIdx.x; i < st.bar_words; i += TPB) st.bar[i] = 0u;
   double prr = 0, prz = 0, pzz = 0;
   if (b < nbc) {
     const int c = b * 64 + threadIdx.x;
@@ -310,6 +314,7 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
   }
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0 && st.left) *st.left = 0; // a new loop starts
+  if (b == 0 && st.bar) for (int i = threadIdx.x; i < st.bar_words; i += TPB) st.bar[i] = 0u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double prr = 0, prz = 0, pzz = 0;
   if (b < nbc) {

@@ -155,7 +155,13 @@ typedef struct {
                                    host runs the rejection.  0: the round-4 kernels and the host-driven loop                              */
   int32_t spchol_bwd_chain;     /* GR_SPCHOL_BWD_CHAIN 1: the backward substitution of the nested-dissection Cholesky as ONE dependency-driven
                                    launch (items fetch their tile into registers before waiting for x_i); 0: one launch per level       */
-  int32_t reserved[2];
+  int32_t pcg_resident;         /* GR_PCG_RESIDENT  -1 auto (= 0: measured slower) | 0 | 1: GR_SOLVER_PCG / _IDENTITY inside the LM loop (built-in model, one GPU, plain
+                                   camera-major order, a problem whose per-lane share fits: observations <= 6 x 512 x CUs, tiles of 170
+                                   points / 56 cameras <= 4 x CUs) — the WHOLE inner solve and the trial step as ONE resident launch
+                                   (kernels_rp.hpp: one 512-thread workgroup per CU, the lane's observations and the thread's x, r, p, z'
+                                   in LDS / VGPRs for all inner iterations, two grid barriers per iteration).  0: operator / update /
+                                   direction launches                                                                                  */
+  int32_t reserved[1];
 } gr_bal_tuning;
 void gr_bal_tuning_default(gr_bal_tuning *t);
 
