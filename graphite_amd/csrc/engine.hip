@@ -1162,6 +1162,7 @@ template <typename T> struct Engine final : EngineBase {
     gr_model_step_args a{};
     a.dx = dx; a.scales = scales.p; a.bu = bu.p; a.mu = mu; a.with_backup = with_backup ? 1 : 0; a.cam_weight = cam_weight();
     a.rho_partial = rho_part; a.lm = lm; a.gate = gate; a.cam_fixed = cam_fixed_p(); a.pt_fixed = pt_fixed_p(); a.stream = stream;
+    a.restore_on_hsel = (lm && sf_cont) ? 1 : 0; // (LmDev::hsel bit 1 is only meaningful in the head that goes on after a rejected step)
     if (clear_state && ctl_cap > 0) {
       const PcgState st = pcg_state();
       a.clear_ptr[0] = ctl.p; a.clear_bytes[0] = (int64_t)(ctl.n * sizeof(double));
@@ -2184,7 +2185,7 @@ template <typename T> struct Engine final : EngineBase {
   // ---- device-decided LM iteration of PCGSchurSolver on small reduced systems (kernels_sf.hpp) ------------------------------------
   DevBuf<unsigned> coop_bar;
   DevBuf<double> coop_part;
-  DevBuf<int> coop_iters;
+  DevBuf<int> coop_iters, coop_fail_dev;
   volatile int *h_coop_fail = nullptr; // pinned, sticky
   bool sf_active = false;              // armed by lm()
   // ... and in that form (built-in model, gr_bal_tuning.schur_fused = 2 / auto) a rejected step does not stop the head: RejectCont (kernels_sf.hpp)
@@ -2193,10 +2194,25 @@ template <typename T> struct Engine final : EngineBase {
   DevBuf<T> Hcp1;                      // second buffer of camera-point blocks (LmDev::hsel)
   DevBuf<double> sf_vsum;              // per-point sums of the current linearisation
   bool schur_fused_ok(int max_iter) const { return !comm && max_iter >= 1 && tune.schur_fused != 0 && tune.lm_fused != 0; }
-  // the whole PCG on S in one cooperative launch: one wave per camera row, all of them resident at once
-  bool schur_coop() const { return Nc <= 2 * (int64_t)num_cu; }
+  // the whole PCG on S in one cooperative launch: one wave per camera row, all of them resident at once — checked against the
+  // launch's own residency (occupancy query x CUs), not assumed from the camera count; a handle whose barrier has
+  // timed out once (CUs held by another stream or process) keeps the per-iteration launches from then on (sf_disabled)
+  bool sf_disabled = false;
+  int coop_capacity = -1;
+  int coop_test_timeouts = 0; // GR_TEST_COOP_TIMEOUT = N: the first N cooperative launches of this handle wait for a workgroup that is not there
+  bool schur_coop() {
+    if (sf_disabled || Nc > 2 * (int64_t)num_cu) return false;
+    if (coop_capacity < 0) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_schur_pcg_coop<T>), 64, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 0; }
+      coop_capacity = nb * num_cu;
+      coop_test_timeouts = env_int("GR_TEST_COOP_TIMEOUT", 0);
+    }
+    return Nc <= (int64_t)coop_capacity;
+  }
   void ensure_coop(int max_iter) {
     coop_bar.alloc(1); coop_iters.alloc(1);
+    if (!coop_fail_dev.n) { coop_fail_dev.alloc(1); coop_fail_dev.zero(stream); }
     coop_part.alloc((3 * (size_t)max_iter + 4) * (size_t)Nc);
     if (!h_coop_fail) {
       void *q = nullptr;
@@ -2215,7 +2231,8 @@ template <typename T> struct Engine final : EngineBase {
     const LmDev *lm = (dec.seq && !dec.report_only) ? lmdev.p : nullptr;
     const int ui = use_identity ? 1 : 0;
     CoopState cs{};
-    cs.barrier = coop_bar.p; cs.part = coop_part.p; cs.iters = coop_iters.p; cs.hiters = h_iters(); cs.fail = h_coop_fail; cs.ts = h_ts ? h_ts + 2 * ts_slot : nullptr;
+    cs.barrier = coop_bar.p; cs.part = coop_part.p; cs.iters = coop_iters.p; cs.hiters = h_iters(); cs.fail = h_coop_fail; cs.fail_dev = coop_fail_dev.p; cs.ts = h_ts ? h_ts + 2 * ts_slot : nullptr;
+    if (coop_test_timeouts > 0) { --coop_test_timeouts; cs.absent = 1; }
     const int nbc = cdiv(Nc, 28), nbp = std::max(1, std::min(cdiv(Np, TPB / FIN_PL), num_cu * 4));
     const bool coop = schur_coop();
     if (!coop) { ensure_scalars(max_iter); for (int k = 0; k < max_iter + 1; ++k) flags()[k] = 0; }
@@ -2297,7 +2314,8 @@ template <typename T> struct Engine final : EngineBase {
       int khz = 0;
       if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) wall_clock_hz = 1e3 * khz;
     }
-    lmdev.alloc(1);
+    // (GR_TEST_POISON_LMDEV: tests/test_engine_model.py fills the record with 0xff instead — no loop may depend on what the allocation held)
+    if (!lmdev.n) { lmdev.alloc(1); GR_HIP(hipMemsetAsync(lmdev.p, env_int("GR_TEST_POISON_LMDEV", 0) ? 0xff : 0, sizeof(LmDev), stream)); }
   }
   DevBuf<double> fbj_part;      // PcgState::part0
   bool lm_fused = false;        // armed by lm() for GR_SOLVER_PCG / _IDENTITY without a communicator, PCG mode 0, max_iter >= 1
@@ -2538,6 +2556,9 @@ template <typename T> struct Engine final : EngineBase {
         const LmDev init{(double)mu, 0, 1}; // hsel = 1: the first linearisation writes buffer 0, the first head flips to it
         GR_HIP(hipMemcpyAsync(lmdev.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
         sf_nu = (double)nu;
+      } else { // the head that stops on a rejected step reads mu / stop only — but never leave the record to what the allocation held
+        const LmDev init{(double)mu, 0, 0};
+        GR_HIP(hipMemcpyAsync(lmdev.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
       }
       campack();
       linearize_hcp_deferred();
@@ -2813,7 +2834,23 @@ template <typename T> struct Engine final : EngineBase {
                rho_partial.p, rho_blocks, h_res, h_seq, seq, nullptr, cam_fixed_p(), pt_fixed_p(), IpcFused{}, 0ull);
       }
       wait_chi2(seq);
-      if (*h_coop_fail) throw HipError("cooperative PCG on S: a grid barrier timed out (workgroups not co-resident); set gr_bal_tuning.schur_fused = 0");
+      if (*h_coop_fail) {
+        // A grid barrier of the cooperative launch timed out: its workgroups were not all resident (CUs held by another stream or
+        // process).  Not sticky: the flag is cleared, THIS handle keeps the per-iteration launches from now on, the stale
+        // step the back-substitution launch applied is taken back and the iteration runs again on the host-driven loop.  (A head already
+        // enqueued behind it times out once more: the synchronisation below waits for it.)
+        GR_HIP(hipStreamSynchronize(stream));
+        *h_coop_fail = 0;
+        coop_fail_dev.zero(stream);
+        sf_disabled = true; sf_active = false; sf_cont = false; head_enqueued = false;
+        if (tune.verbose) std::fprintf(stderr, "[graphite-mi355x] cooperative PCG on S: a grid barrier timed out; this problem uses the host-driven loop from here on\n");
+        revert();
+        hcp_valid = false;
+        linearize_impl(want_hcp);
+        solver_update_values(opt.solver);
+        GR_HIP(hipStreamSynchronize(stream));
+        return host_iteration(i);
+      }
       const int it = *iters_word;
       if (schur_coop()) st.solve_seconds += (double)(h_ts[2 * pr + 1] - h_ts[2 * pr]) / wall_clock_hz; // device stamps around the cooperative PCG
       const double hs[2] = {h_res[0], h_res[1]};

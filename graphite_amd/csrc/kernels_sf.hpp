@@ -81,6 +81,8 @@ struct CoopState {           // k_schur_pcg_coop's cross-workgroup state (device
   volatile int *hiters;      // pinned mirror
   volatile int *fail;        // pinned host word, sticky: != 0 once a grid barrier has timed out (workgroups not co-resident)
   long long *ts;             // pinned [2] wall-clock stamps around the loop (solve_seconds), may be null
+  int *fail_dev = nullptr;   // the same word in device memory: the NEXT head's decision reads it (a step computed behind a timed-out barrier is never accepted)
+  unsigned absent = 0;       // TEST ONLY (GR_TEST_COOP_TIMEOUT): the barriers wait for this many workgroups more than the launch has — they time out
 };
 
 // A REJECTED STEP DOES NOT STOP THE HEAD (round 5, built-in model).  What a rejection needs of the current point is still in memory — Hcc,
@@ -114,7 +116,7 @@ k_finalize_schur(int Nc, int Np, int nbc, int scale_system, const int *__restric
     (void)lm_decide_prologue(dec, mu, s_sum);
     if (!dec.report_only) {
       double mun;
-      const bool ok = lm_accept<T>(dec, s_sum[0], s_sum[1], mun);
+      const bool ok = lm_accept<T>(dec, s_sum[0], s_sum[1], mun) && !(cs.fail_dev && *cs.fail_dev);
       cont = !ok && (rc.cams != nullptr || rc.model_cont);
       if (cont) mun = (double)((T)dec.mu_cur * (T)rc.nu_cur);
       if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -432,7 +434,7 @@ k_schur_reduce(int nitems, int nwg_items, const int *__restrict__ item_blk, cons
 // grid barrier of the cooperative PCG: monotonic counter, every workgroup one wave.  Everything that crosses workgroups is
 // written through (agent-scope stores) and drained before the arrival (cdna_hip_programming.md G16, form R1) and read back with
 // agent-scope loads.  Bounded: a launch whose workgroups are not all resident would wait for ever otherwise.
-__device__ __forceinline__ bool coop_barrier(unsigned *counter, unsigned target, volatile int *fail) {
+__device__ __forceinline__ bool coop_barrier(unsigned *counter, unsigned target, volatile int *fail, int *fail_dev = nullptr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int ok = 1;
   if ((threadIdx.x & 63) == 0) {
@@ -441,7 +443,8 @@ __device__ __forceinline__ bool coop_barrier(unsigned *counter, unsigned target,
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if (wall_clock64() - t0 > 200000000ll) { // 2 s of the 100 MHz clock: the launch's workgroups are not all resident
-        *fail = 1; // pinned host word (sticky): the host raises an error instead of using this solve
+        *fail = 1; // pinned host word: the host takes the step back and leaves the cooperative form (Engine::lm)
+        if (fail_dev) *fail_dev = 1;
         __threadfence_system();
         ok = 0;
         break;
@@ -549,7 +552,7 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
     if (lane == 0) __hip_atomic_store(&part[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (own) __hip_atomic_store(&p_glob[9 * (size_t)i + r], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (!coop_barrier(cs.barrier, ++phase * (unsigned)Nc, cs.fail)) return;
+  if (!coop_barrier(cs.barrier, ++phase * ((unsigned)Nc + cs.absent), cs.fail, cs.fail_dev)) return;
   double rz = coop_sum(part, Nc);
   double rz0 = __builtin_inf();
   int k = 0, iters = 0;
@@ -593,7 +596,7 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
       const double d = wave_allsum(own ? (double)(y * pr) : 0.0);
       if (lane == 0) __hip_atomic_store(&pden[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!coop_barrier(cs.barrier, ++phase * (unsigned)Nc, cs.fail)) return;
+    if (!coop_barrier(cs.barrier, ++phase * ((unsigned)Nc + cs.absent), cs.fail, cs.fail_dev)) return;
     const double den = coop_sum(pden, Nc);
     if (den == 0.0 || den != den) break;
     ++iters;
@@ -606,7 +609,7 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
       const double d = wave_allsum(own ? (double)(rr * zr) : 0.0);
       if (lane == 0) __hip_atomic_store(&prz[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!coop_barrier(cs.barrier, ++phase * (unsigned)Nc, cs.fail)) return;
+    if (!coop_barrier(cs.barrier, ++phase * ((unsigned)Nc + cs.absent), cs.fail, cs.fail_dev)) return;
     const T rz_new = (T)coop_sum(prz, Nc);
     const bool reject = (fabs((double)rz_new) > rejection_ratio * rz0) || (rz_new != rz_new);
     if (reject) { xr = xbr; break; }
@@ -616,7 +619,7 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
     rz = (double)rz_new; // pcg_schur.hpp keeps rz in T
     if (fabs((double)rz_new) < tol) { ++k; break; }
     if (own) __hip_atomic_store(&p_glob[9 * (size_t)i + r], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!coop_barrier(cs.barrier, ++phase * (unsigned)Nc, cs.fail)) return;
+    if (!coop_barrier(cs.barrier, ++phase * ((unsigned)Nc + cs.absent), cs.fail, cs.fail_dev)) return;
   }
   if (own) x_out[9 * (size_t)i + r] = xr;
   if (i == 0 && lane == 0) {

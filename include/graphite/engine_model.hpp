@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256) k_em_step(gr_model_step_args a, slot_vert
   if (a.lm && static_cast<const gr::LmDev *>(a.lm)->stop) return;
   if (a.gate && !*a.gate) return;
   if (a.lm) a.mu = static_cast<const gr::LmDev *>(a.lm)->mu; // device-decided loop: the damping the decision left
-  const bool restore_first = a.lm && (static_cast<const gr::LmDev *>(a.lm)->hsel & 2) != 0;
+  const bool restore_first = a.restore_on_hsel && a.lm && (static_cast<const gr::LmDev *>(a.lm)->hsel & 2) != 0;
   __shared__ double red[4];
   const T *dx = static_cast<const T *>(a.dx), *sc = static_cast<const T *>(a.scales), *bu = static_cast<const T *>(a.bu);
 #ifndef GR_NO_CLEAR

@@ -101,8 +101,11 @@ typedef struct {
   void *clear_ptr[3];
   int64_t clear_bytes[3];
   double *inf_word;
-  /* `lm` != NULL and bit 1 of its hsel field set: the vertices still sit at a rejected trial point — restore every vertex from its
-     backup first (and leave the backup alone), then apply this step */
+  /* restore_on_hsel != 0 (only the device-decided Schur loop whose rejected steps do not stop the head sets it), `lm` != NULL and
+     bit 1 of its hsel field set: the vertices still sit at a rejected trial point — restore every vertex from its backup first (and
+     leave the backup alone), then apply this step.  With restore_on_hsel == 0 the hsel field is never read: a head that stops on a
+     rejected step passes `lm` for the gate and the damping only. */
+  int32_t restore_on_hsel;
 } gr_model_step_args;
 
 typedef struct gr_model_ops {

@@ -144,6 +144,16 @@ def test_user_traits_take_the_device_decided_loops(tmp_path, mode, solver, form)
     assert "host loop" in host.stderr
     a, b = parse_trace(dev.stdout), parse_trace(host.stdout)
     assert len(a) == len(b) and np.allclose(a[:, 1], b[:, 1], rtol=1e-10) and np.allclose(a[:, 2], b[:, 2], rtol=1e-8)
+    if solver == "pcg-schur":
+        # the head that STOPS on a rejected step (GR_SCHUR_FUSED=1) passes the device's LM record to the user-side step launch
+        # for the gate and the damping only; the record's hsel word (bit 1: "restore the backup first") belongs to the form that goes on
+        # after a rejection.  With the record poisoned at allocation (all bits set) the stopping head must still give the same trace.
+        stop = run({"GR_VERBOSE": "1", "GR_SCHUR_FUSED": "1", "GR_TEST_POISON_LMDEV": "1"})
+        c = parse_trace(stop.stdout)
+        assert len(c) == len(b) and np.allclose(c[:, 1], b[:, 1], rtol=1e-10) and np.allclose(c[:, 2], b[:, 2], rtol=1e-8)
+        cont = run({"GR_VERBOSE": "1", "GR_TEST_POISON_LMDEV": "1"})
+        d = parse_trace(cont.stdout)
+        assert len(d) == len(b) and np.allclose(d[:, 1], b[:, 1], rtol=1e-10)
 
 
 @pytest.mark.gpu

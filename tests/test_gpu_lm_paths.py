@@ -90,3 +90,24 @@ def test_schur_head_that_goes_on_after_a_rejected_step(oracle_mod, monkeypatch, 
             r[mode] = run(l49, np.float32, ga.SOLVER_PCG_SCHUR, 20, **kw49)
         assert r["2"][2]["accepted"] < r["2"][2]["iterations_run"]
         assert r["2"][2]["accepted"] == r["1"][2]["accepted"] and np.allclose(r["2"][0], r["1"][0], rtol=1e-6)
+
+
+def test_a_cooperative_launch_that_times_out_is_not_sticky(monkeypatch):
+    """the cooperative PCG on S (one launch, software grid barrier) is armed only when the occupancy query says its
+    workgroups are all resident, and a barrier that times out all the same (CUs held by someone else) no longer breaks the handle:
+    the flag is cleared, the stale step is taken back, the iteration runs again on the host-driven loop and so do all later ones.
+    GR_TEST_COOP_TIMEOUT=1 makes the first cooperative launch of a handle wait for a workgroup that does not exist (2 s bound)."""
+    prob = synth.make_config("mini-50")
+    base = run(prob, np.float64, ga.SOLVER_PCG_SCHUR, 8)
+    monkeypatch.setenv("GR_TEST_COOP_TIMEOUT", "1")
+    g = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    ct, lt, st = g.levenberg_marquardt(solver=ga.SOLVER_PCG_SCHUR, iterations=8)
+    assert len(ct) == len(base[0]) and np.allclose(ct, base[0], rtol=1e-8)
+    assert st["accepted"] == base[2]["accepted"]
+    import time
+    g.set_params(prob.cameras, prob.points)
+    t0 = time.perf_counter()
+    ct2, _, st2 = g.levenberg_marquardt(solver=ga.SOLVER_PCG_SCHUR, iterations=8)  # same handle: host-driven loop, no new time-out
+    assert time.perf_counter() - t0 < 1.0
+    assert np.allclose(ct2, base[0], rtol=1e-8)
+    g.close()
