@@ -1005,7 +1005,18 @@ template <typename T> struct SparseChol {
   bool ok() {
     GR_HIP(hipMemcpyAsync(h_fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     GR_HIP(hipStreamSynchronize(stream));
-    return *h_fail == 0;
+    if (*h_fail != 0) {
+      // a bounded wait gave up: workgroups that arrived after it have left the per-panel counters, the quadrant counters
+      // and the ready words of the dependency-driven launches in an unknown state — clear them (and the chain's sequence number)
+      // before anybody factorises again, or a later finisher could be released early and read stale partial sums
+      if (d_bcnt.n) d_bcnt.zero(stream);
+      if (d_ready.n) d_ready.zero(stream);
+      if (d_qcnt.n) d_qcnt.zero(stream);
+      chain_seq = 0;
+      GR_HIP(hipStreamSynchronize(stream));
+      return false;
+    }
+    return true;
   }
 };
 

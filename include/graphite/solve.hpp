@@ -798,7 +798,10 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
     std::vector<T> obs;
     int loss_kind = 0; double loss_delta = 0;
     const size_t nc = fresh->cam_used.empty() ? cd->count() : fresh->cam_used.size(), np = fresh->pt_used.empty() ? pd->count() : fresh->pt_used.size();
-    auto bad = [&](const char *what) { std::cerr << "graphite: engine hand-over failed in " << what << ": " << gr_last_error_string() << "; using the generic kernels" << std::endl; return false; };
+    // (which path a graph takes is reported once both attempts below have decided — ADVICE r5: a step that fails here says what failed,
+    // not where the graph ends up)
+    std::string declined;
+    auto bad = [&](const char *what) { declined = std::string(what) + " failed: " + gr_last_error_string(); std::cerr << "graphite: engine hand-over: " << declined << std::endl; return false; };
     // the library's built-in camera model, when the user's traits are verified to BE it (by value, below)
     auto try_builtin = [&]() -> bool {
     if (!bal_dims || force_model) return false;
@@ -821,8 +824,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
       const size_t ns = pc.size() / 9;
       std::vector<T> er(2 * ns), eJc(18 * ns), eJp(6 * ns);
       if (gr_bal_model_evaluate(dt, (int64_t)ns, pc.data(), pp.data(), po.data(), er.data(), eJc.data(), eJp.data(), dev, nullptr) != GR_OK) {
-        std::cerr << "graphite: engine hand-over: gr_bal_model_evaluate failed: " << gr_last_error_string() << "; using the generic kernels" << std::endl;
-        return false;
+        return bad("gr_bal_model_evaluate");
       }
       const double tol = sizeof(T) == 8 ? 1e-10 : 1e-4;
       double worst = 0, worst_syn = 0;
@@ -847,7 +849,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
           std::cerr << "graphite: the factor traits declare bal_reprojection_model, but " << (model_ok ? "update()" : "error()/jacobian()")
                     << " differ from the engine's model (relative deviation " << (model_ok ? update_dev : std::max(worst, worst_syn))
                     << (worst <= tol && !(worst_syn <= tol) ? ", on the synthetic branch triples only" : "")
-                    << "); not the library's built-in camera model: the engine's kernels are instantiated on these traits instead (engine_model.hpp)" << std::endl;
+                    << "); not the library's built-in camera model: trying the engine's kernels instantiated on these traits (engine_model.hpp)" << std::endl;
         return false;
       }
     }
@@ -875,10 +877,10 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
     // losses, constraint data, any (<= 9, <= 3) -> <= 2 error / jacobian / update
     auto try_model = [&]() -> bool {
       if (fresh->prob) { gr_bal_destroy(fresh->prob); fresh->prob = nullptr; }
-      if (kind == GR_SOLVER_PCG_SCHUR_IMPLICIT) return false; // beyond the explicit form's camera count: generic kernels
+      if (kind == GR_SOLVER_PCG_SCHUR_IMPLICIT) { declined = "the implicit Schur form recomputes the built-in Jacobian"; return false; } // beyond the explicit form's camera count: generic kernels
       ci.clear(); pi.clear();
       fresh->model = fds[0]->make_engine_model(ci, pi, nc, np);
-      if (!fresh->model) return false;
+      if (!fresh->model) { declined = "traits outside the engine's model (dimensions beyond (9, 3) -> 2, non-plain-data types, or a precision matrix that is not symmetric positive semi-definite)"; return false; }
       if (!fresh->cam_used.empty() || !fresh->pt_used.empty())
         for (size_t f = 0; f < ci.size(); ++f) { ci[f] = cam_new[ci[f]]; pi[f] = pt_new[pi[f]]; }
       if (gr_bal_create_model(&fresh->prob, dt, (int64_t)nc, (int64_t)np, (int64_t)ci.size(), ci.data(), pi.data(), fresh->model->ops(), dev, nullptr) != GR_OK) return bad("gr_bal_create_model");
@@ -890,8 +892,15 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
     };
     if (!try_builtin()) {
       fresh->model.reset();
-      if (!try_model()) { fresh->model.reset(); return false; }
-    }
+      if (!try_model()) {
+        if (fresh->prob) { gr_bal_destroy(fresh->prob); fresh->prob = nullptr; } // (it holds the model's launcher table: before the model goes)
+        fresh->model.reset();
+        if (getenv("GR_VERBOSE") || !declined.empty())
+          std::cerr << "graphite: engine hand-over declined" << (declined.empty() ? "" : " (") << declined << (declined.empty() ? "" : ")") << ": this graph runs on the generic kernels" << std::endl;
+        return false;
+      }
+      if (getenv("GR_VERBOSE")) std::cerr << "[graphite] engine hand-over: the engine's kernels instantiated on the user's traits (engine_model.hpp)" << std::endl;
+    } else if (getenv("GR_VERBOSE")) std::cerr << "[graphite] engine hand-over: the library's built-in camera model" << std::endl;
     if (any_fixed && gr_bal_set_fixed(fresh->prob, cam_fixed.data(), pt_fixed.data()) != GR_OK) return bad("gr_bal_set_fixed");
     fresh->cd = cd; fresh->pd = pd; fresh->fd = fds[0];
     fresh->epoch_c = cd->structure_epoch; fresh->epoch_p = pd->structure_epoch; fresh->epoch_f = fds[0]->structure_epoch;
