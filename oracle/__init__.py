@@ -384,3 +384,22 @@ class CpuBaseline:
                      loop_seconds=st[4], setup_seconds=st[5])
         times = dict(zip(self.TIME_KEYS, (float(x) for x in tm)))
         return ct[:k], lt[:k], stats, times
+
+
+def circle_lm(points, radius, fixed=None, factor_on=None, solver="eigen", iterations=100, initial_damping=1e-6, use_identity=False,
+              pcg_max_iter=50, pcg_tol=1e-20, pcg_rej=10.0):
+    """BASELINE configs[0] on the CPU (oracle/circle_fit.hpp): examples/circle.cu's unary-factor graph through
+    optimizer::levenberg_marquardt with EigenLDLTSolver ("eigen") or PCGSolver + IdentityPreconditioner ("pcg").
+    Returns (chi2 trace, lambda trace, final points, stats)."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2).copy()
+    n = len(pts)
+    fx = np.ascontiguousarray(np.zeros(n, np.uint8) if fixed is None else (np.asarray(fixed) != 0).astype(np.uint8))
+    on = np.ascontiguousarray(np.ones(n, np.uint8) if factor_on is None else (np.asarray(factor_on) != 0).astype(np.uint8))
+    ct = np.zeros(iterations + 1); lt = np.zeros(iterations + 1)
+    stats = np.zeros(2, np.int32)
+    f = lib().gro_circle_lm_f64
+    f.restype = C.c_int
+    it = f(C.c_size_t(n), C.c_double(radius), _p(pts), _p(fx), _p(on), C.c_int({"eigen": 0, "pcg": 1}[solver]), C.c_int(iterations),
+           C.c_double(initial_damping), C.c_int(int(use_identity)), C.c_int(pcg_max_iter), C.c_double(pcg_tol), C.c_double(pcg_rej),
+           _p(ct), _p(lt), _p(stats))
+    return ct[:it + 1], lt[:it + 1], pts, dict(iterations_run=it, accepted=int(stats[0]), pcg_iterations=int(stats[1]))

@@ -2,6 +2,7 @@
 // extern "C" surface for ctypes (oracle/__init__.py).  _f32 / _f64 variants.
 #include "bal_pipeline.hpp"
 #include "cpu_baseline.hpp"
+#include "circle_fit.hpp"
 
 using namespace gro;
 
@@ -237,5 +238,17 @@ GRO_FOR_T(X)
   }
 GRO_FOR_T(X)
 #undef X
+
+// BASELINE configs[0] (circle_fit.hpp): pts [n][2] in / out; fixed, factor_on: n bytes each; solver 0 EigenLDLTSolver, 1 PCGSolver +
+// IdentityPreconditioner; traces of iterations + 1 doubles; stats: accepted, inner PCG iterations.  Returns the iterations run.
+int gro_circle_lm_f64(size_t n, double R, double *pts, const unsigned char *fixed, const unsigned char *factor_on, int solver, int iterations,
+                      double initial_damping, int use_identity, int pcg_max_iter, double pcg_tol, double pcg_rej, double *chi2_trace,
+                      double *lambda_trace, int *stats) {
+  CircleOracle o(n, R, pts);
+  for (size_t i = 0; i < n; ++i) { o.fixed[i] = fixed ? fixed[i] : 0; o.factor_on[i] = factor_on ? factor_on[i] : 1; }
+  const int it = o.levenberg_marquardt(solver, iterations, initial_damping, use_identity != 0, pcg_max_iter, pcg_tol, pcg_rej, chi2_trace, lambda_trace, &stats[0], &stats[1]);
+  for (size_t i = 0; i < 2 * n; ++i) pts[i] = o.p[i];
+  return it;
+}
 
 } // extern "C"

@@ -390,3 +390,35 @@ def test_fixed_dimension_schur_kernels_equal_the_any_dimension_ones(solver):
     assert np.allclose(outs[0], outs[1], rtol=1e-9, atol=1e-11)
     assert outs[0][0] < 10.0  # the optimisation converged (chi2 of the noisy observations)
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["eigen", "pcg"])
+@pytest.mark.parametrize("mode", ["manual", "auto"])
+def test_baseline_configs0_circle_100_vertices(oracle_mod, tmp_path, solver, mode):
+    """BASELINE configs[0] as stated: the reference's examples/circle.cu pose-graph-style plumbing problem (circle.cu:87-160) at ~100
+    vertices, fp64, through the `eigen_solver` path — EigenLDLTSolver (solver/eigen.hpp:49-98) — and through circle.cu's own
+    PCGSolver + IdentityPreconditioner, on the HIP generic layer, against the oracle's run of the same unary-factor graph
+    (oracle/circle_fit.hpp: levenberg_marquardt.hpp:110-242 on sparse_ldlt.hpp / pcg.hpp:61-232) from the same start bits:
+    chi2 and damping per LM iteration (the table prints 12 digits), final chi2 and every final vertex at 1e-10; the fixed vertex and
+    the vertex whose only factor is switched off keep their bits."""
+    exe = build_all()[0]
+    n, R = 100, 4.0
+    pts = synth.make_circle(n, R)
+    f = tmp_path / "start.txt"
+    f.write_text("".join(f"{float(x)!r} {float(y)!r}\n" for x, y in pts))
+    r = subprocess.run([exe, str(n), mode, "lm", solver, str(f)], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-3000:], r.stderr[-800:])
+    assert r.returncode == 0 and "OK (0 failures)" in r.stdout
+    fixed = np.zeros(n); fixed[n - 1] = 1
+    on = np.ones(n); on[2] = 0
+    ct, lt, p_ref, st = oracle_mod.circle_lm(pts, R, fixed, on, solver=solver, iterations=100)
+    tr = parse_trace(r.stdout)
+    assert len(tr) == len(ct) - 1 >= 3
+    assert np.allclose(tr[:, 0], ct[:-1], rtol=1e-10) and np.allclose(tr[:, 1], ct[1:], rtol=1e-10, atol=1e-13) and np.allclose(tr[:, 2], lt[1:], rtol=1e-9)
+    got = np.array([[float(v) for v in ln.split()[2:4]] for ln in r.stdout.splitlines() if ln.startswith("POINT ")])
+    assert got.shape == (n, 2) and np.allclose(got, p_ref, rtol=1e-10, atol=1e-12)
+    assert np.array_equal(got[2], pts[2]) and np.array_equal(got[n - 1], pts[n - 1])
+    final = float([ln for ln in r.stdout.splitlines() if ln.startswith("FINAL_CHI2")][0].split()[1])
+    assert abs(final - ct[-1]) <= 1e-10 * max(1.0, ct[-1])
+    assert np.allclose(np.hypot(*np.delete(got, [2, n - 1], 0).T), R, atol=1e-9)

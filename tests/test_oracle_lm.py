@@ -28,3 +28,35 @@ def test_early_stop_is_a_prefix_ending_on_three_small_gains(oracle_mod, solver):
                 break
     assert stop is not None and stop + 1 == k
     assert st2["iterations_run"] == stop
+
+
+def test_circle_oracle_configs0(oracle_mod):
+    """oracle/circle_fit.hpp (BASELINE configs[0], examples/circle.cu:87-160 at 100 vertices): both inner solvers of the
+    restatement — sparse LDL^T of the damped Hessian and PCG with the identity preconditioner — walk the same LM trace on this
+    block-diagonal system, every free vertex lands on the circle, the fixed vertex and the vertex whose factor is off keep their
+    bits, and what is left of chi2 is the fixed vertex's own residual."""
+    import numpy as np
+    from graphite_amd import synth
+    n, R = 100, 4.0
+    pts = synth.make_circle(n, R)
+    fixed = np.zeros(n); fixed[n - 1] = 1
+    on = np.ones(n); on[2] = 0
+    a = oracle_mod.circle_lm(pts, R, fixed, on, solver="eigen", iterations=100)
+    b = oracle_mod.circle_lm(pts, R, fixed, on, solver="pcg", iterations=100)
+    assert len(a[0]) == len(b[0]) and np.allclose(a[0], b[0], rtol=1e-10) and a[3]["accepted"] == b[3]["accepted"]
+    assert b[3]["pcg_iterations"] > 0 and a[3]["pcg_iterations"] == 0
+    for ct, lt, p, st in (a, b):
+        free = np.delete(np.arange(n), [2, n - 1])
+        assert np.allclose(np.hypot(p[free, 0], p[free, 1]), R, atol=1e-12)
+        assert np.array_equal(p[2], pts[2]) and np.array_equal(p[n - 1], pts[n - 1])
+        r_fixed = pts[n - 1] @ pts[n - 1] - R * R
+        assert abs(ct[-1] - r_fixed ** 2) < 1e-12 and ct[0] > 100 * ct[-1]
+    # the first step is the damped Gauss-Newton step of each vertex in its scaled coordinates (graph.hpp:254-287): with J = [2x, 2y]
+    # scaled to signs, p moves by -r / (2 + mu) * [1 / (2x), 1 / (2y)]
+    one = oracle_mod.circle_lm(pts, R, fixed, on, solver="eigen", iterations=1)
+    i = 0
+    x, y = pts[i]
+    r0 = x * x + y * y - R * R
+    mu = 1e-6
+    step = -r0 / (2.0 + mu * 1.0) * np.array([1 / (2 * x), 1 / (2 * y)])
+    assert np.allclose(one[2][i] - pts[i], step, rtol=1e-9)
