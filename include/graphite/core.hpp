@@ -202,9 +202,10 @@ public:
     if (n_ == cap_) grow(std::max<size_t>(2 * cap_, 8));
     new (p_ + n_++) T(v);
   }
-  void pop_back() { --n_; }
+  void pop_back() { if (n_) --n_; } // (a no-op on an empty vector, tests/vector.cu:31-35)
   void clear() { n_ = 0; }
   size_t size() const { return n_; }
+  size_t capacity() const { return cap_; }
   bool empty() const { return n_ == 0; }
   T &operator[](size_t i) { return p_[i]; }
   const T &operator[](size_t i) const { return p_[i]; }
@@ -372,6 +373,15 @@ template <typename Fn, typename... A> struct invocable {
 // =================================================================================================
 // VertexDescriptor (vertex.hpp:28-392)
 // =================================================================================================
+// block.hpp:19-30 — hashable, as the reference's tests build their own block -> offset maps
+} // namespace graphite
+namespace std {
+template <> struct hash<graphite::BlockCoordinates> {
+  size_t operator()(const graphite::BlockCoordinates &b) const noexcept { return std::hash<size_t>()(b.row) * 0x9E3779B97F4A7C15ull ^ std::hash<size_t>()(b.col); }
+};
+} // namespace std
+namespace graphite {
+
 template <typename T, typename S> class BaseVertexDescriptor {
 public:
   virtual ~BaseVertexDescriptor() = default;
@@ -383,6 +393,8 @@ public:
   virtual size_t get_local_id(size_t id) const = 0;
   virtual uint8_t *get_active_state() const = 0;
   virtual size_t *get_hessian_ids() const = 0;
+  virtual const size_t *get_block_ids() const = 0;                               // block column of each vertex (vertex.hpp:47)
+  virtual const std::unordered_map<size_t, size_t> &get_global_map() const = 0; // global id -> local id (vertex.hpp:37)
   // what kernels read: HBM copies while an optimiser loop has the vertices mirrored (begin_mirror/end_mirror), else the above
   virtual const uint8_t *device_active_state() const = 0;
   virtual const size_t *device_hessian_ids() const = 0;
@@ -456,6 +468,32 @@ template <typename V> __global__ void k_mirror_out(V *const *user, size_t n, con
 }
 } // namespace detail
 
+namespace detail {
+// ops/hessian.hpp:80-112 augment_hessian_diagonal_kernel: the diagonal of every ACTIVE vertex's block <- d + mu clamp(d, 1e-6, 1e32)
+// (or d + mu), d from the scalar diagonal, in double; blocks indexed by LOCAL vertex id, everything else untouched
+template <typename P, int D> __global__ void k_augment_block_diagonal(P *blocks, const P *scalar_diagonal, P mu, int identity, const uint8_t *state, size_t count) {
+  const size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (v >= count || !is_vertex_active(state, v)) return;
+  P *block = blocks + v * D * D;
+  for (int i = 0; i < D; ++i) {
+    const double d = (double)scalar_diagonal[v * D + i];
+    const double cl = d < 1.0e-6 ? 1.0e-6 : (d > 1.0e32 ? 1.0e32 : d);
+    block[i * D + i] = (P)(identity ? d + (double)mu : d + (double)mu * cl);
+  }
+}
+// ops/hessian.hpp:127-152 apply_block_jacobi_kernel: z[col .. col + d) = block * r[col .. col + d) per active vertex
+// (column-major block indexed by local vertex id, `hid` = the vertex's scalar column)
+template <typename T, typename P> __global__ void k_block_apply(const P *inv, const size_t *hid, const uint8_t *state, size_t count, int d, T *z, const T *r) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= count * d) return;
+  const size_t v = t / d, row = t % d;
+  if (!is_vertex_active(state, v)) return;
+  T s = 0;
+  for (int c = 0; c < d; ++c) s += (T)inv[v * d * d + row + c * d] * r[hid[v] + c];
+  z[hid[v] + row] = s;
+}
+} // namespace detail
+
 template <typename T, typename S, typename VTraits> class VertexDescriptor : public BaseVertexDescriptor<T, S> {
 public:
   using Traits = VTraits;
@@ -466,6 +504,7 @@ public:
   managed_vector<VertexType *> x_device;  // pointers into user memory (vertex.hpp:65)
   managed_vector<uint8_t> active_state;   // bit0 fixed, bit7 not used by an active factor
   managed_vector<size_t> hessian_ids;     // scalar column of each vertex
+  managed_vector<size_t> block_ids;       // block column of each vertex (vertex.hpp:74)
   managed_vector<StateType> backup_state;
   std::unordered_map<size_t, size_t> global_to_local_map;
   std::vector<size_t> local_to_global_map;
@@ -488,14 +527,14 @@ public:
     dense_usable = true;
   }
 
-  void reserve(size_t n) { x_device.reserve(n); active_state.reserve(n); hessian_ids.reserve(n); backup_state.reserve(n); local_to_global_map.reserve(n); global_to_local_map.reserve(n); }
+  void reserve(size_t n) { x_device.reserve(n); active_state.reserve(n); hessian_ids.reserve(n); block_ids.reserve(n); backup_state.reserve(n); local_to_global_map.reserve(n); global_to_local_map.reserve(n); }
   void add_vertex(size_t id, VertexType *vertex, bool fixed = false) { // vertex.hpp:241-256
     dense_dirty = true; ++this->structure_epoch;
     global_to_local_map[id] = x_device.size();
     local_to_global_map.push_back(id);
     x_device.push_back(vertex);
     active_state.push_back(static_cast<uint8_t>(fixed));
-    hessian_ids.push_back(0);
+    hessian_ids.push_back(0); block_ids.push_back(0);
     backup_state.resize(x_device.size());
   }
   void remove_vertex(size_t id) { // swap with last, vertex.hpp:185-215
@@ -503,11 +542,11 @@ public:
     if (it == global_to_local_map.end()) { std::cerr << "Vertex with id " << id << " not found." << std::endl; return; }
     dense_dirty = true; ++this->structure_epoch;
     const size_t l = it->second, last = x_device.size() - 1;
-    x_device[l] = x_device[last]; active_state[l] = active_state[last]; hessian_ids[l] = hessian_ids[last];
+    x_device[l] = x_device[last]; active_state[l] = active_state[last]; hessian_ids[l] = hessian_ids[last]; block_ids[l] = block_ids[last];
     const size_t moved = local_to_global_map[last];
     local_to_global_map[l] = moved; global_to_local_map[moved] = l;
     global_to_local_map.erase(id);
-    x_device.pop_back(); active_state.pop_back(); hessian_ids.pop_back(); local_to_global_map.pop_back();
+    x_device.pop_back(); active_state.pop_back(); hessian_ids.pop_back(); block_ids.pop_back(); local_to_global_map.pop_back();
     backup_state.resize(x_device.size());
   }
   void replace_vertex(size_t id, VertexType *vertex) {
@@ -516,7 +555,18 @@ public:
     x_device[it->second] = vertex; ++this->structure_epoch;
   }
   void set_fixed(size_t id, bool fixed) { active_state[global_to_local_map.at(id)] = static_cast<uint8_t>(fixed); ++this->structure_epoch; }
-  void set_hessian_column(size_t id, size_t column, size_t /*block*/) { hessian_ids[global_to_local_map.at(id)] = column; } // vertex.hpp:288-296
+  void set_hessian_column(size_t id, size_t column, size_t block) { const size_t l = global_to_local_map.at(id); hessian_ids[l] = column; block_ids[l] = block; } // vertex.hpp:288-296
+  const size_t *get_block_ids() const override { return block_ids.raw(); }
+  const std::unordered_map<size_t, size_t> &get_global_map() const override { return global_to_local_map; }
+  // The reference's per-descriptor block-Jacobi steps (vertex.hpp:97-110, ops/hessian.hpp:80-167), as BlockJacobiPreconditioner
+  // drives them there.  Here the preconditioner damps and inverts in one launch (solve.hpp k_block_inverse) and applies through
+  // the same k_block_apply; the two members stay for callers — and the reference's tests/vertex.cu:121-226 — that use them directly.
+  template <typename P> void augment_block_diagonal_async(P *block_diagonal, P *scalar_diagonal, const T mu, const bool use_identity, hipStream_t stream) {
+    if (count()) detail::k_augment_block_diagonal<P, (int)dim><<<detail::blocks(count()), detail::TPB, 0, stream>>>(block_diagonal, scalar_diagonal, (P)mu, use_identity ? 1 : 0, get_active_state(), count());
+  }
+  template <typename P> void apply_block_jacobi(T *z, const T *r, P *block_diagonal, hipStream_t stream) {
+    if (count()) detail::k_block_apply<T, P><<<detail::blocks(count() * dim), detail::TPB, 0, stream>>>(block_diagonal, get_hessian_ids(), get_active_state(), count(), (int)dim, z, r);
+  }
   bool is_fixed(size_t id) const override { return (active_state[global_to_local_map.at(id)] & 0x1) > 0; }
   bool is_active(size_t id) const override { return detail::is_vertex_active(active_state.raw(), global_to_local_map.at(id)); }
   bool exists(size_t id) const override { return global_to_local_map.count(id) > 0; }
@@ -573,7 +623,7 @@ public:
   const size_t *device_hessian_ids() const override { return mirrored ? mirror_hid.raw() : hessian_ids.raw(); }
   const std::vector<size_t> &local_to_global() const override { return local_to_global_map; }
   void to_device() {}
-  void clear() { x_device.clear(); active_state.clear(); hessian_ids.clear(); backup_state.clear(); global_to_local_map.clear(); local_to_global_map.clear(); dense_dirty = true; ++this->structure_epoch; }
+  void clear() { x_device.clear(); active_state.clear(); hessian_ids.clear(); block_ids.clear(); backup_state.clear(); global_to_local_map.clear(); local_to_global_map.clear(); dense_dirty = true; ++this->structure_epoch; }
 
   void apply_update(const T *delta_x, const T *scales) override {
     if (count()) detail::k_vertex_update<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), device_active_state(), device_hessian_ids(), count(), delta_x, scales);
@@ -1295,6 +1345,12 @@ __device__ inline void lds_gauss_jordan(double *A, double *R, int d, int nt) {
   }
 }
 
+// ops/active.hpp:14-31 flag_active_vertices_kernel: over ALL stored factors, those active at `level` mark slot I's vertex
+template <typename VD> __global__ void k_flag_vertices_level(const uint8_t *factor_active, size_t nf, const size_t *ids, size_t N, size_t I, uint8_t level, uint8_t *state) {
+  const size_t f = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (f >= nf || !is_factor_active(factor_active[f], level)) return;
+  state[ids[f * N + I]] |= 0x80;
+}
 template <typename VD> __global__ void k_flag_vertices(const size_t *active_ids, size_t n_active, const size_t *ids, size_t N, size_t I, uint8_t *state) {
   const size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (a >= n_active) return;
@@ -1471,6 +1527,88 @@ public:
   void flag_active_vertices() override {
     for (size_t i = 0; i < N; ++i)
       if (active_count()) detail::k_flag_vertices<void><<<detail::blocks(active_count()), detail::TPB>>>(m_active.get(active_indices, tables_mirrored), active_count(), m_ids.get(device_ids, tables_mirrored), N, i, vertex_descriptors[i]->get_active_state());
+  }
+  // factor.hpp:226-228 / ops/active.hpp:33-59: the same marks taken from the per-factor activity bytes at a GIVEN level (every stored
+  // factor is tested, not the active list of the last initialize_device_ids) — what tests/factor.cu:324-358 drives directly
+  void flag_active_vertices_async(const uint8_t level) {
+    const size_t nf = internal_count();
+    for (size_t i = 0; i < N && nf; ++i)
+      detail::k_flag_vertices_level<void><<<detail::blocks(nf), detail::TPB>>>(active.raw(), nf, device_ids.raw(), N, i, level, vertex_descriptors[i]->get_active_state());
+  }
+
+  // ---- the reference's own Hessian-assembly members (factor.hpp:657-825), for callers that drive the assembly themselves ------------
+  // (tests/factor.cu:854-967 does: coordinates -> its own block -> offset map -> setup -> execute).  Hessian::build_structure /
+  // update_values (sparse.hpp) do the same work through sorted block keys and k_sparse_pair; these three members run THAT kernel on
+  // the caller's offsets.  Vector arguments: anything with to_host() / operator=(std::vector) / raw() (sparse.hpp device_vector).
+  // One coordinate per (slot pair i <= j, active factor) whose two vertices are active; row = the lower block index.
+  template <typename DV> void get_hessian_block_coordinates(DV &block_coords) {
+    detail::sync();
+    std::vector<BlockCoordinates> h = block_coords.to_host();
+    for (size_t i = 0; i < N; ++i)
+      for (size_t j = i; j < N; ++j) {
+        const uint8_t *si = vertex_descriptors[i]->get_active_state(), *sj = vertex_descriptors[j]->get_active_state();
+        const size_t *bi = vertex_descriptors[i]->get_block_ids(), *bj = vertex_descriptors[j]->get_block_ids();
+        for (size_t a = 0; a < active_count(); ++a) {
+          const size_t f = active_indices[a], vi = device_ids[f * N + i], vj = device_ids[f * N + j];
+          if (!detail::is_vertex_active(si, vi) || !detail::is_vertex_active(sj, vj)) continue;
+          const size_t r = bi[vi], c = bj[vj];
+          h.push_back(r > c ? BlockCoordinates{c, r} : BlockCoordinates{r, c});
+        }
+      }
+    block_coords = h;
+  }
+  // h_block_offsets[(pair index) * active_count() + a] = value offset of the block that pair of factor a adds to (0 where a vertex
+  // of the pair is not active); returns pairs x active factors (factor.hpp:702-765)
+  template <typename DV> size_t setup_hessian_computation(std::unordered_map<BlockCoordinates, size_t> &block_indices, DV & /*d_hessian*/, size_t *h_block_offsets, StreamPool &) {
+    detail::sync();
+    size_t w = 0;
+    for (size_t i = 0; i < N; ++i)
+      for (size_t j = i; j < N; ++j) {
+        const uint8_t *si = vertex_descriptors[i]->get_active_state(), *sj = vertex_descriptors[j]->get_active_state();
+        const size_t *bi = vertex_descriptors[i]->get_block_ids(), *bj = vertex_descriptors[j]->get_block_ids();
+        for (size_t a = 0; a < active_count(); ++a) {
+          const size_t f = active_indices[a], vi = device_ids[f * N + i], vj = device_ids[f * N + j];
+          size_t off = 0;
+          if (detail::is_vertex_active(si, vi) && detail::is_vertex_active(sj, vj)) {
+            const size_t r = bi[vi], c = bj[vj];
+            auto it = block_indices.find(r > c ? BlockCoordinates{c, r} : BlockCoordinates{r, c});
+            if (it != block_indices.end()) off = it->second;
+            else std::cerr << "Error: Hessian block coordinate not found!" << std::endl;
+          }
+          h_block_offsets[w++] = off;
+        }
+      }
+    return NUM_PAIRS * active_count();
+  }
+  // rho' J_i^T P J_j of every pair of every active factor, added into d_hessian at the offsets setup_hessian_computation produced
+  // (device copy of them: d_block_offsets), blocks column-major with the rows of the vertex that has the lower scalar column
+  // (ops/hessian.hpp:10-78); returns pairs x active factors (factor.hpp:773-825)
+  template <typename DV> size_t execute_hessian_computation(std::unordered_map<BlockCoordinates, size_t> &, DV &d_hessian, const size_t *d_block_offsets, StreamPool &) {
+    const size_t na = active_count();
+    if (!na) return 0;
+    detail::sync();
+    std::vector<size_t> off(NUM_PAIRS * na), dst(NUM_PAIRS * na);
+    GRAPHITE_HIP(hipMemcpy(off.data(), d_block_offsets, off.size() * sizeof(size_t), hipMemcpyDeviceToHost));
+    size_t p = 0;
+    for (size_t i = 0; i < N; ++i)
+      for (size_t j = i; j < N; ++j, ++p) {
+        const uint8_t *si = vertex_descriptors[i]->get_active_state(), *sj = vertex_descriptors[j]->get_active_state();
+        const size_t *hi = vertex_descriptors[i]->get_hessian_ids(), *hj = vertex_descriptors[j]->get_hessian_ids();
+        for (size_t a = 0; a < na; ++a) {
+          const size_t f = active_indices[a], vi = device_ids[f * N + i], vj = device_ids[f * N + j];
+          size_t d = ~size_t(0); // k_sparse_pair: no block
+          if (detail::is_vertex_active(si, vi) && detail::is_vertex_active(sj, vj)) d = off[p * na + a] | (hi[vi] > hj[vj] ? size_t(1) << 63 : 0);
+          dst[a * NUM_PAIRS + p] = d;
+        }
+      }
+    d_sparse_dst.resize_uninit(dst.size());
+    GRAPHITE_HIP(hipMemcpy(d_sparse_dst.raw(), dst.data(), dst.size() * sizeof(size_t), hipMemcpyHostToDevice));
+    const bool was_ready = gather_ready;
+    gather_ready = false; // every pair through k_sparse_pair (the per-vertex gather of the diagonal pairs needs sparse_setup's tables)
+    sparse_all(d_hessian.raw(), std::make_index_sequence<N>{});
+    detail::sync();
+    gather_ready = was_ready;
+    return NUM_PAIRS * na;
   }
 
   // HBM copies of the per-factor tables the kernels only read (built on the host in pinned memory: ids, observations,
@@ -1833,8 +1971,9 @@ public:
         const auto &l2g = vd->local_to_global();
         const uint8_t *state = vd->get_active_state();
         auto *hid = &vd->get_hessian_ids()[0];
+        auto *bid = const_cast<size_t *>(vd->get_block_ids());
         const size_t nvd = vd->count(), dimv = vd->dimension();
-        auto place = [&](size_t l) { if (detail::is_vertex_active(state, l)) { hid[l] = col; hessian_offsets.push_back(col); col += dimv; } };
+        auto place = [&](size_t l) { if (detail::is_vertex_active(state, l)) { hid[l] = col; bid[l] = hessian_offsets.size(); hessian_offsets.push_back(col); col += dimv; } };
         if (std::is_sorted(l2g.begin(), l2g.begin() + nvd)) { for (size_t l = 0; l < nvd; ++l) place(l); }
         else {
           std::vector<std::pair<size_t, size_t>> order;

@@ -60,15 +60,7 @@ template <typename T> __global__ void __launch_bounds__(BLOCK_INV_THREADS) k_blo
   lds_gauss_jordan(A, R, d, nt);
   for (int i = 0; i < d * d; ++i) X[i] = (T)R[i * nt];
 }
-template <typename T> __global__ void k_block_apply(const T *inv, const size_t *hid, const uint8_t *state, size_t count, int d, T *z, const T *r) {
-  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (t >= count * d) return;
-  const size_t v = t / d, row = t % d;
-  if (!is_vertex_active(state, v)) return;
-  T s = 0;
-  for (int c = 0; c < d; ++c) s += inv[v * d * d + row + c * d] * r[hid[v] + c];
-  z[hid[v] + row] = s;
-}
+// (k_block_apply: core.hpp, with the VertexDescriptor member that also launches it)
 template <typename T> __global__ void k_damp_dense(T *H, size_t n, T mu, int identity) { // hessian.hpp:136-176
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -317,7 +309,7 @@ public:
     auto &vds = graph->get_vertex_descriptors();
     for (size_t k = 0; k < vds.size(); ++k)
       if (vds[k]->count())
-        detail::k_block_apply<T><<<detail::blocks(vds[k]->count() * vds[k]->dimension()), detail::TPB>>>(inverses[k]->raw(), vds[k]->device_hessian_ids(), vds[k]->device_active_state(), vds[k]->count(), (int)vds[k]->dimension(), z, r);
+        detail::k_block_apply<T, T><<<detail::blocks(vds[k]->count() * vds[k]->dimension()), detail::TPB>>>(inverses[k]->raw(), vds[k]->device_hessian_ids(), vds[k]->device_active_state(), vds[k]->count(), (int)vds[k]->dimension(), z, r);
   }
 };
 
