@@ -250,8 +250,10 @@ def main():
                 gdist.init_comm(gpu, rank, world)
                 transport["kind"] = "rccl"
             else:
+                # (gr_bal_tuning.comm_transport / GR_COMM_TRANSPORT: 0 = the same hand-shake but RCCL only, 2 = the peer mapping treated
+                # as refused — both end with every rank on RCCL, the path a node without peer access takes)
                 used = gdist.init_comm_ipc(gpu, rank, world, slot_bytes=4 << 20, rccl_fallback=True)
-                transport["kind"] = "ipc-mailbox+rccl" if used else "rccl (ipc verification failed)"
+                transport["kind"] = "ipc-mailbox+rccl" if used else "rccl (mailboxes not used: refused, failed verification, or comm_transport = 0)"
         else:
             part = prob
             gpu = ga.BalProblem(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=dtype, device=local_rank)
@@ -262,6 +264,10 @@ def main():
         """W untimed LM iterations, then `repeats` x (reset, barrier, time exactly `steps` iterations, barrier)."""
         if warmup > 0:
             gpu.levenberg_marquardt(iterations=warmup, **lm_kw)
+        if os.environ.get("GR_TEST_KILL_RANK") == str(rank):
+            # fault injection (tests/test_gpu_ipc.py): this rank dies after the warm-up, its peers are inside collectives that wait for
+            # it — bounded waits (gr_bal_tuning.ipc_timeout_ms) end them with GR_ERR_COMM, torch.distributed.run ends the job: non-zero exit
+            os._exit(17)
         runs = []
         for _ in range(max(1, repeats)):
             gpu.set_params(part.cameras, part.points)
@@ -505,13 +511,18 @@ def main():
         phase = {"linearise_ms": sum(v["total_ms"] for k, v in ks.items() if k in lin_names),
                  "inner_iterations_ms": sum(v["total_ms"] for k, v in ks.items() if k not in lin_names)}
         infos = [None] * world
-        dist.all_gather_object(infos, {"rank": rank, "device": ci["device"], "transport": ci["transport_name"], "rccl_ranks": ci["rccl_ranks"],
+        # hipDeviceCanAccessPeer of this rank's device to every visible device (what the mailboxes need; counting devices does not
+        # initialise them).  Ranks that share a device (test mode) see one device: [[True]]
+        ndev = torch.cuda.device_count()
+        peers = [bool(d == local_rank or torch.cuda.can_device_access_peer(local_rank, d)) for d in range(ndev)]
+        dist.all_gather_object(infos, {"rank": rank, "device": ci["device"], "peer_access": peers, "transport": ci["transport_name"], "rccl_ranks": ci["rccl_ranks"],
                                        "mailboxes_opened": ci["mailboxes_opened"], "fused_agreed": ci["fused_agreed"],
                                        "oneshot_messages": ci["oneshot_messages"], "fallback_messages": ci["fallback_messages"], **phase,
                                        "observations": int(len(part.cam_idx)), "points": int(len(part.points))})
         shard_audit = {"ranks_seen": {"process_group": world, "rccl_comm_count": [i["rccl_ranks"] for i in infos],
                                       "mailboxes_opened_per_rank": [i["mailboxes_opened"] for i in infos]},
                        "devices": [i["device"] for i in infos], "transport_per_rank": [i["transport"] for i in infos],
+                       "peer_access": {"matrix": [i["peer_access"] for i in infos], "note": "row r: hipDeviceCanAccessPeer(device of rank r, device d) for every visible device d"},
                        "fused_inner_iteration_message": [i["fused_agreed"] for i in infos],
                        "oneshot_messages_per_rank": [i["oneshot_messages"] for i in infos], "fallback_messages_per_rank": [i["fallback_messages"] for i in infos],
                        "per_phase_max_over_ranks_ms": {"linearise": max(i["linearise_ms"] for i in infos), "inner_iterations": max(i["inner_iterations_ms"] for i in infos),

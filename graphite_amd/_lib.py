@@ -64,7 +64,7 @@ class Tuning(C.Structure):
     """gr_bal_tuning (include/graphite_mi355x.h)"""
     _fields_ = [(k, C.c_int32) for k in ("point_tiles", "g3_gather", "point_records", "pcg_lazy", "pcg_single_reduction", "sparse_cholesky",
                                          "spchol_overlap", "lm_speculate", "lm_ahead", "lm_fused", "grid_mult", "vec_per_thread", "schur_item",
-                                         "verbose", "ipc_timeout_ms", "shard_fused", "shard_virtual_ranks", "chol_fuse", "chol_pin", "spchol_fuse", "spchol_slice", "schur_fused", "spchol_bwd_chain", "pcg_resident")] + [("reserved", C.c_int32 * 1)]
+                                         "verbose", "ipc_timeout_ms", "shard_fused", "shard_virtual_ranks", "chol_fuse", "chol_pin", "spchol_fuse", "spchol_slice", "schur_fused", "spchol_bwd_chain", "pcg_resident", "comm_transport")]
 
 
 class DirectSolverInfo(C.Structure):

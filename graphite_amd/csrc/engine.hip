@@ -59,6 +59,7 @@ static void tuning_default(gr_bal_tuning &t) {
   t.spchol_bwd_chain = env_int("GR_SPCHOL_BWD_CHAIN", 1);
   t.schur_fused = env_int("GR_SCHUR_FUSED", -1);
   t.pcg_resident = env_int("GR_PCG_RESIDENT", -1);
+  t.comm_transport = env_int("GR_COMM_TRANSPORT", -1);
   t.spchol_slice = std::max(1, env_int("GR_SPCHOL_SLICE", 1)); // tiles per substitution item (Ladybug-1723 direct Schur: 1 -> 322.5, 2 -> 319.5, 3 -> 314.5, 4 -> 310 LM it/s)
 }
 
@@ -3252,8 +3253,11 @@ gr_status gr_bal_comm_init_ipc(gr_bal_problem *p, const void *handles, int rank,
     try {
       std::vector<char *> boxes(world_size, nullptr);
       std::vector<bool> opened(world_size, false);
+      // gr_bal_tuning.comm_transport: 0 = RCCL only (nothing is opened), 2 = fault injection: the mapping is refused
+      if (p->e->tune.comm_transport == 0) { ok = false; why = "gr_bal_tuning.comm_transport = 0: RCCL only"; }
       for (int r = 0; r < world_size && ok; ++r) {
         if (r == rank) { boxes[r] = p->e->ipc_box; continue; }
+        if (p->e->tune.comm_transport == 2) { ok = false; why = "peer mapping refused (gr_bal_tuning.comm_transport = 2, fault injection)"; break; }
         hipIpcMemHandle_t h;
         std::memcpy(&h, static_cast<const char *>(handles) + 64 * (size_t)r, 64);
         void *q = nullptr;
@@ -3261,6 +3265,7 @@ gr_status gr_bal_comm_init_ipc(gr_bal_problem *p, const void *handles, int rank,
         if (e != hipSuccess) { (void)hipGetLastError(); ok = false; why = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e); break; }
         boxes[r] = static_cast<char *>(q); opened[r] = true;
       }
+      if (ok && p->e->tune.comm_transport == 2 && world_size == 1) { ok = false; why = "peer mapping refused (gr_bal_tuning.comm_transport = 2, fault injection)"; }
       if (ok) {
         ipc.reset(new IpcComm(rank, world_size, p->e->ipc_slot, boxes, opened));
         p->e->ipc_box = nullptr; // owned by the communicator from here on
@@ -3292,6 +3297,7 @@ gr_status gr_bal_comm_init_ipc(gr_bal_problem *p, const void *handles, int rank,
       ok = flag.download(nullptr)[0] == (double)world_size;
       if (!ok) {
         ipc.reset();
+        if (p->e->tune.verbose) std::fprintf(stderr, "[graphite-mi355x] rank %d: IPC mailboxes not used (%s): every rank drops to RCCL\n", rank, why.empty() ? "a peer refused" : why.c_str());
         p->e->set_comm(std::move(rccl));
         if (used_ipc) *used_ipc = 0;
         return GR_OK;

@@ -161,13 +161,17 @@ typedef struct {
                                    (kernels_rp.hpp: one 512-thread workgroup per CU, the lane's observations and the thread's x, r, p, z'
                                    in LDS / VGPRs for all inner iterations, two grid barriers per iteration).  0: operator / update /
                                    direction launches                                                                                  */
-  int32_t reserved[1];
+  int32_t comm_transport;       /* GR_COMM_TRANSPORT -1 auto | 1: gr_bal_comm_init_ipc opens the peers' mailboxes, verifies them and keeps RCCL for
+                                   what does not fit a slot | 0: RCCL only — the mailboxes are not opened, every rank agrees on the fallback
+                                   communicator | 2 (fault injection): the peer mapping is treated as refused AFTER the handles were
+                                   exchanged, i.e. the path a node without peer access takes: the ranks agree to drop to RCCL together.
+                                   0 and 2 need the fallback communicator (unique id); without one gr_bal_comm_init_ipc fails          */
 } gr_bal_tuning;
 void gr_bal_tuning_default(gr_bal_tuning *t);
 
 /* "graphite-mi355x <major.minor> (gfx950)".  ABI note: 0.2 = the layouts below (sizeof(gr_bal_tuning) == 100, sizeof(gr_lm_stats) == 80);
  * a caller built against an earlier header (80 / 64 bytes) must be rebuilt — the library writes the whole struct.  New tuning fields
- * from here on take `reserved` slots so that the size stays at 100. */
+ * since then took the `reserved` slots (pcg_resident, comm_transport): the size stays at 100, there are none left. */
 const char *gr_version(void);
 const char *gr_last_error_string(void);
 /* number of visible HIP devices (0 if none); never initialises a device */

@@ -9,6 +9,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -158,3 +159,67 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
     assert line["parity_rel"] is not None and line["parity_rel"] < 1e-6     # the sharded trace against the oracle of the full problem
     venice = [a for a in line["also"] if "venice-1778" in a["workload"]]
     assert venice and venice[0]["value"] > 0
+
+
+def _bench_line(out):
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_eight_ranks_on_the_one_device():
+    """De-risking the first real 8-GPU run: the driver's own command line for N = 8 —
+    `bench.py --gpus 8`, started plainly — with the eight ranks mapped onto the ONE device of this box (GR_BENCH_SHARE_GPU=1:
+    gloo process group, every collective through the IPC mailboxes of eight processes).  Eight landmark shards of Ladybug-49,
+    the fused inner-iteration message, barriers, max over ranks: all of it runs; the audit record must show eight ranks, eight
+    mailboxes opened per rank, and the sharded trace must equal the FULL problem's oracle trace."""
+    env = dict(os.environ, GR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "8", "--workload", "ladybug-49", "--steps", "6",
+           "--warmup", "1", "--repeats", "2", "--no-also"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _bench_line(out)
+    assert line["n_gpus"] == 8 and line["value"] > 0 and "landmark-sharded x8" in line["config"]["parallelism"]
+    audit = line["shard_audit"]
+    assert audit["ranks_seen"]["process_group"] == 8
+    assert audit["ranks_seen"]["mailboxes_opened_per_rank"] == [7] * 8 or audit["ranks_seen"]["mailboxes_opened_per_rank"] == [8] * 8
+    assert len(audit["per_rank_ms"]) == 8 and sum(r["observations"] for r in audit["per_rank_ms"]) == 31843
+    assert all(t == "ipc-mailbox" for t in audit["transport_per_rank"])
+    assert audit["peer_access"]["matrix"] == [[True]] * 8       # eight ranks, one visible device each
+    assert line["parity_rel"] is not None and line["parity_rel"] < 1e-6
+
+
+def test_bench_with_a_killed_rank_exits_non_zero():
+    """(7a) one of the eight ranks dies after the warm-up (GR_TEST_KILL_RANK): its peers sit in a mailbox all-reduce that waits
+    for it.  Bounded waits (2 s here) return GR_ERR_COMM, the job ends with a non-zero exit code and no JSON line — it does not
+    hang and it does not report a number."""
+    env = dict(os.environ, GR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GR_TEST_KILL_RANK="5", GR_IPC_TIMEOUT_MS="2000")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "8", "--workload", "ladybug-49", "--steps", "4",
+           "--warmup", "1", "--repeats", "1", "--no-also", "--no-cpu-baseline"]
+    t0 = time.time()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert time.time() - t0 < 300
+
+
+@pytest.mark.parametrize("how", ["GR_COMM=rccl", "GR_COMM_TRANSPORT=0", "GR_COMM_TRANSPORT=2"])
+def test_bench_rccl_paths_with_a_single_rank_communicator(how):
+    """(7b) the two ways a run ends up on RCCL alone, as far as one device allows (RCCL cannot put two ranks on one device: world
+    size 1, GR_BENCH_FORCE_COMM=1): RCCL asked for outright (GR_COMM=rccl, or gr_bal_tuning.comm_transport = 0 through the mailbox
+    hand-shake), and the mailbox-refused path (comm_transport = 2: the peer mapping treated as refused, every rank agrees to drop
+    to RCCL).  The audit record names the transport that really ran; the trace equals the oracle's."""
+    k, v = how.split("=")
+    env = dict(os.environ, GR_BENCH_FORCE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), **{k: v})
+    env.pop("WORLD_SIZE", None); env.pop("GR_BENCH_SHARE_GPU", None)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "1", "--workload", "ladybug-49", "--steps", "6",
+           "--warmup", "1", "--repeats", "1", "--no-also"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _bench_line(out)
+    audit = line["shard_audit"]
+    assert audit["transport_per_rank"] == ["rccl"] and audit["ranks_seen"]["rccl_comm_count"] == [1]
+    assert audit["ranks_seen"]["mailboxes_opened_per_rank"] == [0]
+    assert line["parity_rel"] is not None and line["parity_rel"] < 1e-6
