@@ -328,6 +328,41 @@ def main():
                            "lower bound on how close the kernel is to what actually feeds it" if where != "HBM" else
                            "beyond the Infinity Cache: `traffic` is HBM traffic")}
 
+    def latency_roofline(ks, ra, residency, hbm_record):
+        """A workload whose LM iteration touches less than the L2s hold and whose kernels are all a few launch floors long is bound by
+        the NUMBER of dependent launches and in-launch grid barriers, not by bytes: an HBM fraction of 0.005 says nothing.
+        The record then carries the launch-floor model instead: floor = launches per LM iteration x 4.6 us (a launch that finds nothing
+        to do: profiles/HISTORY.md, kernel trace) + grid barriers per LM iteration x 3.0 us (the cooperative PCG's barrier, measured),
+        frac = floor / measured time per LM iteration; `hbm` keeps the byte view of the dominant kernel for reference."""
+        if residency["served_from"] != "L2" or not ks:
+            return None
+        steps_run = max(ra["steps_run"], 1)
+        per_iter_us = ra["dt"] / steps_run * 1e6
+        launches = sum(v["launches"] for v in ks.values())
+        longest = max(v["total_ms"] * 1e3 / max(v.get("active_launches", v["launches"]), 1) for v in ks.values())
+        if longest > 40.0:
+            return None
+        LAUNCH_FLOOR_US, BARRIER_US = 4.6, 3.0
+        inner = ra["st"]["pcg_iterations"] / steps_run
+        coop = ks.get("schur_pcg_coop") or ks.get("pcg_resident")
+        # the cooperative PCG on S: one barrier after its start, then three per inner iteration; the resident matrix-free PCG: two per inner iteration
+        barriers = 0.0
+        if "schur_pcg_coop" in ks:
+            barriers = (1.0 + 3.0 * inner) * ks["schur_pcg_coop"]["launches"] / steps_run
+        elif "pcg_resident" in ks:
+            barriers = 2.0 * inner * ks["pcg_resident"]["launches"] / steps_run
+        per_iter_launches = launches / steps_run
+        floor_us = per_iter_launches * LAUNCH_FLOOR_US + barriers * BARRIER_US
+        kernel_us = sum(v["total_ms"] for v in ks.values()) * 1e3 / steps_run
+        return {"bound": "latency", "kernel": hbm_record["kernel"], "unit": "us per LM iteration", "achieved": round(per_iter_us, 2), "peak": round(floor_us, 2),
+                "frac": round(floor_us / per_iter_us, 4), "traffic": None,
+                "launches_per_lm_iteration": round(per_iter_launches, 2), "launch_floor_us": LAUNCH_FLOOR_US,
+                "grid_barriers_per_lm_iteration": round(barriers, 2), "grid_barrier_us": BARRIER_US,
+                "kernel_time_us_per_lm_iteration": round(kernel_us, 2), "longest_kernel_us": round(longest, 2),
+                "note": "latency-bound: the working set sits in the L2s and every kernel is a few launch floors long; peak = launches x floor + "
+                        "barriers x barrier cost (the time a perfect implementation of THIS launch structure would take), frac = peak / measured",
+                "hbm": {k: hbm_record[k] for k in ("achieved", "peak", "frac", "avg_launch_us", "algorithmic_bytes_per_launch") if k in hbm_record}}
+
     def working_set(nc, npts, nobs, itemsize, nseg_est=None):
         nn = 9 * nc + 3 * npts
         nseg_est = nseg_est or (nobs / 64 + nc)
@@ -370,7 +405,11 @@ def main():
              "collectives_per_lm_iteration": round(ra["st"].get("collectives", 0) / max(ra["steps_run"], 1), 2),
              "chi2_initial": float(ra["ct"][0]), "chi2_final": float(ra["ct"][-1]), "parity_rel": None, "roofline": roofline_of(aks, isz)}
         if e["roofline"]:
-            e["roofline"]["cache_residency"] = cache_residency(working_set(aNc, aNp, aNo, isz))
+            res = cache_residency(working_set(aNc, aNp, aNo, isz))
+            lat = latency_roofline(aks, ra, res, e["roofline"])
+            if lat:
+                e["roofline"] = lat
+            e["roofline"]["cache_residency"] = res
         if parity_iters > 0 and rank == 0 and not args.no_cpu_baseline:
             import oracle
             osolver = {"pcg": oracle.SOLVER_PCG, "pcg-schur": oracle.SOLVER_PCG_SCHUR, "pcg-schur-implicit": oracle.SOLVER_PCG_SCHUR,
@@ -645,12 +684,13 @@ def main():
         if small_enough:
             # (b) the reference's "eigen_solver CPU path": eigen-schur = assembly + Schur reduction (GPU in the reference; here all
             #     host cores) + ONE-thread simplicial LDL^T (src/eigen_solver.cpp:10-29), minimum-degree ordering (Eigen: AMD)
-            c_s, s_s, t_s = leg(oracle.SOLVER_LDLT_SCHUR, it, nproc, 1)
+            # ordering 2 = AMD of the factorised matrix (oracle/amd.hpp): Eigen::SimplicialLDLT's default, i.e. the reference's own choice
+            c_s, s_s, t_s = leg(oracle.SOLVER_LDLT_SCHUR, it, nproc, 2)
             ldlt_s = (t_s["ldlt_factor"] + t_s["ldlt_solve"]) / max(s_s["iterations_run"], 1)
             cpu = {"value": round(s_s["iterations_run"] / s_s["loop_seconds"], 5), "unit": "LM iterations/s", "cores": int(t_s["threads"]), "kind": "port",
                    "sample": f"{it} LM iterations of {sample_tag}: restatement of the reference's eigen-schur path "
                              f"(EigenSchurLDLTSolver): linearise + Hessian + Schur reduction OpenMP on {int(t_s['threads'])} host cores, "
-                             "simplicial LDL^T of S on ONE thread as src/eigen_solver.cpp:21-29, minimum-degree camera order (Eigen: AMD)",
+                             "simplicial LDL^T of S on ONE thread as src/eigen_solver.cpp:21-29, AMD ordering of S as Eigen::SimplicialLDLT's default does (oracle/amd.hpp)",
                    "seconds": round(s_s["loop_seconds"], 3),
                    "ldlt_only_seconds_per_iteration": round(ldlt_s, 4),
                    "ldlt_only_lm_iterations_per_sec": round(1.0 / ldlt_s, 4),
@@ -658,17 +698,21 @@ def main():
                                      "LM rate on this host however fast its GPU stages are",
                    "stage_seconds": {k: round(v, 4) for k, v in t_s.items() if k not in ("threads", "ldlt_nnz")},
                    "ldlt_nnz": int(t_s["ldlt_nnz"]), "chi2_final": float(c_s[-1])}
-            # (c) eigen = the FULL system H (EigenLDLTSolver, solver/eigen.hpp:71-98), points first then cameras by minimum degree
-            c_f, s_f, t_f = leg(oracle.SOLVER_LDLT, max(1, it // 2), nproc, 1)
+            # (c) eigen = the FULL system H (EigenLDLTSolver, solver/eigen.hpp:71-98), AMD ordering of H
+            c_f, s_f, t_f = leg(oracle.SOLVER_LDLT, max(1, it // 2), nproc, 2)
             ldlt_f = (t_f["ldlt_factor"] + t_f["ldlt_solve"]) / max(s_f["iterations_run"], 1)
             cpu["full_h_ldlt"] = {"value": round(s_f["iterations_run"] / s_f["loop_seconds"], 5), "unit": "LM iterations/s", "cores": int(t_f["threads"]),
                                   "kind": "port", "sample": f"{max(1, it // 2)} LM iterations, EigenLDLTSolver restatement (full H, upper CSC, "
-                                  "points then minimum-degree cameras), assembly on all cores, LDL^T on one thread",
+                                  "AMD ordering), assembly on all cores, LDL^T on one thread",
                                   "seconds": round(s_f["loop_seconds"], 3), "ldlt_only_seconds_per_iteration": round(ldlt_f, 4),
                                   "ldlt_nnz": int(t_f["ldlt_nnz"])}
-            # (d) the same eigen-schur leg with the oracle's own RCM camera order, for the ordering's effect
+            # (d) the same eigen-schur leg under the two other orderings, for the ordering's effect: exact minimum degree on the camera
+            #     graph (what rounds 2-5 quoted) and the oracle's own reverse Cuthill-McKee
+            _, s_m, t_m = leg(oracle.SOLVER_LDLT_SCHUR, 1, nproc, 1)
+            cpu["eigen_schur_minimum_degree_order"] = {"ldlt_only_seconds_per_iteration": round(t_m["ldlt_factor"] + t_m["ldlt_solve"], 4), "ldlt_nnz": int(t_m["ldlt_nnz"])}
             _, s_r, t_r = leg(oracle.SOLVER_LDLT_SCHUR, 1, nproc, 0)
             cpu["eigen_schur_rcm_order"] = {"ldlt_only_seconds_per_iteration": round(t_r["ldlt_factor"] + t_r["ldlt_solve"], 4), "ldlt_nnz": int(t_r["ldlt_nnz"])}
+            cpu["ldlt_nnz_by_ordering"] = {"amd": int(t_s["ldlt_nnz"]), "minimum_degree": int(t_m["ldlt_nnz"]), "rcm": int(t_r["ldlt_nnz"])}
         # (e) all host cores on the GPU line's own algorithm (matrix-free block-Jacobi PCG)
         if solver_name == "pcg" and not args.parity_only:
             pit = int(max(4, min(16, 12.0 / (0.35 * No / 678718.0))))

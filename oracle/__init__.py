@@ -371,7 +371,8 @@ class CpuBaseline:
 
     def levenberg_marquardt(self, solver, iterations, threads=0, ordering=1, initial_damping=1e-4, pcg_max_iter=10,
                             pcg_tol=1.0, pcg_rej=5.0):
-        """threads: 0 = all host cores; ordering: 1 = minimum degree (the AMD role), 0 = reverse Cuthill-McKee."""
+        """threads: 0 = all host cores; ordering: 2 = AMD of the factorised matrix (oracle/amd.hpp: Eigen::SimplicialLDLT's default, the
+        reference's own choice), 1 = exact minimum degree on the camera graph, 0 = reverse Cuthill-McKee."""
         ct = np.zeros(iterations + 1)
         lt = np.zeros(iterations + 1)
         st = np.zeros(6)
@@ -403,3 +404,22 @@ def circle_lm(points, radius, fixed=None, factor_on=None, solver="eigen", iterat
            C.c_double(initial_damping), C.c_int(int(use_identity)), C.c_int(pcg_max_iter), C.c_double(pcg_tol), C.c_double(pcg_rej),
            _p(ct), _p(lt), _p(stats))
     return ct[:it + 1], lt[:it + 1], pts, dict(iterations_run=it, accepted=int(stats[0]), pcg_iterations=int(stats[1]))
+
+
+def amd_order(n, indptr, indices):
+    """oracle/amd.hpp: approximate minimum degree order (perm[new] = old) of a symmetric matrix given by the scalar CSC of its upper triangle"""
+    ap = np.ascontiguousarray(indptr, dtype=np.int64); ai = np.ascontiguousarray(indices, dtype=np.int64)
+    perm = np.zeros(n, np.int64)
+    f = lib().gro_amd_order
+    f.restype = None
+    f(C.c_int64(n), _p(ap), _p(ai), _p(perm))
+    return perm
+
+
+def ldlt_fill(n, indptr, indices, perm=None):
+    """nnz of the strictly lower part of L for the simplicial LDL^T (oracle/sparse_ldlt.hpp) under `perm` (None: natural order)"""
+    ap = np.ascontiguousarray(indptr, dtype=np.int64); ai = np.ascontiguousarray(indices, dtype=np.int64)
+    pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+    f = lib().gro_ldlt_fill
+    f.restype = C.c_int64
+    return int(f(C.c_int64(n), _p(ap), _p(ai), _p(pm)))

@@ -13,11 +13,13 @@
 // Ordering of the simplicial LDL^T: Eigen::SimplicialLDLT orders with AMD.  Here: points first (they have
 // the lowest degrees of a bundle-adjustment Hessian and no minimum-degree heuristic does anything else),
 // then the cameras by exact minimum degree on the camera co-observation graph (ordering = 1, the AMD role)
-// or by reverse Cuthill-McKee (ordering = 0, what the oracle itself uses).
+// or by reverse Cuthill-McKee (ordering = 0, what the oracle itself uses), or — ordering = 2, the reference's own choice —
+// AMD of the scalar pattern of the matrix that is factorised (amd.hpp: Eigen::SimplicialLDLT's default AMDOrdering).
 // The parallel stages sum per vertex in observation order, like the sequential oracle; only the Schur
 // products are grouped by destination block column instead of by point (rounding-level differences).
 #pragma once
 #include "bal_pipeline.hpp"
+#include "amd.hpp"
 #include <omp.h>
 
 namespace gro {
@@ -401,8 +403,14 @@ template <typename T> struct CpuBaseline : BalOracle<T> {
     if (!analyzed || analyzed_kind != kind) {
       t = clk::now();
       std::vector<int64_t> perm;
-      if (kind == SOLVER_LDLT) for (size_t l = 0; l < Np; ++l) for (int k = 0; k < 3; ++k) perm.push_back(pose_dim + 3 * l + k);
-      for (int64_t c : camera_order()) for (int k = 0; k < 9; ++k) perm.push_back(9 * c + k);
+      if (ordering == 2) {
+        // AMD of the matrix that is factorised, as Eigen::SimplicialLDLT's default AMDOrdering does on its scalar pattern
+        // (src/eigen_solver.cpp:10-13; amd.hpp) — for S and for the full H alike
+        perm = amd_order((int64_t)(kind == SOLVER_LDLT ? n : pose_dim), csc_p.data(), csc_i.data());
+      } else {
+        if (kind == SOLVER_LDLT) for (size_t l = 0; l < Np; ++l) for (int k = 0; k < 3; ++k) perm.push_back(pose_dim + 3 * l + k);
+        for (int64_t c : camera_order()) for (int k = 0; k < 9; ++k) perm.push_back(9 * c + k);
+      }
       ldlt.analyze(kind == SOLVER_LDLT ? n : pose_dim, csc_p.data(), csc_i.data(), perm);
       analyzed = true; analyzed_kind = kind;
       tm.ldlt_analyze += since(t);

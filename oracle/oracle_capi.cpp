@@ -239,6 +239,20 @@ GRO_FOR_T(X)
 GRO_FOR_T(X)
 #undef X
 
+// amd.hpp: perm[new] = old of the symmetric matrix whose UPPER triangle is given in scalar CSC (tests)
+void gro_amd_order(int64_t n, const int64_t *Ap, const int64_t *Ai, int64_t *perm) {
+  const std::vector<int64_t> p = amd_order(n, Ap, Ai);
+  for (int64_t i = 0; i < n; ++i) perm[i] = i < (int64_t)p.size() ? p[i] : -1;
+}
+// nnz(L) (strictly lower part) of the simplicial LDL^T under a given order (perm may be NULL: natural order)
+int64_t gro_ldlt_fill(int64_t n, const int64_t *Ap, const int64_t *Ai, const int64_t *perm) {
+  SparseLDLT l;
+  std::vector<int64_t> pv;
+  if (perm) pv.assign(perm, perm + n);
+  l.analyze(n, Ap, Ai, pv);
+  return (int64_t)l.Li.size();
+}
+
 // BASELINE configs[0] (circle_fit.hpp): pts [n][2] in / out; fixed, factor_on: n bytes each; solver 0 EigenLDLTSolver, 1 PCGSolver +
 // IdentityPreconditioner; traces of iterations + 1 doubles; stats: accepted, inner PCG iterations.  Returns the iterations run.
 int gro_circle_lm_f64(size_t n, double R, double *pts, const unsigned char *fixed, const unsigned char *factor_on, int solver, int iterations,

@@ -183,3 +183,37 @@ def test_oracle_fixed_vertices(oracle_mod):
         assert np.abs(c[~cf] - prob.cameras[~cf]).max() > 1e-3 and ct[-1] < 0.1 * ct[0]
         finals[solver] = ct[-1]
     assert abs(finals[oracle_mod.SOLVER_LDLT_SCHUR] - finals[oracle_mod.SOLVER_LDLT]) / finals[oracle_mod.SOLVER_LDLT] < 1e-9
+
+
+def test_amd_ordering_of_the_cpu_baseline(oracle_mod):
+    """oracle/amd.hpp — the approximate minimum degree ordering Eigen::SimplicialLDLT applies by default, i.e. the ordering of the
+    reference's eigen_solver CPU path (/root/reference/src/eigen_solver.cpp:10-13).  No reference vector pins it (Eigen is absent,
+    SURVEY 8c), so it is held to its defining properties: a permutation; on unstructured sparse symmetric patterns a fill far
+    below the natural order's; on a BAL-shaped reduced camera system a fill within 15 % of EXACT minimum degree on the camera
+    graph and of the block-level AMD; and the CPU baseline's LM trace does not depend on which ordering factorises S or H."""
+    import scipy.sparse as sp
+    for n, dens in ((300, 0.02), (3000, 0.0015)):
+        A = sp.random(n, n, density=dens, random_state=1, format="csc")
+        U = sp.triu(A + A.T + sp.eye(n), format="csc")
+        perm = oracle_mod.amd_order(n, U.indptr, U.indices)
+        assert sorted(perm.tolist()) == list(range(n))
+        assert oracle_mod.ldlt_fill(n, U.indptr, U.indices, perm) < 0.6 * oracle_mod.ldlt_fill(n, U.indptr, U.indices)
+    # arrow matrix: natural order (dense row first) fills completely, minimum degree orders the hub last: no fill at all
+    n = 200
+    rows = [0] * n + list(range(1, n)); cols = list(range(n)) + list(range(1, n))
+    U = sp.csc_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))
+    U.sum_duplicates()
+    perm = oracle_mod.amd_order(n, U.indptr, U.indices)
+    assert oracle_mod.ldlt_fill(n, U.indptr, U.indices) == n * (n - 1) // 2
+    assert oracle_mod.ldlt_fill(n, U.indptr, U.indices, perm) == n - 1
+    # the CPU baseline: same LM trace whichever ordering factorises (eigen-schur and eigen legs), fill reported per ordering
+    prob = synth.make_problem(40, 1500, 7000, seed=11, window=10)
+    base = oracle_mod.CpuBaseline(prob.cameras, prob.points, prob.obs, prob.cam_idx, prob.pt_idx, dtype=np.float64)
+    for solver in (oracle_mod.SOLVER_LDLT_SCHUR, oracle_mod.SOLVER_LDLT):
+        out = {}
+        for ordering in (0, 1, 2):
+            base.reset()
+            ct, _, st, tm = base.levenberg_marquardt(solver, 4, threads=2, ordering=ordering)
+            out[ordering] = (ct, tm["ldlt_nnz"])
+        assert np.allclose(out[2][0], out[1][0], rtol=1e-9) and np.allclose(out[2][0], out[0][0], rtol=1e-9)
+        assert out[2][1] <= 1.15 * out[1][1], (out[2][1], out[1][1])   # AMD against exact minimum degree on the camera graph
