@@ -1711,17 +1711,16 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         else
         {
           // the workgroups that hold a camera tile start their point share after it: the segment sums are on the launch's critical
-          // path — four loads in flight (the last batch clamped), added in segment order
+          // path — sixteen loads in flight (round 6; four before: a Venice camera has 44 segments = 11 dependent rounds), lanes past
+          // the camera's last segment issue nothing, added in segment order
           int sg = cam_seg_ptr[c];
-          const int sg1 = cam_seg_ptr[c + 1], last = sg1 - 1;
-          for (; sg < sg1; sg += 4) {
-            const int n = sg1 - sg;
-            const T q0 = op_partial[9 * (size_t)sg + i], q1 = op_partial[9 * (size_t)(sg + 1 < last ? sg + 1 : last) + i],
-                    q2 = op_partial[9 * (size_t)(sg + 2 < last ? sg + 2 : last) + i], q3 = op_partial[9 * (size_t)(sg + 3 < last ? sg + 3 : last) + i];
-            raw += q0;
-            if (n > 1) raw += q1;
-            if (n > 2) raw += q2;
-            if (n > 3) raw += q3;
+          const int sg1 = cam_seg_ptr[c + 1];
+          for (; sg < sg1; sg += 16) {
+            T q[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) q[u] = sg + u < sg1 ? op_partial[9 * (size_t)(sg + u) + i] : T(0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (sg + u < sg1) raw += q[u];
           }
         }
         if (gg.cam_fixed && gg.cam_fixed[c]) raw = T(0);
@@ -1813,33 +1812,31 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         int a = pt_ptr[l];
         const int a_end = pt_ptr[l + 1];
 #if UPD_VAR != 1
-        if (gg.gidx) {
-          for (; a + 4 <= a_end; a += 4) { // same order of the sum; the slots sit where the operator's wave wrote them
-            const int j0 = gg.gidx[a], j1 = gg.gidx[a + 1], j2 = gg.gidx[a + 2], j3 = gg.gidx[a + 3];
-            const T g0 = g3[3 * (size_t)j0 + li], g1 = g3[3 * (size_t)j1 + li], g2 = g3[3 * (size_t)j2 + li], g3v = g3[3 * (size_t)j3 + li];
-            raw += g0; raw += g1; raw += g2; raw += g3v;
-          }
-          if (a < a_end) { // 1-3 left: ONE batch with clamped indices (a serial loop is a dependent index -> value round trip per element)
-            const int n = a_end - a, last = a_end - 1;
-            const int j0 = gg.gidx[a], j1 = gg.gidx[a + 1 < last ? a + 1 : last], j2 = gg.gidx[a + 2 < last ? a + 2 : last];
-            const T g0 = g3[3 * (size_t)j0 + li], g1 = g3[3 * (size_t)j1 + li], g2 = g3[3 * (size_t)j2 + li];
-            raw += g0;
-            if (n > 1) raw += g1;
-            if (n > 2) raw += g2;
+        // A point's run of observation rows, summed in observation order, EIGHT requests in flight per round (round 6): the sum is a
+        // chain of dependent round trips — with four per round a point of five to eight observations (most waves hold one) cost
+        // two rounds of values (and, gathered, two of indices before them); the launch is latency-bound (Venice-1778 fp32: 77 % of
+        // wave-cycles parked on memory at 1.04 x algorithmic traffic), so the rounds are what counts.  Lanes past their run's end
+        // issue nothing (predicated), the additions keep their order.
+        if (gg.gidx) { // the slots sit where the operator's wave wrote them
+          for (; a < a_end; a += 8) {
+            int jx[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) jx[u] = a + u < a_end ? gg.gidx[a + u] : -1;
+            T gq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gq[u] = jx[u] >= 0 ? g3[3 * (size_t)jx[u] + li] : T(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (jx[u] >= 0) raw += gq[u];
           }
         } else {
-        for (; a + 4 <= a_end; a += 4) { // 4 independent loads in flight, the sum stays in observation order
-          const T *gp = g3 + 3 * (size_t)a + li;
-          const T g0 = gp[0], g1 = gp[3], g2 = gp[6], g3v = gp[9];
-          raw += g0; raw += g1; raw += g2; raw += g3v;
-        }
-        if (a < a_end) { // 1-3 left: one batch, clamped
-          const int n = a_end - a, last = a_end - 1;
-          const T g0 = g3[3 * (size_t)a + li], g1 = g3[3 * (size_t)(a + 1 < last ? a + 1 : last) + li], g2 = g3[3 * (size_t)(a + 2 < last ? a + 2 : last) + li];
-          raw += g0;
-          if (n > 1) raw += g1;
-          if (n > 2) raw += g2;
-        }
+          for (; a < a_end; a += 8) {
+            const T *gp = g3 + 3 * (size_t)a + li;
+            T gq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gq[u] = a + u < a_end ? gp[3 * u] : T(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (a + u < a_end) raw += gq[u];
+          }
         }
 #else
         raw = (double)(a_end - a);
