@@ -475,6 +475,7 @@ k_pcg_resident(const RpParams<T> P, const int *__restrict__ cam_cm, const int *_
     }
     const double den_tot = rp_slot_sum(st.slots(k, DEN));
     const T alpha = rz / (T)(den_tot + mu * pdp);
+    if (P.var & 256) stamp(); // (fine stamps) den known
     double dots[4] = {0.0, 0.0, 0.0, 0.0}; // r.r, r.z', p.D.z', z'.D.z'
 #pragma unroll
     for (int q = 0; q < RP_RV; ++q) {
@@ -550,6 +551,7 @@ k_pcg_resident(const RpParams<T> P, const int *__restrict__ cam_cm, const int *_
     alpha_pend = alpha;
     stamp(); // update done
     rp_block_allsum4(dots, l_red);
+    if (P.var & 256) stamp(); // (fine stamps) dots reduced in the workgroup
     if (tid < 4) rp_slot_add(st.slots(k + 1, tid == 0 ? RR : tid == 1 ? RZP : tid == 2 ? PDZ : ZDZ), tid == 0 ? dots[0] : tid == 1 ? dots[1] : tid == 2 ? dots[2] : dots[3]);
     if (!rp_barrier(P.bar, ++epoch, P.fail, l_flag)) return;
     stamp(); // barrier B passed
