@@ -1780,17 +1780,32 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
   int q = (int)(blockIdx.x & 7), tile = sweep ? (int)(blockIdx.x >> 3) : pt0;
   unsigned P0 = 0, P1 = (unsigned)Np;
   if (sweep && q < gg.n_ptiles) { P0 = (unsigned)gg.ptile_ptr[q]; P1 = (unsigned)gg.ptile_ptr[q + 1]; }
-  for (;;) {
+  // the tile walk, one step: first point of the workgroup's next tile and the end of the range it lies in; false: no tile left
+  auto next_tile = [&](unsigned &lbase, unsigned &lend) __attribute__((always_inline)) -> bool {
     if (sweep) {
       while (q < gg.n_ptiles && P0 + 85u * (unsigned)tile >= P1) { // next point tile of this XCD
         q += 8; tile = (int)(blockIdx.x >> 3);
         if (q < gg.n_ptiles) { P0 = (unsigned)gg.ptile_ptr[q]; P1 = (unsigned)gg.ptile_ptr[q + 1]; }
       }
-      if (q >= gg.n_ptiles) break;
-    } else if (tile >= pt1) break;
-    const unsigned l = P0 + (unsigned)tile * 85u + lt;
-    const bool on = threadIdx.x < 255 && l < P1;
+      if (q >= gg.n_ptiles) return false;
+    } else if (tile >= pt1) return false;
+    lbase = P0 + (unsigned)tile * 85u; lend = P1;
     tile += sweep ? (int)(gridDim.x >> 3) : 1;
+    return true;
+  };
+  // (round 6) the run bounds of the NEXT tile's points are requested while this tile is worked on: they are what the dependent chain
+  // of a tile starts with (bounds -> [indices ->] rows); with them at hand the rows are requested together with the tile's vectors
+  unsigned lb_n = 0, le_n = 0;
+  bool have_n = next_tile(lb_n, le_n);
+  int a_n = 0, ae_n = 0;
+  if (have_n && MODE == 1) { const unsigned ln = lb_n + lt; if (threadIdx.x < 255 && ln < le_n) { a_n = pt_ptr[ln]; ae_n = pt_ptr[ln + 1]; } }
+  while (have_n) {
+    const unsigned l = lb_n + lt;
+    const bool on = threadIdx.x < 255 && l < le_n;
+    const int a_cur = a_n, ae_cur = ae_n;
+    have_n = next_tile(lb_n, le_n);
+    a_n = ae_n = 0;
+    if (have_n && MODE == 1) { const unsigned ln = lb_n + lt; if (threadIdx.x < 255 && ln < le_n) { a_n = pt_ptr[ln]; ae_n = pt_ptr[ln + 1]; } }
     const size_t t = (size_t)pose_dim + 3 * (size_t)l + li;
     T rn = 0, pv = 0, m0 = 0, m1 = 0, m2 = 0, dg = T(1);
     if (on) {
@@ -1809,8 +1824,8 @@ k_pcg_update(int Nc, int Np, const T *__restrict__ bu, const T *__restrict__ sca
         }
         const T xo = FIRST ? T(0) : x[t], ro = r[t];
         double raw = 0; // summed in double whatever T is (a point's rows cancel; T = double: unchanged)
-        int a = pt_ptr[l];
-        const int a_end = pt_ptr[l + 1];
+        int a = a_cur;
+        const int a_end = ae_cur;
 #if UPD_VAR != 1
         // A point's run of observation rows, summed in observation order, EIGHT requests in flight per round (round 6): the sum is a
         // chain of dependent round trips — with four per round a point of five to eight observations (most waves hold one) cost
