@@ -445,9 +445,15 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
     constexpr int PPB = TPB / FIN_PL;
     const int ntile = (Np + PPB - 1) / PPB;
     const unsigned jl = threadIdx.x % FIN_PL;
+    // (round 6) the run bounds of the NEXT tile's points are requested while this tile is worked on: a tile's dependent chain is
+    // bounds -> records -> sums -> inverse -> stores, and the first link is now off it
+    int pa_n = 0, pe_n = 0;
+    { const int l0 = (b - nbc) * PPB + (int)(threadIdx.x / FIN_PL); if (b - nbc < ntile && l0 < Np) { pa_n = pt_ptr[l0]; pe_n = pt_ptr[l0 + 1]; } }
     for (int tile = b - nbc; tile < ntile; tile += gridDim.x - nbc) {
       const int l = tile * PPB + (int)(threadIdx.x / FIN_PL);
       const bool on = l < Np;
+      const int pa = pa_n, pe = pe_n;
+      { const int tn = tile + (int)gridDim.x - nbc, ln = tn * PPB + (int)(threadIdx.x / FIN_PL); pa_n = pe_n = 0; if (tn < ntile && ln < Np) { pa_n = pt_ptr[ln]; pe_n = pt_ptr[ln + 1]; } }
       // The sums of a point's records, its scales, the scaled damped block, the inverse and z' = Minv r are taken in DOUBLE whatever
       // T is (for T = double nothing changes): the 3 x 3 block of a weakly observed point has a condition number of 1e3-1e4, and in
       // fp32 every rounding of the block's entries came back that much larger in the inverse (fp32 step 2.8 x further from the fp64
@@ -457,7 +463,7 @@ k_finalize_bj(int Nc, int Np, int nbc, int scale_system, const int *__restrict__
       for (int i = 0; i < 9; ++i) v[i] = 0.0;
       if (on && (VAR & 4)) { v[0] = v[3] = v[5] = (double)(2 + l % 3); v[6] = 1.0; }
       if (on && !(VAR & 4)) {
-        for (int a = pt_ptr[l] + (int)jl; a < pt_ptr[l + 1]; a += FIN_PL) {
+        for (int a = pa + (int)jl; a < pe; a += FIN_PL) {
           const V2 *gq = reinterpret_cast<const V2 *>(g9 + 8 * (size_t)a);
           const V2 q0 = gq[0], q1 = gq[1], q2 = gq[2], qe = gq[3]; // sqrt(w) Jp columns, sqrt(w) e
           const double c0x = q0.x, c0y = q0.y, c1x = q1.x, c1y = q1.y, c2x = q2.x, c2y = q2.y, ex = qe.x, ey = qe.y;
