@@ -137,6 +137,25 @@ __device__ __forceinline__ void rp_block_allsum4(double (&v)[4], double *red) {
 __device__ __forceinline__ double rp_slot_sum(const double *base) {
   return wave_allsum(__hip_atomic_load(&base[(size_t)(threadIdx.x & 63) * SS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// NV dot products after a barrier: ONE wave of the workgroup reads the 64 slots of each (all 2 048 waves of the grid reading the same
+// 512-byte records at the same instant took 3.5 us: one memory channel), the totals reach the other waves through LDS
+template <int NV> __device__ __forceinline__ void rp_slot_sums_block(const double *const (&base)[NV], double (&out)[NV], double *red) {
+  if (threadIdx.x < 64) {
+    double v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = __hip_atomic_load(&base[i][(size_t)threadIdx.x * SS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_allsum(v[i]);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) red[i] = v[i];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) out[i] = red[i];
+  __syncthreads(); // (red is reused by the next reduction)
+}
 __device__ __forceinline__ void rp_slot_add(double *base, double v) {
   (void)__hip_atomic_fetch_add(&base[(size_t)(blockIdx.x & (NS - 1)) * SS], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -296,8 +315,18 @@ k_pcg_resident(const RpParams<T> P, const int *__restrict__ cam_cm, const int *_
   // What the block's FIRST camera needs was requested a block ahead: pkraw (lanes 0..23: its pack), seg0 (its segment slot) and,
   // except in iteration 0, craw (lanes 0..8 / 9..17: s.z'_c / s.p_c).  Further cameras of the block (one block in six has a second)
   // fetch theirs here.  first: direction sigma s.z'_0 from k_finalize_bj's zs; the loss weight is taken from the residual and returned.
+  // The outputs of a block are STORED ONE BLOCK LATER (Pend; flush_pend): a wave's `s_waitcnt vmcnt` for the next block's gathers also
+  // waits for every store issued before it (loads and stores return out of order with respect to each other, so the compiler waits
+  // for all), and a write-through store is acknowledged late; issued right after the next fetch, the stores have a whole block's
+  // arithmetic to complete before anything waits again (ablation: the g4 stores cost 4.5 of the phase's 22 us where they stood).
+  struct Pend { T g0, g1, g2, tot; int a, seg; bool hasg, hasp; };
+  auto flush_pend = [&](Pend &pd) __attribute__((always_inline)) {
+    if (pd.hasg && !(P.var & 1)) rp_st_g4(r_g4, pd.a, pd.g0, pd.g1, pd.g2);
+    if (pd.hasp && (lane & 3) == 0 && (lane >> 2) < 9 && !(P.var & 2)) rp_st(&P.op_partial[9 * (size_t)pd.seg + (lane >> 2)], pd.tot);
+    pd.hasg = false; pd.hasp = false;
+  };
   auto obs_math = [&](const int j, const bool valid, const int c, const int a, const T ox, const T oy, T wl, const T X, const T Y, const T Z,
-                      const T pl0, const T pl1, const T pl2, const bool first, T craw, const T pkraw, const int seg0, double &den) __attribute__((always_inline)) -> T {
+                      const T pl0, const T pl1, const T pl2, const bool first, T craw, const T pkraw, const int seg0, double &den, Pend &pend) __attribute__((always_inline)) -> T {
     unsigned long long remaining = __ballot(valid);
     if (!remaining) return wl;
     bool head = true;
@@ -349,9 +378,12 @@ k_pcg_resident(const RpParams<T> P, const int *__restrict__ cam_cm, const int *_
       for (int i = 0; i < 9; ++i) m[i] = mine ? Jc[2 * i] * u0 + Jc[2 * i + 1] * u1 : T(0);
 #pragma unroll
       for (int i = 9; i < 16; ++i) m[i] = T(0);
-      if (mine && !(P.var & 1)) rp_st_g4(r_g4, a, Jp[0] * u0 + Jp[1] * u1, Jp[2] * u0 + Jp[3] * u1, Jp[4] * u0 + Jp[5] * u1);
+      if (mine) { pend.g0 = Jp[0] * u0 + Jp[1] * u1; pend.g1 = Jp[2] * u0 + Jp[3] * u1; pend.g2 = Jp[4] * u0 + Jp[5] * u1; pend.a = a; pend.hasg = true; }
       const T tot = wave_transpose_sum<T, 16>(m, lane);
-      if ((lane & 3) == 0 && (lane >> 2) < 9 && !(P.var & 2)) rp_st(&P.op_partial[9 * (size_t)segl + (lane >> 2)], tot);
+      if (pend.hasp) { // an earlier camera of this block is still held: out it goes (one block in six has a second camera)
+        if ((lane & 3) == 0 && (lane >> 2) < 9 && !(P.var & 2)) rp_st(&P.op_partial[9 * (size_t)pend.seg + (lane >> 2)], pend.tot);
+      }
+      pend.tot = tot; pend.seg = segl; pend.hasp = true;
       remaining &= ~__ballot(mine);
     }
     return wl;
@@ -391,6 +423,7 @@ k_pcg_resident(const RpParams<T> P, const int *__restrict__ cam_cm, const int *_
     };
     Idx i_cur = load_idx(0), i_nxt = load_idx(1);
     Gat g_cur = gather(i_cur);
+    Pend pend{T(0), T(0), T(0), T(0), 0, 0, false, false};
 #pragma unroll 1
     for (int s = 0; s < niter; ++s) {
       const Idx ix = i_cur;
@@ -398,12 +431,14 @@ k_pcg_resident(const RpParams<T> P, const int *__restrict__ cam_cm, const int *_
       i_cur = i_nxt;
       g_cur = gather(i_cur);   // block s + 1: its indices arrived during block s - 1
       i_nxt = load_idx(s + 2);
+      flush_pend(pend);        // block s - 1's outputs
       const int j = j0 + s * RTPB + tid;
-      const T wl = obs_math(j, ix.c >= 0, ix.c, ix.a, ix.ox, ix.oy, T(0), g.X, g.Y, g.Z, sigma * g.z0, sigma * g.z1, sigma * g.z2, true, T(0), g.pk, g.sg, den);
+      const T wl = obs_math(j, ix.c >= 0, ix.c, ix.a, ix.ox, ix.oy, T(0), g.X, g.Y, g.Z, sigma * g.z0, sigma * g.z1, sigma * g.z2, true, T(0), g.pk, g.sg, den, pend);
       l_c[s * RTPB + tid] = ix.c; l_l[s * RTPB + tid] = ix.l; l_a[s * RTPB + tid] = ix.a; l_sg[s * RTPB + tid] = g.sg;
       l_xyz[(3 * s) * RTPB + tid] = g.X; l_xyz[(3 * s + 1) * RTPB + tid] = g.Y; l_xyz[(3 * s + 2) * RTPB + tid] = g.Z;
       l_w[s * RTPB + tid] = wl;
     }
+    flush_pend(pend);
   }
 
   for (int k = 0; k < P.max_iter; ++k) {
@@ -429,6 +464,7 @@ k_pcg_resident(const RpParams<T> P, const int *__restrict__ cam_cm, const int *_
         }
       };
       if (niter > 0) fetch(0);
+      Pend pend{T(0), T(0), T(0), T(0), 0, 0, false, false};
 #pragma unroll 1
       for (int s = 0; s < niter; ++s) {
         const int j = j0 + s * RTPB + tid;
@@ -436,9 +472,11 @@ k_pcg_resident(const RpParams<T> P, const int *__restrict__ cam_cm, const int *_
         const T cr = craw, pr = pkraw;
         const T pl0 = sigma * gv[0] + beta * gv[3], pl1 = sigma * gv[1] + beta * gv[4], pl2 = sigma * gv[2] + beta * gv[5];
         if (s + 1 < niter) fetch(s + 1);
+        flush_pend(pend); // block s - 1's outputs: behind the next fetch, a block's arithmetic ahead of the next wait
         (void)obs_math(j, c >= 0, c, l_a[s * RTPB + tid], T(0), T(0), l_w[s * RTPB + tid], l_xyz[(3 * s) * RTPB + tid], l_xyz[(3 * s + 1) * RTPB + tid],
-                       l_xyz[(3 * s + 2) * RTPB + tid], pl0, pl1, pl2, false, cr, pr, l_sg[s * RTPB + tid], den);
+                       l_xyz[(3 * s + 2) * RTPB + tid], pl0, pl1, pl2, false, cr, pr, l_sg[s * RTPB + tid], den, pend);
       }
+      flush_pend(pend);
     }
     {
       double v4[4] = {den, 0.0, 0.0, 0.0};
@@ -447,33 +485,41 @@ k_pcg_resident(const RpParams<T> P, const int *__restrict__ cam_cm, const int *_
     }
     stamp(); // operator done
     if (tid == 0) rp_slot_add(st.slots(k, DEN), den);
+    // what the update needs that no workgroup writes in this launch (column scale, clamped diagonal, the point's row of its inverse) is
+    // requested BEFORE the barrier: its latency passes under the wait (3 us stood between "barrier passed" and "den known" for them)
+    T sc[RP_RV], dg[RP_RV], mrow[RP_RV][3];
+#pragma unroll
+    for (int q = 0; q < RP_RV; ++q) {
+      sc[q] = dg[q] = T(1); mrow[q][0] = mrow[q][1] = mrow[q][2] = T(0);
+      if (!((onmask >> q) & 1u)) continue;
+      const unsigned t = st_[q];
+      sc[q] = scales[t];
+      if (!P.use_identity) dg[q] = diag[t];
+      if (!((cammask >> q) & 1u) && !P.identity_precond) { // row li of the point's inverse
+        const T *M = MinvP + 9 * (size_t)((t - pose_dim) / 3u);
+        mrow[q][0] = M[li]; mrow[q][1] = M[li + 3]; mrow[q][2] = M[li + 6];
+      }
+    }
     if (!rp_barrier(P.bar, ++epoch, P.fail, l_flag)) return;
     stamp(); // barrier A passed
 
     // ---- update (pcg.hpp:166-195): alpha, x, r, z' = Minv r, the four dots; the owner forms p_k in registers ---------------
     // every unit's loads are issued before the first is used: ONE exposed round trip per phase, not one per unit
     constexpr int RG = 4; // run entries fetched up front (a point has 4.3 observations on average); longer runs: a loop (eight: 165 spilled VGPRs)
-    T gq[RP_RV][RG], sc[RP_RV], dg[RP_RV], mrow[RP_RV][3];
+    T gq[RP_RV][RG];
 #pragma unroll
     for (int q = 0; q < RP_RV; ++q) {
-      sc[q] = dg[q] = T(1); mrow[q][0] = mrow[q][1] = mrow[q][2] = T(0);
 #pragma unroll
       for (int u = 0; u < RG; ++u) gq[q][u] = T(0);
       if (!((onmask >> q) & 1u)) continue;
       const bool is_cam = (cammask >> q) & 1u;
-      const unsigned t = st_[q];
-      sc[q] = scales[t];
-      if (!P.use_identity) dg[q] = diag[t];
-      if (!is_cam && !P.identity_precond) { // row li of the point's inverse
-        const T *M = MinvP + 9 * (size_t)((t - pose_dim) / 3u);
-        mrow[q][0] = M[li]; mrow[q][1] = M[li + 3]; mrow[q][2] = M[li + 6];
-      }
       const T *src = is_cam ? P.op_partial + ci : P.g4 + li;
       const int stride = is_cam ? 9 : 4;
 #pragma unroll
       for (int u = 0; u < RG; ++u) if (sa0[q] + u < sa1[q] && !(P.var & 32)) gq[q][u] = rp_ld(src + (size_t)stride * (size_t)(sa0[q] + u));
     }
-    const double den_tot = rp_slot_sum(st.slots(k, DEN));
+    double den_tot;
+    { const double *const sl[1] = {st.slots(k, DEN)}; double o[1]; rp_slot_sums_block<1>(sl, o, l_red); den_tot = o[0]; }
     const T alpha = rz / (T)(den_tot + mu * pdp);
     if (P.var & 256) stamp(); // (fine stamps) den known
     double dots[4] = {0.0, 0.0, 0.0, 0.0}; // r.r, r.z', p.D.z', z'.D.z'
@@ -557,9 +603,13 @@ k_pcg_resident(const RpParams<T> P, const int *__restrict__ cam_cm, const int *_
     stamp(); // barrier B passed
 
     // ---- loop control (pcg.hpp:197-229), the same in every thread -----------------------------------------------------------
-    rr = rp_slot_sum(st.slots(k + 1, RR)); rzp = rp_slot_sum(st.slots(k + 1, RZP));
-    const double pdz = rp_slot_sum(st.slots(k + 1, PDZ));
-    zdz = rp_slot_sum(st.slots(k + 1, ZDZ));
+    double pdz;
+    {
+      const double *const sl[4] = {st.slots(k + 1, RR), st.slots(k + 1, RZP), st.slots(k + 1, PDZ), st.slots(k + 1, ZDZ)};
+      double o[4];
+      rp_slot_sums_block<4>(sl, o, l_red);
+      rr = o[0]; rzp = o[1]; pdz = o[2]; zdz = o[3];
+    }
     iters = k + 1;
     const T sigma_n = (T)(1.0 / (double)(T)sqrt((double)(T)rr));
     const T rz_new = (T)rzp * sigma_n;
