@@ -190,3 +190,69 @@ def schur_test_fixture(dtype=np.float64) -> BalProblem:
     cam_idx = np.array([0, 1, 0, 1, 0, 1], np.int32)
     pt_idx = np.array([0, 0, 1, 1, 2, 2], np.int32)
     return BalProblem(cams, pts, obs, cam_idx, pt_idx, "schur-2x3")
+
+
+def make_pose_graph(n_poses=2000, factors_per_pose=5, seed=7, sigma_t=0.02, sigma_th=0.005, huber=False):
+    """A planar pose graph (SE(2) between-factors: the SLAM back-end workload the reference's README names, and what BASELINE
+    configs[0] calls a "2D pose-graph"): a wandering trajectory, for every pose i the odometry factor (i, i + 1), short-range
+    factors (i, i + 2), (i, i + 3) and loop closures to earlier poses that lie nearby, `factors_per_pose` per pose on average.
+    Returns (poses0 [n, 3] initial guess from integrated noisy odometry, fixed [n] (pose 0), edges [F, 2] int32, meas [F, 3],
+    info [F, 3, 3] per-factor information matrices (symmetric positive definite, not diagonal), truth [n, 3])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = n_poses
+    # ground truth: constant forward speed, slowly varying turn rate (loops back on itself)
+    th = np.cumsum(0.12 * np.sin(0.013 * np.arange(n)) + 0.05 + rng.normal(0, 0.01, n))
+    step = 0.5
+    xy = np.cumsum(np.stack([step * np.cos(th), step * np.sin(th)], 1), 0)
+    truth = np.concatenate([xy, th[:, None]], 1)
+
+    def rel(a, b):  # measurement of b in a's frame (the factor's error at the truth is zero)
+        c, s = np.cos(a[:, 2]), np.sin(a[:, 2])
+        dx, dy = b[:, 0] - a[:, 0], b[:, 1] - a[:, 1]
+        return np.stack([c * dx + s * dy, -s * dx + c * dy, b[:, 2] - a[:, 2]], 1)
+
+    ii = [np.arange(n - 1)]; jj = [np.arange(1, n)]
+    for d in (2, 3):
+        ii.append(np.arange(n - d)); jj.append(np.arange(d, n))
+    target = int(factors_per_pose * n)
+    have = sum(len(a) for a in ii)
+    if target > have:  # loop closures: a random earlier pose within a window of 40 steps in space order
+        order = np.argsort(xy[:, 0] + 1e-3 * xy[:, 1])
+        k = target - have
+        a = rng.integers(0, n, k)
+        pos = np.empty(n, np.int64); pos[order] = np.arange(n)
+        b = order[np.clip(pos[a] + rng.integers(-20, 21, k), 0, n - 1)]
+        keep = np.abs(a - b) > 3
+        ii.append(np.minimum(a, b)[keep]); jj.append(np.maximum(a, b)[keep])
+    i = np.concatenate(ii).astype(np.int32); j = np.concatenate(jj).astype(np.int32)
+    F = len(i)
+    meas = rel(truth[i], truth[j]) + rng.normal(0, 1, (F, 3)) * np.array([sigma_t, sigma_t, sigma_th])
+    # information: R diag(1 / sigma^2) R^T with a small random rotation of the (x, y) axes and an x-theta coupling: symmetric, SPD, full
+    w = np.array([1 / sigma_t ** 2, 1 / sigma_t ** 2, 1 / sigma_th ** 2]) * 1e-3  # (scaled: chi2 of order F)
+    ang = rng.uniform(-0.3, 0.3, F)
+    info = np.zeros((F, 3, 3))
+    c, s = np.cos(ang), np.sin(ang)
+    sx, sy = w[0] * rng.uniform(0.5, 1.5, F), w[1] * rng.uniform(0.5, 1.5, F)
+    info[:, 0, 0] = c * c * sx + s * s * sy; info[:, 1, 1] = s * s * sx + c * c * sy
+    info[:, 0, 1] = info[:, 1, 0] = c * s * (sx - sy)
+    info[:, 2, 2] = w[2] * rng.uniform(0.5, 1.5, F)
+    cpl = 0.1 * np.sqrt(info[:, 0, 0] * info[:, 2, 2]) * rng.uniform(-1, 1, F)
+    info[:, 0, 2] = info[:, 2, 0] = cpl
+    # initial guess: the odometry chain integrated with its noise (drifts away from the truth)
+    poses0 = np.zeros((n, 3)); poses0[0] = truth[0]
+    odo = meas[: n - 1]
+    for k_ in range(n - 1):
+        c0, s0 = np.cos(poses0[k_, 2]), np.sin(poses0[k_, 2])
+        poses0[k_ + 1] = [poses0[k_, 0] + c0 * odo[k_, 0] - s0 * odo[k_, 1], poses0[k_, 1] + s0 * odo[k_, 0] + c0 * odo[k_, 1], poses0[k_, 2] + odo[k_, 2]]
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1
+    return poses0, fixed, np.stack([i, j], 1), meas, info, truth
+
+
+def write_pose_graph(path, poses, fixed, edges, meas, info, huber_delta=0.0):
+    """text file read by tests/cpp/test_pose_graph.hip: 'N F delta', N lines 'x y theta fixed', F lines 'i j mx my mth p00 .. p22' (row-major)"""
+    with open(path, "w") as f:
+        f.write(f"{len(poses)} {len(edges)} {float(huber_delta)!r}\n")
+        for p, fx in zip(poses, fixed):
+            f.write(f"{float(p[0])!r} {float(p[1])!r} {float(p[2])!r} {int(fx)}\n")
+        for e, m, P in zip(edges, meas, info):
+            f.write(f"{int(e[0])} {int(e[1])} " + " ".join(repr(float(v)) for v in m) + " " + " ".join(repr(float(v)) for v in P.ravel()) + "\n")

@@ -42,15 +42,15 @@ def build_all():
     # the clients are independent translation units (tens of seconds each: the whole header-only layer): built side by side
     from concurrent.futures import ThreadPoolExecutor
     names = ["test_generic_radius", "test_generic_bal", "test_generic_known_answers", "test_generic_schur_mixed", "test_sparse_schur",
-             "test_generic_schur_dims", "test_engine_model"]
+             "test_generic_schur_dims", "test_engine_model", "test_pose_graph"]
     lib = os.path.join(ROOT, "graphite_amd", "libgraphite_mi355x.so")
     if not os.path.exists(lib):
         import __graft_entry__ as g
         g.build()
-    with ThreadPoolExecutor(max_workers=7) as pool:  # (seven translation units, eight cores; the longest, test_engine_model, sets the wall time)
+    with ThreadPoolExecutor(max_workers=8) as pool:  # (eight translation units, eight cores; the longest, test_engine_model, sets the wall time)
         exe = list(pool.map(lambda n: hipcc(os.path.join(ROOT, "tests", "cpp", n + ".hip"), os.path.join(BUILD, n)), names))
     radius = exe[0]
-    return (radius, radius, exe[1], exe[2], exe[3], exe[4], exe[5], exe[6])
+    return (radius, radius, exe[1], exe[2], exe[3], exe[4], exe[5], exe[6], exe[7])
 
 
 def test_generic_layer_compiles_for_gfx950():
@@ -422,3 +422,34 @@ def test_baseline_configs0_circle_100_vertices(oracle_mod, tmp_path, solver, mod
     final = float([ln for ln in r.stdout.splitlines() if ln.startswith("FINAL_CHI2")][0].split()[1])
     assert abs(final - ct[-1]) <= 1e-10 * max(1.0, ct[-1])
     assert np.allclose(np.hypot(*np.delete(got, [2, n - 1], 0).T), R, atol=1e-9)
+
+
+def _pose_graph_run(tmp_path, n, its, mode, pcg_it, pcg_tol, solver="pcg", env=None, huber=0.0):
+    from oracle.pose_graph import PoseGraphOracle
+    exe = build_all()[8]
+    p0, fx, e, m, info, _ = synth.make_pose_graph(n)
+    f = tmp_path / "graph.txt"
+    out = tmp_path / "poses.txt"
+    synth.write_pose_graph(f, p0, fx, e, m, info, huber_delta=huber)
+    r = subprocess.run([exe, str(f), solver, str(its), mode, str(pcg_it), repr(pcg_tol), str(out)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    o = PoseGraphOracle(p0, fx, e, m, info, huber_delta=huber)
+    ct, lt, st = o.levenberg_marquardt(iterations=its, pcg_max_iter=pcg_it, pcg_tol=pcg_tol, identity_precond=(solver == "pcg-identity"))
+    return r, parse_trace(r.stdout), np.loadtxt(out), ct, lt, st, o
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,solver,pcg_it,pcg_tol,huber", [("manual", "pcg", 10, 1.0, 0.0), ("auto", "pcg", 30, 1e-10, 0.0), ("manual", "pcg-identity", 15, 1e-6, 0.0),
+                                                         ("manual-huber", "pcg", 10, 1.0, 3.0)])
+def test_pose_graph_on_the_generic_kernels(tmp_path, mode, solver, pcg_it, pcg_tol, huber):
+    """A planar pose graph — one vertex descriptor, binary between-factors on it, full 3 x 3 information matrices, one fixed pose, optional
+    Huber loss: the shape BASELINE configs[0] names and SLAM users of the reference run (README.md:27) — through levenberg_marquardt with
+    PCGSolver + BlockJacobiPreconditioner / IdentityPreconditioner on the HIP generic layer, against oracle/pose_graph.py (numpy restatement of
+    graph.hpp:236-290, block_jacobi.hpp:79-186, pcg.hpp:61-232, levenberg_marquardt.hpp:110-242): chi2 and damping traces at 1e-9, every final
+    pose at 1e-9; manual Jacobians and dual numbers."""
+    r, tr, got, ct, lt, st, o = _pose_graph_run(tmp_path, 2000, 8, mode, pcg_it, pcg_tol, solver, env={"GRAPHITE_GENERIC_ONLY": "1"}, huber=huber)
+    assert len(tr) == len(ct) - 1 and ct[-1] < 0.05 * ct[0]
+    assert np.allclose(tr[:, 1], ct[1:], rtol=1e-9) and np.allclose(tr[:, 2], lt[1:], rtol=1e-8)
+    assert np.allclose(got, o.x, rtol=1e-9, atol=1e-9)
+    assert np.array_equal(got[0], synth.make_pose_graph(2000)[0][0])  # the fixed pose keeps its bits
