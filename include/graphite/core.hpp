@@ -651,9 +651,13 @@ public:
 // FactorDescriptor (factor.hpp:120-830)
 // =================================================================================================
 namespace detail { class EngineModelBase; } // engine_model.hpp
+namespace detail { struct PoseEngineOptions; struct PoseEngineResult; } // engine_pose.hpp
 template <typename T, typename S> class BaseFactorDescriptor {
 public:
   virtual ~BaseFactorDescriptor() = default;
+  // The pose-graph engine (engine_pose.hpp) on THIS descriptor's traits: the whole levenberg_marquardt + PCGSolver loop of a graph
+  // whose only factors are binary factors between vertices of one descriptor.  -1: not such a descriptor (the reason in the result).
+  virtual int pose_engine_lm(const detail::PoseEngineOptions &, detail::PoseEngineResult &, T * /*graph b*/, T * /*graph scales*/, size_t /*hessian dimension*/) { return -1; }
   // The engine's per-observation kernels instantiated on THIS descriptor's traits (engine_model.hpp), for the active factors:
   // local pose / landmark ids per active factor (active_indices order) in cam / pt.  nullptr: not a (<= 9, <= 3) -> <= 2 binary
   // factor of plain-data types, or a precision matrix that is not symmetric positive semi-definite.
@@ -1765,6 +1769,8 @@ public:
   }
   bool declares_bal_model() const override { return detail::has_bal_tag<Traits>::value; }
   std::shared_ptr<detail::EngineModelBase> make_engine_model(std::vector<int32_t> &cam, std::vector<int32_t> &pt, size_t num_poses, size_t num_landmarks) override; // engine_model.hpp
+  int pose_engine_lm(const detail::PoseEngineOptions &o, detail::PoseEngineResult &res, T *graph_b, T *graph_scales, size_t hessian_dim) override; // engine_pose.hpp
+  std::shared_ptr<void> pose_engine_state; // its buffers, kept between optimiser calls
   bool probe_bal(size_t max_samples, std::vector<T> &cam, std::vector<T> &pt, std::vector<T> &obs, std::vector<T> &res, std::vector<T> &Jc, std::vector<T> &Jp, double &update_dev,
                  size_t *num_synthetic = nullptr) override {
     if constexpr (bal_shaped()) {
@@ -2035,3 +2041,4 @@ public:
 } // namespace graphite
 
 #include "engine_model.hpp" // the engine's kernels on user traits: needs everything above
+#include "engine_pose.hpp"  // the pose-graph engine on user traits

@@ -708,6 +708,69 @@ template <typename T> struct EngineCache {
   ~EngineCache() { if (prob) gr_bal_destroy(prob); } // before `model`: the problem calls into it
 };
 
+// optimiser calls that ran on the pose-graph engine (engine_pose.hpp)
+inline size_t &pose_engine_handovers() { static size_t n = 0; return n; }
+// A graph of ONE vertex descriptor and ONE binary factor descriptor between its vertices, solved by PCGSolver with the block-Jacobi
+// or identity preconditioner: the pose-graph engine (engine_pose.hpp, kernels instantiated on the user's traits).  false: the graph
+// stays on the generic kernels (the reason under GR_VERBOSE).
+template <typename T, typename S>
+bool pose_engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, bool early_stop, bool &result) {
+  if (getenv("GRAPHITE_POSE_ENGINE") && atoi(getenv("GRAPHITE_POSE_ENGINE")) == 0) return false;
+  auto *vd = graph->get_vertex_descriptors()[0];
+  auto *fd = graph->get_factor_descriptors()[0];
+  const bool verbose_why = getenv("GR_VERBOSE") != nullptr;
+  auto why = [&](const std::string &w) { if (verbose_why) std::cerr << "[graphite] pose-graph engine: " << w << "; using the generic kernels" << std::endl; return false; };
+  if (fd->slot_descriptor(0) != vd || fd->slot_descriptor(1) != vd) return why("the factor's slots are not the graph's vertex descriptor");
+  if (vd->eliminate) return why("the vertex descriptor is marked for elimination");
+  const int kind = options->solver->engine_kind(vd->count());
+  if (kind != GR_SOLVER_PCG && kind != GR_SOLVER_PCG_IDENTITY) return why("the solver is not PCGSolver with the block-Jacobi or identity preconditioner");
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  if (!graph->initialize_optimization(options->optimization_level, /*light=*/true)) return false;
+  graphite::detail::PoseEngineOptions o;
+  o.iterations = options->iterations; o.initial_damping = (double)options->initial_damping; o.use_identity = options->use_identity;
+  int m = 0; double tol = 0, rej = 0;
+  options->solver->engine_pcg_parameters(m, tol, rej);
+  o.pcg_max_iter = m; o.pcg_tol = tol; o.pcg_rej = rej; o.identity_precond = kind == GR_SOLVER_PCG_IDENTITY;
+  o.early_stop = early_stop; o.scale_system = graph->scales_system(); o.stop_flag = options->stop_flag;
+  graphite::detail::PoseEngineResult r;
+  int rc;
+  {
+    typename Graph<T, S>::DeviceMirrorScope mirror_scope(graph); // written back into the user's vertices on the way out
+    rc = fd->pose_engine_lm(o, r, graph->get_b().raw(), graph->get_jacobian_scales().raw(), graph->get_hessian_dimension());
+    if (rc == 0) { graph->compute_error(); graphite::detail::sync(); } // the residuals of the optimised vertices, as the generic loop leaves them
+  }
+  if (rc < 0) return why(r.declined);
+  if (verbose_why) std::cerr << "[graphite] pose-graph engine: set-up " << 1e3 * r.setup_seconds << " ms (of which " << r.detail << "), loop " << 1e3 * r.loop_seconds << " ms, "
+                             << r.iterations_run << " LM iterations, " << r.pcg_iterations << " PCG iterations" << std::endl;
+  if (rc > 0) { std::cerr << "graphite: pose-graph engine: " << r.declined << "; the graph's vertices are unchanged, using the generic kernels" << std::endl; return false; }
+  ++pose_engine_handovers();
+  ++engine_model_handovers(); // (kernels instantiated on the user's traits: counted there too)
+  const double total = std::chrono::duration<double>(clk::now() - t0).count();
+  engine_last_setup_seconds() = total - r.loop_seconds;
+  engine_last_loop_seconds() = r.loop_seconds;
+  engine_last_iterations() = r.iterations_run;
+  if (options->verbose) { // levenberg_marquardt.hpp:216-221; the set-up is in the first row's total, as the reference's is
+    const int prec = early_stop ? 4 : 12, w0 = early_stop ? 10 : 18, w = early_stop ? 16 : 24;
+    std::cout << std::setprecision(12) << std::setw(18) << "Iteration" << std::setw(24) << "Initial Chi2" << std::setw(24)
+              << "Current Chi2" << std::setw(24) << "Lambda" << std::setw(24) << "Time" << std::setw(24) << "Total Time" << std::endl;
+    std::cout << std::string(138, '-') << std::endl;
+    double run = 0;
+    for (double sec : r.seconds) run += sec;
+    run = total - run;
+    for (int i = 0; i < r.iterations_run; ++i) {
+      run += r.seconds[i];
+      std::cout << std::setprecision(prec) << std::setw(w0) << i << std::setw(w) << (T)r.chi2[i] << std::setw(w) << (T)r.chi2[i + 1] << std::setw(w)
+                << (T)r.lambda[i + 1] << std::setw(w) << r.seconds[i] << std::setw(w) << run << std::endl;
+    }
+  }
+  if (r.stop_bits & 1) std::cout << "Damping factor is infinite, terminating optimization" << std::endl;
+  if (r.stop_bits & 2) std::cout << "Rho is zero, terminating optimization" << std::endl;
+  if (r.stop_bits & 8) std::cout << "Stopping optimization due to stop flag" << std::endl;
+  result = r.ok;
+  return true;
+}
+
 template <typename T, typename S>
 bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, bool early_stop, bool &result) {
   if (getenv("GRAPHITE_GENERIC_ONLY") && atoi(getenv("GRAPHITE_GENERIC_ONLY")) != 0) return false;
@@ -720,6 +783,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   }
   auto &vds = graph->get_vertex_descriptors();
   auto &fds = graph->get_factor_descriptors();
+  if (vds.size() == 1 && fds.size() == 1 && fds[0]->num_slots() == 2) return pose_engine_levenberg_marquardt(graph, options, early_stop, result);
   if (vds.size() != 2 || fds.size() != 1 || fds[0]->num_slots() != 2) return false;
   auto *cd = fds[0]->slot_descriptor(0), *pd = fds[0]->slot_descriptor(1);
   if (cd == pd || cd->dimension() > 9 || pd->dimension() > 3 || fds[0]->error_dimension() > 2 || cd->eliminate) return false;
@@ -1080,6 +1144,8 @@ inline size_t engine_handover_count() { return detail::engine_handovers(); }
 inline size_t engine_cache_hit_count() { return detail::engine_cache_hits(); }
 // ... of which: calls whose per-observation kernels were instantiated on the user's traits (user-traits engine)
 inline size_t engine_model_handover_count() { return detail::engine_model_handovers(); }
+// optimiser calls of this process that ran on the pose-graph engine (engine_pose.hpp: one vertex descriptor, binary factors between its vertices)
+inline size_t pose_engine_handover_count() { return detail::pose_engine_handovers(); }
 // host seconds the last hand-over spent around gr_bal_levenberg_marquardt (checks, export, probe, create or cache look-up, transfers)
 inline double engine_last_setup_seconds() { return detail::engine_last_setup_seconds(); }
 // seconds inside the engine's LM loop of the last hand-over, and the LM iterations it ran

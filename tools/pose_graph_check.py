@@ -33,3 +33,4 @@ for env_extra, tag in (({"GRAPHITE_GENERIC_ONLY": "1"}, "generic kernels"), ({},
     print(f"{tag}: {len(e)} factors, {n} poses; chi2 {ct[0]:.6g} -> {ct[-1]:.6g}; trace rel diff {rel:.2e} over {k} iterations; lambda rel diff "
           f"{np.max(np.abs(tr_gpu[:k, 2] - lt[1:k + 1]) / lt[1:k + 1]):.2e}; max |pose - oracle| {np.abs(got - o.x).max():.2e}; oracle pcg iterations {st['pcg_iterations']}")
     print("   ", [ln for ln in r.stdout.splitlines() if ln.startswith(("ENGINE", "LM_SECONDS"))])
+    if os.environ.get("POSE_TABLE"): print(r.stdout)
