@@ -242,8 +242,7 @@ template <typename T> struct SolveArgs {
   Ctl *ctl;
   int max_iter, identity_precond, use_identity, scale_system;
   double tol, rej;
-  int var;                     // GRAPHITE_POSE_VAR, timing ablations (results are wrong): 1 neighbour records read from the vertex's own, 2 no record loads,
-                               // 4 entry blocks of the first group only; 256 (tests): workgroup 0 never announces itself, every rendezvous times out
+  int var;                     // GRAPHITE_POSE_VAR 256 (tests): workgroup 0 never announces itself, every rendezvous times out
   long long timeout;           // rendezvous time-out in 10 ns ticks (2 s; 20 ms with var 256)
   long long *dbg;              // GRAPHITE_POSE_DEBUG: wall-clock stamps of workgroup 0 at its phase boundaries, [64]; nullptr off
   T *graph_b, *graph_scales, *dx; // Graph::get_b / get_jacobian_scales / the step, column order (what the generic loop leaves behind)
@@ -252,9 +251,13 @@ template <typename T> struct SolveArgs {
 // ---- the solve ------------------------------------------------------------------------------------------------------------------
 // LPV = 1 << lg lanes share a vertex: each gathers every LPV-th entry of it (their partial sums meet through lane shuffles), all of them
 // carry the vertex's own small products redundantly, sub-lane 0 stores.  A wave's SLICE is its 64 >> lg vertices.
+// ONE_PASS (the grid has a wave for every slice — graphs up to 64 k lanes of vertices x LPV — and D <= 4): the vertex's own state
+// (x, its backup, r, z', p, y, scales, b, clamped diagonal, the scaled Hessian block, the block-Jacobi inverse) stays in REGISTERS
+// for the whole launch: the update phase touches no memory but the record it publishes (2.0 -> 0.5 us per PCG iteration on 10 k
+// poses), the operator phase reads only neighbour records and entry blocks.  Otherwise every phase reloads it (grid-stride over slices).
 constexpr int LDS_GROUPS = 16;  // entry groups of a wave's slice whose neighbour ids stay in LDS for the whole launch (4 KB per wave)
-template <typename T, typename VTr, int D>
-__global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, typename VTr::Vertex **verts, typename state_of<VTr>::type *backup) {
+template <typename T, typename VTr, int D, bool ONE_PASS>
+__global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, typename VTr::Vertex *verts /* the HBM mirror, by local vertex id */, typename state_of<VTr>::type *backup) {
   Ctl *const ctl = A.ctl;
   if (ctl->stop) return;
   constexpr int DD = D * D;
@@ -276,7 +279,17 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
   const __amdgpu_buffer_rsrc_t r_ex = rsrc(A.ex, (size_t)NVp * 2 * D * sizeof(T));
   const __amdgpu_buffer_rsrc_t r_sum = rsrc(A.sums, (size_t)2 * MAX_GRID * 2 * 16);
   constexpr int REC = 2 * D * (int)sizeof(T);
-  auto over_lanes = [&](T &v) __attribute__((always_inline)) { for (int m = 1; m < LPV; m <<= 1) v += __shfl_xor(v, m, 64); }; // the LPV partial sums of a vertex, fixed order
+  // the LPV partial sums of a vertex meet in every one of its lanes, fixed order; the shuffles of one step are issued together
+  auto over_lanes = [&](auto &arr) __attribute__((always_inline)) {
+    constexpr int NE = (int)(sizeof(arr) / sizeof(arr[0]));
+    for (int m = 1; m < LPV; m <<= 1) {
+      T o[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) o[e] = __shfl_xor(arr[e], m, 64);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) arr[e] += o[e];
+    }
+  };
   // one slice per wave (the grid covers every vertex in one pass) and a short one: its neighbour ids are read once
   bool nbr_in_lds = false;
   if (nwaves >= nslices && gwave < nslices) {
@@ -286,10 +299,14 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
       for (int j = 0; j < ng; ++j) s_nbr[wv][j * W + lane] = A.enbr[(size_t)(g0 + j) * W + lane];
     }
   }
+  // the vertex's own state: registers for the whole launch (ONE_PASS) or reloaded by every phase
+  T ox[D], oxb[D], orr[D], ot[D], op[D], oy[D], os[D], ob[D], odg[D], oH[DD], oMi[DD];
+  const int last = ONE_PASS ? gwave + 1 : nslices, step = ONE_PASS ? 1 : nwaves; // (ONE_PASS: a wave's loop over slices is its own slice, once)
+#define PE_AT(arr, e, k) A.arr[(size_t)(e) * NVp + (k)]
 
   // ---- assemble (new linearisation), damp, invert, start --------------------------------------------------------------------------
   double acc[2] = {0, 0};
-  for (int ws = gwave; ws < nslices; ws += nwaves) {
+  for (int ws = gwave; ws < last && ws < nslices; ws += step) {
     const int k = ws * VPW + vl, g0 = A.sbase[ws], g1 = A.sbase[ws + 1];
     const bool valid = k < NV, owner = valid && sub == 0;
     const int kk = valid ? k : 0;
@@ -307,40 +324,43 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
 #pragma unroll
         for (int e = 0; e < D; ++e) g[e] += A.gd[((size_t)grp * D + e) * W + lane];
       }
+      over_lanes(H);
+      over_lanes(g);
 #pragma unroll
-      for (int e = 0; e < DD; ++e) over_lanes(H[e]);
-#pragma unroll
-      for (int e = 0; e < D; ++e) over_lanes(g[e]);
-      if (owner) {
-        T s[D];
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          // graph.hpp:253-262: scales 1 / (eps + sqrt(diag)) in double
-          s[c] = A.scale_system ? (T)(1.0 / (std::numeric_limits<double>::epsilon() + sqrt((double)H[c * D + c]))) : T(1);
-          A.s[(size_t)c * NVp + k] = s[c];
-          A.graph_scales[(size_t)k * D + c] = s[c];
-          const T bc = -(s[c] * g[c]);
-          A.b[(size_t)c * NVp + k] = bc;
-          A.graph_b[(size_t)k * D + c] = bc;
-        }
-#pragma unroll
-        for (int r = 0; r < D; ++r)
-#pragma unroll
-          for (int c = 0; c < D; ++c) A.Hs[(size_t)(r * D + c) * NVp + k] = s[r] * H[r * D + c] * s[c];
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          const double d = (double)(s[c] * H[c * D + c] * s[c]);
-          A.dg[(size_t)c * NVp + k] = (T)(d < 1.0e-6 ? 1.0e-6 : (d > 1.0e32 ? 1.0e32 : d)); // pcg.hpp:93-103
-        }
+      for (int c = 0; c < D; ++c) {
+        // graph.hpp:253-262: scales 1 / (eps + sqrt(diag)) in double
+        os[c] = A.scale_system ? (T)(1.0 / (std::numeric_limits<double>::epsilon() + sqrt((double)H[c * D + c]))) : T(1);
+        ob[c] = -(os[c] * g[c]);
       }
+#pragma unroll
+      for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) oH[r * D + c] = os[r] * H[r * D + c] * os[c];
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        const double d = (double)oH[c * D + c];
+        odg[c] = (T)(d < 1.0e-6 ? 1.0e-6 : (d > 1.0e32 ? 1.0e32 : d)); // pcg.hpp:93-103
+      }
+      if (owner) { // (kept in memory too: a rejected step's next launch and the caller's Graph::get_b / get_jacobian_scales read them)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          PE_AT(s, c, k) = os[c]; PE_AT(b, c, k) = ob[c]; PE_AT(dg, c, k) = odg[c];
+          A.graph_scales[(size_t)k * D + c] = os[c]; A.graph_b[(size_t)k * D + c] = ob[c];
+        }
+#pragma unroll
+        for (int e = 0; e < DD; ++e) PE_AT(Hs, e, k) = oH[e];
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < D; ++c) { os[c] = PE_AT(s, c, kk); ob[c] = PE_AT(b, c, kk); odg[c] = PE_AT(dg, c, kk); }
+#pragma unroll
+      for (int e = 0; e < DD; ++e) oH[e] = PE_AT(Hs, e, kk);
     }
-    if (!owner) continue;
     // block-Jacobi: diagonal <- d + mu clamp(d, 1e-6, 1e32) (or d + mu), ops/hessian.hpp:80-112; inverse; identity.hpp: z = r
-    T Mi[DD];
     if (!A.identity_precond) {
       double M[DD], R[DD];
 #pragma unroll
-      for (int e = 0; e < DD; ++e) M[e] = (double)A.Hs[(size_t)e * NVp + kk];
+      for (int e = 0; e < DD; ++e) M[e] = (double)oH[e];
 #pragma unroll
       for (int c = 0; c < D; ++c) {
         const double d = M[c * D + c], cl = d < 1.0e-6 ? 1.0e-6 : (d > 1.0e32 ? 1.0e32 : d);
@@ -348,29 +368,34 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
       }
       invert<D>(M, R);
 #pragma unroll
-      for (int e = 0; e < DD; ++e) { Mi[e] = (T)R[e]; A.Minv[(size_t)e * NVp + k] = Mi[e]; }
+      for (int e = 0; e < DD; ++e) oMi[e] = (T)R[e];
     }
-    T r[D], t[D], rec[2 * D];
-#pragma unroll
-    for (int c = 0; c < D; ++c) r[c] = A.b[(size_t)c * NVp + k];
+    T rec[2 * D];
 #pragma unroll
     for (int q = 0; q < D; ++q) {
-      T z = r[q];
+      orr[q] = ob[q];
+      T z = ob[q];
       if (!A.identity_precond) {
         z = T(0);
 #pragma unroll
-        for (int c = 0; c < D; ++c) z += Mi[q * D + c] * r[c];
+        for (int c = 0; c < D; ++c) z += oMi[q * D + c] * ob[c];
       }
-      t[q] = z;
+      ot[q] = z; ox[q] = T(0); oxb[q] = T(0); op[q] = T(0);
+      rec[q] = os[q] * z; rec[D + q] = T(0);
     }
+    if (owner) {
 #pragma unroll
-    for (int c = 0; c < D; ++c) {
-      A.r[(size_t)c * NVp + k] = r[c]; A.t[(size_t)c * NVp + k] = t[c]; A.x[(size_t)c * NVp + k] = T(0); A.xb[(size_t)c * NVp + k] = T(0);
-      A.p[(size_t)c * NVp + k] = T(0);
-      rec[c] = A.s[(size_t)c * NVp + k] * t[c]; rec[D + c] = T(0);
-      acc[0] += (double)r[c] * (double)r[c]; acc[1] += (double)r[c] * (double)t[c];
+      for (int c = 0; c < D; ++c) { acc[0] += (double)orr[c] * (double)orr[c]; acc[1] += (double)orr[c] * (double)ot[c]; }
+      st_rec<T, 2 * D>(r_ex, k * REC, rec);
+      if (!ONE_PASS) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) { PE_AT(r, c, k) = orr[c]; PE_AT(t, c, k) = ot[c]; PE_AT(x, c, k) = T(0); PE_AT(xb, c, k) = T(0); PE_AT(p, c, k) = T(0); }
+        if (!A.identity_precond) {
+#pragma unroll
+          for (int e = 0; e < DD; ++e) PE_AT(Minv, e, k) = oMi[e];
+        }
+      }
     }
-    st_rec<T, 2 * D>(r_ex, k * REC, rec);
   }
   stamp();
   if (!grid_sums<2, true>(acc, r_sum, launch_tag, epoch, A.fail, s_red, A.timeout, (A.var & 256) && blockIdx.x == 0)) { if (threadIdx.x == 0) ctl->stop = 16; return; }
@@ -382,61 +407,70 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
     if (rz == 0) break; // pcg.hpp:133
     // ---- operator: p = sigma z' + beta p;  y = (S J^T rho' P J S + mu D) p;  p . y ------------------------------------------------
     double den[1] = {0};
-    for (int ws = gwave; ws < nslices; ws += nwaves) {
+    for (int ws = gwave; ws < last && ws < nslices; ws += step) {
       const int k = ws * VPW + vl, g0 = A.sbase[ws], ng = A.sbase[ws + 1] - g0;
       const bool valid = k < NV, owner = valid && sub == 0;
       const int kk = valid ? k : 0;
-      // everything the phase reads is requested up front (no branch between the loads): the vertex's own state and blocks, then per
-      // chunk the neighbours' records (the only sc1 round trip) and the entry blocks; padding entries read the vertex's own record
-      // against a zero block
-      T p[D], a[D], sv[D], dgv[D], Hv[DD];
+      // everything the phase reads is requested up front (no branch between the loads): the vertex's own state and blocks (not
+      // ONE_PASS), then per chunk the neighbours' records (the only sc1 round trip) and the entry blocks; padding entries read the
+      // vertex's own record against a zero block
+      T a[D];
+      if (!ONE_PASS) {
 #pragma unroll
-      for (int c = 0; c < D; ++c) {
-        p[c] = (T)sigma * A.t[(size_t)c * NVp + kk] + (T)beta * A.p[(size_t)c * NVp + kk];
-        sv[c] = A.s[(size_t)c * NVp + kk];
-        dgv[c] = A.use_identity ? T(1) : A.dg[(size_t)c * NVp + kk];
-        a[c] = T(0);
+        for (int c = 0; c < D; ++c) { ot[c] = PE_AT(t, c, kk); op[c] = PE_AT(p, c, kk); os[c] = PE_AT(s, c, kk); odg[c] = PE_AT(dg, c, kk); }
+#pragma unroll
+        for (int e = 0; e < DD; ++e) oH[e] = PE_AT(Hs, e, kk);
       }
 #pragma unroll
-      for (int e = 0; e < DD; ++e) Hv[e] = A.Hs[(size_t)e * NVp + kk];
-      for (int j0 = 0; j0 < ng; j0 += CH) {
-        int nb[CH];
-        T rec[CH][2 * D], Bv[CH][DD];
+      for (int c = 0; c < D; ++c) { op[c] = (T)sigma * ot[c] + (T)beta * op[c]; a[c] = T(0); }
+      // (straight-line per chunk — no branch between the loads of a chunk, or the compiler waits for each group's loads in turn)
+      auto gather = [&](auto in_lds) __attribute__((always_inline)) {
+        for (int j0 = 0; j0 < ng; j0 += CH) {
+          int nb[CH];
+          T rec[CH][2 * D], Bv[CH][DD];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int j = j0 + u < ng ? j0 + u : ng - 1; // (a short last chunk reads its last group again, weight zero below)
-          const int n = nbr_in_lds ? s_nbr[wv][j * W + lane] : A.enbr[(size_t)(g0 + j) * W + lane];
-          nb[u] = j0 + u < ng ? n : -2;
-          if (A.var & 2) { for (int c = 0; c < 2 * D; ++c) rec[u][c] = T(1); }
-          else ld_rec<T, 2 * D>(r_ex, ((n >= 0 && !(A.var & 1)) ? n : kk) * REC, rec[u]);
+          for (int u = 0; u < CH; ++u) {
+            const int j = j0 + u < ng ? j0 + u : ng - 1; // (a short last chunk reads its last group again, weight zero below)
+            int n;
+            if constexpr (decltype(in_lds)::value) n = s_nbr[wv][j * W + lane];
+            else n = A.enbr[(size_t)(g0 + j) * W + lane];
+            nb[u] = j0 + u < ng ? n : -2;
+          }
 #pragma unroll
-          for (int e = 0; e < DD; ++e) Bv[u][e] = A.B[((size_t)(g0 + ((A.var & 4) ? 0 : j)) * DD + e) * W + lane];
+          for (int u = 0; u < CH; ++u) ld_rec<T, 2 * D>(r_ex, (nb[u] >= 0 ? nb[u] : kk) * REC, rec[u]);
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int j = j0 + u < ng ? j0 + u : ng - 1;
+#pragma unroll
+            for (int e = 0; e < DD; ++e) Bv[u][e] = A.B[((size_t)(g0 + j) * DD + e) * W + lane];
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const T on = nb[u] >= 0 ? T(1) : T(0);
+            T pn[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) pn[c] = on * ((T)sigma * rec[u][c] + (T)beta * rec[u][D + c]);
+#pragma unroll
+            for (int q = 0; q < D; ++q)
+#pragma unroll
+              for (int c = 0; c < D; ++c) a[q] += Bv[u][q * D + c] * pn[c];
+          }
         }
+      };
+      if (nbr_in_lds) gather(std::true_type{}); else gather(std::false_type{});
+      over_lanes(a);
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const T on = nb[u] >= 0 ? T(1) : T(0);
-          T pn[D];
+      for (int q = 0; q < D; ++q) {
+        T yq = os[q] * a[q];
 #pragma unroll
-          for (int c = 0; c < D; ++c) pn[c] = on * ((T)sigma * rec[u][c] + (T)beta * rec[u][D + c]);
-#pragma unroll
-          for (int q = 0; q < D; ++q)
-#pragma unroll
-            for (int c = 0; c < D; ++c) a[q] += Bv[u][q * D + c] * pn[c];
-        }
+        for (int c = 0; c < D; ++c) yq += oH[q * D + c] * op[c];
+        yq += (T)mu * (A.use_identity ? T(1) : odg[q]) * op[q]; // ops/vector.hpp:25-41
+        oy[q] = yq;
+        if (owner) den[0] += (double)op[q] * (double)yq;
       }
+      if (!ONE_PASS && owner) {
 #pragma unroll
-      for (int q = 0; q < D; ++q) over_lanes(a[q]);
-      if (owner) {
-#pragma unroll
-        for (int q = 0; q < D; ++q) {
-          T yq = sv[q] * a[q];
-#pragma unroll
-          for (int c = 0; c < D; ++c) yq += Hv[q * D + c] * p[c];
-          yq += (T)mu * dgv[q] * p[q]; // ops/vector.hpp:25-41
-          A.y[(size_t)q * NVp + k] = yq;
-          A.p[(size_t)q * NVp + k] = p[q];
-          den[0] += (double)p[q] * (double)yq;
-        }
+        for (int q = 0; q < D; ++q) { PE_AT(y, q, k) = oy[q]; PE_AT(p, q, k) = op[q]; }
       }
     }
     stamp();
@@ -446,33 +480,45 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
     const T alpha = (T)(rz / den[0]);
     // ---- update: x += alpha p (backup first), r -= alpha y, z' = Minv r, the two dots, publish [s.z' | s.p] -----------------------
     double dots[2] = {0, 0};
-    for (int ws = gwave; ws < nslices; ws += nwaves) {
+    for (int ws = gwave; ws < last && ws < nslices; ws += step) {
       const int k = ws * VPW + vl;
-      if (!(k < NV && sub == 0)) continue;
-      T r[D], p[D], rec[2 * D];
+      const bool valid = k < NV, owner = valid && sub == 0;
+      if (!ONE_PASS) {
+        if (!owner) continue;
+#pragma unroll
+        for (int c = 0; c < D; ++c) { ox[c] = PE_AT(x, c, k); op[c] = PE_AT(p, c, k); oy[c] = PE_AT(y, c, k); orr[c] = PE_AT(r, c, k); os[c] = PE_AT(s, c, k); }
+        if (!A.identity_precond) {
+#pragma unroll
+          for (int e = 0; e < DD; ++e) oMi[e] = PE_AT(Minv, e, k);
+        }
+      }
+      T rec[2 * D];
 #pragma unroll
       for (int c = 0; c < D; ++c) {
-        const T xo = A.x[(size_t)c * NVp + k];
-        p[c] = A.p[(size_t)c * NVp + k];
-        A.xb[(size_t)c * NVp + k] = xo;
-        A.x[(size_t)c * NVp + k] = alpha * p[c] + xo;
-        r[c] = -alpha * A.y[(size_t)c * NVp + k] + A.r[(size_t)c * NVp + k];
-        A.r[(size_t)c * NVp + k] = r[c];
+        oxb[c] = ox[c];
+        ox[c] = alpha * op[c] + ox[c];
+        orr[c] = -alpha * oy[c] + orr[c];
       }
 #pragma unroll
       for (int q = 0; q < D; ++q) {
-        T z = r[q];
+        T z = orr[q];
         if (!A.identity_precond) {
           z = T(0);
 #pragma unroll
-          for (int c = 0; c < D; ++c) z += A.Minv[(size_t)(q * D + c) * NVp + k] * r[c];
+          for (int c = 0; c < D; ++c) z += oMi[q * D + c] * orr[c];
         }
-        A.t[(size_t)q * NVp + k] = z;
-        const T sc = A.s[(size_t)q * NVp + k];
-        rec[q] = sc * z; rec[D + q] = sc * p[q];
-        dots[0] += (double)r[q] * (double)r[q]; dots[1] += (double)r[q] * (double)z;
+        ot[q] = z;
+        rec[q] = os[q] * z; rec[D + q] = os[q] * op[q];
       }
-      st_rec<T, 2 * D>(r_ex, k * REC, rec);
+      if (owner) {
+#pragma unroll
+        for (int q = 0; q < D; ++q) { dots[0] += (double)orr[q] * (double)orr[q]; dots[1] += (double)orr[q] * (double)ot[q]; }
+        st_rec<T, 2 * D>(r_ex, k * REC, rec);
+        if (!ONE_PASS) {
+#pragma unroll
+          for (int c = 0; c < D; ++c) { PE_AT(xb, c, k) = oxb[c]; PE_AT(x, c, k) = ox[c]; PE_AT(r, c, k) = orr[c]; PE_AT(t, c, k) = ot[c]; }
+        }
+      }
     }
     stamp();
     if (!grid_sums<2, true>(dots, r_sum, launch_tag, epoch, A.fail, s_red, A.timeout)) { if (threadIdx.x == 0) ctl->stop = 16; return; }
@@ -488,27 +534,32 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
   }
   // ---- trial step: Graph::backup_parameters / apply_update (graph.hpp:292-309), rho-denominator partials (levenberg_marquardt.hpp:20-47)
   double rden = 0;
-  for (int ws = gwave; ws < nslices; ws += nwaves) {
+  for (int ws = gwave; ws < last && ws < nslices; ws += step) {
     const int k = ws * VPW + vl;
     if (!(k < NV && sub == 0)) continue;
+    if (!ONE_PASS) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) { ox[c] = PE_AT(x, c, k); oxb[c] = PE_AT(xb, c, k); ob[c] = PE_AT(b, c, k); os[c] = PE_AT(s, c, k); }
+    }
     T d[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-      const T xc = reject ? A.xb[(size_t)c * NVp + k] : A.x[(size_t)c * NVp + k];
+      const T xc = reject ? oxb[c] : ox[c];
       A.dx[(size_t)k * D + c] = xc;
-      rden += (double)xc * ((double)(T)mu * (double)xc + (double)A.b[(size_t)c * NVp + k]);
-      d[c] = xc * A.s[(size_t)c * NVp + k]; // ops/update.hpp:26
+      rden += (double)xc * ((double)(T)mu * (double)xc + (double)ob[c]);
+      d[c] = xc * os[c]; // ops/update.hpp:26
     }
     const int l = A.k2l[k];
     if (fresh) {
-      if constexpr (state_of<VTr>::custom) backup[l] = VTr::get_state(*verts[l]);
-      else backup[l] = *verts[l];
+      if constexpr (state_of<VTr>::custom) backup[l] = VTr::get_state(verts[l]);
+      else backup[l] = verts[l];
     } else {
-      if constexpr (state_of<VTr>::custom) VTr::set_state(*verts[l], backup[l]);
-      else *verts[l] = backup[l];
+      if constexpr (state_of<VTr>::custom) VTr::set_state(verts[l], backup[l]);
+      else verts[l] = backup[l];
     }
-    VTr::update(*verts[l], d);
+    VTr::update(verts[l], d);
   }
+#undef PE_AT
   rden = wave_sum(rden);
   if (lane == 0) A.part_rho[gwave] = rden;
   if (first_thread) { ctl->last_pcg_its = its; ctl->pcg_its += its; }
@@ -516,13 +567,13 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
   if (A.dbg && first_thread) A.dbg[63] = n_stamp;
 }
 
-template <typename VTr> __global__ void k_pe_finish(const Ctl *ctl, const int *k2l, int NV, typename VTr::Vertex **verts, const typename state_of<VTr>::type *backup) {
+template <typename VTr> __global__ void k_pe_finish(const Ctl *ctl, const int *k2l, int NV, typename VTr::Vertex *verts, const typename state_of<VTr>::type *backup) {
   if (ctl->fresh) return; // the last trial was accepted (or there was none): the vertices are where they belong
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= NV) return;
   const int l = k2l[k];
-  if constexpr (state_of<VTr>::custom) VTr::set_state(*verts[l], backup[l]);
-  else *verts[l] = backup[l];
+  if constexpr (state_of<VTr>::custom) VTr::set_state(verts[l], backup[l]);
+  else verts[l] = backup[l];
 }
 
 template <typename T> struct FactorArgs {
@@ -535,13 +586,15 @@ template <typename T> struct FactorArgs {
   double *tr_chi2, *tr_mu;  // [iterations + 1]
   long long *tr_clock;      // [iterations + 1]
   const int *pos;           // [na][2] entry slot of (factor, side): group * 64 + lane, -1: that vertex has no column
+  const int *lij;           // [na][2] descriptor-local vertex ids of the active factor (the vertex objects are read from the mirror
+                            // directly: active list -> id table -> pointer table -> vertex is two dependent loads longer)
   T *Hd, *gd, *B;
   int early;
 };
 
 // ---- error + chi2 at the trial point, LM decision by the last workgroup (mode 0: the starting point, no decision) ---------------
 template <typename F, size_t... Is>
-__global__ void __launch_bounds__(TPB) k_pe_error(FactorView<F> fv, const FactorArgs<typename F::Scalar> A, int mode, std::index_sequence<Is...> seq) {
+__global__ void __launch_bounds__(TPB) k_pe_error(FactorView<F> fv, const FactorArgs<typename F::Scalar> A, slot_vertex<F, 0> *mirror, int mode, std::index_sequence<Is...> seq) {
   using T = typename F::Scalar;
   constexpr size_t E = F::E;
   __shared__ double red[TPB];
@@ -553,7 +606,7 @@ __global__ void __launch_bounds__(TPB) k_pe_error(FactorView<F> fv, const Factor
   double c2 = 0;
   if (a < A.na) {
     const size_t f = fv.active_ids[a];
-    auto v = gather_vertices<F, T>(fv, f, seq);
+    auto v = std::make_tuple((mirror + A.lij[2 * a + Is])...);
     std::tuple<T[slot_dim<F, Is>()]...> p;
     ((slot_traits<F, Is>::parameters(*std::get<Is>(v), (T *)std::get<Is>(p))), ...);
     T err[E];
@@ -640,11 +693,10 @@ __global__ void __launch_bounds__(TPB) k_pe_error(FactorView<F> fv, const Factor
 }
 
 // ---- Jacobians at the accepted point and the factor's contributions to its two vertices -----------------------------------------
-template <typename F, size_t I, size_t... Is>
-__device__ inline void pe_jacobian(const FactorView<F> &fv, size_t f, typename F::Scalar *J, std::index_sequence<Is...> seq) {
+template <typename F, size_t I, typename VT, size_t... Is>
+__device__ inline void pe_jacobian(const FactorView<F> &fv, size_t f, const VT &v, typename F::Scalar *J, std::index_sequence<Is...> seq) {
   using T = typename F::Scalar;
   constexpr size_t d = slot_dim<F, I>(), E = F::E;
-  auto v = gather_vertices<F, T>(fv, f, seq);
   if constexpr (std::is_same<typename F::Traits::Differentiation, DifferentiationMode::Manual>::value) {
     for (size_t k = 0; k < E * d; ++k) J[k] = T(0); // ops/linearize.hpp:127
     call_jacobian_t<F, I, T>(v, fv.obs[f], fv.data[f], J, seq);
@@ -661,7 +713,7 @@ __device__ inline void pe_jacobian(const FactorView<F> &fv, size_t f, typename F
   }
 }
 template <typename F, size_t... Is>
-__global__ void __launch_bounds__(TPB) k_pe_linearize(FactorView<F> fv, const FactorArgs<typename F::Scalar> A, std::index_sequence<Is...> seq) {
+__global__ void __launch_bounds__(TPB) k_pe_linearize(FactorView<F> fv, const FactorArgs<typename F::Scalar> A, slot_vertex<F, 0> *mirror, std::index_sequence<Is...> seq) {
   using T = typename F::Scalar;
   constexpr int E = (int)F::E, D = (int)slot_dim<F, 0>(), DD = D * D;
   const Ctl *const ctl = A.ctl;
@@ -673,8 +725,9 @@ __global__ void __launch_bounds__(TPB) k_pe_linearize(FactorView<F> fv, const Fa
   const size_t f = fv.active_ids[a];
   const int buf = ctl->cur;
   T J0[E * D], J1[E * D]; // column-major E x D (ops/error.hpp:146-149)
-  if (p0 >= 0) pe_jacobian<F, 0>(fv, f, J0, seq); else for (int k = 0; k < E * D; ++k) J0[k] = T(0);
-  if (p1 >= 0) pe_jacobian<F, 1>(fv, f, J1, seq); else for (int k = 0; k < E * D; ++k) J1[k] = T(0);
+  const auto v = std::make_tuple((mirror + A.lij[2 * a + Is])...);
+  if (p0 >= 0) pe_jacobian<F, 0>(fv, f, v, J0, seq); else for (int k = 0; k < E * D; ++k) J0[k] = T(0);
+  if (p1 >= 0) pe_jacobian<F, 1>(fv, f, v, J1, seq); else for (int k = 0; k < E * D; ++k) J1[k] = T(0);
   const T w = A.w[(size_t)buf * A.na + a];
   T Wm[E * E], Wr[E], A0[E * D], A1[E * D];
 #pragma unroll
@@ -717,7 +770,7 @@ __global__ void __launch_bounds__(TPB) k_pe_linearize(FactorView<F> fv, const Fa
 
 // buffers of one descriptor's engine, kept between optimiser calls (capacity is reused)
 template <typename T> struct Buffers {
-  hbm_vector<int> sbase, enbr, k2l, pos;
+  hbm_vector<int> sbase, enbr, k2l, pos, lij;
   hbm_vector<T> Hd, gd, B, vert, vec, ex, res, w, dx;
   hbm_vector<double> sums, part_rho, part_chi2, tr;
   hbm_vector<long long> clock, dbg;
@@ -798,7 +851,7 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     }
     const size_t ngroups = (size_t)sbase[nslices];
     if (ngroups * pe::W > 0x3fffffffu) { res.declined = "entry lists above 2^30 slots (a vertex of very high degree)"; return -1; }
-    std::vector<int> enbr(ngroups * pe::W, -2), pos(2 * na, -1), fill(NV, 0);
+    std::vector<int> enbr(ngroups * pe::W, -2), pos(2 * na, -1), fill(NV, 0), lij(2 * na);
     auto slot_of = [&](int k) { // entry e of vertex k: sub-lane e % LPV, group e / LPV of its slice
       const int e = fill[k]++, w = k / VPW;
       return (sbase[w] + e / LPV) * pe::W + (k % VPW) * LPV + e % LPV;
@@ -806,13 +859,14 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     for (size_t a = 0; a < na; ++a) { // ascending factor order per (vertex, sub-lane): the order of the sums
       const size_t f = active_indices[a];
       const int ki = l2k[device_ids[f * 2]], kj = l2k[device_ids[f * 2 + 1]];
+      lij[2 * a] = (int)device_ids[f * 2]; lij[2 * a + 1] = (int)device_ids[f * 2 + 1];
       if (ki >= 0) { const int slot = slot_of(ki); pos[2 * a] = slot; enbr[slot] = kj; }
       if (kj >= 0) { const int slot = slot_of(kj); pos[2 * a + 1] = slot; enbr[slot] = ki; }
     }
     lap("lists");
     if (!pose_engine_state) pose_engine_state = std::make_shared<pe::Buffers<T>>();
     auto &bf = *std::static_pointer_cast<pe::Buffers<T>>(pose_engine_state);
-    bf.sbase.assign(sbase.data(), sbase.size()); bf.enbr.assign(enbr.data(), enbr.size()); bf.k2l.assign(k2l.data(), k2l.size()); bf.pos.assign(pos.data(), pos.size());
+    bf.sbase.assign(sbase.data(), sbase.size()); bf.enbr.assign(enbr.data(), enbr.size()); bf.k2l.assign(k2l.data(), k2l.size()); bf.pos.assign(pos.data(), pos.size()); bf.lij.assign(lij.data(), lij.size());
     bf.Hd.resize_uninit(ngroups * DD * pe::W); bf.gd.resize_uninit(ngroups * D * pe::W); bf.B.resize_uninit(ngroups * DD * pe::W);
     const size_t per_vertex = (size_t)(2 * DD + 3 * D), per_vec = (size_t)6 * D;
     bf.vert.resize_uninit(per_vertex * NVp); bf.vec.resize_uninit(per_vec * NVp); bf.ex.resize_uninit((size_t)NVp * 2 * D);
@@ -829,13 +883,22 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     int dev = 0, cus = 0, per_cu = 0;
     GRAPHITE_HIP(hipGetDevice(&dev));
     GRAPHITE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    auto *solve_kernel = &pe::k_pe_solve<T, VTr, D>;
-    GRAPHITE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, solve_kernel, pe::W * pe::WPB, 0));
-    const int G = std::max(1, std::min(std::min((nslices + pe::WPB - 1) / pe::WPB, pe::MAX_GRID), per_cu * cus));
+    // (the one-pass form keeps a vertex's state in registers: only when the grid has a wave for every slice, and blocks of at most 4 x 4)
+    constexpr bool CAN_ONE_PASS = DD <= 16;
+    auto *solve_multi = &pe::k_pe_solve<T, VTr, D, false>;
+    auto *solve_one = &pe::k_pe_solve<T, VTr, D, CAN_ONE_PASS>;
+    int per_cu_one = 0;
+    GRAPHITE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, solve_multi, pe::W * pe::WPB, 0));
+    GRAPHITE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_one, solve_one, pe::W * pe::WPB, 0));
+    const int G_all = (nslices + pe::WPB - 1) / pe::WPB;
+    const bool one_pass = CAN_ONE_PASS && G_all <= std::min(pe::MAX_GRID, per_cu_one * cus) && !(getenv("GRAPHITE_POSE_ONE_PASS") && atoi(getenv("GRAPHITE_POSE_ONE_PASS")) == 0);
+    auto *solve_kernel = one_pass ? solve_one : solve_multi;
+    if (one_pass) per_cu = per_cu_one;
+    const int G = std::max(1, std::min(std::min(G_all, pe::MAX_GRID), per_cu * cus));
     if (per_cu < 1) { res.declined = "the solve kernel does not fit a compute unit"; return -1; }
 
     lap("occupancy query");
-    res.detail += std::to_string(NV) + " vertices x " + std::to_string(LPV) + " lanes, " + std::to_string(ngroups) + " entry groups, grid " + std::to_string(G) + " x " + std::to_string(pe::W * pe::WPB);
+    res.detail += std::to_string(NV) + " vertices x " + std::to_string(LPV) + " lanes, " + std::to_string(ngroups) + " entry groups, grid " + std::to_string(G) + " x " + std::to_string(pe::W * pe::WPB) + (one_pass ? ", state in registers" : ", state in memory");
     pe::Ctl h{};
     h.mu = o.initial_damping; h.nu = 2; h.fresh = 1;
     GRAPHITE_HIP(hipMemcpy(bf.ctl.raw(), &h, sizeof(h), hipMemcpyHostToDevice));
@@ -864,17 +927,17 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     sa.graph_b = graph_b; sa.graph_scales = graph_scales; sa.dx = bf.dx.raw();
     pe::FactorArgs<T> fa{};
     fa.ctl = bf.ctl.raw(); fa.res = bf.res.raw(); fa.w = bf.w.raw(); fa.part = bf.part_chi2.raw(); fa.part_rho = bf.part_rho.raw(); fa.n_rho = G * pe::WPB;
-    fa.na = na; fa.tr_chi2 = bf.tr.raw(); fa.tr_mu = bf.tr.raw() + ntr; fa.tr_clock = bf.clock.raw(); fa.pos = bf.pos.raw();
+    fa.na = na; fa.tr_chi2 = bf.tr.raw(); fa.tr_mu = bf.tr.raw() + ntr; fa.tr_clock = bf.clock.raw(); fa.pos = bf.pos.raw(); fa.lij = bf.lij.raw();
     fa.Hd = bf.Hd.raw(); fa.gd = bf.gd.raw(); fa.B = bf.B.raw(); fa.early = o.early_stop ? 1 : 0;
 
     auto fv = view();
-    auto **verts = vd->vertices();
     auto *backup = vd->backup_ptr();
+    auto *vmirror = vd->mirror.raw();
     constexpr auto seq = std::make_index_sequence<N>{};
     res.setup_seconds = std::chrono::duration<double>(clk::now() - t_begin).count();
     const auto t_loop = clk::now();
-    pe::k_pe_error<FactorDescriptor><<<nbe, TPB>>>(fv, fa, 0, seq);
-    pe::k_pe_linearize<FactorDescriptor><<<nbe, TPB>>>(fv, fa, seq);
+    pe::k_pe_error<FactorDescriptor><<<nbe, TPB>>>(fv, fa, vmirror, 0, seq);
+    pe::k_pe_linearize<FactorDescriptor><<<nbe, TPB>>>(fv, fa, vmirror, seq);
     size_t enq = 0;
     // The solve needs its whole grid resident (rendezvous inside the launch).  The grid is sized to fit (occupancy query above), so a
     // PLAIN launch into an idle device is resident; hipLaunchCooperativeKernel guarantees it but costs 22 us more per launch and 11 ms
@@ -889,11 +952,12 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     GRAPHITE_HIP(hipMemcpyAsync(bf.start.raw(), vd->mirror.raw(), vbytes, hipMemcpyDeviceToDevice, nullptr));
     for (size_t i = 0; i < o.iterations; ++i) {
       if (coop) {
-        void *args[] = {(void *)&sa, (void *)&verts, (void *)&backup};
+        void *args[] = {(void *)&sa, (void *)&vmirror, (void *)&backup};
         GRAPHITE_HIP(hipLaunchCooperativeKernel((const void *)solve_kernel, dim3(G), dim3(pe::W * pe::WPB), args, 0, nullptr));
-      } else pe::k_pe_solve<T, VTr, D><<<G, pe::W * pe::WPB>>>(sa, verts, backup);
-      pe::k_pe_error<FactorDescriptor><<<nbe, TPB>>>(fv, fa, 1, seq);
-      pe::k_pe_linearize<FactorDescriptor><<<nbe, TPB>>>(fv, fa, seq);
+      } else if (one_pass) pe::k_pe_solve<T, VTr, D, CAN_ONE_PASS><<<G, pe::W * pe::WPB>>>(sa, vmirror, backup);
+      else pe::k_pe_solve<T, VTr, D, false><<<G, pe::W * pe::WPB>>>(sa, vmirror, backup);
+      pe::k_pe_error<FactorDescriptor><<<nbe, TPB>>>(fv, fa, vmirror, 1, seq);
+      pe::k_pe_linearize<FactorDescriptor><<<nbe, TPB>>>(fv, fa, vmirror, seq);
       ++enq;
       if (o.stop_flag) { // the caller may ask between iterations (levenberg_marquardt.hpp:232): keep the loop in step with the host
         sync();
@@ -902,7 +966,7 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
         if (h.stop) break;
       }
     }
-    pe::k_pe_finish<VTr><<<blocks((size_t)NV), TPB>>>(bf.ctl.raw(), bf.k2l.raw(), NV, verts, backup);
+    pe::k_pe_finish<VTr><<<blocks((size_t)NV), TPB>>>(bf.ctl.raw(), bf.k2l.raw(), NV, vmirror, backup);
     sync();
     res.loop_seconds = std::chrono::duration<double>(clk::now() - t_loop).count();
     GRAPHITE_HIP(hipMemcpy(&h, bf.ctl.raw(), sizeof(h), hipMemcpyDeviceToHost));
