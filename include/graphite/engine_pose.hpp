@@ -777,6 +777,14 @@ template <typename T> struct Buffers {
   hbm_vector<Ctl> ctl;
   hbm_vector<int> fail;
   hbm_vector<unsigned char> start; // the vertices as the call found them (restored when a launch fails)
+  // structure cache: the lists below depend on the descriptors' structure (epochs: add / remove / set_active / set_fixed ...), on the
+  // optimisation level (through the active list) and on the vertex states and Hessian columns of this initialisation; a call that
+  // finds all of them unchanged (the SLAM loop that optimises the same graph again) re-uses lists, uploads and the symmetry check
+  bool have_structure = false;
+  size_t key_epoch_f = 0, key_epoch_v = 0, key_na = 0, key_nvl = 0, key_dim = 0;
+  uint64_t key_digest = 0;
+  int c_NV = 0, c_NVp = 0, c_lg = 0, c_nslices = 0;
+  size_t c_ngroups = 0;
   bool prefer_cooperative = false;  // a plain launch timed out at a rendezvous once: later calls ask the runtime for co-residency
 };
 } // namespace pe
@@ -806,6 +814,19 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     const size_t na = active_count(), nvl = vd->count();
     if (!na || !hessian_dim || hessian_dim % D) { res.declined = "nothing to optimise"; return -1; }
     if (na > 0x3fffffffu || nvl > 0x3fffffffu) { res.declined = "more than 2^30 factors or vertices"; return -1; }
+    if (!pose_engine_state) pose_engine_state = std::make_shared<pe::Buffers<T>>();
+    auto &bf = *std::static_pointer_cast<pe::Buffers<T>>(pose_engine_state);
+    const uint8_t *state = vd->get_active_state();
+    const size_t *hid = vd->get_hessian_ids();
+    uint64_t dg = digest(0x706F7365ull, active_indices.raw(), na * sizeof(size_t));
+    dg = digest(dg, state, nvl);
+    dg = digest(dg, hid, nvl * sizeof(size_t));
+    const bool cached = bf.have_structure && bf.key_epoch_f == this->structure_epoch && bf.key_epoch_v == vd->structure_epoch && bf.key_na == na && bf.key_nvl == nvl &&
+                        bf.key_dim == hessian_dim && bf.key_digest == dg && !(getenv("GRAPHITE_POSE_CACHE") && atoi(getenv("GRAPHITE_POSE_CACHE")) == 0);
+    int NV = bf.c_NV, NVp = bf.c_NVp, lg = bf.c_lg, nslices = bf.c_nslices;
+    size_t ngroups = bf.c_ngroups;
+    if (!cached) {
+    bf.have_structure = false;
     // symmetric precision matrices: the blocks of the two sides are formed from one W = rho' P
     for (size_t a = 0; a < na; ++a) {
       const S *P = precision_matrices.raw() + active_indices[a] * E * E;
@@ -815,9 +836,7 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     }
     lap("checks");
     // ---- structure: engine vertices = the descriptor's vertices that have a column, in column order; wave-sliced entry lists ----
-    const uint8_t *state = vd->get_active_state();
-    const size_t *hid = vd->get_hessian_ids();
-    const int NV = (int)(hessian_dim / D);
+    NV = (int)(hessian_dim / D);
     std::vector<int> l2k(nvl, -1), k2l(NV, -1);
     for (size_t l = 0; l < nvl; ++l)
       if (is_vertex_active(state, l)) {
@@ -836,20 +855,21 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     }
     // lanes per vertex: as many as keep the grid at about one 4-wave workgroup per CU, at most a quarter of the mean degree's worth
     // of idle lanes (1 << lg <= mean degree), at most 8
-    int lg = 0;
+    lg = 0;
     {
       const double mean = (double)nentries / NV;
       while (lg < 3 && (double)(2 << lg) <= mean && (size_t)NV * (size_t)(2 << lg) <= (size_t)pe::W * pe::WPB * 256) ++lg;
       if (getenv("GRAPHITE_POSE_LPV")) { const int want = atoi(getenv("GRAPHITE_POSE_LPV")); lg = want >= 8 ? 3 : want >= 4 ? 2 : want >= 2 ? 1 : 0; }
     }
-    const int LPV = 1 << lg, VPW = pe::W >> lg, nslices = (NV + VPW - 1) / VPW, NVp = (nslices * VPW + pe::W - 1) / pe::W * pe::W;
+    const int LPV = 1 << lg, VPW = pe::W >> lg;
+    nslices = (NV + VPW - 1) / VPW; NVp = (nslices * VPW + pe::W - 1) / pe::W * pe::W;
     std::vector<int> sbase(nslices + 1, 0);
     for (int w = 0; w < nslices; ++w) {
       int m = 0;
       for (int k = w * VPW; k < std::min(NV, (w + 1) * VPW); ++k) m = std::max(m, (deg[k] + LPV - 1) / LPV);
       sbase[w + 1] = sbase[w] + m;
     }
-    const size_t ngroups = (size_t)sbase[nslices];
+    ngroups = (size_t)sbase[nslices];
     if (ngroups * pe::W > 0x3fffffffu) { res.declined = "entry lists above 2^30 slots (a vertex of very high degree)"; return -1; }
     std::vector<int> enbr(ngroups * pe::W, -2), pos(2 * na, -1), fill(NV, 0), lij(2 * na);
     auto slot_of = [&](int k) { // entry e of vertex k: sub-lane e % LPV, group e / LPV of its slice
@@ -864,9 +884,12 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
       if (kj >= 0) { const int slot = slot_of(kj); pos[2 * a + 1] = slot; enbr[slot] = ki; }
     }
     lap("lists");
-    if (!pose_engine_state) pose_engine_state = std::make_shared<pe::Buffers<T>>();
-    auto &bf = *std::static_pointer_cast<pe::Buffers<T>>(pose_engine_state);
     bf.sbase.assign(sbase.data(), sbase.size()); bf.enbr.assign(enbr.data(), enbr.size()); bf.k2l.assign(k2l.data(), k2l.size()); bf.pos.assign(pos.data(), pos.size()); bf.lij.assign(lij.data(), lij.size());
+    bf.key_epoch_f = this->structure_epoch; bf.key_epoch_v = vd->structure_epoch; bf.key_na = na; bf.key_nvl = nvl; bf.key_dim = hessian_dim; bf.key_digest = dg;
+    bf.c_NV = NV; bf.c_NVp = NVp; bf.c_lg = lg; bf.c_nslices = nslices; bf.c_ngroups = ngroups;
+    bf.have_structure = true;
+    } else lap("structure cache hit (epochs + digests)");
+    const int LPV = 1 << lg;
     bf.Hd.resize_uninit(ngroups * DD * pe::W); bf.gd.resize_uninit(ngroups * D * pe::W); bf.B.resize_uninit(ngroups * DD * pe::W);
     const size_t per_vertex = (size_t)(2 * DD + 3 * D), per_vec = (size_t)6 * D;
     bf.vert.resize_uninit(per_vertex * NVp); bf.vec.resize_uninit(per_vec * NVp); bf.ex.resize_uninit((size_t)NVp * 2 * D);
@@ -876,7 +899,8 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     const int nbe = blocks(na);
     bf.part_chi2.resize_uninit((size_t)nbe);
     bf.ctl.resize_uninit(1); bf.fail.resize_uninit(1);
-    if (!tables_mirrored || m_pmat.get(precision_matrices, true) == precision_matrices.raw()) refresh_table_mirrors(false); // the precision matrices in HBM
+    if (!tables_mirrored) refresh_table_mirrors(false);
+    else if (m_pmat.get(precision_matrices, true) == precision_matrices.raw()) m_pmat.refresh(precision_matrices); // (the light initialisation leaves the precision matrices in pinned host memory)
 
     lap("buffers + uploads");
     // ---- launch shapes ----

@@ -112,6 +112,8 @@ template <typename T, typename Mode, template <typename, int> class LossT> stati
   double sec = 0;
   for (int rep = 0; rep < repeat; ++rep) {
     if (rep) { std::copy(start.begin(), start.end(), poses.begin()); std::cout << "REPEAT " << rep << std::endl; }
+    // POSE_MUTATE=k: before the LAST call pose k is fixed too (a structure change between optimiser calls: what was cached for the graph no longer holds)
+    if (rep && rep == repeat - 1 && getenv("POSE_MUTATE")) vd.set_fixed((size_t)atoi(getenv("POSE_MUTATE")), true);
     const auto t0 = std::chrono::steady_clock::now();
     if (lm2) optimizer::levenberg_marquardt2<T, T>(&graph, &opt); else optimizer::levenberg_marquardt<T, T>(&graph, &opt);
     sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
