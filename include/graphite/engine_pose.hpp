@@ -232,7 +232,9 @@ template <typename T> struct SolveArgs {
   const int *sbase;            // [nslices + 1] first entry group of a slice
   const int *enbr;             // [groups][64] neighbour vertex of an entry (-1: none / padding / fixed)
   const int *k2l;              // engine vertex -> descriptor-local vertex
-  const T *Hd, *gd, *B;        // per entry group, element-major: [(group * NE + e) * 64 + lane]
+  const int *efac;             // [groups][64] active factor of an entry * 2 + its side (-1: padding)
+  const T *frec;               // [active factors][4 E D + E] what k_pe_linearize left: J_0 | J_1 | W J_0 | W J_1 | W r  (W = rho' P)
+  T *B;                        // per entry group, element-major [(group * D D + e) * 64 + lane]: J_v^T W J_nbr, formed by the assemble phase
   T *Hs, *Minv, *s, *b, *dg;   // per vertex, element-major [e * NVp + k]
   T *x, *xb, *r, *t, *p, *y;
   T *ex;                       // [NVp][2 D] s.z' | s.p
@@ -256,7 +258,7 @@ template <typename T> struct SolveArgs {
 // for the whole launch: the update phase touches no memory but the record it publishes (2.0 -> 0.5 us per PCG iteration on 10 k
 // poses), the operator phase reads only neighbour records and entry blocks.  Otherwise every phase reloads it (grid-stride over slices).
 constexpr int LDS_GROUPS = 16;  // entry groups of a wave's slice whose neighbour ids stay in LDS for the whole launch (4 KB per wave)
-template <typename T, typename VTr, int D, bool ONE_PASS>
+template <typename T, typename VTr, int D, int E, bool ONE_PASS>
 __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, typename VTr::Vertex *verts /* the HBM mirror, by local vertex id */, typename state_of<VTr>::type *backup) {
   Ctl *const ctl = A.ctl;
   if (ctl->stop) return;
@@ -316,13 +318,37 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
       for (int e = 0; e < DD; ++e) H[e] = T(0);
 #pragma unroll
       for (int e = 0; e < D; ++e) g[e] = T(0);
-      // (padding slots hold the zeros of the set-up: no branch, the loads of several groups are in flight together)
-#pragma unroll 4
+      // Every entry forms its three products from the factor's record (gathered: the factor kernel wrote it contiguously; the
+      // entry-slot form of round 6's first version had that kernel scatter 42 eight-byte stores per factor, 22 us of a 141 us
+      // iteration) and keeps the off-diagonal block for the PCG iterations, lane-consecutive.  Padding entries read factor 0 with
+      // weight zero: no branch between the loads.
+      constexpr int ED = E * D, RF = 4 * ED + E, UNR = DD <= 9 ? 2 : 1;
+#pragma unroll UNR
       for (int grp = g0; grp < g1; ++grp) {
+        const int code = A.efac[(size_t)grp * W + lane];
+        const T on = code >= 0 ? T(1) : T(0);
+        const int cc = code >= 0 ? code : 0, side = cc & 1;
+        const T *rec = A.frec + (size_t)(cc >> 1) * RF;
+        T Js[ED], As[ED], Ao[ED], Wr[E];
 #pragma unroll
-        for (int e = 0; e < DD; ++e) H[e] += A.Hd[((size_t)grp * DD + e) * W + lane];
+        for (int q = 0; q < ED; ++q) { Js[q] = rec[side * ED + q]; As[q] = rec[(2 + side) * ED + q]; Ao[q] = rec[(3 - side) * ED + q]; }
 #pragma unroll
-        for (int e = 0; e < D; ++e) g[e] += A.gd[((size_t)grp * D + e) * W + lane];
+        for (int i = 0; i < E; ++i) Wr[i] = rec[4 * ED + i];
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+          T gg = T(0);
+#pragma unroll
+          for (int i = 0; i < E; ++i) gg += Js[r * E + i] * Wr[i];
+          g[r] += on * gg;
+#pragma unroll
+          for (int c = 0; c < D; ++c) {
+            T h = T(0), b = T(0);
+#pragma unroll
+            for (int i = 0; i < E; ++i) { h += Js[r * E + i] * As[i * D + c]; b += Js[r * E + i] * Ao[i * D + c]; }
+            H[r * D + c] += on * h;
+            if (code >= 0) A.B[((size_t)grp * DD + r * D + c) * W + lane] = b;
+          }
+        }
       }
       over_lanes(H);
       over_lanes(g);
@@ -588,7 +614,7 @@ template <typename T> struct FactorArgs {
   const int *pos;           // [na][2] entry slot of (factor, side): group * 64 + lane, -1: that vertex has no column
   const int *lij;           // [na][2] descriptor-local vertex ids of the active factor (the vertex objects are read from the mirror
                             // directly: active list -> id table -> pointer table -> vertex is two dependent loads longer)
-  T *Hd, *gd, *B;
+  T *frec;                  // [na][4 E D + E] J_0 | J_1 | W J_0 | W J_1 | W r of the accepted point (entries gather it in the solve's assemble phase)
   int early;
 };
 
@@ -715,7 +741,7 @@ __device__ inline void pe_jacobian(const FactorView<F> &fv, size_t f, const VT &
 template <typename F, size_t... Is>
 __global__ void __launch_bounds__(TPB) k_pe_linearize(FactorView<F> fv, const FactorArgs<typename F::Scalar> A, slot_vertex<F, 0> *mirror, std::index_sequence<Is...> seq) {
   using T = typename F::Scalar;
-  constexpr int E = (int)F::E, D = (int)slot_dim<F, 0>(), DD = D * D;
+  constexpr int E = (int)F::E, D = (int)slot_dim<F, 0>();
   const Ctl *const ctl = A.ctl;
   if (ctl->stop || !ctl->fresh) return;
   const size_t a = blockIdx.x * (size_t)TPB + threadIdx.x;
@@ -746,32 +772,18 @@ __global__ void __launch_bounds__(TPB) k_pe_linearize(FactorView<F> fv, const Fa
       A0[i * D + c] = s0; A1[i * D + c] = s1;
     }
   }
-  auto emit = [&](int pos, const T *Jm, const T *Am, const T *Ao) {
-    const size_t grp = (size_t)(pos >> 6), ln = (size_t)(pos & 63);
+  // one contiguous record per factor (312 bytes for SE(2) fp64): the blocks of a vertex without a column are zero
+  T *rec = A.frec + a * (size_t)(4 * E * D + E);
 #pragma unroll
-    for (int r = 0; r < D; ++r) {
-      T g = T(0);
+  for (int q = 0; q < E * D; ++q) { rec[q] = J0[q]; rec[E * D + q] = J1[q]; rec[2 * E * D + q] = A0[q]; rec[3 * E * D + q] = A1[q]; }
 #pragma unroll
-      for (int i = 0; i < E; ++i) g += Jm[r * E + i] * Wr[i];
-      A.gd[(grp * D + r) * W + ln] = g;
-#pragma unroll
-      for (int c = 0; c < D; ++c) {
-        T h = T(0), b = T(0);
-#pragma unroll
-        for (int i = 0; i < E; ++i) { h += Jm[r * E + i] * Am[i * D + c]; b += Jm[r * E + i] * Ao[i * D + c]; }
-        A.Hd[(grp * DD + r * D + c) * W + ln] = h;
-        A.B[(grp * DD + r * D + c) * W + ln] = b;
-      }
-    }
-  };
-  if (p0 >= 0) emit(p0, J0, A0, A1);
-  if (p1 >= 0) emit(p1, J1, A1, A0);
+  for (int i = 0; i < E; ++i) rec[4 * E * D + i] = Wr[i];
 }
 
 // buffers of one descriptor's engine, kept between optimiser calls (capacity is reused)
 template <typename T> struct Buffers {
-  hbm_vector<int> sbase, enbr, k2l, pos, lij;
-  hbm_vector<T> Hd, gd, B, vert, vec, ex, res, w, dx;
+  hbm_vector<int> sbase, enbr, efac, k2l, pos, lij;
+  hbm_vector<T> frec, B, vert, vec, ex, res, w, dx;
   hbm_vector<double> sums, part_rho, part_chi2, tr;
   hbm_vector<long long> clock, dbg;
   hbm_vector<Ctl> ctl;
@@ -871,7 +883,7 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     }
     ngroups = (size_t)sbase[nslices];
     if (ngroups * pe::W > 0x3fffffffu) { res.declined = "entry lists above 2^30 slots (a vertex of very high degree)"; return -1; }
-    std::vector<int> enbr(ngroups * pe::W, -2), pos(2 * na, -1), fill(NV, 0), lij(2 * na);
+    std::vector<int> enbr(ngroups * pe::W, -2), efac(ngroups * pe::W, -1), pos(2 * na, -1), fill(NV, 0), lij(2 * na);
     auto slot_of = [&](int k) { // entry e of vertex k: sub-lane e % LPV, group e / LPV of its slice
       const int e = fill[k]++, w = k / VPW;
       return (sbase[w] + e / LPV) * pe::W + (k % VPW) * LPV + e % LPV;
@@ -880,17 +892,17 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
       const size_t f = active_indices[a];
       const int ki = l2k[device_ids[f * 2]], kj = l2k[device_ids[f * 2 + 1]];
       lij[2 * a] = (int)device_ids[f * 2]; lij[2 * a + 1] = (int)device_ids[f * 2 + 1];
-      if (ki >= 0) { const int slot = slot_of(ki); pos[2 * a] = slot; enbr[slot] = kj; }
-      if (kj >= 0) { const int slot = slot_of(kj); pos[2 * a + 1] = slot; enbr[slot] = ki; }
+      if (ki >= 0) { const int slot = slot_of(ki); pos[2 * a] = slot; enbr[slot] = kj; efac[slot] = (int)(2 * a); }
+      if (kj >= 0) { const int slot = slot_of(kj); pos[2 * a + 1] = slot; enbr[slot] = ki; efac[slot] = (int)(2 * a + 1); }
     }
     lap("lists");
-    bf.sbase.assign(sbase.data(), sbase.size()); bf.enbr.assign(enbr.data(), enbr.size()); bf.k2l.assign(k2l.data(), k2l.size()); bf.pos.assign(pos.data(), pos.size()); bf.lij.assign(lij.data(), lij.size());
+    bf.sbase.assign(sbase.data(), sbase.size()); bf.enbr.assign(enbr.data(), enbr.size()); bf.efac.assign(efac.data(), efac.size()); bf.k2l.assign(k2l.data(), k2l.size()); bf.pos.assign(pos.data(), pos.size()); bf.lij.assign(lij.data(), lij.size());
     bf.key_epoch_f = this->structure_epoch; bf.key_epoch_v = vd->structure_epoch; bf.key_na = na; bf.key_nvl = nvl; bf.key_dim = hessian_dim; bf.key_digest = dg;
     bf.c_NV = NV; bf.c_NVp = NVp; bf.c_lg = lg; bf.c_nslices = nslices; bf.c_ngroups = ngroups;
     bf.have_structure = true;
     } else lap("structure cache hit (epochs + digests)");
     const int LPV = 1 << lg;
-    bf.Hd.resize_uninit(ngroups * DD * pe::W); bf.gd.resize_uninit(ngroups * D * pe::W); bf.B.resize_uninit(ngroups * DD * pe::W);
+    bf.frec.resize_uninit(na * (size_t)(4 * E * D + E)); bf.B.resize_uninit(ngroups * DD * pe::W);
     const size_t per_vertex = (size_t)(2 * DD + 3 * D), per_vec = (size_t)6 * D;
     bf.vert.resize_uninit(per_vertex * NVp); bf.vec.resize_uninit(per_vec * NVp); bf.ex.resize_uninit((size_t)NVp * 2 * D);
     bf.res.resize_uninit(2 * na * E); bf.w.resize_uninit(2 * na); bf.dx.resize_uninit(hessian_dim);
@@ -909,8 +921,8 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     GRAPHITE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     // (the one-pass form keeps a vertex's state in registers: only when the grid has a wave for every slice, and blocks of at most 4 x 4)
     constexpr bool CAN_ONE_PASS = DD <= 16;
-    auto *solve_multi = &pe::k_pe_solve<T, VTr, D, false>;
-    auto *solve_one = &pe::k_pe_solve<T, VTr, D, CAN_ONE_PASS>;
+    auto *solve_multi = &pe::k_pe_solve<T, VTr, D, (int)E, false>;
+    auto *solve_one = &pe::k_pe_solve<T, VTr, D, (int)E, CAN_ONE_PASS>;
     int per_cu_one = 0;
     GRAPHITE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, solve_multi, pe::W * pe::WPB, 0));
     GRAPHITE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_one, solve_one, pe::W * pe::WPB, 0));
@@ -928,14 +940,12 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     GRAPHITE_HIP(hipMemcpy(bf.ctl.raw(), &h, sizeof(h), hipMemcpyHostToDevice));
     GRAPHITE_HIP(hipMemset(bf.fail.raw(), 0, sizeof(int)));
     GRAPHITE_HIP(hipMemsetAsync(bf.sums.raw(), 0, bf.sums.size() * sizeof(double), nullptr)); // no record carries a tag of this call
-    // padding slots of the entry lists are never written: their zeros are what the assemble loop adds
-    GRAPHITE_HIP(hipMemsetAsync(bf.Hd.raw(), 0, bf.Hd.size() * sizeof(T), nullptr));
-    GRAPHITE_HIP(hipMemsetAsync(bf.gd.raw(), 0, bf.gd.size() * sizeof(T), nullptr));
+    // padding slots of the entry blocks are never written: the operator multiplies their zeros
     GRAPHITE_HIP(hipMemsetAsync(bf.B.raw(), 0, bf.B.size() * sizeof(T), nullptr));
 
     pe::SolveArgs<T> sa{};
     sa.NV = NV; sa.NVp = NVp; sa.lg = lg; sa.nslices = nslices; sa.sbase = bf.sbase.raw(); sa.enbr = bf.enbr.raw(); sa.k2l = bf.k2l.raw();
-    sa.Hd = bf.Hd.raw(); sa.gd = bf.gd.raw(); sa.B = bf.B.raw();
+    sa.efac = bf.efac.raw(); sa.frec = bf.frec.raw(); sa.B = bf.B.raw();
     T *vp = bf.vert.raw();
     sa.Hs = vp; sa.Minv = vp + (size_t)DD * NVp; sa.s = vp + (size_t)2 * DD * NVp; sa.b = sa.s + (size_t)D * NVp; sa.dg = sa.b + (size_t)D * NVp;
     T *vv = bf.vec.raw();
@@ -952,7 +962,7 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     pe::FactorArgs<T> fa{};
     fa.ctl = bf.ctl.raw(); fa.res = bf.res.raw(); fa.w = bf.w.raw(); fa.part = bf.part_chi2.raw(); fa.part_rho = bf.part_rho.raw(); fa.n_rho = G * pe::WPB;
     fa.na = na; fa.tr_chi2 = bf.tr.raw(); fa.tr_mu = bf.tr.raw() + ntr; fa.tr_clock = bf.clock.raw(); fa.pos = bf.pos.raw(); fa.lij = bf.lij.raw();
-    fa.Hd = bf.Hd.raw(); fa.gd = bf.gd.raw(); fa.B = bf.B.raw(); fa.early = o.early_stop ? 1 : 0;
+    fa.frec = bf.frec.raw(); fa.early = o.early_stop ? 1 : 0;
 
     auto fv = view();
     auto *backup = vd->backup_ptr();
@@ -978,8 +988,8 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
       if (coop) {
         void *args[] = {(void *)&sa, (void *)&vmirror, (void *)&backup};
         GRAPHITE_HIP(hipLaunchCooperativeKernel((const void *)solve_kernel, dim3(G), dim3(pe::W * pe::WPB), args, 0, nullptr));
-      } else if (one_pass) pe::k_pe_solve<T, VTr, D, CAN_ONE_PASS><<<G, pe::W * pe::WPB>>>(sa, vmirror, backup);
-      else pe::k_pe_solve<T, VTr, D, false><<<G, pe::W * pe::WPB>>>(sa, vmirror, backup);
+      } else if (one_pass) pe::k_pe_solve<T, VTr, D, (int)E, CAN_ONE_PASS><<<G, pe::W * pe::WPB>>>(sa, vmirror, backup);
+      else pe::k_pe_solve<T, VTr, D, (int)E, false><<<G, pe::W * pe::WPB>>>(sa, vmirror, backup);
       pe::k_pe_error<FactorDescriptor><<<nbe, TPB>>>(fv, fa, vmirror, 1, seq);
       pe::k_pe_linearize<FactorDescriptor><<<nbe, TPB>>>(fv, fa, vmirror, seq);
       ++enq;
