@@ -468,9 +468,9 @@ def main():
                "generic_kernels": {"value": round(1.0 / it_g, 2), "unit": "LM iterations/s", "ms_per_step": round(it_g * 1e3, 4), "whole_call_ms": round(wall(g.stdout) * 1e3, 3)},
                "speedup_vs_generic_kernels": round(it_g / it_e, 2), "parity_rel": None,
                "roofline": {"bound": "latency", "kernel": "k_pe_solve", "unit": "us per LM iteration", "achieved": round(it_e * 1e6, 2),
-                            "peak": round(3 * 4.6 + 21 * 2.3, 2), "frac": round((3 * 4.6 + 21 * 2.3) / (it_e * 1e6), 4), "traffic": None,
-                            "launches_per_lm_iteration": 3, "launch_floor_us": 4.6, "grid_rendezvous_per_lm_iteration": 21, "grid_rendezvous_us": 2.3,
-                            "note": "latency-bound: 3 launches and 1 + 2 x 10 grid-wide rendezvous (one write-through store + one polling load each, measured 2.3 us) "
+                            "peak": round(2 * 4.6 + 21 * 2.3, 2), "frac": round((2 * 4.6 + 21 * 2.3) / (it_e * 1e6), 4), "traffic": None,
+                            "launches_per_lm_iteration": 2, "launch_floor_us": 4.6, "grid_rendezvous_per_lm_iteration": 21, "grid_rendezvous_us": 2.3,
+                            "note": "latency-bound: 2 launches and 1 + 2 x 10 grid-wide rendezvous (one write-through store + one polling load each, measured 2.3 us) "
                                     "per LM iteration; peak = the time this launch structure would take with nothing else on the chain, frac = peak / measured"}}
         if not args.no_cpu_baseline:
             from oracle.pose_graph import PoseGraphOracle
