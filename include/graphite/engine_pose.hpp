@@ -940,10 +940,11 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     GRAPHITE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, solve_multi, pe::W * pe::WPB, 0));
     GRAPHITE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_one, solve_one, pe::W * pe::WPB, 0));
     const int G_all = (nslices + pe::WPB - 1) / pe::WPB;
-    const bool one_pass = CAN_ONE_PASS && G_all <= std::min(pe::MAX_GRID, per_cu_one * cus) && !(getenv("GRAPHITE_POSE_ONE_PASS") && atoi(getenv("GRAPHITE_POSE_ONE_PASS")) == 0);
+    const int max_grid = getenv("GRAPHITE_POSE_MAX_GRID") ? std::max(1, std::min(pe::MAX_GRID, atoi(getenv("GRAPHITE_POSE_MAX_GRID")))) : pe::MAX_GRID; // (tests: a small grid walks several slices per wave)
+    const bool one_pass = CAN_ONE_PASS && G_all <= std::min(max_grid, per_cu_one * cus) && !(getenv("GRAPHITE_POSE_ONE_PASS") && atoi(getenv("GRAPHITE_POSE_ONE_PASS")) == 0);
     auto *solve_kernel = one_pass ? solve_one : solve_multi;
     if (one_pass) per_cu = per_cu_one;
-    const int G = std::max(1, std::min(std::min(G_all, pe::MAX_GRID), per_cu * cus));
+    const int G = std::max(1, std::min(std::min(G_all, max_grid), per_cu * cus));
     if (per_cu < 1) { res.declined = "the solve kernel does not fit a compute unit"; return -1; }
 
     lap("occupancy query");

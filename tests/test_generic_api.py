@@ -578,3 +578,21 @@ def test_pose_graph_engine_structure_cache(tmp_path):
     assert np.allclose(tr[:6, 1], ct[1:], rtol=1e-9) and np.allclose(tr[6:, 1], ct2[1:], rtol=1e-9) and not np.allclose(ct[1:], ct2[1:], rtol=1e-9)
     got = np.loadtxt(out)
     assert np.allclose(got, o2.x, rtol=1e-9, atol=1e-9) and np.array_equal(got[777], np.asarray(p0)[777])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"GRAPHITE_POSE_ONE_PASS": "0"}, {"GRAPHITE_POSE_MAX_GRID": "3"}, {"GRAPHITE_POSE_LPV": "1"}, {"GRAPHITE_POSE_LPV": "2"},
+                                 {"GRAPHITE_POSE_LPV": "8", "GRAPHITE_POSE_COOP": "1"}, {"GRAPHITE_POSE_MAX_GRID": "5", "GRAPHITE_POSE_LPV": "1"}],
+                         ids=["state-in-memory", "three-workgroups", "one-lane-per-vertex", "two-lanes", "eight-lanes-cooperative", "five-workgroups-one-lane"])
+def test_pose_graph_engine_forms_agree_with_the_oracle(tmp_path, env):
+    """The solve's other forms on the 2 000-pose graph, each against the oracle at the same bars as the default (four lanes per vertex, vertex
+    state in registers, plain launch): state reloaded per phase; a grid of three / five workgroups (every wave walks many slices: the form
+    graphs beyond 64 k vertex-lanes run); one, two and eight lanes per vertex; the cooperative launch."""
+    r, tr, got, ct, lt, st, o = _pose_graph_run(tmp_path, 2000, 8, "manual", 10, 1.0, env=dict(env, GR_VERBOSE="1"))
+    assert "POSE_ENGINE_HANDOVERS 1" in r.stdout
+    if "GRAPHITE_POSE_ONE_PASS" in env or "GRAPHITE_POSE_MAX_GRID" in env:
+        assert "state in memory" in r.stderr
+    if "GRAPHITE_POSE_LPV" in env:
+        assert f"x {env['GRAPHITE_POSE_LPV']} lanes" in r.stderr
+    assert np.allclose(tr[:, 1], ct[1:], rtol=1e-9) and np.allclose(tr[:, 2], lt[1:], rtol=1e-8)
+    assert np.allclose(got, o.x, rtol=1e-9, atol=1e-9)
