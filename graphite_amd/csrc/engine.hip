@@ -2186,6 +2186,8 @@ template <typename T> struct Engine final : EngineBase {
   // ---- device-decided LM iteration of PCGSchurSolver on small reduced systems (kernels_sf.hpp) ------------------------------------
   DevBuf<unsigned> coop_bar;
   DevBuf<double> coop_part;
+  DevBuf<double> coop_recs;   // k_schur_pcg_coop's flagged records (coop_exchange): [2][Nc + 2] x 16 bytes
+  unsigned coop_seq = 0;      // launches of the cooperative PCG so far: the records' tag
   DevBuf<int> coop_iters, coop_fail_dev;
   volatile int *h_coop_fail = nullptr; // pinned, sticky
   bool sf_active = false;              // armed by lm()
@@ -2215,6 +2217,7 @@ template <typename T> struct Engine final : EngineBase {
     coop_bar.alloc(1); coop_iters.alloc(1);
     if (!coop_fail_dev.n) { coop_fail_dev.alloc(1); coop_fail_dev.zero(stream); }
     coop_part.alloc((3 * (size_t)max_iter + 4) * (size_t)Nc);
+    if (!coop_recs.n) { coop_recs.alloc(2 * 2 * ((size_t)Nc + 2)); coop_recs.zero(stream); }
     if (!h_coop_fail) {
       void *q = nullptr;
       GR_HIP(hipHostMalloc(&q, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -2233,6 +2236,7 @@ template <typename T> struct Engine final : EngineBase {
     const int ui = use_identity ? 1 : 0;
     CoopState cs{};
     cs.barrier = coop_bar.p; cs.part = coop_part.p; cs.iters = coop_iters.p; cs.hiters = h_iters(); cs.fail = h_coop_fail; cs.fail_dev = coop_fail_dev.p; cs.ts = h_ts ? h_ts + 2 * ts_slot : nullptr;
+    cs.recs = coop_recs.p; cs.rec_cap = (int)Nc + 2; cs.launch_id = ++coop_seq;
     if (coop_test_timeouts > 0) { --coop_test_timeouts; cs.absent = 1; }
     const int nbc = cdiv(Nc, 28), nbp = std::max(1, std::min(cdiv(Np, TPB / FIN_PL), num_cu * 4));
     const bool coop = schur_coop();

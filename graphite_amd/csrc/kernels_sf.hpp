@@ -83,6 +83,9 @@ struct CoopState {           // k_schur_pcg_coop's cross-workgroup state (device
   long long *ts;             // pinned [2] wall-clock stamps around the loop (solve_seconds), may be null
   int *fail_dev = nullptr;   // the same word in device memory: the NEXT head's decision reads it (a step computed behind a timed-out barrier is never accepted)
   unsigned absent = 0;       // TEST ONLY (GR_TEST_COOP_TIMEOUT): the barriers wait for this many workgroups more than the launch has — they time out
+  double *recs = nullptr;    // [2][rec_cap] 16-byte flagged records {partial, tag} of coop_exchange (round 6); zero at allocation
+  int rec_cap = 0;
+  unsigned launch_id = 0;    // unique per launch of a handle: the upper half of the records' tags
 };
 
 // A REJECTED STEP DOES NOT STOP THE HEAD (round 5, built-in model).  What a rejection needs of the current point is still in memory — Hcc,
@@ -460,6 +463,55 @@ __device__ __forceinline__ double coop_sum(const double *part, int Nc) {
   return wave_allsum(s);
 }
 
+// Round 6: the barrier AND the sum over the rows as ONE exchange of flagged records (the rendezvous of include/graphite/engine_pose.hpp):
+// a workgroup stores {its partial, tag} with one 16-byte write-through store, then polls the records of all workgroups until each carries
+// the tag (launch << 32 | phase); the sum runs in the order of coop_sum (lane-strided, then the butterfly): the same bits as the counter
+// barrier + partial reads it replaces, one store -> load hop instead of store -> counter -> poll -> partial reads.  DRAIN: the phase
+// published p (write-through stores that must be acknowledged before the record announces them).  Bounded like coop_barrier.
+typedef unsigned sf_u32x4 __attribute__((ext_vector_type(4)));
+template <bool DRAIN> __device__ __forceinline__ bool coop_exchange(const CoopState &cs, unsigned phase, int i, int Nc, double mine, double &total) {
+  const int lane = threadIdx.x & 63, n = Nc + (int)cs.absent, cap = cs.rec_cap;
+  const unsigned long long tag = ((unsigned long long)cs.launch_id << 32) | phase;
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(cs.recs, 0, 2 * cap * 16, 0x00020000);
+  const int set = (int)(phase & 1u) * cap;
+  if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, mine);
+    sf_u32x4 a;
+    a.x = (unsigned)bits; a.y = (unsigned)(bits >> 32); a.z = (unsigned)tag; a.w = (unsigned)(tag >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(a, rr, (set + i) * 16, 0, 16);
+  }
+  double acc = 0;
+  bool ok = true;
+  const int nper = (n + 63) / 64;
+  for (int c0 = 0; c0 < nper && ok; c0 += 4) {
+    sf_u32x4 rec[4];
+    unsigned pend = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (c0 + u < nper && lane + 64 * (c0 + u) < n) pend |= 1u << u;
+    const long long t0 = wall_clock64();
+    while (true) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (pend & (1u << u)) rec[u] = __builtin_amdgcn_raw_buffer_load_b128(rr, (set + lane + 64 * (c0 + u)) * 16, 0, 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if ((pend & (1u << u)) && (((unsigned long long)rec[u].w << 32) | rec[u].z) == tag) pend &= ~(1u << u);
+      if (!__any(pend != 0)) break;
+      if (wall_clock64() - t0 > 200000000ll) { ok = false; break; } // 2 s of the 100 MHz clock: the launch's workgroups are not all resident
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) break;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c0 + u < nper && lane + 64 * (c0 + u) < Nc) acc += __builtin_bit_cast(double, ((unsigned long long)rec[u].y << 32) | rec[u].x);
+  }
+  if (!ok) {
+    if (lane == 0) { *cs.fail = 1; if (cs.fail_dev) *cs.fail_dev = 1; __threadfence_system(); }
+    return false;
+  }
+  total = wave_allsum(acc);
+  return true;
+}
+
 // PCGSchurSolver::solve (solver/pcg_schur.hpp:79-168) + BlockJacobiSchurPreconditioner (block_jacobi_schur.hpp:114-178), all of
 // it in ONE launch: grid = Nc workgroups of one wave, workgroup i owns block row i of S.  Lanes 0..8 hold the row's x, r, z, p,
 // x_backup entries in registers for the whole loop; p and the dot-product partials cross workgroups through device memory.
@@ -546,14 +598,12 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
     return s;
   };
   T xr = T(0), rr = b, zr = apply_minv(b), pr = zr, xbr = T(0);
-  double *part = cs.part;
+  double rz = 0.0;
   {
     const double d = wave_allsum(own ? (double)(rr * zr) : 0.0);
-    if (lane == 0) __hip_atomic_store(&part[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (own) __hip_atomic_store(&p_glob[9 * (size_t)i + r], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!coop_exchange<true>(cs, ++phase, i, Nc, d, rz)) return;
   }
-  if (!coop_barrier(cs.barrier, ++phase * ((unsigned)Nc + cs.absent), cs.fail, cs.fail_dev)) return;
-  double rz = coop_sum(part, Nc);
   double rz0 = __builtin_inf();
   int k = 0, iters = 0;
   for (; k < max_iter; ++k) {
@@ -591,13 +641,11 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
     T y = acc;
 #pragma unroll
     for (int gg = 1; gg < 7; ++gg) y += __shfl(acc, gg * 9 + r, 64);
-    double *pden = part + (size_t)(3 * k + 1) * Nc, *prz = part + (size_t)(3 * k + 3) * Nc;
+    double den = 0.0;
     {
       const double d = wave_allsum(own ? (double)(y * pr) : 0.0);
-      if (lane == 0) __hip_atomic_store(&pden[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!coop_exchange<false>(cs, ++phase, i, Nc, d, den)) return;
     }
-    if (!coop_barrier(cs.barrier, ++phase * ((unsigned)Nc + cs.absent), cs.fail, cs.fail_dev)) return;
-    const double den = coop_sum(pden, Nc);
     if (den == 0.0 || den != den) break;
     ++iters;
     const T alpha = (T)rz / (T)den;
@@ -605,12 +653,12 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
     xr = alpha * pr + xr;
     rr = -alpha * y + rr;
     zr = apply_minv(rr);
+    double rz_sum = 0.0;
     {
       const double d = wave_allsum(own ? (double)(rr * zr) : 0.0);
-      if (lane == 0) __hip_atomic_store(&prz[i], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!coop_exchange<false>(cs, ++phase, i, Nc, d, rz_sum)) return;
     }
-    if (!coop_barrier(cs.barrier, ++phase * ((unsigned)Nc + cs.absent), cs.fail, cs.fail_dev)) return;
-    const T rz_new = (T)coop_sum(prz, Nc);
+    const T rz_new = (T)rz_sum;
     const bool reject = (fabs((double)rz_new) > rejection_ratio * rz0) || (rz_new != rz_new);
     if (reject) { xr = xbr; break; }
     const T beta = rz_new / (T)rz;
@@ -619,7 +667,7 @@ k_schur_pcg_coop(int Nc, const int *__restrict__ row_ptr, const int *__restrict_
     rz = (double)rz_new; // pcg_schur.hpp keeps rz in T
     if (fabs((double)rz_new) < tol) { ++k; break; }
     if (own) __hip_atomic_store(&p_glob[9 * (size_t)i + r], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!coop_barrier(cs.barrier, ++phase * ((unsigned)Nc + cs.absent), cs.fail, cs.fail_dev)) return;
+    { double unused; if (!coop_exchange<true>(cs, ++phase, i, Nc, 0.0, unused)) return; } // every row's p is published before any row reads it
   }
   if (own) x_out[9 * (size_t)i + r] = xr;
   if (i == 0 && lane == 0) {
