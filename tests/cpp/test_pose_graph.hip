@@ -90,6 +90,11 @@ template <typename T, typename Mode, template <typename, int> class LossT> stati
     if constexpr (std::is_same<LossT<T, 3>, HuberLoss<T, 3>>::value) fd.add_factor({i, j}, Rel2<T>{mx, my, mth}, P, Empty(), HuberLoss<T, 3>(delta));
     else fd.add_factor({i, j}, Rel2<T>{mx, my, mth}, P, Empty(), DefaultLoss<T, 3>());
   }
+  // POSE_DEACTIVATE=k: every k-th factor gets activity level 1 (inactive at optimisation level 0: factor.hpp:419-431, active.hpp:11-21);
+  // POSE_EXTRA_VERTICES=m: m vertices no factor touches are added behind the poses (they take no part in the optimisation)
+  if (getenv("POSE_DEACTIVATE")) { const size_t k = (size_t)std::max(2, atoi(getenv("POSE_DEACTIVATE"))); for (size_t f = 0; f < nf; f += k) fd.set_active(f, 1); }
+  managed_vector<Pose2<T>> extra(getenv("POSE_EXTRA_VERTICES") ? (size_t)atoi(getenv("POSE_EXTRA_VERTICES")) : 0);
+  for (size_t i = 0; i < extra.size(); ++i) { extra[i] = Pose2<T>{T(100 + i), T(-3), T(0.5)}; vd.add_vertex(n + 10 + i, &extra[i], false); }
   BlockJacobiPreconditioner<T, T> bj;
   IdentityPreconditioner<T, T> ident;
   PCGSolver<T, T> pcg(pcg_it, pcg_tol, 5.0, solver == "pcg-identity" ? static_cast<Preconditioner<T, T> *>(&ident) : static_cast<Preconditioner<T, T> *>(&bj));
@@ -100,6 +105,7 @@ template <typename T, typename Mode, template <typename, int> class LossT> stati
   opt.iterations = iterations;
   opt.optimization_level = 0;
   opt.verbose = true;
+  opt.use_identity = getenv("POSE_IDENTITY_DAMPING") && atoi(getenv("POSE_IDENTITY_DAMPING")) != 0; // mu I instead of mu clamp(diag)
   opt.streams = &streams;
   bool stop = getenv("POSE_STOP") && atoi(getenv("POSE_STOP")) != 0; // already raised: the loop ends after its first iteration (levenberg_marquardt.hpp:232)
   if (getenv("POSE_STOP")) opt.stop_flag = &stop;

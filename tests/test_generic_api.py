@@ -596,3 +596,29 @@ def test_pose_graph_engine_forms_agree_with_the_oracle(tmp_path, env):
         assert f"x {env['GRAPHITE_POSE_LPV']} lanes" in r.stderr
     assert np.allclose(tr[:, 1], ct[1:], rtol=1e-9) and np.allclose(tr[:, 2], lt[1:], rtol=1e-8)
     assert np.allclose(got, o.x, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_pose_graph_engine_inactive_factors_unused_vertices_identity_damping(tmp_path):
+    """What changes the engine's lists rather than its arithmetic: every fifth factor inactive at the optimisation level (factor.hpp:419-431),
+    seven vertices no factor touches added behind the poses (bit 7 of their state: no column, active.hpp:14-30), and mu I damping
+    (use_identity): the oracle run on the graph without those factors, with that damping — traces and poses at 1e-9, the unused vertices and the
+    vertices only inactive factors touched untouched."""
+    from oracle.pose_graph import PoseGraphOracle
+    exe = build_all()[8]
+    p0, fx, e, m, info, _ = synth.make_pose_graph(1500)
+    f = tmp_path / "graph.txt"
+    out = tmp_path / "poses.txt"
+    synth.write_pose_graph(f, p0, fx, e, m, info, huber_delta=0.0)
+    env = dict(os.environ, POSE_DEACTIVATE="5", POSE_EXTRA_VERTICES="7", POSE_IDENTITY_DAMPING="1")
+    r = subprocess.run([exe, str(f), "pcg", "8", "manual", "12", "1e-3", str(out)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "POSE_ENGINE_HANDOVERS 1" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    keep = np.ones(len(e), bool); keep[::5] = False
+    o = PoseGraphOracle(p0, fx, np.asarray(e)[keep], np.asarray(m)[keep], np.asarray(info)[keep])
+    ct, lt, st = o.levenberg_marquardt(iterations=8, pcg_max_iter=12, pcg_tol=1e-3, use_identity=True)
+    tr = parse_trace(r.stdout)
+    assert len(tr) == len(ct) - 1 and np.allclose(tr[:, 1], ct[1:], rtol=1e-9) and np.allclose(tr[:, 2], lt[1:], rtol=1e-8)
+    got = np.loadtxt(out)
+    assert np.allclose(got, o.x, rtol=1e-9, atol=1e-9)
+    g = subprocess.run([exe, str(f), "pcg", "8", "manual", "12", "1e-3"], capture_output=True, text=True, timeout=600, env=dict(env, GRAPHITE_GENERIC_ONLY="1"))
+    assert g.returncode == 0 and np.allclose(parse_trace(g.stdout)[:, 1], ct[1:], rtol=1e-9)
