@@ -332,7 +332,7 @@ def main():
         """A workload whose LM iteration touches less than the L2s hold and whose kernels are all a few launch floors long is bound by
         the NUMBER of dependent launches and in-launch grid barriers, not by bytes: an HBM fraction of 0.005 says nothing.
         The record then carries the launch-floor model instead: floor = launches per LM iteration x 4.6 us (a launch that finds nothing
-        to do: profiles/HISTORY.md, kernel trace) + grid barriers per LM iteration x 3.0 us (the cooperative PCG's barrier, measured),
+        to do: profiles/HISTORY.md, kernel trace) + grid barriers per LM iteration x 2.3 us (the cooperative PCG's flagged-record rendezvous; 3.0 us for the counter barrier of the resident matrix-free PCG; measured),
         frac = floor / measured time per LM iteration; `hbm` keeps the byte view of the dominant kernel for reference."""
         if residency["served_from"] != "L2" or not ks:
             return None
@@ -342,7 +342,7 @@ def main():
         longest = max(v["total_ms"] * 1e3 / max(v.get("active_launches", v["launches"]), 1) for v in ks.values())
         if longest > 40.0:
             return None
-        LAUNCH_FLOOR_US, BARRIER_US = 4.6, 3.0
+        LAUNCH_FLOOR_US, BARRIER_US = 4.6, (2.3 if "schur_pcg_coop" in ks else 3.0)  # (round 6: the cooperative PCG on S meets through flagged records, 2.3 us measured)
         inner = ra["st"]["pcg_iterations"] / steps_run
         coop = ks.get("schur_pcg_coop") or ks.get("pcg_resident")
         # the cooperative PCG on S: one barrier after its start, then three per inner iteration; the resident matrix-free PCG: two per inner iteration
