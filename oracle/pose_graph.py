@@ -16,6 +16,11 @@ valid instance of the reference's unordered float atomics.
                                     diagonal + mu clamp(d, 1e-6, 1e32) or + mu (ops/hessian.hpp:80-112), batched inverse, z = B r
   PCGSolver::solve                  solver/pcg.hpp:61-232 (preconditioner applied to r / |r|; rejection ratio; x backup)
   levenberg_marquardt               optimizer/levenberg_marquardt.hpp:20-47,110-242
+
+PARITY UNPINNED: the reference holds no test, example or golden vector on a pose graph.  What ties this restatement to the reference is the
+formula of every line cited above (the same formulas oracle/generic_ops.hpp states for the graphs the reference's vectors DO pin), its own
+consistency checks on the CPU (tests/test_oracle_pose_graph.py) and the agreement of the HIP generic kernels — pinned on the reference's
+vectors — with it at 1e-12 on the same graphs (tests/test_generic_api.py::test_pose_graph_on_the_generic_kernels).
 """
 import numpy as np
 
