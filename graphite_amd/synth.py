@@ -248,11 +248,17 @@ def make_pose_graph(n_poses=2000, factors_per_pose=5, seed=7, sigma_t=0.02, sigm
     return poses0, fixed, np.stack([i, j], 1), meas, info, truth
 
 
-def write_pose_graph(path, poses, fixed, edges, meas, info, huber_delta=0.0):
-    """text file read by tests/cpp/test_pose_graph.hip: 'N F delta', N lines 'x y theta fixed', F lines 'i j mx my mth p00 .. p22' (row-major)"""
+def write_pose_graph(path, poses, fixed, edges, meas, info, huber_delta=0.0, priors=None):
+    """text file read by tests/cpp/test_pose_graph.hip: 'N F delta', N lines 'x y theta fixed', F lines 'i j mx my mth p00 .. p22' (row-major);
+    priors = (vertex ids, measurements [n, 3], information matrices [n, 3, 3]): then 'PRIORS n' and n lines 'i mx my mth p00 .. p22' — unary
+    factors x_i - m of a second factor descriptor"""
     with open(path, "w") as f:
         f.write(f"{len(poses)} {len(edges)} {float(huber_delta)!r}\n")
         for p, fx in zip(poses, fixed):
             f.write(f"{float(p[0])!r} {float(p[1])!r} {float(p[2])!r} {int(fx)}\n")
         for e, m, P in zip(edges, meas, info):
             f.write(f"{int(e[0])} {int(e[1])} " + " ".join(repr(float(v)) for v in m) + " " + " ".join(repr(float(v)) for v in P.ravel()) + "\n")
+        if priors is not None:
+            f.write(f"PRIORS {len(priors[0])}\n")
+            for i, m, P in zip(priors[0], priors[1], priors[2]):
+                f.write(f"{int(i)} " + " ".join(repr(float(v)) for v in m) + " " + " ".join(repr(float(v)) for v in np.asarray(P).ravel()) + "\n")

@@ -382,6 +382,7 @@ template <> struct hash<graphite::BlockCoordinates> {
 } // namespace std
 namespace graphite {
 
+namespace detail { struct PoseEngineOptions; struct PoseEngineResult; namespace pe { struct FactorInfo; struct VertexInfo; template <typename T> struct SolveArgs; template <typename T> struct FactorArgs; } } // engine_pose.hpp
 template <typename T, typename S> class BaseVertexDescriptor {
 public:
   virtual ~BaseVertexDescriptor() = default;
@@ -408,6 +409,14 @@ public:
   virtual void gather_parameters(T *out) = 0;
   virtual void scatter_parameters(const T *in) = 0;
   bool eliminate = false; // set_eliminate (vertex.hpp:98): kept for API parity, the PCG path ignores it
+  // The pose-graph engine (engine_pose.hpp), the pieces that see THIS descriptor's traits: what the driver needs to know (false: the vertex
+  // type is not plain data or its tangent dimension is above 7), the resident workgroups per CU of its solve kernel, the solve launch
+  // (every PCG iteration and the trial step through Traits::update) and the launch that takes a rejected last step back
+  virtual bool pose_engine_vertex(detail::pe::VertexInfo &) { return false; }
+  virtual int pose_engine_occupancy(bool /*one_pass*/) { return 0; }
+  virtual void pose_engine_solve(const detail::pe::SolveArgs<T> &, int /*grid*/, bool /*cooperative*/, bool /*one_pass*/) {}
+  virtual void pose_engine_finish(const void * /*Ctl*/, const int * /*k2l*/, int /*NV*/) {}
+  std::shared_ptr<void> pose_engine_state; // the engine's buffers and structure cache for graphs on this descriptor, kept between optimiser calls
   void set_eliminate(bool e) { eliminate = e; ++structure_epoch; }
   // bumped by every call that changes the vertex set, a vertex's address or its fixed flag: what a cached engine problem
   // (solve.hpp, EngineCache) is keyed on, next to the factor descriptor's epoch and content fingerprint
@@ -625,6 +634,10 @@ public:
   void to_device() {}
   void clear() { x_device.clear(); active_state.clear(); hessian_ids.clear(); block_ids.clear(); backup_state.clear(); global_to_local_map.clear(); local_to_global_map.clear(); dense_dirty = true; ++this->structure_epoch; }
 
+  bool pose_engine_vertex(detail::pe::VertexInfo &vi) override; // engine_pose.hpp
+  int pose_engine_occupancy(bool one_pass) override;
+  void pose_engine_solve(const detail::pe::SolveArgs<T> &sa, int G, bool cooperative, bool one_pass) override;
+  void pose_engine_finish(const void *ctl, const int *k2l, int NV) override;
   void apply_update(const T *delta_x, const T *scales) override {
     if (count()) detail::k_vertex_update<T, Traits><<<detail::blocks(count()), detail::TPB>>>(vertices(), device_active_state(), device_hessian_ids(), count(), delta_x, scales);
   }
@@ -651,13 +664,16 @@ public:
 // FactorDescriptor (factor.hpp:120-830)
 // =================================================================================================
 namespace detail { class EngineModelBase; } // engine_model.hpp
-namespace detail { struct PoseEngineOptions; struct PoseEngineResult; } // engine_pose.hpp
+// (pose-graph engine types: declared above BaseVertexDescriptor)
 template <typename T, typename S> class BaseFactorDescriptor {
 public:
   virtual ~BaseFactorDescriptor() = default;
-  // The pose-graph engine (engine_pose.hpp) on THIS descriptor's traits: the whole levenberg_marquardt + PCGSolver loop of a graph
-  // whose only factors are binary factors between vertices of one descriptor.  -1: not such a descriptor (the reason in the result).
-  virtual int pose_engine_lm(const detail::PoseEngineOptions &, detail::PoseEngineResult &, T * /*graph b*/, T * /*graph scales*/, size_t /*hessian dimension*/) { return -1; }
+  // The pose-graph engine (engine_pose.hpp), the pieces that see THIS descriptor's traits: what the driver needs to know (false: more than two
+  // slots or an error dimension above 7), the local vertex ids of its active factors ([active][2], -1 for a unary factor's missing slot) and
+  // the launch of the factor kernel (error, chi2, Jacobians, product records, LM decision by the last workgroup of the graph's launches)
+  virtual bool pose_engine_factor(detail::pe::FactorInfo &, bool /*check precision-matrix symmetry*/) { return false; }
+  virtual void pose_engine_ids(int * /*lij*/) {}
+  virtual void pose_engine_launch(const detail::pe::FactorArgs<T> &, void * /*vertex mirror*/, int /*mode*/) {}
   // The engine's per-observation kernels instantiated on THIS descriptor's traits (engine_model.hpp), for the active factors:
   // local pose / landmark ids per active factor (active_indices order) in cam / pt.  nullptr: not a (<= 9, <= 3) -> <= 2 binary
   // factor of plain-data types, or a precision matrix that is not symmetric positive semi-definite.
@@ -1769,8 +1785,10 @@ public:
   }
   bool declares_bal_model() const override { return detail::has_bal_tag<Traits>::value; }
   std::shared_ptr<detail::EngineModelBase> make_engine_model(std::vector<int32_t> &cam, std::vector<int32_t> &pt, size_t num_poses, size_t num_landmarks) override; // engine_model.hpp
-  int pose_engine_lm(const detail::PoseEngineOptions &o, detail::PoseEngineResult &res, T *graph_b, T *graph_scales, size_t hessian_dim) override; // engine_pose.hpp
-  std::shared_ptr<void> pose_engine_state; // its buffers, kept between optimiser calls
+  bool pose_engine_factor(detail::pe::FactorInfo &fi, bool check_symmetry) override; // engine_pose.hpp
+  void pose_engine_ids(int *lij) override;
+  void pose_engine_launch(const detail::pe::FactorArgs<T> &fa, void *mirror, int mode) override;
+  bool pose_stage_attr_set = false; // the factor kernel's LDS staging above 64 KB was allowed once
   bool probe_bal(size_t max_samples, std::vector<T> &cam, std::vector<T> &pt, std::vector<T> &obs, std::vector<T> &res, std::vector<T> &Jc, std::vector<T> &Jp, double &update_dev,
                  size_t *num_synthetic = nullptr) override {
     if constexpr (bal_shaped()) {

@@ -259,7 +259,7 @@ template <typename T> struct SolveArgs {
 // for the whole launch: the update phase touches no memory but the record it publishes (2.0 -> 0.5 us per PCG iteration on 10 k
 // poses), the operator phase reads only neighbour records and entry blocks.  Otherwise every phase reloads it (grid-stride over slices).
 constexpr int LDS_GROUPS = 16;  // entry groups of a wave's slice whose neighbour ids stay in LDS for the whole launch (4 KB per wave)
-template <typename T, typename VTr, int D, int E, bool ONE_PASS>
+template <typename T, typename VTr, int D, bool ONE_PASS>
 __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, typename VTr::Vertex *verts /* the HBM mirror, by local vertex id */, typename state_of<VTr>::type *backup) {
   Ctl *const ctl = A.ctl;
   if (ctl->stop) return;
@@ -599,13 +599,15 @@ template <typename T> struct FactorArgs {
   double *part;             // chi2 partials, one per workgroup
   const double *part_rho;   // the solve's rho-denominator partials
   int n_rho;
-  size_t na;
+  size_t na;                // active factors of THIS descriptor
+  size_t a0, na_all;        // ... which are factors [a0, a0 + na) of the na_all active factors of the graph's descriptors (records, pos, lij)
+  int block0, total_blocks; // this launch's first chi2 partial; workgroups of all the descriptors' launches (the last of them decides)
   double *tr_chi2, *tr_mu;  // [iterations + 1]
   long long *tr_clock;      // [iterations + 1]
-  const int *pos;           // [na][2] entry slot of (factor, side): group * 64 + lane, -1: that vertex has no column
-  const int *lij;           // [na][2] descriptor-local vertex ids of the active factor (the vertex objects are read from the mirror
+  const int *pos;           // [na_all][2] entry slot of (factor, side): group * 64 + lane, -1: that vertex has no column
+  const int *lij;           // [na_all][2] descriptor-local vertex ids of the active factor, -1 for the missing slot of a unary factor (the vertex objects are read from the mirror
                             // directly: active list -> id table -> pointer table -> vertex is two dependent loads longer)
-  T *frec;                  // [2][na][2 (2 D D + D)] per side J_v^T W J_v | J_v^T W r | J_v^T W J_other: the accepted point's set (ctl->cur) and the trial point's
+  T *frec;                  // [2][na_all][2 (2 D D + D)] per side J_v^T W J_v | J_v^T W r | J_v^T W J_other: the accepted point's set (ctl->cur) and the trial point's
   int early;
 };
 
@@ -648,11 +650,11 @@ __global__ void __launch_bounds__(TPB) k_pe_factor(FactorView<F> fv, const Facto
   if (ctl->stop) return;
   const int buf = mode == 0 ? ctl->cur : ctl->cur ^ 1;
   bool have = false;
-  const size_t a = blockIdx.x * (size_t)TPB + threadIdx.x;
+  const size_t a = blockIdx.x * (size_t)TPB + threadIdx.x, ga = A.a0 + a; // in this descriptor's active list / among all the graph's active factors
   double c2 = 0;
   if (a < A.na) {
     const size_t f = fv.active_ids[a];
-    auto v = std::make_tuple((mirror + A.lij[2 * a + Is])...);
+    auto v = std::make_tuple((mirror + A.lij[2 * ga + Is])...);
     std::tuple<T[slot_dim<F, Is>()]...> p;
     ((slot_traits<F, Is>::parameters(*std::get<Is>(v), (T *)std::get<Is>(p))), ...);
     T err[E];
@@ -672,11 +674,12 @@ __global__ void __launch_bounds__(TPB) k_pe_factor(FactorView<F> fv, const Facto
     const T w = (T)fv.loss[f].loss_derivative(value);
     // the record: for each side v of the factor  J_v^T W J_v (D x D) | J_v^T W r (D) | J_v^T W J_other (D x D)  with W = rho' P
     // (column-major E x D Jacobian blocks, ops/error.hpp:146-149); the block of a vertex without a column is zero (ops/linearize.hpp:24)
-    const int p0 = A.pos[2 * a], p1 = A.pos[2 * a + 1];
+    const int p0 = A.pos[2 * ga], p1 = A.pos[2 * ga + 1]; // (a unary factor has no second slot: p1 = -1, its second side stays zero)
     if (p0 >= 0 || p1 >= 0) {
       T J0[Ei * D], J1[Ei * D], A0[Ei * D], A1[Ei * D], Wr[Ei];
       if (p0 >= 0) pe_jacobian<F, 0>(fv, f, v, J0, seq); else for (int k = 0; k < Ei * D; ++k) J0[k] = T(0);
-      if (p1 >= 0) pe_jacobian<F, 1>(fv, f, v, J1, seq); else for (int k = 0; k < Ei * D; ++k) J1[k] = T(0);
+      if constexpr (F::N == 2) { if (p1 >= 0) pe_jacobian<F, 1>(fv, f, v, J1, seq); else for (int k = 0; k < Ei * D; ++k) J1[k] = T(0); }
+      else for (int k = 0; k < Ei * D; ++k) J1[k] = T(0);
 #pragma unroll
       for (int i = 0; i < Ei; ++i) {
         T sr = T(0);
@@ -707,7 +710,7 @@ __global__ void __launch_bounds__(TPB) k_pe_factor(FactorView<F> fv, const Facto
           }
         }
       };
-      T *const out = STAGE ? stage + (size_t)threadIdx.x * RF : A.frec + ((size_t)buf * A.na + a) * RF;
+      T *const out = STAGE ? stage + (size_t)threadIdx.x * RF : A.frec + ((size_t)buf * A.na_all + ga) * RF;
       side(out, J0, A0, A1);
       side(out + RS, J1, A1, A0);
       have = true;
@@ -718,7 +721,7 @@ __global__ void __launch_bounds__(TPB) k_pe_factor(FactorView<F> fv, const Facto
   __syncthreads();
   { // the workgroup's records leave lane-consecutive (each thread's own 336 bytes at a 336-byte stride were 42 partial-line stores per wave instruction)
     const size_t first = blockIdx.x * (size_t)TPB, count = first < A.na ? (A.na - first < (size_t)TPB ? A.na - first : (size_t)TPB) : 0;
-    T *dst = A.frec + ((size_t)buf * A.na + first) * RF;
+    T *dst = A.frec + ((size_t)buf * A.na_all + A.a0 + first) * RF;
     for (size_t i = threadIdx.x; i < count * RF; i += TPB) dst[i] = stage[i];
   }
   }
@@ -726,15 +729,15 @@ __global__ void __launch_bounds__(TPB) k_pe_factor(FactorView<F> fv, const Facto
   __syncthreads();
   for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) {
-    st_x(A.part + blockIdx.x, red[0]);
+    st_x(A.part + A.block0 + blockIdx.x, red[0]);
     __threadfence();
     const unsigned tk = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = tk == gridDim.x - 1;
+    s_last = tk == (unsigned)A.total_blocks - 1u; // (the ticket runs over the launches of all the graph's factor descriptors)
   }
   __syncthreads();
   if (!s_last) return;
   double tot = 0, rd = 0;
-  for (int g = threadIdx.x; g < (int)gridDim.x; g += TPB) tot += ld_x(A.part + g);
+  for (int g = threadIdx.x; g < A.total_blocks; g += TPB) tot += ld_x(A.part + g);
   __syncthreads();
   red[threadIdx.x] = tot;
   __syncthreads();
@@ -793,7 +796,9 @@ __global__ void __launch_bounds__(TPB) k_pe_factor(FactorView<F> fv, const Facto
   ctl->stop = stop;
 }
 
-// buffers of one descriptor's engine, kept between optimiser calls (capacity is reused)
+template <typename F, size_t... Is> inline const void *factor_kernel_ptr(std::index_sequence<Is...>) { return (const void *)&k_pe_factor<F, Is...>; }
+
+// buffers of one vertex descriptor's engine, kept between optimiser calls (capacity is reused)
 template <typename T> struct Buffers {
   hbm_vector<int> sbase, enbr, efac, k2l, pos, lij;
   hbm_vector<T> frec, B, vert, vec, ex, dx;
@@ -806,7 +811,8 @@ template <typename T> struct Buffers {
   // optimisation level (through the active list) and on the vertex states and Hessian columns of this initialisation; a call that
   // finds all of them unchanged (the SLAM loop that optimises the same graph again) re-uses lists, uploads and the symmetry check
   bool have_structure = false;
-  size_t key_epoch_f = 0, key_epoch_v = 0, key_na = 0, key_nvl = 0, key_dim = 0;
+  std::vector<size_t> key_f;  // per factor descriptor: address, structure epoch, active count, digest of the active list
+  size_t key_epoch_v = 0, key_nvl = 0, key_dim = 0;
   uint64_t key_digest = 0;
   int c_NV = 0, c_NVp = 0, c_lg = 0, c_nslices = 0;
   size_t c_ngroups = 0;
@@ -815,51 +821,162 @@ template <typename T> struct Buffers {
 } // namespace pe
 } // namespace detail
 
-// levenberg_marquardt (early_stop: levenberg_marquardt2) of THIS descriptor's graph on the pose-graph engine.  The caller has run
-// Graph::initialize_optimization(level, light) and holds the device mirror of the vertices.  Returns -1 (with res.declined) when
-// the descriptor is not an engine configuration, 0 when the loop ran.
+namespace detail {
+namespace pe {
+// what the driver asks of a factor descriptor (typed code behind BaseFactorDescriptor's virtuals)
+struct FactorInfo {
+  int slots = 0, error_dim = 0;
+  size_t active = 0, epoch = 0;
+  uint64_t active_digest = 0;
+  const void *vertex_descriptor = nullptr; // the descriptor of EVERY slot, nullptr when they differ
+  bool storage_is_scalar = false, symmetric = true;
+};
+struct VertexInfo {
+  int dim = 0;
+  size_t count = 0, vertex_bytes = 0, epoch = 0;
+  void *mirror = nullptr;
+  bool plain = false, mirrored = false;
+};
+} // namespace pe
+} // namespace detail
+
+// ---- typed pieces: the factor kernel on a factor descriptor's traits ---------------------------------------------------------------
 template <typename T, typename S, typename FTraits>
-int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOptions &o, detail::PoseEngineResult &res, T *graph_b, T *graph_scales, size_t hessian_dim) {
+bool FactorDescriptor<T, S, FTraits>::pose_engine_factor(detail::pe::FactorInfo &fi, bool check_symmetry) {
   using namespace detail;
-  using VD0 = typename std::tuple_element<0, VDTuple>::type;
-  if constexpr (N != 2) { res.declined = "not a binary factor"; return -1; }
-  else if constexpr (!std::is_same<VD0, typename std::tuple_element<1, VDTuple>::type>::value) { res.declined = "the two slots are different vertex types"; return -1; }
-  else if constexpr (!std::is_same<T, S>::value || !std::is_floating_point<T>::value) { res.declined = "Jacobian storage type differs from the graph's scalar"; return -1; }
-  else if constexpr (!VD0::can_mirror || VD0::dim > 7 || E > 7) { res.declined = "vertex type is not plain data, or a dimension above 7"; return -1; }
-  else {
-    using VTr = typename VD0::Traits;
-    constexpr int D = (int)VD0::dim, DD = D * D;
-    using clk = std::chrono::steady_clock;
-    const auto t_begin = clk::now();
-    auto t_last = t_begin;
-    auto lap = [&](const char *what) { const auto now = clk::now(); res.detail += std::string(what) + " " + std::to_string(1e3 * std::chrono::duration<double>(now - t_last).count()) + " ms, "; t_last = now; };
-    VD0 *vd = static_cast<VD0 *>(typed_descriptors[0]);
-    if (typed_descriptors[0] != typed_descriptors[1]) { res.declined = "the two slots are different descriptors"; return -1; }
-    if (!vd->mirrored) { res.declined = "no device mirror of the vertices"; return -1; }
-    const size_t na = active_count(), nvl = vd->count();
-    if (!na || !hessian_dim || hessian_dim % D) { res.declined = "nothing to optimise"; return -1; }
-    if (na > 0x3fffffffu || nvl > 0x3fffffffu) { res.declined = "more than 2^30 factors or vertices"; return -1; }
-    if (!pose_engine_state) pose_engine_state = std::make_shared<pe::Buffers<T>>();
-    auto &bf = *std::static_pointer_cast<pe::Buffers<T>>(pose_engine_state);
-    const uint8_t *state = vd->get_active_state();
-    const size_t *hid = vd->get_hessian_ids();
-    uint64_t dg = digest(0x706F7365ull, active_indices.raw(), na * sizeof(size_t));
-    dg = digest(dg, state, nvl);
-    dg = digest(dg, hid, nvl * sizeof(size_t));
-    const bool cached = bf.have_structure && bf.key_epoch_f == this->structure_epoch && bf.key_epoch_v == vd->structure_epoch && bf.key_na == na && bf.key_nvl == nvl &&
-                        bf.key_dim == hessian_dim && bf.key_digest == dg && !(getenv("GRAPHITE_POSE_CACHE") && atoi(getenv("GRAPHITE_POSE_CACHE")) == 0);
-    int NV = bf.c_NV, NVp = bf.c_NVp, lg = bf.c_lg, nslices = bf.c_nslices;
-    size_t ngroups = bf.c_ngroups;
-    if (!cached) {
-    bf.have_structure = false;
-    // symmetric precision matrices: the blocks of the two sides are formed from one W = rho' P
-    for (size_t a = 0; a < na; ++a) {
+  fi.slots = (int)N; fi.error_dim = (int)E; fi.active = active_count(); fi.epoch = this->structure_epoch;
+  fi.storage_is_scalar = std::is_same<T, S>::value && std::is_floating_point<T>::value;
+  fi.vertex_descriptor = vertex_descriptors[0];
+  for (size_t i = 1; i < N; ++i) if (vertex_descriptors[i] != vertex_descriptors[0]) fi.vertex_descriptor = nullptr;
+  fi.active_digest = digest(0x706F7365ull, active_indices.raw(), fi.active * sizeof(size_t));
+  if (check_symmetry) // symmetric precision matrices: the blocks of the two sides are formed from one W = rho' P
+    for (size_t a = 0; a < fi.active && fi.symmetric; ++a) {
       const S *P = precision_matrices.raw() + active_indices[a] * E * E;
       for (size_t i = 0; i < E; ++i)
         for (size_t j = i + 1; j < E; ++j)
-          if (P[i * E + j] != P[j * E + i]) { res.declined = "a precision matrix is not symmetric"; return -1; }
+          if (P[i * E + j] != P[j * E + i]) fi.symmetric = false;
     }
-    lap("checks");
+  if (!tables_mirrored) refresh_table_mirrors(false);
+  else if (m_pmat.get(precision_matrices, true) == precision_matrices.raw()) m_pmat.refresh(precision_matrices); // (the light initialisation leaves the precision matrices in pinned host memory)
+  return N <= 2 && E <= 7 && std::is_same<typename std::tuple_element<0, VDTuple>::type, typename std::tuple_element<N - 1, VDTuple>::type>::value;
+}
+template <typename T, typename S, typename FTraits>
+void FactorDescriptor<T, S, FTraits>::pose_engine_ids(int *lij) {
+  const size_t na = active_count();
+  for (size_t a = 0; a < na; ++a) {
+    const size_t f = active_indices[a];
+    lij[2 * a] = (int)device_ids[f * N];
+    lij[2 * a + 1] = N > 1 ? (int)device_ids[f * N + 1] : -1;
+  }
+}
+template <typename T, typename S, typename FTraits>
+void FactorDescriptor<T, S, FTraits>::pose_engine_launch(const detail::pe::FactorArgs<T> &fa, void *mirror, int mode) {
+  using namespace detail;
+  if constexpr (N <= 2 && std::is_same<T, S>::value && std::is_same<typename std::tuple_element<0, VDTuple>::type, typename std::tuple_element<N - 1, VDTuple>::type>::value) {
+    using VD0 = typename std::tuple_element<0, VDTuple>::type;
+    constexpr int D = (int)VD0::dim, DD = D * D;
+    size_t stage_bytes = (size_t)TPB * (2 * (2 * DD + D)) * sizeof(T);
+    if (stage_bytes > 96 * 1024) stage_bytes = 0; // (written directly, see k_pe_factor)
+    constexpr auto seq = std::make_index_sequence<N>{};
+    if (stage_bytes > 64 * 1024 && !pose_stage_attr_set) {
+      GRAPHITE_HIP(hipFuncSetAttribute(pe::factor_kernel_ptr<FactorDescriptor>(seq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes));
+      pose_stage_attr_set = true;
+    }
+    pe::k_pe_factor<FactorDescriptor><<<blocks(fa.na), TPB, stage_bytes>>>(view(), fa, static_cast<typename VD0::VertexType *>(mirror), mode, seq);
+  }
+}
+
+// ---- typed pieces: the solve on a vertex descriptor's traits ------------------------------------------------------------------------
+template <typename T, typename S, typename VTraits>
+bool VertexDescriptor<T, S, VTraits>::pose_engine_vertex(detail::pe::VertexInfo &vi) {
+  vi.dim = (int)dim; vi.count = count(); vi.vertex_bytes = sizeof(VertexType); vi.epoch = this->structure_epoch;
+  vi.plain = can_mirror; vi.mirrored = mirrored;
+  if constexpr (can_mirror) vi.mirror = mirror.raw();
+  return can_mirror && dim <= 7;
+}
+template <typename T, typename S, typename VTraits>
+int VertexDescriptor<T, S, VTraits>::pose_engine_occupancy(bool one_pass) {
+  using namespace detail;
+  int per_cu = 0;
+  if constexpr (can_mirror && dim <= 7 && std::is_floating_point<T>::value) {
+    constexpr int D = (int)dim;
+    constexpr bool CAN = D * D <= 16;
+    if (one_pass && !CAN) return 0;
+    const void *fn = one_pass ? (const void *)&pe::k_pe_solve<T, VTraits, D, CAN> : (const void *)&pe::k_pe_solve<T, VTraits, D, false>;
+    GRAPHITE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, pe::W * pe::WPB, 0));
+  }
+  return per_cu;
+}
+template <typename T, typename S, typename VTraits>
+void VertexDescriptor<T, S, VTraits>::pose_engine_solve(const detail::pe::SolveArgs<T> &sa, int G, bool cooperative, bool one_pass) {
+  using namespace detail;
+  if constexpr (can_mirror && dim <= 7 && std::is_floating_point<T>::value) {
+    constexpr int D = (int)dim;
+    constexpr bool CAN = D * D <= 16;
+    auto *vm = mirror.raw();
+    auto *bk = backup_ptr();
+    if (cooperative) {
+      void *args[] = {(void *)&sa, (void *)&vm, (void *)&bk};
+      const void *fn = one_pass ? (const void *)&pe::k_pe_solve<T, VTraits, D, CAN> : (const void *)&pe::k_pe_solve<T, VTraits, D, false>;
+      GRAPHITE_HIP(hipLaunchCooperativeKernel(fn, dim3(G), dim3(pe::W * pe::WPB), args, 0, nullptr));
+    } else if (one_pass) pe::k_pe_solve<T, VTraits, D, CAN><<<G, pe::W * pe::WPB>>>(sa, vm, bk);
+    else pe::k_pe_solve<T, VTraits, D, false><<<G, pe::W * pe::WPB>>>(sa, vm, bk);
+  }
+}
+template <typename T, typename S, typename VTraits>
+void VertexDescriptor<T, S, VTraits>::pose_engine_finish(const void *ctl, const int *k2l, int NV) {
+  using namespace detail;
+  if constexpr (can_mirror) pe::k_pe_finish<VTraits><<<blocks((size_t)NV), TPB>>>(static_cast<const pe::Ctl *>(ctl), k2l, NV, mirror.raw(), backup_ptr());
+}
+
+namespace detail {
+// levenberg_marquardt (early_stop: levenberg_marquardt2) of a graph of ONE vertex descriptor whose factor descriptors are unary or binary
+// on it, on the pose-graph engine.  The caller has run Graph::initialize_optimization(level, light) and holds the device mirror of the
+// vertices.  Returns -1 (with res.declined) when the graph is not an engine configuration, 0 when the loop ran, 1 when a launch failed
+// (the vertices are as the call found them).
+template <typename T, typename S>
+int pose_engine_run(Graph<T, S> *graph, const PoseEngineOptions &o, PoseEngineResult &res) {
+  using clk = std::chrono::steady_clock;
+  const auto t_begin = clk::now();
+  auto t_last = t_begin;
+  auto lap = [&](const char *what) { const auto now = clk::now(); res.detail += std::string(what) + " " + std::to_string(1e3 * std::chrono::duration<double>(now - t_last).count()) + " ms, "; t_last = now; };
+  auto *vd = graph->get_vertex_descriptors()[0];
+  auto &fds = graph->get_factor_descriptors();
+  const size_t hessian_dim = graph->get_hessian_dimension();
+  pe::VertexInfo vi;
+  if (!vd->pose_engine_vertex(vi)) { res.declined = "vertex type is not plain data, or a tangent dimension above 7"; return -1; }
+  if (!vi.mirrored) { res.declined = "no device mirror of the vertices"; return -1; }
+  const int D = vi.dim, DD = D * D;
+  const size_t nvl = vi.count;
+  if (!vd->pose_engine_state) vd->pose_engine_state = std::make_shared<pe::Buffers<T>>();
+  auto &bf = *std::static_pointer_cast<pe::Buffers<T>>(vd->pose_engine_state);
+  const bool use_cache = !(getenv("GRAPHITE_POSE_CACHE") && atoi(getenv("GRAPHITE_POSE_CACHE")) == 0);
+  // ---- the factor descriptors: all unary / binary on this vertex descriptor; their active factors numbered one after the other ----
+  std::vector<pe::FactorInfo> fis(fds.size());
+  std::vector<size_t> key_f, a0(fds.size() + 1, 0);
+  for (size_t d = 0; d < fds.size(); ++d) {
+    // (the symmetry check reads every precision matrix: skipped while the descriptor's epoch is the cached one)
+    const bool known = use_cache && bf.have_structure && bf.key_f.size() == 4 * fds.size() && bf.key_f[4 * d] == (size_t)(uintptr_t)fds[d] && bf.key_f[4 * d + 1] == fds[d]->structure_epoch;
+    if (!fds[d]->pose_engine_factor(fis[d], !known)) { res.declined = "a factor descriptor with more than two slots or an error dimension above 7"; return -1; }
+    if (fis[d].vertex_descriptor != (const void *)vd) { res.declined = "a factor slot on another vertex descriptor"; return -1; }
+    if (!fis[d].storage_is_scalar) { res.declined = "Jacobian storage type differs from the graph's scalar"; return -1; }
+    if (!fis[d].symmetric) { res.declined = "a precision matrix is not symmetric"; return -1; }
+    a0[d + 1] = a0[d] + fis[d].active;
+    key_f.push_back((size_t)(uintptr_t)fds[d]); key_f.push_back(fis[d].epoch); key_f.push_back(fis[d].active); key_f.push_back((size_t)fis[d].active_digest);
+  }
+  const size_t na = a0[fds.size()];
+  if (!na || !hessian_dim || hessian_dim % D) { res.declined = "nothing to optimise"; return -1; }
+  if (na > 0x3fffffffu || nvl > 0x3fffffffu) { res.declined = "more than 2^30 factors or vertices"; return -1; }
+  const uint8_t *state = vd->get_active_state();
+  const size_t *hid = vd->get_hessian_ids();
+  uint64_t dg = digest(0x706F7365ull, state, nvl);
+  dg = digest(dg, hid, nvl * sizeof(size_t));
+  const bool cached = use_cache && bf.have_structure && bf.key_f == key_f && bf.key_epoch_v == vi.epoch && bf.key_nvl == nvl && bf.key_dim == hessian_dim && bf.key_digest == dg;
+  lap("checks");
+  int NV = bf.c_NV, NVp = bf.c_NVp, lg = bf.c_lg, nslices = bf.c_nslices;
+  size_t ngroups = bf.c_ngroups;
+  if (!cached) {
+    bf.have_structure = false;
     // ---- structure: engine vertices = the descriptor's vertices that have a column, in column order; wave-sliced entry lists ----
     NV = (int)(hessian_dim / D);
     std::vector<int> l2k(nvl, -1), k2l(NV, -1);
@@ -870,14 +987,15 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
         l2k[l] = (int)k; k2l[k] = (int)l;
       }
     for (int k = 0; k < NV; ++k) if (k2l[k] < 0) { res.declined = "Hessian columns are not one block per vertex"; return -1; }
+    std::vector<int> lij(2 * na);
+    for (size_t d = 0; d < fds.size(); ++d) fds[d]->pose_engine_ids(lij.data() + 2 * a0[d]);
     std::vector<int> deg(NV, 0);
     size_t nentries = 0;
-    for (size_t a = 0; a < na; ++a) {
-      const size_t f = active_indices[a];
-      const int ki = l2k[device_ids[f * 2]], kj = l2k[device_ids[f * 2 + 1]];
-      if (ki >= 0) { ++deg[ki]; ++nentries; }
-      if (kj >= 0) { ++deg[kj]; ++nentries; }
-    }
+    for (size_t a = 0; a < na; ++a)
+      for (int sd = 0; sd < 2; ++sd) {
+        const int k = lij[2 * a + sd] >= 0 ? l2k[lij[2 * a + sd]] : -1;
+        if (k >= 0) { ++deg[k]; ++nentries; }
+      }
     // lanes per vertex: as many as keep the grid at about one 4-wave workgroup per CU, at most a quarter of the mean degree's worth
     // of idle lanes (1 << lg <= mean degree), at most 8
     lg = 0;
@@ -896,155 +1014,140 @@ int FactorDescriptor<T, S, FTraits>::pose_engine_lm(const detail::PoseEngineOpti
     }
     ngroups = (size_t)sbase[nslices];
     if (ngroups * pe::W > 0x3fffffffu) { res.declined = "entry lists above 2^30 slots (a vertex of very high degree)"; return -1; }
-    std::vector<int> enbr(ngroups * pe::W, -2), efac(ngroups * pe::W, -1), pos(2 * na, -1), fill(NV, 0), lij(2 * na);
+    std::vector<int> enbr(ngroups * pe::W, -2), efac(ngroups * pe::W, -1), pos(2 * na, -1), fill(NV, 0);
     auto slot_of = [&](int k) { // entry e of vertex k: sub-lane e % LPV, group e / LPV of its slice
       const int e = fill[k]++, w = k / VPW;
       return (sbase[w] + e / LPV) * pe::W + (k % VPW) * LPV + e % LPV;
     };
     for (size_t a = 0; a < na; ++a) { // ascending factor order per (vertex, sub-lane): the order of the sums
-      const size_t f = active_indices[a];
-      const int ki = l2k[device_ids[f * 2]], kj = l2k[device_ids[f * 2 + 1]];
-      lij[2 * a] = (int)device_ids[f * 2]; lij[2 * a + 1] = (int)device_ids[f * 2 + 1];
+      const int ki = lij[2 * a] >= 0 ? l2k[lij[2 * a]] : -1, kj = lij[2 * a + 1] >= 0 ? l2k[lij[2 * a + 1]] : -1;
       if (ki >= 0) { const int slot = slot_of(ki); pos[2 * a] = slot; enbr[slot] = kj; efac[slot] = (int)(2 * a); }
       if (kj >= 0) { const int slot = slot_of(kj); pos[2 * a + 1] = slot; enbr[slot] = ki; efac[slot] = (int)(2 * a + 1); }
     }
     lap("lists");
     bf.sbase.assign(sbase.data(), sbase.size()); bf.enbr.assign(enbr.data(), enbr.size()); bf.efac.assign(efac.data(), efac.size()); bf.k2l.assign(k2l.data(), k2l.size()); bf.pos.assign(pos.data(), pos.size()); bf.lij.assign(lij.data(), lij.size());
-    bf.key_epoch_f = this->structure_epoch; bf.key_epoch_v = vd->structure_epoch; bf.key_na = na; bf.key_nvl = nvl; bf.key_dim = hessian_dim; bf.key_digest = dg;
+    bf.key_f = key_f; bf.key_epoch_v = vi.epoch; bf.key_nvl = nvl; bf.key_dim = hessian_dim; bf.key_digest = dg;
     bf.c_NV = NV; bf.c_NVp = NVp; bf.c_lg = lg; bf.c_nslices = nslices; bf.c_ngroups = ngroups;
     bf.have_structure = true;
-    } else lap("structure cache hit (epochs + digests)");
-    const int LPV = 1 << lg;
-    bf.frec.resize_uninit(2 * na * (size_t)(2 * (2 * DD + D))); bf.B.resize_uninit(ngroups * DD * pe::W);
-    const size_t per_vertex = (size_t)(2 * DD + 3 * D), per_vec = (size_t)6 * D;
-    bf.vert.resize_uninit(per_vertex * NVp); bf.vec.resize_uninit(per_vec * NVp); bf.ex.resize_uninit((size_t)NVp * 2 * D);
-    bf.dx.resize_uninit(hessian_dim);
-    const size_t ntr = o.iterations + 1;
-    bf.sums.resize_uninit((size_t)2 * pe::MAX_GRID * 2 * 2); bf.part_rho.resize_uninit((size_t)pe::MAX_GRID * pe::WPB); bf.tr.resize_uninit(2 * ntr); bf.clock.resize_uninit(ntr);
-    const int nbe = blocks(na);
-    bf.part_chi2.resize_uninit((size_t)nbe);
-    bf.ctl.resize_uninit(1); bf.fail.resize_uninit(1);
-    if (!tables_mirrored) refresh_table_mirrors(false);
-    else if (m_pmat.get(precision_matrices, true) == precision_matrices.raw()) m_pmat.refresh(precision_matrices); // (the light initialisation leaves the precision matrices in pinned host memory)
+  } else lap("structure cache hit (epochs + digests)");
+  const int LPV = 1 << lg;
+  bf.frec.resize_uninit(2 * na * (size_t)(2 * (2 * DD + D))); bf.B.resize_uninit(ngroups * DD * pe::W);
+  const size_t per_vertex = (size_t)(2 * DD + 3 * D), per_vec = (size_t)6 * D;
+  bf.vert.resize_uninit(per_vertex * NVp); bf.vec.resize_uninit(per_vec * NVp); bf.ex.resize_uninit((size_t)NVp * 2 * D);
+  bf.dx.resize_uninit(hessian_dim);
+  const size_t ntr = o.iterations + 1;
+  bf.sums.resize_uninit((size_t)2 * pe::MAX_GRID * 2 * 2); bf.part_rho.resize_uninit((size_t)pe::MAX_GRID * pe::WPB); bf.tr.resize_uninit(2 * ntr); bf.clock.resize_uninit(ntr);
+  std::vector<int> block0(fds.size() + 1, 0);
+  for (size_t d = 0; d < fds.size(); ++d) block0[d + 1] = block0[d] + blocks(fis[d].active);
+  const int total_blocks = block0[fds.size()];
+  bf.part_chi2.resize_uninit((size_t)std::max(1, total_blocks));
+  bf.ctl.resize_uninit(1); bf.fail.resize_uninit(1);
+  lap("buffers + uploads");
 
-    lap("buffers + uploads");
-    // ---- launch shapes ----
-    int dev = 0, cus = 0, per_cu = 0;
-    GRAPHITE_HIP(hipGetDevice(&dev));
-    GRAPHITE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    // (the one-pass form keeps a vertex's state in registers: only when the grid has a wave for every slice, and blocks of at most 4 x 4)
-    constexpr bool CAN_ONE_PASS = DD <= 16;
-    auto *solve_multi = &pe::k_pe_solve<T, VTr, D, (int)E, false>;
-    auto *solve_one = &pe::k_pe_solve<T, VTr, D, (int)E, CAN_ONE_PASS>;
-    int per_cu_one = 0;
-    GRAPHITE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, solve_multi, pe::W * pe::WPB, 0));
-    GRAPHITE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_one, solve_one, pe::W * pe::WPB, 0));
-    const int G_all = (nslices + pe::WPB - 1) / pe::WPB;
-    const int max_grid = getenv("GRAPHITE_POSE_MAX_GRID") ? std::max(1, std::min(pe::MAX_GRID, atoi(getenv("GRAPHITE_POSE_MAX_GRID")))) : pe::MAX_GRID; // (tests: a small grid walks several slices per wave)
-    const bool one_pass = CAN_ONE_PASS && G_all <= std::min(max_grid, per_cu_one * cus) && !(getenv("GRAPHITE_POSE_ONE_PASS") && atoi(getenv("GRAPHITE_POSE_ONE_PASS")) == 0);
-    auto *solve_kernel = one_pass ? solve_one : solve_multi;
-    if (one_pass) per_cu = per_cu_one;
-    const int G = std::max(1, std::min(std::min(G_all, max_grid), per_cu * cus));
-    if (per_cu < 1) { res.declined = "the solve kernel does not fit a compute unit"; return -1; }
+  // ---- launch shapes ----
+  int dev = 0, cus = 0;
+  GRAPHITE_HIP(hipGetDevice(&dev));
+  GRAPHITE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // (the one-pass form keeps a vertex's state in registers: only when the grid has a wave for every slice, and blocks of at most 4 x 4)
+  const int per_cu_multi = vd->pose_engine_occupancy(false), per_cu_one = vd->pose_engine_occupancy(true);
+  if (per_cu_multi < 1) { res.declined = "the solve kernel does not fit a compute unit"; return -1; }
+  const int G_all = (nslices + pe::WPB - 1) / pe::WPB;
+  const int max_grid = getenv("GRAPHITE_POSE_MAX_GRID") ? std::max(1, std::min(pe::MAX_GRID, atoi(getenv("GRAPHITE_POSE_MAX_GRID")))) : pe::MAX_GRID; // (tests: a small grid walks several slices per wave)
+  const bool one_pass = per_cu_one >= 1 && G_all <= std::min(max_grid, per_cu_one * cus) && !(getenv("GRAPHITE_POSE_ONE_PASS") && atoi(getenv("GRAPHITE_POSE_ONE_PASS")) == 0);
+  const int G = std::max(1, std::min(std::min(G_all, max_grid), (one_pass ? per_cu_one : per_cu_multi) * cus));
+  lap("occupancy query");
+  res.detail += std::to_string(NV) + " vertices x " + std::to_string(LPV) + " lanes, " + std::to_string(ngroups) + " entry groups, " + std::to_string(fds.size()) + " factor descriptor(s), grid " +
+                std::to_string(G) + " x " + std::to_string(pe::W * pe::WPB) + (one_pass ? ", state in registers" : ", state in memory");
+  pe::Ctl h{};
+  h.mu = o.initial_damping; h.nu = 2; h.fresh = 1;
+  GRAPHITE_HIP(hipMemcpy(bf.ctl.raw(), &h, sizeof(h), hipMemcpyHostToDevice));
+  GRAPHITE_HIP(hipMemset(bf.fail.raw(), 0, sizeof(int)));
+  GRAPHITE_HIP(hipMemsetAsync(bf.sums.raw(), 0, bf.sums.size() * sizeof(double), nullptr)); // no record carries a tag of this call
+  // padding slots of the entry blocks are never written: the operator multiplies their zeros
+  GRAPHITE_HIP(hipMemsetAsync(bf.B.raw(), 0, bf.B.size() * sizeof(T), nullptr));
 
-    lap("occupancy query");
-    res.detail += std::to_string(NV) + " vertices x " + std::to_string(LPV) + " lanes, " + std::to_string(ngroups) + " entry groups, grid " + std::to_string(G) + " x " + std::to_string(pe::W * pe::WPB) + (one_pass ? ", state in registers" : ", state in memory");
-    pe::Ctl h{};
-    h.mu = o.initial_damping; h.nu = 2; h.fresh = 1;
-    GRAPHITE_HIP(hipMemcpy(bf.ctl.raw(), &h, sizeof(h), hipMemcpyHostToDevice));
-    GRAPHITE_HIP(hipMemset(bf.fail.raw(), 0, sizeof(int)));
-    GRAPHITE_HIP(hipMemsetAsync(bf.sums.raw(), 0, bf.sums.size() * sizeof(double), nullptr)); // no record carries a tag of this call
-    // padding slots of the entry blocks are never written: the operator multiplies their zeros
-    GRAPHITE_HIP(hipMemsetAsync(bf.B.raw(), 0, bf.B.size() * sizeof(T), nullptr));
-
-    pe::SolveArgs<T> sa{};
-    sa.NV = NV; sa.NVp = NVp; sa.lg = lg; sa.nslices = nslices; sa.sbase = bf.sbase.raw(); sa.enbr = bf.enbr.raw(); sa.k2l = bf.k2l.raw();
-    sa.efac = bf.efac.raw(); sa.frec = bf.frec.raw(); sa.na = na; sa.B = bf.B.raw();
-    T *vp = bf.vert.raw();
-    sa.Hs = vp; sa.Minv = vp + (size_t)DD * NVp; sa.s = vp + (size_t)2 * DD * NVp; sa.b = sa.s + (size_t)D * NVp; sa.dg = sa.b + (size_t)D * NVp;
-    T *vv = bf.vec.raw();
-    sa.x = vv; sa.xb = vv + (size_t)D * NVp; sa.r = vv + (size_t)2 * D * NVp; sa.t = vv + (size_t)3 * D * NVp; sa.p = vv + (size_t)4 * D * NVp; sa.y = vv + (size_t)5 * D * NVp;
-    sa.ex = bf.ex.raw(); sa.sums = bf.sums.raw(); sa.part_rho = bf.part_rho.raw(); sa.fail = bf.fail.raw(); sa.ctl = bf.ctl.raw();
-    sa.max_iter = o.pcg_max_iter; sa.identity_precond = o.identity_precond; sa.use_identity = o.use_identity; sa.scale_system = o.scale_system;
-    sa.tol = o.pcg_tol; sa.rej = o.pcg_rej;
-    const bool debug = getenv("GRAPHITE_POSE_DEBUG") && atoi(getenv("GRAPHITE_POSE_DEBUG")) != 0;
-    if (debug) { bf.dbg.resize(64); sa.dbg = bf.dbg.raw(); }
-    sa.var = getenv("GRAPHITE_POSE_VAR") ? atoi(getenv("GRAPHITE_POSE_VAR")) : 0;
-    sa.timeout = (sa.var & 256) ? 2000000ll : 200000000ll;
-    if ((sa.var & 256) && bf.prefer_cooperative) sa.var &= ~256; // (the test's failure happens once)
-    sa.graph_b = graph_b; sa.graph_scales = graph_scales; sa.dx = bf.dx.raw();
-    pe::FactorArgs<T> fa{};
-    fa.ctl = bf.ctl.raw(); fa.part = bf.part_chi2.raw(); fa.part_rho = bf.part_rho.raw(); fa.n_rho = G * pe::WPB;
-    fa.na = na; fa.tr_chi2 = bf.tr.raw(); fa.tr_mu = bf.tr.raw() + ntr; fa.tr_clock = bf.clock.raw(); fa.pos = bf.pos.raw(); fa.lij = bf.lij.raw();
-    fa.frec = bf.frec.raw(); fa.early = o.early_stop ? 1 : 0;
-
-    auto fv = view();
-    auto *backup = vd->backup_ptr();
-    auto *vmirror = vd->mirror.raw();
-    constexpr auto seq = std::make_index_sequence<N>{};
-    res.setup_seconds = std::chrono::duration<double>(clk::now() - t_begin).count();
-    size_t stage_bytes = (size_t)TPB * (2 * (2 * DD + D)) * sizeof(T);
-    if (stage_bytes > 96 * 1024) stage_bytes = 0; // (written directly, see k_pe_factor)
-    if (stage_bytes > 64 * 1024) GRAPHITE_HIP(hipFuncSetAttribute((const void *)&pe::k_pe_factor<FactorDescriptor, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes));
-    const auto t_loop = clk::now();
-    pe::k_pe_factor<FactorDescriptor><<<nbe, TPB, stage_bytes>>>(fv, fa, vmirror, 0, seq);
-    size_t enq = 0;
-    // The solve needs its whole grid resident (rendezvous inside the launch).  The grid is sized to fit (occupancy query above), so a
-    // PLAIN launch into an idle device is resident; hipLaunchCooperativeKernel guarantees it but costs 22 us more per launch and 11 ms
-    // at its first use in a process (measured, 10 k poses).  Plain by default; a rendezvous that times out (another process or stream
-    // holds CUs) fails the call over to the generic kernels from the untouched start and makes later calls cooperative.
-    // GRAPHITE_POSE_COOP=1 / 0 forces either.
-    bool coop = bf.prefer_cooperative;
-    if (getenv("GRAPHITE_POSE_COOP")) coop = atoi(getenv("GRAPHITE_POSE_COOP")) != 0;
-    res.detail += coop ? ", cooperative launch" : ", plain launch";
-    const size_t vbytes = vd->count() * sizeof(typename VD0::VertexType);
-    bf.start.resize_uninit(vbytes);
-    GRAPHITE_HIP(hipMemcpyAsync(bf.start.raw(), vd->mirror.raw(), vbytes, hipMemcpyDeviceToDevice, nullptr));
-    for (size_t i = 0; i < o.iterations; ++i) {
-      if (coop) {
-        void *args[] = {(void *)&sa, (void *)&vmirror, (void *)&backup};
-        GRAPHITE_HIP(hipLaunchCooperativeKernel((const void *)solve_kernel, dim3(G), dim3(pe::W * pe::WPB), args, 0, nullptr));
-      } else if (one_pass) pe::k_pe_solve<T, VTr, D, (int)E, CAN_ONE_PASS><<<G, pe::W * pe::WPB>>>(sa, vmirror, backup);
-      else pe::k_pe_solve<T, VTr, D, (int)E, false><<<G, pe::W * pe::WPB>>>(sa, vmirror, backup);
-      pe::k_pe_factor<FactorDescriptor><<<nbe, TPB, stage_bytes>>>(fv, fa, vmirror, 1, seq);
-        ++enq;
-      if (o.stop_flag) { // the caller may ask between iterations (levenberg_marquardt.hpp:232): keep the loop in step with the host
-        sync();
-        if (*o.stop_flag) { res.stop_bits |= 8; break; }
-        GRAPHITE_HIP(hipMemcpy(&h, bf.ctl.raw(), sizeof(h), hipMemcpyDeviceToHost));
-        if (h.stop) break;
-      }
+  pe::SolveArgs<T> sa{};
+  sa.NV = NV; sa.NVp = NVp; sa.lg = lg; sa.nslices = nslices; sa.sbase = bf.sbase.raw(); sa.enbr = bf.enbr.raw(); sa.k2l = bf.k2l.raw();
+  sa.efac = bf.efac.raw(); sa.frec = bf.frec.raw(); sa.na = na; sa.B = bf.B.raw();
+  T *vp = bf.vert.raw();
+  sa.Hs = vp; sa.Minv = vp + (size_t)DD * NVp; sa.s = vp + (size_t)2 * DD * NVp; sa.b = sa.s + (size_t)D * NVp; sa.dg = sa.b + (size_t)D * NVp;
+  T *vv = bf.vec.raw();
+  sa.x = vv; sa.xb = vv + (size_t)D * NVp; sa.r = vv + (size_t)2 * D * NVp; sa.t = vv + (size_t)3 * D * NVp; sa.p = vv + (size_t)4 * D * NVp; sa.y = vv + (size_t)5 * D * NVp;
+  sa.ex = bf.ex.raw(); sa.sums = bf.sums.raw(); sa.part_rho = bf.part_rho.raw(); sa.fail = bf.fail.raw(); sa.ctl = bf.ctl.raw();
+  sa.max_iter = o.pcg_max_iter; sa.identity_precond = o.identity_precond; sa.use_identity = o.use_identity; sa.scale_system = o.scale_system;
+  sa.tol = o.pcg_tol; sa.rej = o.pcg_rej;
+  const bool debug = getenv("GRAPHITE_POSE_DEBUG") && atoi(getenv("GRAPHITE_POSE_DEBUG")) != 0;
+  if (debug) { bf.dbg.resize(64); sa.dbg = bf.dbg.raw(); }
+  sa.var = getenv("GRAPHITE_POSE_VAR") ? atoi(getenv("GRAPHITE_POSE_VAR")) : 0;
+  sa.timeout = (sa.var & 256) ? 2000000ll : 200000000ll;
+  if ((sa.var & 256) && bf.prefer_cooperative) sa.var &= ~256; // (the test's failure happens once)
+  sa.graph_b = graph->get_b().raw(); sa.graph_scales = graph->get_jacobian_scales().raw(); sa.dx = bf.dx.raw();
+  pe::FactorArgs<T> fa{};
+  fa.ctl = bf.ctl.raw(); fa.part = bf.part_chi2.raw(); fa.part_rho = bf.part_rho.raw(); fa.n_rho = G * pe::WPB;
+  fa.na_all = na; fa.total_blocks = total_blocks; fa.tr_chi2 = bf.tr.raw(); fa.tr_mu = bf.tr.raw() + ntr; fa.tr_clock = bf.clock.raw(); fa.pos = bf.pos.raw(); fa.lij = bf.lij.raw();
+  fa.frec = bf.frec.raw(); fa.early = o.early_stop ? 1 : 0;
+  auto factor_pass = [&](int mode) {
+    for (size_t d = 0; d < fds.size(); ++d) {
+      if (!fis[d].active) continue;
+      pe::FactorArgs<T> f = fa;
+      f.na = fis[d].active; f.a0 = a0[d]; f.block0 = block0[d];
+      fds[d]->pose_engine_launch(f, vi.mirror, mode);
     }
-    pe::k_pe_finish<VTr><<<blocks((size_t)NV), TPB>>>(bf.ctl.raw(), bf.k2l.raw(), NV, vmirror, backup);
-    sync();
-    res.loop_seconds = std::chrono::duration<double>(clk::now() - t_loop).count();
-    GRAPHITE_HIP(hipMemcpy(&h, bf.ctl.raw(), sizeof(h), hipMemcpyDeviceToHost));
-    int failed = 0;
-    GRAPHITE_HIP(hipMemcpy(&failed, bf.fail.raw(), sizeof(int), hipMemcpyDeviceToHost));
-    if (failed || (h.stop & 16)) {
-      GRAPHITE_HIP(hipMemcpy(vd->mirror.raw(), bf.start.raw(), vbytes, hipMemcpyDeviceToDevice)); // the vertices as the call found them
-      bf.prefer_cooperative = true;
-      res.stop_bits |= 16; res.ok = false;
-      res.declined = "a rendezvous inside the solve timed out (its grid was not fully resident: the device is shared); later calls use a cooperative launch";
-      return 1;
+  };
+
+  // The solve needs its whole grid resident (rendezvous inside the launch).  The grid is sized to fit (occupancy query above), so a
+  // PLAIN launch into an idle device is resident; hipLaunchCooperativeKernel guarantees it but costs 22 us more per launch and 11 ms
+  // at its first use in a process (measured, 10 k poses).  Plain by default; a rendezvous that times out (another process or stream
+  // holds CUs) fails the call over to the generic kernels from the untouched start and makes later calls cooperative.
+  // GRAPHITE_POSE_COOP=1 / 0 forces either.
+  bool coop = bf.prefer_cooperative;
+  if (getenv("GRAPHITE_POSE_COOP")) coop = atoi(getenv("GRAPHITE_POSE_COOP")) != 0;
+  res.detail += coop ? ", cooperative launch" : ", plain launch";
+  const size_t vbytes = vi.count * vi.vertex_bytes;
+  bf.start.resize_uninit(vbytes);
+  GRAPHITE_HIP(hipMemcpyAsync(bf.start.raw(), vi.mirror, vbytes, hipMemcpyDeviceToDevice, nullptr));
+  res.setup_seconds = std::chrono::duration<double>(clk::now() - t_begin).count();
+  const auto t_loop = clk::now();
+  factor_pass(0);
+  for (size_t i = 0; i < o.iterations; ++i) {
+    vd->pose_engine_solve(sa, G, coop, one_pass);
+    factor_pass(1);
+    if (o.stop_flag) { // the caller may ask between iterations (levenberg_marquardt.hpp:232): keep the loop in step with the host
+      sync();
+      if (*o.stop_flag) { res.stop_bits |= 8; break; }
+      GRAPHITE_HIP(hipMemcpy(&h, bf.ctl.raw(), sizeof(h), hipMemcpyDeviceToHost));
+      if (h.stop) break;
     }
-    if (debug) { // the LAST solve's stamps
-      const std::vector<long long> d = bf.dbg.to_host();
-      std::cerr << "[graphite] pose-graph engine, last solve, workgroup 0 (us since its start; start | assemble+invert | sums | then per PCG iteration: operator | sums | update | sums ... | step):";
-      for (int i = 1; i < (int)d[63] && i < 63; ++i) std::cerr << " " << (double)(d[i] - d[i - 1]) * 0.01;
-      std::cerr << std::endl;
-    }
-    const std::vector<double> tr = bf.tr.to_host();
-    const std::vector<long long> ck = bf.clock.to_host();
-    res.iterations_run = h.it; res.accepted = h.accepted; res.pcg_iterations = h.pcg_its; res.stop_bits |= h.stop;
-    res.chi2.assign(tr.begin(), tr.begin() + h.it + 1);
-    res.lambda.assign(tr.begin() + ntr, tr.begin() + ntr + h.it + 1);
-    res.seconds.resize(h.it);
-    for (int i = 0; i < h.it; ++i) res.seconds[i] = (double)(ck[i + 1] - ck[i]) * 1.0e-8; // the 100 MHz wall clock
-    res.ok = !(h.stop & 1);
-    (void)enq;
-    return 0;
   }
+  vd->pose_engine_finish(bf.ctl.raw(), bf.k2l.raw(), NV);
+  sync();
+  res.loop_seconds = std::chrono::duration<double>(clk::now() - t_loop).count();
+  GRAPHITE_HIP(hipMemcpy(&h, bf.ctl.raw(), sizeof(h), hipMemcpyDeviceToHost));
+  int failed = 0;
+  GRAPHITE_HIP(hipMemcpy(&failed, bf.fail.raw(), sizeof(int), hipMemcpyDeviceToHost));
+  if (failed || (h.stop & 16)) {
+    GRAPHITE_HIP(hipMemcpy(vi.mirror, bf.start.raw(), vbytes, hipMemcpyDeviceToDevice)); // the vertices as the call found them
+    bf.prefer_cooperative = true;
+    res.stop_bits |= 16; res.ok = false;
+    res.declined = "a rendezvous inside the solve timed out (its grid was not fully resident: the device is shared); later calls use a cooperative launch";
+    return 1;
+  }
+  if (debug) { // the LAST solve's stamps
+    const std::vector<long long> d = bf.dbg.to_host();
+    std::cerr << "[graphite] pose-graph engine, last solve, workgroup 0 (us since its start; start | assemble+invert | sums | then per PCG iteration: operator | sums | update | sums ... | step):";
+    for (int i = 1; i < (int)d[63] && i < 63; ++i) std::cerr << " " << (double)(d[i] - d[i - 1]) * 0.01;
+    std::cerr << std::endl;
+  }
+  const std::vector<double> tr = bf.tr.to_host();
+  const std::vector<long long> ck = bf.clock.to_host();
+  res.iterations_run = h.it; res.accepted = h.accepted; res.pcg_iterations = h.pcg_its; res.stop_bits |= h.stop;
+  res.chi2.assign(tr.begin(), tr.begin() + h.it + 1);
+  res.lambda.assign(tr.begin() + ntr, tr.begin() + ntr + h.it + 1);
+  res.seconds.resize(h.it);
+  for (int i = 0; i < h.it; ++i) res.seconds[i] = (double)(ck[i + 1] - ck[i]) * 1.0e-8; // the 100 MHz wall clock
+  res.ok = !(h.stop & 1);
+  return 0;
 }
+} // namespace detail
 
 } // namespace graphite

@@ -717,10 +717,12 @@ template <typename T, typename S>
 bool pose_engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T, S> *options, bool early_stop, bool &result) {
   if (getenv("GRAPHITE_POSE_ENGINE") && atoi(getenv("GRAPHITE_POSE_ENGINE")) == 0) return false;
   auto *vd = graph->get_vertex_descriptors()[0];
-  auto *fd = graph->get_factor_descriptors()[0];
   const bool verbose_why = getenv("GR_VERBOSE") != nullptr;
   auto why = [&](const std::string &w) { if (verbose_why) std::cerr << "[graphite] pose-graph engine: " << w << "; using the generic kernels" << std::endl; return false; };
-  if (fd->slot_descriptor(0) != vd || fd->slot_descriptor(1) != vd) return why("the factor's slots are not the graph's vertex descriptor");
+  for (auto *fd : graph->get_factor_descriptors()) {
+    if (fd->num_slots() > 2) return why("a factor descriptor with more than two slots");
+    for (size_t sl = 0; sl < fd->num_slots(); ++sl) if (fd->slot_descriptor(sl) != vd) return why("a factor slot that is not the graph's vertex descriptor");
+  }
   if (vd->eliminate) return why("the vertex descriptor is marked for elimination");
   const int kind = options->solver->engine_kind(vd->count());
   if (kind != GR_SOLVER_PCG && kind != GR_SOLVER_PCG_IDENTITY) return why("the solver is not PCGSolver with the block-Jacobi or identity preconditioner");
@@ -737,7 +739,7 @@ bool pose_engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptio
   int rc;
   {
     typename Graph<T, S>::DeviceMirrorScope mirror_scope(graph); // written back into the user's vertices on the way out
-    rc = fd->pose_engine_lm(o, r, graph->get_b().raw(), graph->get_jacobian_scales().raw(), graph->get_hessian_dimension());
+    rc = graphite::detail::pose_engine_run(graph, o, r);
     if (rc == 0) { graph->compute_error(); graphite::detail::sync(); } // the residuals of the optimised vertices, as the generic loop leaves them
   }
   if (rc < 0) return why(r.declined);
@@ -783,7 +785,7 @@ bool engine_levenberg_marquardt(Graph<T, S> *graph, LevenbergMarquardtOptions<T,
   }
   auto &vds = graph->get_vertex_descriptors();
   auto &fds = graph->get_factor_descriptors();
-  if (vds.size() == 1 && fds.size() == 1 && fds[0]->num_slots() == 2) return pose_engine_levenberg_marquardt(graph, options, early_stop, result);
+  if (vds.size() == 1 && !fds.empty()) return pose_engine_levenberg_marquardt(graph, options, early_stop, result); // (no BAL shape has one vertex descriptor)
   if (vds.size() != 2 || fds.size() != 1 || fds[0]->num_slots() != 2) return false;
   auto *cd = fds[0]->slot_descriptor(0), *pd = fds[0]->slot_descriptor(1);
   if (cd == pd || cd->dimension() > 9 || pd->dimension() > 3 || fds[0]->error_dimension() > 2 || cd->eliminate) return false;

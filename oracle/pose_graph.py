@@ -28,7 +28,9 @@ EPS = np.finfo(np.float64).eps
 
 
 class PoseGraphOracle:
-    def __init__(self, poses, fixed, edges, meas, info, huber_delta=0.0):
+    def __init__(self, poses, fixed, edges, meas, info, huber_delta=0.0, priors=None):
+        """priors = (vertex ids, measurements [n, 3], information matrices [n, 3, 3]): a SECOND factor descriptor of unary factors
+        e = x_i - m (Jacobian = identity), default loss — the graph then has two factor descriptors on its one vertex descriptor"""
         self.x = np.array(poses, dtype=np.float64).reshape(-1, 3).copy()
         self.n = len(self.x)
         self.fixed = np.asarray(fixed).astype(bool)
@@ -37,9 +39,14 @@ class PoseGraphOracle:
         self.meas = np.asarray(meas, dtype=np.float64)
         self.P = np.asarray(info, dtype=np.float64)          # [F, 3, 3], read row-major
         self.delta = float(huber_delta)
+        if priors is None:
+            self.pi = np.zeros(0, np.int64); self.pm = np.zeros((0, 3)); self.pP = np.zeros((0, 3, 3))
+        else:
+            self.pi = np.asarray(priors[0]).astype(np.int64); self.pm = np.asarray(priors[1], dtype=np.float64).reshape(-1, 3)
+            self.pP = np.asarray(priors[2], dtype=np.float64).reshape(-1, 3, 3)
         # Graph::initialize_optimization: columns for the active vertices in vertex order
         used = np.zeros(self.n, bool)
-        used[self.i] = True; used[self.j] = True
+        used[self.i] = True; used[self.j] = True; used[self.pi] = True
         self.active = used & ~self.fixed
         self.col = np.full(self.n, -1, np.int64)
         self.col[self.active] = 3 * np.arange(int(self.active.sum()))
@@ -69,6 +76,7 @@ class PoseGraphOracle:
 
     def compute_error(self):
         self.r = self._error()
+        self.pr = self.x[self.pi] - self.pm
 
     def chi2(self):
         raw = np.einsum("fi,fij,fj->f", self.r, self.P, self.r)
@@ -80,6 +88,8 @@ class PoseGraphOracle:
             val = raw; self.dchi2 = np.ones_like(raw)
         tot = 0.0
         for v in val:       # sequential, factor order
+            tot += v
+        for v in np.einsum("fi,fij,fj->f", self.pr, self.pP, self.pr):   # the prior descriptor's factors, default loss
             tot += v
         return tot
 
@@ -96,6 +106,8 @@ class PoseGraphOracle:
                 d = np.einsum("fad,fad->fd", J, PJ) * w[:, None]
                 m = self.active[v]
                 np.add.at(diag, (self.col[v[m]][:, None] + np.arange(3)[None, :]).ravel(), d[m].ravel())
+            pa = self.active[self.pi]
+            np.add.at(diag, (self.col[self.pi[pa]][:, None] + np.arange(3)[None, :]).ravel(), np.einsum("fdd->fd", self.pP)[pa].ravel())
             self.scales = 1.0 / (EPS + np.sqrt(diag))
         else:
             self.scales = np.ones(self.dim)
@@ -110,6 +122,12 @@ class PoseGraphOracle:
             g = -np.einsum("fad,fa->fd", J, Pr)
             m = self.active[v]
             np.add.at(self.b, (self.col[v[m]][:, None] + np.arange(3)[None, :]).ravel(), g[m].ravel())
+        # the priors: J = diag(scales of the vertex), b -= J^T P r
+        pa = self.active[self.pi]
+        self.pS = np.zeros((len(self.pi), 3))
+        self.pS[pa] = self.scales[self.col[self.pi[pa]][:, None] + np.arange(3)[None, :]]
+        gp = -self.pS * np.einsum("fab,fb->fa", self.pP, self.pr)
+        np.add.at(self.b, (self.col[self.pi[pa]][:, None] + np.arange(3)[None, :]).ravel(), gp[pa].ravel())
 
     # ---- BlockJacobiPreconditioner ---------------------------------------------------------------------------------------------
     def block_diagonal(self):
@@ -119,6 +137,8 @@ class PoseGraphOracle:
             blk = np.einsum("fad,fab,fbe->fde", J, self.P, J) * self.dchi2[:, None, None]
             m = self.active[v]
             np.add.at(B, self.col[v[m]] // 3, blk[m])
+        pa = self.active[self.pi]
+        np.add.at(B, self.col[self.pi[pa]] // 3, (self.pS[:, :, None] * self.pP * self.pS[:, None, :])[pa])
         self.Bdiag = B
         self.hdiag = np.einsum("kii->ki", B).reshape(-1).copy()
 
@@ -150,6 +170,11 @@ class PoseGraphOracle:
             g = np.einsum("fad,fa->fd", J, u)
             m = self.active[vx]
             np.add.at(y, (self.col[vx[m]][:, None] + np.arange(3)[None, :]).ravel(), g[m].ravel())
+        pa = self.active[self.pi]
+        if pa.any():
+            cols = self.col[self.pi[pa]][:, None] + np.arange(3)[None, :]
+            up = np.einsum("fab,fb->fa", self.pP[pa], self.pS[pa] * v[cols])
+            np.add.at(y, cols.ravel(), (self.pS[pa] * up).ravel())
         return y + self.mu * (1.0 if self.use_identity else diag) * v
 
     def solve_pcg(self, max_iter, tol, rej, identity_precond):

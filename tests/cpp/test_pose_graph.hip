@@ -60,6 +60,20 @@ template <typename T, typename S, typename Mode, template <typename, int> class 
   }
 };
 
+// unary prior on a pose: e = x - m, Jacobian = identity (a SECOND factor descriptor on the same vertex descriptor: the optional PRIORS section of the file)
+template <typename T, typename S> struct Prior2Traits {
+  static constexpr size_t dimension = 3;
+  using VertexDescriptors = std::tuple<Pose2Descriptor<T, S>>;
+  using Observation = Rel2<T>;
+  using Data = Empty;
+  using Loss = DefaultLoss<T, 3>;
+  using Differentiation = DifferentiationMode::Manual;
+  template <typename D> d_fn static void error(const D *a, const Observation &m, D *e) { e[0] = a[0] - D(m.x); e[1] = a[1] - D(m.y); e[2] = a[2] - D(m.th); }
+  template <typename J, size_t I> d_fn static void jacobian(const Pose2<T> &, const Observation &, J *jac) {
+    for (int k = 0; k < 9; ++k) jac[k] = J(k % 4 == 0 ? 1 : 0);
+  }
+};
+
 template <typename T, typename Mode, template <typename, int> class LossT> static int run(int argc, char **argv) {
   using Factor = FactorDescriptor<T, T, Between2Traits<T, T, Mode, LossT>>;
   std::ifstream in(argv[1]);
@@ -89,6 +103,25 @@ template <typename T, typename Mode, template <typename, int> class LossT> stati
     if (!in) { std::cerr << "short file at factor " << f << std::endl; return 2; }
     if constexpr (std::is_same<LossT<T, 3>, HuberLoss<T, 3>>::value) fd.add_factor({i, j}, Rel2<T>{mx, my, mth}, P, Empty(), HuberLoss<T, 3>(delta));
     else fd.add_factor({i, j}, Rel2<T>{mx, my, mth}, P, Empty(), DefaultLoss<T, 3>());
+  }
+  // optional second factor descriptor: unary priors
+  FactorDescriptor<T, T, Prior2Traits<T, T>> pd(&vd);
+  {
+    std::string word;
+    size_t np = 0;
+    if (in >> word >> np && word == "PRIORS") {
+      pd.reserve(np);
+      graph.add_descriptor(&pd);
+      for (size_t q = 0; q < np; ++q) {
+        size_t i;
+        T mx, my, mth, P[9];
+        in >> i >> mx >> my >> mth;
+        for (int k = 0; k < 9; ++k) in >> P[k];
+        if (!in) { std::cerr << "short file at prior " << q << std::endl; return 2; }
+        pd.add_factor({i}, Rel2<T>{mx, my, mth}, P, Empty(), DefaultLoss<T, 3>());
+      }
+      std::cout << "PRIORS " << np << std::endl;
+    }
   }
   // POSE_DEACTIVATE=k: every k-th factor gets activity level 1 (inactive at optimisation level 0: factor.hpp:419-431, active.hpp:11-21);
   // POSE_EXTRA_VERTICES=m: m vertices no factor touches are added behind the poses (they take no part in the optimisation)

@@ -622,3 +622,39 @@ def test_pose_graph_engine_inactive_factors_unused_vertices_identity_damping(tmp
     assert np.allclose(got, o.x, rtol=1e-9, atol=1e-9)
     g = subprocess.run([exe, str(f), "pcg", "8", "manual", "12", "1e-3"], capture_output=True, text=True, timeout=600, env=dict(env, GRAPHITE_GENERIC_ONLY="1"))
     assert g.returncode == 0 and np.allclose(parse_trace(g.stdout)[:, 1], ct[1:], rtol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"GRAPHITE_GENERIC_ONLY": "1"}], ids=["pose-graph-engine", "generic-kernels"])
+def test_pose_graph_with_a_second_factor_descriptor_of_unary_priors(tmp_path, env):
+    """Two factor descriptors on one vertex descriptor — the between-factors and unary priors x_i - m on every seventh pose, each with its own
+    dense information matrix (what a SLAM back end with GPS / map priors builds): through the pose-graph engine (the factor kernel runs once per
+    descriptor, the last workgroup of the last launch decides) and through the generic kernels, against the oracle with the same priors: traces
+    and poses at 1e-9."""
+    from oracle.pose_graph import PoseGraphOracle
+    exe = build_all()[8]
+    n = 2000
+    p0, fx, e, m, info, truth = synth.make_pose_graph(n)
+    rng = np.random.default_rng(5)
+    idx = np.arange(3, n, 7)
+    pm = np.asarray(truth)[idx] + 0.02 * rng.standard_normal((len(idx), 3))
+    L = 0.3 * rng.standard_normal((len(idx), 3, 3)) + 2.0 * np.eye(3)
+    P = np.einsum("fab,fcb->fac", L, L)
+    P = 0.5 * (P + P.transpose(0, 2, 1))
+    f = tmp_path / "graph.txt"
+    out = tmp_path / "poses.txt"
+    synth.write_pose_graph(f, p0, fx, e, m, info, priors=(idx, pm, P))
+    r = subprocess.run([exe, str(f), "pcg", "8", "manual", "10", "1.0", str(out)], capture_output=True, text=True, timeout=600, env=dict(os.environ, GR_VERBOSE="1", **env))
+    assert r.returncode == 0 and f"PRIORS {len(idx)}" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    if env:
+        assert "POSE_ENGINE_HANDOVERS 0" in r.stdout
+    else:
+        assert "POSE_ENGINE_HANDOVERS 1" in r.stdout and "2 factor descriptor(s)" in r.stderr
+    o = PoseGraphOracle(p0, fx, e, m, info, priors=(idx, pm, P))
+    ct, lt, st = o.levenberg_marquardt(iterations=8, pcg_max_iter=10, pcg_tol=1.0)
+    o0 = PoseGraphOracle(p0, fx, e, m, info)
+    ct0, _, _ = o0.levenberg_marquardt(iterations=8, pcg_max_iter=10, pcg_tol=1.0)
+    assert not np.allclose(ct[1:], ct0[1:], rtol=1e-3)  # the priors matter
+    tr = parse_trace(r.stdout)
+    assert len(tr) == len(ct) - 1 and np.allclose(tr[:, 1], ct[1:], rtol=1e-9) and np.allclose(tr[:, 2], lt[1:], rtol=1e-8)
+    assert np.allclose(np.loadtxt(out), o.x, rtol=1e-9, atol=1e-9)

@@ -73,3 +73,37 @@ def test_lm_descends_keeps_fixed_vertices_and_huber_changes_the_trace():
     oh, _ = _graph(200, huber=0.05)
     cth, _, _ = oh.levenberg_marquardt(iterations=8)
     assert cth[0] < ct[0] and not np.allclose(cth[1:], ct[1:], rtol=1e-3)
+
+
+def test_priors_as_a_second_factor_descriptor_match_dense_numpy():
+    p0, fx, e, m, info, truth = synth.make_pose_graph(120)
+    rng = np.random.default_rng(1)
+    idx = np.arange(5, 120, 7)
+    pm = np.asarray(truth)[idx] + 0.01 * rng.standard_normal((len(idx), 3))
+    L = 0.3 * rng.standard_normal((len(idx), 3, 3)) + 2.0 * np.eye(3)
+    P = np.einsum("fab,fcb->fac", L, L)
+    P = 0.5 * (P + P.transpose(0, 2, 1))
+    o = PoseGraphOracle(p0, fx, e, m, info, priors=(idx, pm, P))
+    o.linearize(); o.block_diagonal(); o.set_damping(1e-3, False)
+    F, n = len(o.i), o.dim
+    J = np.zeros((3 * F + 3 * len(idx), n)); W = np.zeros((J.shape[0], J.shape[0]))
+    r = np.concatenate([o.r.ravel(), o.pr.ravel()])
+    for f in range(F):
+        for blk, v in ((o.Ji[f], o.i[f]), (o.Jj[f], o.j[f])):
+            if o.active[v]:
+                J[3 * f:3 * f + 3, o.col[v]:o.col[v] + 3] += blk
+        W[3 * f:3 * f + 3, 3 * f:3 * f + 3] = o.dchi2[f] * o.P[f]
+    for q, v in enumerate(idx):
+        rr = 3 * F + 3 * q
+        if o.active[v]:
+            J[rr:rr + 3, o.col[v]:o.col[v] + 3] = np.diag(o.scales[o.col[v]:o.col[v] + 3])
+        W[rr:rr + 3, rr:rr + 3] = P[q]
+    H = J.T @ W @ J
+    v = rng.standard_normal(n)
+    diag = np.clip(o.hdiag, 1e-6, 1e32)
+    assert np.allclose(o.b, -J.T @ W @ r, rtol=1e-12, atol=1e-12)
+    assert np.allclose(o.operator(v, diag), H @ v + 1e-3 * diag * v, rtol=1e-11, atol=1e-11)
+    assert np.allclose(np.diag(H), o.hdiag, rtol=1e-12)
+    assert abs(o.chi2() - r @ W @ r) < 1e-9 * abs(r @ W @ r)
+    ct, _, st = o.levenberg_marquardt(iterations=6)
+    assert st["accepted"] >= 4 and ct[-1] < ct[0]
