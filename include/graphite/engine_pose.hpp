@@ -1,5 +1,5 @@
-// graphite/engine_pose.hpp — POSE-GRAPH ENGINE: levenberg_marquardt + PCGSolver on a graph of BINARY factors between vertices of
-// ONE descriptor (pose–pose "between" factors: the SLAM back-end shape of the reference's README.md:27), device-resident, gfx950.
+// graphite/engine_pose.hpp — POSE-GRAPH ENGINE: levenberg_marquardt + PCGSolver on a graph whose factors are unary or BINARY between vertices
+// of ONE descriptor (pose–pose "between" factors and priors: the SLAM back-end shape of the reference's README.md:27), device-resident, gfx950.
 //
 // The generic kernels (core.hpp / solve.hpp) follow the reference launch by launch: per LM iteration ~25 launches and several
 // host round trips for the linearisation, ~9 launches per PCG iteration (1.0 ms per LM iteration on 10 k poses / 48.6 k factors,
@@ -25,9 +25,11 @@
 // stored write-through and read with sc1 loads (cdna_hip_programming.md Guideline 16, form R1).  The recurrence is the LAZY form
 // of kernels_rp.hpp: p_k = sigma_k z'_k + beta_k p_{k-1} is formed where it is used, so beta needs no pass of its own.
 //
-// Fits: one vertex descriptor, one factor descriptor with N == 2 and both slots that descriptor, T == S, vertex / state types
-// trivially copyable, tangent and error dimension <= 7, symmetric precision matrices, PCGSolver with the block-Jacobi or identity
-// preconditioner.  Anything else stays on the generic kernels.  GRAPHITE_POSE_ENGINE=0 switches it off.
+// Fits: ONE vertex descriptor and any number of factor descriptors that are unary or binary on it (between-factors, priors; the
+// reference's circle example is such a graph too), T == S, vertex / state types trivially copyable, tangent and error dimension <= 7,
+// symmetric precision matrices, PCGSolver with the block-Jacobi or identity preconditioner.  Anything else stays on the generic kernels.
+// GRAPHITE_POSE_ENGINE=0 switches it off.  The typed pieces (kernels on a descriptor's traits) sit behind virtuals of the base
+// descriptors (core.hpp); detail::pose_engine_run below drives them.
 #pragma once
 #include "core.hpp"
 
