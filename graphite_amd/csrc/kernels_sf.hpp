@@ -476,9 +476,10 @@ template <bool DRAIN> __device__ __forceinline__ bool coop_exchange(const CoopSt
   const int set = (int)(phase & 1u) * cap;
   if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) {
-    const unsigned long long bits = __builtin_bit_cast(unsigned long long, mine);
+    // (the second half is tag XOR the value's bits: halves of different stores — should a 16-byte access ever be split — carry no valid tag)
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, mine), mark = tag ^ bits;
     sf_u32x4 a;
-    a.x = (unsigned)bits; a.y = (unsigned)(bits >> 32); a.z = (unsigned)tag; a.w = (unsigned)(tag >> 32);
+    a.x = (unsigned)bits; a.y = (unsigned)(bits >> 32); a.z = (unsigned)mark; a.w = (unsigned)(mark >> 32);
     __builtin_amdgcn_raw_buffer_store_b128(a, rr, (set + i) * 16, 0, 16);
   }
   double acc = 0;
@@ -494,7 +495,7 @@ template <bool DRAIN> __device__ __forceinline__ bool coop_exchange(const CoopSt
 #pragma unroll
       for (int u = 0; u < 4; ++u) if (pend & (1u << u)) rec[u] = __builtin_amdgcn_raw_buffer_load_b128(rr, (set + lane + 64 * (c0 + u)) * 16, 0, 16);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if ((pend & (1u << u)) && (((unsigned long long)rec[u].w << 32) | rec[u].z) == tag) pend &= ~(1u << u);
+      for (int u = 0; u < 4; ++u) if ((pend & (1u << u)) && ((((unsigned long long)rec[u].w << 32) | rec[u].z) ^ (((unsigned long long)rec[u].y << 32) | rec[u].x)) == tag) pend &= ~(1u << u);
       if (!__any(pend != 0)) break;
       if (wall_clock64() - t0 > 200000000ll) { ok = false; break; } // 2 s of the 100 MHz clock: the launch's workgroups are not all resident
       __builtin_amdgcn_s_sleep(1);

@@ -138,9 +138,11 @@ template <typename T, int NW> __device__ __forceinline__ void st_rec(__amdgpu_bu
 // record buffer is cleared at set-up); two record sets alternate by epoch parity (a workgroup overwrites its epoch-e record only
 // after every workgroup has announced e + 1, i.e. finished reading e).  A grid that is not fully resident times out (2 s).
 __device__ __forceinline__ void st_sum(__amdgpu_buffer_rsrc_t r, int off, double v, unsigned long long tag) {
-  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+  // the second half is tag XOR the value's bits: a reader that saw the two halves of different stores (should a 16-byte access ever be
+  // split) finds no valid tag and polls again
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v), mark = tag ^ bits;
   u32x4 a;
-  a.x = (unsigned)bits; a.y = (unsigned)(bits >> 32); a.z = (unsigned)tag; a.w = (unsigned)(tag >> 32);
+  a.x = (unsigned)bits; a.y = (unsigned)(bits >> 32); a.z = (unsigned)mark; a.w = (unsigned)(mark >> 32);
   __builtin_amdgcn_raw_buffer_store_b128(a, r, off, 0, SC1);
 }
 // DRAIN: the phase published exchange records that must be acknowledged before the workgroup's record announces them.
@@ -182,7 +184,7 @@ template <int NR, bool DRAIN> __device__ __forceinline__ bool grid_sums(double (
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int i = 0; i < NR; ++i)
-            if ((pend & (1u << (NR * u + i))) && (((unsigned long long)rec[u][i].w << 32) | rec[u][i].z) == tag) pend &= ~(1u << (NR * u + i));
+            if ((pend & (1u << (NR * u + i))) && ((((unsigned long long)rec[u][i].w << 32) | rec[u][i].z) ^ (((unsigned long long)rec[u][i].y << 32) | rec[u][i].x)) == tag) pend &= ~(1u << (NR * u + i));
         if (!__any(pend != 0)) break;
         if (wall_clock64() - t0 > timeout) { ok = false; break; }
         __builtin_amdgcn_s_sleep(1);
