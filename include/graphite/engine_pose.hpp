@@ -240,6 +240,7 @@ template <typename T> struct SolveArgs {
   const T *frec;               // [2][na][2 (2 D D + D)] the factor kernel's records, per side J_v^T W J_v | J_v^T W r | J_v^T W J_other; set ctl->cur is the accepted point's
   size_t na;
   T *B;                        // per entry group, element-major [(group * D D + e) * 64 + lane]: J_v^T W J_nbr, formed by the assemble phase
+  size_t zero_block;           // offset in B of D D x 64 zeros behind the last group (what padding entries multiply)
   T *Hs, *Minv, *s, *b, *dg;   // per vertex, element-major [e * NVp + k]
   T *x, *xb, *r, *t, *p, *y;
   T *ex;                       // [NVp][2 D] s.z' | s.p
@@ -283,6 +284,7 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
   int n_stamp = 0;
   auto stamp = [&]() __attribute__((always_inline)) { if (A.dbg && first_thread && n_stamp < 63) A.dbg[n_stamp++] = wall_clock64(); };
   stamp();
+  long long op_t0 = 0; // (debug: every workgroup's time in the operator phase of the launch's LAST PCG iteration, dbg[64 + blockIdx])
   const __amdgpu_buffer_rsrc_t r_ex = rsrc(A.ex, (size_t)NVp * 2 * D * sizeof(T));
   const __amdgpu_buffer_rsrc_t r_sum = rsrc(A.sums, (size_t)2 * MAX_GRID * 2 * 16);
   constexpr int REC = 2 * D * (int)sizeof(T);
@@ -429,6 +431,7 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
     if (rz == 0) break; // pcg.hpp:133
     // ---- operator: p = sigma z' + beta p;  y = (S J^T rho' P J S + mu D) p;  p . y ------------------------------------------------
     double den[1] = {0};
+    if (A.dbg && threadIdx.x == 0) op_t0 = wall_clock64();
     for (int ws = gwave; ws < last && ws < nslices; ws += step) {
       const int k = ws * VPW + vl, g0 = A.sbase[ws], ng = A.sbase[ws + 1] - g0;
       const bool valid = k < NV, owner = valid && sub == 0;
@@ -462,9 +465,12 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
           for (int u = 0; u < CH; ++u) ld_rec<T, 2 * D>(r_ex, (nb[u] >= 0 ? nb[u] : kk) * REC, rec[u]);
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
+            // (a padding entry reads the ONE zero block behind the last group — the same line for every such lane — instead of its own
+            // slot: on large graphs, where this phase streams the blocks from HBM, a third of the slots are padding)
             const int j = j0 + u < ng ? j0 + u : ng - 1;
+            const size_t base = nb[u] >= 0 ? (size_t)(g0 + j) * DD * W + lane : A.zero_block;
 #pragma unroll
-            for (int e = 0; e < DD; ++e) Bv[u][e] = A.B[((size_t)(g0 + j) * DD + e) * W + lane];
+            for (int e = 0; e < DD; ++e) Bv[u][e] = A.B[base + (size_t)e * W];
           }
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
@@ -495,6 +501,7 @@ __global__ void __launch_bounds__(W * WPB) k_pe_solve(const SolveArgs<T> A, type
         for (int q = 0; q < D; ++q) { PE_AT(y, q, k) = oy[q]; PE_AT(p, q, k) = op[q]; }
       }
     }
+    if (A.dbg && threadIdx.x == 0) A.dbg[64 + blockIdx.x] = wall_clock64() - op_t0;
     stamp();
     if (!grid_sums<1, false>(den, r_sum, launch_tag, epoch, A.fail, s_red, A.timeout)) { if (threadIdx.x == 0) ctl->stop = 16; return; }
     stamp();
@@ -1035,7 +1042,7 @@ int pose_engine_run(Graph<T, S> *graph, const PoseEngineOptions &o, PoseEngineRe
     bf.have_structure = true;
   } else lap("structure cache hit (epochs + digests)");
   const int LPV = 1 << lg;
-  bf.frec.resize_uninit(2 * na * (size_t)(2 * (2 * DD + D))); bf.B.resize_uninit(ngroups * DD * pe::W);
+  bf.frec.resize_uninit(2 * na * (size_t)(2 * (2 * DD + D))); bf.B.resize_uninit((ngroups + 1) * DD * pe::W);
   const size_t per_vertex = (size_t)(2 * DD + 3 * D), per_vec = (size_t)6 * D;
   bf.vert.resize_uninit(per_vertex * NVp); bf.vec.resize_uninit(per_vec * NVp); bf.ex.resize_uninit((size_t)NVp * 2 * D);
   bf.dx.resize_uninit(hessian_dim);
@@ -1072,7 +1079,7 @@ int pose_engine_run(Graph<T, S> *graph, const PoseEngineOptions &o, PoseEngineRe
 
   pe::SolveArgs<T> sa{};
   sa.NV = NV; sa.NVp = NVp; sa.lg = lg; sa.nslices = nslices; sa.sbase = bf.sbase.raw(); sa.enbr = bf.enbr.raw(); sa.k2l = bf.k2l.raw();
-  sa.efac = bf.efac.raw(); sa.frec = bf.frec.raw(); sa.na = na; sa.B = bf.B.raw();
+  sa.efac = bf.efac.raw(); sa.frec = bf.frec.raw(); sa.na = na; sa.B = bf.B.raw(); sa.zero_block = ngroups * (size_t)DD * pe::W;
   T *vp = bf.vert.raw();
   sa.Hs = vp; sa.Minv = vp + (size_t)DD * NVp; sa.s = vp + (size_t)2 * DD * NVp; sa.b = sa.s + (size_t)D * NVp; sa.dg = sa.b + (size_t)D * NVp;
   T *vv = bf.vec.raw();
@@ -1081,7 +1088,7 @@ int pose_engine_run(Graph<T, S> *graph, const PoseEngineOptions &o, PoseEngineRe
   sa.max_iter = o.pcg_max_iter; sa.identity_precond = o.identity_precond; sa.use_identity = o.use_identity; sa.scale_system = o.scale_system;
   sa.tol = o.pcg_tol; sa.rej = o.pcg_rej;
   const bool debug = getenv("GRAPHITE_POSE_DEBUG") && atoi(getenv("GRAPHITE_POSE_DEBUG")) != 0;
-  if (debug) { bf.dbg.resize(64); sa.dbg = bf.dbg.raw(); }
+  if (debug) { bf.dbg.resize(64 + pe::MAX_GRID); sa.dbg = bf.dbg.raw(); }
   sa.var = getenv("GRAPHITE_POSE_VAR") ? atoi(getenv("GRAPHITE_POSE_VAR")) : 0;
   sa.timeout = (sa.var & 256) ? 2000000ll : 200000000ll;
   if ((sa.var & 256) && bf.prefer_cooperative) sa.var &= ~256; // (the test's failure happens once)
@@ -1141,6 +1148,11 @@ int pose_engine_run(Graph<T, S> *graph, const PoseEngineOptions &o, PoseEngineRe
     std::cerr << "[graphite] pose-graph engine, last solve, workgroup 0 (us since its start; start | assemble+invert | sums | then per PCG iteration: operator | sums | update | sums ... | step):";
     for (int i = 1; i < (int)d[63] && i < 63; ++i) std::cerr << " " << (double)(d[i] - d[i - 1]) * 0.01;
     std::cerr << std::endl;
+    std::vector<double> op(d.begin() + 64, d.begin() + 64 + G);
+    std::cerr << "[graphite] pose-graph engine, operator phase of the last PCG iteration by workgroup (us): first " << op.front() * 0.01 << ", last " << op.back() * 0.01;
+    { std::vector<double> q = op; std::sort(q.begin(), q.end()); std::cerr << ", min " << q.front() * 0.01 << ", median " << q[q.size() / 2] * 0.01 << ", p90 " << q[q.size() * 9 / 10] * 0.01 << ", max " << q.back() * 0.01; }
+    { double a = 0, b = 0; int na_ = 0, nb_ = 0; for (int i = 0; i < G; ++i) { if (i + cus < G || i >= cus) { b += op[i]; ++nb_; } else { a += op[i]; ++na_; } }
+      std::cerr << "; mean of workgroups alone on their CU " << (na_ ? a / na_ * 0.01 : 0.0) << " (" << na_ << "), sharing it " << (nb_ ? b / nb_ * 0.01 : 0.0) << " (" << nb_ << ")" << std::endl; }
   }
   const std::vector<double> tr = bf.tr.to_host();
   const std::vector<long long> ck = bf.clock.to_host();
