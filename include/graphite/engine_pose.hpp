@@ -622,6 +622,13 @@ template <typename T> struct FactorArgs {
   int early;
 };
 
+// threads per workgroup of the factor kernel (measured on 10 k poses, us per LM iteration: 64 threads 142.6, 128 132.8, 256 124.9 — fewer
+// partials and tickets, longer staged runs — although 256 threads leave a quarter of the CUs without a workgroup there)
+#ifndef GRAPHITE_POSE_FACTOR_THREADS
+#define GRAPHITE_POSE_FACTOR_THREADS 256
+#endif
+constexpr int FTPB = GRAPHITE_POSE_FACTOR_THREADS;
+
 // Jacobian block of slot I at the vertices v: the user's jacobian<> or one dual-number evaluation per column (ops/linearize.hpp:43-138)
 template <typename F, size_t I, typename VT, size_t... Is>
 __device__ inline void pe_jacobian(const FactorView<F> &fv, size_t f, const VT &v, typename F::Scalar *J, std::index_sequence<Is...> seq) {
@@ -648,20 +655,20 @@ __device__ inline void pe_jacobian(const FactorView<F> &fv, size_t f, const VT &
 // rejected trial are wasted work (rare), a launch per LM iteration is saved.
 
 template <typename F, size_t... Is>
-__global__ void __launch_bounds__(TPB) k_pe_factor(FactorView<F> fv, const FactorArgs<typename F::Scalar> A, slot_vertex<F, 0> *mirror, int mode, std::index_sequence<Is...> seq) {
+__global__ void __launch_bounds__(FTPB) k_pe_factor(FactorView<F> fv, const FactorArgs<typename F::Scalar> A, slot_vertex<F, 0> *mirror, int mode, std::index_sequence<Is...> seq) {
   using T = typename F::Scalar;
   constexpr size_t E = F::E;
   constexpr int D = (int)slot_dim<F, 0>(), Ei = (int)F::E, RS = 2 * D * D + D, RF = 2 * RS;
-  constexpr bool STAGE = (size_t)TPB * RF * sizeof(T) <= 96 * 1024; // (larger records are written by their own thread, strided)
-  __shared__ double red[TPB];
+  constexpr bool STAGE = (size_t)FTPB * RF * sizeof(T) <= 96 * 1024; // (larger records are written by their own thread, strided)
+  __shared__ double red[FTPB];
   __shared__ int s_last;
   extern __shared__ __align__(16) unsigned char pe_stage_raw[];
-  T *const stage = reinterpret_cast<T *>(pe_stage_raw); // [TPB][RF]: the records of this workgroup's factors
+  T *const stage = reinterpret_cast<T *>(pe_stage_raw); // [FTPB][RF]: the records of this workgroup's factors
   Ctl *const ctl = A.ctl;
   if (ctl->stop) return;
   const int buf = mode == 0 ? ctl->cur : ctl->cur ^ 1;
   bool have = false;
-  const size_t a = blockIdx.x * (size_t)TPB + threadIdx.x, ga = A.a0 + a; // in this descriptor's active list / among all the graph's active factors
+  const size_t a = blockIdx.x * (size_t)FTPB + threadIdx.x, ga = A.a0 + a; // in this descriptor's active list / among all the graph's active factors
   double c2 = 0;
   if (a < A.na) {
     const size_t f = fv.active_ids[a];
@@ -731,14 +738,14 @@ __global__ void __launch_bounds__(TPB) k_pe_factor(FactorView<F> fv, const Facto
   if (!have) for (int q = 0; q < RF; ++q) stage[(size_t)threadIdx.x * RF + q] = T(0);
   __syncthreads();
   { // the workgroup's records leave lane-consecutive (each thread's own 336 bytes at a 336-byte stride were 42 partial-line stores per wave instruction)
-    const size_t first = blockIdx.x * (size_t)TPB, count = first < A.na ? (A.na - first < (size_t)TPB ? A.na - first : (size_t)TPB) : 0;
+    const size_t first = blockIdx.x * (size_t)FTPB, count = first < A.na ? (A.na - first < (size_t)FTPB ? A.na - first : (size_t)FTPB) : 0;
     T *dst = A.frec + ((size_t)buf * A.na_all + A.a0 + first) * RF;
-    for (size_t i = threadIdx.x; i < count * RF; i += TPB) dst[i] = stage[i];
+    for (size_t i = threadIdx.x; i < count * RF; i += FTPB) dst[i] = stage[i];
   }
   }
   red[threadIdx.x] = c2;
   __syncthreads();
-  for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  for (int o = FTPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) {
     st_x(A.part + A.block0 + blockIdx.x, red[0]);
     __threadfence();
@@ -748,18 +755,18 @@ __global__ void __launch_bounds__(TPB) k_pe_factor(FactorView<F> fv, const Facto
   __syncthreads();
   if (!s_last) return;
   double tot = 0, rd = 0;
-  for (int g = threadIdx.x; g < A.total_blocks; g += TPB) tot += ld_x(A.part + g);
+  for (int g = threadIdx.x; g < A.total_blocks; g += FTPB) tot += ld_x(A.part + g);
   __syncthreads();
   red[threadIdx.x] = tot;
   __syncthreads();
-  for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  for (int o = FTPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   tot = red[0];
   __syncthreads();
   if (mode) {
-    for (int g = threadIdx.x; g < A.n_rho; g += TPB) rd += A.part_rho[g];
+    for (int g = threadIdx.x; g < A.n_rho; g += FTPB) rd += A.part_rho[g];
     red[threadIdx.x] = rd;
     __syncthreads();
-    for (int o = TPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    for (int o = FTPB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     rd = red[0];
   }
   if (threadIdx.x != 0) return;
@@ -886,14 +893,14 @@ void FactorDescriptor<T, S, FTraits>::pose_engine_launch(const detail::pe::Facto
   if constexpr (N <= 2 && std::is_same<T, S>::value && std::is_same<typename std::tuple_element<0, VDTuple>::type, typename std::tuple_element<N - 1, VDTuple>::type>::value) {
     using VD0 = typename std::tuple_element<0, VDTuple>::type;
     constexpr int D = (int)VD0::dim, DD = D * D;
-    size_t stage_bytes = (size_t)TPB * (2 * (2 * DD + D)) * sizeof(T);
+    size_t stage_bytes = (size_t)pe::FTPB * (2 * (2 * DD + D)) * sizeof(T);
     if (stage_bytes > 96 * 1024) stage_bytes = 0; // (written directly, see k_pe_factor)
     constexpr auto seq = std::make_index_sequence<N>{};
     if (stage_bytes > 64 * 1024 && !pose_stage_attr_set) {
       GRAPHITE_HIP(hipFuncSetAttribute(pe::factor_kernel_ptr<FactorDescriptor>(seq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes));
       pose_stage_attr_set = true;
     }
-    pe::k_pe_factor<FactorDescriptor><<<blocks(fa.na), TPB, stage_bytes>>>(view(), fa, static_cast<typename VD0::VertexType *>(mirror), mode, seq);
+    pe::k_pe_factor<FactorDescriptor><<<(unsigned)((fa.na + pe::FTPB - 1) / pe::FTPB), pe::FTPB, stage_bytes>>>(view(), fa, static_cast<typename VD0::VertexType *>(mirror), mode, seq);
   }
 }
 
@@ -1049,7 +1056,7 @@ int pose_engine_run(Graph<T, S> *graph, const PoseEngineOptions &o, PoseEngineRe
   const size_t ntr = o.iterations + 1;
   bf.sums.resize_uninit((size_t)2 * pe::MAX_GRID * 2 * 2); bf.part_rho.resize_uninit((size_t)pe::MAX_GRID * pe::WPB); bf.tr.resize_uninit(2 * ntr); bf.clock.resize_uninit(ntr);
   std::vector<int> block0(fds.size() + 1, 0);
-  for (size_t d = 0; d < fds.size(); ++d) block0[d + 1] = block0[d] + blocks(fis[d].active);
+  for (size_t d = 0; d < fds.size(); ++d) block0[d + 1] = block0[d] + (int)((fis[d].active + pe::FTPB - 1) / pe::FTPB);
   const int total_blocks = block0[fds.size()];
   bf.part_chi2.resize_uninit((size_t)std::max(1, total_blocks));
   bf.ctl.resize_uninit(1); bf.fail.resize_uninit(1);
