@@ -595,7 +595,16 @@ public:
         } catch (const std::invalid_argument &) { eliminate_first = false; }
       }
     }
-    if (!eliminate_first) { Hd.resize(n * n); Hdd.resize(n * n); }
+    if (!eliminate_first) {
+      // no elimination order: the whole damped Hessian as ONE dense matrix for the MFMA Cholesky (the reference hands a sparse one to
+      // SimplicialLDLT on the host, solver/eigen.hpp:49-98).  Fine for the graphs that solver is used on here (hundreds to a few thousand
+      // columns); a graph whose n^2 does not fit says so instead of failing inside an allocation
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 2.0 * (double)n * (double)n * sizeof(T) > 0.9 * (double)free_b + (double)(Hd.size() + Hdd.size()) * sizeof(T))
+        throw std::runtime_error("graphite: EigenLDLTSolver without an elimination order factorises the dense " + std::to_string(n) + " x " + std::to_string(n) +
+                                 " Hessian (" + std::to_string(2.0 * (double)n * (double)n * sizeof(T) / 1e9) + " GB): it does not fit this device — mark the landmark descriptor with set_eliminate(true), or use PCGSolver");
+      Hd.resize(n * n); Hdd.resize(n * n);
+    }
   }
   void update_values(Graph<T, S> *graph, StreamPool &streams) override {
     if (eliminate_first) { H.update_values(graph, streams); return; }
