@@ -29,6 +29,7 @@ EXPORTS = [
     "gr_bal_levenberg_marquardt", "gr_bal_kernel_stats", "gr_comm_unique_id", "gr_bal_comm_init", "gr_bal_comm_ipc_mailbox", "gr_bal_comm_set_contributors", "gr_bal_comm_init_ipc", "gr_bal_set_fixed",
     "gr_dense_cholesky_solve", "gr_bal_model_evaluate", "gr_bal_tuning_default", "gr_bal_set_tuning", "gr_bal_get_tuning",
     "gr_bal_direct_solver_info", "gr_bal_lm_iteration_seconds", "gr_bal_comm_info",
+    "gr_spchol_create", "gr_spchol_factor_solve", "gr_spchol_info", "gr_spchol_destroy",
     "gr_bal_create_model", "gr_bal_model_orders",  # include/graphite_mi355x_model.h: the engine on user traits
 ]
 # include/graphite_mi355x_test.h (test / diagnostic entry points, not part of the drop-in boundary)

@@ -3001,6 +3001,32 @@ template <typename T> static void model_evaluate_impl(int64_t n, const void *cam
   if (Jp) GR_HIP(hipMemcpyAsync(Jp, djp.p, 6 * (size_t)n * sizeof(T), hipMemcpyDefault, stream));
   GR_HIP(hipStreamSynchronize(stream));
 }
+// ---- gr_spchol: the nested-dissection tile Cholesky on any block-sparse SPD matrix (include/graphite_mi355x.h) -----------------------
+struct gr_spchol {
+  gr_dtype dtype = GR_F64;
+  int device = 0;
+  int64_t nnzb = 0;
+  SparseChol<double> d;
+  SparseChol<float> f;
+  DevBuf<int> rowi, coli;
+};
+template <typename T> static void spchol_create_impl(gr_spchol *h, SparseChol<T> &sc, int64_t nodes, int bs, int64_t nnzb, const int64_t *brow, const int64_t *bcol, hipStream_t stream) {
+  std::vector<int> r((size_t)nnzb), c((size_t)nnzb);
+  std::vector<char> has_diag((size_t)nodes, 0);
+  for (int64_t q = 0; q < nnzb; ++q) {
+    if (brow[q] < 0 || bcol[q] >= nodes || brow[q] > bcol[q]) throw std::invalid_argument("gr_spchol_create: block (" + std::to_string(brow[q]) + ", " + std::to_string(bcol[q]) + ") is not an upper block of the matrix");
+    r[(size_t)q] = (int)brow[q]; c[(size_t)q] = (int)bcol[q];
+    if (brow[q] == bcol[q]) has_diag[(size_t)brow[q]] = 1;
+  }
+  for (int64_t i = 0; i < nodes; ++i) if (!has_diag[(size_t)i]) throw std::invalid_argument("gr_spchol_create: node " + std::to_string(i) + " has no diagonal block");
+  if (!sc.set_structure((int)nodes, r, c, stream, bs)) throw std::range_error("gr_spchol_create: the node graph does not dissect (one supernode): use gr_dense_cholesky_solve");
+  sc.allocate();
+  h->rowi.alloc((size_t)nnzb); h->coli.alloc((size_t)nnzb);
+  GR_HIP(hipMemcpyAsync(h->rowi.p, r.data(), (size_t)nnzb * sizeof(int), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipMemcpyAsync(h->coli.p, c.data(), (size_t)nnzb * sizeof(int), hipMemcpyHostToDevice, stream));
+  GR_HIP(hipStreamSynchronize(stream));
+}
+
 extern "C" {
 
 const char *gr_version(void) { return "graphite-mi355x 0.2 (gfx950)"; } // 0.2: sizeof(gr_bal_tuning) = 100, sizeof(gr_lm_stats) = 80 (both grew in round 4), gr_model_ops
@@ -3142,6 +3168,49 @@ gr_status gr_dense_cholesky_solve(gr_dtype dtype, int64_t n, const void *A, int6
   catch (const CommError &ex) { g_last_error = ex.what(); return GR_ERR_COMM; }
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
 }
+gr_status gr_spchol_create(gr_spchol **out, gr_dtype dtype, int64_t num_nodes, int32_t block_size, int64_t num_blocks, const int64_t *block_row, const int64_t *block_col, int device, void *stream) {
+  if (!out || num_nodes <= 0 || block_size <= 0 || block_size > 128 || num_blocks < num_nodes || !block_row || !block_col || num_nodes * (int64_t)block_size > (1 << 24) || (dtype != GR_F64 && dtype != GR_F32)) {
+    g_last_error = "gr_spchol_create: bad argument"; return GR_ERR_INVALID;
+  }
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= device || device < 0) { g_last_error = "no HIP device: the MI355X path has no CPU fallback"; return GR_ERR_NO_DEVICE; }
+  gr_spchol *h = nullptr;
+  try {
+    GR_HIP(hipSetDevice(device));
+    h = new gr_spchol();
+    h->dtype = dtype; h->device = device; h->nnzb = num_blocks;
+    if (dtype == GR_F64) spchol_create_impl<double>(h, h->d, num_nodes, block_size, num_blocks, block_row, block_col, static_cast<hipStream_t>(stream));
+    else spchol_create_impl<float>(h, h->f, num_nodes, block_size, num_blocks, block_row, block_col, static_cast<hipStream_t>(stream));
+    *out = h;
+    return GR_OK;
+  } catch (const HipError &ex) { delete h; g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::range_error &ex) { delete h; g_last_error = ex.what(); return GR_ERR_SOLVE_FAILED; }
+  catch (const std::exception &ex) { delete h; g_last_error = ex.what(); return GR_ERR_INVALID; }
+}
+gr_status gr_spchol_factor_solve(gr_spchol *h, const void *blocks, const void *b, void *x) {
+  if (!h || !blocks || !b || !x) { g_last_error = "gr_spchol_factor_solve: bad argument"; return GR_ERR_INVALID; }
+  try {
+    GR_HIP(hipSetDevice(h->device));
+    bool ok;
+    if (h->dtype == GR_F64) { h->d.load(h->nnzb, h->rowi.p, h->coli.p, static_cast<const double *>(blocks)); h->d.factor(); h->d.solve(static_cast<const double *>(b), static_cast<double *>(x)); ok = h->d.ok(); }
+    else { h->f.load(h->nnzb, h->rowi.p, h->coli.p, static_cast<const float *>(blocks)); h->f.factor(); h->f.solve(static_cast<const float *>(b), static_cast<float *>(x)); ok = h->f.ok(); }
+    if (!ok) { g_last_error = "gr_spchol_factor_solve: a pivot is not positive"; return GR_ERR_SOLVE_FAILED; }
+    return GR_OK;
+  } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }
+  catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
+}
+gr_status gr_spchol_info(const gr_spchol *h, gr_direct_solver_info *o) {
+  if (!h || !o) { g_last_error = "gr_spchol_info: bad argument"; return GR_ERR_INVALID; }
+  std::memset(o, 0, sizeof(*o));
+  auto fill = [&](const auto &sc) {
+    o->sparse = 1; o->tile_columns = sc.nt; o->levels = sc.nlevels; o->supernodes = sc.nsuper; o->padded_n = sc.npad;
+    o->factor_tiles = sc.nz_tiles; o->factor_bytes = (int64_t)sc.bytes(); o->dense_bytes = (int64_t)sc.dense_bytes();
+  };
+  if (h->dtype == GR_F64) fill(h->d); else fill(h->f);
+  return GR_OK;
+}
+void gr_spchol_destroy(gr_spchol *h) { delete h; }
+
 gr_status gr_bal_model_evaluate(gr_dtype dtype, int64_t n, const void *cameras, const void *points, const void *observations,
                                 void *residuals, void *Jc, void *Jp, int device, void *stream) {
   if (n <= 0 || n > (1 << 24) || !cameras || !points || !observations) { g_last_error = "gr_bal_model_evaluate: bad argument"; return GR_ERR_INVALID; }

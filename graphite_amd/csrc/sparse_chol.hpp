@@ -404,15 +404,16 @@ __global__ __launch_bounds__(256) void k_sp_trsm_rows(T *__restrict__ A, const i
 // and event bubbles it removes (~0.45 ms) come back as fence + poll latency on the same chain, whose length is set by the compute
 // of its links — panel solve 10 us, diagonal update + 128 x 128 factorisation 67 us, 21 times.)
 
-// permuted scatter of the upper 9x9 blocks of S (column-major blocks, block (i <= j)) into the lower triangle;
-// camcol[c] = first (padded, permuted) column of camera c
+// permuted scatter of the upper bs x bs blocks of S (column-major blocks, block (i <= j); bs = 9 for the reduced camera system, any
+// block size for gr_spchol) into the lower triangle; camcol[c] = first (padded, permuted) column of node c
 template <typename T>
 __global__ __launch_bounds__(256) void k_sp_scatter(int64_t nnzb, const int *__restrict__ rowi, const int *__restrict__ coli, const int *__restrict__ camcol,
-                                                    const T *__restrict__ S, T *__restrict__ A, const int *__restrict__ tmap, int nt) {
+                                                    const T *__restrict__ S, T *__restrict__ A, const int *__restrict__ tmap, int nt, int bs) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= 81 * nnzb) return;
-  const int64_t q = e / 81;
-  const int w = (int)(e - 81 * q), c = w / 9, r = w - 9 * c; // S_q(r, c) = S(9 i + r, 9 j + c), i <= j
+  const int bb = bs * bs;
+  if (e >= (int64_t)bb * nnzb) return;
+  const int64_t q = e / bb;
+  const int w = (int)(e - (int64_t)bb * q), c = w / bs, r = w - bs * c; // S_q(r, c) = S(bs i + r, bs j + c), i <= j
   int R = camcol[rowi[q]] + r, C = camcol[coli[q]] + c;
   if (rowi[q] == coli[q]) { if (R < C) return; } // diagonal block: its lower half
   else if (R < C) { const int x = R; R = C; C = x; }
@@ -662,7 +663,8 @@ template <typename T> struct SparseChol {
   int *h_fail = nullptr;
   CholProfSink *sink = nullptr;
   bool attrs_set = false;
-  static constexpr int LEAF = 56; // cameras per leaf supernode: 504 columns = 4 tiles (8 padding columns)
+  static constexpr int LEAF = 56; // cameras per leaf supernode: 504 columns = 4 tiles (8 padding columns); other block sizes: 504 / bs nodes
+  int bs = 9;                     // scalar columns per node (9: cameras of the reduced system)
   bool fuse_potrf = true; // gr_bal_tuning.spchol_fuse: the next level's diagonal tiles factorised inside this level's update launch
   bool fuse_quads = true; // ... and that tile's update spread over three workgroups by quadrant (spchol_fuse = 2; 1: one workgroup)
   int quad_max_targets = 1 << 30; // levels with more update targets would keep the one-workgroup form (measured: 64 / 128 / 256 / all -> 364 / 366 / 368 / 367 LM it/s: all)
@@ -688,7 +690,7 @@ template <typename T> struct SparseChol {
   }
 
   // nested dissection of the camera graph: returns the supernodes (camera lists) in elimination order
-  static std::vector<std::vector<int>> nested_dissection(int Nc, const std::vector<std::vector<int>> &adj) {
+  static std::vector<std::vector<int>> nested_dissection(int Nc, const std::vector<std::vector<int>> &adj, int leaf = LEAF) {
     std::vector<std::vector<int>> out;
     std::vector<int> mark(Nc, -1), dist(Nc, 0);
     int stamp = 0;
@@ -714,7 +716,7 @@ template <typename T> struct SparseChol {
       stack.pop_back();
       auto &nodes = job.nodes;
       if (nodes.empty()) continue;
-      if (job.emit_only || (int)nodes.size() <= LEAF) { out.push_back(std::move(nodes)); continue; }
+      if (job.emit_only || (int)nodes.size() <= leaf) { out.push_back(std::move(nodes)); continue; }
       ++stamp;
       for (int v : nodes) mark[v] = stamp;
       std::vector<int> order, order2;
@@ -750,19 +752,20 @@ template <typename T> struct SparseChol {
   }
 
   // Nc cameras, upper block list (rowi <= coli) of S.  Returns false when the graph does not dissect (one supernode).
-  bool set_structure(int Nc, const std::vector<int> &rowi, const std::vector<int> &coli, hipStream_t s) {
+  bool set_structure(int Nc, const std::vector<int> &rowi, const std::vector<int> &coli, hipStream_t s, int block = 9) {
     stream = s;
-    n = 9 * Nc;
+    bs = block;
+    n = bs * Nc;
     std::vector<std::vector<int>> adj(Nc);
     for (size_t q = 0; q < rowi.size(); ++q) if (rowi[q] != coli[q]) { adj[rowi[q]].push_back(coli[q]); adj[coli[q]].push_back(rowi[q]); }
-    const auto supers = nested_dissection(Nc, adj);
+    const auto supers = nested_dissection(Nc, adj, bs == 9 ? LEAF : std::max(8, 504 / bs));
     nsuper = (int)supers.size();
     if (nsuper <= 1) return false;
     // padded permuted columns
     std::vector<int> camcol(Nc, 0), src;
     std::vector<unsigned char> pad;
     for (const auto &sn : supers) {
-      for (int c : sn) { camcol[c] = (int)src.size(); for (int k = 0; k < 9; ++k) { src.push_back(9 * c + k); pad.push_back(0); } }
+      for (int c : sn) { camcol[c] = (int)src.size(); for (int k = 0; k < bs; ++k) { src.push_back(bs * c + k); pad.push_back(0); } }
       while (src.size() % CH_NB) { src.push_back(-1); pad.push_back(1); }
     }
     npad = (int)src.size(); nt = npad / CH_NB;
@@ -771,7 +774,7 @@ template <typename T> struct SparseChol {
     auto nz = [&](int i, int j) -> char & { return tz[(size_t)i * nt + j]; };
     for (int i = 0; i < nt; ++i) nz(i, i) = 1;
     for (size_t q = 0; q < rowi.size(); ++q) {
-      const int a0 = camcol[rowi[q]] / CH_NB, a1 = (camcol[rowi[q]] + 8) / CH_NB, b0 = camcol[coli[q]] / CH_NB, b1 = (camcol[coli[q]] + 8) / CH_NB;
+      const int a0 = camcol[rowi[q]] / CH_NB, a1 = (camcol[rowi[q]] + bs - 1) / CH_NB, b0 = camcol[coli[q]] / CH_NB, b1 = (camcol[coli[q]] + bs - 1) / CH_NB;
       for (int a = a0; a <= a1; ++a)
         for (int b = b0; b <= b1; ++b) nz(std::max(a, b), std::min(a, b)) = 1;
     }
@@ -917,7 +920,7 @@ template <typename T> struct SparseChol {
   // S (upper 9x9 blocks) -> permuted dense lower triangle
   void load(int64_t nnzb, const int *rowi, const int *coli, const T *S) {
     k_sp_clear<T><<<nz_tiles, 256, 0, stream>>>(A.p, d_pad.p, d_nz.p);
-    k_sp_scatter<T><<<(unsigned)((81 * nnzb + 255) / 256), 256, 0, stream>>>(nnzb, rowi, coli, d_camcol.p, S, A.p, d_tmap.p, nt);
+    k_sp_scatter<T><<<(unsigned)(((int64_t)bs * bs * nnzb + 255) / 256), 256, 0, stream>>>(nnzb, rowi, coli, d_camcol.p, S, A.p, d_tmap.p, nt, bs);
   }
   void factor() { factor_levels([](int) {}); }
   template <typename After> void factor_levels(After &&after_level, bool ride_fwd = false) {

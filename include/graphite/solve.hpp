@@ -578,8 +578,15 @@ template <typename T, typename S> class EigenLDLTSolver : public Solver<T, S> {
   T damping = 0;
   bool damping_identity = false, eliminate_first = false;
   static constexpr bool same_type = std::is_same<T, S>::value;
+  // no elimination order, every block column of the same dimension, more than a few thousand columns (a pose graph): the block-sparse
+  // Hessian goes to the nested-dissection tile Cholesky (gr_spchol) instead of a dense n x n array
+  gr_spchol *sparse_chol = nullptr;
+  bool sparse_direct = false;
 public:
   EigenLDLTSolver() : schur(H) {}
+  EigenLDLTSolver(const EigenLDLTSolver &) = delete;
+  ~EigenLDLTSolver() { if (sparse_chol) gr_spchol_destroy(sparse_chol); }
+  bool uses_sparse_factorisation() const { return sparse_direct; }
   int engine_kind(size_t) const override { return GR_SOLVER_DENSE_SCHUR; }
   bool uses_elimination_order() const { return eliminate_first; }
   void update_structure(Graph<T, S> *graph, StreamPool &streams) override {
@@ -595,6 +602,34 @@ public:
         } catch (const std::invalid_argument &) { eliminate_first = false; }
       }
     }
+    if (sparse_chol) { gr_spchol_destroy(sparse_chol); sparse_chol = nullptr; }
+    sparse_direct = false;
+    if constexpr (same_type && std::is_floating_point<T>::value) {
+      const size_t nb = graph->get_num_block_columns();
+      const size_t sparse_min = getenv("GRAPHITE_LDLT_SPARSE_MIN") ? (size_t)std::max(1, atoi(getenv("GRAPHITE_LDLT_SPARSE_MIN"))) : 4096;
+      if (!eliminate_first && nb && n % nb == 0 && n >= sparse_min) {
+        const size_t bs = n / nb;
+        bool uniform = bs <= 128;
+        for (size_t j = 0; j < nb && uniform; ++j) uniform = graph->get_variable_dimension(j) == bs;
+        if (uniform) {
+          H.build_structure(graph, streams);
+          const auto &cp = H.host_col_pointers(), &ri = H.host_row_indices();
+          std::vector<int64_t> brow(ri.size()), bcol(ri.size());
+          for (size_t j = 0; j < nb; ++j)
+            for (size_t q = cp[j]; q < cp[j + 1]; ++q) { brow[q] = (int64_t)ri[q]; bcol[q] = (int64_t)j; }
+          int dev = 0;
+          GRAPHITE_HIP(hipGetDevice(&dev));
+          const gr_status st = gr_spchol_create(&sparse_chol, sizeof(T) == 8 ? GR_F64 : GR_F32, (int64_t)nb, (int32_t)bs, (int64_t)ri.size(), brow.data(), bcol.data(), dev, nullptr);
+          if (st == GR_OK) sparse_direct = true;
+          else {
+            sparse_chol = nullptr;
+            if (st != GR_ERR_SOLVE_FAILED) throw std::runtime_error(std::string("graphite: EigenLDLTSolver: gr_spchol_create: ") + gr_last_error_string());
+            if (getenv("GR_VERBOSE")) std::cerr << "[graphite] EigenLDLTSolver: " << gr_last_error_string() << "; dense factorisation" << std::endl;
+          }
+        }
+      }
+    }
+    if (sparse_direct) return;
     if (!eliminate_first) {
       // no elimination order: the whole damped Hessian as ONE dense matrix for the MFMA Cholesky (the reference hands a sparse one to
       // SimplicialLDLT on the host, solver/eigen.hpp:49-98).  Fine for the graphs that solver is used on here (hundreds to a few thousand
@@ -607,7 +642,7 @@ public:
     }
   }
   void update_values(Graph<T, S> *graph, StreamPool &streams) override {
-    if (eliminate_first) { H.update_values(graph, streams); return; }
+    if (eliminate_first || sparse_direct) { H.update_values(graph, streams); return; }
     const size_t n = graph->get_hessian_dimension();
     detail::fill<T>(Hd.raw(), n * n, T(0));
     for (auto *fd : graph->get_factor_descriptors()) fd->dense_hessian(Hd.raw(), n);
@@ -615,11 +650,18 @@ public:
   }
   void set_damping_factor(Graph<T, S> *graph, T mu, const bool use_identity, StreamPool &streams) override {
     damping = mu; damping_identity = use_identity;
-    if (eliminate_first) H.apply_damping(graph, mu, use_identity, streams);
+    if (eliminate_first || sparse_direct) H.apply_damping(graph, mu, use_identity, streams);
   }
   bool solve(Graph<T, S> *graph, T *x, StreamPool &streams) override {
     const size_t n = graph->get_hessian_dimension();
     if (!n) return true;
+    if constexpr (same_type) {
+      if (sparse_direct) { // block-sparse damped Hessian (upper blocks, column-major) -> tile Cholesky -> x
+        const bool ok = gr_spchol_factor_solve(sparse_chol, H.get_values_ptr(), graph->get_b().raw(), x) == GR_OK;
+        detail::sync();
+        return ok;
+      }
+    }
     int dev = 0;
     GRAPHITE_HIP(hipGetDevice(&dev));
     const gr_dtype dt = sizeof(T) == 8 ? GR_F64 : GR_F32;

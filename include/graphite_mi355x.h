@@ -368,6 +368,22 @@ gr_status gr_bal_comm_info(gr_bal_problem *p, gr_comm_info *info);
 gr_status gr_dense_cholesky_solve(gr_dtype dtype, int64_t n, const void *A, int64_t lda, const void *b, void *x,
                                   int device, void *stream, double *factor_seconds);
 
+/* Sparse SPD solve A x = b of a BLOCK-sparse matrix on the nested-dissection tile Cholesky that GR_SOLVER_DENSE_SCHUR uses for the reduced
+ * camera system (sparse_chol.hpp) — the numerical role of Eigen::SimplicialLDLT in solver/eigen.hpp:49-98 (EigenLDLTSolver on a graph
+ * without an elimination order, e.g. a pose graph) and of cuDSS in solver/cudss.hpp:183-256.  Structure once, values per solve.
+ *   gr_spchol_create: num_nodes block rows / columns of block_size scalars each; num_blocks UPPER blocks (block_row[q] <= block_col[q], every
+ *     diagonal block present), host arrays.  GR_ERR_SOLVE_FAILED when the node graph does not dissect into more than one supernode (then the
+ *     matrix is as good as dense: use gr_dense_cholesky_solve).
+ *   gr_spchol_factor_solve: blocks = num_blocks x block_size x block_size scalars, block q column-major, in the order given to create;
+ *     blocks, b, x DEVICE pointers (x may alias b).  GR_ERR_SOLVE_FAILED when a pivot is not positive.
+ *   gr_spchol_info: sizes of the factor (gr_direct_solver_info, as gr_bal_direct_solver_info reports them). */
+typedef struct gr_spchol gr_spchol;
+gr_status gr_spchol_create(gr_spchol **out, gr_dtype dtype, int64_t num_nodes, int32_t block_size, int64_t num_blocks,
+                           const int64_t *block_row, const int64_t *block_col, int device, void *stream);
+gr_status gr_spchol_factor_solve(gr_spchol *h, const void *blocks, const void *b, void *x);
+gr_status gr_spchol_info(const gr_spchol *h, gr_direct_solver_info *info);
+void gr_spchol_destroy(gr_spchol *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -207,12 +207,37 @@ class PoseGraphOracle:
                 break
         return x, its
 
+    # ---- EigenLDLTSolver (solver/eigen.hpp:49-98): the damped system assembled sparse and solved directly (hessian.hpp:136-176 damping) ----
+    def solve_direct(self):
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+        rows, cols, vals = [], [], []
+        ar = np.arange(3)
+
+        def add(va, vb, blk):     # blk [F, 3, 3] at block (va, vb), both active
+            m = self.active[va] & self.active[vb]
+            if not m.any():
+                return
+            r = (self.col[va[m]][:, None, None] + ar[None, :, None]) + 0 * ar[None, None, :]
+            c = (self.col[vb[m]][:, None, None] + ar[None, None, :]) + 0 * ar[None, :, None]
+            rows.append(r.ravel()); cols.append(c.ravel()); vals.append(blk[m].ravel())
+        W = self.P * self.dchi2[:, None, None]
+        for Ja, va in ((self.Ji, self.i), (self.Jj, self.j)):
+            for Jb, vb in ((self.Ji, self.i), (self.Jj, self.j)):
+                add(va, vb, np.einsum("fad,fab,fbe->fde", Ja, W, Jb))
+        if len(self.pi):
+            add(self.pi, self.pi, self.pS[:, :, None] * self.pP * self.pS[:, None, :])
+        H = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(self.dim, self.dim))
+        d = H.diagonal()
+        H = H + sp.diags(self.mu * (np.ones_like(d) if self.use_identity else np.clip(d, 1.0e-6, 1.0e32)))
+        return spla.spsolve(H.tocsc(), self.b), 0
+
     def apply_update(self, dx):
         m = self.active
         self.x[m] += (dx * self.scales).reshape(-1, 3)
 
     def levenberg_marquardt(self, iterations=10, initial_damping=1e-4, use_identity=False, pcg_max_iter=10, pcg_tol=1.0, pcg_rej=5.0,
-                            identity_precond=False):
+                            identity_precond=False, direct=False):
         mu, nu = initial_damping, 2.0
         self.linearize(); self.block_diagonal()
         chi2v = self.chi2()
@@ -220,7 +245,7 @@ class PoseGraphOracle:
         st = dict(accepted=0, pcg_iterations=0, iterations_run=0)
         for _ in range(iterations):
             self.set_damping(mu, use_identity)
-            dx, its = self.solve_pcg(pcg_max_iter, pcg_tol, pcg_rej, identity_precond)
+            dx, its = self.solve_direct() if direct else self.solve_pcg(pcg_max_iter, pcg_tol, pcg_rej, identity_precond)
             st["pcg_iterations"] += its
             backup = self.x.copy()
             self.apply_update(dx)

@@ -12,6 +12,7 @@
 #include <graphite/optimizer/levenberg_marquardt.hpp>
 #include <graphite/preconditioner/block_jacobi.hpp>
 #include <graphite/preconditioner/identity.hpp>
+#include <graphite/solver/eigen.hpp>
 #include <graphite/solver/pcg.hpp>
 #include <iomanip>
 #include <iostream>
@@ -131,9 +132,10 @@ template <typename T, typename Mode, template <typename, int> class LossT> stati
   BlockJacobiPreconditioner<T, T> bj;
   IdentityPreconditioner<T, T> ident;
   PCGSolver<T, T> pcg(pcg_it, pcg_tol, 5.0, solver == "pcg-identity" ? static_cast<Preconditioner<T, T> *>(&ident) : static_cast<Preconditioner<T, T> *>(&bj));
+  EigenLDLTSolver<T, T> ldlt; // solver "eigen": the direct solve of the whole damped system (solver/eigen.hpp:49-98)
   StreamPool streams(1);
   optimizer::LevenbergMarquardtOptions<T, T> opt;
-  opt.solver = &pcg;
+  opt.solver = solver == "eigen" ? static_cast<Solver<T, T> *>(&ldlt) : static_cast<Solver<T, T> *>(&pcg);
   opt.initial_damping = 1e-4;
   opt.iterations = iterations;
   opt.optimization_level = 0;
@@ -158,6 +160,7 @@ template <typename T, typename Mode, template <typename, int> class LossT> stati
     sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
   std::cout << std::setprecision(17) << "FINAL_CHI2 " << graph.chi2() << std::endl;
+  if (solver == "eigen") std::cout << "SPARSE_FACTORISATION " << (ldlt.uses_sparse_factorisation() ? 1 : 0) << std::endl;
   std::cout << "ENGINE_HANDOVERS " << optimizer::engine_handover_count() << " ENGINE_MODEL_HANDOVERS " << optimizer::engine_model_handover_count()
             << " POSE_ENGINE_HANDOVERS " << optimizer::pose_engine_handover_count() << std::endl;
   if (optimizer::pose_engine_handover_count())

@@ -658,3 +658,28 @@ def test_pose_graph_with_a_second_factor_descriptor_of_unary_priors(tmp_path, en
     tr = parse_trace(r.stdout)
     assert len(tr) == len(ct) - 1 and np.allclose(tr[:, 1], ct[1:], rtol=1e-9) and np.allclose(tr[:, 2], lt[1:], rtol=1e-8)
     assert np.allclose(np.loadtxt(out), o.x, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,env,sparse", [(2000, {}, 1), (2000, {"GRAPHITE_LDLT_SPARSE_MIN": "100000000"}, 0), (300, {}, 0), (300, {"GRAPHITE_LDLT_SPARSE_MIN": "1"}, 1)],
+                         ids=["2000-poses-sparse", "2000-poses-dense", "300-poses-dense", "300-poses-sparse"])
+def test_pose_graph_through_the_direct_solver(tmp_path, n, env, sparse):
+    """EigenLDLTSolver (solver/eigen.hpp:49-98: the direct solve of the WHOLE damped system) on a pose graph — no elimination order, every block
+    column of dimension 3.  From 4 096 columns on, the header-only layer hands the block-sparse Hessian<T, S> (upper blocks, column-major) to the
+    nested-dissection tile Cholesky of the library (gr_spchol: sparse_chol.hpp with a general block size) instead of a dense n x n array; below
+    that, the dense MFMA Cholesky.  Both against the oracle's sparse direct solve (oracle/pose_graph.py::solve_direct): traces and poses at 1e-9."""
+    from oracle.pose_graph import PoseGraphOracle
+    exe = build_all()[8]
+    p0, fx, e, m, info, _ = synth.make_pose_graph(n)
+    f = tmp_path / "graph.txt"
+    out = tmp_path / "poses.txt"
+    synth.write_pose_graph(f, p0, fx, e, m, info)
+    its = 6 if n > 1000 else 3  # (the small graph has converged after three exact steps: beyond that, accept / reject is decided by rounding)
+    r = subprocess.run([exe, str(f), "eigen", str(its), "manual", "10", "1.0", str(out)], capture_output=True, text=True, timeout=600, env=dict(os.environ, GR_VERBOSE="1", **env))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert f"SPARSE_FACTORISATION {sparse}" in r.stdout and "POSE_ENGINE_HANDOVERS 0" in r.stdout
+    o = PoseGraphOracle(p0, fx, e, m, info)
+    ct, lt, st = o.levenberg_marquardt(iterations=its, direct=True)
+    tr = parse_trace(r.stdout)
+    assert len(tr) == len(ct) - 1 and np.allclose(tr[:, 1], ct[1:], rtol=1e-9) and np.allclose(tr[:, 2], lt[1:], rtol=1e-8)
+    assert np.allclose(np.loadtxt(out), o.x, rtol=1e-9, atol=1e-9)
