@@ -3169,8 +3169,9 @@ gr_status gr_dense_cholesky_solve(gr_dtype dtype, int64_t n, const void *A, int6
   catch (const std::exception &ex) { g_last_error = ex.what(); return GR_ERR_INVALID; }
 }
 gr_status gr_spchol_create(gr_spchol **out, gr_dtype dtype, int64_t num_nodes, int32_t block_size, int64_t num_blocks, const int64_t *block_row, const int64_t *block_col, int device, void *stream) {
-  if (!out || num_nodes <= 0 || block_size <= 0 || block_size > 128 || num_blocks < num_nodes || !block_row || !block_col || num_nodes * (int64_t)block_size > (1 << 24) || (dtype != GR_F64 && dtype != GR_F32)) {
-    g_last_error = "gr_spchol_create: bad argument"; return GR_ERR_INVALID;
+  if (!out || num_nodes <= 0 || block_size <= 0 || block_size > 128 || num_blocks < num_nodes || !block_row || !block_col || num_nodes * (int64_t)block_size > (1 << 22) || (dtype != GR_F64 && dtype != GR_F32)) {
+    // (the symbolic phase keeps a dense map of 128-column tiles: 2^22 columns = 1 GB of host memory for it)
+    g_last_error = "gr_spchol_create: bad argument (at most 2^22 columns, block size 1 .. 128, every diagonal block listed)"; return GR_ERR_INVALID;
   }
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd <= device || device < 0) { g_last_error = "no HIP device: the MI355X path has no CPU fallback"; return GR_ERR_NO_DEVICE; }
