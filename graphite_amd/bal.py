@@ -263,10 +263,9 @@ class SparseCholesky:
 
     block_row / block_col: the UPPER blocks (row <= col, every diagonal block present) of a matrix of num_nodes x num_nodes blocks of
     block_size x block_size scalars.  solve(blocks, b): blocks [num_blocks, block_size, block_size] with blocks[q][r, c] = A[bs row + r, bs col + c]
-    (numpy; uploaded here), b [num_nodes * block_size]; returns x."""
+    (numpy host arrays: the library stages them), b [num_nodes * block_size]; returns x."""
 
     def __init__(self, num_nodes, block_size, block_row, block_col, dtype=np.float64, device=0):
-        import torch
         self._L = _lib.lib()
         self.dtype = np.dtype(dtype)
         self.n, self.bs, self.nb = int(num_nodes), int(block_size), len(block_row)
@@ -274,8 +273,6 @@ class SparseCholesky:
         self._h = C.c_void_p()
         check(self._L.gr_spchol_create(C.byref(self._h), C.c_int(F64 if self.dtype == np.float64 else F32), C.c_int64(self.n), C.c_int32(self.bs),
                                        C.c_int64(self.nb), _ptr(r), _ptr(c), C.c_int(device), None))
-        self._torch = torch
-        self._dev = torch.device("cuda", device)
 
     def info(self):
         from ._lib import DirectSolverInfo
@@ -284,15 +281,12 @@ class SparseCholesky:
         return {k: getattr(o, k) for k, _ in o._fields_}
 
     def solve(self, blocks, b):
-        t = self._torch
-        tt = t.float64 if self.dtype == np.float64 else t.float32
         # the ABI takes column-major blocks: element (r, c) of block q at q bs^2 + c bs + r
-        bl = t.as_tensor(np.ascontiguousarray(np.asarray(blocks, self.dtype).reshape(self.nb, self.bs, self.bs).transpose(0, 2, 1)), dtype=tt, device=self._dev).contiguous()
-        bb = t.as_tensor(np.asarray(b, self.dtype), dtype=tt, device=self._dev).contiguous()
-        x = t.empty_like(bb)
-        check(self._L.gr_spchol_factor_solve(self._h, C.c_void_p(bl.data_ptr()), C.c_void_p(bb.data_ptr()), C.c_void_p(x.data_ptr())))
-        t.cuda.synchronize()
-        return x.cpu().numpy()
+        bl = np.ascontiguousarray(np.asarray(blocks, self.dtype).reshape(self.nb, self.bs, self.bs).transpose(0, 2, 1))
+        bb = np.ascontiguousarray(np.asarray(b, self.dtype))
+        x = np.zeros(self.n * self.bs, self.dtype)
+        check(self._L.gr_spchol_factor_solve(self._h, _ptr(bl), _ptr(bb), _ptr(x)))
+        return x
 
     def close(self):
         if self._h:

@@ -3009,7 +3009,16 @@ struct gr_spchol {
   SparseChol<double> d;
   SparseChol<float> f;
   DevBuf<int> rowi, coli;
+  DevBuf<double> stage_d; // host-pointer callers: staged copies of blocks | b (x goes back from there)
+  DevBuf<float> stage_f;
+  int64_t n = 0, bb = 0;  // scalar columns, scalars per block
 };
+// true: p can be dereferenced by a kernel (device or managed memory, or registered / pinned host memory the device maps)
+static bool spchol_device_visible(const void *p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
 template <typename T> static void spchol_create_impl(gr_spchol *h, SparseChol<T> &sc, int64_t nodes, int bs, int64_t nnzb, const int64_t *brow, const int64_t *bcol, hipStream_t stream) {
   std::vector<int> r((size_t)nnzb), c((size_t)nnzb);
   std::vector<char> has_diag((size_t)nodes, 0);
@@ -3179,7 +3188,7 @@ gr_status gr_spchol_create(gr_spchol **out, gr_dtype dtype, int64_t num_nodes, i
   try {
     GR_HIP(hipSetDevice(device));
     h = new gr_spchol();
-    h->dtype = dtype; h->device = device; h->nnzb = num_blocks;
+    h->dtype = dtype; h->device = device; h->nnzb = num_blocks; h->n = num_nodes * (int64_t)block_size; h->bb = (int64_t)block_size * block_size;
     if (dtype == GR_F64) spchol_create_impl<double>(h, h->d, num_nodes, block_size, num_blocks, block_row, block_col, static_cast<hipStream_t>(stream));
     else spchol_create_impl<float>(h, h->f, num_nodes, block_size, num_blocks, block_row, block_col, static_cast<hipStream_t>(stream));
     *out = h;
@@ -3192,9 +3201,27 @@ gr_status gr_spchol_factor_solve(gr_spchol *h, const void *blocks, const void *b
   if (!h || !blocks || !b || !x) { g_last_error = "gr_spchol_factor_solve: bad argument"; return GR_ERR_INVALID; }
   try {
     GR_HIP(hipSetDevice(h->device));
-    bool ok;
-    if (h->dtype == GR_F64) { h->d.load(h->nnzb, h->rowi.p, h->coli.p, static_cast<const double *>(blocks)); h->d.factor(); h->d.solve(static_cast<const double *>(b), static_cast<double *>(x)); ok = h->d.ok(); }
-    else { h->f.load(h->nnzb, h->rowi.p, h->coli.p, static_cast<const float *>(blocks)); h->f.factor(); h->f.solve(static_cast<const float *>(b), static_cast<float *>(x)); ok = h->f.ok(); }
+    auto run = [&](auto &sc, auto &stage) {
+      using T = typename std::remove_pointer<decltype(stage.p)>::type;
+      hipStream_t st = sc.stream;
+      const size_t nv = (size_t)h->nnzb * (size_t)h->bb, n = (size_t)h->n;
+      const T *bl = static_cast<const T *>(blocks), *rhs = static_cast<const T *>(b);
+      T *sol = static_cast<T *>(x);
+      const bool dev_bl = spchol_device_visible(blocks), dev_b = spchol_device_visible(b), dev_x = spchol_device_visible(x);
+      if (!dev_bl || !dev_b || !dev_x) { // host-pointer callers (the Python binding, a CPU-side client): staged through the handle's own buffers
+        stage.alloc(nv + 2 * n);
+        if (!dev_bl) { GR_HIP(hipMemcpyAsync(stage.p, blocks, nv * sizeof(T), hipMemcpyHostToDevice, st)); bl = stage.p; }
+        if (!dev_b) { GR_HIP(hipMemcpyAsync(stage.p + nv, b, n * sizeof(T), hipMemcpyHostToDevice, st)); rhs = stage.p + nv; }
+        if (!dev_x) sol = stage.p + nv + n;
+      }
+      sc.load(h->nnzb, h->rowi.p, h->coli.p, bl);
+      sc.factor();
+      sc.solve(rhs, sol);
+      const bool ok = sc.ok();
+      if (!dev_x) { GR_HIP(hipMemcpyAsync(x, sol, n * sizeof(T), hipMemcpyDeviceToHost, st)); GR_HIP(hipStreamSynchronize(st)); }
+      return ok;
+    };
+    const bool ok = h->dtype == GR_F64 ? run(h->d, h->stage_d) : run(h->f, h->stage_f);
     if (!ok) { g_last_error = "gr_spchol_factor_solve: a pivot is not positive"; return GR_ERR_SOLVE_FAILED; }
     return GR_OK;
   } catch (const HipError &ex) { g_last_error = ex.what(); return GR_ERR_HIP; }

@@ -375,7 +375,8 @@ gr_status gr_dense_cholesky_solve(gr_dtype dtype, int64_t n, const void *A, int6
  *     diagonal block present), host arrays.  GR_ERR_SOLVE_FAILED when the node graph does not dissect into more than one supernode (then the
  *     matrix is as good as dense: use gr_dense_cholesky_solve).
  *   gr_spchol_factor_solve: blocks = num_blocks x block_size x block_size scalars, block q column-major, in the order given to create;
- *     blocks, b, x DEVICE pointers (x may alias b).  GR_ERR_SOLVE_FAILED when a pivot is not positive.
+ *     blocks, b, x device OR host pointers, each on its own (host ones are staged through the handle; x may alias b).  GR_ERR_SOLVE_FAILED
+ *     when a pivot is not positive.
  *   gr_spchol_info: sizes of the factor (gr_direct_solver_info, as gr_bal_direct_solver_info reports them). */
 typedef struct gr_spchol gr_spchol;
 gr_status gr_spchol_create(gr_spchol **out, gr_dtype dtype, int64_t num_nodes, int32_t block_size, int64_t num_blocks,
