@@ -661,11 +661,11 @@ def test_pose_graph_with_a_second_factor_descriptor_of_unary_priors(tmp_path, en
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,env,sparse", [(2000, {}, 1), (2000, {"GRAPHITE_LDLT_SPARSE_MIN": "100000000"}, 0), (300, {}, 0), (300, {"GRAPHITE_LDLT_SPARSE_MIN": "1"}, 1)],
-                         ids=["2000-poses-sparse", "2000-poses-dense", "300-poses-dense", "300-poses-sparse"])
+@pytest.mark.parametrize("n,env,sparse", [(2000, {}, 1), (2000, {"GRAPHITE_LDLT_SPARSE_MIN": "100000000"}, 0), (300, {"GRAPHITE_LDLT_SPARSE_MIN": "100000000"}, 0), (300, {}, 1), (120, {}, 0)],
+                         ids=["2000-poses-sparse", "2000-poses-dense", "300-poses-dense", "300-poses-sparse", "120-poses-below-the-threshold"])
 def test_pose_graph_through_the_direct_solver(tmp_path, n, env, sparse):
     """EigenLDLTSolver (solver/eigen.hpp:49-98: the direct solve of the WHOLE damped system) on a pose graph — no elimination order, every block
-    column of dimension 3.  From 4 096 columns on, the header-only layer hands the block-sparse Hessian<T, S> (upper blocks, column-major) to the
+    column of dimension 3.  From 512 columns on, the header-only layer hands the block-sparse Hessian<T, S> (upper blocks, column-major) to the
     nested-dissection tile Cholesky of the library (gr_spchol: sparse_chol.hpp with a general block size) instead of a dense n x n array; below
     that, the dense MFMA Cholesky.  Both against the oracle's sparse direct solve (oracle/pose_graph.py::solve_direct): traces and poses at 1e-9."""
     from oracle.pose_graph import PoseGraphOracle

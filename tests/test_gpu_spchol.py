@@ -80,3 +80,35 @@ def test_errors_are_reported():
     x = ch.solve(vals, np.ones(2400))  # the handle is usable afterwards
     assert np.abs(A @ x - 1.0).max() < 1e-8
     ch.close()
+
+
+@pytest.mark.parametrize("nodes,extra_edges", [(600, 0), (600, 5), (900, 300)], ids=["no-edges", "five-edges", "two-components-and-singletons"])
+def test_disconnected_node_graphs(nodes, extra_edges):
+    """A graph of unary factors only (the circle example with more vertices) has a block-DIAGONAL Hessian: no edges at all; graphs with a few
+    edges or several components must factorise as well."""
+    import graphite_amd as ga
+    from graphite_amd._lib import GraphiteError
+    rng = np.random.default_rng(nodes + extra_edges)
+    bs = 2
+    blocks = {(i, i): (lambda M: M @ M.T + np.eye(bs))(rng.standard_normal((bs, bs))) for i in range(nodes)}
+    for _ in range(extra_edges):
+        i, j = sorted(rng.choice(nodes // 2, 2, replace=False))   # edges only among the first half: the second half stays singletons
+        J = rng.standard_normal((bs, 2 * bs)); H = J.T @ J
+        blocks[(i, i)] = blocks[(i, i)] + H[:bs, :bs]; blocks[(j, j)] = blocks[(j, j)] + H[bs:, bs:]
+        blocks[(i, j)] = blocks.get((i, j), np.zeros((bs, bs))) + H[:bs, bs:]
+    keys = sorted(blocks, key=lambda k: (k[1], k[0]))
+    row = np.array([k[0] for k in keys]); col = np.array([k[1] for k in keys]); vals = np.stack([blocks[k] for k in keys])
+    A = np.zeros((bs * nodes, bs * nodes))
+    for (i, j), B in zip(keys, vals):
+        A[bs * i:bs * i + bs, bs * j:bs * j + bs] = B
+        A[bs * j:bs * j + bs, bs * i:bs * i + bs] = B.T
+    b = rng.standard_normal(bs * nodes)
+    try:
+        ch = ga.bal.SparseCholesky(nodes, bs, row, col)
+    except GraphiteError as ex:  # allowed answer: "does not dissect" (the caller then takes the dense form)
+        assert "does not dissect" in str(ex)
+        return
+    x = ch.solve(vals, b)
+    ref = np.linalg.solve(A, b)
+    assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+    ch.close()
