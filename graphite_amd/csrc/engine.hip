@@ -3215,8 +3215,7 @@ gr_status gr_spchol_factor_solve(gr_spchol *h, const void *blocks, const void *b
         if (!dev_x) sol = stage.p + nv + n;
       }
       sc.load(h->nnzb, h->rowi.p, h->coli.p, bl);
-      sc.factor();
-      sc.solve(rhs, sol);
+      sc.factor_solve(rhs, sol); // (a level's forward substitution rides in its update launch, the backward one is one dependency-driven launch: §5)
       const bool ok = sc.ok();
       if (!dev_x) { GR_HIP(hipMemcpyAsync(x, sol, n * sizeof(T), hipMemcpyDeviceToHost, st)); GR_HIP(hipStreamSynchronize(st)); }
       return ok;
