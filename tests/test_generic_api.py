@@ -683,3 +683,28 @@ def test_pose_graph_through_the_direct_solver(tmp_path, n, env, sparse):
     tr = parse_trace(r.stdout)
     assert len(tr) == len(ct) - 1 and np.allclose(tr[:, 1], ct[1:], rtol=1e-9) and np.allclose(tr[:, 2], lt[1:], rtol=1e-8)
     assert np.allclose(np.loadtxt(out), o.x, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_direct_solver_keeps_its_analysis_between_calls_and_drops_it_when_the_structure_changes(tmp_path):
+    """EigenLDLTSolver keeps the sparse factorisation's analysis (nested dissection, tile symbolic phase) from one optimiser call to the next while
+    the Hessian's block structure is the same; one more fixed pose between the calls changes it: the last call's trace is the oracle's for the changed
+    graph (and a third call on the unchanged graph repeats the first one's)."""
+    from oracle.pose_graph import PoseGraphOracle
+    exe = build_all()[8]
+    p0, fx, e, m, info, _ = synth.make_pose_graph(2000)
+    f = tmp_path / "graph.txt"
+    synth.write_pose_graph(f, p0, fx, e, m, info)
+    run = lambda env: subprocess.run([exe, str(f), "eigen", "4", "manual", "10", "1.0"], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    o = PoseGraphOracle(p0, fx, e, m, info)
+    ct, _, _ = o.levenberg_marquardt(iterations=4, direct=True)
+    r = run({"POSE_REPEAT": "3"})
+    assert r.returncode == 0 and "SPARSE_FACTORISATION 1" in r.stdout
+    tr = parse_trace(r.stdout)
+    assert len(tr) == 12 and all(np.allclose(tr[4 * i:4 * i + 4, 1], ct[1:], rtol=1e-9) for i in range(3))
+    fx2 = np.array(fx).copy(); fx2[777] = 1
+    ct2, _, _ = PoseGraphOracle(p0, fx2, e, m, info).levenberg_marquardt(iterations=4, direct=True)
+    r = run({"POSE_REPEAT": "2", "POSE_MUTATE": "777"})
+    assert r.returncode == 0 and "SPARSE_FACTORISATION 1" in r.stdout
+    tr = parse_trace(r.stdout)
+    assert np.allclose(tr[:4, 1], ct[1:], rtol=1e-9) and np.allclose(tr[4:, 1], ct2[1:], rtol=1e-9) and not np.allclose(ct[1:], ct2[1:], rtol=1e-9)
