@@ -472,8 +472,23 @@ def main():
                             "launches_per_lm_iteration": 2, "launch_floor_us": 4.6, "grid_rendezvous_per_lm_iteration": 21, "grid_rendezvous_us": 2.3,
                             "note": "latency-bound: 2 launches and 1 + 2 x 10 grid-wide rendezvous (one write-through store + one polling load each, measured 2.3 us) "
                                     "per LM iteration; peak = the time this launch structure would take with nothing else on the chain, frac = peak / measured"}}
+        # the same graph through EigenLDLTSolver: the block-sparse Hessian on the library's nested-dissection tile Cholesky (gr_spchol)
+        dsteps = 5
+        try:
+            d = subprocess.run([exe, path, "eigen", str(dsteps), "manual", "10", "1.0"], env=env, capture_output=True, text=True, timeout=600)
+        except Exception:
+            d = None
+        if d is not None and d.returncode == 0 and "SPARSE_FACTORISATION 1" in d.stdout:
+            td = table(d.stdout)[-dsteps:]
+            ent["direct_solver"] = {"solver": "EigenLDLTSolver -> gr_spchol (tile-sparse nested-dissection Cholesky, block size 3)", "ms_per_step": round(float(np.median(td[1:, 3])) * 1e3, 4),
+                                    "value": round(1.0 / float(np.median(td[1:, 3])), 2), "unit": "LM iterations/s", "steps_run": len(td), "chi2_final": float(td[-1, 1]), "parity_rel": None}
         if not args.no_cpu_baseline:
             from oracle.pose_graph import PoseGraphOracle
+            if "direct_solver" in ent:
+                od = PoseGraphOracle(p0, fx, e, m, info)
+                cd, _, _ = od.levenberg_marquardt(iterations=dsteps, direct=True)
+                kd = min(len(td), len(cd) - 1)
+                ent["direct_solver"]["parity_rel"] = float(np.max(np.abs(td[:kd, 1] - cd[1:kd + 1]) / np.abs(cd[1:kd + 1])))
             o = PoseGraphOracle(p0, fx, e, m, info)
             ct, _, _ = o.levenberg_marquardt(iterations=steps, pcg_max_iter=10, pcg_tol=1.0)
             k = min(len(te), len(ct) - 1)
